@@ -1,0 +1,46 @@
+# Build everything in-tree.  `make` = host library + HIP library + CLI; `make oracle` = the test checker.
+ROCM    ?= /opt/rocm
+HIPCC   ?= $(ROCM)/bin/hipcc
+CXX     ?= g++
+ARCH    ?= gfx950
+CXXFLAGS = -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude
+HIPFLAGS = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Wall -Wno-unused-result
+
+LIBDIR = seeksv_amd/lib
+HOST_SRC = seeksv_amd/host/bam_reader.cpp seeksv_amd/host/getsv_plan.cpp
+HIP_SRC  = seeksv_amd/csrc/seeksv_hip.hip
+HIP_DEPS = $(wildcard seeksv_amd/csrc/*.h) $(wildcard seeksv_amd/csrc/*.hip) include/seeksv_hip.h
+
+all: host hip synth
+
+host: $(LIBDIR)/libseeksv_host.so
+hip: $(LIBDIR)/libseeksv_hip.so
+synth: $(LIBDIR)/libseeksv_synth.so $(LIBDIR)/libseeksv_synth_cpu.so
+
+$(LIBDIR)/libseeksv_host.so: $(HOST_SRC) include/seeksv_host.h include/seeksv_hip.h
+	mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz
+
+$(LIBDIR)/libseeksv_hip.so: $(HIP_DEPS)
+	mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+# synthetic BAM-record generator: the same source compiled for the GPU (bench) and for the CPU (tests, cpu baseline)
+$(LIBDIR)/libseeksv_synth.so: seeksv_amd/csrc/synth.hip seeksv_amd/csrc/synth_core.h
+	mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ seeksv_amd/csrc/synth.hip
+
+$(LIBDIR)/libseeksv_synth_cpu.so: seeksv_amd/csrc/synth_cpu.cpp seeksv_amd/csrc/synth_core.h
+	mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ seeksv_amd/csrc/synth_cpu.cpp
+
+oracle:
+	$(MAKE) -C oracle liboracle.so
+
+oracle-ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -rf $(LIBDIR) && $(MAKE) -C oracle clean
+
+.PHONY: all host hip synth oracle oracle-ref clean

@@ -1,0 +1,212 @@
+/*
+ * seeksv_hip.h - C ABI of libseeksv_hip.so: the MI355X (gfx950) implementation of seeksv's
+ * per-BAM-record hot path (getclip -> cluster -> getsv BAM passes).
+ *
+ * The reference (qiukunlong/seeksv v1.2.3) has no FFI/plugin API: the path sits behind four C++
+ * call sites.  Each entry point below names the reference interface it replaces.
+ * Conventions: plain C structs of pointers + counts over CALLER-OWNED buffers (structure of
+ * arrays); every call returns int (0 = ok, <0 = ssv_status); nothing throws, nothing exits;
+ * work is queued on the context's HIP stream and calls that return results synchronise that
+ * stream before returning.  One context per GPU, not shared between threads.
+ *
+ * There is NO CPU fallback in this library: without a usable HIP device ssv_ctx_create fails
+ * with SSV_E_NODEVICE and nothing else can be called.
+ */
+#ifndef SEEKSV_HIP_H_
+#define SEEKSV_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSV_ABI_VERSION 1
+
+typedef enum {
+	SSV_OK = 0,
+	SSV_E_NODEVICE = -1, /* no HIP device / HIP runtime error at init */
+	SSV_E_HIP = -2,      /* a HIP call failed; text in ssv_last_error() */
+	SSV_E_ARG = -3,      /* bad argument */
+	SSV_E_STATE = -4,    /* call out of sequence (e.g. finish before begin) */
+	SSV_E_NOMEM = -5,    /* device allocation failed */
+	SSV_E_RANGE = -6     /* an output buffer supplied by the caller is too small */
+} ssv_status;
+
+/* Where the arrays of a batch live. */
+typedef enum {
+	SSV_MEM_HOST = 0,   /* host memory (pinned preferred); the library stages it to the GPU */
+	SSV_MEM_DEVICE = 1  /* already resident in this GPU's HBM; used in place, zero copies */
+} ssv_mem;
+
+/*
+ * One batch of decoded BAM records, structure-of-arrays, in file order.  Field meaning follows
+ * samtools' bam1_core_t (reference: sam/bam.h:169-178) - the reference's samread() loop bodies
+ * (clip_reads.h:410, cluster.cpp:48, getsv.cpp:1067, bam2depth.h:29) consume exactly these.
+ *   seq_off[i] = byte offset into seqqual of record i's ceil(l_qseq/2) packed 4-bit bases followed
+ *   by l_qseq quality bytes, or SSV_NO_SEQ when the batcher did not ship them.  The batcher must
+ *   ship them for every record whose first or last CIGAR operation is 'S' (only those can become
+ *   clip events, clip_reads.cpp:124,150); it may omit all others.
+ */
+#define SSV_NO_SEQ UINT64_MAX
+typedef struct {
+	int64_t n;                 /* records in the batch (< 2^31) */
+	int32_t mem;               /* ssv_mem */
+	int32_t reserved;
+	const int32_t *tid;        /* [n] reference id, -1 = unplaced */
+	const int32_t *pos;        /* [n] 0-based leftmost coordinate */
+	const uint16_t *flag;      /* [n] */
+	const uint8_t *mapq;       /* [n] */
+	const uint16_t *n_cigar;   /* [n] */
+	const int32_t *l_qseq;     /* [n] */
+	const int32_t *mtid;       /* [n] */
+	const int32_t *mpos;       /* [n] */
+	const int32_t *isize;      /* [n] */
+	const uint32_t *cigar_off; /* [n] index of the record's first op in cigar[] */
+	const uint32_t *cigar;     /* [n_cigar_total] BAM encoding: len<<4 | op */
+	const uint8_t *xc;         /* [n] 1 if the XC:i aux value != 0 (clip_reads.cpp:126-129); NULL = all 0 */
+	const uint64_t *seq_off;   /* [n] see above */
+	const uint8_t *seqqual;    /* [seqqual_bytes] */
+	int64_t n_cigar_total;
+	int64_t seqqual_bytes;
+} ssv_batch_t;
+
+typedef struct ssv_ctx ssv_ctx; /* opaque */
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* device = HIP device ordinal.  Fails (SSV_E_NODEVICE) when there is no GPU: no CPU path exists. */
+int ssv_ctx_create(int device, ssv_ctx **out);
+void ssv_ctx_destroy(ssv_ctx *ctx);
+/* Block until everything queued on the context's stream has finished. */
+int ssv_sync(ssv_ctx *ctx);
+/* Text of the last error on this context (or of the last failed ssv_ctx_create when ctx == NULL). */
+const char *ssv_last_error(const ssv_ctx *ctx);
+int ssv_abi_version(void);
+/* The hipStream_t the context launches on (for callers that time with HIP events). */
+void *ssv_stream(ssv_ctx *ctx);
+
+/* ---- getclip: replaces InputBamOutputReads<>'s record loop (clip_reads.h:363, 410-446) ------ */
+
+typedef struct {
+	double match_rate;      /* -t, default 0.9  (seeksv.cpp:15,131) */
+	int32_t min_mapq;       /* -q, default 1    (seeksv.cpp:130) */
+	int32_t save_low_quality; /* -s             (seeksv.cpp:141) */
+} ssv_clip_params;
+
+/* Start a getclip pass.  last_tid state starts at 0 like the reference's (clip_reads.h:407). */
+int ssv_clip_begin(ssv_ctx *ctx, const ssv_clip_params *p);
+/*
+ * Scan one batch (GetSClipReads, clip_reads.cpp:112-192, incl. the contig-switch rule of
+ * clip_reads.h:423-438): appends the batch's clip events - key, slice lengths, packed bases,
+ * qualities, CIGAR - to context-owned HBM.  The batch buffers may be reused after ssv_sync().
+ */
+int ssv_clip_scan(ssv_ctx *ctx, const ssv_batch_t *b);
+/* Events collected so far (synchronises). */
+int ssv_clip_event_count(ssv_ctx *ctx, int64_t *n_events);
+
+/*
+ * Cluster table = what the two multimaps hold when the reference flushes them
+ * (InsertSeq/ChangeSeqAndQual, clip_reads.cpp:57-108,260-283), in the reference's emit order
+ * (per contig: all '5' rows by position, then all '3' rows; ties in creation order,
+ * clip_reads.h:432-433).  All pointers are HOST buffers owned by the context, valid until the
+ * next ssv_clip_begin / ssv_ctx_destroy.
+ */
+typedef struct {
+	int64_t n_clusters;
+	int64_t n_events;
+	const int32_t *tid;        /* [n_clusters] */
+	const int32_t *pos;        /* [n_clusters] 1-based breakpoint coordinate */
+	const uint8_t *side;       /* [n_clusters] '5' or '3' */
+	const int32_t *support;    /* [n_clusters] support_read_no */
+	const int32_t *left_len;   /* [n_clusters] |seq_left|  */
+	const int32_t *right_len;  /* [n_clusters] |seq_right| */
+	const uint8_t *qual_missing; /* [n_clusters] 1: reference prints "*" for both qualities */
+	const uint64_t *str_off;   /* [n_clusters] offset into str of: seq_left, qual_left, seq_right, qual_right */
+	const uint8_t *str;        /* ASCII, not NUL terminated */
+	const uint64_t *cigar_off; /* [n_clusters] offset into cigar */
+	const int32_t *n_cigar;    /* [n_clusters] ops of the record whose CIGAR the cluster carries */
+	const uint32_t *cigar;     /* BAM-encoded ops INCLUDING S/H (GenerateCigar drops those when printing) */
+} ssv_cluster_table;
+
+/* Sort events into (contig, side, position) bins and run the greedy consensus clustering. */
+int ssv_clip_cluster(ssv_ctx *ctx, ssv_cluster_table *out);
+
+/* ---- getsv pass 1: replaces CalculateInsertsizeDeviation (cluster.cpp:15-83) ---------------- */
+
+int ssv_isize_begin(ssv_ctx *ctx, int32_t min_mapq, int64_t max_pairs);
+/* *done is set to 1 once max_pairs qualifying records have been seen (the reference breaks there). */
+int ssv_isize_accumulate(ssv_ctx *ctx, const ssv_batch_t *b, int32_t *done);
+/* Returns n_pairs==0 exactly when the reference returns 1 and leaves mean/sd untouched. */
+int ssv_isize_finish(ssv_ctx *ctx, int64_t *n_pairs, int32_t *mean, int32_t *sd);
+
+/* ---- getsv passes 2+3, fused: FindDiscordantReadPairs (getsv.cpp:990-1120) and
+ *      main_depth (bam2depth.cpp:17-142) ------------------------------------------------------- */
+
+/* One junction and its (already clamped) query window, getsv.cpp:1041-1060. */
+typedef struct {
+	int32_t up_tid;      /* tid of up_chr */
+	int32_t down_tid;    /* tid of down_chr, -1 if absent from the header (never matches) */
+	int32_t up_pos;      /* 1-based */
+	int32_t down_pos;    /* 1-based */
+	int32_t beg;         /* 0-based window start after clamping */
+	int32_t end;         /* window end after clamping; candidates: ref_end > beg && pos < end */
+	uint8_t up_strand;   /* '+' or '-' */
+	uint8_t down_strand;
+	uint8_t pad[2];
+} ssv_junction;
+
+/* 1-based inclusive interval on a contig. */
+typedef struct {
+	int32_t tid;
+	int32_t beg;
+	int32_t end;
+} ssv_interval;
+
+typedef struct {
+	/* discordant tally (may be disabled with n_junctions = 0) */
+	const ssv_junction *junctions; /* host */
+	int64_t n_junctions;
+	int32_t mean, sd, times;       /* from ssv_isize_finish; times = 4 (seeksv.cpp:161) */
+	int32_t disc_min_mapq;         /* -q (20) */
+	/* depth (may be disabled with n_windows = 0) */
+	const ssv_interval *windows;   /* host; merged windows: sorted by (tid,beg), pairwise disjoint */
+	int64_t n_windows;
+	int32_t depth_min_mapq;        /* -q (20) */
+	int32_t n_targets;             /* contigs in the BAM header */
+	const int32_t *target_len;     /* host [n_targets] */
+} ssv_getsv_params;
+
+int ssv_getsv_begin(ssv_ctx *ctx, const ssv_getsv_params *p);
+/* One fused pass over a batch: discordant-pair tally per junction + coverage of the windows. */
+int ssv_getsv_scan(ssv_ctx *ctx, const ssv_batch_t *b);
+/*
+ * counts[n_junctions]      = abnormal_read_pair_no per junction (getsv.cpp:1116)
+ * range_sum[n_ranges]      = sum over the interval of per-column depth (bam2depth.cpp:101-122);
+ *                            each range must lie inside one window
+ * point_depth[n_points]    = depth at (tid, beg) (bam2depth.cpp:123-124); 0 outside every window
+ * max_depth                = largest per-column depth seen (the 0.1.16 pileup stops accepting reads
+ *                            at ~8000 live reads; above 7998 parity with the reference is not pinned)
+ */
+int ssv_getsv_finish(ssv_ctx *ctx, int32_t *counts,
+                     const ssv_interval *ranges, int64_t n_ranges, uint64_t *range_sum,
+                     const ssv_interval *points, int64_t n_points, int32_t *point_depth,
+                     int32_t *max_depth);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+
+/*
+ * Per-kernel launch timing with HIP events on the context's stream.  Enable, run, then read back.
+ * name = kernel name as in DESIGN.md ("clip_scan", "getsv_scan", ...).  Returns SSV_E_ARG for an
+ * unknown name.  Reading synchronises and resets nothing; ssv_prof_reset clears.
+ */
+int ssv_prof_enable(ssv_ctx *ctx, int on);
+int ssv_prof_reset(ssv_ctx *ctx);
+int ssv_prof_get(ssv_ctx *ctx, const char *name, double *total_ms, int64_t *launches, int64_t *units);
+/* Names of all timed kernels, '\n' separated. */
+const char *ssv_prof_names(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEKSV_HIP_H_ */

@@ -1,0 +1,95 @@
+/*
+ * seeksv_host.h - C ABI of libseeksv_host.so: the host side of the hot path, i.e. what replaces
+ * the reference's use of samtools-0.1.16 libbam *below* the record loops (samopen/samread,
+ * sam/sam.h:59,73) and the small ordered-container bookkeeping *around* the BAM passes of getsv
+ * (GetBreak / MergeOverlap, getsv.cpp:752-835; the window arithmetic of FindDiscordantReadPairs,
+ * getsv.cpp:1041-1060; the lookup rules of main_depth, bam2depth.cpp:82-124).
+ * No GPU code here; it produces the structure-of-arrays batches that include/seeksv_hip.h consumes.
+ */
+#ifndef SEEKSV_HOST_H_
+#define SEEKSV_HOST_H_
+
+#include <stdint.h>
+#include "seeksv_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssvh_bam ssvh_bam; /* an open BAM file */
+
+/* Open a BAM file and parse its header.  Returns 0, or <0 and a message in ssvh_last_error(). */
+int ssvh_bam_open(const char *path, ssvh_bam **out);
+void ssvh_bam_close(ssvh_bam *b);
+const char *ssvh_last_error(void);
+
+int32_t ssvh_bam_n_targets(const ssvh_bam *b);
+const char *ssvh_bam_target_name(const ssvh_bam *b, int32_t tid);
+int32_t ssvh_bam_target_len(const ssvh_bam *b, int32_t tid);
+const int32_t *ssvh_bam_target_lens(const ssvh_bam *b);
+
+/*
+ * Decode up to max_records records (file order) into a structure-of-arrays batch (SSV_MEM_HOST).
+ * The arrays are owned by the reader and stay valid until the next call on the same handle.
+ * Bases + qualities are shipped only for records whose first or last CIGAR op is 'S'.
+ * out->n == 0 at end of file.  keep_all_seq != 0 ships bases/qualities for every record.
+ */
+int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_batch_t *out);
+
+/* Records with UNMAP|MUNMAP seen in the last batch: qname / decoded bases / qualities for the
+ * unmapped-pair FASTQ side channel (clip_reads.h:415-419).  Index k in [0, n).  Host only. */
+int64_t ssvh_bam_unmapped_count(const ssvh_bam *b);
+int ssvh_bam_unmapped_get(const ssvh_bam *b, int64_t k, const char **qname, const char **seq, const char **qual, int *is_read1);
+
+/* ---- getsv bookkeeping around the BAM passes -------------------------------------------------- */
+
+typedef struct ssvh_plan ssvh_plan; /* junction list -> windows / ranges / points, and back */
+
+/* One junction as the reference keys it (Junction, getsv.h:149-227): contig NAMES, 1-based positions. */
+typedef struct {
+	const char *up_chr;
+	const char *down_chr;
+	int32_t up_pos;
+	int32_t down_pos;
+	char up_strand;
+	char down_strand;
+} ssvh_junction_in;
+
+/*
+ * Build the query plan for a junction multimap (given in Junction::operator< order, duplicates
+ * allowed) plus extra one-end-unmapped points (GetBreak overload, getsv.cpp:791-802):
+ *   - discordant windows per junction with mean/sd/times (getsv.cpp:1032-1060),
+ *   - GetBreak's point set and the four flank windows per junction (unsigned arithmetic and its
+ *     wrap-around included), MergeOverlap's begin2end, and from them the proper merged windows,
+ *     the device range list and the device point list.
+ * flank_length = -L (200).  do_discordant / do_depth mirror seeksv.cpp:246,288.
+ */
+int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int64_t n_junctions,
+                     const char *const *extra_point_chr, const int32_t *extra_point_pos, int64_t n_extra_points,
+                     int32_t mean, int32_t sd, int32_t times, int32_t flank_length, ssvh_plan **out);
+void ssvh_plan_destroy(ssvh_plan *p);
+
+/* Device-facing tables (host memory owned by the plan). */
+const ssv_junction *ssvh_plan_junctions(const ssvh_plan *p, int64_t *n);
+const ssv_interval *ssvh_plan_windows(const ssvh_plan *p, int64_t *n);
+const ssv_interval *ssvh_plan_ranges(const ssvh_plan *p, int64_t *n);
+const ssv_interval *ssvh_plan_points(const ssvh_plan *p, int64_t *n);
+
+/*
+ * Fold device results back into the reference's per-junction view:
+ *   counts[j]           -> abnormal_read_pair_no (junctions whose up_chr is not in the header keep
+ *                          prev_counts[j], getsv.cpp:1043)
+ *   up_depth/down_depth -> pos2depth values at both ends (before the support counts are added)
+ *   flank[4*j + k]      -> range2depth sums of up_up, up_down, down_up, down_down, and
+ *   flank_len[4*j + k]  -> the divisor (end - begin + 1) in unsigned arithmetic (getsv.cpp:946)
+ * following main_depth's lookup rules for wrapped / empty windows.
+ */
+int ssvh_plan_fold(const ssvh_plan *p, const int32_t *counts, const int32_t *prev_counts,
+                   const uint64_t *range_sum, const int32_t *point_depth,
+                   int32_t *abnormal, int32_t *up_depth, int32_t *down_depth,
+                   uint64_t *flank, uint32_t *flank_len, int32_t *extra_point_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,196 @@
+"""ctypes mirror of include/seeksv_hip.h and include/seeksv_host.h (struct layouts + library loading).
+
+Plumbing only: every computation happens in libseeksv_hip.so (HIP kernels) or libseeksv_host.so
+(BAM decoding, getsv bookkeeping).  There is no Python or CPU fallback for the GPU path: loading
+libseeksv_hip.so or creating a context without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(_HERE, "lib")
+
+NO_SEQ = (1 << 64) - 1
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class Batch(C.Structure):
+    """ssv_batch_t"""
+    _fields_ = [
+        ("n", C.c_int64), ("mem", C.c_int32), ("reserved", C.c_int32),
+        ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
+        ("n_cigar", C.c_void_p), ("l_qseq", C.c_void_p), ("mtid", C.c_void_p), ("mpos", C.c_void_p),
+        ("isize", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("xc", C.c_void_p),
+        ("seq_off", C.c_void_p), ("seqqual", C.c_void_p),
+        ("n_cigar_total", C.c_int64), ("seqqual_bytes", C.c_int64),
+    ]
+
+
+BATCH_FIELDS = [  # (name, numpy dtype) in struct order
+    ("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("n_cigar", np.uint16),
+    ("l_qseq", np.int32), ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32),
+    ("cigar_off", np.uint32), ("cigar", np.uint32), ("xc", np.uint8), ("seq_off", np.uint64), ("seqqual", np.uint8),
+]
+
+
+class ClipParams(C.Structure):
+    _fields_ = [("match_rate", C.c_double), ("min_mapq", C.c_int32), ("save_low_quality", C.c_int32)]
+
+
+class ClusterTable(C.Structure):
+    """ssv_cluster_table (and the leading part of orc_cluster_table)"""
+    _fields_ = [
+        ("n_clusters", C.c_int64), ("n_events", C.c_int64),
+        ("tid", C.POINTER(C.c_int32)), ("pos", C.POINTER(C.c_int32)), ("side", C.POINTER(C.c_uint8)),
+        ("support", C.POINTER(C.c_int32)), ("left_len", C.POINTER(C.c_int32)), ("right_len", C.POINTER(C.c_int32)),
+        ("qual_missing", C.POINTER(C.c_uint8)), ("str_off", C.POINTER(C.c_uint64)), ("str", C.POINTER(C.c_uint8)),
+        ("cigar_off", C.POINTER(C.c_uint64)), ("n_cigar", C.POINTER(C.c_int32)), ("cigar", C.POINTER(C.c_uint32)),
+    ]
+
+
+class OrcClusterTable(C.Structure):
+    _fields_ = ClusterTable._fields_ + [("str_bytes", C.c_int64), ("cigar_ops", C.c_int64)]
+
+
+class Junction(C.Structure):
+    """ssv_junction"""
+    _fields_ = [
+        ("up_tid", C.c_int32), ("down_tid", C.c_int32), ("up_pos", C.c_int32), ("down_pos", C.c_int32),
+        ("beg", C.c_int32), ("end", C.c_int32), ("up_strand", C.c_uint8), ("down_strand", C.c_uint8), ("pad", C.c_uint8 * 2),
+    ]
+
+
+JUNCTION_DTYPE = np.dtype([
+    ("up_tid", np.int32), ("down_tid", np.int32), ("up_pos", np.int32), ("down_pos", np.int32),
+    ("beg", np.int32), ("end", np.int32), ("up_strand", np.uint8), ("down_strand", np.uint8), ("pad", np.uint8, (2,)),
+])
+INTERVAL_DTYPE = np.dtype([("tid", np.int32), ("beg", np.int32), ("end", np.int32)])
+assert JUNCTION_DTYPE.itemsize == C.sizeof(Junction) == 28
+assert INTERVAL_DTYPE.itemsize == 12
+
+
+class GetsvParams(C.Structure):
+    _fields_ = [
+        ("junctions", C.c_void_p), ("n_junctions", C.c_int64),
+        ("mean", C.c_int32), ("sd", C.c_int32), ("times", C.c_int32), ("disc_min_mapq", C.c_int32),
+        ("windows", C.c_void_p), ("n_windows", C.c_int64),
+        ("depth_min_mapq", C.c_int32), ("n_targets", C.c_int32), ("target_len", C.c_void_p),
+    ]
+
+
+class JunctionIn(C.Structure):
+    """ssvh_junction_in"""
+    _fields_ = [("up_chr", C.c_char_p), ("down_chr", C.c_char_p), ("up_pos", C.c_int32), ("down_pos", C.c_int32),
+                ("up_strand", C.c_char), ("down_strand", C.c_char)]
+
+
+def make_batch(arrays, mem=MEM_HOST, n=None):
+    """Build an ssv_batch_t over numpy arrays (host) or raw device pointers (ints). Returns (Batch, keepalive)."""
+    b = Batch()
+    keep = []
+    for name, dt in BATCH_FIELDS:
+        a = arrays.get(name)
+        if a is None:
+            setattr(b, name, None)
+            continue
+        if isinstance(a, np.ndarray):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            setattr(b, name, a.ctypes.data if a.size else None)
+        else:
+            setattr(b, name, int(a))
+    b.mem = mem
+    if n is None:
+        n = len(arrays["tid"])
+    b.n = int(n)
+    b.n_cigar_total = int(arrays["n_cigar_total"]) if "n_cigar_total" in arrays else int(len(arrays["cigar"]))
+    b.seqqual_bytes = int(arrays["seqqual_bytes"]) if "seqqual_bytes" in arrays else (int(len(arrays["seqqual"])) if arrays.get("seqqual") is not None else 0)
+    return b, keep
+
+
+def batch_to_arrays(b):
+    """Copy a HOST ssv_batch_t (e.g. from the BAM reader) into owned numpy arrays."""
+    assert b.mem == MEM_HOST
+    n = b.n
+    sizes = {"cigar": b.n_cigar_total, "seqqual": b.seqqual_bytes}
+    out = {}
+    for name, dt in BATCH_FIELDS:
+        cnt = sizes.get(name, n)
+        ptr = getattr(b, name)
+        if not ptr or cnt == 0:
+            out[name] = np.zeros(cnt, dtype=dt)
+            continue
+        buf = (C.c_uint8 * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
+        out[name] = np.frombuffer(buf, dtype=dt, count=cnt).copy()
+    return out
+
+
+_libs = {}
+
+
+def _load(name):
+    if name not in _libs:
+        path = os.path.join(LIBDIR, name)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' or `make`)")
+        _libs[name] = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return _libs[name]
+
+
+def host_lib():
+    lib = _load("libseeksv_host.so")
+    if not getattr(lib, "_typed", False):
+        lib.ssvh_last_error.restype = C.c_char_p
+        lib.ssvh_bam_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.ssvh_bam_close.argtypes = [C.c_void_p]
+        lib.ssvh_bam_n_targets.argtypes = [C.c_void_p]
+        lib.ssvh_bam_target_name.argtypes = [C.c_void_p, C.c_int32]
+        lib.ssvh_bam_target_name.restype = C.c_char_p
+        lib.ssvh_bam_target_len.argtypes = [C.c_void_p, C.c_int32]
+        lib.ssvh_bam_target_len.restype = C.c_int32
+        lib.ssvh_bam_read_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(Batch)]
+        lib.ssvh_bam_unmapped_count.argtypes = [C.c_void_p]
+        lib.ssvh_bam_unmapped_count.restype = C.c_int64
+        lib.ssvh_bam_unmapped_get.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        lib.ssvh_plan_create.argtypes = [C.c_void_p, C.POINTER(JunctionIn), C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int64,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.ssvh_plan_destroy.argtypes = [C.c_void_p]
+        for f in ("junctions", "windows", "ranges", "points"):
+            fn = getattr(lib, "ssvh_plan_" + f)
+            fn.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+            fn.restype = C.c_void_p
+        lib.ssvh_plan_fold.argtypes = [C.c_void_p] + [C.c_void_p] * 10
+        lib._typed = True
+    return lib
+
+
+def hip_lib():
+    """libseeksv_hip.so - raises when it is not built; creating a context raises when there is no GPU."""
+    lib = _load("libseeksv_hip.so")
+    if not getattr(lib, "_typed", False):
+        V = C.c_void_p
+        lib.ssv_ctx_create.argtypes = [C.c_int, C.POINTER(V)]
+        lib.ssv_ctx_destroy.argtypes = [V]
+        lib.ssv_sync.argtypes = [V]
+        lib.ssv_last_error.argtypes = [V]
+        lib.ssv_last_error.restype = C.c_char_p
+        lib.ssv_stream.argtypes = [V]
+        lib.ssv_stream.restype = V
+        lib.ssv_clip_begin.argtypes = [V, C.POINTER(ClipParams)]
+        lib.ssv_clip_scan.argtypes = [V, C.POINTER(Batch)]
+        lib.ssv_clip_event_count.argtypes = [V, C.POINTER(C.c_int64)]
+        lib.ssv_clip_cluster.argtypes = [V, C.POINTER(ClusterTable)]
+        lib.ssv_isize_begin.argtypes = [V, C.c_int32, C.c_int64]
+        lib.ssv_isize_accumulate.argtypes = [V, C.POINTER(Batch), C.POINTER(C.c_int32)]
+        lib.ssv_isize_finish.argtypes = [V, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.ssv_getsv_begin.argtypes = [V, C.POINTER(GetsvParams)]
+        lib.ssv_getsv_scan.argtypes = [V, C.POINTER(Batch)]
+        lib.ssv_getsv_finish.argtypes = [V, V, V, C.c_int64, V, V, C.c_int64, V, C.POINTER(C.c_int32)]
+        lib.ssv_prof_enable.argtypes = [V, C.c_int]
+        lib.ssv_prof_reset.argtypes = [V]
+        lib.ssv_prof_get.argtypes = [V, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.ssv_prof_names.restype = C.c_char_p
+        lib._typed = True
+    return lib

@@ -1,0 +1,193 @@
+"""Python face of libseeksv_host.so (BAM -> SoA batches, getsv bookkeeping) plus the text formats of
+`seeksv getclip` (clip.gz rows / clip.fq.gz records).  Used by tests and bench.py; the C++ `seeksv`
+CLI uses the same library directly.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+CIGAR_CHARS = "MIDNSHP=X"
+
+
+class BamReader:
+    """samopen()/samread() stand-in (reference: sam/sam.h:59,73) producing structure-of-arrays batches."""
+
+    def __init__(self, path):
+        self._lib = _abi.host_lib()
+        h = C.c_void_p()
+        if self._lib.ssvh_bam_open(path.encode(), C.byref(h)) != 0:
+            raise IOError(self._lib.ssvh_last_error().decode())
+        self._h = h
+        n = self._lib.ssvh_bam_n_targets(h)
+        self.target_names = [self._lib.ssvh_bam_target_name(h, i).decode() for i in range(n)]
+        self.target_lens = np.array([self._lib.ssvh_bam_target_len(h, i) for i in range(n)], dtype=np.int32)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def read_batch(self, max_records=1 << 20, keep_all_seq=False):
+        """Next batch as a dict of owned numpy arrays (None at EOF)."""
+        b = _abi.Batch()
+        if self._lib.ssvh_bam_read_batch(self._h, max_records, int(keep_all_seq), C.byref(b)) != 0:
+            raise IOError(self._lib.ssvh_last_error().decode())
+        if b.n == 0:
+            return None
+        return _abi.batch_to_arrays(b)
+
+    def unmapped(self):
+        """(qname, seq, qual, is_read1) of the UNMAP|MUNMAP records of the last batch."""
+        out = []
+        q, s, u, r = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_int()
+        for k in range(self._lib.ssvh_bam_unmapped_count(self._h)):
+            self._lib.ssvh_bam_unmapped_get(self._h, k, C.byref(q), C.byref(s), C.byref(u), C.byref(r))
+            out.append((q.value.decode(), s.value.decode(), u.value.decode(), bool(r.value)))
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.ssvh_bam_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def read_bam(path, batch_records=1 << 20):
+    """Whole BAM as (target_names, target_lens, [batch dicts])."""
+    with BamReader(path) as r:
+        batches = []
+        while True:
+            b = r.read_batch(batch_records)
+            if b is None:
+                break
+            batches.append(b)
+        return r.target_names, r.target_lens, batches
+
+
+class Plan:
+    """Junction list -> device query tables and back (ssvh_plan_*): GetBreak / MergeOverlap /
+    FindDiscordantReadPairs window arithmetic / main_depth lookup rules of the reference."""
+
+    def __init__(self, bam, junctions, mean, sd, times=4, flank_length=200, extra_points=()):
+        """junctions: list of (up_chr, up_pos, up_strand, down_chr, down_pos, down_strand) in Junction order."""
+        self._lib = _abi.host_lib()
+        n = len(junctions)
+        arr = (_abi.JunctionIn * max(n, 1))()
+        self._keep = []
+        for i, (uc, up, us, dc, dp, ds) in enumerate(junctions):
+            ucb, dcb = uc.encode(), dc.encode()
+            self._keep += [ucb, dcb]
+            arr[i].up_chr, arr[i].down_chr = ucb, dcb
+            arr[i].up_pos, arr[i].down_pos = up, dp
+            arr[i].up_strand, arr[i].down_strand = us.encode(), ds.encode()
+        ne = len(extra_points)
+        echr = (C.c_char_p * max(ne, 1))(*[c.encode() for c, _ in extra_points])
+        epos = (C.c_int32 * max(ne, 1))(*[p for _, p in extra_points])
+        h = C.c_void_p()
+        rc = self._lib.ssvh_plan_create(bam.handle, arr, n, echr, epos, ne, mean, sd, times, flank_length, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("ssvh_plan_create failed")
+        self._h = h
+        self.n_junctions = n
+        self.n_extra = ne
+        self.junctions = self._table("junctions", _abi.JUNCTION_DTYPE)
+        self.windows = self._table("windows", _abi.INTERVAL_DTYPE)
+        self.ranges = self._table("ranges", _abi.INTERVAL_DTYPE)
+        self.points = self._table("points", _abi.INTERVAL_DTYPE)
+
+    def _table(self, what, dt):
+        n = C.c_int64()
+        ptr = getattr(self._lib, "ssvh_plan_" + what)(self._h, C.byref(n))
+        if n.value == 0:
+            return np.zeros(0, dtype=dt)
+        buf = (C.c_uint8 * (n.value * dt.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dt, count=n.value).copy()
+
+    def fold(self, counts, range_sum, point_depth, prev_counts=None):
+        """-> dict(abnormal, up_depth, down_depth, flank[J,4], flank_len[J,4], extra_point_depth)"""
+        J = self.n_junctions
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        range_sum = np.ascontiguousarray(range_sum, dtype=np.uint64)
+        point_depth = np.ascontiguousarray(point_depth, dtype=np.int32)
+        prev = np.ascontiguousarray(prev_counts if prev_counts is not None else np.zeros(J), dtype=np.int32)
+        out = dict(abnormal=np.zeros(J, np.int32), up_depth=np.zeros(J, np.int32), down_depth=np.zeros(J, np.int32),
+                   flank=np.zeros((J, 4), np.uint64), flank_len=np.zeros((J, 4), np.uint32),
+                   extra_point_depth=np.zeros(self.n_extra, np.int32))
+        p = lambda a: a.ctypes.data if a.size else None
+        self._lib.ssvh_plan_fold(self._h, p(counts), p(prev), p(range_sum), p(point_depth), p(out["abnormal"]),
+                                 p(out["up_depth"]), p(out["down_depth"]), p(out["flank"]), p(out["flank_len"]),
+                                 p(out["extra_point_depth"]))
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.ssvh_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- cluster table -> text (DisplaySClipReadsAndClipFq / DisplayCigarVector, clip_reads.h:300-345,489-505) ----
+
+def table_to_dict(t):
+    """ctypes ssv_cluster_table / orc_cluster_table -> dict of numpy arrays (copies)."""
+    n = t.n_clusters
+
+    def arr(ptr, cnt, dt):
+        if cnt == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True)
+
+    d = dict(n_clusters=n, n_events=t.n_events)
+    for name, dt in (("tid", np.int32), ("pos", np.int32), ("side", np.uint8), ("support", np.int32), ("left_len", np.int32),
+                     ("right_len", np.int32), ("qual_missing", np.uint8), ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
+        d[name] = arr(getattr(t, name), n, dt)
+    if n:
+        sb = int(d["str_off"][-1]) + 2 * int(d["left_len"][-1] + d["right_len"][-1])
+        cb = int(d["cigar_off"][-1]) + int(d["n_cigar"][-1])
+    else:
+        sb = cb = 0
+    d["str"] = arr(t.str, sb, np.uint8)
+    d["cigar"] = arr(t.cigar, cb, np.uint32)
+    return d
+
+
+def cluster_strings(d, k):
+    """(seq_left, qual_left, seq_right, qual_right, cigar_text) of cluster k."""
+    o, ll, lr = int(d["str_off"][k]), int(d["left_len"][k]), int(d["right_len"][k])
+    s = d["str"]
+    sl = s[o:o + ll].tobytes().decode("latin-1")
+    ql = s[o + ll:o + 2 * ll].tobytes().decode("latin-1")
+    sr = s[o + 2 * ll:o + 2 * ll + lr].tobytes().decode("latin-1")
+    qr = s[o + 2 * ll + lr:o + 2 * ll + 2 * lr].tobytes().decode("latin-1")
+    if d["qual_missing"][k]:
+        ql = qr = "*"
+    co, nc = int(d["cigar_off"][k]), int(d["n_cigar"][k])
+    cig = "".join(f"{int(c) >> 4}{CIGAR_CHARS[int(c) & 15]}" for c in d["cigar"][co:co + nc] if (int(c) & 15) not in (4, 5))
+    return sl, ql, sr, qr, cig
+
+
+def format_clip_outputs(d, target_names):
+    """-> (clip text, clip.fq text): decompressed contents of prefix.clip.gz and prefix.clip.fq.gz."""
+    rows, fq = [], []
+    for k in range(d["n_clusters"]):
+        sl, ql, sr, qr, cig = cluster_strings(d, k)
+        chrom = target_names[int(d["tid"][k])]
+        side = chr(int(d["side"][k]))
+        if side == "5":   # aligned = seq_right, clipped = seq_left (clip_reads.h:308-311,320-321)
+            rows.append(f"{chrom}\t{int(d['pos'][k])}\t5\t{cig}\t{sr}\t{qr}\t{sl}\t{ql}\t{int(d['support'][k])}\n")
+            fq.append(f"@{sl}\n{sl}\n+\n{ql}\n")
+        else:             # aligned = seq_left, clipped = seq_right (clip_reads.h:329-332,339-340)
+            rows.append(f"{chrom}\t{int(d['pos'][k])}\t3\t{cig}\t{sl}\t{ql}\t{sr}\t{qr}\t{int(d['support'][k])}\n")
+            fq.append(f"@{sr}\n{sr}\n+\n{qr}\n")
+    return "".join(rows), "".join(fq)

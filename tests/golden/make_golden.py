@@ -1,0 +1,353 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/ by running the REAL reference (oracle/_ref/seeksv_ref, built from
+/root/reference by `make -C oracle ref`) on the bundled example BAMs and on crafted BAMs written here.
+
+Runs only in the build container (needs /root/reference).  What is committed is data: input BAMs,
+junction lists and the reference's outputs.  bwa (example/bin/bwa, 0.7.10) is only needed for the
+example clip.bam fixtures, exactly as example/seeksv.sh:3 uses it.
+
+usage: python tests/golden/make_golden.py
+"""
+import gzip
+import os
+import random
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bamio  # noqa: E402
+
+REF = "/root/reference"
+BIN = os.path.join(ROOT, "oracle", "_ref")
+SEEKSV = os.path.join(BIN, "seeksv_ref")
+TMP = "/tmp/seeksv_golden_work"
+
+
+def run(cmd, stdout=None, stderr=None, cwd=None):
+    with open(stdout, "wb") if stdout else open(os.devnull, "wb") as so, open(stderr, "wb") if stderr else open(os.devnull, "wb") as se:
+        subprocess.check_call(cmd, stdout=so, stderr=se, cwd=cwd)
+
+
+def gunzip_to(src, dst):
+    with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+        g.write(f.read())
+
+
+# ------------------------------------------------------------------------------------------------
+# 1. bundled example BAMs: full pipeline of example/seeksv.sh + seeksv.somatic.sh
+# ------------------------------------------------------------------------------------------------
+
+def example():
+    out = os.path.join(HERE, "example")
+    os.makedirs(out, exist_ok=True)
+    os.makedirs(TMP, exist_ok=True)
+    bwa = os.path.join(TMP, "bwa")
+    shutil.copy(os.path.join(REF, "example/bin/bwa"), bwa)
+    os.chmod(bwa, 0o755)
+    for s in ("cancer", "normal"):
+        bam = os.path.join(out, f"{s}.sort.bam")
+        shutil.copy(os.path.join(REF, f"example/{s}.sort.bam"), bam)
+        shutil.copy(os.path.join(REF, f"example/{s}.sort.bam.bai"), bam + ".bai")
+        os.chmod(bam, 0o644), os.chmod(bam + ".bai", 0o644)
+        run([SEEKSV, "getclip", "-o", s, bam], cwd=TMP, stderr=os.path.join(out, f"{s}.getclip.stderr"))
+        gunzip_to(os.path.join(TMP, f"{s}.clip.gz"), os.path.join(out, f"{s}.clip.txt"))
+        gunzip_to(os.path.join(TMP, f"{s}.clip.fq.gz"), os.path.join(out, f"{s}.clip.fq.txt"))
+        gunzip_to(os.path.join(TMP, f"{s}.unmapped_1.fq.gz"), os.path.join(out, f"{s}.unmapped_1.fq.txt"))
+        gunzip_to(os.path.join(TMP, f"{s}.unmapped_2.fq.gz"), os.path.join(out, f"{s}.unmapped_2.fq.txt"))
+        run([bwa, "mem", os.path.join(REF, "example/reference/example.fa"), f"{s}.clip.fq.gz"], cwd=TMP, stdout=os.path.join(TMP, f"{s}.clip.sam"))
+        run([os.path.join(BIN, "sam2bam"), f"{s}.clip.sam", os.path.join(out, f"{s}.clip.bam")], cwd=TMP)
+        run([SEEKSV, "getsv", os.path.join(out, f"{s}.clip.bam"), bam, f"{s}.clip.gz", os.path.join(out, f"{s}.sv"), f"{s}.clipunmap.fq"],
+            cwd=TMP, stdout=os.path.join(out, f"{s}.getsv.stdout"), stderr=os.path.join(TMP, f"{s}.getsv.stderr"))
+        # stderr carries the absolute path of the BAM: keep only the insert size line values
+        with open(os.path.join(TMP, f"{s}.getsv.stderr")) as f, open(os.path.join(out, f"{s}.isize.txt"), "w") as g:
+            txt = f.read()
+            mean = txt.split("Mean insert size : ")[1].split()[0]
+            sd = txt.split("Mean deviation: ")[1].split()[0]
+            g.write(f"{mean}\t{sd}\n")
+        # every filter reason at least once
+        for tag, flags in (("b40", ["-b", "40"]), ("f2", ["-f", "2"]), ("d400", ["-d", "400"]), ("e60", ["-e", "60"]), ("D", ["-D"]), ("n0", ["-n", "0"])):
+            run([SEEKSV, "getsv"] + flags + [os.path.join(out, f"{s}.clip.bam"), bam, f"{s}.clip.gz", os.path.join(out, f"{s}.{tag}.sv"), f"{s}.clipunmap.fq"],
+                cwd=TMP, stdout=os.path.join(out, f"{s}.{tag}.getsv.stdout"))
+    run([SEEKSV, "somatic", os.path.join(out, "normal.sort.bam"), os.path.join(TMP, "normal.clip.gz"), os.path.join(out, "cancer.sv"),
+         os.path.join(out, "cancer.somatic.temp.sv")], cwd=TMP)
+
+
+# ------------------------------------------------------------------------------------------------
+# 2. crafted getclip cases
+# ------------------------------------------------------------------------------------------------
+
+def rnd_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def rnd_qual(rng, n):
+    return bytes(rng.choice((2, 11, 25, 37, 40)) for _ in range(n))
+
+
+def mutate(rng, s, rate):
+    return "".join(rng.choice("ACGT".replace(c, "")) if rng.random() < rate else c for c in s)
+
+
+def getclip_filters_case():
+    """One record per filter / CIGAR shape (SURVEY 8c 'behaviours verified with crafted BAMs')."""
+    rng = random.Random(11)
+    names, lens = ["c1", "c2", "c3"], [5000, 5000, 3000]
+    recs = []
+
+    def add(tid, pos, cigar, flag=0, mapq=60, aux=b"", qual="rand", mtid=None, mpos=None, isize=0, seq=None):
+        L = sum(l for l, op in bamio.parse_cigar(cigar) if op in (0, 1, 4, 7, 8))
+        recs.append(dict(qname=f"r{len(recs)}", flag=flag, tid=tid, pos=pos, mapq=mapq, cigar=cigar, mtid=tid if mtid is None else mtid,
+                         mpos=pos + 200 if mpos is None else mpos, isize=isize, seq=seq or rnd_seq(rng, L),
+                         qual=rnd_qual(rng, L) if qual == "rand" else qual, aux=aux))
+
+    xc = b"XCi" + (7).to_bytes(4, "little")
+    xc_c = b"XCC" + bytes([3])
+    xc0 = b"XCi" + (0).to_bytes(4, "little")
+    nm = b"NMC" + bytes([1])
+    add(0, 100, "50M")                       # first record of contig 0 (tid == initial last_tid 0): processed, no clip
+    add(0, 299, "10S30M10S")                 # both sides: '5' at 300, '3' at 329
+    add(0, 400, "20S80M")                    # left clip
+    add(0, 500, "80M20S")                    # right clip -> key 500+80
+    add(0, 600, "20S80M", flag=256)          # secondary: kept
+    add(0, 610, "20S80M", flag=512)          # QC fail: kept
+    add(0, 620, "20S80M", flag=2048)         # supplementary: kept
+    add(0, 700, "20S80M", mapq=0)            # MAPQ 0: dropped (default -q 1)
+    add(0, 710, "20S80M", mapq=1)            # MAPQ 1: kept
+    add(0, 800, "20S80M", flag=1024)         # duplicate: dropped
+    add(0, 900, "20H80M")                    # hard clip: dropped
+    add(0, 910, "20S60M20H")                 # hard clip at the other end: dropped
+    add(0, 1000, "20S80M", flag=8)           # mate unmapped: unmapped side channel, no clip
+    add(0, 1010, "20S80M", flag=4)           # unmapped flag: same
+    add(0, 1100, "20S40M5D40M")              # deletion in the span
+    add(0, 1200, "40M5I35M20S")              # insertion; right clip key = 1200 + 75
+    add(0, 1300, "30M100N50M20S")            # ref skip counts in the span
+    add(0, 1400, "30=5X45M20S")              # '=' counts, 'X' does NOT (clip_reads.cpp:322)
+    add(0, 1500, "20S80M", aux=xc)           # XC != 0, one sided: dropped
+    add(0, 1510, "20S80M", aux=nm + xc_c)    # XC as type C after another tag: dropped
+    add(0, 1520, "20S80M", aux=xc0)          # XC == 0: kept
+    add(0, 1600, "15S70M15S", aux=xc)        # XC != 0, both sided, forward: '5' only
+    add(0, 1700, "15S70M15S", aux=xc, flag=16)  # reverse: '3' only
+    add(0, 1800, "20S80M", qual=None)        # qualities absent: "*"
+    add(0, 1900, "100M")
+    add(1, 50, "20S80M")                     # first record of contig 1: triggers the flush and is LOST
+    add(1, 60, "20S80M")                     # kept
+    add(1, 70, "80M20S", flag=4)             # unmapped in between does not touch last_tid
+    add(1, 80, "80M20S")
+    add(2, 10, "100M")                       # switch, lost (no clip anyway)
+    add(2, 20, "30S70M")
+    add(2, 20, "35S65M", flag=16)
+    return names, lens, recs
+
+
+def getclip_stress_case(seed, n_bp=40, depth=30, L=100):
+    """Deep bins: reads of varying clip length piled on shared breakpoints, with base errors and low
+    qualities so that consensus updates, prepend/append growth, cigar replacement and second clusters all occur."""
+    rng = random.Random(seed)
+    names, lens = ["chrS", "chrT"], [60000, 30000]
+    genome = [rnd_seq(rng, l) for l in lens]
+    recs = []
+    for tid in (0, 1):
+        recs.append(dict(qname=f"lead{tid}", flag=0, tid=tid, pos=5, mapq=60, cigar=f"{L}M", mtid=tid, mpos=300, isize=0,
+                         seq=genome[tid][5:5 + L], qual=rnd_qual(rng, L)))
+    for b in range(n_bp):
+        tid = rng.randrange(2)
+        bp = rng.randrange(1000, lens[tid] - 1000)  # 0-based first aligned base (left clip) / last aligned+1 (right clip)
+        n_alleles = rng.choice((1, 1, 2))
+        partner = [rnd_seq(rng, L) for _ in range(n_alleles)]
+        left = rng.random() < 0.5
+        err = rng.choice((0.0, 0.01, 0.05, 0.12))
+        for _ in range(rng.randrange(2, depth)):
+            clip = rng.randrange(3, L - 20)
+            al = L - clip
+            a = rng.randrange(n_alleles)
+            q = rnd_qual(rng, L)
+            if left:
+                seq = partner[a][L - clip:] + genome[tid][bp:bp + al]
+                if rng.random() < 0.15:  # an indel inside the aligned part changes cigar_vec
+                    cigar, pos = f"{clip}S{al - 10}M2D10M", bp
+                else:
+                    cigar, pos = f"{clip}S{al}M", bp
+            else:
+                seq = genome[tid][bp - al:bp] + partner[a][:clip]
+                cigar, pos = f"{al}M{clip}S", bp - al
+            recs.append(dict(qname=f"b{b}_{len(recs)}", flag=rng.choice((0, 16, 99, 147)), tid=tid, pos=pos, mapq=rng.choice((0, 1, 20, 60, 60, 60)),
+                             cigar=cigar, mtid=tid, mpos=pos + 250, isize=350, seq=mutate(rng, seq, err), qual=q))
+        if rng.random() < 0.3:  # double-clipped reads sharing the bin
+            for _ in range(rng.randrange(1, 6)):
+                c1, c2 = rng.randrange(5, 30), rng.randrange(5, 30)
+                al = L - c1 - c2
+                seq = partner[0][L - c1:] + genome[tid][bp:bp + al] + rnd_seq(rng, c2)
+                recs.append(dict(qname=f"d{b}_{len(recs)}", flag=0, tid=tid, pos=bp, mapq=60, cigar=f"{c1}S{al}M{c2}S", mtid=tid, mpos=bp + 250,
+                                 isize=350, seq=mutate(rng, seq, err), qual=rnd_qual(rng, L)))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    return names, lens, recs
+
+
+def crafted_getclip():
+    out = os.path.join(HERE, "getclip")
+    os.makedirs(out, exist_ok=True)
+    cases = {"filters": getclip_filters_case(), "stress1": getclip_stress_case(1), "stress2": getclip_stress_case(2, n_bp=60, depth=80, L=150)}
+    for name, (names, lens, recs) in cases.items():
+        bam = os.path.join(out, f"{name}.bam")
+        bamio.write_bam(bam, names, lens, recs)
+        variants = [("", [])]
+        if name == "filters":
+            variants += [(".s", ["-s"]), (".q0", ["-q", "0"]), (".q30", ["-q", "30"])]
+        if name == "stress1":
+            variants += [(".t08", ["-t", "0.8"]), (".t1", ["-t", "1"])]
+        for tag, flags in variants:
+            pre = f"{name}{tag}"
+            run([SEEKSV, "getclip"] + flags + ["-o", pre, bam], cwd=TMP)
+            gunzip_to(os.path.join(TMP, f"{pre}.clip.gz"), os.path.join(out, f"{pre}.clip.txt"))
+            gunzip_to(os.path.join(TMP, f"{pre}.clip.fq.gz"), os.path.join(out, f"{pre}.clip.fq.txt"))
+
+
+# ------------------------------------------------------------------------------------------------
+# 3. getsv BAM passes through the -B junction-injection harness
+# ------------------------------------------------------------------------------------------------
+
+def junction_row(uc, up, us, dc, dp, ds, prev_abnormal=0):
+    return "\t".join(str(x) for x in (uc, up, us, 0, dc, dp, ds, 0, 0, prev_abnormal, "NA", 0, 0, 0, 0, 0, 0, 0, 0, "50M", "50M", "ACGT", "ACGT")) + "\n"
+
+
+def getsv_case(seed, n_pairs=6000, L=100, with_small_contig=True):
+    rng = random.Random(seed)
+    names, lens = ["chrA", "chrB"], [40000, 15000]
+    if with_small_contig:
+        names.append("HBV")
+        lens.append(3215)
+    recs = []
+    cig_pool = [f"{L}M"] * 12 + [f"40M2D{L - 40}M", f"30M3I{L - 33}M", f"20S{L - 20}M", f"{L - 25}M25S", f"20H{L - 20}M", f"50M100N{L - 50}M", f"10S{L - 20}M10S"]
+
+    def qlen(c):
+        return sum(l for l, op in bamio.parse_cigar(c) if op in (0, 1, 4, 7, 8))
+
+    def mk(tid, pos, flag, mtid, mpos, isize, cigar=None, mapq=None):
+        cigar = cigar or rng.choice(cig_pool)
+        lq = qlen(cigar)
+        mq = mapq if mapq is not None else rng.choice((0, 10, 19, 20, 30, 60, 60, 60, 60))
+        return dict(qname=f"q{len(recs)}", flag=flag, tid=tid, pos=pos, mapq=mq, cigar=cigar, mtid=mtid, mpos=mpos, isize=isize,
+                    seq="A" * lq, qual=b"\x1e" * lq)
+
+    def extra_flags():
+        f = 0
+        if rng.random() < 0.05: f |= 1024
+        if rng.random() < 0.02: f |= 256
+        if rng.random() < 0.02: f |= 512
+        return f
+
+    # background proper pairs
+    for _ in range(n_pairs):
+        tid = rng.randrange(len(names))
+        isz = max(L + 1, int(rng.gauss(300, 20)))
+        p = rng.randrange(0, max(1, lens[tid] - isz - 150))
+        ef = extra_flags()
+        recs.append(mk(tid, p, 99 | ef, tid, p + isz - L, isz))
+        recs.append(mk(tid, p + isz - L, 147 | ef, tid, p, -isz))
+    junctions = []
+    # planted junctions with supporting discordant reads
+    for _ in range(60):
+        kind = rng.choice(("del", "dup", "inv_mp", "inv_pm", "ctx", "ctx_mp"))
+        ta = rng.randrange(len(names))
+        tb = ta if not kind.startswith("ctx") else (ta + 1 + rng.randrange(len(names) - 1)) % len(names)
+        up = rng.randrange(1, lens[ta])
+        if kind == "del": down = min(lens[tb] - 1, up + rng.randrange(1, 3000)); us, ds = "+", "+"
+        elif kind == "dup": down = max(1, up - rng.randrange(1, 400)); us, ds = "+", "+"
+        elif kind == "inv_mp" or kind == "ctx_mp": down = rng.randrange(1, lens[tb]); us, ds = "-", "+"
+        elif kind == "inv_pm": down = rng.randrange(1, lens[tb]); us, ds = "+", "-"
+        else: down = rng.randrange(1, lens[tb]); us, ds = "+", "+"
+        junctions.append((names[ta], up, us, names[tb], down, ds))
+        for _ in range(rng.randrange(0, 25)):
+            lq = L
+            jitter = rng.randrange(-40, 40)
+            if us == "+" and ds == "+":
+                p = up - rng.randrange(lq - 8, 420) + (jitter if rng.random() < 0.2 else 0)
+                mp = down - 1 + rng.randrange(-8, 300)
+                flag = rng.choice((97, 97, 97, 65, 81, 113, 161))
+            elif us == "-":
+                p = up - 1 + rng.randrange(-8, 320)
+                mp = down - 1 + rng.randrange(-8, 300)
+                flag = rng.choice((113, 113, 113, 97, 177))
+            else:
+                p = up - rng.randrange(lq - 8, 420)
+                mp = down - lq - rng.randrange(-8, 300)
+                flag = rng.choice((65, 65, 65, 97, 129))
+            if p < 0 or mp < 0 or p >= lens[ta]:
+                continue
+            isz = rng.choice((0, mp - p, 5000, -5000, 300))
+            recs.append(mk(ta, p, flag | extra_flags(), tb, mp, isz, cigar=rng.choice((f"{L}M", f"{L}M", f"{L}M", None))))
+    # junctions without any support, duplicates, near contig ends, unknown contig, identical positions
+    for _ in range(25):
+        ta, tb = rng.randrange(len(names)), rng.randrange(len(names))
+        junctions.append((names[ta], rng.randrange(1, lens[ta]), rng.choice("+-"), names[tb], rng.randrange(1, lens[tb]), "+"))
+    junctions.append(junctions[3])
+    junctions.append((names[0], 5, "+", names[0], 150, "+"))
+    junctions.append((names[0], 120, "-", names[1], 60, "+"))
+    junctions.append((names[0], lens[0] - 3, "+", names[1], lens[1] - 10, "+"))
+    junctions.append((names[0], lens[0] - 30, "-", names[1], 100, "+"))
+    junctions.append((names[1], 700, "+", names[1], 701, "+"))     # l == 0 windows
+    junctions.append((names[1], 900, "+", names[1], 902, "+"))     # l == 1 windows
+    junctions.append((names[1], 1200, "+", names[1], 1230, "+"))   # l == 29
+    if with_small_contig:
+        junctions.append((names[0], 2000, "+", "HBV", 150, "+"))   # wraps below the contig start
+        junctions.append(("HBV", 3200, "+", names[0], 2500, "+"))  # runs past the contig end
+        junctions.append(("HBV", 100, "-", names[0], 9000, "+"))
+    junctions.append(("chrZ", 100, "+", names[0], 300, "+"))       # up_chr not in the header: keeps its previous count
+    junctions.append((names[0], 3000, "+", "chrZ", 300, "+"))      # down_chr not in the header
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+
+    def jkey(j):
+        return (j[0], j[3], j[2], j[5], j[1], j[4])  # Junction::operator<, getsv.h:187-225
+    junctions.sort(key=jkey)
+    return names, lens, recs, junctions
+
+
+def crafted_getsv():
+    out = os.path.join(HERE, "getsv")
+    os.makedirs(out, exist_ok=True)
+    # header-only clip.bam and empty clip file for the harness
+    for name, seed, kw in (("pairs1", 5, {}), ("pairs2", 6, dict(n_pairs=12000, L=150)), ("pairs3", 7, dict(n_pairs=3000, with_small_contig=False))):
+        names, lens, recs, junctions = getsv_case(seed, **kw)
+        bam = os.path.join(out, f"{name}.bam")
+        bamio.write_bam(bam, names, lens, recs)
+        run([os.path.join(BIN, "bamidx"), bam])
+        empty_bam = os.path.join(TMP, f"{name}.empty.clip.bam")
+        bamio.write_bam(empty_bam, names, lens, [])
+        empty_clip = os.path.join(TMP, "empty.clip")
+        open(empty_clip, "w").close()
+        jfile = os.path.join(out, f"{name}.junctions.txt")
+        with open(jfile, "w") as f:
+            for j in junctions:
+                f.write(junction_row(*j, prev_abnormal=7 if j[0] == "chrZ" else 0))
+        variants = [("", [])]
+        if name == "pairs1":
+            variants += [(".q0", ["-q", "0"]), (".L50", ["-L", "50"]), (".L1", ["-L", "1"])]
+        for tag, flags in variants:
+            pre = os.path.join(out, f"{name}{tag}")
+            # -d 0 -f 0 -b 0: every junction with a discordant pair reaches the table with all depth columns
+            cmd = [SEEKSV, "getsv", "-d", "0", "-f", "0", "-b", "0", "-T", "100000"] + flags + ["-B", jfile, empty_bam, bam, empty_clip, pre + ".sv", os.path.join(TMP, "x.fq")]
+            with open(pre + ".stdout", "wb") as so, open(os.path.join(TMP, "stderr.txt"), "wb") as se:
+                rc = subprocess.call(cmd, stdout=so, stderr=se)
+            txt = open(os.path.join(TMP, "stderr.txt")).read()
+            with open(pre + ".isize.txt", "w") as g:
+                if "Mean insert size : " in txt:
+                    g.write(txt.split("Mean insert size : ")[1].split()[0] + "\t" + txt.split("Mean deviation: ")[1].split()[0] + "\n")
+                else:
+                    g.write("NA\tNA\n")
+            if rc != 0:
+                print(f"  reference exited with {rc} on {name}{tag} (kept: this is reference behaviour)")
+                with open(pre + ".rc", "w") as g:
+                    g.write(f"{rc}\n")
+
+
+if __name__ == "__main__":
+    if not os.path.exists(SEEKSV):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    os.makedirs(TMP, exist_ok=True)
+    example()
+    crafted_getclip()
+    crafted_getsv()
+    print("goldens regenerated under", HERE)

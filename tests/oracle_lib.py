@@ -1,0 +1,83 @@
+"""ctypes access to oracle/liboracle.so (the CPU checker).  TESTS ONLY - nothing in seeksv_amd/ imports this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from seeksv_amd import _abi
+from seeksv_amd.host import table_to_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        src = os.path.join(ORACLE_DIR, "seeksv_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(so)
+        V = C.c_void_p
+        _lib.orc_getclip.argtypes = [C.POINTER(_abi.Batch), C.c_int, C.POINTER(_abi.ClipParams), C.POINTER(_abi.OrcClusterTable)]
+        _lib.orc_cluster_table_free.argtypes = [C.POINTER(_abi.OrcClusterTable)]
+        _lib.orc_isize_stats.argtypes = [C.POINTER(_abi.Batch), C.c_int, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        _lib.orc_discordant.argtypes = [C.POINTER(_abi.Batch), C.c_int, V, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, V]
+        _lib.orc_depth.argtypes = [C.POINTER(_abi.Batch), C.c_int, V, C.c_int64, C.c_int32, V, C.c_int64, V, V, C.c_int64, V, C.POINTER(C.c_int32)]
+    return _lib
+
+
+def _batches(batches):
+    arr = (_abi.Batch * max(len(batches), 1))()
+    keep = []
+    for i, b in enumerate(batches):
+        bb, k = _abi.make_batch(b)
+        arr[i] = bb
+        keep.append(k)
+    return arr, keep
+
+
+def getclip(batches, match_rate=0.9, min_mapq=1, save_low_quality=False):
+    arr, keep = _batches(batches)
+    p = _abi.ClipParams(match_rate, min_mapq, int(save_low_quality))
+    t = _abi.OrcClusterTable()
+    rc = lib().orc_getclip(arr, len(batches), C.byref(p), C.byref(t))
+    assert rc == 0
+    d = table_to_dict(t)
+    lib().orc_cluster_table_free(C.byref(t))
+    return d
+
+
+def isize_stats(batches, min_mapq=20, max_pairs=5000000):
+    arr, keep = _batches(batches)
+    n, mean, sd = C.c_int64(), C.c_int32(0), C.c_int32(0)
+    rc = lib().orc_isize_stats(arr, len(batches), min_mapq, max_pairs, C.byref(n), C.byref(mean), C.byref(sd))
+    return rc, n.value, mean.value, sd.value
+
+
+def discordant(batches, junctions, mean, sd, times=4, min_mapq=20):
+    arr, keep = _batches(batches)
+    j = np.ascontiguousarray(junctions, dtype=_abi.JUNCTION_DTYPE)
+    counts = np.zeros(len(j), dtype=np.int32)
+    rc = lib().orc_discordant(arr, len(batches), j.ctypes.data if len(j) else None, len(j), mean, sd, times, min_mapq,
+                              counts.ctypes.data if len(j) else None)
+    assert rc == 0
+    return counts
+
+
+def depth(batches, windows, ranges, points, min_mapq=20):
+    arr, keep = _batches(batches)
+    w = np.ascontiguousarray(windows, dtype=_abi.INTERVAL_DTYPE)
+    r = np.ascontiguousarray(ranges, dtype=_abi.INTERVAL_DTYPE)
+    q = np.ascontiguousarray(points, dtype=_abi.INTERVAL_DTYPE)
+    rs = np.zeros(len(r), dtype=np.uint64)
+    pd = np.zeros(len(q), dtype=np.int32)
+    mx = C.c_int32(0)
+    p = lambda a: a.ctypes.data if a.size else None
+    rc = lib().orc_depth(arr, len(batches), p(w), len(w), min_mapq, p(r), len(r), p(rs), p(q), len(q), p(pd), C.byref(mx))
+    assert rc == 0
+    return rs, pd, mx.value

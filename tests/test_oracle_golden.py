@@ -1,0 +1,92 @@
+"""Pins the CPU oracle (oracle/seeksv_oracle.c) + the host bookkeeping (libseeksv_host.so) against outputs
+of the REAL reference committed under tests/golden/ (made by tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+from seeksv_amd import host
+
+GETCLIP_CASES = [
+    ("example", "cancer.sort.bam", "cancer", {}),
+    ("example", "normal.sort.bam", "normal", {}),
+    ("getclip", "filters.bam", "filters", {}),
+    ("getclip", "filters.bam", "filters.s", dict(save_low_quality=True)),
+    ("getclip", "filters.bam", "filters.q0", dict(min_mapq=0)),
+    ("getclip", "filters.bam", "filters.q30", dict(min_mapq=30)),
+    ("getclip", "stress1.bam", "stress1", {}),
+    ("getclip", "stress1.bam", "stress1.t08", dict(match_rate=0.8)),
+    ("getclip", "stress1.bam", "stress1.t1", dict(match_rate=1.0)),
+    ("getclip", "stress2.bam", "stress2", {}),
+]
+
+GETSV_CASES = [
+    ("pairs1", "pairs1", dict()),
+    ("pairs1", "pairs1.q0", dict(min_mapq=0)),
+    ("pairs1", "pairs1.L50", dict(flank_length=50)),
+    ("pairs1", "pairs1.L1", dict(flank_length=1)),
+    ("pairs2", "pairs2", dict()),
+    ("pairs3", "pairs3", dict()),
+]
+
+
+class OracleBackend:
+    def isize_stats(self, batches, min_mapq, max_pairs):
+        return O.isize_stats(batches, min_mapq, max_pairs)
+
+    def discordant_and_depth(self, batches, plan, mean, sd, min_mapq, target_lens):
+        counts = O.discordant(batches, plan.junctions, mean, sd, 4, min_mapq)
+        rs, pd, _ = O.depth(batches, plan.windows, plan.ranges, plan.points, min_mapq)
+        return counts, rs, pd
+
+
+@pytest.mark.parametrize("sub,bam,prefix,kw", GETCLIP_CASES, ids=[c[2] for c in GETCLIP_CASES])
+@pytest.mark.parametrize("batch_records", [1 << 20, 1000])
+def test_getclip_oracle_matches_reference(sub, bam, prefix, kw, batch_records):
+    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, sub, bam), batch_records)
+    d = O.getclip(batches, **kw)
+    clip, fq = host.format_clip_outputs(d, names)
+    assert clip == G.read_text(sub, prefix + ".clip.txt")
+    assert fq == G.read_text(sub, prefix + ".clip.fq.txt")
+
+
+@pytest.mark.parametrize("sample", ["cancer", "normal"])
+def test_isize_oracle_matches_reference_example(sample):
+    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, "example", sample + ".sort.bam"))
+    rc, n, mean, sd = O.isize_stats(batches, 20, 5000000)
+    exp = G.read_text("example", sample + ".isize.txt").split()
+    assert rc == 0 and [str(mean), str(sd)] == exp
+
+
+@pytest.mark.parametrize("case,prefix,kw", GETSV_CASES, ids=[c[1] for c in GETSV_CASES])
+def test_getsv_passes_oracle_matches_reference(case, prefix, kw):
+    base = os.path.join(G.GOLDEN, "getsv")
+    rows = G.read_junction_file(os.path.join(base, case + ".junctions.txt"))
+    stats, junctions, folded = G.run_getsv_case(os.path.join(base, case + ".bam"), rows, OracleBackend(), **kw)
+    exp = G.read_text("getsv", prefix + ".isize.txt").split()
+    assert [str(stats[2]), str(stats[3])] == exp
+    golden = G.parse_sv_outputs(os.path.join(base, prefix + ".sv"), os.path.join(base, prefix + ".stdout"))
+    assert sum(len(v) for v in golden.values()) == len(junctions)
+    checked = G.check_getsv_against_golden(junctions, folded, golden)
+    assert checked > 3 * len(junctions)
+
+
+def test_example_sv_table_bam_columns():
+    """Columns 10 and 12-17 of the full-pipeline table on example/cancer.sort.bam (the libbam-dependent ones)."""
+    base = os.path.join(G.GOLDEN, "example")
+    rows = []
+    for line in G.read_text("example", "cancer.sv").splitlines():
+        if line.startswith("@"):
+            continue
+        t = line.split("\t")
+        rows.append((t[0], int(t[1]), t[2], t[4], int(t[5]), t[6], 0, int(t[3]), int(t[7]), line))
+    stats, junctions, folded = G.run_getsv_case(os.path.join(base, "cancer.sort.bam"), [r[:7] for r in rows], OracleBackend())
+    for i, r in enumerate(rows):
+        t = r[9].split("\t")
+        assert int(folded["abnormal"][i]) == int(t[9])
+        assert int(folded["up_depth"][i]) + r[8] == int(t[11])      # updepth = depth(up) + down support (getsv.cpp:858)
+        assert int(folded["down_depth"][i]) + r[7] == int(t[12])
+        for c in range(4):
+            assert int(folded["flank"][i, c]) // int(folded["flank_len"][i, c]) == int(t[13 + c])
