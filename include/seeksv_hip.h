@@ -52,7 +52,8 @@ typedef enum {
 typedef struct {
 	int64_t n;                 /* records in the batch (< 2^31) */
 	int32_t mem;               /* ssv_mem */
-	int32_t reserved;
+	int32_t max_ref_span;      /* >= the longest reference span (sum of M,D,N,=,X lengths) of any record in the batch;
+	                              0 = unknown (the library then measures it with an extra pass over the CIGARs) */
 	const int32_t *tid;        /* [n] reference id, -1 = unplaced */
 	const int32_t *pos;        /* [n] 0-based leftmost coordinate */
 	const uint16_t *flag;      /* [n] */

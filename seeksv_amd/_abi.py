@@ -19,7 +19,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 class Batch(C.Structure):
     """ssv_batch_t"""
     _fields_ = [
-        ("n", C.c_int64), ("mem", C.c_int32), ("reserved", C.c_int32),
+        ("n", C.c_int64), ("mem", C.c_int32), ("max_ref_span", C.c_int32),
         ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
         ("n_cigar", C.c_void_p), ("l_qseq", C.c_void_p), ("mtid", C.c_void_p), ("mpos", C.c_void_p),
         ("isize", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("xc", C.c_void_p),
@@ -102,6 +102,7 @@ def make_batch(arrays, mem=MEM_HOST, n=None):
         else:
             setattr(b, name, int(a))
     b.mem = mem
+    b.max_ref_span = int(arrays.get("max_ref_span", 0))
     if n is None:
         n = len(arrays["tid"])
     b.n = int(n)
@@ -124,6 +125,7 @@ def batch_to_arrays(b):
             continue
         buf = (C.c_uint8 * (cnt * np.dtype(dt).itemsize)).from_address(ptr)
         out[name] = np.frombuffer(buf, dtype=dt, count=cnt).copy()
+    out["max_ref_span"] = int(b.max_ref_span)
     return out
 
 

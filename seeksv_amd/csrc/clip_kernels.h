@@ -1,0 +1,477 @@
+// clip_kernels.h - getclip on the GPU: CIGAR-end scan -> ordered clip events -> (contig, side, pos) bins
+// -> greedy consensus clustering, one wavefront per bin.
+//
+// Reference behaviour being reproduced (file:line in /root/reference/seeksv):
+//   record routing + contig-switch rule   clip_reads.h:410-440
+//   GetSClipReads / GenerateCigar         clip_reads.cpp:112-192, 309-329
+//   GetSeq                                clip_reads.cpp:286-306
+//   InsertSeq / CompareString* / ChangeSeqAndQual   clip_reads.cpp:260-283, 194-217, 57-108
+#pragma once
+
+#include "common.h"
+
+namespace ssv {
+
+// device view of one batch (all pointers in HBM)
+struct DevBatch {
+	int64_t n;
+	const int32_t *tid, *pos;
+	const uint16_t *flag;
+	const uint8_t *mapq;
+	const uint16_t *n_cigar;
+	const int32_t *l_qseq, *mtid, *mpos, *isize;
+	const uint32_t *cigar_off, *cigar;
+	const uint8_t *xc;
+	const uint64_t *seq_off;
+	const uint8_t *seqqual;
+	int32_t max_ref_span;
+};
+
+constexpr int CLIP_ITEMS = 4;
+constexpr int CLIP_TILE = BLOCK * CLIP_ITEMS; // 1024 records per tile: every streamed load is <= 16 B per lane, fully coalesced
+
+// one clip event as staged by the scan kernel (order restored afterwards from tile + slot)
+struct StagedEvent {
+	uint64_t key;    // tid << 33 | side << 32 | pos1   (side 0 = '5' / breakpoint2read_l, 1 = '3' / breakpoint2read_r)
+	uint32_t rec;    // record index inside the batch
+	uint32_t tile;
+	int32_t begin;   // first query base of seq_left  (GetSeq's begin_pos)
+	int32_t ll, lr;  // |seq_left|, |seq_right|
+	int32_t lq;      // l_qseq
+	uint32_t ncig;
+	uint32_t pad;
+};
+
+struct ClipCounters {
+	unsigned long long stage_cursor; // staging slots handed out
+	unsigned long long seq_bytes;    // packed bases + qualities of all events of this batch
+	unsigned long long cig_ops;
+	unsigned long long max_key;
+	int max_ll, max_lr;
+	int overflow;
+	int pad;
+};
+
+struct ClipScanArgs {
+	DevBatch b;
+	int min_mapq;
+	int save_low_quality;
+	const int *last_tid_in;  // tid of the last mapped-pair record before this batch (clip_reads.h:407: starts at 0)
+	uint32_t *tile_cnt;      // [ntiles] events per tile
+	uint32_t *tile_off;      // [ntiles] staging offset of the tile's events
+	StagedEvent *stage;
+	int64_t stage_cap;
+	ClipCounters *ctr;
+	int64_t ntiles;
+};
+
+// GenerateCigar's l: M, D, =, N advance the reference; X does not (clip_reads.cpp:322)
+__device__ __forceinline__ int ref_len_generate_cigar(const uint32_t *cig, int n)
+{
+	int l = 0;
+	for (int i = 0; i < n; ++i) {
+		uint32_t c = cig[i];
+		int op = (int)(c & 15u);
+		if (op == C_M || op == C_D || op == C_EQ || op == C_N) l += (int)(c >> 4);
+	}
+	return l;
+}
+
+// Decide the 0/1/2 events of record i.  Only called for records whose first or last op is 'S' (about 1 % of a WGS BAM),
+// so everything it touches beyond the CIGAR is a lazy, sparse load.
+__device__ __forceinline__ int clip_events_of(const ClipScanArgs &a, int64_t i, int nc, uint32_t c0, uint32_t cl, StagedEvent ev[2])
+{
+	const DevBatch &b = a.b;
+	int op1 = (int)(c0 & 15u), op2 = (int)(cl & 15u);
+	int flag = b.flag[i];
+	if (flag & (F_UNMAP | F_MUNMAP)) return 0;          // unmapped-pair side channel (host), clip_reads.h:415
+	int tid = b.tid[i];
+	// contig-switch rule: processed only if tid equals the tid of the previous mapped-pair record
+	int prev_tid = *a.last_tid_in;
+	for (int64_t j = i - 1; j >= 0; --j) {
+		if (!(b.flag[j] & (F_UNMAP | F_MUNMAP))) { prev_tid = b.tid[j]; break; }
+	}
+	if (tid != prev_tid || tid < 0) return 0;
+	if (op1 == C_H || op2 == C_H || (int)b.mapq[i] < a.min_mapq || (flag & F_DUP)) return 0; // clip_reads.cpp:118
+	if (b.seq_off[i] == ~0ull) return 0;                // batcher contract: bases must be shipped for 'S'-ended records
+	bool s1 = op1 == C_S, s2 = op2 == C_S;
+	int xc = b.xc ? b.xc[i] : 0;
+	int lq = b.l_qseq[i];
+	int pos0 = b.pos[i];
+	const uint32_t *cig = b.cigar + b.cigar_off[i];
+	int n = 0;
+	uint64_t tkey = (uint64_t)(uint32_t)tid << 33;
+	if (s1 != s2) {
+		if (xc != 0 && !a.save_low_quality) return 0;   // clip_reads.cpp:129
+		if (s1) {
+			int ll = (int)(c0 >> 4), lr = lq - ll;
+			if (lr < 0) return 0;
+			ev[0].key = tkey | (uint32_t)(pos0 + 1); ev[0].begin = 0; ev[0].ll = ll; ev[0].lr = lr; n = 1;
+		} else {
+			int lr = (int)(cl >> 4), ll = lq - lr;
+			if (ll < 0) return 0;
+			int ref_len = ref_len_generate_cigar(cig, nc);
+			ev[0].key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); ev[0].begin = 0; ev[0].ll = ll; ev[0].lr = lr; n = 1;
+		}
+	} else {
+		int ll = (int)(c0 >> 4), rc = (int)(cl >> 4), mid = lq - ll - rc;
+		if (mid < 0) return 0;
+		bool do_l = true, do_r = true;
+		if (xc != 0 && !a.save_low_quality) { if (!(flag & F_REV)) do_r = false; else do_l = false; } // clip_reads.cpp:160-175
+		if (do_l) { ev[n].key = tkey | (uint32_t)(pos0 + 1); ev[n].begin = 0; ev[n].ll = ll; ev[n].lr = mid; ++n; }
+		if (do_r) {
+			int ref_len = ref_len_generate_cigar(cig, nc);
+			ev[n].key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); ev[n].begin = ll; ev[n].ll = mid; ev[n].lr = rc; ++n;
+		}
+	}
+	for (int k = 0; k < n; ++k) { ev[k].rec = (uint32_t)i; ev[k].lq = lq; ev[k].ncig = (uint32_t)nc; ev[k].pad = 0; }
+	return n;
+}
+
+// K1 clip_scan: streams n_cigar, cigar_off and the end ops of every record (~10 B/record); everything else is touched
+// only for the ~1 % of records with a soft clip.  Events are staged per tile; k_clip_place restores BAM order.
+__global__ __launch_bounds__(BLOCK) void k_clip_scan(ClipScanArgs a)
+{
+	__shared__ uint32_t lds[WAVES_PER_BLOCK + 1];
+	__shared__ uint32_t s_off;
+	const DevBatch &b = a.b;
+	for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+		const int64_t i0 = tile * CLIP_TILE + (int64_t)threadIdx.x * CLIP_ITEMS;
+		uint32_t nc[CLIP_ITEMS], off[CLIP_ITEMS];
+		if (i0 + CLIP_ITEMS <= b.n) {
+			ushort4 n4 = *reinterpret_cast<const ushort4 *>(b.n_cigar + i0);
+			uint4 o4 = *reinterpret_cast<const uint4 *>(b.cigar_off + i0);
+			nc[0] = n4.x; nc[1] = n4.y; nc[2] = n4.z; nc[3] = n4.w;
+			off[0] = o4.x; off[1] = o4.y; off[2] = o4.z; off[3] = o4.w;
+		} else {
+#pragma unroll
+			for (int k = 0; k < CLIP_ITEMS; ++k) {
+				bool in = i0 + k < b.n;
+				nc[k] = in ? b.n_cigar[i0 + k] : 0u;
+				off[k] = in ? b.cigar_off[i0 + k] : 0u;
+			}
+		}
+		uint32_t c0[CLIP_ITEMS], cl[CLIP_ITEMS];
+#pragma unroll
+		for (int k = 0; k < CLIP_ITEMS; ++k) {
+			c0[k] = nc[k] ? b.cigar[off[k]] : 0u;
+			cl[k] = nc[k] > 1 ? b.cigar[off[k] + nc[k] - 1] : c0[k];
+		}
+		// phase 1: how many events does each record emit (the full predicate chain runs only for soft-clipped records)
+		int cnt[CLIP_ITEMS];
+		uint32_t mine = 0;
+#pragma unroll
+		for (int k = 0; k < CLIP_ITEMS; ++k) {
+			cnt[k] = 0;
+			// a lone "nS" CIGAR gives negative slice lengths in the reference; like the oracle we emit nothing
+			bool cand = nc[k] >= 2 && ((c0[k] & 15u) == C_S || (cl[k] & 15u) == C_S);
+			if (cand) { StagedEvent tmp[2]; cnt[k] = clip_events_of(a, i0 + k, (int)nc[k], c0[k], cl[k], tmp); }
+			mine += (uint32_t)cnt[k];
+		}
+		uint32_t total;
+		uint32_t ex = block_exclusive_sum(mine, lds, &total);
+		if (threadIdx.x == 0) {
+			uint32_t so = 0;
+			if (total) {
+				unsigned long long s = atomicAdd(&a.ctr->stage_cursor, (unsigned long long)total);
+				if (s + total > (unsigned long long)a.stage_cap) { atomicExch(&a.ctr->overflow, 1); so = 0xffffffffu; }
+				else so = (uint32_t)s;
+			}
+			a.tile_cnt[tile] = total;
+			a.tile_off[tile] = so;
+			s_off = so;
+		}
+		__syncthreads();
+		const uint32_t so = s_off;
+		// phase 2: the (rare) emitting lanes rebuild their events and write them to the tile's staging slots in record order
+		if (mine && so != 0xffffffffu) {
+			unsigned long long sb = 0, co = 0, mk = 0;
+			int mll = 0, mlr = 0;
+			uint32_t slot = so + ex;
+#pragma unroll
+			for (int k = 0; k < CLIP_ITEMS; ++k) {
+				if (!cnt[k]) continue;
+				StagedEvent ev[2];
+				int ne = clip_events_of(a, i0 + k, (int)nc[k], c0[k], cl[k], ev);
+				for (int e = 0; e < ne; ++e) {
+					StagedEvent x = ev[e];
+					x.tile = (uint32_t)tile;
+					a.stage[slot++] = x;
+					sb += (unsigned long long)((x.lq + 1) / 2 + x.lq);
+					co += x.ncig;
+					mk = x.key > mk ? x.key : mk;
+					mll = x.ll > mll ? x.ll : mll;
+					mlr = x.lr > mlr ? x.lr : mlr;
+				}
+			}
+			atomicAdd(&a.ctr->seq_bytes, sb);
+			atomicAdd(&a.ctr->cig_ops, co);
+			atomicMax(&a.ctr->max_key, mk);
+			atomicMax(&a.ctr->max_ll, mll);
+			atomicMax(&a.ctr->max_lr, mlr);
+		}
+		__syncthreads(); // s_off reused by the next tile
+	}
+}
+
+// tid of the last mapped-pair record of the batch -> *last_tid (unchanged when there is none)
+__global__ __launch_bounds__(BLOCK) void k_last_tid(DevBatch b, int *last_tid)
+{
+	__shared__ long long best;
+	if (threadIdx.x == 0) best = -1;
+	__syncthreads();
+	for (int64_t hi = b.n; hi > 0; hi -= BLOCK) {
+		int64_t i = hi - 1 - threadIdx.x;
+		if (i >= 0 && !(b.flag[i] & (F_UNMAP | F_MUNMAP))) atomicMax(&best, (long long)i);
+		__syncthreads();
+		if (best >= 0) break;
+	}
+	if (threadIdx.x == 0 && best >= 0) *last_tid = b.tid[best];
+}
+
+// final, ordered event arrays (context owned, all batches)
+struct EventArrays {
+	uint64_t *key;
+	int32_t *begin, *ll, *lr, *lq;
+	uint32_t *ncig;
+	uint32_t *seq_bytes;     // packed bases + qualities
+	uint64_t *seq_off;       // into seq_blob
+	uint64_t *cig_off;       // into cig_blob
+	uint64_t *src_seq;       // scratch: offset in the batch's seqqual
+	uint32_t *src_cig;       // scratch: offset in the batch's cigar
+};
+
+// staged slot s -> final position ev_base + tile_base[tile] + (s - tile_off[tile])
+__global__ void k_clip_place(const StagedEvent *__restrict__ stage, int64_t n_staged, const uint32_t *__restrict__ tile_base,
+                             const uint32_t *__restrict__ tile_off, DevBatch b, EventArrays ev, int64_t ev_base)
+{
+	int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_staged) return;
+	StagedEvent x = stage[s];
+	int64_t e = ev_base + tile_base[x.tile] + (s - tile_off[x.tile]);
+	ev.key[e] = x.key; ev.begin[e] = x.begin; ev.ll[e] = x.ll; ev.lr[e] = x.lr; ev.lq[e] = x.lq; ev.ncig[e] = x.ncig;
+	ev.seq_bytes[e] = (uint32_t)((x.lq + 1) / 2 + x.lq);
+	ev.src_seq[e] = b.seq_off[x.rec];
+	ev.src_cig[e] = b.cigar_off[x.rec];
+}
+
+// K2 clip_gather: one wavefront per event copies its packed bases, qualities and CIGAR into context-owned blobs so that
+// the batch buffers can be recycled.
+__global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays ev, int64_t ev_base, int64_t n_new, uint8_t *__restrict__ seq_blob, uint32_t *__restrict__ cig_blob)
+{
+	int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (w >= n_new) return;
+	int64_t e = ev_base + w;
+	const uint8_t *src = b.seqqual + ev.src_seq[e];
+	uint8_t *dst = seq_blob + ev.seq_off[e];
+	uint32_t nb = ev.seq_bytes[e];
+	for (uint32_t k = lane_id(); k < nb; k += WAVE) dst[k] = src[k];
+	const uint32_t *cs = b.cigar + ev.src_cig[e];
+	uint32_t *cd = cig_blob + ev.cig_off[e];
+	uint32_t nc = ev.ncig[e];
+	for (uint32_t k = lane_id(); k < nc; k += WAVE) cd[k] = cs[k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K3 cluster_bins
+// ---------------------------------------------------------------------------------------------------------------------
+
+__device__ __constant__ char NT16[16] = {'=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'}; // bam_nt16_rev_table
+
+struct ClusterArgs {
+	// sorted events
+	const uint64_t *skey;  // [E] sorted keys
+	const uint32_t *perm;  // [E] sorted position -> event index
+	int64_t E;
+	EventArrays ev;
+	const uint8_t *seq_blob;
+	double match_rate;
+	// per sorted slot outputs
+	int32_t *support;      // [E], zero initialised; > 0 marks a cluster created by the event at this slot
+	int32_t *c_ll, *c_lr;  // [E]
+	uint32_t *c_cig_ev;    // [E] event whose CIGAR the cluster carries
+	uint8_t *c_qmiss;      // [E]
+	uint8_t *strings;      // [E * stride]: left seq (reversed), left qual (reversed), right seq, right qual
+	int32_t SL, SR;        // capacity of a left / right string
+};
+
+constexpr int CL_CACHE = 64; // clusters of the current bin tracked in LDS; deeper bins fall back to scanning the slots
+
+struct EventView {
+	const uint8_t *sp, *qp;
+	int begin, ll, lr;
+	bool qmiss;
+	// i-th base of seq_left counted from its END (i = 0 is adjacent to the breakpoint side of the compare)
+	__device__ __forceinline__ int lpos(int i) const { return begin + ll - 1 - i; }
+	__device__ __forceinline__ int rpos(int i) const { return begin + ll + i; }
+	__device__ __forceinline__ char base(int p) const { return NT16[(sp[p >> 1] >> ((~p & 1) << 2)) & 15]; }
+	__device__ __forceinline__ char qual(int p) const { return qmiss ? '*' : (char)(qp[p] + 33); }
+};
+
+// One wavefront per bin (= run of equal keys in the sorted event list).  The wave walks the bin's events in BAM order -
+// the order the reference's multimap::equal_range scan sees them - and keeps the evolving clusters in HBM; lanes are
+// spread over bases, match counts come from ballots.  Bins are independent, so there is no cross-wave communication.
+__global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
+{
+	__shared__ int32_t s_slot[WAVES_PER_BLOCK][CL_CACHE];
+	const int64_t j0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (j0 >= a.E) return;
+	const uint64_t key0 = a.skey[j0];
+	if (j0 > 0 && a.skey[j0 - 1] == key0) return; // not the start of a bin
+	const int lane = lane_id();
+	const int w = wave_id();
+	const bool left_clipped = ((key0 >> 32) & 1ull) == 0; // side '5' = breakpoint2read_l = LEFT_CLIPPED
+	const int64_t stride = 2ll * (a.SL + a.SR);
+	int nclu = 0;
+	for (int64_t jj = j0; jj < a.E && a.skey[jj] == key0; ++jj) {
+		const uint32_t e = a.perm[jj];
+		EventView v;
+		const int lq = a.ev.lq[e];
+		v.sp = a.seq_blob + a.ev.seq_off[e];
+		v.qp = v.sp + (lq + 1) / 2;
+		v.begin = a.ev.begin[e]; v.ll = a.ev.ll[e]; v.lr = a.ev.lr[e];
+		v.qmiss = lq > 0 && v.qp[0] == 0xff;
+		// ---- find the first cluster of the bin that absorbs this event (clip_reads.cpp:262-273) ----
+		auto absorbs = [&](int64_t slot) -> bool {
+			const uint8_t *cs = a.strings + slot * stride;
+			const int cll = a.c_ll[slot], clr = a.c_lr[slot];
+			const int n1 = v.ll < cll ? v.ll : cll;
+			int m1 = 0;
+			for (int i0 = 0; i0 < n1; i0 += WAVE) {
+				int i = i0 + lane;
+				bool eq = i < n1 && v.base(v.lpos(i)) == (char)cs[i];
+				m1 += (int)__popcll(__ballot(eq));
+			}
+			if (!((double)m1 / (double)n1 >= a.match_rate)) return false; // n1 == 0 -> NaN -> false, like the reference
+			const int n2 = v.lr < clr ? v.lr : clr;
+			int m2 = 0;
+			const uint8_t *csr = cs + 2 * a.SL;
+			for (int i0 = 0; i0 < n2; i0 += WAVE) {
+				int i = i0 + lane;
+				bool eq = i < n2 && v.base(v.rpos(i)) == (char)csr[i];
+				m2 += (int)__popcll(__ballot(eq));
+			}
+			return (double)m2 / (double)n2 >= a.match_rate;
+		};
+		int64_t hit = -1;
+		const int kmax = nclu < CL_CACHE ? nclu : CL_CACHE;
+		for (int k = 0; k < kmax && hit < 0; ++k) {
+			int64_t slot = j0 + s_slot[w][k];
+			if (absorbs(slot)) hit = slot;
+		}
+		if (hit < 0 && nclu > CL_CACHE) {
+			// clusters beyond the LDS cache: they were created after the last cached one, i.e. at later slots
+			for (int64_t s = j0 + s_slot[w][CL_CACHE - 1] + 1; s < jj && hit < 0; ++s)
+				if (a.support[s] > 0 && absorbs(s)) hit = s;
+		}
+		if (hit >= 0) {
+			// ---- ReadsInfo::ChangeSeqAndQual (clip_reads.cpp:57-108) on the reversed-left / forward-right storage ----
+			uint8_t *cs = a.strings + hit * stride;
+			uint8_t *cq = cs + a.SL, *rs = cs + 2 * a.SL, *rq = rs + a.SR;
+			const int cll = a.c_ll[hit], clr = a.c_lr[hit];
+			const int n1 = v.ll < cll ? v.ll : cll;
+			for (int i = lane; i < v.ll; i += WAVE) {
+				int p = v.lpos(i);
+				char q = v.qual(p);
+				if (i < n1) {
+					if ((signed char)cq[i] < (signed char)q) { cq[i] = (uint8_t)q; cs[i] = (uint8_t)v.base(p); }
+				} else if (cll <= v.ll) { cs[i] = (uint8_t)v.base(p); cq[i] = (uint8_t)q; } // prepend the extra prefix
+			}
+			if (cll <= v.ll) {
+				a.c_ll[hit] = v.ll;
+				if (!left_clipped) a.c_cig_ev[hit] = e;  // aa == RIGHT_CLIPPED (also when the lengths are equal)
+			}
+			const int n2 = v.lr < clr ? v.lr : clr;
+			for (int i = lane; i < v.lr; i += WAVE) {
+				int p = v.rpos(i);
+				char q = v.qual(p);
+				if (i < n2) {
+					if ((signed char)rq[i] < (signed char)q) { rq[i] = (uint8_t)q; rs[i] = (uint8_t)v.base(p); }
+				} else if (clr < v.lr) { rs[i] = (uint8_t)v.base(p); rq[i] = (uint8_t)q; } // append the extra suffix
+			}
+			if (clr < v.lr) {
+				a.c_lr[hit] = v.lr;
+				if (left_clipped) a.c_cig_ev[hit] = e;   // aa == LEFT_CLIPPED
+			}
+			a.support[hit] += 1; // every lane stores the same value; each lane later reads back what it stored
+		} else {
+			// ---- new cluster at this event's slot (clip_reads.cpp:276-281) ----
+			uint8_t *cs = a.strings + jj * stride;
+			uint8_t *cq = cs + a.SL, *rs = cs + 2 * a.SL, *rq = rs + a.SR;
+			for (int i = lane; i < v.ll; i += WAVE) { int p = v.lpos(i); cs[i] = (uint8_t)v.base(p); cq[i] = (uint8_t)v.qual(p); }
+			for (int i = lane; i < v.lr; i += WAVE) { int p = v.rpos(i); rs[i] = (uint8_t)v.base(p); rq[i] = (uint8_t)v.qual(p); }
+			a.c_ll[jj] = v.ll; a.c_lr[jj] = v.lr; a.c_cig_ev[jj] = e; a.c_qmiss[jj] = v.qmiss ? 1 : 0;
+			a.support[jj] = 1;
+			if (nclu < CL_CACHE) s_slot[w][nclu] = (int32_t)(jj - j0);
+			++nclu;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cluster table packing
+// ---------------------------------------------------------------------------------------------------------------------
+
+__global__ void k_cluster_flags(const int32_t *__restrict__ support, int64_t E, uint32_t *__restrict__ flag)
+{
+	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < E) flag[j] = support[j] > 0 ? 1u : 0u;
+}
+
+struct PackArgs {
+	ClusterArgs c;
+	const uint32_t *flag;     // [E]
+	const uint32_t *cidx;     // [E] exclusive scan of flag
+	// dense outputs [n_clusters]
+	int32_t *tid, *pos;
+	uint8_t *side;
+	int32_t *support, *ll, *lr;
+	uint8_t *qmiss;
+	uint32_t *slot;           // dense index -> sorted slot
+	uint64_t *str_bytes;      // 2 * (ll + lr)
+	uint64_t *ncig64;
+	int32_t *ncig;
+};
+
+__global__ void k_cluster_pack_meta(PackArgs p)
+{
+	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= p.c.E || !p.flag[j]) return;
+	uint32_t c = p.cidx[j];
+	uint64_t key = p.c.skey[j];
+	p.tid[c] = (int32_t)(key >> 33);
+	p.pos[c] = (int32_t)(uint32_t)key;
+	p.side[c] = ((key >> 32) & 1ull) ? '3' : '5';
+	p.support[c] = p.c.support[j];
+	int ll = p.c.c_ll[j], lr = p.c.c_lr[j];
+	p.ll[c] = ll; p.lr[c] = lr;
+	p.qmiss[c] = p.c.c_qmiss[j];
+	p.slot[c] = (uint32_t)j;
+	p.str_bytes[c] = 2ull * (uint64_t)(ll + lr);
+	uint32_t nc = p.c.ev.ncig[p.c.c_cig_ev[j]];
+	p.ncig[c] = (int32_t)nc;
+	p.ncig64[c] = nc;
+}
+
+// one wavefront per cluster: strings (left part un-reversed) and the CIGAR of the carrying event into dense blobs
+__global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
+                                                                const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
+{
+	int64_t c = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (c >= n_clusters) return;
+	const int64_t j = p.slot[c];
+	const int64_t stride = 2ll * (p.c.SL + p.c.SR);
+	const uint8_t *cs = p.c.strings + j * stride;
+	const uint8_t *cq = cs + p.c.SL, *rs = cs + 2 * p.c.SL, *rq = rs + p.c.SR;
+	const int ll = p.ll[c], lr = p.lr[c];
+	uint8_t *d = out_str + str_off[c];
+	for (int i = lane_id(); i < ll; i += WAVE) { d[i] = cs[ll - 1 - i]; d[ll + i] = cq[ll - 1 - i]; }
+	for (int i = lane_id(); i < lr; i += WAVE) { d[2 * ll + i] = rs[i]; d[2 * ll + lr + i] = rq[i]; }
+	const uint32_t e = p.c.c_cig_ev[j];
+	const uint32_t *src = cig_blob + p.c.ev.cig_off[e];
+	uint32_t *dc = out_cig + cig_off[c];
+	const int nc = p.ncig[c];
+	for (int i = lane_id(); i < nc; i += WAVE) dc[i] = src[i];
+}
+
+} // namespace ssv

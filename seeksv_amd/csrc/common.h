@@ -1,0 +1,69 @@
+// common.h - shared device helpers for the gfx950 kernels (64-wide wavefronts throughout).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ssv {
+
+// sam/bam.h:97-124 flag bits, :133-155 CIGAR ops
+enum : int { F_PAIRED = 1, F_PROPER = 2, F_UNMAP = 4, F_MUNMAP = 8, F_REV = 16, F_MREV = 32, F_SECONDARY = 256, F_QCFAIL = 512, F_DUP = 1024 };
+enum : int { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, C_P = 6, C_EQ = 7, C_X = 8 };
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;            // 4 waves per workgroup
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// inclusive prefix sum across the 64 lanes of a wave
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_sum(T v)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		T o = __shfl_up(v, d, 64);
+		if (lane_id() >= d) v += o;
+	}
+	return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { T o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+	return v;
+}
+
+// Exclusive prefix sum of one value per thread over a 256-thread block; *total = block sum.
+// lds must hold WAVES_PER_BLOCK + 1 elements.  Contains two barriers.
+template <typename T>
+__device__ __forceinline__ T block_exclusive_sum(T v, T *lds, T *total)
+{
+	T inc = wave_inclusive_sum(v);
+	if (lane_id() == 63) lds[wave_id()] = inc;
+	__syncthreads();
+	T base = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+		T x = lds[w];
+		if (w < wave_id()) base += x;
+		tot += x;
+	}
+	__syncthreads();
+	*total = tot;
+	return base + inc - v;
+}
+
+} // namespace ssv

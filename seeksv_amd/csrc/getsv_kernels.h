@@ -1,0 +1,355 @@
+// getsv_kernels.h - the BAM passes of `seeksv getsv` on the GPU.
+//
+// Reference behaviour being reproduced (file:line in /root/reference/seeksv):
+//   CalculateInsertsizeDeviation      cluster.cpp:15-83
+//   IsConcordant / IsHardClip         cluster.cpp:136-147, clip_reads.cpp:247-257
+//   FindDiscordantReadPairs           getsv.cpp:990-1120   (candidate set = bam_iter_query/bam_iter_read of libbam 0.1.16:
+//                                     records of tid with bam_calend > beg && pos < end; calend counts M, D, N)
+//   main_depth + read_bam             bam2depth.cpp:17-142, bam2depth.h:29-35 (pileup mask sam/bam.h:124)
+#pragma once
+
+#include "clip_kernels.h"
+#include "common.h"
+
+namespace ssv {
+
+__device__ __forceinline__ bool is_hard_clip(const DevBatch &b, int64_t i)
+{
+	int n = b.n_cigar[i];
+	if (n == 0) return false; // the reference reads cigar[-1] here (undefined); "not hard clipped" like the oracle
+	const uint32_t *cig = b.cigar + b.cigar_off[i];
+	return (cig[0] & 15u) == C_H || (cig[n - 1] & 15u) == C_H;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K4 insert-size statistics
+// ---------------------------------------------------------------------------------------------------------------------
+
+constexpr int ISZ_ITEMS = 4;
+constexpr int ISZ_TILE = BLOCK * ISZ_ITEMS;
+
+// cluster.cpp:51-67: MAPQ >= q, not hard clipped, PAIRED && PROPER_PAIR && !DUP && isize > 0
+__device__ __forceinline__ bool isize_qualifies(const DevBatch &b, int64_t i, int min_mapq)
+{
+	if ((int)b.mapq[i] < min_mapq) return false;
+	int f = b.flag[i];
+	if (!((f & F_PAIRED) && (f & F_PROPER) && !(f & F_DUP))) return false;
+	if (b.isize[i] <= 0) return false;
+	return !is_hard_clip(b, i);
+}
+
+// pass A: qualifying records per tile
+__global__ __launch_bounds__(BLOCK) void k_isize_count(DevBatch b, int min_mapq, uint32_t *__restrict__ tile_cnt)
+{
+	__shared__ uint32_t lds[WAVES_PER_BLOCK];
+	int64_t i0 = (int64_t)blockIdx.x * ISZ_TILE + (int64_t)threadIdx.x * ISZ_ITEMS;
+	uint32_t c = 0;
+#pragma unroll
+	for (int k = 0; k < ISZ_ITEMS; ++k) if (i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq)) ++c;
+	c = wave_sum(c);
+	if (lane_id() == 0) lds[wave_id()] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// pass B: the qualifying record with file-order ordinal o < max_pairs stores its isize at vals[o]
+__global__ __launch_bounds__(BLOCK) void k_isize_collect(DevBatch b, int min_mapq, const uint32_t *__restrict__ tile_base, int64_t count_before, int64_t max_pairs,
+                                                         int32_t *__restrict__ vals)
+{
+	__shared__ uint32_t lds[WAVES_PER_BLOCK + 1];
+	int64_t i0 = (int64_t)blockIdx.x * ISZ_TILE + (int64_t)threadIdx.x * ISZ_ITEMS;
+	bool q[ISZ_ITEMS];
+	uint32_t c = 0;
+#pragma unroll
+	for (int k = 0; k < ISZ_ITEMS; ++k) { q[k] = i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq); c += q[k]; }
+	uint32_t tot;
+	uint32_t ex = block_exclusive_sum(c, lds, &tot);
+	int64_t o = count_before + tile_base[blockIdx.x] + ex;
+#pragma unroll
+	for (int k = 0; k < ISZ_ITEMS; ++k) if (q[k]) { if (o < max_pairs) vals[o] = b.isize[i0 + k]; ++o; }
+}
+
+// sum of vals (mode 0) or of the int-wrapped squared deviations from mean (mode 1, cluster.cpp:77) into *acc
+__global__ __launch_bounds__(BLOCK) void k_isize_reduce(const int32_t *__restrict__ vals, int64_t n, int mode, int mean, long long *__restrict__ acc)
+{
+	__shared__ long long lds[WAVES_PER_BLOCK];
+	long long s = 0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		int x = vals[i];
+		if (mode == 0) s += x;
+		else {
+			int d = (int)((unsigned)x - (unsigned)mean);
+			s += (int)((unsigned)d * (unsigned)d);
+		}
+	}
+	s = wave_sum(s);
+	if (lane_id() == 0) lds[wave_id()] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd((unsigned long long *)acc, (unsigned long long)(lds[0] + lds[1] + lds[2] + lds[3]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K5+K7 getsv_scan: one fused pass = discordant-pair tally per junction + coverage of the depth windows
+// ---------------------------------------------------------------------------------------------------------------------
+
+constexpr int TILE_SHIFT = 9;          // genome tiles of 512 bp
+constexpr uint8_t TM_DEPTH = 1, TM_JUNC = 2;
+
+struct DevJunction { // sorted by (up_tid, beg)
+	int32_t up_tid, down_tid, up_pos, down_pos, beg, end;
+	uint8_t up_strand, down_strand;
+	uint16_t pad;
+	int32_t orig; // index in the caller's junction array
+};
+
+struct GetsvArgs {
+	DevBatch b;
+	// genome tile map: which 512-bp tiles can hold the START of a record that matters (windows are extended to the left by
+	// the longest reference span when the map is built, so one lookup per record is enough)
+	const uint8_t *tilemap;
+	const int64_t *ctg_tile_off; // [n_targets + 1]
+	int32_t n_targets;
+	// discordant
+	const DevJunction *junc;
+	int64_t n_junc;
+	int32_t junc_wmax;           // longest junction window
+	int32_t mean, sd, times, min_ins, max_ins, disc_min_mapq;
+	int32_t *counts;             // [n_junc] by orig index
+	// depth
+	const int32_t *win_tid, *win_beg, *win_end; // merged windows, 1-based inclusive, sorted, disjoint
+	const int64_t *win_off;      // [n_win + 1] offset of the window's difference array (len + 1 entries each)
+	int64_t n_win;
+	int32_t depth_min_mapq;
+	int32_t *diff;
+};
+
+// IsConcordant, cluster.cpp:136-147 (lower bound NOT clamped here)
+__device__ __forceinline__ bool is_concordant(int flag, int isize, int mean, int sd, int times)
+{
+	int lo = mean - sd * times, hi = mean + sd * times;
+	if (!(flag & F_REV) && (flag & F_MREV) && lo <= isize && isize <= hi) return true;
+	if ((flag & F_REV) && !(flag & F_MREV) && isize < 0) {
+		int a = isize < 0 ? -isize : isize;
+		return lo <= a && a <= hi;
+	}
+	return false;
+}
+
+// the strand-specific geometry of getsv.cpp:1074-1113 for one candidate read and one junction
+__device__ __forceinline__ bool discordant_geometry(const DevJunction &j, int flag, int pos, int mpos, int lq, int mtid, int min_ins, int max_ins)
+{
+	if (!(j.down_tid != -1 && j.down_tid == mtid)) return false;
+	const int K = 5; // kCrossLength, getsv.cpp:15
+	const int up = j.up_pos, down = j.down_pos;
+	if (j.up_strand == '+' && j.down_strand == '+' && pos + lq <= up + K && mpos + 1 >= down - K) {
+		if (!(flag & F_REV) && (flag & F_MREV)) {
+			int ins = up - pos + mpos + lq - down + 1;
+			if (j.up_tid == j.down_tid && up > down && up - down + 1 + 2 * lq <= max_ins) { // tandem duplication
+				while (ins <= max_ins) {
+					if (ins >= min_ins) return true;
+					ins += up - down + 1;
+				}
+				return false;
+			}
+			return min_ins <= ins && ins <= max_ins;
+		}
+		return false;
+	} else if (j.up_strand == '-' && j.down_strand == '+' && (flag & F_REV) && (flag & F_MREV) && mpos + 1 >= down - K) {
+		int ins = pos + 1 - up + 1 + mpos + lq - down + 1;
+		return min_ins <= ins && ins <= max_ins;
+	} else if (j.up_strand == '+' && j.down_strand == '-' && !(flag & F_REV) && !(flag & F_MREV) && pos + lq <= up + K && mpos + lq <= down + K) {
+		int ins = up - pos + down - (mpos + lq) + 1;
+		return min_ins <= ins && ins <= max_ins;
+	}
+	return false;
+}
+
+__device__ __forceinline__ void discordant_record(const GetsvArgs &a, int64_t i, int tid, int pos)
+{
+	const DevBatch &b = a.b;
+	if ((int)b.mapq[i] < a.disc_min_mapq) return;
+	int flag = b.flag[i];
+	if (flag & (F_DUP | F_UNMAP | F_MUNMAP)) return;
+	if (is_concordant(flag, b.isize[i], a.mean, a.sd, a.times)) return;
+	if (is_hard_clip(b, i)) return;
+	// bam_calend of libbam 0.1.16: M, D, N advance; no CIGAR -> pos + 1
+	int rend = pos;
+	{
+		int n = b.n_cigar[i];
+		if (n == 0) rend = pos + 1;
+		else {
+			const uint32_t *cig = b.cigar + b.cigar_off[i];
+			for (int k = 0; k < n; ++k) { uint32_t c = cig[k]; int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) rend += (int)(c >> 4); }
+		}
+	}
+	// junction windows that can overlap [pos, rend): beg in (pos - wmax, rend) on this contig
+	int64_t lo = 0, hi = a.n_junc;
+	const int64_t want = (int64_t)pos - a.junc_wmax;
+	while (lo < hi) {
+		int64_t m = (lo + hi) >> 1;
+		const DevJunction &j = a.junc[m];
+		if (j.up_tid < tid || (j.up_tid == tid && (int64_t)j.beg <= want)) lo = m + 1; else hi = m;
+	}
+	const int mtid = b.mtid[i], mpos = b.mpos[i], lq = b.l_qseq[i];
+	for (int64_t m = lo; m < a.n_junc; ++m) {
+		const DevJunction j = a.junc[m];
+		if (j.up_tid != tid || j.beg >= rend) break;
+		if (!(rend > j.beg && pos < j.end)) continue;
+		if (discordant_geometry(j, flag, pos, mpos, lq, mtid, a.min_ins, a.max_ins)) atomicAdd(&a.counts[j.orig], 1);
+	}
+}
+
+// first window with (tid, end) >= (tid, col); windows are disjoint and sorted so ends are sorted too
+__device__ __forceinline__ int64_t first_window_ending_at_or_after(const GetsvArgs &a, int tid, int col)
+{
+	int64_t lo = 0, hi = a.n_win;
+	while (lo < hi) {
+		int64_t m = (lo + hi) >> 1;
+		int wt = a.win_tid[m];
+		if (wt < tid || (wt == tid && a.win_end[m] < col)) lo = m + 1; else hi = m;
+	}
+	return lo;
+}
+
+__device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int tid, int pos)
+{
+	const DevBatch &b = a.b;
+	if ((int)b.mapq[i] < a.depth_min_mapq) return;                    // read_bam: MAPQ < mapQ -> treated as unmapped
+	if (b.flag[i] & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) return; // BAM_DEF_MASK
+	int n = b.n_cigar[i];
+	const uint32_t *cig = b.cigar + b.cigar_off[i];
+	int col = pos + 1; // 1-based
+	int64_t w = -1;
+	for (int k = 0; k < n; ++k) {
+		uint32_t c = cig[k];
+		int op = (int)(c & 15u), len = (int)(c >> 4);
+		if (op == C_M || op == C_EQ || op == C_X) {
+			if (len > 0) {
+				int s = col, e = col + len - 1;
+				if (w < 0) w = first_window_ending_at_or_after(a, tid, s);
+				while (w < a.n_win && a.win_tid[w] == tid && a.win_end[w] < s) ++w;
+				for (int64_t x = w; x < a.n_win && a.win_tid[x] == tid && a.win_beg[x] <= e; ++x) {
+					int wb = a.win_beg[x], we = a.win_end[x];
+					int lo = s > wb ? s : wb, hi = e < we ? e : we;
+					int32_t *d = a.diff + a.win_off[x];
+					atomicAdd(&d[lo - wb], 1);
+					atomicAdd(&d[hi + 1 - wb], -1);
+				}
+			}
+			col += len;
+		} else if (op == C_D || op == C_N) col += len;
+	}
+}
+
+constexpr int GS_ITEMS = 4;
+constexpr int GS_TILE = BLOCK * GS_ITEMS;
+
+// Streams tid and pos of every record (8 B/record) and looks the record's start tile up in the genome tile map (L2 resident,
+// wave-coherent because the BAM is coordinate sorted).  Only records that start near a depth window / junction window - a few
+// per cent - take the slow paths, which load the remaining fields lazily.
+__global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, int64_t ntiles)
+{
+	const DevBatch &b = a.b;
+	for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const int64_t i0 = tile * GS_TILE + (int64_t)threadIdx.x * GS_ITEMS;
+		int tid[GS_ITEMS], pos[GS_ITEMS];
+		if (i0 + GS_ITEMS <= b.n) {
+			int4 t4 = *reinterpret_cast<const int4 *>(b.tid + i0);
+			int4 p4 = *reinterpret_cast<const int4 *>(b.pos + i0);
+			tid[0] = t4.x; tid[1] = t4.y; tid[2] = t4.z; tid[3] = t4.w;
+			pos[0] = p4.x; pos[1] = p4.y; pos[2] = p4.z; pos[3] = p4.w;
+		} else {
+#pragma unroll
+			for (int k = 0; k < GS_ITEMS; ++k) {
+				bool in = i0 + k < b.n;
+				tid[k] = in ? b.tid[i0 + k] : -1;
+				pos[k] = in ? b.pos[i0 + k] : 0;
+			}
+		}
+		uint8_t m[GS_ITEMS];
+#pragma unroll
+		for (int k = 0; k < GS_ITEMS; ++k) {
+			m[k] = 0;
+			if (tid[k] >= 0 && tid[k] < a.n_targets && pos[k] >= 0) {
+				int64_t t = a.ctg_tile_off[tid[k]] + (pos[k] >> TILE_SHIFT);
+				if (t < a.ctg_tile_off[tid[k] + 1]) m[k] = a.tilemap[t];
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < GS_ITEMS; ++k) {
+			if (m[k] & TM_JUNC) discordant_record(a, i0 + k, tid[k], pos[k]);
+			if (m[k] & TM_DEPTH) depth_record(a, i0 + k, tid[k], pos[k]);
+		}
+	}
+}
+
+// K8: per window, running sum of the difference array -> per-column depth (in place); one wavefront per window
+__global__ __launch_bounds__(BLOCK) void k_depth_prefix(const int64_t *__restrict__ win_off, int64_t n_win, int32_t *__restrict__ diff, int32_t *__restrict__ max_depth)
+{
+	int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (w >= n_win) return;
+	int32_t *d = diff + win_off[w];
+	const int64_t len = win_off[w + 1] - win_off[w] - 1; // columns (the extra slot absorbs the closing -1)
+	int32_t carry = 0, mx = 0;
+	for (int64_t base = 0; base < len; base += WAVE) {
+		int64_t i = base + lane_id();
+		int32_t v = i < len ? d[i] : 0;
+		int32_t inc = wave_inclusive_sum(v) + carry;
+		if (i < len) { d[i] = inc; mx = inc > mx ? inc : mx; }
+		carry = __shfl(inc, 63, 64);
+	}
+	mx = wave_max(mx);
+	if (lane_id() == 0 && mx > 0) atomicMax(max_depth, mx);
+}
+
+// one wavefront per query range: sum of depth over [beg, end] (the range lies inside one window)
+__global__ __launch_bounds__(BLOCK) void k_range_sum(const int32_t *__restrict__ win_tid, const int32_t *__restrict__ win_beg, const int32_t *__restrict__ win_end,
+                                                     const int64_t *__restrict__ win_off, int64_t n_win, const int32_t *__restrict__ depth,
+                                                     const int32_t *__restrict__ q_tid, const int32_t *__restrict__ q_beg, const int32_t *__restrict__ q_end, int64_t n_q,
+                                                     unsigned long long *__restrict__ out)
+{
+	int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (r >= n_q) return;
+	const int tid = q_tid[r], beg = q_beg[r], end = q_end[r];
+	// last window with (tid, beg) <= (tid, q.beg)
+	int64_t lo = 0, hi = n_win;
+	while (lo < hi) {
+		int64_t m = (lo + hi) >> 1;
+		int wt = win_tid[m];
+		if (wt < tid || (wt == tid && win_beg[m] <= beg)) lo = m + 1; else hi = m;
+	}
+	unsigned long long s = 0;
+	if (lo > 0) {
+		int64_t w = lo - 1;
+		if (win_tid[w] == tid && beg <= win_end[w]) {
+			int e = end < win_end[w] ? end : win_end[w];
+			const int32_t *d = depth + win_off[w] - win_beg[w];
+			for (int64_t c = (int64_t)beg + lane_id(); c <= e; c += WAVE) s += (unsigned long long)(uint32_t)d[c];
+		}
+	}
+	s = wave_sum(s);
+	if (lane_id() == 0) out[r] = s;
+}
+
+__global__ void k_point_depth(const int32_t *__restrict__ win_tid, const int32_t *__restrict__ win_beg, const int32_t *__restrict__ win_end,
+                              const int64_t *__restrict__ win_off, int64_t n_win, const int32_t *__restrict__ depth,
+                              const int32_t *__restrict__ q_tid, const int32_t *__restrict__ q_pos, int64_t n_q, int32_t *__restrict__ out)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_q) return;
+	const int tid = q_tid[r], c = q_pos[r];
+	int64_t lo = 0, hi = n_win;
+	while (lo < hi) {
+		int64_t m = (lo + hi) >> 1;
+		int wt = win_tid[m];
+		if (wt < tid || (wt == tid && win_beg[m] <= c)) lo = m + 1; else hi = m;
+	}
+	int v = 0;
+	if (lo > 0) {
+		int64_t w = lo - 1;
+		if (win_tid[w] == tid && c <= win_end[w]) v = depth[win_off[w] + (c - win_beg[w])];
+	}
+	out[r] = v;
+}
+
+} // namespace ssv

@@ -1,0 +1,779 @@
+// seeksv_hip.hip - context, memory management and the C ABI (include/seeksv_hip.h) over the gfx950 kernels.
+// One context = one GPU = one HIP stream.  No CPU fallback: every entry point needs a live device.
+#include "seeksv_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "clip_kernels.h"
+#include "common.h"
+#include "getsv_kernels.h"
+#include "radix_sort.h"
+#include "scan.h"
+
+using namespace ssv;
+
+namespace {
+
+std::string g_create_error;
+
+// timed kernel groups (ssv_prof_*)
+enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_ISIZE, P_GETSV_SCAN, P_DEPTH_FINISH, P_COUNT };
+const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "isize_stats", "getsv_scan", "depth_finish"};
+const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\nisize_stats\ngetsv_scan\ndepth_finish";
+
+struct DBuf { // grow-only device buffer
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct HBuf { // grow-only pinned host buffer
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct ProfRec {
+	int id;
+	hipEvent_t a, b;
+	int64_t units;
+};
+
+} // namespace
+
+struct ssv_ctx {
+	int device = 0;
+	hipStream_t st = nullptr;
+	std::string err;
+
+	// staging of host batches
+	DBuf sb[14];
+
+	// scratch shared by the passes
+	DBuf tile_cnt, tile_off, tile_base, scan_scratch, scan_scratch64, counters;
+	HBuf h_counters;
+
+	// ---- getclip ----
+	bool clip_active = false;
+	ssv_clip_params clip_p{};
+	DBuf d_last_tid, stage;
+	int64_t stage_cap = 0;
+	DBuf ev_key, ev_begin, ev_ll, ev_lr, ev_lq, ev_ncig, ev_seq_bytes, ev_seq_off, ev_cig_off, ev_src_seq, ev_src_cig;
+	int64_t ev_cap = 0, n_events = 0;
+	DBuf seq_blob, cig_blob;
+	uint64_t seq_used = 0, cig_used = 0;
+	uint64_t max_key = 0;
+	int max_ll = 0, max_lr = 0;
+	// clustering temporaries / outputs
+	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_strings, c_flag, c_idx;
+	DBuf o_tid, o_pos, o_side, o_support, o_ll, o_lr, o_qmiss, o_slot, o_strbytes, o_ncig64, o_ncig, o_stroff, o_cigoff, o_str, o_cig, totals;
+	HBuf h_tid, h_pos, h_side, h_support, h_ll, h_lr, h_qmiss, h_stroff, h_cigoff, h_ncig, h_str, h_cig, h_totals;
+
+	// ---- isize ----
+	bool isz_active = false;
+	int isz_min_mapq = 0;
+	int64_t isz_max = 0, isz_count = 0;
+	DBuf isz_vals, isz_acc;
+
+	// ---- getsv ----
+	bool gs_active = false;
+	ssv_getsv_params gs_p{};
+	std::vector<DevJunction> gs_junc;
+	std::vector<ssv_interval> gs_win;
+	std::vector<int32_t> gs_tlen;
+	std::vector<int64_t> gs_ctg_tile_off;
+	std::vector<uint8_t> gs_tilemap_host;
+	int32_t gs_map_span = -1;
+	int32_t gs_wmax = 0;
+	int64_t gs_diff_len = 0;
+	DBuf gs_djunc, gs_counts, gs_wtid, gs_wbeg, gs_wend, gs_woff, gs_diff, gs_tilemap, gs_ctgoff, gs_maxdepth, gs_span;
+	DBuf q_tid, q_beg, q_end, q_out64, q_out32;
+	HBuf h_q;
+
+	// ---- profiling ----
+	int prof_mode = 0;
+	std::vector<ProfRec> prof_recs;
+	std::vector<hipEvent_t> prof_pool;
+	double prof_ms[P_COUNT] = {0};
+	int64_t prof_launches[P_COUNT] = {0};
+	int64_t prof_units[P_COUNT] = {0};
+};
+
+namespace {
+
+#define HIPCHECK(ctx, call)                                                                              \
+	do {                                                                                                   \
+		hipError_t e_ = (call);                                                                              \
+		if (e_ != hipSuccess) {                                                                              \
+			(ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                    \
+			return e_ == hipErrorOutOfMemory ? SSV_E_NOMEM : SSV_E_HIP;                                        \
+		}                                                                                                    \
+	} while (0)
+
+#define CHECK(expr)          \
+	do {                       \
+		int rc_ = (expr);        \
+		if (rc_ != SSV_OK) return rc_; \
+	} while (0)
+
+int ensure(ssv_ctx *c, DBuf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0)
+{
+	if (bytes <= b.cap) return SSV_OK;
+	size_t ncap = std::max(bytes, b.cap + b.cap / 2);
+	ncap = (ncap + 255) & ~(size_t)255;
+	void *np = nullptr;
+	HIPCHECK(c, hipMalloc(&np, ncap));
+	if (keep && b.p && keep_bytes) {
+		HIPCHECK(c, hipMemcpyAsync(np, b.p, keep_bytes, hipMemcpyDeviceToDevice, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+	}
+	if (b.p) {
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+		HIPCHECK(c, hipFree(b.p));
+	}
+	b.p = np; b.cap = ncap;
+	return SSV_OK;
+}
+
+int ensure_host(ssv_ctx *c, HBuf &b, size_t bytes)
+{
+	if (bytes <= b.cap) return SSV_OK;
+	if (b.p) HIPCHECK(c, hipHostFree(b.p));
+	size_t ncap = (std::max(bytes, b.cap + b.cap / 2) + 255) & ~(size_t)255;
+	b.p = nullptr; b.cap = 0;
+	HIPCHECK(c, hipHostMalloc(&b.p, ncap, hipHostMallocDefault));
+	b.cap = ncap;
+	return SSV_OK;
+}
+
+template <typename T> T *P(DBuf &b) { return reinterpret_cast<T *>(b.p); }
+template <typename T> T *P(HBuf &b) { return reinterpret_cast<T *>(b.p); }
+
+struct ProfScope {
+	ssv_ctx *c;
+	int id;
+	bool on;
+	hipEvent_t a{}, b{};
+	int64_t units;
+	ProfScope(ssv_ctx *ctx, int id_, int64_t units_) : c(ctx), id(id_), units(units_)
+	{
+		on = c->prof_mode == 1 || (c->prof_mode == 2 && (id == P_CLIP_SCAN || id == P_GETSV_SCAN));
+		if (!on) return;
+		for (hipEvent_t *e : {&a, &b}) {
+			if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+			else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
+		}
+		(void)hipEventRecord(a, c->st);
+	}
+	~ProfScope()
+	{
+		if (!on) return;
+		(void)hipEventRecord(b, c->st);
+		c->prof_recs.push_back({id, a, b, units});
+	}
+};
+
+void prof_collect(ssv_ctx *c)
+{
+	if (c->prof_recs.empty()) return;
+	(void)hipStreamSynchronize(c->st);
+	for (ProfRec &r : c->prof_recs) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+			c->prof_ms[r.id] += ms; c->prof_launches[r.id] += 1; c->prof_units[r.id] += r.units;
+		}
+		c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
+	}
+	c->prof_recs.clear();
+}
+
+inline unsigned grid_for(int64_t n, int per_block) { return (unsigned)std::max<int64_t>(1, (n + per_block - 1) / per_block); }
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Make the batch visible to the kernels: device batches are used in place, host batches are copied to HBM.
+int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
+{
+	if (!b || b->n < 0 || b->n >= (1ll << 31)) { c->err = "bad batch"; return SSV_E_ARG; }
+	if (b->n > 0 && (!b->tid || !b->pos || !b->flag || !b->mapq || !b->n_cigar || !b->l_qseq || !b->mtid || !b->mpos || !b->isize || !b->cigar_off || !b->seq_off)) {
+		c->err = "batch with null arrays"; return SSV_E_ARG;
+	}
+	d.n = b->n; d.max_ref_span = b->max_ref_span;
+	if (b->mem == SSV_MEM_DEVICE) {
+		if (!aligned16(b->tid) || !aligned16(b->pos) || !aligned16(b->n_cigar) || !aligned16(b->cigar_off)) { c->err = "device batch arrays must be 16-byte aligned"; return SSV_E_ARG; }
+		d.tid = b->tid; d.pos = b->pos; d.flag = b->flag; d.mapq = b->mapq; d.n_cigar = b->n_cigar; d.l_qseq = b->l_qseq; d.mtid = b->mtid; d.mpos = b->mpos;
+		d.isize = b->isize; d.cigar_off = b->cigar_off; d.cigar = b->cigar; d.xc = b->xc; d.seq_off = b->seq_off; d.seqqual = b->seqqual;
+		return SSV_OK;
+	}
+	if (b->mem != SSV_MEM_HOST) { c->err = "bad batch.mem"; return SSV_E_ARG; }
+	ProfScope ps(c, P_H2D, b->n);
+	const size_t n = (size_t)b->n;
+	struct { const void *src; size_t bytes; } f[14] = {
+		{b->tid, n * 4}, {b->pos, n * 4}, {b->flag, n * 2}, {b->mapq, n}, {b->n_cigar, n * 2}, {b->l_qseq, n * 4}, {b->mtid, n * 4}, {b->mpos, n * 4},
+		{b->isize, n * 4}, {b->cigar_off, n * 4}, {b->cigar, (size_t)b->n_cigar_total * 4}, {b->xc, b->xc ? n : 0}, {b->seq_off, n * 8}, {b->seqqual, (size_t)b->seqqual_bytes}};
+	for (int k = 0; k < 14; ++k) {
+		CHECK(ensure(c, c->sb[k], f[k].bytes + 16));
+		if (f[k].bytes && f[k].src) HIPCHECK(c, hipMemcpyAsync(c->sb[k].p, f[k].src, f[k].bytes, hipMemcpyHostToDevice, c->st));
+	}
+	d.tid = P<int32_t>(c->sb[0]); d.pos = P<int32_t>(c->sb[1]); d.flag = P<uint16_t>(c->sb[2]); d.mapq = P<uint8_t>(c->sb[3]); d.n_cigar = P<uint16_t>(c->sb[4]);
+	d.l_qseq = P<int32_t>(c->sb[5]); d.mtid = P<int32_t>(c->sb[6]); d.mpos = P<int32_t>(c->sb[7]); d.isize = P<int32_t>(c->sb[8]);
+	d.cigar_off = P<uint32_t>(c->sb[9]); d.cigar = P<uint32_t>(c->sb[10]); d.xc = b->xc ? P<uint8_t>(c->sb[11]) : nullptr;
+	d.seq_off = P<uint64_t>(c->sb[12]); d.seqqual = P<uint8_t>(c->sb[13]);
+	return SSV_OK;
+}
+
+int ensure_events(ssv_ctx *c, int64_t need)
+{
+	if (need <= c->ev_cap) return SSV_OK;
+	int64_t ncap = std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2);
+	ncap = std::max<int64_t>(ncap, 1 << 16);
+	const size_t used = (size_t)c->n_events;
+	CHECK(ensure(c, c->ev_key, ncap * 8, true, used * 8));
+	CHECK(ensure(c, c->ev_begin, ncap * 4, true, used * 4));
+	CHECK(ensure(c, c->ev_ll, ncap * 4, true, used * 4));
+	CHECK(ensure(c, c->ev_lr, ncap * 4, true, used * 4));
+	CHECK(ensure(c, c->ev_lq, ncap * 4, true, used * 4));
+	CHECK(ensure(c, c->ev_ncig, ncap * 4, true, used * 4));
+	CHECK(ensure(c, c->ev_seq_bytes, ncap * 4, true, used * 4));
+	CHECK(ensure(c, c->ev_seq_off, ncap * 8, true, used * 8));
+	CHECK(ensure(c, c->ev_cig_off, ncap * 8, true, used * 8));
+	CHECK(ensure(c, c->ev_src_seq, ncap * 8));
+	CHECK(ensure(c, c->ev_src_cig, ncap * 4));
+	c->ev_cap = ncap;
+	return SSV_OK;
+}
+
+EventArrays event_arrays(ssv_ctx *c)
+{
+	EventArrays e;
+	e.key = P<uint64_t>(c->ev_key); e.begin = P<int32_t>(c->ev_begin); e.ll = P<int32_t>(c->ev_ll); e.lr = P<int32_t>(c->ev_lr); e.lq = P<int32_t>(c->ev_lq);
+	e.ncig = P<uint32_t>(c->ev_ncig); e.seq_bytes = P<uint32_t>(c->ev_seq_bytes); e.seq_off = P<uint64_t>(c->ev_seq_off); e.cig_off = P<uint64_t>(c->ev_cig_off);
+	e.src_seq = P<uint64_t>(c->ev_src_seq); e.src_cig = P<uint32_t>(c->ev_src_cig);
+	return e;
+}
+
+__global__ void k_max_span(DevBatch b, int *out)
+{
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int span = 0;
+	if (i < b.n) {
+		int n = b.n_cigar[i];
+		const uint32_t *cig = b.cigar + b.cigar_off[i];
+		long long s = 0;
+		for (int k = 0; k < n; ++k) { uint32_t x = cig[k]; int op = (int)(x & 15u); if (op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) s += x >> 4; }
+		span = s > 0x7fffffff ? 0x7fffffff : (int)s;
+	}
+	span = wave_max(span);
+	if (lane_id() == 0 && span > 0) atomicMax(out, span);
+}
+
+} // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+int ssv_abi_version(void) { return SSV_ABI_VERSION; }
+
+int ssv_ctx_create(int device, ssv_ctx **out)
+{
+	if (!out) return SSV_E_ARG;
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0) {
+		g_create_error = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") + "); libseeksv_hip has no CPU path";
+		return SSV_E_NODEVICE;
+	}
+	if (device < 0 || device >= ndev) { g_create_error = "device ordinal out of range"; return SSV_E_ARG; }
+	if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return SSV_E_NODEVICE; }
+	ssv_ctx *c = new ssv_ctx();
+	c->device = device;
+	if ((e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return SSV_E_NODEVICE; }
+	*out = c;
+	return SSV_OK;
+}
+
+void ssv_ctx_destroy(ssv_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->st);
+	// every DBuf / HBuf member
+	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->ev_key, &c->ev_begin, &c->ev_ll,
+	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_tid,
+	                 &c->o_pos, &c->o_side, &c->o_support, &c->o_ll, &c->o_lr, &c->o_qmiss, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_ncig, &c->o_stroff, &c->o_cigoff, &c->o_str,
+	                 &c->o_cig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap,
+	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
+	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
+	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
+	HBuf *hbufs[] = {&c->h_counters, &c->h_tid, &c->h_pos, &c->h_side, &c->h_support, &c->h_ll, &c->h_lr, &c->h_qmiss, &c->h_stroff, &c->h_cigoff, &c->h_ncig, &c->h_str, &c->h_cig,
+	                 &c->h_totals, &c->h_q};
+	for (HBuf *b : hbufs) if (b->p) (void)hipHostFree(b->p);
+	for (ProfRec &r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+	for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
+	(void)hipStreamDestroy(c->st);
+	delete c;
+}
+
+int ssv_sync(ssv_ctx *c)
+{
+	if (!c) return SSV_E_ARG;
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	return SSV_OK;
+}
+
+const char *ssv_last_error(const ssv_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+void *ssv_stream(ssv_ctx *c) { return c ? (void *)c->st : nullptr; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// getclip
+// ---------------------------------------------------------------------------------------------------------------------
+
+int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
+{
+	if (!c || !p) return SSV_E_ARG;
+	HIPCHECK(c, hipSetDevice(c->device));
+	c->clip_p = *p;
+	c->clip_active = true;
+	c->n_events = 0; c->seq_used = 0; c->cig_used = 0; c->max_key = 0; c->max_ll = 0; c->max_lr = 0;
+	CHECK(ensure(c, c->d_last_tid, 16));
+	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
+	CHECK(ensure_host(c, c->h_counters, sizeof(ClipCounters)));
+	HIPCHECK(c, hipMemsetAsync(c->d_last_tid.p, 0, 16, c->st)); // last_tid = 0, clip_reads.h:407
+	return SSV_OK;
+}
+
+int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
+{
+	if (!c || !b) return SSV_E_ARG;
+	if (!c->clip_active) { c->err = "ssv_clip_scan before ssv_clip_begin"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	if (b->n == 0) return SSV_OK;
+	DevBatch d;
+	CHECK(stage_batch(c, b, d));
+	if (!d.cigar || !d.seq_off) { c->err = "batch without cigar / seq_off"; return SSV_E_ARG; }
+	const int64_t ntiles = (d.n + CLIP_TILE - 1) / CLIP_TILE;
+	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
+	CHECK(ensure(c, c->tile_off, ntiles * 4));
+	CHECK(ensure(c, c->tile_base, ntiles * 4));
+	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(std::max<int64_t>(ntiles, 1)) * 4));
+	if (c->stage_cap == 0) c->stage_cap = std::max<int64_t>(1 << 16, d.n / 16);
+	ClipCounters *hc = P<ClipCounters>(c->h_counters);
+	for (int attempt = 0;; ++attempt) {
+		CHECK(ensure(c, c->stage, (size_t)c->stage_cap * sizeof(StagedEvent)));
+		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
+		ClipScanArgs a;
+		a.b = d; a.min_mapq = c->clip_p.min_mapq; a.save_low_quality = c->clip_p.save_low_quality; a.last_tid_in = P<int>(c->d_last_tid);
+		a.tile_cnt = P<uint32_t>(c->tile_cnt); a.tile_off = P<uint32_t>(c->tile_off); a.stage = P<StagedEvent>(c->stage); a.stage_cap = c->stage_cap;
+		a.ctr = P<ClipCounters>(c->counters); a.ntiles = ntiles;
+		{
+			ProfScope ps(c, P_CLIP_SCAN, d.n);
+			unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * 8);
+			k_clip_scan<<<grid, BLOCK, 0, c->st>>>(a);
+		}
+		HIPCHECK(c, hipGetLastError());
+		HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+		if (!hc->overflow) break;
+		if (attempt > 2) { c->err = "clip staging overflow"; return SSV_E_HIP; }
+		c->stage_cap = (int64_t)hc->stage_cursor + 1024; // the cursor kept counting: this is the exact need
+	}
+	const int64_t nb = (int64_t)hc->stage_cursor;
+	if (nb > 0) {
+		ProfScope ps(c, P_CLIP_PLACE, nb);
+		CHECK(ensure_events(c, c->n_events + nb));
+		exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_base), ntiles, 0u, P<uint32_t>(c->scan_scratch), nullptr);
+		EventArrays ev = event_arrays(c);
+		k_clip_place<<<grid_for(nb, BLOCK), BLOCK, 0, c->st>>>(P<StagedEvent>(c->stage), nb, P<uint32_t>(c->tile_base), P<uint32_t>(c->tile_off), d, ev, c->n_events);
+		CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nb) * 8));
+		exclusive_scan<uint32_t, uint64_t>(c->st, ev.seq_bytes + c->n_events, ev.seq_off + c->n_events, nb, c->seq_used, P<uint64_t>(c->scan_scratch64), nullptr);
+		exclusive_scan<uint32_t, uint64_t>(c->st, ev.ncig + c->n_events, ev.cig_off + c->n_events, nb, c->cig_used, P<uint64_t>(c->scan_scratch64), nullptr);
+		HIPCHECK(c, hipGetLastError());
+	}
+	if (nb > 0) {
+		ProfScope ps(c, P_CLIP_GATHER, nb);
+		CHECK(ensure(c, c->seq_blob, c->seq_used + hc->seq_bytes + 16, true, c->seq_used));
+		CHECK(ensure(c, c->cig_blob, (c->cig_used + hc->cig_ops) * 4 + 16, true, c->cig_used * 4));
+		k_clip_gather<<<grid_for(nb, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob));
+		HIPCHECK(c, hipGetLastError());
+	}
+	k_last_tid<<<1, BLOCK, 0, c->st>>>(d, P<int>(c->d_last_tid));
+	HIPCHECK(c, hipGetLastError());
+	c->n_events += nb; c->seq_used += hc->seq_bytes; c->cig_used += hc->cig_ops;
+	c->max_key = std::max<uint64_t>(c->max_key, hc->max_key); c->max_ll = std::max(c->max_ll, hc->max_ll); c->max_lr = std::max(c->max_lr, hc->max_lr);
+	return SSV_OK;
+}
+
+int ssv_clip_event_count(ssv_ctx *c, int64_t *n)
+{
+	if (!c || !n) return SSV_E_ARG;
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	*n = c->n_events;
+	return SSV_OK;
+}
+
+int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
+{
+	if (!c || !out) return SSV_E_ARG;
+	if (!c->clip_active) { c->err = "ssv_clip_cluster before ssv_clip_begin"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	memset(out, 0, sizeof(*out));
+	const int64_t E = c->n_events;
+	out->n_events = E;
+	if (E == 0) { HIPCHECK(c, hipStreamSynchronize(c->st)); return SSV_OK; }
+	EventArrays ev = event_arrays(c);
+	// ---- bin the events: stable sort by (contig, side, position) ----
+	int cur = 0;
+	{
+		ProfScope ps(c, P_SORT, E);
+		for (int k = 0; k < 2; ++k) { CHECK(ensure(c, c->keys2[k], E * 8)); CHECK(ensure(c, c->vals2[k], E * 4)); }
+		const int64_t nt = rs_tiles(E);
+		CHECK(ensure(c, c->ghist, 256 * nt * 4));
+		CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(256 * nt) * 4));
+		HIPCHECK(c, hipMemcpyAsync(c->keys2[0].p, ev.key, E * 8, hipMemcpyDeviceToDevice, c->st));
+		k_iota<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(P<uint32_t>(c->vals2[0]), E);
+		int key_bits = 1;
+		while (key_bits < 64 && (c->max_key >> key_bits)) ++key_bits;
+		uint64_t *keys[2] = {P<uint64_t>(c->keys2[0]), P<uint64_t>(c->keys2[1])};
+		uint32_t *vals[2] = {P<uint32_t>(c->vals2[0]), P<uint32_t>(c->vals2[1])};
+		cur = radix_sort_pairs(c->st, keys, vals, E, key_bits, P<uint32_t>(c->ghist), P<uint32_t>(c->scan_scratch));
+		HIPCHECK(c, hipGetLastError());
+	}
+	// ---- greedy consensus clustering, one wavefront per bin ----
+	ClusterArgs ca;
+	ca.skey = P<uint64_t>(c->keys2[cur]); ca.perm = P<uint32_t>(c->vals2[cur]); ca.E = E; ca.ev = ev; ca.seq_blob = P<uint8_t>(c->seq_blob);
+	ca.match_rate = c->clip_p.match_rate;
+	ca.SL = std::max(1, c->max_ll); ca.SR = std::max(1, c->max_lr);
+	const size_t stride = 2 * ((size_t)ca.SL + (size_t)ca.SR);
+	{
+		ProfScope ps(c, P_CLUSTER_BINS, E);
+		CHECK(ensure(c, c->c_support, E * 4)); CHECK(ensure(c, c->c_ll, E * 4)); CHECK(ensure(c, c->c_lr, E * 4)); CHECK(ensure(c, c->c_cig_ev, E * 4));
+		CHECK(ensure(c, c->c_qmiss, E)); CHECK(ensure(c, c->c_strings, (size_t)E * stride));
+		HIPCHECK(c, hipMemsetAsync(c->c_support.p, 0, E * 4, c->st));
+		ca.support = P<int32_t>(c->c_support); ca.c_ll = P<int32_t>(c->c_ll); ca.c_lr = P<int32_t>(c->c_lr); ca.c_cig_ev = P<uint32_t>(c->c_cig_ev);
+		ca.c_qmiss = P<uint8_t>(c->c_qmiss); ca.strings = P<uint8_t>(c->c_strings);
+		k_cluster_bins<<<grid_for(E, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
+		HIPCHECK(c, hipGetLastError());
+	}
+	// ---- compact the clusters into a dense table ----
+	ProfScope ps(c, P_CLUSTER_PACK, E);
+	CHECK(ensure(c, c->c_flag, E * 4)); CHECK(ensure(c, c->c_idx, E * 4));
+	CHECK(ensure(c, c->totals, 64)); CHECK(ensure_host(c, c->h_totals, 64));
+	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(E) * 4));
+	k_cluster_flags<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.support, E, P<uint32_t>(c->c_flag));
+	exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_flag), P<uint32_t>(c->c_idx), E, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	const int64_t nc = *P<uint32_t>(c->h_totals);
+	out->n_clusters = nc;
+	if (nc == 0) return SSV_OK;
+	DBuf *d4[] = {&c->o_tid, &c->o_pos, &c->o_support, &c->o_ll, &c->o_lr, &c->o_slot, &c->o_ncig};
+	for (DBuf *b : d4) CHECK(ensure(c, *b, nc * 4));
+	CHECK(ensure(c, c->o_side, nc)); CHECK(ensure(c, c->o_qmiss, nc));
+	DBuf *d8[] = {&c->o_strbytes, &c->o_ncig64, &c->o_stroff, &c->o_cigoff};
+	for (DBuf *b : d8) CHECK(ensure(c, *b, nc * 8));
+	PackArgs pa;
+	pa.c = ca; pa.flag = P<uint32_t>(c->c_flag); pa.cidx = P<uint32_t>(c->c_idx);
+	pa.tid = P<int32_t>(c->o_tid); pa.pos = P<int32_t>(c->o_pos); pa.side = P<uint8_t>(c->o_side); pa.support = P<int32_t>(c->o_support); pa.ll = P<int32_t>(c->o_ll);
+	pa.lr = P<int32_t>(c->o_lr); pa.qmiss = P<uint8_t>(c->o_qmiss); pa.slot = P<uint32_t>(c->o_slot); pa.str_bytes = P<uint64_t>(c->o_strbytes);
+	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(c->o_ncig);
+	k_cluster_pack_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
+	CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nc) * 8));
+	uint64_t *tot = P<uint64_t>(c->totals);
+	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_strbytes), P<uint64_t>(c->o_stroff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
+	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_ncig64), P<uint64_t>(c->o_cigoff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 2);
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 32, hipMemcpyDeviceToHost, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	const uint64_t str_total = P<uint64_t>(c->h_totals)[1], cig_total = P<uint64_t>(c->h_totals)[2];
+	CHECK(ensure(c, c->o_str, str_total + 16)); CHECK(ensure(c, c->o_cig, cig_total * 4 + 16));
+	k_cluster_pack_strings<<<grid_for(nc, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(c->o_stroff), P<uint64_t>(c->o_cigoff), P<uint32_t>(c->cig_blob),
+	                                                                          P<uint8_t>(c->o_str), P<uint32_t>(c->o_cig));
+	HIPCHECK(c, hipGetLastError());
+	struct { HBuf *h; DBuf *d; size_t bytes; } cp[] = {
+		{&c->h_tid, &c->o_tid, (size_t)nc * 4}, {&c->h_pos, &c->o_pos, (size_t)nc * 4}, {&c->h_side, &c->o_side, (size_t)nc}, {&c->h_support, &c->o_support, (size_t)nc * 4},
+		{&c->h_ll, &c->o_ll, (size_t)nc * 4}, {&c->h_lr, &c->o_lr, (size_t)nc * 4}, {&c->h_qmiss, &c->o_qmiss, (size_t)nc}, {&c->h_stroff, &c->o_stroff, (size_t)nc * 8},
+		{&c->h_cigoff, &c->o_cigoff, (size_t)nc * 8}, {&c->h_ncig, &c->o_ncig, (size_t)nc * 4}, {&c->h_str, &c->o_str, (size_t)str_total}, {&c->h_cig, &c->o_cig, (size_t)cig_total * 4}};
+	for (auto &x : cp) {
+		CHECK(ensure_host(c, *x.h, x.bytes + 16));
+		if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st));
+	}
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	out->tid = P<int32_t>(c->h_tid); out->pos = P<int32_t>(c->h_pos); out->side = P<uint8_t>(c->h_side); out->support = P<int32_t>(c->h_support);
+	out->left_len = P<int32_t>(c->h_ll); out->right_len = P<int32_t>(c->h_lr); out->qual_missing = P<uint8_t>(c->h_qmiss); out->str_off = P<uint64_t>(c->h_stroff);
+	out->str = P<uint8_t>(c->h_str); out->cigar_off = P<uint64_t>(c->h_cigoff); out->n_cigar = P<int32_t>(c->h_ncig); out->cigar = P<uint32_t>(c->h_cig);
+	return SSV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// insert-size statistics
+// ---------------------------------------------------------------------------------------------------------------------
+
+int ssv_isize_begin(ssv_ctx *c, int32_t min_mapq, int64_t max_pairs)
+{
+	if (!c) return SSV_E_ARG;
+	HIPCHECK(c, hipSetDevice(c->device));
+	c->isz_active = true; c->isz_min_mapq = min_mapq; c->isz_max = max_pairs; c->isz_count = 0;
+	return SSV_OK;
+}
+
+int ssv_isize_accumulate(ssv_ctx *c, const ssv_batch_t *b, int32_t *done)
+{
+	if (!c || !b) return SSV_E_ARG;
+	if (!c->isz_active) { c->err = "ssv_isize_accumulate before ssv_isize_begin"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	// the reference tests `read_pair_number == read_pair_used` after every record (cluster.cpp:68): with max_pairs == 0 it stops at once
+	if (c->isz_count >= c->isz_max || b->n == 0) { if (done) *done = c->isz_count >= c->isz_max; return SSV_OK; }
+	DevBatch d;
+	CHECK(stage_batch(c, b, d));
+	ProfScope ps(c, P_ISIZE, d.n);
+	const int64_t ntiles = (d.n + ISZ_TILE - 1) / ISZ_TILE;
+	CHECK(ensure(c, c->tile_cnt, ntiles * 4)); CHECK(ensure(c, c->tile_base, ntiles * 4));
+	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(ntiles) * 4));
+	CHECK(ensure(c, c->totals, 64)); CHECK(ensure_host(c, c->h_totals, 64));
+	const int64_t need = std::min<int64_t>(c->isz_max, c->isz_count + d.n);
+	CHECK(ensure(c, c->isz_vals, (size_t)need * 4 + 16, true, (size_t)c->isz_count * 4));
+	k_isize_count<<<(unsigned)ntiles, BLOCK, 0, c->st>>>(d, c->isz_min_mapq, P<uint32_t>(c->tile_cnt));
+	exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_base), ntiles, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
+	k_isize_collect<<<(unsigned)ntiles, BLOCK, 0, c->st>>>(d, c->isz_min_mapq, P<uint32_t>(c->tile_base), c->isz_count, c->isz_max, P<int32_t>(c->isz_vals));
+	HIPCHECK(c, hipGetLastError());
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	c->isz_count = std::min<int64_t>(c->isz_max, c->isz_count + *P<uint32_t>(c->h_totals));
+	if (done) *done = c->isz_count >= c->isz_max;
+	return SSV_OK;
+}
+
+int ssv_isize_finish(ssv_ctx *c, int64_t *n_pairs, int32_t *mean, int32_t *sd)
+{
+	if (!c || !n_pairs || !mean || !sd) return SSV_E_ARG;
+	if (!c->isz_active) { c->err = "ssv_isize_finish before ssv_isize_begin"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	c->isz_active = false;
+	const int64_t n = c->isz_count;
+	*n_pairs = n;
+	if (n == 0) { HIPCHECK(c, hipStreamSynchronize(c->st)); return SSV_OK; } // cluster.cpp:71: mean / sd untouched
+	ProfScope ps(c, P_ISIZE, 0);
+	CHECK(ensure(c, c->isz_acc, 16)); CHECK(ensure_host(c, c->h_totals, 64));
+	long long *acc = P<long long>(c->isz_acc);
+	unsigned grid = (unsigned)std::min<int64_t>(1024, (n + BLOCK - 1) / BLOCK);
+	HIPCHECK(c, hipMemsetAsync(acc, 0, 16, c->st));
+	k_isize_reduce<<<grid, BLOCK, 0, c->st>>>(P<int32_t>(c->isz_vals), n, 0, 0, acc);
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, acc, 8, hipMemcpyDeviceToHost, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	const unsigned long total = (unsigned long)*P<long long>(c->h_totals);
+	const int m = (int)(total / (unsigned long)n); // cluster.cpp:72
+	k_isize_reduce<<<grid, BLOCK, 0, c->st>>>(P<int32_t>(c->isz_vals), n, 1, m, acc + 1);
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, acc + 1, 8, hipMemcpyDeviceToHost, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	// cluster.cpp:73-80 adds the (int) squares one by one into a double; the exact integer sum is the same value as long as it
+	// stays below 2^53 (5e6 pairs * 2^31 is ~2^53.2: only reachable with absurd insert sizes)
+	const double dsum = (double)*P<long long>(c->h_totals);
+	*mean = m;
+	*sd = (int)std::sqrt(dsum / (double)n);
+	return SSV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// getsv: discordant tally + depth
+// ---------------------------------------------------------------------------------------------------------------------
+
+static int gs_build_tilemap(ssv_ctx *c, int32_t span)
+{
+	// which 512-bp tiles can hold the start (0-based pos) of a record that overlaps a depth window / is a candidate of a junction window
+	std::vector<uint8_t> &tm = c->gs_tilemap_host;
+	std::fill(tm.begin(), tm.end(), 0);
+	const int nt = (int)c->gs_tlen.size();
+	auto mark = [&](int tid, int64_t p0, int64_t p1, uint8_t bit) { // pos range [p0, p1] inclusive, 0-based
+		if (tid < 0 || tid >= nt || p1 < 0) return;
+		if (p0 < 0) p0 = 0;
+		int64_t ntile = c->gs_ctg_tile_off[tid + 1] - c->gs_ctg_tile_off[tid];
+		int64_t t0 = p0 >> TILE_SHIFT, t1 = p1 >> TILE_SHIFT;
+		if (t0 >= ntile) return;
+		if (t1 >= ntile) t1 = ntile - 1;
+		for (int64_t t = t0; t <= t1; ++t) tm[(size_t)(c->gs_ctg_tile_off[tid] + t)] |= bit;
+	};
+	for (const ssv_interval &w : c->gs_win) mark(w.tid, (int64_t)w.beg - span, (int64_t)w.end - 1, TM_DEPTH);    // cols [beg,end] 1-based <-> pos+1 <= end, pos+span >= beg
+	for (const DevJunction &j : c->gs_junc) mark(j.up_tid, (int64_t)j.beg - span, (int64_t)j.end - 1, TM_JUNC);    // rend > beg && pos < end
+	CHECK(ensure(c, c->gs_tilemap, tm.size() + 16));
+	if (!tm.empty()) HIPCHECK(c, hipMemcpyAsync(c->gs_tilemap.p, tm.data(), tm.size(), hipMemcpyHostToDevice, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	c->gs_map_span = span;
+	return SSV_OK;
+}
+
+int ssv_getsv_begin(ssv_ctx *c, const ssv_getsv_params *p)
+{
+	if (!c || !p || p->n_targets < 0 || p->n_junctions < 0 || p->n_windows < 0) return SSV_E_ARG;
+	if ((p->n_targets && !p->target_len) || (p->n_junctions && !p->junctions) || (p->n_windows && !p->windows)) return SSV_E_ARG;
+	HIPCHECK(c, hipSetDevice(c->device));
+	c->gs_p = *p;
+	c->gs_tlen.assign(p->target_len, p->target_len + p->n_targets);
+	c->gs_ctg_tile_off.assign((size_t)p->n_targets + 1, 0);
+	for (int t = 0; t < p->n_targets; ++t) c->gs_ctg_tile_off[(size_t)t + 1] = c->gs_ctg_tile_off[(size_t)t] + ((int64_t)std::max(0, c->gs_tlen[(size_t)t]) >> TILE_SHIFT) + 1;
+	c->gs_tilemap_host.assign((size_t)c->gs_ctg_tile_off.back(), 0);
+	c->gs_map_span = -1;
+	// junctions sorted by (up_tid, beg); the window test itself is repeated exactly on the device
+	c->gs_junc.clear();
+	c->gs_wmax = 0;
+	for (int64_t k = 0; k < p->n_junctions; ++k) {
+		const ssv_junction &s = p->junctions[k];
+		DevJunction j;
+		j.up_tid = s.up_tid; j.down_tid = s.down_tid; j.up_pos = s.up_pos; j.down_pos = s.down_pos; j.beg = s.beg; j.end = s.end;
+		j.up_strand = s.up_strand; j.down_strand = s.down_strand; j.pad = 0; j.orig = (int32_t)k;
+		c->gs_junc.push_back(j);
+		if ((int64_t)s.end - s.beg > c->gs_wmax) c->gs_wmax = (int32_t)std::min<int64_t>((int64_t)s.end - s.beg, 0x7fffffff);
+	}
+	std::stable_sort(c->gs_junc.begin(), c->gs_junc.end(), [](const DevJunction &a, const DevJunction &b) { return a.up_tid != b.up_tid ? a.up_tid < b.up_tid : a.beg < b.beg; });
+	c->gs_win.assign(p->windows, p->windows + p->n_windows);
+	for (size_t k = 0; k < c->gs_win.size(); ++k) {
+		const ssv_interval &w = c->gs_win[k];
+		if (w.end < w.beg || (k && (c->gs_win[k - 1].tid > w.tid || (c->gs_win[k - 1].tid == w.tid && c->gs_win[k - 1].end >= w.beg)))) {
+			c->err = "depth windows must be sorted, disjoint and non-empty"; return SSV_E_ARG;
+		}
+	}
+	const size_t nj = c->gs_junc.size(), nw = c->gs_win.size();
+	std::vector<int32_t> wt(nw), wb(nw), we(nw);
+	std::vector<int64_t> wo(nw + 1, 0);
+	for (size_t k = 0; k < nw; ++k) { wt[k] = c->gs_win[k].tid; wb[k] = c->gs_win[k].beg; we[k] = c->gs_win[k].end; wo[k + 1] = wo[k] + ((int64_t)we[k] - wb[k] + 1) + 1; }
+	c->gs_diff_len = wo[nw];
+	CHECK(ensure(c, c->gs_djunc, nj * sizeof(DevJunction) + 16)); CHECK(ensure(c, c->gs_counts, nj * 4 + 16));
+	CHECK(ensure(c, c->gs_wtid, nw * 4 + 16)); CHECK(ensure(c, c->gs_wbeg, nw * 4 + 16)); CHECK(ensure(c, c->gs_wend, nw * 4 + 16)); CHECK(ensure(c, c->gs_woff, (nw + 1) * 8));
+	CHECK(ensure(c, c->gs_diff, (size_t)c->gs_diff_len * 4 + 16)); CHECK(ensure(c, c->gs_ctgoff, c->gs_ctg_tile_off.size() * 8)); CHECK(ensure(c, c->gs_maxdepth, 16));
+	CHECK(ensure(c, c->gs_span, 16));
+	if (nj) HIPCHECK(c, hipMemcpyAsync(c->gs_djunc.p, c->gs_junc.data(), nj * sizeof(DevJunction), hipMemcpyHostToDevice, c->st));
+	if (nw) {
+		HIPCHECK(c, hipMemcpyAsync(c->gs_wtid.p, wt.data(), nw * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHECK(c, hipMemcpyAsync(c->gs_wbeg.p, wb.data(), nw * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHECK(c, hipMemcpyAsync(c->gs_wend.p, we.data(), nw * 4, hipMemcpyHostToDevice, c->st));
+	}
+	HIPCHECK(c, hipMemcpyAsync(c->gs_woff.p, wo.data(), (nw + 1) * 8, hipMemcpyHostToDevice, c->st));
+	HIPCHECK(c, hipMemcpyAsync(c->gs_ctgoff.p, c->gs_ctg_tile_off.data(), c->gs_ctg_tile_off.size() * 8, hipMemcpyHostToDevice, c->st));
+	HIPCHECK(c, hipMemsetAsync(c->gs_counts.p, 0, nj * 4 + 16, c->st));
+	HIPCHECK(c, hipMemsetAsync(c->gs_diff.p, 0, (size_t)c->gs_diff_len * 4 + 16, c->st));
+	HIPCHECK(c, hipMemsetAsync(c->gs_maxdepth.p, 0, 16, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st)); // the host vectors above go out of scope
+	c->gs_active = true;
+	return SSV_OK;
+}
+
+int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
+{
+	if (!c || !b) return SSV_E_ARG;
+	if (!c->gs_active) { c->err = "ssv_getsv_scan before ssv_getsv_begin"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	if (b->n == 0) return SSV_OK;
+	DevBatch d;
+	CHECK(stage_batch(c, b, d));
+	if (!d.cigar) { c->err = "batch without cigar"; return SSV_E_ARG; }
+	int32_t span = d.max_ref_span;
+	if (span <= 0) { // unknown: measure it
+		HIPCHECK(c, hipMemsetAsync(c->gs_span.p, 0, 16, c->st));
+		k_max_span<<<grid_for(d.n, BLOCK), BLOCK, 0, c->st>>>(d, P<int>(c->gs_span));
+		CHECK(ensure_host(c, c->h_totals, 64));
+		HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->gs_span.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+		span = std::max(1, *P<int>(c->h_totals));
+	}
+	if (span > c->gs_map_span) CHECK(gs_build_tilemap(c, span));
+	GetsvArgs a;
+	a.b = d; a.tilemap = P<uint8_t>(c->gs_tilemap); a.ctg_tile_off = P<int64_t>(c->gs_ctgoff); a.n_targets = c->gs_p.n_targets;
+	a.junc = P<DevJunction>(c->gs_djunc); a.n_junc = (int64_t)c->gs_junc.size(); a.junc_wmax = c->gs_wmax;
+	a.mean = c->gs_p.mean; a.sd = c->gs_p.sd; a.times = c->gs_p.times; a.disc_min_mapq = c->gs_p.disc_min_mapq;
+	a.min_ins = std::max(0, a.mean - a.sd * a.times); a.max_ins = a.mean + a.sd * a.times; // getsv.cpp:1032-1034
+	a.counts = P<int32_t>(c->gs_counts);
+	a.win_tid = P<int32_t>(c->gs_wtid); a.win_beg = P<int32_t>(c->gs_wbeg); a.win_end = P<int32_t>(c->gs_wend); a.win_off = P<int64_t>(c->gs_woff);
+	a.n_win = (int64_t)c->gs_win.size(); a.depth_min_mapq = c->gs_p.depth_min_mapq; a.diff = P<int32_t>(c->gs_diff);
+	const int64_t ntiles = (d.n + GS_TILE - 1) / GS_TILE;
+	{
+		ProfScope ps(c, P_GETSV_SCAN, d.n);
+		unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * 8);
+		k_getsv_scan<<<grid, BLOCK, 0, c->st>>>(a, ntiles);
+	}
+	HIPCHECK(c, hipGetLastError());
+	return SSV_OK;
+}
+
+int ssv_getsv_finish(ssv_ctx *c, int32_t *counts, const ssv_interval *ranges, int64_t n_ranges, uint64_t *range_sum,
+                     const ssv_interval *points, int64_t n_points, int32_t *point_depth, int32_t *max_depth)
+{
+	if (!c || n_ranges < 0 || n_points < 0 || (n_ranges && (!ranges || !range_sum)) || (n_points && (!points || !point_depth))) return SSV_E_ARG;
+	if (!c->gs_active) { c->err = "ssv_getsv_finish before ssv_getsv_begin"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	c->gs_active = false;
+	const int64_t nw = (int64_t)c->gs_win.size(), nj = (int64_t)c->gs_junc.size();
+	ProfScope ps(c, P_DEPTH_FINISH, nw);
+	if (nw) k_depth_prefix<<<grid_for(nw, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<int64_t>(c->gs_woff), nw, P<int32_t>(c->gs_diff), P<int32_t>(c->gs_maxdepth));
+	const int64_t nq = std::max(n_ranges, n_points);
+	CHECK(ensure(c, c->q_tid, nq * 4 + 16)); CHECK(ensure(c, c->q_beg, nq * 4 + 16)); CHECK(ensure(c, c->q_end, nq * 4 + 16));
+	CHECK(ensure(c, c->q_out64, n_ranges * 8 + 16)); CHECK(ensure(c, c->q_out32, n_points * 4 + 16));
+	std::vector<int32_t> t((size_t)nq), bg((size_t)nq), en((size_t)nq);
+	if (n_ranges) {
+		for (int64_t k = 0; k < n_ranges; ++k) { t[(size_t)k] = ranges[k].tid; bg[(size_t)k] = ranges[k].beg; en[(size_t)k] = ranges[k].end; }
+		HIPCHECK(c, hipMemcpyAsync(c->q_tid.p, t.data(), n_ranges * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHECK(c, hipMemcpyAsync(c->q_beg.p, bg.data(), n_ranges * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHECK(c, hipMemcpyAsync(c->q_end.p, en.data(), n_ranges * 4, hipMemcpyHostToDevice, c->st));
+		k_range_sum<<<grid_for(n_ranges, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<int32_t>(c->gs_wtid), P<int32_t>(c->gs_wbeg), P<int32_t>(c->gs_wend), P<int64_t>(c->gs_woff), nw,
+		                                                                      P<int32_t>(c->gs_diff), P<int32_t>(c->q_tid), P<int32_t>(c->q_beg), P<int32_t>(c->q_end), n_ranges,
+		                                                                      P<unsigned long long>(c->q_out64));
+		HIPCHECK(c, hipMemcpyAsync(range_sum, c->q_out64.p, n_ranges * 8, hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st)); // t/bg/en are reused for the points
+	}
+	if (n_points) {
+		for (int64_t k = 0; k < n_points; ++k) { t[(size_t)k] = points[k].tid; bg[(size_t)k] = points[k].beg; }
+		HIPCHECK(c, hipMemcpyAsync(c->q_tid.p, t.data(), n_points * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHECK(c, hipMemcpyAsync(c->q_beg.p, bg.data(), n_points * 4, hipMemcpyHostToDevice, c->st));
+		k_point_depth<<<grid_for(n_points, BLOCK), BLOCK, 0, c->st>>>(P<int32_t>(c->gs_wtid), P<int32_t>(c->gs_wbeg), P<int32_t>(c->gs_wend), P<int64_t>(c->gs_woff), nw,
+		                                                              P<int32_t>(c->gs_diff), P<int32_t>(c->q_tid), P<int32_t>(c->q_beg), n_points, P<int32_t>(c->q_out32));
+		HIPCHECK(c, hipMemcpyAsync(point_depth, c->q_out32.p, n_points * 4, hipMemcpyDeviceToHost, c->st));
+	}
+	if (counts && nj) HIPCHECK(c, hipMemcpyAsync(counts, c->gs_counts.p, nj * 4, hipMemcpyDeviceToHost, c->st));
+	if (max_depth) HIPCHECK(c, hipMemcpyAsync(max_depth, c->gs_maxdepth.p, 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHECK(c, hipGetLastError());
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	return SSV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------------------------------------------------
+
+int ssv_prof_enable(ssv_ctx *c, int on)
+{
+	if (!c) return SSV_E_ARG;
+	prof_collect(c);
+	c->prof_mode = on;
+	return SSV_OK;
+}
+
+int ssv_prof_reset(ssv_ctx *c)
+{
+	if (!c) return SSV_E_ARG;
+	prof_collect(c);
+	for (int k = 0; k < P_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; c->prof_units[k] = 0; }
+	return SSV_OK;
+}
+
+int ssv_prof_get(ssv_ctx *c, const char *name, double *total_ms, int64_t *launches, int64_t *units)
+{
+	if (!c || !name) return SSV_E_ARG;
+	prof_collect(c);
+	for (int k = 0; k < P_COUNT; ++k) {
+		if (strcmp(name, kProfNames[k]) == 0) {
+			if (total_ms) *total_ms = c->prof_ms[k];
+			if (launches) *launches = c->prof_launches[k];
+			if (units) *units = c->prof_units[k];
+			return SSV_OK;
+		}
+	}
+	return SSV_E_ARG;
+}
+
+const char *ssv_prof_names(void) { return kProfNameList; }
+
+} // extern "C"

@@ -1,0 +1,156 @@
+"""Python face of libseeksv_hip.so (include/seeksv_hip.h).  Thin ctypes plumbing: every operation runs in
+hand-written HIP kernels on the GPU.  There is no fallback - without the built library or without a GPU
+the constructor raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .host import table_to_dict
+
+
+class SeeksvError(RuntimeError):
+    pass
+
+
+class Context:
+    """One GPU, one HIP stream (ssv_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = _abi.hip_lib()
+        h = C.c_void_p()
+        rc = self._lib.ssv_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise SeeksvError(f"ssv_ctx_create({device}) failed ({rc}): {self._lib.ssv_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SeeksvError(f"{what} failed ({rc}): {self._lib.ssv_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ssv_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self._lib.ssv_sync(self._h), "ssv_sync")
+
+    @staticmethod
+    def _as_batch(b):
+        if isinstance(b, _abi.Batch):
+            return b, None
+        return _abi.make_batch(b)
+
+    # ---- getclip ----
+    def clip_begin(self, match_rate=0.9, min_mapq=1, save_low_quality=False):
+        p = _abi.ClipParams(match_rate, min_mapq, int(save_low_quality))
+        self._check(self._lib.ssv_clip_begin(self._h, C.byref(p)), "ssv_clip_begin")
+
+    def clip_scan(self, batch):
+        b, keep = self._as_batch(batch)
+        self._check(self._lib.ssv_clip_scan(self._h, C.byref(b)), "ssv_clip_scan")
+        if keep is not None:
+            self.sync()  # host arrays may go away
+
+    def clip_event_count(self):
+        n = C.c_int64()
+        self._check(self._lib.ssv_clip_event_count(self._h, C.byref(n)), "ssv_clip_event_count")
+        return n.value
+
+    def clip_cluster(self, as_dict=True):
+        t = _abi.ClusterTable()
+        self._check(self._lib.ssv_clip_cluster(self._h, C.byref(t)), "ssv_clip_cluster")
+        return table_to_dict(t) if as_dict else t
+
+    def getclip(self, batches, match_rate=0.9, min_mapq=1, save_low_quality=False):
+        """InputBamOutputReads' record loop over a list of batches -> cluster table dict."""
+        self.clip_begin(match_rate, min_mapq, save_low_quality)
+        for b in batches:
+            self.clip_scan(b)
+        return self.clip_cluster()
+
+    # ---- getsv pass 1 ----
+    def isize_stats(self, batches, min_mapq=20, max_pairs=5000000):
+        """-> (rc, n_pairs, mean, sd); rc == 1 when no pair qualifies (the reference's return value)."""
+        self._check(self._lib.ssv_isize_begin(self._h, min_mapq, max_pairs), "ssv_isize_begin")
+        done = C.c_int32(0)
+        for bt in batches:
+            b, keep = self._as_batch(bt)
+            self._check(self._lib.ssv_isize_accumulate(self._h, C.byref(b), C.byref(done)), "ssv_isize_accumulate")
+            if done.value:
+                break
+        n, mean, sd = C.c_int64(), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.ssv_isize_finish(self._h, C.byref(n), C.byref(mean), C.byref(sd)), "ssv_isize_finish")
+        return (1 if n.value == 0 else 0), n.value, mean.value, sd.value
+
+    # ---- getsv passes 2+3 ----
+    def getsv_begin(self, junctions, windows, mean, sd, target_lens, times=4, disc_min_mapq=20, depth_min_mapq=20):
+        j = np.ascontiguousarray(junctions, dtype=_abi.JUNCTION_DTYPE)
+        w = np.ascontiguousarray(windows, dtype=_abi.INTERVAL_DTYPE)
+        tl = np.ascontiguousarray(target_lens, dtype=np.int32)
+        p = _abi.GetsvParams()
+        p.junctions = j.ctypes.data if len(j) else None
+        p.n_junctions = len(j)
+        p.mean, p.sd, p.times, p.disc_min_mapq = mean, sd, times, disc_min_mapq
+        p.windows = w.ctypes.data if len(w) else None
+        p.n_windows = len(w)
+        p.depth_min_mapq = depth_min_mapq
+        p.n_targets = len(tl)
+        p.target_len = tl.ctypes.data if len(tl) else None
+        self._gs_nj = len(j)
+        self._check(self._lib.ssv_getsv_begin(self._h, C.byref(p)), "ssv_getsv_begin")
+
+    def getsv_scan(self, batch):
+        b, keep = self._as_batch(batch)
+        self._check(self._lib.ssv_getsv_scan(self._h, C.byref(b)), "ssv_getsv_scan")
+        if keep is not None:
+            self.sync()
+
+    def getsv_finish(self, ranges, points):
+        r = np.ascontiguousarray(ranges, dtype=_abi.INTERVAL_DTYPE)
+        q = np.ascontiguousarray(points, dtype=_abi.INTERVAL_DTYPE)
+        counts = np.zeros(self._gs_nj, dtype=np.int32)
+        rs = np.zeros(len(r), dtype=np.uint64)
+        pd = np.zeros(len(q), dtype=np.int32)
+        mx = C.c_int32(0)
+        ptr = lambda a: a.ctypes.data if a.size else None
+        self._check(self._lib.ssv_getsv_finish(self._h, ptr(counts), ptr(r), len(r), ptr(rs), ptr(q), len(q), ptr(pd), C.byref(mx)), "ssv_getsv_finish")
+        return counts, rs, pd, mx.value
+
+    def discordant_and_depth(self, batches, plan, mean, sd, min_mapq, target_lens):
+        """Backend protocol shared with the oracle in the tests (see tests/golden_util.py)."""
+        self.getsv_begin(plan.junctions, plan.windows, mean, sd, target_lens, 4, min_mapq, min_mapq)
+        for b in batches:
+            self.getsv_scan(b)
+        counts, rs, pd, _ = self.getsv_finish(plan.ranges, plan.points)
+        return counts, rs, pd
+
+    # ---- measurement ----
+    def prof_enable(self, mode=1):
+        self._check(self._lib.ssv_prof_enable(self._h, mode), "ssv_prof_enable")
+
+    def prof_reset(self):
+        self._check(self._lib.ssv_prof_reset(self._h), "ssv_prof_reset")
+
+    def prof_get(self, name):
+        ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self._lib.ssv_prof_get(self._h, name.encode(), C.byref(ms), C.byref(n), C.byref(u)), "ssv_prof_get")
+        return dict(total_ms=ms.value, launches=n.value, units=u.value)
+
+    def prof_all(self):
+        return {n: self.prof_get(n) for n in self._lib.ssv_prof_names().decode().split("\n")}

@@ -183,7 +183,7 @@ int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_
 	b->flag.clear(); b->n_cigar.clear(); b->mapq.clear(); b->xc.clear(); b->seqqual.clear();
 	b->cigar_off.clear(); b->cigar.clear(); b->seq_off.clear(); b->unmapped.clear();
 	g_err.clear();
-	int64_t n = 0;
+	int64_t n = 0, max_span = 1;
 	while (n < max_records) {
 		int32_t block_size;
 		size_t got = b->z.read(&block_size, 4);
@@ -205,11 +205,15 @@ int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_
 		b->n_cigar.push_back(ncig); b->l_qseq.push_back(l_seq); b->mtid.push_back(next_ref); b->mpos.push_back(next_pos); b->isize.push_back(tlen);
 		b->cigar_off.push_back((uint32_t)b->cigar.size());
 		bool soft = false;
+		int64_t span = 0;
 		for (unsigned k = 0; k < ncig; ++k) {
 			uint32_t c; memcpy(&c, r + o_cig + 4 * k, 4);
 			b->cigar.push_back(c);
 			if ((k == 0 || k + 1 == ncig) && (c & 15) == 4) soft = true;
+			unsigned op = c & 15;
+			if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += c >> 4;
 		}
+		if (span > max_span) max_span = span;
 		b->xc.push_back(soft ? (uint8_t)(aux_xc(r + o_aux, r + block_size) != 0) : (uint8_t)0);
 		if (soft || keep_all_seq) {
 			b->seq_off.push_back((uint64_t)b->seqqual.size());
@@ -231,6 +235,7 @@ int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_
 	if (!g_err.empty()) return -1;
 	memset(out, 0, sizeof(*out));
 	out->n = n; out->mem = SSV_MEM_HOST;
+	out->max_ref_span = (int32_t)(max_span > INT32_MAX ? INT32_MAX : max_span);
 	out->tid = b->tid.data(); out->pos = b->pos.data(); out->flag = b->flag.data(); out->mapq = b->mapq.data();
 	out->n_cigar = b->n_cigar.data(); out->l_qseq = b->l_qseq.data(); out->mtid = b->mtid.data(); out->mpos = b->mpos.data();
 	out->isize = b->isize.data(); out->cigar_off = b->cigar_off.data(); out->cigar = b->cigar.data(); out->xc = b->xc.data();

@@ -1,0 +1,49 @@
+"""CPU: the C-ABI libraries load and export every symbol their headers declare; without a GPU the HIP
+library refuses to create a context (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from seeksv_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header, prefix):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    lib = _abi.hip_lib()
+    names = declared_functions("seeksv_hip.h", "ssv_")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.ssv_abi_version() == 1
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = _abi.host_lib()
+    names = declared_functions("seeksv_host.h", "ssvh_")
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_abi.Batch) == 8 + 4 + 4 + 14 * 8 + 16
+    assert C.sizeof(_abi.Junction) == 28
+    assert C.sizeof(_abi.ClipParams) == 16
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from seeksv_amd.device import Context, SeeksvError
+    with pytest.raises(SeeksvError):
+        Context(0)
