@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py - BAM records/s through the getclip + getsv device path on synthetic WGS records resident in HBM.
+
+One "step" = one full pass of the hot path over this rank's shard:
+    clip_scan -> event sort -> cluster_bins -> cluster table to host            (seeksv getclip)
+    insert-size stats on the global file prefix                                 (getsv pass 1)
+    host bookkeeping (junction windows, flank windows) -> fused getsv_scan -> depth finish   (getsv passes 2+3)
+    one all-gather of the per-rank result vector (N > 1)
+Workload (BASELINE.json configs[1] + planted SVs so that the getsv passes have junctions to serve): synthetic 30x WGS,
+150 bp paired end, ~617 M records per GPU, 1 % random soft clips, 10 k planted DEL/INV/TRA at VAF 0.5.  With N GPUs the
+depth is 30x * N over the same genome (weak scaling: per-GPU records fixed), range-partitioned by reference interval.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--genome-frac F]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# Bytes each streaming kernel MUST read per record with the implemented (lazy) algorithm - DESIGN.md "Kernels":
+#   clip_scan : n_cigar 2 + cigar_off 4 + first/last CIGAR op 4.1 (avg 1.03 ops/record)          = 10.1 B
+#   getsv_scan: tid 4 + pos 4 (everything else only for the few % of records near a window)      =  8.0 B
+# (SURVEY 8d's eager figures are 21 B and 15+27 B; the kernels read less than that by design.)
+ALGO_BYTES = {"clip_scan": 10.1, "getsv_scan": 8.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genome-frac", type=float, default=1.0, help="scale the contigs (and the record count) down, e.g. 0.015625 for a quick run")
+    ap.add_argument("--depth", type=float, default=30.0, help="per-GPU coverage")
+    ap.add_argument("--n-sv", type=int, default=10000)
+    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="records of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from seeksv_amd import host, shard, synth
+    from seeksv_amd.device import Context
+
+    w = synth.Workload(genome_frac=args.genome_frac, depth=args.depth * world, n_sv=args.n_sv)
+    sp = shard.shard_plan(w, rank, world)
+    t0 = time.time()
+    n_scan = sp["own_hi_rec"] - sp["scan_lo_rec"]
+    n_own = sp["own_hi_rec"] - sp["own_lo_rec"]
+    scan_batch, scan_t = w.generate_device(sp["scan_lo_rec"], n_scan, local_rank)
+    # the rank's own records = the scan batch minus the leading halo (same cigar / seqqual blobs, offsets are absolute)
+    from seeksv_amd import _abi
+
+    def sub_batch(batch, first, n):
+        arrays = {}
+        for name, dt in _abi.BATCH_FIELDS:
+            ptr = getattr(batch, name)
+            arrays[name] = ptr if name in ("cigar", "seqqual", "xc") or ptr is None else ptr + first * np.dtype(dt).itemsize
+        arrays["n_cigar_total"], arrays["seqqual_bytes"], arrays["max_ref_span"] = batch.n_cigar_total, batch.seqqual_bytes, batch.max_ref_span
+        return _abi.make_batch(arrays, mem=_abi.MEM_DEVICE, n=n)[0]
+
+    own_batch = sub_batch(scan_batch, sp["own_lo_rec"] - sp["scan_lo_rec"], n_own)
+    # global file prefix for the insert-size statistics (cluster.cpp:68 stops after 5 M qualifying records)
+    n_prefix = min(w.n_total, 6_500_000)
+    if sp["scan_lo_rec"] == 0 and n_prefix <= n_scan:
+        prefix_batch, prefix_t = sub_batch(scan_batch, 0, n_prefix), None
+    else:
+        prefix_batch, prefix_t = w.generate_device(0, n_prefix, local_rank)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+
+    ctx = Context(local_rank)
+    hdr = host.Header(w.names, w.lens)
+    own = sp["own"] if world > 1 else None
+
+    def step():
+        ctx.clip_begin(0.9, 1, False, own, sp["initial_last_tid"])
+        ctx.clip_scan(scan_batch)
+        table = ctx.clip_cluster(as_dict=False)
+        n_clusters, n_events = table.n_clusters, table.n_events
+        support_sum = int(np.ctypeslib.as_array(table.support, shape=(n_clusters,)).sum()) if n_clusters else 0
+        rc, npairs, mean, sd = ctx.isize_stats([prefix_batch], 20, 5000000)
+        plan = host.Plan(hdr, w.junctions, mean, sd)
+        ctx.getsv_begin(plan.junctions, plan.windows, mean, sd, hdr.target_lens, 4, 20, 20)
+        ctx.getsv_scan(own_batch)
+        counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
+        vec = shard.pack_results(counts, rs, pd, n_clusters, n_events, support_sum)
+        stacked = shard.all_gather_vector(vec, dev if world > 1 else None)
+        merged = shard.merge_results(stacked, len(counts), len(rs), len(pd))
+        folded = plan.fold(merged[0], merged[1], merged[2])
+        plan.close()
+        return dict(n_clusters=merged[3], n_events=merged[4], support_sum=merged[5], mean=mean, sd=sd, abnormal_sum=int(folded["abnormal"].sum()),
+                    depth_sum=int(folded["up_depth"].sum() + folded["down_depth"].sum()), flank_sum=int(folded["flank"].sum()), max_depth=max_depth)
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    ctx.prof_reset()
+    ctx.prof_enable(2)  # HIP events around the two streaming kernels only, on the context's stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = {k: ctx.prof_get(k) for k in ("clip_scan", "getsv_scan")}
+    ctx.prof_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # one extra, untimed step with every kernel group bracketed by events: the per-kernel breakdown
+    ctx.prof_reset()
+    ctx.prof_enable(1)
+    step()
+    breakdown = {k: round(v["total_ms"], 4) for k, v in ctx.prof_all().items() if v["launches"]}
+    ctx.prof_enable(0)
+
+    if rank == 0:
+        assert res["support_sum"] == res["n_events"], "clip events were lost or duplicated"
+        total_records = w.n_total
+        ms_per_step = dt / args.steps * 1e3
+        dom = max(prof, key=lambda k: prof[k]["total_ms"])
+        launches = max(prof[dom]["launches"], 1)
+        avg_ms = prof[dom]["total_ms"] / launches
+        units = prof[dom]["units"] / launches
+        achieved = ALGO_BYTES[dom] * units / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_record")
+                traffic = traffic * units if traffic is not None else None
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "BAM records/sec through getclip+getsv",
+            "value": total_records * args.steps / dt,
+            "unit": "records/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8 (fp64 match-rate compare)", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.depth:g}x-per-GPU WGS, 150 bp PE, 1% random soft clips, {len(w.junctions)} planted DEL/INV/TRA (VAF 0.5), "
+                                   f"genome_frac {args.genome_frac:g}, {n_own} records/GPU resident in HBM",
+                       "records_total": total_records, "records_per_gpu": n_own, "junctions": len(w.junctions), "parallelism": f"range-partition x{world}",
+                       "generation_s": round(gen_s, 2)},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_record": ALGO_BYTES[dom], "records_per_launch": units, "avg_launch_ms": avg_ms,
+                         "other": {k: {"avg_launch_ms": prof[k]["total_ms"] / max(prof[k]["launches"], 1),
+                                       "achieved_GBs": ALGO_BYTES[k] * (prof[k]["units"] / max(prof[k]["launches"], 1)) / (prof[k]["total_ms"] / max(prof[k]["launches"], 1) * 1e-3) / 1e9}
+                                   for k in prof if prof[k]["launches"]}},
+            "kernel_ms_one_step": breakdown,
+            "result": res,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(w, hdr, min(args.cpu_sample, w.n_total))
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(w, hdr, n_sample):
+    """The CPU oracle (plain-C restatement of the reference, oracle/) on a bounded prefix of the same workload, 1 thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from seeksv_amd import host
+    b = w.generate_host(0, n_sample)
+    t0 = time.perf_counter()
+    d = O.getclip([b])
+    t_clip = time.perf_counter() - t0
+    rc, npairs, mean, sd = O.isize_stats([b], 20, 5000000)
+    plan = host.Plan(hdr, w.junctions, mean, sd)
+    counts = O.discordant([b], plan.junctions, mean, sd, 4, 20)
+    rs, pd, _ = O.depth([b], plan.windows, plan.ranges, plan.points, 20)
+    dt = time.perf_counter() - t0
+    plan.close()
+    return {"value": n_sample / dt, "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} records of the same synthetic workload (getclip {t_clip:.2f} s of {dt:.2f} s); oracle = plain-C restatement of seeksv v1.2.3, "
+                      "pinned to the real reference on tests/golden",
+            "clusters": int(d["n_clusters"]), "events": int(d["n_events"])}
+
+
+if __name__ == "__main__":
+    main()

@@ -93,9 +93,18 @@ typedef struct {
 	double match_rate;      /* -t, default 0.9  (seeksv.cpp:15,131) */
 	int32_t min_mapq;       /* -q, default 1    (seeksv.cpp:130) */
 	int32_t save_low_quality; /* -s             (seeksv.cpp:141) */
+	/* Range-partitioned runs (one GPU per reference interval).  A rank scans its interval plus a halo of
+	 * records that start before it, and keeps only the clip events whose breakpoint (tid, 1-based pos) lies in
+	 * [own_lo, own_hi): every (contig, side, position) bin then lives on exactly one rank with its reads in BAM order.
+	 * initial_last_tid = tid of the last mapped-pair record before the first scanned record (0 at the start of the
+	 * file, clip_reads.h:407).  All zero = whole file on one GPU. */
+	int32_t use_ownership;
+	int32_t initial_last_tid;
+	int32_t own_lo_tid, own_lo_pos;
+	int32_t own_hi_tid, own_hi_pos;
 } ssv_clip_params;
 
-/* Start a getclip pass.  last_tid state starts at 0 like the reference's (clip_reads.h:407). */
+/* Start a getclip pass.  last_tid state starts at initial_last_tid (0 like the reference's, clip_reads.h:407). */
 int ssv_clip_begin(ssv_ctx *ctx, const ssv_clip_params *p);
 /*
  * Scan one batch (GetSClipReads, clip_reads.cpp:112-192, incl. the contig-switch rule of

@@ -20,6 +20,8 @@ typedef struct ssvh_bam ssvh_bam; /* an open BAM file */
 
 /* Open a BAM file and parse its header.  Returns 0, or <0 and a message in ssvh_last_error(). */
 int ssvh_bam_open(const char *path, ssvh_bam **out);
+/* Header-only handle (no file): contig names and lengths for ssvh_plan_create when the records do not come from a BAM file. */
+int ssvh_bam_from_header(const char *const *names, const int32_t *lens, int32_t n, ssvh_bam **out);
 void ssvh_bam_close(ssvh_bam *b);
 const char *ssvh_last_error(void);
 

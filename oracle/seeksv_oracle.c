@@ -53,6 +53,8 @@ typedef struct {
 	int *order; uint8_t *order_side; int32_t *order_tid;
 	int64_t nord, capord;
 	int64_t n_events;
+	const ssv_clip_params *p;
+	int32_t cur_tid;
 } clip_state;
 
 static void posmap_init(posmap_t *m)
@@ -185,6 +187,12 @@ static void insert_seq(clip_state *st, int side, int pos, const char *sl, const 
                        int qual_missing, int batch, int rec, double limit)
 {
 	posmap_t *m = &st->map[side];
+	if (st->p->use_ownership) {
+		/* range-partitioned runs: only the events whose breakpoint lies in [own_lo, own_hi) belong to this rank */
+		long long k = ((long long)st->cur_tid << 32) | (unsigned)pos;
+		long long lo = ((long long)st->p->own_lo_tid << 32) | (unsigned)st->p->own_lo_pos, hi = ((long long)st->p->own_hi_tid << 32) | (unsigned)st->p->own_hi_pos;
+		if (k < lo || k >= hi) return;
+	}
 	slot_t *slot = posmap_find(m, pos, 1);
 	st->n_events++;
 	for (int id = slot->head; id >= 0; id = st->cl[id].next) {
@@ -316,11 +324,13 @@ int orc_getclip(const ssv_batch_t *batches, int n_batches, const ssv_clip_params
 	memset(&st, 0, sizeof(st));
 	posmap_init(&st.map[0]); posmap_init(&st.map[1]);
 	char *buf = NULL; int bufcap = 0;
-	int32_t last_tid = 0;
+	int32_t last_tid = p->initial_last_tid; /* 0 in the reference (clip_reads.h:407) */
+	st.p = p;
 	for (int bi = 0; bi < n_batches; ++bi) {
 		const ssv_batch_t *b = &batches[bi];
 		for (int64_t i = 0; i < b->n; ++i) {
 			if (b->flag[i] & (F_UNMAP | F_MUNMAP)) continue; /* unmapped-pair FASTQ side channel: host only */
+			st.cur_tid = b->tid[i];
 			if (b->tid[i] == last_tid) get_sclip_reads(&st, b, bi, i, p, &buf, &bufcap);
 			else { flush_run(&st, last_tid); last_tid = b->tid[i]; } /* this record is NOT processed */
 		}

@@ -36,7 +36,18 @@ BATCH_FIELDS = [  # (name, numpy dtype) in struct order
 
 
 class ClipParams(C.Structure):
-    _fields_ = [("match_rate", C.c_double), ("min_mapq", C.c_int32), ("save_low_quality", C.c_int32)]
+    _fields_ = [("match_rate", C.c_double), ("min_mapq", C.c_int32), ("save_low_quality", C.c_int32),
+                ("use_ownership", C.c_int32), ("initial_last_tid", C.c_int32), ("own_lo_tid", C.c_int32), ("own_lo_pos", C.c_int32),
+                ("own_hi_tid", C.c_int32), ("own_hi_pos", C.c_int32)]
+
+    @classmethod
+    def make(cls, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
+        """own = ((lo_tid, lo_pos), (hi_tid, hi_pos)) keeps only events with lo <= (tid, pos) < hi."""
+        p = cls(match_rate, min_mapq, int(save_low_quality), 0, initial_last_tid, 0, 0, 0, 0)
+        if own is not None:
+            p.use_ownership = 1
+            (p.own_lo_tid, p.own_lo_pos), (p.own_hi_tid, p.own_hi_pos) = own
+        return p
 
 
 class ClusterTable(C.Structure):
@@ -146,6 +157,7 @@ def host_lib():
     if not getattr(lib, "_typed", False):
         lib.ssvh_last_error.restype = C.c_char_p
         lib.ssvh_bam_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.ssvh_bam_from_header.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
         lib.ssvh_bam_close.argtypes = [C.c_void_p]
         lib.ssvh_bam_n_targets.argtypes = [C.c_void_p]
         lib.ssvh_bam_target_name.argtypes = [C.c_void_p, C.c_int32]

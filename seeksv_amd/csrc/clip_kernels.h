@@ -56,6 +56,8 @@ struct ClipScanArgs {
 	DevBatch b;
 	int min_mapq;
 	int save_low_quality;
+	int use_ownership;       // range-partitioned runs: keep only events with own_lo <= (tid << 32 | pos1) < own_hi
+	long long own_lo, own_hi;
 	const int *last_tid_in;  // tid of the last mapped-pair record before this batch (clip_reads.h:407: starts at 0)
 	uint32_t *tile_cnt;      // [ntiles] events per tile
 	uint32_t *tile_off;      // [ntiles] staging offset of the tile's events
@@ -123,6 +125,14 @@ __device__ __forceinline__ int clip_events_of(const ClipScanArgs &a, int64_t i, 
 			int ref_len = ref_len_generate_cigar(cig, nc);
 			ev[n].key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); ev[n].begin = ll; ev[n].ll = mid; ev[n].lr = rc; ++n;
 		}
+	}
+	if (a.use_ownership) {
+		int m = 0;
+		for (int k = 0; k < n; ++k) {
+			long long kk = ((long long)tid << 32) | (long long)(uint32_t)ev[k].key;
+			if (kk >= a.own_lo && kk < a.own_hi) { if (m != k) ev[m] = ev[k]; ++m; }
+		}
+		n = m;
 	}
 	for (int k = 0; k < n; ++k) { ev[k].rec = (uint32_t)i; ev[k].lq = lq; ev[k].ncig = (uint32_t)nc; ev[k].pad = 0; }
 	return n;

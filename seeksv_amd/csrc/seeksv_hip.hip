@@ -345,7 +345,11 @@ int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 	CHECK(ensure(c, c->d_last_tid, 16));
 	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
 	CHECK(ensure_host(c, c->h_counters, sizeof(ClipCounters)));
-	HIPCHECK(c, hipMemsetAsync(c->d_last_tid.p, 0, 16, c->st)); // last_tid = 0, clip_reads.h:407
+	HIPCHECK(c, hipMemsetAsync(c->d_last_tid.p, 0, 16, c->st));
+	int *h_lt = P<int>(c->h_counters);
+	*h_lt = p->initial_last_tid; // 0 in the reference, clip_reads.h:407
+	HIPCHECK(c, hipMemcpyAsync(c->d_last_tid.p, h_lt, 4, hipMemcpyHostToDevice, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
 	return SSV_OK;
 }
 
@@ -370,6 +374,9 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
 		ClipScanArgs a;
 		a.b = d; a.min_mapq = c->clip_p.min_mapq; a.save_low_quality = c->clip_p.save_low_quality; a.last_tid_in = P<int>(c->d_last_tid);
+		a.use_ownership = c->clip_p.use_ownership;
+		a.own_lo = ((long long)c->clip_p.own_lo_tid << 32) | (long long)(uint32_t)c->clip_p.own_lo_pos;
+		a.own_hi = ((long long)c->clip_p.own_hi_tid << 32) | (long long)(uint32_t)c->clip_p.own_hi_pos;
 		a.tile_cnt = P<uint32_t>(c->tile_cnt); a.tile_off = P<uint32_t>(c->tile_off); a.stage = P<StagedEvent>(c->stage); a.stage_cap = c->stage_cap;
 		a.ctr = P<ClipCounters>(c->counters); a.ntiles = ntiles;
 		{

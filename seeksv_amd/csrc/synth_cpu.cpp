@@ -1,0 +1,44 @@
+// synth_cpu.cpp - host build of the synthetic generator (tests and the CPU-baseline leg of bench.py).
+#include "synth.h"
+
+#include <cstring>
+#include <string>
+
+static std::string g_err;
+
+extern "C" {
+
+const char *ssvs_last_error(void) { return g_err.c_str(); }
+
+int ssvs_plan(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n, uint16_t *n_cigar, uint32_t *cigar_off, uint64_t *seq_off,
+              int64_t *n_cigar_total, int64_t *seqqual_bytes)
+{
+	uint64_t co = 0, so = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		sy_record r;
+		sy_decide(cfg, be, g0 + i, &r);
+		n_cigar[i] = r.n_cigar;
+		cigar_off[i] = (uint32_t)co; co += r.n_cigar;
+		if (r.has_seq) { seq_off[i] = so; so += (uint64_t)((r.l_qseq + 1) / 2 + r.l_qseq); }
+		else seq_off[i] = UINT64_MAX;
+	}
+	*n_cigar_total = (int64_t)co; *seqqual_bytes = (int64_t)so;
+	return 0;
+}
+
+int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n, int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *mapq,
+              const uint16_t *n_cigar, int32_t *l_qseq, int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar,
+              const uint64_t *seq_off, uint8_t *seqqual)
+{
+	(void)n_cigar;
+	for (int64_t i = 0; i < n; ++i) {
+		sy_record r;
+		sy_decide(cfg, be, g0 + i, &r);
+		tid[i] = r.tid; pos[i] = r.pos; flag[i] = r.flag; mapq[i] = r.mapq; l_qseq[i] = r.l_qseq; mtid[i] = r.mtid; mpos[i] = r.mpos; isize[i] = r.isize;
+		for (int k = 0; k < r.n_cigar; ++k) cigar[cigar_off[i] + k] = r.cigar[k];
+		if (r.has_seq) sy_fill_seq(cfg, be, g0 + i, &r, seqqual + seq_off[i]);
+	}
+	return 0;
+}
+
+} // extern "C"

@@ -57,8 +57,8 @@ class Context:
         return _abi.make_batch(b)
 
     # ---- getclip ----
-    def clip_begin(self, match_rate=0.9, min_mapq=1, save_low_quality=False):
-        p = _abi.ClipParams(match_rate, min_mapq, int(save_low_quality))
+    def clip_begin(self, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
+        p = _abi.ClipParams.make(match_rate, min_mapq, save_low_quality, own, initial_last_tid)
         self._check(self._lib.ssv_clip_begin(self._h, C.byref(p)), "ssv_clip_begin")
 
     def clip_scan(self, batch):
@@ -77,9 +77,9 @@ class Context:
         self._check(self._lib.ssv_clip_cluster(self._h, C.byref(t)), "ssv_clip_cluster")
         return table_to_dict(t) if as_dict else t
 
-    def getclip(self, batches, match_rate=0.9, min_mapq=1, save_low_quality=False):
+    def getclip(self, batches, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
         """InputBamOutputReads' record loop over a list of batches -> cluster table dict."""
-        self.clip_begin(match_rate, min_mapq, save_low_quality)
+        self.clip_begin(match_rate, min_mapq, save_low_quality, own, initial_last_tid)
         for b in batches:
             self.clip_scan(b)
         return self.clip_cluster()

@@ -58,6 +58,30 @@ class BamReader:
         self.close()
 
 
+class Header:
+    """Contig names + lengths without a BAM file (synthetic inputs); usable wherever a BamReader's header is."""
+
+    def __init__(self, names, lens):
+        self._lib = _abi.host_lib()
+        self.target_names = list(names)
+        self.target_lens = np.asarray(lens, dtype=np.int32)
+        n = len(self.target_names)
+        nb = (C.c_char_p * max(n, 1))(*[s.encode() for s in self.target_names])
+        lb = (C.c_int32 * max(n, 1))(*[int(x) for x in self.target_lens])
+        h = C.c_void_p()
+        self._lib.ssvh_bam_from_header(nb, lb, n, C.byref(h))
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self._lib.ssvh_bam_close(self._h)
+            self._h = None
+
+
 def read_bam(path, batch_records=1 << 20):
     """Whole BAM as (target_names, target_lens, [batch dicts])."""
     with BamReader(path) as r:

@@ -165,6 +165,15 @@ int ssvh_bam_open(const char *path, ssvh_bam **out)
 	return 0;
 }
 
+int ssvh_bam_from_header(const char *const *names, const int32_t *lens, int32_t n, ssvh_bam **out)
+{
+	ssvh_bam *b = new ssvh_bam();
+	for (int32_t i = 0; i < n; ++i) { b->names.push_back(names[i]); b->lens.push_back(lens[i]); }
+	b->z.eof = true;
+	*out = b;
+	return 0;
+}
+
 void ssvh_bam_close(ssvh_bam *b)
 {
 	if (!b) return;

@@ -1,0 +1,190 @@
+"""Synthetic WGS workloads: bench / test tooling around csrc/synth_core.h.
+
+A Workload is a pure description (contigs, read count, planted structural variants); records are produced
+on demand for any index range [g0, g0+n) either on the host (libseeksv_synth_cpu.so -> numpy arrays) or directly
+in HBM (libseeksv_synth.so -> torch tensors), byte-identical by construction.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import _abi
+
+HG38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+        133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+HG38_NAMES = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY"]
+SEED = 0x5EE45F
+MAX_CONTIGS = 64
+
+
+class SyConfig(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_total", C.c_int64), ("n_contigs", C.c_int32), ("read_len", C.c_int32),
+                ("contig_off", C.c_int64 * (MAX_CONTIGS + 1)), ("contig_len", C.c_int32 * MAX_CONTIGS), ("spacing_fp", C.c_uint64),
+                ("clip_permille", C.c_int32), ("indel_permille", C.c_int32), ("dup_permille", C.c_int32), ("sec_permille", C.c_int32),
+                ("improper_permille", C.c_int32), ("vaf_permille", C.c_int32), ("n_breakends", C.c_int32), ("pad", C.c_int32)]
+
+
+BREAKEND_DTYPE = np.dtype([("lin", np.int64), ("tid", np.int32), ("q", np.int32), ("ptid", np.int32), ("ppos", np.int32),
+                           ("side", np.int8), ("pdir", np.int8), ("mate_rev", np.int8), ("is_up", np.int8), ("mate_anchor", np.int32)])
+assert BREAKEND_DTYPE.itemsize == 32
+
+_synth_libs = {}
+
+
+def _lib(gpu):
+    name = "libseeksv_synth.so" if gpu else "libseeksv_synth_cpu.so"
+    if name not in _synth_libs:
+        path = os.path.join(_abi.LIBDIR, name)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make synth`")
+        lib = C.CDLL(path)
+        V = C.c_void_p
+        lib.ssvs_plan.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64, V, V, V, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.ssvs_fill.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64] + [V] * 13
+        lib.ssvs_last_error.restype = C.c_char_p
+        _synth_libs[name] = lib
+    return _synth_libs[name]
+
+
+class Workload:
+    def __init__(self, genome_frac=1.0, depth=30.0, n_sv=10000, seed=SEED, read_len=150, clip_permille=10, indel_permille=20,
+                 dup_permille=80, sec_permille=2, improper_permille=20, vaf_permille=500, n_contigs=24, min_contig=30000):
+        self.names = HG38_NAMES[:n_contigs]
+        self.lens = np.array([max(int(l * genome_frac), min_contig) for l in HG38[:n_contigs]], dtype=np.int64)
+        self.offs = np.concatenate([[0], np.cumsum(self.lens)])
+        G = int(self.offs[-1])
+        self.genome_len = G
+        self.read_len = read_len
+        self.n_total = int(depth * G / read_len)
+        self.depth = depth
+        cfg = SyConfig()
+        cfg.seed = seed
+        cfg.n_total = self.n_total
+        cfg.n_contigs = n_contigs
+        cfg.read_len = read_len
+        for i in range(n_contigs):
+            cfg.contig_off[i] = int(self.offs[i])
+            cfg.contig_len[i] = int(self.lens[i])
+        cfg.contig_off[n_contigs] = G
+        cfg.spacing_fp = ((G - read_len - 16) << 20) // max(self.n_total, 1)
+        cfg.clip_permille, cfg.indel_permille, cfg.dup_permille = clip_permille, indel_permille, dup_permille
+        cfg.sec_permille, cfg.improper_permille, cfg.vaf_permille = sec_permille, improper_permille, vaf_permille
+        self.cfg = cfg
+        self.max_ref_span = read_len + 8
+        self._plant(n_sv, seed)
+        cfg.n_breakends = len(self.breakends)
+        self._be_dev = {}
+
+    # ---- planted structural variants -> breakends (generator side) + junctions (getsv side) ----
+    def _plant(self, n_sv, seed):
+        rng = np.random.RandomState(seed & 0x7fffffff)
+        occupied = set()
+        L = self.read_len
+
+        def free(tid, pos):
+            if pos < 1500 or pos > self.lens[tid] - 1500:
+                return False
+            b = int(self.offs[tid] + pos) // 1000
+            return not any((b + d) in occupied for d in (-1, 0, 1))
+
+        def take(tid, pos):
+            occupied.add(int(self.offs[tid] + pos) // 1000)
+
+        be, junctions = [], []
+        weights = self.lens / self.lens.sum()
+        tries = 0
+        while len(junctions) < n_sv and tries < 50 * max(n_sv, 1):
+            tries += 1
+            k = len(junctions) % 8
+            ta = int(rng.choice(len(self.lens), p=weights))
+            A = int(rng.randint(1500, self.lens[ta] - 1500))
+            if k < 4:      # DEL, log-uniform 300 bp .. 1 Mbp
+                kind, tb = "DEL", ta
+                B = A + int(math.exp(rng.uniform(math.log(300), math.log(min(1e6, self.lens[ta] / 4))))) + 1
+            elif k < 6:    # INV, both orientations
+                kind, tb = ("INVpm" if k == 4 else "INVmp"), ta
+                B = A + int(rng.randint(1000, min(100000, self.lens[ta] // 4)))
+            else:          # TRA
+                kind = "TRA"
+                tb = int(rng.choice(len(self.lens), p=weights))
+                if tb == ta:
+                    continue
+                B = int(rng.randint(1500, self.lens[tb] - 1500))
+            if not (free(ta, A) and free(tb, B)) or (ta == tb and abs(A - B) < 300):
+                continue
+            take(ta, A), take(tb, B)
+            la, lb = int(self.offs[ta]), int(self.offs[tb])
+            if kind in ("DEL", "TRA"):     # (A,+) -> (B,+): aligned [..,A) | clip = ref[B-1..]   and   clip = ref[..A-1] | aligned [B-1,..)
+                junctions.append((self.names[ta], A, "+", self.names[tb], B, "+"))
+                be.append((la + A, ta, A, tb, B - 1, 0, 1, 1, 1, B - 1))
+                be.append((lb + B - 1, tb, B - 1, ta, A - 1, 1, -1, 0, 0, 0))
+            elif kind == "INVpm":          # (A,+) -> (B,-): both aligned parts end at their breakpoint, partner walked backwards
+                junctions.append((self.names[ta], A, "+", self.names[tb], B, "-"))
+                be.append((la + A, ta, A, tb, B - 1, 0, -1, 0, 1, B - 1))
+                be.append((lb + B, tb, B, ta, A - 1, 0, -1, 0, 0, 0))
+            else:                          # (A,-) -> (B,+): both aligned parts start at their breakpoint, partner walked forwards
+                junctions.append((self.names[ta], A, "-", self.names[tb], B, "+"))
+                be.append((la + A - 1, ta, A - 1, tb, B - 1, 1, 1, 1, 1, B - 1))
+                be.append((lb + B - 1, tb, B - 1, ta, A - 1, 1, 1, 0, 0, 0))
+        arr = np.array(be, dtype=BREAKEND_DTYPE) if be else np.zeros(0, dtype=BREAKEND_DTYPE)
+        self.breakends = np.sort(arr, order="lin")
+        # multimap<Junction,...> order (getsv.h:187-225)
+        self.junctions = sorted(junctions, key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
+
+    # ---- record generation ----
+    def generate_host(self, g0, n):
+        """records [g0, g0+n) as a dict of numpy arrays (a SSV_MEM_HOST batch)."""
+        lib = _lib(False)
+        be = self.breakends
+        bep = be.ctypes.data if len(be) else None
+        a = dict(n_cigar=np.zeros(n, np.uint16), cigar_off=np.zeros(n, np.uint32), seq_off=np.zeros(n, np.uint64))
+        nct, sqb = C.c_int64(), C.c_int64()
+        p = lambda x: x.ctypes.data if x.size else None
+        lib.ssvs_plan(C.byref(self.cfg), bep, g0, n, p(a["n_cigar"]), p(a["cigar_off"]), p(a["seq_off"]), C.byref(nct), C.byref(sqb))
+        for name, dt in (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("l_qseq", np.int32),
+                         ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32)):
+            a[name] = np.zeros(n, dt)
+        a["cigar"] = np.zeros(nct.value, np.uint32)
+        a["seqqual"] = np.zeros(sqb.value, np.uint8)
+        lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, p(a["tid"]), p(a["pos"]), p(a["flag"]), p(a["mapq"]), p(a["n_cigar"]), p(a["l_qseq"]),
+                      p(a["mtid"]), p(a["mpos"]), p(a["isize"]), p(a["cigar_off"]), p(a["cigar"]), p(a["seq_off"]), p(a["seqqual"]))
+        a["xc"] = None
+        a["max_ref_span"] = self.max_ref_span
+        return a
+
+    def generate_device(self, g0, n, device):
+        """records [g0, g0+n) resident in HBM: -> (ssv_batch_t with device pointers, dict of torch tensors keeping them alive)."""
+        import torch
+        lib = _lib(True)
+        torch.cuda.set_device(device)
+        dev = torch.device("cuda", device)
+        if device not in self._be_dev:
+            be = self.breakends
+            self._be_dev[device] = torch.from_numpy(be.view(np.uint8).copy()).to(dev) if len(be) else torch.zeros(32, dtype=torch.uint8, device=dev)
+        bep = self._be_dev[device].data_ptr()
+        t = dict(n_cigar=torch.empty(n, dtype=torch.int16, device=dev), cigar_off=torch.empty(n, dtype=torch.int32, device=dev),
+                 seq_off=torch.empty(n, dtype=torch.int64, device=dev))
+        nct, sqb = C.c_int64(), C.c_int64()
+        torch.cuda.synchronize(dev)
+        rc = lib.ssvs_plan(C.byref(self.cfg), bep, g0, n, t["n_cigar"].data_ptr(), t["cigar_off"].data_ptr(), t["seq_off"].data_ptr(), C.byref(nct), C.byref(sqb))
+        if rc != 0:
+            raise RuntimeError("ssvs_plan: " + lib.ssvs_last_error().decode())
+        for name, dt in (("tid", torch.int32), ("pos", torch.int32), ("flag", torch.int16), ("mapq", torch.uint8), ("l_qseq", torch.int32),
+                         ("mtid", torch.int32), ("mpos", torch.int32), ("isize", torch.int32)):
+            t[name] = torch.empty(n, dtype=dt, device=dev)
+        t["cigar"] = torch.empty(max(nct.value, 4), dtype=torch.int32, device=dev)
+        t["seqqual"] = torch.empty(max(sqb.value, 16), dtype=torch.uint8, device=dev)
+        rc = lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, t["tid"].data_ptr(), t["pos"].data_ptr(), t["flag"].data_ptr(), t["mapq"].data_ptr(),
+                           t["n_cigar"].data_ptr(), t["l_qseq"].data_ptr(), t["mtid"].data_ptr(), t["mpos"].data_ptr(), t["isize"].data_ptr(),
+                           t["cigar_off"].data_ptr(), t["cigar"].data_ptr(), t["seq_off"].data_ptr(), t["seqqual"].data_ptr())
+        if rc != 0:
+            raise RuntimeError("ssvs_fill: " + lib.ssvs_last_error().decode())
+        arrays = {k: v.data_ptr() for k, v in t.items()}
+        arrays["xc"] = None
+        arrays["n_cigar_total"] = nct.value
+        arrays["seqqual_bytes"] = sqb.value
+        arrays["max_ref_span"] = self.max_ref_span
+        b, _ = _abi.make_batch(arrays, mem=_abi.MEM_DEVICE, n=n)
+        return b, t

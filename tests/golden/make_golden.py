@@ -343,6 +343,67 @@ def crafted_getsv():
                     g.write(f"{rc}\n")
 
 
+# ------------------------------------------------------------------------------------------------
+# 4. the synthetic generator's records through the real reference (inputs are regenerated by the tests,
+#    only the reference's outputs are committed)
+# ------------------------------------------------------------------------------------------------
+
+SYNTH_CASES = {"synth30x": dict(genome_frac=1 / 2048, depth=30, n_sv=40), "synth300x": dict(genome_frac=1 / 8192, depth=300, n_sv=24)}
+
+
+def soa_to_bam(path, names, lens, b):
+    import numpy as np
+    NT = "=ACMGRSVTWYHKDBN"
+    recs = []
+    no_seq = np.uint64(2 ** 64 - 1)
+    for i in range(len(b["tid"])):
+        co, nc, lq = int(b["cigar_off"][i]), int(b["n_cigar"][i]), int(b["l_qseq"][i])
+        cig = [(int(c) >> 4, int(c) & 15) for c in b["cigar"][co:co + nc]]
+        if b["seq_off"][i] != no_seq:
+            so = int(b["seq_off"][i])
+            packed = b["seqqual"][so:so + (lq + 1) // 2]
+            seq = "".join(NT[(int(packed[k >> 1]) >> (4 if k % 2 == 0 else 0)) & 15] for k in range(lq))
+            qual = bytes(b["seqqual"][so + (lq + 1) // 2: so + (lq + 1) // 2 + lq])
+        else:
+            seq, qual = "A" * lq, b"\x1e" * lq
+        recs.append(dict(qname=f"s{i}", flag=int(b["flag"][i]), tid=int(b["tid"][i]), pos=int(b["pos"][i]), mapq=int(b["mapq"][i]), cigar=cig,
+                         mtid=int(b["mtid"][i]), mpos=int(b["mpos"][i]), isize=int(b["isize"][i]), seq=seq, qual=qual))
+    bamio.write_bam(path, names, [int(x) for x in lens], recs)
+
+
+def synthetic():
+    sys.path.insert(0, ROOT)
+    from seeksv_amd import synth
+    out = os.path.join(HERE, "synth")
+    os.makedirs(out, exist_ok=True)
+    for name, kw in SYNTH_CASES.items():
+        w = synth.Workload(**kw)
+        b = w.generate_host(0, w.n_total)
+        bam = os.path.join(TMP, f"{name}.bam")
+        soa_to_bam(bam, w.names, w.lens, b)
+        run([os.path.join(BIN, "bamidx"), bam])
+        run([SEEKSV, "getclip", "-o", name, bam], cwd=TMP)
+        for ext in ("clip", "clip.fq"):
+            with gzip.open(os.path.join(TMP, f"{name}.{ext}.gz"), "rb") as f, gzip.GzipFile(os.path.join(out, f"{name}.{ext}.txt.gz"), "wb", mtime=0) as g:
+                g.write(f.read())
+        empty_bam = os.path.join(TMP, f"{name}.empty.clip.bam")
+        bamio.write_bam(empty_bam, w.names, [int(x) for x in w.lens], [])
+        empty_clip = os.path.join(TMP, "empty.clip")
+        open(empty_clip, "w").close()
+        jfile = os.path.join(out, f"{name}.junctions.txt")
+        with open(jfile, "w") as f:
+            for j in w.junctions:
+                f.write(junction_row(*j))
+        pre = os.path.join(out, name)
+        with open(pre + ".stdout", "wb") as so, open(os.path.join(TMP, "stderr.txt"), "wb") as se:
+            subprocess.check_call([SEEKSV, "getsv", "-d", "0", "-f", "0", "-b", "0", "-T", "100000", "-B", jfile, empty_bam, bam, empty_clip, pre + ".sv",
+                                   os.path.join(TMP, "x.fq")], stdout=so, stderr=se)
+        txt = open(os.path.join(TMP, "stderr.txt")).read()
+        with open(pre + ".isize.txt", "w") as g:
+            g.write(txt.split("Mean insert size : ")[1].split()[0] + "\t" + txt.split("Mean deviation: ")[1].split()[0] + "\n")
+        print(f"  {name}: {w.n_total} records, {len(w.junctions)} junctions")
+
+
 if __name__ == "__main__":
     if not os.path.exists(SEEKSV):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -350,4 +411,5 @@ if __name__ == "__main__":
     example()
     crafted_getclip()
     crafted_getsv()
+    synthetic()
     print("goldens regenerated under", HERE)

@@ -94,3 +94,28 @@ def check_getsv_against_golden(junctions, folded, golden):
                 assert avg == g["flank"][c], (key, "flank", c, avg, g)
                 checked += 1
     return checked
+
+
+# ---- synthetic workloads whose reference outputs are committed under golden/synth (inputs are regenerated) ----
+
+SYNTH_CASES = {"synth30x": dict(genome_frac=1 / 2048, depth=30, n_sv=40), "synth300x": dict(genome_frac=1 / 8192, depth=300, n_sv=24)}
+
+
+def read_gz(*parts):
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, *parts), "rt") as f:
+        return f.read()
+
+
+def run_getsv_batches(header, batches, junction_rows, backend, min_mapq=20, flank_length=200, n_pairs=5000000):
+    """Like run_getsv_case but for batches that are already in memory (synthetic inputs)."""
+    rc, n, mean, sd = backend.isize_stats(batches, min_mapq, n_pairs)
+    if rc != 0:
+        mean, sd = 0, 0
+    junctions = [j[:6] for j in junction_rows]
+    prev = np.array([j[6] for j in junction_rows], dtype=np.int32)
+    plan = host.Plan(header, junctions, mean, sd, 4, flank_length)
+    counts, range_sum, point_depth = backend.discordant_and_depth(batches, plan, mean, sd, min_mapq, header.target_lens)
+    folded = plan.fold(counts, range_sum, point_depth, prev)
+    plan.close()
+    return (rc, n, mean, sd), junctions, folded

@@ -41,9 +41,9 @@ def _batches(batches):
     return arr, keep
 
 
-def getclip(batches, match_rate=0.9, min_mapq=1, save_low_quality=False):
+def getclip(batches, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
     arr, keep = _batches(batches)
-    p = _abi.ClipParams(match_rate, min_mapq, int(save_low_quality))
+    p = _abi.ClipParams.make(match_rate, min_mapq, save_low_quality, own, initial_last_tid)
     t = _abi.OrcClusterTable()
     rc = lib().orc_getclip(arr, len(batches), C.byref(p), C.byref(t))
     assert rc == 0

@@ -37,7 +37,7 @@ def test_host_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(_abi.Batch) == 8 + 4 + 4 + 14 * 8 + 16
     assert C.sizeof(_abi.Junction) == 28
-    assert C.sizeof(_abi.ClipParams) == 16
+    assert C.sizeof(_abi.ClipParams) == 40
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -71,3 +71,70 @@ def test_no_seq_and_empty_batches(ctx):
     assert_tables_equal(d, O.getclip([batches[0]]))
     d0 = ctx.getclip([empty])
     assert d0["n_clusters"] == 0 and d0["n_events"] == 0
+
+
+def _device_batch_to_host(t, n_cigar_total, seqqual_bytes):
+    import torch
+    out = {}
+    for k, dt in (("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("n_cigar", np.uint16), ("l_qseq", np.int32),
+                  ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32), ("cigar_off", np.uint32), ("seq_off", np.uint64)):
+        out[k] = t[k].cpu().numpy().view(dt)
+    out["cigar"] = t["cigar"].cpu().numpy().view(np.uint32)[:n_cigar_total]
+    out["seqqual"] = t["seqqual"].cpu().numpy()[:seqqual_bytes]
+    return out
+
+
+@pytest.mark.parametrize("name", list(G.SYNTH_CASES))
+def test_synthetic_workload_hip_device_resident(ctx, name):
+    """Records generated straight into HBM (the bench path): identical to the CPU generator's, and the HIP path on the
+    device-resident batch reproduces the real reference's clip table / discordant counts / depths."""
+    from seeksv_amd import synth
+    from test_oracle_golden import split_batch
+    w = synth.Workload(**G.SYNTH_CASES[name])
+    hb = w.generate_host(0, w.n_total)
+    db, tensors = w.generate_device(0, w.n_total, 0)
+    got = _device_batch_to_host(tensors, db.n_cigar_total, db.seqqual_bytes)
+    for k in got:
+        assert np.array_equal(got[k], hb[k]), k
+    d = ctx.getclip([db])
+    clip, fq = host.format_clip_outputs(d, w.names)
+    assert clip == G.read_gz("synth", name + ".clip.txt.gz")
+    assert fq == G.read_gz("synth", name + ".clip.fq.txt.gz")
+    hdr = host.Header(w.names, w.lens)
+    rows = G.read_junction_file(os.path.join(G.GOLDEN, "synth", name + ".junctions.txt"))
+    stats, junctions, folded = G.run_getsv_batches(hdr, [db], rows, ctx)
+    assert [str(stats[2]), str(stats[3])] == G.read_text("synth", name + ".isize.txt").split()
+    golden = G.parse_sv_outputs(os.path.join(G.GOLDEN, "synth", name + ".sv"), os.path.join(G.GOLDEN, "synth", name + ".stdout"))
+    assert G.check_getsv_against_golden(junctions, folded, golden) == 7 * len(junctions)
+    # the same through host batches cut at awkward places
+    cuts = [0, 777, w.n_total // 2 + 3, w.n_total]
+    hbs = [split_batch(hb, cuts[i], cuts[i + 1]) for i in range(3)]
+    assert_tables_equal(ctx.getclip(hbs), d)
+    hdr.close()
+
+
+def test_full_size_properties(ctx):
+    """Size-independent checks on a batch too large for the reference fixtures: clip-event conservation, support sums,
+    depth linearity (two passes over the same batch double every sum) and agreement with the oracle."""
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 64, depth=30, n_sv=300)
+    n = min(w.n_total, 6_000_000)
+    db, tensors = w.generate_device(0, n, 0)
+    d = ctx.getclip([db])
+    assert int(d["support"].sum()) == d["n_events"]
+    key = d["tid"].astype(np.int64) << 33 | (d["side"] == ord("3")).astype(np.int64) << 32 | d["pos"].astype(np.int64)
+    assert np.all(np.diff(key) >= 0)
+    hb = w.generate_host(0, n)
+    assert_tables_equal(d, O.getclip([hb]))
+    hdr = host.Header(w.names, w.lens)
+    rc, npairs, mean, sd = ctx.isize_stats([db], 20, 5000000)
+    assert (rc, npairs, mean, sd) == O.isize_stats([hb], 20, 5000000)
+    plan = host.Plan(hdr, w.junctions, mean, sd)
+    c1, r1, p1 = ctx.discordant_and_depth([db], plan, mean, sd, 20, hdr.target_lens)
+    c2, r2, p2 = ctx.discordant_and_depth([db, db], plan, mean, sd, 20, hdr.target_lens)
+    assert np.array_equal(2 * c1, c2) and np.array_equal(2 * r1, r2) and np.array_equal(2 * p1, p2)
+    oc = O.discordant([hb], plan.junctions, mean, sd, 4, 20)
+    ors, opd, _ = O.depth([hb], plan.windows, plan.ranges, plan.points, 20)
+    assert np.array_equal(c1, oc) and np.array_equal(r1, ors) and np.array_equal(p1, opd)
+    assert c1.sum() > 0 and r1.sum() > 0
+    plan.close(), hdr.close()
