@@ -69,6 +69,9 @@ typedef struct {
 int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int64_t n_junctions,
                      const char *const *extra_point_chr, const int32_t *extra_point_pos, int64_t n_extra_points,
                      int32_t mean, int32_t sd, int32_t times, int32_t flank_length, ssvh_plan **out);
+/* New insert-size statistics: recompute the junction windows only (everything about depth is independent of them), so a
+ * driver can build the plan while the GPU is still busy with the insert-size pass. */
+int ssvh_plan_update_isize(ssvh_plan *p, int32_t mean, int32_t sd, int32_t times);
 void ssvh_plan_destroy(ssvh_plan *p);
 
 /* Device-facing tables (host memory owned by the plan). */

@@ -171,6 +171,7 @@ def host_lib():
         lib.ssvh_plan_create.argtypes = [C.c_void_p, C.POINTER(JunctionIn), C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int64,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         lib.ssvh_plan_destroy.argtypes = [C.c_void_p]
+        lib.ssvh_plan_update_isize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         for f in ("junctions", "windows", "ranges", "points"):
             fn = getattr(lib, "ssvh_plan_" + f)
             fn.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]

@@ -27,14 +27,16 @@ struct DevBatch {
 	int32_t max_ref_span;
 };
 
-constexpr int CLIP_ITEMS = 4;
-constexpr int CLIP_TILE = BLOCK * CLIP_ITEMS; // 1024 records per tile: every streamed load is <= 16 B per lane, fully coalesced
+constexpr int CS_ITEMS = 4;                           // records per lane per sub-tile: every streamed load is <= 16 B per lane, fully coalesced
+constexpr int CS_SUB = 4;                             // sub-tiles per tile
+constexpr int CS_TILE = BLOCK * CS_ITEMS * CS_SUB;    // 4096 records per workgroup iteration, one barrier each
+constexpr int CS_MAX_BLOCKS = 2048;                   // persistent grid: 256 CUs x 8 workgroups
 
-// one clip event as staged by the scan kernel (order restored afterwards from tile + slot)
+// one clip event as produced by the filter kernel (two stash slots per candidate record)
 struct StagedEvent {
 	uint64_t key;    // tid << 33 | side << 32 | pos1   (side 0 = '5' / breakpoint2read_l, 1 = '3' / breakpoint2read_r)
 	uint32_t rec;    // record index inside the batch
-	uint32_t tile;
+	uint32_t pad0;
 	int32_t begin;   // first query base of seq_left  (GetSeq's begin_pos)
 	int32_t ll, lr;  // |seq_left|, |seq_right|
 	int32_t lq;      // l_qseq
@@ -43,28 +45,38 @@ struct StagedEvent {
 };
 
 struct ClipCounters {
-	unsigned long long stage_cursor; // staging slots handed out
-	unsigned long long seq_bytes;    // packed bases + qualities of all events of this batch
-	unsigned long long cig_ops;
-	unsigned long long max_key;
+	unsigned long long n_cand;       // candidates of the batch (total of the tile-count scan)
+	unsigned long long n_new;        // events of the batch (total of the per-candidate count scan)
+	unsigned long long max_key;      // filled by k_event_max (grid-level reduction, a few hundred atomics)
+	unsigned long long seq_total;    // running totals written by the offset scans
+	unsigned long long cig_total;
 	int max_ll, max_lr;
 	int overflow;
 	int pad;
 };
 
+// K1 clip_scan arguments: the streaming pass only needs the CIGAR arrays
 struct ClipScanArgs {
+	const uint16_t *n_cigar;
+	const uint32_t *cigar_off;
+	const uint32_t *cigar;
+	int64_t n;
+	uint32_t *tile_cnt;      // [ntiles] candidates per tile
+	uint32_t *tile_off;      // [ntiles] where the tile's candidates sit in stage[]
+	uint32_t *stage;         // record indices; workgroup b owns stage[b * block_cap .. (b + 1) * block_cap)
+	int64_t block_cap;
+	int *overflow;
+	int64_t ntiles;
+};
+
+// per-candidate filter arguments (GetSClipReads' predicate chain)
+struct ClipFilterArgs {
 	DevBatch b;
 	int min_mapq;
 	int save_low_quality;
 	int use_ownership;       // range-partitioned runs: keep only events with own_lo <= (tid << 32 | pos1) < own_hi
 	long long own_lo, own_hi;
 	const int *last_tid_in;  // tid of the last mapped-pair record before this batch (clip_reads.h:407: starts at 0)
-	uint32_t *tile_cnt;      // [ntiles] events per tile
-	uint32_t *tile_off;      // [ntiles] staging offset of the tile's events
-	StagedEvent *stage;
-	int64_t stage_cap;
-	ClipCounters *ctr;
-	int64_t ntiles;
 };
 
 // GenerateCigar's l: M, D, =, N advance the reference; X does not (clip_reads.cpp:322)
@@ -81,7 +93,7 @@ __device__ __forceinline__ int ref_len_generate_cigar(const uint32_t *cig, int n
 
 // Decide the 0/1/2 events of record i.  Only called for records whose first or last op is 'S' (about 1 % of a WGS BAM),
 // so everything it touches beyond the CIGAR is a lazy, sparse load.
-__device__ __forceinline__ int clip_events_of(const ClipScanArgs &a, int64_t i, int nc, uint32_t c0, uint32_t cl, StagedEvent ev[2])
+__device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i, int nc, uint32_t c0, uint32_t cl, StagedEvent ev[2])
 {
 	const DevBatch &b = a.b;
 	int op1 = (int)(c0 & 15u), op2 = (int)(cl & 15u);
@@ -138,90 +150,109 @@ __device__ __forceinline__ int clip_events_of(const ClipScanArgs &a, int64_t i, 
 	return n;
 }
 
-// K1 clip_scan: streams n_cigar, cigar_off and the end ops of every record (~10 B/record); everything else is touched
-// only for the ~1 % of records with a soft clip.  Events are staged per tile; k_clip_place restores BAM order.
+// K1 clip_scan: the streaming pass.  Reads n_cigar, cigar_off and the first / last CIGAR op of every record (~10 B/record) and
+// writes the indices of the records that have a soft clip at either end (~1 %) - nothing else.  Persistent workgroups, each with a
+// private staging region (no global atomics); within a tile the candidates keep record order (one packed block scan, one barrier
+// per 4096 records); k_cand_place restores the order across tiles.
 __global__ __launch_bounds__(BLOCK) void k_clip_scan(ClipScanArgs a)
 {
-	__shared__ uint32_t lds[WAVES_PER_BLOCK + 1];
-	__shared__ uint32_t s_off;
-	const DevBatch &b = a.b;
-	for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-		const int64_t i0 = tile * CLIP_TILE + (int64_t)threadIdx.x * CLIP_ITEMS;
-		uint32_t nc[CLIP_ITEMS], off[CLIP_ITEMS];
-		if (i0 + CLIP_ITEMS <= b.n) {
-			ushort4 n4 = *reinterpret_cast<const ushort4 *>(b.n_cigar + i0);
-			uint4 o4 = *reinterpret_cast<const uint4 *>(b.cigar_off + i0);
-			nc[0] = n4.x; nc[1] = n4.y; nc[2] = n4.z; nc[3] = n4.w;
-			off[0] = o4.x; off[1] = o4.y; off[2] = o4.z; off[3] = o4.w;
-		} else {
+	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
+	uint32_t cursor = 0; // workgroup-uniform: every thread tracks it from the block totals
+	int parity = 0;
+	const int64_t region = (int64_t)blockIdx.x * a.block_cap;
+	for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
+		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+		uint32_t nc[CS_SUB][CS_ITEMS], off[CS_SUB][CS_ITEMS];
 #pragma unroll
-			for (int k = 0; k < CLIP_ITEMS; ++k) {
-				bool in = i0 + k < b.n;
-				nc[k] = in ? b.n_cigar[i0 + k] : 0u;
-				off[k] = in ? b.cigar_off[i0 + k] : 0u;
-			}
-		}
-		uint32_t c0[CLIP_ITEMS], cl[CLIP_ITEMS];
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CS_ITEMS);
+			if (i0 + CS_ITEMS <= a.n) {
+				ushort4 n4 = *reinterpret_cast<const ushort4 *>(a.n_cigar + i0);
+				uint4 o4 = *reinterpret_cast<const uint4 *>(a.cigar_off + i0);
+				nc[sub][0] = n4.x; nc[sub][1] = n4.y; nc[sub][2] = n4.z; nc[sub][3] = n4.w;
+				off[sub][0] = o4.x; off[sub][1] = o4.y; off[sub][2] = o4.z; off[sub][3] = o4.w;
+			} else {
 #pragma unroll
-		for (int k = 0; k < CLIP_ITEMS; ++k) {
-			c0[k] = nc[k] ? b.cigar[off[k]] : 0u;
-			cl[k] = nc[k] > 1 ? b.cigar[off[k] + nc[k] - 1] : c0[k];
-		}
-		// phase 1: how many events does each record emit (the full predicate chain runs only for soft-clipped records)
-		int cnt[CLIP_ITEMS];
-		uint32_t mine = 0;
-#pragma unroll
-		for (int k = 0; k < CLIP_ITEMS; ++k) {
-			cnt[k] = 0;
-			// a lone "nS" CIGAR gives negative slice lengths in the reference; like the oracle we emit nothing
-			bool cand = nc[k] >= 2 && ((c0[k] & 15u) == C_S || (cl[k] & 15u) == C_S);
-			if (cand) { StagedEvent tmp[2]; cnt[k] = clip_events_of(a, i0 + k, (int)nc[k], c0[k], cl[k], tmp); }
-			mine += (uint32_t)cnt[k];
-		}
-		uint32_t total;
-		uint32_t ex = block_exclusive_sum(mine, lds, &total);
-		if (threadIdx.x == 0) {
-			uint32_t so = 0;
-			if (total) {
-				unsigned long long s = atomicAdd(&a.ctr->stage_cursor, (unsigned long long)total);
-				if (s + total > (unsigned long long)a.stage_cap) { atomicExch(&a.ctr->overflow, 1); so = 0xffffffffu; }
-				else so = (uint32_t)s;
-			}
-			a.tile_cnt[tile] = total;
-			a.tile_off[tile] = so;
-			s_off = so;
-		}
-		__syncthreads();
-		const uint32_t so = s_off;
-		// phase 2: the (rare) emitting lanes rebuild their events and write them to the tile's staging slots in record order
-		if (mine && so != 0xffffffffu) {
-			unsigned long long sb = 0, co = 0, mk = 0;
-			int mll = 0, mlr = 0;
-			uint32_t slot = so + ex;
-#pragma unroll
-			for (int k = 0; k < CLIP_ITEMS; ++k) {
-				if (!cnt[k]) continue;
-				StagedEvent ev[2];
-				int ne = clip_events_of(a, i0 + k, (int)nc[k], c0[k], cl[k], ev);
-				for (int e = 0; e < ne; ++e) {
-					StagedEvent x = ev[e];
-					x.tile = (uint32_t)tile;
-					a.stage[slot++] = x;
-					sb += (unsigned long long)((x.lq + 1) / 2 + x.lq);
-					co += x.ncig;
-					mk = x.key > mk ? x.key : mk;
-					mll = x.ll > mll ? x.ll : mll;
-					mlr = x.lr > mlr ? x.lr : mlr;
+				for (int k = 0; k < CS_ITEMS; ++k) {
+					bool in = i0 + k < a.n;
+					nc[sub][k] = in ? a.n_cigar[i0 + k] : 0u;
+					off[sub][k] = in ? a.cigar_off[i0 + k] : 0u;
 				}
 			}
-			atomicAdd(&a.ctr->seq_bytes, sb);
-			atomicAdd(&a.ctr->cig_ops, co);
-			atomicMax(&a.ctr->max_key, mk);
-			atomicMax(&a.ctr->max_ll, mll);
-			atomicMax(&a.ctr->max_lr, mlr);
 		}
-		__syncthreads(); // s_off reused by the next tile
+		uint32_t mask = 0; // bit (sub * 4 + k): record is a clip candidate
+		uint64_t packed = 0;
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+#pragma unroll
+			for (int k = 0; k < CS_ITEMS; ++k) {
+				// a lone "nS" CIGAR gives negative slice lengths in the reference; like the oracle we emit nothing for it
+				uint32_t n = nc[sub][k];
+				uint32_t c0 = n >= 2 ? a.cigar[off[sub][k]] : 0u;
+				uint32_t cl = n >= 2 ? a.cigar[off[sub][k] + n - 1] : 0u;
+				bool cand = n >= 2 && ((c0 & 15u) == C_S || (cl & 15u) == C_S);
+				mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
+				packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
+			}
+		}
+		// packed block scan: four 16-bit per-sub-tile counters in one 64-bit word
+		uint64_t inc = wave_inclusive_sum(packed);
+		if (lane_id() == 63) lds[parity][wave_id()] = inc;
+		__syncthreads();
+		uint64_t base = 0, tot = 0;
+#pragma unroll
+		for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+			uint64_t x = lds[parity][w];
+			if (w < wave_id()) base += x;
+			tot += x;
+		}
+		const uint64_t ex = base + inc - packed;
+		const uint32_t total = (uint32_t)(tot & 0xffff) + (uint32_t)((tot >> 16) & 0xffff) + (uint32_t)((tot >> 32) & 0xffff) + (uint32_t)(tot >> 48);
+		const bool fits = (int64_t)cursor + total <= a.block_cap;
+		if (threadIdx.x == 0) {
+			a.tile_cnt[tile] = total;
+			a.tile_off[tile] = (uint32_t)(region + cursor);
+			if (!fits) *a.overflow = 1;
+		}
+		if (mask && fits) {
+			uint32_t sub_base = 0;
+#pragma unroll
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				uint32_t slot = cursor + sub_base + (uint32_t)((ex >> (16 * sub)) & 0xffff);
+#pragma unroll
+				for (int k = 0; k < CS_ITEMS; ++k)
+					if (mask & (1u << (sub * CS_ITEMS + k))) a.stage[region + slot++] = (uint32_t)(t0 + (int64_t)sub * (BLOCK * CS_ITEMS) + k);
+				sub_base += (uint32_t)((tot >> (16 * sub)) & 0xffff);
+			}
+		}
+		if (fits) cursor += total;
 	}
+}
+
+// candidates of tile t: stage[tile_off[t] ..] -> cand[tile_base[t] ..]; one wavefront per tile
+__global__ __launch_bounds__(BLOCK) void k_cand_place(const uint32_t *__restrict__ stage, const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off,
+                                                      const uint32_t *__restrict__ tile_base, int64_t ntiles, uint32_t *__restrict__ cand)
+{
+	int64_t t = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (t >= ntiles) return;
+	const uint32_t n = tile_cnt[t], so = tile_off[t], db = tile_base[t];
+	for (uint32_t k = lane_id(); k < n; k += WAVE) cand[db + k] = stage[so + k];
+}
+
+// K1b clip_filter: one thread per candidate record runs GetSClipReads' predicate chain (flag, contig-switch rule, MAPQ, DUP, XC,
+// hard clips) and leaves its 0, 1 or 2 events in the candidate's two stash slots.
+__global__ void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ cand, int64_t n_cand, StagedEvent *__restrict__ stash, uint32_t *__restrict__ cnt)
+{
+	int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_cand) return;
+	const int64_t i = cand[c];
+	const int nc = a.b.n_cigar[i];
+	const uint32_t off = a.b.cigar_off[i];
+	const uint32_t c0 = a.b.cigar[off], cl = a.b.cigar[off + nc - 1];
+	StagedEvent ev[2];
+	int n = clip_events_of(a, i, nc, c0, cl, ev);
+	for (int e = 0; e < n; ++e) stash[2 * c + e] = ev[e];
+	cnt[c] = (uint32_t)n;
 }
 
 // tid of the last mapped-pair record of the batch -> *last_tid (unchanged when there is none)
@@ -251,18 +282,37 @@ struct EventArrays {
 	uint32_t *src_cig;       // scratch: offset in the batch's cigar
 };
 
-// staged slot s -> final position ev_base + tile_base[tile] + (s - tile_off[tile])
-__global__ void k_clip_place(const StagedEvent *__restrict__ stage, int64_t n_staged, const uint32_t *__restrict__ tile_base,
-                             const uint32_t *__restrict__ tile_off, DevBatch b, EventArrays ev, int64_t ev_base)
+// candidate c's events -> final, BAM-ordered position ev_base + ev_off[c] + e
+__global__ void k_clip_place(const StagedEvent *__restrict__ stash, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ ev_off, int64_t n_cand,
+                             DevBatch b, EventArrays ev, int64_t ev_base)
 {
-	int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= n_staged) return;
-	StagedEvent x = stage[s];
-	int64_t e = ev_base + tile_base[x.tile] + (s - tile_off[x.tile]);
-	ev.key[e] = x.key; ev.begin[e] = x.begin; ev.ll[e] = x.ll; ev.lr[e] = x.lr; ev.lq[e] = x.lq; ev.ncig[e] = x.ncig;
-	ev.seq_bytes[e] = (uint32_t)((x.lq + 1) / 2 + x.lq);
-	ev.src_seq[e] = b.seq_off[x.rec];
-	ev.src_cig[e] = b.cigar_off[x.rec];
+	int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_cand) return;
+	const uint32_t n = cnt[c];
+	for (uint32_t k = 0; k < n; ++k) {
+		StagedEvent x = stash[2 * c + k];
+		int64_t e = ev_base + ev_off[c] + k;
+		ev.key[e] = x.key; ev.begin[e] = x.begin; ev.ll[e] = x.ll; ev.lr[e] = x.lr; ev.lq[e] = x.lq; ev.ncig[e] = x.ncig;
+		ev.seq_bytes[e] = (uint32_t)((x.lq + 1) / 2 + x.lq);
+		ev.src_seq[e] = b.seq_off[x.rec];
+		ev.src_cig[e] = b.cigar_off[x.rec];
+	}
+}
+
+// largest key / slice lengths of the batch's events: grid-stride partial maxima, one atomic per wave
+__global__ __launch_bounds__(BLOCK) void k_event_max(EventArrays ev, int64_t ev_base, int64_t n_new, ClipCounters *ctr)
+{
+	unsigned long long mk = 0;
+	int mll = 0, mlr = 0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += (int64_t)gridDim.x * blockDim.x) {
+		int64_t e = ev_base + i;
+		unsigned long long k = ev.key[e];
+		mk = k > mk ? k : mk;
+		mll = ev.ll[e] > mll ? ev.ll[e] : mll;
+		mlr = ev.lr[e] > mlr ? ev.lr[e] : mlr;
+	}
+	mk = wave_max(mk); mll = wave_max(mll); mlr = wave_max(mlr);
+	if (lane_id() == 0) { atomicMax(&ctr->max_key, mk); atomicMax(&ctr->max_ll, mll); atomicMax(&ctr->max_lr, mlr); }
 }
 
 // K2 clip_gather: one wavefront per event copies its packed bases, qualities and CIGAR into context-owned blobs so that

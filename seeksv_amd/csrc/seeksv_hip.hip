@@ -61,7 +61,7 @@ struct ssv_ctx {
 	// ---- getclip ----
 	bool clip_active = false;
 	ssv_clip_params clip_p{};
-	DBuf d_last_tid, stage;
+	DBuf d_last_tid, stage, cand, cand_cnt, cand_off, stash;
 	int64_t stage_cap = 0;
 	DBuf ev_key, ev_begin, ev_ll, ev_lr, ev_lq, ev_ncig, ev_seq_bytes, ev_seq_off, ev_cig_off, ev_src_seq, ev_src_cig;
 	int64_t ev_cap = 0, n_events = 0;
@@ -304,7 +304,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->st);
 	// every DBuf / HBuf member
-	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->ev_key, &c->ev_begin, &c->ev_ll,
+	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_tid,
 	                 &c->o_pos, &c->o_side, &c->o_support, &c->o_ll, &c->o_lr, &c->o_qmiss, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_ncig, &c->o_stroff, &c->o_cigoff, &c->o_str,
@@ -362,58 +362,84 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 	DevBatch d;
 	CHECK(stage_batch(c, b, d));
 	if (!d.cigar || !d.seq_off) { c->err = "batch without cigar / seq_off"; return SSV_E_ARG; }
-	const int64_t ntiles = (d.n + CLIP_TILE - 1) / CLIP_TILE;
+	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
+	const unsigned grid = (unsigned)std::min<int64_t>(ntiles, CS_MAX_BLOCKS);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
 	CHECK(ensure(c, c->tile_off, ntiles * 4));
 	CHECK(ensure(c, c->tile_base, ntiles * 4));
 	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(std::max<int64_t>(ntiles, 1)) * 4));
-	if (c->stage_cap == 0) c->stage_cap = std::max<int64_t>(1 << 16, d.n / 16);
+	if (c->stage_cap == 0) c->stage_cap = std::max<int64_t>(1 << 16, d.n / 8);
 	ClipCounters *hc = P<ClipCounters>(c->h_counters);
+	ClipCounters *dc = P<ClipCounters>(c->counters);
 	for (int attempt = 0;; ++attempt) {
-		CHECK(ensure(c, c->stage, (size_t)c->stage_cap * sizeof(StagedEvent)));
+		const int64_t block_cap = (c->stage_cap + grid - 1) / grid;
+		CHECK(ensure(c, c->stage, (size_t)block_cap * grid * 4));
 		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
 		ClipScanArgs a;
-		a.b = d; a.min_mapq = c->clip_p.min_mapq; a.save_low_quality = c->clip_p.save_low_quality; a.last_tid_in = P<int>(c->d_last_tid);
-		a.use_ownership = c->clip_p.use_ownership;
-		a.own_lo = ((long long)c->clip_p.own_lo_tid << 32) | (long long)(uint32_t)c->clip_p.own_lo_pos;
-		a.own_hi = ((long long)c->clip_p.own_hi_tid << 32) | (long long)(uint32_t)c->clip_p.own_hi_pos;
-		a.tile_cnt = P<uint32_t>(c->tile_cnt); a.tile_off = P<uint32_t>(c->tile_off); a.stage = P<StagedEvent>(c->stage); a.stage_cap = c->stage_cap;
-		a.ctr = P<ClipCounters>(c->counters); a.ntiles = ntiles;
+		a.n_cigar = d.n_cigar; a.cigar_off = d.cigar_off; a.cigar = d.cigar; a.n = d.n;
+		a.tile_cnt = P<uint32_t>(c->tile_cnt); a.tile_off = P<uint32_t>(c->tile_off); a.stage = P<uint32_t>(c->stage); a.block_cap = block_cap;
+		a.overflow = &dc->overflow; a.ntiles = ntiles;
 		{
 			ProfScope ps(c, P_CLIP_SCAN, d.n);
-			unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * 8);
 			k_clip_scan<<<grid, BLOCK, 0, c->st>>>(a);
 		}
 		HIPCHECK(c, hipGetLastError());
+		// order across tiles: exclusive scan of the tile counts; its total is the number of candidates
+		exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_base), ntiles, 0u, P<uint32_t>(c->scan_scratch), reinterpret_cast<uint32_t *>(&dc->n_cand));
 		HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
 		HIPCHECK(c, hipStreamSynchronize(c->st));
 		if (!hc->overflow) break;
-		if (attempt > 2) { c->err = "clip staging overflow"; return SSV_E_HIP; }
-		c->stage_cap = (int64_t)hc->stage_cursor + 1024; // the cursor kept counting: this is the exact need
+		if (attempt > 4) { c->err = "clip staging overflow"; return SSV_E_HIP; }
+		c->stage_cap = std::max<int64_t>(c->stage_cap * 4, (int64_t)(uint32_t)hc->n_cand * 4); // a workgroup's private region was too small
 	}
-	const int64_t nb = (int64_t)hc->stage_cursor;
-	if (nb > 0) {
-		ProfScope ps(c, P_CLIP_PLACE, nb);
-		CHECK(ensure_events(c, c->n_events + nb));
-		exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_base), ntiles, 0u, P<uint32_t>(c->scan_scratch), nullptr);
-		EventArrays ev = event_arrays(c);
-		k_clip_place<<<grid_for(nb, BLOCK), BLOCK, 0, c->st>>>(P<StagedEvent>(c->stage), nb, P<uint32_t>(c->tile_base), P<uint32_t>(c->tile_off), d, ev, c->n_events);
-		CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nb) * 8));
-		exclusive_scan<uint32_t, uint64_t>(c->st, ev.seq_bytes + c->n_events, ev.seq_off + c->n_events, nb, c->seq_used, P<uint64_t>(c->scan_scratch64), nullptr);
-		exclusive_scan<uint32_t, uint64_t>(c->st, ev.ncig + c->n_events, ev.cig_off + c->n_events, nb, c->cig_used, P<uint64_t>(c->scan_scratch64), nullptr);
-		HIPCHECK(c, hipGetLastError());
-	}
-	if (nb > 0) {
-		ProfScope ps(c, P_CLIP_GATHER, nb);
-		CHECK(ensure(c, c->seq_blob, c->seq_used + hc->seq_bytes + 16, true, c->seq_used));
-		CHECK(ensure(c, c->cig_blob, (c->cig_used + hc->cig_ops) * 4 + 16, true, c->cig_used * 4));
-		k_clip_gather<<<grid_for(nb, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob));
-		HIPCHECK(c, hipGetLastError());
+	const int64_t ncand = (int64_t)(uint32_t)hc->n_cand;
+	if (ncand > 0) {
+		int64_t nb = 0;
+		{
+			ProfScope ps(c, P_CLIP_PLACE, ncand);
+			CHECK(ensure(c, c->cand, ncand * 4)); CHECK(ensure(c, c->cand_cnt, ncand * 4)); CHECK(ensure(c, c->cand_off, ncand * 4));
+			CHECK(ensure(c, c->stash, (size_t)ncand * 2 * sizeof(StagedEvent)));
+			CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(ncand) * 4));
+			CHECK(ensure_events(c, c->n_events + 2 * ncand));
+			k_cand_place<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<uint32_t>(c->stage), P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_off), P<uint32_t>(c->tile_base), ntiles,
+			                                                                    P<uint32_t>(c->cand));
+			ClipFilterArgs f;
+			f.b = d; f.min_mapq = c->clip_p.min_mapq; f.save_low_quality = c->clip_p.save_low_quality; f.last_tid_in = P<int>(c->d_last_tid);
+			f.use_ownership = c->clip_p.use_ownership;
+			f.own_lo = ((long long)c->clip_p.own_lo_tid << 32) | (long long)(uint32_t)c->clip_p.own_lo_pos;
+			f.own_hi = ((long long)c->clip_p.own_hi_tid << 32) | (long long)(uint32_t)c->clip_p.own_hi_pos;
+			k_clip_filter<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(f, P<uint32_t>(c->cand), ncand, P<StagedEvent>(c->stash), P<uint32_t>(c->cand_cnt));
+			exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->cand_cnt), P<uint32_t>(c->cand_off), ncand, 0u, P<uint32_t>(c->scan_scratch), reinterpret_cast<uint32_t *>(&dc->n_new));
+			EventArrays ev = event_arrays(c);
+			k_clip_place<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(P<StagedEvent>(c->stash), P<uint32_t>(c->cand_cnt), P<uint32_t>(c->cand_off), ncand, d, ev, c->n_events);
+			HIPCHECK(c, hipGetLastError());
+			HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
+			HIPCHECK(c, hipStreamSynchronize(c->st));
+			nb = (int64_t)(uint32_t)hc->n_new;
+			if (nb > 0) {
+				CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nb) * 8));
+				exclusive_scan<uint32_t, uint64_t>(c->st, ev.seq_bytes + c->n_events, ev.seq_off + c->n_events, nb, c->seq_used, P<uint64_t>(c->scan_scratch64),
+				                                   reinterpret_cast<uint64_t *>(&dc->seq_total));
+				exclusive_scan<uint32_t, uint64_t>(c->st, ev.ncig + c->n_events, ev.cig_off + c->n_events, nb, c->cig_used, P<uint64_t>(c->scan_scratch64),
+				                                   reinterpret_cast<uint64_t *>(&dc->cig_total));
+				k_event_max<<<(unsigned)std::min<int64_t>(256, (nb + BLOCK - 1) / BLOCK), BLOCK, 0, c->st>>>(ev, c->n_events, nb, dc);
+				HIPCHECK(c, hipGetLastError());
+				HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
+				HIPCHECK(c, hipStreamSynchronize(c->st));
+			}
+		}
+		if (nb > 0) {
+			ProfScope ps(c, P_CLIP_GATHER, nb);
+			CHECK(ensure(c, c->seq_blob, hc->seq_total + 16, true, c->seq_used));
+			CHECK(ensure(c, c->cig_blob, hc->cig_total * 4 + 16, true, c->cig_used * 4));
+			k_clip_gather<<<grid_for(nb, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob));
+			HIPCHECK(c, hipGetLastError());
+			c->n_events += nb; c->seq_used = hc->seq_total; c->cig_used = hc->cig_total;
+			c->max_key = std::max<uint64_t>(c->max_key, hc->max_key); c->max_ll = std::max(c->max_ll, hc->max_ll); c->max_lr = std::max(c->max_lr, hc->max_lr);
+		}
 	}
 	k_last_tid<<<1, BLOCK, 0, c->st>>>(d, P<int>(c->d_last_tid));
 	HIPCHECK(c, hipGetLastError());
-	c->n_events += nb; c->seq_used += hc->seq_bytes; c->cig_used += hc->cig_ops;
-	c->max_key = std::max<uint64_t>(c->max_key, hc->max_key); c->max_ll = std::max(c->max_ll, hc->max_ll); c->max_lr = std::max(c->max_lr, hc->max_lr);
 	return SSV_OK;
 }
 

@@ -94,22 +94,31 @@ def read_bam(path, batch_records=1 << 20):
         return r.target_names, r.target_lens, batches
 
 
+class JunctionTable:
+    """ctypes form of a junction list (built once, reusable across Plan objects)."""
+
+    def __init__(self, junctions):
+        n = len(junctions)
+        self.n = n
+        self.arr = (_abi.JunctionIn * max(n, 1))()
+        self._keep = {}
+        for i, (uc, up, us, dc, dp, ds) in enumerate(junctions):
+            ucb = self._keep.setdefault(uc, uc.encode())
+            dcb = self._keep.setdefault(dc, dc.encode())
+            a = self.arr[i]
+            a.up_chr, a.down_chr, a.up_pos, a.down_pos, a.up_strand, a.down_strand = ucb, dcb, up, dp, us.encode(), ds.encode()
+
+
 class Plan:
     """Junction list -> device query tables and back (ssvh_plan_*): GetBreak / MergeOverlap /
     FindDiscordantReadPairs window arithmetic / main_depth lookup rules of the reference."""
 
     def __init__(self, bam, junctions, mean, sd, times=4, flank_length=200, extra_points=()):
-        """junctions: list of (up_chr, up_pos, up_strand, down_chr, down_pos, down_strand) in Junction order."""
+        """junctions: list of (up_chr, up_pos, up_strand, down_chr, down_pos, down_strand) in Junction order, or a JunctionTable."""
         self._lib = _abi.host_lib()
-        n = len(junctions)
-        arr = (_abi.JunctionIn * max(n, 1))()
-        self._keep = []
-        for i, (uc, up, us, dc, dp, ds) in enumerate(junctions):
-            ucb, dcb = uc.encode(), dc.encode()
-            self._keep += [ucb, dcb]
-            arr[i].up_chr, arr[i].down_chr = ucb, dcb
-            arr[i].up_pos, arr[i].down_pos = up, dp
-            arr[i].up_strand, arr[i].down_strand = us.encode(), ds.encode()
+        jt = junctions if isinstance(junctions, JunctionTable) else JunctionTable(junctions)
+        self._jt = jt
+        n, arr = jt.n, jt.arr
         ne = len(extra_points)
         echr = (C.c_char_p * max(ne, 1))(*[c.encode() for c, _ in extra_points])
         epos = (C.c_int32 * max(ne, 1))(*[p for _, p in extra_points])
@@ -132,6 +141,11 @@ class Plan:
             return np.zeros(0, dtype=dt)
         buf = (C.c_uint8 * (n.value * dt.itemsize)).from_address(ptr)
         return np.frombuffer(buf, dtype=dt, count=n.value).copy()
+
+    def update_isize(self, mean, sd, times=4):
+        """New insert-size statistics -> new junction windows (the depth tables do not depend on them)."""
+        self._lib.ssvh_plan_update_isize(self._h, mean, sd, times)
+        self.junctions = self._table("junctions", _abi.JUNCTION_DTYPE)
 
     def fold(self, counts, range_sum, point_depth, prev_counts=None):
         """-> dict(abnormal, up_depth, down_depth, flank[J,4], flank_len[J,4], extra_point_depth)"""
