@@ -26,11 +26,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-# Bytes each streaming kernel MUST read per record with the implemented (lazy) algorithm - DESIGN.md "Kernels":
-#   clip_scan : n_cigar 2 + cigar_off 4 + first/last CIGAR op 4.1 (avg 1.03 ops/record)          = 10.1 B
-#   getsv_scan: tid 4 + pos 4 (everything else only for the few % of records near a window)      =  8.0 B
-# (SURVEY 8d's eager figures are 21 B and 15+27 B; the kernels read less than that by design.)
-ALGO_BYTES = {"clip_scan": 10.1, "getsv_scan": 8.0}
+# HBM bytes each kernel group must move per unit with the implemented algorithm (DESIGN.md "Kernels"); unit = what the group's
+# launch processes (records for the streaming passes, clip events / clusters for the rest).
+#   clip_scan   : n_cigar 2 + cigar_off 4 per record, + first/last op 8 for the ~3 % of records with >= 2 CIGAR ops      = 6.3 B/record
+#                 (SURVEY 8d's eager figure is 21 B/record: the kernel reads less by evaluating flag/MAPQ/tid/pos lazily)
+#   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                        = 8.0 B/record
+#   clip_gather : packed bases+qualities 228 read + 228 written, CIGAR 8 + 8                                             = 472 B/event
+#   event_sort  : 5 radix passes x (12 B histogram read + 12 B read + 12 B written)                                       = 180 B/event
+#   cluster_pack: 228 read + 2*(ll+lr) ~ 300 written + ~70 B of per-cluster columns                                       = 600 B/cluster-slot
+ALGO_BYTES = {"clip_scan": 6.3, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 600.0}
 
 
 def main():
@@ -170,17 +174,21 @@ def main():
     ctx.prof_reset()
     ctx.prof_enable(1)
     step(wall)
-    breakdown = {k: round(v["total_ms"], 4) for k, v in ctx.prof_all().items() if v["launches"]}
+    allprof = ctx.prof_all()
+    breakdown = {k: round(v["total_ms"], 4) for k, v in allprof.items() if v["launches"]}
     ctx.prof_enable(0)
 
     if rank == 0:
         assert res["support_sum"] == res["n_events"], "clip events were lost or duplicated"
         total_records = w.n_total
         ms_per_step = dt / args.steps * 1e3
-        dom = max(prof, key=lambda k: prof[k]["total_ms"])
-        launches = max(prof[dom]["launches"], 1)
-        avg_ms = prof[dom]["total_ms"] / launches
-        units = prof[dom]["units"] / launches
+        # dominant kernel = the longest-running kernel group of the device path that streams HBM (PCIe copies excluded)
+        cand = {k: v for k, v in allprof.items() if k in ALGO_BYTES and v["launches"]}
+        dom = max(cand, key=lambda k: cand[k]["total_ms"] / cand[k]["launches"])
+        src = prof[dom] if dom in prof and prof[dom]["launches"] else allprof[dom]  # streaming kernels: averaged over the timed region
+        launches = max(src["launches"], 1)
+        avg_ms = src["total_ms"] / launches
+        units = src["units"] / launches
         achieved = ALGO_BYTES[dom] * units / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -202,9 +210,9 @@ def main():
                        "generation_s": round(gen_s, 2)},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_record": ALGO_BYTES[dom], "records_per_launch": units, "avg_launch_ms": avg_ms,
-                         "other": {k: {"avg_launch_ms": prof[k]["total_ms"] / max(prof[k]["launches"], 1),
-                                       "achieved_GBs": ALGO_BYTES[k] * (prof[k]["units"] / max(prof[k]["launches"], 1)) / (prof[k]["total_ms"] / max(prof[k]["launches"], 1) * 1e-3) / 1e9}
-                                   for k in prof if prof[k]["launches"]}},
+                         "other": {k: {"avg_launch_ms": round(v["total_ms"] / v["launches"], 4), "units": v["units"] // v["launches"],
+                                       "achieved_GBs": round(ALGO_BYTES[k] * (v["units"] / v["launches"]) / (v["total_ms"] / v["launches"] * 1e-3) / 1e9, 1)}
+                                   for k, v in cand.items()}},
             "kernel_ms_one_step": breakdown,
             "wall_ms_one_step": {k: round(v, 3) for k, v in wall.items()},
             "result": res,

@@ -47,6 +47,8 @@ typedef enum {
  *   by l_qseq quality bytes, or SSV_NO_SEQ when the batcher did not ship them.  The batcher must
  *   ship them for every record whose first or last CIGAR operation is 'S' (only those can become
  *   clip events, clip_reads.cpp:124,150); it may omit all others.
+ *   A SSV_MEM_DEVICE batch must leave at least 8 readable bytes after seqqual[seqqual_bytes - 1] (the gather kernel
+ *   copies whole aligned dwords).
  */
 #define SSV_NO_SEQ UINT64_MAX
 typedef struct {

@@ -293,7 +293,7 @@ __global__ void k_clip_place(const StagedEvent *__restrict__ stash, const uint32
 		StagedEvent x = stash[2 * c + k];
 		int64_t e = ev_base + ev_off[c] + k;
 		ev.key[e] = x.key; ev.begin[e] = x.begin; ev.ll[e] = x.ll; ev.lr[e] = x.lr; ev.lq[e] = x.lq; ev.ncig[e] = x.ncig;
-		ev.seq_bytes[e] = (uint32_t)((x.lq + 1) / 2 + x.lq);
+		ev.seq_bytes[e] = ((uint32_t)((x.lq + 1) / 2 + x.lq) + 3u) & ~3u; // entries of the context blob are 4-byte aligned
 		ev.src_seq[e] = b.seq_off[x.rec];
 		ev.src_cig[e] = b.cigar_off[x.rec];
 	}
@@ -316,16 +316,23 @@ __global__ __launch_bounds__(BLOCK) void k_event_max(EventArrays ev, int64_t ev_
 }
 
 // K2 clip_gather: one wavefront per event copies its packed bases, qualities and CIGAR into context-owned blobs so that
-// the batch buffers can be recycled.
+// the batch buffers can be recycled.  Destination entries start 4-byte aligned (sizes are padded when the offsets are scanned);
+// the source may start anywhere, so every lane assembles one aligned output dword from two aligned source dwords.
 __global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays ev, int64_t ev_base, int64_t n_new, uint8_t *__restrict__ seq_blob, uint32_t *__restrict__ cig_blob)
 {
 	int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
 	if (w >= n_new) return;
 	int64_t e = ev_base + w;
 	const uint8_t *src = b.seqqual + ev.src_seq[e];
-	uint8_t *dst = seq_blob + ev.seq_off[e];
-	uint32_t nb = ev.seq_bytes[e];
-	for (uint32_t k = lane_id(); k < nb; k += WAVE) dst[k] = src[k];
+	uint32_t *dst = reinterpret_cast<uint32_t *>(seq_blob + ev.seq_off[e]);
+	const uint32_t nb = ev.seq_bytes[e];          // padded to a multiple of 4
+	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
+	const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src - mis);
+	for (uint32_t k = lane_id(); k < nb / 4; k += WAVE) {
+		uint32_t lo = s4[k];
+		uint32_t hi = mis ? s4[k + 1] : 0u;       // reads at most 3 bytes past the entry: the batcher's blob is padded by the library / caller by >= 4 bytes
+		dst[k] = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+	}
 	const uint32_t *cs = b.cigar + ev.src_cig[e];
 	uint32_t *cd = cig_blob + ev.cig_off[e];
 	uint32_t nc = ev.ncig[e];
@@ -351,7 +358,9 @@ struct ClusterArgs {
 	int32_t *c_ll, *c_lr;  // [E]
 	uint32_t *c_cig_ev;    // [E] event whose CIGAR the cluster carries
 	uint8_t *c_qmiss;      // [E]
-	uint8_t *strings;      // [E * stride]: left seq (reversed), left qual (reversed), right seq, right qual
+	const uint32_t *mflag; // [E] 1: the slot belongs to a bin with more than one event
+	const uint32_t *mslot; // [E] exclusive scan of mflag: index of the slot's string storage
+	uint8_t *strings;      // [M * stride]: left seq (reversed), left qual (reversed), right seq, right qual - multi-event bins only
 	int32_t SL, SR;        // capacity of a left / right string
 };
 
@@ -368,6 +377,25 @@ struct EventView {
 	__device__ __forceinline__ char qual(int p) const { return qmiss ? '*' : (char)(qp[p] + 33); }
 };
 
+// Classify the sorted slots.  A bin with a single event (97 % of a WGS sample: random clips) needs no clustering: its cluster is
+// the event itself, recorded here; only bins with several events go through k_cluster_bins and get string storage.
+__global__ void k_bin_mark(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm, int64_t E, EventArrays ev, const uint8_t *__restrict__ seq_blob,
+                           uint32_t *__restrict__ mflag, int32_t *__restrict__ support, int32_t *__restrict__ c_ll, int32_t *__restrict__ c_lr,
+                           uint32_t *__restrict__ c_cig_ev, uint8_t *__restrict__ c_qmiss)
+{
+	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= E) return;
+	const uint64_t k = skey[j];
+	const bool single = (j == 0 || skey[j - 1] != k) && (j + 1 == E || skey[j + 1] != k);
+	mflag[j] = single ? 0u : 1u;
+	if (single) {
+		const uint32_t e = perm[j];
+		const int lq = ev.lq[e];
+		support[j] = 1; c_ll[j] = ev.ll[e]; c_lr[j] = ev.lr[e]; c_cig_ev[j] = e;
+		c_qmiss[j] = (lq > 0 && seq_blob[ev.seq_off[e] + (uint64_t)((lq + 1) / 2)] == 0xff) ? 1 : 0;
+	} else support[j] = 0;
+}
+
 // One wavefront per bin (= run of equal keys in the sorted event list).  The wave walks the bin's events in BAM order -
 // the order the reference's multimap::equal_range scan sees them - and keeps the evolving clusters in HBM; lanes are
 // spread over bases, match counts come from ballots.  Bins are independent, so there is no cross-wave communication.
@@ -376,6 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 	__shared__ int32_t s_slot[WAVES_PER_BLOCK][CL_CACHE];
 	const int64_t j0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
 	if (j0 >= a.E) return;
+	if (!a.mflag[j0]) return;                      // single-event bin: nothing to cluster (k_bin_mark filled its slot)
 	const uint64_t key0 = a.skey[j0];
 	if (j0 > 0 && a.skey[j0 - 1] == key0) return; // not the start of a bin
 	const int lane = lane_id();
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 		v.qmiss = lq > 0 && v.qp[0] == 0xff;
 		// ---- find the first cluster of the bin that absorbs this event (clip_reads.cpp:262-273) ----
 		auto absorbs = [&](int64_t slot) -> bool {
-			const uint8_t *cs = a.strings + slot * stride;
+			const uint8_t *cs = a.strings + (int64_t)a.mslot[slot] * stride;
 			const int cll = a.c_ll[slot], clr = a.c_lr[slot];
 			const int n1 = v.ll < cll ? v.ll : cll;
 			int m1 = 0;
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 		}
 		if (hit >= 0) {
 			// ---- ReadsInfo::ChangeSeqAndQual (clip_reads.cpp:57-108) on the reversed-left / forward-right storage ----
-			uint8_t *cs = a.strings + hit * stride;
+			uint8_t *cs = a.strings + (int64_t)a.mslot[hit] * stride;
 			uint8_t *cq = cs + a.SL, *rs = cs + 2 * a.SL, *rq = rs + a.SR;
 			const int cll = a.c_ll[hit], clr = a.c_lr[hit];
 			const int n1 = v.ll < cll ? v.ll : cll;
@@ -456,7 +485,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 			a.support[hit] += 1; // every lane stores the same value; each lane later reads back what it stored
 		} else {
 			// ---- new cluster at this event's slot (clip_reads.cpp:276-281) ----
-			uint8_t *cs = a.strings + jj * stride;
+			uint8_t *cs = a.strings + (int64_t)a.mslot[jj] * stride;
 			uint8_t *cq = cs + a.SL, *rs = cs + 2 * a.SL, *rq = rs + a.SR;
 			for (int i = lane; i < v.ll; i += WAVE) { int p = v.lpos(i); cs[i] = (uint8_t)v.base(p); cq[i] = (uint8_t)v.qual(p); }
 			for (int i = lane; i < v.lr; i += WAVE) { int p = v.rpos(i); rs[i] = (uint8_t)v.base(p); rq[i] = (uint8_t)v.qual(p); }
@@ -513,21 +542,34 @@ __global__ void k_cluster_pack_meta(PackArgs p)
 	p.ncig64[c] = nc;
 }
 
-// one wavefront per cluster: strings (left part un-reversed) and the CIGAR of the carrying event into dense blobs
+// one wavefront per cluster: strings and the CIGAR of the carrying event into dense blobs.  Single-event clusters are decoded
+// straight from the event's packed bases / qualities (GetSeq, clip_reads.cpp:286-306); clusters of multi-event bins are copied from
+// their consensus storage (left part un-reversed).
 __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
                                                                 const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
 {
 	int64_t c = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
 	if (c >= n_clusters) return;
 	const int64_t j = p.slot[c];
-	const int64_t stride = 2ll * (p.c.SL + p.c.SR);
-	const uint8_t *cs = p.c.strings + j * stride;
-	const uint8_t *cq = cs + p.c.SL, *rs = cs + 2 * p.c.SL, *rq = rs + p.c.SR;
 	const int ll = p.ll[c], lr = p.lr[c];
 	uint8_t *d = out_str + str_off[c];
-	for (int i = lane_id(); i < ll; i += WAVE) { d[i] = cs[ll - 1 - i]; d[ll + i] = cq[ll - 1 - i]; }
-	for (int i = lane_id(); i < lr; i += WAVE) { d[2 * ll + i] = rs[i]; d[2 * ll + lr + i] = rq[i]; }
 	const uint32_t e = p.c.c_cig_ev[j];
+	if (!p.c.mflag[j]) {
+		EventView v;
+		const int lq = p.c.ev.lq[e];
+		v.sp = p.c.seq_blob + p.c.ev.seq_off[e];
+		v.qp = v.sp + (lq + 1) / 2;
+		v.begin = p.c.ev.begin[e]; v.ll = ll; v.lr = lr;
+		v.qmiss = lq > 0 && v.qp[0] == 0xff;
+		for (int i = lane_id(); i < ll; i += WAVE) { int q = v.begin + i; d[i] = (uint8_t)v.base(q); d[ll + i] = (uint8_t)v.qual(q); }
+		for (int i = lane_id(); i < lr; i += WAVE) { int q = v.begin + ll + i; d[2 * ll + i] = (uint8_t)v.base(q); d[2 * ll + lr + i] = (uint8_t)v.qual(q); }
+	} else {
+		const int64_t stride = 2ll * (p.c.SL + p.c.SR);
+		const uint8_t *cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
+		const uint8_t *cq = cs + p.c.SL, *rs = cs + 2 * p.c.SL, *rq = rs + p.c.SR;
+		for (int i = lane_id(); i < ll; i += WAVE) { d[i] = cs[ll - 1 - i]; d[ll + i] = cq[ll - 1 - i]; }
+		for (int i = lane_id(); i < lr; i += WAVE) { d[2 * ll + i] = rs[i]; d[2 * ll + lr + i] = rq[i]; }
+	}
 	const uint32_t *src = cig_blob + p.c.ev.cig_off[e];
 	uint32_t *dc = out_cig + cig_off[c];
 	const int nc = p.ncig[c];

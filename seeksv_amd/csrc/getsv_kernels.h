@@ -241,45 +241,104 @@ __device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int 
 	}
 }
 
-constexpr int GS_ITEMS = 4;
-constexpr int GS_TILE = BLOCK * GS_ITEMS;
-
-// Streams tid and pos of every record (8 B/record) and looks the record's start tile up in the genome tile map (L2 resident,
-// wave-coherent because the BAM is coordinate sorted).  Only records that start near a depth window / junction window - a few
-// per cent - take the slow paths, which load the remaining fields lazily.
-__global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, int64_t ntiles)
+// tile-map lookup of one record: which slow paths (if any) it needs
+__device__ __forceinline__ uint32_t getsv_tile_bits(const GetsvArgs &a, int tid, int pos)
 {
+	if (tid < 0 || tid >= a.n_targets || pos < 0) return 0;
+	int64_t t = a.ctg_tile_off[tid] + (pos >> TILE_SHIFT);
+	return t < a.ctg_tile_off[tid + 1] ? a.tilemap[t] : 0u;
+}
+
+struct GetsvStage {
+	uint32_t *tile_cnt, *tile_off, *stage;
+	int64_t block_cap;
+	int *overflow;
+	int64_t ntiles;
+};
+
+// K5/K7 getsv_scan, the streaming pass: reads tid and pos of every record (8 B/record), looks the record's start tile up in the
+// genome tile map (L2 resident, wave-coherent because the BAM is coordinate sorted) and writes the indices of the ~1 % of records
+// that start near a depth window or a junction window.  Same persistent, atomic-free structure as k_clip_scan.
+__global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
+{
+	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
 	const DevBatch &b = a.b;
-	for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const int64_t i0 = tile * GS_TILE + (int64_t)threadIdx.x * GS_ITEMS;
-		int tid[GS_ITEMS], pos[GS_ITEMS];
-		if (i0 + GS_ITEMS <= b.n) {
-			int4 t4 = *reinterpret_cast<const int4 *>(b.tid + i0);
-			int4 p4 = *reinterpret_cast<const int4 *>(b.pos + i0);
-			tid[0] = t4.x; tid[1] = t4.y; tid[2] = t4.z; tid[3] = t4.w;
-			pos[0] = p4.x; pos[1] = p4.y; pos[2] = p4.z; pos[3] = p4.w;
-		} else {
+	uint32_t cursor = 0;
+	int parity = 0;
+	const int64_t region = (int64_t)blockIdx.x * g.block_cap;
+	for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, parity ^= 1) {
+		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+		uint32_t mask = 0;
+		uint64_t packed = 0;
 #pragma unroll
-			for (int k = 0; k < GS_ITEMS; ++k) {
-				bool in = i0 + k < b.n;
-				tid[k] = in ? b.tid[i0 + k] : -1;
-				pos[k] = in ? b.pos[i0 + k] : 0;
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CS_ITEMS);
+			int tid[CS_ITEMS], pos[CS_ITEMS];
+			if (i0 + CS_ITEMS <= b.n) {
+				int4 t4 = *reinterpret_cast<const int4 *>(b.tid + i0);
+				int4 p4 = *reinterpret_cast<const int4 *>(b.pos + i0);
+				tid[0] = t4.x; tid[1] = t4.y; tid[2] = t4.z; tid[3] = t4.w;
+				pos[0] = p4.x; pos[1] = p4.y; pos[2] = p4.z; pos[3] = p4.w;
+			} else {
+#pragma unroll
+				for (int k = 0; k < CS_ITEMS; ++k) {
+					bool in = i0 + k < b.n;
+					tid[k] = in ? b.tid[i0 + k] : -1;
+					pos[k] = in ? b.pos[i0 + k] : 0;
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < CS_ITEMS; ++k) {
+				bool cand = getsv_tile_bits(a, tid[k], pos[k]) != 0;
+				mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
+				packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
 			}
 		}
-		uint8_t m[GS_ITEMS];
+		uint64_t inc = wave_inclusive_sum(packed);
+		if (lane_id() == 63) lds[parity][wave_id()] = inc;
+		__syncthreads();
+		uint64_t base = 0, tot = 0;
 #pragma unroll
-		for (int k = 0; k < GS_ITEMS; ++k) {
-			m[k] = 0;
-			if (tid[k] >= 0 && tid[k] < a.n_targets && pos[k] >= 0) {
-				int64_t t = a.ctg_tile_off[tid[k]] + (pos[k] >> TILE_SHIFT);
-				if (t < a.ctg_tile_off[tid[k] + 1]) m[k] = a.tilemap[t];
+		for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+			uint64_t x = lds[parity][w];
+			if (w < wave_id()) base += x;
+			tot += x;
+		}
+		const uint64_t ex = base + inc - packed;
+		const uint32_t total = (uint32_t)(tot & 0xffff) + (uint32_t)((tot >> 16) & 0xffff) + (uint32_t)((tot >> 32) & 0xffff) + (uint32_t)(tot >> 48);
+		const bool fits = (int64_t)cursor + total <= g.block_cap;
+		if (threadIdx.x == 0) {
+			g.tile_cnt[tile] = fits ? total : 0u;
+			g.tile_off[tile] = (uint32_t)(region + cursor);
+			if (!fits) *g.overflow = 1;
+		}
+		if (mask && fits) {
+			uint32_t sub_base = 0;
+#pragma unroll
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				uint32_t slot = cursor + sub_base + (uint32_t)((ex >> (16 * sub)) & 0xffff);
+#pragma unroll
+				for (int k = 0; k < CS_ITEMS; ++k)
+					if (mask & (1u << (sub * CS_ITEMS + k))) g.stage[region + slot++] = (uint32_t)(t0 + (int64_t)sub * (BLOCK * CS_ITEMS) + k);
+				sub_base += (uint32_t)((tot >> (16 * sub)) & 0xffff);
 			}
 		}
-#pragma unroll
-		for (int k = 0; k < GS_ITEMS; ++k) {
-			if (m[k] & TM_JUNC) discordant_record(a, i0 + k, tid[k], pos[k]);
-			if (m[k] & TM_DEPTH) depth_record(a, i0 + k, tid[k], pos[k]);
-		}
+		if (fits) cursor += total;
+	}
+}
+
+// the slow paths, one thread per staged record (a wavefront walks one tile's candidates): discordant tally and / or depth coverage
+__global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
+{
+	int64_t t = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (t >= g.ntiles) return;
+	const uint32_t n = g.tile_cnt[t], so = g.tile_off[t];
+	for (uint32_t k = lane_id(); k < n; k += WAVE) {
+		const int64_t i = g.stage[so + k];
+		const int tid = a.b.tid[i], pos = a.b.pos[i];
+		const uint32_t m = getsv_tile_bits(a, tid, pos);
+		if (m & TM_JUNC) discordant_record(a, i, tid, pos);
+		if (m & TM_DEPTH) depth_record(a, i, tid, pos);
 	}
 }
 

@@ -24,9 +24,9 @@ namespace {
 std::string g_create_error;
 
 // timed kernel groups (ssv_prof_*)
-enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_ISIZE, P_GETSV_SCAN, P_DEPTH_FINISH, P_COUNT };
-const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "isize_stats", "getsv_scan", "depth_finish"};
-const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\nisize_stats\ngetsv_scan\ndepth_finish";
+enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_COUNT };
+const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "table_d2h", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish"};
+const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\ntable_d2h\nisize_stats\ngetsv_scan\ngetsv_cand\ndepth_finish";
 
 struct DBuf { // grow-only device buffer
 	void *p = nullptr;
@@ -70,7 +70,7 @@ struct ssv_ctx {
 	uint64_t max_key = 0;
 	int max_ll = 0, max_lr = 0;
 	// clustering temporaries / outputs
-	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_strings, c_flag, c_idx;
+	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_strings, c_flag, c_idx;
 	DBuf o_tid, o_pos, o_side, o_support, o_ll, o_lr, o_qmiss, o_slot, o_strbytes, o_ncig64, o_ncig, o_stroff, o_cigoff, o_str, o_cig, totals;
 	HBuf h_tid, h_pos, h_side, h_support, h_ll, h_lr, h_qmiss, h_stroff, h_cigoff, h_ncig, h_str, h_cig, h_totals;
 
@@ -306,7 +306,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_tid,
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_tid,
 	                 &c->o_pos, &c->o_side, &c->o_support, &c->o_ll, &c->o_lr, &c->o_qmiss, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_ncig, &c->o_stroff, &c->o_cigoff, &c->o_str,
 	                 &c->o_cig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap,
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
@@ -478,7 +478,7 @@ int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
 		cur = radix_sort_pairs(c->st, keys, vals, E, key_bits, P<uint32_t>(c->ghist), P<uint32_t>(c->scan_scratch));
 		HIPCHECK(c, hipGetLastError());
 	}
-	// ---- greedy consensus clustering, one wavefront per bin ----
+	// ---- greedy consensus clustering, one wavefront per multi-event bin ----
 	ClusterArgs ca;
 	ca.skey = P<uint64_t>(c->keys2[cur]); ca.perm = P<uint32_t>(c->vals2[cur]); ca.E = E; ca.ev = ev; ca.seq_blob = P<uint8_t>(c->seq_blob);
 	ca.match_rate = c->clip_p.match_rate;
@@ -487,15 +487,24 @@ int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
 	{
 		ProfScope ps(c, P_CLUSTER_BINS, E);
 		CHECK(ensure(c, c->c_support, E * 4)); CHECK(ensure(c, c->c_ll, E * 4)); CHECK(ensure(c, c->c_lr, E * 4)); CHECK(ensure(c, c->c_cig_ev, E * 4));
-		CHECK(ensure(c, c->c_qmiss, E)); CHECK(ensure(c, c->c_strings, (size_t)E * stride));
-		HIPCHECK(c, hipMemsetAsync(c->c_support.p, 0, E * 4, c->st));
+		CHECK(ensure(c, c->c_qmiss, E)); CHECK(ensure(c, c->c_mflag, E * 4)); CHECK(ensure(c, c->c_mslot, E * 4));
+		CHECK(ensure(c, c->totals, 64)); CHECK(ensure_host(c, c->h_totals, 64));
+		CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(E) * 4));
 		ca.support = P<int32_t>(c->c_support); ca.c_ll = P<int32_t>(c->c_ll); ca.c_lr = P<int32_t>(c->c_lr); ca.c_cig_ev = P<uint32_t>(c->c_cig_ev);
-		ca.c_qmiss = P<uint8_t>(c->c_qmiss); ca.strings = P<uint8_t>(c->c_strings);
-		k_cluster_bins<<<grid_for(E, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
+		ca.c_qmiss = P<uint8_t>(c->c_qmiss); ca.mflag = P<uint32_t>(c->c_mflag); ca.mslot = P<uint32_t>(c->c_mslot);
+		k_bin_mark<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.skey, ca.perm, E, ev, ca.seq_blob, P<uint32_t>(c->c_mflag), ca.support, ca.c_ll, ca.c_lr, ca.c_cig_ev, ca.c_qmiss);
+		exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_mflag), P<uint32_t>(c->c_mslot), E, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
+		HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+		const int64_t M = *P<uint32_t>(c->h_totals); // events in multi-event bins: only they need consensus storage
+		CHECK(ensure(c, c->c_strings, (size_t)std::max<int64_t>(M, 1) * stride));
+		ca.strings = P<uint8_t>(c->c_strings);
+		if (M > 0) k_cluster_bins<<<grid_for(E, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
 		HIPCHECK(c, hipGetLastError());
 	}
 	// ---- compact the clusters into a dense table ----
-	ProfScope ps(c, P_CLUSTER_PACK, E);
+	ProfScope *pack_scope = new ProfScope(c, P_CLUSTER_PACK, E);
+	struct ScopeGuard { ProfScope *&p; ~ScopeGuard() { delete p; p = nullptr; } } pack_guard{pack_scope};
 	CHECK(ensure(c, c->c_flag, E * 4)); CHECK(ensure(c, c->c_idx, E * 4));
 	CHECK(ensure(c, c->totals, 64)); CHECK(ensure_host(c, c->h_totals, 64));
 	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(E) * 4));
@@ -528,13 +537,17 @@ int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
 	k_cluster_pack_strings<<<grid_for(nc, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(c->o_stroff), P<uint64_t>(c->o_cigoff), P<uint32_t>(c->cig_blob),
 	                                                                          P<uint8_t>(c->o_str), P<uint32_t>(c->o_cig));
 	HIPCHECK(c, hipGetLastError());
+	delete pack_scope; pack_scope = nullptr; // the copy below is PCIe time, not kernel time
 	struct { HBuf *h; DBuf *d; size_t bytes; } cp[] = {
 		{&c->h_tid, &c->o_tid, (size_t)nc * 4}, {&c->h_pos, &c->o_pos, (size_t)nc * 4}, {&c->h_side, &c->o_side, (size_t)nc}, {&c->h_support, &c->o_support, (size_t)nc * 4},
 		{&c->h_ll, &c->o_ll, (size_t)nc * 4}, {&c->h_lr, &c->o_lr, (size_t)nc * 4}, {&c->h_qmiss, &c->o_qmiss, (size_t)nc}, {&c->h_stroff, &c->o_stroff, (size_t)nc * 8},
 		{&c->h_cigoff, &c->o_cigoff, (size_t)nc * 8}, {&c->h_ncig, &c->o_ncig, (size_t)nc * 4}, {&c->h_str, &c->o_str, (size_t)str_total}, {&c->h_cig, &c->o_cig, (size_t)cig_total * 4}};
-	for (auto &x : cp) {
-		CHECK(ensure_host(c, *x.h, x.bytes + 16));
-		if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st));
+	{
+		ProfScope pd(c, P_TABLE_D2H, nc);
+		for (auto &x : cp) {
+			CHECK(ensure_host(c, *x.h, x.bytes + 16));
+			if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st));
+		}
 	}
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	out->tid = P<int32_t>(c->h_tid); out->pos = P<int32_t>(c->h_pos); out->side = P<uint8_t>(c->h_side); out->support = P<int32_t>(c->h_support);
@@ -722,11 +735,36 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	a.counts = P<int32_t>(c->gs_counts);
 	a.win_tid = P<int32_t>(c->gs_wtid); a.win_beg = P<int32_t>(c->gs_wbeg); a.win_end = P<int32_t>(c->gs_wend); a.win_off = P<int64_t>(c->gs_woff);
 	a.n_win = (int64_t)c->gs_win.size(); a.depth_min_mapq = c->gs_p.depth_min_mapq; a.diff = P<int32_t>(c->gs_diff);
-	const int64_t ntiles = (d.n + GS_TILE - 1) / GS_TILE;
+	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
+	const unsigned grid = (unsigned)std::min<int64_t>(ntiles, CS_MAX_BLOCKS);
+	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
+	CHECK(ensure(c, c->tile_off, ntiles * 4));
+	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
+	CHECK(ensure_host(c, c->h_counters, sizeof(ClipCounters)));
+	if (c->stage_cap == 0) c->stage_cap = std::max<int64_t>(1 << 16, d.n / 8);
+	ClipCounters *hc = P<ClipCounters>(c->h_counters);
+	ClipCounters *dc = P<ClipCounters>(c->counters);
+	GetsvStage g;
+	for (int attempt = 0;; ++attempt) {
+		const int64_t block_cap = (c->stage_cap + grid - 1) / grid;
+		CHECK(ensure(c, c->stage, (size_t)block_cap * grid * 4));
+		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
+		g.tile_cnt = P<uint32_t>(c->tile_cnt); g.tile_off = P<uint32_t>(c->tile_off); g.stage = P<uint32_t>(c->stage); g.block_cap = block_cap;
+		g.overflow = &dc->overflow; g.ntiles = ntiles;
+		{
+			ProfScope ps(c, P_GETSV_SCAN, d.n);
+			k_getsv_scan<<<grid, BLOCK, 0, c->st>>>(a, g);
+		}
+		HIPCHECK(c, hipGetLastError());
+		HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+		if (!hc->overflow) break;
+		if (attempt > 6) { c->err = "getsv staging overflow"; return SSV_E_HIP; }
+		c->stage_cap *= 4; // a workgroup's private region was too small for the records near its windows
+	}
 	{
-		ProfScope ps(c, P_GETSV_SCAN, d.n);
-		unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * 8);
-		k_getsv_scan<<<grid, BLOCK, 0, c->st>>>(a, ntiles);
+		ProfScope ps(c, P_GETSV_CAND, d.n);
+		k_getsv_cand<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(a, g);
 	}
 	HIPCHECK(c, hipGetLastError());
 	return SSV_OK;

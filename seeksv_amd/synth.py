@@ -175,7 +175,7 @@ class Workload:
                          ("mtid", torch.int32), ("mpos", torch.int32), ("isize", torch.int32)):
             t[name] = torch.empty(n, dtype=dt, device=dev)
         t["cigar"] = torch.empty(max(nct.value, 4), dtype=torch.int32, device=dev)
-        t["seqqual"] = torch.empty(max(sqb.value, 16), dtype=torch.uint8, device=dev)
+        t["seqqual"] = torch.empty(sqb.value + 16, dtype=torch.uint8, device=dev)
         rc = lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, t["tid"].data_ptr(), t["pos"].data_ptr(), t["flag"].data_ptr(), t["mapq"].data_ptr(),
                            t["n_cigar"].data_ptr(), t["l_qseq"].data_ptr(), t["mtid"].data_ptr(), t["mpos"].data_ptr(), t["isize"].data_ptr(),
                            t["cigar_off"].data_ptr(), t["cigar"].data_ptr(), t["seq_off"].data_ptr(), t["seqqual"].data_ptr())
