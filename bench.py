@@ -28,13 +28,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # HBM bytes each kernel group must move per unit with the implemented algorithm (DESIGN.md "Kernels"); unit = what the group's
 # launch processes (records for the streaming passes, clip events / clusters for the rest).
-#   clip_scan   : n_cigar 2 + cigar_off 4 per record, + first/last op 8 for the ~3 % of records with >= 2 CIGAR ops      = 6.3 B/record
-#                 (SURVEY 8d's eager figure is 21 B/record: the kernel reads less by evaluating flag/MAPQ/tid/pos lazily)
+#   clip_scan   : n_cigar 2 per record - only records with >= 2 CIGAR ops (~3 %) can carry a usable soft clip and go on to       = 2.0 B/record
+#                 clip_filter (SURVEY 8d's eager figure is 21 B/record: everything else is evaluated lazily, per candidate)
 #   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                        = 8.0 B/record
 #   clip_gather : packed bases+qualities 228 read + 228 written, CIGAR 8 + 8                                             = 472 B/event
 #   event_sort  : 5 radix passes x (12 B histogram read + 12 B read + 12 B written)                                       = 180 B/event
 #   cluster_pack: 228 read + 2*(ll+lr) ~ 300 written + ~70 B of per-cluster columns                                       = 600 B/cluster-slot
-ALGO_BYTES = {"clip_scan": 6.3, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 600.0}
+ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 600.0}
 
 
 def main():

@@ -134,7 +134,8 @@ typedef struct {
 	const int32_t *left_len;   /* [n_clusters] |seq_left|  */
 	const int32_t *right_len;  /* [n_clusters] |seq_right| */
 	const uint8_t *qual_missing; /* [n_clusters] 1: reference prints "*" for both qualities */
-	const uint64_t *str_off;   /* [n_clusters] offset into str of: seq_left, qual_left, seq_right, qual_right */
+	const uint64_t *str_off;   /* [n_clusters] offset into str of: seq_left, qual_left, seq_right, qual_right; every block starts
+	                              4-byte aligned and is zero padded to a multiple of 4 bytes */
 	const uint8_t *str;        /* ASCII, not NUL terminated */
 	const uint64_t *cigar_off; /* [n_clusters] offset into cigar */
 	const int32_t *n_cigar;    /* [n_clusters] ops of the record whose CIGAR the cluster carries */

@@ -349,11 +349,11 @@ int orc_getclip(const ssv_batch_t *batches, int n_batches, const ssv_clip_params
 	uint64_t sb = 0, co = 0;
 	for (int64_t k = 0; k < nc; ++k) {
 		const cluster_t *c = &st.cl[st.order[k]];
-		out->str_off[k] = sb; sb += 2ull * (uint64_t)(c->ll + c->lr);
+		out->str_off[k] = sb; sb += (2ull * (uint64_t)(c->ll + c->lr) + 3ull) & ~3ull; /* same layout as ssv_cluster_table: 4-byte aligned blocks */
 		out->cigar_off[k] = co; co += batches[c->batch].n_cigar[c->rec];
 	}
 	out->str_bytes = (int64_t)sb; out->cigar_ops = (int64_t)co;
-	out->str = (uint8_t *)malloc((size_t)sb + 1); out->cigar = (uint32_t *)malloc((size_t)(co + 1) * 4);
+	out->str = (uint8_t *)calloc((size_t)sb + 1, 1); out->cigar = (uint32_t *)malloc((size_t)(co + 1) * 4);
 	for (int64_t k = 0; k < nc; ++k) {
 		const cluster_t *c = &st.cl[st.order[k]];
 		out->tid[k] = st.order_tid[k]; out->pos[k] = c->pos; out->side[k] = st.order_side[k];

@@ -27,10 +27,12 @@ struct DevBatch {
 	int32_t max_ref_span;
 };
 
-constexpr int CS_ITEMS = 4;                           // records per lane per sub-tile: every streamed load is <= 16 B per lane, fully coalesced
+constexpr int CS_ITEMS = 4;                           // getsv scan: records per lane per sub-tile (two 16-byte loads per lane)
 constexpr int CS_SUB = 4;                             // sub-tiles per tile
 constexpr int CS_TILE = BLOCK * CS_ITEMS * CS_SUB;    // 4096 records per workgroup iteration, one barrier each
-constexpr int CS_MAX_BLOCKS = 2048;                   // persistent grid: 256 CUs x 8 workgroups
+constexpr int CC_ITEMS = 8;                           // clip scan: 8 x u16 = one 16-byte load per lane per sub-tile
+constexpr int CC_TILE = BLOCK * CC_ITEMS * CS_SUB;    // 8192 records per workgroup iteration
+constexpr int CS_MAX_BLOCKS = 8192;                   // upper bound of the persistent grid (private staging regions are sized by the actual grid)
 
 // one clip event as produced by the filter kernel (two stash slots per candidate record)
 struct StagedEvent {
@@ -55,11 +57,9 @@ struct ClipCounters {
 	int pad;
 };
 
-// K1 clip_scan arguments: the streaming pass only needs the CIGAR arrays
+// K1 clip_scan arguments: the streaming pass only needs n_cigar
 struct ClipScanArgs {
 	const uint16_t *n_cigar;
-	const uint32_t *cigar_off;
-	const uint32_t *cigar;
 	int64_t n;
 	uint32_t *tile_cnt;      // [ntiles] candidates per tile
 	uint32_t *tile_off;      // [ntiles] where the tile's candidates sit in stage[]
@@ -150,82 +150,86 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 	return n;
 }
 
-// K1 clip_scan: the streaming pass.  Reads n_cigar, cigar_off and the first / last CIGAR op of every record (~10 B/record) and
-// writes the indices of the records that have a soft clip at either end (~1 %) - nothing else.  Persistent workgroups, each with a
-// private staging region (no global atomics); within a tile the candidates keep record order (one packed block scan, one barrier
-// per 4096 records); k_cand_place restores the order across tiles.
+// Shared tail of the two streaming passes: given each lane's candidate bits (bit sub * ITEMS + k) and its per-sub-tile counts
+// packed as four 16-bit fields, give every candidate of the tile a slot in the workgroup's private staging region, in record order.
+// One barrier per tile (double-buffered LDS); the cursor is workgroup-uniform state that every thread tracks from the block totals.
+template <int ITEMS>
+__device__ __forceinline__ void stage_tile_candidates(uint32_t mask, uint64_t packed, int64_t tile, int64_t first_rec_of_lane, uint64_t (&lds)[2][WAVES_PER_BLOCK], int parity,
+                                                      uint32_t &cursor, int64_t region, int64_t block_cap, uint32_t *tile_cnt, uint32_t *tile_off, uint32_t *stage, int *overflow)
+{
+	uint64_t inc = wave_inclusive_sum(packed);
+	if (lane_id() == 63) lds[parity][wave_id()] = inc;
+	__syncthreads();
+	uint64_t base = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+		uint64_t x = lds[parity][w];
+		if (w < wave_id()) base += x;
+		tot += x;
+	}
+	const uint64_t ex = base + inc - packed;
+	const uint32_t total = (uint32_t)(tot & 0xffff) + (uint32_t)((tot >> 16) & 0xffff) + (uint32_t)((tot >> 32) & 0xffff) + (uint32_t)(tot >> 48);
+	const bool fits = (int64_t)cursor + total <= block_cap;
+	if (threadIdx.x == 0) {
+		tile_cnt[tile] = fits ? total : 0u;
+		tile_off[tile] = (uint32_t)(region + cursor);
+		if (!fits) *overflow = 1;
+	}
+	if (mask && fits) {
+		uint32_t sub_base = 0;
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			uint32_t slot = cursor + sub_base + (uint32_t)((ex >> (16 * sub)) & 0xffff);
+#pragma unroll
+			for (int k = 0; k < ITEMS; ++k)
+				if (mask & (1u << (sub * ITEMS + k))) stage[region + slot++] = (uint32_t)(first_rec_of_lane + (int64_t)sub * (BLOCK * ITEMS) + k);
+			sub_base += (uint32_t)((tot >> (16 * sub)) & 0xffff);
+		}
+	}
+	if (fits) cursor += total;
+}
+
+// K1 clip_scan: the streaming pass.  A record can only carry a usable soft clip if its CIGAR has at least two operations (a lone
+// "nS" is skipped like in the oracle), so the pass reads nothing but n_cigar - 2 B/record, one 16-byte load per lane per 8 records,
+// four loads in flight per lane - and writes the indices of the records with n_cigar >= 2 (indels and clips: ~3 % of a WGS BAM).
+// Their CIGAR ends are looked at by k_clip_filter, one thread per candidate.  Persistent workgroups, private staging, no atomics.
 __global__ __launch_bounds__(BLOCK) void k_clip_scan(ClipScanArgs a)
 {
 	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
-	uint32_t cursor = 0; // workgroup-uniform: every thread tracks it from the block totals
+	uint32_t cursor = 0;
 	int parity = 0;
 	const int64_t region = (int64_t)blockIdx.x * a.block_cap;
 	for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
-		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
-		uint32_t nc[CS_SUB][CS_ITEMS], off[CS_SUB][CS_ITEMS];
+		const int64_t t0 = tile * CC_TILE + (int64_t)threadIdx.x * CC_ITEMS;
+		uint4 v[CS_SUB];
+		if ((tile + 1) * CC_TILE <= a.n) { // workgroup-uniform: the whole tile is in range, all four loads issue back to back
 #pragma unroll
-		for (int sub = 0; sub < CS_SUB; ++sub) {
-			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CS_ITEMS);
-			if (i0 + CS_ITEMS <= a.n) {
-				ushort4 n4 = *reinterpret_cast<const ushort4 *>(a.n_cigar + i0);
-				uint4 o4 = *reinterpret_cast<const uint4 *>(a.cigar_off + i0);
-				nc[sub][0] = n4.x; nc[sub][1] = n4.y; nc[sub][2] = n4.z; nc[sub][3] = n4.w;
-				off[sub][0] = o4.x; off[sub][1] = o4.y; off[sub][2] = o4.z; off[sub][3] = o4.w;
-			} else {
+			for (int sub = 0; sub < CS_SUB; ++sub) v[sub] = *reinterpret_cast<const uint4 *>(a.n_cigar + t0 + (int64_t)sub * (BLOCK * CC_ITEMS));
+		} else {
 #pragma unroll
-				for (int k = 0; k < CS_ITEMS; ++k) {
-					bool in = i0 + k < a.n;
-					nc[sub][k] = in ? a.n_cigar[i0 + k] : 0u;
-					off[sub][k] = in ? a.cigar_off[i0 + k] : 0u;
-				}
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CC_ITEMS);
+				uint32_t h[CC_ITEMS];
+#pragma unroll
+				for (int k = 0; k < CC_ITEMS; ++k) h[k] = i0 + k < a.n ? a.n_cigar[i0 + k] : 0u;
+				v[sub] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
 			}
 		}
-		uint32_t mask = 0; // bit (sub * 4 + k): record is a clip candidate
+		uint32_t mask = 0;
 		uint64_t packed = 0;
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) {
+			const uint32_t w4[4] = {v[sub].x, v[sub].y, v[sub].z, v[sub].w};
+			uint32_t bits = 0;
 #pragma unroll
-			for (int k = 0; k < CS_ITEMS; ++k) {
-				// a lone "nS" CIGAR gives negative slice lengths in the reference; like the oracle we emit nothing for it
-				uint32_t n = nc[sub][k];
-				uint32_t c0 = n >= 2 ? a.cigar[off[sub][k]] : 0u;
-				uint32_t cl = n >= 2 ? a.cigar[off[sub][k] + n - 1] : 0u;
-				bool cand = n >= 2 && ((c0 & 15u) == C_S || (cl & 15u) == C_S);
-				mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
-				packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
+			for (int k = 0; k < 4; ++k) {
+				bits |= ((w4[k] & 0xffffu) >= 2u ? 1u : 0u) << (2 * k);
+				bits |= ((w4[k] >> 16) >= 2u ? 1u : 0u) << (2 * k + 1);
 			}
+			mask |= bits << (sub * CC_ITEMS);
+			packed += (uint64_t)__popc(bits) << (16 * sub);
 		}
-		// packed block scan: four 16-bit per-sub-tile counters in one 64-bit word
-		uint64_t inc = wave_inclusive_sum(packed);
-		if (lane_id() == 63) lds[parity][wave_id()] = inc;
-		__syncthreads();
-		uint64_t base = 0, tot = 0;
-#pragma unroll
-		for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
-			uint64_t x = lds[parity][w];
-			if (w < wave_id()) base += x;
-			tot += x;
-		}
-		const uint64_t ex = base + inc - packed;
-		const uint32_t total = (uint32_t)(tot & 0xffff) + (uint32_t)((tot >> 16) & 0xffff) + (uint32_t)((tot >> 32) & 0xffff) + (uint32_t)(tot >> 48);
-		const bool fits = (int64_t)cursor + total <= a.block_cap;
-		if (threadIdx.x == 0) {
-			a.tile_cnt[tile] = total;
-			a.tile_off[tile] = (uint32_t)(region + cursor);
-			if (!fits) *a.overflow = 1;
-		}
-		if (mask && fits) {
-			uint32_t sub_base = 0;
-#pragma unroll
-			for (int sub = 0; sub < CS_SUB; ++sub) {
-				uint32_t slot = cursor + sub_base + (uint32_t)((ex >> (16 * sub)) & 0xffff);
-#pragma unroll
-				for (int k = 0; k < CS_ITEMS; ++k)
-					if (mask & (1u << (sub * CS_ITEMS + k))) a.stage[region + slot++] = (uint32_t)(t0 + (int64_t)sub * (BLOCK * CS_ITEMS) + k);
-				sub_base += (uint32_t)((tot >> (16 * sub)) & 0xffff);
-			}
-		}
-		if (fits) cursor += total;
+		stage_tile_candidates<CC_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, a.block_cap, a.tile_cnt, a.tile_off, a.stage, a.overflow);
 	}
 }
 
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_place(const uint32_t *__restrict
 	for (uint32_t k = lane_id(); k < n; k += WAVE) cand[db + k] = stage[so + k];
 }
 
-// K1b clip_filter: one thread per candidate record runs GetSClipReads' predicate chain (flag, contig-switch rule, MAPQ, DUP, XC,
+// K1b clip_filter: one thread per candidate record (n_cigar >= 2) looks at the CIGAR ends and, for soft-clipped ones, runs GetSClipReads' predicate chain (flag, contig-switch rule, MAPQ, DUP, XC,
 // hard clips) and leaves its 0, 1 or 2 events in the candidate's two stash slots.
 __global__ void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ cand, int64_t n_cand, StagedEvent *__restrict__ stash, uint32_t *__restrict__ cnt)
 {
@@ -250,7 +254,8 @@ __global__ void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ can
 	const uint32_t off = a.b.cigar_off[i];
 	const uint32_t c0 = a.b.cigar[off], cl = a.b.cigar[off + nc - 1];
 	StagedEvent ev[2];
-	int n = clip_events_of(a, i, nc, c0, cl, ev);
+	int n = 0;
+	if ((c0 & 15u) == C_S || (cl & 15u) == C_S) n = clip_events_of(a, i, nc, c0, cl, ev);
 	for (int e = 0; e < n; ++e) stash[2 * c + e] = ev[e];
 	cnt[c] = (uint32_t)n;
 }
@@ -318,25 +323,30 @@ __global__ __launch_bounds__(BLOCK) void k_event_max(EventArrays ev, int64_t ev_
 // K2 clip_gather: one wavefront per event copies its packed bases, qualities and CIGAR into context-owned blobs so that
 // the batch buffers can be recycled.  Destination entries start 4-byte aligned (sizes are padded when the offsets are scanned);
 // the source may start anywhere, so every lane assembles one aligned output dword from two aligned source dwords.
+constexpr int GROUP = 16;                      // lanes that cooperate on one event / cluster in the gather and pack kernels
+constexpr int GROUPS_PER_WAVE = WAVE / GROUP;  // 4 items in flight per wavefront: the per-item metadata loads overlap
+constexpr int GROUPS_PER_BLOCK = BLOCK / GROUP;
+
 __global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays ev, int64_t ev_base, int64_t n_new, uint8_t *__restrict__ seq_blob, uint32_t *__restrict__ cig_blob)
 {
-	int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	const int64_t w = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
 	if (w >= n_new) return;
+	const uint32_t gl = threadIdx.x % GROUP;
 	int64_t e = ev_base + w;
 	const uint8_t *src = b.seqqual + ev.src_seq[e];
 	uint32_t *dst = reinterpret_cast<uint32_t *>(seq_blob + ev.seq_off[e]);
 	const uint32_t nb = ev.seq_bytes[e];          // padded to a multiple of 4
 	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
 	const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src - mis);
-	for (uint32_t k = lane_id(); k < nb / 4; k += WAVE) {
+	for (uint32_t k = gl; k < nb / 4; k += GROUP) {
 		uint32_t lo = s4[k];
-		uint32_t hi = mis ? s4[k + 1] : 0u;       // reads at most 3 bytes past the entry: the batcher's blob is padded by the library / caller by >= 4 bytes
+		uint32_t hi = mis ? s4[k + 1] : 0u;       // may read up to 7 bytes past the entry: see the slack rule in seeksv_hip.h
 		dst[k] = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
 	}
 	const uint32_t *cs = b.cigar + ev.src_cig[e];
 	uint32_t *cd = cig_blob + ev.cig_off[e];
 	uint32_t nc = ev.ncig[e];
-	for (uint32_t k = lane_id(); k < nc; k += WAVE) cd[k] = cs[k];
+	for (uint32_t k = gl; k < nc; k += GROUP) cd[k] = cs[k];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -536,44 +546,68 @@ __global__ void k_cluster_pack_meta(PackArgs p)
 	p.ll[c] = ll; p.lr[c] = lr;
 	p.qmiss[c] = p.c.c_qmiss[j];
 	p.slot[c] = (uint32_t)j;
-	p.str_bytes[c] = 2ull * (uint64_t)(ll + lr);
+	p.str_bytes[c] = (2ull * (uint64_t)(ll + lr) + 3ull) & ~3ull; // blocks start 4-byte aligned
 	uint32_t nc = p.c.ev.ncig[p.c.c_cig_ev[j]];
 	p.ncig[c] = (int32_t)nc;
 	p.ncig64[c] = nc;
 }
 
-// one wavefront per cluster: strings and the CIGAR of the carrying event into dense blobs.  Single-event clusters are decoded
-// straight from the event's packed bases / qualities (GetSeq, clip_reads.cpp:286-306); clusters of multi-event bins are copied from
-// their consensus storage (left part un-reversed).
+// 16 lanes per cluster, four clusters per wavefront: strings and the CIGAR of the carrying event into dense blobs.  Every lane
+// assembles whole output dwords (a cluster's block starts 4-byte aligned and is zero padded to a multiple of 4 bytes):
+// [seq_left | qual_left | seq_right | qual_right].  Single-event clusters are decoded straight from the event's packed bases /
+// qualities (GetSeq, clip_reads.cpp:286-306); clusters of multi-event bins come from their consensus storage (left part un-reversed).
 __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
                                                                 const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
 {
-	int64_t c = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
 	if (c >= n_clusters) return;
+	const int gl = (int)(threadIdx.x % GROUP);
 	const int64_t j = p.slot[c];
 	const int ll = p.ll[c], lr = p.lr[c];
-	uint8_t *d = out_str + str_off[c];
+	const int total = 2 * (ll + lr);
+	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + str_off[c]);
 	const uint32_t e = p.c.c_cig_ev[j];
-	if (!p.c.mflag[j]) {
-		EventView v;
+	const bool single = !p.c.mflag[j];
+	EventView v;
+	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+	if (single) {
 		const int lq = p.c.ev.lq[e];
 		v.sp = p.c.seq_blob + p.c.ev.seq_off[e];
 		v.qp = v.sp + (lq + 1) / 2;
 		v.begin = p.c.ev.begin[e]; v.ll = ll; v.lr = lr;
 		v.qmiss = lq > 0 && v.qp[0] == 0xff;
-		for (int i = lane_id(); i < ll; i += WAVE) { int q = v.begin + i; d[i] = (uint8_t)v.base(q); d[ll + i] = (uint8_t)v.qual(q); }
-		for (int i = lane_id(); i < lr; i += WAVE) { int q = v.begin + ll + i; d[2 * ll + i] = (uint8_t)v.base(q); d[2 * ll + lr + i] = (uint8_t)v.qual(q); }
 	} else {
 		const int64_t stride = 2ll * (p.c.SL + p.c.SR);
-		const uint8_t *cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
-		const uint8_t *cq = cs + p.c.SL, *rs = cs + 2 * p.c.SL, *rq = rs + p.c.SR;
-		for (int i = lane_id(); i < ll; i += WAVE) { d[i] = cs[ll - 1 - i]; d[ll + i] = cq[ll - 1 - i]; }
-		for (int i = lane_id(); i < lr; i += WAVE) { d[2 * ll + i] = rs[i]; d[2 * ll + lr + i] = rq[i]; }
+		cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
+		cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
+	}
+	for (int w = gl; w * 4 < total; w += GROUP) {
+		uint32_t word = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int q = w * 4 + k; // byte position inside the cluster's block
+			uint32_t ch = 0;
+			if (q < total) {
+				if (single) {
+					if (q < ll) ch = (uint8_t)v.base(v.begin + q);
+					else if (q < 2 * ll) ch = (uint8_t)v.qual(v.begin + q - ll);
+					else if (q < 2 * ll + lr) ch = (uint8_t)v.base(v.begin + ll + q - 2 * ll);
+					else ch = (uint8_t)v.qual(v.begin + ll + q - 2 * ll - lr);
+				} else {
+					if (q < ll) ch = cs[ll - 1 - q];
+					else if (q < 2 * ll) ch = cq[ll - 1 - (q - ll)];
+					else if (q < 2 * ll + lr) ch = rs[q - 2 * ll];
+					else ch = rq[q - 2 * ll - lr];
+				}
+			}
+			word |= ch << (8 * k);
+		}
+		d[w] = word;
 	}
 	const uint32_t *src = cig_blob + p.c.ev.cig_off[e];
 	uint32_t *dc = out_cig + cig_off[c];
 	const int nc = p.ncig[c];
-	for (int i = lane_id(); i < nc; i += WAVE) dc[i] = src[i];
+	for (int i = gl; i < nc; i += GROUP) dc[i] = src[i];
 }
 
 } // namespace ssv

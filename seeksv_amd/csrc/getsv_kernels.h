@@ -256,9 +256,10 @@ struct GetsvStage {
 	int64_t ntiles;
 };
 
-// K5/K7 getsv_scan, the streaming pass: reads tid and pos of every record (8 B/record), looks the record's start tile up in the
-// genome tile map (L2 resident, wave-coherent because the BAM is coordinate sorted) and writes the indices of the ~1 % of records
-// that start near a depth window or a junction window.  Same persistent, atomic-free structure as k_clip_scan.
+// K5/K7 getsv_scan, the streaming pass: reads tid and pos of every record (8 B/record, eight 16-byte loads in flight per lane), looks
+// the record's start tile up in the genome tile map (L2 resident, wave-coherent because the BAM is coordinate sorted) and writes the
+// indices of the ~1 % of records that start near a depth window or a junction window.  Same persistent, atomic-free structure as
+// k_clip_scan; the lookups are branch-free (clamped indices) so that they pipeline.
 __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 {
 	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
@@ -266,64 +267,46 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 	uint32_t cursor = 0;
 	int parity = 0;
 	const int64_t region = (int64_t)blockIdx.x * g.block_cap;
+	const int last_tid = a.n_targets - 1;
 	for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, parity ^= 1) {
 		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+		int4 t4[CS_SUB], p4[CS_SUB];
+		if ((tile + 1) * CS_TILE <= b.n) { // workgroup-uniform
+#pragma unroll
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				t4[sub] = *reinterpret_cast<const int4 *>(b.tid + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
+				p4[sub] = *reinterpret_cast<const int4 *>(b.pos + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
+			}
+		} else {
+#pragma unroll
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CS_ITEMS);
+				int tt[CS_ITEMS], pp[CS_ITEMS];
+#pragma unroll
+				for (int k = 0; k < CS_ITEMS; ++k) { bool in = i0 + k < b.n; tt[k] = in ? b.tid[i0 + k] : -1; pp[k] = in ? b.pos[i0 + k] : 0; }
+				t4[sub] = make_int4(tt[0], tt[1], tt[2], tt[3]); p4[sub] = make_int4(pp[0], pp[1], pp[2], pp[3]);
+			}
+		}
 		uint32_t mask = 0;
 		uint64_t packed = 0;
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) {
-			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CS_ITEMS);
-			int tid[CS_ITEMS], pos[CS_ITEMS];
-			if (i0 + CS_ITEMS <= b.n) {
-				int4 t4 = *reinterpret_cast<const int4 *>(b.tid + i0);
-				int4 p4 = *reinterpret_cast<const int4 *>(b.pos + i0);
-				tid[0] = t4.x; tid[1] = t4.y; tid[2] = t4.z; tid[3] = t4.w;
-				pos[0] = p4.x; pos[1] = p4.y; pos[2] = p4.z; pos[3] = p4.w;
-			} else {
-#pragma unroll
-				for (int k = 0; k < CS_ITEMS; ++k) {
-					bool in = i0 + k < b.n;
-					tid[k] = in ? b.tid[i0 + k] : -1;
-					pos[k] = in ? b.pos[i0 + k] : 0;
-				}
-			}
+			const int tid[CS_ITEMS] = {t4[sub].x, t4[sub].y, t4[sub].z, t4[sub].w};
+			const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
 #pragma unroll
 			for (int k = 0; k < CS_ITEMS; ++k) {
-				bool cand = getsv_tile_bits(a, tid[k], pos[k]) != 0;
+				// clamped, unconditional lookups; validity is applied afterwards
+				const int tc = tid[k] < 0 ? 0 : (tid[k] > last_tid ? last_tid : tid[k]);
+				const int64_t lo = a.ctg_tile_off[tc], hi = a.ctg_tile_off[tc + 1];
+				int64_t t = lo + ((pos[k] < 0 ? 0 : pos[k]) >> TILE_SHIFT);
+				const bool valid = tid[k] >= 0 && tid[k] <= last_tid && pos[k] >= 0 && t < hi;
+				t = t < hi ? t : hi - 1;
+				const bool cand = valid && a.tilemap[t] != 0;
 				mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
 				packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
 			}
 		}
-		uint64_t inc = wave_inclusive_sum(packed);
-		if (lane_id() == 63) lds[parity][wave_id()] = inc;
-		__syncthreads();
-		uint64_t base = 0, tot = 0;
-#pragma unroll
-		for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
-			uint64_t x = lds[parity][w];
-			if (w < wave_id()) base += x;
-			tot += x;
-		}
-		const uint64_t ex = base + inc - packed;
-		const uint32_t total = (uint32_t)(tot & 0xffff) + (uint32_t)((tot >> 16) & 0xffff) + (uint32_t)((tot >> 32) & 0xffff) + (uint32_t)(tot >> 48);
-		const bool fits = (int64_t)cursor + total <= g.block_cap;
-		if (threadIdx.x == 0) {
-			g.tile_cnt[tile] = fits ? total : 0u;
-			g.tile_off[tile] = (uint32_t)(region + cursor);
-			if (!fits) *g.overflow = 1;
-		}
-		if (mask && fits) {
-			uint32_t sub_base = 0;
-#pragma unroll
-			for (int sub = 0; sub < CS_SUB; ++sub) {
-				uint32_t slot = cursor + sub_base + (uint32_t)((ex >> (16 * sub)) & 0xffff);
-#pragma unroll
-				for (int k = 0; k < CS_ITEMS; ++k)
-					if (mask & (1u << (sub * CS_ITEMS + k))) g.stage[region + slot++] = (uint32_t)(t0 + (int64_t)sub * (BLOCK * CS_ITEMS) + k);
-				sub_base += (uint32_t)((tot >> (16 * sub)) & 0xffff);
-			}
-		}
-		if (fits) cursor += total;
+		stage_tile_candidates<CS_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
 	}
 }
 

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -192,6 +193,13 @@ void prof_collect(ssv_ctx *c)
 	c->prof_recs.clear();
 }
 
+// persistent streaming kernels: workgroups per launch (override for experiments: SSV_SCAN_BLOCKS)
+inline unsigned scan_blocks(int64_t ntiles)
+{
+	static int64_t cfg = [] { const char *e = getenv("SSV_SCAN_BLOCKS"); return e ? atoll(e) : (int64_t)1536; }(); // 256 CUs x 6 resident workgroups (SGPR-limited)
+	return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, std::min<int64_t>(cfg, CS_MAX_BLOCKS)));
+}
+
 inline unsigned grid_for(int64_t n, int per_block) { return (unsigned)std::max<int64_t>(1, (n + per_block - 1) / per_block); }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -362,8 +370,8 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 	DevBatch d;
 	CHECK(stage_batch(c, b, d));
 	if (!d.cigar || !d.seq_off) { c->err = "batch without cigar / seq_off"; return SSV_E_ARG; }
-	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
-	const unsigned grid = (unsigned)std::min<int64_t>(ntiles, CS_MAX_BLOCKS);
+	const int64_t ntiles = (d.n + CC_TILE - 1) / CC_TILE;
+	const unsigned grid = scan_blocks(ntiles);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
 	CHECK(ensure(c, c->tile_off, ntiles * 4));
 	CHECK(ensure(c, c->tile_base, ntiles * 4));
@@ -376,7 +384,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 		CHECK(ensure(c, c->stage, (size_t)block_cap * grid * 4));
 		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
 		ClipScanArgs a;
-		a.n_cigar = d.n_cigar; a.cigar_off = d.cigar_off; a.cigar = d.cigar; a.n = d.n;
+		a.n_cigar = d.n_cigar; a.n = d.n;
 		a.tile_cnt = P<uint32_t>(c->tile_cnt); a.tile_off = P<uint32_t>(c->tile_off); a.stage = P<uint32_t>(c->stage); a.block_cap = block_cap;
 		a.overflow = &dc->overflow; a.ntiles = ntiles;
 		{
@@ -432,7 +440,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			ProfScope ps(c, P_CLIP_GATHER, nb);
 			CHECK(ensure(c, c->seq_blob, hc->seq_total + 16, true, c->seq_used));
 			CHECK(ensure(c, c->cig_blob, hc->cig_total * 4 + 16, true, c->cig_used * 4));
-			k_clip_gather<<<grid_for(nb, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob));
+			k_clip_gather<<<grid_for(nb, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob));
 			HIPCHECK(c, hipGetLastError());
 			c->n_events += nb; c->seq_used = hc->seq_total; c->cig_used = hc->cig_total;
 			c->max_key = std::max<uint64_t>(c->max_key, hc->max_key); c->max_ll = std::max(c->max_ll, hc->max_ll); c->max_lr = std::max(c->max_lr, hc->max_lr);
@@ -534,7 +542,7 @@ int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	const uint64_t str_total = P<uint64_t>(c->h_totals)[1], cig_total = P<uint64_t>(c->h_totals)[2];
 	CHECK(ensure(c, c->o_str, str_total + 16)); CHECK(ensure(c, c->o_cig, cig_total * 4 + 16));
-	k_cluster_pack_strings<<<grid_for(nc, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(c->o_stroff), P<uint64_t>(c->o_cigoff), P<uint32_t>(c->cig_blob),
+	k_cluster_pack_strings<<<grid_for(nc, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(c->o_stroff), P<uint64_t>(c->o_cigoff), P<uint32_t>(c->cig_blob),
 	                                                                          P<uint8_t>(c->o_str), P<uint32_t>(c->o_cig));
 	HIPCHECK(c, hipGetLastError());
 	delete pack_scope; pack_scope = nullptr; // the copy below is PCIe time, not kernel time
@@ -736,7 +744,7 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	a.win_tid = P<int32_t>(c->gs_wtid); a.win_beg = P<int32_t>(c->gs_wbeg); a.win_end = P<int32_t>(c->gs_wend); a.win_off = P<int64_t>(c->gs_woff);
 	a.n_win = (int64_t)c->gs_win.size(); a.depth_min_mapq = c->gs_p.depth_min_mapq; a.diff = P<int32_t>(c->gs_diff);
 	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
-	const unsigned grid = (unsigned)std::min<int64_t>(ntiles, CS_MAX_BLOCKS);
+	const unsigned grid = scan_blocks(ntiles);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
 	CHECK(ensure(c, c->tile_off, ntiles * 4));
 	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
@@ -761,6 +769,14 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 		if (!hc->overflow) break;
 		if (attempt > 6) { c->err = "getsv staging overflow"; return SSV_E_HIP; }
 		c->stage_cap *= 4; // a workgroup's private region was too small for the records near its windows
+	}
+	if (getenv("SSV_DEBUG")) {
+		std::vector<uint32_t> tc((size_t)ntiles), to((size_t)ntiles);
+		(void)hipMemcpy(tc.data(), c->tile_cnt.p, ntiles * 4, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(to.data(), c->tile_off.p, ntiles * 4, hipMemcpyDeviceToHost);
+		uint64_t sum = 0; for (uint32_t x : tc) sum += x;
+		fprintf(stderr, "[ssv debug] getsv_scan: n=%lld ntiles=%lld grid=%u block_cap=%lld candidates=%llu first cnt/off=%u/%u span=%d ntargets=%d nwin=%lld njunc=%lld\n", (long long)d.n, (long long)ntiles, grid,
+		        (long long)g.block_cap, (unsigned long long)sum, tc[0], to[0], span, a.n_targets, (long long)a.n_win, (long long)a.n_junc);
 	}
 	{
 		ProfScope ps(c, P_GETSV_CAND, d.n);

@@ -191,7 +191,7 @@ def table_to_dict(t):
                      ("right_len", np.int32), ("qual_missing", np.uint8), ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
         d[name] = arr(getattr(t, name), n, dt)
     if n:
-        sb = int(d["str_off"][-1]) + 2 * int(d["left_len"][-1] + d["right_len"][-1])
+        sb = int(d["str_off"][-1]) + ((2 * int(d["left_len"][-1] + d["right_len"][-1]) + 3) & ~3)
         cb = int(d["cigar_off"][-1]) + int(d["n_cigar"][-1])
     else:
         sb = cb = 0
