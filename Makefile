@@ -11,11 +11,12 @@ HOST_SRC = seeksv_amd/host/bam_reader.cpp seeksv_amd/host/getsv_plan.cpp
 HIP_SRC  = seeksv_amd/csrc/seeksv_hip.hip
 HIP_DEPS = $(wildcard seeksv_amd/csrc/*.h) $(wildcard seeksv_amd/csrc/*.hip) include/seeksv_hip.h
 
-all: host hip synth
+all: host hip synth cli
 
 host: $(LIBDIR)/libseeksv_host.so
 hip: $(LIBDIR)/libseeksv_hip.so
 synth: $(LIBDIR)/libseeksv_synth.so $(LIBDIR)/libseeksv_synth_cpu.so
+cli: seeksv_amd/bin/seeksv
 
 $(LIBDIR)/libseeksv_host.so: $(HOST_SRC) include/seeksv_host.h include/seeksv_hip.h
 	mkdir -p $(LIBDIR)
@@ -24,6 +25,12 @@ $(LIBDIR)/libseeksv_host.so: $(HOST_SRC) include/seeksv_host.h include/seeksv_hi
 $(LIBDIR)/libseeksv_hip.so: $(HIP_DEPS)
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+# the `seeksv` command line (getclip / getsv) over the two libraries
+seeksv_amd/bin/seeksv: seeksv_amd/host/seeksv_cli.cpp $(LIBDIR)/libseeksv_host.so $(LIBDIR)/libseeksv_hip.so
+	mkdir -p seeksv_amd/bin
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ seeksv_amd/host/seeksv_cli.cpp -L$(LIBDIR) -lseeksv_host -lseeksv_hip -lz \
+		-Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,$(ROCM)/lib
 
 # synthetic BAM-record generator: the same source compiled for the GPU (bench) and for the CPU (tests, cpu baseline)
 $(LIBDIR)/libseeksv_synth.so: seeksv_amd/csrc/synth.hip seeksv_amd/csrc/synth_core.h
@@ -43,4 +50,4 @@ oracle-ref:
 clean:
 	rm -rf $(LIBDIR) && $(MAKE) -C oracle clean
 
-.PHONY: all host hip synth oracle oracle-ref clean
+.PHONY: all host hip synth cli oracle oracle-ref clean

@@ -1,0 +1,456 @@
+// seeksv_cli.cpp - the `seeksv` command line on top of libseeksv_host (BAM decoding, getsv bookkeeping) and
+// libseeksv_hip (HIP kernels).  Keeps the reference's sub-commands, flags, defaults, file names, output columns and
+// stderr / stdout messages for the hot path (seeksv.cpp:128-155 CallGetclip, :157-330 CallGetsv):
+//
+//   seeksv getclip [-t f] [-q n] [-s] [-o prefix] in.sorted.bam
+//   seeksv getsv   [options] clip.bam in.sorted.bam clip.gz out.sv out.unmapped.clip.fq
+//
+// getsv in this build takes its junctions from `-B <table>` (the reference's ReadBreakpoint, getsv.cpp:1292); assembling
+// junctions from clip.bam x clip.gz (InputSoftInfoStoreBreakpoint / GetJunction / MergeJunction) is not part of it yet
+// and the program says so instead of producing a different table.  No .bai is needed: the discordant pass scans the BAM.
+#include <getopt.h>
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "seeksv_hip.h"
+#include "seeksv_host.h"
+
+using namespace std;
+
+static const char *kVersion = "1.2.3-mi355x";
+
+[[noreturn]] static void die(const string &msg)
+{
+	cerr << msg << endl;
+	exit(1);
+}
+
+[[noreturn]] static void usage_top()
+{
+	cerr << "Program: seeksv (structural variation / virus integration detection; MI355X build of the soft-clip hot path)\n"
+	     << "Version: " << kVersion << "\n\n"
+	     << "Usage: seeksv <command> [options]\n\n"
+	     << "Command: getclip\tget soft-clipped reads\n"
+	     << "         getsv  \tget final sv" << endl;
+	exit(1);
+}
+
+[[noreturn]] static void usage_getclip()
+{
+	cerr << "Usage: seeksv getclip [options] <input.sorted.bam>\n\n"
+	     << "Options: -t <double>           Threshold of match rate while combining two soft-clipped reads [0.9]\n"
+	     << "         -q <int>              Minimum mapping quality of soft-clipped reads [1]\n"
+	     << "         -s                    Save the low quality sequence clipped before alignment by bwa.\n"
+	     << "         -o <string>           Prefix of output files [output]\n"
+	     << "         -G <int>              GPU ordinal [0]" << endl;
+	exit(1);
+}
+
+[[noreturn]] static void usage_getsv()
+{
+	cerr << "Usage: seeksv getsv [options] <input clipped sequence bam> <input orignal sorted bam> <soft-clipped reads file(*clip.gz)> <output SVs> <output unmaped clipped sequence fastq>\n"
+	     << "Options: -B <FILE>             junction table (23 columns, as written by getsv) to evaluate\n"
+	     << "         -q <int>              Minimum mapping quality of discordant read pair [20]\n"
+	     << "         -n <int>              Number of read pairs used to calculate insert size [5000000]; < 100000 switches the discordant pass off\n"
+	     << "         -b <int>              Minimum number of soft clipping reads (left + right) [3]\n"
+	     << "         -d <int>              Minimum distance between the two breakpoints [50]\n"
+	     << "         -D                    Do not calculate depth of the breakpoints and their ajacency regions (sets -f 0)\n"
+	     << "         -e <int>              Minimum number of read pairs which support the junction [0]\n"
+	     << "         -f <double>           Minimum mutation frequency [0.1]\n"
+	     << "         -T <int>              Maximum length of microhomology [50]\n"
+	     << "         -m <int>              Minimum length of up_seq / down_seq when no read pair supports the junction [30]\n"
+	     << "         -i <int>              Maximum indel number of up_seq / down_seq when no read pair supports the junction [1]\n"
+	     << "         -L <int>              Flank length for the average depths [200]\n"
+	     << "         -l <int> -t <double> -Q <int> -w <int> -F <FILE>   accepted for compatibility (junction assembly options)\n"
+	     << "         -G <int>              GPU ordinal [0]" << endl;
+	exit(1);
+}
+
+static const char CIGAR_CHARS[] = "MIDNSHP=X";
+
+struct GzOut {
+	gzFile f = nullptr;
+	bool open(const string &path) { f = gzopen(path.c_str(), "wb"); return f != nullptr; }
+	void write(const string &s) { if (!s.empty()) gzwrite(f, s.data(), (unsigned)s.size()); }
+	void close() { if (f) gzclose(f); f = nullptr; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// getclip
+// ---------------------------------------------------------------------------------------------------------------------
+
+static int cmd_getclip(int argc, char **argv)
+{
+	int c, min_mapQ = 1, device = 0;
+	double threshold = 0.9;
+	string prefix = "output";
+	bool save_low_quality = false;
+	while ((c = getopt(argc, argv, "t:q:o:sG:")) >= 0) {
+		switch (c) {
+		case 't': threshold = atof(optarg); break;
+		case 'q': min_mapQ = atoi(optarg); break;
+		case 's': save_low_quality = true; break;
+		case 'o': prefix = optarg; break;
+		case 'G': device = atoi(optarg); break;
+		default: usage_getclip();
+		}
+	}
+	if (argc != optind + 1) usage_getclip();
+	const string bamfile = argv[optind];
+
+	ssvh_bam *bam = nullptr;
+	if (ssvh_bam_open(bamfile.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
+	GzOut softfout, fqfout, fuout1, fuout2;
+	const string f_clip = prefix + ".clip.gz", f_fq = prefix + ".clip.fq.gz", f_u1 = prefix + ".unmapped_1.fq.gz", f_u2 = prefix + ".unmapped_2.fq.gz";
+	if (!softfout.open(f_clip)) die("Cannot open file " + f_clip);
+	if (!fqfout.open(f_fq)) die("Cannot open file " + f_fq);
+	if (!fuout1.open(f_u1)) die("Cannot open file " + f_u1);
+	if (!fuout2.open(f_u2)) die("Cannot open file " + f_u2);
+
+	ssv_ctx *ctx = nullptr;
+	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+	ssv_clip_params p;
+	memset(&p, 0, sizeof(p));
+	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
+	if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+
+	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219)
+	map<string, pair<pair<string, string>, char>> id2seq_qual;
+	vector<int32_t> run_tids; // contig of every flush, in order (clip_reads.h:428-438, :442)
+	int32_t last_tid = 0;
+	for (;;) {
+		ssv_batch_t b;
+		if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		if (b.n == 0) break;
+		for (int64_t k = 0, nu = ssvh_bam_unmapped_count(bam); k < nu; ++k) {
+			const char *qname, *seq, *qual; int is_read1;
+			ssvh_bam_unmapped_get(bam, k, &qname, &seq, &qual, &is_read1);
+			auto it = id2seq_qual.find(qname);
+			if (it != id2seq_qual.end()) {
+				if (is_read1 && it->second.second == '2') {
+					fuout1.write(string("@") + it->first + "/1\n" + seq + "\n+\n" + qual + "\n");
+					fuout2.write(string("@") + it->first + "/2\n" + it->second.first.first + "\n+\n" + it->second.first.second + "\n");
+					id2seq_qual.erase(it);
+				} else if (!is_read1 && it->second.second == '1') {
+					fuout1.write(string("@") + it->first + "/1\n" + it->second.first.first + "\n+\n" + it->second.first.second + "\n");
+					fuout2.write(string("@") + it->first + "/2\n" + seq + "\n+\n" + qual + "\n");
+					id2seq_qual.erase(it);
+				}
+			} else id2seq_qual.insert(make_pair(string(qname), make_pair(make_pair(string(seq), string(qual)), is_read1 ? '1' : '2')));
+		}
+		for (int64_t i = 0; i < b.n; ++i) { // the flush sequence, for the stderr messages and the order check
+			if (b.flag[i] & (4 | 8)) continue;
+			if (b.tid[i] != last_tid) { run_tids.push_back(last_tid); last_tid = b.tid[i]; }
+		}
+		if (ssv_clip_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		ssv_sync(ctx);
+	}
+	run_tids.push_back(last_tid);
+	for (size_t k = 1; k < run_tids.size(); ++k)
+		if (run_tids[k] <= run_tids[k - 1]) die("[seeksv] the BAM is not coordinate sorted (contig " + string(ssvh_bam_target_name(bam, run_tids[k]) ? ssvh_bam_target_name(bam, run_tids[k]) : "?") + " appears out of order)");
+
+	ssv_cluster_table t;
+	if (ssv_clip_cluster(ctx, &t) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+	// DisplaySClipReadsAndClipFq ('5' rows then '3' rows per contig run), clip_reads.h:300-345
+	int64_t k = 0;
+	string row, fq;
+	for (int32_t tid : run_tids) {
+		const char *name = ssvh_bam_target_name(bam, tid);
+		cerr << "Output merged soft-clipped reads of " << (name ? name : "") << endl;
+		for (; k < t.n_clusters && t.tid[k] == tid; ++k) {
+			const uint8_t *s = t.str + t.str_off[k];
+			const int ll = t.left_len[k], lr = t.right_len[k];
+			string sl((const char *)s, (size_t)ll), ql((const char *)s + ll, (size_t)ll), sr((const char *)s + 2 * ll, (size_t)lr), qr((const char *)s + 2 * ll + lr, (size_t)lr);
+			if (t.qual_missing[k]) ql = qr = "*";
+			string cig;
+			for (int q = 0; q < t.n_cigar[k]; ++q) {
+				uint32_t op = t.cigar[t.cigar_off[k] + q];
+				if ((op & 15) == 4 || (op & 15) == 5) continue;
+				cig += to_string(op >> 4); cig += CIGAR_CHARS[op & 15];
+			}
+			row.clear(); fq.clear();
+			row += name; row += '\t'; row += to_string(t.pos[k]); row += '\t'; row += (char)t.side[k]; row += '\t'; row += cig; row += '\t';
+			if (t.side[k] == '5') { row += sr + '\t' + qr + '\t' + sl + '\t' + ql; fq = "@" + sl + "\n" + sl + "\n+\n" + ql + "\n"; }
+			else { row += sl + '\t' + ql + '\t' + sr + '\t' + qr; fq = "@" + sr + "\n" + sr + "\n+\n" + qr + "\n"; }
+			row += '\t'; row += to_string(t.support[k]); row += '\n';
+			softfout.write(row); fqfout.write(fq);
+		}
+	}
+	cerr << "[GetSClipReads] finished!" << endl;
+	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
+	ssv_ctx_destroy(ctx);
+	ssvh_bam_close(bam);
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// getsv (junctions from -B)
+// ---------------------------------------------------------------------------------------------------------------------
+
+struct Junction { // getsv.h:149-227
+	string up_chr; int up_pos; char up_strand; string down_chr; int down_pos; char down_strand;
+	bool operator<(const Junction &o) const
+	{
+		if (up_chr != o.up_chr) return up_chr < o.up_chr;
+		if (down_chr != o.down_chr) return down_chr < o.down_chr;
+		if (up_strand != o.up_strand) return up_strand < o.up_strand;
+		if (down_strand != o.down_strand) return down_strand < o.down_strand;
+		if (up_pos != o.up_pos) return up_pos < o.up_pos;
+		return down_pos < o.down_pos;
+	}
+};
+
+struct SeqInfo { string seq; vector<pair<int, char>> cigar_vec; int left_clipped = 0, right_clipped = 0, support = 0, uniq = 0; };
+struct OtherInfo { SeqInfo up, down; int microhomology = 0, abnormal = 0; };
+
+static vector<pair<int, char>> parse_cigar(const string &cigar) // ChangeCigarType, getsv.cpp:433
+{
+	vector<pair<int, char>> v;
+	int len = 0;
+	for (char ch : cigar) { if (isdigit((unsigned char)ch)) len = len * 10 + (ch - 48); else { v.push_back(make_pair(len, ch)); len = 0; } }
+	return v;
+}
+
+static string cigar_text(const SeqInfo &s) // DisplayCigarVector, clip_reads.h:489-505
+{
+	string o;
+	if (s.left_clipped > 0) o += to_string(s.left_clipped) + "S";
+	for (auto &pr : s.cigar_vec) { o += to_string(pr.first); o += pr.second; }
+	if (s.right_clipped > 0) o += to_string(s.right_clipped) + "S";
+	return o;
+}
+
+static string sv_type(const Junction &j) // GetSVType, clip_reads.cpp:572-581
+{
+	if (j.up_chr != j.down_chr) return "CTX";
+	if (j.up_strand != j.down_strand) return "INV";
+	if (j.up_pos < j.down_pos) return "DEL";
+	if (j.up_pos > j.down_pos) return "INS";
+	return "Unknown";
+}
+
+static double largest_base_frequency(const string &seq) // CountLargestBaseFrequency, getsv.cpp:1485
+{
+	int a = 0, t = 0, c = 0, g = 0, n = 0;
+	for (char ch : seq) {
+		if (ch == 'A' || ch == 'a') ++a; else if (ch == 'T' || ch == 't') ++t; else if (ch == 'C' || ch == 'c') ++c; else if (ch == 'G' || ch == 'g') ++g; else ++n;
+	}
+	int largest = max(max(max(a, t), max(c, g)), n);
+	return largest / (double)seq.length();
+}
+
+static int cmd_getsv(int argc, char **argv)
+{
+	string connect_bam, temp_breakpoint;
+	double frequency = 0.1;
+	int c, min_mapQ = 20, read_pair_used = 5000000, sum_min_no_both_clipped_reads = 3, min_distance = 50, microhomology_length = 50, times = 4, device = 0,
+	       min_abnormal_read_pair_no = 0, flank_length = 200, min_seq_len = 30, max_seq_indel_no = 1, flank = 50;
+	bool output_depth = true;
+	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:")) >= 0) {
+		switch (c) {
+		case 'F': connect_bam = optarg; break;
+		case 'B': temp_breakpoint = optarg; break;
+		case 'l': flank = atoi(optarg); break;
+		case 'q': min_mapQ = atoi(optarg); break;
+		case 'n': read_pair_used = atoi(optarg); break;
+		case 'b': sum_min_no_both_clipped_reads = atoi(optarg); break;
+		case 'd': min_distance = atoi(optarg); break;
+		case 'e': min_abnormal_read_pair_no = atoi(optarg); break;
+		case 'm': min_seq_len = atoi(optarg); break;
+		case 'i': max_seq_indel_no = atoi(optarg); break;
+		case 'D': output_depth = false; break;
+		case 'f': frequency = atof(optarg); break;
+		case 'T': microhomology_length = atoi(optarg); break;
+		case 'L': flank_length = atoi(optarg); break;
+		case 'G': device = atoi(optarg); break;
+		default: break; // -t -Q -w -a -R -r: junction assembly options, accepted
+		}
+	}
+	if (argc != optind + 5) usage_getsv();
+	if (flank > 90 || flank < 0 || min_seq_len < 0) usage_getsv();
+	const string clip_bam = argv[optind], original_bam = argv[optind + 1], clipfile = argv[optind + 2], breakpoint_file = argv[optind + 3], clip_unmap_fq_file = argv[optind + 4];
+	if (!connect_bam.empty()) die("[seeksv] -F (bwasw read-through input) is not supported by this build");
+
+	multimap<Junction, OtherInfo> junction2other;
+	if (!temp_breakpoint.empty()) { // ReadBreakpoint, getsv.cpp:1292-1323
+		ifstream fin(temp_breakpoint.c_str());
+		if (!fin) cerr << "Cannot open file " << temp_breakpoint << endl;
+		string up_chr, down_chr, svt, up_cigar, down_cigar, up_seq, down_seq, temp;
+		int up_pos, up_reads_no, down_pos, down_reads_no, micro, abnormal, d1, d2, d3, d4, d5, d6;
+		char up_strand, down_strand;
+		double r1, r2;
+		while (fin >> up_chr) {
+			if (up_chr[0] == '@') { getline(fin, temp); continue; }
+			fin >> up_pos >> up_strand >> up_reads_no >> down_chr >> down_pos >> down_strand >> down_reads_no >> micro >> abnormal >> svt >> d1 >> d2 >> d3 >> d4 >> d5 >> d6 >> r1 >> r2 >>
+			    up_cigar >> down_cigar >> up_seq >> down_seq;
+			getline(fin, temp);
+			Junction j{up_chr, up_pos, up_strand, down_chr, down_pos, down_strand};
+			OtherInfo o;
+			o.up.seq = up_seq; o.up.cigar_vec = parse_cigar(up_cigar); o.up.support = up_reads_no;
+			o.down.seq = down_seq; o.down.cigar_vec = parse_cigar(down_cigar); o.down.support = down_reads_no;
+			o.microhomology = micro; o.abnormal = abnormal;
+			junction2other.insert(make_pair(j, o));
+		}
+		cerr << "[ReadBreakpoint] finish" << endl;
+	}
+	{ // junction assembly from clip.bam x clip.gz is not in this build: refuse rather than print a different table
+		ssvh_bam *cb = nullptr;
+		if (ssvh_bam_open(clip_bam.c_str(), &cb) != 0) die("[main_samview] fail to open file for reading.");
+		ssv_batch_t b;
+		if (ssvh_bam_read_batch(cb, 1, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		if (b.n > 0) die("[seeksv] this build evaluates junctions given with -B; assembling junctions from clip.bam x clip.gz is not implemented yet");
+		ssvh_bam_close(cb);
+	}
+	cerr << "'InputSoftInfoStoreBreakpoint' finished" << endl;
+
+	ssvh_bam *bam = nullptr;
+	if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file " + original_bam + "for reading.");
+	ssv_ctx *ctx = nullptr;
+	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+
+	int mean_insert_size = 0, deviation = 0;
+	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
+	if (do_discordant) { // CalculateInsertsizeDeviation, cluster.cpp:15-83
+		ssv_isize_begin(ctx, min_mapQ, read_pair_used);
+		int32_t done = 0;
+		while (!done) {
+			ssv_batch_t b;
+			if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+			if (b.n == 0) break;
+			if (ssv_isize_accumulate(ctx, &b, &done) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		}
+		int64_t n; int32_t m = 0, sd = 0;
+		ssv_isize_finish(ctx, &n, &m, &sd);
+		if (n > 0) {
+			mean_insert_size = m; deviation = sd;
+			cerr << "Bam/sam " << original_bam << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << endl;
+		}
+		cerr << "'CalculateInsertsizeDeviation' finished" << endl;
+		ssvh_bam_close(bam);
+		if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
+	} else min_abnormal_read_pair_no = 0; // seeksv.cpp:285
+
+	// ---- the fused BAM pass: discordant tally + depth ----
+	vector<ssvh_junction_in> J;
+	vector<int32_t> prev;
+	for (auto &kv : junction2other) {
+		J.push_back(ssvh_junction_in{kv.first.up_chr.c_str(), kv.first.down_chr.c_str(), kv.first.up_pos, kv.first.down_pos, kv.first.up_strand, kv.first.down_strand});
+		prev.push_back(kv.second.abnormal);
+	}
+	const int64_t nJ = (int64_t)J.size();
+	ssvh_plan *plan = nullptr;
+	ssvh_plan_create(bam, J.data(), nJ, nullptr, nullptr, 0, mean_insert_size, deviation, times, flank_length, &plan);
+	int64_t nj, nw, nr, np;
+	const ssv_junction *dj = ssvh_plan_junctions(plan, &nj);
+	const ssv_interval *dw = ssvh_plan_windows(plan, &nw);
+	const ssv_interval *dr = ssvh_plan_ranges(plan, &nr);
+	const ssv_interval *dp = ssvh_plan_points(plan, &np);
+	vector<int32_t> counts((size_t)nj + 1, 0), pdepth((size_t)np + 1, 0);
+	vector<uint64_t> rsum((size_t)nr + 1, 0);
+	if (do_discordant || output_depth) {
+		ssv_getsv_params gp;
+		memset(&gp, 0, sizeof(gp));
+		gp.junctions = dj; gp.n_junctions = do_discordant ? nj : 0;
+		gp.mean = mean_insert_size; gp.sd = deviation; gp.times = times; gp.disc_min_mapq = min_mapQ;
+		gp.windows = dw; gp.n_windows = output_depth ? nw : 0; gp.depth_min_mapq = min_mapQ;
+		gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
+		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		for (;;) {
+			ssv_batch_t b;
+			if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+			if (b.n == 0) break;
+			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			ssv_sync(ctx);
+		}
+		int32_t maxd = 0;
+		if (ssv_getsv_finish(ctx, do_discordant ? counts.data() : nullptr, dr, output_depth ? nr : 0, rsum.data(), dp, output_depth ? np : 0, pdepth.data(), &maxd) != SSV_OK)
+			die(string("[seeksv] ") + ssv_last_error(ctx));
+		if (maxd >= 7999) cerr << "[seeksv] warning: depth " << maxd << " reaches the pileup cap of samtools 0.1.16 (~8000 reads); the reference's depths saturate there" << endl;
+	}
+	if (do_discordant) { cerr << "'StoreSeqName2Tid' finished" << endl; cerr << "'FindDiscordantReadPairs' finished" << endl; }
+	if (output_depth) { cerr << "'MergeOverlap' finished" << endl; cerr << "'main_depth' finished" << endl; }
+	else frequency = 0; // seeksv.cpp:300
+	vector<int32_t> abnormal((size_t)nJ + 1), up_depth((size_t)nJ + 1), down_depth((size_t)nJ + 1);
+	vector<uint64_t> flank_sum((size_t)nJ * 4 + 4);
+	vector<uint32_t> flank_len((size_t)nJ * 4 + 4);
+	ssvh_plan_fold(plan, do_discordant ? counts.data() : nullptr, prev.data(), rsum.data(), pdepth.data(), abnormal.data(), up_depth.data(), down_depth.data(), flank_sum.data(),
+	               flank_len.data(), nullptr);
+
+	ofstream fout(breakpoint_file.c_str());
+	if (!fout) die("Cannot open file " + breakpoint_file);
+	fout << "@left_chr\tleft_pos\tleft_strand\tleft_clip_read_NO\tright_chr\tright_pos\tright_strand\tright_clip_read_NO\tmicrohomology_length\tabnormal_readpair_NO\tsvtype\tleft_pos_depth\t"
+	        "right_pos_depth\taverage_depth_of_left_pos_5end\taverage_depth_of_left_pos_3end\taverage_depth_of_right_pos_5end\taverage_depth_of_right_pos_3end\tleft_pos_clip_percentage\t"
+	        "right_pos_clip_percentage\tleft_seq_cigar\tright_seq_cigar\tleft_seq\tright_seq" << endl;
+	// OutputBreakpoint, getsv.cpp:838-987
+	int64_t idx = 0;
+	for (auto it = junction2other.begin(); it != junction2other.end(); ++it, ++idx) {
+		const Junction &j = it->first;
+		OtherInfo &o = it->second;
+		if (do_discordant) o.abnormal = abnormal[(size_t)idx];
+		const int updepth = (output_depth ? up_depth[(size_t)idx] : 0) + o.down.support;     // without the depth pass pos2depth is empty: the reference prints an error and uses 0
+		const int downdepth = (output_depth ? down_depth[(size_t)idx] : 0) + o.up.support;
+		const int up_only = output_depth ? updepth : 0, down_only = output_depth ? downdepth : 0;
+		if (!output_depth) {
+			cerr << "Error: There is something wrong in upstream position " << j.up_chr << ":" << j.up_pos << endl;
+			cerr << "Error: There is something wrong in downstream position " << j.down_chr << ":" << j.down_pos << endl;
+		}
+		const int ud = up_only, dd = down_only;
+		const int junction_reads_no = o.up.support + o.down.support;
+		const double rate1 = ud == 0 ? 0 : (double)junction_reads_no / ud, rate2 = dd == 0 ? 0 : (double)junction_reads_no / dd;
+		auto filtered = [&](const char *reason) { // OutputFilteredBreakpoint, getsv.cpp:1846
+			cout << reason << '\t' << j.up_chr << '\t' << j.up_pos << '\t' << j.up_strand << '\t' << o.up.support << '\t' << j.down_chr << '\t' << j.down_pos << '\t' << j.down_strand << '\t'
+			     << o.down.support << '\t' << o.microhomology << '\t' << o.abnormal << '\t' << sv_type(j) << '\t' << ud << '\t' << dd << '\t' << rate1 << '\t' << rate2 << '\t'
+			     << cigar_text(o.up) << '\t' << cigar_text(o.down) << '\t' << o.up.seq << '\t' << o.down.seq << endl;
+		};
+		if (!(o.up.uniq + o.down.uniq >= 2 || o.abnormal > 0)) { filtered("mappingQ_too_low"); continue; }
+		if (j.up_chr == j.down_chr && abs(j.up_pos - j.down_pos) < min_distance) { filtered("distance_too_near"); continue; }
+		if (o.microhomology > microhomology_length) { filtered("microhomology_len_too_long"); continue; }
+		if (o.abnormal < min_abnormal_read_pair_no) { filtered("abnormal_read_pair_no_not_pass"); continue; }
+		if ((o.up.support > 0 && o.down.support > 0 && rate1 < frequency && rate2 < frequency) || (o.up.support == 0 && rate2 < frequency) || (o.down.support == 0 && rate1 < frequency)) {
+			filtered("frequency_too_low"); continue;
+		}
+		if (o.up.support + o.down.support < sum_min_no_both_clipped_reads) { filtered("total_clipped_reads_NO_not_pass"); continue; }
+		if (o.abnormal == 0) {
+			if (o.up.seq.length() < (size_t)(o.up.left_clipped + o.up.right_clipped + min_seq_len) || o.down.seq.length() < (size_t)(o.down.left_clipped + o.down.right_clipped + min_seq_len)) {
+				filtered("seq_length_too_short"); continue;
+			}
+			if (o.up.cigar_vec.size() > (size_t)(2 * max_seq_indel_no + 1) || o.down.cigar_vec.size() > (size_t)(2 * max_seq_indel_no + 1)) { filtered("seq_with_too_many_indels"); continue; }
+			if (largest_base_frequency(o.up.seq) >= 0.8 || largest_base_frequency(o.down.seq) >= 0.8) { filtered("repeat_bases"); continue; }
+		}
+		unsigned int fl[4] = {0, 0, 0, 0};
+		if (output_depth) for (int k = 0; k < 4; ++k) fl[k] = (unsigned int)(flank_sum[(size_t)idx * 4 + k] / flank_len[(size_t)idx * 4 + k]); // getsv.cpp:946 (divides by zero like the reference if a window is empty)
+		else cerr << "Error depth in the vicinity of junction " << j.up_chr << '\t' << j.up_pos << '\t' << j.up_strand << '\t' << j.down_chr << '\t' << j.down_pos << '\t' << j.down_strand << endl;
+		fout << j.up_chr << '\t' << j.up_pos << '\t' << j.up_strand << '\t' << o.up.support << '\t' << j.down_chr << '\t' << j.down_pos << '\t' << j.down_strand << '\t' << o.down.support << '\t'
+		     << o.microhomology << '\t' << o.abnormal << '\t' << sv_type(j) << '\t' << ud << '\t' << dd << '\t' << (int)fl[0] << '\t' << (int)fl[1] << '\t' << (int)fl[2] << '\t' << (int)fl[3] << '\t'
+		     << rate1 << '\t' << rate2 << '\t' << cigar_text(o.up) << '\t' << cigar_text(o.down) << '\t' << o.up.seq << '\t' << o.down.seq << endl;
+	}
+	ofstream foutuq(clip_unmap_fq_file.c_str()); // OutputOneendUnmapBreakpoint: always empty (GetJunction returns early for type 'n')
+	if (!foutuq) die("Cannot open file " + clip_unmap_fq_file);
+	ssvh_plan_destroy(plan);
+	ssv_ctx_destroy(ctx);
+	ssvh_bam_close(bam);
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc == 1) usage_top();
+	const string cmd = argv[1];
+	if (cmd != "getclip" && cmd != "getsv") {
+		cerr << "[seeksv] unrecognized command '" << argv[1] << "'" << endl;
+		return 1;
+	}
+	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else usage_getsv(); }
+	optind = 1; // like SelectStep (seeksv.cpp:444-452): the sub-command becomes argv[0]
+	return cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
+}

@@ -1,0 +1,56 @@
+"""-m gpu: the C++ `seeksv` command line (seeksv_amd/bin/seeksv) against the reference's own output files, byte for byte."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import bamio
+import golden_util as G
+from seeksv_amd import host
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEEKSV = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
+
+GETCLIP = [("example", "cancer.sort.bam", "cancer", []), ("example", "normal.sort.bam", "normal", []), ("getclip", "filters.bam", "filters", []),
+           ("getclip", "filters.bam", "filters.s", ["-s"]), ("getclip", "filters.bam", "filters.q30", ["-q", "30"]), ("getclip", "stress1.bam", "stress1.t08", ["-t", "0.8"]),
+           ("getclip", "stress2.bam", "stress2", [])]
+
+
+@pytest.mark.parametrize("sub,bam,prefix,flags", GETCLIP, ids=[c[2] for c in GETCLIP])
+def test_cli_getclip(tmp_path, sub, bam, prefix, flags):
+    out = str(tmp_path / "o")
+    r = subprocess.run([SEEKSV, "getclip"] + flags + ["-o", out, os.path.join(G.GOLDEN, sub, bam)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(out + ".clip.gz", "rt").read() == G.read_text(sub, prefix + ".clip.txt")
+    assert gzip.open(out + ".clip.fq.gz", "rt").read() == G.read_text(sub, prefix + ".clip.fq.txt")
+    assert gzip.open(out + ".unmapped_1.fq.gz", "rt").read() == "" and gzip.open(out + ".unmapped_2.fq.gz", "rt").read() == ""
+    if sub == "example":
+        assert r.stderr == G.read_text(sub, prefix + ".getclip.stderr")
+
+
+GETSV = [("pairs1", "pairs1", []), ("pairs1", "pairs1.q0", ["-q", "0"]), ("pairs1", "pairs1.L50", ["-L", "50"]), ("pairs1", "pairs1.L1", ["-L", "1"]),
+         ("pairs2", "pairs2", []), ("pairs3", "pairs3", [])]
+
+
+@pytest.mark.parametrize("case,prefix,flags", GETSV, ids=[c[1] for c in GETSV])
+def test_cli_getsv_junction_table(tmp_path, case, prefix, flags):
+    """The reference's -B harness: same junction file, same flags -> identical SV table and identical filtered lines on stdout."""
+    base = os.path.join(G.GOLDEN, "getsv")
+    bam = os.path.join(base, case + ".bam")
+    with host.BamReader(bam) as r:
+        names, lens = r.target_names, [int(x) for x in r.target_lens]
+    empty_bam = str(tmp_path / "empty.clip.bam")
+    bamio.write_bam(empty_bam, names, lens, [])
+    empty_clip = str(tmp_path / "empty.clip")
+    open(empty_clip, "w").close()
+    sv = str(tmp_path / "out.sv")
+    r = subprocess.run([SEEKSV, "getsv", "-d", "0", "-f", "0", "-b", "0", "-T", "100000"] + flags + ["-B", os.path.join(base, case + ".junctions.txt"), empty_bam, bam, empty_clip, sv,
+                        str(tmp_path / "x.fq")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(sv).read() == G.read_text("getsv", prefix + ".sv")
+    assert r.stdout == G.read_text("getsv", prefix + ".stdout")
+    mean, sd = G.read_text("getsv", prefix + ".isize.txt").split()
+    assert f"Mean insert size : {mean}\nMean deviation: {sd}\n" in r.stderr
+    assert os.path.getsize(str(tmp_path / "x.fq")) == 0
