@@ -61,11 +61,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # test hooks (a 1-GPU box can still exercise the N > 1 code path): SSV_FORCE_DEVICE pins every rank to one GPU,
+    # SSV_DIST_BACKEND=gloo replaces RCCL (which needs one GPU per rank) by gloo over host memory
+    if os.environ.get("SSV_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["SSV_FORCE_DEVICE"])
+    backend = os.environ.get("SSV_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = dev if (world > 1 and backend == "nccl") else None
 
     from seeksv_amd import host, shard, synth
     from seeksv_amd.device import Context
@@ -103,6 +112,20 @@ def main():
     jtable = host.JunctionTable(w.junctions)
 
     wall = {}
+    state = {"pending": False, "support_sum": 0, "tables": 0}
+
+    def collect_table(prev):
+        t = ctx.clip_table_wait(prev=prev)
+        ssum = int(np.ctypeslib.as_array(t.support, shape=(t.n_clusters,)).sum()) if t.n_clusters else 0
+        assert ssum == t.n_events, "clip events were lost or duplicated"
+        state["support_sum"] = ssum
+        state["tables"] += 1
+
+    def drain():
+        if state["pending"]:
+            collect_table(prev=False)
+            state["pending"] = False
+
 
     def step(timed=None):
         t = [time.perf_counter()]
@@ -121,10 +144,10 @@ def main():
         ctx.clip_begin(0.9, 1, False, own, sp["initial_last_tid"])
         ctx.clip_scan(scan_batch)
         lap("clip_scan+events")
-        table = ctx.clip_cluster(as_dict=False)
-        n_clusters, n_events = table.n_clusters, table.n_events
-        support_sum = int(np.ctypeslib.as_array(table.support, shape=(n_clusters,)).sum()) if n_clusters else 0
-        lap("clip_cluster+table_d2h")
+        # the cluster table's copy to the host (1.8 GB over PCIe) is queued on a second stream and collected one step later, so it
+        # overlaps with the getsv passes and with the next step's kernels; every table is collected before the timed region ends
+        n_clusters, n_events = ctx.clip_cluster_async()
+        lap("clip_cluster(kernels)")
         rc, npairs, mean, sd = ctx.isize_stats([prefix_batch], 20, 5000000)
         lap("isize_stats")
         worker.join()
@@ -136,8 +159,12 @@ def main():
         ctx.getsv_scan(own_batch)
         counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
         lap("getsv_scan+finish")
-        vec = shard.pack_results(counts, rs, pd, n_clusters, n_events, support_sum)
-        stacked = shard.all_gather_vector(vec, dev if world > 1 else None)
+        if state["pending"]:
+            collect_table(prev=True)
+        state["pending"] = True
+        lap("table_wait(previous step)")
+        vec = shard.pack_results(counts, rs, pd, n_clusters, n_events, state["support_sum"])
+        stacked = shard.all_gather_vector(vec, coll_dev)
         merged = shard.merge_results(stacked, len(counts), len(rs), len(pd))
         lap("exchange")
         folded = plan.fold(merged[0], merged[1], merged[2])
@@ -147,6 +174,7 @@ def main():
                     depth_sum=int(folded["up_depth"].sum() + folded["down_depth"].sum()), flank_sum=int(folded["flank"].sum()), max_depth=max_depth)
 
     def barrier():
+        drain()
         torch.cuda.synchronize()
         ctx.sync()
         if world > 1:
@@ -167,19 +195,20 @@ def main():
     prof = {k: ctx.prof_get(k) for k in ("clip_scan", "getsv_scan")}
     ctx.prof_enable(0)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # one extra, untimed step with every kernel group bracketed by events: the per-kernel breakdown
     ctx.prof_reset()
     ctx.prof_enable(1)
     step(wall)
+    drain()
     allprof = ctx.prof_all()
     breakdown = {k: round(v["total_ms"], 4) for k, v in allprof.items() if v["launches"]}
     ctx.prof_enable(0)
 
     if rank == 0:
-        assert res["support_sum"] == res["n_events"], "clip events were lost or duplicated"
+        assert state["tables"] >= args.steps, "every step's cluster table must have reached the host"
         total_records = w.n_total
         ms_per_step = dt / args.steps * 1e3
         # dominant kernel = the longest-running kernel group of the device path that streams HBM (PCIe copies excluded)

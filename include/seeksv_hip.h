@@ -144,6 +144,17 @@ typedef struct {
 
 /* Sort events into (contig, side, position) bins and run the greedy consensus clustering. */
 int ssv_clip_cluster(ssv_ctx *ctx, ssv_cluster_table *out);
+/*
+ * The same in two halves: ssv_clip_cluster_async returns as soon as the clustering kernels are done and the copy of the table
+ * to host memory has been queued on a second stream (n_clusters / n_events are known then); ssv_clip_table_wait blocks until
+ * that copy has landed and hands the table out.  Two tables are kept, so the caller may start the next getclip pass (or the
+ * getsv passes) while the previous table is still crossing PCIe: a table stays valid until the second-next
+ * ssv_clip_cluster[_async] call.
+ */
+int ssv_clip_cluster_async(ssv_ctx *ctx, int64_t *n_clusters, int64_t *n_events);
+int ssv_clip_table_wait(ssv_ctx *ctx, ssv_cluster_table *out);
+/* The table of the call before the most recent ssv_clip_cluster[_async] (pipelined drivers: cluster k+1, then collect table k). */
+int ssv_clip_table_wait_prev(ssv_ctx *ctx, ssv_cluster_table *out);
 
 /* ---- getsv pass 1: replaces CalculateInsertsizeDeviation (cluster.cpp:15-83) ---------------- */
 

@@ -197,6 +197,9 @@ def hip_lib():
         lib.ssv_clip_scan.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_clip_event_count.argtypes = [V, C.POINTER(C.c_int64)]
         lib.ssv_clip_cluster.argtypes = [V, C.POINTER(ClusterTable)]
+        lib.ssv_clip_cluster_async.argtypes = [V, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.ssv_clip_table_wait.argtypes = [V, C.POINTER(ClusterTable)]
+        lib.ssv_clip_table_wait_prev.argtypes = [V, C.POINTER(ClusterTable)]
         lib.ssv_isize_begin.argtypes = [V, C.c_int32, C.c_int64]
         lib.ssv_isize_accumulate.argtypes = [V, C.POINTER(Batch), C.POINTER(C.c_int32)]
         lib.ssv_isize_finish.argtypes = [V, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

@@ -552,57 +552,129 @@ __global__ void k_cluster_pack_meta(PackArgs p)
 	p.ncig64[c] = nc;
 }
 
+// bam_nt16_rev_table "=ACMGRSVTWYHKDBN" as two little-endian 64-bit words: nibble -> ASCII without touching memory
+__device__ __forceinline__ uint32_t nt16_char(uint32_t nib)
+{
+	const uint64_t LO = ((uint64_t)'=') | ((uint64_t)'A' << 8) | ((uint64_t)'C' << 16) | ((uint64_t)'M' << 24) | ((uint64_t)'G' << 32) | ((uint64_t)'R' << 40) | ((uint64_t)'S' << 48) | ((uint64_t)'V' << 56);
+	const uint64_t HI = ((uint64_t)'T') | ((uint64_t)'W' << 8) | ((uint64_t)'Y' << 16) | ((uint64_t)'H' << 24) | ((uint64_t)'K' << 32) | ((uint64_t)'D' << 40) | ((uint64_t)'B' << 48) | ((uint64_t)'N' << 56);
+	return (uint32_t)(((nib & 8u) ? HI : LO) >> (8u * (nib & 7u))) & 0xffu;
+}
+
+constexpr int PACK_MAX_LQ = 256; // reads up to this length take the LDS-staged path of k_cluster_pack_strings
+
 // 16 lanes per cluster, four clusters per wavefront: strings and the CIGAR of the carrying event into dense blobs.  Every lane
 // assembles whole output dwords (a cluster's block starts 4-byte aligned and is zero padded to a multiple of 4 bytes):
-// [seq_left | qual_left | seq_right | qual_right].  Single-event clusters are decoded straight from the event's packed bases /
-// qualities (GetSeq, clip_reads.cpp:286-306); clusters of multi-event bins come from their consensus storage (left part un-reversed).
+// [seq_left | qual_left | seq_right | qual_right].  Single-event clusters (97 %) are decoded from the event's packed bases /
+// qualities (GetSeq, clip_reads.cpp:286-306): the group expands the read once into LDS with dword loads (8 bases per packed dword,
+// 4 qualities per dword via alignbyte and a packed +33) and then composes the output dwords from LDS bytes.  Clusters of multi-event
+// bins come from their consensus storage (left part un-reversed); reads longer than PACK_MAX_LQ take the per-byte path.
 __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
                                                                 const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
 {
-	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
-	if (c >= n_clusters) return;
+	__shared__ uint32_t s_seq[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 2];
+	__shared__ uint32_t s_qual[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 2];
+	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
-	const int64_t j = p.slot[c];
-	const int ll = p.ll[c], lr = p.lr[c];
+	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const bool active = c < n_clusters;
+	int64_t j = 0;
+	int ll = 0, lr = 0, lq = 0, begin = 0;
+	uint32_t e = 0;
+	bool single = false, staged = false, qmiss = false;
+	const uint8_t *sp = nullptr;
+	if (active) {
+		j = p.slot[c]; ll = p.ll[c]; lr = p.lr[c];
+		e = p.c.c_cig_ev[j];
+		single = !p.c.mflag[j];
+		if (single) {
+			lq = p.c.ev.lq[e];
+			sp = p.c.seq_blob + p.c.ev.seq_off[e]; // 4-byte aligned
+			begin = p.c.ev.begin[e];
+			qmiss = lq > 0 && sp[(lq + 1) / 2] == 0xff;
+			staged = lq <= PACK_MAX_LQ;
+		}
+	}
+	if (staged) {
+		const uint32_t *sp4 = reinterpret_cast<const uint32_t *>(sp);
+		const int nseq4 = ((lq + 1) / 2 + 3) / 4; // packed dwords holding the bases
+		for (int w = gl; w < nseq4; w += GROUP) {
+			const uint32_t pk = sp4[w];
+			uint32_t lo = 0, hi = 0;
+#pragma unroll
+			for (int b = 0; b < 2; ++b) { // packed bytes 0,1 -> chars 0..3 ; bytes 2,3 -> chars 4..7
+				const uint32_t b0 = (pk >> (16 * b)) & 0xffu, b1 = (pk >> (16 * b + 8)) & 0xffu;
+				const uint32_t four = nt16_char(b0 >> 4) | (nt16_char(b0 & 15u) << 8) | (nt16_char(b1 >> 4) << 16) | (nt16_char(b1 & 15u) << 24);
+				if (b == 0) lo = four; else hi = four;
+			}
+			s_seq[grp][2 * w] = lo; s_seq[grp][2 * w + 1] = hi;
+		}
+		const uint8_t *qp = sp + (lq + 1) / 2;
+		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(qp) & 3u);
+		const uint32_t *q4 = reinterpret_cast<const uint32_t *>(qp - mis);
+		const int nq4 = (lq + 3) / 4;
+		for (int w = gl; w < nq4; w += GROUP) {
+			uint32_t lo = q4[w];
+			uint32_t hi = mis ? q4[w + 1] : 0u; // stays inside the 4-byte padded entry (or the blob's slack) like k_clip_gather
+			uint32_t v = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+			s_qual[grp][w] = qmiss ? 0x2a2a2a2au : v + 0x21212121u; // phred + 33 (qualities <= 93: no carry between bytes); '*' when absent
+		}
+	}
+	__syncthreads();
+	if (!active) return;
 	const int total = 2 * (ll + lr);
 	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + str_off[c]);
-	const uint32_t e = p.c.c_cig_ev[j];
-	const bool single = !p.c.mflag[j];
-	EventView v;
-	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
-	if (single) {
-		const int lq = p.c.ev.lq[e];
-		v.sp = p.c.seq_blob + p.c.ev.seq_off[e];
-		v.qp = v.sp + (lq + 1) / 2;
-		v.begin = p.c.ev.begin[e]; v.ll = ll; v.lr = lr;
-		v.qmiss = lq > 0 && v.qp[0] == 0xff;
-	} else {
-		const int64_t stride = 2ll * (p.c.SL + p.c.SR);
-		cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
-		cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
-	}
-	for (int w = gl; w * 4 < total; w += GROUP) {
-		uint32_t word = 0;
+	if (staged) {
+		const uint8_t *sq = reinterpret_cast<const uint8_t *>(s_seq[grp]);
+		const uint8_t *qq = reinterpret_cast<const uint8_t *>(s_qual[grp]);
+		for (int w = gl; w * 4 < total; w += GROUP) {
+			uint32_t word = 0;
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int q = w * 4 + k; // byte position inside the cluster's block
-			uint32_t ch = 0;
-			if (q < total) {
-				if (single) {
-					if (q < ll) ch = (uint8_t)v.base(v.begin + q);
-					else if (q < 2 * ll) ch = (uint8_t)v.qual(v.begin + q - ll);
-					else if (q < 2 * ll + lr) ch = (uint8_t)v.base(v.begin + ll + q - 2 * ll);
-					else ch = (uint8_t)v.qual(v.begin + ll + q - 2 * ll - lr);
-				} else {
-					if (q < ll) ch = cs[ll - 1 - q];
-					else if (q < 2 * ll) ch = cq[ll - 1 - (q - ll)];
-					else if (q < 2 * ll + lr) ch = rs[q - 2 * ll];
-					else ch = rq[q - 2 * ll - lr];
+			for (int k = 0; k < 4; ++k) {
+				const int q = w * 4 + k;
+				uint32_t ch = 0;
+				if (q < total) {
+					if (q < ll) ch = sq[begin + q];
+					else if (q < 2 * ll) ch = qq[begin + q - ll];
+					else if (q < 2 * ll + lr) ch = sq[begin + ll + q - 2 * ll];
+					else ch = qq[begin + ll + q - 2 * ll - lr];
 				}
+				word |= ch << (8 * k);
 			}
-			word |= ch << (8 * k);
+			d[w] = word;
 		}
-		d[w] = word;
+	} else {
+		EventView v;
+		const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+		if (single) {
+			v.sp = sp; v.qp = sp + (lq + 1) / 2; v.begin = begin; v.ll = ll; v.lr = lr; v.qmiss = qmiss;
+		} else {
+			const int64_t stride = 2ll * (p.c.SL + p.c.SR);
+			cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
+			cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
+		}
+		for (int w = gl; w * 4 < total; w += GROUP) {
+			uint32_t word = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int q = w * 4 + k; // byte position inside the cluster's block
+				uint32_t ch = 0;
+				if (q < total) {
+					if (single) {
+						if (q < ll) ch = (uint8_t)v.base(v.begin + q);
+						else if (q < 2 * ll) ch = (uint8_t)v.qual(v.begin + q - ll);
+						else if (q < 2 * ll + lr) ch = (uint8_t)v.base(v.begin + ll + q - 2 * ll);
+						else ch = (uint8_t)v.qual(v.begin + ll + q - 2 * ll - lr);
+					} else {
+						if (q < ll) ch = cs[ll - 1 - q];
+						else if (q < 2 * ll) ch = cq[ll - 1 - (q - ll)];
+						else if (q < 2 * ll + lr) ch = rs[q - 2 * ll];
+						else ch = rq[q - 2 * ll - lr];
+					}
+				}
+				word |= ch << (8 * k);
+			}
+			d[w] = word;
+		}
 	}
 	const uint32_t *src = cig_blob + p.c.ev.cig_off[e];
 	uint32_t *dc = out_cig + cig_off[c];

@@ -72,8 +72,20 @@ struct ssv_ctx {
 	int max_ll = 0, max_lr = 0;
 	// clustering temporaries / outputs
 	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_strings, c_flag, c_idx;
-	DBuf o_tid, o_pos, o_side, o_support, o_ll, o_lr, o_qmiss, o_slot, o_strbytes, o_ncig64, o_ncig, o_stroff, o_cigoff, o_str, o_cig, totals;
-	HBuf h_tid, h_pos, h_side, h_support, h_ll, h_lr, h_qmiss, h_stroff, h_cigoff, h_ncig, h_str, h_cig, h_totals;
+	DBuf o_slot, o_strbytes, o_ncig64, totals;
+	HBuf h_totals;
+	// the dense cluster table: device columns + pinned host copy, double buffered so that the PCIe copy of one table can overlap
+	// with whatever the caller runs next (ssv_clip_cluster_async / ssv_clip_table_wait)
+	struct TableSet {
+		DBuf o_tid, o_pos, o_side, o_support, o_ll, o_lr, o_qmiss, o_ncig, o_stroff, o_cigoff, o_str, o_cig;
+		HBuf h_tid, h_pos, h_side, h_support, h_ll, h_lr, h_qmiss, h_stroff, h_cigoff, h_ncig, h_str, h_cig;
+		hipEvent_t copied = nullptr;
+		bool in_flight = false;
+		int64_t n_clusters = 0, n_events = 0;
+	} tab[2];
+	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
+	hipStream_t st_copy = nullptr;
+	hipEvent_t ev_packed = nullptr;
 
 	// ---- isize ----
 	bool isz_active = false;
@@ -302,6 +314,10 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 	ssv_ctx *c = new ssv_ctx();
 	c->device = device;
 	if ((e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return SSV_E_NODEVICE; }
+	if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->tab[0].copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->tab[1].copied, hipEventDisableTiming) != hipSuccess) {
+		g_create_error = "cannot create the copy stream / events"; ssv_ctx_destroy(c); return SSV_E_NODEVICE;
+	}
 	*out = c;
 	return SSV_OK;
 }
@@ -314,15 +330,21 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_tid,
-	                 &c->o_pos, &c->o_side, &c->o_support, &c->o_ll, &c->o_lr, &c->o_qmiss, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_ncig, &c->o_stroff, &c->o_cigoff, &c->o_str,
-	                 &c->o_cig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap,
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap,
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
-	HBuf *hbufs[] = {&c->h_counters, &c->h_tid, &c->h_pos, &c->h_side, &c->h_support, &c->h_ll, &c->h_lr, &c->h_qmiss, &c->h_stroff, &c->h_cigoff, &c->h_ncig, &c->h_str, &c->h_cig,
-	                 &c->h_totals, &c->h_q};
+	HBuf *hbufs[] = {&c->h_counters, &c->h_totals, &c->h_q};
 	for (HBuf *b : hbufs) if (b->p) (void)hipHostFree(b->p);
+	for (auto &t : c->tab) {
+		DBuf *td[] = {&t.o_tid, &t.o_pos, &t.o_side, &t.o_support, &t.o_ll, &t.o_lr, &t.o_qmiss, &t.o_ncig, &t.o_stroff, &t.o_cigoff, &t.o_str, &t.o_cig};
+		HBuf *th[] = {&t.h_tid, &t.h_pos, &t.h_side, &t.h_support, &t.h_ll, &t.h_lr, &t.h_qmiss, &t.h_stroff, &t.h_cigoff, &t.h_ncig, &t.h_str, &t.h_cig};
+		for (DBuf *b : td) if (b->p) (void)hipFree(b->p);
+		for (HBuf *b : th) if (b->p) (void)hipHostFree(b->p);
+		if (t.copied) (void)hipEventDestroy(t.copied);
+	}
+	if (c->st_copy) { (void)hipStreamSynchronize(c->st_copy); (void)hipStreamDestroy(c->st_copy); }
+	if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
 	for (ProfRec &r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
 	for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
 	(void)hipStreamDestroy(c->st);
@@ -459,14 +481,20 @@ int ssv_clip_event_count(ssv_ctx *c, int64_t *n)
 	return SSV_OK;
 }
 
-int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
+int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 {
-	if (!c || !out) return SSV_E_ARG;
+	if (!c) return SSV_E_ARG;
 	if (!c->clip_active) { c->err = "ssv_clip_cluster before ssv_clip_begin"; return SSV_E_STATE; }
 	HIPCHECK(c, hipSetDevice(c->device));
-	memset(out, 0, sizeof(*out));
+	// take the table set that is not the most recent one; its previous copy (two calls ago) must have landed
+	const int s_ = c->tab_cur ^ 1;
+	ssv_ctx::TableSet &T = c->tab[s_];
+	if (T.in_flight) { HIPCHECK(c, hipEventSynchronize(T.copied)); T.in_flight = false; }
+	c->tab_cur = s_;
 	const int64_t E = c->n_events;
-	out->n_events = E;
+	T.n_events = E; T.n_clusters = 0;
+	if (n_events) *n_events = E;
+	if (n_clusters) *n_clusters = 0;
 	if (E == 0) { HIPCHECK(c, hipStreamSynchronize(c->st)); return SSV_OK; }
 	EventArrays ev = event_arrays(c);
 	// ---- bin the events: stable sort by (contig, side, position) ----
@@ -521,47 +549,76 @@ int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
 	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 4, hipMemcpyDeviceToHost, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	const int64_t nc = *P<uint32_t>(c->h_totals);
-	out->n_clusters = nc;
+	T.n_clusters = nc;
+	if (n_clusters) *n_clusters = nc;
 	if (nc == 0) return SSV_OK;
-	DBuf *d4[] = {&c->o_tid, &c->o_pos, &c->o_support, &c->o_ll, &c->o_lr, &c->o_slot, &c->o_ncig};
+	DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &c->o_slot, &T.o_ncig};
 	for (DBuf *b : d4) CHECK(ensure(c, *b, nc * 4));
-	CHECK(ensure(c, c->o_side, nc)); CHECK(ensure(c, c->o_qmiss, nc));
-	DBuf *d8[] = {&c->o_strbytes, &c->o_ncig64, &c->o_stroff, &c->o_cigoff};
+	CHECK(ensure(c, T.o_side, nc)); CHECK(ensure(c, T.o_qmiss, nc));
+	DBuf *d8[] = {&c->o_strbytes, &c->o_ncig64, &T.o_stroff, &T.o_cigoff};
 	for (DBuf *b : d8) CHECK(ensure(c, *b, nc * 8));
 	PackArgs pa;
 	pa.c = ca; pa.flag = P<uint32_t>(c->c_flag); pa.cidx = P<uint32_t>(c->c_idx);
-	pa.tid = P<int32_t>(c->o_tid); pa.pos = P<int32_t>(c->o_pos); pa.side = P<uint8_t>(c->o_side); pa.support = P<int32_t>(c->o_support); pa.ll = P<int32_t>(c->o_ll);
-	pa.lr = P<int32_t>(c->o_lr); pa.qmiss = P<uint8_t>(c->o_qmiss); pa.slot = P<uint32_t>(c->o_slot); pa.str_bytes = P<uint64_t>(c->o_strbytes);
-	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(c->o_ncig);
+	pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
+	pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.slot = P<uint32_t>(c->o_slot); pa.str_bytes = P<uint64_t>(c->o_strbytes);
+	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(T.o_ncig);
 	k_cluster_pack_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
 	CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nc) * 8));
 	uint64_t *tot = P<uint64_t>(c->totals);
-	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_strbytes), P<uint64_t>(c->o_stroff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
-	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_ncig64), P<uint64_t>(c->o_cigoff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 2);
+	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_strbytes), P<uint64_t>(T.o_stroff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
+	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_ncig64), P<uint64_t>(T.o_cigoff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 2);
 	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 32, hipMemcpyDeviceToHost, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	const uint64_t str_total = P<uint64_t>(c->h_totals)[1], cig_total = P<uint64_t>(c->h_totals)[2];
-	CHECK(ensure(c, c->o_str, str_total + 16)); CHECK(ensure(c, c->o_cig, cig_total * 4 + 16));
-	k_cluster_pack_strings<<<grid_for(nc, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(c->o_stroff), P<uint64_t>(c->o_cigoff), P<uint32_t>(c->cig_blob),
-	                                                                          P<uint8_t>(c->o_str), P<uint32_t>(c->o_cig));
+	CHECK(ensure(c, T.o_str, str_total + 16)); CHECK(ensure(c, T.o_cig, cig_total * 4 + 16));
+	k_cluster_pack_strings<<<grid_for(nc, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(T.o_stroff), P<uint64_t>(T.o_cigoff), P<uint32_t>(c->cig_blob),
+	                                                                          P<uint8_t>(T.o_str), P<uint32_t>(T.o_cig));
 	HIPCHECK(c, hipGetLastError());
 	delete pack_scope; pack_scope = nullptr; // the copy below is PCIe time, not kernel time
 	struct { HBuf *h; DBuf *d; size_t bytes; } cp[] = {
-		{&c->h_tid, &c->o_tid, (size_t)nc * 4}, {&c->h_pos, &c->o_pos, (size_t)nc * 4}, {&c->h_side, &c->o_side, (size_t)nc}, {&c->h_support, &c->o_support, (size_t)nc * 4},
-		{&c->h_ll, &c->o_ll, (size_t)nc * 4}, {&c->h_lr, &c->o_lr, (size_t)nc * 4}, {&c->h_qmiss, &c->o_qmiss, (size_t)nc}, {&c->h_stroff, &c->o_stroff, (size_t)nc * 8},
-		{&c->h_cigoff, &c->o_cigoff, (size_t)nc * 8}, {&c->h_ncig, &c->o_ncig, (size_t)nc * 4}, {&c->h_str, &c->o_str, (size_t)str_total}, {&c->h_cig, &c->o_cig, (size_t)cig_total * 4}};
-	{
-		ProfScope pd(c, P_TABLE_D2H, nc);
-		for (auto &x : cp) {
-			CHECK(ensure_host(c, *x.h, x.bytes + 16));
-			if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st));
-		}
+		{&T.h_tid, &T.o_tid, (size_t)nc * 4}, {&T.h_pos, &T.o_pos, (size_t)nc * 4}, {&T.h_side, &T.o_side, (size_t)nc}, {&T.h_support, &T.o_support, (size_t)nc * 4},
+		{&T.h_ll, &T.o_ll, (size_t)nc * 4}, {&T.h_lr, &T.o_lr, (size_t)nc * 4}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_stroff, &T.o_stroff, (size_t)nc * 8},
+		{&T.h_cigoff, &T.o_cigoff, (size_t)nc * 8}, {&T.h_ncig, &T.o_ncig, (size_t)nc * 4}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * 4}};
+	// the table goes to pinned host memory on the copy stream, behind the pack kernels; ssv_clip_table_wait() waits for it
+	HIPCHECK(c, hipEventRecord(c->ev_packed, c->st));
+	HIPCHECK(c, hipStreamWaitEvent(c->st_copy, c->ev_packed, 0));
+	for (auto &x : cp) {
+		CHECK(ensure_host(c, *x.h, x.bytes + 16));
+		if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st_copy));
 	}
-	HIPCHECK(c, hipStreamSynchronize(c->st));
-	out->tid = P<int32_t>(c->h_tid); out->pos = P<int32_t>(c->h_pos); out->side = P<uint8_t>(c->h_side); out->support = P<int32_t>(c->h_support);
-	out->left_len = P<int32_t>(c->h_ll); out->right_len = P<int32_t>(c->h_lr); out->qual_missing = P<uint8_t>(c->h_qmiss); out->str_off = P<uint64_t>(c->h_stroff);
-	out->str = P<uint8_t>(c->h_str); out->cigar_off = P<uint64_t>(c->h_cigoff); out->n_cigar = P<int32_t>(c->h_ncig); out->cigar = P<uint32_t>(c->h_cig);
+	HIPCHECK(c, hipEventRecord(T.copied, c->st_copy));
+	T.in_flight = true;
 	return SSV_OK;
+}
+
+static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out);
+
+int ssv_clip_table_wait(ssv_ctx *c, ssv_cluster_table *out) { return c && out ? table_wait(c, c->tab_cur, out) : SSV_E_ARG; }
+int ssv_clip_table_wait_prev(ssv_ctx *c, ssv_cluster_table *out) { return c && out ? table_wait(c, c->tab_cur ^ 1, out) : SSV_E_ARG; }
+
+static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
+{
+	HIPCHECK(c, hipSetDevice(c->device));
+	ssv_ctx::TableSet &T = c->tab[which];
+	memset(out, 0, sizeof(*out));
+	if (T.in_flight) {
+		ProfScope pd(c, P_TABLE_D2H, T.n_clusters); // what is left of the copy when the caller asks for the table
+		HIPCHECK(c, hipEventSynchronize(T.copied));
+		T.in_flight = false;
+	}
+	out->n_events = T.n_events; out->n_clusters = T.n_clusters;
+	if (T.n_clusters == 0) return SSV_OK;
+	out->tid = P<int32_t>(T.h_tid); out->pos = P<int32_t>(T.h_pos); out->side = P<uint8_t>(T.h_side); out->support = P<int32_t>(T.h_support);
+	out->left_len = P<int32_t>(T.h_ll); out->right_len = P<int32_t>(T.h_lr); out->qual_missing = P<uint8_t>(T.h_qmiss); out->str_off = P<uint64_t>(T.h_stroff);
+	out->str = P<uint8_t>(T.h_str); out->cigar_off = P<uint64_t>(T.h_cigoff); out->n_cigar = P<int32_t>(T.h_ncig); out->cigar = P<uint32_t>(T.h_cig);
+	return SSV_OK;
+}
+
+int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
+{
+	if (!c || !out) return SSV_E_ARG;
+	CHECK(ssv_clip_cluster_async(c, nullptr, nullptr));
+	return ssv_clip_table_wait(c, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -77,6 +77,18 @@ class Context:
         self._check(self._lib.ssv_clip_cluster(self._h, C.byref(t)), "ssv_clip_cluster")
         return table_to_dict(t) if as_dict else t
 
+    def clip_cluster_async(self):
+        """Cluster and queue the table's copy to the host; -> (n_clusters, n_events).  Collect with clip_table_wait()."""
+        nc, ne = C.c_int64(), C.c_int64()
+        self._check(self._lib.ssv_clip_cluster_async(self._h, C.byref(nc), C.byref(ne)), "ssv_clip_cluster_async")
+        return nc.value, ne.value
+
+    def clip_table_wait(self, prev=False, as_dict=False):
+        t = _abi.ClusterTable()
+        fn = self._lib.ssv_clip_table_wait_prev if prev else self._lib.ssv_clip_table_wait
+        self._check(fn(self._h, C.byref(t)), "ssv_clip_table_wait")
+        return table_to_dict(t) if as_dict else t
+
     def getclip(self, batches, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
         """InputBamOutputReads' record loop over a list of batches -> cluster table dict."""
         self.clip_begin(match_rate, min_mapq, save_low_quality, own, initial_last_tid)
