@@ -45,8 +45,9 @@ def main():
     ap.add_argument("--genome-frac", type=float, default=1.0, help="scale the contigs (and the record count) down, e.g. 0.015625 for a quick run")
     ap.add_argument("--depth", type=float, default=30.0, help="per-GPU coverage")
     ap.add_argument("--n-sv", type=int, default=10000)
-    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="records of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="collect every cluster table in its own step (no copy in flight while other kernels run); use under rocprofv3, which serialises dispatches of different streams")
     args = ap.parse_args()
 
     import torch
@@ -148,6 +149,9 @@ def main():
         # overlaps with the getsv passes and with the next step's kernels; every table is collected before the timed region ends
         n_clusters, n_events = ctx.clip_cluster_async()
         lap("clip_cluster(kernels)")
+        if args.no_overlap or timed is not None:
+            collect_table(prev=False)   # the per-kernel breakdown step and --no-overlap runs: nothing else in flight
+            lap("table_d2h(wait)")
         rc, npairs, mean, sd = ctx.isize_stats([prefix_batch], 20, 5000000)
         lap("isize_stats")
         worker.join()
@@ -159,10 +163,11 @@ def main():
         ctx.getsv_scan(own_batch)
         counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
         lap("getsv_scan+finish")
-        if state["pending"]:
-            collect_table(prev=True)
-        state["pending"] = True
-        lap("table_wait(previous step)")
+        if not (args.no_overlap or timed is not None):
+            if state["pending"]:
+                collect_table(prev=True)
+            state["pending"] = True
+            lap("table_wait(previous step)")
         vec = shard.pack_results(counts, rs, pd, n_clusters, n_events, state["support_sum"])
         stacked = shard.all_gather_vector(vec, coll_dev)
         merged = shard.merge_results(stacked, len(counts), len(rs), len(pd))
@@ -214,7 +219,7 @@ def main():
         # dominant kernel = the longest-running kernel group of the device path that streams HBM (PCIe copies excluded)
         cand = {k: v for k, v in allprof.items() if k in ALGO_BYTES and v["launches"]}
         dom = max(cand, key=lambda k: cand[k]["total_ms"] / cand[k]["launches"])
-        src = prof[dom] if dom in prof and prof[dom]["launches"] else allprof[dom]  # streaming kernels: averaged over the timed region
+        src = allprof[dom]  # from the extra step that runs with no PCIe copy in flight (kernels of the timed steps overlap with the table copy)
         launches = max(src["launches"], 1)
         avg_ms = src["total_ms"] / launches
         units = src["units"] / launches
@@ -254,24 +259,31 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(w, hdr, n_sample):
-    """The CPU oracle (plain-C restatement of the reference, oracle/) on a bounded prefix of the same workload, 1 thread."""
+def cpu_baseline(w, hdr, n_sample, min_seconds=10.0):
+    """The CPU oracle (plain-C restatement of the reference, oracle/) on a bounded prefix of the same workload, 1 thread:
+    whole passes (getclip + insert size + discordant + depth) are repeated until >= min_seconds of CPU work have been timed."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from seeksv_amd import host
     b = w.generate_host(0, n_sample)
+    passes, t_clip = 0, 0.0
     t0 = time.perf_counter()
-    d = O.getclip([b])
-    t_clip = time.perf_counter() - t0
-    rc, npairs, mean, sd = O.isize_stats([b], 20, 5000000)
-    plan = host.Plan(hdr, w.junctions, mean, sd)
-    counts = O.discordant([b], plan.junctions, mean, sd, 4, 20)
-    rs, pd, _ = O.depth([b], plan.windows, plan.ranges, plan.points, 20)
-    dt = time.perf_counter() - t0
-    plan.close()
-    return {"value": n_sample / dt, "unit": "records/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_sample} records of the same synthetic workload (getclip {t_clip:.2f} s of {dt:.2f} s); oracle = plain-C restatement of seeksv v1.2.3, "
-                      "pinned to the real reference on tests/golden",
+    while True:
+        t1 = time.perf_counter()
+        d = O.getclip([b])
+        t_clip += time.perf_counter() - t1
+        rc, npairs, mean, sd = O.isize_stats([b], 20, 5000000)
+        plan = host.Plan(hdr, w.junctions, mean, sd)
+        O.discordant([b], plan.junctions, mean, sd, 4, 20)
+        O.depth([b], plan.windows, plan.ranges, plan.points, 20)
+        plan.close()
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or passes >= 64:
+            break
+    return {"value": n_sample * passes / dt, "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} passes over the first {n_sample} records of the same synthetic workload = {dt:.1f} s of CPU work (getclip {t_clip:.1f} s); "
+                      "oracle = plain-C restatement of seeksv v1.2.3 on decoded SoA records (no BGZF inflate / BAM parse), pinned to the real reference on tests/golden",
             "clusters": int(d["n_clusters"]), "events": int(d["n_events"])}
 
 
