@@ -193,9 +193,14 @@ def main():
     ctx.prof_enable(2)  # HIP events around the two streaming kernels only, on the context's stream
     barrier()
     t0 = time.perf_counter()
+    step_walls = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         res = step()
+        step_walls.append(round((time.perf_counter() - ts) * 1e3, 2))
+    tb = time.perf_counter()
     barrier()
+    step_walls.append(("final_barrier", round((time.perf_counter() - tb) * 1e3, 2)))
     dt = time.perf_counter() - t0
     prof = {k: ctx.prof_get(k) for k in ("clip_scan", "getsv_scan")}
     ctx.prof_enable(0)
@@ -249,6 +254,7 @@ def main():
                                    for k, v in cand.items()}},
             "kernel_ms_one_step": breakdown,
             "wall_ms_one_step": {k: round(v, 3) for k, v in wall.items()},
+            "wall_ms_timed_steps": step_walls,
             "result": res,
         }
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:

@@ -176,14 +176,27 @@ __device__ __forceinline__ void stage_tile_candidates(uint32_t mask, uint64_t pa
 		if (!fits) *overflow = 1;
 	}
 	if (mask && fits) {
+		// first slot of this lane inside each sub-tile
+		uint32_t first[CS_SUB];
 		uint32_t sub_base = 0;
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) {
-			uint32_t slot = cursor + sub_base + (uint32_t)((ex >> (16 * sub)) & 0xffff);
-#pragma unroll
-			for (int k = 0; k < ITEMS; ++k)
-				if (mask & (1u << (sub * ITEMS + k))) stage[region + slot++] = (uint32_t)(first_rec_of_lane + (int64_t)sub * (BLOCK * ITEMS) + k);
+			first[sub] = cursor + sub_base + (uint32_t)((ex >> (16 * sub)) & 0xffff);
 			sub_base += (uint32_t)((tot >> (16 * sub)) & 0xffff);
+		}
+		// one store per candidate: the loop runs max-popcount-in-the-wave times (1-3 at WGS rates) instead of one predicated
+		// store instruction per record slot
+		constexpr uint32_t SUBMASK = ITEMS == 32 ? 0xffffffffu : ((1u << ITEMS) - 1u);
+		uint32_t m = mask;
+		while (m) {
+			const int b = __ffs((int)m) - 1;
+			m &= m - 1;
+			const int sub = b / ITEMS, k = b % ITEMS;
+			const uint32_t below = mask & ((1u << b) - 1u) & (SUBMASK << (sub * ITEMS));
+			uint32_t f = first[0];
+#pragma unroll
+			for (int q = 1; q < CS_SUB; ++q) f = sub == q ? first[q] : f;
+			stage[region + f + (uint32_t)__popc(below)] = (uint32_t)(first_rec_of_lane + (int64_t)sub * (BLOCK * ITEMS) + k);
 		}
 	}
 	if (fits) cursor += total;
@@ -193,28 +206,37 @@ __device__ __forceinline__ void stage_tile_candidates(uint32_t mask, uint64_t pa
 // "nS" is skipped like in the oracle), so the pass reads nothing but n_cigar - 2 B/record, one 16-byte load per lane per 8 records,
 // four loads in flight per lane - and writes the indices of the records with n_cigar >= 2 (indels and clips: ~3 % of a WGS BAM).
 // Their CIGAR ends are looked at by k_clip_filter, one thread per candidate.  Persistent workgroups, private staging, no atomics.
+__device__ __forceinline__ void clip_scan_load(const ClipScanArgs &a, int64_t tile, uint4 (&v)[CS_SUB])
+{
+	const int64_t t0 = tile * CC_TILE + (int64_t)threadIdx.x * CC_ITEMS;
+	if ((tile + 1) * CC_TILE <= a.n) { // workgroup-uniform: the whole tile is in range, all four loads issue back to back
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) v[sub] = stream_load_u4(a.n_cigar + t0 + (int64_t)sub * (BLOCK * CC_ITEMS));
+	} else {
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CC_ITEMS);
+			uint32_t h[CC_ITEMS];
+#pragma unroll
+			for (int k = 0; k < CC_ITEMS; ++k) h[k] = i0 + k < a.n ? a.n_cigar[i0 + k] : 0u;
+			v[sub] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+		}
+	}
+}
+
 __global__ __launch_bounds__(BLOCK) void k_clip_scan(ClipScanArgs a)
 {
 	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
 	uint32_t cursor = 0;
 	int parity = 0;
 	const int64_t region = (int64_t)blockIdx.x * a.block_cap;
+	uint4 v[CS_SUB], nxt[CS_SUB];
+	if ((int64_t)blockIdx.x < a.ntiles) clip_scan_load(a, blockIdx.x, v);
 	for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
 		const int64_t t0 = tile * CC_TILE + (int64_t)threadIdx.x * CC_ITEMS;
-		uint4 v[CS_SUB];
-		if ((tile + 1) * CC_TILE <= a.n) { // workgroup-uniform: the whole tile is in range, all four loads issue back to back
-#pragma unroll
-			for (int sub = 0; sub < CS_SUB; ++sub) v[sub] = *reinterpret_cast<const uint4 *>(a.n_cigar + t0 + (int64_t)sub * (BLOCK * CC_ITEMS));
-		} else {
-#pragma unroll
-			for (int sub = 0; sub < CS_SUB; ++sub) {
-				const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CC_ITEMS);
-				uint32_t h[CC_ITEMS];
-#pragma unroll
-				for (int k = 0; k < CC_ITEMS; ++k) h[k] = i0 + k < a.n ? a.n_cigar[i0 + k] : 0u;
-				v[sub] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-			}
-		}
+		// software pipeline: the next tile's loads are in flight while this tile is classified, scanned and staged
+		const int64_t next = tile + gridDim.x;
+		if (next < a.ntiles) clip_scan_load(a, next, nxt);
 		uint32_t mask = 0;
 		uint64_t packed = 0;
 #pragma unroll
@@ -230,6 +252,8 @@ __global__ __launch_bounds__(BLOCK) void k_clip_scan(ClipScanArgs a)
 			packed += (uint64_t)__popc(bits) << (16 * sub);
 		}
 		stage_tile_candidates<CC_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, a.block_cap, a.tile_cnt, a.tile_off, a.stage, a.overflow);
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) v[sub] = nxt[sub];
 	}
 }
 

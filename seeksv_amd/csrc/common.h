@@ -10,6 +10,21 @@ namespace ssv {
 enum : int { F_PAIRED = 1, F_PROPER = 2, F_UNMAP = 4, F_MUNMAP = 8, F_REV = 16, F_MREV = 32, F_SECONDARY = 256, F_QCFAIL = 512, F_DUP = 1024 };
 enum : int { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5, C_P = 6, C_EQ = 7, C_X = 8 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte streaming load that does not displace the L2 working set (the record arrays are read exactly once)
+__device__ __forceinline__ uint4 stream_load_u4(const void *p)
+{
+	u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int4 stream_load_i4(const void *p)
+{
+	i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
+	return make_int4(v.x, v.y, v.z, v.w);
+}
+
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;            // 4 waves per workgroup
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;

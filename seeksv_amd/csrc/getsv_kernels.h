@@ -260,6 +260,27 @@ struct GetsvStage {
 // the record's start tile up in the genome tile map (L2 resident, wave-coherent because the BAM is coordinate sorted) and writes the
 // indices of the ~1 % of records that start near a depth window or a junction window.  Same persistent, atomic-free structure as
 // k_clip_scan; the lookups are branch-free (clamped indices) so that they pipeline.
+__device__ __forceinline__ void getsv_scan_load(const DevBatch &b, int64_t tile, int4 (&t4)[CS_SUB], int4 (&p4)[CS_SUB])
+{
+	const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+	if ((tile + 1) * CS_TILE <= b.n) { // workgroup-uniform
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			t4[sub] = stream_load_i4(b.tid + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
+			p4[sub] = stream_load_i4(b.pos + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
+		}
+	} else {
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CS_ITEMS);
+			int tt[CS_ITEMS], pp[CS_ITEMS];
+#pragma unroll
+			for (int k = 0; k < CS_ITEMS; ++k) { bool in = i0 + k < b.n; tt[k] = in ? b.tid[i0 + k] : -1; pp[k] = in ? b.pos[i0 + k] : 0; }
+			t4[sub] = make_int4(tt[0], tt[1], tt[2], tt[3]); p4[sub] = make_int4(pp[0], pp[1], pp[2], pp[3]);
+		}
+	}
+}
+
 __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 {
 	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
@@ -268,25 +289,12 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 	int parity = 0;
 	const int64_t region = (int64_t)blockIdx.x * g.block_cap;
 	const int last_tid = a.n_targets - 1;
+	int4 t4[CS_SUB], p4[CS_SUB], nt4[CS_SUB], np4[CS_SUB];
+	if ((int64_t)blockIdx.x < g.ntiles) getsv_scan_load(b, blockIdx.x, t4, p4);
 	for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, parity ^= 1) {
 		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
-		int4 t4[CS_SUB], p4[CS_SUB];
-		if ((tile + 1) * CS_TILE <= b.n) { // workgroup-uniform
-#pragma unroll
-			for (int sub = 0; sub < CS_SUB; ++sub) {
-				t4[sub] = *reinterpret_cast<const int4 *>(b.tid + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
-				p4[sub] = *reinterpret_cast<const int4 *>(b.pos + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
-			}
-		} else {
-#pragma unroll
-			for (int sub = 0; sub < CS_SUB; ++sub) {
-				const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CS_ITEMS);
-				int tt[CS_ITEMS], pp[CS_ITEMS];
-#pragma unroll
-				for (int k = 0; k < CS_ITEMS; ++k) { bool in = i0 + k < b.n; tt[k] = in ? b.tid[i0 + k] : -1; pp[k] = in ? b.pos[i0 + k] : 0; }
-				t4[sub] = make_int4(tt[0], tt[1], tt[2], tt[3]); p4[sub] = make_int4(pp[0], pp[1], pp[2], pp[3]);
-			}
-		}
+		const int64_t next = tile + gridDim.x;
+		if (next < g.ntiles) getsv_scan_load(b, next, nt4, np4); // software pipeline, as in k_clip_scan
 		uint32_t mask = 0;
 		uint64_t packed = 0;
 #pragma unroll
@@ -307,6 +315,8 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 			}
 		}
 		stage_tile_candidates<CS_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) { t4[sub] = nt4[sub]; p4[sub] = np4[sub]; }
 	}
 }
 

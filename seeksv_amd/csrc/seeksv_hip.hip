@@ -205,10 +205,13 @@ void prof_collect(ssv_ctx *c)
 	c->prof_recs.clear();
 }
 
-// persistent streaming kernels: workgroups per launch (override for experiments: SSV_SCAN_BLOCKS)
-inline unsigned scan_blocks(int64_t ntiles)
+// persistent streaming kernels: the grid is the number of workgroups that are resident at once (a larger grid queues the surplus
+// behind the first wave of workgroups and stretches the kernel).  clip_scan: 106 SGPRs -> 6 workgroups of 256 threads per CU;
+// getsv_scan: 104 VGPRs (software-pipelined loads) -> 4 per CU.  Overrides for experiments: SSV_CLIP_SCAN_BLOCKS, SSV_GETSV_SCAN_BLOCKS.
+inline unsigned scan_blocks(int64_t ntiles, const char *env, int64_t dflt)
 {
-	static int64_t cfg = [] { const char *e = getenv("SSV_SCAN_BLOCKS"); return e ? atoll(e) : (int64_t)1536; }(); // 256 CUs x 6 resident workgroups (SGPR-limited)
+	const char *e = getenv(env);
+	int64_t cfg = e ? atoll(e) : dflt;
 	return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, std::min<int64_t>(cfg, CS_MAX_BLOCKS)));
 }
 
@@ -393,7 +396,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 	CHECK(stage_batch(c, b, d));
 	if (!d.cigar || !d.seq_off) { c->err = "batch without cigar / seq_off"; return SSV_E_ARG; }
 	const int64_t ntiles = (d.n + CC_TILE - 1) / CC_TILE;
-	const unsigned grid = scan_blocks(ntiles);
+	const unsigned grid = scan_blocks(ntiles, "SSV_CLIP_SCAN_BLOCKS", 256 * 6);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
 	CHECK(ensure(c, c->tile_off, ntiles * 4));
 	CHECK(ensure(c, c->tile_base, ntiles * 4));
@@ -588,6 +591,18 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	}
 	HIPCHECK(c, hipEventRecord(T.copied, c->st_copy));
 	T.in_flight = true;
+	// size the other table set like this one now (pinning ~2 GB of host memory takes ~100 ms: better here than in the caller's next pass)
+	ssv_ctx::TableSet &O = c->tab[s_ ^ 1];
+	if (!O.in_flight) {
+		struct { HBuf *h; DBuf *d; size_t bytes; } oc[] = {
+			{&O.h_tid, &O.o_tid, (size_t)nc * 4}, {&O.h_pos, &O.o_pos, (size_t)nc * 4}, {&O.h_side, &O.o_side, (size_t)nc}, {&O.h_support, &O.o_support, (size_t)nc * 4},
+			{&O.h_ll, &O.o_ll, (size_t)nc * 4}, {&O.h_lr, &O.o_lr, (size_t)nc * 4}, {&O.h_qmiss, &O.o_qmiss, (size_t)nc}, {&O.h_stroff, &O.o_stroff, (size_t)nc * 8},
+			{&O.h_cigoff, &O.o_cigoff, (size_t)nc * 8}, {&O.h_ncig, &O.o_ncig, (size_t)nc * 4}, {&O.h_str, &O.o_str, (size_t)str_total}, {&O.h_cig, &O.o_cig, (size_t)cig_total * 4}};
+		for (auto &x : oc) {
+			if (x.h->cap < x.bytes + 16) CHECK(ensure_host(c, *x.h, x.bytes + 16));
+			if (x.d->cap < x.bytes + 16) { void *np = nullptr; HIPCHECK(c, hipMalloc(&np, x.bytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.bytes + 16; }
+		}
+	}
 	return SSV_OK;
 }
 
@@ -801,7 +816,7 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	a.win_tid = P<int32_t>(c->gs_wtid); a.win_beg = P<int32_t>(c->gs_wbeg); a.win_end = P<int32_t>(c->gs_wend); a.win_off = P<int64_t>(c->gs_woff);
 	a.n_win = (int64_t)c->gs_win.size(); a.depth_min_mapq = c->gs_p.depth_min_mapq; a.diff = P<int32_t>(c->gs_diff);
 	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
-	const unsigned grid = scan_blocks(ntiles);
+	const unsigned grid = scan_blocks(ntiles, "SSV_GETSV_SCAN_BLOCKS", 256 * 4);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
 	CHECK(ensure(c, c->tile_off, ntiles * 4));
 	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
