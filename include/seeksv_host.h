@@ -38,6 +38,19 @@ const int32_t *ssvh_bam_target_lens(const ssvh_bam *b);
  */
 int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_batch_t *out);
 
+/* One record at a time, with its read name and CIGAR (host-side consumers of small BAMs: the clip.bam join of getsv,
+ * getsv.h:445-527).  Returns 1 and fills *out (pointers valid until the next call), 0 at end of file, <0 on error. */
+typedef struct {
+	int32_t tid, pos, l_qseq;
+	uint16_t flag, n_cigar;
+	uint8_t mapq;
+	const char *qname;
+	const uint32_t *cigar;
+	const uint8_t *seq;   /* packed 4-bit bases */
+	const uint8_t *qual;
+} ssvh_record;
+int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out);
+
 /* Records with UNMAP|MUNMAP seen in the last batch: qname / decoded bases / qualities for the
  * unmapped-pair FASTQ side channel (clip_reads.h:415-419).  Index k in [0, n).  Host only. */
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b);

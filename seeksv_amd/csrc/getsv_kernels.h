@@ -297,21 +297,61 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 		if (next < g.ntiles) getsv_scan_load(b, next, nt4, np4); // software pipeline, as in k_clip_scan
 		uint32_t mask = 0;
 		uint64_t packed = 0;
+		// Fast path (coordinate-sorted input at WGS depth): every record of this wavefront's share of the tile is on one contig and
+		// their start tiles span < 64 genome tiles.  Then 64 tile-map bytes are fetched once per wavefront (one byte per lane), turned
+		// into a wave-uniform 64-bit "tile is interesting" mask by a ballot, and each record only shifts that mask - no per-record
+		// memory access at all.
+		const int tid0 = __builtin_amdgcn_readfirstlane(t4[0].x);
+		bool same = true;
+		int tmin = 0x7fffffff, tmax = -1;
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) {
 			const int tid[CS_ITEMS] = {t4[sub].x, t4[sub].y, t4[sub].z, t4[sub].w};
 			const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
 #pragma unroll
 			for (int k = 0; k < CS_ITEMS; ++k) {
-				// clamped, unconditional lookups; validity is applied afterwards
-				const int tc = tid[k] < 0 ? 0 : (tid[k] > last_tid ? last_tid : tid[k]);
-				const int64_t lo = a.ctg_tile_off[tc], hi = a.ctg_tile_off[tc + 1];
-				int64_t t = lo + ((pos[k] < 0 ? 0 : pos[k]) >> TILE_SHIFT);
-				const bool valid = tid[k] >= 0 && tid[k] <= last_tid && pos[k] >= 0 && t < hi;
-				t = t < hi ? t : hi - 1;
-				const bool cand = valid && a.tilemap[t] != 0;
-				mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
-				packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
+				same = same && tid[k] == tid0 && pos[k] >= 0;
+				const int tl = pos[k] >> TILE_SHIFT;
+				tmin = tl < tmin ? tl : tmin;
+				tmax = tl > tmax ? tl : tmax;
+			}
+		}
+		const bool uniform = __all(same) && tid0 >= 0 && tid0 <= last_tid;
+		int wmin = 0, wmax = 0;
+		if (uniform) { wmin = -wave_max(-tmin); wmax = wave_max(tmax); }
+		if (uniform && wmax - wmin < WAVE) {
+			const int64_t lo = a.ctg_tile_off[tid0], hi = a.ctg_tile_off[tid0 + 1]; // wave-uniform addresses
+			const int64_t mine = lo + wmin + lane_id();
+			const uint64_t interesting = __ballot(mine < hi && a.tilemap[mine < hi ? mine : hi - 1] != 0);
+			const int ntile_ctg = (int)(hi - lo);
+#pragma unroll
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
+#pragma unroll
+				for (int k = 0; k < CS_ITEMS; ++k) {
+					const int tl = pos[k] >> TILE_SHIFT;
+					const bool cand = tl < ntile_ctg && ((interesting >> (tl - wmin)) & 1ull);
+					mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
+					packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				const int tid[CS_ITEMS] = {t4[sub].x, t4[sub].y, t4[sub].z, t4[sub].w};
+				const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
+#pragma unroll
+				for (int k = 0; k < CS_ITEMS; ++k) {
+					// clamped, unconditional lookups; validity is applied afterwards
+					const int tc = tid[k] < 0 ? 0 : (tid[k] > last_tid ? last_tid : tid[k]);
+					const int64_t lo = a.ctg_tile_off[tc], hi = a.ctg_tile_off[tc + 1];
+					int64_t t = lo + ((pos[k] < 0 ? 0 : pos[k]) >> TILE_SHIFT);
+					const bool valid = tid[k] >= 0 && tid[k] <= last_tid && pos[k] >= 0 && t < hi;
+					t = t < hi ? t : hi - 1;
+					const bool cand = valid && a.tilemap[t] != 0;
+					mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
+					packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
+				}
 			}
 		}
 		stage_tile_candidates<CS_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);

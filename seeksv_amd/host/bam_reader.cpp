@@ -253,6 +253,30 @@ int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_
 	return 0;
 }
 
+int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
+{
+	g_err.clear();
+	int32_t block_size;
+	size_t got = b->z.read(&block_size, 4);
+	if (got == 0) return g_err.empty() ? 0 : -1;
+	if (got != 4 || block_size < 32) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
+	b->rec.resize((size_t)block_size + 4);
+	if (b->z.read(b->rec.data(), (size_t)block_size) != (size_t)block_size) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
+	const uint8_t *r = b->rec.data();
+	memcpy(&out->tid, r, 4); memcpy(&out->pos, r + 4, 4);
+	const uint8_t l_read_name = r[8];
+	out->mapq = r[9];
+	memcpy(&out->n_cigar, r + 12, 2); memcpy(&out->flag, r + 14, 2); memcpy(&out->l_qseq, r + 16, 4);
+	const size_t o_cig = 32 + (size_t)l_read_name, o_seq = o_cig + 4 * (size_t)out->n_cigar, o_qual = o_seq + ((size_t)out->l_qseq + 1) / 2;
+	if (out->l_qseq < 0 || o_qual + (size_t)out->l_qseq > (size_t)block_size) { g_err = "corrupt BAM record"; return -1; }
+	out->qname = (const char *)r + 32;
+	b->cigar.assign((size_t)out->n_cigar, 0); // aligned copy
+	if (out->n_cigar) memcpy(b->cigar.data(), r + o_cig, 4 * (size_t)out->n_cigar);
+	out->cigar = b->cigar.data();
+	out->seq = r + o_seq; out->qual = r + o_qual;
+	return 1;
+}
+
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { return (int64_t)b->unmapped.size(); }
 
 int ssvh_bam_unmapped_get(const ssvh_bam *b, int64_t k, const char **qname, const char **seq, const char **qual, int *is_read1)

@@ -5,9 +5,9 @@
 //   seeksv getclip [-t f] [-q n] [-s] [-o prefix] in.sorted.bam
 //   seeksv getsv   [options] clip.bam in.sorted.bam clip.gz out.sv out.unmapped.clip.fq
 //
-// getsv in this build takes its junctions from `-B <table>` (the reference's ReadBreakpoint, getsv.cpp:1292); assembling
-// junctions from clip.bam x clip.gz (InputSoftInfoStoreBreakpoint / GetJunction / MergeJunction) is not part of it yet
-// and the program says so instead of producing a different table.  No .bai is needed: the discordant pass scans the BAM.
+// getsv: junctions come from `-B <table>` (ReadBreakpoint, getsv.cpp:1292) and / or from the join of clip.gz with clip.bam
+// (junction_stage.cpp); the BAM passes run on the GPU; OutputBreakpoint's filter chain and columns are reproduced here.
+// No .bai is needed: the discordant pass scans the BAM instead of seeking in it.
 #include <getopt.h>
 #include <zlib.h>
 
@@ -22,10 +22,16 @@
 #include <string>
 #include <vector>
 
+#include "junction_stage.h"
 #include "seeksv_hip.h"
 #include "seeksv_host.h"
 
 using namespace std;
+using seeksv::Junction;
+using seeksv::JunctionMap;
+using seeksv::OtherInfo;
+using seeksv::SeqInfo;
+using seeksv::parse_cigar;
 
 static const char *kVersion = "1.2.3-mi355x";
 
@@ -59,7 +65,8 @@ static const char *kVersion = "1.2.3-mi355x";
 [[noreturn]] static void usage_getsv()
 {
 	cerr << "Usage: seeksv getsv [options] <input clipped sequence bam> <input orignal sorted bam> <soft-clipped reads file(*clip.gz)> <output SVs> <output unmaped clipped sequence fastq>\n"
-	     << "Options: -B <FILE>             junction table (23 columns, as written by getsv) to evaluate\n"
+	     << "Options: -B <FILE>             junction table (23 columns, as written by getsv) to evaluate in addition\n"
+	     << "         -l <int>              Maximum search length to find microhomology [50]\n"
 	     << "         -q <int>              Minimum mapping quality of discordant read pair [20]\n"
 	     << "         -n <int>              Number of read pairs used to calculate insert size [5000000]; < 100000 switches the discordant pass off\n"
 	     << "         -b <int>              Minimum number of soft clipping reads (left + right) [3]\n"
@@ -71,7 +78,7 @@ static const char *kVersion = "1.2.3-mi355x";
 	     << "         -m <int>              Minimum length of up_seq / down_seq when no read pair supports the junction [30]\n"
 	     << "         -i <int>              Maximum indel number of up_seq / down_seq when no read pair supports the junction [1]\n"
 	     << "         -L <int>              Flank length for the average depths [200]\n"
-	     << "         -l <int> -t <double> -Q <int> -w <int> -F <FILE>   accepted for compatibility (junction assembly options)\n"
+	     << "         -t <double> -Q <int> -w <int>   accepted for compatibility\n"
 	     << "         -G <int>              GPU ordinal [0]" << endl;
 	exit(1);
 }
@@ -197,30 +204,6 @@ static int cmd_getclip(int argc, char **argv)
 // getsv (junctions from -B)
 // ---------------------------------------------------------------------------------------------------------------------
 
-struct Junction { // getsv.h:149-227
-	string up_chr; int up_pos; char up_strand; string down_chr; int down_pos; char down_strand;
-	bool operator<(const Junction &o) const
-	{
-		if (up_chr != o.up_chr) return up_chr < o.up_chr;
-		if (down_chr != o.down_chr) return down_chr < o.down_chr;
-		if (up_strand != o.up_strand) return up_strand < o.up_strand;
-		if (down_strand != o.down_strand) return down_strand < o.down_strand;
-		if (up_pos != o.up_pos) return up_pos < o.up_pos;
-		return down_pos < o.down_pos;
-	}
-};
-
-struct SeqInfo { string seq; vector<pair<int, char>> cigar_vec; int left_clipped = 0, right_clipped = 0, support = 0, uniq = 0; };
-struct OtherInfo { SeqInfo up, down; int microhomology = 0, abnormal = 0; };
-
-static vector<pair<int, char>> parse_cigar(const string &cigar) // ChangeCigarType, getsv.cpp:433
-{
-	vector<pair<int, char>> v;
-	int len = 0;
-	for (char ch : cigar) { if (isdigit((unsigned char)ch)) len = len * 10 + (ch - 48); else { v.push_back(make_pair(len, ch)); len = 0; } }
-	return v;
-}
-
 static string cigar_text(const SeqInfo &s) // DisplayCigarVector, clip_reads.h:489-505
 {
 	string o;
@@ -251,12 +234,12 @@ static double largest_base_frequency(const string &seq) // CountLargestBaseFrequ
 
 static int cmd_getsv(int argc, char **argv)
 {
-	string connect_bam, temp_breakpoint;
+	string connect_bam, temp_breakpoint, dump_junctions;
 	double frequency = 0.1;
 	int c, min_mapQ = 20, read_pair_used = 5000000, sum_min_no_both_clipped_reads = 3, min_distance = 50, microhomology_length = 50, times = 4, device = 0,
 	       min_abnormal_read_pair_no = 0, flank_length = 200, min_seq_len = 30, max_seq_indel_no = 1, flank = 50;
 	bool output_depth = true;
-	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:")) >= 0) {
+	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:")) >= 0) {
 		switch (c) {
 		case 'F': connect_bam = optarg; break;
 		case 'B': temp_breakpoint = optarg; break;
@@ -273,7 +256,8 @@ static int cmd_getsv(int argc, char **argv)
 		case 'T': microhomology_length = atoi(optarg); break;
 		case 'L': flank_length = atoi(optarg); break;
 		case 'G': device = atoi(optarg); break;
-		default: break; // -t -Q -w -a -R -r: junction assembly options, accepted
+		case 'J': dump_junctions = optarg; break;
+		default: break; // -t -Q -w -a -R -r: accepted, unused (as in the reference, where -t / -Q no longer reach the join)
 		}
 	}
 	if (argc != optind + 5) usage_getsv();
@@ -281,7 +265,7 @@ static int cmd_getsv(int argc, char **argv)
 	const string clip_bam = argv[optind], original_bam = argv[optind + 1], clipfile = argv[optind + 2], breakpoint_file = argv[optind + 3], clip_unmap_fq_file = argv[optind + 4];
 	if (!connect_bam.empty()) die("[seeksv] -F (bwasw read-through input) is not supported by this build");
 
-	multimap<Junction, OtherInfo> junction2other;
+	JunctionMap junction2other;
 	if (!temp_breakpoint.empty()) { // ReadBreakpoint, getsv.cpp:1292-1323
 		ifstream fin(temp_breakpoint.c_str());
 		if (!fin) cerr << "Cannot open file " << temp_breakpoint << endl;
@@ -303,15 +287,22 @@ static int cmd_getsv(int argc, char **argv)
 		}
 		cerr << "[ReadBreakpoint] finish" << endl;
 	}
-	{ // junction assembly from clip.bam x clip.gz is not in this build: refuse rather than print a different table
-		ssvh_bam *cb = nullptr;
-		if (ssvh_bam_open(clip_bam.c_str(), &cb) != 0) die("[main_samview] fail to open file for reading.");
-		ssv_batch_t b;
-		if (ssvh_bam_read_batch(cb, 1, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
-		if (b.n > 0) die("[seeksv] this build evaluates junctions given with -B; assembling junctions from clip.bam x clip.gz is not implemented yet");
-		ssvh_bam_close(cb);
+	{ // InputSoftInfoStoreBreakpoint + GetJunction (getsv.h:423, getsv.cpp:1705): clip clusters x re-alignments of their clipped sequences
+		string err = seeksv::assemble_junctions(clipfile, clip_bam, junction2other);
+		if (!err.empty()) die(err);
 	}
 	cerr << "'InputSoftInfoStoreBreakpoint' finished" << endl;
+	seeksv::merge_junctions(junction2other, flank); // MergeJunction(flank = -l)
+	if (!dump_junctions.empty()) { // test hook: the junction table before any BAM pass (no GPU needed)
+		ofstream jd(dump_junctions.c_str());
+		for (auto &kv : junction2other) {
+			const Junction &j = kv.first; const OtherInfo &o = kv.second;
+			jd << j.up_chr << '\t' << j.up_pos << '\t' << j.up_strand << '\t' << o.up.support << '\t' << j.down_chr << '\t' << j.down_pos << '\t' << j.down_strand << '\t' << o.down.support << '\t'
+			   << o.microhomology << '\t' << o.abnormal << '\t' << sv_type(j) << "\t0\t0\t0\t0\t0\t0\t0\t0\t" << cigar_text(o.up) << '\t' << cigar_text(o.down) << '\t' << o.up.seq << '\t' << o.down.seq
+			   << '\t' << o.up.uniq << '\t' << o.down.uniq << '\n';
+		}
+		return 0;
+	}
 
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file " + original_bam + "for reading.");

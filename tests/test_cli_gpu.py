@@ -54,3 +54,24 @@ def test_cli_getsv_junction_table(tmp_path, case, prefix, flags):
     mean, sd = G.read_text("getsv", prefix + ".isize.txt").split()
     assert f"Mean insert size : {mean}\nMean deviation: {sd}\n" in r.stderr
     assert os.path.getsize(str(tmp_path / "x.fq")) == 0
+
+
+FULL = [("", []), (".b40", ["-b", "40"]), (".f2", ["-f", "2"]), (".d400", ["-d", "400"]), (".e60", ["-e", "60"]), (".D", ["-D"]), (".n0", ["-n", "0"])]
+
+
+@pytest.mark.parametrize("sample", ["cancer", "normal"])
+@pytest.mark.parametrize("tag,flags", FULL, ids=[t[0] or "default" for t in FULL])
+def test_cli_getsv_full_pipeline_example(tmp_path, sample, tag, flags):
+    """BASELINE configs[0]: getclip -> (bwa mem, committed clip.bam fixture) -> getsv on the bundled example BAMs: output.sv.txt and the
+    filtered-junction lines on stdout are byte-identical to seeksv v1.2.3's, for every filter flag the goldens were made with."""
+    ex = os.path.join(G.GOLDEN, "example")
+    out = str(tmp_path / "s")
+    r = subprocess.run([SEEKSV, "getclip", "-o", out, os.path.join(ex, sample + ".sort.bam")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sv = str(tmp_path / "out.sv")
+    r = subprocess.run([SEEKSV, "getsv"] + flags + [os.path.join(ex, sample + ".clip.bam"), os.path.join(ex, sample + ".sort.bam"), out + ".clip.gz", sv, str(tmp_path / "u.fq")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(sv).read() == G.read_text("example", f"{sample}{tag}.sv")
+    assert r.stdout == G.read_text("example", f"{sample}{tag}.getsv.stdout")
+    assert os.path.getsize(str(tmp_path / "u.fq")) == 0
