@@ -41,4 +41,12 @@ int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n
 	return 0;
 }
 
+// reference bases of a contig as ASCII (FASTA export of the hash-generated genome; golden generation only)
+int ssvs_ref_bases(const sy_config *cfg, int32_t tid, int64_t start, int64_t n, char *out)
+{
+	static const char T[16] = {'N', 'A', 'C', 'N', 'G', 'N', 'N', 'N', 'T', 'N', 'N', 'N', 'N', 'N', 'N', 'N'};
+	for (int64_t i = 0; i < n; ++i) out[i] = T[sy_ref_base(cfg, tid, start + i)];
+	return 0;
+}
+
 } // extern "C"

@@ -133,6 +133,18 @@ class Workload:
         # multimap<Junction,...> order (getsv.h:187-225)
         self.junctions = sorted(junctions, key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
 
+    def reference_fasta(self):
+        """The hash-generated reference genome as FASTA text (small workloads only; golden generation)."""
+        lib = _lib(False)
+        lib.ssvs_ref_bases.argtypes = [C.POINTER(SyConfig), C.c_int32, C.c_int64, C.c_int64, C.c_char_p]
+        out = []
+        for tid, (name, ln) in enumerate(zip(self.names, self.lens)):
+            buf = C.create_string_buffer(int(ln))
+            lib.ssvs_ref_bases(C.byref(self.cfg), tid, 0, int(ln), buf)
+            seq = buf.raw.decode()
+            out.append(f">{name}\n" + "\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)) + "\n")
+        return "".join(out)
+
     # ---- record generation ----
     def generate_host(self, g0, n):
         """records [g0, g0+n) as a dict of numpy arrays (a SSV_MEM_HOST batch)."""

@@ -89,3 +89,25 @@ def write_bam(path, target_names, target_lens, records, sam_header_text=None):
         if buf:
             f.write(_bgzf_block(bytes(buf)))
         f.write(BGZF_EOF)
+
+
+def soa_to_bam(path, names, lens, b):
+    import numpy as np
+    NT = "=ACMGRSVTWYHKDBN"
+    recs = []
+    no_seq = np.uint64(2 ** 64 - 1)
+    for i in range(len(b["tid"])):
+        co, nc, lq = int(b["cigar_off"][i]), int(b["n_cigar"][i]), int(b["l_qseq"][i])
+        cig = [(int(c) >> 4, int(c) & 15) for c in b["cigar"][co:co + nc]]
+        if b["seq_off"][i] != no_seq:
+            so = int(b["seq_off"][i])
+            packed = b["seqqual"][so:so + (lq + 1) // 2]
+            seq = "".join(NT[(int(packed[k >> 1]) >> (4 if k % 2 == 0 else 0)) & 15] for k in range(lq))
+            qual = bytes(b["seqqual"][so + (lq + 1) // 2: so + (lq + 1) // 2 + lq])
+        else:
+            seq, qual = "A" * lq, b"\x1e" * lq
+        recs.append(dict(qname=f"s{i}", flag=int(b["flag"][i]), tid=int(b["tid"][i]), pos=int(b["pos"][i]), mapq=int(b["mapq"][i]), cigar=cig,
+                         mtid=int(b["mtid"][i]), mpos=int(b["mpos"][i]), isize=int(b["isize"][i]), seq=seq, qual=qual))
+    write_bam(path, names, [int(x) for x in lens], recs)
+
+

@@ -351,26 +351,6 @@ def crafted_getsv():
 SYNTH_CASES = {"synth30x": dict(genome_frac=1 / 2048, depth=30, n_sv=40), "synth300x": dict(genome_frac=1 / 8192, depth=300, n_sv=24)}
 
 
-def soa_to_bam(path, names, lens, b):
-    import numpy as np
-    NT = "=ACMGRSVTWYHKDBN"
-    recs = []
-    no_seq = np.uint64(2 ** 64 - 1)
-    for i in range(len(b["tid"])):
-        co, nc, lq = int(b["cigar_off"][i]), int(b["n_cigar"][i]), int(b["l_qseq"][i])
-        cig = [(int(c) >> 4, int(c) & 15) for c in b["cigar"][co:co + nc]]
-        if b["seq_off"][i] != no_seq:
-            so = int(b["seq_off"][i])
-            packed = b["seqqual"][so:so + (lq + 1) // 2]
-            seq = "".join(NT[(int(packed[k >> 1]) >> (4 if k % 2 == 0 else 0)) & 15] for k in range(lq))
-            qual = bytes(b["seqqual"][so + (lq + 1) // 2: so + (lq + 1) // 2 + lq])
-        else:
-            seq, qual = "A" * lq, b"\x1e" * lq
-        recs.append(dict(qname=f"s{i}", flag=int(b["flag"][i]), tid=int(b["tid"][i]), pos=int(b["pos"][i]), mapq=int(b["mapq"][i]), cigar=cig,
-                         mtid=int(b["mtid"][i]), mpos=int(b["mpos"][i]), isize=int(b["isize"][i]), seq=seq, qual=qual))
-    bamio.write_bam(path, names, [int(x) for x in lens], recs)
-
-
 def synthetic():
     sys.path.insert(0, ROOT)
     from seeksv_amd import synth
@@ -380,7 +360,7 @@ def synthetic():
         w = synth.Workload(**kw)
         b = w.generate_host(0, w.n_total)
         bam = os.path.join(TMP, f"{name}.bam")
-        soa_to_bam(bam, w.names, w.lens, b)
+        bamio.soa_to_bam(bam, w.names, w.lens, b)
         run([os.path.join(BIN, "bamidx"), bam])
         run([SEEKSV, "getclip", "-o", name, bam], cwd=TMP)
         for ext in ("clip", "clip.fq"):
@@ -404,6 +384,45 @@ def synthetic():
         print(f"  {name}: {w.n_total} records, {len(w.junctions)} junctions")
 
 
+
+# ------------------------------------------------------------------------------------------------
+# 5. full pipeline on a synthetic sample with planted DEL / INV / TRA: getclip -> bwa mem against the
+#    hash-generated reference -> getsv.  Exercises the junction stage (reverse-strand re-alignments,
+#    translocations, MergeJunction) far beyond the three deletions of the bundled example.
+# ------------------------------------------------------------------------------------------------
+
+SYNTH_FULL = {"synthfull": dict(genome_frac=1 / 8192, depth=40, n_sv=24)}
+
+
+def synthetic_full():
+    sys.path.insert(0, ROOT)
+    from seeksv_amd import synth
+    out = os.path.join(HERE, "synth")
+    os.makedirs(out, exist_ok=True)
+    bwa = os.path.join(TMP, "bwa")
+    if not os.path.exists(bwa):
+        shutil.copy(os.path.join(REF, "example/bin/bwa"), bwa)
+        os.chmod(bwa, 0o755)
+    for name, kw in SYNTH_FULL.items():
+        w = synth.Workload(**kw)
+        b = w.generate_host(0, w.n_total)
+        bam = os.path.join(TMP, f"{name}.bam")
+        bamio.soa_to_bam(bam, w.names, w.lens, b)
+        run([os.path.join(BIN, "bamidx"), bam])
+        fa = os.path.join(TMP, f"{name}.fa")
+        with open(fa, "w") as f:
+            f.write(w.reference_fasta())
+        run([bwa, "index", fa], cwd=TMP)
+        run([SEEKSV, "getclip", "-o", name, bam], cwd=TMP)
+        run([bwa, "mem", fa, f"{name}.clip.fq.gz"], cwd=TMP, stdout=os.path.join(TMP, f"{name}.clip.sam"))
+        run([os.path.join(BIN, "sam2bam"), f"{name}.clip.sam", os.path.join(out, f"{name}.clip.bam")], cwd=TMP)
+        for tag, flags in (("", []), (".l90", ["-l", "90"]), (".loose", ["-f", "0", "-b", "0", "-d", "0"]), (".strict", ["-e", "10", "-b", "20"])):
+            run([SEEKSV, "getsv"] + flags + [os.path.join(out, f"{name}.clip.bam"), bam, f"{name}.clip.gz", os.path.join(out, f"{name}{tag}.sv"), "x.fq"], cwd=TMP,
+                stdout=os.path.join(out, f"{name}{tag}.stdout"))
+        n_sv = sum(1 for l in open(os.path.join(out, f"{name}.sv")) if not l.startswith("@"))
+        print(f"  {name}: {w.n_total} records, {len(w.junctions)} planted, {n_sv} SV rows")
+
+
 if __name__ == "__main__":
     if not os.path.exists(SEEKSV):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -412,4 +431,5 @@ if __name__ == "__main__":
     crafted_getclip()
     crafted_getsv()
     synthetic()
+    synthetic_full()
     print("goldens regenerated under", HERE)
