@@ -20,7 +20,7 @@ cli: seeksv_amd/bin/seeksv
 
 $(LIBDIR)/libseeksv_host.so: $(HOST_SRC) include/seeksv_host.h include/seeksv_hip.h
 	mkdir -p $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz -lpthread
 
 $(LIBDIR)/libseeksv_hip.so: $(HIP_DEPS)
 	mkdir -p $(LIBDIR)

@@ -51,6 +51,12 @@ typedef struct {
 } ssvh_record;
 int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out);
 
+/* Tooling: write a structure-of-arrays batch (SSV_MEM_HOST) as a BAM file (BGZF, deflate level 1, blocks compressed in parallel).
+ * Records without shipped bases get l_qseq 'A's with quality 30; read names are "<prefix><index>".  append != 0 continues a file
+ * started by an earlier call (the header is written only when append == 0); finish != 0 writes the BGZF end-of-file block. */
+int ssvh_bam_write_batch(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
+                         const char *qname_prefix, int64_t first_index, int append, int finish);
+
 /* Records with UNMAP|MUNMAP seen in the last batch: qname / decoded bases / qualities for the
  * unmapped-pair FASTQ side channel (clip_reads.h:415-419).  Index k in [0, n).  Host only. */
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b);

@@ -159,6 +159,7 @@ def host_lib():
         lib.ssvh_bam_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         lib.ssvh_bam_from_header.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
         lib.ssvh_bam_close.argtypes = [C.c_void_p]
+        lib.ssvh_bam_write_batch.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(Batch), C.c_char_p, C.c_int64, C.c_int, C.c_int]
         lib.ssvh_bam_n_targets.argtypes = [C.c_void_p]
         lib.ssvh_bam_target_name.argtypes = [C.c_void_p, C.c_int32]
         lib.ssvh_bam_target_name.restype = C.c_char_p

@@ -82,6 +82,25 @@ class Header:
             self._h = None
 
 
+def write_bam(path, names, lens, batches, qname_prefix="s"):
+    """Tooling: SoA batches (dicts of numpy arrays) -> BAM file (parallel BGZF deflate in libseeksv_host)."""
+    lib = _abi.host_lib()
+    n = len(names)
+    nb = (C.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    lb = (C.c_int32 * max(n, 1))(*[int(x) for x in lens])
+    first = 0
+    batches = list(batches)
+    if not batches:
+        assert lib.ssvh_bam_write_batch(path.encode(), nb, lb, n, None, qname_prefix.encode(), 0, 0, 1) == 0
+        return
+    for i, b in enumerate(batches):
+        bb, keep = _abi.make_batch(b)
+        rc = lib.ssvh_bam_write_batch(path.encode(), nb, lb, n, C.byref(bb), qname_prefix.encode(), first, int(i > 0), int(i == len(batches) - 1))
+        if rc != 0:
+            raise IOError(lib.ssvh_last_error().decode())
+        first += bb.n
+
+
 def read_bam(path, batch_records=1 << 20):
     """Whole BAM as (target_names, target_lens, [batch dicts])."""
     with BamReader(path) as r:

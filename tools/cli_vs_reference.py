@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""End-to-end, file to file: the `seeksv` CLI of this repository next to the REAL reference binary (oracle/_ref/seeksv_ref, built from
+/root/reference by `make -C oracle ref` in the build container; it travels to the GPU box with the snapshot) on the same synthetic BAM.
+Checks that the outputs are identical and prints the wall times.  usage: python tools/cli_vs_reference.py [genome_frac] [depth] [n_sv]"""
+import gzip
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from seeksv_amd import host, synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "seeksv_ref")
+BAMIDX = os.path.join(ROOT, "oracle", "_ref", "bamidx")
+OURS = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
+
+
+def timed(cmd, **kw):
+    t = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, **kw)
+    return time.perf_counter() - t, r
+
+
+def main():
+    frac = float(sys.argv[1]) if len(sys.argv) > 1 else 1 / 128
+    depth = float(sys.argv[2]) if len(sys.argv) > 2 else 30
+    n_sv = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    w = synth.Workload(genome_frac=frac, depth=depth, n_sv=n_sv)
+    d = tempfile.mkdtemp(prefix="ssv_cli_")
+    bam = os.path.join(d, "synth.bam")
+    t = time.perf_counter()
+    chunk = 2_000_000
+    host.write_bam(bam, w.names, w.lens, (w.generate_host(g, min(chunk, w.n_total - g)) for g in range(0, w.n_total, chunk)))
+    t_write = time.perf_counter() - t
+    out = {"records": w.n_total, "bam_bytes": os.path.getsize(bam), "write_s": round(t_write, 2), "junctions": len(w.junctions), "host_cpus": os.cpu_count()}
+    have_ref = os.path.exists(REF)
+    if have_ref:
+        subprocess.run([BAMIDX, bam], capture_output=True)
+        out["ref_getclip_s"], r = timed([REF, "getclip", "-o", os.path.join(d, "ref"), bam])
+        assert r.returncode == 0, r.stderr
+    out["ours_getclip_s"], r = timed([OURS, "getclip", "-o", os.path.join(d, "ours"), bam])
+    assert r.returncode == 0, r.stderr
+    if have_ref:
+        for ext in ("clip.gz", "clip.fq.gz"):
+            assert gzip.open(os.path.join(d, "ref." + ext)).read() == gzip.open(os.path.join(d, "ours." + ext)).read(), ext
+        out["getclip_outputs_identical"] = True
+    # getsv on the planted junctions through the -B harness (no bwa on the box)
+    jfile = os.path.join(d, "junctions.txt")
+    with open(jfile, "w") as f:
+        for j in w.junctions:
+            f.write("\t".join(str(x) for x in (j[0], j[1], j[2], 0, j[3], j[4], j[5], 0, 0, 0, "NA", 0, 0, 0, 0, 0, 0, 0, 0, "50M", "50M", "ACGT", "ACGT")) + "\n")
+    empty_bam = os.path.join(d, "empty.clip.bam")
+    host.write_bam(empty_bam, w.names, w.lens, [])
+    empty_clip = os.path.join(d, "empty.clip")
+    open(empty_clip, "w").close()
+    args = ["-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip]
+    if have_ref:
+        out["ref_getsv_s"], r = timed([REF, "getsv"] + args + [os.path.join(d, "ref.sv"), os.path.join(d, "x.fq")])
+        assert r.returncode == 0, r.stderr
+        ref_stdout = r.stdout
+    out["ours_getsv_s"], r = timed([OURS, "getsv"] + args + [os.path.join(d, "ours.sv"), os.path.join(d, "y.fq")])
+    assert r.returncode == 0, r.stderr
+    if have_ref:
+        assert open(os.path.join(d, "ref.sv")).read() == open(os.path.join(d, "ours.sv")).read()
+        assert ref_stdout == r.stdout
+        out["getsv_outputs_identical"] = True
+        out["ref_records_per_s"] = round(w.n_total / (out["ref_getclip_s"] + out["ref_getsv_s"]))
+        out["speedup_getclip"] = round(out["ref_getclip_s"] / out["ours_getclip_s"], 2)
+        out["speedup_getsv"] = round(out["ref_getsv_s"] / out["ours_getsv_s"], 2)
+    out["ours_records_per_s"] = round(w.n_total / (out["ours_getclip_s"] + out["ours_getsv_s"]))
+    for k in list(out):
+        if k.endswith("_s"):
+            out[k] = round(out[k], 3)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
