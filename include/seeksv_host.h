@@ -57,6 +57,12 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out);
 int ssvh_bam_write_batch(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
                          const char *qname_prefix, int64_t first_index, int append, int finish);
 
+/* Append text to a .gz file as independent gzip members compressed in parallel (1 MiB of text each, zlib level 6 like gzstream's
+ * default).  Concatenated members are a valid gzip stream: zlib's gzread (igzstream, bwa, zcat) decompresses them to exactly the bytes
+ * written.  append == 0 truncates the file first.  n == 0 with append == 0 creates an empty gzip stream like an ogzstream that is
+ * closed without writes. */
+int ssvh_gz_append(const char *path, const char *text, size_t n, int append);
+
 /* Records with UNMAP|MUNMAP seen in the last batch: qname / decoded bases / qualities for the
  * unmapped-pair FASTQ side channel (clip_reads.h:415-419).  Index k in [0, n).  Host only. */
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b);

@@ -476,6 +476,36 @@ int ssvh_bam_write_batch(const char *path, const char *const *names, const int32
 	return 0;
 }
 
+int ssvh_gz_append(const char *path, const char *text, size_t n, int append)
+{
+	FILE *f = fopen(path, append ? "ab" : "wb");
+	if (!f) { g_err = std::string("cannot open ") + path; return -1; }
+	const size_t PIECE = 1 << 20;
+	const size_t np = n ? (n + PIECE - 1) / PIECE : (append ? 0 : 1);
+	std::vector<std::vector<uint8_t>> comp(np);
+	std::vector<int> ok(np, 1);
+	pool().run((int)np, [&](int i) {
+		const size_t off = (size_t)i * PIECE, len = n ? std::min(PIECE, n - off) : 0;
+		std::vector<uint8_t> &c = comp[(size_t)i];
+		z_stream zs;
+		memset(&zs, 0, sizeof(zs));
+		if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok[(size_t)i] = 0; return; }
+		c.resize(deflateBound(&zs, (uLong)len) + 64);
+		zs.next_in = (Bytef *)const_cast<char *>(text + off); zs.avail_in = (uInt)len;
+		zs.next_out = c.data(); zs.avail_out = (uInt)c.size();
+		if (deflate(&zs, Z_FINISH) != Z_STREAM_END) ok[(size_t)i] = 0;
+		c.resize(zs.total_out);
+		deflateEnd(&zs);
+	});
+	int rc = 0;
+	for (size_t i = 0; i < np; ++i) {
+		if (!ok[i]) { g_err = "deflate failed"; rc = -1; break; }
+		if (fwrite(comp[i].data(), 1, comp[i].size(), f) != comp[i].size()) { g_err = std::string("write error on ") + path; rc = -1; break; }
+	}
+	fclose(f);
+	return rc;
+}
+
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { return (int64_t)b->unmapped.size(); }
 
 int ssvh_bam_unmapped_get(const ssvh_bam *b, int64_t k, const char **qname, const char **seq, const char **qual, int *is_read1)

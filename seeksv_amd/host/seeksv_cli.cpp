@@ -11,6 +11,7 @@
 #include <getopt.h>
 #include <zlib.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +35,23 @@ using seeksv::SeqInfo;
 using seeksv::parse_cigar;
 
 static const char *kVersion = "1.2.3-mi355x";
+
+// SSV_TIMING=1: wall time of the phases on stderr
+struct PhaseTimer {
+	bool on = getenv("SSV_TIMING") != nullptr;
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	std::map<std::string, double> acc;
+	std::vector<std::string> order;
+	void lap(const char *name)
+	{
+		if (!on) return;
+		auto t1 = std::chrono::steady_clock::now();
+		if (!acc.count(name)) order.push_back(name);
+		acc[name] += std::chrono::duration<double>(t1 - t0).count();
+		t0 = t1;
+	}
+	~PhaseTimer() { if (on) for (auto &n : order) std::cerr << "[timing] " << n << " " << acc[n] << " s" << std::endl; }
+};
 
 [[noreturn]] static void die(const string &msg)
 {
@@ -85,11 +103,27 @@ static const char *kVersion = "1.2.3-mi355x";
 
 static const char CIGAR_CHARS[] = "MIDNSHP=X";
 
+// .gz output: text is collected and written as gzip members compressed in parallel by libseeksv_host (ssvh_gz_append)
 struct GzOut {
-	gzFile f = nullptr;
-	bool open(const string &path) { f = gzopen(path.c_str(), "wb"); return f != nullptr; }
-	void write(const string &s) { if (!s.empty()) gzwrite(f, s.data(), (unsigned)s.size()); }
-	void close() { if (f) gzclose(f); f = nullptr; }
+	string path, buf;
+	bool started = false;
+	bool open(const string &p)
+	{
+		path = p;
+		FILE *f = fopen(p.c_str(), "wb"); // like ogzstream: fail early when the file cannot be created
+		if (!f) return false;
+		fclose(f);
+		return true;
+	}
+	void flush(bool final)
+	{
+		if (buf.empty() && (started || !final)) return;
+		if (ssvh_gz_append(path.c_str(), buf.data(), buf.size(), started ? 1 : 0) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		started = true;
+		buf.clear();
+	}
+	void write(const string &s) { buf += s; if (buf.size() >= ((size_t)256 << 20)) flush(false); }
+	void close() { flush(true); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -115,6 +149,7 @@ static int cmd_getclip(int argc, char **argv)
 	if (argc != optind + 1) usage_getclip();
 	const string bamfile = argv[optind];
 
+	PhaseTimer pt;
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(bamfile.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
 	GzOut softfout, fqfout, fuout1, fuout2;
@@ -130,6 +165,7 @@ static int cmd_getclip(int argc, char **argv)
 	memset(&p, 0, sizeof(p));
 	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
 	if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+	pt.lap("open+gpu_init");
 
 	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219)
 	map<string, pair<pair<string, string>, char>> id2seq_qual;
@@ -138,6 +174,7 @@ static int cmd_getclip(int argc, char **argv)
 	for (;;) {
 		ssv_batch_t b;
 		if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		pt.lap("bam_read");
 		if (b.n == 0) break;
 		for (int64_t k = 0, nu = ssvh_bam_unmapped_count(bam); k < nu; ++k) {
 			const char *qname, *seq, *qual; int is_read1;
@@ -159,8 +196,10 @@ static int cmd_getclip(int argc, char **argv)
 			if (b.flag[i] & (4 | 8)) continue;
 			if (b.tid[i] != last_tid) { run_tids.push_back(last_tid); last_tid = b.tid[i]; }
 		}
+		pt.lap("host_side_channel");
 		if (ssv_clip_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		ssv_sync(ctx);
+		pt.lap("gpu_scan(h2d+kernels)");
 	}
 	run_tids.push_back(last_tid);
 	for (size_t k = 1; k < run_tids.size(); ++k)
@@ -168,6 +207,7 @@ static int cmd_getclip(int argc, char **argv)
 
 	ssv_cluster_table t;
 	if (ssv_clip_cluster(ctx, &t) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+	pt.lap("gpu_cluster+table");
 	// DisplaySClipReadsAndClipFq ('5' rows then '3' rows per contig run), clip_reads.h:300-345
 	int64_t k = 0;
 	string row, fq;
@@ -195,8 +235,10 @@ static int cmd_getclip(int argc, char **argv)
 	}
 	cerr << "[GetSClipReads] finished!" << endl;
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
+	pt.lap("format+gzip");
 	ssv_ctx_destroy(ctx);
 	ssvh_bam_close(bam);
+	pt.lap("teardown");
 	return 0;
 }
 
