@@ -9,6 +9,7 @@
 #ifndef SEEKSV_HOST_H_
 #define SEEKSV_HOST_H_
 
+#include <stddef.h>
 #include <stdint.h>
 #include "seeksv_hip.h"
 
