@@ -39,6 +39,11 @@ const int32_t *ssvh_bam_target_lens(const ssvh_bam *b);
  */
 int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_batch_t *out);
 
+/* on != 0: after handing out a batch, ssvh_bam_read_batch decodes the following one on a background thread into a second set
+ * of arrays, so that inflate + decode overlap whatever the caller does with the current batch (upload, kernels, output).  While
+ * it is on, every read_batch call must pass the same max_records / keep_all_seq, and ssvh_bam_next_record is refused. */
+int ssvh_bam_set_readahead(ssvh_bam *b, int on);
+
 /* One record at a time, with its read name and CIGAR (host-side consumers of small BAMs: the clip.bam join of getsv,
  * getsv.h:445-527).  Returns 1 and fills *out (pointers valid until the next call), 0 at end of file, <0 on error. */
 typedef struct {

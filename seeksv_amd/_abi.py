@@ -166,6 +166,7 @@ def host_lib():
         lib.ssvh_bam_target_len.argtypes = [C.c_void_p, C.c_int32]
         lib.ssvh_bam_target_len.restype = C.c_int32
         lib.ssvh_bam_read_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(Batch)]
+        lib.ssvh_bam_set_readahead.argtypes = [C.c_void_p, C.c_int]
         lib.ssvh_bam_unmapped_count.argtypes = [C.c_void_p]
         lib.ssvh_bam_unmapped_count.restype = C.c_int64
         lib.ssvh_bam_unmapped_get.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]

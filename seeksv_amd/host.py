@@ -14,12 +14,14 @@ CIGAR_CHARS = "MIDNSHP=X"
 class BamReader:
     """samopen()/samread() stand-in (reference: sam/sam.h:59,73) producing structure-of-arrays batches."""
 
-    def __init__(self, path):
+    def __init__(self, path, readahead=False):
         self._lib = _abi.host_lib()
         h = C.c_void_p()
         if self._lib.ssvh_bam_open(path.encode(), C.byref(h)) != 0:
             raise IOError(self._lib.ssvh_last_error().decode())
         self._h = h
+        if readahead:  # decode batch k+1 on a background thread while the caller uses batch k
+            self._lib.ssvh_bam_set_readahead(h, 1)
         n = self._lib.ssvh_bam_n_targets(h)
         self.target_names = [self._lib.ssvh_bam_target_name(h, i).decode() for i in range(n)]
         self.target_lens = np.array([self._lib.ssvh_bam_target_len(h, i) for i in range(n)], dtype=np.int32)

@@ -9,12 +9,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -42,6 +44,7 @@ public:
 	{
 		if (n <= 0) return;
 		if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+		std::lock_guard<std::mutex> one_at_a_time(run_m_);
 		{
 			std::lock_guard<std::mutex> l(m_);
 			fn_ = &fn; n_ = n; next_.store(0); pending_ = n; ++gen_;
@@ -77,7 +80,7 @@ private:
 		}
 	}
 	std::vector<std::thread> th_;
-	std::mutex m_;
+	std::mutex m_, run_m_;
 	std::condition_variable cv_, done_;
 	const std::function<void(int)> *fn_ = nullptr;
 	std::atomic<int> next_{0};
@@ -91,10 +94,16 @@ static int host_threads()
 	const char *e = getenv("SSV_HOST_THREADS");
 	int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
 	if (n < 1) n = 1;
-	return n > 32 ? 32 : n;
+	return n > 64 ? 64 : n;
 }
 
-static Pool &pool()
+static Pool &pool() // the reading side (inflate + decode); may run on the read-ahead thread
+{
+	static Pool p(host_threads() - 1);
+	return p;
+}
+
+static Pool &wpool() // the writing side (deflate), so that a read-ahead in flight and an output writer do not queue behind each other
 {
 	static Pool p(host_threads() - 1);
 	return p;
@@ -102,10 +111,26 @@ static Pool &pool()
 
 struct Bgzf {
 	FILE *fp = nullptr;
-	static constexpr int CHUNK_BLOCKS = 256; // up to 16 MB of uncompressed data per refill
+	static constexpr int CHUNK_BLOCKS = 1024; // up to 64 MB of uncompressed data per refill
 	struct Block { std::vector<uint8_t> c; uint32_t isize = 0; size_t uoff = 0; bool ok = true; };
 	std::vector<Block> blocks;
-	std::vector<uint8_t> ubuf;
+	// the inflated window: a plain malloc'd buffer, never value-initialised (fresh pages are touched only by the inflating threads) and
+	// reserved once at its working size so that growing it does not copy
+	struct RawBuf {
+		uint8_t *p = nullptr; size_t cap = 0;
+		~RawBuf() { free(p); }
+		uint8_t *data() { return p; }
+		size_t size() const { return cap; }
+		void reserve_keep(size_t need, size_t keep)
+		{
+			if (need <= cap) return;
+			size_t ncap = std::max(need, cap + cap / 2);
+			uint8_t *q = (uint8_t *)malloc(ncap);
+			if (!q) throw std::bad_alloc();
+			if (keep) memcpy(q, p, keep);
+			free(p); p = q; cap = ncap;
+		}
+	} ubuf;
 	size_t upos = 0, ulen = 0;
 	bool eof = false;
 
@@ -150,7 +175,7 @@ struct Bgzf {
 		}
 		if (!g_err.empty()) return false;
 		if (nb == 0) return false;
-		ubuf.resize(total ? total : 1);
+		ubuf.reserve_keep(total + 1, 0);
 		uint8_t *out = ubuf.data();
 		std::vector<Block> &bl = blocks;
 		pool().run(nb, [&bl, out](int i) {
@@ -189,6 +214,59 @@ struct Bgzf {
 		return done;
 	}
 	bool refill_after_eof() { return false; }
+
+	// drop the consumed bytes [0, upos) of the window; returns the shift applied to every offset into it
+	size_t compact()
+	{
+		size_t shift = upos;
+		if (shift) { memmove(ubuf.data(), ubuf.data() + upos, ulen - upos); ulen -= shift; upos = 0; }
+		return shift;
+	}
+
+	// append the next chunk of blocks behind the unread data.  The chunk is cut into segments of SEG_BLOCKS consecutive blocks; one task
+	// inflates a segment and then calls scan(segment index, begin, end) on it while its bytes are still in that core's cache.
+	// Returns the number of segments (0 at end of file or on error, g_err set on error).
+	static constexpr int SEG_BLOCKS = 8;
+	size_t window_reserve = 0; // set by the batch reader: the size the window is expected to reach
+	int grow(const std::function<void(int, size_t, size_t)> &scan)
+	{
+		if (eof) return 0;
+		if (blocks.empty()) blocks.resize(CHUNK_BLOCKS);
+		int nb = 0;
+		size_t total = 0;
+		while (nb < CHUNK_BLOCKS) {
+			if (!read_block(blocks[(size_t)nb])) break;
+			blocks[(size_t)nb].uoff = ulen + total;
+			total += blocks[(size_t)nb].isize;
+			++nb;
+		}
+		if (!g_err.empty() || nb == 0) return 0;
+		ubuf.reserve_keep(std::max(ulen + total + 1, window_reserve), ulen);
+		uint8_t *out = ubuf.data();
+		std::vector<Block> &bl = blocks;
+		const int nseg = (nb + SEG_BLOCKS - 1) / SEG_BLOCKS;
+		pool().run(nseg, [&bl, out, nb, &scan](int sg) {
+			const int b0 = sg * SEG_BLOCKS, b1 = std::min(nb, b0 + SEG_BLOCKS);
+			bool ok = true;
+			for (int i = b0; i < b1; ++i) {
+				Block &b = bl[(size_t)i];
+				b.ok = true;
+				if (b.isize == 0) continue;
+				z_stream zs;
+				memset(&zs, 0, sizeof(zs));
+				if (inflateInit2(&zs, -15) != Z_OK) { b.ok = ok = false; continue; }
+				zs.next_in = b.c.data(); zs.avail_in = (uInt)(b.c.size() - 8);
+				zs.next_out = out + b.uoff; zs.avail_out = b.isize;
+				int rc = inflate(&zs, Z_FINISH);
+				inflateEnd(&zs);
+				if (rc != Z_STREAM_END || zs.total_out != b.isize) b.ok = ok = false;
+			}
+			if (ok) scan(sg, bl[(size_t)b0].uoff, bl[(size_t)b1 - 1].uoff + bl[(size_t)b1 - 1].isize);
+		});
+		for (int i = 0; i < nb; ++i) if (!blocks[(size_t)i].ok) { g_err = "BGZF inflate failed"; eof = true; return 0; }
+		ulen += total;
+		return nseg;
+	}
 };
 
 struct Unmapped {
@@ -198,18 +276,70 @@ struct Unmapped {
 
 } // namespace
 
+// One inflated segment's speculative record list: offsets of the records that start in [begin, end) if the guess of the first record
+// start is right, and the offset the chain leaves the segment at.  read_batch verifies every list against the true chain.
+struct Segment { std::vector<size_t> list; size_t end = 0, exit = 0; };
+
+// does a BAM record header that could be real start at u[o]?  (o + 36 <= end is the caller's business)
+static inline bool plausible_record(const uint8_t *u, size_t o, size_t end, int32_t n_targets)
+{
+	uint32_t bs; int32_t refid, pos, l_seq, next_ref, next_pos; uint16_t ncig;
+	memcpy(&bs, u + o, 4);
+	if (bs < 32 || bs > (1u << 28)) return false;
+	const uint8_t *r = u + o + 4;
+	memcpy(&refid, r, 4); memcpy(&pos, r + 4, 4); memcpy(&ncig, r + 12, 2); memcpy(&l_seq, r + 16, 4); memcpy(&next_ref, r + 20, 4); memcpy(&next_pos, r + 24, 4);
+	const size_t l_name = r[8];
+	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name == 0) return false;
+	if (32 + l_name + 4 * (size_t)ncig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) return false;
+	const size_t nul = o + 4 + 32 + l_name - 1;
+	return nul >= end || u[nul] == 0;
+}
+
+static void find_records(const uint8_t *u, size_t begin, size_t end, int32_t n_targets, Segment &S)
+{
+	S.list.clear(); S.end = end;
+	size_t o = begin;
+	// guess: the first offset from which three plausible headers follow one another
+	for (; o + 36 <= end; ++o) {
+		size_t q = o; int k = 0;
+		for (; k < 3 && q + 36 <= end; ++k) {
+			if (!plausible_record(u, q, end, n_targets)) break;
+			uint32_t bs; memcpy(&bs, u + q, 4);
+			q += 4 + (size_t)bs;
+		}
+		if (k == 3 || (k > 0 && q + 36 > end)) break;
+	}
+	if (o + 36 > end) { S.exit = begin; return; }
+	while (o + 4 <= end) {
+		uint32_t bs; memcpy(&bs, u + o, 4);
+		if (bs < 32) break;
+		S.list.push_back(o);
+		o += 4 + (size_t)bs;
+	}
+	S.exit = o;
+}
+
 struct ssvh_bam {
 	Bgzf z;
 	std::vector<std::string> names;
 	std::vector<int32_t> lens;
-	// the current batch
-	std::vector<int32_t> tid, pos, l_qseq, mtid, mpos, isize;
-	std::vector<uint16_t> flag, n_cigar;
-	std::vector<uint8_t> mapq, xc, seqqual;
-	std::vector<uint32_t> cigar_off, cigar;
-	std::vector<uint64_t> seq_off;
-	std::vector<Unmapped> unmapped;
+	// batch storage: two sets, so that with read-ahead the next batch is decoded while the caller still uses the current one
+	struct BatchBuf {
+		std::vector<int32_t> tid, pos, l_qseq, mtid, mpos, isize;
+		std::vector<uint16_t> flag, n_cigar;
+		std::vector<uint8_t> mapq, xc, seqqual;
+		std::vector<uint32_t> cigar_off, cigar;
+		std::vector<uint64_t> seq_off;
+		std::vector<Unmapped> unmapped;
+	} buf[2];
+	int cur = 0;
+	bool readahead = false;
+	std::thread ra_thread;
+	int ra_rc = 0; std::string ra_err; ssv_batch_t ra_batch; int64_t ra_max = 0; int ra_keep = 0;
 	std::vector<uint8_t> rec;
+	std::vector<size_t> found; // located, not yet handed out record offsets in z.ubuf
+	size_t found_pos = 0, chain_cur = 0;
+	std::vector<Segment> segs;
 };
 
 static const char NT16[] = "=ACMGRSVTWYHKDBN";
@@ -255,6 +385,7 @@ const char *ssvh_last_error(void) { return g_err.c_str(); }
 int ssvh_bam_open(const char *path, ssvh_bam **out)
 {
 	*out = nullptr;
+	g_err.clear();
 	ssvh_bam *b = new ssvh_bam();
 	b->z.fp = fopen(path, "rb");
 	if (!b->z.fp) { g_err = std::string("cannot open ") + path; delete b; return -1; }
@@ -289,6 +420,7 @@ int ssvh_bam_from_header(const char *const *names, const int32_t *lens, int32_t 
 void ssvh_bam_close(ssvh_bam *b)
 {
 	if (!b) return;
+	if (b->ra_thread.joinable()) b->ra_thread.join();
 	if (b->z.fp) fclose(b->z.fp);
 	delete b;
 }
@@ -298,76 +430,219 @@ const char *ssvh_bam_target_name(const ssvh_bam *b, int32_t tid) { return (tid >
 int32_t ssvh_bam_target_len(const ssvh_bam *b, int32_t tid) { return (tid >= 0 && (size_t)tid < b->lens.size()) ? b->lens[(size_t)tid] : -1; }
 const int32_t *ssvh_bam_target_lens(const ssvh_bam *b) { return b->lens.data(); }
 
-int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_batch_t *out)
+static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records, int keep_all_seq, ssv_batch_t *out)
 {
-	b->tid.clear(); b->pos.clear(); b->l_qseq.clear(); b->mtid.clear(); b->mpos.clear(); b->isize.clear();
-	b->flag.clear(); b->n_cigar.clear(); b->mapq.clear(); b->xc.clear(); b->seqqual.clear();
-	b->cigar_off.clear(); b->cigar.clear(); b->seq_off.clear(); b->unmapped.clear();
 	g_err.clear();
-	int64_t n = 0, max_span = 1;
-	while (n < max_records) {
-		int32_t block_size;
-		size_t got = b->z.read(&block_size, 4);
-		if (got == 0) break;
-		if (got != 4 || block_size < 32) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
-		b->rec.resize((size_t)block_size);
-		if (b->z.read(b->rec.data(), (size_t)block_size) != (size_t)block_size) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
-		const uint8_t *r = b->rec.data();
-		int32_t refid, pos, l_seq, next_ref, next_pos, tlen;
-		uint16_t ncig, flag;
-		memcpy(&refid, r, 4); memcpy(&pos, r + 4, 4);
-		uint8_t l_read_name = r[8], mapq = r[9];
-		memcpy(&ncig, r + 12, 2); memcpy(&flag, r + 14, 2); memcpy(&l_seq, r + 16, 4);
-		memcpy(&next_ref, r + 20, 4); memcpy(&next_pos, r + 24, 4); memcpy(&tlen, r + 28, 4);
-		size_t o_name = 32, o_cig = o_name + l_read_name, o_seq = o_cig + 4 * (size_t)ncig;
-		size_t o_qual = o_seq + ((size_t)l_seq + 1) / 2, o_aux = o_qual + (size_t)l_seq;
-		if (l_seq < 0 || o_aux > (size_t)block_size) { g_err = "corrupt BAM record"; return -1; }
-		b->tid.push_back(refid); b->pos.push_back(pos); b->flag.push_back(flag); b->mapq.push_back(mapq);
-		b->n_cigar.push_back(ncig); b->l_qseq.push_back(l_seq); b->mtid.push_back(next_ref); b->mpos.push_back(next_pos); b->isize.push_back(tlen);
-		b->cigar_off.push_back((uint32_t)b->cigar.size());
-		bool soft = false;
-		int64_t span = 0;
-		for (unsigned k = 0; k < ncig; ++k) {
-			uint32_t c; memcpy(&c, r + o_cig + 4 * k, 4);
-			b->cigar.push_back(c);
-			if ((k == 0 || k + 1 == ncig) && (c & 15) == 4) soft = true;
-			unsigned op = c & 15;
-			if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += c >> 4;
-		}
-		if (span > max_span) max_span = span;
-		b->xc.push_back(soft ? (uint8_t)(aux_xc(r + o_aux, r + block_size) != 0) : (uint8_t)0);
-		if (soft || keep_all_seq) {
-			b->seq_off.push_back((uint64_t)b->seqqual.size());
-			b->seqqual.insert(b->seqqual.end(), r + o_seq, r + o_aux);
-		} else b->seq_off.push_back(SSV_NO_SEQ);
-		if (flag & (4 | 8)) {
-			// GetSeqAndQual (clip_reads.cpp:375-388): bases as stored, qualities +33, "*" when absent
-			Unmapped u;
-			u.qname.assign((const char *)r + o_name);
-			u.seq.resize((size_t)l_seq);
-			for (int32_t k = 0; k < l_seq; ++k) u.seq[(size_t)k] = NT16[(r[o_seq + (k >> 1)] >> ((~k & 1) << 2)) & 15];
-			if (l_seq > 0 && r[o_qual] == 0xff) u.qual = "*";
-			else { u.qual.resize((size_t)l_seq); for (int32_t k = 0; k < l_seq; ++k) u.qual[(size_t)k] = (char)(r[o_qual + k] + 33); }
-			u.is_read1 = (flag & 64) ? 1 : 0;
-			b->unmapped.push_back(std::move(u));
-		}
-		++n;
+	B.unmapped.clear();
+	Bgzf &z = b->z;
+	static const bool timing = getenv("SSV_TIMING_READ") != nullptr;
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = now();
+	// ---- record boundaries.  Walking the block_size chain is a chain of dependent cache misses, so it is done speculatively per
+	// inflated segment by the task that just inflated it (find_records), and only stitched together here. ----
+	const size_t BYTE_LIMIT = (size_t)384 << 20; // stop growing the window once a batch holds this much raw BAM
+	z.window_reserve = BYTE_LIMIT + 2 * (size_t)Bgzf::CHUNK_BLOCKS * 65536;
+	std::vector<size_t> &found = b->found;
+	if (b->found_pos >= found.size()) { found.clear(); b->chain_cur = z.upos; }
+	else found.erase(found.begin(), found.begin() + (ptrdiff_t)b->found_pos);
+	b->found_pos = 0;
+	{
+		const size_t shift = z.compact();
+		if (shift) { for (size_t &o : found) o -= shift; b->chain_cur -= shift; }
 	}
-	if (!g_err.empty()) return -1;
+	const int32_t n_targets = (int32_t)b->names.size();
+	std::vector<Segment> &segs = b->segs;
+	// whole records in already inflated bytes that no segment list covers (the window the header read left behind): follow the chain by hand
+	auto hop_tail = [&]() -> bool {
+		const uint8_t *u = z.ubuf.data();
+		size_t cur = b->chain_cur;
+		while (cur + 4 <= z.ulen) {
+			uint32_t bs; memcpy(&bs, u + cur, 4);
+			if (bs < 32) { g_err = "corrupt BAM record"; return false; }
+			if (cur + 4 + (size_t)bs > z.ulen) break;
+			found.push_back(cur);
+			cur += 4 + (size_t)bs;
+		}
+		b->chain_cur = cur;
+		return true;
+	};
+	if (!hop_tail()) return -1;
+	while ((int64_t)found.size() < max_records && b->chain_cur < BYTE_LIMIT) {
+		if (segs.size() < (size_t)(Bgzf::CHUNK_BLOCKS / Bgzf::SEG_BLOCKS + 1)) segs.resize((size_t)(Bgzf::CHUNK_BLOCKS / Bgzf::SEG_BLOCKS + 1));
+		Bgzf *zp = &z;
+		const double tg0 = now();
+		const int nseg = z.grow([&segs, zp, n_targets](int sg, size_t s0, size_t s1) { find_records(zp->ubuf.data(), s0, s1, n_targets, segs[(size_t)sg]); });
+		if (nseg == 0) {
+			if (!g_err.empty()) return -1;
+			break;
+		}
+		const double tg1 = now();
+		if (timing && getenv("SSV_TIMING_GROW")) fprintf(stderr, "  grow %.4f s nseg %d ulen %zu cap %zu found %zu\n", tg1 - tg0, nseg, z.ulen, z.ubuf.size(), found.size());
+		const uint8_t *u = z.ubuf.data();
+		size_t cur = b->chain_cur;
+		bool window_end = false;
+		for (int sg = 0; sg < nseg && !window_end; ++sg) {
+			const Segment &S = segs[(size_t)sg];
+			while (cur < S.end) {
+				size_t k = 0;
+				if (S.list.empty() || S.list[0] != cur) k = (size_t)(std::lower_bound(S.list.begin(), S.list.end(), cur) - S.list.begin());
+				if (k < S.list.size() && S.list[k] == cur) { found.insert(found.end(), S.list.begin() + (ptrdiff_t)k, S.list.end()); cur = S.exit; break; }
+				// not on the speculated chain (a record that straddles segments, or a wrong guess): follow the true chain by hand
+				uint32_t bs;
+				if (cur + 4 > z.ulen) { window_end = true; break; }
+				memcpy(&bs, u + cur, 4);
+				if (bs < 32) { g_err = "corrupt BAM record"; return -1; }
+				if (cur + 4 + (size_t)bs > z.ulen) { window_end = true; break; }
+				found.push_back(cur);
+				cur += 4 + (size_t)bs;
+			}
+		}
+		// records of the last list that run past the window are completed by the next chunk
+		while (!found.empty()) {
+			uint32_t bs; memcpy(&bs, u + found.back(), 4);
+			if (found.back() + 4 + (size_t)bs <= z.ulen) break;
+			cur = found.back(); found.pop_back();
+		}
+		b->chain_cur = cur;
+		if (!hop_tail()) return -1;
+	}
+	if (z.eof && g_err.empty() && (int64_t)found.size() < max_records && b->chain_cur != z.ulen) { g_err = "truncated BAM record"; return -1; }
+	const double t1 = now();
+	const int64_t n = std::min<int64_t>((int64_t)found.size(), max_records);
+	const std::vector<size_t> &off = found;
+	const uint8_t *base = z.ubuf.data();
+	// ---- pass 1 (parallel over record ranges, header fields only): sizes of the variable-length parts, then their prefix ----
+	B.tid.resize((size_t)n); B.pos.resize((size_t)n); B.l_qseq.resize((size_t)n); B.mtid.resize((size_t)n); B.mpos.resize((size_t)n); B.isize.resize((size_t)n);
+	B.flag.resize((size_t)n); B.n_cigar.resize((size_t)n); B.mapq.resize((size_t)n); B.xc.resize((size_t)n); B.cigar_off.resize((size_t)n); B.seq_off.resize((size_t)n);
+	const int nt = (int)std::min<int64_t>(std::max<int64_t>(1, n / 8192), 128);
+	std::vector<uint64_t> c_of((size_t)nt + 1, 0), s_of((size_t)nt + 1, 0);
+	std::atomic<int> bad{0};
+	pool().run(nt, [&](int t) {
+		const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+		uint64_t ct = 0, st = 0;
+		for (int64_t i = i0; i < i1; ++i) {
+			const uint8_t *r = base + off[(size_t)i] + 4;
+			uint32_t bs; memcpy(&bs, r - 4, 4);
+			uint16_t ncig; int32_t l_seq;
+			memcpy(&ncig, r + 12, 2); memcpy(&l_seq, r + 16, 4);
+			const size_t o_cig = 32 + (size_t)r[8];
+			if (l_seq < 0 || o_cig + 4 * (size_t)ncig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) { bad.store(1); return; }
+			bool soft = false;
+			if (ncig) {
+				uint32_t c0, cl; memcpy(&c0, r + o_cig, 4); memcpy(&cl, r + o_cig + 4 * ((size_t)ncig - 1), 4);
+				soft = (c0 & 15) == 4 || (cl & 15) == 4;
+			}
+			ct += ncig;
+			if (soft || keep_all_seq) st += ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+		}
+		c_of[(size_t)t + 1] = ct; s_of[(size_t)t + 1] = st;
+	});
+	if (bad.load()) { g_err = "corrupt BAM record"; return -1; }
+	for (int t = 0; t < nt; ++t) { c_of[(size_t)t + 1] += c_of[(size_t)t]; s_of[(size_t)t + 1] += s_of[(size_t)t]; }
+	const uint64_t ctot = c_of[(size_t)nt], stot = s_of[(size_t)nt];
+	if (ctot > 0xffffffffull) { g_err = "too many CIGAR operations in one batch"; return -1; }
+	if (B.cigar.size() < (size_t)ctot + 1) B.cigar.resize((size_t)ctot + 1);
+	if (B.seqqual.size() < (size_t)stot + 16) B.seqqual.resize((size_t)stot + 16);
+	const double t2 = now();
+	// ---- pass 2 (parallel): decode the records into the structure-of-arrays batch ----
+	std::vector<int64_t> span_of((size_t)nt, 1);
+	std::vector<std::vector<Unmapped>> un((size_t)nt);
+	pool().run(nt, [&](int t) {
+		const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+		int64_t max_span = 1;
+		uint64_t c_run = c_of[(size_t)t], s_run = s_of[(size_t)t];
+		for (int64_t i = i0; i < i1; ++i) {
+			const uint8_t *r = base + off[(size_t)i] + 4;
+			uint32_t bs; memcpy(&bs, r - 4, 4);
+			int32_t refid, pos, l_seq, next_ref, next_pos, tlen;
+			uint16_t ncig, flag;
+			memcpy(&refid, r, 4); memcpy(&pos, r + 4, 4);
+			const uint8_t l_read_name = r[8], mapq = r[9];
+			memcpy(&ncig, r + 12, 2); memcpy(&flag, r + 14, 2); memcpy(&l_seq, r + 16, 4);
+			memcpy(&next_ref, r + 20, 4); memcpy(&next_pos, r + 24, 4); memcpy(&tlen, r + 28, 4);
+			const size_t o_name = 32, o_cig = o_name + l_read_name, o_seq = o_cig + 4 * (size_t)ncig;
+			const size_t o_qual = o_seq + ((size_t)l_seq + 1) / 2, o_aux = o_qual + (size_t)l_seq;
+			B.tid[(size_t)i] = refid; B.pos[(size_t)i] = pos; B.flag[(size_t)i] = flag; B.mapq[(size_t)i] = mapq; B.n_cigar[(size_t)i] = ncig;
+			B.l_qseq[(size_t)i] = l_seq; B.mtid[(size_t)i] = next_ref; B.mpos[(size_t)i] = next_pos; B.isize[(size_t)i] = tlen;
+			uint32_t *cd = B.cigar.data() + c_run;
+			B.cigar_off[(size_t)i] = (uint32_t)c_run; c_run += ncig;
+			if (ncig) memcpy(cd, r + o_cig, 4 * (size_t)ncig);
+			int64_t span = 0;
+			for (unsigned k = 0; k < ncig; ++k) { unsigned op = cd[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += cd[k] >> 4; }
+			if (span > max_span) max_span = span;
+			const bool soft = ncig && ((cd[0] & 15) == 4 || (cd[ncig - 1] & 15) == 4);
+			B.xc[(size_t)i] = soft ? (uint8_t)(aux_xc(r + o_aux, r + bs) != 0) : (uint8_t)0;
+			if (soft || keep_all_seq) {
+				B.seq_off[(size_t)i] = s_run;
+				memcpy(B.seqqual.data() + s_run, r + o_seq, o_aux - o_seq);
+				s_run += o_aux - o_seq;
+			} else B.seq_off[(size_t)i] = SSV_NO_SEQ;
+			if (flag & (4 | 8)) {
+				// GetSeqAndQual (clip_reads.cpp:375-388): bases as stored, qualities +33, "*" when absent
+				Unmapped u;
+				u.qname.assign((const char *)r + o_name);
+				u.seq.resize((size_t)l_seq);
+				for (int32_t k = 0; k < l_seq; ++k) u.seq[(size_t)k] = NT16[(r[o_seq + (k >> 1)] >> ((~k & 1) << 2)) & 15];
+				if (l_seq > 0 && r[o_qual] == 0xff) u.qual = "*";
+				else { u.qual.resize((size_t)l_seq); for (int32_t k = 0; k < l_seq; ++k) u.qual[(size_t)k] = (char)(r[o_qual + k] + 33); }
+				u.is_read1 = (flag & 64) ? 1 : 0;
+				un[(size_t)t].push_back(std::move(u));
+			}
+		}
+		span_of[(size_t)t] = max_span;
+	});
+	int64_t max_span = 1;
+	for (int t = 0; t < nt; ++t) {
+		max_span = std::max(max_span, span_of[(size_t)t]);
+		for (auto &u : un[(size_t)t]) B.unmapped.push_back(std::move(u));
+	}
+	if (timing) fprintf(stderr, "[read_batch] n=%lld inflate+find %.3f s, sizes %.3f s, decode %.3f s, window %zu MB\n", (long long)n, t1 - t0, t2 - t1, now() - t2, z.ulen >> 20);
+	// the batch's raw bytes are consumed; records already located behind them stay queued for the next call
+	b->found_pos = (size_t)n;
+	z.upos = (size_t)n < found.size() ? found[(size_t)n] : b->chain_cur;
 	memset(out, 0, sizeof(*out));
 	out->n = n; out->mem = SSV_MEM_HOST;
 	out->max_ref_span = (int32_t)(max_span > INT32_MAX ? INT32_MAX : max_span);
-	out->tid = b->tid.data(); out->pos = b->pos.data(); out->flag = b->flag.data(); out->mapq = b->mapq.data();
-	out->n_cigar = b->n_cigar.data(); out->l_qseq = b->l_qseq.data(); out->mtid = b->mtid.data(); out->mpos = b->mpos.data();
-	out->isize = b->isize.data(); out->cigar_off = b->cigar_off.data(); out->cigar = b->cigar.data(); out->xc = b->xc.data();
-	out->seq_off = b->seq_off.data(); out->seqqual = b->seqqual.data();
-	out->n_cigar_total = (int64_t)b->cigar.size(); out->seqqual_bytes = (int64_t)b->seqqual.size();
+	out->tid = B.tid.data(); out->pos = B.pos.data(); out->flag = B.flag.data(); out->mapq = B.mapq.data();
+	out->n_cigar = B.n_cigar.data(); out->l_qseq = B.l_qseq.data(); out->mtid = B.mtid.data(); out->mpos = B.mpos.data();
+	out->isize = B.isize.data(); out->cigar_off = B.cigar_off.data(); out->cigar = B.cigar.data(); out->xc = B.xc.data();
+	out->seq_off = B.seq_off.data(); out->seqqual = B.seqqual.data();
+	out->n_cigar_total = (int64_t)ctot; out->seqqual_bytes = (int64_t)stot;
+	return 0;
+}
+
+int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_batch_t *out)
+{
+	if (!b->readahead) { b->cur = 0; return decode_batch(b, b->buf[0], max_records, keep_all_seq, out); }
+	int rc;
+	if (b->ra_thread.joinable()) {
+		b->ra_thread.join();
+		if (b->ra_max != max_records || b->ra_keep != keep_all_seq) { g_err = "read-ahead is on: every ssvh_bam_read_batch call must ask for the same batch"; return -1; }
+		b->cur ^= 1;
+		rc = b->ra_rc; g_err = b->ra_err; *out = b->ra_batch;
+	} else rc = decode_batch(b, b->buf[b->cur], max_records, keep_all_seq, out);
+	if (rc == 0 && out->n > 0) {
+		b->ra_max = max_records; b->ra_keep = keep_all_seq;
+		b->ra_thread = std::thread([b] {
+			b->ra_rc = decode_batch(b, b->buf[b->cur ^ 1], b->ra_max, b->ra_keep, &b->ra_batch);
+			b->ra_err = g_err;
+		});
+	}
+	return rc;
+}
+
+int ssvh_bam_set_readahead(ssvh_bam *b, int on)
+{
+	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight"; return -1; }
+	b->readahead = on != 0;
 	return 0;
 }
 
 int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 {
 	g_err.clear();
+	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight: record-at-a-time reads cannot be mixed in"; return -1; }
+	b->found.clear(); b->found_pos = 0; // record-at-a-time reads continue at z.upos; read_batch re-derives its chain from there
 	int32_t block_size;
 	size_t got = b->z.read(&block_size, 4);
 	if (got == 0) return g_err.empty() ? 0 : -1;
@@ -382,9 +657,9 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 	const size_t o_cig = 32 + (size_t)l_read_name, o_seq = o_cig + 4 * (size_t)out->n_cigar, o_qual = o_seq + ((size_t)out->l_qseq + 1) / 2;
 	if (out->l_qseq < 0 || o_qual + (size_t)out->l_qseq > (size_t)block_size) { g_err = "corrupt BAM record"; return -1; }
 	out->qname = (const char *)r + 32;
-	b->cigar.assign((size_t)out->n_cigar, 0); // aligned copy
-	if (out->n_cigar) memcpy(b->cigar.data(), r + o_cig, 4 * (size_t)out->n_cigar);
-	out->cigar = b->cigar.data();
+	b->buf[0].cigar.assign((size_t)out->n_cigar, 0); // aligned copy
+	if (out->n_cigar) memcpy(b->buf[0].cigar.data(), r + o_cig, 4 * (size_t)out->n_cigar);
+	out->cigar = b->buf[0].cigar.data();
 	out->seq = r + o_seq; out->qual = r + o_qual;
 	return 1;
 }
@@ -396,7 +671,7 @@ static void bgzf_compress_blocks(const std::vector<uint8_t> &raw, std::vector<ui
 	const size_t BS = 0xff00;
 	const size_t nb = (raw.size() + BS - 1) / BS;
 	std::vector<std::vector<uint8_t>> comp(nb);
-	pool().run((int)nb, [&](int i) {
+	wpool().run((int)nb, [&](int i) {
 		const size_t off = (size_t)i * BS, len = std::min(BS, raw.size() - off);
 		std::vector<uint8_t> &c = comp[(size_t)i];
 		c.resize(len + 1024);
@@ -484,7 +759,7 @@ int ssvh_gz_append(const char *path, const char *text, size_t n, int append)
 	const size_t np = n ? (n + PIECE - 1) / PIECE : (append ? 0 : 1);
 	std::vector<std::vector<uint8_t>> comp(np);
 	std::vector<int> ok(np, 1);
-	pool().run((int)np, [&](int i) {
+	wpool().run((int)np, [&](int i) {
 		const size_t off = (size_t)i * PIECE, len = n ? std::min(PIECE, n - off) : 0;
 		std::vector<uint8_t> &c = comp[(size_t)i];
 		z_stream zs;
@@ -506,12 +781,12 @@ int ssvh_gz_append(const char *path, const char *text, size_t n, int append)
 	return rc;
 }
 
-int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { return (int64_t)b->unmapped.size(); }
+int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { return (int64_t)b->buf[b->cur].unmapped.size(); }
 
 int ssvh_bam_unmapped_get(const ssvh_bam *b, int64_t k, const char **qname, const char **seq, const char **qual, int *is_read1)
 {
-	if (k < 0 || (size_t)k >= b->unmapped.size()) return -1;
-	const Unmapped &u = b->unmapped[(size_t)k];
+	if (k < 0 || (size_t)k >= b->buf[b->cur].unmapped.size()) return -1;
+	const Unmapped &u = b->buf[b->cur].unmapped[(size_t)k];
 	*qname = u.qname.c_str(); *seq = u.seq.c_str(); *qual = u.qual.c_str(); *is_read1 = u.is_read1;
 	return 0;
 }

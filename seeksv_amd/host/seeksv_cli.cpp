@@ -152,6 +152,7 @@ static int cmd_getclip(int argc, char **argv)
 	PhaseTimer pt;
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(bamfile.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
+	ssvh_bam_set_readahead(bam, 1);
 	GzOut softfout, fqfout, fuout1, fuout2;
 	const string f_clip = prefix + ".clip.gz", f_fq = prefix + ".clip.fq.gz", f_u1 = prefix + ".unmapped_1.fq.gz", f_u2 = prefix + ".unmapped_2.fq.gz";
 	if (!softfout.open(f_clip)) die("Cannot open file " + f_clip);
@@ -355,6 +356,7 @@ static int cmd_getsv(int argc, char **argv)
 	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
 	if (do_discordant) { // CalculateInsertsizeDeviation, cluster.cpp:15-83
 		ssv_isize_begin(ctx, min_mapQ, read_pair_used);
+		ssvh_bam_set_readahead(bam, 1);
 		int32_t done = 0;
 		while (!done) {
 			ssv_batch_t b;
@@ -398,6 +400,7 @@ static int cmd_getsv(int argc, char **argv)
 		gp.windows = dw; gp.n_windows = output_depth ? nw : 0; gp.depth_min_mapq = min_mapQ;
 		gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		ssvh_bam_set_readahead(bam, 1);
 		for (;;) {
 			ssv_batch_t b;
 			if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());

@@ -1,0 +1,120 @@
+"""Host BAM reader (seeksv_amd/host/bam_reader.cpp): the batches must not depend on how the BGZF blocks cut the record stream, on the
+batch size, or on read-ahead.  Stands where the reference relies on samtools' samread() (sam/sam.h:73)."""
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import bamio
+from seeksv_amd import host
+
+NAMES, LENS = ["chr1", "chr2", "chrX"], [100000, 50000, 30000]
+KEYS = ("tid", "pos", "flag", "mapq", "n_cigar", "l_qseq", "mtid", "mpos", "isize", "xc")
+
+
+def _records(n, seed):
+    rng = random.Random(seed)
+    recs = []
+    for i in range(n):
+        l = rng.choice([1, 2, 35, 100, 151, 3000 if i % 97 == 0 else 76])
+        shape = rng.randrange(5)
+        if shape == 0:
+            cig = f"{l}M"
+        elif shape == 1 and l > 20:
+            cig = f"10S{l - 10}M"
+        elif shape == 2 and l > 20:
+            cig = f"{l - 7}M7S"
+        elif shape == 3 and l > 30:
+            cig = f"5S{l - 25}M3I4M2D8M5S"
+        else:
+            cig = f"{l}M"
+        flag = rng.choice([99, 147, 83, 163, 65, 129, 73, 133, 1024 + 99])
+        aux = b"XCi" + struct.pack("<i", 1) if rng.random() < 0.1 else b"NMC\x01"
+        recs.append(dict(qname=f"read{i}" + "x" * rng.randrange(0, 40), flag=flag, tid=rng.randrange(3), pos=rng.randrange(20000), mapq=rng.randrange(61), cigar=cig,
+                         mtid=rng.randrange(3), mpos=rng.randrange(20000), isize=rng.randrange(-900, 900), seq="".join(rng.choice("ACGTN") for _ in range(l)),
+                         qual=None if rng.random() < 0.05 else bytes(rng.randrange(42) for _ in range(l)), aux=aux))
+    return recs
+
+
+def _read_all(path, batch, readahead):
+    out, unm = [], []
+    with host.BamReader(path, readahead=readahead) as r:
+        while True:
+            b = r.read_batch(batch)
+            if b is None:
+                break
+            unm += r.unmapped()
+            out.append(b)
+    cat = {k: np.concatenate([x[k] for x in out]) for k in KEYS}
+    cat["cigar"] = np.concatenate([x["cigar"][:int(x["cigar_off"][-1]) + int(x["n_cigar"][-1])] for x in out])
+    seqs = []
+    for x in out:
+        for i in np.nonzero(x["seq_off"] != np.uint64(2 ** 64 - 1))[0]:
+            lq, so = int(x["l_qseq"][i]), int(x["seq_off"][i])
+            seqs.append(bytes(x["seqqual"][so:so + (lq + 1) // 2 + lq]))
+    cat["seqs"] = seqs
+    cat["unmapped"] = unm
+    return cat
+
+
+@pytest.fixture(scope="module")
+def bam(tmp_path_factory):
+    d = tmp_path_factory.mktemp("bamreader")
+    recs = _records(6000, 11)
+    path = str(d / "ragged.bam")
+    bamio.write_bam(path, NAMES, LENS, recs)  # blocks cut every 0xff00 bytes, wherever that falls inside a record
+    return path, recs
+
+
+def test_batches_independent_of_batch_size_and_readahead(bam):
+    path, recs = bam
+    base = _read_all(path, 1 << 20, False)
+    assert len(base["tid"]) == len(recs)
+    assert list(base["pos"]) == [r["pos"] for r in recs]
+    assert list(base["isize"]) == [r["isize"] for r in recs]
+    soft = [r for r in recs if "S" in r["cigar"]]
+    assert len(base["seqs"]) == len(soft)
+    assert [int(x) for x in base["xc"]] == [int("S" in r["cigar"] and r["aux"].startswith(b"XC")) for r in recs]
+    n_unm = sum(1 for r in recs if r["flag"] & 12)
+    assert len(base["unmapped"]) == n_unm and n_unm > 0
+    for batch, ra in ((1, False), (7, True), (1000, True), (4096, False), (1 << 20, True)):
+        if batch == 1:
+            continue  # one record per batch is covered by the 7-record case; keeps the test fast
+        got = _read_all(path, batch, ra)
+        for k in KEYS + ("cigar",):
+            assert np.array_equal(got[k], base[k]), (k, batch, ra)
+        assert got["seqs"] == base["seqs"] and got["unmapped"] == base["unmapped"], (batch, ra)
+
+
+def test_truncated_and_corrupt_inputs_fail_loudly(bam, tmp_path):
+    path, _ = bam
+    raw = open(path, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    # drop the last data block and the EOF marker: the stream then ends inside a record
+    blocks, o = [], 0
+    while o < len(raw):
+        bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+        blocks.append(raw[o:o + bsize])
+        o += bsize
+    open(cut, "wb").write(b"".join(blocks[:-2]))
+    with pytest.raises(IOError):
+        _read_all(cut, 1000, False)
+    with pytest.raises(IOError):
+        _read_all(cut, 1000, True)
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(raw[:len(raw) // 2] + b"\0" * 64 + raw[len(raw) // 2 + 64:])
+    with pytest.raises(IOError):
+        _read_all(bad, 1000, False)
+
+
+def test_next_record_refused_during_readahead(bam):
+    path, _ = bam
+    import ctypes as C
+    lib = host._abi.host_lib()
+    rec = (C.c_uint8 * 256)()  # room for an ssvh_record; the call must fail before it writes one
+    with host.BamReader(path, readahead=True) as r:
+        assert r.read_batch(100) is not None
+        assert lib.ssvh_bam_next_record(r.handle, C.byref(rec)) == -1
+        assert b"read-ahead" in lib.ssvh_last_error()

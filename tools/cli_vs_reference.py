@@ -19,6 +19,16 @@ BAMIDX = os.path.join(ROOT, "oracle", "_ref", "bamidx")
 OURS = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
 
 
+def phases(stderr):
+    """the `[timing] phase seconds s` lines the CLI prints under SSV_TIMING=1"""
+    out = {}
+    for line in stderr.splitlines():
+        if line.startswith("[timing] "):
+            name, sec, _ = line[9:].rsplit(" ", 2)
+            out[name] = round(float(sec), 3)
+    return out
+
+
 def timed(cmd, **kw):
     t = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, **kw)
@@ -44,6 +54,8 @@ def main():
         assert r.returncode == 0, r.stderr
     out["ours_getclip_s"], r = timed([OURS, "getclip", "-o", os.path.join(d, "ours"), bam])
     assert r.returncode == 0, r.stderr
+    if phases(r.stderr):
+        out["ours_getclip_phases_s"] = phases(r.stderr)
     if have_ref:
         for ext in ("clip.gz", "clip.fq.gz"):
             assert gzip.open(os.path.join(d, "ref." + ext)).read() == gzip.open(os.path.join(d, "ours." + ext)).read(), ext
@@ -64,6 +76,8 @@ def main():
         ref_stdout = r.stdout
     out["ours_getsv_s"], r = timed([OURS, "getsv"] + args + [os.path.join(d, "ours.sv"), os.path.join(d, "y.fq")])
     assert r.returncode == 0, r.stderr
+    if phases(r.stderr):
+        out["ours_getsv_phases_s"] = phases(r.stderr)
     if have_ref:
         assert open(os.path.join(d, "ref.sv")).read() == open(os.path.join(d, "ours.sv")).read()
         assert ref_stdout == r.stdout
@@ -73,7 +87,7 @@ def main():
         out["speedup_getsv"] = round(out["ref_getsv_s"] / out["ours_getsv_s"], 2)
     out["ours_records_per_s"] = round(w.n_total / (out["ours_getclip_s"] + out["ours_getsv_s"]))
     for k in list(out):
-        if k.endswith("_s"):
+        if k.endswith("_s") and not isinstance(out[k], dict):
             out[k] = round(out[k], 3)
     print(json.dumps(out))
 
