@@ -11,6 +11,7 @@
 #include <getopt.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +22,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "junction_stage.h"
@@ -209,34 +211,57 @@ static int cmd_getclip(int argc, char **argv)
 	ssv_cluster_table t;
 	if (ssv_clip_cluster(ctx, &t) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 	pt.lap("gpu_cluster+table");
-	// DisplaySClipReadsAndClipFq ('5' rows then '3' rows per contig run), clip_reads.h:300-345
-	int64_t k = 0;
-	string row, fq;
+	// DisplaySClipReadsAndClipFq ('5' rows then '3' rows per contig run), clip_reads.h:300-345.  The rows of one cluster depend on nothing
+	// else, so cluster ranges are formatted by several host threads and written out in order.
+	int64_t k_end = 0;
 	for (int32_t tid : run_tids) {
 		const char *name = ssvh_bam_target_name(bam, tid);
 		cerr << "Output merged soft-clipped reads of " << (name ? name : "") << endl;
-		for (; k < t.n_clusters && t.tid[k] == tid; ++k) {
-			const uint8_t *s = t.str + t.str_off[k];
-			const int ll = t.left_len[k], lr = t.right_len[k];
-			string sl((const char *)s, (size_t)ll), ql((const char *)s + ll, (size_t)ll), sr((const char *)s + 2 * ll, (size_t)lr), qr((const char *)s + 2 * ll + lr, (size_t)lr);
-			if (t.qual_missing[k]) ql = qr = "*";
-			string cig;
+		for (; k_end < t.n_clusters && t.tid[k_end] == tid; ++k_end) {}
+	}
+	const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, k_end / 4096}));
+	vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
+	auto format_range = [&](int w) {
+		const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
+		string &row = rows[(size_t)w], &fq = fqs[(size_t)w];
+		row.reserve((size_t)(k1 - k0) * 480); fq.reserve((size_t)(k1 - k0) * 200);
+		char num[16];
+		for (int64_t k = k0; k < k1; ++k) {
+			const char *name = ssvh_bam_target_name(bam, t.tid[k]);
+			const char *s = (const char *)t.str + t.str_off[k];
+			const size_t ll = (size_t)t.left_len[k], lr = (size_t)t.right_len[k];
+			const char *sl = s, *ql = s + ll, *sr = s + 2 * ll, *qr = s + 2 * ll + lr;
+			size_t lql = ll, lqr = lr;
+			if (t.qual_missing[k]) { ql = qr = "*"; lql = lqr = 1; }
+			row += name ? name : ""; row += '\t';
+			row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.pos[k])); row += '\t'; row += (char)t.side[k]; row += '\t';
 			for (int q = 0; q < t.n_cigar[k]; ++q) {
 				uint32_t op = t.cigar[t.cigar_off[k] + q];
 				if ((op & 15) == 4 || (op & 15) == 5) continue;
-				cig += to_string(op >> 4); cig += CIGAR_CHARS[op & 15];
+				row.append(num, (size_t)snprintf(num, sizeof(num), "%u", op >> 4)); row += CIGAR_CHARS[op & 15];
 			}
-			row.clear(); fq.clear();
-			row += name; row += '\t'; row += to_string(t.pos[k]); row += '\t'; row += (char)t.side[k]; row += '\t'; row += cig; row += '\t';
-			if (t.side[k] == '5') { row += sr + '\t' + qr + '\t' + sl + '\t' + ql; fq = "@" + sl + "\n" + sl + "\n+\n" + ql + "\n"; }
-			else { row += sl + '\t' + ql + '\t' + sr + '\t' + qr; fq = "@" + sr + "\n" + sr + "\n+\n" + qr + "\n"; }
-			row += '\t'; row += to_string(t.support[k]); row += '\n';
-			softfout.write(row); fqfout.write(fq);
+			row += '\t';
+			if (t.side[k] == '5') {
+				row.append(sr, lr); row += '\t'; row.append(qr, lqr); row += '\t'; row.append(sl, ll); row += '\t'; row.append(ql, lql);
+				fq += '@'; fq.append(sl, ll); fq += '\n'; fq.append(sl, ll); fq += "\n+\n"; fq.append(ql, lql); fq += '\n';
+			} else {
+				row.append(sl, ll); row += '\t'; row.append(ql, lql); row += '\t'; row.append(sr, lr); row += '\t'; row.append(qr, lqr);
+				fq += '@'; fq.append(sr, lr); fq += '\n'; fq.append(sr, lr); fq += "\n+\n"; fq.append(qr, lqr); fq += '\n';
+			}
+			row += '\t'; row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.support[k])); row += '\n';
 		}
+	};
+	{
+		vector<std::thread> th;
+		for (int w = 1; w < n_fmt; ++w) th.emplace_back(format_range, w);
+		format_range(0);
+		for (auto &x : th) x.join();
 	}
+	pt.lap("format");
+	for (int w = 0; w < n_fmt; ++w) { softfout.write(rows[(size_t)w]); fqfout.write(fqs[(size_t)w]); }
 	cerr << "[GetSClipReads] finished!" << endl;
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
-	pt.lap("format+gzip");
+	pt.lap("gzip");
 	ssv_ctx_destroy(ctx);
 	ssvh_bam_close(bam);
 	pt.lap("teardown");
@@ -282,6 +307,7 @@ static int cmd_getsv(int argc, char **argv)
 	int c, min_mapQ = 20, read_pair_used = 5000000, sum_min_no_both_clipped_reads = 3, min_distance = 50, microhomology_length = 50, times = 4, device = 0,
 	       min_abnormal_read_pair_no = 0, flank_length = 200, min_seq_len = 30, max_seq_indel_no = 1, flank = 50;
 	bool output_depth = true;
+	PhaseTimer pt;
 	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:")) >= 0) {
 		switch (c) {
 		case 'F': connect_bam = optarg; break;
@@ -347,11 +373,13 @@ static int cmd_getsv(int argc, char **argv)
 		return 0;
 	}
 
+	pt.lap("junction_stage");
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file " + original_bam + "for reading.");
 	ssv_ctx *ctx = nullptr;
 	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
 
+	pt.lap("open+gpu_init");
 	int mean_insert_size = 0, deviation = 0;
 	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
 	if (do_discordant) { // CalculateInsertsizeDeviation, cluster.cpp:15-83
@@ -375,6 +403,7 @@ static int cmd_getsv(int argc, char **argv)
 		if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
 	} else min_abnormal_read_pair_no = 0; // seeksv.cpp:285
 
+	pt.lap("isize_pass");
 	// ---- the fused BAM pass: discordant tally + depth ----
 	vector<ssvh_junction_in> J;
 	vector<int32_t> prev;
@@ -390,6 +419,7 @@ static int cmd_getsv(int argc, char **argv)
 	const ssv_interval *dw = ssvh_plan_windows(plan, &nw);
 	const ssv_interval *dr = ssvh_plan_ranges(plan, &nr);
 	const ssv_interval *dp = ssvh_plan_points(plan, &np);
+	pt.lap("plan");
 	vector<int32_t> counts((size_t)nj + 1, 0), pdepth((size_t)np + 1, 0);
 	vector<uint64_t> rsum((size_t)nr + 1, 0);
 	if (do_discordant || output_depth) {
@@ -413,6 +443,7 @@ static int cmd_getsv(int argc, char **argv)
 			die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (maxd >= 7999) cerr << "[seeksv] warning: depth " << maxd << " reaches the pileup cap of samtools 0.1.16 (~8000 reads); the reference's depths saturate there" << endl;
 	}
+	pt.lap("fused_pass");
 	if (do_discordant) { cerr << "'StoreSeqName2Tid' finished" << endl; cerr << "'FindDiscordantReadPairs' finished" << endl; }
 	if (output_depth) { cerr << "'MergeOverlap' finished" << endl; cerr << "'main_depth' finished" << endl; }
 	else frequency = 0; // seeksv.cpp:300
@@ -472,9 +503,11 @@ static int cmd_getsv(int argc, char **argv)
 	}
 	ofstream foutuq(clip_unmap_fq_file.c_str()); // OutputOneendUnmapBreakpoint: always empty (GetJunction returns early for type 'n')
 	if (!foutuq) die("Cannot open file " + clip_unmap_fq_file);
+	pt.lap("fold+output");
 	ssvh_plan_destroy(plan);
 	ssv_ctx_destroy(ctx);
 	ssvh_bam_close(bam);
+	pt.lap("teardown");
 	return 0;
 }
 
