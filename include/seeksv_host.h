@@ -68,6 +68,8 @@ int ssvh_bam_write_batch(const char *path, const char *const *names, const int32
  * written.  append == 0 truncates the file first.  n == 0 with append == 0 creates an empty gzip stream like an ogzstream that is
  * closed without writes. */
 int ssvh_gz_append(const char *path, const char *text, size_t n, int append);
+/* the same for several buffers that follow one another in the output (one call keeps every host thread busy) */
+int ssvh_gz_append_v(const char *path, const char *const *texts, const size_t *lens, int count, int append);
 
 /* Records with UNMAP|MUNMAP seen in the last batch: qname / decoded bases / qualities for the
  * unmapped-pair FASTQ side channel (clip_reads.h:415-419).  Index k in [0, n).  Host only. */

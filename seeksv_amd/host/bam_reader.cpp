@@ -751,22 +751,27 @@ int ssvh_bam_write_batch(const char *path, const char *const *names, const int32
 	return 0;
 }
 
-int ssvh_gz_append(const char *path, const char *text, size_t n, int append)
+int ssvh_gz_append_v(const char *path, const char *const *texts, const size_t *lens, int count, int append)
 {
 	FILE *f = fopen(path, append ? "ab" : "wb");
 	if (!f) { g_err = std::string("cannot open ") + path; return -1; }
 	const size_t PIECE = 1 << 20;
-	const size_t np = n ? (n + PIECE - 1) / PIECE : (append ? 0 : 1);
+	struct Piece { const char *p; size_t n; };
+	std::vector<Piece> pieces;
+	for (int k = 0; k < count; ++k)
+		for (size_t off = 0; off < lens[k]; off += PIECE) pieces.push_back(Piece{texts[k] + off, std::min(PIECE, lens[k] - off)});
+	if (pieces.empty() && !append) pieces.push_back(Piece{"", 0}); // an empty file is one empty member, like gzstream's
+	const size_t np = pieces.size();
 	std::vector<std::vector<uint8_t>> comp(np);
 	std::vector<int> ok(np, 1);
 	wpool().run((int)np, [&](int i) {
-		const size_t off = (size_t)i * PIECE, len = n ? std::min(PIECE, n - off) : 0;
+		const Piece &pc = pieces[(size_t)i];
 		std::vector<uint8_t> &c = comp[(size_t)i];
 		z_stream zs;
 		memset(&zs, 0, sizeof(zs));
 		if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok[(size_t)i] = 0; return; }
-		c.resize(deflateBound(&zs, (uLong)len) + 64);
-		zs.next_in = (Bytef *)const_cast<char *>(text + off); zs.avail_in = (uInt)len;
+		c.resize(deflateBound(&zs, (uLong)pc.n) + 64);
+		zs.next_in = (Bytef *)const_cast<char *>(pc.p); zs.avail_in = (uInt)pc.n;
 		zs.next_out = c.data(); zs.avail_out = (uInt)c.size();
 		if (deflate(&zs, Z_FINISH) != Z_STREAM_END) ok[(size_t)i] = 0;
 		c.resize(zs.total_out);
@@ -780,6 +785,8 @@ int ssvh_gz_append(const char *path, const char *text, size_t n, int append)
 	fclose(f);
 	return rc;
 }
+
+int ssvh_gz_append(const char *path, const char *text, size_t n, int append) { return ssvh_gz_append_v(path, &text, &n, 1, append); }
 
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { return (int64_t)b->buf[b->cur].unmapped.size(); }
 

@@ -125,6 +125,15 @@ struct GzOut {
 		buf.clear();
 	}
 	void write(const string &s) { buf += s; if (buf.size() >= ((size_t)256 << 20)) flush(false); }
+	void write_parts(const vector<string> &parts) // large, already formatted pieces: compressed from where they lie
+	{
+		flush(false);
+		vector<const char *> ptr; vector<size_t> len;
+		for (auto &s : parts) if (!s.empty()) { ptr.push_back(s.data()); len.push_back(s.size()); }
+		if (ptr.empty()) return;
+		if (ssvh_gz_append_v(path.c_str(), ptr.data(), len.data(), (int)ptr.size(), started ? 1 : 0) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		started = true;
+	}
 	void close() { flush(true); }
 };
 
@@ -258,7 +267,7 @@ static int cmd_getclip(int argc, char **argv)
 		for (auto &x : th) x.join();
 	}
 	pt.lap("format");
-	for (int w = 0; w < n_fmt; ++w) { softfout.write(rows[(size_t)w]); fqfout.write(fqs[(size_t)w]); }
+	softfout.write_parts(rows); fqfout.write_parts(fqs);
 	cerr << "[GetSClipReads] finished!" << endl;
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
 	pt.lap("gzip");
