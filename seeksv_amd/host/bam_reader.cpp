@@ -755,7 +755,7 @@ int ssvh_gz_append_v(const char *path, const char *const *texts, const size_t *l
 {
 	FILE *f = fopen(path, append ? "ab" : "wb");
 	if (!f) { g_err = std::string("cannot open ") + path; return -1; }
-	const size_t PIECE = 1 << 20;
+	const size_t PIECE = 1 << 18;
 	struct Piece { const char *p; size_t n; };
 	std::vector<Piece> pieces;
 	for (int k = 0; k < count; ++k)
