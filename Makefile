@@ -27,9 +27,9 @@ $(LIBDIR)/libseeksv_hip.so: $(HIP_DEPS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
 # the `seeksv` command line (getclip / getsv) over the two libraries
-seeksv_amd/bin/seeksv: seeksv_amd/host/seeksv_cli.cpp seeksv_amd/host/junction_stage.cpp seeksv_amd/host/junction_stage.h $(LIBDIR)/libseeksv_host.so $(LIBDIR)/libseeksv_hip.so
+seeksv_amd/bin/seeksv: seeksv_amd/host/seeksv_cli.cpp seeksv_amd/host/junction_stage.cpp seeksv_amd/host/junction_stage.h seeksv_amd/host/somatic_stage.cpp seeksv_amd/host/somatic_stage.h $(LIBDIR)/libseeksv_host.so $(LIBDIR)/libseeksv_hip.so
 	mkdir -p seeksv_amd/bin
-	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ seeksv_amd/host/seeksv_cli.cpp seeksv_amd/host/junction_stage.cpp -L$(LIBDIR) -lseeksv_host -lseeksv_hip -lz \
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ seeksv_amd/host/seeksv_cli.cpp seeksv_amd/host/junction_stage.cpp seeksv_amd/host/somatic_stage.cpp -L$(LIBDIR) -lseeksv_host -lseeksv_hip -lz \
 		-Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,$(ROCM)/lib
 
 # synthetic BAM-record generator: the same source compiled for the GPU (bench) and for the CPU (tests, cpu baseline)

@@ -56,6 +56,9 @@ int ssvh_plan_update_isize(ssvh_plan *p, int32_t mean, int32_t sd, int32_t times
 		else { beg = d.up_pos - 1 - 5; end = d.up_pos - 1 + max_ins; }
 		if (beg <= 0) beg = 1;
 		if ((unsigned)end > p->dev_chr_length[k]) end = (int)p->dev_chr_length[k]; // int vs unsigned compare, getsv.cpp:1060
+		// bam_iter_query on an empty interval visits no record (reg2bins returns no bins when beg >= end); this happens for '+'
+		// junctions when mean = sd = 0 (somatic.cpp:111 calls the tally without insert-size statistics).  Empty window here too.
+		if (beg >= end) beg = end = 0;
 		d.beg = beg; d.end = end;
 	}
 	return 0;

@@ -30,20 +30,6 @@ struct AlignInfo { // getsv.h:27-44
 
 typedef std::map<std::pair<std::string, std::pair<std::string, int>>, AlignInfo> AlignMap; // (name, (chr, pos)) -> alignment
 
-double match_end_first(const std::string &a, const std::string &b) // CompareStringEndFirst, clip_reads.cpp:194
-{
-	int la = (int)a.size(), lb = (int)b.size(), n = la < lb ? la : lb, m = 0;
-	for (int i = 0; i < n; ++i) if (a[(size_t)(la - 1 - i)] == b[(size_t)(lb - 1 - i)]) ++m;
-	return (double)m / n;
-}
-
-double match_begin_first(const std::string &a, const std::string &b) // CompareStringBeginFirst, clip_reads.cpp:207
-{
-	int n = (int)(a.size() < b.size() ? a.size() : b.size()), m = 0;
-	for (int i = 0; i < n; ++i) if (a[(size_t)i] == b[(size_t)i]) ++m;
-	return (double)m / n;
-}
-
 void reverse_cigar(CigarVec &v) // ReverseCigar, getsv.cpp:453
 {
 	for (size_t i = 0, n = v.size(); i < n / 2; ++i) std::swap(v[i], v[n - 1 - i]);
@@ -168,6 +154,22 @@ void flush_group(const std::vector<ClipRow> &rows, AlignMap &aligns, JunctionMap
 		for (; a != aligns.end(); ++a) add_junction(rows[r], a->second, j2o);
 }
 
+} // namespace
+
+double match_end_first(const std::string &a, const std::string &b) // CompareStringEndFirst, clip_reads.cpp:194
+{
+	int la = (int)a.size(), lb = (int)b.size(), n = la < lb ? la : lb, m = 0;
+	for (int i = 0; i < n; ++i) if (a[(size_t)(la - 1 - i)] == b[(size_t)(lb - 1 - i)]) ++m;
+	return (double)m / n;
+}
+
+double match_begin_first(const std::string &a, const std::string &b) // CompareStringBeginFirst, clip_reads.cpp:207
+{
+	int n = (int)(a.size() < b.size() ? a.size() : b.size()), m = 0;
+	for (int i = 0; i < n; ++i) if (a[(size_t)i] == b[(size_t)i]) ++m;
+	return (double)m / n;
+}
+
 std::string slurp_gz(const std::string &path, std::string &out)
 {
 	gzFile f = gzopen(path.c_str(), "rb"); // reads plain files too
@@ -179,7 +181,6 @@ std::string slurp_gz(const std::string &path, std::string &out)
 	return "";
 }
 
-} // namespace
 
 CigarVec parse_cigar(const std::string &cigar)
 {

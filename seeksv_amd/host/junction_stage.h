@@ -29,6 +29,9 @@ struct SeqInfo { std::string seq; CigarVec cigar_vec; int left_clipped = 0, righ
 struct OtherInfo { SeqInfo up, down; int microhomology = 0, abnormal = 0; };                                             // getsv.h:89-108
 typedef std::multimap<Junction, OtherInfo> JunctionMap;
 
+double match_end_first(const std::string &a, const std::string &b);   // CompareStringEndFirst, clip_reads.cpp:194 (NaN for an empty string)
+double match_begin_first(const std::string &a, const std::string &b); // CompareStringBeginFirst, clip_reads.cpp:207
+std::string slurp_gz(const std::string &path, std::string &out);      // whole file (gzip or plain) into out; "" or an error text
 CigarVec parse_cigar(const std::string &cigar);  // ChangeCigarType, getsv.cpp:433
 void reverse_complement(std::string &seq);       // GetReverseComplementSeq, clip_reads.cpp:414
 

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "junction_stage.h"
+#include "somatic_stage.h"
 #include "seeksv_hip.h"
 #include "seeksv_host.h"
 
@@ -35,6 +36,10 @@ using seeksv::JunctionMap;
 using seeksv::OtherInfo;
 using seeksv::SeqInfo;
 using seeksv::parse_cigar;
+using seeksv::ClusterMap;
+using seeksv::SomaticRow;
+using seeksv::load_normal_clusters;
+using seeksv::scan_tumor_table;
 
 static const char *kVersion = "1.2.3-mi355x";
 
@@ -67,7 +72,8 @@ struct PhaseTimer {
 	     << "Version: " << kVersion << "\n\n"
 	     << "Usage: seeksv <command> [options]\n\n"
 	     << "Command: getclip\tget soft-clipped reads\n"
-	     << "         getsv  \tget final sv" << endl;
+	     << "         getsv  \tget final sv\n"
+	     << "         somatic\tget somatic sv" << endl;
 	exit(1);
 }
 
@@ -99,6 +105,18 @@ struct PhaseTimer {
 	     << "         -i <int>              Maximum indel number of up_seq / down_seq when no read pair supports the junction [1]\n"
 	     << "         -L <int>              Flank length for the average depths [200]\n"
 	     << "         -t <double> -Q <int> -w <int>   accepted for compatibility\n"
+	     << "         -G <int>              GPU ordinal [0]" << endl;
+	exit(1);
+}
+
+[[noreturn]] static void usage_somatic()
+{
+	cerr << "Usage: seeksv somatic [options] <input normal original bam> <input normal soft-clipped reads file(*.clip.gz)> <input tumor SV file> <output somatic SV file>\n\n"
+	     << "         -t <double>           Threshold of match rate while comparing two soft-clipped reads [0.9]\n"
+	     << "         -q <int>              Minimum mapping quality of discordant read pair [20]\n"
+	     << "         -l <int>              Maximum search length to find microhomology [30]\n"
+	     << "         -m <int>              Minimum length of the clipped sequence  in normal [10]\n"
+	     << "         -n <int>              Number of read pairs used to calculate insert size [5000000]; < 100000 switches the insert-size pass off\n"
 	     << "         -G <int>              GPU ordinal [0]" << endl;
 	exit(1);
 }
@@ -309,6 +327,29 @@ static double largest_base_frequency(const string &seq) // CountLargestBaseFrequ
 	return largest / (double)seq.length();
 }
 
+// CalculateInsertsizeDeviation (cluster.cpp:15-83) over the head of a BAM, with the reference's stderr lines
+static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation)
+{
+	ssvh_bam *bam = nullptr;
+	if (ssvh_bam_open(bamfile.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
+	ssv_isize_begin(ctx, min_mapQ, read_pair_used);
+	ssvh_bam_set_readahead(bam, 1);
+	int32_t done = 0;
+	while (!done) {
+		ssv_batch_t b;
+		if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		if (b.n == 0) break;
+		if (ssv_isize_accumulate(ctx, &b, &done) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+	}
+	int64_t n; int32_t m = 0, sd = 0;
+	ssv_isize_finish(ctx, &n, &m, &sd);
+	if (n > 0) {
+		mean_insert_size = m; deviation = sd;
+		cerr << "Bam/sam " << bamfile << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << endl;
+	}
+	ssvh_bam_close(bam);
+}
+
 static int cmd_getsv(int argc, char **argv)
 {
 	string connect_bam, temp_breakpoint, dump_junctions;
@@ -391,25 +432,9 @@ static int cmd_getsv(int argc, char **argv)
 	pt.lap("open+gpu_init");
 	int mean_insert_size = 0, deviation = 0;
 	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
-	if (do_discordant) { // CalculateInsertsizeDeviation, cluster.cpp:15-83
-		ssv_isize_begin(ctx, min_mapQ, read_pair_used);
-		ssvh_bam_set_readahead(bam, 1);
-		int32_t done = 0;
-		while (!done) {
-			ssv_batch_t b;
-			if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
-			if (b.n == 0) break;
-			if (ssv_isize_accumulate(ctx, &b, &done) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		}
-		int64_t n; int32_t m = 0, sd = 0;
-		ssv_isize_finish(ctx, &n, &m, &sd);
-		if (n > 0) {
-			mean_insert_size = m; deviation = sd;
-			cerr << "Bam/sam " << original_bam << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << endl;
-		}
+	if (do_discordant) {
+		insert_size_pass(ctx, original_bam, min_mapQ, read_pair_used, mean_insert_size, deviation);
 		cerr << "'CalculateInsertsizeDeviation' finished" << endl;
-		ssvh_bam_close(bam);
-		if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
 	} else min_abnormal_read_pair_no = 0; // seeksv.cpp:285
 
 	pt.lap("isize_pass");
@@ -520,15 +545,124 @@ static int cmd_getsv(int argc, char **argv)
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// somatic (CallSomatic, seeksv.cpp:366-407; ReadTumorFileAndOutputSomaticInfo, somatic.cpp:14-427)
+// ---------------------------------------------------------------------------------------------------------------------
+
+static int cmd_somatic(int argc, char **argv)
+{
+	int offset = 30, c, min_len_of_clipped_seq = 10, read_pair_used = 5000000, min_mapQ = 20, device = 0;
+	double min_map_rate = 0.9;
+	PhaseTimer pt;
+	while ((c = getopt(argc, argv, "t:q:l:m:n:G:")) >= 0) {
+		switch (c) {
+		case 't': min_map_rate = atof(optarg); break;
+		case 'q': min_mapQ = atoi(optarg); break;
+		case 'l': offset = atoi(optarg); break;
+		case 'm': min_len_of_clipped_seq = atoi(optarg); break;
+		case 'n': read_pair_used = atoi(optarg); break;
+		case 'G': device = atoi(optarg); break;
+		}
+	}
+	if (argc != optind + 4) { cerr << argc << '\t' << optind << endl; usage_somatic(); }
+	else if (offset >= 90 || offset < 0) { cerr << "Error: value of -l must in range [0, 90) " << endl; usage_somatic(); }
+	const string normal_bam_file = argv[optind++], clipped_file = argv[optind++], tumor_file = argv[optind++], somatic_file = argv[optind++];
+
+	ClusterMap clip3, clip5;
+	{
+		string warnings, err = load_normal_clusters(clipped_file, min_len_of_clipped_seq, clip3, clip5, warnings);
+		if (!err.empty()) die(err);
+		cerr << warnings;
+	}
+	pt.lap("normal_clusters");
+	ssv_ctx *ctx = nullptr;
+	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+	pt.lap("gpu_init");
+	int mean_insert_size = 0, deviation = 0;
+	if (read_pair_used >= 100000) insert_size_pass(ctx, normal_bam_file, min_mapQ, read_pair_used, mean_insert_size, deviation);
+	pt.lap("isize_pass");
+
+	ofstream fout(somatic_file.c_str());
+	if (!fout) die("Error: Cannot open output file " + somatic_file);
+	ssvh_bam *bam = nullptr;
+	if (ssvh_bam_open(normal_bam_file.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
+	vector<SomaticRow> rows;
+	{
+		string err = scan_tumor_table(tumor_file, clip3, clip5, offset, min_map_rate, mean_insert_size, rows);
+		if (!err.empty()) die(err);
+	}
+	pt.lap("cluster_lookups");
+
+	// every row that asks for FindDiscordantReadPairs (getsv.cpp:1123-1247) becomes one junction of a single pass over the normal BAM
+	vector<ssvh_junction_in> J;
+	vector<size_t> row_of;
+	for (size_t r = 0; r < rows.size(); ++r) {
+		if (rows[r].kind != SomaticRow::JUNCTION || !rows[r].tally) continue;
+		J.push_back(ssvh_junction_in{rows[r].up_chr.c_str(), rows[r].down_chr.c_str(), rows[r].up_pos, rows[r].down_pos, rows[r].up_strand, rows[r].down_strand});
+		row_of.push_back(r);
+	}
+	vector<int32_t> abnormal(J.size() + 1, 0);
+	if (!J.empty()) {
+		const int times = 4; // seeksv.cpp:406
+		ssvh_plan *plan = nullptr;
+		ssvh_plan_create(bam, J.data(), (int64_t)J.size(), nullptr, nullptr, 0, mean_insert_size, deviation, times, 200, &plan);
+		int64_t nj;
+		const ssv_junction *dj = ssvh_plan_junctions(plan, &nj);
+		vector<int32_t> counts((size_t)nj + 1, 0);
+		ssv_getsv_params gp;
+		memset(&gp, 0, sizeof(gp));
+		gp.junctions = dj; gp.n_junctions = nj;
+		gp.mean = mean_insert_size; gp.sd = deviation; gp.times = times; gp.disc_min_mapq = min_mapQ;
+		gp.n_windows = 0; gp.depth_min_mapq = min_mapQ;
+		gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
+		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		ssvh_bam_set_readahead(bam, 1);
+		for (;;) {
+			ssv_batch_t b;
+			if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+			if (b.n == 0) break;
+			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			ssv_sync(ctx);
+		}
+		int32_t maxd = 0;
+		if (ssv_getsv_finish(ctx, counts.data(), nullptr, 0, nullptr, nullptr, 0, nullptr, &maxd) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		vector<int32_t> prev(J.size() + 1, 0), ud(J.size() + 1), dd(J.size() + 1);
+		vector<uint64_t> fs(J.size() * 4 + 4);
+		vector<uint32_t> fl(J.size() * 4 + 4);
+		ssvh_plan_fold(plan, counts.data(), prev.data(), nullptr, nullptr, abnormal.data(), ud.data(), dd.data(), fs.data(), fl.data(), nullptr);
+		ssvh_plan_destroy(plan);
+	}
+	pt.lap("discordant_pass");
+	size_t k = 0;
+	for (size_t r = 0; r < rows.size(); ++r) {
+		const SomaticRow &row = rows[r];
+		if (row.kind == SomaticRow::HEADER) { fout << row.text << endl; continue; }
+		if (row.kind == SomaticRow::MESSAGE) { cerr << row.text << endl; continue; }
+		int normal_abnormal = 0;
+		if (row.tally) {
+			if (k < row_of.size() && row_of[k] == r) normal_abnormal = abnormal[k++];
+			bool known = false;
+			for (int32_t t = 0, nt = ssvh_bam_n_targets(bam); t < nt && !known; ++t) known = row.up_chr == ssvh_bam_target_name(bam, t);
+			if (!known) cerr << "Cannot find " << row.up_chr << ", please check whether you input a wrong file" << endl;
+		}
+		fout << row.text << '\t' << row.normal_left_reads << '\t' << row.normal_right_reads << '\t' << normal_abnormal << endl;
+	}
+	pt.lap("output");
+	ssv_ctx_destroy(ctx);
+	ssvh_bam_close(bam);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc == 1) usage_top();
 	const string cmd = argv[1];
-	if (cmd != "getclip" && cmd != "getsv") {
+	if (cmd != "getclip" && cmd != "getsv" && cmd != "somatic") {
 		cerr << "[seeksv] unrecognized command '" << argv[1] << "'" << endl;
 		return 1;
 	}
-	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else usage_getsv(); }
+	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else if (cmd == "getsv") usage_getsv(); else usage_somatic(); }
 	optind = 1; // like SelectStep (seeksv.cpp:444-452): the sub-command becomes argv[0]
+	if (cmd == "somatic") return cmd_somatic(argc - 1, argv + 1);
 	return cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
 }

@@ -423,6 +423,69 @@ def synthetic_full():
         print(f"  {name}: {w.n_total} records, {len(w.junctions)} planted, {n_sv} SV rows")
 
 
+# ------------------------------------------------------------------------------------------------
+# 6. somatic: the synthetic sample as the "normal", and a tumor SV table made of the sample's own
+#    junctions plus systematic variants of them, so that every branch of ReadTumorFileAndOutputSomaticInfo
+#    (strand pair x microhomology known or -1 x which side has no clipped reads, shifted positions for the
+#    anchored range searches, the two error messages) is taken.
+# ------------------------------------------------------------------------------------------------
+
+def somatic_table(sv_rows):
+    out = []
+    for k, row in enumerate(sv_rows):
+        c = row.rstrip("\n").split("\t")
+        out.append(c)
+        for var in range(8):
+            v = list(c)
+            if var == 0:
+                v[8], v[3] = "-1", "0"                      # only the right breakend clipped
+            elif var == 1:
+                v[8], v[7] = "-1", "0"                      # only the left breakend clipped
+            elif var == 2:
+                v[8] = "-1"                                 # both clipped but no microhomology: the reference prints a message
+            elif var == 3:
+                v[8], v[3], v[1] = "-1", "0", str(int(c[1]) - 3 - k % 5)   # range probe has to walk to the bin
+            elif var == 4:
+                v[8], v[7], v[5] = "-1", "0", str(int(c[5]) + 2 + k % 7)
+            elif var == 5:
+                v[8] = str(1 + k % 3)                       # bins move by the microhomology
+            elif var == 6:
+                v[8], v[3], v[1] = "-1", "0", str(int(c[1]) + 2)
+            elif var == 7:
+                v[8], v[7], v[5] = "-1", "0", str(int(c[5]) - 4)
+            out.append(v)
+        if k % 6 == 0:
+            v = list(c); v[2], v[6] = "-", "-"; out.append(v)   # unsupported strand pair
+        if k % 4 == 1:
+            v = list(c); v[21] = c[21][:8]; v[22] = c[22][:9]; v[8], v[3] = "-1", "0"; out.append(v)  # sequences shorter than the 10-base anchor
+    return out
+
+
+def somatic_synth():
+    sys.path.insert(0, ROOT)
+    from seeksv_amd import synth
+    out = os.path.join(HERE, "somatic")
+    os.makedirs(out, exist_ok=True)
+    name, kw = "synthfull", SYNTH_FULL["synthfull"]
+    w = synth.Workload(**kw)
+    bam = os.path.join(TMP, f"{name}.bam")
+    if not os.path.exists(bam):
+        bamio.soa_to_bam(bam, w.names, w.lens, w.generate_host(0, w.n_total))
+    run([os.path.join(BIN, "bamidx"), bam])
+    run([SEEKSV, "getclip", "-o", name, bam], cwd=TMP)
+    lines = open(os.path.join(HERE, "synth", f"{name}.loose.sv")).read().splitlines()
+    header, rows = lines[0], [l for l in lines[1:] if l]
+    table = os.path.join(out, "tumor.sv")
+    with open(table, "w") as f:
+        f.write(header + "\n")
+        for v in somatic_table(rows):
+            f.write("\t".join(v) + "\n")
+    for tag, flags in (("", []), (".n0", ["-n", "0"]), (".l0", ["-l", "0"]), (".l60", ["-l", "60"]), (".t05", ["-t", "0.5"]), (".m60", ["-m", "60"]), (".q0", ["-q", "0"])):
+        run([SEEKSV, "somatic"] + flags + [bam, f"{name}.clip.gz", table, os.path.join(out, f"somatic{tag}.sv")], cwd=TMP, stderr=os.path.join(out, f"somatic{tag}.stderr"))
+    n = sum(1 for _ in open(os.path.join(out, "somatic.sv")))
+    print(f"  somatic: {len(open(table).read().splitlines())} table rows -> {n} output rows")
+
+
 if __name__ == "__main__":
     if not os.path.exists(SEEKSV):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -432,4 +495,5 @@ if __name__ == "__main__":
     crafted_getsv()
     synthetic()
     synthetic_full()
+    somatic_synth()
     print("goldens regenerated under", HERE)

@@ -104,3 +104,42 @@ def test_cli_full_pipeline_synthetic_sv_table(synthfull_bam, tag, flags):
     assert r.returncode == 0, r.stderr
     assert open(sv).read() == G.read_text("synth", f"synthfull{tag}.sv")
     assert r.stdout == G.read_text("synth", f"synthfull{tag}.stdout")
+
+
+SOMATIC_VARIANTS = [("", []), (".n0", ["-n", "0"]), (".l0", ["-l", "0"]), (".l60", ["-l", "60"]), (".t05", ["-t", "0.5"]), (".m60", ["-m", "60"]), (".q0", ["-q", "0"])]
+
+
+def _somatic_stderr(text):
+    """the reference prints the BAM path it was given; compare everything else"""
+    return [("Bam/sam <bam>" + l[l.index("    Mean insert size"):]) if l.startswith("Bam/sam ") else l for l in text.splitlines() if l != "'CalculateInsertsizeDeviation' finished"]
+
+
+@pytest.mark.parametrize("tag,flags", SOMATIC_VARIANTS, ids=[t[0] or "default" for t in SOMATIC_VARIANTS])
+def test_cli_somatic_synthetic(synthfull_bam, tag, flags):
+    """`seeksv somatic`: 227 tumor junction rows (the sample's own junctions and systematic variants that take every branch of
+    ReadTumorFileAndOutputSomaticInfo) against the synthetic sample as the normal: output table and stderr messages equal the real reference's."""
+    bam, clip_gz, d = synthfull_bam
+    out = str(d / f"somatic{tag}.sv")
+    r = subprocess.run([SEEKSV, "somatic"] + flags + [bam, clip_gz, os.path.join(G.GOLDEN, "somatic", "tumor.sv"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out).read() == G.read_text("somatic", f"somatic{tag}.sv")
+    assert _somatic_stderr(r.stderr) == _somatic_stderr(G.read_text("somatic", f"somatic{tag}.stderr"))
+
+
+def test_cli_somatic_example(tmp_path):
+    """example/seeksv.somatic.sh: tumor table of cancer.sort.bam against normal.sort.bam + its clip.gz"""
+    ex = os.path.join(G.GOLDEN, "example")
+    pre = str(tmp_path / "normal")
+    r = subprocess.run([SEEKSV, "getclip", "-o", pre, os.path.join(ex, "normal.sort.bam")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = str(tmp_path / "somatic.sv")
+    r = subprocess.run([SEEKSV, "somatic", os.path.join(ex, "normal.sort.bam"), pre + ".clip.gz", os.path.join(ex, "cancer.sv"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out).read() == G.read_text("example", "cancer.somatic.temp.sv")
+
+
+def test_cli_somatic_usage():
+    r = subprocess.run([SEEKSV, "somatic", "-l", "95", "a", "b", "c", "d"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error: value of -l must in range [0, 90) " in r.stderr
+    r = subprocess.run([SEEKSV, "somatic", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("3\t1\n") and "Usage: seeksv somatic" in r.stderr
