@@ -553,8 +553,9 @@ static int cmd_somatic(int argc, char **argv)
 {
 	int offset = 30, c, min_len_of_clipped_seq = 10, read_pair_used = 5000000, min_mapQ = 20, device = 0;
 	double min_map_rate = 0.9;
+	string dump_lookups;
 	PhaseTimer pt;
-	while ((c = getopt(argc, argv, "t:q:l:m:n:G:")) >= 0) {
+	while ((c = getopt(argc, argv, "t:q:l:m:n:G:J:")) >= 0) {
 		switch (c) {
 		case 't': min_map_rate = atof(optarg); break;
 		case 'q': min_mapQ = atoi(optarg); break;
@@ -562,6 +563,7 @@ static int cmd_somatic(int argc, char **argv)
 		case 'm': min_len_of_clipped_seq = atoi(optarg); break;
 		case 'n': read_pair_used = atoi(optarg); break;
 		case 'G': device = atoi(optarg); break;
+		case 'J': dump_lookups = optarg; break; // test hook: the host look-ups only (no BAM pass, no GPU), one line per output row
 		}
 	}
 	if (argc != optind + 4) { cerr << argc << '\t' << optind << endl; usage_somatic(); }
@@ -575,6 +577,18 @@ static int cmd_somatic(int argc, char **argv)
 		cerr << warnings;
 	}
 	pt.lap("normal_clusters");
+	if (!dump_lookups.empty()) {
+		vector<SomaticRow> rows;
+		string err = scan_tumor_table(tumor_file, clip3, clip5, offset, min_map_rate, 1, rows);
+		if (!err.empty()) die(err);
+		ofstream jd(dump_lookups.c_str());
+		for (auto &row : rows) {
+			if (row.kind == SomaticRow::HEADER) jd << row.text << '\n';
+			else if (row.kind == SomaticRow::MESSAGE) cerr << row.text << endl;
+			else jd << row.text << '\t' << row.normal_left_reads << '\t' << row.normal_right_reads << '\n';
+		}
+		return 0;
+	}
 	ssv_ctx *ctx = nullptr;
 	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
 	pt.lap("gpu_init");
@@ -626,10 +640,8 @@ static int cmd_somatic(int argc, char **argv)
 		}
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, counts.data(), nullptr, 0, nullptr, nullptr, 0, nullptr, &maxd) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		vector<int32_t> prev(J.size() + 1, 0), ud(J.size() + 1), dd(J.size() + 1);
-		vector<uint64_t> fs(J.size() * 4 + 4);
-		vector<uint32_t> fl(J.size() * 4 + 4);
-		ssvh_plan_fold(plan, counts.data(), prev.data(), nullptr, nullptr, abnormal.data(), ud.data(), dd.data(), fs.data(), fl.data(), nullptr);
+		vector<int32_t> prev(J.size() + 1, 0); // a row whose left contig is not in the normal's header reports 0
+		ssvh_plan_fold(plan, counts.data(), prev.data(), nullptr, nullptr, abnormal.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
 		ssvh_plan_destroy(plan);
 	}
 	pt.lap("discordant_pass");
