@@ -217,6 +217,50 @@ int ssv_getsv_finish(ssv_ctx *ctx, int32_t *counts,
                      const ssv_interval *points, int64_t n_points, int32_t *point_depth,
                      int32_t *max_depth);
 
+/* ---- device-side BGZF inflate + BAM record decode ---------------------------- */
+
+/*
+ * What libbam's samread() does per record on one core (sam/sam.h:73: bgzf inflate + bam_read1) for a whole chunk of the file on
+ * the GPU: the caller hands over the COMPRESSED bytes of a run of whole BGZF blocks plus their table, and gets the decoded records
+ * as an SSV_MEM_DEVICE batch that ssv_clip_scan / ssv_isize_accumulate / ssv_getsv_scan consume directly - the inflated bytes
+ * never cross PCIe.  libseeksv_host's ssvh_bam_read_blocks produces the input.
+ *   one chunk = blocks in file order; a record may straddle chunks (its head is carried over inside the context);
+ *   c_off/c_len = the block's raw deflate payload inside `comp` (after the 18-byte BGZF header, without the 8-byte trailer),
+ *   u_len = its ISIZE.  A chunk must inflate to < 4 GB.
+ */
+typedef struct {
+	uint64_t c_off;
+	uint32_t c_len;
+	uint32_t u_len;
+} ssv_bgzf_block;
+
+typedef struct {
+	int64_t n_records;           /* records of the last chunk */
+	uint64_t inflated_bytes;     /* bytes the chunk inflated to */
+	uint64_t tail_offset;        /* internal: where the unfinished record starts */
+	uint32_t repaired_blocks;    /* blocks whose speculated first record start had to be corrected (diagnostic) */
+	int32_t last_tid;            /* contig of the last record without UNMAP|MUNMAP so far */
+	/* host-side lists of the last chunk (pinned memory owned by the context, valid until the next decode): */
+	const uint8_t *unmapped_raw; /* the UNMAP|MUNMAP records as they lie in the BAM stream (block_size prefixed), in order: */
+	uint64_t unmapped_bytes;     /*   the unmapped-pair FASTQ side channel of getclip (clip_reads.h:415-419) decodes them on the host */
+	uint32_t n_tid_runs;         /* contig changes among the other records, in order (the flush sequence of clip_reads.h:423-438): */
+	const uint32_t *tid_run_index; /* record index inside the batch, */
+	const int32_t *tid_run_tid;    /* its contig */
+} ssv_bamdec_info;
+
+/* Start a file: n_targets of its header (plausibility of speculated record starts), and the offset of the first record inside the
+ * inflated stream of the first chunk (= the length of the BAM header: magic, text, reference list). */
+int ssv_bamdec_begin(ssv_ctx *ctx, int32_t n_targets, uint64_t first_record_offset);
+/* Pinned host buffer (grow-only, owned by the context) to read the compressed bytes of a chunk into; any host memory works too. */
+int ssv_bamdec_staging(ssv_ctx *ctx, size_t bytes, void **host_ptr);
+/* Inflate + decode one chunk.  *out is an SSV_MEM_DEVICE batch owned by the context, valid until the next decode on it (stream
+ * ordered: kernels already enqueued on the context's stream may still read it).  n_blocks == 0 = end of input (fails if a record
+ * is unfinished).  keep_all_seq as in ssvh_bam_read_batch.  Synchronises the stream. */
+int ssv_bamdec_decode(ssv_ctx *ctx, const void *comp, size_t comp_bytes, const ssv_bgzf_block *blocks, int64_t n_blocks, int keep_all_seq, ssv_batch_t *out);
+int ssv_bamdec_last(ssv_ctx *ctx, ssv_bamdec_info *info);
+/* Copy a device batch into host arrays owned by the context (valid until the next call): tests and debugging. */
+int ssv_batch_to_host(ssv_ctx *ctx, const ssv_batch_t *device_batch, ssv_batch_t *host_batch);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 
 /*

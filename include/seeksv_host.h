@@ -44,6 +44,16 @@ int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_
  * it is on, every read_batch call must pass the same max_records / keep_all_seq, and ssvh_bam_next_record is refused. */
 int ssvh_bam_set_readahead(ssvh_bam *b, int on);
 
+/* Raw mode, for the device-side decoder (ssv_bamdec_*, seeksv_hip.h): rewind to the first BGZF block and hand out COMPRESSED blocks.
+ * *first_record_offset = length of the BAM header inside the inflated stream.  Not to be mixed with read_batch / next_record. */
+int ssvh_bam_raw_begin(ssvh_bam *b, uint64_t *first_record_offset);
+/* Read whole BGZF blocks: their deflate payloads back to back into dst (dst_bytes; 8 spare bytes are kept behind the last one), at most
+ * max_blocks of them and about max_inflated bytes of inflated data; blocks[k] describes payload k.  *n_blocks == 0 at end of file. */
+int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes);
+/* Decode the k-th record of a run of raw BAM records (block_size prefixed, as ssv_bamdec_info.unmapped_raw holds them) the way the
+ * unmapped side channel wants it (GetSeqAndQual, clip_reads.cpp:375-388).  Returns the offset of the next record, 0 at the end. */
+size_t ssvh_raw_record_fastq(const uint8_t *raw, size_t raw_bytes, size_t offset, const char **qname, const char **seq, const char **qual, int *is_read1);
+
 /* One record at a time, with its read name and CIGAR (host-side consumers of small BAMs: the clip.bam join of getsv,
  * getsv.h:445-527).  Returns 1 and fills *out (pointers valid until the next call), 0 at end of file, <0 on error. */
 typedef struct {

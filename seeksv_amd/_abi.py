@@ -140,6 +140,17 @@ def batch_to_arrays(b):
     return out
 
 
+class BgzfBlock(C.Structure):
+    """ssv_bgzf_block (include/seeksv_hip.h)"""
+    _fields_ = [("c_off", C.c_uint64), ("c_len", C.c_uint32), ("u_len", C.c_uint32)]
+
+
+class BamdecInfo(C.Structure):
+    """ssv_bamdec_info (include/seeksv_hip.h)"""
+    _fields_ = [("n_records", C.c_int64), ("inflated_bytes", C.c_uint64), ("tail_offset", C.c_uint64), ("repaired_blocks", C.c_uint32), ("last_tid", C.c_int32),
+                ("unmapped_raw", C.c_void_p), ("unmapped_bytes", C.c_uint64), ("n_tid_runs", C.c_uint32), ("tid_run_index", C.c_void_p), ("tid_run_tid", C.c_void_p)]
+
+
 _libs = {}
 
 
@@ -167,6 +178,10 @@ def host_lib():
         lib.ssvh_bam_target_len.restype = C.c_int32
         lib.ssvh_bam_read_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(Batch)]
         lib.ssvh_bam_set_readahead.argtypes = [C.c_void_p, C.c_int]
+        lib.ssvh_bam_raw_begin.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.ssvh_bam_read_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(BgzfBlock), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_size_t)]
+        lib.ssvh_raw_record_fastq.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        lib.ssvh_raw_record_fastq.restype = C.c_size_t
         lib.ssvh_bam_unmapped_count.argtypes = [C.c_void_p]
         lib.ssvh_bam_unmapped_count.restype = C.c_int64
         lib.ssvh_bam_unmapped_get.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
@@ -208,6 +223,11 @@ def hip_lib():
         lib.ssv_getsv_begin.argtypes = [V, C.POINTER(GetsvParams)]
         lib.ssv_getsv_scan.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_getsv_finish.argtypes = [V, V, V, C.c_int64, V, V, C.c_int64, V, C.POINTER(C.c_int32)]
+        lib.ssv_bamdec_begin.argtypes = [V, C.c_int32, C.c_uint64]
+        lib.ssv_bamdec_staging.argtypes = [V, C.c_size_t, C.POINTER(V)]
+        lib.ssv_bamdec_decode.argtypes = [V, V, C.c_size_t, C.POINTER(BgzfBlock), C.c_int64, C.c_int, C.POINTER(Batch)]
+        lib.ssv_bamdec_last.argtypes = [V, C.POINTER(BamdecInfo)]
+        lib.ssv_batch_to_host.argtypes = [V, C.POINTER(Batch), C.POINTER(Batch)]
         lib.ssv_prof_enable.argtypes = [V, C.c_int]
         lib.ssv_prof_reset.argtypes = [V]
         lib.ssv_prof_get.argtypes = [V, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

@@ -1,0 +1,368 @@
+// bamdec_kernels.h - BGZF inflate and BAM record decode on the device.
+//
+// Replaces, for whole-file passes, libbam's samread() (sam/sam.h:73: bgzf inflate + bam_read1) that the reference calls once per
+// record on one core.  Data flow of one chunk (a run of whole BGZF blocks, compressed bytes already in HBM):
+//   k_bgzf_inflate    one LANE per BGZF block (independent deflate streams), Huffman tables in LDS interleaved by lane
+//   k_find_records    one lane per block: speculate the first record start inside the block (three plausible headers in a row), follow
+//                     the block_size chain to the block end: guess, exit offset, record count
+//   k_stitch_blocks   one wavefront: verify every guess against the true chain (exit of the previous block), repair wrong ones by
+//                     following the chain by hand; carries the position across blocks -> exact record starts, whatever the guesses
+//   k_list_records    per block: write the record offsets at their ranks (exclusive scan of the counts)
+//   k_record_fields   per record: fixed fields -> structure-of-arrays columns; CIGAR count, soft-clip test, bytes to ship
+//   k_record_payload  per record: CIGAR ops, packed bases + qualities (soft-clipped records only), XC aux flag
+//   k_raw_copy        UNMAP|MUNMAP records as raw bytes for the host's unmapped-FASTQ side channel (clip_reads.h:415-419)
+//   k_tid_runs        contig changes among the mapped-pair records (the flush sequence of clip_reads.h:423-438) for the host
+// The chain of record starts is a dependent-load chain; the speculation makes all but the (tiny) stitch parallel, and the stitch
+// makes the result independent of the speculation.
+#pragma once
+
+#include "common.h"
+#include "inflate_core.h"
+
+namespace ssv {
+
+constexpr uint32_t BD_NONE = 0xffffffffu;
+
+// Huffman tables of the 64 lanes of a wavefront, element i of lane l at [i * 64 + l]: every lane touches its own bank column
+struct LdsTab {
+	uint16_t *sym; uint32_t *nib; uint16_t *off; int lane;
+	__device__ __forceinline__ uint16_t sym_get(int i) const { return sym[i * 64 + lane]; }
+	__device__ __forceinline__ void sym_set(int i, uint16_t v) { sym[i * 64 + lane] = v; }
+	__device__ __forceinline__ int len_get(int i) const { return (int)((nib[(i >> 3) * 64 + lane] >> ((i & 7) * 4)) & 15u); }
+	__device__ __forceinline__ void len_set(int i, int v)
+	{
+		uint32_t &w = nib[(i >> 3) * 64 + lane];
+		w = (w & ~(15u << ((i & 7) * 4))) | ((uint32_t)v << ((i & 7) * 4));
+	}
+	__device__ __forceinline__ uint16_t off_get(int i) const { return off[i * 64 + lane]; }
+	__device__ __forceinline__ void off_set(int i, uint16_t v) { off[i * 64 + lane] = v; }
+};
+
+constexpr int INFLATE_LDS_BYTES = 320 * 64 * 2 + 40 * 64 * 4 + 16 * 64 * 2; // 53,248 B per wavefront: three wavefronts per CU
+
+struct BgzfBlock { uint64_t c_off; uint32_t c_len, u_len; }; // deflate payload inside the chunk buffer; inflated size
+
+// One lane per BGZF block.  status[b] = 0 or the lane's error code.
+__global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
+                                                       uint8_t *__restrict__ out, int *__restrict__ status)
+{
+	extern __shared__ uint8_t lds_raw[];
+	LdsTab tab;
+	tab.sym = reinterpret_cast<uint16_t *>(lds_raw);
+	tab.nib = reinterpret_cast<uint32_t *>(lds_raw + 320 * 64 * 2);
+	tab.off = reinterpret_cast<uint16_t *>(lds_raw + 320 * 64 * 2 + 40 * 64 * 4);
+	tab.lane = lane_id();
+	const int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+	if (b >= n_blocks) return;
+	const BgzfBlock blk = blocks[b];
+	int rc = INF_OK;
+	if (blk.u_len) rc = inflate_stream(comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tab);
+	status[b] = rc;
+}
+
+// ---- record boundaries ----------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ int32_t ld_i32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint16_t ld_u16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+// could a BAM record start at u[o]?  (o + 36 <= total is the caller's business)
+__device__ __forceinline__ bool plausible_record(const uint8_t *u, uint64_t o, uint64_t total, int32_t n_targets)
+{
+	const uint32_t bs = ld_u32(u + o);
+	if (bs < 32 || bs > (1u << 28)) return false;
+	const uint8_t *r = u + o + 4;
+	const int32_t refid = ld_i32(r), pos = ld_i32(r + 4), l_seq = ld_i32(r + 16), next_ref = ld_i32(r + 20), next_pos = ld_i32(r + 24);
+	const uint32_t l_name = r[8], ncig = ld_u16(r + 12);
+	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name == 0) return false;
+	if (32ull + l_name + 4ull * ncig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > bs) return false;
+	const uint64_t nul = o + 4 + 32 + l_name - 1;
+	return nul >= total || u[nul] == 0;
+}
+
+// follow the chain from o while records START before `end` and lie completely inside [0, total); returns the count, *exit = where it stopped
+__device__ __forceinline__ uint32_t follow_chain(const uint8_t *u, uint64_t o, uint64_t end, uint64_t total, uint64_t *exit, bool *corrupt)
+{
+	uint32_t n = 0;
+	while (o < end) {
+		if (o + 4 > total) break;
+		const uint32_t bs = ld_u32(u + o);
+		if (bs < 32) { *corrupt = true; break; }
+		if (o + 4 + (uint64_t)bs > total) break;
+		++n;
+		o += 4 + (uint64_t)bs;
+	}
+	*exit = o;
+	return n;
+}
+
+struct BlockChain { uint64_t guess, exit; uint32_t count, pad; }; // guess == ~0: no plausible start found in the block
+
+// stream = [carry bytes | inflated blocks]; block b covers [u_off[b], u_off[b] + u_len)
+__global__ __launch_bounds__(BLOCK) void k_find_records(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
+                                                       uint64_t total, int32_t n_targets, BlockChain *__restrict__ chain)
+{
+	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (b >= n_blocks) return;
+	// the first block also stands for what lies before it (the carried-over head of a record, or the BAM header): its chain begins at `start`
+	const uint64_t begin = b == 0 ? start : u_off[b], end = u_off[b] + blocks[b].u_len;
+	BlockChain c;
+	c.guess = ~0ull; c.exit = begin; c.count = 0; c.pad = 0;
+	uint64_t o = begin;
+	for (; o < end && o + 36 <= total; ++o) {
+		uint64_t q = o;
+		int k = 0;
+		for (; k < 3 && q + 36 <= total; ++k) {
+			if (!plausible_record(u, q, total, n_targets)) break;
+			q += 4 + (uint64_t)ld_u32(u + q);
+		}
+		if (k == 3 || (k > 0 && q + 36 > total)) { c.guess = o; break; }
+	}
+	if (c.guess != ~0ull) {
+		bool corrupt = false;
+		c.count = follow_chain(u, c.guess, end, total, &c.exit, &corrupt);
+	}
+	chain[b] = c;
+}
+
+struct StitchOut { uint64_t tail; uint32_t n_records, n_repaired, corrupt, pad; };
+
+// One wavefront walks the blocks in order (64 at a time, lane-serial inside the wavefront): `cur` is the true position of the next record
+// start.  A block whose guess equals cur keeps its speculated count/exit; a block that cur has already passed holds no record start;
+// anything else is repaired by following the chain by hand from cur.  first[b] = first record start in block b (or ~0), count[b] fixed up.
+__global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
+                                                        uint64_t total, BlockChain *__restrict__ chain, uint32_t *__restrict__ count, StitchOut *__restrict__ out)
+{
+	uint64_t cur = start; // wave-uniform
+	uint32_t n_rec = 0, n_rep = 0, bad = 0;
+	for (int64_t base = 0; base < n_blocks; base += WAVE) {
+		const int64_t b = base + lane_id();
+		BlockChain c;
+		uint64_t begin = 0, end = 0;
+		c.guess = ~0ull; c.exit = 0; c.count = 0;
+		if (b < n_blocks) { c = chain[b]; begin = u_off[b]; end = begin + blocks[b].u_len; }
+		uint64_t my_first = ~0ull;
+		uint32_t my_count = 0;
+		const int m = (int)(n_blocks - base < WAVE ? n_blocks - base : WAVE);
+		for (int l = 0; l < m; ++l) {
+			const uint64_t g = __shfl(c.guess, l, 64), e = __shfl(c.exit, l, 64), bend = __shfl(end, l, 64);
+			const uint32_t cn = __shfl(c.count, l, 64);
+			uint64_t first = ~0ull, nxt = cur;
+			uint32_t cnt = 0;
+			if (cur < bend) {
+				if (g == cur) { first = cur; cnt = cn; nxt = e; }
+				else {
+					// wave-uniform branch: every lane follows the same chain (same addresses: one load per step)
+					bool corrupt = false;
+					first = cur;
+					cnt = follow_chain(u, cur, bend, total, &nxt, &corrupt);
+					if (cnt == 0) first = ~0ull;
+					if (corrupt) bad = 1;
+					++n_rep;
+				}
+			}
+			if (lane_id() == l) { my_first = first; my_count = cnt; }
+			n_rec += cnt;
+			cur = nxt;
+		}
+		if (b < n_blocks) { chain[b].guess = my_first; count[b] = my_count; }
+	}
+	if (lane_id() == 0) { out->tail = cur; out->n_records = n_rec; out->n_repaired = n_rep; out->corrupt = bad; out->pad = 0; }
+}
+
+// rec_off[rank] for every record: block b's records start at rank base[b]
+__global__ __launch_bounds__(BLOCK) void k_list_records(const uint8_t *__restrict__ u, const BlockChain *__restrict__ chain, const uint32_t *__restrict__ count, const uint32_t *__restrict__ base,
+                                                       int64_t n_blocks, uint32_t *__restrict__ rec_off)
+{
+	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (b >= n_blocks) return;
+	uint64_t o = chain[b].guess;
+	const uint32_t n = count[b], r0 = base[b];
+	for (uint32_t i = 0; i < n; ++i) {
+		rec_off[r0 + i] = (uint32_t)o;
+		o += 4 + (uint64_t)ld_u32(u + o);
+	}
+}
+
+// ---- records -> structure of arrays ----------------------------------------------------------------------------------------------
+
+struct RecColumns {
+	int32_t *tid, *pos, *l_qseq, *mtid, *mpos, *isize;
+	uint16_t *flag, *n_cigar;
+	uint8_t *mapq, *xc;
+	uint32_t *seq_bytes;  // bytes of packed bases + qualities to ship (0 when not shipped)
+	uint32_t *raw_bytes;  // 4 + block_size for UNMAP|MUNMAP records (else 0)
+	int32_t *max_span;    // one int: largest reference span (atomicMax)
+	uint32_t *bad;        // one flag: a record whose fields overrun its block_size
+};
+
+__global__ __launch_bounds__(BLOCK) void k_record_fields(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t n, int keep_all_seq, RecColumns c)
+{
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	int span = 1;
+	if (i < n) {
+		const uint8_t *r = u + rec_off[i] + 4;
+		const uint32_t bs = ld_u32(r - 4);
+		const int32_t l_seq = ld_i32(r + 16);
+		const uint32_t l_name = r[8], ncig = ld_u16(r + 12), flag = ld_u16(r + 14);
+		c.tid[i] = ld_i32(r); c.pos[i] = ld_i32(r + 4); c.mapq[i] = r[9]; c.n_cigar[i] = (uint16_t)ncig; c.flag[i] = (uint16_t)flag; c.l_qseq[i] = l_seq;
+		c.mtid[i] = ld_i32(r + 20); c.mpos[i] = ld_i32(r + 24); c.isize[i] = ld_i32(r + 28);
+		const uint64_t o_cig = 32ull + l_name, need = o_cig + 4ull * ncig + ((uint64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (uint64_t)(l_seq < 0 ? 0 : l_seq);
+		bool soft = false;
+		if (l_seq < 0 || need > bs) { *c.bad = 1; c.seq_bytes[i] = 0; c.raw_bytes[i] = 0; c.n_cigar[i] = 0; }
+		else {
+			int s = 0;
+			for (uint32_t k = 0; k < ncig; ++k) {
+				const uint32_t op = ld_u32(r + o_cig + 4ull * k);
+				const uint32_t t = op & 15u;
+				if (t == 0 || t == 2 || t == 3 || t == 7 || t == 8) s += (int)(op >> 4);
+				if ((k == 0 || k == ncig - 1) && t == 4) soft = true;
+			}
+			if (s > span) span = s;
+			c.seq_bytes[i] = (soft || keep_all_seq) ? (uint32_t)(((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq) : 0u;
+			c.raw_bytes[i] = (flag & (F_UNMAP | F_MUNMAP)) ? 4u + bs : 0u;
+		}
+		c.xc[i] = soft ? 2 : 0; // 2 = "soft clipped, aux not looked at yet": k_record_payload turns it into the XC flag
+	}
+	span = wave_max(span);
+	if (lane_id() == 0 && span > 1) atomicMax(c.max_span, span);
+}
+
+// bam_aux_get(b, "XC") + bam_aux2i (clip_reads.cpp:126-127): integer value of the XC tag != 0
+__device__ __forceinline__ int aux_xc_flag(const uint8_t *p, const uint8_t *end)
+{
+	while (p + 3 <= end) {
+		const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+		p += 3;
+		const bool hit = t0 == 'X' && t1 == 'C';
+		int64_t v = 0;
+		uint32_t sz;
+		switch (ty) {
+		case 'A': case 'c': sz = 1; if (hit && ty == 'c') v = (int8_t)p[0]; break;
+		case 'C': sz = 1; if (hit) v = p[0]; break;
+		case 's': sz = 2; if (hit) v = (int16_t)ld_u16(p); break;
+		case 'S': sz = 2; if (hit) v = ld_u16(p); break;
+		case 'i': sz = 4; if (hit) v = ld_i32(p); break;
+		case 'I': sz = 4; if (hit) v = ld_u32(p); break;
+		case 'f': sz = 4; break;
+		case 'd': sz = 8; break;
+		case 'Z': case 'H': { const uint8_t *q = p; while (q < end && *q) ++q; sz = (uint32_t)(q - p) + 1; break; }
+		case 'B': {
+			if (p + 5 > end) return 0;
+			const uint8_t st = p[0];
+			const uint32_t cnt = ld_u32(p + 1);
+			const uint32_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+			sz = 5 + cnt * es;
+			break;
+		}
+		default: return 0; // unknown type: libbam stops here too
+		}
+		if (p + sz > end) return 0;
+		if (hit) return v != 0;
+		p += sz;
+	}
+	return 0;
+}
+
+// 16 lanes per record: CIGAR ops and (for the records that ship them) packed bases + qualities, byte for byte as they lie in the record
+__global__ __launch_bounds__(BLOCK) void k_record_payload(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t n, const uint16_t *__restrict__ n_cigar,
+                                                         const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ seq_bytes, uint64_t *__restrict__ seq_off,
+                                                         uint32_t *__restrict__ cigar, uint8_t *__restrict__ seqqual, uint8_t *__restrict__ xc)
+{
+	const int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
+	const int sub = (int)(threadIdx.x & 15);
+	if (i >= n) return;
+	const uint8_t *r = u + rec_off[i] + 4;
+	const uint32_t bs = ld_u32(r - 4), l_name = r[8], ncig = n_cigar[i];
+	const uint64_t o_cig = 32ull + l_name, o_seq = o_cig + 4ull * ncig;
+	const uint32_t co = cigar_off[i];
+	for (uint32_t k = (uint32_t)sub; k < ncig; k += 16) cigar[co + k] = ld_u32(r + o_cig + 4ull * k);
+	const uint32_t sb = seq_bytes[i];
+	const uint64_t so = seq_off[i]; // exclusive scan of seq_bytes
+	if (sb) for (uint32_t k = (uint32_t)sub; k < sb; k += 16) seqqual[so + k] = r[o_seq + k];
+	if (sub == 0) {
+		if (!sb) seq_off[i] = ~0ull; // SSV_NO_SEQ
+		if (xc[i] == 2) {
+			const int32_t l_seq = ld_i32(r + 16);
+			xc[i] = (uint8_t)aux_xc_flag(r + o_seq + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq, r + bs);
+		}
+	}
+}
+
+// raw bytes of the UNMAP|MUNMAP records, in file order (16 lanes per record)
+__global__ __launch_bounds__(BLOCK) void k_raw_copy(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t n, const uint32_t *__restrict__ raw_bytes,
+                                                   const uint64_t *__restrict__ raw_off, uint8_t *__restrict__ raw)
+{
+	const int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
+	const int sub = (int)(threadIdx.x & 15);
+	if (i >= n) return;
+	const uint32_t nb = raw_bytes[i];
+	if (!nb) return;
+	const uint8_t *r = u + rec_off[i];
+	const uint64_t o = raw_off[i];
+	for (uint32_t k = (uint32_t)sub; k < nb; k += 16) raw[o + k] = r[k];
+}
+
+// The flush sequence of getclip's record loop (clip_reads.h:423-438) needs, in order, every change of contig among the records that
+// are not UNMAP|MUNMAP ("qualifying").  Three small kernels: the last qualifying tid of every 256-record tile; one wavefront carries it
+// across tiles; then every qualifying record compares its tid with the qualifying record before it (ballot + shuffle inside the
+// wavefront, LDS across the workgroup's wavefronts, the carried value across tiles) and reports (index, tid) when it differs.
+struct TidRun { uint32_t index; int32_t tid; };
+constexpr int32_t TID_NONE = INT32_MIN;
+
+__global__ __launch_bounds__(BLOCK) void k_tid_tile_last(const int32_t *__restrict__ tid, const uint16_t *__restrict__ flag, int64_t n, int32_t *__restrict__ tile_last)
+{
+	__shared__ int lds[WAVES_PER_BLOCK];
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const bool q = i < n && !(flag[i] & (F_UNMAP | F_MUNMAP));
+	int idx = wave_max(q ? (int)threadIdx.x : -1);
+	if (lane_id() == 0) lds[wave_id()] = idx;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int m = -1;
+		for (int w = 0; w < WAVES_PER_BLOCK; ++w) m = lds[w] > m ? lds[w] : m;
+		tile_last[blockIdx.x] = m >= 0 ? tid[(int64_t)blockIdx.x * BLOCK + m] : TID_NONE;
+	}
+}
+
+__global__ __launch_bounds__(WAVE) void k_tid_tile_carry(const int32_t *__restrict__ tile_last, int64_t n_tiles, int32_t prev_tid, int32_t *__restrict__ tile_prev, int32_t *__restrict__ last_tid)
+{
+	int32_t cur = prev_tid; // wave-uniform
+	for (int64_t base = 0; base < n_tiles; base += WAVE) {
+		const int64_t t = base + lane_id();
+		const int32_t mine = t < n_tiles ? tile_last[t] : TID_NONE;
+		// exclusive "last value that is not NONE" over the 64 lanes
+		const uint64_t have = __ballot(mine != TID_NONE);
+		const uint64_t below = have & lanemask_lt();
+		const int src = below ? 63 - __clzll((long long)below) : 0;
+		const int32_t got = __shfl(mine, src, 64);
+		if (t < n_tiles) tile_prev[t] = below ? got : cur;
+		if (have) cur = __shfl(mine, 63 - __clzll((long long)have), 64);
+	}
+	if (lane_id() == 0) *last_tid = cur;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_tid_runs(const int32_t *__restrict__ tid, const uint16_t *__restrict__ flag, int64_t n, const int32_t *__restrict__ tile_prev,
+                                                   TidRun *__restrict__ runs, uint32_t cap, uint32_t *__restrict__ n_runs)
+{
+	__shared__ int32_t wave_last[WAVES_PER_BLOCK];
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const bool q = i < n && !(flag[i] & (F_UNMAP | F_MUNMAP));
+	const int32_t mine = q ? tid[i] : TID_NONE;
+	const uint64_t have = __ballot(q);
+	const int32_t top = __shfl(mine, have ? 63 - __clzll((long long)have) : 0, 64); // all lanes take part in the shuffle
+	if (lane_id() == 0) wave_last[wave_id()] = have ? top : TID_NONE;
+	const uint64_t below = have & lanemask_lt();
+	int32_t before = __shfl(mine, below ? 63 - __clzll((long long)below) : 0, 64);
+	__syncthreads();
+	if (!below) {
+		before = tile_prev[blockIdx.x];
+		for (int w = 0; w < wave_id(); ++w) if (wave_last[w] != TID_NONE) before = wave_last[w];
+	}
+	if (q && mine != before) {
+		const uint32_t k = atomicAdd(n_runs, 1u);
+		if (k < cap) { runs[k].index = (uint32_t)i; runs[k].tid = mine; }
+	}
+}
+
+} // namespace ssv

@@ -1,0 +1,204 @@
+// inflate_core.h - a DEFLATE (RFC 1951) decoder written for one GPU lane per BGZF block.
+//
+// the reference spends 78 % of getclip inside libbam's samread() = zlib inflate + record parse on one core.  BGZF
+// blocks (<= 64 KB each) are independent deflate streams, so a BAM file offers millions of them; here every lane of a wavefront
+// decodes its own block.  What shapes the code:
+//   * no per-lane arrays in registers or scratch: the Huffman decode is canonical (count-per-length walk, as in Mark Adler's `puff`
+//     description of the algorithm) with the 15 per-length counts packed into 8 registers and only the symbol permutation in a
+//     table; tables live behind an accessor `Tab` (LDS interleaved by lane on the GPU, plain arrays in the CPU test build);
+//   * length/distance bases are computed from the symbol, not looked up (a divergent constant-table index is a waterfall loop);
+//   * the bit buffer is refilled 32 bits at a time with one unaligned load.
+// The same source is compiled by g++ for tests/test_inflate_core.py (against zlib) - which is why nothing here is HIP specific.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#ifndef SSV_HD
+#ifdef __HIPCC__
+#define SSV_HD __host__ __device__ __forceinline__
+#else
+#define SSV_HD inline
+#endif
+#endif
+
+namespace ssv {
+
+enum : int { INF_OK = 0, INF_E_BTYPE = -1, INF_E_STORED = -2, INF_E_CODE = -3, INF_E_OVERSUB = -4, INF_E_DIST = -5, INF_E_OUTPUT = -6, INF_E_INPUT = -7, INF_E_REPEAT = -8 };
+
+// Table storage for one stream.  SYM: 320 u16 (literal/length permutation at [0,288), distance at [288,320); the code-length code
+// borrows [300,319) while the header is read).  NIB: 320 code lengths as nibbles.  OFF: 16 running offsets.
+struct PlainTab {
+	uint16_t sym[320]; uint8_t len[320]; uint16_t off[16];
+	SSV_HD uint16_t sym_get(int i) const { return sym[i]; }
+	SSV_HD void sym_set(int i, uint16_t v) { sym[i] = v; }
+	SSV_HD int len_get(int i) const { return len[i]; }
+	SSV_HD void len_set(int i, int v) { len[i] = (uint8_t)v; }
+	SSV_HD uint16_t off_get(int i) const { return off[i]; }
+	SSV_HD void off_set(int i, uint16_t v) { off[i] = v; }
+};
+
+struct BitReader {
+	const uint8_t *p;   // next unread byte
+	uint64_t bb = 0;    // bit buffer, LSB first
+	int bc = 0;         // valid bits in bb
+	SSV_HD explicit BitReader(const uint8_t *in) : p(in) {}
+	SSV_HD void refill() // afterwards bc >= 32 (reads up to 4 bytes past the data: buffers are padded)
+	{
+		if (bc < 32) {
+			uint32_t w;
+			memcpy(&w, p, 4);
+			bb |= (uint64_t)w << bc;
+			bc += 32; p += 4;
+		}
+	}
+	SSV_HD uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+	SSV_HD void drop(int n) { bb >>= n; bc -= n; }
+	SSV_HD uint32_t take(int n) { uint32_t v = peek(n); drop(n); return v; }
+};
+
+struct HuffCounts { uint32_t c[8]; }; // count of codes of length L in bits [16*(L&1), +16) of c[L>>1]
+
+// canonical decode: walk the lengths, one bit per step; the first length at which the code falls below first+count wins
+template <class Tab>
+SSV_HD int huff_decode(BitReader &br, const HuffCounts &h, const Tab &tab, int sym_base)
+{
+	int code = 0, first = 0, index = 0;
+	uint32_t bits = (uint32_t)br.bb; // caller guarantees >= 15 valid bits
+#pragma unroll
+	for (int len = 1; len <= 15; ++len) {
+		code |= (int)(bits & 1u); bits >>= 1;
+		const int count = (int)((h.c[len >> 1] >> ((len & 1) * 16)) & 0xffffu);
+		if (code - count < first) { br.drop(len); return tab.sym_get(sym_base + index + (code - first)); }
+		index += count; first += count; first <<= 1; code <<= 1;
+	}
+	return -1;
+}
+
+// build the decoding tables of one code from the lengths at Tab::len[len_base, len_base + n): counts -> h, permutation -> Tab::sym[sym_base...)
+template <class Tab>
+SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCounts &h)
+{
+	for (int l = 0; l < 16; ++l) tab.off_set(l, 0);
+	for (int s = 0; s < n; ++s) { const int l = tab.len_get(len_base + s); tab.off_set(l, (uint16_t)(tab.off_get(l) + 1)); }
+	int left = 1, run = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) h.c[k] = 0;
+#pragma unroll
+	for (int l = 1; l <= 15; ++l) {
+		const int count = tab.off_get(l);
+		h.c[l >> 1] |= (uint32_t)count << ((l & 1) * 16);
+		left <<= 1; left -= count;
+		if (left < 0) return INF_E_OVERSUB;
+		tab.off_set(l, (uint16_t)run); // offset of the first symbol of this length in the permutation
+		run += count;
+	}
+	for (int s = 0; s < n; ++s) {
+		const int l = tab.len_get(len_base + s);
+		if (l) { const int o = tab.off_get(l); tab.sym_set(sym_base + o, (uint16_t)s); tab.off_set(l, (uint16_t)(o + 1)); }
+	}
+	return INF_OK;
+}
+
+// Inflate one raw deflate stream of in_len bytes into exactly out_len bytes.  Returns INF_OK or an error (the lane's block is then bad).
+template <class Tab>
+SSV_HD int inflate_stream(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tab &tab)
+{
+	BitReader br(in);
+	uint32_t o = 0;
+	int last;
+	do {
+		br.refill();
+		last = (int)br.take(1);
+		const int type = (int)br.take(2);
+		if (type == 0) {
+			// stored: to the byte boundary, LEN, ~LEN, bytes
+			br.drop(br.bc & 7);
+			br.refill();
+			const uint32_t len = br.take(16);
+			br.refill();
+			const uint32_t nlen = br.take(16);
+			if ((len ^ 0xffffu) != nlen) return INF_E_STORED;
+			if (o + len > out_len) return INF_E_OUTPUT;
+			for (uint32_t i = 0; i < len; ++i) { br.refill(); out[o++] = (uint8_t)br.take(8); }
+			continue;
+		}
+		if (type == 3) return INF_E_BTYPE;
+		HuffCounts lit, dist;
+		if (type == 1) {
+			for (int s = 0; s < 288; ++s) tab.len_set(s, s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+			for (int s = 0; s < 30; ++s) tab.len_set(288 + s, 5);
+			huff_construct(tab, 0, 288, 0, lit);
+			huff_construct(tab, 288, 30, 288, dist);
+		} else {
+			const int nlen = (int)br.take(5) + 257, ndist = (int)br.take(5) + 1, ncode = (int)br.take(4) + 4;
+			if (nlen > 286 || ndist > 30) return INF_E_CODE;
+			for (int s = 0; s < 19; ++s) tab.len_set(s, 0);
+			for (int k = 0; k < ncode; ++k) {
+				br.refill();
+				// order of the code-length code lengths: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+				const int s = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
+				tab.len_set(s, (int)br.take(3));
+			}
+			HuffCounts cl;
+			int rc = huff_construct(tab, 0, 19, 300, cl);
+			if (rc != INF_OK) return rc;
+			int idx = 0, prev = 0;
+			while (idx < nlen + ndist) {
+				br.refill();
+				int s = huff_decode(br, cl, tab, 300);
+				if (s < 0) return INF_E_CODE;
+				if (s < 16) { tab.len_set(idx++, s); prev = s; continue; }
+				int rep, val = 0;
+				if (s == 16) { if (idx == 0) return INF_E_REPEAT; val = prev; rep = 3 + (int)br.take(2); }
+				else if (s == 17) rep = 3 + (int)br.take(3);
+				else rep = 11 + (int)br.take(7);
+				if (idx + rep > nlen + ndist) return INF_E_REPEAT;
+				while (rep--) tab.len_set(idx++, val);
+				prev = val;
+			}
+			if (tab.len_get(256) == 0) return INF_E_CODE; // no end-of-block code
+			// the distance lengths sit right behind the literal/length lengths: build the distance code first (its lengths are read in
+			// place), then the literal/length code
+			rc = huff_construct(tab, nlen, ndist, 288, dist);
+			if (rc != INF_OK) return rc;
+			rc = huff_construct(tab, 0, nlen, 0, lit);
+			if (rc != INF_OK) return rc;
+		}
+		for (;;) {
+			br.refill();
+			int s = huff_decode(br, lit, tab, 0);
+			if (s < 0) return INF_E_CODE;
+			if (s < 256) {
+				if (o >= out_len) return INF_E_OUTPUT;
+				out[o++] = (uint8_t)s;
+				continue;
+			}
+			if (s == 256) break;
+			if (s > 285) return INF_E_CODE;
+			// length: 257..264 -> 3..10; then groups of four symbols share an extra-bit count; 285 -> 258
+			uint32_t len;
+			if (s < 265) len = (uint32_t)s - 254u;
+			else if (s == 285) len = 258;
+			else { const int e = (s - 261) >> 2; len = ((4u + (uint32_t)((s - 265) & 3)) << e) + 3u + br.take(e); }
+			br.refill();
+			const int d = huff_decode(br, dist, tab, 288);
+			if (d < 0 || d > 29) return INF_E_CODE;
+			uint32_t dst;
+			if (d < 4) dst = (uint32_t)d + 1u;
+			else { const int e = (d >> 1) - 1; dst = ((2u + (uint32_t)(d & 1)) << e) + 1u + br.take(e); }
+			if (dst > o) return INF_E_DIST;
+			if (o + len > out_len) return INF_E_OUTPUT;
+			const uint8_t *from = out + o - dst;
+			uint8_t *to = out + o;
+			for (uint32_t i = 0; i < len; ++i) to[i] = from[i]; // may overlap forward: byte order matters
+			o += len;
+		}
+	} while (!last);
+	if (o != out_len) return INF_E_OUTPUT;
+	// bytes taken from the input: everything up to p except the whole bytes still in the buffer
+	if ((uint32_t)(br.p - in) - (uint32_t)(br.bc >> 3) > in_len) return INF_E_INPUT;
+	return INF_OK;
+}
+
+} // namespace ssv

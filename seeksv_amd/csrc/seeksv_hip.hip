@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "bamdec_kernels.h"
 #include "clip_kernels.h"
 #include "common.h"
 #include "getsv_kernels.h"
@@ -25,9 +26,9 @@ namespace {
 std::string g_create_error;
 
 // timed kernel groups (ssv_prof_*)
-enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_COUNT };
-const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "table_d2h", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish"};
-const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\ntable_d2h\nisize_stats\ngetsv_scan\ngetsv_cand\ndepth_finish";
+enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_BAM_INFLATE, P_BAM_RECORDS, P_BAM_DECODE, P_COUNT };
+const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "table_d2h", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish", "bam_inflate", "bam_records", "bam_decode"};
+const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\ntable_d2h\nisize_stats\ngetsv_scan\ngetsv_cand\ndepth_finish\nbam_inflate\nbam_records\nbam_decode";
 
 struct DBuf { // grow-only device buffer
 	void *p = nullptr;
@@ -107,6 +108,10 @@ struct ssv_ctx {
 	DBuf gs_djunc, gs_counts, gs_wtid, gs_wbeg, gs_wend, gs_woff, gs_diff, gs_tilemap, gs_ctgoff, gs_maxdepth, gs_span;
 	DBuf q_tid, q_beg, q_end, q_out64, q_out32;
 	HBuf h_q;
+
+	// ---- device BGZF/BAM decoder (bamdec_api.inc) ----
+	struct ssv_bamdec_state *bd = nullptr;
+	HBuf h_batch;
 
 	// ---- profiling ----
 	int prof_mode = 0;
@@ -325,11 +330,15 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 	return SSV_OK;
 }
 
+static void bamdec_free(ssv_ctx *c); // bamdec_api.inc
+
 void ssv_ctx_destroy(ssv_ctx *c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->st);
+	bamdec_free(c);
+	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
@@ -934,5 +943,7 @@ int ssv_prof_get(ssv_ctx *c, const char *name, double *total_ms, int64_t *launch
 }
 
 const char *ssv_prof_names(void) { return kProfNameList; }
+
+#include "bamdec_api.inc"
 
 } // extern "C"

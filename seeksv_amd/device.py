@@ -56,6 +56,48 @@ class Context:
             return b, None
         return _abi.make_batch(b)
 
+    # ---- device-side BGZF inflate + BAM decode ----
+    def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False):
+        """Generator over SSV_MEM_DEVICE batches of a whole BAM file (host.BamReader), decoded on the GPU: yields (Batch, info dict).
+        The batch is valid until the next iteration."""
+        hl = reader._lib
+        first = C.c_uint64()
+        if hl.ssvh_bam_raw_begin(reader.handle, C.byref(first)) != 0:
+            raise IOError(hl.ssvh_last_error().decode())
+        self._check(self._lib.ssv_bamdec_begin(self._h, len(reader.target_names), first.value), "ssv_bamdec_begin")
+        stage = C.c_void_p()
+        self._check(self._lib.ssv_bamdec_staging(self._h, chunk_bytes, C.byref(stage)), "ssv_bamdec_staging")
+        blocks = (_abi.BgzfBlock * max_blocks)()
+        while True:
+            nb, nbytes = C.c_int64(), C.c_size_t()
+            if hl.ssvh_bam_read_blocks(reader.handle, stage, chunk_bytes, 1 << 31, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
+                raise IOError(hl.ssvh_last_error().decode())
+            b = _abi.Batch()
+            self._check(self._lib.ssv_bamdec_decode(self._h, stage, nbytes.value, blocks, nb.value, int(keep_all_seq), C.byref(b)), "ssv_bamdec_decode")
+            if nb.value == 0:
+                return
+            info = _abi.BamdecInfo()
+            self._check(self._lib.ssv_bamdec_last(self._h, C.byref(info)), "ssv_bamdec_last")
+            d = dict(n_records=info.n_records, inflated_bytes=info.inflated_bytes, repaired_blocks=info.repaired_blocks, last_tid=info.last_tid, n_blocks=nb.value, compressed_bytes=nbytes.value)
+            k = info.n_tid_runs
+            d["tid_runs"] = list(zip(np.ctypeslib.as_array((C.c_uint32 * k).from_address(info.tid_run_index)).tolist(), np.ctypeslib.as_array((C.c_int32 * k).from_address(info.tid_run_tid)).tolist())) if k else []
+            unm, off = [], 0
+            q, sq, ql, r1 = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_int()
+            while info.unmapped_bytes:
+                nxt = hl.ssvh_raw_record_fastq(info.unmapped_raw, info.unmapped_bytes, off, C.byref(q), C.byref(sq), C.byref(ql), C.byref(r1))
+                if nxt == 0:
+                    break
+                unm.append((q.value.decode(), sq.value.decode(), ql.value.decode(), bool(r1.value)))
+                off = nxt
+            d["unmapped"] = unm
+            yield b, d
+
+    def batch_to_host(self, dev_batch):
+        """Device batch -> dict of owned numpy arrays (tests)."""
+        h = _abi.Batch()
+        self._check(self._lib.ssv_batch_to_host(self._h, C.byref(dev_batch), C.byref(h)), "ssv_batch_to_host")
+        return _abi.batch_to_arrays(h)
+
     # ---- getclip ----
     def clip_begin(self, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
         p = _abi.ClipParams.make(match_rate, min_mapq, save_low_quality, own, initial_last_tid)

@@ -161,6 +161,36 @@ struct Bgzf {
 		return true;
 	}
 
+	// the next block's raw deflate payload straight into dst (no inflate): 1 = ok, 0 = end of file, 2 = does not fit in `room`
+	// (file position unchanged), -1 = error (g_err set)
+	int read_block_raw(uint8_t *dst, size_t room, uint32_t *payload, uint32_t *isize)
+	{
+		uint8_t hdr[18];
+		const long at = ftell(fp);
+		size_t got = fread(hdr, 1, 18, fp);
+		if (got == 0) { eof = true; return 0; }
+		if (got < 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { g_err = "not a BGZF block"; eof = true; return -1; }
+		const unsigned xlen = hdr[10] | (hdr[11] << 8);
+		std::vector<uint8_t> extra(xlen);
+		memcpy(extra.data(), hdr + 12, xlen < 6 ? xlen : 6);
+		if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp) != xlen - 6) { g_err = "truncated BGZF header"; eof = true; return -1; }
+		int bsize = -1;
+		for (size_t off = 0; off + 4 <= xlen;) {
+			unsigned slen = extra[off + 2] | (extra[off + 3] << 8);
+			if (extra[off] == 'B' && extra[off + 1] == 'C' && slen == 2) bsize = extra[off + 4] | (extra[off + 5] << 8);
+			off += 4 + slen;
+		}
+		if (bsize < 0) { g_err = "BGZF block without BC field"; eof = true; return -1; }
+		const size_t clen = (size_t)bsize + 1 - 12 - xlen;
+		if (clen < 8) { g_err = "bad BGZF block size"; eof = true; return -1; }
+		if (clen - 8 + 8 > room) { fseek(fp, at, SEEK_SET); return 2; } // 8 spare bytes: the device bit reader looks 4 bytes ahead
+		uint8_t tail[8];
+		if (fread(dst, 1, clen - 8, fp) != clen - 8 || fread(tail, 1, 8, fp) != 8) { g_err = "truncated BGZF block"; eof = true; return -1; }
+		*payload = (uint32_t)(clen - 8);
+		memcpy(isize, tail + 4, 4);
+		return 1;
+	}
+
 	// read up to CHUNK_BLOCKS compressed blocks and inflate them in parallel into ubuf
 	bool refill()
 	{
@@ -322,7 +352,8 @@ static void find_records(const uint8_t *u, size_t begin, size_t end, int32_t n_t
 struct ssvh_bam {
 	Bgzf z;
 	std::vector<std::string> names;
-	std::vector<int32_t> lens;
+	std::vector<int32_t> lens, name_field_len;
+	uint64_t header_len = 0; // bytes of the inflated stream before the first record
 	// batch storage: two sets, so that with read-ahead the next batch is decoded while the caller still uses the current one
 	struct BatchBuf {
 		std::vector<int32_t> tid, pos, l_qseq, mtid, mpos, isize;
@@ -400,11 +431,48 @@ int ssvh_bam_open(const char *path, ssvh_bam **out)
 		if (b->z.read(&l_name, 4) != 4 || l_name <= 0) { g_err = "bad BAM header"; fclose(b->z.fp); delete b; return -1; }
 		std::string nm((size_t)l_name, '\0');
 		if (b->z.read(&nm[0], (size_t)l_name) != (size_t)l_name || b->z.read(&l_ref, 4) != 4) { g_err = "bad BAM header"; fclose(b->z.fp); delete b; return -1; }
+		b->name_field_len.push_back(l_name);
 		nm.resize(strlen(nm.c_str()));
 		b->names.push_back(nm);
 		b->lens.push_back(l_ref);
 	}
+	b->header_len = 12 + (uint64_t)l_text;
+	for (int32_t i = 0; i < n_ref; ++i) b->header_len += 8 + (uint64_t)b->name_field_len[(size_t)i];
 	*out = b;
+	return 0;
+}
+
+int ssvh_bam_raw_begin(ssvh_bam *b, uint64_t *first_record_offset)
+{
+	g_err.clear();
+	if (!b->z.fp) { g_err = "no file behind this handle"; return -1; }
+	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight"; return -1; }
+	if (fseek(b->z.fp, 0, SEEK_SET) != 0) { g_err = "cannot seek"; return -1; }
+	b->z.eof = false; b->z.upos = b->z.ulen = 0; b->found.clear(); b->found_pos = 0;
+	*first_record_offset = b->header_len;
+	return 0;
+}
+
+int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes)
+{
+	g_err.clear();
+	size_t used = 0;
+	uint64_t inflated = 0;
+	int64_t n = 0;
+	while (n < max_blocks && !b->z.eof) {
+		uint32_t payload = 0, isize = 0;
+		const long at = ftell(b->z.fp);
+		int rc = b->z.read_block_raw((uint8_t *)dst + used, dst_bytes - used, &payload, &isize);
+		if (rc < 0) return -1;
+		if (rc == 0 || rc == 2) break;
+		if (n > 0 && inflated + isize > max_inflated) { fseek(b->z.fp, at, SEEK_SET); break; }
+		if (isize == 0) continue; // empty blocks (the EOF marker) carry nothing
+		blocks[n].c_off = used; blocks[n].c_len = payload; blocks[n].u_len = isize;
+		used += payload; inflated += isize;
+		++n;
+	}
+	if (n == 0 && !b->z.eof && used == 0 && dst_bytes < 65536 + 8) { g_err = "buffer smaller than one BGZF block"; return -1; }
+	*n_blocks = n; *n_bytes = used;
 	return 0;
 }
 
@@ -787,6 +855,26 @@ int ssvh_gz_append_v(const char *path, const char *const *texts, const size_t *l
 }
 
 int ssvh_gz_append(const char *path, const char *text, size_t n, int append) { return ssvh_gz_append_v(path, &text, &n, 1, append); }
+
+size_t ssvh_raw_record_fastq(const uint8_t *raw, size_t raw_bytes, size_t offset, const char **qname, const char **seq, const char **qual, int *is_read1)
+{
+	static thread_local Unmapped u;
+	if (offset + 36 > raw_bytes) return 0;
+	uint32_t bs; memcpy(&bs, raw + offset, 4);
+	if (bs < 32 || offset + 4 + (size_t)bs > raw_bytes) return 0;
+	const uint8_t *r = raw + offset + 4;
+	uint16_t ncig, flag; int32_t l_seq;
+	memcpy(&ncig, r + 12, 2); memcpy(&flag, r + 14, 2); memcpy(&l_seq, r + 16, 4);
+	const size_t o_seq = 32 + (size_t)r[8] + 4 * (size_t)ncig, o_qual = o_seq + ((size_t)l_seq + 1) / 2;
+	if (l_seq < 0 || o_qual + (size_t)l_seq > bs) return 0;
+	u.qname.assign((const char *)r + 32);
+	u.seq.resize((size_t)l_seq);
+	for (int32_t k = 0; k < l_seq; ++k) u.seq[(size_t)k] = NT16[(r[o_seq + (k >> 1)] >> ((~k & 1) << 2)) & 15];
+	if (l_seq > 0 && r[o_qual] == 0xff) u.qual = "*";
+	else { u.qual.resize((size_t)l_seq); for (int32_t k = 0; k < l_seq; ++k) u.qual[(size_t)k] = (char)(r[o_qual + k] + 33); }
+	*qname = u.qname.c_str(); *seq = u.seq.c_str(); *qual = u.qual.c_str(); *is_read1 = (flag & 64) ? 1 : 0;
+	return offset + 4 + (size_t)bs;
+}
 
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { return (int64_t)b->buf[b->cur].unmapped.size(); }
 

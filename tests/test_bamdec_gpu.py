@@ -1,0 +1,151 @@
+"""-m gpu: the device-side BGZF inflate + BAM record decode (ssv_bamdec_*) against the host reader, array for array, and
+through the getclip kernels against the reference goldens.  Chunk sizes are chosen so that records straddle chunks and blocks."""
+import os
+
+import numpy as np
+import pytest
+
+import bamio
+import golden_util as G
+from seeksv_amd import device, host, synth
+from test_bam_reader import NAMES, LENS, _records
+
+pytestmark = pytest.mark.gpu
+KEYS = ("tid", "pos", "flag", "mapq", "n_cigar", "l_qseq", "mtid", "mpos", "isize", "xc")
+NO_SEQ = np.uint64(2 ** 64 - 1)
+
+
+def _host_all(path, keep_all_seq=False):
+    out, unm = [], []
+    with host.BamReader(path) as r:
+        while True:
+            b = r.read_batch(1 << 20, keep_all_seq)
+            if b is None:
+                break
+            unm += r.unmapped()
+            out.append(b)
+    return out, unm
+
+
+def _flatten(batches):
+    """batches of owned arrays -> one comparable view: fixed columns, CIGARs per record, shipped bases+qualities per record"""
+    cat = {k: np.concatenate([b[k] for b in batches]) if batches else np.zeros(0) for k in KEYS}
+    cig, seqs, shipped = [], [], []
+    for b in batches:
+        co, nc = b["cigar_off"].astype(np.int64), b["n_cigar"].astype(np.int64)
+        for i in range(len(nc)):
+            cig.append(b["cigar"][co[i]:co[i] + nc[i]].tobytes())
+        for i in np.nonzero(b["seq_off"] != NO_SEQ)[0]:
+            lq, so = int(b["l_qseq"][i]), int(b["seq_off"][i])
+            seqs.append(bytes(b["seqqual"][so:so + (lq + 1) // 2 + lq]))
+        shipped.append(b["seq_off"] != NO_SEQ)
+    cat["cigars"], cat["seqs"] = cig, seqs
+    cat["shipped"] = np.concatenate(shipped) if shipped else np.zeros(0, bool)
+    cat["max_ref_span"] = max([int(b["max_ref_span"]) for b in batches] or [0])
+    return cat
+
+
+def _runs_reference(flag, tid):
+    runs, last = [], 0
+    for i in range(len(tid)):
+        if flag[i] & 12:
+            continue
+        if tid[i] != last:
+            runs.append((i, int(tid[i])))
+            last = int(tid[i])
+    return runs
+
+
+def _device_all(ctx, path, chunk_bytes, max_blocks, keep_all_seq=False):
+    out, unm, runs, base, repaired = [], [], [], 0, 0
+    with host.BamReader(path) as r:
+        for b, info in ctx.bam_batches(r, chunk_bytes=chunk_bytes, max_blocks=max_blocks, keep_all_seq=keep_all_seq):
+            if b.n:
+                out.append(ctx.batch_to_host(b))
+            unm += info["unmapped"]
+            runs += [(base + i, t) for i, t in info["tid_runs"]]
+            base += info["n_records"]
+            repaired += info["repaired_blocks"]
+    return out, unm, runs, repaired
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with device.Context(0) as c:
+        yield c
+
+
+@pytest.fixture(scope="module")
+def ragged(tmp_path_factory):
+    d = tmp_path_factory.mktemp("bamdec")
+    path = str(d / "ragged.bam")
+    bamio.write_bam(path, NAMES, LENS, _records(6000, 11))  # blocks cut every 0xff00 bytes, anywhere inside a record
+    return path
+
+
+CHUNKS = [(64 << 20, 1 << 16), (1 << 17, 1 << 16), (64 << 20, 1), (64 << 20, 3), (200_000, 7)]
+
+
+@pytest.mark.parametrize("chunk_bytes,max_blocks", CHUNKS, ids=[f"{c}B-{m}blk" for c, m in CHUNKS])
+def test_device_decode_equals_host_reader_ragged(ctx, ragged, chunk_bytes, max_blocks):
+    hb, hunm = _host_all(ragged)
+    db, dunm, druns, _ = _device_all(ctx, ragged, chunk_bytes, max_blocks)
+    h, d = _flatten(hb), _flatten(db)
+    for k in KEYS + ("shipped",):
+        assert np.array_equal(h[k], d[k]), k
+    assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"]
+    assert d["max_ref_span"] >= 1 and h["max_ref_span"] == d["max_ref_span"]
+    assert hunm == dunm and len(hunm) > 0
+    assert druns == _runs_reference(h["flag"], h["tid"])
+
+
+@pytest.mark.parametrize("sub,name", [("example", "cancer.sort.bam"), ("example", "normal.sort.bam"), ("getclip", "filters.bam"), ("getclip", "stress2.bam"), ("getsv", "pairs1.bam")])
+@pytest.mark.parametrize("keep_all", [False, True], ids=["clipseq", "allseq"])
+def test_device_decode_equals_host_reader_goldens(ctx, sub, name, keep_all):
+    path = os.path.join(G.GOLDEN, sub, name)
+    hb, hunm = _host_all(path, keep_all)
+    db, dunm, druns, _ = _device_all(ctx, path, 1 << 18, 5, keep_all)
+    h, d = _flatten(hb), _flatten(db)
+    for k in KEYS + ("shipped",):
+        assert np.array_equal(h[k], d[k]), k
+    assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"]
+    assert hunm == dunm
+    assert druns == _runs_reference(h["flag"], h["tid"])
+
+
+def test_device_decode_feeds_getclip(ctx):
+    """BAM bytes -> device inflate/decode -> clip kernels, nothing decoded on the host: the reference's clip rows"""
+    path = os.path.join(G.GOLDEN, "example", "cancer.sort.bam")
+    ctx.clip_begin(0.9, 1, False)
+    with host.BamReader(path) as r:
+        names = r.target_names
+        for b, _ in ctx.bam_batches(r, chunk_bytes=1 << 18, max_blocks=4):
+            if b.n:
+                ctx.clip_scan(b)
+    table = ctx.clip_cluster()
+    rows, fq = host.format_clip_outputs(table, names)
+    assert rows == G.read_text("example", "cancer.clip.txt")
+    assert fq == G.read_text("example", "cancer.clip.fq.txt")
+
+
+def test_device_decode_synthetic_large(ctx, tmp_path):
+    """a few hundred BGZF blocks written by the host writer; every speculated record start must be right or repaired"""
+    w = synth.Workload(genome_frac=1 / 1024, depth=30, n_sv=20)
+    b = w.generate_host(0, w.n_total)
+    path = str(tmp_path / "s.bam")
+    host.write_bam(path, w.names, w.lens, [b])
+    db, _, _, repaired = _device_all(ctx, path, 8 << 20, 1 << 16)
+    d = _flatten(db)
+    for k in ("tid", "pos", "flag", "mapq", "n_cigar", "l_qseq", "mtid", "mpos", "isize"):
+        assert np.array_equal(d[k], b[k]), k
+    assert len(d["tid"]) == w.n_total
+    assert repaired <= 2 * len(db) + 2  # only chunk heads may need the hand-followed chain
+
+
+def test_device_decode_rejects_damage(ctx, ragged, tmp_path):
+    raw = bytearray(open(ragged, "rb").read())
+    raw[len(raw) // 2] ^= 0x5A  # inside some block's deflate payload
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises((device.SeeksvError, IOError)):
+        _device_all(ctx, bad, 64 << 20, 1 << 16)
