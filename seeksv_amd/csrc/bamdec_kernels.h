@@ -23,34 +23,49 @@ namespace ssv {
 
 constexpr uint32_t BD_NONE = 0xffffffffu;
 
-// Huffman tables of the 64 lanes of a wavefront, element i of lane l at [i * 64 + l]: every lane touches its own bank column
+// Huffman tables of the 64 lanes of a wavefront.  The decoder is latency bound (every symbol is a chain of dependent LDS and global
+// accesses), so what matters is how many wavefronts a CU can hold, i.e. LDS bytes per lane.  Only what the symbol loop reads stays in
+// LDS, element i of lane l at [i * 64 + l] (each lane its own bank column):
+//   lit8  288 B   low byte of the literal/length permutation        hi  9 dwords  its ninth bit (symbols >= 256 are lengths / end of block)
+//   dst8   32 B   distance permutation (also borrowed by the code-length code while a block header is read)
+// = 356 B per lane, 22,784 B per wavefront: seven wavefronts per CU (the u16 table + lengths + offsets of the first version: three).
+// The code lengths and the running offsets are only touched while a block header is parsed: they live in global scratch, same
+// interleaving (coalesced 64-byte rows).
 struct LdsTab {
-	uint16_t *sym; uint32_t *nib; uint16_t *off; int lane;
-	__device__ __forceinline__ uint16_t sym_get(int i) const { return sym[i * 64 + lane]; }
-	__device__ __forceinline__ void sym_set(int i, uint16_t v) { sym[i * 64 + lane] = v; }
-	__device__ __forceinline__ int len_get(int i) const { return (int)((nib[(i >> 3) * 64 + lane] >> ((i & 7) * 4)) & 15u); }
-	__device__ __forceinline__ void len_set(int i, int v)
+	uint8_t *lit8; uint32_t *hi; uint8_t *dst8;  // LDS
+	uint8_t *len8; uint16_t *off16;              // global scratch of this wavefront: 320 x 64 bytes, 16 x 64 halves
+	int lane;
+	__device__ __forceinline__ uint16_t lit_get(int i) const { return (uint16_t)(lit8[i * 64 + lane] | (((hi[(i >> 5) * 64 + lane] >> (i & 31)) & 1u) << 8)); }
+	__device__ __forceinline__ void lit_set(int i, uint16_t v)
 	{
-		uint32_t &w = nib[(i >> 3) * 64 + lane];
-		w = (w & ~(15u << ((i & 7) * 4))) | ((uint32_t)v << ((i & 7) * 4));
+		lit8[i * 64 + lane] = (uint8_t)v;
+		uint32_t &w = hi[(i >> 5) * 64 + lane];
+		w = (w & ~(1u << (i & 31))) | ((uint32_t)(v >> 8) << (i & 31));
 	}
-	__device__ __forceinline__ uint16_t off_get(int i) const { return off[i * 64 + lane]; }
-	__device__ __forceinline__ void off_set(int i, uint16_t v) { off[i * 64 + lane] = v; }
+	__device__ __forceinline__ uint16_t dst_get(int i) const { return dst8[i * 64 + lane]; }
+	__device__ __forceinline__ void dst_set(int i, uint16_t v) { dst8[i * 64 + lane] = (uint8_t)v; }
+	__device__ __forceinline__ int len_get(int i) const { return len8[i * 64 + lane]; }
+	__device__ __forceinline__ void len_set(int i, int v) { len8[i * 64 + lane] = (uint8_t)v; }
+	__device__ __forceinline__ uint16_t off_get(int i) const { return off16[i * 64 + lane]; }
+	__device__ __forceinline__ void off_set(int i, uint16_t v) { off16[i * 64 + lane] = v; }
 };
 
-constexpr int INFLATE_LDS_BYTES = 320 * 64 * 2 + 40 * 64 * 4 + 16 * 64 * 2; // 53,248 B per wavefront: three wavefronts per CU
+constexpr int INFLATE_LDS_BYTES = 288 * 64 + 9 * 64 * 4 + 32 * 64;      // 22,784 B per wavefront
+constexpr int INFLATE_SCRATCH_BYTES = 320 * 64 + 16 * 64 * 2;           // global scratch per wavefront
 
 struct BgzfBlock { uint64_t c_off; uint32_t c_len, u_len; }; // deflate payload inside the chunk buffer; inflated size
 
 // One lane per BGZF block.  status[b] = 0 or the lane's error code.
 __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
-                                                       uint8_t *__restrict__ out, int *__restrict__ status)
+                                                       uint8_t *__restrict__ out, int *__restrict__ status, uint8_t *__restrict__ scratch)
 {
 	extern __shared__ uint8_t lds_raw[];
 	LdsTab tab;
-	tab.sym = reinterpret_cast<uint16_t *>(lds_raw);
-	tab.nib = reinterpret_cast<uint32_t *>(lds_raw + 320 * 64 * 2);
-	tab.off = reinterpret_cast<uint16_t *>(lds_raw + 320 * 64 * 2 + 40 * 64 * 4);
+	tab.lit8 = lds_raw;
+	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * 64);
+	tab.dst8 = lds_raw + 288 * 64 + 9 * 64 * 4;
+	tab.len8 = scratch + (size_t)blockIdx.x * INFLATE_SCRATCH_BYTES;
+	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * 64);
 	tab.lane = lane_id();
 	const int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
 	if (b >= n_blocks) return;
@@ -144,6 +159,17 @@ __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restric
 		uint64_t my_first = ~0ull;
 		uint32_t my_count = 0;
 		const int m = (int)(n_blocks - base < WAVE ? n_blocks - base : WAVE);
+		// the usual case, checked for all 64 blocks at once: every guess is the exit of the block before it
+		{
+			const uint64_t prev_exit = __shfl_up(c.exit, 1, 64);
+			const bool ok = b >= n_blocks || (c.guess != ~0ull && c.guess == (lane_id() == 0 ? cur : prev_exit));
+			if (__all(ok)) {
+				if (b < n_blocks) count[b] = c.count; // chain[b].guess already is the first record start
+				n_rec += wave_sum(b < n_blocks ? c.count : 0u);
+				cur = __shfl(c.exit, m - 1, 64);
+				continue;
+			}
+		}
 		for (int l = 0; l < m; ++l) {
 			const uint64_t g = __shfl(c.guess, l, 64), e = __shfl(c.exit, l, 64), bend = __shfl(end, l, 64);
 			const uint32_t cn = __shfl(c.count, l, 64);
@@ -172,14 +198,14 @@ __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restric
 
 // rec_off[rank] for every record: block b's records start at rank base[b]
 __global__ __launch_bounds__(BLOCK) void k_list_records(const uint8_t *__restrict__ u, const BlockChain *__restrict__ chain, const uint32_t *__restrict__ count, const uint32_t *__restrict__ base,
-                                                       int64_t n_blocks, uint32_t *__restrict__ rec_off)
+                                                       int64_t n_blocks, uint64_t *__restrict__ rec_off)
 {
 	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (b >= n_blocks) return;
 	uint64_t o = chain[b].guess;
 	const uint32_t n = count[b], r0 = base[b];
 	for (uint32_t i = 0; i < n; ++i) {
-		rec_off[r0 + i] = (uint32_t)o;
+		rec_off[r0 + i] = o;
 		o += 4 + (uint64_t)ld_u32(u + o);
 	}
 }
@@ -196,7 +222,7 @@ struct RecColumns {
 	uint32_t *bad;        // one flag: a record whose fields overrun its block_size
 };
 
-__global__ __launch_bounds__(BLOCK) void k_record_fields(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t n, int keep_all_seq, RecColumns c)
+__global__ __launch_bounds__(BLOCK) void k_record_fields(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, int keep_all_seq, RecColumns c)
 {
 	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	int span = 1;
@@ -265,7 +291,7 @@ __device__ __forceinline__ int aux_xc_flag(const uint8_t *p, const uint8_t *end)
 }
 
 // 16 lanes per record: CIGAR ops and (for the records that ship them) packed bases + qualities, byte for byte as they lie in the record
-__global__ __launch_bounds__(BLOCK) void k_record_payload(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t n, const uint16_t *__restrict__ n_cigar,
+__global__ __launch_bounds__(BLOCK) void k_record_payload(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, const uint16_t *__restrict__ n_cigar,
                                                          const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ seq_bytes, uint64_t *__restrict__ seq_off,
                                                          uint32_t *__restrict__ cigar, uint8_t *__restrict__ seqqual, uint8_t *__restrict__ xc)
 {
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) void k_record_payload(const uint8_t *__restr
 }
 
 // raw bytes of the UNMAP|MUNMAP records, in file order (16 lanes per record)
-__global__ __launch_bounds__(BLOCK) void k_raw_copy(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, int64_t n, const uint32_t *__restrict__ raw_bytes,
+__global__ __launch_bounds__(BLOCK) void k_raw_copy(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, const uint32_t *__restrict__ raw_bytes,
                                                    const uint64_t *__restrict__ raw_off, uint8_t *__restrict__ raw)
 {
 	const int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;

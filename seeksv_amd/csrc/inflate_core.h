@@ -13,6 +13,7 @@
 
 #include <stdint.h>
 #include <string.h>
+#include <stddef.h>
 
 #ifndef SSV_HD
 #ifdef __HIPCC__
@@ -26,12 +27,14 @@ namespace ssv {
 
 enum : int { INF_OK = 0, INF_E_BTYPE = -1, INF_E_STORED = -2, INF_E_CODE = -3, INF_E_OVERSUB = -4, INF_E_DIST = -5, INF_E_OUTPUT = -6, INF_E_INPUT = -7, INF_E_REPEAT = -8 };
 
-// Table storage for one stream.  SYM: 320 u16 (literal/length permutation at [0,288), distance at [288,320); the code-length code
-// borrows [300,319) while the header is read).  NIB: 320 code lengths as nibbles.  OFF: 16 running offsets.
+// Table storage for one stream: the literal/length permutation (288 symbols of 9 bits), the distance permutation (32 symbols; the
+// code-length code borrows its slots [12,31) while a block header is read), 320 code lengths, 16 running offsets.
 struct PlainTab {
-	uint16_t sym[320]; uint8_t len[320]; uint16_t off[16];
-	SSV_HD uint16_t sym_get(int i) const { return sym[i]; }
-	SSV_HD void sym_set(int i, uint16_t v) { sym[i] = v; }
+	uint16_t lit[288]; uint8_t dst[32]; uint8_t len[320]; uint16_t off[16];
+	SSV_HD uint16_t lit_get(int i) const { return lit[i]; }
+	SSV_HD void lit_set(int i, uint16_t v) { lit[i] = v; }
+	SSV_HD uint16_t dst_get(int i) const { return dst[i]; }
+	SSV_HD void dst_set(int i, uint16_t v) { dst[i] = (uint8_t)v; }
 	SSV_HD int len_get(int i) const { return len[i]; }
 	SSV_HD void len_set(int i, int v) { len[i] = (uint8_t)v; }
 	SSV_HD uint16_t off_get(int i) const { return off[i]; }
@@ -39,28 +42,81 @@ struct PlainTab {
 };
 
 struct BitReader {
-	const uint8_t *p;   // next unread byte
+	const uint8_t *p;   // address of `ahead`
 	uint64_t bb = 0;    // bit buffer, LSB first
 	int bc = 0;         // valid bits in bb
-	SSV_HD explicit BitReader(const uint8_t *in) : p(in) {}
-	SSV_HD void refill() // afterwards bc >= 32 (reads up to 4 bytes past the data: buffers are padded)
+	uint32_t ahead;     // the next 32 input bits, loaded one refill early: its latency hides behind the symbols decoded meanwhile
+	SSV_HD explicit BitReader(const uint8_t *in) : p(in) { memcpy(&ahead, p, 4); }
+	SSV_HD void refill() // afterwards bc >= 32 (looks up to 8 bytes past the data: buffers are padded)
 	{
 		if (bc < 32) {
-			uint32_t w;
-			memcpy(&w, p, 4);
-			bb |= (uint64_t)w << bc;
+			bb |= (uint64_t)ahead << bc;
 			bc += 32; p += 4;
+			memcpy(&ahead, p, 4);
 		}
 	}
 	SSV_HD uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
 	SSV_HD void drop(int n) { bb >>= n; bc -= n; }
 	SSV_HD uint32_t take(int n) { uint32_t v = peek(n); drop(n); return v; }
+	SSV_HD uint32_t consumed(const uint8_t *in) const { return (uint32_t)(p - in) - (uint32_t)(bc >> 3); } // whole bytes taken from the input
 };
+
+// LZ77 copy of len bytes from `dist` bytes back.  Measured on MI355X (profiles/r01_bamdec_*.json): the lane is latency bound and the
+// wavefront runs every divergent path its lanes take, so the copy is kept to few, short paths:
+//   head         up to three bytes bring the destination to a dword boundary (hipcc turns unaligned dword STORES into four byte
+//                stores; unaligned dword loads stay single instructions)
+//   dist >= len  source and destination are disjoint: 16 bytes per step, the four loads issued before the four (merged) stores
+//   dist >= 4    overlapping, but every source dword lies behind the write position: dword steps
+//   dist 1..3    a short period: the pattern is built in registers once and only stored
+// Tried and slower here: issuing all loads of up to 32 bytes before the first store (more instructions per match: 37.6 ms vs 27.4 ms
+// for 5.3 GB), and the same with loads running ahead of the write position (those lines are not in L2 yet: 45 ms).
+SSV_HD uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; } // unaligned load (one dword load on gfx950)
+
+SSV_HD void lz_copy_disjoint(uint32_t *__restrict__ to, const uint8_t *__restrict__ from, uint32_t len)
+{
+	uint32_t i = 0;
+	for (; i + 16 <= len; i += 16) {
+		const uint32_t a = ld32(from + i), b = ld32(from + i + 4), c = ld32(from + i + 8), d = ld32(from + i + 12);
+		to[i >> 2] = a; to[(i >> 2) + 1] = b; to[(i >> 2) + 2] = c; to[(i >> 2) + 3] = d;
+	}
+	for (; i + 4 <= len; i += 4) to[i >> 2] = ld32(from + i);
+	uint8_t *tb = reinterpret_cast<uint8_t *>(to);
+	for (; i < len; ++i) tb[i] = from[i];
+}
+
+SSV_HD void lz_copy(uint8_t *to_, uint32_t dist, uint32_t len)
+{
+	uint32_t head = (uint32_t)(0u - (uint32_t)(uintptr_t)to_) & 3u;
+	if (head > len) head = len;
+	const uint8_t *from_ = to_ - dist;
+	for (uint32_t i = 0; i < head; ++i) to_[i] = from_[i];
+	len -= head;
+	if (!len) return;
+	uint8_t *to = to_ + head;
+	uint32_t *to4 = reinterpret_cast<uint32_t *>(to); // aligned: dword stores
+	const uint8_t *from = to - dist;
+	if (dist >= len) { lz_copy_disjoint(to4, from, len); return; }
+	if (dist >= 4) {
+		uint32_t i = 0;
+		for (; i + 4 <= len; i += 4) to4[i >> 2] = ld32(from + i);
+		for (; i < len; ++i) to[i] = from[i];
+		return;
+	}
+	// period 1, 2 or 3: twelve bytes hold a whole number of periods (no runtime-indexed local arrays: they would live in scratch)
+	const uint32_t a = from[0], b = dist > 1 ? from[1] : a, c = dist > 2 ? from[2] : a;
+	uint32_t w0, w1, w2;
+	if (dist == 3) { w0 = a | b << 8 | c << 16 | a << 24; w1 = b | c << 8 | a << 16 | b << 24; w2 = c | a << 8 | b << 16 | c << 24; }
+	else { w0 = w1 = w2 = dist == 1 ? a * 0x01010101u : (a | b << 8) * 0x00010001u; }
+	uint32_t i = 0;
+	for (; i + 12 <= len; i += 12) { to4[i >> 2] = w0; to4[(i >> 2) + 1] = w1; to4[(i >> 2) + 2] = w2; }
+	for (uint32_t k = 0; i < len; ++i, ++k) to[i] = (uint8_t)((k < 4 ? w0 : k < 8 ? w1 : w2) >> (8 * (k & 3)));
+}
 
 struct HuffCounts { uint32_t c[8]; }; // count of codes of length L in bits [16*(L&1), +16) of c[L>>1]
 
 // canonical decode: walk the lengths, one bit per step; the first length at which the code falls below first+count wins
-template <class Tab>
+// LIT selects the literal/length table; otherwise the distance table at slot offset sym_base
+template <bool LIT, class Tab>
 SSV_HD int huff_decode(BitReader &br, const HuffCounts &h, const Tab &tab, int sym_base)
 {
 	int code = 0, first = 0, index = 0;
@@ -69,14 +125,14 @@ SSV_HD int huff_decode(BitReader &br, const HuffCounts &h, const Tab &tab, int s
 	for (int len = 1; len <= 15; ++len) {
 		code |= (int)(bits & 1u); bits >>= 1;
 		const int count = (int)((h.c[len >> 1] >> ((len & 1) * 16)) & 0xffffu);
-		if (code - count < first) { br.drop(len); return tab.sym_get(sym_base + index + (code - first)); }
+		if (code - count < first) { br.drop(len); const int k = sym_base + index + (code - first); return LIT ? tab.lit_get(k) : tab.dst_get(k); }
 		index += count; first += count; first <<= 1; code <<= 1;
 	}
 	return -1;
 }
 
 // build the decoding tables of one code from the lengths at Tab::len[len_base, len_base + n): counts -> h, permutation -> Tab::sym[sym_base...)
-template <class Tab>
+template <bool LIT, class Tab>
 SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCounts &h)
 {
 	for (int l = 0; l < 16; ++l) tab.off_set(l, 0);
@@ -95,7 +151,11 @@ SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCount
 	}
 	for (int s = 0; s < n; ++s) {
 		const int l = tab.len_get(len_base + s);
-		if (l) { const int o = tab.off_get(l); tab.sym_set(sym_base + o, (uint16_t)s); tab.off_set(l, (uint16_t)(o + 1)); }
+		if (l) {
+			const int o = tab.off_get(l);
+			if (LIT) tab.lit_set(sym_base + o, (uint16_t)s); else tab.dst_set(sym_base + o, (uint16_t)s);
+			tab.off_set(l, (uint16_t)(o + 1));
+		}
 	}
 	return INF_OK;
 }
@@ -128,8 +188,8 @@ SSV_HD int inflate_stream(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
 		if (type == 1) {
 			for (int s = 0; s < 288; ++s) tab.len_set(s, s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
 			for (int s = 0; s < 30; ++s) tab.len_set(288 + s, 5);
-			huff_construct(tab, 0, 288, 0, lit);
-			huff_construct(tab, 288, 30, 288, dist);
+			huff_construct<true>(tab, 0, 288, 0, lit);
+			huff_construct<false>(tab, 288, 30, 0, dist);
 		} else {
 			const int nlen = (int)br.take(5) + 257, ndist = (int)br.take(5) + 1, ncode = (int)br.take(4) + 4;
 			if (nlen > 286 || ndist > 30) return INF_E_CODE;
@@ -141,12 +201,12 @@ SSV_HD int inflate_stream(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
 				tab.len_set(s, (int)br.take(3));
 			}
 			HuffCounts cl;
-			int rc = huff_construct(tab, 0, 19, 300, cl);
+			int rc = huff_construct<false>(tab, 0, 19, 12, cl);
 			if (rc != INF_OK) return rc;
 			int idx = 0, prev = 0;
 			while (idx < nlen + ndist) {
 				br.refill();
-				int s = huff_decode(br, cl, tab, 300);
+				int s = huff_decode<false>(br, cl, tab, 12);
 				if (s < 0) return INF_E_CODE;
 				if (s < 16) { tab.len_set(idx++, s); prev = s; continue; }
 				int rep, val = 0;
@@ -160,14 +220,14 @@ SSV_HD int inflate_stream(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
 			if (tab.len_get(256) == 0) return INF_E_CODE; // no end-of-block code
 			// the distance lengths sit right behind the literal/length lengths: build the distance code first (its lengths are read in
 			// place), then the literal/length code
-			rc = huff_construct(tab, nlen, ndist, 288, dist);
+			rc = huff_construct<false>(tab, nlen, ndist, 0, dist);
 			if (rc != INF_OK) return rc;
-			rc = huff_construct(tab, 0, nlen, 0, lit);
+			rc = huff_construct<true>(tab, 0, nlen, 0, lit);
 			if (rc != INF_OK) return rc;
 		}
 		for (;;) {
 			br.refill();
-			int s = huff_decode(br, lit, tab, 0);
+			int s = huff_decode<true>(br, lit, tab, 0);
 			if (s < 0) return INF_E_CODE;
 			if (s < 256) {
 				if (o >= out_len) return INF_E_OUTPUT;
@@ -182,22 +242,20 @@ SSV_HD int inflate_stream(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
 			else if (s == 285) len = 258;
 			else { const int e = (s - 261) >> 2; len = ((4u + (uint32_t)((s - 265) & 3)) << e) + 3u + br.take(e); }
 			br.refill();
-			const int d = huff_decode(br, dist, tab, 288);
+			const int d = huff_decode<false>(br, dist, tab, 0);
 			if (d < 0 || d > 29) return INF_E_CODE;
 			uint32_t dst;
 			if (d < 4) dst = (uint32_t)d + 1u;
 			else { const int e = (d >> 1) - 1; dst = ((2u + (uint32_t)(d & 1)) << e) + 1u + br.take(e); }
 			if (dst > o) return INF_E_DIST;
 			if (o + len > out_len) return INF_E_OUTPUT;
-			const uint8_t *from = out + o - dst;
-			uint8_t *to = out + o;
-			for (uint32_t i = 0; i < len; ++i) to[i] = from[i]; // may overlap forward: byte order matters
+			lz_copy(out + o, dst, len);
 			o += len;
 		}
 	} while (!last);
 	if (o != out_len) return INF_E_OUTPUT;
 	// bytes taken from the input: everything up to p except the whole bytes still in the buffer
-	if ((uint32_t)(br.p - in) - (uint32_t)(br.bc >> 3) > in_len) return INF_E_INPUT;
+	if (br.consumed(in) > in_len) return INF_E_INPUT;
 	return INF_OK;
 }
 

@@ -57,7 +57,7 @@ class Context:
         return _abi.make_batch(b)
 
     # ---- device-side BGZF inflate + BAM decode ----
-    def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False):
+    def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False, chunk_inflated=1 << 31):
         """Generator over SSV_MEM_DEVICE batches of a whole BAM file (host.BamReader), decoded on the GPU: yields (Batch, info dict).
         The batch is valid until the next iteration."""
         hl = reader._lib
@@ -70,7 +70,7 @@ class Context:
         blocks = (_abi.BgzfBlock * max_blocks)()
         while True:
             nb, nbytes = C.c_int64(), C.c_size_t()
-            if hl.ssvh_bam_read_blocks(reader.handle, stage, chunk_bytes, 1 << 31, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
+            if hl.ssvh_bam_read_blocks(reader.handle, stage, chunk_bytes, chunk_inflated, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
                 raise IOError(hl.ssvh_last_error().decode())
             b = _abi.Batch()
             self._check(self._lib.ssv_bamdec_decode(self._h, stage, nbytes.value, blocks, nb.value, int(keep_all_seq), C.byref(b)), "ssv_bamdec_decode")
