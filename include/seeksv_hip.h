@@ -251,8 +251,10 @@ typedef struct {
 /* Start a file: n_targets of its header (plausibility of speculated record starts), and the offset of the first record inside the
  * inflated stream of the first chunk (= the length of the BAM header: magic, text, reference list). */
 int ssv_bamdec_begin(ssv_ctx *ctx, int32_t n_targets, uint64_t first_record_offset);
-/* Pinned host buffer (grow-only, owned by the context) to read the compressed bytes of a chunk into; any host memory works too. */
-int ssv_bamdec_staging(ssv_ctx *ctx, size_t bytes, void **host_ptr);
+/* Pinned host buffers (two, which = 0 | 1; grow-only, owned by the context) to read the compressed bytes of a chunk into, so that a
+ * reader thread can fill one while the other is being decoded; any host memory works too.  A buffer is free again when the decode
+ * call that was given it returns. */
+int ssv_bamdec_staging(ssv_ctx *ctx, int which, size_t bytes, void **host_ptr);
 /* Inflate + decode one chunk.  *out is an SSV_MEM_DEVICE batch owned by the context, valid until the next decode on it (stream
  * ordered: kernels already enqueued on the context's stream may still read it).  n_blocks == 0 = end of input (fails if a record
  * is unfinished).  keep_all_seq as in ssvh_bam_read_batch.  Synchronises the stream. */

@@ -66,7 +66,7 @@ class Context:
             raise IOError(hl.ssvh_last_error().decode())
         self._check(self._lib.ssv_bamdec_begin(self._h, len(reader.target_names), first.value), "ssv_bamdec_begin")
         stage = C.c_void_p()
-        self._check(self._lib.ssv_bamdec_staging(self._h, chunk_bytes, C.byref(stage)), "ssv_bamdec_staging")
+        self._check(self._lib.ssv_bamdec_staging(self._h, 0, chunk_bytes, C.byref(stage)), "ssv_bamdec_staging")
         blocks = (_abi.BgzfBlock * max_blocks)()
         while True:
             nb, nbytes = C.c_int64(), C.c_size_t()

@@ -84,7 +84,8 @@ struct PhaseTimer {
 	     << "         -q <int>              Minimum mapping quality of soft-clipped reads [1]\n"
 	     << "         -s                    Save the low quality sequence clipped before alignment by bwa.\n"
 	     << "         -o <string>           Prefix of output files [output]\n"
-	     << "         -G <int>              GPU ordinal [0]" << endl;
+	     << "         -G <int>              GPU ordinal [0]\n"
+	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
 	exit(1);
 }
 
@@ -105,7 +106,8 @@ struct PhaseTimer {
 	     << "         -i <int>              Maximum indel number of up_seq / down_seq when no read pair supports the junction [1]\n"
 	     << "         -L <int>              Flank length for the average depths [200]\n"
 	     << "         -t <double> -Q <int> -w <int>   accepted for compatibility\n"
-	     << "         -G <int>              GPU ordinal [0]" << endl;
+	     << "         -G <int>              GPU ordinal [0]\n"
+	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
 	exit(1);
 }
 
@@ -117,7 +119,8 @@ struct PhaseTimer {
 	     << "         -l <int>              Maximum search length to find microhomology [30]\n"
 	     << "         -m <int>              Minimum length of the clipped sequence  in normal [10]\n"
 	     << "         -n <int>              Number of read pairs used to calculate insert size [5000000]; < 100000 switches the insert-size pass off\n"
-	     << "         -G <int>              GPU ordinal [0]" << endl;
+	     << "         -G <int>              GPU ordinal [0]\n"
+	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
 	exit(1);
 }
 
@@ -156,6 +159,105 @@ struct GzOut {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
+// where the record batches come from: the host reader (inflate + decode on the host threads, batches uploaded by the kernels' H2D
+// staging), or -Z: the compressed BGZF blocks go to the GPU as they are and are inflated and decoded there (ssv_bamdec_*); a reader
+// thread fills one pinned staging buffer while the chunk in the other one is being decoded.
+// ---------------------------------------------------------------------------------------------------------------------
+
+struct BatchSource {
+	ssvh_bam *bam = nullptr;
+	ssv_ctx *ctx = nullptr;
+	bool on_device = false;
+	// device mode
+	size_t stage_bytes = 0;
+	uint64_t chunk_inflated = 0;
+	void *stage[2] = {nullptr, nullptr};
+	vector<ssv_bgzf_block> blocks[2];
+	int64_t n_blocks[2] = {0, 0};
+	size_t n_bytes[2] = {0, 0};
+	string read_err[2];
+	int cur = 0;
+	std::thread reader;
+	bool reader_running = false, at_end = false;
+	ssv_bamdec_info info{};
+
+	void open(const string &path, ssv_ctx *c, bool device_inflate, const char *open_error)
+	{
+		ctx = c; on_device = device_inflate;
+		if (ssvh_bam_open(path.c_str(), &bam) != 0) die(open_error);
+		if (!on_device) { ssvh_bam_set_readahead(bam, 1); return; }
+		const char *e1 = getenv("SSV_CHUNK_INFLATED_MB"), *e2 = getenv("SSV_STAGE_MB");
+		chunk_inflated = (uint64_t)(e1 ? atoll(e1) : 4096) << 20;
+		stage_bytes = (size_t)(e2 ? atoll(e2) : 1536) << 20;
+		uint64_t first = 0;
+		if (ssvh_bam_raw_begin(bam, &first) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		for (int k = 0; k < 2; ++k) {
+			if (ssv_bamdec_staging(ctx, k, stage_bytes, &stage[k]) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			blocks[k].resize((size_t)(chunk_inflated >> 12) + 1024); // blocks are <= 64 KB but may be much smaller
+		}
+		start_read(0);
+	}
+	void start_read(int k)
+	{
+		reader = std::thread([this, k] {
+			read_err[k].clear();
+			if (ssvh_bam_read_blocks(bam, stage[k], stage_bytes, chunk_inflated, blocks[k].data(), (int64_t)blocks[k].size(), &n_blocks[k], &n_bytes[k]) != 0) read_err[k] = ssvh_last_error();
+		});
+		reader_running = true;
+	}
+	// the next batch (valid until the following call); false at the end of the file
+	bool next(ssv_batch_t *b, int keep_all_seq)
+	{
+		if (!on_device) {
+			if (ssvh_bam_read_batch(bam, 1 << 22, keep_all_seq, b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+			return b->n != 0;
+		}
+		for (;;) {
+			if (at_end) return false;
+			if (reader_running) { reader.join(); reader_running = false; }
+			const int k = cur;
+			if (!read_err[k].empty()) die("[seeksv] " + read_err[k]);
+			if (n_blocks[k] > 0) { cur ^= 1; start_read(cur); } // the other buffer fills while this chunk is decoded
+			if (ssv_bamdec_decode(ctx, stage[k], n_bytes[k], blocks[k].data(), n_blocks[k], keep_all_seq, b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			if (n_blocks[k] == 0) { at_end = true; return false; }
+			ssv_bamdec_last(ctx, &info);
+			if (b->n) return true; // (a chunk can hold only the middle of one huge record)
+		}
+	}
+	// UNMAP|MUNMAP records of the current batch, in order
+	template <class F> void for_each_unmapped(F fn)
+	{
+		const char *qname, *seq, *qual; int is_read1;
+		if (!on_device) {
+			for (int64_t k = 0, nu = ssvh_bam_unmapped_count(bam); k < nu; ++k) { ssvh_bam_unmapped_get(bam, k, &qname, &seq, &qual, &is_read1); fn(qname, seq, qual, is_read1); }
+			return;
+		}
+		for (size_t off = 0, nxt; (nxt = ssvh_raw_record_fastq(info.unmapped_raw, info.unmapped_bytes, off, &qname, &seq, &qual, &is_read1)) != 0; off = nxt) fn(qname, seq, qual, is_read1);
+	}
+	// the contig changes among the other records of the current batch (the flush sequence of clip_reads.h:423-438)
+	void contig_runs(const ssv_batch_t &b, int32_t &last_tid, vector<int32_t> &run_tids)
+	{
+		if (!on_device) {
+			for (int64_t i = 0; i < b.n; ++i) {
+				if (b.flag[i] & (4 | 8)) continue;
+				if (b.tid[i] != last_tid) { run_tids.push_back(last_tid); last_tid = b.tid[i]; }
+			}
+			return;
+		}
+		for (uint32_t k = 0; k < info.n_tid_runs; ++k) { run_tids.push_back(last_tid); last_tid = info.tid_run_tid[k]; }
+	}
+	void close()
+	{
+		if (reader_running) { reader.join(); reader_running = false; }
+		if (bam) ssvh_bam_close(bam);
+		bam = nullptr;
+	}
+};
+
+static bool device_inflate_default() { const char *e = getenv("SSV_DEVICE_INFLATE"); return e && atoi(e) != 0; }
+
+// ---------------------------------------------------------------------------------------------------------------------
 // getclip
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -164,14 +266,15 @@ static int cmd_getclip(int argc, char **argv)
 	int c, min_mapQ = 1, device = 0;
 	double threshold = 0.9;
 	string prefix = "output";
-	bool save_low_quality = false;
-	while ((c = getopt(argc, argv, "t:q:o:sG:")) >= 0) {
+	bool save_low_quality = false, device_inflate = device_inflate_default();
+	while ((c = getopt(argc, argv, "t:q:o:sG:Z")) >= 0) {
 		switch (c) {
 		case 't': threshold = atof(optarg); break;
 		case 'q': min_mapQ = atoi(optarg); break;
 		case 's': save_low_quality = true; break;
 		case 'o': prefix = optarg; break;
 		case 'G': device = atoi(optarg); break;
+		case 'Z': device_inflate = true; break;
 		default: usage_getclip();
 		}
 	}
@@ -179,9 +282,11 @@ static int cmd_getclip(int argc, char **argv)
 	const string bamfile = argv[optind];
 
 	PhaseTimer pt;
-	ssvh_bam *bam = nullptr;
-	if (ssvh_bam_open(bamfile.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
-	ssvh_bam_set_readahead(bam, 1);
+	{ // like the reference: complain about the input before anything is created
+		ssvh_bam *probe = nullptr;
+		if (ssvh_bam_open(bamfile.c_str(), &probe) != 0) die("[main_samview] fail to open file for reading.");
+		ssvh_bam_close(probe);
+	}
 	GzOut softfout, fqfout, fuout1, fuout2;
 	const string f_clip = prefix + ".clip.gz", f_fq = prefix + ".clip.fq.gz", f_u1 = prefix + ".unmapped_1.fq.gz", f_u2 = prefix + ".unmapped_2.fq.gz";
 	if (!softfout.open(f_clip)) die("Cannot open file " + f_clip);
@@ -195,6 +300,9 @@ static int cmd_getclip(int argc, char **argv)
 	memset(&p, 0, sizeof(p));
 	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
 	if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+	BatchSource src;
+	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
+	ssvh_bam *bam = src.bam;
 	pt.lap("open+gpu_init");
 
 	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219)
@@ -203,12 +311,10 @@ static int cmd_getclip(int argc, char **argv)
 	int32_t last_tid = 0;
 	for (;;) {
 		ssv_batch_t b;
-		if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
-		pt.lap("bam_read");
-		if (b.n == 0) break;
-		for (int64_t k = 0, nu = ssvh_bam_unmapped_count(bam); k < nu; ++k) {
-			const char *qname, *seq, *qual; int is_read1;
-			ssvh_bam_unmapped_get(bam, k, &qname, &seq, &qual, &is_read1);
+		const bool more = src.next(&b, 0);
+		pt.lap(device_inflate ? "bam_read(wait)+gpu_inflate+decode" : "bam_read");
+		if (!more) break;
+		src.for_each_unmapped([&](const char *qname, const char *seq, const char *qual, int is_read1) {
 			auto it = id2seq_qual.find(qname);
 			if (it != id2seq_qual.end()) {
 				if (is_read1 && it->second.second == '2') {
@@ -221,11 +327,8 @@ static int cmd_getclip(int argc, char **argv)
 					id2seq_qual.erase(it);
 				}
 			} else id2seq_qual.insert(make_pair(string(qname), make_pair(make_pair(string(seq), string(qual)), is_read1 ? '1' : '2')));
-		}
-		for (int64_t i = 0; i < b.n; ++i) { // the flush sequence, for the stderr messages and the order check
-			if (b.flag[i] & (4 | 8)) continue;
-			if (b.tid[i] != last_tid) { run_tids.push_back(last_tid); last_tid = b.tid[i]; }
-		}
+		});
+		src.contig_runs(b, last_tid, run_tids); // the flush sequence, for the stderr messages and the order check
 		pt.lap("host_side_channel");
 		if (ssv_clip_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		ssv_sync(ctx);
@@ -289,8 +392,8 @@ static int cmd_getclip(int argc, char **argv)
 	cerr << "[GetSClipReads] finished!" << endl;
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
 	pt.lap("gzip");
+	src.close();
 	ssv_ctx_destroy(ctx);
-	ssvh_bam_close(bam);
 	pt.lap("teardown");
 	return 0;
 }
@@ -328,17 +431,15 @@ static double largest_base_frequency(const string &seq) // CountLargestBaseFrequ
 }
 
 // CalculateInsertsizeDeviation (cluster.cpp:15-83) over the head of a BAM, with the reference's stderr lines
-static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation)
+static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation)
 {
-	ssvh_bam *bam = nullptr;
-	if (ssvh_bam_open(bamfile.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
+	BatchSource src;
+	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 	ssv_isize_begin(ctx, min_mapQ, read_pair_used);
-	ssvh_bam_set_readahead(bam, 1);
 	int32_t done = 0;
 	while (!done) {
 		ssv_batch_t b;
-		if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
-		if (b.n == 0) break;
+		if (!src.next(&b, 0)) break;
 		if (ssv_isize_accumulate(ctx, &b, &done) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 	}
 	int64_t n; int32_t m = 0, sd = 0;
@@ -347,7 +448,7 @@ static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, int min_mapQ, 
 		mean_insert_size = m; deviation = sd;
 		cerr << "Bam/sam " << bamfile << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << endl;
 	}
-	ssvh_bam_close(bam);
+	src.close();
 }
 
 static int cmd_getsv(int argc, char **argv)
@@ -356,9 +457,9 @@ static int cmd_getsv(int argc, char **argv)
 	double frequency = 0.1;
 	int c, min_mapQ = 20, read_pair_used = 5000000, sum_min_no_both_clipped_reads = 3, min_distance = 50, microhomology_length = 50, times = 4, device = 0,
 	       min_abnormal_read_pair_no = 0, flank_length = 200, min_seq_len = 30, max_seq_indel_no = 1, flank = 50;
-	bool output_depth = true;
+	bool output_depth = true, device_inflate = device_inflate_default();
 	PhaseTimer pt;
-	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:")) >= 0) {
+	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:Z")) >= 0) {
 		switch (c) {
 		case 'F': connect_bam = optarg; break;
 		case 'B': temp_breakpoint = optarg; break;
@@ -375,6 +476,7 @@ static int cmd_getsv(int argc, char **argv)
 		case 'T': microhomology_length = atoi(optarg); break;
 		case 'L': flank_length = atoi(optarg); break;
 		case 'G': device = atoi(optarg); break;
+		case 'Z': device_inflate = true; break;
 		case 'J': dump_junctions = optarg; break;
 		default: break; // -t -Q -w -a -R -r: accepted, unused (as in the reference, where -t / -Q no longer reach the join)
 		}
@@ -433,7 +535,7 @@ static int cmd_getsv(int argc, char **argv)
 	int mean_insert_size = 0, deviation = 0;
 	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
 	if (do_discordant) {
-		insert_size_pass(ctx, original_bam, min_mapQ, read_pair_used, mean_insert_size, deviation);
+		insert_size_pass(ctx, original_bam, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation);
 		cerr << "'CalculateInsertsizeDeviation' finished" << endl;
 	} else min_abnormal_read_pair_no = 0; // seeksv.cpp:285
 
@@ -464,14 +566,15 @@ static int cmd_getsv(int argc, char **argv)
 		gp.windows = dw; gp.n_windows = output_depth ? nw : 0; gp.depth_min_mapq = min_mapQ;
 		gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		ssvh_bam_set_readahead(bam, 1);
+		BatchSource src; // a second handle: `bam` keeps serving the header
+		src.open(original_bam, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 		for (;;) {
 			ssv_batch_t b;
-			if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
-			if (b.n == 0) break;
+			if (!src.next(&b, 0)) break;
 			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 			ssv_sync(ctx);
 		}
+		src.close();
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, do_discordant ? counts.data() : nullptr, dr, output_depth ? nr : 0, rsum.data(), dp, output_depth ? np : 0, pdepth.data(), &maxd) != SSV_OK)
 			die(string("[seeksv] ") + ssv_last_error(ctx));
@@ -554,8 +657,9 @@ static int cmd_somatic(int argc, char **argv)
 	int offset = 30, c, min_len_of_clipped_seq = 10, read_pair_used = 5000000, min_mapQ = 20, device = 0;
 	double min_map_rate = 0.9;
 	string dump_lookups;
+	bool device_inflate = device_inflate_default();
 	PhaseTimer pt;
-	while ((c = getopt(argc, argv, "t:q:l:m:n:G:J:")) >= 0) {
+	while ((c = getopt(argc, argv, "t:q:l:m:n:G:J:Z")) >= 0) {
 		switch (c) {
 		case 't': min_map_rate = atof(optarg); break;
 		case 'q': min_mapQ = atoi(optarg); break;
@@ -563,6 +667,7 @@ static int cmd_somatic(int argc, char **argv)
 		case 'm': min_len_of_clipped_seq = atoi(optarg); break;
 		case 'n': read_pair_used = atoi(optarg); break;
 		case 'G': device = atoi(optarg); break;
+		case 'Z': device_inflate = true; break;
 		case 'J': dump_lookups = optarg; break; // test hook: the host look-ups only (no BAM pass, no GPU), one line per output row
 		}
 	}
@@ -593,7 +698,7 @@ static int cmd_somatic(int argc, char **argv)
 	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
 	pt.lap("gpu_init");
 	int mean_insert_size = 0, deviation = 0;
-	if (read_pair_used >= 100000) insert_size_pass(ctx, normal_bam_file, min_mapQ, read_pair_used, mean_insert_size, deviation);
+	if (read_pair_used >= 100000) insert_size_pass(ctx, normal_bam_file, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation);
 	pt.lap("isize_pass");
 
 	ofstream fout(somatic_file.c_str());
@@ -630,14 +735,15 @@ static int cmd_somatic(int argc, char **argv)
 		gp.n_windows = 0; gp.depth_min_mapq = min_mapQ;
 		gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		ssvh_bam_set_readahead(bam, 1);
+		BatchSource src; // a second handle: `bam` keeps serving the header
+		src.open(normal_bam_file, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 		for (;;) {
 			ssv_batch_t b;
-			if (ssvh_bam_read_batch(bam, 1 << 22, 0, &b) != 0) die(string("[seeksv] ") + ssvh_last_error());
-			if (b.n == 0) break;
+			if (!src.next(&b, 0)) break;
 			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 			ssv_sync(ctx);
 		}
+		src.close();
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, counts.data(), nullptr, 0, nullptr, nullptr, 0, nullptr, &maxd) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		vector<int32_t> prev(J.size() + 1, 0); // a row whose left contig is not in the normal's header reports 0

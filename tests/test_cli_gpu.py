@@ -10,6 +10,21 @@ import golden_util as G
 from seeksv_amd import host
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["host-inflate", "device-inflate"])
+def inflate_mode(request, monkeypatch):
+    """every CLI test runs twice: BAM inflated + decoded by the host threads, and on the GPU (-Z / SSV_DEVICE_INFLATE=1);
+    small chunks in the second mode so that even the example BAMs span several chunks and records straddle them"""
+    if request.param == "device-inflate":
+        monkeypatch.setenv("SSV_DEVICE_INFLATE", "1")
+        monkeypatch.setenv("SSV_CHUNK_INFLATED_MB", "1")
+        monkeypatch.setenv("SSV_STAGE_MB", "1")
+    else:
+        monkeypatch.delenv("SSV_DEVICE_INFLATE", raising=False)
+    return request.param
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEEKSV = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
 

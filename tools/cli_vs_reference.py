@@ -56,6 +56,13 @@ def main():
     assert r.returncode == 0, r.stderr
     if phases(r.stderr):
         out["ours_getclip_phases_s"] = phases(r.stderr)
+    # the same with the BAM inflated and decoded on the GPU
+    out["ours_getclip_Z_s"], r = timed([OURS, "getclip", "-Z", "-o", os.path.join(d, "oursz"), bam])
+    assert r.returncode == 0, r.stderr
+    if phases(r.stderr):
+        out["ours_getclip_Z_phases_s"] = phases(r.stderr)
+    for ext in ("clip.gz", "clip.fq.gz"):
+        assert gzip.open(os.path.join(d, "ours." + ext)).read() == gzip.open(os.path.join(d, "oursz." + ext)).read(), ext
     if have_ref:
         for ext in ("clip.gz", "clip.fq.gz"):
             assert gzip.open(os.path.join(d, "ref." + ext)).read() == gzip.open(os.path.join(d, "ours." + ext)).read(), ext
@@ -78,6 +85,11 @@ def main():
     assert r.returncode == 0, r.stderr
     if phases(r.stderr):
         out["ours_getsv_phases_s"] = phases(r.stderr)
+    out["ours_getsv_Z_s"], rz = timed([OURS, "getsv", "-Z"] + args + [os.path.join(d, "oursz.sv"), os.path.join(d, "z.fq")])
+    assert rz.returncode == 0, rz.stderr
+    if phases(rz.stderr):
+        out["ours_getsv_Z_phases_s"] = phases(rz.stderr)
+    assert open(os.path.join(d, "ours.sv")).read() == open(os.path.join(d, "oursz.sv")).read() and rz.stdout == r.stdout
     if have_ref:
         assert open(os.path.join(d, "ref.sv")).read() == open(os.path.join(d, "ours.sv")).read()
         assert ref_stdout == r.stdout
