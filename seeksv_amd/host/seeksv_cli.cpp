@@ -178,7 +178,8 @@ struct BatchSource {
 	string read_err[2];
 	int cur = 0;
 	std::thread reader;
-	bool reader_running = false, at_end = false;
+	bool reader_running = false, at_end = false, end_pending = false;
+	uint64_t file_bytes = 0, consumed = 0;
 	ssv_bamdec_info info{};
 
 	void open(const string &path, ssv_ctx *c, bool device_inflate, const char *open_error)
@@ -189,17 +190,22 @@ struct BatchSource {
 		const char *e1 = getenv("SSV_CHUNK_INFLATED_MB"), *e2 = getenv("SSV_STAGE_MB");
 		chunk_inflated = (uint64_t)(e1 ? atoll(e1) : 4096) << 20;
 		stage_bytes = (size_t)(e2 ? atoll(e2) : 1536) << 20;
+		{ // no more pinned memory than the file can fill (pinning costs ~0.2 s per GB, twice: at allocation and at release)
+			FILE *f = fopen(path.c_str(), "rb");
+			if (f) { fseek(f, 0, SEEK_END); file_bytes = (uint64_t)ftell(f); fclose(f); }
+			if (file_bytes && file_bytes + 65536 < stage_bytes) stage_bytes = (size_t)file_bytes + 65536;
+		}
 		uint64_t first = 0;
 		if (ssvh_bam_raw_begin(bam, &first) != 0) die(string("[seeksv] ") + ssvh_last_error());
 		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		for (int k = 0; k < 2; ++k) {
-			if (ssv_bamdec_staging(ctx, k, stage_bytes, &stage[k]) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-			blocks[k].resize((size_t)(chunk_inflated >> 12) + 1024); // blocks are <= 64 KB but may be much smaller
-		}
 		start_read(0);
 	}
 	void start_read(int k)
 	{
+		if (!stage[k]) { // the second buffer only exists for files that need a second chunk
+			if (ssv_bamdec_staging(ctx, k, stage_bytes, &stage[k]) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			blocks[k].resize((size_t)(std::min<uint64_t>(chunk_inflated, file_bytes ? file_bytes * 64 : chunk_inflated) >> 12) + 1024); // blocks are <= 64 KB but may be much smaller
+		}
 		reader = std::thread([this, k] {
 			read_err[k].clear();
 			if (ssvh_bam_read_blocks(bam, stage[k], stage_bytes, chunk_inflated, blocks[k].data(), (int64_t)blocks[k].size(), &n_blocks[k], &n_bytes[k]) != 0) read_err[k] = ssvh_last_error();
@@ -215,12 +221,23 @@ struct BatchSource {
 		}
 		for (;;) {
 			if (at_end) return false;
+			if (end_pending) { // the last chunk has been handed out: tell the decoder the input is over (an unfinished record is an error)
+				ssv_batch_t none;
+				if (ssv_bamdec_decode(ctx, nullptr, 0, nullptr, 0, keep_all_seq, &none) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+				at_end = true;
+				return false;
+			}
 			if (reader_running) { reader.join(); reader_running = false; }
 			const int k = cur;
 			if (!read_err[k].empty()) die("[seeksv] " + read_err[k]);
-			if (n_blocks[k] > 0) { cur ^= 1; start_read(cur); } // the other buffer fills while this chunk is decoded
+			// payload + 18-byte header + 8-byte trailer per block, 28 bytes for the empty end-of-file block: when nothing can be left, do not
+			// start (and allocate a second staging buffer for) another read
+			consumed += n_bytes[k] + 26ull * (uint64_t)n_blocks[k];
+			const bool last_chunk = n_blocks[k] == 0 || (file_bytes && consumed + 28 >= file_bytes);
+			if (!last_chunk) { cur ^= 1; start_read(cur); } // the other buffer fills while this chunk is decoded
 			if (ssv_bamdec_decode(ctx, stage[k], n_bytes[k], blocks[k].data(), n_blocks[k], keep_all_seq, b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 			if (n_blocks[k] == 0) { at_end = true; return false; }
+			if (last_chunk) end_pending = true;
 			ssv_bamdec_last(ctx, &info);
 			if (b->n) return true; // (a chunk can hold only the middle of one huge record)
 		}
