@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 #   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                        = 8.0 B/record
 #   clip_gather : packed bases+qualities 228 read + 228 written, CIGAR 8 + 8                                             = 472 B/event
 #   event_sort  : 5 radix passes x (12 B histogram read + 12 B read + 12 B written)                                       = 180 B/event
-#   cluster_pack: 228 read + 2*(ll+lr) ~ 300 written + ~70 B of per-cluster columns                                       = 600 B/cluster-slot
-ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 600.0}
+#   cluster_pack: 228 read + 1.5*(ll+lr) ~ 225 written (4-bit sequence codes + qualities) + ~70 B of per-cluster columns   = 525 B/cluster-slot
+ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 525.0}
 
 
 def main():
@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--n-sv", type=int, default=10000)
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
     ap.add_argument("--no-overlap", action="store_true", help="collect every cluster table in its own step (no copy in flight while other kernels run); use under rocprofv3, which serialises dispatches of different streams")
     args = ap.parse_args()
 
@@ -108,6 +109,7 @@ def main():
     gen_s = time.time() - t0
 
     ctx = Context(local_rank)
+    ctx.clip_table_format(not args.ascii_table)  # sequences cross PCIe as 4-bit codes (the CLI expands them while it formats the rows)
     hdr = host.Header(w.names, w.lens)
     own = sp["own"] if world > 1 else None
     jtable = host.JunctionTable(w.junctions)
@@ -119,6 +121,7 @@ def main():
         t = ctx.clip_table_wait(prev=prev)
         ssum = int(np.ctypeslib.as_array(t.support, shape=(t.n_clusters,)).sum()) if t.n_clusters else 0
         assert ssum == t.n_events, "clip events were lost or duplicated"
+        assert bool(t.seq_packed) == (not args.ascii_table)
         state["support_sum"] = ssum
         state["tables"] += 1
 

@@ -140,7 +140,21 @@ typedef struct {
 	const uint64_t *cigar_off; /* [n_clusters] offset into cigar */
 	const int32_t *n_cigar;    /* [n_clusters] ops of the record whose CIGAR the cluster carries */
 	const uint32_t *cigar;     /* BAM-encoded ops INCLUDING S/H (GenerateCigar drops those when printing) */
+	int32_t seq_packed;        /* 0: the layout above.  1 (ssv_clip_table_format): the two sequences are 4-bit codes, two per byte, first
+	                              base in the high nibble, index into "=ACMGRSVTWYHKDBN" (BAM's own packing):
+	                              [seq_left ceil(left_len/2) B | qual_left left_len B | seq_right ceil(right_len/2) B | qual_right right_len B];
+	                              ssv_table_block_bytes() gives a block's size.  The table is the path's output and it crosses PCIe:
+	                              a quarter fewer string bytes. */
 } ssv_cluster_table;
+
+/* Table format of the following ssv_clip_cluster[_async] calls: packed != 0 selects the 4-bit sequence layout (default 0). */
+int ssv_clip_table_format(ssv_ctx *ctx, int packed);
+/* Bytes of one cluster's string block (a multiple of 4). */
+static inline uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed)
+{
+	const uint64_t l = (uint64_t)left_len, r = (uint64_t)right_len;
+	return ((seq_packed ? (l + 1) / 2 + l + (r + 1) / 2 + r : 2 * (l + r)) + 3) & ~(uint64_t)3;
+}
 
 /* Sort events into (contig, side, position) bins and run the greedy consensus clustering. */
 int ssv_clip_cluster(ssv_ctx *ctx, ssv_cluster_table *out);

@@ -65,6 +65,11 @@ class OrcClusterTable(C.Structure):
     _fields_ = ClusterTable._fields_ + [("str_bytes", C.c_int64), ("cigar_ops", C.c_int64)]
 
 
+class HipClusterTable(C.Structure):
+    """ssv_cluster_table as libseeksv_hip.so hands it out: the common part + the sequence format flag"""
+    _fields_ = ClusterTable._fields_ + [("seq_packed", C.c_int32)]
+
+
 class Junction(C.Structure):
     """ssv_junction"""
     _fields_ = [
@@ -213,10 +218,11 @@ def hip_lib():
         lib.ssv_clip_begin.argtypes = [V, C.POINTER(ClipParams)]
         lib.ssv_clip_scan.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_clip_event_count.argtypes = [V, C.POINTER(C.c_int64)]
-        lib.ssv_clip_cluster.argtypes = [V, C.POINTER(ClusterTable)]
+        lib.ssv_clip_cluster.argtypes = [V, C.POINTER(HipClusterTable)]
+        lib.ssv_clip_table_format.argtypes = [V, C.c_int]
         lib.ssv_clip_cluster_async.argtypes = [V, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        lib.ssv_clip_table_wait.argtypes = [V, C.POINTER(ClusterTable)]
-        lib.ssv_clip_table_wait_prev.argtypes = [V, C.POINTER(ClusterTable)]
+        lib.ssv_clip_table_wait.argtypes = [V, C.POINTER(HipClusterTable)]
+        lib.ssv_clip_table_wait_prev.argtypes = [V, C.POINTER(HipClusterTable)]
         lib.ssv_isize_begin.argtypes = [V, C.c_int32, C.c_int64]
         lib.ssv_isize_accumulate.argtypes = [V, C.POINTER(Batch), C.POINTER(C.c_int32)]
         lib.ssv_isize_finish.argtypes = [V, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

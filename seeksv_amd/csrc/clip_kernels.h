@@ -551,7 +551,8 @@ struct PackArgs {
 	int32_t *support, *ll, *lr;
 	uint8_t *qmiss;
 	uint32_t *slot;           // dense index -> sorted slot
-	uint64_t *str_bytes;      // 2 * (ll + lr)
+	uint64_t *str_bytes;      // bytes of the cluster's string block
+	int packed;               // 1: sequences as 4-bit codes (ssv_cluster_table.seq_packed)
 	uint64_t *ncig64;
 	int32_t *ncig;
 };
@@ -570,7 +571,8 @@ __global__ void k_cluster_pack_meta(PackArgs p)
 	p.ll[c] = ll; p.lr[c] = lr;
 	p.qmiss[c] = p.c.c_qmiss[j];
 	p.slot[c] = (uint32_t)j;
-	p.str_bytes[c] = (2ull * (uint64_t)(ll + lr) + 3ull) & ~3ull; // blocks start 4-byte aligned
+	const uint64_t L = (uint64_t)ll, R = (uint64_t)lr;
+	p.str_bytes[c] = ((p.packed ? (L + 1) / 2 + L + (R + 1) / 2 + R : 2 * (L + R)) + 3ull) & ~3ull; // blocks start 4-byte aligned
 	uint32_t nc = p.c.ev.ncig[p.c.c_cig_ev[j]];
 	p.ncig[c] = (int32_t)nc;
 	p.ncig64[c] = nc;
@@ -584,6 +586,15 @@ __device__ __forceinline__ uint32_t nt16_char(uint32_t nib)
 	return (uint32_t)(((nib & 8u) ? HI : LO) >> (8u * (nib & 7u))) & 0xffu;
 }
 
+// the inverse: ASCII (upper case, as the consensus strings hold it) -> 4-bit code; anything else is N
+__device__ __forceinline__ uint32_t nt16_code(uint32_t ch)
+{
+	uint32_t code = 15;
+#pragma unroll
+	for (uint32_t k = 0; k < 16; ++k) if (nt16_char(k) == ch) code = k;
+	return code;
+}
+
 constexpr int PACK_MAX_LQ = 256; // reads up to this length take the LDS-staged path of k_cluster_pack_strings
 
 // 16 lanes per cluster, four clusters per wavefront: strings and the CIGAR of the carrying event into dense blobs.  Every lane
@@ -592,6 +603,8 @@ constexpr int PACK_MAX_LQ = 256; // reads up to this length take the LDS-staged 
 // qualities (GetSeq, clip_reads.cpp:286-306): the group expands the read once into LDS with dword loads (8 bases per packed dword,
 // 4 qualities per dword via alignbyte and a packed +33) and then composes the output dwords from LDS bytes.  Clusters of multi-event
 // bins come from their consensus storage (left part un-reversed); reads longer than PACK_MAX_LQ take the per-byte path.
+// PACKED: the two sequences leave as 4-bit codes (ssv_cluster_table.seq_packed); the LDS stage then holds codes instead of characters.
+template <bool PACKED>
 __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
                                                                 const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
 {
@@ -627,7 +640,8 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 #pragma unroll
 			for (int b = 0; b < 2; ++b) { // packed bytes 0,1 -> chars 0..3 ; bytes 2,3 -> chars 4..7
 				const uint32_t b0 = (pk >> (16 * b)) & 0xffu, b1 = (pk >> (16 * b + 8)) & 0xffu;
-				const uint32_t four = nt16_char(b0 >> 4) | (nt16_char(b0 & 15u) << 8) | (nt16_char(b1 >> 4) << 16) | (nt16_char(b1 & 15u) << 24);
+				const uint32_t four = PACKED ? ((b0 >> 4) | ((b0 & 15u) << 8) | ((b1 >> 4) << 16) | ((b1 & 15u) << 24))
+				                             : (nt16_char(b0 >> 4) | (nt16_char(b0 & 15u) << 8) | (nt16_char(b1 >> 4) << 16) | (nt16_char(b1 & 15u) << 24));
 				if (b == 0) lo = four; else hi = four;
 			}
 			s_seq[grp][2 * w] = lo; s_seq[grp][2 * w + 1] = hi;
@@ -645,30 +659,17 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 	}
 	__syncthreads();
 	if (!active) return;
-	const int total = 2 * (ll + lr);
+	// one block = four pieces: sequence / quality of the left part, sequence / quality of the right part.  A piece position maps to a
+	// character through sl/ql/sr/qr below (three sources: the LDS stage, the event's packed read, the consensus storage); the byte at
+	// block offset q is then either that character or, for a packed sequence piece, two 4-bit codes.
+	const int A = PACKED ? (ll + 1) / 2 : ll, C = PACKED ? (lr + 1) / 2 : lr;
+	const int total = A + ll + C + lr;
 	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + str_off[c]);
-	if (staged) {
-		const uint8_t *sq = reinterpret_cast<const uint8_t *>(s_seq[grp]);
-		const uint8_t *qq = reinterpret_cast<const uint8_t *>(s_qual[grp]);
-		for (int w = gl; w * 4 < total; w += GROUP) {
-			uint32_t word = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const int q = w * 4 + k;
-				uint32_t ch = 0;
-				if (q < total) {
-					if (q < ll) ch = sq[begin + q];
-					else if (q < 2 * ll) ch = qq[begin + q - ll];
-					else if (q < 2 * ll + lr) ch = sq[begin + ll + q - 2 * ll];
-					else ch = qq[begin + ll + q - 2 * ll - lr];
-				}
-				word |= ch << (8 * k);
-			}
-			d[w] = word;
-		}
-	} else {
-		EventView v;
-		const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+	EventView v;
+	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+	const uint8_t *sq = reinterpret_cast<const uint8_t *>(s_seq[grp]);
+	const uint8_t *qq = reinterpret_cast<const uint8_t *>(s_qual[grp]);
+	if (!staged) {
 		if (single) {
 			v.sp = sp; v.qp = sp + (lq + 1) / 2; v.begin = begin; v.ll = ll; v.lr = lr; v.qmiss = qmiss;
 		} else {
@@ -676,29 +677,33 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 			cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
 			cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
 		}
-		for (int w = gl; w * 4 < total; w += GROUP) {
-			uint32_t word = 0;
+	}
+	// sequence position -> character (ASCII layout) or 4-bit code (packed layout); in the stage the conversion has been done already
+	auto seq_at = [&](bool right, int i) -> uint32_t {
+		if (staged) return sq[begin + (right ? ll : 0) + i];
+		const uint32_t ch = single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i]);
+		return PACKED ? nt16_code(ch) : ch;
+	};
+	auto qual_at = [&](bool right, int i) -> uint32_t {
+		if (staged) return qq[begin + (right ? ll : 0) + i];
+		return single ? (uint32_t)(uint8_t)v.qual(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rq[i] : cq[ll - 1 - i]);
+	};
+	for (int w = gl; w * 4 < total; w += GROUP) {
+		uint32_t word = 0;
 #pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const int q = w * 4 + k; // byte position inside the cluster's block
-				uint32_t ch = 0;
-				if (q < total) {
-					if (single) {
-						if (q < ll) ch = (uint8_t)v.base(v.begin + q);
-						else if (q < 2 * ll) ch = (uint8_t)v.qual(v.begin + q - ll);
-						else if (q < 2 * ll + lr) ch = (uint8_t)v.base(v.begin + ll + q - 2 * ll);
-						else ch = (uint8_t)v.qual(v.begin + ll + q - 2 * ll - lr);
-					} else {
-						if (q < ll) ch = cs[ll - 1 - q];
-						else if (q < 2 * ll) ch = cq[ll - 1 - (q - ll)];
-						else if (q < 2 * ll + lr) ch = rs[q - 2 * ll];
-						else ch = rq[q - 2 * ll - lr];
-					}
-				}
-				word |= ch << (8 * k);
+		for (int k = 0; k < 4; ++k) {
+			const int q = w * 4 + k; // byte position inside the cluster's block
+			uint32_t ch = 0;
+			if (q < total) {
+				const bool right = q >= A + ll;
+				const int r = right ? q - A - ll : q, S = right ? C : A, n = right ? lr : ll; // offset inside the half, its sequence bytes, its length
+				if (r >= S) ch = qual_at(right, r - S);
+				else if (!PACKED) ch = seq_at(right, r);
+				else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
 			}
-			d[w] = word;
+			word |= ch << (8 * k);
 		}
+		d[w] = word;
 	}
 	const uint32_t *src = cig_blob + p.c.ev.cig_off[e];
 	uint32_t *dc = out_cig + cig_off[c];

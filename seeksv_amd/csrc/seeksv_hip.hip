@@ -83,8 +83,10 @@ struct ssv_ctx {
 		hipEvent_t copied = nullptr;
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
+		int packed = 0;
 	} tab[2];
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
+	bool table_packed = false; // ssv_clip_table_format
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
 
@@ -573,7 +575,8 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	pa.c = ca; pa.flag = P<uint32_t>(c->c_flag); pa.cidx = P<uint32_t>(c->c_idx);
 	pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
 	pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.slot = P<uint32_t>(c->o_slot); pa.str_bytes = P<uint64_t>(c->o_strbytes);
-	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(T.o_ncig);
+	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(T.o_ncig); pa.packed = c->table_packed ? 1 : 0;
+	T.packed = pa.packed;
 	k_cluster_pack_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
 	CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nc) * 8));
 	uint64_t *tot = P<uint64_t>(c->totals);
@@ -583,8 +586,12 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	const uint64_t str_total = P<uint64_t>(c->h_totals)[1], cig_total = P<uint64_t>(c->h_totals)[2];
 	CHECK(ensure(c, T.o_str, str_total + 16)); CHECK(ensure(c, T.o_cig, cig_total * 4 + 16));
-	k_cluster_pack_strings<<<grid_for(nc, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(T.o_stroff), P<uint64_t>(T.o_cigoff), P<uint32_t>(c->cig_blob),
-	                                                                          P<uint8_t>(T.o_str), P<uint32_t>(T.o_cig));
+	if (pa.packed)
+		k_cluster_pack_strings<true><<<grid_for(nc, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(T.o_stroff), P<uint64_t>(T.o_cigoff), P<uint32_t>(c->cig_blob),
+		                                                                                P<uint8_t>(T.o_str), P<uint32_t>(T.o_cig));
+	else
+		k_cluster_pack_strings<false><<<grid_for(nc, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, nc, P<uint64_t>(T.o_stroff), P<uint64_t>(T.o_cigoff), P<uint32_t>(c->cig_blob),
+		                                                                                 P<uint8_t>(T.o_str), P<uint32_t>(T.o_cig));
 	HIPCHECK(c, hipGetLastError());
 	delete pack_scope; pack_scope = nullptr; // the copy below is PCIe time, not kernel time
 	struct { HBuf *h; DBuf *d; size_t bytes; } cp[] = {
@@ -617,6 +624,13 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 
 static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out);
 
+int ssv_clip_table_format(ssv_ctx *c, int packed)
+{
+	if (!c) return SSV_E_ARG;
+	c->table_packed = packed != 0;
+	return SSV_OK;
+}
+
 int ssv_clip_table_wait(ssv_ctx *c, ssv_cluster_table *out) { return c && out ? table_wait(c, c->tab_cur, out) : SSV_E_ARG; }
 int ssv_clip_table_wait_prev(ssv_ctx *c, ssv_cluster_table *out) { return c && out ? table_wait(c, c->tab_cur ^ 1, out) : SSV_E_ARG; }
 
@@ -630,7 +644,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 		HIPCHECK(c, hipEventSynchronize(T.copied));
 		T.in_flight = false;
 	}
-	out->n_events = T.n_events; out->n_clusters = T.n_clusters;
+	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed;
 	if (T.n_clusters == 0) return SSV_OK;
 	out->tid = P<int32_t>(T.h_tid); out->pos = P<int32_t>(T.h_pos); out->side = P<uint8_t>(T.h_side); out->support = P<int32_t>(T.h_support);
 	out->left_len = P<int32_t>(T.h_ll); out->right_len = P<int32_t>(T.h_lr); out->qual_missing = P<uint8_t>(T.h_qmiss); out->str_off = P<uint64_t>(T.h_stroff);

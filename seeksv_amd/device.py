@@ -103,6 +103,10 @@ class Context:
         p = _abi.ClipParams.make(match_rate, min_mapq, save_low_quality, own, initial_last_tid)
         self._check(self._lib.ssv_clip_begin(self._h, C.byref(p)), "ssv_clip_begin")
 
+    def clip_table_format(self, packed):
+        """packed=True: cluster tables carry their sequences as 4-bit codes (a quarter fewer string bytes over PCIe); host.cluster_strings decodes both"""
+        self._check(self._lib.ssv_clip_table_format(self._h, int(bool(packed))), "ssv_clip_table_format")
+
     def clip_scan(self, batch):
         b, keep = self._as_batch(batch)
         self._check(self._lib.ssv_clip_scan(self._h, C.byref(b)), "ssv_clip_scan")
@@ -115,7 +119,7 @@ class Context:
         return n.value
 
     def clip_cluster(self, as_dict=True):
-        t = _abi.ClusterTable()
+        t = _abi.HipClusterTable()
         self._check(self._lib.ssv_clip_cluster(self._h, C.byref(t)), "ssv_clip_cluster")
         return table_to_dict(t) if as_dict else t
 
@@ -126,7 +130,7 @@ class Context:
         return nc.value, ne.value
 
     def clip_table_wait(self, prev=False, as_dict=False):
-        t = _abi.ClusterTable()
+        t = _abi.HipClusterTable()
         fn = self._lib.ssv_clip_table_wait_prev if prev else self._lib.ssv_clip_table_wait
         self._check(fn(self._h, C.byref(t)), "ssv_clip_table_wait")
         return table_to_dict(t) if as_dict else t

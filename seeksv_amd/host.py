@@ -207,12 +207,13 @@ def table_to_dict(t):
             return np.zeros(0, dtype=dt)
         return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True)
 
-    d = dict(n_clusters=n, n_events=t.n_events)
+    packed = int(getattr(t, "seq_packed", 0))
+    d = dict(n_clusters=n, n_events=t.n_events, seq_packed=packed)
     for name, dt in (("tid", np.int32), ("pos", np.int32), ("side", np.uint8), ("support", np.int32), ("left_len", np.int32),
                      ("right_len", np.int32), ("qual_missing", np.uint8), ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
         d[name] = arr(getattr(t, name), n, dt)
     if n:
-        sb = int(d["str_off"][-1]) + ((2 * int(d["left_len"][-1] + d["right_len"][-1]) + 3) & ~3)
+        sb = int(d["str_off"][-1]) + block_bytes(int(d["left_len"][-1]), int(d["right_len"][-1]), packed)
         cb = int(d["cigar_off"][-1]) + int(d["n_cigar"][-1])
     else:
         sb = cb = 0
@@ -221,14 +222,32 @@ def table_to_dict(t):
     return d
 
 
+NT16 = "=ACMGRSVTWYHKDBN"
+
+
+def block_bytes(ll, lr, packed):
+    """ssv_table_block_bytes (include/seeksv_hip.h)"""
+    return (((ll + 1) // 2 + ll + (lr + 1) // 2 + lr if packed else 2 * (ll + lr)) + 3) & ~3
+
+
 def cluster_strings(d, k):
     """(seq_left, qual_left, seq_right, qual_right, cigar_text) of cluster k."""
     o, ll, lr = int(d["str_off"][k]), int(d["left_len"][k]), int(d["right_len"][k])
     s = d["str"]
-    sl = s[o:o + ll].tobytes().decode("latin-1")
-    ql = s[o + ll:o + 2 * ll].tobytes().decode("latin-1")
-    sr = s[o + 2 * ll:o + 2 * ll + lr].tobytes().decode("latin-1")
-    qr = s[o + 2 * ll + lr:o + 2 * ll + 2 * lr].tobytes().decode("latin-1")
+    if d.get("seq_packed"):
+        a, c = (ll + 1) // 2, (lr + 1) // 2
+
+        def unpack(buf, n):
+            return "".join(NT16[(int(buf[i >> 1]) >> (0 if i & 1 else 4)) & 15] for i in range(n))
+        sl = unpack(s[o:o + a], ll)
+        ql = s[o + a:o + a + ll].tobytes().decode("latin-1")
+        sr = unpack(s[o + a + ll:o + a + ll + c], lr)
+        qr = s[o + a + ll + c:o + a + ll + c + lr].tobytes().decode("latin-1")
+    else:
+        sl = s[o:o + ll].tobytes().decode("latin-1")
+        ql = s[o + ll:o + 2 * ll].tobytes().decode("latin-1")
+        sr = s[o + 2 * ll:o + 2 * ll + lr].tobytes().decode("latin-1")
+        qr = s[o + 2 * ll + lr:o + 2 * ll + 2 * lr].tobytes().decode("latin-1")
     if d["qual_missing"][k]:
         ql = qr = "*"
     co, nc = int(d["cigar_off"][k]), int(d["n_cigar"][k])

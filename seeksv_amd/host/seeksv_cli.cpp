@@ -317,6 +317,7 @@ static int cmd_getclip(int argc, char **argv)
 	memset(&p, 0, sizeof(p));
 	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
 	if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+	ssv_clip_table_format(ctx, 1); // sequences as 4-bit codes over PCIe; expanded by the formatting threads below
 	BatchSource src;
 	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 	ssvh_bam *bam = src.bam;
@@ -373,11 +374,20 @@ static int cmd_getclip(int argc, char **argv)
 		string &row = rows[(size_t)w], &fq = fqs[(size_t)w];
 		row.reserve((size_t)(k1 - k0) * 480); fq.reserve((size_t)(k1 - k0) * 200);
 		char num[16];
+		string seqbuf;
 		for (int64_t k = k0; k < k1; ++k) {
 			const char *name = ssvh_bam_target_name(bam, t.tid[k]);
-			const char *s = (const char *)t.str + t.str_off[k];
+			const uint8_t *s = t.str + t.str_off[k];
 			const size_t ll = (size_t)t.left_len[k], lr = (size_t)t.right_len[k];
-			const char *sl = s, *ql = s + ll, *sr = s + 2 * ll, *qr = s + 2 * ll + lr;
+			const char *sl, *ql, *sr, *qr;
+			if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right]
+				const size_t a = (ll + 1) / 2, c2 = (lr + 1) / 2;
+				seqbuf.resize(ll + lr);
+				for (size_t i = 0; i < ll; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((~i & 1) << 2)) & 15];
+				for (size_t i = 0; i < lr; ++i) seqbuf[ll + i] = "=ACMGRSVTWYHKDBN"[(s[a + ll + (i >> 1)] >> ((~i & 1) << 2)) & 15];
+				sl = seqbuf.data(); sr = seqbuf.data() + ll;
+				ql = (const char *)s + a; qr = (const char *)s + a + ll + c2;
+			} else { sl = (const char *)s; ql = sl + ll; sr = sl + 2 * ll; qr = sl + 2 * ll + lr; }
 			size_t lql = ll, lqr = lr;
 			if (t.qual_missing[k]) { ql = qr = "*"; lql = lqr = 1; }
 			row += name ? name : ""; row += '\t';

@@ -42,6 +42,28 @@ def test_getclip_hip_matches_reference(ctx, sub, bam, prefix, kw, batch_records)
     assert_tables_equal(d, O.getclip(batches, **kw))
 
 
+@pytest.mark.parametrize("sub,bam,prefix,kw", GETCLIP_CASES, ids=[c[2] for c in GETCLIP_CASES])
+def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw):
+    """ssv_clip_table_format(1): sequences leave the GPU as 4-bit codes; decoded, the table is the ASCII table (and the reference's rows)"""
+    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, sub, bam), 1 << 20)
+    ref = ctx.getclip(batches, **kw)
+    ctx.clip_table_format(True)
+    try:
+        d = ctx.getclip(batches, **kw)
+    finally:
+        ctx.clip_table_format(False)
+    assert d["seq_packed"] == 1 and ref["seq_packed"] == 0
+    for k in ("tid", "pos", "side", "support", "left_len", "right_len", "qual_missing", "cigar_off", "n_cigar", "cigar"):
+        assert np.array_equal(d[k], ref[k]), k
+    assert all(host.cluster_strings(d, k) == host.cluster_strings(ref, k) for k in range(d["n_clusters"]))
+    if d["n_clusters"]:
+        assert len(d["str"]) < len(ref["str"])
+        offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1) for a, b in zip(d["left_len"], d["right_len"])])])
+        assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))
+    clip, fq = host.format_clip_outputs(d, names)
+    assert clip == G.read_text(sub, prefix + ".clip.txt") and fq == G.read_text(sub, prefix + ".clip.fq.txt")
+
+
 @pytest.mark.parametrize("sample", ["cancer", "normal"])
 def test_isize_hip_matches_reference_example(ctx, sample):
     names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, "example", sample + ".sort.bam"), 5000)
