@@ -149,12 +149,8 @@ typedef struct {
 
 /* Table format of the following ssv_clip_cluster[_async] calls: packed != 0 selects the 4-bit sequence layout (default 0). */
 int ssv_clip_table_format(ssv_ctx *ctx, int packed);
-/* Bytes of one cluster's string block (a multiple of 4). */
-static inline uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed)
-{
-	const uint64_t l = (uint64_t)left_len, r = (uint64_t)right_len;
-	return ((seq_packed ? (l + 1) / 2 + l + (r + 1) / 2 + r : 2 * (l + r)) + 3) & ~(uint64_t)3;
-}
+/* Bytes of one cluster's string block (a multiple of 4): 2(l+r) for ASCII, ceil(l/2)+l+ceil(r/2)+r for the packed layout, rounded up. */
+uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed);
 
 /* Sort events into (contig, side, position) bins and run the greedy consensus clustering. */
 int ssv_clip_cluster(ssv_ctx *ctx, ssv_cluster_table *out);

@@ -624,6 +624,12 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 
 static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out);
 
+uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed)
+{
+	const uint64_t l = (uint64_t)left_len, r = (uint64_t)right_len;
+	return ((seq_packed ? (l + 1) / 2 + l + (r + 1) / 2 + r : 2 * (l + r)) + 3) & ~(uint64_t)3;
+}
+
 int ssv_clip_table_format(ssv_ctx *c, int packed)
 {
 	if (!c) return SSV_E_ARG;
