@@ -12,16 +12,33 @@ sys.path.insert(0, ROOT)
 from seeksv_amd import device, host, synth  # noqa: E402
 
 
+class _Total:
+    def __init__(self, n):
+        self.n_total = n
+
+
 def main():
-    frac = float(sys.argv[1]) if len(sys.argv) > 1 else 1 / 32
-    depth = float(sys.argv[2]) if len(sys.argv) > 2 else 30
-    chunk_gb = int(sys.argv[3]) if len(sys.argv) > 3 else 7
-    w = synth.Workload(genome_frac=frac, depth=depth, n_sv=200)
     d = tempfile.mkdtemp(prefix="ssv_bamdec_")
     bam = os.path.join(d, "synth.bam")
-    chunk = 2_000_000
-    host.write_bam(bam, w.names, w.lens, (w.generate_host(g, min(chunk, w.n_total - g)) for g in range(0, w.n_total, chunk)))
-    out = {"chunk_inflated_GB": chunk_gb, "records": w.n_total, "bam_bytes": os.path.getsize(bam), "host_cpus": os.cpu_count()}
+    if len(sys.argv) > 1 and sys.argv[1] == "example":
+        # real reads, real base qualities: the records of the reference's bundled example BAM (tests/golden/example/cancer.sort.bam), written
+        # K times over - what a lane sees inside one BGZF block (literal / match mix, Huffman code lengths) is then that of real data
+        k = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
+        chunk_gb = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+        with host.BamReader(os.path.join(ROOT, "tests", "golden", "example", "cancer.sort.bam")) as r:
+            names, lens, b = r.target_names, r.target_lens, r.read_batch(1 << 22, keep_all_seq=True)
+        host.write_bam(bam, names, lens, [b] * k)
+        w = _Total(len(b["tid"]) * k)
+        label = f"example/cancer.sort.bam x {k}"
+    else:
+        frac = float(sys.argv[1]) if len(sys.argv) > 1 else 1 / 32
+        depth = float(sys.argv[2]) if len(sys.argv) > 2 else 30
+        chunk_gb = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+        w = synth.Workload(genome_frac=frac, depth=depth, n_sv=200)
+        chunk = 2_000_000
+        host.write_bam(bam, w.names, w.lens, (w.generate_host(g, min(chunk, w.n_total - g)) for g in range(0, w.n_total, chunk)))
+        label = f"synthetic 30x, genome_frac {frac}"
+    out = {"input": label, "chunk_inflated_GB": chunk_gb, "records": w.n_total, "bam_bytes": os.path.getsize(bam), "host_cpus": os.cpu_count()}
     # host reader (all threads, read-ahead)
     for rep in range(2):
         t = time.perf_counter()
