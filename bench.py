@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--depth", type=float, default=30.0, help="per-GPU coverage")
     ap.add_argument("--n-sv", type=int, default=10000)
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--ref-sample", type=int, default=3_000_000, help="records of the sample the real reference binary (oracle/_ref, if it travelled) is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
     ap.add_argument("--no-overlap", action="store_true", help="collect every cluster table in its own step (no copy in flight while other kernels run); use under rocprofv3, which serialises dispatches of different streams")
@@ -269,6 +270,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(w, hdr, min(args.cpu_sample, w.n_total))
+            ref = cpu_reference(w, min(args.ref_sample, w.n_total))
+            if ref:
+                line["cpu_reference"] = ref
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
@@ -301,6 +305,47 @@ def cpu_baseline(w, hdr, n_sample, min_seconds=10.0):
             "sample": f"{passes} passes over the first {n_sample} records of the same synthetic workload = {dt:.1f} s of CPU work (getclip {t_clip:.1f} s); "
                       "oracle = plain-C restatement of seeksv v1.2.3 on decoded SoA records (no BGZF inflate / BAM parse), pinned to the real reference on tests/golden",
             "clusters": int(d["n_clusters"]), "events": int(d["n_events"])}
+
+
+def cpu_reference(w, n_sample):
+    """The REAL reference (oracle/_ref/seeksv_ref, built from the reference's own sources by `make -C oracle ref` where they exist; the binary
+    travels with the snapshot) on a bounded prefix of the same workload written as a BAM file: `getclip`, then `getsv -B` (insert size +
+    discordant tally + depth for the planted junctions that fall into the sample).  File to file, so unlike `cpu_baseline` it includes
+    the BGZF inflate + BAM parse the reference spends most of its time in.  None when the binary is not there."""
+    import shutil
+    import subprocess
+    import tempfile
+    from seeksv_amd import host
+    ref, bamidx = os.path.join(ROOT, "oracle", "_ref", "seeksv_ref"), os.path.join(ROOT, "oracle", "_ref", "bamidx")
+    if n_sample <= 0 or not (os.path.exists(ref) and os.path.exists(bamidx)):
+        return None
+    d = tempfile.mkdtemp(prefix="ssv_ref_")
+    try:
+        b = w.generate_host(0, n_sample)
+        bam = os.path.join(d, "sample.bam")
+        host.write_bam(bam, w.names, w.lens, [b])
+        subprocess.run([bamidx, bam], check=True, capture_output=True)
+        last_tid, last_pos = int(b["tid"][-1]), int(b["pos"][-1])
+        rows = [j for j in w.junctions if (w.names.index(j[0]), j[1]) <= (last_tid, last_pos)][:1000]
+        jfile = os.path.join(d, "junctions.txt")
+        with open(jfile, "w") as f:
+            for j in rows:
+                f.write("\t".join(str(x) for x in (j[0], j[1], j[2], 0, j[3], j[4], j[5], 0, 0, 0, "NA", 0, 0, 0, 0, 0, 0, 0, 0, "50M", "50M", "ACGT", "ACGT")) + "\n")
+        empty_bam, empty_clip = os.path.join(d, "empty.clip.bam"), os.path.join(d, "empty.clip")
+        host.write_bam(empty_bam, w.names, w.lens, [])
+        open(empty_clip, "w").close()
+        t0 = time.perf_counter()
+        subprocess.run([ref, "getclip", "-o", os.path.join(d, "ref"), bam], check=True, capture_output=True)
+        t1 = time.perf_counter()
+        subprocess.run([ref, "getsv", "-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip, os.path.join(d, "ref.sv"), os.path.join(d, "x.fq")], check=True, capture_output=True)
+        t2 = time.perf_counter()
+        return {"value": n_sample / (t2 - t0), "unit": "records/s", "cores": 1, "kind": "reference",
+                "sample": f"seeksv v1.2.3 binary on a BAM of the first {n_sample} records of the same workload ({os.path.getsize(bam) >> 20} MB): getclip {t1 - t0:.2f} s + "
+                          f"getsv -B with {len(rows)} junctions {t2 - t1:.2f} s, file to file (BGZF inflate and BAM parse included)"}
+    except Exception as e:  # the baseline is a courtesy: never fail the bench for it
+        return {"value": None, "unit": "records/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":
