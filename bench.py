@@ -110,7 +110,7 @@ def main():
     gen_s = time.time() - t0
 
     ctx = Context(local_rank)
-    ctx.clip_table_format(not args.ascii_table)  # sequences cross PCIe as 4-bit codes (the CLI expands them while it formats the rows)
+    ctx.clip_table_format(0 if args.ascii_table else 2)  # sequences cross PCIe as 4-bit codes, qualities as alphabet indices (the CLI expands them while it formats the rows)
     hdr = host.Header(w.names, w.lens)
     own = sp["own"] if world > 1 else None
     jtable = host.JunctionTable(w.junctions)

@@ -140,17 +140,23 @@ typedef struct {
 	const uint64_t *cigar_off; /* [n_clusters] offset into cigar */
 	const int32_t *n_cigar;    /* [n_clusters] ops of the record whose CIGAR the cluster carries */
 	const uint32_t *cigar;     /* BAM-encoded ops INCLUDING S/H (GenerateCigar drops those when printing) */
-	int32_t seq_packed;        /* 0: the layout above.  1 (ssv_clip_table_format): the two sequences are 4-bit codes, two per byte, first
-	                              base in the high nibble, index into "=ACMGRSVTWYHKDBN" (BAM's own packing):
-	                              [seq_left ceil(left_len/2) B | qual_left left_len B | seq_right ceil(right_len/2) B | qual_right right_len B];
-	                              ssv_table_block_bytes() gives a block's size.  The table is the path's output and it crosses PCIe:
-	                              a quarter fewer string bytes. */
+	int32_t seq_packed;        /* 0: the layout above.  1 (ssv_clip_table_format): a block is
+	                              [seq_left ceil(left_len/2) B | qual_left | seq_right ceil(right_len/2) B | qual_right]
+	                              with the sequences as 4-bit codes, two per byte, first base in the high nibble, index into
+	                              "=ACMGRSVTWYHKDBN" (BAM's own packing).  The table is the path's output and it crosses PCIe. */
+	int32_t qual_bits;         /* 8: qualities are characters (phred + 33), one byte each.  1, 2, 4 (format 2 only, when at most 2, 4,
+	                              16 distinct quality values occur in the pass): quality i of a piece is an index into qual_alphabet,
+	                              qual_bits wide, at bit (i * qual_bits) % 8 of byte (i * qual_bits) / 8; a piece of n qualities takes
+	                              ceil(n * qual_bits / 8) bytes.  Lossless: base qualities are most of the table's bytes and come from
+	                              a small alphabet (4 to ~40 values, depending on the sequencer). */
+	uint8_t qual_alphabet[16]; /* index -> quality character */
 } ssv_cluster_table;
 
-/* Table format of the following ssv_clip_cluster[_async] calls: packed != 0 selects the 4-bit sequence layout (default 0). */
-int ssv_clip_table_format(ssv_ctx *ctx, int packed);
-/* Bytes of one cluster's string block (a multiple of 4): 2(l+r) for ASCII, ceil(l/2)+l+ceil(r/2)+r for the packed layout, rounded up. */
-uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed);
+/* Table format of the following ssv_clip_cluster[_async] calls: 0 ASCII (default), 1 sequences as 4-bit codes, 2 the same plus
+ * qualities as alphabet indices when the pass's quality alphabet is small enough (else they stay bytes: qual_bits tells). */
+int ssv_clip_table_format(ssv_ctx *ctx, int format);
+/* Bytes of one cluster's string block (a multiple of 4). */
+uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits);
 
 /* Sort events into (contig, side, position) bins and run the greedy consensus clustering. */
 int ssv_clip_cluster(ssv_ctx *ctx, ssv_cluster_table *out);

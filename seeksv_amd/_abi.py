@@ -67,7 +67,7 @@ class OrcClusterTable(C.Structure):
 
 class HipClusterTable(C.Structure):
     """ssv_cluster_table as libseeksv_hip.so hands it out: the common part + the sequence format flag"""
-    _fields_ = ClusterTable._fields_ + [("seq_packed", C.c_int32)]
+    _fields_ = ClusterTable._fields_ + [("seq_packed", C.c_int32), ("qual_bits", C.c_int32), ("qual_alphabet", C.c_uint8 * 16)]
 
 
 class Junction(C.Structure):

@@ -541,6 +541,35 @@ __global__ void k_cluster_flags(const int32_t *__restrict__ support, int64_t E, 
 	if (j < E) flag[j] = support[j] > 0 ? 1u : 0u;
 }
 
+// Which base-quality values occur among the events (256-bit set).  The cluster table can then carry qualities as indices into that
+// alphabet (1, 2 or 4 bits each when it has at most 2, 4 or 16 members - sequencers emit 4 to ~40 distinct values) instead of bytes:
+// they are 60 % of the table, and the table is what crosses PCIe.  Persistent grid, 16 lanes per event, one set of atomics per block.
+__global__ __launch_bounds__(BLOCK) void k_qual_presence(EventArrays ev, int64_t n_events, const uint8_t *__restrict__ seq_blob, unsigned long long *__restrict__ present)
+{
+	__shared__ unsigned long long s_m[4];
+	if (threadIdx.x < 4) s_m[threadIdx.x] = 0ull;
+	__syncthreads();
+	unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+	const int gl = (int)(threadIdx.x % GROUP);
+	const int64_t stride = (int64_t)gridDim.x * GROUPS_PER_BLOCK;
+	for (int64_t e = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / GROUP; e < n_events; e += stride) {
+		const int lq = ev.lq[e];
+		const uint8_t *qp = seq_blob + ev.seq_off[e] + (uint64_t)((lq + 1) / 2);
+		if (lq > 0 && qp[0] == 0xff) continue; // qualities absent: the row prints "*"
+		for (int k = gl; k < lq; k += GROUP) {
+			const uint32_t v = qp[k];
+			const unsigned long long bit = 1ull << (v & 63u);
+			const uint32_t w = v >> 6;
+			m0 |= w == 0 ? bit : 0ull; m1 |= w == 1 ? bit : 0ull; m2 |= w == 2 ? bit : 0ull; m3 |= w == 3 ? bit : 0ull;
+		}
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { m0 |= __shfl_xor(m0, d, 64); m1 |= __shfl_xor(m1, d, 64); m2 |= __shfl_xor(m2, d, 64); m3 |= __shfl_xor(m3, d, 64); }
+	if (lane_id() == 0) { atomicOr(&s_m[0], m0); atomicOr(&s_m[1], m1); atomicOr(&s_m[2], m2); atomicOr(&s_m[3], m3); }
+	__syncthreads();
+	if (threadIdx.x < 4 && s_m[threadIdx.x]) atomicOr(&present[threadIdx.x], s_m[threadIdx.x]);
+}
+
 struct PackArgs {
 	ClusterArgs c;
 	const uint32_t *flag;     // [E]
@@ -553,6 +582,8 @@ struct PackArgs {
 	uint32_t *slot;           // dense index -> sorted slot
 	uint64_t *str_bytes;      // bytes of the cluster's string block
 	int packed;               // 1: sequences as 4-bit codes (ssv_cluster_table.seq_packed)
+	int qual_bits;            // 8: quality characters; 1, 2, 4: indices into the table's quality alphabet
+	const uint8_t *qlut;      // [256] quality character (phred + 33) -> index, when qual_bits < 8
 	uint64_t *ncig64;
 	int32_t *ncig;
 };
@@ -571,8 +602,8 @@ __global__ void k_cluster_pack_meta(PackArgs p)
 	p.ll[c] = ll; p.lr[c] = lr;
 	p.qmiss[c] = p.c.c_qmiss[j];
 	p.slot[c] = (uint32_t)j;
-	const uint64_t L = (uint64_t)ll, R = (uint64_t)lr;
-	p.str_bytes[c] = ((p.packed ? (L + 1) / 2 + L + (R + 1) / 2 + R : 2 * (L + R)) + 3ull) & ~3ull; // blocks start 4-byte aligned
+	const uint64_t L = (uint64_t)ll, R = (uint64_t)lr, W = (uint64_t)p.qual_bits;
+	p.str_bytes[c] = ((p.packed ? (L + 1) / 2 + (L * W + 7) / 8 + (R + 1) / 2 + (R * W + 7) / 8 : 2 * (L + R)) + 3ull) & ~3ull; // blocks start 4-byte aligned
 	uint32_t nc = p.c.ev.ncig[p.c.c_cig_ev[j]];
 	p.ncig[c] = (int32_t)nc;
 	p.ncig64[c] = nc;
@@ -610,6 +641,9 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 {
 	__shared__ uint32_t s_seq[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 2];
 	__shared__ uint32_t s_qual[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 2];
+	__shared__ uint8_t s_lut[256];
+	const int W = PACKED ? p.qual_bits : 8;
+	if (PACKED && W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256; made visible by the barrier below
 	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
 	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
@@ -663,7 +697,8 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 	// character through sl/ql/sr/qr below (three sources: the LDS stage, the event's packed read, the consensus storage); the byte at
 	// block offset q is then either that character or, for a packed sequence piece, two 4-bit codes.
 	const int A = PACKED ? (ll + 1) / 2 : ll, C = PACKED ? (lr + 1) / 2 : lr;
-	const int total = A + ll + C + lr;
+	const int QA = (ll * W + 7) / 8, QC = (lr * W + 7) / 8, per = 8 / W; // bytes of the two quality pieces, qualities per byte
+	const int total = A + QA + C + QC;
 	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + str_off[c]);
 	EventView v;
 	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
@@ -695,9 +730,12 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 			const int q = w * 4 + k; // byte position inside the cluster's block
 			uint32_t ch = 0;
 			if (q < total) {
-				const bool right = q >= A + ll;
-				const int r = right ? q - A - ll : q, S = right ? C : A, n = right ? lr : ll; // offset inside the half, its sequence bytes, its length
-				if (r >= S) ch = qual_at(right, r - S);
+				const bool right = q >= A + QA;
+				const int r = right ? q - A - QA : q, S = right ? C : A, n = right ? lr : ll; // offset inside the half, its sequence bytes, its length
+				if (r >= S) {
+					if (W == 8) ch = qual_at(right, r - S);
+					else for (int t = 0, i = (r - S) * per; t < per && i < n; ++t, ++i) ch |= (uint32_t)s_lut[qual_at(right, i)] << (t * W);
+				}
 				else if (!PACKED) ch = seq_at(right, r);
 				else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
 			}

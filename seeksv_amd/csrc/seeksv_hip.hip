@@ -83,10 +83,12 @@ struct ssv_ctx {
 		hipEvent_t copied = nullptr;
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
-		int packed = 0;
+		int packed = 0, qual_bits = 8;
+		uint8_t qual_alphabet[16] = {0};
 	} tab[2];
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
-	bool table_packed = false; // ssv_clip_table_format
+	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices
+	DBuf qual_lut; HBuf h_qual_lut;
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
 
@@ -341,6 +343,8 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	(void)hipStreamSynchronize(c->st);
 	bamdec_free(c);
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
+	if (c->qual_lut.p) (void)hipFree(c->qual_lut.p);
+	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
@@ -560,10 +564,30 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(E) * 4));
 	k_cluster_flags<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.support, E, P<uint32_t>(c->c_flag));
 	exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_flag), P<uint32_t>(c->c_idx), E, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
-	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 4, hipMemcpyDeviceToHost, c->st));
+	if (c->table_mode == 2) { // which quality values occur: totals[4..7] (256 bits), read back with the cluster count
+		HIPCHECK(c, hipMemsetAsync(P<uint8_t>(c->totals) + 32, 0, 32, c->st));
+		k_qual_presence<<<1024, BLOCK, 0, c->st>>>(ev, E, P<uint8_t>(c->seq_blob), reinterpret_cast<unsigned long long *>(P<uint8_t>(c->totals) + 32));
+	}
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 64, hipMemcpyDeviceToHost, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	const int64_t nc = *P<uint32_t>(c->h_totals);
 	T.n_clusters = nc;
+	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
+	if (c->table_mode == 2) {
+		// alphabet = the occurring values in increasing order; 1, 2 or 4 bits per quality when it has at most 2, 4 or 16 members
+		const uint64_t *present = P<uint64_t>(c->h_totals) + 4;
+		int n_vals = 0;
+		uint8_t vals[256];
+		for (int v = 0; v < 256; ++v) if ((present[v >> 6] >> (v & 63)) & 1ull) vals[n_vals++] = (uint8_t)v;
+		if (n_vals <= 16) {
+			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : 4;
+			CHECK(ensure(c, c->qual_lut, 256)); CHECK(ensure_host(c, c->h_qual_lut, 256));
+			uint8_t *lut = P<uint8_t>(c->h_qual_lut);
+			memset(lut, 0, 256);
+			for (int k = 0; k < n_vals; ++k) { T.qual_alphabet[k] = (uint8_t)(vals[k] + 33); lut[(uint8_t)(vals[k] + 33)] = (uint8_t)k; } // the kernels see characters (phred + 33)
+			HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
+		}
+	}
 	if (n_clusters) *n_clusters = nc;
 	if (nc == 0) return SSV_OK;
 	DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &c->o_slot, &T.o_ncig};
@@ -575,8 +599,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	pa.c = ca; pa.flag = P<uint32_t>(c->c_flag); pa.cidx = P<uint32_t>(c->c_idx);
 	pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
 	pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.slot = P<uint32_t>(c->o_slot); pa.str_bytes = P<uint64_t>(c->o_strbytes);
-	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(T.o_ncig); pa.packed = c->table_packed ? 1 : 0;
-	T.packed = pa.packed;
+	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(T.o_ncig); pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut);
 	k_cluster_pack_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
 	CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nc) * 8));
 	uint64_t *tot = P<uint64_t>(c->totals);
@@ -624,16 +647,17 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 
 static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out);
 
-uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed)
+uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits)
 {
-	const uint64_t l = (uint64_t)left_len, r = (uint64_t)right_len;
-	return ((seq_packed ? (l + 1) / 2 + l + (r + 1) / 2 + r : 2 * (l + r)) + 3) & ~(uint64_t)3;
+	const uint64_t l = (uint64_t)left_len, r = (uint64_t)right_len, w = seq_packed ? (uint64_t)qual_bits : 8;
+	return ((seq_packed ? (l + 1) / 2 + (l * w + 7) / 8 + (r + 1) / 2 + (r * w + 7) / 8 : 2 * (l + r)) + 3) & ~(uint64_t)3;
 }
 
 int ssv_clip_table_format(ssv_ctx *c, int packed)
 {
 	if (!c) return SSV_E_ARG;
-	c->table_packed = packed != 0;
+	if (packed < 0 || packed > 2) return SSV_E_ARG;
+	c->table_mode = packed;
 	return SSV_OK;
 }
 
@@ -650,7 +674,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 		HIPCHECK(c, hipEventSynchronize(T.copied));
 		T.in_flight = false;
 	}
-	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed;
+	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
 	if (T.n_clusters == 0) return SSV_OK;
 	out->tid = P<int32_t>(T.h_tid); out->pos = P<int32_t>(T.h_pos); out->side = P<uint8_t>(T.h_side); out->support = P<int32_t>(T.h_support);
 	out->left_len = P<int32_t>(T.h_ll); out->right_len = P<int32_t>(T.h_lr); out->qual_missing = P<uint8_t>(T.h_qmiss); out->str_off = P<uint64_t>(T.h_stroff);

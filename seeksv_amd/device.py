@@ -104,8 +104,9 @@ class Context:
         self._check(self._lib.ssv_clip_begin(self._h, C.byref(p)), "ssv_clip_begin")
 
     def clip_table_format(self, packed):
-        """packed=True: cluster tables carry their sequences as 4-bit codes (a quarter fewer string bytes over PCIe); host.cluster_strings decodes both"""
-        self._check(self._lib.ssv_clip_table_format(self._h, int(bool(packed))), "ssv_clip_table_format")
+        """0 / False: ASCII; 1 / True: sequences as 4-bit codes; 2: also qualities as indices into the pass's quality alphabet when it is
+        small (fewer table bytes over PCIe); host.cluster_strings decodes all three"""
+        self._check(self._lib.ssv_clip_table_format(self._h, int(packed)), "ssv_clip_table_format")
 
     def clip_scan(self, batch):
         b, keep = self._as_batch(batch)

@@ -208,12 +208,13 @@ def table_to_dict(t):
         return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True)
 
     packed = int(getattr(t, "seq_packed", 0))
-    d = dict(n_clusters=n, n_events=t.n_events, seq_packed=packed)
+    qbits = int(getattr(t, "qual_bits", 8)) if packed else 8
+    d = dict(n_clusters=n, n_events=t.n_events, seq_packed=packed, qual_bits=qbits, qual_alphabet=bytes(getattr(t, "qual_alphabet", b"")))
     for name, dt in (("tid", np.int32), ("pos", np.int32), ("side", np.uint8), ("support", np.int32), ("left_len", np.int32),
                      ("right_len", np.int32), ("qual_missing", np.uint8), ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
         d[name] = arr(getattr(t, name), n, dt)
     if n:
-        sb = int(d["str_off"][-1]) + block_bytes(int(d["left_len"][-1]), int(d["right_len"][-1]), packed)
+        sb = int(d["str_off"][-1]) + block_bytes(int(d["left_len"][-1]), int(d["right_len"][-1]), packed, qbits)
         cb = int(d["cigar_off"][-1]) + int(d["n_cigar"][-1])
     else:
         sb = cb = 0
@@ -225,9 +226,10 @@ def table_to_dict(t):
 NT16 = "=ACMGRSVTWYHKDBN"
 
 
-def block_bytes(ll, lr, packed):
+def block_bytes(ll, lr, packed, qual_bits=8):
     """ssv_table_block_bytes (include/seeksv_hip.h)"""
-    return (((ll + 1) // 2 + ll + (lr + 1) // 2 + lr if packed else 2 * (ll + lr)) + 3) & ~3
+    w = qual_bits if packed else 8
+    return (((ll + 1) // 2 + (ll * w + 7) // 8 + (lr + 1) // 2 + (lr * w + 7) // 8 if packed else 2 * (ll + lr)) + 3) & ~3
 
 
 def cluster_strings(d, k):
@@ -235,14 +237,21 @@ def cluster_strings(d, k):
     o, ll, lr = int(d["str_off"][k]), int(d["left_len"][k]), int(d["right_len"][k])
     s = d["str"]
     if d.get("seq_packed"):
-        a, c = (ll + 1) // 2, (lr + 1) // 2
+        a, c, w = (ll + 1) // 2, (lr + 1) // 2, int(d.get("qual_bits", 8))
+        qa, qc = (ll * w + 7) // 8, (lr * w + 7) // 8
+        alphabet = d.get("qual_alphabet", b"")
 
         def unpack(buf, n):
             return "".join(NT16[(int(buf[i >> 1]) >> (0 if i & 1 else 4)) & 15] for i in range(n))
+
+        def quals(buf, n):
+            if w == 8:
+                return buf[:n].tobytes().decode("latin-1")
+            return "".join(chr(alphabet[(int(buf[(i * w) >> 3]) >> ((i * w) & 7)) & ((1 << w) - 1)]) for i in range(n))
         sl = unpack(s[o:o + a], ll)
-        ql = s[o + a:o + a + ll].tobytes().decode("latin-1")
-        sr = unpack(s[o + a + ll:o + a + ll + c], lr)
-        qr = s[o + a + ll + c:o + a + ll + c + lr].tobytes().decode("latin-1")
+        ql = quals(s[o + a:o + a + qa], ll)
+        sr = unpack(s[o + a + qa:o + a + qa + c], lr)
+        qr = quals(s[o + a + qa + c:o + a + qa + c + qc], lr)
     else:
         sl = s[o:o + ll].tobytes().decode("latin-1")
         ql = s[o + ll:o + 2 * ll].tobytes().decode("latin-1")

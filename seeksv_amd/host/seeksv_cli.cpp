@@ -317,7 +317,7 @@ static int cmd_getclip(int argc, char **argv)
 	memset(&p, 0, sizeof(p));
 	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
 	if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-	ssv_clip_table_format(ctx, 1); // sequences as 4-bit codes over PCIe; expanded by the formatting threads below
+	ssv_clip_table_format(ctx, 2); // sequences as 4-bit codes, qualities as alphabet indices over PCIe; expanded by the formatting threads below
 	BatchSource src;
 	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 	ssvh_bam *bam = src.bam;
@@ -380,13 +380,21 @@ static int cmd_getclip(int argc, char **argv)
 			const uint8_t *s = t.str + t.str_off[k];
 			const size_t ll = (size_t)t.left_len[k], lr = (size_t)t.right_len[k];
 			const char *sl, *ql, *sr, *qr;
-			if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right]
-				const size_t a = (ll + 1) / 2, c2 = (lr + 1) / 2;
-				seqbuf.resize(ll + lr);
+			if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right], qualities possibly as alphabet indices
+				const size_t W = (size_t)t.qual_bits, a = (ll + 1) / 2, c2 = (lr + 1) / 2, qa = (ll * W + 7) / 8;
+				seqbuf.resize(2 * (ll + lr));
 				for (size_t i = 0; i < ll; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((~i & 1) << 2)) & 15];
-				for (size_t i = 0; i < lr; ++i) seqbuf[ll + i] = "=ACMGRSVTWYHKDBN"[(s[a + ll + (i >> 1)] >> ((~i & 1) << 2)) & 15];
+				for (size_t i = 0; i < lr; ++i) seqbuf[ll + i] = "=ACMGRSVTWYHKDBN"[(s[a + qa + (i >> 1)] >> ((~i & 1) << 2)) & 15];
 				sl = seqbuf.data(); sr = seqbuf.data() + ll;
-				ql = (const char *)s + a; qr = (const char *)s + a + ll + c2;
+				if (W == 8) { ql = (const char *)s + a; qr = (const char *)s + a + qa + c2; }
+				else {
+					const uint8_t *pl = s + a, *pr = s + a + qa + c2;
+					const unsigned mask = (1u << W) - 1u;
+					char *dl = &seqbuf[ll + lr], *dr = dl + ll;
+					for (size_t i = 0; i < ll; ++i) dl[i] = (char)t.qual_alphabet[(pl[(i * W) >> 3] >> ((i * W) & 7)) & mask];
+					for (size_t i = 0; i < lr; ++i) dr[i] = (char)t.qual_alphabet[(pr[(i * W) >> 3] >> ((i * W) & 7)) & mask];
+					ql = dl; qr = dr;
+				}
 			} else { sl = (const char *)s; ql = sl + ll; sr = sl + 2 * ll; qr = sl + 2 * ll + lr; }
 			size_t lql = ll, lqr = lr;
 			if (t.qual_missing[k]) { ql = qr = "*"; lql = lqr = 1; }

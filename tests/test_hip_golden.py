@@ -43,11 +43,13 @@ def test_getclip_hip_matches_reference(ctx, sub, bam, prefix, kw, batch_records)
 
 
 @pytest.mark.parametrize("sub,bam,prefix,kw", GETCLIP_CASES, ids=[c[2] for c in GETCLIP_CASES])
-def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw):
-    """ssv_clip_table_format(1): sequences leave the GPU as 4-bit codes; decoded, the table is the ASCII table (and the reference's rows)"""
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw, fmt):
+    """ssv_clip_table_format: 1 = sequences leave the GPU as 4-bit codes, 2 = also qualities as indices into the pass's quality alphabet when
+    it has at most 16 members; decoded, the table is the ASCII table (and the reference's rows)"""
     names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, sub, bam), 1 << 20)
     ref = ctx.getclip(batches, **kw)
-    ctx.clip_table_format(True)
+    ctx.clip_table_format(fmt)
     try:
         d = ctx.getclip(batches, **kw)
     finally:
@@ -58,7 +60,8 @@ def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw):
     assert all(host.cluster_strings(d, k) == host.cluster_strings(ref, k) for k in range(d["n_clusters"]))
     if d["n_clusters"]:
         assert len(d["str"]) < len(ref["str"])
-        offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1) for a, b in zip(d["left_len"], d["right_len"])])])
+        assert d["qual_bits"] in ((8,) if fmt == 1 else (1, 2, 4, 8))
+        offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1, d["qual_bits"]) for a, b in zip(d["left_len"], d["right_len"])])])
         assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))
     clip, fq = host.format_clip_outputs(d, names)
     assert clip == G.read_text(sub, prefix + ".clip.txt") and fq == G.read_text(sub, prefix + ".clip.fq.txt")
