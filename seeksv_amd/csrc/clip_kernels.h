@@ -351,26 +351,45 @@ constexpr int GROUP = 16;                      // lanes that cooperate on one ev
 constexpr int GROUPS_PER_WAVE = WAVE / GROUP;  // 4 items in flight per wavefront: the per-item metadata loads overlap
 constexpr int GROUPS_PER_BLOCK = BLOCK / GROUP;
 
-__global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays ev, int64_t ev_base, int64_t n_new, uint8_t *__restrict__ seq_blob, uint32_t *__restrict__ cig_blob)
+__global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays ev, int64_t ev_base, int64_t n_new, uint8_t *__restrict__ seq_blob, uint32_t *__restrict__ cig_blob,
+                                                       uint8_t *__restrict__ qual_present)
 {
+	// which base-quality values occur among the events (the cluster table can carry qualities as indices into that alphabet, see
+	// ssv_clip_table_format): byte flags in LDS while the quality bytes pass through the registers anyway, one plain store per
+	// occurring value and workgroup at the end.  Events without qualities (first quality byte 0xff, the row prints "*") do not count.
+	__shared__ uint8_t s_present[BLOCK];
+	s_present[threadIdx.x] = 0;
+	__syncthreads();
 	const int64_t w = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
-	if (w >= n_new) return;
-	const uint32_t gl = threadIdx.x % GROUP;
-	int64_t e = ev_base + w;
-	const uint8_t *src = b.seqqual + ev.src_seq[e];
-	uint32_t *dst = reinterpret_cast<uint32_t *>(seq_blob + ev.seq_off[e]);
-	const uint32_t nb = ev.seq_bytes[e];          // padded to a multiple of 4
-	const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
-	const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src - mis);
-	for (uint32_t k = gl; k < nb / 4; k += GROUP) {
-		uint32_t lo = s4[k];
-		uint32_t hi = mis ? s4[k + 1] : 0u;       // may read up to 7 bytes past the entry: see the slack rule in seeksv_hip.h
-		dst[k] = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+	if (w < n_new) {
+		const uint32_t gl = threadIdx.x % GROUP;
+		int64_t e = ev_base + w;
+		const uint8_t *src = b.seqqual + ev.src_seq[e];
+		uint32_t *dst = reinterpret_cast<uint32_t *>(seq_blob + ev.seq_off[e]);
+		const uint32_t nb = ev.seq_bytes[e];          // padded to a multiple of 4
+		const uint32_t lq = (uint32_t)ev.lq[e];
+		const uint32_t q0 = (lq + 1) / 2, q1 = q0 + lq; // the quality bytes of the entry
+		const bool has_qual = lq > 0 && src[q0] != 0xff;
+		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
+		const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src - mis);
+		for (uint32_t k = gl; k < nb / 4; k += GROUP) {
+			uint32_t lo = s4[k];
+			uint32_t hi = mis ? s4[k + 1] : 0u;       // may read up to 7 bytes past the entry: see the slack rule in seeksv_hip.h
+			const uint32_t word = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+			dst[k] = word;
+			if (has_qual && 4 * k + 4 > q0 && 4 * k < q1) {
+#pragma unroll
+				for (uint32_t j = 0; j < 4; ++j)
+					if (4 * k + j >= q0 && 4 * k + j < q1) s_present[(word >> (8 * j)) & 0xffu] = 1;
+			}
+		}
+		const uint32_t *cs = b.cigar + ev.src_cig[e];
+		uint32_t *cd = cig_blob + ev.cig_off[e];
+		uint32_t nc = ev.ncig[e];
+		for (uint32_t k = gl; k < nc; k += GROUP) cd[k] = cs[k];
 	}
-	const uint32_t *cs = b.cigar + ev.src_cig[e];
-	uint32_t *cd = cig_blob + ev.cig_off[e];
-	uint32_t nc = ev.ncig[e];
-	for (uint32_t k = gl; k < nc; k += GROUP) cd[k] = cs[k];
+	__syncthreads();
+	if (s_present[threadIdx.x]) qual_present[threadIdx.x] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -539,35 +558,6 @@ __global__ void k_cluster_flags(const int32_t *__restrict__ support, int64_t E, 
 {
 	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j < E) flag[j] = support[j] > 0 ? 1u : 0u;
-}
-
-// Which base-quality values occur among the events (256-bit set).  The cluster table can then carry qualities as indices into that
-// alphabet (1, 2 or 4 bits each when it has at most 2, 4 or 16 members - sequencers emit 4 to ~40 distinct values) instead of bytes:
-// they are 60 % of the table, and the table is what crosses PCIe.  Persistent grid, 16 lanes per event, one set of atomics per block.
-__global__ __launch_bounds__(BLOCK) void k_qual_presence(EventArrays ev, int64_t n_events, const uint8_t *__restrict__ seq_blob, unsigned long long *__restrict__ present)
-{
-	__shared__ unsigned long long s_m[4];
-	if (threadIdx.x < 4) s_m[threadIdx.x] = 0ull;
-	__syncthreads();
-	unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-	const int gl = (int)(threadIdx.x % GROUP);
-	const int64_t stride = (int64_t)gridDim.x * GROUPS_PER_BLOCK;
-	for (int64_t e = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / GROUP; e < n_events; e += stride) {
-		const int lq = ev.lq[e];
-		const uint8_t *qp = seq_blob + ev.seq_off[e] + (uint64_t)((lq + 1) / 2);
-		if (lq > 0 && qp[0] == 0xff) continue; // qualities absent: the row prints "*"
-		for (int k = gl; k < lq; k += GROUP) {
-			const uint32_t v = qp[k];
-			const unsigned long long bit = 1ull << (v & 63u);
-			const uint32_t w = v >> 6;
-			m0 |= w == 0 ? bit : 0ull; m1 |= w == 1 ? bit : 0ull; m2 |= w == 2 ? bit : 0ull; m3 |= w == 3 ? bit : 0ull;
-		}
-	}
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) { m0 |= __shfl_xor(m0, d, 64); m1 |= __shfl_xor(m1, d, 64); m2 |= __shfl_xor(m2, d, 64); m3 |= __shfl_xor(m3, d, 64); }
-	if (lane_id() == 0) { atomicOr(&s_m[0], m0); atomicOr(&s_m[1], m1); atomicOr(&s_m[2], m2); atomicOr(&s_m[3], m3); }
-	__syncthreads();
-	if (threadIdx.x < 4 && s_m[threadIdx.x]) atomicOr(&present[threadIdx.x], s_m[threadIdx.x]);
 }
 
 struct PackArgs {

@@ -88,7 +88,7 @@ struct ssv_ctx {
 	} tab[2];
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
 	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices
-	DBuf qual_lut; HBuf h_qual_lut;
+	DBuf qual_lut, qual_present; HBuf h_qual_lut, h_qual_present; // qual_present: 256 byte flags, set by k_clip_gather
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
 
@@ -345,6 +345,8 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
 	if (c->qual_lut.p) (void)hipFree(c->qual_lut.p);
 	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
+	if (c->qual_present.p) (void)hipFree(c->qual_present.p);
+	if (c->h_qual_present.p) (void)hipHostFree(c->h_qual_present.p);
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
@@ -394,6 +396,8 @@ int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
 	CHECK(ensure_host(c, c->h_counters, sizeof(ClipCounters)));
 	HIPCHECK(c, hipMemsetAsync(c->d_last_tid.p, 0, 16, c->st));
+	CHECK(ensure(c, c->qual_present, 256)); CHECK(ensure_host(c, c->h_qual_present, 256));
+	HIPCHECK(c, hipMemsetAsync(c->qual_present.p, 0, 256, c->st));
 	int *h_lt = P<int>(c->h_counters);
 	*h_lt = p->initial_last_tid; // 0 in the reference, clip_reads.h:407
 	HIPCHECK(c, hipMemcpyAsync(c->d_last_tid.p, h_lt, 4, hipMemcpyHostToDevice, c->st));
@@ -480,7 +484,8 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			ProfScope ps(c, P_CLIP_GATHER, nb);
 			CHECK(ensure(c, c->seq_blob, hc->seq_total + 16, true, c->seq_used));
 			CHECK(ensure(c, c->cig_blob, hc->cig_total * 4 + 16, true, c->cig_used * 4));
-			k_clip_gather<<<grid_for(nb, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob));
+			k_clip_gather<<<grid_for(nb, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob),
+			                                                                          P<uint8_t>(c->qual_present));
 			HIPCHECK(c, hipGetLastError());
 			c->n_events += nb; c->seq_used = hc->seq_total; c->cig_used = hc->cig_total;
 			c->max_key = std::max<uint64_t>(c->max_key, hc->max_key); c->max_ll = std::max(c->max_ll, hc->max_ll); c->max_lr = std::max(c->max_lr, hc->max_lr);
@@ -564,10 +569,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(E) * 4));
 	k_cluster_flags<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.support, E, P<uint32_t>(c->c_flag));
 	exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_flag), P<uint32_t>(c->c_idx), E, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
-	if (c->table_mode == 2) { // which quality values occur: totals[4..7] (256 bits), read back with the cluster count
-		HIPCHECK(c, hipMemsetAsync(P<uint8_t>(c->totals) + 32, 0, 32, c->st));
-		k_qual_presence<<<1024, BLOCK, 0, c->st>>>(ev, E, P<uint8_t>(c->seq_blob), reinterpret_cast<unsigned long long *>(P<uint8_t>(c->totals) + 32));
-	}
+	if (c->table_mode == 2) HIPCHECK(c, hipMemcpyAsync(c->h_qual_present.p, c->qual_present.p, 256, hipMemcpyDeviceToHost, c->st)); // which quality values occur (k_clip_gather)
 	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 64, hipMemcpyDeviceToHost, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	const int64_t nc = *P<uint32_t>(c->h_totals);
@@ -575,10 +577,10 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
 	if (c->table_mode == 2) {
 		// alphabet = the occurring values in increasing order; 1, 2 or 4 bits per quality when it has at most 2, 4 or 16 members
-		const uint64_t *present = P<uint64_t>(c->h_totals) + 4;
+		const uint8_t *present = P<uint8_t>(c->h_qual_present);
 		int n_vals = 0;
 		uint8_t vals[256];
-		for (int v = 0; v < 256; ++v) if ((present[v >> 6] >> (v & 63)) & 1ull) vals[n_vals++] = (uint8_t)v;
+		for (int v = 0; v < 256; ++v) if (present[v]) vals[n_vals++] = (uint8_t)v;
 		if (n_vals <= 16) {
 			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : 4;
 			CHECK(ensure(c, c->qual_lut, 256)); CHECK(ensure_host(c, c->h_qual_lut, 256));
