@@ -576,6 +576,12 @@ struct PackArgs {
 	const uint8_t *qlut;      // [256] quality character (phred + 33) -> index, when qual_bits < 8
 	uint64_t *ncig64;
 	int32_t *ncig;
+	// where a cluster's characters come from, resolved once per cluster by k_cluster_pack_meta so that the pack kernel starts with
+	// coalesced loads instead of a slot -> event -> offset chain: src_lq >= 0: single-event cluster, the event's entry in seq_blob starts
+	// at src_off, its seq_left at base src_begin; src_lq < 0: consensus storage of a multi-event bin
+	uint64_t *src_off;
+	int32_t *src_begin, *src_lq;
+	uint64_t *src_cig;        // where the carrying event's CIGAR starts in cig_blob
 };
 
 __global__ void k_cluster_pack_meta(PackArgs p)
@@ -597,6 +603,14 @@ __global__ void k_cluster_pack_meta(PackArgs p)
 	uint32_t nc = p.c.ev.ncig[p.c.c_cig_ev[j]];
 	p.ncig[c] = (int32_t)nc;
 	p.ncig64[c] = nc;
+	if (p.src_off) {
+		const uint32_t e = p.c.c_cig_ev[j];
+		const bool single = !p.c.mflag[j];
+		p.src_off[c] = single ? p.c.ev.seq_off[e] : 0ull;
+		p.src_begin[c] = single ? p.c.ev.begin[e] : 0;
+		p.src_lq[c] = single ? p.c.ev.lq[e] : -1;
+		p.src_cig[c] = p.c.ev.cig_off[e];
+	}
 }
 
 // bam_nt16_rev_table "=ACMGRSVTWYHKDBN" as two little-endian 64-bit words: nibble -> ASCII without touching memory
@@ -624,16 +638,12 @@ constexpr int PACK_MAX_LQ = 256; // reads up to this length take the LDS-staged 
 // qualities (GetSeq, clip_reads.cpp:286-306): the group expands the read once into LDS with dword loads (8 bases per packed dword,
 // 4 qualities per dword via alignbyte and a packed +33) and then composes the output dwords from LDS bytes.  Clusters of multi-event
 // bins come from their consensus storage (left part un-reversed); reads longer than PACK_MAX_LQ take the per-byte path.
-// PACKED: the two sequences leave as 4-bit codes (ssv_cluster_table.seq_packed); the LDS stage then holds codes instead of characters.
-template <bool PACKED>
-__global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
+// This is the ASCII layout (ssv_clip_table_format 0, the C ABI's default); the packed layouts have their own kernel below.
+__global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
                                                                 const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
 {
 	__shared__ uint32_t s_seq[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 2];
 	__shared__ uint32_t s_qual[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 2];
-	__shared__ uint8_t s_lut[256];
-	const int W = PACKED ? p.qual_bits : 8;
-	if (PACKED && W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256; made visible by the barrier below
 	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
 	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
@@ -664,8 +674,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 #pragma unroll
 			for (int b = 0; b < 2; ++b) { // packed bytes 0,1 -> chars 0..3 ; bytes 2,3 -> chars 4..7
 				const uint32_t b0 = (pk >> (16 * b)) & 0xffu, b1 = (pk >> (16 * b + 8)) & 0xffu;
-				const uint32_t four = PACKED ? ((b0 >> 4) | ((b0 & 15u) << 8) | ((b1 >> 4) << 16) | ((b1 & 15u) << 24))
-				                             : (nt16_char(b0 >> 4) | (nt16_char(b0 & 15u) << 8) | (nt16_char(b1 >> 4) << 16) | (nt16_char(b1 & 15u) << 24));
+				const uint32_t four = nt16_char(b0 >> 4) | (nt16_char(b0 & 15u) << 8) | (nt16_char(b1 >> 4) << 16) | (nt16_char(b1 & 15u) << 24);
 				if (b == 0) lo = four; else hi = four;
 			}
 			s_seq[grp][2 * w] = lo; s_seq[grp][2 * w + 1] = hi;
@@ -684,11 +693,8 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 	__syncthreads();
 	if (!active) return;
 	// one block = four pieces: sequence / quality of the left part, sequence / quality of the right part.  A piece position maps to a
-	// character through sl/ql/sr/qr below (three sources: the LDS stage, the event's packed read, the consensus storage); the byte at
-	// block offset q is then either that character or, for a packed sequence piece, two 4-bit codes.
-	const int A = PACKED ? (ll + 1) / 2 : ll, C = PACKED ? (lr + 1) / 2 : lr;
-	const int QA = (ll * W + 7) / 8, QC = (lr * W + 7) / 8, per = 8 / W; // bytes of the two quality pieces, qualities per byte
-	const int total = A + QA + C + QC;
+	// character through seq_at / qual_at below (three sources: the LDS stage, the event's packed read, the consensus storage).
+	const int total = 2 * (ll + lr);
 	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + str_off[c]);
 	EventView v;
 	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
@@ -703,11 +709,9 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 			cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
 		}
 	}
-	// sequence position -> character (ASCII layout) or 4-bit code (packed layout); in the stage the conversion has been done already
 	auto seq_at = [&](bool right, int i) -> uint32_t {
 		if (staged) return sq[begin + (right ? ll : 0) + i];
-		const uint32_t ch = single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i]);
-		return PACKED ? nt16_code(ch) : ch;
+		return single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i]);
 	};
 	auto qual_at = [&](bool right, int i) -> uint32_t {
 		if (staged) return qq[begin + (right ? ll : 0) + i];
@@ -720,14 +724,9 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 			const int q = w * 4 + k; // byte position inside the cluster's block
 			uint32_t ch = 0;
 			if (q < total) {
-				const bool right = q >= A + QA;
-				const int r = right ? q - A - QA : q, S = right ? C : A, n = right ? lr : ll; // offset inside the half, its sequence bytes, its length
-				if (r >= S) {
-					if (W == 8) ch = qual_at(right, r - S);
-					else for (int t = 0, i = (r - S) * per; t < per && i < n; ++t, ++i) ch |= (uint32_t)s_lut[qual_at(right, i)] << (t * W);
-				}
-				else if (!PACKED) ch = seq_at(right, r);
-				else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
+				const bool right = q >= 2 * ll;
+				const int r = right ? q - 2 * ll : q, S = right ? lr : ll; // offset inside the half, its sequence bytes
+				ch = r >= S ? qual_at(right, r - S) : seq_at(right, r);
 			}
 			word |= ch << (8 * k);
 		}
@@ -737,6 +736,177 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_strings(PackArgs p, int6
 	uint32_t *dc = out_cig + cig_off[c];
 	const int nc = p.ncig[c];
 	for (int i = gl; i < nc; i += GROUP) dc[i] = src[i];
+}
+
+// ---- packed table (ssv_clip_table_format 1 / 2): sequences as 4-bit codes, qualities W bits each ----
+//
+// A cluster's block is four pieces [seq_left | qual_left | seq_right | qual_right] at byte offsets that are not dword aligned, cut
+// out of a read at arbitrary nibble / byte offsets.  Composing the block byte by byte costs ~100 instructions per byte; here every
+// lane works on whole dwords twice:
+//   0. the event's entry (packed bases + qualities, <= 384 B) into LDS: one batch of independent, coalesced loads per cluster.
+//   1. piece dwords into LDS: a sequence piece dword is 8 nibbles of the BAM-packed read = a 40-bit window of the source shifted by
+//      0 or 4 bits (the table keeps BAM's nibble order); a quality piece dword is 32 / W source bytes through the alphabet LUT.
+//      Tails are zeroed, and every piece sits between zero guard dwords.
+//   2. output dword at block byte o = OR over the (1, rarely 2-3) pieces it overlaps of that piece's bytes [o - start, o - start + 4):
+//      two LDS dwords and one alignbyte each; the guards supply the zeros on either side of a piece.
+// 16 lanes per cluster.  Clusters of multi-event bins (consensus storage) and reads longer than PACK_MAX_LQ take the bytewise path.
+constexpr int PACK_RAW_DWORDS = (PACK_MAX_LQ / 2 + PACK_MAX_LQ) / 4 + 2; // entry of a PACK_MAX_LQ read + read-ahead
+constexpr int PACK_LDS_DWORDS = (PACK_MAX_LQ / 8 + 2) + (PACK_MAX_LQ / 4 + 2) + 5 + 1; // two sequence + two quality pieces of left_len + right_len <= PACK_MAX_LQ (W = 8 worst case) + guards
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
+                                                              const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
+{
+	__shared__ uint32_t s_piece[GROUPS_PER_BLOCK][PACK_LDS_DWORDS];
+	__shared__ uint32_t s_raw[GROUPS_PER_BLOCK][PACK_RAW_DWORDS]; // the event's entry (packed bases, qualities) as it lies in the blob
+	__shared__ uint8_t s_lut[256]; // phred -> alphabet index
+	if (W < 8) s_lut[threadIdx.x] = p.qlut[(threadIdx.x + 33u) & 255u]; // BLOCK == 256; p.qlut is indexed by character
+	const int grp = (int)(threadIdx.x / GROUP);
+	const int gl = (int)(threadIdx.x % GROUP);
+	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const bool active = c < n_clusters;
+	int ll = 0, lr = 0, lq = -1, begin = 0;
+	uint64_t soff = 0;
+	int ncg = 0;
+	uint64_t scig = 0, dcig = 0, doff = 0;
+	if (active) { ll = p.ll[c]; lr = p.lr[c]; lq = p.src_lq[c]; begin = p.src_begin[c]; soff = p.src_off[c]; ncg = p.ncig[c]; scig = p.src_cig[c]; dcig = cig_off[c]; doff = str_off[c]; }
+	const uint32_t cig_first = gl < ncg ? cig_blob[scig + gl] : 0u; // issued with the entry's loads below; CIGARs longer than 16 ops finish at the end
+	const bool fast = active && lq >= 0 && lq <= PACK_MAX_LQ && ll + lr <= PACK_MAX_LQ;
+	// piece k: 0 seq_left, 1 qual_left, 2 seq_right, 3 qual_right; nB bytes, nD dwords, at block byte oP, at LDS dword st
+	constexpr int QPD = 32 / W; // qualities per dword
+	int nB[4], nD[4], oP[4], st[4];
+	nB[0] = (ll + 1) / 2; nB[1] = (ll * W + 7) / 8; nB[2] = (lr + 1) / 2; nB[3] = (lr * W + 7) / 8;
+	{
+		int o = 0, s_ = 1;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { nD[k] = (nB[k] + 3) / 4; oP[k] = o; st[k] = s_; o += nB[k]; s_ += nD[k] + 1; }
+	}
+	const int total = oP[3] + nB[3];
+	uint32_t *L = s_piece[grp];
+	const uint32_t *s4 = s_raw[grp];
+	const int qb = (lq + 1) / 2; // first quality byte of the entry
+	if (fast) {
+		// 0. the whole entry into LDS with one batch of independent loads (one memory round trip per cluster; everything after reads LDS)
+		const uint32_t *g4 = reinterpret_cast<const uint32_t *>(p.c.seq_blob + soff); // entries are 4-byte aligned
+		const int nraw = (qb + lq + 3) / 4 + 1; // + one dword of read-ahead for the unaligned windows below (blob slack, see k_clip_gather)
+		uint32_t r[PACK_RAW_DWORDS / GROUP + 1];
+#pragma unroll
+		for (int u = 0; u < PACK_RAW_DWORDS / GROUP + 1; ++u) { const int i = gl + GROUP * u; r[u] = i < nraw ? g4[i] : 0u; }
+#pragma unroll
+		for (int u = 0; u < PACK_RAW_DWORDS / GROUP + 1; ++u) { const int i = gl + GROUP * u; if (i < nraw) s_raw[grp][i] = r[u]; }
+	}
+	__syncthreads(); // s_raw, s_lut
+	if (fast) {
+		const bool qmiss = lq > 0 && ((s4[qb >> 2] >> (8 * (qb & 3))) & 0xffu) == 0xffu;
+		if (gl == 0) L[0] = 0u; // guards: before the first piece and after each piece
+#pragma unroll
+		for (int k = 0; k < 4; ++k) if (gl == k + 1) L[st[k] + nD[k]] = 0u;
+		// sequence pieces
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int nib0 = begin + (h ? ll : 0), len = h ? lr : ll, k = 2 * h;
+			for (int t = gl; t < nD[k]; t += GROUP) {
+				const int B = (nib0 >> 1) + 4 * t;
+				const uint32_t d0 = s4[B >> 2], d1 = s4[(B >> 2) + 1];
+				const uint64_t X = (((uint64_t)d1 << 32) | d0) >> (8 * (B & 3));
+				const uint32_t lo = (uint32_t)X, nx = (uint32_t)(X >> 8);
+				uint32_t v = (nib0 & 1) ? (((lo & 0x0f0f0f0fu) << 4) | ((nx >> 4) & 0x0f0f0f0fu)) : lo;
+				const int rem = len - 8 * t; // nibbles of the piece in this dword
+				if (rem < 8) v &= ((1u << (8 * (rem >> 1))) - 1u) | ((rem & 1) ? 0xf0u << (8 * (rem >> 1)) : 0u);
+				L[st[k] + t] = v;
+			}
+		}
+		// quality pieces
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int q0 = begin + (h ? ll : 0), len = h ? lr : ll, k = 2 * h + 1;
+			for (int t = gl; t < nD[k]; t += GROUP) {
+				const int a = qb + q0 + t * QPD; // first source byte
+				const uint32_t *q4 = s4 + (a >> 2);
+				const int sh = a & 3;
+				const int rem = len - t * QPD;   // qualities of the piece in this dword
+				uint32_t v = 0;
+				uint32_t prev = q4[0];
+#pragma unroll
+				for (int j = 0; j < QPD / 4; ++j) {
+					if (4 * j >= rem) break; // nothing of the piece left (also keeps the reads inside the staged entry)
+					const uint32_t next = q4[j + 1];
+					const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
+					prev = next;
+					if (W == 8) v = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
+					else {
+#pragma unroll
+						for (int b = 0; b < 4; ++b) {
+							const uint32_t ph = qmiss ? (uint32_t)('*' - 33) : (four >> (8 * b)) & 0xffu;
+							v |= (uint32_t)s_lut[ph] << ((4 * j + b) * W);
+						}
+					}
+				}
+				if (rem < QPD) v &= (W == 8 ? (1u << (8 * rem)) : (1u << (rem * W))) - 1u;
+				L[st[k] + t] = v;
+			}
+		}
+	}
+	__syncthreads();
+	if (!active) return;
+	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + doff);
+	if (fast) {
+		for (int w = gl; 4 * w < total; w += GROUP) {
+			const int o = 4 * w;
+			uint32_t word = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				if (o + 4 > oP[k] && o < oP[k] + nB[k]) {
+					const int r0 = o - oP[k];     // -3 .. nB - 1
+					const int i = st[k] + (r0 >> 2); // floor: -1 reads the guard in front of the piece
+					word |= __builtin_amdgcn_alignbyte(L[i + 1], L[i], (uint32_t)(r0 & 3));
+				}
+			}
+			d[w] = word;
+		}
+	} else {
+		// bytewise: from the event's packed read (long reads) or from the consensus storage (left part kept reversed)
+		const int64_t j = p.slot[c];
+		const bool single = lq >= 0;
+		EventView v;
+		const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+		if (single) {
+			v.sp = p.c.seq_blob + soff; v.qp = v.sp + (lq + 1) / 2; v.begin = begin; v.ll = ll; v.lr = lr; v.qmiss = lq > 0 && v.qp[0] == 0xff;
+		} else {
+			const int64_t stride = 2ll * (p.c.SL + p.c.SR);
+			cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
+			cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
+		}
+		auto seq_at = [&](bool right, int i) -> uint32_t {
+			return nt16_code(single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i]));
+		};
+		auto qual_at = [&](bool right, int i) -> uint32_t { // character
+			return single ? (uint32_t)(uint8_t)v.qual(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rq[i] : cq[ll - 1 - i]);
+		};
+		constexpr int per = 8 / W;
+		const int A = nB[0], QA = nB[1], C = nB[2];
+		for (int w = gl; w * 4 < total; w += GROUP) {
+			uint32_t word = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int q = w * 4 + k;
+				uint32_t ch = 0;
+				if (q < total) {
+					const bool right = q >= A + QA;
+					const int r = right ? q - A - QA : q, S = right ? C : A, n = right ? lr : ll;
+					if (r >= S) {
+						if (W == 8) ch = qual_at(right, r - S);
+						else for (int t = 0, i = (r - S) * per; t < per && i < n; ++t, ++i) ch |= (uint32_t)s_lut[(qual_at(right, i) - 33u) & 255u] << (t * W);
+					} else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
+				}
+				word |= ch << (8 * k);
+			}
+			d[w] = word;
+		}
+	}
+	uint32_t *dc = out_cig + dcig;
+	if (gl < ncg) dc[gl] = cig_first;
+	for (int i = gl + GROUP; i < ncg; i += GROUP) dc[i] = cig_blob[scig + i];
 }
 
 } // namespace ssv

@@ -163,3 +163,51 @@ def test_full_size_properties(ctx):
     assert np.array_equal(c1, oc) and np.array_equal(r1, ors) and np.array_equal(p1, opd)
     assert c1.sum() > 0 and r1.sum() > 0
     plan.close(), hdr.close()
+
+
+def _remap_qualities(batch, alphabet):
+    """a copy of the batch whose base qualities are drawn from `alphabet` (deterministically, from the old value and the position)"""
+    b = dict(batch)
+    sq = batch["seqqual"].copy()
+    alphabet = np.asarray(alphabet, dtype=np.uint8)
+    for off, lq in zip(batch["seq_off"], batch["l_qseq"]):
+        if off == np.uint64(0xFFFFFFFFFFFFFFFF) or lq <= 0:
+            continue
+        q0 = int(off) + (int(lq) + 1) // 2
+        if sq[q0] == 0xFF:
+            continue  # qualities absent: stays absent
+        old = sq[q0:q0 + lq].astype(np.int64)
+        sq[q0:q0 + lq] = alphabet[(old * 7 + np.arange(lq)) % len(alphabet)]
+    b["seqqual"] = sq
+    return b
+
+
+@pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (3, 2), (4, 2), (5, 4), (16, 4), (17, 8)])
+@pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300"])
+def test_packed_table_quality_alphabets(ctx, source, n_values, bits):
+    """format 2 with every index width: the decoded packed table equals the ASCII table and the oracle's, on deep bins (consensus
+    storage), odd clip offsets, reads longer than the kernel's LDS-staged limit, missing qualities"""
+    if source.startswith("synth"):
+        from seeksv_amd import synth
+        w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, read_len=int(source[5:]))
+        batches = [w.generate_host(0, w.n_total)]
+    else:
+        batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", source + ".bam"))[2]
+    alphabet = [(3 + 5 * k) % 94 for k in range(n_values)]
+    batches = [_remap_qualities(b, alphabet) for b in batches]
+    ref = ctx.getclip(batches)
+    assert_tables_equal(ref, O.getclip(batches))
+    ctx.clip_table_format(2)
+    try:
+        d = ctx.getclip(batches)
+    finally:
+        ctx.clip_table_format(0)
+    assert d["n_clusters"] == ref["n_clusters"] > 0
+    assert d["qual_bits"] == bits, (d["qual_bits"], bits)
+    for k in ("tid", "pos", "side", "support", "left_len", "right_len", "qual_missing", "cigar_off", "n_cigar", "cigar"):
+        assert np.array_equal(d[k], ref[k]), k
+    for k in range(d["n_clusters"]):
+        assert host.cluster_strings(d, k) == host.cluster_strings(ref, k), k
+    # the bytes of the packed table itself: every block zero padded, laid out back to back
+    offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1, d["qual_bits"]) for a, b in zip(d["left_len"], d["right_len"])])])
+    assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))

@@ -10,7 +10,7 @@ else
   (timeout 900 python -m pytest tests/test_hip_golden.py -m gpu -x -q 2>&1 | tail -5) > $out/tests.log
 fi
 python bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats -d $out/prof -o bench -- python3 bench.py --no-overlap --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_noov.json 2> $out/bench_noov.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --no-overlap --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_noov.json 2> $out/bench_noov.err
 find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 rm -rf $out/prof
 cat $out/tests.log
