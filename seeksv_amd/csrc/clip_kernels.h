@@ -372,9 +372,10 @@ __global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays e
 		const bool has_qual = lq > 0 && src[q0] != 0xff;
 		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
 		const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src - mis);
-		for (uint32_t k = gl; k < nb / 4; k += GROUP) {
-			uint32_t lo = s4[k];
-			uint32_t hi = mis ? s4[k + 1] : 0u;       // may read up to 7 bytes past the entry: see the slack rule in seeksv_hip.h
+		const uint32_t *cs = b.cigar + ev.src_cig[e];
+		uint32_t *cd = cig_blob + ev.cig_off[e];
+		const uint32_t nc = ev.ncig[e];
+		auto put = [&](uint32_t k, uint32_t lo, uint32_t hi) {
 			const uint32_t word = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
 			dst[k] = word;
 			if (has_qual && 4 * k + 4 > q0 && 4 * k < q1) {
@@ -382,11 +383,27 @@ __global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays e
 				for (uint32_t j = 0; j < 4; ++j)
 					if (4 * k + j >= q0 && 4 * k + j < q1) s_present[(word >> (8 * j)) & 0xffu] = 1;
 			}
+		};
+		// every load of the event issued before the first store: the entry of a read of up to 256 bases (96 dwords) is covered by the
+		// unrolled batch, so an event costs one memory round trip after its metadata; longer reads and CIGARs continue in the loops
+		constexpr int BATCH = 6;
+		uint32_t lo[BATCH], hi[BATCH];
+#pragma unroll
+		for (int u = 0; u < BATCH; ++u) {
+			const uint32_t k = gl + GROUP * u;
+			const bool in = k < nb / 4;
+			lo[u] = in ? s4[k] : 0u;
+			hi[u] = in && mis ? s4[k + 1] : 0u;       // may read up to 7 bytes past the entry: see the slack rule in seeksv_hip.h
 		}
-		const uint32_t *cs = b.cigar + ev.src_cig[e];
-		uint32_t *cd = cig_blob + ev.cig_off[e];
-		uint32_t nc = ev.ncig[e];
-		for (uint32_t k = gl; k < nc; k += GROUP) cd[k] = cs[k];
+		const uint32_t c_first = gl < nc ? cs[gl] : 0u;
+#pragma unroll
+		for (int u = 0; u < BATCH; ++u) {
+			const uint32_t k = gl + GROUP * u;
+			if (k < nb / 4) put(k, lo[u], hi[u]);
+		}
+		if (gl < nc) cd[gl] = c_first;
+		for (uint32_t k = gl + GROUP * BATCH; k < nb / 4; k += GROUP) put(k, s4[k], mis ? s4[k + 1] : 0u);
+		for (uint32_t k = gl + GROUP; k < nc; k += GROUP) cd[k] = cs[k];
 	}
 	__syncthreads();
 	if (s_present[threadIdx.x]) qual_present[threadIdx.x] = 1;
@@ -413,6 +430,8 @@ struct ClusterArgs {
 	uint8_t *c_qmiss;      // [E]
 	const uint32_t *mflag; // [E] 1: the slot belongs to a bin with more than one event
 	const uint32_t *mslot; // [E] exclusive scan of mflag: index of the slot's string storage
+	const uint32_t *mlist; // [M] the slots with mflag set, ascending (inverse of mslot)
+	int64_t M;
 	uint8_t *strings;      // [M * stride]: left seq (reversed), left qual (reversed), right seq, right qual - multi-event bins only
 	int32_t SL, SR;        // capacity of a left / right string
 };
@@ -449,15 +468,22 @@ __global__ void k_bin_mark(const uint64_t *__restrict__ skey, const uint32_t *__
 	} else support[j] = 0;
 }
 
+// slots of multi-event bins, densely: mlist[mslot[j]] = j
+__global__ void k_multi_list(const uint32_t *__restrict__ mflag, const uint32_t *__restrict__ mslot, int64_t E, uint32_t *__restrict__ mlist)
+{
+	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < E && mflag[j]) mlist[mslot[j]] = (uint32_t)j;
+}
+
 // One wavefront per bin (= run of equal keys in the sorted event list).  The wave walks the bin's events in BAM order -
 // the order the reference's multimap::equal_range scan sees them - and keeps the evolving clusters in HBM; lanes are
 // spread over bases, match counts come from ballots.  Bins are independent, so there is no cross-wave communication.
 __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 {
 	__shared__ int32_t s_slot[WAVES_PER_BLOCK][CL_CACHE];
-	const int64_t j0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
-	if (j0 >= a.E) return;
-	if (!a.mflag[j0]) return;                      // single-event bin: nothing to cluster (k_bin_mark filled its slot)
+	const int64_t m0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (m0 >= a.M) return;
+	const int64_t j0 = a.mlist[m0];                // slots of multi-event bins only (single-event bins were finished by k_bin_mark)
 	const uint64_t key0 = a.skey[j0];
 	if (j0 > 0 && a.skey[j0 - 1] == key0) return; // not the start of a bin
 	const int lane = lane_id();

@@ -72,7 +72,7 @@ struct ssv_ctx {
 	uint64_t max_key = 0;
 	int max_ll = 0, max_lr = 0;
 	// clustering temporaries / outputs
-	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_strings, c_flag, c_idx;
+	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_strings, c_flag, c_idx;
 	DBuf o_slot, o_strbytes, o_ncig64, o_srcoff, o_srcbegin, o_srclq, o_srccig, totals;
 	HBuf h_totals;
 	// the dense cluster table: device columns + pinned host copy, double buffered so that the PCIe copy of one table can overlap
@@ -350,7 +350,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap,
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap,
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
@@ -558,7 +558,14 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		const int64_t M = *P<uint32_t>(c->h_totals); // events in multi-event bins: only they need consensus storage
 		CHECK(ensure(c, c->c_strings, (size_t)std::max<int64_t>(M, 1) * stride));
 		ca.strings = P<uint8_t>(c->c_strings);
-		if (M > 0) k_cluster_bins<<<grid_for(E, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
+		ca.M = M; ca.mlist = nullptr;
+		if (M > 0) {
+			// one wavefront per slot of a multi-event bin (3 % of the slots; the waves that do not sit on a bin start leave at once)
+			CHECK(ensure(c, c->c_mlist, M * 4));
+			ca.mlist = P<uint32_t>(c->c_mlist);
+			k_multi_list<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.mflag, ca.mslot, E, P<uint32_t>(c->c_mlist));
+			k_cluster_bins<<<grid_for(M, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
+		}
 		HIPCHECK(c, hipGetLastError());
 	}
 	// ---- compact the clusters into a dense table ----

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 if [ "$mode" = full ]; then
   (timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > $out/tests.log
 else
-  (timeout 900 python -m pytest tests/test_hip_golden.py -m gpu -x -q 2>&1 | tail -5) > $out/tests.log
+  (timeout 300 python -m pytest tests/test_hip_golden.py -m gpu -x -q 2>&1 | tail -5) > $out/tests.log
 fi
 python bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --no-overlap --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_noov.json 2> $out/bench_noov.err
