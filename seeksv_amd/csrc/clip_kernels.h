@@ -38,12 +38,13 @@ constexpr int CS_MAX_BLOCKS = 8192;                   // upper bound of the pers
 struct StagedEvent {
 	uint64_t key;    // tid << 33 | side << 32 | pos1   (side 0 = '5' / breakpoint2read_l, 1 = '3' / breakpoint2read_r)
 	uint32_t rec;    // record index inside the batch
-	uint32_t pad0;
+	uint32_t src_cig; // the record's cigar_off
 	int32_t begin;   // first query base of seq_left  (GetSeq's begin_pos)
 	int32_t ll, lr;  // |seq_left|, |seq_right|
 	int32_t lq;      // l_qseq
 	uint32_t ncig;
 	uint32_t pad;
+	uint64_t src_seq; // the record's seq_off
 };
 
 struct ClipCounters {
@@ -80,39 +81,40 @@ struct ClipFilterArgs {
 };
 
 // GenerateCigar's l: M, D, =, N advance the reference; X does not (clip_reads.cpp:322)
-__device__ __forceinline__ int ref_len_generate_cigar(const uint32_t *cig, int n)
+__device__ __forceinline__ int ref_advance(uint32_t c)
 {
-	int l = 0;
-	for (int i = 0; i < n; ++i) {
-		uint32_t c = cig[i];
-		int op = (int)(c & 15u);
-		if (op == C_M || op == C_D || op == C_EQ || op == C_N) l += (int)(c >> 4);
-	}
-	return l;
+	const int op = (int)(c & 15u);
+	return (op == C_M || op == C_D || op == C_EQ || op == C_N) ? (int)(c >> 4) : 0;
 }
 
-// Decide the 0/1/2 events of record i.  Only called for records whose first or last op is 'S' (about 1 % of a WGS BAM),
-// so everything it touches beyond the CIGAR is a lazy, sparse load.
-__device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i, int nc, uint32_t c0, uint32_t cl, StagedEvent ev[2])
+// Decide the 0/1/2 events of record i.  Only called for records whose first or last op is 'S' (about 1 % of a WGS BAM), so everything
+// it touches beyond the CIGAR ends is a lazy, sparse load: one 64-byte sector per column.  The kernel is bound by the number of sectors it
+// touches, not by their latency (issuing all loads before the first test made it slower), so the chain leaves as early as GetSClipReads.
+__device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i, int nc, uint32_t c0, uint32_t cl, const uint32_t *cig, uint32_t cig_off, StagedEvent ev[2])
 {
 	const DevBatch &b = a.b;
-	int op1 = (int)(c0 & 15u), op2 = (int)(cl & 15u);
-	int flag = b.flag[i];
+	const int op1 = (int)(c0 & 15u), op2 = (int)(cl & 15u);
+	const int flag = b.flag[i];
 	if (flag & (F_UNMAP | F_MUNMAP)) return 0;          // unmapped-pair side channel (host), clip_reads.h:415
-	int tid = b.tid[i];
+	const int tid = b.tid[i];
 	// contig-switch rule: processed only if tid equals the tid of the previous mapped-pair record
 	int prev_tid = *a.last_tid_in;
 	for (int64_t j = i - 1; j >= 0; --j) {
 		if (!(b.flag[j] & (F_UNMAP | F_MUNMAP))) { prev_tid = b.tid[j]; break; }
 	}
 	if (tid != prev_tid || tid < 0) return 0;
-	if (op1 == C_H || op2 == C_H || (int)b.mapq[i] < a.min_mapq || (flag & F_DUP)) return 0; // clip_reads.cpp:118
-	if (b.seq_off[i] == ~0ull) return 0;                // batcher contract: bases must be shipped for 'S'-ended records
+	if (op1 == C_H || op2 == C_H || (flag & F_DUP) || (int)b.mapq[i] < a.min_mapq) return 0; // clip_reads.cpp:118
+	const uint64_t soff = b.seq_off[i];
+	if (soff == ~0ull) return 0;                        // batcher contract: bases must be shipped for 'S'-ended records
+	const int xc = b.xc ? b.xc[i] : 0;
+	const int lq = b.l_qseq[i];
+	const int pos0 = b.pos[i];
+	int ref_len = 0;                                    // only right-clip events need it
+	if (op2 == C_S) {
+		ref_len = ref_advance(c0) + ref_advance(cl);    // nc >= 2: first and last op are distinct
+		for (int k = 1; k < nc - 1; ++k) ref_len += ref_advance(cig[k]);
+	}
 	bool s1 = op1 == C_S, s2 = op2 == C_S;
-	int xc = b.xc ? b.xc[i] : 0;
-	int lq = b.l_qseq[i];
-	int pos0 = b.pos[i];
-	const uint32_t *cig = b.cigar + b.cigar_off[i];
 	int n = 0;
 	uint64_t tkey = (uint64_t)(uint32_t)tid << 33;
 	if (s1 != s2) {
@@ -124,7 +126,6 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 		} else {
 			int lr = (int)(cl >> 4), ll = lq - lr;
 			if (ll < 0) return 0;
-			int ref_len = ref_len_generate_cigar(cig, nc);
 			ev[0].key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); ev[0].begin = 0; ev[0].ll = ll; ev[0].lr = lr; n = 1;
 		}
 	} else {
@@ -133,10 +134,7 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 		bool do_l = true, do_r = true;
 		if (xc != 0 && !a.save_low_quality) { if (!(flag & F_REV)) do_r = false; else do_l = false; } // clip_reads.cpp:160-175
 		if (do_l) { ev[n].key = tkey | (uint32_t)(pos0 + 1); ev[n].begin = 0; ev[n].ll = ll; ev[n].lr = mid; ++n; }
-		if (do_r) {
-			int ref_len = ref_len_generate_cigar(cig, nc);
-			ev[n].key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); ev[n].begin = ll; ev[n].ll = mid; ev[n].lr = rc; ++n;
-		}
+		if (do_r) { ev[n].key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); ev[n].begin = ll; ev[n].ll = mid; ev[n].lr = rc; ++n; }
 	}
 	if (a.use_ownership) {
 		int m = 0;
@@ -146,7 +144,7 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 		}
 		n = m;
 	}
-	for (int k = 0; k < n; ++k) { ev[k].rec = (uint32_t)i; ev[k].lq = lq; ev[k].ncig = (uint32_t)nc; ev[k].pad = 0; }
+	for (int k = 0; k < n; ++k) { ev[k].rec = (uint32_t)i; ev[k].lq = lq; ev[k].ncig = (uint32_t)nc; ev[k].pad = 0; ev[k].src_cig = cig_off; ev[k].src_seq = soff; }
 	return n;
 }
 
@@ -279,7 +277,7 @@ __global__ void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ can
 	const uint32_t c0 = a.b.cigar[off], cl = a.b.cigar[off + nc - 1];
 	StagedEvent ev[2];
 	int n = 0;
-	if ((c0 & 15u) == C_S || (cl & 15u) == C_S) n = clip_events_of(a, i, nc, c0, cl, ev);
+	if ((c0 & 15u) == C_S || (cl & 15u) == C_S) n = clip_events_of(a, i, nc, c0, cl, a.b.cigar + off, off, ev);
 	for (int e = 0; e < n; ++e) stash[2 * c + e] = ev[e];
 	cnt[c] = (uint32_t)n;
 }
@@ -323,8 +321,8 @@ __global__ void k_clip_place(const StagedEvent *__restrict__ stash, const uint32
 		int64_t e = ev_base + ev_off[c] + k;
 		ev.key[e] = x.key; ev.begin[e] = x.begin; ev.ll[e] = x.ll; ev.lr[e] = x.lr; ev.lq[e] = x.lq; ev.ncig[e] = x.ncig;
 		ev.seq_bytes[e] = ((uint32_t)((x.lq + 1) / 2 + x.lq) + 3u) & ~3u; // entries of the context blob are 4-byte aligned
-		ev.src_seq[e] = b.seq_off[x.rec];
-		ev.src_cig[e] = b.cigar_off[x.rec];
+		ev.src_seq[e] = x.src_seq;
+		ev.src_cig[e] = x.src_cig;
 	}
 }
 
