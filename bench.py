@@ -33,8 +33,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 #   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                        = 8.0 B/record
 #   clip_gather : packed bases+qualities 228 read + 228 written, CIGAR 8 + 8                                             = 472 B/event
 #   event_sort  : 5 radix passes x (12 B histogram read + 12 B read + 12 B written)                                       = 180 B/event
-#   cluster_pack: 228 read + 1.5*(ll+lr) ~ 225 written (4-bit sequence codes + qualities) + ~70 B of per-cluster columns   = 525 B/cluster-slot
-ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 525.0}
+#   cluster_pack: 228 read + (ll+lr) ~ 150 written (4-bit sequence codes + 4-bit quality indices) + ~70 B of per-cluster columns = 450 B/cluster-slot
+ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 450.0}
+# minimum traffic of the whole path if every field of a record were read once by one fused pass (33 B fixed part +
+# 4.1 B CIGAR + 1 % x 225 B bases/qualities + ~0.7 B out).  The implemented path reads far less per record (the streaming passes touch
+# 2 + 8 B; everything else is evaluated lazily for ~1-3 % of the records), so this figure over the sum of ALL device kernels of a step
+# is the whole-path view of the same roofline: "path" in the bench line.
+PATH_BYTES_PER_RECORD = 40.0
 
 
 def main():
@@ -263,6 +268,11 @@ def main():
                          "other": {k: {"avg_launch_ms": round(v["total_ms"] / v["launches"], 4), "units": v["units"] // v["launches"],
                                        "achieved_GBs": round(ALGO_BYTES[k] * (v["units"] / v["launches"]) / (v["total_ms"] / v["launches"] * 1e-3) / 1e9, 1)}
                                    for k, v in cand.items()}},
+            "path": {"algorithmic_bytes_per_record": PATH_BYTES_PER_RECORD, "device_kernels_ms": round(sum(v["total_ms"] for k, v in allprof.items() if k not in ("table_d2h", "h2d")), 3),
+                     "achieved": PATH_BYTES_PER_RECORD * n_own / (sum(v["total_ms"] for k, v in allprof.items() if k not in ("table_d2h", "h2d")) * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": PATH_BYTES_PER_RECORD * n_own / (sum(v["total_ms"] for k, v in allprof.items() if k not in ("table_d2h", "h2d")) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "SURVEY 8(d)'s fused-pass figure x this rank's records / the sum of every device kernel of one step (getclip + insert size + getsv passes; PCIe copy excluded)"},
             "kernel_ms_one_step": breakdown,
             "wall_ms_one_step": {k: round(v, 3) for k, v in wall.items()},
             "wall_ms_timed_steps": step_walls,

@@ -267,19 +267,24 @@ __global__ __launch_bounds__(BLOCK) void k_cand_place(const uint32_t *__restrict
 
 // K1b clip_filter: one thread per candidate record (n_cigar >= 2) looks at the CIGAR ends and, for soft-clipped ones, runs GetSClipReads' predicate chain (flag, contig-switch rule, MAPQ, DUP, XC,
 // hard clips) and leaves its 0, 1 or 2 events in the candidate's two stash slots.
-__global__ void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ cand, int64_t n_cand, StagedEvent *__restrict__ stash, uint32_t *__restrict__ cnt)
+__global__ __launch_bounds__(BLOCK) void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ cand, int64_t n_cand, StagedEvent *__restrict__ stash, uint32_t *__restrict__ cnt)
 {
-	int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= n_cand) return;
-	const int64_t i = cand[c];
-	const int nc = a.b.n_cigar[i];
-	const uint32_t off = a.b.cigar_off[i];
-	const uint32_t c0 = a.b.cigar[off], cl = a.b.cigar[off + nc - 1];
+	const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	StagedEvent ev[2];
 	int n = 0;
-	if ((c0 & 15u) == C_S || (cl & 15u) == C_S) n = clip_events_of(a, i, nc, c0, cl, a.b.cigar + off, off, ev);
-	for (int e = 0; e < n; ++e) stash[2 * c + e] = ev[e];
-	cnt[c] = (uint32_t)n;
+	if (c < n_cand) {
+		const int64_t i = cand[c];
+		const int nc = a.b.n_cigar[i];
+		const uint32_t off = a.b.cigar_off[i];
+		const uint32_t c0 = a.b.cigar[off], cl = a.b.cigar[off + nc - 1];
+		if ((c0 & 15u) == C_S || (cl & 15u) == C_S) n = clip_events_of(a, i, nc, c0, cl, a.b.cigar + off, off, ev);
+		cnt[c] = (uint32_t)n;
+	}
+	// the wavefront's events side by side (two slots per candidate are reserved, the wave fills its 128 from the front): a third of
+	// the candidates emit, and 48-byte stores scattered at a 96-byte stride cost four times their bytes in partial-line writes
+	const int ex = wave_inclusive_sum(n) - n;
+	StagedEvent *dst = stash + 2 * (c - lane_id()) + ex;
+	for (int e = 0; e < n; ++e) dst[e] = ev[e];
 }
 
 // tid of the last mapped-pair record of the batch -> *last_tid (unchanged when there is none)
@@ -310,14 +315,15 @@ struct EventArrays {
 };
 
 // candidate c's events -> final, BAM-ordered position ev_base + ev_off[c] + e
-__global__ void k_clip_place(const StagedEvent *__restrict__ stash, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ ev_off, int64_t n_cand,
-                             DevBatch b, EventArrays ev, int64_t ev_base)
+__global__ __launch_bounds__(BLOCK) void k_clip_place(const StagedEvent *__restrict__ stash, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ ev_off, int64_t n_cand,
+                                                      EventArrays ev, int64_t ev_base)
 {
-	int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= n_cand) return;
-	const uint32_t n = cnt[c];
-	for (uint32_t k = 0; k < n; ++k) {
-		StagedEvent x = stash[2 * c + k];
+	const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const int n = c < n_cand ? (int)cnt[c] : 0;
+	const int ex = wave_inclusive_sum(n) - n; // same thread-to-candidate mapping as k_clip_filter: the wave's events are packed from its first slot
+	const StagedEvent *src = stash + 2 * (c - lane_id()) + ex;
+	for (int k = 0; k < n; ++k) {
+		StagedEvent x = src[k];
 		int64_t e = ev_base + ev_off[c] + k;
 		ev.key[e] = x.key; ev.begin[e] = x.begin; ev.ll[e] = x.ll; ev.lr[e] = x.lr; ev.lq[e] = x.lq; ev.ncig[e] = x.ncig;
 		ev.seq_bytes[e] = ((uint32_t)((x.lq + 1) / 2 + x.lq) + 3u) & ~3u; // entries of the context blob are 4-byte aligned

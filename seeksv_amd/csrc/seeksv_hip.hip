@@ -450,7 +450,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 		{
 			ProfScope ps(c, P_CLIP_PLACE, ncand);
 			CHECK(ensure(c, c->cand, ncand * 4)); CHECK(ensure(c, c->cand_cnt, ncand * 4)); CHECK(ensure(c, c->cand_off, ncand * 4));
-			CHECK(ensure(c, c->stash, (size_t)ncand * 2 * sizeof(StagedEvent)));
+			CHECK(ensure(c, c->stash, (size_t)(ncand + WAVE) * 2 * sizeof(StagedEvent)));
 			CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(ncand) * 4));
 			CHECK(ensure_events(c, c->n_events + 2 * ncand));
 			k_cand_place<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<uint32_t>(c->stage), P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_off), P<uint32_t>(c->tile_base), ntiles,
@@ -463,7 +463,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			k_clip_filter<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(f, P<uint32_t>(c->cand), ncand, P<StagedEvent>(c->stash), P<uint32_t>(c->cand_cnt));
 			exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->cand_cnt), P<uint32_t>(c->cand_off), ncand, 0u, P<uint32_t>(c->scan_scratch), reinterpret_cast<uint32_t *>(&dc->n_new));
 			EventArrays ev = event_arrays(c);
-			k_clip_place<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(P<StagedEvent>(c->stash), P<uint32_t>(c->cand_cnt), P<uint32_t>(c->cand_off), ncand, d, ev, c->n_events);
+			k_clip_place<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(P<StagedEvent>(c->stash), P<uint32_t>(c->cand_cnt), P<uint32_t>(c->cand_off), ncand, ev, c->n_events);
 			HIPCHECK(c, hipGetLastError());
 			HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
 			HIPCHECK(c, hipStreamSynchronize(c->st));
