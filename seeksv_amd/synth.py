@@ -50,9 +50,21 @@ def _lib(gpu):
 
 class Workload:
     def __init__(self, genome_frac=1.0, depth=30.0, n_sv=10000, seed=SEED, read_len=150, clip_permille=10, indel_permille=20,
-                 dup_permille=80, sec_permille=2, improper_permille=20, vaf_permille=500, n_contigs=24, min_contig=30000):
-        self.names = HG38_NAMES[:n_contigs]
+                 dup_permille=80, sec_permille=2, improper_permille=20, vaf_permille=500, n_contigs=24, min_contig=30000,
+                 hbv=False, n_integrations=0):
+        """hbv / n_integrations (BASELINE config 5, SURVEY 8d "C5"): a hybrid reference - the human contigs plus an `HBV` contig of 3,215 bp -
+        and n_integrations planted human<->HBV junctions in all three orientations the junction model has, some of them within 200 bp of
+        the HBV contig's ends (the unsigned-wrap flank windows of getsv.cpp:760-777).  A normal sample of the same patient is the same
+        workload with n_integrations=0 (same seed: same reference, same germline SVs) at its own depth."""
+        self.names = list(HG38_NAMES[:n_contigs])
         self.lens = np.array([max(int(l * genome_frac), min_contig) for l in HG38[:n_contigs]], dtype=np.int64)
+        self.hbv_tid = -1
+        if hbv or n_integrations:
+            self.hbv_tid = n_contigs
+            self.names.append("HBV")
+            self.lens = np.concatenate([self.lens, [3215]]).astype(np.int64)
+            n_contigs += 1
+        self.n_integrations = n_integrations
         self.offs = np.concatenate([[0], np.cumsum(self.lens)])
         G = int(self.offs[-1])
         self.genome_len = G
@@ -93,12 +105,13 @@ class Workload:
             occupied.add(int(self.offs[tid] + pos) // 1000)
 
         be, junctions = [], []
-        weights = self.lens / self.lens.sum()
+        n_human = len(self.lens) - (1 if self.hbv_tid >= 0 else 0)
+        weights = self.lens[:n_human] / self.lens[:n_human].sum()
         tries = 0
         while len(junctions) < n_sv and tries < 50 * max(n_sv, 1):
             tries += 1
             k = len(junctions) % 8
-            ta = int(rng.choice(len(self.lens), p=weights))
+            ta = int(rng.choice(n_human, p=weights))
             A = int(rng.randint(1500, self.lens[ta] - 1500))
             if k < 4:      # DEL, log-uniform 300 bp .. 1 Mbp
                 kind, tb = "DEL", ta
@@ -108,7 +121,7 @@ class Workload:
                 B = A + int(rng.randint(1000, min(100000, self.lens[ta] // 4)))
             else:          # TRA
                 kind = "TRA"
-                tb = int(rng.choice(len(self.lens), p=weights))
+                tb = int(rng.choice(n_human, p=weights))
                 if tb == ta:
                     continue
                 B = int(rng.randint(1500, self.lens[tb] - 1500))
@@ -128,6 +141,45 @@ class Workload:
                 junctions.append((self.names[ta], A, "-", self.names[tb], B, "+"))
                 be.append((la + A - 1, ta, A - 1, tb, B - 1, 1, 1, 1, 1, B - 1))
                 be.append((lb + B - 1, tb, B - 1, ta, A - 1, 1, 1, 0, 0, 0))
+        # virus integrations: human (A) <-> HBV (B), own random stream so that the human SVs above do not depend on their number.
+        # HBV breakpoints are spread over the whole contig, the first ones close to its ends.
+        if self.n_integrations:
+            rng2 = np.random.RandomState((seed + 0x48425631) & 0x7fffffff)
+            tb, lb, hl = self.hbv_tid, int(self.offs[self.hbv_tid]), int(self.lens[self.hbv_tid])
+            made, tries = 0, 0
+            used_b = set()
+            while made < self.n_integrations and tries < 200 * self.n_integrations:
+                tries += 1
+                ta = int(rng2.choice(n_human, p=weights))
+                A = int(rng2.randint(1500, self.lens[ta] - 1500))
+                if made == 0:
+                    B = int(rng2.randint(40, 190))             # flank windows wrap below the contig start
+                elif made == 1:
+                    B = int(rng2.randint(hl - 190, hl - 40))   # ... and run past its end
+                else:
+                    B = int(rng2.randint(200, hl - 200))
+                if not free(ta, A) or any(abs(B - u) < 40 for u in used_b):
+                    continue
+                take(ta, A); used_b.add(B)
+                la = int(self.offs[ta])
+                kind = made % 4
+                if kind == 0:      # human (A,+) -> HBV (B,+)
+                    junctions.append((self.names[ta], A, "+", "HBV", B, "+"))
+                    be.append((la + A, ta, A, tb, B - 1, 0, 1, 1, 1, B - 1))
+                    be.append((lb + B - 1, tb, B - 1, ta, A - 1, 1, -1, 0, 0, 0))
+                elif kind == 1:    # HBV (B,+) -> human (A,+): the viral side is the up end
+                    junctions.append(("HBV", B, "+", self.names[ta], A, "+"))
+                    be.append((lb + B, tb, B, ta, A - 1, 0, 1, 1, 1, A - 1))
+                    be.append((la + A - 1, ta, A - 1, tb, B - 1, 1, -1, 0, 0, 0))
+                elif kind == 2:    # human (A,+) -> HBV (B,-): virus inserted in reverse orientation
+                    junctions.append((self.names[ta], A, "+", "HBV", B, "-"))
+                    be.append((la + A, ta, A, tb, B - 1, 0, -1, 0, 1, B - 1))
+                    be.append((lb + B, tb, B, ta, A - 1, 0, -1, 0, 0, 0))
+                else:              # human (A,-) -> HBV (B,+)
+                    junctions.append((self.names[ta], A, "-", "HBV", B, "+"))
+                    be.append((la + A - 1, ta, A - 1, tb, B - 1, 1, 1, 1, 1, B - 1))
+                    be.append((lb + B - 1, tb, B - 1, ta, A - 1, 1, 1, 0, 0, 0))
+                made += 1
         arr = np.array(be, dtype=BREAKEND_DTYPE) if be else np.zeros(0, dtype=BREAKEND_DTYPE)
         self.breakends = np.sort(arr, order="lin")
         # multimap<Junction,...> order (getsv.h:187-225)

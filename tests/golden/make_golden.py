@@ -348,7 +348,9 @@ def crafted_getsv():
 #    only the reference's outputs are committed)
 # ------------------------------------------------------------------------------------------------
 
-SYNTH_CASES = {"synth30x": dict(genome_frac=1 / 2048, depth=30, n_sv=40), "synth300x": dict(genome_frac=1 / 8192, depth=300, n_sv=24)}
+SYNTH_CASES = {"synth30x": dict(genome_frac=1 / 2048, depth=30, n_sv=40), "synth300x": dict(genome_frac=1 / 8192, depth=300, n_sv=24),
+               # BASELINE config 5 in small: human + HBV hybrid reference, virus integrations (two of them within 200 bp of the HBV contig's ends)
+               "synthhbv": dict(genome_frac=1 / 8192, depth=60, n_sv=8, n_integrations=10)}
 
 
 def synthetic():
@@ -391,7 +393,9 @@ def synthetic():
 #    translocations, MergeJunction) far beyond the three deletions of the bundled example.
 # ------------------------------------------------------------------------------------------------
 
-SYNTH_FULL = {"synthfull": dict(genome_frac=1 / 8192, depth=40, n_sv=24)}
+SYNTH_FULL = {"synthfull": dict(genome_frac=1 / 8192, depth=40, n_sv=24),
+              "hbvfull": dict(genome_frac=1 / 8192, depth=60, n_sv=8, n_integrations=10)}   # the tumor of config 5
+HBV_NORMAL = dict(genome_frac=1 / 8192, depth=30, n_sv=8, hbv=True)                          # its normal: same reference, same germline SVs, no virus
 
 
 def synthetic_full():
@@ -486,6 +490,28 @@ def somatic_synth():
     print(f"  somatic: {len(open(table).read().splitlines())} table rows -> {n} output rows")
 
 
+# ------------------------------------------------------------------------------------------------
+# 7. BASELINE config 5 in small: tumor (human + HBV, planted integrations) against its normal -
+#    getclip on both, the tumor's SV table from section 5 (bwa mem on the hybrid reference), somatic.
+# ------------------------------------------------------------------------------------------------
+
+def somatic_hbv():
+    sys.path.insert(0, ROOT)
+    from seeksv_amd import synth
+    out = os.path.join(HERE, "somatic")
+    os.makedirs(out, exist_ok=True)
+    n = synth.Workload(**HBV_NORMAL)
+    bam = os.path.join(TMP, "hbvnormal.bam")
+    bamio.soa_to_bam(bam, n.names, n.lens, n.generate_host(0, n.n_total))
+    run([os.path.join(BIN, "bamidx"), bam])
+    run([SEEKSV, "getclip", "-o", "hbvnormal", bam], cwd=TMP)
+    table = os.path.join(HERE, "synth", "hbvfull.loose.sv")
+    for tag, flags in (("", []), (".n0", ["-n", "0"]), (".q0", ["-q", "0"])):
+        run([SEEKSV, "somatic"] + flags + [bam, "hbvnormal.clip.gz", table, os.path.join(out, f"hbv.somatic{tag}.sv")], cwd=TMP, stderr=os.path.join(out, f"hbv.somatic{tag}.stderr"))
+    rows = [l.split("\t") for l in open(os.path.join(out, "hbv.somatic.sv")) if not l.startswith("@")]
+    print(f"  hbv somatic: {len(rows)} rows, {sum(1 for r in rows if 'HBV' in (r[0], r[4]))} with a viral end")
+
+
 if __name__ == "__main__":
     if not os.path.exists(SEEKSV):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -496,4 +522,5 @@ if __name__ == "__main__":
     synthetic()
     synthetic_full()
     somatic_synth()
+    somatic_hbv()
     print("goldens regenerated under", HERE)

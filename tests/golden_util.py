@@ -98,7 +98,8 @@ def check_getsv_against_golden(junctions, folded, golden):
 
 # ---- synthetic workloads whose reference outputs are committed under golden/synth (inputs are regenerated) ----
 
-SYNTH_CASES = {"synth30x": dict(genome_frac=1 / 2048, depth=30, n_sv=40), "synth300x": dict(genome_frac=1 / 8192, depth=300, n_sv=24)}
+SYNTH_CASES = {"synth30x": dict(genome_frac=1 / 2048, depth=30, n_sv=40), "synth300x": dict(genome_frac=1 / 8192, depth=300, n_sv=24),
+               "synthhbv": dict(genome_frac=1 / 8192, depth=60, n_sv=8, n_integrations=10)}  # BASELINE config 5 in small (human + HBV)
 
 
 def read_gz(*parts):

@@ -92,33 +92,62 @@ def test_cli_getsv_full_pipeline_example(tmp_path, sample, tag, flags):
     assert os.path.getsize(str(tmp_path / "u.fq")) == 0
 
 
-SYNTH_FULL = dict(genome_frac=1 / 8192, depth=40, n_sv=24)
+SYNTH_FULL = {"synthfull": dict(genome_frac=1 / 8192, depth=40, n_sv=24),
+              "hbvfull": dict(genome_frac=1 / 8192, depth=60, n_sv=8, n_integrations=10)}  # the tumor of BASELINE config 5 in small: human + HBV, 10 integrations
+HBV_NORMAL = dict(genome_frac=1 / 8192, depth=30, n_sv=8, hbv=True)                         # its normal: same reference and germline SVs, no virus
 SYNTH_FULL_VARIANTS = [("", []), (".l90", ["-l", "90"]), (".loose", ["-f", "0", "-b", "0", "-d", "0"]), (".strict", ["-e", "10", "-b", "20"])]
+_synth_samples = {}
+
+
+def _synth_sample(tmp_path_factory, name, kw):
+    """A synthetic sample regenerated and written as a BAM; getclip'ed once with the CLI."""
+    if name not in _synth_samples:
+        from seeksv_amd import synth
+        d = tmp_path_factory.mktemp(name)
+        w = synth.Workload(**kw)
+        bam = str(d / f"{name}.bam")
+        bamio.soa_to_bam(bam, w.names, w.lens, w.generate_host(0, w.n_total))
+        r = subprocess.run([SEEKSV, "getclip", "-o", str(d / "s"), bam], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        _synth_samples[name] = (bam, str(d / "s.clip.gz"), d)
+    return _synth_samples[name]
 
 
 @pytest.fixture(scope="module")
 def synthfull_bam(tmp_path_factory):
-    """The synthetic sample with planted DEL / INV / TRA, regenerated and written as a BAM; getclip'ed once with the CLI."""
-    from seeksv_amd import synth
-    d = tmp_path_factory.mktemp("synthfull")
-    w = synth.Workload(**SYNTH_FULL)
-    bam = str(d / "synthfull.bam")
-    bamio.soa_to_bam(bam, w.names, w.lens, w.generate_host(0, w.n_total))
-    r = subprocess.run([SEEKSV, "getclip", "-o", str(d / "s"), bam], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    return bam, str(d / "s.clip.gz"), d
+    return _synth_sample(tmp_path_factory, "synthfull", SYNTH_FULL["synthfull"])
 
 
 @pytest.mark.parametrize("tag,flags", SYNTH_FULL_VARIANTS, ids=[t[0] or "default" for t in SYNTH_FULL_VARIANTS])
-def test_cli_full_pipeline_synthetic_sv_table(synthfull_bam, tag, flags):
-    """getclip -> (bwa mem against the hash-generated reference: committed clip.bam) -> getsv on 24 planted DEL / INV / TRA:
-    the SV table (reverse-strand junctions, translocations, merged junctions included) equals the real reference's byte for byte."""
-    bam, clip_gz, d = synthfull_bam
+@pytest.mark.parametrize("name", list(SYNTH_FULL))
+def test_cli_full_pipeline_synthetic_sv_table(tmp_path_factory, name, tag, flags):
+    """getclip -> (bwa mem against the hash-generated reference: committed clip.bam) -> getsv on planted DEL / INV / TRA (synthfull) and on
+    the human + HBV hybrid sample with planted virus integrations (hbvfull): the SV table (reverse-strand junctions, translocations, merged
+    junctions, viral ends near the HBV contig's ends included) equals the real reference's byte for byte."""
+    bam, clip_gz, d = _synth_sample(tmp_path_factory, name, SYNTH_FULL[name])
     sv = str(d / f"out{tag}.sv")
-    r = subprocess.run([SEEKSV, "getsv"] + flags + [os.path.join(G.GOLDEN, "synth", "synthfull.clip.bam"), bam, clip_gz, sv, str(d / "u.fq")], capture_output=True, text=True)
+    r = subprocess.run([SEEKSV, "getsv"] + flags + [os.path.join(G.GOLDEN, "synth", f"{name}.clip.bam"), bam, clip_gz, sv, str(d / "u.fq")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert open(sv).read() == G.read_text("synth", f"synthfull{tag}.sv")
-    assert r.stdout == G.read_text("synth", f"synthfull{tag}.stdout")
+    assert open(sv).read() == G.read_text("synth", f"{name}{tag}.sv")
+    assert r.stdout == G.read_text("synth", f"{name}{tag}.stdout")
+
+
+@pytest.mark.parametrize("tag,flags", [("", []), (".n0", ["-n", "0"]), (".q0", ["-q", "0"])], ids=["default", "n0", "q0"])
+def test_cli_config5_virus_integration_somatic(tmp_path_factory, tag, flags):
+    """BASELINE config 5 in small: the tumor's SV table (human + HBV hybrid reference, 10 planted integrations + 8 germline SVs) filtered against
+    the patient's normal sample (`seeksv getclip` on the normal, then `seeksv somatic`): every viral junction is somatic (no support in the
+    control), the germline SVs carry the control's clipped-read and discordant-pair counts; table and stderr equal the real reference's."""
+    bam, clip_gz, d = _synth_sample(tmp_path_factory, "hbvnormal", HBV_NORMAL)
+    out = str(d / f"somatic{tag}.sv")
+    r = subprocess.run([SEEKSV, "somatic"] + flags + [bam, clip_gz, os.path.join(G.GOLDEN, "synth", "hbvfull.loose.sv"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out).read() == G.read_text("somatic", f"hbv.somatic{tag}.sv")
+    assert _somatic_stderr(r.stderr) == _somatic_stderr(G.read_text("somatic", f"hbv.somatic{tag}.stderr"))
+    rows = [l.split("\t") for l in open(out) if not l.startswith("@")]
+    viral = [r_ for r_ in rows if "HBV" in (r_[0], r_[4])]
+    assert len(viral) == 10 and all(r_[-3:] == ["0", "0", "0\n"] for r_ in viral)
+    if not flags:
+        assert all(int(r_[-1]) > 0 for r_ in rows if r_ not in viral)
 
 
 SOMATIC_VARIANTS = [("", []), (".n0", ["-n", "0"]), (".l0", ["-l", "0"]), (".l60", ["-l", "60"]), (".t05", ["-t", "0.5"]), (".m60", ["-m", "60"]), (".q0", ["-q", "0"])]
