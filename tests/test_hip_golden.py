@@ -211,3 +211,38 @@ def test_packed_table_quality_alphabets(ctx, source, n_values, bits):
     # the bytes of the packed table itself: every block zero padded, laid out back to back
     offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1, d["qual_bits"]) for a, b in zip(d["left_len"], d["right_len"])])])
     assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))
+
+
+@pytest.mark.parametrize("kw", [dict(genome_frac=1 / 4096, depth=60, n_sv=30), dict(genome_frac=1 / 8192, depth=60, n_sv=8, n_integrations=10)], ids=["wgs", "hbv"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_range_partitioned_hip_equals_single(ctx, kw, world):
+    """BASELINE configs 4 / 5 (the BAM range-partitioned over up to 8 GPUs) on one GPU: every rank's share - its records plus the leading
+    halo for getclip, exactly its records for the getsv passes - goes through the HIP path in turn (device-resident batches, ownership by
+    breakpoint position), the per-rank result vectors are merged the way the all-gather merges them, the cluster tables are concatenated:
+    equal to the unpartitioned run, bin for bin."""
+    from seeksv_amd import shard, synth
+    from _shard_worker import cluster_rows
+    w = synth.Workload(**kw)
+    hdr = host.Header(w.names, w.lens)
+    whole, keep = w.generate_device(0, w.n_total, 0)
+    single = ctx.getclip([whole])
+    stats = ctx.isize_stats([whole], 20, 100000)
+    plan = host.Plan(hdr, w.junctions, stats[2], stats[3])
+    c1, r1, p1 = ctx.discordant_and_depth([whole], plan, stats[2], stats[3], 20, hdr.target_lens)
+    rows, vecs, per_rank = [], [], []
+    for rank in range(world):
+        sp = shard.shard_plan(w, rank, world)
+        scan, k1 = w.generate_device(sp["scan_lo_rec"], sp["own_hi_rec"] - sp["scan_lo_rec"], 0)
+        own, k2 = w.generate_device(sp["own_lo_rec"], sp["own_hi_rec"] - sp["own_lo_rec"], 0)
+        d = ctx.getclip([scan], own=sp["own"], initial_last_tid=sp["initial_last_tid"])
+        c, r, p = ctx.discordant_and_depth([own], plan, stats[2], stats[3], 20, hdr.target_lens)
+        vecs.append(shard.pack_results(c, r, p, d["n_clusters"], d["n_events"], int(d["support"].sum())))
+        rows += cluster_rows(d)
+        per_rank.append(d["n_events"])
+    m = shard.merge_results(np.stack(vecs), len(c1), len(r1), len(p1))
+    assert np.array_equal(m[0], c1) and np.array_equal(m[1], r1) and np.array_equal(m[2], p1)
+    assert m[3] == single["n_clusters"] and m[4] == single["n_events"] == m[5]
+    assert sum(1 for n in per_rank if n > 0) >= min(world, 2)
+    assert sorted(rows, key=lambda r: r[:3]) == sorted(cluster_rows(single), key=lambda r: r[:3])
+    plan.close()
+    hdr.close()
