@@ -292,6 +292,35 @@ int ssv_prof_get(ssv_ctx *ctx, const char *name, double *total_ms, int64_t *laun
 /* Names of all timed kernels, '\n' separated. */
 const char *ssv_prof_names(void);
 
+/* ---- clipped-sequence re-aligner ----------------------------------------------------------------------
+ * Stand-in for the EXTERNAL `bwa mem` step between `seeksv getclip` and `seeksv getsv` (README.md:22-34, example/seeksv.sh:3:
+ * `bwa mem ref.fa prefix.clip.fq.gz | samtools view -Sb - > prefix.clip.bam`) on hosts without bwa, for references that behave
+ * like random sequence (the synthetic genomes of bench.py / tests).  getsv consumes of each clip.bam record: flag & {4, 16, 256},
+ * MAPQ == 0 or not, tid, pos, the CIGAR with its S ends, the read name = the sequence (getsv.cpp:25-71, getsv.h:445-527).
+ * K-mer index of the reference in HBM + seed look-ups on both strands + ungapped extension with bwa mem's default scores
+ * (match 1, mismatch 4, end clipping 5, minimum 30).  NOT bit-identical to bwa: no gaps, no chaining, one record per query. */
+typedef struct {
+	int32_t tid;         /* -1: unaligned (flag 4) */
+	int32_t pos;         /* 0-based reference position of the aligned segment's first base */
+	int32_t q_beg, q_end;/* aligned segment [q_beg, q_end) of the query as a BAM record stores it (reverse-complemented when `reverse`): CIGAR = q_beg S, M, rest S */
+	int32_t score;       /* matches - 4 * mismatches of the segment */
+	int32_t second;      /* best score at another locus (0: none) */
+	int32_t n_mismatch;
+	uint8_t reverse;     /* flag 16 */
+	uint8_t mapq;        /* 0 when another locus scores as well, 60 when the runner-up is >= 10 behind */
+	uint8_t pad[2];
+} ssv_realign_hit;
+
+/* Build the index.  ref2bit: base i of the concatenated contigs at bits [2 (i % 32), +2) of word i / 32, A C G T = 0 1 2 3 (the
+ * caller decides what N becomes); target_off[n_targets + 1] = first base of every contig, target_off[0] = 0, target_off[n_targets] =
+ * n_bases.  SSV_MEM_DEVICE arrays are used in place and need one readable word after the last one.  *n_dropped (optional) = sampled
+ * positions that found no slot within the probe limit (low-complexity sequence). */
+int ssv_realign_index(ssv_ctx *ctx, const uint64_t *ref2bit, int32_t mem, int64_t n_bases, const int64_t *target_off, int32_t n_targets, int64_t *n_dropped);
+/* Align n ASCII sequences (host memory, concatenated; seq_off[n + 1]) -> hits[n] (host).  Queries shorter than 20 or longer than 1024
+ * bases come back unaligned. */
+int ssv_realign_query(ssv_ctx *ctx, const char *seqs, const uint64_t *seq_off, int64_t n, ssv_realign_hit *hits);
+int ssv_realign_free(ssv_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

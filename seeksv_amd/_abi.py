@@ -203,6 +203,10 @@ def host_lib():
     return lib
 
 
+REALIGN_HIT = [("tid", "<i4"), ("pos", "<i4"), ("q_beg", "<i4"), ("q_end", "<i4"), ("score", "<i4"), ("second", "<i4"), ("n_mismatch", "<i4"),
+               ("reverse", "u1"), ("mapq", "u1"), ("pad", "u1", (2,))]  # ssv_realign_hit
+
+
 def hip_lib():
     """libseeksv_hip.so - raises when it is not built; creating a context raises when there is no GPU."""
     lib = _load("libseeksv_hip.so")
@@ -234,6 +238,9 @@ def hip_lib():
         lib.ssv_bamdec_decode.argtypes = [V, V, C.c_size_t, C.POINTER(BgzfBlock), C.c_int64, C.c_int, C.POINTER(Batch)]
         lib.ssv_bamdec_last.argtypes = [V, C.POINTER(BamdecInfo)]
         lib.ssv_batch_to_host.argtypes = [V, C.POINTER(Batch), C.POINTER(Batch)]
+        lib.ssv_realign_index.argtypes = [V, V, C.c_int32, C.c_int64, V, C.c_int32, C.POINTER(C.c_int64)]
+        lib.ssv_realign_query.argtypes = [V, V, V, C.c_int64, V]
+        lib.ssv_realign_free.argtypes = [V]
         lib.ssv_prof_enable.argtypes = [V, C.c_int]
         lib.ssv_prof_reset.argtypes = [V]
         lib.ssv_prof_get.argtypes = [V, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "bamdec_kernels.h"
+#include "realign_kernels.h"
 #include "clip_kernels.h"
 #include "common.h"
 #include "getsv_kernels.h"
@@ -26,9 +27,9 @@ namespace {
 std::string g_create_error;
 
 // timed kernel groups (ssv_prof_*)
-enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_BAM_INFLATE, P_BAM_RECORDS, P_BAM_DECODE, P_COUNT };
-const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "table_d2h", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish", "bam_inflate", "bam_records", "bam_decode"};
-const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\ntable_d2h\nisize_stats\ngetsv_scan\ngetsv_cand\ndepth_finish\nbam_inflate\nbam_records\nbam_decode";
+enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_BAM_INFLATE, P_BAM_RECORDS, P_BAM_DECODE, P_REALIGN_INDEX, P_REALIGN_QUERY, P_COUNT };
+const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "table_d2h", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish", "bam_inflate", "bam_records", "bam_decode", "realign_index", "realign_query"};
+const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\ntable_d2h\nisize_stats\ngetsv_scan\ngetsv_cand\ndepth_finish\nbam_inflate\nbam_records\nbam_decode\nrealign_index\nrealign_query";
 
 struct DBuf { // grow-only device buffer
 	void *p = nullptr;
@@ -115,6 +116,8 @@ struct ssv_ctx {
 
 	// ---- device BGZF/BAM decoder (bamdec_api.inc) ----
 	struct ssv_bamdec_state *bd = nullptr;
+	// ---- clipped-sequence re-aligner (realign_api.inc) ----
+	struct ssv_realign_state *ra = nullptr;
 	HBuf h_batch;
 
 	// ---- profiling ----
@@ -335,6 +338,7 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 }
 
 static void bamdec_free(ssv_ctx *c); // bamdec_api.inc
+static void realign_free(ssv_ctx *c); // realign_api.inc
 
 void ssv_ctx_destroy(ssv_ctx *c)
 {
@@ -342,6 +346,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->st);
 	bamdec_free(c);
+	realign_free(c);
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
 	if (c->qual_lut.p) (void)hipFree(c->qual_lut.p);
 	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
@@ -1009,5 +1014,6 @@ int ssv_prof_get(ssv_ctx *c, const char *name, double *total_ms, int64_t *launch
 const char *ssv_prof_names(void) { return kProfNameList; }
 
 #include "bamdec_api.inc"
+#include "realign_api.inc"
 
 } // extern "C"

@@ -45,7 +45,23 @@ __global__ void k_sy_fill(sy_config cfg, const sy_breakend *be, int64_t g0, int6
 	if (r.has_seq) sy_fill_seq(&cfg, be, g0 + i, &r, seqqual + seq_off[i]);
 }
 
+__global__ void k_sy_ref2bit(sy_config cfg, uint64_t *out, int64_t n_words)
+{
+	int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w < n_words) out[w] = sy_ref_word(&cfg, w);
+}
+
 extern "C" {
+
+// the whole reference as 2-bit words in device memory (ssv_realign_index layout, SSV_MEM_DEVICE); out has (total + 31) / 32 + 1 words
+int ssvs_ref_2bit(const sy_config *cfg, uint64_t *out, int64_t n_words)
+{
+	if (n_words <= 0) return 0;
+	k_sy_ref2bit<<<(unsigned)((n_words + 255) / 256), 256>>>(*cfg, out, n_words);
+	SY_CHECK(hipGetLastError());
+	SY_CHECK(hipDeviceSynchronize());
+	return 0;
+}
 
 const char *ssvs_last_error(void) { return g_err.c_str(); }
 

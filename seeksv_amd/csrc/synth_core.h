@@ -220,3 +220,20 @@ SY_HD void sy_fill_seq(const sy_config *c, const sy_breakend *be, int64_t g, con
 		q[i] = uq < 2 ? 2 : uq < 7 ? 11 : uq < 20 ? 25 : uq < 60 ? 37 : 40;
 	}
 }
+
+// 32 bases of the concatenated reference (linear coordinates 32 w ..) as one 2-bit word, A C G T = 0 1 2 3 (the re-aligner's layout)
+SY_HD uint64_t sy_ref_word(const sy_config *c, int64_t w)
+{
+	const int64_t total = c->contig_off[c->n_contigs];
+	uint64_t out = 0;
+	int64_t lin = w * 32;
+	if (lin >= total) return 0;
+	int32_t tid = sy_contig_of(c, lin);
+	for (int j = 0; j < 32 && lin < total; ++j, ++lin) {
+		while (lin >= c->contig_off[tid + 1]) ++tid;
+		const uint32_t b = sy_ref_base(c, tid, lin - c->contig_off[tid]); // nibble code 1 2 4 8
+		const uint64_t two = b == 1 ? 0 : b == 2 ? 1 : b == 4 ? 2 : 3;
+		out |= two << (2 * j);
+	}
+	return out;
+}

@@ -49,4 +49,11 @@ int ssvs_ref_bases(const sy_config *cfg, int32_t tid, int64_t start, int64_t n, 
 	return 0;
 }
 
+// the whole reference as 2-bit words (ssv_realign_index layout); out has (total + 31) / 32 + 1 words, the last one zero
+int ssvs_ref_2bit(const sy_config *cfg, uint64_t *out, int64_t n_words)
+{
+	for (int64_t w = 0; w < n_words; ++w) out[w] = sy_ref_word(cfg, w);
+	return 0;
+}
+
 } // extern "C"

@@ -199,6 +199,24 @@ class Context:
         counts, rs, pd, _ = self.getsv_finish(plan.ranges, plan.points)
         return counts, rs, pd
 
+    # ---- clipped-sequence re-aligner (stand-in for the pipeline's external `bwa mem` step) ----
+    def realign_index(self, ref2bit, target_off, mem=_abi.MEM_HOST):
+        """ref2bit: numpy uint64 array (host) or a device pointer (mem=MEM_DEVICE); target_off: first base of every contig + total"""
+        off = np.ascontiguousarray(target_off, np.int64)
+        ptr = ref2bit.ctypes.data if isinstance(ref2bit, np.ndarray) else int(ref2bit)
+        dropped = C.c_int64()
+        self._check(self._lib.ssv_realign_index(self._h, ptr, mem, int(off[-1]), off.ctypes.data, len(off) - 1, C.byref(dropped)), "ssv_realign_index")
+        return dropped.value
+
+    def realign(self, seqs):
+        """list of str -> numpy structured array of ssv_realign_hit"""
+        blob = "".join(seqs).encode()
+        off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.uint64)
+        hits = np.zeros(len(seqs), dtype=np.dtype(_abi.REALIGN_HIT))
+        if len(seqs):
+            self._check(self._lib.ssv_realign_query(self._h, C.c_char_p(blob), off.ctypes.data, len(seqs), hits.ctypes.data), "ssv_realign_query")
+        return hits
+
     # ---- measurement ----
     def prof_enable(self, mode=1):
         self._check(self._lib.ssv_prof_enable(self._h, mode), "ssv_prof_enable")

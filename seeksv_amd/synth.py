@@ -197,6 +197,24 @@ class Workload:
             out.append(f">{name}\n" + "\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)) + "\n")
         return "".join(out)
 
+    def reference_2bit(self, device=None):
+        """The reference in the re-aligner's layout (ssv_realign_index): -> (words, target_off).  device=None: numpy uint64 array;
+        device=k: torch int64 tensor resident on GPU k (SSV_MEM_DEVICE), generated there."""
+        n_words = (self.genome_len + 31) // 32 + 1
+        off = np.asarray(self.offs, np.int64)
+        if device is None:
+            lib = _lib(False)
+            out = np.zeros(n_words, np.uint64)
+            lib.ssvs_ref_2bit(C.byref(self.cfg), C.c_void_p(out.ctypes.data), C.c_int64(n_words))
+            return out, off
+        import torch
+        lib = _lib(True)
+        torch.cuda.set_device(device)
+        out = torch.zeros(n_words, dtype=torch.int64, device=torch.device("cuda", device))
+        if lib.ssvs_ref_2bit(C.byref(self.cfg), C.c_void_p(out.data_ptr()), C.c_int64(n_words)) != 0:
+            raise RuntimeError("ssvs_ref_2bit: " + lib.ssvs_last_error().decode())
+        return out, off
+
     # ---- record generation ----
     def generate_host(self, g0, n):
         """records [g0, g0+n) as a dict of numpy arrays (a SSV_MEM_HOST batch)."""

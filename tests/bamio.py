@@ -111,3 +111,30 @@ def soa_to_bam(path, names, lens, b):
     write_bam(path, names, [int(x) for x in lens], recs)
 
 
+
+
+def read_bam_records(path):
+    """-> (target_names, [dict(qname, flag, tid, pos, mapq, cigar=[(len, op_char)], l_qseq)]) - plain Python, small files only"""
+    import gzip
+    import struct
+    data = gzip.open(path, "rb").read()  # BGZF = concatenated gzip members
+    assert data[:4] == b"BAM\x01"
+    l_text, = struct.unpack_from("<i", data, 4)
+    p = 8 + l_text
+    n_ref, = struct.unpack_from("<i", data, p)
+    p += 4
+    names = []
+    for _ in range(n_ref):
+        l, = struct.unpack_from("<i", data, p)
+        names.append(data[p + 4:p + 4 + l - 1].decode())
+        p += 4 + l + 4
+    recs = []
+    while p < len(data):
+        bs, tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiiBBHHHi", data, p)
+        q = p + 36
+        qname = data[q:q + l_rn - 1].decode()
+        q += l_rn
+        cig = [(c >> 4, "MIDNSHP=X"[c & 15]) for c in struct.unpack_from("<%dI" % n_cig, data, q)]
+        recs.append(dict(qname=qname, flag=flag, tid=tid, pos=pos, mapq=mapq, cigar=cig, l_qseq=l_seq))
+        p += 4 + bs
+    return names, recs
