@@ -72,6 +72,10 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out);
  * started by an earlier call (the header is written only when append == 0); finish != 0 writes the BGZF end-of-file block. */
 int ssvh_bam_write_batch(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
                          const char *qname_prefix, int64_t first_index, int append, int finish);
+/* The same with explicit read names (qnames[b->n], each <= 254 characters): the clip.bam of `seeksv realign`, whose read names are
+ * the clipped sequences like in the output of `bwa mem prefix.clip.fq.gz` (getsv.h:482-485 joins on them). */
+int ssvh_bam_write_batch_named(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
+                               const char *const *qnames, int append, int finish);
 
 /* Append text to a .gz file as independent gzip members compressed in parallel (1 MiB of text each, zlib level 6 like gzstream's
  * default).  Concatenated members are a valid gzip stream: zlib's gzread (igzstream, bwa, zcat) decompresses them to exactly the bytes

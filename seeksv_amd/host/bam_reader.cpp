@@ -773,8 +773,26 @@ static int reg2bin(int beg, int end)
 	return 0;
 }
 
+static int write_batch_impl(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
+                            const char *qname_prefix, int64_t first_index, const char *const *qnames, int append, int finish);
+
 int ssvh_bam_write_batch(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
                          const char *qname_prefix, int64_t first_index, int append, int finish)
+{
+	return write_batch_impl(path, names, lens, n_targets, b, qname_prefix, first_index, nullptr, append, finish);
+}
+
+int ssvh_bam_write_batch_named(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
+                               const char *const *qnames, int append, int finish)
+{
+	if (b && b->n > 0 && !qnames) { g_err = "ssvh_bam_write_batch_named: no read names"; return -1; }
+	for (int64_t i = 0; b && i < b->n; ++i)
+		if (strlen(qnames[i]) > 254) { g_err = "read name longer than 254 characters (BAM's limit)"; return -1; }
+	return write_batch_impl(path, names, lens, n_targets, b, nullptr, 0, qnames, append, finish);
+}
+
+static int write_batch_impl(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
+                            const char *qname_prefix, int64_t first_index, const char *const *qnames, int append, int finish)
 {
 	FILE *f = fopen(path, append ? "ab" : "wb");
 	if (!f) { g_err = std::string("cannot open ") + path; return -1; }
@@ -791,7 +809,7 @@ int ssvh_bam_write_batch(const char *path, const char *const *names, const int32
 		raw.clear();
 	}
 	for (int64_t i = 0; b && i < b->n; ++i) {
-		std::string qn = std::string(qname_prefix ? qname_prefix : "r") + std::to_string(first_index + i);
+		std::string qn = qnames ? std::string(qnames[i]) : std::string(qname_prefix ? qname_prefix : "r") + std::to_string(first_index + i);
 		const int lq = b->l_qseq[i], nc = b->n_cigar[i];
 		const uint32_t *cig = b->cigar + b->cigar_off[i];
 		int span = 0;

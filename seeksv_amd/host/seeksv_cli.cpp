@@ -73,7 +73,8 @@ struct PhaseTimer {
 	     << "Usage: seeksv <command> [options]\n\n"
 	     << "Command: getclip\tget soft-clipped reads\n"
 	     << "         getsv  \tget final sv\n"
-	     << "         somatic\tget somatic sv" << endl;
+	     << "         somatic\tget somatic sv\n"
+	     << "         realign\talign the clipped sequences of getclip to a reference (stand-in for the pipeline's external `bwa mem` step)" << endl;
 	exit(1);
 }
 
@@ -806,16 +807,169 @@ static int cmd_somatic(int argc, char **argv)
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// seeksv realign: prefix.clip.fq.gz -> prefix.clip.bam.  The reference's pipeline runs an external aligner here
+// (README.md:22-34, example/seeksv.sh:3: `bwa mem ref.fa prefix.clip.fq.gz | samtools view -Sb - > prefix.clip.bam`); this is the
+// stand-in for hosts without bwa (ssv_realign_*, include/seeksv_hip.h): one record per clipped sequence, in FASTQ order, the
+// read name is the sequence.  Meant for references that behave like random sequence (synthetic genomes); no gapped alignment.
+// ---------------------------------------------------------------------------------------------------------------------
+[[noreturn]] static void usage_realign()
+{
+	cerr << "Usage: seeksv realign [options] <reference fasta(.gz)> <input clipped reads (*.clip.fq.gz)> <output clip.bam>\n\n"
+	     << "         -G <int>              GPU ordinal [0]" << endl;
+	exit(1);
+}
+
+static bool gz_getline(gzFile f, string &line)
+{
+	line.clear();
+	char buf[1 << 16];
+	while (gzgets(f, buf, sizeof(buf))) {
+		line += buf;
+		if (!line.empty() && line.back() == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+	}
+	return !line.empty();
+}
+
+static int cmd_realign(int argc, char **argv)
+{
+	int gpu = 0, c;
+	while ((c = getopt(argc, argv, "G:")) != -1) {
+		if (c == 'G') gpu = atoi(optarg); else usage_realign();
+	}
+	if (argc - optind != 3) usage_realign();
+	const string fasta = argv[optind], fq = argv[optind + 1], out_bam = argv[optind + 2];
+	PhaseTimer pt;
+	// ---- reference: names, lengths, 2-bit bases (anything but ACGT becomes a position-dependent pseudo-random base, like bwa's index) ----
+	vector<string> names;
+	vector<int32_t> lens;
+	vector<int64_t> offs(1, 0);
+	vector<uint64_t> words;
+	{
+		gzFile f = gzopen(fasta.c_str(), "rb");
+		if (!f) die("Cannot open reference file " + fasta);
+		string line;
+		int64_t n = 0;
+		auto push = [&](uint64_t two) { if ((n & 31) == 0) words.push_back(0); words.back() |= two << (2 * (n & 31)); ++n; };
+		while (gz_getline(f, line)) {
+			if (line.empty()) continue;
+			if (line[0] == '>') {
+				if (!names.empty()) { lens.push_back((int32_t)(n - offs.back())); offs.push_back(n); }
+				size_t e = line.find_first_of(" \t");
+				names.push_back(line.substr(1, e == string::npos ? string::npos : e - 1));
+			} else {
+				if (names.empty()) die("Reference file " + fasta + " does not start with a '>' line");
+				for (char ch : line) {
+					uint64_t two;
+					switch (ch) {
+					case 'A': case 'a': two = 0; break;
+					case 'C': case 'c': two = 1; break;
+					case 'G': case 'g': two = 2; break;
+					case 'T': case 't': two = 3; break;
+					default: { uint64_t h = (uint64_t)n * 0x9E3779B97F4A7C15ull; two = (h >> 61) & 3; }
+					}
+					push(two);
+				}
+			}
+		}
+		gzclose(f);
+		if (names.empty()) die("No sequence in reference file " + fasta);
+		lens.push_back((int32_t)(n - offs.back())); offs.push_back(n);
+		words.push_back(0);
+	}
+	pt.lap("read reference");
+	// ---- clipped sequences ----
+	vector<string> seqs, quals;
+	{
+		gzFile f = gzopen(fq.c_str(), "rb");
+		if (!f) die("Cannot open clipped reads file " + fq);
+		string l1, l2, l3, l4;
+		while (gz_getline(f, l1)) {
+			if (!gz_getline(f, l2) || !gz_getline(f, l3) || !gz_getline(f, l4)) die("Truncated FASTQ record in " + fq);
+			if (l1.empty() || l1[0] != '@' || l3.empty() || l3[0] != '+') die("Malformed FASTQ record in " + fq);
+			seqs.push_back(l2);
+			quals.push_back(l4);
+		}
+		gzclose(f);
+	}
+	const int64_t n = (int64_t)seqs.size();
+	pt.lap("read fastq");
+	ssv_ctx *ctx = nullptr;
+	if (ssv_ctx_create(gpu, &ctx) != SSV_OK) die(string("[seeksv] GPU context: ") + ssv_last_error(nullptr));
+	int64_t dropped = 0;
+	if (ssv_realign_index(ctx, words.data(), SSV_MEM_HOST, offs.back(), offs.data(), (int32_t)names.size(), &dropped) != SSV_OK) die(string("[seeksv] realign index: ") + ssv_last_error(ctx));
+	pt.lap("index");
+	string blob;
+	vector<uint64_t> soff(1, 0);
+	for (const string &q : seqs) { blob += q; soff.push_back(blob.size()); }
+	vector<ssv_realign_hit> hits((size_t)n);
+	if (ssv_realign_query(ctx, blob.data(), soff.data(), n, hits.data()) != SSV_OK) die(string("[seeksv] realign query: ") + ssv_last_error(ctx));
+	pt.lap("align");
+	// ---- BAM records (read name = sequence as given; SEQ / QUAL reverse-complemented / reversed for reverse-strand hits) ----
+	vector<int32_t> tid((size_t)n), pos((size_t)n), lq((size_t)n), mtid((size_t)n, -1), mpos((size_t)n, -1), isz((size_t)n, 0);
+	vector<uint16_t> flag((size_t)n), ncig((size_t)n);
+	vector<uint8_t> mapq((size_t)n), seqqual;
+	vector<uint32_t> cig_off((size_t)n), cig;
+	vector<uint64_t> seq_off((size_t)n);
+	vector<const char *> qn((size_t)n);
+	auto code4 = [](char ch) -> uint8_t {
+		switch (ch) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4; case 'T': case 't': return 8; default: return 15; }
+	};
+	auto comp4 = [](uint8_t b) -> uint8_t { return (uint8_t)(((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3)); };
+	int64_t n_aligned = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		const ssv_realign_hit &h = hits[(size_t)i];
+		const string &s = seqs[(size_t)i], &q = quals[(size_t)i];
+		const int L = (int)s.size();
+		const bool al = h.tid >= 0, rev = al && h.reverse;
+		qn[(size_t)i] = s.c_str();
+		tid[(size_t)i] = al ? h.tid : -1; pos[(size_t)i] = al ? h.pos : -1; lq[(size_t)i] = L;
+		flag[(size_t)i] = (uint16_t)(al ? (rev ? 16 : 0) : 4); mapq[(size_t)i] = al ? h.mapq : 0;
+		cig_off[(size_t)i] = (uint32_t)cig.size();
+		if (al) {
+			++n_aligned;
+			if (h.q_beg > 0) cig.push_back(((uint32_t)h.q_beg << 4) | 4u);
+			cig.push_back(((uint32_t)(h.q_end - h.q_beg) << 4) | 0u);
+			if (h.q_end < L) cig.push_back(((uint32_t)(L - h.q_end) << 4) | 4u);
+		}
+		ncig[(size_t)i] = (uint16_t)(cig.size() - cig_off[(size_t)i]);
+		seq_off[(size_t)i] = seqqual.size();
+		seqqual.resize(seqqual.size() + ((size_t)L + 1) / 2 + (size_t)L, 0);
+		uint8_t *sp = seqqual.data() + seq_off[(size_t)i], *qp = sp + ((size_t)L + 1) / 2;
+		for (int k = 0; k < L; ++k) {
+			const uint8_t b = rev ? comp4(code4(s[(size_t)(L - 1 - k)])) : code4(s[(size_t)k]);
+			sp[k >> 1] |= (k & 1) ? b : (uint8_t)(b << 4);
+			const char qc = (int)q.size() == L ? (rev ? q[(size_t)(L - 1 - k)] : q[(size_t)k]) : '!';
+			qp[k] = (uint8_t)(qc - 33);
+		}
+	}
+	seqqual.resize(seqqual.size() + 16, 0);
+	ssv_batch_t b;
+	memset(&b, 0, sizeof(b));
+	b.n = n; b.mem = SSV_MEM_HOST;
+	b.tid = tid.data(); b.pos = pos.data(); b.flag = flag.data(); b.mapq = mapq.data(); b.n_cigar = ncig.data(); b.l_qseq = lq.data();
+	b.mtid = mtid.data(); b.mpos = mpos.data(); b.isize = isz.data(); b.cigar_off = cig_off.data(); b.cigar = cig.data(); b.n_cigar_total = (int64_t)cig.size();
+	b.seq_off = seq_off.data(); b.seqqual = seqqual.data(); b.seqqual_bytes = (int64_t)seqqual.size() - 16;
+	vector<const char *> tn;
+	for (const string &x : names) tn.push_back(x.c_str());
+	if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), lens.data(), (int32_t)names.size(), &b, qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
+	pt.lap("write bam");
+	cerr << "[seeksv realign] " << n << " clipped sequences, " << n_aligned << " aligned" << (dropped ? ", " + to_string(dropped) + " repetitive index positions dropped" : string()) << endl;
+	ssv_ctx_destroy(ctx);
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc == 1) usage_top();
 	const string cmd = argv[1];
-	if (cmd != "getclip" && cmd != "getsv" && cmd != "somatic") {
+	if (cmd != "getclip" && cmd != "getsv" && cmd != "somatic" && cmd != "realign") {
 		cerr << "[seeksv] unrecognized command '" << argv[1] << "'" << endl;
 		return 1;
 	}
-	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else if (cmd == "getsv") usage_getsv(); else usage_somatic(); }
+	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else if (cmd == "getsv") usage_getsv(); else if (cmd == "realign") usage_realign(); else usage_somatic(); }
 	optind = 1; // like SelectStep (seeksv.cpp:444-452): the sub-command becomes argv[0]
 	if (cmd == "somatic") return cmd_somatic(argc - 1, argv + 1);
+	if (cmd == "realign") return cmd_realign(argc - 1, argv + 1);
 	return cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
 }

@@ -187,3 +187,27 @@ def test_cli_somatic_usage():
     assert r.returncode == 1 and "Error: value of -l must in range [0, 90) " in r.stderr
     r = subprocess.run([SEEKSV, "somatic", "a", "b"], capture_output=True, text=True)
     assert r.returncode == 1 and r.stderr.startswith("3\t1\n") and "Usage: seeksv somatic" in r.stderr
+
+
+@pytest.mark.parametrize("name", list(SYNTH_FULL))
+def test_cli_realign_full_pipeline(tmp_path_factory, name):
+    """The whole pipeline without the external aligner: getclip -> `seeksv realign` (GPU re-aligner) -> getsv.  Every planted
+    junction is found and the SV table equals, in every column, the table the real reference makes from bwa mem's clip.bam."""
+    from seeksv_amd import synth
+    bam, clip_gz, d = _synth_sample(tmp_path_factory, name, SYNTH_FULL[name])
+    w = synth.Workload(**SYNTH_FULL[name])
+    fa = str(d / "ref.fa")
+    with open(fa, "w") as f:
+        f.write(w.reference_fasta())
+    clip_bam = str(d / "realigned.clip.bam")
+    r = subprocess.run([SEEKSV, "realign", fa, clip_gz.replace(".clip.gz", ".clip.fq.gz"), clip_bam], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sv = str(d / "realigned.sv")
+    r = subprocess.run([SEEKSV, "getsv", clip_bam, bam, clip_gz, sv, str(d / "u2.fq")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [l.split("\t") for l in open(sv).read().splitlines() if not l.startswith("@")]
+    want = [l.split("\t") for l in G.read_text("synth", f"{name}.sv").splitlines() if not l.startswith("@")]
+    assert got == want  # all 23 columns of every row: the table equals the one made from bwa mem 0.7.10's clip.bam
+    planted = {(j[0], j[1], j[2], j[3], j[4], j[5]) for j in w.junctions}
+    found = {(c[0], int(c[1]), c[2], c[4], int(c[5]), c[6]) for c in got}
+    assert len(found) == len(planted)
