@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end, file to file: the `seeksv` CLI of this repository next to the REAL reference binary (oracle/_ref/seeksv_ref, built from
 /root/reference by `make -C oracle ref` in the build container; it travels to the GPU box with the snapshot) on the same synthetic BAM.
-Checks that the outputs are identical and prints the wall times.  usage: python tools/cli_vs_reference.py [genome_frac] [depth] [n_sv]"""
+Checks that the outputs are identical and prints the wall times.  usage: python tools/cli_vs_reference.py [genome_frac] [depth] [n_sv] [full]
+With `full` the junction stage runs too (BASELINE config 3 at a size the reference finishes in minutes): `seeksv realign` (the GPU stand-in for
+bwa mem; there is no bwa on the GPU box) makes ONE clip.bam, and both programs run `getsv clip.bam in.bam clip.gz` on it - the two SV tables
+must be identical and must hold every planted junction."""
 import gzip
 import json
 import os
@@ -98,6 +101,32 @@ def main():
         out["speedup_getclip"] = round(out["ref_getclip_s"] / out["ours_getclip_s"], 2)
         out["speedup_getsv"] = round(out["ref_getsv_s"] / out["ours_getsv_s"], 2)
     out["ours_records_per_s"] = round(w.n_total / (out["ours_getclip_s"] + out["ours_getsv_s"]))
+    if len(sys.argv) > 4 and sys.argv[4] == "full":
+        fa = os.path.join(d, "ref.fa")
+        with open(fa, "w") as f:
+            f.write(w.reference_fasta())
+        clip_bam = os.path.join(d, "ours.clip.bam")
+        out["ours_realign_s"], r = timed([OURS, "realign", fa, os.path.join(d, "ours.clip.fq.gz"), clip_bam])
+        assert r.returncode == 0, r.stderr
+        out["realign_summary"] = r.stderr.strip().splitlines()[-1]
+        if phases(r.stderr):
+            out["ours_realign_phases_s"] = phases(r.stderr)
+        full = [clip_bam, bam, os.path.join(d, "ours.clip.gz")]
+        out["ours_getsv_full_s"], r = timed([OURS, "getsv"] + full + [os.path.join(d, "ours.full.sv"), os.path.join(d, "u1.fq")])
+        assert r.returncode == 0, r.stderr
+        if phases(r.stderr):
+            out["ours_getsv_full_phases_s"] = phases(r.stderr)
+        rows = [l.split("\t") for l in open(os.path.join(d, "ours.full.sv")) if not l.startswith("@")]
+        found = {(c[0], int(c[1]), c[2], c[4], int(c[5]), c[6]) for c in rows}
+        planted = {tuple(j[:6]) for j in w.junctions}
+        out["planted"], out["planted_found"], out["sv_rows"] = len(planted), len(planted & found), len(rows)
+        if have_ref:
+            out["ref_getsv_full_s"], rr = timed([REF, "getsv"] + full + [os.path.join(d, "ref.full.sv"), os.path.join(d, "u2.fq")])
+            assert rr.returncode == 0, rr.stderr
+            assert open(os.path.join(d, "ref.full.sv")).read() == open(os.path.join(d, "ours.full.sv")).read()
+            assert rr.stdout == r.stdout
+            out["full_pipeline_sv_table_identical"] = True
+            out["speedup_getsv_full"] = round(out["ref_getsv_full_s"] / out["ours_getsv_full_s"], 2)
     for k in list(out):
         if k.endswith("_s") and not isinstance(out[k], dict):
             out[k] = round(out[k], 3)
