@@ -107,6 +107,8 @@ struct GetsvArgs {
 	// genome tile map: which 512-bp tiles can hold the START of a record that matters (windows are extended to the left by
 	// the longest reference span when the map is built, so one lookup per record is enough)
 	const uint8_t *tilemap;
+	const uint32_t *tile_win;    // per tile with TM_DEPTH: the first window that ends at or after the tile's first column
+	const uint32_t *tile_junc;   // per tile with TM_JUNC: the first junction window that begins after (tile start - junc_wmax)
 	const int64_t *ctg_tile_off; // [n_targets + 1]
 	int32_t n_targets;
 	// discordant
@@ -164,7 +166,7 @@ __device__ __forceinline__ bool discordant_geometry(const DevJunction &j, int fl
 	return false;
 }
 
-__device__ __forceinline__ void discordant_record(const GetsvArgs &a, int64_t i, int tid, int pos)
+__device__ __forceinline__ void discordant_record(const GetsvArgs &a, int64_t i, int tid, int pos, int64_t tile)
 {
 	const DevBatch &b = a.b;
 	if ((int)b.mapq[i] < a.disc_min_mapq) return;
@@ -182,14 +184,9 @@ __device__ __forceinline__ void discordant_record(const GetsvArgs &a, int64_t i,
 			for (int k = 0; k < n; ++k) { uint32_t c = cig[k]; int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) rend += (int)(c >> 4); }
 		}
 	}
-	// junction windows that can overlap [pos, rend): beg in (pos - wmax, rend) on this contig
-	int64_t lo = 0, hi = a.n_junc;
-	const int64_t want = (int64_t)pos - a.junc_wmax;
-	while (lo < hi) {
-		int64_t m = (lo + hi) >> 1;
-		const DevJunction &j = a.junc[m];
-		if (j.up_tid < tid || (j.up_tid == tid && (int64_t)j.beg <= want)) lo = m + 1; else hi = m;
-	}
+	// junction windows that can overlap [pos, rend): beg in (pos - wmax, rend) on this contig.  The tile of the record's start knows the
+	// first junction that begins after (tile start - wmax): a lower bound of the binary search's answer, the loop below skips the rest.
+	const int64_t lo = a.tile_junc[tile];
 	const int mtid = b.mtid[i], mpos = b.mpos[i], lq = b.l_qseq[i];
 	for (int64_t m = lo; m < a.n_junc; ++m) {
 		const DevJunction j = a.junc[m];
@@ -199,19 +196,7 @@ __device__ __forceinline__ void discordant_record(const GetsvArgs &a, int64_t i,
 	}
 }
 
-// first window with (tid, end) >= (tid, col); windows are disjoint and sorted so ends are sorted too
-__device__ __forceinline__ int64_t first_window_ending_at_or_after(const GetsvArgs &a, int tid, int col)
-{
-	int64_t lo = 0, hi = a.n_win;
-	while (lo < hi) {
-		int64_t m = (lo + hi) >> 1;
-		int wt = a.win_tid[m];
-		if (wt < tid || (wt == tid && a.win_end[m] < col)) lo = m + 1; else hi = m;
-	}
-	return lo;
-}
-
-__device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int tid, int pos)
+__device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int tid, int pos, int64_t tile)
 {
 	const DevBatch &b = a.b;
 	if ((int)b.mapq[i] < a.depth_min_mapq) return;                    // read_bam: MAPQ < mapQ -> treated as unmapped
@@ -226,7 +211,7 @@ __device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int 
 		if (op == C_M || op == C_EQ || op == C_X) {
 			if (len > 0) {
 				int s = col, e = col + len - 1;
-				if (w < 0) w = first_window_ending_at_or_after(a, tid, s);
+				if (w < 0) w = a.tile_win[tile]; // first window ending at or after the tile's first column (<= s): the loop below walks on
 				while (w < a.n_win && a.win_tid[w] == tid && a.win_end[w] < s) ++w;
 				for (int64_t x = w; x < a.n_win && a.win_tid[x] == tid && a.win_beg[x] <= e; ++x) {
 					int wb = a.win_beg[x], we = a.win_end[x];
@@ -241,12 +226,71 @@ __device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int 
 	}
 }
 
-// tile-map lookup of one record: which slow paths (if any) it needs
-__device__ __forceinline__ uint32_t getsv_tile_bits(const GetsvArgs &a, int tid, int pos)
+// tile-map lookup of one record: which slow paths (if any) it needs, and its tile
+__device__ __forceinline__ uint32_t getsv_tile_bits(const GetsvArgs &a, int tid, int pos, int64_t &tile)
 {
+	tile = 0;
 	if (tid < 0 || tid >= a.n_targets || pos < 0) return 0;
 	int64_t t = a.ctg_tile_off[tid] + (pos >> TILE_SHIFT);
+	tile = t;
 	return t < a.ctg_tile_off[tid + 1] ? a.tilemap[t] : 0u;
+}
+
+// Built on the device at ssv_getsv_begin (and again when a batch reports a longer reference span): one thread per depth window /
+// junction window marks the tiles that can hold the START (0-based pos) of a record overlapping it - columns [beg, end] 1-based <->
+// pos + 1 <= end, pos + span >= beg - and leaves, per marked tile, where the per-record look-up starts, so that a candidate record
+// needs one load instead of a binary search over the windows / junctions (the value does not depend on which window marks the tile).
+__global__ void k_tile_mark_windows(const int32_t *__restrict__ win_tid, const int32_t *__restrict__ win_beg, const int32_t *__restrict__ win_end, int64_t n_win, int32_t span,
+                                    const int64_t *__restrict__ ctg_tile_off, int32_t n_targets, uint32_t *__restrict__ map32, uint32_t *__restrict__ tile_win)
+{
+	const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_win) return;
+	const int tid = win_tid[w];
+	if (tid < 0 || tid >= n_targets) return;
+	int64_t p0 = (int64_t)win_beg[w] - span, p1 = (int64_t)win_end[w] - 1;
+	if (p1 < 0) return;
+	if (p0 < 0) p0 = 0;
+	const int64_t base = ctg_tile_off[tid], ntile = ctg_tile_off[tid + 1] - base;
+	int64_t t0 = p0 >> TILE_SHIFT, t1 = p1 >> TILE_SHIFT;
+	if (t0 >= ntile) return;
+	if (t1 >= ntile) t1 = ntile - 1;
+	for (int64_t t = t0; t <= t1; ++t) {
+		const int col = (int)(t << TILE_SHIFT) + 1; // first column a record starting in this tile can cover
+		int64_t lo = 0, hi = n_win;                  // first window with (tid, end) >= (tid, col)
+		while (lo < hi) {
+			const int64_t m = (lo + hi) >> 1;
+			const int wt = win_tid[m];
+			if (wt < tid || (wt == tid && win_end[m] < col)) lo = m + 1; else hi = m;
+		}
+		tile_win[base + t] = (uint32_t)lo;
+		atomicOr(&map32[(base + t) >> 2], (uint32_t)TM_DEPTH << (8 * ((base + t) & 3)));
+	}
+}
+
+__global__ void k_tile_mark_junctions(const DevJunction *__restrict__ junc, int64_t n_junc, int32_t span, int32_t wmax, const int64_t *__restrict__ ctg_tile_off, int32_t n_targets,
+                                      uint32_t *__restrict__ map32, uint32_t *__restrict__ tile_junc)
+{
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_junc) return;
+	const int tid = junc[k].up_tid;
+	if (tid < 0 || tid >= n_targets) return;
+	int64_t p0 = (int64_t)junc[k].beg - span, p1 = (int64_t)junc[k].end - 1; // rend > beg && pos < end
+	if (p1 < 0) return;
+	if (p0 < 0) p0 = 0;
+	const int64_t base = ctg_tile_off[tid], ntile = ctg_tile_off[tid + 1] - base;
+	int64_t t0 = p0 >> TILE_SHIFT, t1 = p1 >> TILE_SHIFT;
+	if (t0 >= ntile) return;
+	if (t1 >= ntile) t1 = ntile - 1;
+	for (int64_t t = t0; t <= t1; ++t) {
+		const int64_t want = (t << TILE_SHIFT) - (int64_t)wmax; // records of this tile have pos >= tile start
+		int64_t lo = 0, hi = n_junc;                             // first junction with (up_tid, beg) > (tid, want)
+		while (lo < hi) {
+			const int64_t m = (lo + hi) >> 1;
+			if (junc[m].up_tid < tid || (junc[m].up_tid == tid && (int64_t)junc[m].beg <= want)) lo = m + 1; else hi = m;
+		}
+		tile_junc[base + t] = (uint32_t)lo;
+		atomicOr(&map32[(base + t) >> 2], (uint32_t)TM_JUNC << (8 * ((base + t) & 3)));
+	}
 }
 
 struct GetsvStage {
@@ -369,9 +413,10 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 	for (uint32_t k = lane_id(); k < n; k += WAVE) {
 		const int64_t i = g.stage[so + k];
 		const int tid = a.b.tid[i], pos = a.b.pos[i];
-		const uint32_t m = getsv_tile_bits(a, tid, pos);
-		if (m & TM_JUNC) discordant_record(a, i, tid, pos);
-		if (m & TM_DEPTH) depth_record(a, i, tid, pos);
+		int64_t tile;
+		const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
+		if (m & TM_JUNC) discordant_record(a, i, tid, pos, tile);
+		if (m & TM_DEPTH) depth_record(a, i, tid, pos, tile);
 	}
 }
 

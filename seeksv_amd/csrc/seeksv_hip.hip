@@ -106,11 +106,10 @@ struct ssv_ctx {
 	std::vector<ssv_interval> gs_win;
 	std::vector<int32_t> gs_tlen;
 	std::vector<int64_t> gs_ctg_tile_off;
-	std::vector<uint8_t> gs_tilemap_host;
 	int32_t gs_map_span = -1;
 	int32_t gs_wmax = 0;
 	int64_t gs_diff_len = 0;
-	DBuf gs_djunc, gs_counts, gs_wtid, gs_wbeg, gs_wend, gs_woff, gs_diff, gs_tilemap, gs_ctgoff, gs_maxdepth, gs_span;
+	DBuf gs_djunc, gs_counts, gs_wtid, gs_wbeg, gs_wend, gs_woff, gs_diff, gs_tilemap, gs_tile_win, gs_tile_junc, gs_ctgoff, gs_maxdepth, gs_span;
 	DBuf q_tid, q_beg, q_end, q_out64, q_out32;
 	HBuf h_q;
 
@@ -355,7 +354,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap,
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc,
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
@@ -789,24 +788,17 @@ int ssv_isize_finish(ssv_ctx *c, int64_t *n_pairs, int32_t *mean, int32_t *sd)
 
 static int gs_build_tilemap(ssv_ctx *c, int32_t span)
 {
-	// which 512-bp tiles can hold the start (0-based pos) of a record that overlaps a depth window / is a candidate of a junction window
-	std::vector<uint8_t> &tm = c->gs_tilemap_host;
-	std::fill(tm.begin(), tm.end(), 0);
-	const int nt = (int)c->gs_tlen.size();
-	auto mark = [&](int tid, int64_t p0, int64_t p1, uint8_t bit) { // pos range [p0, p1] inclusive, 0-based
-		if (tid < 0 || tid >= nt || p1 < 0) return;
-		if (p0 < 0) p0 = 0;
-		int64_t ntile = c->gs_ctg_tile_off[tid + 1] - c->gs_ctg_tile_off[tid];
-		int64_t t0 = p0 >> TILE_SHIFT, t1 = p1 >> TILE_SHIFT;
-		if (t0 >= ntile) return;
-		if (t1 >= ntile) t1 = ntile - 1;
-		for (int64_t t = t0; t <= t1; ++t) tm[(size_t)(c->gs_ctg_tile_off[tid] + t)] |= bit;
-	};
-	for (const ssv_interval &w : c->gs_win) mark(w.tid, (int64_t)w.beg - span, (int64_t)w.end - 1, TM_DEPTH);    // cols [beg,end] 1-based <-> pos+1 <= end, pos+span >= beg
-	for (const DevJunction &j : c->gs_junc) mark(j.up_tid, (int64_t)j.beg - span, (int64_t)j.end - 1, TM_JUNC);    // rend > beg && pos < end
-	CHECK(ensure(c, c->gs_tilemap, tm.size() + 16));
-	if (!tm.empty()) HIPCHECK(c, hipMemcpyAsync(c->gs_tilemap.p, tm.data(), tm.size(), hipMemcpyHostToDevice, c->st));
-	HIPCHECK(c, hipStreamSynchronize(c->st));
+	// which 512-bp tiles can hold the start (0-based pos) of a record that overlaps a depth window / is a candidate of a junction window,
+	// and where such a record's look-up starts: marked by the windows and junctions themselves, on the device
+	const size_t ntile = (size_t)c->gs_ctg_tile_off.back();
+	CHECK(ensure(c, c->gs_tilemap, ntile + 16)); CHECK(ensure(c, c->gs_tile_win, ntile * 4 + 16)); CHECK(ensure(c, c->gs_tile_junc, ntile * 4 + 16));
+	HIPCHECK(c, hipMemsetAsync(c->gs_tilemap.p, 0, ntile + 16, c->st));
+	const int64_t nw = (int64_t)c->gs_win.size(), nj = (int64_t)c->gs_junc.size();
+	if (nw) k_tile_mark_windows<<<grid_for(nw, BLOCK), BLOCK, 0, c->st>>>(P<int32_t>(c->gs_wtid), P<int32_t>(c->gs_wbeg), P<int32_t>(c->gs_wend), nw, span, P<int64_t>(c->gs_ctgoff),
+	                                                                        c->gs_p.n_targets, P<uint32_t>(c->gs_tilemap), P<uint32_t>(c->gs_tile_win));
+	if (nj) k_tile_mark_junctions<<<grid_for(nj, BLOCK), BLOCK, 0, c->st>>>(P<DevJunction>(c->gs_djunc), nj, span, c->gs_wmax, P<int64_t>(c->gs_ctgoff), c->gs_p.n_targets,
+	                                                                          P<uint32_t>(c->gs_tilemap), P<uint32_t>(c->gs_tile_junc));
+	HIPCHECK(c, hipGetLastError());
 	c->gs_map_span = span;
 	return SSV_OK;
 }
@@ -820,7 +812,6 @@ int ssv_getsv_begin(ssv_ctx *c, const ssv_getsv_params *p)
 	c->gs_tlen.assign(p->target_len, p->target_len + p->n_targets);
 	c->gs_ctg_tile_off.assign((size_t)p->n_targets + 1, 0);
 	for (int t = 0; t < p->n_targets; ++t) c->gs_ctg_tile_off[(size_t)t + 1] = c->gs_ctg_tile_off[(size_t)t] + ((int64_t)std::max(0, c->gs_tlen[(size_t)t]) >> TILE_SHIFT) + 1;
-	c->gs_tilemap_host.assign((size_t)c->gs_ctg_tile_off.back(), 0);
 	c->gs_map_span = -1;
 	// junctions sorted by (up_tid, beg); the window test itself is repeated exactly on the device
 	c->gs_junc.clear();
@@ -886,7 +877,7 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	}
 	if (span > c->gs_map_span) CHECK(gs_build_tilemap(c, span));
 	GetsvArgs a;
-	a.b = d; a.tilemap = P<uint8_t>(c->gs_tilemap); a.ctg_tile_off = P<int64_t>(c->gs_ctgoff); a.n_targets = c->gs_p.n_targets;
+	a.b = d; a.tilemap = P<uint8_t>(c->gs_tilemap); a.tile_win = P<uint32_t>(c->gs_tile_win); a.tile_junc = P<uint32_t>(c->gs_tile_junc); a.ctg_tile_off = P<int64_t>(c->gs_ctgoff); a.n_targets = c->gs_p.n_targets;
 	a.junc = P<DevJunction>(c->gs_djunc); a.n_junc = (int64_t)c->gs_junc.size(); a.junc_wmax = c->gs_wmax;
 	a.mean = c->gs_p.mean; a.sd = c->gs_p.sd; a.times = c->gs_p.times; a.disc_min_mapq = c->gs_p.disc_min_mapq;
 	a.min_ins = std::max(0, a.mean - a.sd * a.times); a.max_ins = a.mean + a.sd * a.times; // getsv.cpp:1032-1034
