@@ -30,21 +30,21 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const TIn *__restrict__ i
 	}
 }
 
-// one workgroup: exclusive scan of sums[0..m) in place; *total = carry_in + sum of everything
+// one workgroup: exclusive scan of sums[0..m) in place; *total = carry_in + sum of everything.  Every thread owns a contiguous run of
+// ceil(m / BLOCK) sums, so the whole array takes one block-level scan (two barriers) whatever m is - this kernel runs once per
+// device-wide scan, ~25 times per pass of the path, and a loop of 256-element rounds made it the longest part of the small scans.
 template <typename TOut>
 __global__ __launch_bounds__(BLOCK) void k_scan_sums(TOut *__restrict__ sums, int64_t m, TOut carry_in, TOut *__restrict__ total)
 {
 	__shared__ TOut lds[WAVES_PER_BLOCK + 1];
-	TOut carry = carry_in;
-	for (int64_t base = 0; base < m; base += BLOCK) {
-		int64_t i = base + threadIdx.x;
-		TOut v = i < m ? sums[i] : (TOut)0;
-		TOut tot;
-		TOut ex = block_exclusive_sum(v, lds, &tot);
-		if (i < m) sums[i] = carry + ex;
-		carry += tot;
-	}
-	if (threadIdx.x == 0 && total) *total = carry;
+	const int64_t per = (m + BLOCK - 1) / BLOCK;
+	const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+	TOut s = 0;
+	for (int64_t i = lo; i < hi; ++i) s += sums[i];
+	TOut tot;
+	TOut ex = carry_in + block_exclusive_sum(s, lds, &tot);
+	for (int64_t i = lo; i < hi; ++i) { const TOut v = sums[i]; sums[i] = ex; ex += v; }
+	if (threadIdx.x == 0 && total) *total = carry_in + tot;
 }
 
 // out[i] = block_sums[block] + exclusive prefix of in within the block (block_sums already include carry_in)
