@@ -246,3 +246,15 @@ def test_range_partitioned_hip_equals_single(ctx, kw, world):
     assert sorted(rows, key=lambda r: r[:3]) == sorted(cluster_rows(single), key=lambda r: r[:3])
     plan.close()
     hdr.close()
+
+
+def test_config3_streaming_chunking_independent():
+    """BASELINE config 3's shape (300x, planted SVs) streamed through the path in HBM-sized chunks under two chunkings (tools/config3_full_size.py
+    runs this at the full 6.2 G records): identical cluster table (sha256 of every column) and identical tallies / depths wherever the
+    batches are cut; event conservation; every planted junction seen by both getsv passes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import config3_full_size as C3
+    out = C3.main(genome_frac=1 / 128, depth=300, n_sv=80, chunks_a=3, chunks_b=7)
+    assert out["results_identical"] and out["junctions_with_discordant_pairs"] == out["junctions"] == 80
+    assert out["records"] > 40_000_000 and out["table"]["max_support"] > 50
