@@ -47,7 +47,23 @@ oracle:
 oracle-ref:
 	$(MAKE) -C oracle ref
 
+# Sanitizer pass over everything that runs on the CPU (GPU AddressSanitizer is not available on the pool): host library, CPU build of the
+# generator, the oracle and the CLI's host stages under ASan + UBSan, then the CPU test suite against that build.
+ASAN_DIR = build/asan
+ASAN_FLAGS = -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined
+asan: $(LIBDIR)/libseeksv_hip.so
+	mkdir -p $(ASAN_DIR)
+	$(CXX) $(ASAN_FLAGS) -std=c++17 -Wall -Wextra -fPIC -Iinclude -shared -o $(ASAN_DIR)/libseeksv_host.so $(HOST_SRC) -lz -lpthread
+	$(CXX) $(ASAN_FLAGS) -std=c++17 -Wall -Wextra -fPIC -Iinclude -shared -o $(ASAN_DIR)/libseeksv_synth_cpu.so seeksv_amd/csrc/synth_cpu.cpp
+	gcc $(ASAN_FLAGS) -std=c11 -Wall -Wextra -fPIC -shared -o $(ASAN_DIR)/liboracle.so oracle/seeksv_oracle.c -lm
+	cp $(LIBDIR)/libseeksv_hip.so $(ASAN_DIR)/
+	$(CXX) $(ASAN_FLAGS) -std=c++17 -Wall -Wextra -Iinclude -o $(ASAN_DIR)/seeksv seeksv_amd/host/seeksv_cli.cpp seeksv_amd/host/junction_stage.cpp seeksv_amd/host/somatic_stage.cpp \
+		-L$(ASAN_DIR) -lseeksv_host -lseeksv_hip -lz -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,$(ROCM)/lib
+	LD_PRELOAD=$$(gcc -print-file-name=libasan.so):$$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
+		SSV_LIBDIR=$(abspath $(ASAN_DIR)) SSV_ORACLE_SO=$(abspath $(ASAN_DIR))/liboracle.so SSV_CLI=$(abspath $(ASAN_DIR))/seeksv \
+		python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
+
 clean:
 	rm -rf $(LIBDIR) && $(MAKE) -C oracle clean
 
-.PHONY: all host hip synth cli oracle oracle-ref clean
+.PHONY: all host hip synth cli oracle oracle-ref asan clean

@@ -15,6 +15,7 @@
 #ifndef SEEKSV_HIP_H_
 #define SEEKSV_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(_HERE, "lib")
+LIBDIR = os.environ.get("SSV_LIBDIR") or os.path.join(_HERE, "lib")  # SSV_LIBDIR: an alternative build of the libraries (`make asan`)
 
 NO_SEQ = (1 << 64) - 1
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -17,7 +17,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        so = os.environ.get("SSV_ORACLE_SO") or os.path.join(ORACLE_DIR, "liboracle.so")
         src = os.path.join(ORACLE_DIR, "seeksv_oracle.c")
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)

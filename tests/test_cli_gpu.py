@@ -26,7 +26,7 @@ def inflate_mode(request, monkeypatch):
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SEEKSV = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
+SEEKSV = os.environ.get("SSV_CLI") or os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
 
 GETCLIP = [("example", "cancer.sort.bam", "cancer", []), ("example", "normal.sort.bam", "normal", []), ("getclip", "filters.bam", "filters", []),
            ("getclip", "filters.bam", "filters.s", ["-s"]), ("getclip", "filters.bam", "filters.q30", ["-q", "30"]), ("getclip", "stress1.bam", "stress1.t08", ["-t", "0.8"]),

@@ -8,7 +8,7 @@ import pytest
 import golden_util as G
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SEEKSV = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
+SEEKSV = os.environ.get("SSV_CLI") or os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
 
 
 @pytest.mark.parametrize("sample", ["cancer", "normal"])

@@ -11,7 +11,7 @@ import oracle_lib
 from seeksv_amd import host, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SEEKSV = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
+SEEKSV = os.environ.get("SSV_CLI") or os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
 SYNTH_FULL = dict(genome_frac=1 / 8192, depth=40, n_sv=24)
 
 
