@@ -472,6 +472,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
 			HIPCHECK(c, hipStreamSynchronize(c->st));
 			nb = (int64_t)(uint32_t)hc->n_new;
+			if (c->n_events + nb >= (1ll << 32) - 1) { c->err = "more than 2^32 clip events in one pass (the sorted permutation is 32 bits wide)"; return SSV_E_RANGE; }
 			if (nb > 0) {
 				CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nb) * 8));
 				exclusive_scan<uint32_t, uint64_t>(c->st, ev.seq_bytes + c->n_events, ev.seq_off + c->n_events, nb, c->seq_used, P<uint64_t>(c->scan_scratch64),
