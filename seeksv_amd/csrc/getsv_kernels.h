@@ -208,7 +208,7 @@ __device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int 
 	for (int k = 0; k < n; ++k) {
 		uint32_t c = cig[k];
 		int op = (int)(c & 15u), len = (int)(c >> 4);
-		if (op == C_M || op == C_EQ || op == C_X) {
+		if (op == C_M) { // libbam 0.1.16 pileup: only M covers, only M / D / N advance; '=' and 'X' are skipped like padding (tests/golden/getsv/eqx.*)
 			if (len > 0) {
 				int s = col, e = col + len - 1;
 				if (w < 0) w = a.tile_win[tile]; // first window ending at or after the tile's first column (<= s): the loop below walks on

@@ -305,12 +305,48 @@ def getsv_case(seed, n_pairs=6000, L=100, with_small_contig=True):
     return names, lens, recs, junctions
 
 
+def eqx_case():
+    """reads whose CIGARs use '=' / 'X' (and an 'S' + '=' + 'M' mix) among plain M reads: pins what the depth pass of libbam 0.1.16 does with them"""
+    names, lens = ["chrA", "chrB"], [20000, 5000]
+    recs = []
+
+    def mk(tid, pos, cigar, flag=99, mapq=60):
+        lq = sum(l for l, op in bamio.parse_cigar(cigar) if op in (0, 1, 4, 7, 8))
+        recs.append(dict(qname=f"q{len(recs)}", flag=flag, tid=tid, pos=pos, mapq=mapq, cigar=cigar, mtid=tid, mpos=pos + 200, isize=280 + pos % 41, seq="A" * lq, qual=b"\x1e" * lq))
+    for p in range(900, 1300, 7): mk(0, p, "100M")
+    for p in range(1000, 1100, 3): mk(0, p, "100=")
+    for p in range(1001, 1100, 5): mk(0, p, "40=5X55=")
+    for p in range(1002, 1100, 11): mk(0, p, "30M10X60=")
+    for p in range(1003, 1100, 13): mk(0, p, "10S40=50M")
+    for p in range(1004, 1100, 17): mk(0, p, "20M5D10=3I20X30M")
+    for p in range(300, 500, 9): mk(1, p, "50=50M", flag=163)
+    for p in range(305, 500, 19): mk(1, p, "25X25M2D25=25M", flag=83, mapq=30)
+    junctions = [("chrA", 1050, "+", "chrA", 1150, "+"), ("chrA", 1100, "+", "chrA", 1250, "+"), ("chrA", 950, "+", "chrA", 1201, "+"),
+                 ("chrA", 1030, "-", "chrB", 400, "+"), ("chrB", 350, "+", "chrB", 460, "-")]
+    # discordant pairs so that the junctions reach the SV table with their flank depths (some of the supporting reads use '=' too)
+    for k, (uc, up, us, dc, dp, ds) in enumerate(junctions):
+        ta, tb = names.index(uc), names.index(dc)
+        for r in range(4):
+            cigar = "100M" if r % 2 == 0 else "60=40M"
+            if us == "+" and ds == "+":
+                pos, mpos, flag = up - 130 - 9 * r, dp + 15 + r, 97
+            elif us == "-":
+                pos, mpos, flag = up + 10 + 7 * r, dp + 140 + r, 113
+            else:
+                pos, mpos, flag = up - 140 - 5 * r, dp - 100 - 120 - r, 65
+            lq = 100
+            recs.append(dict(qname=f"d{k}_{r}", flag=flag, tid=ta, pos=pos, mapq=60, cigar=cigar, mtid=tb, mpos=mpos, isize=0 if ta != tb else mpos - pos, seq="A" * lq, qual=b"\x1e" * lq))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    junctions.sort(key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
+    return names, lens, recs, junctions
+
+
 def crafted_getsv():
     out = os.path.join(HERE, "getsv")
     os.makedirs(out, exist_ok=True)
     # header-only clip.bam and empty clip file for the harness
-    for name, seed, kw in (("pairs1", 5, {}), ("pairs2", 6, dict(n_pairs=12000, L=150)), ("pairs3", 7, dict(n_pairs=3000, with_small_contig=False))):
-        names, lens, recs, junctions = getsv_case(seed, **kw)
+    for name, seed, kw in (("pairs1", 5, {}), ("pairs2", 6, dict(n_pairs=12000, L=150)), ("pairs3", 7, dict(n_pairs=3000, with_small_contig=False)), ("eqx", None, {})):
+        names, lens, recs, junctions = getsv_case(seed, **kw) if seed is not None else eqx_case()
         bam = os.path.join(out, f"{name}.bam")
         bamio.write_bam(bam, names, lens, recs)
         run([os.path.join(BIN, "bamidx"), bam])

@@ -29,6 +29,7 @@ GETSV_CASES = [
     ("pairs1", "pairs1.L1", dict(flank_length=1)),
     ("pairs2", "pairs2", dict()),
     ("pairs3", "pairs3", dict()),
+    ("eqx", "eqx", dict()),   # '=' / 'X' CIGAR operations in the depth pass (skipped by libbam 0.1.16's pileup)
 ]
 
 
