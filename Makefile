@@ -49,7 +49,7 @@ oracle-ref:
 
 # Sanitizer pass over everything that runs on the CPU (GPU AddressSanitizer is not available on the pool): host library, CPU build of the
 # generator, the oracle and the CLI's host stages under ASan + UBSan, then the CPU test suite against that build.
-ASAN_DIR = build/asan
+ASAN_DIR ?= /tmp/seeksv_asan
 ASAN_FLAGS = -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined
 asan: $(LIBDIR)/libseeksv_hip.so
 	mkdir -p $(ASAN_DIR)
