@@ -6,7 +6,8 @@
 // getsv.h:445-527).  This is a stand-in for that step on hosts without bwa, for references that behave like random sequence
 // (the synthetic genomes of bench / tests): a k-mer index of the reference in HBM, seed look-ups for every k-mer of a query on
 // both strands, ungapped extension with bwa mem's default scores (match 1, mismatch 4, end clipping 5, report >= 30).
-// It does not reproduce bwa's alignments bit for bit (no gapped extension, no chaining, no supplementary records).
+// It does not reproduce bwa's alignments bit for bit (no gapped extension, no chaining, no supplementary records; at most
+// RA_MAX_CAND seed hits per query are followed, probe runs longer than RA_MAX_PROBE are cut).
 //
 // Index: every SAMPLE-th reference position p whose K-mer lies inside one contig is a slot of an open-addressing table
 // (u32 slot = p / SAMPLE + 1, 0 = empty; linear probing; load <= 1/2); a slot does not hold its key - a look-up checks the K-mer
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(BLOCK) void k_ra_query(RaQueryArgs a)
 {
 	__shared__ uint8_t s_code[WAVES_PER_BLOCK][2][RA_MAX_Q];
 	__shared__ int64_t s_diag[WAVES_PER_BLOCK][RA_MAX_CAND];
-	__shared__ uint8_t s_strand[WAVES_PER_BLOCK][RA_MAX_CAND];
+	__shared__ uint16_t s_so[WAVES_PER_BLOCK][RA_MAX_CAND]; // seed offset in the query | strand << 15
+	__shared__ uint16_t s_tid[WAVES_PER_BLOCK][RA_MAX_CAND]; // contig of the seed (a query can hang over a contig's end: same diagonal, two contigs)
 	__shared__ int s_n[WAVES_PER_BLOCK];
 	const int w = wave_id(), lane = lane_id();
 	const int64_t q = (int64_t)blockIdx.x * WAVES_PER_BLOCK + w;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(BLOCK) void k_ra_query(RaQueryArgs a)
 				const int64_t p = (int64_t)(v - 1u) * RA_SAMPLE;
 				if (ra_kmer_at(ix.ref, p) == km) {
 					const int at = atomicAdd(&s_n[w], 1);
-					if (at < RA_MAX_CAND) { s_diag[w][at] = p - o; s_strand[w][at] = (uint8_t)st; }
+					if (at < RA_MAX_CAND) { s_diag[w][at] = p - o; s_so[w][at] = (uint16_t)(o | (st << 15)); s_tid[w][at] = (uint16_t)ra_contig_of(ix, p); }
 				}
 				slot = (slot + 1) & ix.mask;
 			}
@@ -165,17 +167,14 @@ __global__ __launch_bounds__(BLOCK) void k_ra_query(RaQueryArgs a)
 		const int c = c0 + lane;
 		bool mine = c < m;
 		int64_t d = 0;
-		int st = 0;
+		int st = 0, t = 0;
 		if (mine) {
-			d = s_diag[w][c]; st = s_strand[w][c];
-			for (int e = 0; e < c; ++e) if (s_diag[w][e] == d && s_strand[w][e] == st) { mine = false; break; }
+			d = s_diag[w][c]; st = s_so[w][c] >> 15; t = s_tid[w][c];
+			for (int e = 0; e < c; ++e) if (s_diag[w][e] == d && (s_so[w][e] >> 15) == st && s_tid[w][e] == t) { mine = false; break; }
 		}
 		if (!mine) continue;
 		const uint8_t *code = s_code[w][st];
-		// the contig of the diagonal = the contig of any of its seeds; take the reference position of the query's middle and clamp
-		int64_t mid = d + n / 2;
-		mid = mid < 0 ? 0 : (mid >= ix.n_bases ? ix.n_bases - 1 : mid);
-		const int t = ra_contig_of(ix, mid);
+		// the query is scored inside the contig of the seed only (a seed never spans two contigs)
 		const int64_t c_lo = ix.ctg_off[t], c_hi = ix.ctg_off[t + 1];
 		int i_lo = (int)(c_lo - d > 0 ? c_lo - d : 0), i_hi = (int)(c_hi - d < n ? c_hi - d : n); // query positions inside the contig
 		if (i_hi - i_lo < RA_K) continue;
@@ -218,7 +217,8 @@ __global__ __launch_bounds__(BLOCK) void k_ra_query(RaQueryArgs a)
 		if (take) { win_score = os; win_lane = ol; win_diag = od; win_st = ost; }
 	}
 	if (win_score < RA_MIN_SCORE) { if (lane == 0) a.hits[q] = out; return; }
-	const bool same_locus = best_score > 0 && best_st == win_st && (best_diag - win_diag <= 32 && win_diag - best_diag <= 32);
+	const int win_tid = __shfl(best_tid, win_lane, 64);
+	const bool same_locus = best_score > 0 && best_st == win_st && best_tid == win_tid && (best_diag - win_diag <= 32 && win_diag - best_diag <= 32);
 	int second = (best_score > 0 && !same_locus) ? best_score : 0;
 	second = wave_max(second);
 	if (lane == win_lane) {

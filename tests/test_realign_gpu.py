@@ -70,6 +70,12 @@ def test_realign_constructed_queries(ctx, device_ref):
     junk = ["".join("ACGT"[x] for x in rng.randint(0, 4, 60)) for _ in range(50)] + ["ACGTACGTACGTACG", "", "N" * 40]
     hj = ctx.realign(junk)
     assert (hj["tid"] == -1).all()
+    # a query hanging over a contig's end: 40 bases of the end of contig 3 followed by the first 60 of contig 4 -> the longer part wins,
+    # the other part is soft clipped; and the mirror image (60 + 35)
+    over = ctx.realign([ref[3][-40:] + ref[4][:60], ref[7][-60:] + ref[8][:35]])
+    assert (over["tid"][0], over["pos"][0], over["q_beg"][0], over["q_end"][0]) == (4, 0, 40, 100)
+    assert (over["tid"][1], over["pos"][1], over["q_beg"][1], over["q_end"][1]) == (7, len(ref[7]) - 60, 0, 60)
+    assert over["second"][0] >= 40 and over["second"][1] >= 35  # the other contig's part is the runner-up
     # the last bases of the last contig (HBV) and the first of the first
     ends = [ref[-1][-50:], ref[0][:45], ref[-1][:40].translate(COMP)[::-1]]
     he = ctx.realign(ends)
