@@ -145,11 +145,12 @@ typedef struct {
 	                              [seq_left ceil(left_len/2) B | qual_left | seq_right ceil(right_len/2) B | qual_right]
 	                              with the sequences as 4-bit codes, two per byte, first base in the high nibble, index into
 	                              "=ACMGRSVTWYHKDBN" (BAM's own packing).  The table is the path's output and it crosses PCIe. */
-	int32_t qual_bits;         /* 8: qualities are characters (phred + 33), one byte each.  1, 2, 4 (format 2 only, when at most 2, 4,
-	                              16 distinct quality values occur in the pass): quality i of a piece is an index into qual_alphabet,
-	                              qual_bits wide, at bit (i * qual_bits) % 8 of byte (i * qual_bits) / 8; a piece of n qualities takes
-	                              ceil(n * qual_bits / 8) bytes.  Lossless: base qualities are most of the table's bytes and come from
-	                              a small alphabet (4 to ~40 values, depending on the sequencer). */
+	int32_t qual_bits;         /* 8: qualities are characters (phred + 33), one byte each.  1, 2, 3, 4 (format 2 only, when at most 2, 4, 8,
+	                              16 distinct quality values occur in the pass): a piece of n qualities is the stream of their indices
+	                              into qual_alphabet, qual_bits wide each, quality i at stream bit i * qual_bits (bit b of the stream = bit
+	                              b % 8 of byte b / 8; with 3 bits an index can straddle two bytes); the piece takes
+	                              ceil(n * qual_bits / 8) bytes, unused bits are 0.  Lossless: base qualities are most of the table's bytes
+	                              and come from a handful of values on current sequencers. */
 	uint8_t qual_alphabet[16]; /* index -> quality character */
 } ssv_cluster_table;
 

@@ -775,7 +775,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, int64_
 // lane works on whole dwords twice:
 //   0. the event's entry (packed bases + qualities, <= 384 B) into LDS: one batch of independent, coalesced loads per cluster.
 //   1. piece dwords into LDS: a sequence piece dword is 8 nibbles of the BAM-packed read = a 40-bit window of the source shifted by
-//      0 or 4 bits (the table keeps BAM's nibble order); a quality piece dword is 32 / W source bytes through the alphabet LUT.
+//      0 or 4 bits (the table keeps BAM's nibble order); a quality piece dword is the next 32 bits of the stream of W-bit alphabet indices.
 //      Tails are zeroed, and every piece sits between zero guard dwords.
 //   2. output dword at block byte o = OR over the (1, rarely 2-3) pieces it overlaps of that piece's bytes [o - start, o - start + 4):
 //      two LDS dwords and one alignbyte each; the guards supply the zeros on either side of a piece.
@@ -803,7 +803,6 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 	const uint32_t cig_first = gl < ncg ? cig_blob[scig + gl] : 0u; // issued with the entry's loads below; CIGARs longer than 16 ops finish at the end
 	const bool fast = active && lq >= 0 && lq <= PACK_MAX_LQ && ll + lr <= PACK_MAX_LQ;
 	// piece k: 0 seq_left, 1 qual_left, 2 seq_right, 3 qual_right; nB bytes, nD dwords, at block byte oP, at LDS dword st
-	constexpr int QPD = 32 / W; // qualities per dword
 	int nB[4], nD[4], oP[4], st[4];
 	nB[0] = (ll + 1) / 2; nB[1] = (ll * W + 7) / 8; nB[2] = (lr + 1) / 2; nB[3] = (lr * W + 7) / 8;
 	{
@@ -846,33 +845,38 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 				L[st[k] + t] = v;
 			}
 		}
-		// quality pieces
+		// quality pieces: a piece is the bit stream of its W-bit indices, quality i at stream bit i * W (for W = 3 an index can straddle
+		// a byte or a dword); dword t of the piece = stream bits [32 t, 32 t + 32) = the CNT qualities from i0 = 32 t / W on, shifted
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			const int q0 = begin + (h ? ll : 0), len = h ? lr : ll, k = 2 * h + 1;
 			for (int t = gl; t < nD[k]; t += GROUP) {
-				const int a = qb + q0 + t * QPD; // first source byte
+				constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
+				const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
+				const int a = qb + q0 + i0;                            // first source byte
 				const uint32_t *q4 = s4 + (a >> 2);
 				const int sh = a & 3;
-				const int rem = len - t * QPD;   // qualities of the piece in this dword
-				uint32_t v = 0;
+				const int rem = len - i0;                              // qualities of the piece from i0 on
+				uint64_t acc = 0;
 				uint32_t prev = q4[0];
 #pragma unroll
-				for (int j = 0; j < QPD / 4; ++j) {
-					if (4 * j >= rem) break; // nothing of the piece left (also keeps the reads inside the staged entry)
-					const uint32_t next = q4[j + 1];
+				for (int g = 0; g < (CNT + 3) / 4; ++g) {
+					if (4 * g >= rem) break; // nothing of the piece left (also keeps the reads inside the staged entry)
+					const uint32_t next = q4[g + 1];
 					const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
 					prev = next;
-					if (W == 8) v = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
+					if (W == 8) acc = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
 					else {
 #pragma unroll
 						for (int b = 0; b < 4; ++b) {
+							const int j = 4 * g + b;
 							const uint32_t ph = qmiss ? (uint32_t)('*' - 33) : (four >> (8 * b)) & 0xffu;
-							v |= (uint32_t)s_lut[ph] << ((4 * j + b) * W);
+							if (j < CNT && j < rem) acc |= (uint64_t)s_lut[ph] << (j * W);
 						}
 					}
 				}
-				if (rem < QPD) v &= (W == 8 ? (1u << (8 * rem)) : (1u << (rem * W))) - 1u;
+				uint32_t v = (uint32_t)(acc >> off);
+				if (W == 8 && rem < 4) v &= (1u << (8 * rem)) - 1u;
 				L[st[k] + t] = v;
 			}
 		}
@@ -913,7 +917,6 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 		auto qual_at = [&](bool right, int i) -> uint32_t { // character
 			return single ? (uint32_t)(uint8_t)v.qual(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rq[i] : cq[ll - 1 - i]);
 		};
-		constexpr int per = 8 / W;
 		const int A = nB[0], QA = nB[1], C = nB[2];
 		for (int w = gl; w * 4 < total; w += GROUP) {
 			uint32_t word = 0;
@@ -926,7 +929,12 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 					const int r = right ? q - A - QA : q, S = right ? C : A, n = right ? lr : ll;
 					if (r >= S) {
 						if (W == 8) ch = qual_at(right, r - S);
-						else for (int t = 0, i = (r - S) * per; t < per && i < n; ++t, ++i) ch |= (uint32_t)s_lut[(qual_at(right, i) - 33u) & 255u] << (t * W);
+						else { // stream bits [8 r', 8 r' + 8) of the quality piece
+							const int bit0 = 8 * (r - S), i0 = bit0 / W, off = bit0 - W * i0;
+							uint32_t acc = 0;
+							for (int j = 0, i = i0; W * j < off + 8 && i < n; ++j, ++i) acc |= (uint32_t)s_lut[(qual_at(right, i) - 33u) & 255u] << (W * j);
+							ch = (acc >> off) & 0xffu;
+						}
 					} else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
 				}
 				word |= ch << (8 * k);

@@ -588,13 +588,13 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	T.n_clusters = nc;
 	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
 	if (c->table_mode == 2) {
-		// alphabet = the occurring values in increasing order; 1, 2 or 4 bits per quality when it has at most 2, 4 or 16 members
+		// alphabet = the occurring values in increasing order; 1, 2, 3 or 4 bits per quality when it has at most 2, 4, 8 or 16 members
 		const uint8_t *present = P<uint8_t>(c->h_qual_present);
 		int n_vals = 0;
 		uint8_t vals[256];
 		for (int v = 0; v < 256; ++v) if (present[v]) vals[n_vals++] = (uint8_t)v;
 		if (n_vals <= 16) {
-			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : 4;
+			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : n_vals <= 8 ? 3 : 4;
 			CHECK(ensure(c, c->qual_lut, 256)); CHECK(ensure_host(c, c->h_qual_lut, 256));
 			uint8_t *lut = P<uint8_t>(c->h_qual_lut);
 			memset(lut, 0, 256);
@@ -637,6 +637,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		if (!pa.packed) k_cluster_pack_ascii<<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
 		else if (pa.qual_bits == 8) k_cluster_pack_codes<8><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
 		else if (pa.qual_bits == 4) k_cluster_pack_codes<4><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
+		else if (pa.qual_bits == 3) k_cluster_pack_codes<3><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
 		else if (pa.qual_bits == 2) k_cluster_pack_codes<2><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
 		else k_cluster_pack_codes<1><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
 	}

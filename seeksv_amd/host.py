@@ -247,7 +247,8 @@ def cluster_strings(d, k):
         def quals(buf, n):
             if w == 8:
                 return buf[:n].tobytes().decode("latin-1")
-            return "".join(chr(alphabet[(int(buf[(i * w) >> 3]) >> ((i * w) & 7)) & ((1 << w) - 1)]) for i in range(n))
+            word = lambda b: int(buf[b]) | ((int(buf[b + 1]) << 8) if b + 1 < len(buf) else 0)  # a 3-bit index can straddle two bytes
+            return "".join(chr(alphabet[(word((i * w) >> 3) >> ((i * w) & 7)) & ((1 << w) - 1)]) for i in range(n))
         sl = unpack(s[o:o + a], ll)
         ql = quals(s[o + a:o + a + qa], ll)
         sr = unpack(s[o + a + qa:o + a + qa + c], lr)

@@ -392,8 +392,9 @@ static int cmd_getclip(int argc, char **argv)
 					const uint8_t *pl = s + a, *pr = s + a + qa + c2;
 					const unsigned mask = (1u << W) - 1u;
 					char *dl = &seqbuf[ll + lr], *dr = dl + ll;
-					for (size_t i = 0; i < ll; ++i) dl[i] = (char)t.qual_alphabet[(pl[(i * W) >> 3] >> ((i * W) & 7)) & mask];
-					for (size_t i = 0; i < lr; ++i) dr[i] = (char)t.qual_alphabet[(pr[(i * W) >> 3] >> ((i * W) & 7)) & mask];
+					// stream bit i * W; a 3-bit index can straddle two bytes (the byte after a piece is the next piece or the block's padding)
+					for (size_t i = 0; i < ll; ++i) { const size_t b = (i * W) >> 3; dl[i] = (char)t.qual_alphabet[((pl[b] | (unsigned)pl[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
+					for (size_t i = 0; i < lr; ++i) { const size_t b = (i * W) >> 3; dr[i] = (char)t.qual_alphabet[((pr[b] | (unsigned)pr[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
 					ql = dl; qr = dr;
 				}
 			} else { sl = (const char *)s; ql = sl + ll; sr = sl + 2 * ll; qr = sl + 2 * ll + lr; }

@@ -60,7 +60,7 @@ def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw, fmt):
     assert all(host.cluster_strings(d, k) == host.cluster_strings(ref, k) for k in range(d["n_clusters"]))
     if d["n_clusters"]:
         assert len(d["str"]) < len(ref["str"])
-        assert d["qual_bits"] in ((8,) if fmt == 1 else (1, 2, 4, 8))
+        assert d["qual_bits"] in ((8,) if fmt == 1 else (1, 2, 3, 4, 8))
         offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1, d["qual_bits"]) for a, b in zip(d["left_len"], d["right_len"])])])
         assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))
     clip, fq = host.format_clip_outputs(d, names)
@@ -182,7 +182,7 @@ def _remap_qualities(batch, alphabet):
     return b
 
 
-@pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (3, 2), (4, 2), (5, 4), (16, 4), (17, 8)])
+@pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (3, 2), (4, 2), (5, 3), (8, 3), (9, 4), (16, 4), (17, 8)])
 @pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300"])
 def test_packed_table_quality_alphabets(ctx, source, n_values, bits):
     """format 2 with every index width: the decoded packed table equals the ASCII table and the oracle's, on deep bins (consensus
