@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 #   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                        = 8.0 B/record
 #   clip_gather : packed bases+qualities 228 read + 228 written, CIGAR 8 + 8                                             = 472 B/event
 #   event_sort  : 5 radix passes x (12 B histogram read + 12 B read + 12 B written)                                       = 180 B/event
-#   cluster_pack: 228 read + (ll+lr) ~ 150 written (4-bit sequence codes + 4-bit quality indices) + ~70 B of per-cluster columns = 450 B/cluster-slot
-ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 450.0}
+#   cluster_pack: 228 read + 7/8 (ll+lr) ~ 131 written (4-bit sequence codes + 3-bit quality indices) + ~70 B of per-cluster columns = 430 B/cluster-slot
+ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 430.0}
 # minimum traffic of the whole path if every field of a record were read once by one fused pass (33 B fixed part +
 # 4.1 B CIGAR + 1 % x 225 B bases/qualities + ~0.7 B out).  The implemented path reads far less per record (the streaming passes touch
 # 2 + 8 B; everything else is evaluated lazily for ~1-3 % of the records), so this figure over the sum of ALL device kernels of a step
