@@ -564,8 +564,15 @@ static int64_t find_window(const ssv_interval *w, int64_t n, int32_t tid, int32_
 
 /* main_depth, bam2depth.cpp:17-142 with read_bam (bam2depth.h:29-35) and libbam 0.1.16's pileup:
  * a read contributes iff MAPQ >= mapQ and none of UNMAP|SECONDARY|QCFAIL|DUP (BAM_DEF_MASK, sam/bam.h:124),
- * tid >= 0; it adds 1 to every column under an M/=/X base (deletion and ref-skip columns appear in the
- * pileup but are subtracted again at bam2depth.cpp:92-96).  The ~8000 live reads cap is NOT modelled. */
+ * tid >= 0; it adds 1 to every column under an M base (deletion and ref-skip columns appear in the
+ * pileup but are subtracted again at bam2depth.cpp:92-96; '=' / 'X' are skipped by the pileup).
+ * The pileup's read cap (bam_plp_push of samtools 0.1.16: `iter->tid == b->core.tid && iter->pos == b->core.pos &&
+ * iter->mp->cnt > iter->maxcnt` with maxcnt = 8000 and two nodes of the pool always allocated): a read that starts where the
+ * previous accepted read of its contig started - i.e. not the first read at its start - is dropped when
+ * 2 + (accepted reads of the contig whose bam_calend end is >= the start) > 8000.  The first read at a new start is always taken.
+ * Pinned by tests/golden/getsv/deep*.  (Reads without any M/D/N operation are not counted as live here.) */
+#define ORC_PLP_MAXCNT 8000
+#define ORC_RING_BITS 22
 int orc_depth(const ssv_batch_t *batches, int n_batches, const ssv_interval *windows, int64_t n_windows,
               int32_t min_mapq, const ssv_interval *ranges, int64_t n_ranges, uint64_t *range_sum,
               const ssv_interval *points, int64_t n_points, int32_t *point_depth, int32_t *max_depth)
@@ -574,6 +581,11 @@ int orc_depth(const ssv_batch_t *batches, int n_batches, const ssv_interval *win
 	off[0] = 0;
 	for (int64_t k = 0; k < n_windows; ++k) off[k + 1] = off[k] + (windows[k].end - windows[k].beg + 1);
 	int32_t *depth = (int32_t *)calloc((size_t)off[n_windows] + 1, sizeof(int32_t));
+	/* pileup state: accepted reads of the current contig that are still allocated, by their (exclusive, 0-based) end */
+	const int64_t ring_mask = ((int64_t)1 << ORC_RING_BITS) - 1;
+	int32_t *ring = (int32_t *)calloc((size_t)ring_mask + 1, sizeof(int32_t));
+	int32_t plp_tid = -1;
+	int64_t plp_pos = -1, live = 0;
 	for (int bi = 0; bi < n_batches; ++bi) {
 		const ssv_batch_t *b = &batches[bi];
 		for (int64_t i = 0; i < b->n; ++i) {
@@ -583,6 +595,18 @@ int orc_depth(const ssv_batch_t *batches, int n_batches, const ssv_interval *win
 			if (b->tid[i] < 0) continue;
 			int n = b->n_cigar[i];
 			const uint32_t *cig = b->cigar + b->cigar_off[i];
+			{
+				int64_t p0 = b->pos[i], end = p0;
+				for (int k = 0; k < n; ++k) { int op = (int)(cig[k] & 15); if (op == C_M || op == C_D || op == C_N) end += (int64_t)(cig[k] >> 4); }
+				if (b->tid[i] != plp_tid) { memset(ring, 0, ((size_t)ring_mask + 1) * sizeof(int32_t)); live = 0; plp_tid = b->tid[i]; plp_pos = -1; }
+				if (p0 != plp_pos) {
+					/* columns before p0 have been emitted: nodes with end <= p0 - 1 are gone */
+					if (plp_pos >= 0 && p0 - plp_pos <= ring_mask) { for (int64_t e = plp_pos; e < p0; ++e) { live -= ring[e & ring_mask]; ring[e & ring_mask] = 0; } }
+					else if (plp_pos >= 0) { memset(ring, 0, ((size_t)ring_mask + 1) * sizeof(int32_t)); live = 0; }
+					plp_pos = p0;
+				} else if (2 + live > ORC_PLP_MAXCNT) continue; /* dropped by bam_plp_push */
+				if (end > p0) { ring[end & ring_mask]++; live++; }
+			}
 			int32_t col = b->pos[i] + 1; /* 1-based */
 			{
 				/* cheap skip of reads that touch no window (windows are disjoint and sorted, so also sorted by end) */
@@ -624,6 +648,6 @@ int orc_depth(const ssv_batch_t *batches, int n_batches, const ssv_interval *win
 		int64_t w = find_window(windows, n_windows, points[q].tid, points[q].beg);
 		point_depth[q] = w >= 0 ? depth[off[w] + (points[q].beg - windows[w].beg)] : 0;
 	}
-	free(off); free(depth);
+	free(off); free(depth); free(ring);
 	return 0;
 }

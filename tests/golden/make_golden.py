@@ -341,12 +341,57 @@ def eqx_case():
     return names, lens, recs, junctions
 
 
+def deep_case():
+    """stacks of more than 8000 reads: pins the read cap of libbam 0.1.16's pileup (bam_plp_push) - single stacks, stacks that fill up over
+    several start positions, a 500-bp stretch whose uncapped depth would be ~9500x with mixed CIGARs and filtered reads in between, a second deep contig"""
+    rng = random.Random(99)
+    names, lens = ["chrA", "chrB", "chrC"], [30000, 8000, 6000]
+    recs = []
+
+    def mk(tid, pos, cigar="100M", flag=99, mapq=60, mtid=None, mpos=None, isize=None):
+        lq = sum(l for l, op in bamio.parse_cigar(cigar) if op in (0, 1, 4, 7, 8))
+        recs.append(dict(qname=f"q{len(recs)}", flag=flag, tid=tid, pos=pos, mapq=mapq, cigar=cigar, mtid=tid if mtid is None else mtid,
+                         mpos=pos + 200 if mpos is None else mpos, isize=(280 + pos % 41) if isize is None else isize, seq="A" * lq, qual=b"\x1e" * lq))
+    for p in range(200, 29000, 5): mk(0, p)                                   # background, depth 20
+    for _ in range(9000): mk(0, 2000)                                         # one stack
+    for _ in range(8000): mk(0, 5000)                                         # full stack, then ten more 10 bp further
+    for _ in range(10): mk(0, 5010)
+    for _ in range(5000): mk(0, 8000)                                         # two half stacks
+    for _ in range(5000): mk(0, 8020)
+    for _ in range(7990): mk(0, 11000)                                        # nearly full, then 5, then 20
+    for _ in range(5): mk(0, 11007)
+    for _ in range(20): mk(0, 11015)
+    cig_pool = ["100M"] * 6 + ["50M", "30M10D60M", "20S80M", "40M20N40M", "60M3I37M", "10M1D10M1D70M", "100M", "75M25S"]
+    for p in range(15000, 15500):                                             # ~9500x for 500 bp, mixed CIGARs, filtered reads in between
+        for _ in range(110):
+            r = rng.random()
+            flag = 99 | (1024 if r < 0.04 else 0) | (256 if 0.04 <= r < 0.06 else 0) | (512 if 0.06 <= r < 0.07 else 0)
+            mk(0, p, rng.choice(cig_pool), flag=flag, mapq=rng.choice((60, 60, 60, 60, 30, 20, 19, 0)))
+    for p in range(3000, 3300):                                               # a second deep contig right after: the state starts afresh
+        for _ in range(95): mk(1, p, rng.choice(("100M", "100M", "80M", "50M10D50M")))
+    for p in range(100, 5000, 7): mk(2, p)
+    junctions = [("chrA", 2050, "+", "chrA", 5050, "+"), ("chrA", 5012, "+", "chrA", 8030, "+"), ("chrA", 8025, "-", "chrA", 11010, "+"),
+                 ("chrA", 11020, "+", "chrA", 15100, "+"), ("chrA", 15250, "+", "chrA", 15480, "+"), ("chrA", 15050, "-", "chrB", 3100, "+"),
+                 ("chrB", 3250, "+", "chrC", 1000, "+"), ("chrA", 15400, "+", "chrB", 3010, "-"), ("chrA", 20000, "+", "chrA", 25000, "+")]
+    for k, (uc, up, us, dc, dp, ds) in enumerate(junctions):
+        ta, tb = names.index(uc), names.index(dc)
+        for r in range(4):
+            if us == "+" and ds == "+": pos, mpos, flag = up - 130 - 9 * r, dp + 15 + r, 97
+            elif us == "-": pos, mpos, flag = up + 10 + 7 * r, dp + 140 + r, 113
+            else: pos, mpos, flag = up - 140 - 5 * r, dp - 100 - 120 - r, 65
+            mk(ta, pos, "100M", flag=flag, mtid=tb, mpos=mpos, isize=0 if ta != tb else mpos - pos)
+    order = sorted(range(len(recs)), key=lambda i: (recs[i]["tid"], recs[i]["pos"]))   # stable: equal starts keep their creation order
+    recs = [recs[i] for i in order]
+    junctions.sort(key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
+    return names, lens, recs, junctions
+
+
 def crafted_getsv():
     out = os.path.join(HERE, "getsv")
     os.makedirs(out, exist_ok=True)
     # header-only clip.bam and empty clip file for the harness
-    for name, seed, kw in (("pairs1", 5, {}), ("pairs2", 6, dict(n_pairs=12000, L=150)), ("pairs3", 7, dict(n_pairs=3000, with_small_contig=False)), ("eqx", None, {})):
-        names, lens, recs, junctions = getsv_case(seed, **kw) if seed is not None else eqx_case()
+    for name, seed, kw in (("pairs1", 5, {}), ("pairs2", 6, dict(n_pairs=12000, L=150)), ("pairs3", 7, dict(n_pairs=3000, with_small_contig=False)), ("eqx", None, {}), ("deep", None, {})):
+        names, lens, recs, junctions = getsv_case(seed, **kw) if seed is not None else (eqx_case() if name == "eqx" else deep_case())
         bam = os.path.join(out, f"{name}.bam")
         bamio.write_bam(bam, names, lens, recs)
         run([os.path.join(BIN, "bamidx"), bam])

@@ -30,6 +30,7 @@ GETSV_CASES = [
     ("pairs2", "pairs2", dict()),
     ("pairs3", "pairs3", dict()),
     ("eqx", "eqx", dict()),   # '=' / 'X' CIGAR operations in the depth pass (skipped by libbam 0.1.16's pileup)
+    ("deep", "deep", dict()), # stacks of more than 8000 reads: the read cap of libbam 0.1.16's pileup (bam_plp_push)
 ]
 
 
