@@ -123,6 +123,10 @@ struct GetsvArgs {
 	int64_t n_win;
 	int32_t depth_min_mapq;
 	int32_t *diff;
+	// pileup read cap (see the CapArgs block below): the streaming pass raises cap_flag[0] when a wavefront's records of one tile
+	// all start within cap_span bp - a necessary condition for 8000 reads being alive anywhere in the tile's neighbourhood
+	int *cap_flag;               // null: no depth pass
+	int32_t cap_span;
 };
 
 // IsConcordant, cluster.cpp:136-147 (lower bound NOT clamped here)
@@ -196,11 +200,13 @@ __device__ __forceinline__ void discordant_record(const GetsvArgs &a, int64_t i,
 	}
 }
 
-__device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int tid, int pos, int64_t tile)
+__device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int tid, int pos, int64_t tile, int sign = 1)
 {
 	const DevBatch &b = a.b;
-	if ((int)b.mapq[i] < a.depth_min_mapq) return;                    // read_bam: MAPQ < mapQ -> treated as unmapped
-	if (b.flag[i] & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) return; // BAM_DEF_MASK
+	if (sign > 0) { // (the correction pass of the read cap has applied the filter already)
+		if ((int)b.mapq[i] < a.depth_min_mapq) return;                    // read_bam: MAPQ < mapQ -> treated as unmapped
+		if (b.flag[i] & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) return; // BAM_DEF_MASK
+	}
 	int n = b.n_cigar[i];
 	const uint32_t *cig = b.cigar + b.cigar_off[i];
 	int col = pos + 1; // 1-based
@@ -217,8 +223,8 @@ __device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int 
 					int wb = a.win_beg[x], we = a.win_end[x];
 					int lo = s > wb ? s : wb, hi = e < we ? e : we;
 					int32_t *d = a.diff + a.win_off[x];
-					atomicAdd(&d[lo - wb], 1);
-					atomicAdd(&d[hi + 1 - wb], -1);
+					atomicAdd(&d[lo - wb], sign);
+					atomicAdd(&d[hi + 1 - wb], -sign);
 				}
 			}
 			col += len;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 		// memory access at all.
 		const int tid0 = __builtin_amdgcn_readfirstlane(t4[0].x);
 		bool same = true;
-		int tmin = 0x7fffffff, tmax = -1;
+		int pmin = 0x7fffffff, pmax = -1;
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) {
 			const int tid[CS_ITEMS] = {t4[sub].x, t4[sub].y, t4[sub].z, t4[sub].w};
@@ -355,14 +361,19 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 #pragma unroll
 			for (int k = 0; k < CS_ITEMS; ++k) {
 				same = same && tid[k] == tid0 && pos[k] >= 0;
-				const int tl = pos[k] >> TILE_SHIFT;
-				tmin = tl < tmin ? tl : tmin;
-				tmax = tl > tmax ? tl : tmax;
+				pmin = pos[k] < pmin ? pos[k] : pmin;
+				pmax = pos[k] > pmax ? pos[k] : pmax;
 			}
 		}
 		const bool uniform = __all(same) && tid0 >= 0 && tid0 <= last_tid;
 		int wmin = 0, wmax = 0;
-		if (uniform) { wmin = -wave_max(-tmin); wmax = wave_max(tmax); }
+		if (uniform) {
+			const int wpmin = -wave_max(-pmin), wpmax = wave_max(pmax);
+			wmin = wpmin >> TILE_SHIFT; wmax = wpmax >> TILE_SHIFT;
+			// 3,328 consecutive records (this wavefront's share of the tile spans that many) starting within one read span: the read cap of
+			// the reference's pileup may bind near here (k_cap_*); never at WGS depths
+			if (a.cap_flag && wpmax - wpmin <= a.cap_span && lane_id() == 0) *a.cap_flag = 1;
+		}
 		if (uniform && wmax - wmin < WAVE) {
 			const int64_t lo = a.ctg_tile_off[tid0], hi = a.ctg_tile_off[tid0 + 1]; // wave-uniform addresses
 			const int64_t mine = lo + wmin + lane_id();
@@ -488,6 +499,160 @@ __global__ void k_point_depth(const int32_t *__restrict__ win_tid, const int32_t
 		if (win_tid[w] == tid && c <= win_end[w]) v = depth[win_off[w] + (c - win_beg[w])];
 	}
 	out[r] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The read cap of the reference's pileup (libbam 0.1.16, bam_plp_push: `iter->tid == b->core.tid && iter->pos == b->core.pos &&
+// iter->mp->cnt > iter->maxcnt`, maxcnt = 8000, two pool nodes always allocated).  In file order, among the reads that pass the depth
+// filter: a read that is not the first at its start position is dropped when 2 + L > 8000, L = accepted reads of the contig whose
+// bam_calend end (M, D, N) is >= the start.  Pinned by the real reference on tests/golden/getsv/deep.*.  The rule is sequential, but it
+// can only bind where >= 7,998 earlier records start within one read span of a record ("deep" records: impossible below ~5,000x), so:
+//   * the streaming pass raises a flag when a wavefront's records of a tile start within one span (necessary for an interior deep record);
+//   * k_cap_mark then marks the 4096-record tiles that contain deep records (the first and last two tiles of a batch are always looked at:
+//     their look-back windows reach into the previous batch, whose last 8192 records are kept as (tid, pos, end, pass) in a tail buffer);
+//   * k_cap_sweep, ONE wavefront, replays the pileup's bookkeeping over the marked tiles and two tiles either side of them (a sweep that
+//     starts >= 7,999 records before the first deep record starts from the right state: everything before is accepted and no longer alive
+//     there), and takes the contributions of the dropped reads out of the difference arrays again.  A sweep that is still running at the end
+//     of a batch is carried into the next one (state + ring of ends in ctx memory).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int CAP_MAXCNT = 8000, CAP_LOOKBACK = 7998, CAP_TAIL = 8192, CAP_LDS_RING = 8192;
+
+struct CapCarry { int32_t active, tid, pos, live, since_deep, pad[3]; };
+
+struct CapArgs {
+	GetsvArgs g;
+	int32_t span;                 // >= the longest reference span of any record so far
+	const int32_t *tail_tid, *tail_pos, *tail_end; // the last tail_n records of the stream before this batch
+	const uint8_t *tail_pass;
+	int32_t tail_n;
+	uint8_t *deep;                // [ntiles] per CS_TILE records
+	int64_t ntiles;
+	int *flags;                   // [0] raised by the streaming pass, [1] raised by k_cap_mark
+	CapCarry *carry;
+	int32_t *ring;                // accepted reads by (end & ring_mask): carried state, and the working ring when it does not fit in LDS
+	int32_t ring_mask;
+	// next tail (k_cap_tail)
+	int32_t *ntail_tid, *ntail_pos, *ntail_end;
+	uint8_t *ntail_pass;
+	int32_t ntail_n;
+};
+
+__device__ __forceinline__ bool cap_pass(const GetsvArgs &a, int64_t i) // the depth pass's read filter (read_bam + BAM_DEF_MASK)
+{
+	return (int)a.b.mapq[i] >= a.depth_min_mapq && !(a.b.flag[i] & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && a.b.tid[i] >= 0;
+}
+
+__device__ __forceinline__ int cap_calend(const GetsvArgs &a, int64_t i) // bam_calend: M, D, N advance
+{
+	int end = a.b.pos[i];
+	const int n = a.b.n_cigar[i];
+	const uint32_t *cig = a.b.cigar + a.b.cigar_off[i];
+	for (int k = 0; k < n; ++k) { const uint32_t c = cig[k]; const int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) end += (int)(c >> 4); }
+	return end;
+}
+
+// per CS_TILE records: does the tile hold a deep record?  (grid-stride over the tiles: in the usual case every tile but four leaves at once)
+__global__ __launch_bounds__(BLOCK) void k_cap_mark(CapArgs c)
+{
+	const DevBatch &b = c.g.b;
+	const bool all = c.flags[0] || c.carry->active;
+	for (int64_t t = blockIdx.x; t < c.ntiles; t += gridDim.x) {
+		const bool boundary = t < 2 || t + 2 >= c.ntiles;
+		if (!(boundary || all)) { if (threadIdx.x == 0) c.deep[t] = 0; continue; }
+		bool deep = false;
+		for (int k = 0; k < CS_TILE / BLOCK; ++k) {
+			const int64_t i = t * CS_TILE + (int64_t)k * BLOCK + threadIdx.x;
+			if (i >= b.n) break;
+			const int tid = b.tid[i];
+			if (tid < 0) continue;
+			const int64_t j = i - CAP_LOOKBACK;
+			int ptid = -1, ppos = 0;
+			if (j >= 0) { ptid = b.tid[j]; ppos = b.pos[j]; }
+			else if ((int64_t)c.tail_n + j >= 0) { ptid = c.tail_tid[c.tail_n + j]; ppos = c.tail_pos[c.tail_n + j]; }
+			deep = deep || (ptid == tid && b.pos[i] - ppos <= c.span);
+		}
+		const int any = __syncthreads_or(deep ? 1 : 0);
+		if (threadIdx.x == 0) { c.deep[t] = any ? 1 : 0; if (any) c.flags[1] = 1; }
+	}
+}
+
+// the pileup's bookkeeping, replayed by one wavefront (every lane keeps the same scalar state)
+__global__ __launch_bounds__(WAVE) void k_cap_sweep(CapArgs c)
+{
+	__shared__ int32_t s_ring[CAP_LDS_RING];
+	if (!(c.flags[0] | c.flags[1] | c.carry->active)) return;
+	const GetsvArgs &a = c.g;
+	const int lane = lane_id();
+	const bool use_lds = c.ring_mask < CAP_LDS_RING;
+	int32_t *ring = use_lds ? s_ring : c.ring;
+	const int mask = c.ring_mask;
+	bool active = c.carry->active != 0;
+	int s_tid = c.carry->tid, s_pos = c.carry->pos, live = c.carry->live, since_deep = c.carry->since_deep;
+	if (active && use_lds) for (int x = lane; x <= mask; x += WAVE) s_ring[x] = c.ring[x];
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	auto clear_ring = [&]() {
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		for (int x = lane; x <= mask; x += WAVE) ring[x] = 0;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	};
+	auto is_deep = [&](int64_t t) -> bool { return t >= 0 && t < c.ntiles && c.deep[t] != 0; };
+	for (int64_t t = active ? 0 : -2; t < c.ntiles; ++t) {
+		const bool need = is_deep(t) || is_deep(t + 1) || is_deep(t + 2) || (active && since_deep < 2);
+		if (!need) { active = false; continue; }
+		if (!active) { clear_ring(); live = 0; s_tid = -1; s_pos = -1; since_deep = 2; active = true; } // a sweep starts: nothing before this tile is alive at the first deep record
+		for (int base = 0; base < CS_TILE; base += WAVE) {
+			const int64_t i = t * CS_TILE + base + lane; // record index in the batch; negative: the previous records of the stream
+			bool pass = false;
+			int tid = -1, pos = 0, end = 0;
+			if (i >= 0) {
+				if (i < a.b.n && cap_pass(a, i)) { pass = true; tid = a.b.tid[i]; pos = a.b.pos[i]; end = cap_calend(a, i); }
+			} else if ((int64_t)c.tail_n + i >= 0) {
+				const int64_t j = (int64_t)c.tail_n + i;
+				pass = c.tail_pass[j] != 0; tid = c.tail_tid[j]; pos = c.tail_pos[j]; end = c.tail_end[j];
+			}
+			const uint64_t any = __ballot(pass);
+			if (!any) continue;
+			uint64_t dropped = 0;
+			for (int l = 0; l < WAVE; ++l) {
+				if (!((any >> l) & 1ull)) continue;
+				const int r_tid = __shfl(tid, l, WAVE), r_pos = __shfl(pos, l, WAVE), r_end = __shfl(end, l, WAVE);
+				if (r_tid != s_tid) { clear_ring(); live = 0; s_tid = r_tid; s_pos = -1; }
+				bool accept = true;
+				if (r_pos != s_pos) {
+					// the columns before r_pos have been emitted: reads that ended there are gone
+					if (s_pos >= 0 && r_pos - s_pos <= mask) { for (int e = s_pos; e < r_pos; ++e) { live -= ring[e & mask]; ring[e & mask] = 0; } }
+					else if (s_pos >= 0) { clear_ring(); live = 0; }
+					s_pos = r_pos;
+				} else accept = !(2 + live > CAP_MAXCNT); // bam_plp_push
+				if (accept) { if (r_end > r_pos) { ring[r_end & mask] += 1; ++live; } }
+				else dropped |= 1ull << l;
+			}
+			// a dropped read never reached the pileup: take its coverage out of the difference arrays again
+			if (i >= 0 && ((dropped >> lane) & 1ull)) {
+				int64_t tile;
+				const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
+				if (m & TM_DEPTH) depth_record(a, i, tid, pos, tile, -1);
+			}
+		}
+		since_deep = is_deep(t) ? 0 : since_deep + 1;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	if (active && use_lds) for (int x = lane; x <= mask; x += WAVE) c.ring[x] = s_ring[x];
+	if (lane == 0) { c.carry->active = active ? 1 : 0; c.carry->tid = s_tid; c.carry->pos = s_pos; c.carry->live = live; c.carry->since_deep = since_deep; }
+}
+
+// the last (up to) CAP_TAIL records of the stream including this batch, for the next batch's look-backs and sweep starts
+__global__ void k_cap_tail(CapArgs c)
+{
+	const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (j >= c.ntail_n) return;
+	const int64_t s = (int64_t)c.tail_n + c.g.b.n - c.ntail_n + j; // index in (old tail ++ batch)
+	if (s < c.tail_n) { c.ntail_tid[j] = c.tail_tid[s]; c.ntail_pos[j] = c.tail_pos[s]; c.ntail_end[j] = c.tail_end[s]; c.ntail_pass[j] = c.tail_pass[s]; }
+	else {
+		const int64_t i = s - c.tail_n;
+		const bool p = cap_pass(c.g, i);
+		c.ntail_tid[j] = c.g.b.tid[i]; c.ntail_pos[j] = c.g.b.pos[i]; c.ntail_end[j] = p ? cap_calend(c.g, i) : c.g.b.pos[i]; c.ntail_pass[j] = p ? 1 : 0;
+	}
 }
 
 } // namespace ssv

@@ -111,6 +111,9 @@ struct ssv_ctx {
 	int64_t gs_diff_len = 0;
 	DBuf gs_djunc, gs_counts, gs_wtid, gs_wbeg, gs_wend, gs_woff, gs_diff, gs_tilemap, gs_tile_win, gs_tile_junc, gs_ctgoff, gs_maxdepth, gs_span;
 	DBuf q_tid, q_beg, q_end, q_out64, q_out32;
+	// read cap of the reference's pileup (k_cap_*): flags, per-tile marks, carried sweep state + ring, the stream's last records (ping-pong)
+	DBuf cap_flags, cap_deep, cap_carry, cap_ring, cap_tail[2][4];
+	int32_t cap_tail_n = 0, cap_tail_cur = 0, cap_ring_mask = 0;
 	HBuf h_q;
 
 	// ---- device BGZF/BAM decoder (bamdec_api.inc) ----
@@ -354,7 +357,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc,
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry, &c->cap_ring, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
@@ -854,6 +857,9 @@ int ssv_getsv_begin(ssv_ctx *c, const ssv_getsv_params *p)
 	HIPCHECK(c, hipMemsetAsync(c->gs_counts.p, 0, nj * 4 + 16, c->st));
 	HIPCHECK(c, hipMemsetAsync(c->gs_diff.p, 0, (size_t)c->gs_diff_len * 4 + 16, c->st));
 	HIPCHECK(c, hipMemsetAsync(c->gs_maxdepth.p, 0, 16, c->st));
+	CHECK(ensure(c, c->cap_carry, sizeof(CapCarry))); CHECK(ensure(c, c->cap_flags, 16));
+	HIPCHECK(c, hipMemsetAsync(c->cap_carry.p, 0, sizeof(CapCarry), c->st));
+	c->cap_tail_n = 0; c->cap_tail_cur = 0; c->cap_ring_mask = 0;
 	HIPCHECK(c, hipStreamSynchronize(c->st)); // the host vectors above go out of scope
 	c->gs_active = true;
 	return SSV_OK;
@@ -886,6 +892,8 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	a.counts = P<int32_t>(c->gs_counts);
 	a.win_tid = P<int32_t>(c->gs_wtid); a.win_beg = P<int32_t>(c->gs_wbeg); a.win_end = P<int32_t>(c->gs_wend); a.win_off = P<int64_t>(c->gs_woff);
 	a.n_win = (int64_t)c->gs_win.size(); a.depth_min_mapq = c->gs_p.depth_min_mapq; a.diff = P<int32_t>(c->gs_diff);
+	a.cap_flag = nullptr; a.cap_span = c->gs_map_span;
+	if (a.n_win > 0) { HIPCHECK(c, hipMemsetAsync(c->cap_flags.p, 0, 16, c->st)); a.cap_flag = P<int>(c->cap_flags); }
 	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
 	const unsigned grid = scan_blocks(ntiles, "SSV_GETSV_SCAN_BLOCKS", 256 * 4);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
@@ -926,6 +934,28 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 		k_getsv_cand<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(a, g);
 	}
 	HIPCHECK(c, hipGetLastError());
+	if (a.n_win > 0) {
+		// the read cap of the reference's pileup: three small launches that leave at once unless >= 8000 reads can be alive somewhere
+		ProfScope ps(c, P_GETSV_CAND, 0);
+		if (c->cap_ring_mask == 0) { int64_t e = CAP_LDS_RING; while (e < (int64_t)c->gs_map_span + 2) e <<= 1; c->cap_ring_mask = (int32_t)(e - 1); }
+		if ((int64_t)c->gs_map_span + 2 > (int64_t)c->cap_ring_mask + 1) { c->err = "the reference span of the reads grew beyond the pileup ring sized by the pass's first batch"; return SSV_E_RANGE; }
+		CHECK(ensure(c, c->cap_ring, ((size_t)c->cap_ring_mask + 1) * 4)); // sized once per pass (the mask is fixed by its first batch)
+		CHECK(ensure(c, c->cap_deep, (size_t)ntiles + 16));
+		for (int s_ = 0; s_ < 2; ++s_) { CHECK(ensure(c, c->cap_tail[s_][0], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][1], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][2], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][3], CAP_TAIL)); }
+		CapArgs ca;
+		ca.g = a; ca.span = c->gs_map_span;
+		DBuf *ot = c->cap_tail[c->cap_tail_cur], *nt = c->cap_tail[c->cap_tail_cur ^ 1];
+		ca.tail_tid = P<int32_t>(ot[0]); ca.tail_pos = P<int32_t>(ot[1]); ca.tail_end = P<int32_t>(ot[2]); ca.tail_pass = P<uint8_t>(ot[3]); ca.tail_n = c->cap_tail_n;
+		ca.deep = P<uint8_t>(c->cap_deep); ca.ntiles = ntiles; ca.flags = P<int>(c->cap_flags); ca.carry = P<CapCarry>(c->cap_carry);
+		ca.ring = P<int32_t>(c->cap_ring); ca.ring_mask = c->cap_ring_mask;
+		ca.ntail_tid = P<int32_t>(nt[0]); ca.ntail_pos = P<int32_t>(nt[1]); ca.ntail_end = P<int32_t>(nt[2]); ca.ntail_pass = P<uint8_t>(nt[3]);
+		ca.ntail_n = (int32_t)std::min<int64_t>(CAP_TAIL, (int64_t)c->cap_tail_n + d.n);
+		k_cap_mark<<<(unsigned)std::min<int64_t>(ntiles, 1024), BLOCK, 0, c->st>>>(ca);
+		k_cap_sweep<<<1, WAVE, 0, c->st>>>(ca);
+		k_cap_tail<<<grid_for(ca.ntail_n, BLOCK), BLOCK, 0, c->st>>>(ca);
+		HIPCHECK(c, hipGetLastError());
+		c->cap_tail_n = ca.ntail_n; c->cap_tail_cur ^= 1;
+	}
 	return SSV_OK;
 }
 

@@ -615,7 +615,6 @@ static int cmd_getsv(int argc, char **argv)
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, do_discordant ? counts.data() : nullptr, dr, output_depth ? nr : 0, rsum.data(), dp, output_depth ? np : 0, pdepth.data(), &maxd) != SSV_OK)
 			die(string("[seeksv] ") + ssv_last_error(ctx));
-		if (maxd >= 7999) cerr << "[seeksv] warning: depth " << maxd << " reaches the pileup cap of samtools 0.1.16 (~8000 reads); the reference's depths saturate there" << endl;
 	}
 	pt.lap("fused_pass");
 	if (do_discordant) { cerr << "'StoreSeqName2Tid' finished" << endl; cerr << "'FindDiscordantReadPairs' finished" << endl; }

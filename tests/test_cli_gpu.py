@@ -46,7 +46,7 @@ def test_cli_getclip(tmp_path, sub, bam, prefix, flags):
 
 
 GETSV = [("pairs1", "pairs1", []), ("pairs1", "pairs1.q0", ["-q", "0"]), ("pairs1", "pairs1.L50", ["-L", "50"]), ("pairs1", "pairs1.L1", ["-L", "1"]),
-         ("pairs2", "pairs2", []), ("pairs3", "pairs3", []), ("eqx", "eqx", [])]
+         ("pairs2", "pairs2", []), ("pairs3", "pairs3", []), ("eqx", "eqx", []), ("deep", "deep", [])]
 
 
 @pytest.mark.parametrize("case,prefix,flags", GETSV, ids=[c[1] for c in GETSV])

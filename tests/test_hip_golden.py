@@ -258,3 +258,15 @@ def test_config3_streaming_chunking_independent():
     out = C3.main(genome_frac=1 / 128, depth=300, n_sv=80, chunks_a=3, chunks_b=7)
     assert out["results_identical"] and out["junctions_with_discordant_pairs"] == out["junctions"] == 80
     assert out["records"] > 40_000_000 and out["table"]["max_support"] > 50
+
+
+@pytest.mark.parametrize("batch_records", [1000, 4096, 7777, 8192, 20000, 50000])
+def test_pileup_read_cap_across_batch_boundaries(ctx, batch_records):
+    """stacks of more than 8000 reads (tests/golden/getsv/deep.*: the read cap of libbam 0.1.16's pileup) streamed in batches of awkward
+    sizes: the sweep's carried state and the look-back into the previous batch's last records give the reference's depths every time"""
+    base = os.path.join(G.GOLDEN, "getsv")
+    rows = G.read_junction_file(os.path.join(base, "deep.junctions.txt"))
+    stats, junctions, folded = G.run_getsv_case(os.path.join(base, "deep.bam"), rows, ctx, batch_records=batch_records)
+    golden = G.parse_sv_outputs(os.path.join(base, "deep.sv"), os.path.join(base, "deep.stdout"))
+    assert G.check_getsv_against_golden(junctions, folded, golden) == 7 * len(junctions)
+    assert int(folded["up_depth"].max()) == 7999
