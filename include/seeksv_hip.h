@@ -227,8 +227,9 @@ int ssv_getsv_scan(ssv_ctx *ctx, const ssv_batch_t *b);
  * range_sum[n_ranges]      = sum over the interval of per-column depth (bam2depth.cpp:101-122);
  *                            each range must lie inside one window
  * point_depth[n_points]    = depth at (tid, beg) (bam2depth.cpp:123-124); 0 outside every window
- * max_depth                = largest per-column depth seen (the 0.1.16 pileup stops accepting reads
- *                            at ~8000 live reads; above 7998 parity with the reference is not pinned)
+ * max_depth                = largest per-column depth inside the windows.  The depths follow libbam 0.1.16's pileup, which keeps at
+ *                            most ~8000 reads alive: a read that is not the first at its start position is dropped when 2 + (accepted
+ *                            reads of the contig ending at or after that start) > 8000 (bam_plp_push); batches must arrive in file order
  */
 int ssv_getsv_finish(ssv_ctx *ctx, int32_t *counts,
                      const ssv_interval *ranges, int64_t n_ranges, uint64_t *range_sum,
