@@ -270,3 +270,29 @@ def test_pileup_read_cap_across_batch_boundaries(ctx, batch_records):
     golden = G.parse_sv_outputs(os.path.join(base, "deep.sv"), os.path.join(base, "deep.stdout"))
     assert G.check_getsv_against_golden(junctions, folded, golden) == 7 * len(junctions)
     assert int(folded["up_depth"].max()) == 7999
+
+
+def test_pileup_read_cap_synthetic_12000x(ctx):
+    """a synthetic sample at 12000x (the regime of a viral contig or chrM in a deep sample): every record is a "deep" record, the one-wavefront
+    sweep runs over the whole batch and over batch boundaries; depths, flank sums and discordant tallies equal the oracle's (whose cap is
+    pinned by the real reference on tests/golden/getsv/deep.*), and the cap really binds"""
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 65536, depth=12000, n_sv=6, n_contigs=3, min_contig=12000)
+    hdr = host.Header(w.names, w.lens)
+    hb = w.generate_host(0, w.n_total)
+    stats = O.isize_stats([hb], 20, 100000)
+    plan = host.Plan(hdr, w.junctions, stats[2], stats[3])
+    oc = O.discordant([hb], plan.junctions, stats[2], stats[3], 4, 20)
+    ors, opd, omax = O.depth([hb], plan.windows, plan.ranges, plan.points, 20)
+    assert 7800 < int(opd.max()) < 8100             # capped: ~10,400 reads per column pass the filter
+    db, keep = w.generate_device(0, w.n_total, 0)
+    c, r, p = ctx.discordant_and_depth([db], plan, stats[2], stats[3], 20, hdr.target_lens)
+    assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd)
+    # the same in host batches cut at awkward places
+    from test_oracle_golden import split_batch
+    cuts = [0, 5000, 5000 + 12345, w.n_total // 2 + 7, w.n_total]
+    hbs = [split_batch(hb, cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+    c2, r2, p2 = ctx.discordant_and_depth(hbs, plan, stats[2], stats[3], 20, hdr.target_lens)
+    assert np.array_equal(c2, oc) and np.array_equal(r2, ors) and np.array_equal(p2, opd)
+    plan.close()
+    hdr.close()
