@@ -613,20 +613,54 @@ __global__ __launch_bounds__(WAVE) void k_cap_sweep(CapArgs c)
 			const uint64_t any = __ballot(pass);
 			if (!any) continue;
 			uint64_t dropped = 0;
-			for (int l = 0; l < WAVE; ++l) {
-				if (!((any >> l) & 1ull)) continue;
-				const int r_tid = __shfl(tid, l, WAVE), r_pos = __shfl(pos, l, WAVE), r_end = __shfl(end, l, WAVE);
+			// reads with the same start are decided together: in a stack there are a few starts per 64 records, not 64 decisions
+			uint64_t todo = any;
+			while (todo) {
+				const int l = __ffsll((long long)todo) - 1;
+				const int r_tid = __shfl(tid, l, WAVE), r_pos = __shfl(pos, l, WAVE);
+				const uint64_t grp = __ballot(pass && tid == r_tid && pos == r_pos) & todo; // sorted input: the group is what is left of this start
+				todo &= ~grp;
 				if (r_tid != s_tid) { clear_ring(); live = 0; s_tid = r_tid; s_pos = -1; }
-				bool accept = true;
+				int exempt = 0; // the first read at a new start is always taken
 				if (r_pos != s_pos) {
 					// the columns before r_pos have been emitted: reads that ended there are gone
 					if (s_pos >= 0 && r_pos - s_pos <= mask) { for (int e = s_pos; e < r_pos; ++e) { live -= ring[e & mask]; ring[e & mask] = 0; } }
 					else if (s_pos >= 0) { clear_ring(); live = 0; }
 					s_pos = r_pos;
-				} else accept = !(2 + live > CAP_MAXCNT); // bam_plp_push
-				if (accept) { if (r_end > r_pos) { ring[r_end & mask] += 1; ++live; } }
-				else dropped |= 1ull << l;
+					exempt = 1;
+				}
+				// in file order: a read is taken while 2 + live <= CAP_MAXCNT (bam_plp_push); every taken read with a reference span adds one
+				// to live.  Reads without any M / D / N operation (end == pos) do not: if the group holds one, decide it read by read.
+				const bool in_grp = (grp >> lane) & 1ull;
+				const bool spanless = __any(in_grp && end <= pos);
+				if (!spanless) {
+					const int n_g = (int)__popcll(grp);
+					const int room_after_first = CAP_MAXCNT - 2 - (live + exempt) + 1; // reads that can still be taken once the exempt one is in
+					int take = exempt + (room_after_first > 0 ? (n_g - exempt < room_after_first ? n_g - exempt : room_after_first) : 0);
+					if (take > n_g) take = n_g;
+					const int rank = (int)__popcll(grp & lanemask_lt());
+					if (in_grp) {
+						if (rank < take) atomicAdd(&ring[end & mask], 1);
+						else dropped |= 1ull << lane;
+					}
+					live += take;
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				} else {
+					uint64_t g = grp;
+					bool first = exempt != 0;
+					while (g) {
+						const int q = __ffsll((long long)g) - 1;
+						g &= g - 1;
+						const int q_end = __shfl(end, q, WAVE);
+						const bool accept = first || !(2 + live > CAP_MAXCNT);
+						first = false;
+						if (accept) { if (q_end > r_pos) { if (lane == q) ring[q_end & mask] += 1; ++live; } }
+						else if (lane == q) dropped |= 1ull << lane;
+						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					}
+				}
 			}
+			dropped = __ballot((dropped >> lane) & 1ull); // every lane decided for itself above
 			// a dropped read never reached the pileup: take its coverage out of the difference arrays again
 			if (i >= 0 && ((dropped >> lane) & 1ull)) {
 				int64_t tile;
