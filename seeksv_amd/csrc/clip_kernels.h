@@ -660,7 +660,7 @@ __device__ __forceinline__ uint32_t nt16_code(uint32_t ch)
 	return code;
 }
 
-constexpr int PACK_MAX_LQ = 256; // reads up to this length take the LDS-staged path of k_cluster_pack_strings
+constexpr int PACK_MAX_LQ = 256; // reads up to this length take the LDS-staged paths of the pack kernels
 
 // 16 lanes per cluster, four clusters per wavefront: strings and the CIGAR of the carrying event into dense blobs.  Every lane
 // assembles whole output dwords (a cluster's block starts 4-byte aligned and is zero padded to a multiple of 4 bytes):
