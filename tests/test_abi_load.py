@@ -47,3 +47,17 @@ def test_no_cpu_fallback_without_gpu():
     from seeksv_amd.device import Context, SeeksvError
     with pytest.raises(SeeksvError):
         Context(0)
+
+
+def test_headers_compile_as_c_and_link(tmp_path):
+    """a plain C99 program over include/*.h, linked against the two libraries (tests/native/abi_c_smoke.c)"""
+    import subprocess
+    exe = str(tmp_path / "abi_c_smoke")
+    libdir = _abi.LIBDIR
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "abi_c_smoke.c"),
+           "-o", exe, "-L" + libdir, "-lseeksv_host", "-lseeksv_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host: " in r.stdout and ("no device" in r.stdout or "gpu context ok" in r.stdout)
