@@ -1,0 +1,159 @@
+"""-m gpu: randomized differential test, HIP path against the oracle (which the real reference pins on tests/golden).  Small batches with far
+more variety per record than a sequencer produces: every CIGAR operation, clips of every length on either or both ends, odd read lengths,
+missing qualities, XC flags, all flag bits, every MAPQ, stacks of identical starts (deep bins, near-identical and diverging sequences),
+contig changes, unmapped-pair records in between - through getclip (three match rates, -s, -q), the insert-size pass, and the fused getsv
+pass with random junction windows; each sample also cut into batches at random places."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from seeksv_amd import host
+from test_hip_golden import assert_tables_equal
+from test_oracle_golden import split_batch
+
+pytestmark = pytest.mark.gpu
+OPS = "MIDNSHP=X"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from seeksv_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def random_sample(seed, n=1500):
+    rng = np.random.RandomState(seed)
+    lens = [int(x) for x in rng.randint(3000, 9000, 3)]
+    recs = []
+    tid, pos = 0, int(rng.randint(0, 50))
+    templates = ["".join("ACGT"[x] for x in rng.randint(0, 4, 400)) for _ in range(4)]
+    while len(recs) < n and tid < len(lens):
+        pos += int(rng.choice([0, 0, 0, 1, 2, 5, 20, 60]))
+        if pos > lens[tid] - 200:
+            tid += 1; pos = int(rng.randint(0, 30)); continue
+        lq = int(rng.choice([30, 51, 75, 100, 101, 150]))
+        kind = rng.randint(0, 10)
+        ops = []
+        if kind <= 3:
+            ops = [(lq, "M")]
+        else:
+            left = int(rng.randint(1, lq // 2)) if rng.rand() < 0.6 else 0
+            right = int(rng.randint(1, lq // 2 - 1)) if rng.rand() < 0.5 else 0
+            lop = "S" if rng.rand() < 0.85 else "H"
+            rop = "S" if rng.rand() < 0.85 else "H"
+            mid = lq - (left if lop == "S" else 0) - (right if rop == "S" else 0)
+            body = []
+            remaining = mid
+            while remaining > 0:
+                op = str(rng.choice(list("MMMMM=XI")))
+                l = int(min(remaining, rng.randint(1, 40)))
+                body.append((l, op)); remaining -= l
+                if rng.rand() < 0.25 and remaining > 0:
+                    body.append((int(rng.randint(1, 30)), str(rng.choice(list("DNP")))))
+            if left: ops.append((left, lop))
+            ops += body
+            if right: ops.append((right, rop))
+        # bases: stacks at one start share a template so that clusters absorb reads; some diverge
+        t = templates[int(rng.randint(0, 4))]
+        o = int(rng.randint(0, 40)) if rng.rand() < 0.3 else 7
+        seq = list(t[o:o + lq])
+        for _ in range(int(rng.choice([0, 0, 0, 1, 3, 12]))):
+            seq[int(rng.randint(0, lq))] = "ACGTN"[int(rng.randint(0, 5))]
+        qual = rng.choice([2, 11, 25, 37, 40], lq).astype(np.uint8) if rng.rand() < 0.93 else np.full(lq, 255, np.uint8)
+        flag = int(rng.choice([99, 147, 83, 163, 97, 145, 65, 129, 113, 177, 73, 89, 133, 69]))
+        for bit, pr in ((256, 0.03), (512, 0.03), (1024, 0.06), (2048, 0.03)):
+            if rng.rand() < pr: flag |= bit
+        mtid = tid if rng.rand() < 0.9 else int(rng.randint(0, len(lens)))
+        mpos = max(0, pos + int(rng.randint(-600, 600)))
+        isz = int(rng.choice([0, mpos - pos, 300 + int(rng.randint(-60, 60)), -(300 + int(rng.randint(-60, 60)))]))
+        recs.append(dict(tid=tid, pos=pos, flag=flag, mapq=int(rng.choice([0, 1, 5, 19, 20, 30, 60, 60, 60])), ops=ops, lq=lq, seq="".join(seq), qual=qual,
+                         mtid=mtid, mpos=mpos, isize=isz, xc=int(rng.rand() < 0.08)))
+        # a stack on the same start: same CIGAR shape, nearly the same bases -> bins with several reads, absorbed or not depending on -t
+        if len(ops) > 1:
+            for _ in range(int(rng.choice([0, 0, 1, 2, 5, 9]))):
+                r2 = dict(recs[-1])
+                s2 = list(t[o:o + lq])
+                for _k in range(int(rng.choice([0, 0, 1, 2, 8, 30]))):
+                    s2[int(rng.randint(0, lq))] = "ACGT"[int(rng.randint(0, 4))]
+                r2["seq"] = "".join(s2)
+                r2["qual"] = rng.choice([2, 11, 25, 37, 40], lq).astype(np.uint8)
+                r2["mapq"] = int(rng.choice([0, 20, 60, 60]))
+                r2["flag"] = int(rng.choice([99, 147, 83, 163])) | (1024 if rng.rand() < 0.05 else 0)
+                if rng.rand() < 0.4 and ops[0][1] == "S" and ops[0][0] > 3 and ops[1][1] == "M":   # a shorter / longer clip on the same breakpoint side keeps pos + 1
+                    d = int(rng.randint(1, 3))
+                    r2["ops"] = [(ops[0][0] - d, "S"), (ops[1][0] + d, "M")] + list(ops[2:])
+                    r2["pos"] = pos - d
+                recs.append(r2)
+    order = sorted(range(len(recs)), key=lambda i: (recs[i]["tid"], recs[i]["pos"]))
+    recs = [recs[i] for i in order if recs[i]["pos"] >= 0]
+    b = dict(tid=np.array([r["tid"] for r in recs], np.int32), pos=np.array([r["pos"] for r in recs], np.int32),
+             flag=np.array([r["flag"] for r in recs], np.uint16), mapq=np.array([r["mapq"] for r in recs], np.uint8),
+             n_cigar=np.array([len(r["ops"]) for r in recs], np.uint16), l_qseq=np.array([r["lq"] for r in recs], np.int32),
+             mtid=np.array([r["mtid"] for r in recs], np.int32), mpos=np.array([r["mpos"] for r in recs], np.int32),
+             isize=np.array([r["isize"] for r in recs], np.int32), xc=np.array([r["xc"] for r in recs], np.uint8))
+    cig, coff, soff, blob = [], [], [], []
+    nbytes = 0
+    span = 1
+    code = {"=": 0, "A": 1, "C": 2, "G": 4, "T": 8, "N": 15}
+    for r in recs:
+        coff.append(len(cig))
+        cig += [(l << 4) | OPS.index(op) for l, op in r["ops"]]
+        span = max(span, sum(l for l, op in r["ops"] if op in "MDN=X"))
+        if r["ops"][0][1] == "S" or r["ops"][-1][1] == "S" or seed % 3 == 0:
+            soff.append(nbytes)
+            lq = r["lq"]
+            packed = np.zeros((lq + 1) // 2, np.uint8)
+            for i, ch in enumerate(r["seq"]):
+                packed[i >> 1] |= code[ch] << (0 if i & 1 else 4)
+            blob += [packed, r["qual"]]
+            nbytes += len(packed) + lq
+        else:
+            soff.append(0xFFFFFFFFFFFFFFFF)
+    b.update(cigar=np.array(cig, np.uint32), cigar_off=np.array(coff, np.uint32), seq_off=np.array(soff, np.uint64),
+             seqqual=np.concatenate(blob + [np.zeros(16, np.uint8)]) if blob else np.zeros(16, np.uint8), max_ref_span=int(span))
+    names = [f"c{i}" for i in range(len(lens))]
+    return names, lens, b, rng
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_sample_hip_equals_oracle(ctx, seed):
+    names, lens, b, rng = random_sample(seed)
+    n = len(b["tid"])
+    cuts = sorted(set([0, n] + [int(x) for x in rng.randint(1, n, 3)]))
+    parts = [split_batch(b, cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+    for kw in (dict(), dict(match_rate=0.8, min_mapq=0), dict(match_rate=1.0, save_low_quality=True, min_mapq=20)):
+        want = O.getclip([b], **kw)
+        assert_tables_equal(ctx.getclip([b], **kw), want)
+        assert_tables_equal(ctx.getclip(parts, **kw), want)
+    assert want["n_events"] > 50
+    # the packed table formats decode to the same strings (want: the last parameter set)
+    ctx.clip_table_format(1 + seed % 2)
+    try:
+        d = ctx.getclip(parts, **kw)
+    finally:
+        ctx.clip_table_format(0)
+    assert d["n_clusters"] == want["n_clusters"]
+    for k in range(0, d["n_clusters"], 3):
+        assert host.cluster_strings(d, k) == host.cluster_strings(want, k), k
+    for q, cap in ((20, 5000000), (0, 37)):
+        assert ctx.isize_stats(parts, q, cap) == O.isize_stats([b], q, cap)
+    stats = O.isize_stats([b], 20, 5000000)
+    mean, sd = (stats[2], stats[3]) if stats[1] else (300, 40)
+    juncs = []
+    for _ in range(40):
+        ta, tb = int(rng.randint(0, len(lens))), int(rng.randint(0, len(lens)))
+        juncs.append((names[ta], int(rng.randint(1, lens[ta])), "+-"[int(rng.randint(0, 2))], names[tb], int(rng.randint(1, lens[tb])), "+-"[int(rng.randint(0, 2))]))
+    juncs = [j for j in juncs if not (j[2] == "-" and j[5] == "-")]
+    juncs.sort(key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
+    hdr = host.Header(names, lens)
+    plan = host.Plan(hdr, juncs, mean, sd, flank_length=int(rng.choice([1, 50, 200])))
+    for q in (20, 0):
+        oc = O.discordant([b], plan.junctions, mean, sd, 4, q)
+        ors, opd, _ = O.depth([b], plan.windows, plan.ranges, plan.points, q)
+        for bs in ([b], parts):
+            c, r, p = ctx.discordant_and_depth(bs, plan, mean, sd, q, hdr.target_lens)
+            assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd)
+    plan.close()
+    hdr.close()
