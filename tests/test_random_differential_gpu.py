@@ -23,7 +23,8 @@ def ctx():
     c.close()
 
 
-def random_sample(seed, n=1500):
+def random_sample(seed, n=1500, safe=False, want_records=False):
+    """safe: only inputs for which the REFERENCE's behaviour is defined (it reads out of bounds on missing qualities inside a multi-read bin)"""
     rng = np.random.RandomState(seed)
     lens = [int(x) for x in rng.randint(3000, 9000, 3)]
     recs = []
@@ -52,6 +53,10 @@ def random_sample(seed, n=1500):
                 body.append((l, op)); remaining -= l
                 if rng.rand() < 0.25 and remaining > 0:
                     body.append((int(rng.randint(1, 30)), str(rng.choice(list("DNP")))))
+            if safe:  # the pileup of libbam 0.1.16 asserts on CIGARs it does not expect: keep to M / I / D / N, aligned parts that start and end with M
+                body = [(l, {"=": "M", "X": "M", "P": "D"}.get(op, op)) for l, op in body]
+                body[0] = (body[0][0], "M")
+                body[-1] = (body[-1][0], "M")
             if left: ops.append((left, lop))
             ops += body
             if right: ops.append((right, rop))
@@ -61,7 +66,7 @@ def random_sample(seed, n=1500):
         seq = list(t[o:o + lq])
         for _ in range(int(rng.choice([0, 0, 0, 1, 3, 12]))):
             seq[int(rng.randint(0, lq))] = "ACGTN"[int(rng.randint(0, 5))]
-        qual = rng.choice([2, 11, 25, 37, 40], lq).astype(np.uint8) if rng.rand() < 0.93 else np.full(lq, 255, np.uint8)
+        qual = rng.choice([2, 11, 25, 37, 40], lq).astype(np.uint8) if (safe or rng.rand() < 0.93) else np.full(lq, 255, np.uint8)
         flag = int(rng.choice([99, 147, 83, 163, 97, 145, 65, 129, 113, 177, 73, 89, 133, 69]))
         for bit, pr in ((256, 0.03), (512, 0.03), (1024, 0.06), (2048, 0.03)):
             if rng.rand() < pr: flag |= bit
@@ -114,12 +119,15 @@ def random_sample(seed, n=1500):
     b.update(cigar=np.array(cig, np.uint32), cigar_off=np.array(coff, np.uint32), seq_off=np.array(soff, np.uint64),
              seqqual=np.concatenate(blob + [np.zeros(16, np.uint8)]) if blob else np.zeros(16, np.uint8), max_ref_span=int(span))
     names = [f"c{i}" for i in range(len(lens))]
+    if want_records:
+        return names, lens, b, rng, recs
     return names, lens, b, rng
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", list(range(64)) + list(range(100, 112)))
 def test_random_sample_hip_equals_oracle(ctx, seed):
-    names, lens, b, rng = random_sample(seed)
+    # seeds 100-111 are the samples tests/test_random_oracle_vs_reference.py runs through the REAL reference (restricted to inputs it defines)
+    names, lens, b, rng = random_sample(seed, safe=seed >= 100)
     n = len(b["tid"])
     cuts = sorted(set([0, n] + [int(x) for x in rng.randint(1, n, 3)]))
     parts = [split_batch(b, cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
