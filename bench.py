@@ -283,6 +283,9 @@ def main():
             ref = cpu_reference(w, min(args.ref_sample, w.n_total))
             if ref:
                 line["cpu_reference"] = ref
+            allc = cpu_baseline_all_cores(args, w)
+            if allc:
+                line["cpu_baseline_all_cores"] = allc
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
@@ -315,6 +318,33 @@ def cpu_baseline(w, hdr, n_sample, min_seconds=10.0):
             "sample": f"{passes} passes over the first {n_sample} records of the same synthetic workload = {dt:.1f} s of CPU work (getclip {t_clip:.1f} s); "
                       "oracle = plain-C restatement of seeksv v1.2.3 on decoded SoA records (no BGZF inflate / BAM parse), pinned to the real reference on tests/golden",
             "clusters": int(d["n_clusters"]), "events": int(d["n_events"])}
+
+
+def cpu_baseline_all_cores(args, w, seconds=6.0, n_per_worker=2_000_000):
+    """The same oracle on every host core at once: one single-threaded worker process per core (tools/cpu_baseline_worker.py, started as
+    plain child processes that never touch the GPU), each on its own slice of the workload, range-partitioned like the multi-GPU run.
+    Aggregate records/s - what the host of this GPU box could do with the reference's algorithm if it were parallelised by contig range."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    n = min(n_per_worker, max(1, w.n_total // cores))
+    worker = os.path.join(ROOT, "tools", "cpu_baseline_worker.py")
+    try:
+        procs = [subprocess.Popen([sys.executable, worker, repr(args.genome_frac), repr(w.depth), str(args.n_sv), str(k * (w.n_total // cores)), str(n), str(seconds)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+                 for k in range(cores)]
+        rate, ok = 0.0, 0
+        for p in procs:
+            out, _ = p.communicate(timeout=120)
+            if p.returncode == 0 and out.strip():
+                nn, passes, dt = out.split()
+                rate += int(nn) * int(passes) / float(dt)
+                ok += 1
+        if not ok:
+            return None
+        return {"value": rate, "unit": "records/s", "cores": ok, "kind": "port",
+                "sample": f"{ok} single-threaded oracle processes at once, each {seconds:g} s of whole passes over its own {n}-record slice of the same workload"}
+    except Exception as e:  # a courtesy, like cpu_reference
+        return {"value": None, "unit": "records/s", "cores": cores, "kind": "port", "sample": f"failed: {e}"}
 
 
 def cpu_reference(w, n_sample):
