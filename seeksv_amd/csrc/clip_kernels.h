@@ -90,7 +90,7 @@ __device__ __forceinline__ int ref_advance(uint32_t c)
 // Decide the 0/1/2 events of record i.  Only called for records whose first or last op is 'S' (about 1 % of a WGS BAM), so everything
 // it touches beyond the CIGAR ends is a lazy, sparse load: one 64-byte sector per column.  The kernel is bound by the number of sectors it
 // touches, not by their latency (issuing all loads before the first test made it slower), so the chain leaves as early as GetSClipReads.
-__device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i, int nc, uint32_t c0, uint32_t cl, const uint32_t *cig, uint32_t cig_off, StagedEvent ev[2])
+__device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i, int nc, uint32_t c0, uint32_t cl, const uint32_t *cig, uint32_t cig_off, uint64_t soff, StagedEvent ev[2])
 {
 	const DevBatch &b = a.b;
 	const int op1 = (int)(c0 & 15u), op2 = (int)(cl & 15u);
@@ -104,8 +104,6 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 	}
 	if (tid != prev_tid || tid < 0) return 0;
 	if (op1 == C_H || op2 == C_H || (flag & F_DUP) || (int)b.mapq[i] < a.min_mapq) return 0; // clip_reads.cpp:118
-	const uint64_t soff = b.seq_off[i];
-	if (soff == ~0ull) return 0;                        // batcher contract: bases must be shipped for 'S'-ended records
 	const int xc = b.xc ? b.xc[i] : 0;
 	const int lq = b.l_qseq[i];
 	const int pos0 = b.pos[i];
@@ -274,10 +272,15 @@ __global__ __launch_bounds__(BLOCK) void k_clip_filter(ClipFilterArgs a, const u
 	int n = 0;
 	if (c < n_cand) {
 		const int64_t i = cand[c];
-		const int nc = a.b.n_cigar[i];
-		const uint32_t off = a.b.cigar_off[i];
-		const uint32_t c0 = a.b.cigar[off], cl = a.b.cigar[off + nc - 1];
-		if ((c0 & 15u) == C_S || (cl & 15u) == C_S) n = clip_events_of(a, i, nc, c0, cl, a.b.cigar + off, off, ev);
+		// two thirds of the candidates are reads with an indel: no soft clip, so the batcher shipped no bases for them (the contract of
+		// seq_off) and they cannot become events - one load settles them instead of three
+		const uint64_t soff = a.b.seq_off[i];
+		if (soff != ~0ull) {
+			const int nc = a.b.n_cigar[i];
+			const uint32_t off = a.b.cigar_off[i];
+			const uint32_t c0 = a.b.cigar[off], cl = a.b.cigar[off + nc - 1];
+			if ((c0 & 15u) == C_S || (cl & 15u) == C_S) n = clip_events_of(a, i, nc, c0, cl, a.b.cigar + off, off, soff, ev);
+		}
 		cnt[c] = (uint32_t)n;
 	}
 	// the wavefront's events side by side (two slots per candidate are reserved, the wave fills its 128 from the front): a third of
