@@ -45,7 +45,7 @@ PATH_BYTES_PER_RECORD = 40.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome-frac", type=float, default=1.0, help="scale the contigs (and the record count) down, e.g. 0.015625 for a quick run")
     ap.add_argument("--depth", type=float, default=30.0, help="per-GPU coverage")

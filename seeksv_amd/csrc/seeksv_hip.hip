@@ -81,7 +81,7 @@ struct ssv_ctx {
 	struct TableSet {
 		DBuf o_tid, o_pos, o_side, o_support, o_ll, o_lr, o_qmiss, o_ncig, o_stroff, o_cigoff, o_str, o_cig;
 		HBuf h_tid, h_pos, h_side, h_support, h_ll, h_lr, h_qmiss, h_stroff, h_cigoff, h_ncig, h_str, h_cig;
-		hipEvent_t copied = nullptr;
+		hipEvent_t copied = nullptr, started = nullptr; // `started` only with SSV_DEBUG_COPY (times the copy on its stream)
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
 		int packed = 0, qual_bits = 8;
@@ -332,7 +332,8 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 	c->device = device;
 	if ((e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return SSV_E_NODEVICE; }
 	if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->tab[0].copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->tab[1].copied, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&c->tab[0].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->tab[1].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess) {
 		g_create_error = "cannot create the copy stream / events"; ssv_ctx_destroy(c); return SSV_E_NODEVICE;
 	}
 	*out = c;
@@ -653,6 +654,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	// the table goes to pinned host memory on the copy stream, behind the pack kernels; ssv_clip_table_wait() waits for it
 	HIPCHECK(c, hipEventRecord(c->ev_packed, c->st));
 	HIPCHECK(c, hipStreamWaitEvent(c->st_copy, c->ev_packed, 0));
+	if (getenv("SSV_DEBUG_COPY")) { if (!T.started) HIPCHECK(c, hipEventCreate(&T.started)); HIPCHECK(c, hipEventRecord(T.started, c->st_copy)); }
 	for (auto &x : cp) {
 		CHECK(ensure_host(c, *x.h, x.bytes + 16));
 		if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st_copy));
@@ -702,6 +704,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 		ProfScope pd(c, P_TABLE_D2H, T.n_clusters); // what is left of the copy when the caller asks for the table
 		HIPCHECK(c, hipEventSynchronize(T.copied));
 		T.in_flight = false;
+		if (T.started) { float ms = 0; if (hipEventElapsedTime(&ms, T.started, T.copied) == hipSuccess) fprintf(stderr, "[ssv debug] table copy on its stream: %.2f ms\n", ms); }
 	}
 	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
 	if (T.n_clusters == 0) return SSV_OK;
