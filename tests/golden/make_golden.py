@@ -142,7 +142,7 @@ def getclip_filters_case():
     return names, lens, recs
 
 
-def getclip_stress_case(seed, n_bp=40, depth=30, L=100):
+def getclip_stress_case(seed, n_bp=40, depth=30, L=100, alleles=(1, 1, 2)):
     """Deep bins: reads of varying clip length piled on shared breakpoints, with base errors and low
     qualities so that consensus updates, prepend/append growth, cigar replacement and second clusters all occur."""
     rng = random.Random(seed)
@@ -155,7 +155,7 @@ def getclip_stress_case(seed, n_bp=40, depth=30, L=100):
     for b in range(n_bp):
         tid = rng.randrange(2)
         bp = rng.randrange(1000, lens[tid] - 1000)  # 0-based first aligned base (left clip) / last aligned+1 (right clip)
-        n_alleles = rng.choice((1, 1, 2))
+        n_alleles = rng.choice(alleles)
         partner = [rnd_seq(rng, L) for _ in range(n_alleles)]
         left = rng.random() < 0.5
         err = rng.choice((0.0, 0.01, 0.05, 0.12))
@@ -189,7 +189,9 @@ def getclip_stress_case(seed, n_bp=40, depth=30, L=100):
 def crafted_getclip():
     out = os.path.join(HERE, "getclip")
     os.makedirs(out, exist_ok=True)
-    cases = {"filters": getclip_filters_case(), "stress1": getclip_stress_case(1), "stress2": getclip_stress_case(2, n_bp=60, depth=80, L=150)}
+    cases = {"filters": getclip_filters_case(), "stress1": getclip_stress_case(1), "stress2": getclip_stress_case(2, n_bp=60, depth=80, L=150),
+             # a few breakpoints with thousands of reads from ~100 different partner sequences: bins with far more than 64 clusters
+             "stress3": getclip_stress_case(3, n_bp=4, depth=2500, L=100, alleles=(90, 120))}
     for name, (names, lens, recs) in cases.items():
         bam = os.path.join(out, f"{name}.bam")
         bamio.write_bam(bam, names, lens, recs)
@@ -198,6 +200,8 @@ def crafted_getclip():
             variants += [(".s", ["-s"]), (".q0", ["-q", "0"]), (".q30", ["-q", "30"])]
         if name == "stress1":
             variants += [(".t08", ["-t", "0.8"]), (".t1", ["-t", "1"])]
+        if name == "stress3":
+            variants += [(".t08", ["-t", "0.8"])]
         for tag, flags in variants:
             pre = f"{name}{tag}"
             run([SEEKSV, "getclip"] + flags + ["-o", pre, bam], cwd=TMP)

@@ -30,7 +30,7 @@ SEEKSV = os.environ.get("SSV_CLI") or os.path.join(ROOT, "seeksv_amd", "bin", "s
 
 GETCLIP = [("example", "cancer.sort.bam", "cancer", []), ("example", "normal.sort.bam", "normal", []), ("getclip", "filters.bam", "filters", []),
            ("getclip", "filters.bam", "filters.s", ["-s"]), ("getclip", "filters.bam", "filters.q30", ["-q", "30"]), ("getclip", "stress1.bam", "stress1.t08", ["-t", "0.8"]),
-           ("getclip", "stress2.bam", "stress2", [])]
+           ("getclip", "stress2.bam", "stress2", []), ("getclip", "stress3.bam", "stress3", []), ("getclip", "stress3.bam", "stress3.t08", ["-t", "0.8"])]
 
 
 @pytest.mark.parametrize("sub,bam,prefix,flags", GETCLIP, ids=[c[2] for c in GETCLIP])

@@ -20,6 +20,8 @@ GETCLIP_CASES = [
     ("getclip", "stress1.bam", "stress1.t08", dict(match_rate=0.8)),
     ("getclip", "stress1.bam", "stress1.t1", dict(match_rate=1.0)),
     ("getclip", "stress2.bam", "stress2", {}),
+    ("getclip", "stress3.bam", "stress3", {}),                          # thousands of reads per breakpoint, > 64 clusters per bin
+    ("getclip", "stress3.bam", "stress3.t08", dict(match_rate=0.8)),
 ]
 
 GETSV_CASES = [
