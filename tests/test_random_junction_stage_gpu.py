@@ -1,0 +1,135 @@
+"""-m gpu (and only where the REAL reference binary travelled along: oracle/_ref/seeksv_ref): the host junction stage (clip.gz x clip.bam join,
+GetAlignInfo, GetJunction, MergeJunction, OutputBreakpoint: SURVEY 8f #1) on randomized inputs, `seeksv getsv` of this repository against
+the reference's, byte for byte.  The inputs are made directly (no aligner): clip rows of planted junctions in all orientations whose clipped
+sequences re-align to the partner breakpoint (forward / reverse, with microhomology shifts, soft- and hard-clipped ends, MAPQ 0, secondary
+records, both-sided and one-sided support), duplicated and near-duplicate junctions that MergeJunction folds, and noise rows that re-align
+nowhere or anywhere; the BAM passes run on a committed background BAM."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bamio
+import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "seeksv_ref")
+SEEKSV = os.environ.get("SSV_CLI") or os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(REF), reason="the real reference binary is not here")]
+COMP = str.maketrans("ACGT", "TGCA")
+
+
+def rnd(rng, n):
+    return "".join("ACGT"[x] for x in rng.randint(0, 4, n))
+
+
+def revcomp(s):
+    return s.translate(COMP)[::-1]
+
+
+def make_inputs(seed, d):
+    rng = np.random.RandomState(seed)
+    bg = os.path.join(G.GOLDEN, "getsv", "pairs1.bam")
+    names, recs0 = bamio.read_bam_records(bg)
+    lens = {"chrA": 40000, "chrB": 15000, "HBV": 3215}
+    rows, aln = [], {}  # rows: (chr, pos, side, cigar, aligned_seq, clipped_seq, support); aln[clipped_seq] = list of records
+
+    def qual(n):
+        return "".join(chr(33 + int(x)) for x in rng.choice([2, 11, 25, 37, 40], n))
+
+    def add_row(ch, pos, side, aligned, clipped, support, cigar=None):
+        rows.append((ch, int(pos), side, cigar or f"{len(aligned)}M", aligned, clipped, int(support)))
+
+    def add_aln(clipped, ch, pos1, reverse=False, mapq=60, lead=0, trail=0, hard=False, secondary=False, unmapped=False):
+        L = len(clipped)
+        if unmapped:
+            aln.setdefault(clipped, []).append(dict(flag=4, tid=-1, pos=-1, mapq=0, cigar=[], seq=clipped))
+            return
+        m = L - lead - trail
+        op = 5 if hard else 4
+        cig = ([(lead, op)] if lead else []) + [(m, 0)] + ([(trail, op)] if trail else [])
+        seq = revcomp(clipped) if reverse else clipped
+        if hard:
+            seq = seq[lead:L - trail]
+        aln.setdefault(clipped, []).append(dict(flag=(16 if reverse else 0) | (256 if secondary else 0), tid=names.index(ch), pos=int(pos1) - 1, mapq=mapq, cigar=cig, seq=seq))
+
+    for k in range(70):
+        ca, cb = rng.choice(names, 2)
+        same = rng.rand() < 0.6
+        if same: cb = ca
+        A = int(rng.randint(300, lens[ca] - 300)); B = int(rng.randint(300, lens[cb] - 300))
+        if same and abs(A - B) < 120: B = A + 150 + int(rng.randint(0, 3000)) if A + 3300 < lens[ca] else A - 200
+        left, right = rnd(rng, 140), rnd(rng, 140)   # sequence up to A (ends at A) and from B on
+        kind = k % 5
+        ka, kb = int(rng.randint(25, 70)), int(rng.randint(25, 70))
+        sa, sb = int(rng.randint(1, 12)), int(rng.randint(1, 12))
+        mq = int(rng.choice([60, 60, 60, 30, 0]))
+        if kind in (0, 1, 2):   # (A,+) -> (B,+): right-clipped reads at A, left-clipped reads at B
+            if kind != 2:
+                clipped = right[:ka]
+                add_row(ca, A, "3", left[-(100 - ka):], clipped, sa)
+                add_aln(clipped, cb, B + int(rng.choice([0, 0, 0, 1, -2, 5])), mapq=mq, trail=int(rng.choice([0, 0, 4])))
+            if kind != 1:
+                clipped = left[-kb:]
+                add_row(cb, B, "5", right[:100 - kb], clipped, sb)
+                add_aln(clipped, ca, A - kb + 1 + int(rng.choice([0, 0, 0, -1, 3])), mapq=int(rng.choice([60, 60, 0])), lead=int(rng.choice([0, 0, 5])))
+        elif kind == 3:         # inversion-like: the clipped part re-aligns on the reverse strand
+            clipped = revcomp(right[:ka])
+            add_row(ca, A, "3", left[-(100 - ka):], clipped, sa)
+            add_aln(clipped, cb, B, reverse=True, mapq=mq)
+            clipped2 = revcomp(left[-kb:])
+            add_row(cb, B + ka, "3", rnd(rng, 100 - kb), clipped2, sb)
+            add_aln(clipped2, ca, A - kb + 1, reverse=True, mapq=60, hard=bool(rng.rand() < 0.2), lead=int(rng.choice([0, 3])))
+        else:                   # left-clipped at A, partner reverse
+            clipped = revcomp(rnd(rng, ka))
+            add_row(ca, A, "5", right[:100 - ka], clipped, sa)
+            add_aln(clipped, cb, B, reverse=bool(rng.rand() < 0.7), mapq=mq, secondary=bool(rng.rand() < 0.15))
+        if rng.rand() < 0.3:    # a near-duplicate a few bases away: MergeJunction candidates
+            sh = int(rng.choice([1, 2, 3, 7, 20]))
+            clipped = right[sh:sh + ka]
+            add_row(ca, A + sh, "3", (left + right[:sh])[-(100 - ka):], clipped, int(rng.randint(1, 5)))
+            add_aln(clipped, cb, B + sh, mapq=60)
+    for _ in range(60):         # noise
+        ch = str(rng.choice(names)); p = int(rng.randint(200, lens[ch] - 200)); L = int(rng.randint(20, 75))
+        clipped = rnd(rng, L)
+        add_row(ch, p, "53"[int(rng.randint(0, 2))], rnd(rng, 100 - L), clipped, int(rng.randint(1, 4)), cigar=str(rng.choice([f"{100 - L}M", f"{60 - L // 2}M2D{40 - (L - L // 2)}M"])))
+        r = rng.rand()
+        if r < 0.6: add_aln(clipped, None, 0, unmapped=True)
+        else:
+            c2 = str(rng.choice(names))
+            add_aln(clipped, c2, int(rng.randint(100, lens[c2] - 200)), reverse=bool(rng.rand() < 0.5), mapq=int(rng.choice([0, 0, 13, 60])), lead=int(rng.choice([0, 0, 6])), trail=int(rng.choice([0, 0, 6])))
+            if rng.rand() < 0.3: add_aln(clipped, str(rng.choice(names)), int(rng.randint(100, 3000)), secondary=True, mapq=0)
+    # getclip's output order: per contig, side 5 by position, then side 3 by position; rows of one clipped sequence need not be adjacent
+    order = sorted(range(len(rows)), key=lambda i: (names.index(rows[i][0]), rows[i][2] == "3", rows[i][1]))
+    rows = [rows[i] for i in order]
+    clip_gz, clip_bam = os.path.join(d, "in.clip.gz"), os.path.join(d, "in.clip.bam")
+    with gzip.open(clip_gz, "wt") as f:
+        for ch, pos, side, cigar, aligned, clipped, support in rows:
+            f.write("\t".join([ch, str(pos), side, cigar, aligned, qual(len(aligned)), clipped, qual(len(clipped)), str(support)]) + "\n")
+    out, done = [], set()
+    for ch, pos, side, cigar, aligned, clipped, support in rows:  # like bwa mem: records follow the FASTQ, all records of a read together
+        if clipped in done:
+            continue
+        done.add(clipped)
+        for a in aln[clipped]:
+            out.append(dict(qname=clipped, flag=a["flag"], tid=a["tid"], pos=a["pos"], mapq=a["mapq"], cigar=a["cigar"], mtid=-1, mpos=-1, isize=0, seq=a["seq"], qual=None))
+    bamio.write_bam(clip_bam, names, [lens[n] for n in names], out)
+    return bg, clip_bam, clip_gz
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_getsv_full_equals_reference_on_random_junction_inputs(tmp_path, seed):
+    d = str(tmp_path)
+    bg, clip_bam, clip_gz = make_inputs(seed, d)
+    for tag, flags in (("default", []), ("loose", ["-f", "0", "-b", "0", "-d", "0"]), ("l90", ["-l", "90", "-e", "1"])):
+        ref = subprocess.run([REF, "getsv"] + flags + [clip_bam, bg, clip_gz, os.path.join(d, f"ref.{tag}.sv"), os.path.join(d, "r.fq")], capture_output=True, text=True)
+        assert ref.returncode == 0, ref.stderr[-400:]
+        ours = subprocess.run([SEEKSV, "getsv"] + flags + [clip_bam, bg, clip_gz, os.path.join(d, f"ours.{tag}.sv"), os.path.join(d, "o.fq")], capture_output=True, text=True)
+        assert ours.returncode == 0, ours.stderr[-400:]
+        want, got = open(os.path.join(d, f"ref.{tag}.sv")).read(), open(os.path.join(d, f"ours.{tag}.sv")).read()
+        assert got == want, (seed, tag)
+        assert ours.stdout == ref.stdout, (seed, tag)
+        if tag == "loose":
+            assert want.count("\n") > 30 and ref.stdout.count("\n") >= 0, want.count("\n")
