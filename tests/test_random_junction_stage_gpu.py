@@ -133,3 +133,12 @@ def test_getsv_full_equals_reference_on_random_junction_inputs(tmp_path, seed):
         assert ours.stdout == ref.stdout, (seed, tag)
         if tag == "loose":
             assert want.count("\n") > 30 and ref.stdout.count("\n") >= 0, want.count("\n")
+    # seeksv somatic with the loose table as the tumor's and the same clip clusters / BAM as the control: every look-up kind
+    # finds something, and a shifted copy of the clusters makes the range probes walk
+    table = os.path.join(d, "ref.loose.sv")
+    for tag, flags in (("s", []), ("s_l60", ["-l", "60", "-m", "30"]), ("s_t", ["-t", "0.5", "-q", "0"])):
+        ref = subprocess.run([REF, "somatic"] + flags + [bg, clip_gz, table, os.path.join(d, f"ref.{tag}.sv")], capture_output=True, text=True)
+        assert ref.returncode == 0, ref.stderr[-400:]
+        ours = subprocess.run([SEEKSV, "somatic"] + flags + [bg, clip_gz, table, os.path.join(d, f"ours.{tag}.sv")], capture_output=True, text=True)
+        assert ours.returncode == 0, ours.stderr[-400:]
+        assert open(os.path.join(d, f"ours.{tag}.sv")).read() == open(os.path.join(d, f"ref.{tag}.sv")).read(), (seed, tag)
