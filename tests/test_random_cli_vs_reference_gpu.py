@@ -142,3 +142,22 @@ def test_getsv_full_equals_reference_on_random_junction_inputs(tmp_path, seed):
         ours = subprocess.run([SEEKSV, "somatic"] + flags + [bg, clip_gz, table, os.path.join(d, f"ours.{tag}.sv")], capture_output=True, text=True)
         assert ours.returncode == 0, ours.stderr[-400:]
         assert open(os.path.join(d, f"ours.{tag}.sv")).read() == open(os.path.join(d, f"ref.{tag}.sv")).read(), (seed, tag)
+
+
+@pytest.mark.parametrize("seed", range(200, 206))
+@pytest.mark.parametrize("mode", [[], ["-Z"]], ids=["host-inflate", "device-inflate"])
+def test_cli_getclip_equals_reference_on_random_samples(tmp_path, seed, mode):
+    """`seeksv getclip` file to file against the real reference on generated BAMs (the generator of tests/test_random_differential_gpu.py,
+    restricted to inputs the reference defines): the four gzip outputs decompress to the same bytes, with the BAM decoded on the host or on the GPU"""
+    from test_random_differential_gpu import random_sample
+    from test_random_oracle_vs_reference import write_sample
+    names, lens, b, rng, recs = random_sample(seed, n=2500, safe=True, want_records=True)
+    bam = str(tmp_path / "s.bam")
+    write_sample(bam, names, lens, recs)
+    for tag, flags in (("a", []), ("b", ["-t", "0.8", "-q", "0", "-s"])):
+        r = subprocess.run([REF, "getclip"] + flags + ["-o", str(tmp_path / ("ref" + tag)), bam], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-300:]
+        o = subprocess.run([SEEKSV, "getclip"] + mode + flags + ["-o", str(tmp_path / ("our" + tag)), bam], capture_output=True, text=True)
+        assert o.returncode == 0, o.stderr[-300:]
+        for ext in ("clip.gz", "clip.fq.gz", "unmapped_1.fq.gz", "unmapped_2.fq.gz"):
+            assert gzip.open(str(tmp_path / f"our{tag}.{ext}")).read() == gzip.open(str(tmp_path / f"ref{tag}.{ext}")).read(), (seed, tag, ext)
