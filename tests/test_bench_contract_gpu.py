@@ -1,0 +1,51 @@
+"""-m gpu: bench.py at a small size prints ONE JSON line that keeps the driver's contract (metric / value / unit / n_gpus / steps / warmup /
+ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, roofline, cpu_baseline), and the two-rank code path
+gives the same result as the one-rank path on the same total workload (two ranks on one GPU over gloo: the test hook of bench.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-400:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "3", "--warmup", "1", "--cpu-sample", "300000", "--ref-sample", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-600:]
+    d = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "records/s" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["records_total"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "records/s" and cb["value"] > 0 and cb["sample"]
+    assert d["result"]["support_sum"] == d["result"]["n_events"] > 0
+
+
+def test_bench_two_ranks_equal_one():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SSV_FORCE_DEVICE="0", SSV_DIST_BACKEND="gloo")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-800:]
+    a = _line(r2.stdout)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--genome-frac", "0.00390625", "--n-sv", "200", "--depth", "60", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-600:]
+    b = _line(r1.stdout)
+    assert a["n_gpus"] == 2 and a["config"]["records_total"] == b["config"]["records_total"]
+    assert a["result"] == b["result"]
