@@ -391,9 +391,9 @@ __global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays e
 					if (4 * k + j >= q0 && 4 * k + j < q1) s_present[(word >> (8 * j)) & 0xffu] = 1;
 			}
 		};
-		// every load of the event issued before the first store: the entry of a read of up to 256 bases (96 dwords) is covered by the
-		// unrolled batch, so an event costs one memory round trip after its metadata; longer reads and CIGARs continue in the loops
-		constexpr int BATCH = 6;
+		// every load of the event issued before the first store: the entry of a read of up to 320 bases (128 dwords) is covered by the
+		// unrolled batch (128 dwords: 320 bases), so an event costs one memory round trip after its metadata; longer reads and CIGARs continue in the loops
+		constexpr int BATCH = 8;
 		uint32_t lo[BATCH], hi[BATCH];
 #pragma unroll
 		for (int u = 0; u < BATCH; ++u) {
@@ -663,7 +663,7 @@ __device__ __forceinline__ uint32_t nt16_code(uint32_t ch)
 	return code;
 }
 
-constexpr int PACK_MAX_LQ = 256; // reads up to this length take the LDS-staged paths of the pack kernels
+constexpr int PACK_MAX_LQ = 320; // reads up to this length take the LDS-staged paths of the pack kernels
 
 // 16 lanes per cluster, four clusters per wavefront: strings and the CIGAR of the carrying event into dense blobs.  Every lane
 // assembles whole output dwords (a cluster's block starts 4-byte aligned and is zero padded to a multiple of 4 bytes):
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, int64_
 // A cluster's block is four pieces [seq_left | qual_left | seq_right | qual_right] at byte offsets that are not dword aligned, cut
 // out of a read at arbitrary nibble / byte offsets.  Composing the block byte by byte costs ~100 instructions per byte; here every
 // lane works on whole dwords twice:
-//   0. the event's entry (packed bases + qualities, <= 384 B) into LDS: one batch of independent, coalesced loads per cluster.
+//   0. the event's entry (packed bases + qualities, <= 480 B) into LDS: one batch of independent, coalesced loads per cluster.
 //   1. piece dwords into LDS: a sequence piece dword is 8 nibbles of the BAM-packed read = a 40-bit window of the source shifted by
 //      0 or 4 bits (the table keeps BAM's nibble order); a quality piece dword is the next 32 bits of the stream of W-bit alphabet indices.
 //      Tails are zeroed, and every piece sits between zero guard dwords.

@@ -183,7 +183,7 @@ def _remap_qualities(batch, alphabet):
 
 
 @pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (3, 2), (4, 2), (5, 3), (8, 3), (9, 4), (16, 4), (17, 8)])
-@pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300"])
+@pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300", "synth400"])
 def test_packed_table_quality_alphabets(ctx, source, n_values, bits):
     """format 2 with every index width: the decoded packed table equals the ASCII table and the oracle's, on deep bins (consensus
     storage), odd clip offsets, reads longer than the kernel's LDS-staged limit, missing qualities"""
