@@ -10,9 +10,11 @@
  * Parity status: PINNED - tests/test_oracle_golden.py checks this restatement against outputs of the
  * reference itself (oracle/_ref/seeksv_ref, built from /root/reference by oracle/Makefile) committed
  * under tests/golden/: clip tables of both example BAMs, SV tables, and -B junction-injection runs
- * on crafted and synthetic BAMs.  Not pinned (stated in DESIGN.md): the libbam 0.1.16 pileup's
- * ~8000-live-reads cap, reads with '='/'X' CIGAR ops, records the reference treats with undefined
- * behaviour (n_cigar == 0, missing qualities inside a multi-read bin).
+ * on crafted and synthetic BAMs - including '=' / 'X' CIGAR operations in the depth pass (eqx.*) and the
+ * read cap of the libbam 0.1.16 pileup (deep.*); tests/test_random_oracle_vs_reference.py runs the
+ * reference binary itself on generated samples.  Not pinned (stated in DESIGN.md): records the
+ * reference treats with undefined behaviour (n_cigar == 0, missing qualities inside a multi-read bin,
+ * CIGAR shapes on which the 0.1.16 pileup asserts).
  *
  * It shares the batch / junction / interval struct definitions with include/seeksv_hip.h so that both
  * sides are fed byte-identical inputs.
