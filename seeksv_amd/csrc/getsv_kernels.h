@@ -560,16 +560,17 @@ __global__ __launch_bounds__(BLOCK) void k_cap_mark(CapArgs c)
 		const bool boundary = t < 2 || t + 2 >= c.ntiles;
 		if (!(boundary || all)) { if (threadIdx.x == 0) c.deep[t] = 0; continue; }
 		bool deep = false;
-		for (int k = 0; k < CS_TILE / BLOCK; ++k) {
+#pragma unroll
+		for (int k = 0; k < CS_TILE / BLOCK; ++k) { // branch-free: all loads of the tile in flight at once
 			const int64_t i = t * CS_TILE + (int64_t)k * BLOCK + threadIdx.x;
-			if (i >= b.n) break;
-			const int tid = b.tid[i];
-			if (tid < 0) continue;
-			const int64_t j = i - CAP_LOOKBACK;
-			int ptid = -1, ppos = 0;
-			if (j >= 0) { ptid = b.tid[j]; ppos = b.pos[j]; }
-			else if ((int64_t)c.tail_n + j >= 0) { ptid = c.tail_tid[c.tail_n + j]; ppos = c.tail_pos[c.tail_n + j]; }
-			deep = deep || (ptid == tid && b.pos[i] - ppos <= c.span);
+			const bool in = i < b.n;
+			const int64_t ic = in ? i : 0;
+			const int tid = b.tid[ic], pos = b.pos[ic];
+			const int64_t j = ic - CAP_LOOKBACK, jt = (int64_t)c.tail_n + j;
+			const bool from_batch = j >= 0, from_tail = !from_batch && jt >= 0;
+			const int ptid = from_batch ? b.tid[j] : (from_tail ? c.tail_tid[jt] : -1);
+			const int ppos = from_batch ? b.pos[j] : (from_tail ? c.tail_pos[jt] : 0);
+			deep = deep || (in && tid >= 0 && ptid == tid && pos - ppos <= c.span);
 		}
 		const int any = __syncthreads_or(deep ? 1 : 0);
 		if (threadIdx.x == 0) { c.deep[t] = any ? 1 : 0; if (any) c.flags[1] = 1; }
