@@ -833,11 +833,13 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 		if (gl == 0) L[0] = 0u; // guards: before the first piece and after each piece
 #pragma unroll
 		for (int k = 0; k < 4; ++k) if (gl == k + 1) L[st[k] + nD[k]] = 0u;
-		// sequence pieces
-#pragma unroll
-		for (int h = 0; h < 2; ++h) {
-			const int nib0 = begin + (h ? ll : 0), len = h ? lr : ll, k = 2 * h;
-			for (int t = gl; t < nD[k]; t += GROUP) {
+		// sequence pieces (the dwords of both pieces share one index space: with 16 lanes and ~10 dwords per piece, a loop per piece
+		// would leave half the lanes idle in each - and this kernel is VALU bound, 93 % busy in the PMC pass)
+		for (int tt = gl; tt < nD[0] + nD[2]; tt += GROUP) {
+			const bool h = tt >= nD[0];
+			const int t = h ? tt - nD[0] : tt;
+			const int nib0 = begin + (h ? ll : 0), len = h ? lr : ll;
+			{
 				const int B = (nib0 >> 1) + 4 * t;
 				const uint32_t d0 = s4[B >> 2], d1 = s4[(B >> 2) + 1];
 				const uint64_t X = (((uint64_t)d1 << 32) | d0) >> (8 * (B & 3));
@@ -845,15 +847,16 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 				uint32_t v = (nib0 & 1) ? (((lo & 0x0f0f0f0fu) << 4) | ((nx >> 4) & 0x0f0f0f0fu)) : lo;
 				const int rem = len - 8 * t; // nibbles of the piece in this dword
 				if (rem < 8) v &= ((1u << (8 * (rem >> 1))) - 1u) | ((rem & 1) ? 0xf0u << (8 * (rem >> 1)) : 0u);
-				L[st[k] + t] = v;
+				L[(h ? st[2] : st[0]) + t] = v;
 			}
 		}
 		// quality pieces: a piece is the bit stream of its W-bit indices, quality i at stream bit i * W (for W = 3 an index can straddle
 		// a byte or a dword); dword t of the piece = stream bits [32 t, 32 t + 32) = the CNT qualities from i0 = 32 t / W on, shifted
-#pragma unroll
-		for (int h = 0; h < 2; ++h) {
-			const int q0 = begin + (h ? ll : 0), len = h ? lr : ll, k = 2 * h + 1;
-			for (int t = gl; t < nD[k]; t += GROUP) {
+		for (int tt = gl; tt < nD[1] + nD[3]; tt += GROUP) {
+			const bool h = tt >= nD[1];
+			const int t = h ? tt - nD[1] : tt;
+			const int q0 = begin + (h ? ll : 0), len = h ? lr : ll;
+			{
 				constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
 				const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
 				const int a = qb + q0 + i0;                            // first source byte
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 				}
 				uint32_t v = (uint32_t)(acc >> off);
 				if (W == 8 && rem < 4) v &= (1u << (8 * rem)) - 1u;
-				L[st[k] + t] = v;
+				L[(h ? st[3] : st[1]) + t] = v;
 			}
 		}
 	}
