@@ -217,12 +217,21 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    # one extra, untimed step with every kernel group bracketed by events: the per-kernel breakdown
+    # three extra, untimed steps with every kernel group bracketed by events, nothing else in flight: the per-kernel breakdown (per-step means:
+    # one launch of a sub-millisecond kernel varies by a few percent)
+    BREAKDOWN_STEPS = 3
     ctx.prof_reset()
     ctx.prof_enable(1)
-    step(wall)
-    drain()
+    for _ in range(BREAKDOWN_STEPS):
+        step(wall)
+        drain()
     allprof = ctx.prof_all()
+    for v in allprof.values():   # per step
+        v["total_ms"] /= BREAKDOWN_STEPS
+        v["launches"] = v["launches"] // BREAKDOWN_STEPS if v["launches"] >= BREAKDOWN_STEPS else v["launches"]
+        v["units"] = v["units"] // BREAKDOWN_STEPS
+    for k in list(wall):
+        wall[k] /= BREAKDOWN_STEPS
     breakdown = {k: round(v["total_ms"], 4) for k, v in allprof.items() if v["launches"]}
     ctx.prof_enable(0)
 
