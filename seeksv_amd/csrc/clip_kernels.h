@@ -593,6 +593,8 @@ __global__ void k_cluster_flags(const int32_t *__restrict__ support, int64_t E, 
 	if (j < E) flag[j] = support[j] > 0 ? 1u : 0u;
 }
 
+constexpr int PACK_MAX_LQ_ = 320; // = PACK_MAX_LQ below (reads up to this length take the LDS-staged paths of the pack kernels)
+
 struct PackArgs {
 	ClusterArgs c;
 	const uint32_t *flag;     // [E]
@@ -615,6 +617,10 @@ struct PackArgs {
 	uint64_t *src_off;
 	int32_t *src_begin, *src_lq;
 	uint64_t *src_cig;        // where the carrying event's CIGAR starts in cig_blob
+	// clusters that need the bytewise path of the packed kernel (multi-event bins, reads longer than PACK_MAX_LQ), listed by the meta kernel:
+	// they are packed by a launch of their own, so that a wavefront of the main launch never runs the long path for one of its four clusters
+	uint32_t *slow_list;
+	unsigned int *slow_count;
 };
 
 __global__ void k_cluster_pack_meta(PackArgs p)
@@ -643,6 +649,8 @@ __global__ void k_cluster_pack_meta(PackArgs p)
 		p.src_begin[c] = single ? p.c.ev.begin[e] : 0;
 		p.src_lq[c] = single ? p.c.ev.lq[e] : -1;
 		p.src_cig[c] = p.c.ev.cig_off[e];
+		const int lq = single ? p.c.ev.lq[e] : -1;
+		if (!(lq >= 0 && lq <= PACK_MAX_LQ_ && ll + lr <= PACK_MAX_LQ_)) p.slow_list[atomicAdd(p.slow_count, 1u)] = c; // a few thousand of millions: no hot spot
 	}
 }
 
@@ -654,16 +662,11 @@ __device__ __forceinline__ uint32_t nt16_char(uint32_t nib)
 	return (uint32_t)(((nib & 8u) ? HI : LO) >> (8u * (nib & 7u))) & 0xffu;
 }
 
-// the inverse: ASCII (upper case, as the consensus strings hold it) -> 4-bit code; anything else is N
-__device__ __forceinline__ uint32_t nt16_code(uint32_t ch)
-{
-	uint32_t code = 15;
-#pragma unroll
-	for (uint32_t k = 0; k < 16; ++k) if (nt16_char(k) == ch) code = k;
-	return code;
-}
+// the inverse as a table (ASCII -> 4-bit code, anything else N): a compare chain costs 32 instructions per character, and a wavefront with
+// one cluster of a multi-event bin runs its path for all its lanes
+__device__ __constant__ uint8_t NT16_CODE_OF[256] = {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 0, 15, 15, 15, 1, 14, 2, 13, 15, 15, 4, 11, 15, 15, 12, 15, 3, 15, 15, 15, 15, 5, 6, 8, 15, 7, 9, 15, 10, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};
 
-constexpr int PACK_MAX_LQ = 320; // reads up to this length take the LDS-staged paths of the pack kernels
+constexpr int PACK_MAX_LQ = PACK_MAX_LQ_;
 
 // 16 lanes per cluster, four clusters per wavefront: strings and the CIGAR of the carrying event into dense blobs.  Every lane
 // assembles whole output dwords (a cluster's block starts 4-byte aligned and is zero padded to a multiple of 4 bytes):
@@ -786,25 +789,29 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, int64_
 constexpr int PACK_RAW_DWORDS = (PACK_MAX_LQ / 2 + PACK_MAX_LQ) / 4 + 2; // entry of a PACK_MAX_LQ read + read-ahead
 constexpr int PACK_LDS_DWORDS = (PACK_MAX_LQ / 8 + 2) + (PACK_MAX_LQ / 4 + 2) + 5 + 1; // two sequence + two quality pieces of left_len + right_len <= PACK_MAX_LQ (W = 8 worst case) + guards
 
-template <int W>
+template <int W, bool SLOW> // SLOW: the launch over p.slow_list (bytewise path); otherwise every cluster takes the dword path or is skipped
 __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_t n_clusters, const uint64_t *__restrict__ str_off, const uint64_t *__restrict__ cig_off,
                                                               const uint32_t *__restrict__ cig_blob, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
 {
 	__shared__ uint32_t s_piece[GROUPS_PER_BLOCK][PACK_LDS_DWORDS];
 	__shared__ uint32_t s_raw[GROUPS_PER_BLOCK][PACK_RAW_DWORDS]; // the event's entry (packed bases, qualities) as it lies in the blob
 	__shared__ uint8_t s_lut[256]; // phred -> alphabet index
+	__shared__ uint8_t s_code[256]; // character -> 4-bit code (bytewise path)
 	if (W < 8) s_lut[threadIdx.x] = p.qlut[(threadIdx.x + 33u) & 255u]; // BLOCK == 256; p.qlut is indexed by character
+	s_code[threadIdx.x] = NT16_CODE_OF[threadIdx.x];
 	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
-	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
-	const bool active = c < n_clusters;
+	const int64_t k_ = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const int64_t c = SLOW ? (k_ < n_clusters ? (int64_t)p.slow_list[k_] : 0) : k_; // SLOW: n_clusters = entries of the list
+	bool active = k_ < n_clusters;
 	int ll = 0, lr = 0, lq = -1, begin = 0;
 	uint64_t soff = 0;
 	int ncg = 0;
 	uint64_t scig = 0, dcig = 0, doff = 0;
 	if (active) { ll = p.ll[c]; lr = p.lr[c]; lq = p.src_lq[c]; begin = p.src_begin[c]; soff = p.src_off[c]; ncg = p.ncig[c]; scig = p.src_cig[c]; dcig = cig_off[c]; doff = str_off[c]; }
 	const uint32_t cig_first = gl < ncg ? cig_blob[scig + gl] : 0u; // issued with the entry's loads below; CIGARs longer than 16 ops finish at the end
-	const bool fast = active && lq >= 0 && lq <= PACK_MAX_LQ && ll + lr <= PACK_MAX_LQ;
+	const bool fast = !SLOW && active && lq >= 0 && lq <= PACK_MAX_LQ && ll + lr <= PACK_MAX_LQ;
+	if (!SLOW) active = fast; // the others are on the slow list
 	// piece k: 0 seq_left, 1 qual_left, 2 seq_right, 3 qual_right; nB bytes, nD dwords, at block byte oP, at LDS dword st
 	int nB[4], nD[4], oP[4], st[4];
 	nB[0] = (ll + 1) / 2; nB[1] = (ll * W + 7) / 8; nB[2] = (lr + 1) / 2; nB[3] = (lr * W + 7) / 8;
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 			}
 			d[w] = word;
 		}
-	} else {
+	} else if (SLOW) {
 		// bytewise: from the event's packed read (long reads) or from the consensus storage (left part kept reversed)
 		const int64_t j = p.slot[c];
 		const bool single = lq >= 0;
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 			cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
 		}
 		auto seq_at = [&](bool right, int i) -> uint32_t {
-			return nt16_code(single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i]));
+			return s_code[single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i])];
 		};
 		auto qual_at = [&](bool right, int i) -> uint32_t { // character
 			return single ? (uint32_t)(uint8_t)v.qual(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rq[i] : cq[ll - 1 - i]);

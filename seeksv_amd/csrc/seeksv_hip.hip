@@ -74,7 +74,7 @@ struct ssv_ctx {
 	int max_ll = 0, max_lr = 0;
 	// clustering temporaries / outputs
 	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_strings, c_flag, c_idx;
-	DBuf o_slot, o_strbytes, o_ncig64, o_srcoff, o_srcbegin, o_srclq, o_srccig, totals;
+	DBuf o_slot, o_strbytes, o_ncig64, o_srcoff, o_srcbegin, o_srclq, o_srccig, o_slowlist, totals;
 	HBuf h_totals;
 	// the dense cluster table: device columns + pinned host copy, double buffered so that the PCIe copy of one table can overlap
 	// with whatever the caller runs next (ssv_clip_cluster_async / ssv_clip_table_wait)
@@ -358,7 +358,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	// every DBuf / HBuf member
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry, &c->cap_ring, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->o_slowlist, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry, &c->cap_ring, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
@@ -618,10 +618,13 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
 	pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.slot = P<uint32_t>(c->o_slot); pa.str_bytes = P<uint64_t>(c->o_strbytes);
 	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(T.o_ncig); pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut);
-	pa.src_off = nullptr; pa.src_begin = nullptr; pa.src_lq = nullptr; pa.src_cig = nullptr;
+	pa.src_off = nullptr; pa.src_begin = nullptr; pa.src_lq = nullptr; pa.src_cig = nullptr; pa.slow_list = nullptr; pa.slow_count = nullptr;
 	if (pa.packed) {
 		CHECK(ensure(c, c->o_srcoff, nc * 8)); CHECK(ensure(c, c->o_srcbegin, nc * 4)); CHECK(ensure(c, c->o_srclq, nc * 4)); CHECK(ensure(c, c->o_srccig, nc * 8));
 		pa.src_off = P<uint64_t>(c->o_srcoff); pa.src_begin = P<int32_t>(c->o_srcbegin); pa.src_lq = P<int32_t>(c->o_srclq); pa.src_cig = P<uint64_t>(c->o_srccig);
+		CHECK(ensure(c, c->o_slowlist, nc * 4));
+		pa.slow_list = P<uint32_t>(c->o_slowlist); pa.slow_count = reinterpret_cast<unsigned int *>(P<uint64_t>(c->totals) + 3); // read back with the blob totals below
+		HIPCHECK(c, hipMemsetAsync(pa.slow_count, 0, 8, c->st));
 		if (!pa.qlut) { CHECK(ensure(c, c->qual_lut, 256)); pa.qlut = P<uint8_t>(c->qual_lut); } // not read when qual_bits == 8
 	}
 	k_cluster_pack_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
@@ -639,11 +642,15 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		uint32_t *cb = P<uint32_t>(c->cig_blob), *oc = P<uint32_t>(T.o_cig);
 		uint8_t *os = P<uint8_t>(T.o_str);
 		if (!pa.packed) k_cluster_pack_ascii<<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
-		else if (pa.qual_bits == 8) k_cluster_pack_codes<8><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
-		else if (pa.qual_bits == 4) k_cluster_pack_codes<4><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
-		else if (pa.qual_bits == 3) k_cluster_pack_codes<3><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
-		else if (pa.qual_bits == 2) k_cluster_pack_codes<2><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
-		else k_cluster_pack_codes<1><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
+		else {
+			// the dword path for (nearly) all clusters, then the bytewise path for the listed ones
+			const int64_t n_slow = (int64_t)(uint32_t)P<uint64_t>(c->h_totals)[3];
+			const dim3 gs(grid_for(std::max<int64_t>(n_slow, 1), GROUPS_PER_BLOCK));
+#define SSV_PACK(W_) do { k_cluster_pack_codes<W_, false><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc); \
+			if (n_slow) k_cluster_pack_codes<W_, true><<<gs, BLOCK, 0, c->st>>>(pa, n_slow, so, co, cb, os, oc); } while (0)
+			if (pa.qual_bits == 8) SSV_PACK(8); else if (pa.qual_bits == 4) SSV_PACK(4); else if (pa.qual_bits == 3) SSV_PACK(3); else if (pa.qual_bits == 2) SSV_PACK(2); else SSV_PACK(1);
+#undef SSV_PACK
+		}
 	}
 	HIPCHECK(c, hipGetLastError());
 	delete pack_scope; pack_scope = nullptr; // the copy below is PCIe time, not kernel time
