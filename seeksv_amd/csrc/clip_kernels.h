@@ -798,7 +798,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, int64_
 	__shared__ uint8_t s_lut[256]; // phred -> alphabet index
 	__shared__ uint8_t s_code[256]; // character -> 4-bit code (bytewise path)
 	if (W < 8) s_lut[threadIdx.x] = p.qlut[(threadIdx.x + 33u) & 255u]; // BLOCK == 256; p.qlut is indexed by character
-	s_code[threadIdx.x] = NT16_CODE_OF[threadIdx.x];
+	if (SLOW) s_code[threadIdx.x] = NT16_CODE_OF[threadIdx.x];
 	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
 	const int64_t k_ = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
