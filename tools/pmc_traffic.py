@@ -77,7 +77,7 @@ def main():
     t["getsv_scan"] = {"bytes_per_record": (2 * f + w) / records, "fetch_raw_bytes": f, "write_bytes": w}
     f, w = total(["k_clip_gather"], 1)
     t["clip_gather"] = {"bytes_per_record": (f + w) / events, "_unit": "event", "_correction": "none (4-B/lane loads: FETCH_SIZE taken as reported)"}
-    f, w = total(["k_cluster_pack_meta", "k_cluster_pack_codes", "k_cluster_pack_ascii"], 1)
+    f, w = total(["k_cluster_pack_meta", "k_cluster_pack_codes", "k_cluster_pack_ascii"], 1)  # both launches of k_cluster_pack_codes (dword path + bytewise list)
     t["cluster_pack"] = {"bytes_per_record": (f + w) / events, "_unit": "event slot", "_correction": "none"}
     n_steps = by["k_clip_scan"][0]  # steps in the profiled run (the sort kernels run several passes per step)
     f, w = total(["k_rs_hist", "k_rs_scatter"])
