@@ -315,6 +315,7 @@ struct EventArrays {
 	uint64_t *cig_off;       // into cig_blob
 	uint64_t *src_seq;       // scratch: offset in the batch's seqqual
 	uint32_t *src_cig;       // scratch: offset in the batch's cigar
+	uint8_t *qmiss;          // 1: the event's read carries no qualities (first quality byte 0xff; the row prints "*") - set by k_clip_gather
 };
 
 // candidate c's events -> final, BAM-ordered position ev_base + ev_off[c] + e
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(BLOCK) void k_clip_gather(DevBatch b, EventArrays e
 			if (k < nb / 4) put(k, lo[u], hi[u]);
 		}
 		if (gl < nc) cd[gl] = c_first;
+		if (gl == 0) ev.qmiss[e] = (lq > 0 && !has_qual) ? 1 : 0; // (last: a store right after the test would make the loads above wait for it)
 		for (uint32_t k = gl + GROUP * BATCH; k < nb / 4; k += GROUP) put(k, s4[k], mis ? s4[k + 1] : 0u);
 		for (uint32_t k = gl + GROUP; k < nc; k += GROUP) cd[k] = cs[k];
 	}
@@ -469,9 +471,8 @@ __global__ void k_bin_mark(const uint64_t *__restrict__ skey, const uint32_t *__
 	mflag[j] = single ? 0u : 1u;
 	if (single) {
 		const uint32_t e = perm[j];
-		const int lq = ev.lq[e];
 		support[j] = 1; c_ll[j] = ev.ll[e]; c_lr[j] = ev.lr[e]; c_cig_ev[j] = e;
-		c_qmiss[j] = (lq > 0 && seq_blob[ev.seq_off[e] + (uint64_t)((lq + 1) / 2)] == 0xff) ? 1 : 0;
+		c_qmiss[j] = ev.qmiss[e]; // (noted by the gather kernel: looking it up in the blob costs a scattered sector per event)
 	} else support[j] = 0;
 }
 

@@ -66,7 +66,7 @@ struct ssv_ctx {
 	ssv_clip_params clip_p{};
 	DBuf d_last_tid, stage, cand, cand_cnt, cand_off, stash;
 	int64_t stage_cap = 0;
-	DBuf ev_key, ev_begin, ev_ll, ev_lr, ev_lq, ev_ncig, ev_seq_bytes, ev_seq_off, ev_cig_off, ev_src_seq, ev_src_cig;
+	DBuf ev_key, ev_begin, ev_ll, ev_lr, ev_lq, ev_ncig, ev_seq_bytes, ev_seq_off, ev_cig_off, ev_src_seq, ev_src_cig, ev_qmiss;
 	int64_t ev_cap = 0, n_events = 0;
 	DBuf seq_blob, cig_blob;
 	uint64_t seq_used = 0, cig_used = 0;
@@ -279,6 +279,7 @@ int ensure_events(ssv_ctx *c, int64_t need)
 	CHECK(ensure(c, c->ev_seq_bytes, ncap * 4, true, used * 4));
 	CHECK(ensure(c, c->ev_seq_off, ncap * 8, true, used * 8));
 	CHECK(ensure(c, c->ev_cig_off, ncap * 8, true, used * 8));
+	CHECK(ensure(c, c->ev_qmiss, ncap, true, used));
 	CHECK(ensure(c, c->ev_src_seq, ncap * 8));
 	CHECK(ensure(c, c->ev_src_cig, ncap * 4));
 	c->ev_cap = ncap;
@@ -290,7 +291,7 @@ EventArrays event_arrays(ssv_ctx *c)
 	EventArrays e;
 	e.key = P<uint64_t>(c->ev_key); e.begin = P<int32_t>(c->ev_begin); e.ll = P<int32_t>(c->ev_ll); e.lr = P<int32_t>(c->ev_lr); e.lq = P<int32_t>(c->ev_lq);
 	e.ncig = P<uint32_t>(c->ev_ncig); e.seq_bytes = P<uint32_t>(c->ev_seq_bytes); e.seq_off = P<uint64_t>(c->ev_seq_off); e.cig_off = P<uint64_t>(c->ev_cig_off);
-	e.src_seq = P<uint64_t>(c->ev_src_seq); e.src_cig = P<uint32_t>(c->ev_src_cig);
+	e.src_seq = P<uint64_t>(c->ev_src_seq); e.src_cig = P<uint32_t>(c->ev_src_cig); e.qmiss = P<uint8_t>(c->ev_qmiss);
 	return e;
 }
 
@@ -356,7 +357,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (c->qual_present.p) (void)hipFree(c->qual_present.p);
 	if (c->h_qual_present.p) (void)hipHostFree(c->h_qual_present.p);
 	// every DBuf / HBuf member
-	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_begin, &c->ev_ll,
+	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_qmiss, &c->ev_begin, &c->ev_ll,
 	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->o_slowlist, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry, &c->cap_ring, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
