@@ -506,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 		v.sp = a.seq_blob + a.ev.seq_off[e];
 		v.qp = v.sp + (lq + 1) / 2;
 		v.begin = a.ev.begin[e]; v.ll = a.ev.ll[e]; v.lr = a.ev.lr[e];
-		v.qmiss = lq > 0 && v.qp[0] == 0xff;
+		v.qmiss = a.ev.qmiss[e] != 0; // noted by the gather kernel (reading qp[0] here would be one more memory round trip in the per-read chain)
 		// ---- find the first cluster of the bin that absorbs this event (clip_reads.cpp:262-273) ----
 		auto absorbs = [&](int64_t slot) -> bool {
 			const uint8_t *cs = a.strings + (int64_t)a.mslot[slot] * stride;
