@@ -170,49 +170,61 @@ __device__ __forceinline__ bool discordant_geometry(const DevJunction &j, int fl
 	return false;
 }
 
-__device__ __forceinline__ void discordant_record(const GetsvArgs &a, int64_t i, int tid, int pos, int64_t tile)
+// The fixed fields of a candidate record and its first CIGAR operations, loaded in one go: the per-candidate kernels are bound by the
+// latency of dependent loads (VALU 6 % busy), and the predicate chains below would otherwise fetch one field per early exit.
+struct CandRec {
+	int mapq, flag, isize, nc, mtid, mpos, lq;
+	const uint32_t *cig;
+	uint32_t op[4]; // the first four operations (clamped: op[k] = last operation for k >= nc; 0 when there is none)
+};
+
+__device__ __forceinline__ CandRec cand_load(const DevBatch &b, int64_t i)
 {
-	const DevBatch &b = a.b;
-	if ((int)b.mapq[i] < a.disc_min_mapq) return;
-	int flag = b.flag[i];
+	CandRec r;
+	r.mapq = (int)b.mapq[i]; r.flag = b.flag[i]; r.isize = b.isize[i]; r.nc = b.n_cigar[i]; r.mtid = b.mtid[i]; r.mpos = b.mpos[i]; r.lq = b.l_qseq[i];
+	r.cig = b.cigar + b.cigar_off[i];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) r.op[k] = r.nc > 0 ? r.cig[k < r.nc ? k : r.nc - 1] : 0u;
+	return r;
+}
+
+__device__ __forceinline__ uint32_t cand_op(const CandRec &r, int k) { return k < 4 ? (k == 0 ? r.op[0] : k == 1 ? r.op[1] : k == 2 ? r.op[2] : r.op[3]) : r.cig[k]; }
+
+__device__ __forceinline__ void discordant_record(const GetsvArgs &a, const CandRec &r, int tid, int pos, int64_t tile)
+{
+	if (r.mapq < a.disc_min_mapq) return;
+	const int flag = r.flag;
 	if (flag & (F_DUP | F_UNMAP | F_MUNMAP)) return;
-	if (is_concordant(flag, b.isize[i], a.mean, a.sd, a.times)) return;
-	if (is_hard_clip(b, i)) return;
+	if (is_concordant(flag, r.isize, a.mean, a.sd, a.times)) return;
+	const int n = r.nc;
+	if (n > 0 && ((r.op[0] & 15u) == C_H || (cand_op(r, n - 1) & 15u) == C_H)) return; // IsHardClip (n == 0: the reference reads cigar[-1]; "not hard clipped" like the oracle)
 	// bam_calend of libbam 0.1.16: M, D, N advance; no CIGAR -> pos + 1
 	int rend = pos;
-	{
-		int n = b.n_cigar[i];
-		if (n == 0) rend = pos + 1;
-		else {
-			const uint32_t *cig = b.cigar + b.cigar_off[i];
-			for (int k = 0; k < n; ++k) { uint32_t c = cig[k]; int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) rend += (int)(c >> 4); }
-		}
-	}
+	if (n == 0) rend = pos + 1;
+	else for (int k = 0; k < n; ++k) { const uint32_t c = cand_op(r, k); const int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) rend += (int)(c >> 4); }
 	// junction windows that can overlap [pos, rend): beg in (pos - wmax, rend) on this contig.  The tile of the record's start knows the
 	// first junction that begins after (tile start - wmax): a lower bound of the binary search's answer, the loop below skips the rest.
 	const int64_t lo = a.tile_junc[tile];
-	const int mtid = b.mtid[i], mpos = b.mpos[i], lq = b.l_qseq[i];
 	for (int64_t m = lo; m < a.n_junc; ++m) {
 		const DevJunction j = a.junc[m];
 		if (j.up_tid != tid || j.beg >= rend) break;
 		if (!(rend > j.beg && pos < j.end)) continue;
-		if (discordant_geometry(j, flag, pos, mpos, lq, mtid, a.min_ins, a.max_ins)) atomicAdd(&a.counts[j.orig], 1);
+		if (discordant_geometry(j, flag, pos, r.mpos, r.lq, r.mtid, a.min_ins, a.max_ins)) atomicAdd(&a.counts[j.orig], 1);
 	}
 }
 
-__device__ __forceinline__ void depth_record(const GetsvArgs &a, int64_t i, int tid, int pos, int64_t tile, int sign = 1)
+// sign -1: the correction pass of the read cap takes a dropped read's coverage out again (it has applied the filter already)
+__device__ __forceinline__ void depth_record(const GetsvArgs &a, const CandRec &r, int tid, int pos, int64_t tile, int sign = 1)
 {
-	const DevBatch &b = a.b;
-	if (sign > 0) { // (the correction pass of the read cap has applied the filter already)
-		if ((int)b.mapq[i] < a.depth_min_mapq) return;                    // read_bam: MAPQ < mapQ -> treated as unmapped
-		if (b.flag[i] & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) return; // BAM_DEF_MASK
+	if (sign > 0) {
+		if (r.mapq < a.depth_min_mapq) return;                              // read_bam: MAPQ < mapQ -> treated as unmapped
+		if (r.flag & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) return;    // BAM_DEF_MASK
 	}
-	int n = b.n_cigar[i];
-	const uint32_t *cig = b.cigar + b.cigar_off[i];
+	const int n = r.nc;
 	int col = pos + 1; // 1-based
 	int64_t w = -1;
 	for (int k = 0; k < n; ++k) {
-		uint32_t c = cig[k];
+		const uint32_t c = cand_op(r, k);
 		int op = (int)(c & 15u), len = (int)(c >> 4);
 		if (op == C_M) { // libbam 0.1.16 pileup: only M covers, only M / D / N advance; '=' and 'X' are skipped like padding (tests/golden/getsv/eqx.*)
 			if (len > 0) {
@@ -424,10 +436,11 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 	for (uint32_t k = lane_id(); k < n; k += WAVE) {
 		const int64_t i = g.stage[so + k];
 		const int tid = a.b.tid[i], pos = a.b.pos[i];
+		const CandRec r = cand_load(a.b, i);
 		int64_t tile;
 		const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
-		if (m & TM_JUNC) discordant_record(a, i, tid, pos, tile);
-		if (m & TM_DEPTH) depth_record(a, i, tid, pos, tile);
+		if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
+		if (m & TM_DEPTH) depth_record(a, r, tid, pos, tile);
 	}
 }
 
@@ -666,7 +679,7 @@ __global__ __launch_bounds__(WAVE) void k_cap_sweep(CapArgs c)
 			if (i >= 0 && ((dropped >> lane) & 1ull)) {
 				int64_t tile;
 				const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
-				if (m & TM_DEPTH) depth_record(a, i, tid, pos, tile, -1);
+				if (m & TM_DEPTH) depth_record(a, cand_load(a.b, i), tid, pos, tile, -1);
 			}
 		}
 		since_deep = is_deep(t) ? 0 : since_deep + 1;
