@@ -92,7 +92,10 @@ def main():
     t0 = time.time()
     n_scan = sp["own_hi_rec"] - sp["scan_lo_rec"]
     n_own = sp["own_hi_rec"] - sp["own_lo_rec"]
-    scan_batch, scan_t = w.generate_device(sp["scan_lo_rec"], n_scan, local_rank)
+    # the batch as the device decoder hands it over: hot columns (tid, pos, n_cigar), one 64-byte line per record with the cold fields, CIGARs,
+    # packed bases + qualities of the soft-clipped records.  It stays resident and unchanged over the timed region (SSV_MEM_PERSISTENT):
+    # clip events point at the reads' own bytes and the cluster table is cut straight out of them.
+    scan_batch, scan_t = w.generate_device(sp["scan_lo_rec"], n_scan, local_rank, soa=False, persistent=True)
     # the rank's own records = the scan batch minus the leading halo (same cigar / seqqual blobs, offsets are absolute)
     from seeksv_amd import _abi
 
@@ -101,8 +104,9 @@ def main():
         for name, dt in _abi.BATCH_FIELDS:
             ptr = getattr(batch, name)
             arrays[name] = ptr if name in ("cigar", "seqqual", "xc") or ptr is None else ptr + first * np.dtype(dt).itemsize
+        arrays["rec"] = batch.rec + first * 64 if batch.rec else None
         arrays["n_cigar_total"], arrays["seqqual_bytes"], arrays["max_ref_span"] = batch.n_cigar_total, batch.seqqual_bytes, batch.max_ref_span
-        return _abi.make_batch(arrays, mem=_abi.MEM_DEVICE, n=n)[0]
+        return _abi.make_batch(arrays, mem=batch.mem, n=n)[0]
 
     own_batch = sub_batch(scan_batch, sp["own_lo_rec"] - sp["scan_lo_rec"], n_own)
     # global file prefix for the insert-size statistics (cluster.cpp:68 stops after 5 M qualifying records)
@@ -110,7 +114,7 @@ def main():
     if sp["scan_lo_rec"] == 0 and n_prefix <= n_scan:
         prefix_batch, prefix_t = sub_batch(scan_batch, 0, n_prefix), None
     else:
-        prefix_batch, prefix_t = w.generate_device(0, n_prefix, local_rank)
+        prefix_batch, prefix_t = w.generate_device(0, n_prefix, local_rank, soa=False)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 

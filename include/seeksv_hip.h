@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SSV_ABI_VERSION 1
+#define SSV_ABI_VERSION 2
 
 typedef enum {
 	SSV_OK = 0,
@@ -37,19 +37,44 @@ typedef enum {
 /* Where the arrays of a batch live. */
 typedef enum {
 	SSV_MEM_HOST = 0,   /* host memory (pinned preferred); the library stages it to the GPU */
-	SSV_MEM_DEVICE = 1  /* already resident in this GPU's HBM; used in place, zero copies */
+	SSV_MEM_DEVICE = 1, /* already resident in this GPU's HBM; used in place, zero copies */
+	/* SSV_MEM_DEVICE | SSV_MEM_PERSISTENT: a device batch whose `cigar` and `seqqual` arrays stay valid and unchanged until the
+	 * getclip pass that scanned it has delivered its table (ssv_clip_cluster[_async] has returned): clip events then keep
+	 * pointing at the batch's own bytes and the cluster table is cut straight out of them - nothing is copied in between.
+	 * Without the flag ssv_clip_scan copies the bytes of the batch's clip events into context memory before it returns. */
+	SSV_MEM_PERSISTENT = 2
 } ssv_mem;
 
 /*
- * One batch of decoded BAM records, structure-of-arrays, in file order.  Field meaning follows
- * samtools' bam1_core_t (reference: sam/bam.h:169-178) - the reference's samread() loop bodies
- * (clip_reads.h:410, cluster.cpp:48, getsv.cpp:1067, bam2depth.h:29) consume exactly these.
+ * The "cold" fields of one record as ONE 64-byte line: everything of BAM's fixed 32-byte record core (sam/bam.h:169-178)
+ * plus the first five CIGAR operations and the offsets of the variable parts.  The streaming kernels never touch it (they read the
+ * hot columns tid / pos / n_cigar below, 2-8 bytes per record); the per-candidate kernels (1-3 % of the records) fetch exactly this
+ * one line instead of one 64-byte sector per structure-of-arrays column.  Arrays of ssv_record must be 64-byte aligned.
+ */
+typedef struct {
+	int32_t tid, pos;         /* as in the hot columns */
+	uint16_t flag;
+	uint8_t mapq;
+	uint8_t xc;               /* 1 if the XC:i aux value != 0 (clip_reads.cpp:126-129) */
+	uint16_t n_cigar;
+	uint16_t pad;
+	int32_t l_qseq, mtid, mpos, isize;
+	uint32_t cigar_off;       /* index of the record's first operation in cigar[] (all operations are there too) */
+	uint32_t cigar_head[5];   /* operations 0..4 (0 beyond n_cigar): 99.9 % of short-read records need nothing else */
+	uint64_t seq_off;         /* as seq_off[] below */
+} ssv_record;
+
+/*
+ * One batch of decoded BAM records in file order.  Field meaning follows samtools' bam1_core_t (reference: sam/bam.h:169-178) -
+ * the reference's samread() loop bodies (clip_reads.h:410, cluster.cpp:48, getsv.cpp:1067, bam2depth.h:29) consume exactly these.
+ * Layout: the hot columns tid, pos, n_cigar (structure of arrays: what the streaming passes read) are always required; the other
+ * fixed fields come either as the classic structure-of-arrays columns (flag ... seq_off) or as `rec`, one 64-byte line per record
+ * (the device decoder and the GPU generator write it natively).  A batch without `rec` is transposed into one on the device first.
  *   seq_off[i] = byte offset into seqqual of record i's ceil(l_qseq/2) packed 4-bit bases followed
  *   by l_qseq quality bytes, or SSV_NO_SEQ when the batcher did not ship them.  The batcher must
  *   ship them for every record whose first or last CIGAR operation is 'S' (only those can become
  *   clip events, clip_reads.cpp:124,150); it may omit all others.
- *   A SSV_MEM_DEVICE batch must leave at least 8 readable bytes after seqqual[seqqual_bytes - 1] (the gather kernel
- *   copies whole aligned dwords).
+ *   A SSV_MEM_DEVICE batch must leave at least 8 readable bytes after seqqual[seqqual_bytes - 1] (whole aligned dwords are read).
  */
 #define SSV_NO_SEQ UINT64_MAX
 typedef struct {
@@ -73,6 +98,7 @@ typedef struct {
 	const uint8_t *seqqual;    /* [seqqual_bytes] */
 	int64_t n_cigar_total;
 	int64_t seqqual_bytes;
+	const ssv_record *rec;     /* [n] or NULL; when given, flag / mapq / l_qseq / mtid / mpos / isize / cigar_off / xc / seq_off may be NULL */
 } ssv_batch_t;
 
 typedef struct ssv_ctx ssv_ctx; /* opaque */
@@ -111,8 +137,9 @@ typedef struct {
 int ssv_clip_begin(ssv_ctx *ctx, const ssv_clip_params *p);
 /*
  * Scan one batch (GetSClipReads, clip_reads.cpp:112-192, incl. the contig-switch rule of
- * clip_reads.h:423-438): appends the batch's clip events - key, slice lengths, packed bases,
- * qualities, CIGAR - to context-owned HBM.  The batch buffers may be reused after ssv_sync().
+ * clip_reads.h:423-438): appends the batch's clip events - key, slice lengths, CIGAR, where the read's packed bases and
+ * qualities lie - to context-owned HBM.  The batch buffers may be reused after ssv_sync(), except the `cigar` and `seqqual`
+ * arrays of a SSV_MEM_PERSISTENT batch (see ssv_mem).
  */
 int ssv_clip_scan(ssv_ctx *ctx, const ssv_batch_t *b);
 /* Events collected so far (synchronises). */

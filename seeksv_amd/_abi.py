@@ -13,7 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBDIR = os.environ.get("SSV_LIBDIR") or os.path.join(_HERE, "lib")  # SSV_LIBDIR: an alternative build of the libraries (`make asan`)
 
 NO_SEQ = (1 << 64) - 1
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_PERSISTENT = 0, 1, 2
+# ssv_record: one 64-byte line per record (the cold fields + the first five CIGAR operations)
+RECORD_DTYPE = np.dtype([("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("xc", np.uint8), ("n_cigar", np.uint16), ("pad", np.uint16),
+                         ("l_qseq", np.int32), ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32), ("cigar_off", np.uint32), ("cigar_head", np.uint32, (5,)),
+                         ("seq_off", np.uint64)])
+assert RECORD_DTYPE.itemsize == 64
 
 
 class Batch(C.Structure):
@@ -25,6 +30,7 @@ class Batch(C.Structure):
         ("isize", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("xc", C.c_void_p),
         ("seq_off", C.c_void_p), ("seqqual", C.c_void_p),
         ("n_cigar_total", C.c_int64), ("seqqual_bytes", C.c_int64),
+        ("rec", C.c_void_p),
     ]
 
 
@@ -117,6 +123,14 @@ def make_batch(arrays, mem=MEM_HOST, n=None):
             setattr(b, name, a.ctypes.data if a.size else None)
         else:
             setattr(b, name, int(a))
+    rec = arrays.get("rec")
+    if isinstance(rec, np.ndarray):
+        rec = np.ascontiguousarray(rec)
+        assert rec.nbytes == 64 * (len(arrays["tid"]) if n is None else n)
+        keep.append(rec)
+        b.rec = rec.ctypes.data if rec.size else None
+    else:
+        b.rec = int(rec) if rec else None
     b.mem = mem
     b.max_ref_span = int(arrays.get("max_ref_span", 0))
     if n is None:

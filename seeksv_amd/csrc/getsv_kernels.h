@@ -13,12 +13,11 @@
 
 namespace ssv {
 
-__device__ __forceinline__ bool is_hard_clip(const DevBatch &b, int64_t i)
+__device__ __forceinline__ bool is_hard_clip(const DevBatch &b, const RecLine &r)
 {
-	int n = b.n_cigar[i];
+	const int n = r.n_cigar();
 	if (n == 0) return false; // the reference reads cigar[-1] here (undefined); "not hard clipped" like the oracle
-	const uint32_t *cig = b.cigar + b.cigar_off[i];
-	return (cig[0] & 15u) == C_H || (cig[n - 1] & 15u) == C_H;
+	return (r.head(0) & 15u) == C_H || (r.op(b.cigar, n - 1) & 15u) == C_H;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -29,13 +28,15 @@ constexpr int ISZ_ITEMS = 4;
 constexpr int ISZ_TILE = BLOCK * ISZ_ITEMS;
 
 // cluster.cpp:51-67: MAPQ >= q, not hard clipped, PAIRED && PROPER_PAIR && !DUP && isize > 0
-__device__ __forceinline__ bool isize_qualifies(const DevBatch &b, int64_t i, int min_mapq)
+__device__ __forceinline__ bool isize_qualifies(const DevBatch &b, int64_t i, int min_mapq, int *isize)
 {
-	if ((int)b.mapq[i] < min_mapq) return false;
-	int f = b.flag[i];
+	const RecLine r = rec_load(b.rec, i); // the pass covers a bounded prefix of the file (the first -n qualifying records): whole lines are fine
+	*isize = r.isize();
+	if (r.mapq() < min_mapq) return false;
+	const int f = r.flag();
 	if (!((f & F_PAIRED) && (f & F_PROPER) && !(f & F_DUP))) return false;
-	if (b.isize[i] <= 0) return false;
-	return !is_hard_clip(b, i);
+	if (r.isize() <= 0) return false;
+	return !is_hard_clip(b, r);
 }
 
 // pass A: qualifying records per tile
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(BLOCK) void k_isize_count(DevBatch b, int min_mapq,
 	int64_t i0 = (int64_t)blockIdx.x * ISZ_TILE + (int64_t)threadIdx.x * ISZ_ITEMS;
 	uint32_t c = 0;
 #pragma unroll
-	for (int k = 0; k < ISZ_ITEMS; ++k) if (i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq)) ++c;
+	for (int k = 0; k < ISZ_ITEMS; ++k) { int v; if (i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq, &v)) ++c; }
 	c = wave_sum(c);
 	if (lane_id() == 0) lds[wave_id()] = c;
 	__syncthreads();
@@ -59,14 +60,15 @@ __global__ __launch_bounds__(BLOCK) void k_isize_collect(DevBatch b, int min_map
 	__shared__ uint32_t lds[WAVES_PER_BLOCK + 1];
 	int64_t i0 = (int64_t)blockIdx.x * ISZ_TILE + (int64_t)threadIdx.x * ISZ_ITEMS;
 	bool q[ISZ_ITEMS];
+	int val[ISZ_ITEMS];
 	uint32_t c = 0;
 #pragma unroll
-	for (int k = 0; k < ISZ_ITEMS; ++k) { q[k] = i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq); c += q[k]; }
+	for (int k = 0; k < ISZ_ITEMS; ++k) { val[k] = 0; q[k] = i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq, &val[k]); c += q[k]; }
 	uint32_t tot;
 	uint32_t ex = block_exclusive_sum(c, lds, &tot);
 	int64_t o = count_before + tile_base[blockIdx.x] + ex;
 #pragma unroll
-	for (int k = 0; k < ISZ_ITEMS; ++k) if (q[k]) { if (o < max_pairs) vals[o] = b.isize[i0 + k]; ++o; }
+	for (int k = 0; k < ISZ_ITEMS; ++k) if (q[k]) { if (o < max_pairs) vals[o] = val[k]; ++o; }
 }
 
 // sum of vals (mode 0) or of the int-wrapped squared deviations from mean (mode 1, cluster.cpp:77) into *acc
@@ -170,25 +172,25 @@ __device__ __forceinline__ bool discordant_geometry(const DevJunction &j, int fl
 	return false;
 }
 
-// The fixed fields of a candidate record and its first CIGAR operations, loaded in one go: the per-candidate kernels are bound by the
-// latency of dependent loads (VALU 6 % busy), and the predicate chains below would otherwise fetch one field per early exit.
+// The fixed fields of a candidate record and its first five CIGAR operations are ONE 64-byte line (ssv_record): the per-candidate kernels
+// are bound by the number and latency of scattered loads (VALU 6 % busy), and a line is one sector where the structure-of-arrays batch
+// cost one sector per field.
 struct CandRec {
 	int mapq, flag, isize, nc, mtid, mpos, lq;
-	const uint32_t *cig;
-	uint32_t op[4]; // the first four operations (clamped: op[k] = last operation for k >= nc; 0 when there is none)
+	const uint32_t *cig; // all operations (read beyond the fifth)
+	RecLine line;
 };
 
 __device__ __forceinline__ CandRec cand_load(const DevBatch &b, int64_t i)
 {
 	CandRec r;
-	r.mapq = (int)b.mapq[i]; r.flag = b.flag[i]; r.isize = b.isize[i]; r.nc = b.n_cigar[i]; r.mtid = b.mtid[i]; r.mpos = b.mpos[i]; r.lq = b.l_qseq[i];
-	r.cig = b.cigar + b.cigar_off[i];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) r.op[k] = r.nc > 0 ? r.cig[k < r.nc ? k : r.nc - 1] : 0u;
+	r.line = rec_load(b.rec, i);
+	r.mapq = r.line.mapq(); r.flag = r.line.flag(); r.isize = r.line.isize(); r.nc = r.line.n_cigar(); r.mtid = r.line.mtid(); r.mpos = r.line.mpos(); r.lq = r.line.l_qseq();
+	r.cig = b.cigar + r.line.cigar_off();
 	return r;
 }
 
-__device__ __forceinline__ uint32_t cand_op(const CandRec &r, int k) { return k < 4 ? (k == 0 ? r.op[0] : k == 1 ? r.op[1] : k == 2 ? r.op[2] : r.op[3]) : r.cig[k]; }
+__device__ __forceinline__ uint32_t cand_op(const CandRec &r, int k) { return k < 5 ? r.line.head(k) : r.cig[k]; }
 
 __device__ __forceinline__ void discordant_record(const GetsvArgs &a, const CandRec &r, int tid, int pos, int64_t tile)
 {
@@ -197,7 +199,7 @@ __device__ __forceinline__ void discordant_record(const GetsvArgs &a, const Cand
 	if (flag & (F_DUP | F_UNMAP | F_MUNMAP)) return;
 	if (is_concordant(flag, r.isize, a.mean, a.sd, a.times)) return;
 	const int n = r.nc;
-	if (n > 0 && ((r.op[0] & 15u) == C_H || (cand_op(r, n - 1) & 15u) == C_H)) return; // IsHardClip (n == 0: the reference reads cigar[-1]; "not hard clipped" like the oracle)
+	if (n > 0 && ((cand_op(r, 0) & 15u) == C_H || (cand_op(r, n - 1) & 15u) == C_H)) return; // IsHardClip (n == 0: the reference reads cigar[-1]; "not hard clipped" like the oracle)
 	// bam_calend of libbam 0.1.16: M, D, N advance; no CIGAR -> pos + 1
 	int rend = pos;
 	if (n == 0) rend = pos + 1;
@@ -435,8 +437,8 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 	const uint32_t n = g.tile_cnt[t], so = g.tile_off[t];
 	for (uint32_t k = lane_id(); k < n; k += WAVE) {
 		const int64_t i = g.stage[so + k];
-		const int tid = a.b.tid[i], pos = a.b.pos[i];
 		const CandRec r = cand_load(a.b, i);
+		const int tid = r.line.tid(), pos = r.line.pos();
 		int64_t tile;
 		const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
 		if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
@@ -550,18 +552,29 @@ struct CapArgs {
 	int32_t ntail_n;
 };
 
-__device__ __forceinline__ bool cap_pass(const GetsvArgs &a, int64_t i) // the depth pass's read filter (read_bam + BAM_DEF_MASK)
+__device__ __forceinline__ bool cap_pass(const GetsvArgs &a, const RecLine &r) // the depth pass's read filter (read_bam + BAM_DEF_MASK)
 {
-	return (int)a.b.mapq[i] >= a.depth_min_mapq && !(a.b.flag[i] & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && a.b.tid[i] >= 0;
+	return r.mapq() >= a.depth_min_mapq && !(r.flag() & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) && r.tid() >= 0;
 }
 
-__device__ __forceinline__ int cap_calend(const GetsvArgs &a, int64_t i) // bam_calend: M, D, N advance
+__device__ __forceinline__ int cap_calend(const GetsvArgs &a, const RecLine &r) // bam_calend: M, D, N advance
 {
-	int end = a.b.pos[i];
-	const int n = a.b.n_cigar[i];
-	const uint32_t *cig = a.b.cigar + a.b.cigar_off[i];
-	for (int k = 0; k < n; ++k) { const uint32_t c = cig[k]; const int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) end += (int)(c >> 4); }
+	int end = r.pos();
+	const int n = r.n_cigar();
+	for (int k = 0; k < n; ++k) { const uint32_t c = r.op(a.b.cigar, k); const int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) end += (int)(c >> 4); }
 	return end;
+}
+
+// the ring of read ends grows (a batch brought a read with a longer reference span): a carried sweep's live entries - ends in
+// [pos, pos + old size) - move to their slots in the larger, zeroed ring
+__global__ __launch_bounds__(BLOCK) void k_cap_regrow(const CapCarry *__restrict__ carry, const int32_t *__restrict__ old_ring, int32_t old_mask, int32_t *__restrict__ new_ring, int32_t new_mask)
+{
+	if (!carry->active || carry->pos < 0) return;
+	const int64_t pos = carry->pos;
+	for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= old_mask; k += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t e = pos + k;
+		new_ring[e & new_mask] = old_ring[e & old_mask];
+	}
 }
 
 // per CS_TILE records: does the tile hold a deep record?  (grid-stride over the tiles: in the usual case every tile but four leaves at once)
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(WAVE) void k_cap_sweep(CapArgs c)
 			bool pass = false;
 			int tid = -1, pos = 0, end = 0;
 			if (i >= 0) {
-				if (i < a.b.n && cap_pass(a, i)) { pass = true; tid = a.b.tid[i]; pos = a.b.pos[i]; end = cap_calend(a, i); }
+				if (i < a.b.n) { const RecLine rl = rec_load(a.b.rec, i); if (cap_pass(a, rl)) { pass = true; tid = rl.tid(); pos = rl.pos(); end = cap_calend(a, rl); } }
 			} else if ((int64_t)c.tail_n + i >= 0) {
 				const int64_t j = (int64_t)c.tail_n + i;
 				pass = c.tail_pass[j] != 0; tid = c.tail_tid[j]; pos = c.tail_pos[j]; end = c.tail_end[j];
@@ -698,8 +711,9 @@ __global__ void k_cap_tail(CapArgs c)
 	if (s < c.tail_n) { c.ntail_tid[j] = c.tail_tid[s]; c.ntail_pos[j] = c.tail_pos[s]; c.ntail_end[j] = c.tail_end[s]; c.ntail_pass[j] = c.tail_pass[s]; }
 	else {
 		const int64_t i = s - c.tail_n;
-		const bool p = cap_pass(c.g, i);
-		c.ntail_tid[j] = c.g.b.tid[i]; c.ntail_pos[j] = c.g.b.pos[i]; c.ntail_end[j] = p ? cap_calend(c.g, i) : c.g.b.pos[i]; c.ntail_pass[j] = p ? 1 : 0;
+		const RecLine rl = rec_load(c.g.b.rec, i);
+		const bool p = cap_pass(c.g, rl);
+		c.ntail_tid[j] = rl.tid(); c.ntail_pos[j] = rl.pos(); c.ntail_end[j] = p ? cap_calend(c.g, rl) : rl.pos(); c.ntail_pass[j] = p ? 1 : 0;
 	}
 }
 

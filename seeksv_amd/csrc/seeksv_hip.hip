@@ -41,6 +41,13 @@ struct HBuf { // grow-only pinned host buffer
 	size_t cap = 0;
 };
 
+// Device memory that is handed out in pieces and never moves (clip events hold addresses into it): a list of chunks with a cursor,
+// rewound at the start of every getclip pass.
+struct Arena {
+	std::vector<DBuf> chunks;
+	size_t cur = 0, used = 0;
+};
+
 struct ProfRec {
 	int id;
 	hipEvent_t a, b;
@@ -54,8 +61,8 @@ struct ssv_ctx {
 	hipStream_t st = nullptr;
 	std::string err;
 
-	// staging of host batches
-	DBuf sb[14];
+	// staging of host batches, and the record lines built for batches that come without them
+	DBuf sb[14], sb_rec;
 
 	// scratch shared by the passes
 	DBuf tile_cnt, tile_off, tile_base, scan_scratch, scan_scratch64, counters;
@@ -66,15 +73,15 @@ struct ssv_ctx {
 	ssv_clip_params clip_p{};
 	DBuf d_last_tid, stage, cand, cand_cnt, cand_off, stash;
 	int64_t stage_cap = 0;
-	DBuf ev_key, ev_begin, ev_ll, ev_lr, ev_lq, ev_ncig, ev_seq_bytes, ev_seq_off, ev_cig_off, ev_src_seq, ev_src_cig, ev_qmiss;
-	int64_t ev_cap = 0, n_events = 0;
-	DBuf seq_blob, cig_blob;
-	uint64_t seq_used = 0, cig_used = 0;
-	uint64_t max_key = 0;
+	DBuf ev, key_l, val_l, key_r[2], val_r[2];  // the pass's events (BAM order) and the sort keys / event indices of the two sides
+	int64_t ev_cap = 0, n_events = 0, n_l = 0, n_r = 0, n_long = 0;
+	DBuf g_seq_bytes, g_cig_ops, g_seq_off, g_cig_off; // the copying path (batches without SSV_MEM_PERSISTENT)
+	Arena blob;
+	uint64_t max_key = 0, sum_ncig = 0;
 	int max_ll = 0, max_lr = 0;
 	// clustering temporaries / outputs
-	DBuf keys2[2], vals2[2], ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_strings, c_flag, c_idx;
-	DBuf o_slot, o_strbytes, o_ncig64, o_srcoff, o_srcbegin, o_srclq, o_srccig, o_slowlist, totals;
+	DBuf keys2[2], vals2[2], cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_strings, slot_cnt, slot_bytes;
+	DBuf o_slot, o_srcptr, o_srcbegin, o_srclq, o_cigev, o_slowlist, totals;
 	HBuf h_totals;
 	// the dense cluster table: device columns + pinned host copy, double buffered so that the PCIe copy of one table can overlap
 	// with whatever the caller runs next (ssv_clip_cluster_async / ssv_clip_table_wait)
@@ -89,7 +96,7 @@ struct ssv_ctx {
 	} tab[2];
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
 	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices
-	DBuf qual_lut, qual_present; HBuf h_qual_lut, h_qual_present; // qual_present: 256 byte flags, set by k_clip_gather
+	DBuf qual_lut, qual_seen; HBuf h_qual_lut;
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
 
@@ -112,7 +119,7 @@ struct ssv_ctx {
 	DBuf gs_djunc, gs_counts, gs_wtid, gs_wbeg, gs_wend, gs_woff, gs_diff, gs_tilemap, gs_tile_win, gs_tile_junc, gs_ctgoff, gs_maxdepth, gs_span;
 	DBuf q_tid, q_beg, q_end, q_out64, q_out32;
 	// read cap of the reference's pileup (k_cap_*): flags, per-tile marks, carried sweep state + ring, the stream's last records (ping-pong)
-	DBuf cap_flags, cap_deep, cap_carry, cap_ring, cap_tail[2][4];
+	DBuf cap_flags, cap_deep, cap_carry, cap_ring, cap_ring_tmp, cap_tail[2][4];
 	int32_t cap_tail_n = 0, cap_tail_cur = 0, cap_ring_mask = 0;
 	HBuf h_q;
 
@@ -178,6 +185,24 @@ int ensure_host(ssv_ctx *c, HBuf &b, size_t bytes)
 	return SSV_OK;
 }
 
+// `bytes` of device memory that stay where they are until the arena is rewound
+int arena_alloc(ssv_ctx *c, Arena &a, size_t bytes, void **out)
+{
+	bytes = (bytes + 255) & ~(size_t)255;
+	while (a.cur < a.chunks.size() && a.chunks[a.cur].cap - a.used < bytes) { ++a.cur; a.used = 0; }
+	if (a.cur == a.chunks.size()) {
+		DBuf b;
+		const size_t cap = std::max<size_t>(bytes, (size_t)64 << 20);
+		HIPCHECK(c, hipMalloc(&b.p, cap));
+		b.cap = cap;
+		a.chunks.push_back(b);
+		a.used = 0;
+	}
+	*out = reinterpret_cast<uint8_t *>(a.chunks[a.cur].p) + a.used;
+	a.used += bytes;
+	return SSV_OK;
+}
+
 template <typename T> T *P(DBuf &b) { return reinterpret_cast<T *>(b.p); }
 template <typename T> T *P(HBuf &b) { return reinterpret_cast<T *>(b.p); }
 
@@ -232,35 +257,58 @@ inline unsigned scan_blocks(int64_t ntiles, const char *env, int64_t dflt)
 inline unsigned grid_for(int64_t n, int per_block) { return (unsigned)std::max<int64_t>(1, (n + per_block - 1) / per_block); }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool aligned64(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 63) == 0; }
 
-// Make the batch visible to the kernels: device batches are used in place, host batches are copied to HBM.
+// Make the batch visible to the kernels: device batches are used in place, host batches are copied to HBM; a batch that comes as
+// structure-of-arrays columns only is transposed into record lines (ssv_record) on the device.
 int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
 {
 	if (!b || b->n < 0 || b->n >= (1ll << 31)) { c->err = "bad batch"; return SSV_E_ARG; }
-	if (b->n > 0 && (!b->tid || !b->pos || !b->flag || !b->mapq || !b->n_cigar || !b->l_qseq || !b->mtid || !b->mpos || !b->isize || !b->cigar_off || !b->seq_off)) {
-		c->err = "batch with null arrays"; return SSV_E_ARG;
-	}
+	const bool has_soa = b->flag && b->mapq && b->l_qseq && b->mtid && b->mpos && b->isize && b->cigar_off && b->seq_off;
+	if (b->n > 0 && (!b->tid || !b->pos || !b->n_cigar || (!b->rec && !has_soa))) { c->err = "batch with null arrays"; return SSV_E_ARG; }
+	const int mem = b->mem & ~(int)SSV_MEM_PERSISTENT;
+	if (mem != SSV_MEM_DEVICE && b->mem != SSV_MEM_HOST) { c->err = "bad batch.mem"; return SSV_E_ARG; }
 	d.n = b->n; d.max_ref_span = b->max_ref_span;
-	if (b->mem == SSV_MEM_DEVICE) {
-		if (!aligned16(b->tid) || !aligned16(b->pos) || !aligned16(b->n_cigar) || !aligned16(b->cigar_off)) { c->err = "device batch arrays must be 16-byte aligned"; return SSV_E_ARG; }
-		d.tid = b->tid; d.pos = b->pos; d.flag = b->flag; d.mapq = b->mapq; d.n_cigar = b->n_cigar; d.l_qseq = b->l_qseq; d.mtid = b->mtid; d.mpos = b->mpos;
-		d.isize = b->isize; d.cigar_off = b->cigar_off; d.cigar = b->cigar; d.xc = b->xc; d.seq_off = b->seq_off; d.seqqual = b->seqqual;
-		return SSV_OK;
-	}
-	if (b->mem != SSV_MEM_HOST) { c->err = "bad batch.mem"; return SSV_E_ARG; }
-	ProfScope ps(c, P_H2D, b->n);
 	const size_t n = (size_t)b->n;
-	struct { const void *src; size_t bytes; } f[14] = {
-		{b->tid, n * 4}, {b->pos, n * 4}, {b->flag, n * 2}, {b->mapq, n}, {b->n_cigar, n * 2}, {b->l_qseq, n * 4}, {b->mtid, n * 4}, {b->mpos, n * 4},
-		{b->isize, n * 4}, {b->cigar_off, n * 4}, {b->cigar, (size_t)b->n_cigar_total * 4}, {b->xc, b->xc ? n : 0}, {b->seq_off, n * 8}, {b->seqqual, (size_t)b->seqqual_bytes}};
-	for (int k = 0; k < 14; ++k) {
-		CHECK(ensure(c, c->sb[k], f[k].bytes + 16));
-		if (f[k].bytes && f[k].src) HIPCHECK(c, hipMemcpyAsync(c->sb[k].p, f[k].src, f[k].bytes, hipMemcpyHostToDevice, c->st));
+	SoaCols s{};
+	if (mem == SSV_MEM_DEVICE) {
+		if (!aligned16(b->tid) || !aligned16(b->pos) || !aligned16(b->n_cigar) || (b->rec && !aligned64(b->rec))) {
+			c->err = "device batch arrays must be 16-byte aligned (rec: 64-byte aligned)"; return SSV_E_ARG;
+		}
+		d.tid = b->tid; d.pos = b->pos; d.n_cigar = b->n_cigar; d.cigar = b->cigar; d.seqqual = b->seqqual; d.rec = b->rec;
+		if (d.rec || n == 0) return SSV_OK;
+		s.tid = b->tid; s.pos = b->pos; s.flag = b->flag; s.mapq = b->mapq; s.n_cigar = b->n_cigar; s.l_qseq = b->l_qseq; s.mtid = b->mtid; s.mpos = b->mpos; s.isize = b->isize;
+		s.cigar_off = b->cigar_off; s.cigar = b->cigar; s.xc = b->xc; s.seq_off = b->seq_off;
+	} else {
+		ProfScope ps(c, P_H2D, b->n);
+		// with `rec` the host batch ships lines + hot columns + variable parts; without, the classic columns
+		struct { const void *src; size_t bytes; } f[14] = {
+			{b->tid, n * 4}, {b->pos, n * 4}, {b->rec ? nullptr : b->flag, n * 2}, {b->rec ? nullptr : b->mapq, n}, {b->n_cigar, n * 2}, {b->rec ? nullptr : b->l_qseq, n * 4},
+			{b->rec ? nullptr : b->mtid, n * 4}, {b->rec ? nullptr : b->mpos, n * 4}, {b->rec ? nullptr : b->isize, n * 4}, {b->rec ? nullptr : b->cigar_off, n * 4},
+			{b->cigar, (size_t)b->n_cigar_total * 4}, {b->rec ? nullptr : b->xc, b->xc ? n : 0}, {b->rec ? nullptr : b->seq_off, n * 8}, {b->seqqual, (size_t)b->seqqual_bytes}};
+		for (int k = 0; k < 14; ++k) {
+			if (!f[k].src) continue;
+			CHECK(ensure(c, c->sb[k], f[k].bytes + 16));
+			if (f[k].bytes) HIPCHECK(c, hipMemcpyAsync(c->sb[k].p, f[k].src, f[k].bytes, hipMemcpyHostToDevice, c->st));
+		}
+		CHECK(ensure(c, c->sb[10], 16)); CHECK(ensure(c, c->sb[13], 16));
+		d.tid = P<int32_t>(c->sb[0]); d.pos = P<int32_t>(c->sb[1]); d.n_cigar = P<uint16_t>(c->sb[4]); d.cigar = P<uint32_t>(c->sb[10]); d.seqqual = P<uint8_t>(c->sb[13]);
+		d.rec = nullptr;
+		if (b->rec) {
+			CHECK(ensure(c, c->sb_rec, n * sizeof(ssv_record) + 64));
+			if (n) HIPCHECK(c, hipMemcpyAsync(c->sb_rec.p, b->rec, n * sizeof(ssv_record), hipMemcpyHostToDevice, c->st));
+			d.rec = P<ssv_record>(c->sb_rec);
+			return SSV_OK;
+		}
+		if (n == 0) return SSV_OK;
+		s.tid = d.tid; s.pos = d.pos; s.flag = P<uint16_t>(c->sb[2]); s.mapq = P<uint8_t>(c->sb[3]); s.n_cigar = d.n_cigar; s.l_qseq = P<int32_t>(c->sb[5]); s.mtid = P<int32_t>(c->sb[6]);
+		s.mpos = P<int32_t>(c->sb[7]); s.isize = P<int32_t>(c->sb[8]); s.cigar_off = P<uint32_t>(c->sb[9]); s.cigar = d.cigar; s.xc = b->xc ? P<uint8_t>(c->sb[11]) : nullptr;
+		s.seq_off = P<uint64_t>(c->sb[12]);
 	}
-	d.tid = P<int32_t>(c->sb[0]); d.pos = P<int32_t>(c->sb[1]); d.flag = P<uint16_t>(c->sb[2]); d.mapq = P<uint8_t>(c->sb[3]); d.n_cigar = P<uint16_t>(c->sb[4]);
-	d.l_qseq = P<int32_t>(c->sb[5]); d.mtid = P<int32_t>(c->sb[6]); d.mpos = P<int32_t>(c->sb[7]); d.isize = P<int32_t>(c->sb[8]);
-	d.cigar_off = P<uint32_t>(c->sb[9]); d.cigar = P<uint32_t>(c->sb[10]); d.xc = b->xc ? P<uint8_t>(c->sb[11]) : nullptr;
-	d.seq_off = P<uint64_t>(c->sb[12]); d.seqqual = P<uint8_t>(c->sb[13]);
+	CHECK(ensure(c, c->sb_rec, n * sizeof(ssv_record) + 64));
+	k_build_rec<<<grid_for(b->n, BLOCK), BLOCK, 0, c->st>>>(s, b->n, P<ssv_record>(c->sb_rec));
+	HIPCHECK(c, hipGetLastError());
+	d.rec = P<ssv_record>(c->sb_rec);
 	return SSV_OK;
 }
 
@@ -269,30 +317,13 @@ int ensure_events(ssv_ctx *c, int64_t need)
 	if (need <= c->ev_cap) return SSV_OK;
 	int64_t ncap = std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2);
 	ncap = std::max<int64_t>(ncap, 1 << 16);
-	const size_t used = (size_t)c->n_events;
-	CHECK(ensure(c, c->ev_key, ncap * 8, true, used * 8));
-	CHECK(ensure(c, c->ev_begin, ncap * 4, true, used * 4));
-	CHECK(ensure(c, c->ev_ll, ncap * 4, true, used * 4));
-	CHECK(ensure(c, c->ev_lr, ncap * 4, true, used * 4));
-	CHECK(ensure(c, c->ev_lq, ncap * 4, true, used * 4));
-	CHECK(ensure(c, c->ev_ncig, ncap * 4, true, used * 4));
-	CHECK(ensure(c, c->ev_seq_bytes, ncap * 4, true, used * 4));
-	CHECK(ensure(c, c->ev_seq_off, ncap * 8, true, used * 8));
-	CHECK(ensure(c, c->ev_cig_off, ncap * 8, true, used * 8));
-	CHECK(ensure(c, c->ev_qmiss, ncap, true, used));
-	CHECK(ensure(c, c->ev_src_seq, ncap * 8));
-	CHECK(ensure(c, c->ev_src_cig, ncap * 4));
+	CHECK(ensure(c, c->ev, (size_t)ncap * sizeof(ClipEvent), true, (size_t)c->n_events * sizeof(ClipEvent)));
+	CHECK(ensure(c, c->key_l, (size_t)ncap * 8, true, (size_t)c->n_l * 8));
+	CHECK(ensure(c, c->val_l, (size_t)ncap * 4, true, (size_t)c->n_l * 4));
+	CHECK(ensure(c, c->key_r[0], (size_t)ncap * 8, true, (size_t)c->n_r * 8));
+	CHECK(ensure(c, c->val_r[0], (size_t)ncap * 4, true, (size_t)c->n_r * 4));
 	c->ev_cap = ncap;
 	return SSV_OK;
-}
-
-EventArrays event_arrays(ssv_ctx *c)
-{
-	EventArrays e;
-	e.key = P<uint64_t>(c->ev_key); e.begin = P<int32_t>(c->ev_begin); e.ll = P<int32_t>(c->ev_ll); e.lr = P<int32_t>(c->ev_lr); e.lq = P<int32_t>(c->ev_lq);
-	e.ncig = P<uint32_t>(c->ev_ncig); e.seq_bytes = P<uint32_t>(c->ev_seq_bytes); e.seq_off = P<uint64_t>(c->ev_seq_off); e.cig_off = P<uint64_t>(c->ev_cig_off);
-	e.src_seq = P<uint64_t>(c->ev_src_seq); e.src_cig = P<uint32_t>(c->ev_src_cig); e.qmiss = P<uint8_t>(c->ev_qmiss);
-	return e;
 }
 
 __global__ void k_max_span(DevBatch b, int *out)
@@ -300,10 +331,10 @@ __global__ void k_max_span(DevBatch b, int *out)
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int span = 0;
 	if (i < b.n) {
-		int n = b.n_cigar[i];
-		const uint32_t *cig = b.cigar + b.cigar_off[i];
+		const RecLine r = rec_load(b.rec, i);
+		const int n = r.n_cigar();
 		long long s = 0;
-		for (int k = 0; k < n; ++k) { uint32_t x = cig[k]; int op = (int)(x & 15u); if (op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) s += x >> 4; }
+		for (int k = 0; k < n; ++k) { uint32_t x = r.op(b.cigar, k); int op = (int)(x & 15u); if (op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) s += x >> 4; }
 		span = s > 0x7fffffff ? 0x7fffffff : (int)s;
 	}
 	span = wave_max(span);
@@ -352,17 +383,18 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	bamdec_free(c);
 	realign_free(c);
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
-	if (c->qual_lut.p) (void)hipFree(c->qual_lut.p);
 	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
-	if (c->qual_present.p) (void)hipFree(c->qual_present.p);
-	if (c->h_qual_present.p) (void)hipHostFree(c->h_qual_present.p);
 	// every DBuf / HBuf member
-	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash, &c->ev_key, &c->ev_qmiss, &c->ev_begin, &c->ev_ll,
-	                 &c->ev_lr, &c->ev_lq, &c->ev_ncig, &c->ev_seq_bytes, &c->ev_seq_off, &c->ev_cig_off, &c->ev_src_seq, &c->ev_src_cig, &c->seq_blob, &c->cig_blob, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings, &c->c_flag, &c->c_idx, &c->o_slot, &c->o_strbytes, &c->o_ncig64, &c->o_srcoff, &c->o_srcbegin, &c->o_srclq, &c->o_srccig, &c->o_slowlist, &c->totals, &c->isz_vals, &c->isz_acc, &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry, &c->cap_ring, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
+	DBuf *dbufs[] = {&c->sb_rec, &c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash,
+	                 &c->ev, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings,
+	                 &c->slot_cnt, &c->slot_bytes, &c->o_slot, &c->o_srcptr, &c->o_srcbegin, &c->o_srclq, &c->o_cigev, &c->o_slowlist, &c->totals, &c->qual_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc,
+	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry,
+	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
+	for (DBuf &b : c->blob.chunks) if (b.p) (void)hipFree(b.p);
 	HBuf *hbufs[] = {&c->h_counters, &c->h_totals, &c->h_q};
 	for (HBuf *b : hbufs) if (b->p) (void)hipHostFree(b->p);
 	for (auto &t : c->tab) {
@@ -400,13 +432,12 @@ int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 	HIPCHECK(c, hipSetDevice(c->device));
 	c->clip_p = *p;
 	c->clip_active = true;
-	c->n_events = 0; c->seq_used = 0; c->cig_used = 0; c->max_key = 0; c->max_ll = 0; c->max_lr = 0;
+	c->n_events = 0; c->n_l = 0; c->n_r = 0; c->n_long = 0; c->max_key = 0; c->sum_ncig = 0; c->max_ll = 0; c->max_lr = 0;
+	c->blob.cur = 0; c->blob.used = 0;
 	CHECK(ensure(c, c->d_last_tid, 16));
 	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
 	CHECK(ensure_host(c, c->h_counters, sizeof(ClipCounters)));
 	HIPCHECK(c, hipMemsetAsync(c->d_last_tid.p, 0, 16, c->st));
-	CHECK(ensure(c, c->qual_present, 256)); CHECK(ensure_host(c, c->h_qual_present, 256));
-	HIPCHECK(c, hipMemsetAsync(c->qual_present.p, 0, 256, c->st));
 	int *h_lt = P<int>(c->h_counters);
 	*h_lt = p->initial_last_tid; // 0 in the reference, clip_reads.h:407
 	HIPCHECK(c, hipMemcpyAsync(c->d_last_tid.p, h_lt, 4, hipMemcpyHostToDevice, c->st));
@@ -422,7 +453,8 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 	if (b->n == 0) return SSV_OK;
 	DevBatch d;
 	CHECK(stage_batch(c, b, d));
-	if (!d.cigar || !d.seq_off) { c->err = "batch without cigar / seq_off"; return SSV_E_ARG; }
+	if (!d.cigar) { c->err = "batch without cigar"; return SSV_E_ARG; }
+	const bool persistent = b->mem == (SSV_MEM_DEVICE | SSV_MEM_PERSISTENT);
 	const int64_t ntiles = (d.n + CC_TILE - 1) / CC_TILE;
 	const unsigned grid = scan_blocks(ntiles, "SSV_CLIP_SCAN_BLOCKS", 256 * 6);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
@@ -458,9 +490,9 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 		int64_t nb = 0;
 		{
 			ProfScope ps(c, P_CLIP_PLACE, ncand);
-			CHECK(ensure(c, c->cand, ncand * 4)); CHECK(ensure(c, c->cand_cnt, ncand * 4)); CHECK(ensure(c, c->cand_off, ncand * 4));
-			CHECK(ensure(c, c->stash, (size_t)(ncand + WAVE) * 2 * sizeof(StagedEvent)));
-			CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(ncand) * 4));
+			CHECK(ensure(c, c->cand, ncand * 4)); CHECK(ensure(c, c->cand_cnt, ncand * 8)); CHECK(ensure(c, c->cand_off, ncand * 8));
+			CHECK(ensure(c, c->stash, (size_t)(ncand + WAVE) * 2 * sizeof(ClipEvent)));
+			CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(ncand) * 8));
 			CHECK(ensure_events(c, c->n_events + 2 * ncand));
 			k_cand_place<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<uint32_t>(c->stage), P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_off), P<uint32_t>(c->tile_base), ntiles,
 			                                                                    P<uint32_t>(c->cand));
@@ -469,36 +501,40 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			f.use_ownership = c->clip_p.use_ownership;
 			f.own_lo = ((long long)c->clip_p.own_lo_tid << 32) | (long long)(uint32_t)c->clip_p.own_lo_pos;
 			f.own_hi = ((long long)c->clip_p.own_hi_tid << 32) | (long long)(uint32_t)c->clip_p.own_hi_pos;
-			k_clip_filter<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(f, P<uint32_t>(c->cand), ncand, P<StagedEvent>(c->stash), P<uint32_t>(c->cand_cnt));
-			exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->cand_cnt), P<uint32_t>(c->cand_off), ncand, 0u, P<uint32_t>(c->scan_scratch), reinterpret_cast<uint32_t *>(&dc->n_new));
-			EventArrays ev = event_arrays(c);
-			k_clip_place<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(P<StagedEvent>(c->stash), P<uint32_t>(c->cand_cnt), P<uint32_t>(c->cand_off), ncand, ev, c->n_events);
+			k_clip_filter<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(f, P<uint32_t>(c->cand), ncand, P<ClipEvent>(c->stash), P<uint64_t>(c->cand_cnt));
+			exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->cand_cnt), P<uint64_t>(c->cand_off), ncand, 0ull, P<uint64_t>(c->scan_scratch64), reinterpret_cast<uint64_t *>(&dc->n_new));
+			EventLists L;
+			L.ev = P<ClipEvent>(c->ev); L.key_l = P<uint64_t>(c->key_l); L.val_l = P<uint32_t>(c->val_l); L.key_r = P<uint64_t>(c->key_r[0]); L.val_r = P<uint32_t>(c->val_r[0]);
+			k_clip_place<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(P<ClipEvent>(c->stash), P<uint64_t>(c->cand_cnt), P<uint64_t>(c->cand_off), ncand, L, c->n_events, c->n_l, c->n_r);
+			k_event_max<<<256, BLOCK, 0, c->st>>>(P<ClipEvent>(c->ev), c->n_events, dc);
 			HIPCHECK(c, hipGetLastError());
 			HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
 			HIPCHECK(c, hipStreamSynchronize(c->st));
 			nb = (int64_t)(uint32_t)hc->n_new;
 			if (c->n_events + nb >= (1ll << 32) - 1) { c->err = "more than 2^32 clip events in one pass (the sorted permutation is 32 bits wide)"; return SSV_E_RANGE; }
-			if (nb > 0) {
-				CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nb) * 8));
-				exclusive_scan<uint32_t, uint64_t>(c->st, ev.seq_bytes + c->n_events, ev.seq_off + c->n_events, nb, c->seq_used, P<uint64_t>(c->scan_scratch64),
-				                                   reinterpret_cast<uint64_t *>(&dc->seq_total));
-				exclusive_scan<uint32_t, uint64_t>(c->st, ev.ncig + c->n_events, ev.cig_off + c->n_events, nb, c->cig_used, P<uint64_t>(c->scan_scratch64),
-				                                   reinterpret_cast<uint64_t *>(&dc->cig_total));
-				k_event_max<<<(unsigned)std::min<int64_t>(256, (nb + BLOCK - 1) / BLOCK), BLOCK, 0, c->st>>>(ev, c->n_events, nb, dc);
-				HIPCHECK(c, hipGetLastError());
-				HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
-				HIPCHECK(c, hipStreamSynchronize(c->st));
-			}
+		}
+		if (nb > 0 && !persistent) {
+			// the batch's buffers may be recycled after this call: the bytes its events point at move into context memory
+			ProfScope ps(c, P_CLIP_GATHER, nb);
+			CHECK(ensure(c, c->g_seq_bytes, nb * 4)); CHECK(ensure(c, c->g_cig_ops, nb * 4)); CHECK(ensure(c, c->g_seq_off, nb * 8)); CHECK(ensure(c, c->g_cig_off, nb * 8));
+			CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nb) * 8));
+			k_gather_sizes<<<grid_for(nb, BLOCK), BLOCK, 0, c->st>>>(P<ClipEvent>(c->ev), c->n_events, nb, P<uint32_t>(c->g_seq_bytes), P<uint32_t>(c->g_cig_ops));
+			exclusive_scan<uint32_t, uint64_t>(c->st, P<uint32_t>(c->g_seq_bytes), P<uint64_t>(c->g_seq_off), nb, 0ull, P<uint64_t>(c->scan_scratch64), reinterpret_cast<uint64_t *>(&dc->seq_total));
+			exclusive_scan<uint32_t, uint64_t>(c->st, P<uint32_t>(c->g_cig_ops), P<uint64_t>(c->g_cig_off), nb, 0ull, P<uint64_t>(c->scan_scratch64), reinterpret_cast<uint64_t *>(&dc->cig_total));
+			HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
+			HIPCHECK(c, hipStreamSynchronize(c->st));
+			void *seq_dst = nullptr, *cig_dst = nullptr;
+			CHECK(arena_alloc(c, c->blob, (size_t)hc->seq_total + 16, &seq_dst));
+			CHECK(arena_alloc(c, c->blob, (size_t)hc->cig_total * 4 + 16, &cig_dst));
+			k_clip_gather<<<grid_for(nb, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(P<ClipEvent>(c->ev), c->n_events, nb, P<uint64_t>(c->g_seq_off), P<uint64_t>(c->g_cig_off),
+			                                                                          reinterpret_cast<uint8_t *>(seq_dst), reinterpret_cast<uint32_t *>(cig_dst));
+			HIPCHECK(c, hipGetLastError());
 		}
 		if (nb > 0) {
-			ProfScope ps(c, P_CLIP_GATHER, nb);
-			CHECK(ensure(c, c->seq_blob, hc->seq_total + 16, true, c->seq_used));
-			CHECK(ensure(c, c->cig_blob, hc->cig_total * 4 + 16, true, c->cig_used * 4));
-			k_clip_gather<<<grid_for(nb, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(d, event_arrays(c), c->n_events, nb, P<uint8_t>(c->seq_blob), P<uint32_t>(c->cig_blob),
-			                                                                          P<uint8_t>(c->qual_present));
-			HIPCHECK(c, hipGetLastError());
-			c->n_events += nb; c->seq_used = hc->seq_total; c->cig_used = hc->cig_total;
+			const int64_t nbr = (int64_t)(hc->n_new >> 32);
+			c->n_events += nb; c->n_r += nbr; c->n_l += nb - nbr; c->n_long += (int64_t)hc->n_long;
 			c->max_key = std::max<uint64_t>(c->max_key, hc->max_key); c->max_ll = std::max(c->max_ll, hc->max_ll); c->max_lr = std::max(c->max_lr, hc->max_lr);
+			c->sum_ncig += hc->sum_ncig;
 		}
 	}
 	k_last_tid<<<1, BLOCK, 0, c->st>>>(d, P<int>(c->d_last_tid));
@@ -524,48 +560,87 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	ssv_ctx::TableSet &T = c->tab[s_];
 	if (T.in_flight) { HIPCHECK(c, hipEventSynchronize(T.copied)); T.in_flight = false; }
 	c->tab_cur = s_;
-	const int64_t E = c->n_events;
+	const int64_t E = c->n_events, EL = c->n_l, ER = c->n_r;
 	T.n_events = E; T.n_clusters = 0;
+	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
 	if (n_events) *n_events = E;
 	if (n_clusters) *n_clusters = 0;
 	if (E == 0) { HIPCHECK(c, hipStreamSynchronize(c->st)); return SSV_OK; }
-	EventArrays ev = event_arrays(c);
-	// ---- bin the events: stable sort by (contig, side, position) ----
+	ClipCounters *hc = P<ClipCounters>(c->h_counters);
+	ClipCounters *dc = P<ClipCounters>(c->counters);
+	const ClipEvent *ev = P<ClipEvent>(c->ev);
+	CHECK(ensure(c, c->totals, 128)); CHECK(ensure_host(c, c->h_totals, 128));
+	CHECK(ensure(c, c->qual_seen, 32)); CHECK(ensure(c, c->qual_lut, 256)); CHECK(ensure_host(c, c->h_qual_lut, 256));
+	// ---- bin the events by (contig, side, position), BAM order inside a bin.  A coordinate-sorted BAM emits its '5' events in key order
+	//      already (key = start + 1): that is checked, not assumed; only the '3' events (key = start + reference span) need the sort, and
+	//      the two sorted lists interleave per contig.  Unsorted input takes the full sort. ----
 	int cur = 0;
 	{
 		ProfScope ps(c, P_SORT, E);
-		for (int k = 0; k < 2; ++k) { CHECK(ensure(c, c->keys2[k], E * 8)); CHECK(ensure(c, c->vals2[k], E * 4)); }
-		const int64_t nt = rs_tiles(E);
-		CHECK(ensure(c, c->ghist, 256 * nt * 4));
-		CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(256 * nt) * 4));
-		HIPCHECK(c, hipMemcpyAsync(c->keys2[0].p, ev.key, E * 8, hipMemcpyDeviceToDevice, c->st));
-		k_iota<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(P<uint32_t>(c->vals2[0]), E);
+		HIPCHECK(c, hipMemsetAsync(&dc->l_unsorted, 0, 4, c->st));
+		if (EL > 1) k_check_sorted<<<grid_for(EL, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, &dc->l_unsorted);
+		uint32_t *h_seen = reinterpret_cast<uint32_t *>(P<uint8_t>(c->h_totals) + 64);
+		if (c->table_mode == 2) {
+			// first guess of the table's quality alphabet: the qualities of the first events
+			HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
+			const int64_t ns = std::min<int64_t>(E, 16384);
+			k_qual_sample<<<grid_for(ns, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ev, ns, P<uint32_t>(c->qual_seen));
+			HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
+		}
+		HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
 		int key_bits = 1;
 		while (key_bits < 64 && (c->max_key >> key_bits)) ++key_bits;
-		uint64_t *keys[2] = {P<uint64_t>(c->keys2[0]), P<uint64_t>(c->keys2[1])};
-		uint32_t *vals[2] = {P<uint32_t>(c->vals2[0]), P<uint32_t>(c->vals2[1])};
-		cur = radix_sort_pairs(c->st, keys, vals, E, key_bits, P<uint32_t>(c->ghist), P<uint32_t>(c->scan_scratch));
+		CHECK(ensure(c, c->keys2[0], E * 8)); CHECK(ensure(c, c->vals2[0], E * 4));
+		if (!hc->l_unsorted) {
+			int rcur = 0;
+			if (ER > 0) {
+				CHECK(ensure(c, c->key_r[1], ER * 8)); CHECK(ensure(c, c->val_r[1], ER * 4));
+				const int64_t nt = rs_tiles(ER);
+				CHECK(ensure(c, c->ghist, 256 * nt * 4));
+				CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(256 * nt) * 4));
+				uint64_t *keys[2] = {P<uint64_t>(c->key_r[0]), P<uint64_t>(c->key_r[1])};
+				uint32_t *vals[2] = {P<uint32_t>(c->val_r[0]), P<uint32_t>(c->val_r[1])};
+				rcur = radix_sort_pairs(c->st, keys, vals, ER, key_bits, P<uint32_t>(c->ghist), P<uint32_t>(c->scan_scratch));
+			}
+			const int64_t Tn = (int64_t)(c->max_key >> 33) + 1;
+			CHECK(ensure(c, c->cum_l, (size_t)(Tn + 2) * 4)); CHECK(ensure(c, c->cum_r, (size_t)(Tn + 2) * 4));
+			k_side_bounds<<<grid_for(Tn + 1, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, P<uint64_t>(c->key_r[rcur]), ER, Tn, P<uint32_t>(c->cum_l), P<uint32_t>(c->cum_r));
+			k_merge_sides<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), P<uint32_t>(c->val_l), EL, P<uint64_t>(c->key_r[rcur]), P<uint32_t>(c->val_r[rcur]), ER,
+			                                                       P<uint32_t>(c->cum_l), P<uint32_t>(c->cum_r), P<uint64_t>(c->keys2[0]), P<uint32_t>(c->vals2[0]));
+			cur = 0;
+		} else {
+			CHECK(ensure(c, c->keys2[1], E * 8)); CHECK(ensure(c, c->vals2[1], E * 4));
+			const int64_t nt = rs_tiles(E);
+			CHECK(ensure(c, c->ghist, 256 * nt * 4));
+			CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(256 * nt) * 4));
+			k_concat_sides<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), P<uint32_t>(c->val_l), EL, P<uint64_t>(c->key_r[0]), P<uint32_t>(c->val_r[0]), ER,
+			                                                        P<uint64_t>(c->keys2[0]), P<uint32_t>(c->vals2[0]));
+			uint64_t *keys[2] = {P<uint64_t>(c->keys2[0]), P<uint64_t>(c->keys2[1])};
+			uint32_t *vals[2] = {P<uint32_t>(c->vals2[0]), P<uint32_t>(c->vals2[1])};
+			cur = radix_sort_pairs(c->st, keys, vals, E, key_bits, P<uint32_t>(c->ghist), P<uint32_t>(c->scan_scratch));
+		}
 		HIPCHECK(c, hipGetLastError());
 	}
 	// ---- greedy consensus clustering, one wavefront per multi-event bin ----
 	ClusterArgs ca;
-	ca.skey = P<uint64_t>(c->keys2[cur]); ca.perm = P<uint32_t>(c->vals2[cur]); ca.E = E; ca.ev = ev; ca.seq_blob = P<uint8_t>(c->seq_blob);
+	ca.skey = P<uint64_t>(c->keys2[cur]); ca.perm = P<uint32_t>(c->vals2[cur]); ca.E = E; ca.ev = ev;
 	ca.match_rate = c->clip_p.match_rate;
 	ca.SL = std::max(1, c->max_ll); ca.SR = std::max(1, c->max_lr);
 	const size_t stride = 2 * ((size_t)ca.SL + (size_t)ca.SR);
+	int64_t M = 0;
 	{
 		ProfScope ps(c, P_CLUSTER_BINS, E);
 		CHECK(ensure(c, c->c_support, E * 4)); CHECK(ensure(c, c->c_ll, E * 4)); CHECK(ensure(c, c->c_lr, E * 4)); CHECK(ensure(c, c->c_cig_ev, E * 4));
 		CHECK(ensure(c, c->c_qmiss, E)); CHECK(ensure(c, c->c_mflag, E * 4)); CHECK(ensure(c, c->c_mslot, E * 4));
-		CHECK(ensure(c, c->totals, 64)); CHECK(ensure_host(c, c->h_totals, 64));
 		CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(E) * 4));
 		ca.support = P<int32_t>(c->c_support); ca.c_ll = P<int32_t>(c->c_ll); ca.c_lr = P<int32_t>(c->c_lr); ca.c_cig_ev = P<uint32_t>(c->c_cig_ev);
 		ca.c_qmiss = P<uint8_t>(c->c_qmiss); ca.mflag = P<uint32_t>(c->c_mflag); ca.mslot = P<uint32_t>(c->c_mslot);
-		k_bin_mark<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.skey, ca.perm, E, ev, ca.seq_blob, P<uint32_t>(c->c_mflag), ca.support, ca.c_ll, ca.c_lr, ca.c_cig_ev, ca.c_qmiss);
+		k_bin_mark<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.skey, E, P<uint32_t>(c->c_mflag), ca.support);
 		exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_mflag), P<uint32_t>(c->c_mslot), E, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
 		HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHECK(c, hipStreamSynchronize(c->st));
-		const int64_t M = *P<uint32_t>(c->h_totals); // events in multi-event bins: only they need consensus storage
+		M = *P<uint32_t>(c->h_totals); // events in multi-event bins: only they need consensus storage
 		CHECK(ensure(c, c->c_strings, (size_t)std::max<int64_t>(M, 1) * stride));
 		ca.strings = P<uint8_t>(c->c_strings);
 		ca.M = M; ca.mlist = nullptr;
@@ -578,83 +653,84 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		}
 		HIPCHECK(c, hipGetLastError());
 	}
-	// ---- compact the clusters into a dense table ----
-	ProfScope *pack_scope = new ProfScope(c, P_CLUSTER_PACK, E);
-	struct ScopeGuard { ProfScope *&p; ~ScopeGuard() { delete p; p = nullptr; } } pack_guard{pack_scope};
-	CHECK(ensure(c, c->c_flag, E * 4)); CHECK(ensure(c, c->c_idx, E * 4));
-	CHECK(ensure(c, c->totals, 64)); CHECK(ensure_host(c, c->h_totals, 64));
-	CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(E) * 4));
-	k_cluster_flags<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.support, E, P<uint32_t>(c->c_flag));
-	exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_flag), P<uint32_t>(c->c_idx), E, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
-	if (c->table_mode == 2) HIPCHECK(c, hipMemcpyAsync(c->h_qual_present.p, c->qual_present.p, 256, hipMemcpyDeviceToHost, c->st)); // which quality values occur (k_clip_gather)
-	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 64, hipMemcpyDeviceToHost, c->st));
-	HIPCHECK(c, hipStreamSynchronize(c->st));
-	const int64_t nc = *P<uint32_t>(c->h_totals);
-	T.n_clusters = nc;
-	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
-	if (c->table_mode == 2) {
-		// alphabet = the occurring values in increasing order; 1, 2, 3 or 4 bits per quality when it has at most 2, 4, 8 or 16 members
-		const uint8_t *present = P<uint8_t>(c->h_qual_present);
-		int n_vals = 0;
-		uint8_t vals[256];
-		for (int v = 0; v < 256; ++v) if (present[v]) vals[n_vals++] = (uint8_t)v;
-		if (n_vals <= 16) {
-			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : n_vals <= 8 ? 3 : 4;
-			CHECK(ensure(c, c->qual_lut, 256)); CHECK(ensure_host(c, c->h_qual_lut, 256));
+	// ---- the dense table, cut straight out of the reads' bytes.  Nothing below needs a size on the host before the kernels have run:
+	//      the buffers are sized by upper bounds (E clusters, E x the largest block, the events' CIGAR operations), the kernels read the
+	//      cluster count from device memory, and the one synchronisation comes after the pack kernels. ----
+	int64_t nc = 0;
+	uint64_t str_total = 0, cig_total = 0;
+	{
+		ProfScope ps(c, P_CLUSTER_PACK, E);
+		uint32_t *h_seen = reinterpret_cast<uint32_t *>(P<uint8_t>(c->h_totals) + 64);
+		auto set_alphabet = [&](const uint32_t seen[8]) { // -> T.qual_bits / T.qual_alphabet / the phred -> index table (0xff: not in the alphabet)
 			uint8_t *lut = P<uint8_t>(c->h_qual_lut);
-			memset(lut, 0, 256);
-			for (int k = 0; k < n_vals; ++k) { T.qual_alphabet[k] = (uint8_t)(vals[k] + 33); lut[(uint8_t)(vals[k] + 33)] = (uint8_t)k; } // the kernels see characters (phred + 33)
-			HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, lut, 256, hipMemcpyHostToDevice, c->st));
+			memset(lut, 0xff, 256); memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
+			int n_vals = 0;
+			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) ++n_vals;
+			if (n_vals > 16) { T.qual_bits = 8; return; }
+			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : n_vals <= 8 ? 3 : 4;
+			int k = 0;
+			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) { T.qual_alphabet[k] = (uint8_t)(v + 33); lut[v] = (uint8_t)k; ++k; } // increasing order; the table shows characters (phred + 33)
+		};
+		uint32_t guess[8] = {0};
+		if (c->table_mode == 2) { memcpy(guess, h_seen, 32); set_alphabet(guess); }
+		CHECK(ensure(c, c->slot_cnt, E * 8)); CHECK(ensure(c, c->slot_bytes, E * 8));
+		CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(E) * 8));
+		DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &T.o_ncig, &c->o_slot, &c->o_srcbegin, &c->o_srclq, &c->o_cigev, &c->o_slowlist};
+		for (DBuf *b : d4) CHECK(ensure(c, *b, E * 4 + 16));
+		CHECK(ensure(c, T.o_side, E + 16)); CHECK(ensure(c, T.o_qmiss, E + 16));
+		DBuf *d8[] = {&T.o_stroff, &T.o_cigoff, &c->o_srcptr};
+		for (DBuf *b : d8) CHECK(ensure(c, *b, E * 8 + 16));
+		CHECK(ensure(c, T.o_cig, (size_t)c->sum_ncig * 4 + 16));
+		uint64_t *tot = P<uint64_t>(c->totals); // [0] clusters | CIGAR operations << 32, [1] string bytes, [2] slow-list length
+		for (int attempt = 0;; ++attempt) {
+			const size_t str_cap = (size_t)E * (size_t)table_block_bytes((uint64_t)ca.SL, (uint64_t)ca.SR, T.packed, (uint64_t)T.qual_bits);
+			CHECK(ensure(c, T.o_str, str_cap + 16));
+			PackArgs pa;
+			pa.c = ca; pa.slot_cnt = P<uint64_t>(c->slot_cnt); pa.slot_bytes = P<uint64_t>(c->slot_bytes);
+			pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
+			pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.ncig = P<int32_t>(T.o_ncig); pa.str_off = P<uint64_t>(T.o_stroff); pa.cig_off = P<uint64_t>(T.o_cigoff);
+			pa.slot = P<uint32_t>(c->o_slot); pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
+			pa.src_ptr = P<uint64_t>(c->o_srcptr); pa.src_begin = P<int32_t>(c->o_srcbegin); pa.src_lq = P<int32_t>(c->o_srclq); pa.cig_ev = P<uint32_t>(c->o_cigev);
+			pa.slow_list = P<uint32_t>(c->o_slowlist); pa.slow_count = reinterpret_cast<unsigned int *>(tot + 2);
+			HIPCHECK(c, hipMemsetAsync(tot, 0, 32, c->st));
+			HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
+			if (T.packed && T.qual_bits < 8) HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, c->h_qual_lut.p, 256, hipMemcpyHostToDevice, c->st));
+			k_cluster_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
+			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_cnt, pa.slot_cnt, E, 0ull, P<uint64_t>(c->scan_scratch64), tot);
+			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_bytes, pa.slot_bytes, E, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
+			k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
+			const uint32_t *nc_dev = reinterpret_cast<const uint32_t *>(tot);
+			const dim3 g(grid_for(E, GROUPS_PER_BLOCK));                    // upper bound: the kernels read the cluster count themselves
+			const dim3 gs(grid_for(std::max<int64_t>(M + c->n_long, 1), GROUPS_PER_BLOCK)); // multi-event bins + reads too long for the dword path
+			uint8_t *os = P<uint8_t>(T.o_str);
+			uint32_t *oc = P<uint32_t>(T.o_cig);
+			if (!pa.packed) k_cluster_pack_ascii<<<g, BLOCK, 0, c->st>>>(pa, nc_dev, os, oc);
+			else {
+				// the dword path for (nearly) all clusters, then the bytewise path for the listed ones
+#define SSV_PACK(W_) do { k_cluster_pack_codes<W_, false><<<g, BLOCK, 0, c->st>>>(pa, nc_dev, os, oc); \
+			k_cluster_pack_codes<W_, true><<<gs, BLOCK, 0, c->st>>>(pa, pa.slow_count, os, oc); } while (0)
+				if (pa.qual_bits == 8) SSV_PACK(8); else if (pa.qual_bits == 4) SSV_PACK(4); else if (pa.qual_bits == 3) SSV_PACK(3); else if (pa.qual_bits == 2) SSV_PACK(2); else SSV_PACK(1);
+#undef SSV_PACK
+			}
+			HIPCHECK(c, hipGetLastError());
+			HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 32, hipMemcpyDeviceToHost, c->st));
+			HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
+			HIPCHECK(c, hipStreamSynchronize(c->st));
+			if (c->table_mode == 2 && T.qual_bits < 8 && memcmp(h_seen, guess, 32) != 0 && attempt == 0) {
+				// the table's strings hold other quality values than the first events did: pack again with the alphabet they really need
+				memcpy(guess, h_seen, 32);
+				set_alphabet(guess);
+				continue;
+			}
+			break;
 		}
+		nc = (int64_t)(uint32_t)P<uint64_t>(c->h_totals)[0];
+		cig_total = P<uint64_t>(c->h_totals)[0] >> 32;
+		str_total = P<uint64_t>(c->h_totals)[1];
 	}
+	T.n_clusters = nc;
 	if (n_clusters) *n_clusters = nc;
 	if (nc == 0) return SSV_OK;
-	DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &c->o_slot, &T.o_ncig};
-	for (DBuf *b : d4) CHECK(ensure(c, *b, nc * 4));
-	CHECK(ensure(c, T.o_side, nc)); CHECK(ensure(c, T.o_qmiss, nc));
-	DBuf *d8[] = {&c->o_strbytes, &c->o_ncig64, &T.o_stroff, &T.o_cigoff};
-	for (DBuf *b : d8) CHECK(ensure(c, *b, nc * 8));
-	PackArgs pa;
-	pa.c = ca; pa.flag = P<uint32_t>(c->c_flag); pa.cidx = P<uint32_t>(c->c_idx);
-	pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
-	pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.slot = P<uint32_t>(c->o_slot); pa.str_bytes = P<uint64_t>(c->o_strbytes);
-	pa.ncig64 = P<uint64_t>(c->o_ncig64); pa.ncig = P<int32_t>(T.o_ncig); pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut);
-	pa.src_off = nullptr; pa.src_begin = nullptr; pa.src_lq = nullptr; pa.src_cig = nullptr; pa.slow_list = nullptr; pa.slow_count = nullptr;
-	if (pa.packed) {
-		CHECK(ensure(c, c->o_srcoff, nc * 8)); CHECK(ensure(c, c->o_srcbegin, nc * 4)); CHECK(ensure(c, c->o_srclq, nc * 4)); CHECK(ensure(c, c->o_srccig, nc * 8));
-		pa.src_off = P<uint64_t>(c->o_srcoff); pa.src_begin = P<int32_t>(c->o_srcbegin); pa.src_lq = P<int32_t>(c->o_srclq); pa.src_cig = P<uint64_t>(c->o_srccig);
-		CHECK(ensure(c, c->o_slowlist, nc * 4));
-		pa.slow_list = P<uint32_t>(c->o_slowlist); pa.slow_count = reinterpret_cast<unsigned int *>(P<uint64_t>(c->totals) + 3); // read back with the blob totals below
-		HIPCHECK(c, hipMemsetAsync(pa.slow_count, 0, 8, c->st));
-		if (!pa.qlut) { CHECK(ensure(c, c->qual_lut, 256)); pa.qlut = P<uint8_t>(c->qual_lut); } // not read when qual_bits == 8
-	}
-	k_cluster_pack_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
-	CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nc) * 8));
-	uint64_t *tot = P<uint64_t>(c->totals);
-	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_strbytes), P<uint64_t>(T.o_stroff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
-	exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->o_ncig64), P<uint64_t>(T.o_cigoff), nc, 0ull, P<uint64_t>(c->scan_scratch64), tot + 2);
-	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 32, hipMemcpyDeviceToHost, c->st));
-	HIPCHECK(c, hipStreamSynchronize(c->st));
-	const uint64_t str_total = P<uint64_t>(c->h_totals)[1], cig_total = P<uint64_t>(c->h_totals)[2];
-	CHECK(ensure(c, T.o_str, str_total + 16)); CHECK(ensure(c, T.o_cig, cig_total * 4 + 16));
-	{
-		const dim3 g(grid_for(nc, GROUPS_PER_BLOCK));
-		uint64_t *so = P<uint64_t>(T.o_stroff), *co = P<uint64_t>(T.o_cigoff);
-		uint32_t *cb = P<uint32_t>(c->cig_blob), *oc = P<uint32_t>(T.o_cig);
-		uint8_t *os = P<uint8_t>(T.o_str);
-		if (!pa.packed) k_cluster_pack_ascii<<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc);
-		else {
-			// the dword path for (nearly) all clusters, then the bytewise path for the listed ones
-			const int64_t n_slow = (int64_t)(uint32_t)P<uint64_t>(c->h_totals)[3];
-			const dim3 gs(grid_for(std::max<int64_t>(n_slow, 1), GROUPS_PER_BLOCK));
-#define SSV_PACK(W_) do { k_cluster_pack_codes<W_, false><<<g, BLOCK, 0, c->st>>>(pa, nc, so, co, cb, os, oc); \
-			if (n_slow) k_cluster_pack_codes<W_, true><<<gs, BLOCK, 0, c->st>>>(pa, n_slow, so, co, cb, os, oc); } while (0)
-			if (pa.qual_bits == 8) SSV_PACK(8); else if (pa.qual_bits == 4) SSV_PACK(4); else if (pa.qual_bits == 3) SSV_PACK(3); else if (pa.qual_bits == 2) SSV_PACK(2); else SSV_PACK(1);
-#undef SSV_PACK
-		}
-	}
-	HIPCHECK(c, hipGetLastError());
-	delete pack_scope; pack_scope = nullptr; // the copy below is PCIe time, not kernel time
 	struct { HBuf *h; DBuf *d; size_t bytes; } cp[] = {
 		{&T.h_tid, &T.o_tid, (size_t)nc * 4}, {&T.h_pos, &T.o_pos, (size_t)nc * 4}, {&T.h_side, &T.o_side, (size_t)nc}, {&T.h_support, &T.o_support, (size_t)nc * 4},
 		{&T.h_ll, &T.o_ll, (size_t)nc * 4}, {&T.h_lr, &T.o_lr, (size_t)nc * 4}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_stroff, &T.o_stroff, (size_t)nc * 8},
@@ -672,13 +748,14 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	// size the other table set like this one now (pinning ~2 GB of host memory takes ~100 ms: better here than in the caller's next pass)
 	ssv_ctx::TableSet &O = c->tab[s_ ^ 1];
 	if (!O.in_flight) {
-		struct { HBuf *h; DBuf *d; size_t bytes; } oc[] = {
-			{&O.h_tid, &O.o_tid, (size_t)nc * 4}, {&O.h_pos, &O.o_pos, (size_t)nc * 4}, {&O.h_side, &O.o_side, (size_t)nc}, {&O.h_support, &O.o_support, (size_t)nc * 4},
-			{&O.h_ll, &O.o_ll, (size_t)nc * 4}, {&O.h_lr, &O.o_lr, (size_t)nc * 4}, {&O.h_qmiss, &O.o_qmiss, (size_t)nc}, {&O.h_stroff, &O.o_stroff, (size_t)nc * 8},
-			{&O.h_cigoff, &O.o_cigoff, (size_t)nc * 8}, {&O.h_ncig, &O.o_ncig, (size_t)nc * 4}, {&O.h_str, &O.o_str, (size_t)str_total}, {&O.h_cig, &O.o_cig, (size_t)cig_total * 4}};
+		struct { HBuf *h; DBuf *d; size_t bytes, dbytes; } oc[] = {
+			{&O.h_tid, &O.o_tid, (size_t)nc * 4, (size_t)E * 4}, {&O.h_pos, &O.o_pos, (size_t)nc * 4, (size_t)E * 4}, {&O.h_side, &O.o_side, (size_t)nc, (size_t)E}, {&O.h_support, &O.o_support, (size_t)nc * 4, (size_t)E * 4},
+			{&O.h_ll, &O.o_ll, (size_t)nc * 4, (size_t)E * 4}, {&O.h_lr, &O.o_lr, (size_t)nc * 4, (size_t)E * 4}, {&O.h_qmiss, &O.o_qmiss, (size_t)nc, (size_t)E}, {&O.h_stroff, &O.o_stroff, (size_t)nc * 8, (size_t)E * 8},
+			{&O.h_cigoff, &O.o_cigoff, (size_t)nc * 8, (size_t)E * 8}, {&O.h_ncig, &O.o_ncig, (size_t)nc * 4, (size_t)E * 4}, {&O.h_str, &O.o_str, (size_t)str_total, T.o_str.cap - 16},
+			{&O.h_cig, &O.o_cig, (size_t)cig_total * 4, (size_t)c->sum_ncig * 4}};
 		for (auto &x : oc) {
 			if (x.h->cap < x.bytes + 16) CHECK(ensure_host(c, *x.h, x.bytes + 16));
-			if (x.d->cap < x.bytes + 16) { void *np = nullptr; HIPCHECK(c, hipMalloc(&np, x.bytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.bytes + 16; }
+			if (x.d->cap < x.dbytes + 16) { void *np = nullptr; HIPCHECK(c, hipMalloc(&np, x.dbytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.dbytes + 16; }
 		}
 	}
 	return SSV_OK;
@@ -688,8 +765,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out);
 
 uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits)
 {
-	const uint64_t l = (uint64_t)left_len, r = (uint64_t)right_len, w = seq_packed ? (uint64_t)qual_bits : 8;
-	return ((seq_packed ? (l + 1) / 2 + (l * w + 7) / 8 + (r + 1) / 2 + (r * w + 7) / 8 : 2 * (l + r)) + 3) & ~(uint64_t)3;
+	return table_block_bytes((uint64_t)left_len, (uint64_t)right_len, seq_packed, seq_packed ? (uint64_t)qual_bits : 8);
 }
 
 int ssv_clip_table_format(ssv_ctx *c, int packed)
@@ -948,9 +1024,22 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	if (a.n_win > 0) {
 		// the read cap of the reference's pileup: three small launches that leave at once unless >= 8000 reads can be alive somewhere
 		ProfScope ps(c, P_GETSV_CAND, 0);
-		if (c->cap_ring_mask == 0) { int64_t e = CAP_LDS_RING; while (e < (int64_t)c->gs_map_span + 2) e <<= 1; c->cap_ring_mask = (int32_t)(e - 1); }
-		if ((int64_t)c->gs_map_span + 2 > (int64_t)c->cap_ring_mask + 1) { c->err = "the reference span of the reads grew beyond the pileup ring sized by the pass's first batch"; return SSV_E_RANGE; }
-		CHECK(ensure(c, c->cap_ring, ((size_t)c->cap_ring_mask + 1) * 4)); // sized once per pass (the mask is fixed by its first batch)
+		// the ring of read ends covers one reference span; a later batch with a longer read (a long N skip or deletion) makes it grow: the
+		// live entries of a sweep that is carried across the batch boundary move to their slots in the larger ring
+		if (c->cap_ring_mask == 0 || (int64_t)c->gs_map_span + 2 > (int64_t)c->cap_ring_mask + 1) {
+			int64_t e = CAP_LDS_RING;
+			while (e < (int64_t)c->gs_map_span + 2) e <<= 1;
+			if (e > (1ll << 30)) { c->err = "reference span of a read beyond 2^30"; return SSV_E_RANGE; }
+			if (c->cap_ring_mask == 0) CHECK(ensure(c, c->cap_ring, (size_t)e * 4));
+			else {
+				CHECK(ensure(c, c->cap_ring_tmp, (size_t)e * 4));
+				HIPCHECK(c, hipMemsetAsync(c->cap_ring_tmp.p, 0, (size_t)e * 4, c->st));
+				k_cap_regrow<<<64, BLOCK, 0, c->st>>>(P<CapCarry>(c->cap_carry), P<int32_t>(c->cap_ring), c->cap_ring_mask, P<int32_t>(c->cap_ring_tmp), (int32_t)(e - 1));
+				HIPCHECK(c, hipGetLastError());
+				std::swap(c->cap_ring, c->cap_ring_tmp);
+			}
+			c->cap_ring_mask = (int32_t)(e - 1);
+		}
 		CHECK(ensure(c, c->cap_deep, (size_t)ntiles + 16));
 		for (int s_ = 0; s_ < 2; ++s_) { CHECK(ensure(c, c->cap_tail[s_][0], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][1], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][2], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][3], CAP_TAIL)); }
 		CapArgs ca;

@@ -34,15 +34,27 @@ __global__ void k_sy_fix(int64_t n, const uint32_t *seq_bytes, uint64_t *seq_off
 }
 
 __global__ void k_sy_fill(sy_config cfg, const sy_breakend *be, int64_t g0, int64_t n, int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *mapq, int32_t *l_qseq,
-                          int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar, const uint64_t *seq_off, uint8_t *seqqual)
+                          int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar, const uint64_t *seq_off, uint8_t *seqqual, uint4 *rec)
 {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	sy_record r;
 	sy_decide(&cfg, be, g0 + i, &r);
-	tid[i] = r.tid; pos[i] = r.pos; flag[i] = r.flag; mapq[i] = r.mapq; l_qseq[i] = r.l_qseq; mtid[i] = r.mtid; mpos[i] = r.mpos; isize[i] = r.isize;
+	tid[i] = r.tid; pos[i] = r.pos;
+	if (flag) flag[i] = r.flag;
+	if (mapq) mapq[i] = r.mapq;
+	if (l_qseq) l_qseq[i] = r.l_qseq;
+	if (mtid) mtid[i] = r.mtid;
+	if (mpos) mpos[i] = r.mpos;
+	if (isize) isize[i] = r.isize;
 	for (int k = 0; k < r.n_cigar; ++k) cigar[cigar_off[i] + k] = r.cigar[k];
 	if (r.has_seq) sy_fill_seq(&cfg, be, g0 + i, &r, seqqual + seq_off[i]);
+	if (rec) {
+		uint32_t w[16];
+		sy_fill_line(&r, cigar_off[i], seq_off[i], w);
+		rec[4 * i] = make_uint4(w[0], w[1], w[2], w[3]); rec[4 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+		rec[4 * i + 2] = make_uint4(w[8], w[9], w[10], w[11]); rec[4 * i + 3] = make_uint4(w[12], w[13], w[14], w[15]);
+	}
 }
 
 __global__ void k_sy_ref2bit(sy_config cfg, uint64_t *out, int64_t n_words)
@@ -91,11 +103,11 @@ int ssvs_plan(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n
 
 int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n, int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *mapq,
               const uint16_t *n_cigar, int32_t *l_qseq, int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar,
-              const uint64_t *seq_off, uint8_t *seqqual)
+              const uint64_t *seq_off, uint8_t *seqqual, void *rec)
 {
 	(void)n_cigar;
 	if (n <= 0) return 0;
-	k_sy_fill<<<(unsigned)((n + 255) / 256), 256, 0, nullptr>>>(*cfg, be, g0, n, tid, pos, flag, mapq, l_qseq, mtid, mpos, isize, cigar_off, cigar, seq_off, seqqual);
+	k_sy_fill<<<(unsigned)((n + 255) / 256), 256, 0, nullptr>>>(*cfg, be, g0, n, tid, pos, flag, mapq, l_qseq, mtid, mpos, isize, cigar_off, cigar, seq_off, seqqual, reinterpret_cast<uint4 *>(rec));
 	SY_CHECK(hipGetLastError());
 	SY_CHECK(hipDeviceSynchronize());
 	return 0;

@@ -221,6 +221,17 @@ SY_HD void sy_fill_seq(const sy_config *c, const sy_breakend *be, int64_t g, con
 	}
 }
 
+// the record's 64-byte line (ssv_record, include/seeksv_hip.h) as 16 dwords: tid, pos, flag | mapq << 16 | xc << 24, n_cigar, l_qseq, mtid, mpos,
+// isize, cigar_off, the first five CIGAR operations, seq_off (two dwords)
+SY_HD void sy_fill_line(const sy_record *r, uint32_t cigar_off, uint64_t seq_off, uint32_t *w)
+{
+	w[0] = (uint32_t)r->tid; w[1] = (uint32_t)r->pos; w[2] = (uint32_t)r->flag | ((uint32_t)r->mapq << 16); w[3] = (uint32_t)r->n_cigar;
+	w[4] = (uint32_t)r->l_qseq; w[5] = (uint32_t)r->mtid; w[6] = (uint32_t)r->mpos; w[7] = (uint32_t)r->isize;
+	w[8] = cigar_off;
+	for (int k = 0; k < 5; ++k) w[9 + k] = k < r->n_cigar && k < 3 ? r->cigar[k] : 0u;
+	w[14] = (uint32_t)seq_off; w[15] = (uint32_t)(seq_off >> 32);
+}
+
 // 32 bases of the concatenated reference (linear coordinates 32 w ..) as one 2-bit word, A C G T = 0 1 2 3 (the re-aligner's layout)
 SY_HD uint64_t sy_ref_word(const sy_config *c, int64_t w)
 {

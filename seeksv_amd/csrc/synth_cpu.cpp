@@ -28,15 +28,22 @@ int ssvs_plan(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n
 
 int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n, int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *mapq,
               const uint16_t *n_cigar, int32_t *l_qseq, int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar,
-              const uint64_t *seq_off, uint8_t *seqqual)
+              const uint64_t *seq_off, uint8_t *seqqual, void *rec)
 {
 	(void)n_cigar;
 	for (int64_t i = 0; i < n; ++i) {
 		sy_record r;
 		sy_decide(cfg, be, g0 + i, &r);
-		tid[i] = r.tid; pos[i] = r.pos; flag[i] = r.flag; mapq[i] = r.mapq; l_qseq[i] = r.l_qseq; mtid[i] = r.mtid; mpos[i] = r.mpos; isize[i] = r.isize;
+		tid[i] = r.tid; pos[i] = r.pos;
+		if (flag) flag[i] = r.flag;
+		if (mapq) mapq[i] = r.mapq;
+		if (l_qseq) l_qseq[i] = r.l_qseq;
+		if (mtid) mtid[i] = r.mtid;
+		if (mpos) mpos[i] = r.mpos;
+		if (isize) isize[i] = r.isize;
 		for (int k = 0; k < r.n_cigar; ++k) cigar[cigar_off[i] + k] = r.cigar[k];
 		if (r.has_seq) sy_fill_seq(cfg, be, g0 + i, &r, seqqual + seq_off[i]);
+		if (rec) sy_fill_line(&r, cigar_off[i], seq_off[i], reinterpret_cast<uint32_t *>(rec) + 16 * i);
 	}
 	return 0;
 }

@@ -42,7 +42,7 @@ def _lib(gpu):
         lib = C.CDLL(path)
         V = C.c_void_p
         lib.ssvs_plan.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64, V, V, V, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        lib.ssvs_fill.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64] + [V] * 13
+        lib.ssvs_fill.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64] + [V] * 14
         lib.ssvs_last_error.restype = C.c_char_p
         _synth_libs[name] = lib
     return _synth_libs[name]
@@ -216,8 +216,8 @@ class Workload:
         return out, off
 
     # ---- record generation ----
-    def generate_host(self, g0, n):
-        """records [g0, g0+n) as a dict of numpy arrays (a SSV_MEM_HOST batch)."""
+    def generate_host(self, g0, n, with_rec=False):
+        """records [g0, g0+n) as a dict of numpy arrays (a SSV_MEM_HOST batch).  with_rec: also the records' 64-byte lines (ssv_record)."""
         lib = _lib(False)
         be = self.breakends
         bep = be.ctypes.data if len(be) else None
@@ -230,14 +230,21 @@ class Workload:
             a[name] = np.zeros(n, dt)
         a["cigar"] = np.zeros(nct.value, np.uint32)
         a["seqqual"] = np.zeros(sqb.value, np.uint8)
+        rec = np.zeros(n, _abi.RECORD_DTYPE) if with_rec else None
         lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, p(a["tid"]), p(a["pos"]), p(a["flag"]), p(a["mapq"]), p(a["n_cigar"]), p(a["l_qseq"]),
-                      p(a["mtid"]), p(a["mpos"]), p(a["isize"]), p(a["cigar_off"]), p(a["cigar"]), p(a["seq_off"]), p(a["seqqual"]))
+                      p(a["mtid"]), p(a["mpos"]), p(a["isize"]), p(a["cigar_off"]), p(a["cigar"]), p(a["seq_off"]), p(a["seqqual"]),
+                      p(rec) if with_rec else None)
+        if with_rec:
+            a["rec"] = rec
         a["xc"] = None
         a["max_ref_span"] = self.max_ref_span
         return a
 
-    def generate_device(self, g0, n, device):
-        """records [g0, g0+n) resident in HBM: -> (ssv_batch_t with device pointers, dict of torch tensors keeping them alive)."""
+    def generate_device(self, g0, n, device, soa=True, persistent=False):
+        """records [g0, g0+n) resident in HBM: -> (ssv_batch_t with device pointers, dict of torch tensors keeping them alive).
+        The batch always carries the hot columns (tid, pos, n_cigar) and the records' 64-byte lines (ssv_record); soa=False leaves the cold
+        structure-of-arrays columns out (bench.py: the kernels only read the lines).  persistent: the caller keeps the tensors alive and
+        unchanged until the getclip pass has delivered its table (SSV_MEM_PERSISTENT: the table is cut straight out of the batch)."""
         import torch
         lib = _lib(True)
         torch.cuda.set_device(device)
@@ -253,20 +260,24 @@ class Workload:
         rc = lib.ssvs_plan(C.byref(self.cfg), bep, g0, n, t["n_cigar"].data_ptr(), t["cigar_off"].data_ptr(), t["seq_off"].data_ptr(), C.byref(nct), C.byref(sqb))
         if rc != 0:
             raise RuntimeError("ssvs_plan: " + lib.ssvs_last_error().decode())
-        for name, dt in (("tid", torch.int32), ("pos", torch.int32), ("flag", torch.int16), ("mapq", torch.uint8), ("l_qseq", torch.int32),
-                         ("mtid", torch.int32), ("mpos", torch.int32), ("isize", torch.int32)):
+        cold = (("flag", torch.int16), ("mapq", torch.uint8), ("l_qseq", torch.int32), ("mtid", torch.int32), ("mpos", torch.int32), ("isize", torch.int32))
+        for name, dt in (("tid", torch.int32), ("pos", torch.int32)) + (cold if soa else ()):
             t[name] = torch.empty(n, dtype=dt, device=dev)
         t["cigar"] = torch.empty(max(nct.value, 4), dtype=torch.int32, device=dev)
         t["seqqual"] = torch.empty(sqb.value + 16, dtype=torch.uint8, device=dev)
-        rc = lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, t["tid"].data_ptr(), t["pos"].data_ptr(), t["flag"].data_ptr(), t["mapq"].data_ptr(),
-                           t["n_cigar"].data_ptr(), t["l_qseq"].data_ptr(), t["mtid"].data_ptr(), t["mpos"].data_ptr(), t["isize"].data_ptr(),
-                           t["cigar_off"].data_ptr(), t["cigar"].data_ptr(), t["seq_off"].data_ptr(), t["seqqual"].data_ptr())
+        t["rec"] = torch.empty(max(n, 1) * 64, dtype=torch.uint8, device=dev)
+        ptr = lambda k: t[k].data_ptr() if k in t else None
+        rc = lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, ptr("tid"), ptr("pos"), ptr("flag"), ptr("mapq"),
+                           ptr("n_cigar"), ptr("l_qseq"), ptr("mtid"), ptr("mpos"), ptr("isize"),
+                           ptr("cigar_off"), ptr("cigar"), ptr("seq_off"), ptr("seqqual"), ptr("rec"))
         if rc != 0:
             raise RuntimeError("ssvs_fill: " + lib.ssvs_last_error().decode())
+        if not soa:  # the offsets live on in the lines
+            del t["cigar_off"], t["seq_off"]
         arrays = {k: v.data_ptr() for k, v in t.items()}
         arrays["xc"] = None
         arrays["n_cigar_total"] = nct.value
         arrays["seqqual_bytes"] = sqb.value
         arrays["max_ref_span"] = self.max_ref_span
-        b, _ = _abi.make_batch(arrays, mem=_abi.MEM_DEVICE, n=n)
+        b, _ = _abi.make_batch(arrays, mem=_abi.MEM_DEVICE | (_abi.MEM_PERSISTENT if persistent else 0), n=n)
         return b, t
