@@ -69,6 +69,23 @@ struct RecLine {
 	__device__ __forceinline__ uint32_t op(const uint32_t *cigar, int k) const { return k < 5 ? head(k) : cigar[cigar_off() + (uint32_t)k]; }
 };
 
+// lane k of every aligned group of four lanes -> all four (DPP quad_perm broadcast: a plain VALU move, no LDS traffic)
+template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, false); }
+
+// The same line fetched by FOUR lanes, 16 bytes each: one vector memory instruction then carries 16 whole lines (64 contiguous bytes per
+// quad) instead of 64 quarter lines, four instructions per record - the per-candidate kernels were bound by the issue of exactly those
+// (PMC: 64 % of their wave cycles stalled on instruction issue).  All four lanes end up with the whole line.
+__device__ __forceinline__ RecLine rec_load_quad(const ssv_record *rec, int64_t i, int q)
+{
+	const uint4 m = reinterpret_cast<const uint4 *>(rec + i)[q];
+	RecLine r;
+	r.w_tid = quad_bcast<0>(m.x); r.w_pos = quad_bcast<0>(m.y); r.w_fmx = quad_bcast<0>(m.z); r.w_nc = quad_bcast<0>(m.w);
+	r.w_lq = quad_bcast<1>(m.x); r.w_mtid = quad_bcast<1>(m.y); r.w_mpos = quad_bcast<1>(m.z); r.w_isize = quad_bcast<1>(m.w);
+	r.w_coff = quad_bcast<2>(m.x); r.h0 = quad_bcast<2>(m.y); r.h1 = quad_bcast<2>(m.z); r.h2 = quad_bcast<2>(m.w);
+	r.h3 = quad_bcast<3>(m.x); r.h4 = quad_bcast<3>(m.y); r.so_lo = quad_bcast<3>(m.z); r.so_hi = quad_bcast<3>(m.w);
+	return r;
+}
+
 __device__ __forceinline__ RecLine rec_load(const ssv_record *rec, int64_t i)
 {
 	const uint4 *p = reinterpret_cast<const uint4 *>(rec + i);
@@ -210,6 +227,8 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 	const int tid = r.tid();
 	if (tid < 0) return 0;
 	// contig-switch rule: processed only if tid equals the tid of the previous mapped-pair record (clip_reads.h:423-438)
+	// (requested only for soft-clipped records: fetching it beside the line for every candidate cost more - two thirds of them are reads
+	// with an indel that leave above - than the second round trip it saved)
 	int prev_tid = *a.last_tid_in;
 	for (int64_t j = i - 1; j >= 0; --j) {
 		const uint4 pa = reinterpret_cast<const uint4 *>(b.rec + j)[0];
@@ -375,25 +394,55 @@ __global__ __launch_bounds__(BLOCK) void k_cand_place(const uint32_t *__restrict
 
 // K1b clip_filter: one thread per candidate record (n_cigar >= 2) fetches the record's line - one 64-byte sector holds the CIGAR ends
 // and every field of GetSClipReads' predicate chain (flag, MAPQ, DUP, XC, hard clips, lengths) - and leaves its 0, 1 or 2 events in the
-// candidate's two stash slots.  cnt[c] = events | right-clip events << 32.
-__global__ __launch_bounds__(BLOCK) void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ cand, int64_t n_cand, ClipEvent *__restrict__ stash, uint64_t *__restrict__ cnt)
+// candidate's two event slots.  The slots are the events' final place (the event array has holes; everything downstream goes through
+// indices), so an event line is written exactly once; what the ordered side lists need of an event - key, l_qseq, n_cigar: 16 bytes - is
+// staged beside it for k_clip_place.  cnt[c] = bit 0: a '5' event, bit 1: a '3' event; wave_cnt[c / 64] = the wavefront's events | its '3' events << 32
+// (the order-restoring scan runs over one value per wavefront, not per candidate).
+__global__ __launch_bounds__(BLOCK) void k_clip_filter(ClipFilterArgs a, const uint32_t *__restrict__ cand, int64_t n_cand, ClipEvent *__restrict__ stash, uint4 *__restrict__ kv, uint8_t *__restrict__ cnt,
+                                                       uint64_t *__restrict__ wave_cnt)
 {
-	const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	// four lanes per candidate (rec_load_quad): a wavefront handles 16 candidates, every lane of a quad decides the same events and stores
+	// its quarter of their lines
+	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const int64_t c = t >> 2;
+	const int q = (int)(t & 3);
 	ClipEvent evl, evr;
 	int m = 0;
 	if (c < n_cand) {
 		const int64_t i = cand[c];
-		const RecLine r = rec_load(a.b.rec, i);
+		const RecLine r = rec_load_quad(a.b.rec, i, q);
 		m = clip_events_of(a, i, r, evl, evr);
-		cnt[c] = (uint64_t)((m & 1) + (m >> 1)) | ((uint64_t)(m >> 1) << 32);
+		if (q == 0) cnt[c] = (uint8_t)m;
 	}
-	// the wavefront's events side by side (two slots per candidate are reserved, the wave fills its 128 from the front): a third of
+	// the wavefront's events side by side (two slots per candidate are reserved, the wave fills its 32 from the front): a third of
 	// the candidates emit, and an event is one whole 64-byte line
 	const int n = (m & 1) + (m >> 1);
-	const int ex = wave_inclusive_sum(n) - n;
-	ClipEvent *dst = stash + 2 * (c - lane_id()) + ex;
-	if (m & 1) event_store(dst, evl);
-	if (m & 2) event_store(dst + (m & 1), evr);
+	const int v = q == 0 ? n : 0;
+	const int inc = wave_inclusive_sum(v);
+	const int ex = (int)quad_bcast<0>((uint32_t)(inc - v));
+	const uint64_t nr_wave = (uint64_t)__popcll(__ballot((m & 2) != 0 && q == 0));
+	if (lane_id() == 63 && c - 15 < n_cand) wave_cnt[c >> 4] = (uint64_t)inc | (nr_wave << 32); // (whole wavefronts are launched: lane 63 exists also in the last one)
+	const int64_t s0 = 2 * (c - (lane_id() >> 2)) + ex;
+	auto quarter = [&](const ClipEvent &e) -> uint4 {
+		const uint4 p0 = make_uint4((uint32_t)e.key, (uint32_t)(e.key >> 32), (uint32_t)e.src, (uint32_t)(e.src >> 32));
+		const uint4 p1 = make_uint4((uint32_t)e.cig_ptr, (uint32_t)(e.cig_ptr >> 32), (uint32_t)e.begin, (uint32_t)e.ll);
+		const uint4 p2 = make_uint4((uint32_t)e.lr, (uint32_t)e.lq, e.ncig, e.cig[0]);
+		const uint4 p3 = make_uint4(e.cig[1], e.cig[2], e.cig[3], e.cig[4]);
+		// (picked through 64-bit shifts: a plain chain of selects over these sixteen values becomes an indexed stack array under hipcc)
+		auto pick = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) -> uint32_t {
+			const uint64_t p01 = (uint64_t)w0 | ((uint64_t)w1 << 32), p23 = (uint64_t)w2 | ((uint64_t)w3 << 32);
+			return (uint32_t)(((q & 2) ? p23 : p01) >> ((q & 1) << 5));
+		};
+		return make_uint4(pick(p0.x, p1.x, p2.x, p3.x), pick(p0.y, p1.y, p2.y, p3.y), pick(p0.z, p1.z, p2.z, p3.z), pick(p0.w, p1.w, p2.w, p3.w));
+	};
+	if (m & 1) {
+		reinterpret_cast<uint4 *>(stash + s0)[q] = quarter(evl);
+		if (q == 0) kv[s0] = make_uint4((uint32_t)evl.key, (uint32_t)(evl.key >> 32), (uint32_t)evl.lq, evl.ncig);
+	}
+	if (m & 2) {
+		reinterpret_cast<uint4 *>(stash + s0 + (m & 1))[q] = quarter(evr);
+		if (q == 0) kv[s0 + (m & 1)] = make_uint4((uint32_t)evr.key, (uint32_t)(evr.key >> 32), (uint32_t)evr.lq, evr.ncig);
+	}
 }
 
 // tid of the last mapped-pair record of the batch -> *last_tid (unchanged when there is none)
@@ -414,57 +463,83 @@ __global__ __launch_bounds__(BLOCK) void k_last_tid(DevBatch b, int *last_tid)
 // the pass's events: one array of lines in BAM order, and the sort keys of the two sides as separate compact lists (the '5' events
 // come out of a coordinate-sorted BAM already in key order: only the '3' list needs sorting)
 struct EventLists {
-	ClipEvent *ev;           // [n_events] BAM order
 	uint64_t *key_l, *key_r; // keys of the side-0 / side-1 events, BAM order
-	uint32_t *val_l, *val_r; // their event indices
+	uint32_t *val_l, *val_r; // their event slots
+	uint2 *meta;             // per event in BAM order (l_qseq, n_cigar): what the allocation bounds are reduced from without touching the lines again
+	uint32_t *idx;           // per event in BAM order: its slot
 };
 
-// candidate c's events -> final, BAM-ordered position ev_base + ev_off[c] + e; keys into the side lists
-__global__ __launch_bounds__(BLOCK) void k_clip_place(const ClipEvent *__restrict__ stash, const uint64_t *__restrict__ cnt, const uint64_t *__restrict__ ev_off, int64_t n_cand,
-                                                      EventLists L, int64_t ev_base, int64_t l_base, int64_t r_base)
+// candidate c's events, in BAM order: keys and slots into the side lists, (l_qseq, n_cigar) and slot into the per-event arrays
+__global__ __launch_bounds__(BLOCK) void k_clip_place(const uint4 *__restrict__ kv, const uint8_t *__restrict__ cnt, const uint64_t *__restrict__ wave_off, int64_t n_cand,
+                                                      EventLists L, int64_t ev_base, int64_t l_base, int64_t r_base, int64_t slot_base)
 {
 	const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	const int n = c < n_cand ? (int)(uint32_t)cnt[c] : 0;
-	const int ex = wave_inclusive_sum(n) - n; // same thread-to-candidate mapping as k_clip_filter: the wave's events are packed from its first slot
-	const ClipEvent *src = stash + 2 * (c - lane_id()) + ex;
+	const int m = c < n_cand ? (int)cnt[c] : 0;
+	const int n = (m & 1) + (m >> 1);
+	// k_clip_filter packed the events of every 16 candidates (one of its wavefronts) from the first of their 32 slots
+	const int inc = wave_inclusive_sum(n);
+	const int seg = lane_id() & ~15;
+	const int before_seg = __shfl(inc, seg > 0 ? seg - 1 : 0, WAVE);
+	const int ex = inc - n - (seg > 0 ? before_seg : 0);
+	const uint64_t seg_mask = ~((1ull << seg) - 1ull);
+	const int exr = (int)__popcll(__ballot((m & 2) != 0) & lanemask_lt() & seg_mask);
 	if (n == 0) return;
-	const uint64_t off = ev_off[c];
-	const int64_t e0 = ev_base + (int64_t)(uint32_t)off;
-	int64_t ir = r_base + (int64_t)(off >> 32), il = l_base + (int64_t)(uint32_t)off - (int64_t)(off >> 32);
+	const int64_t s0 = 2 * (c - (lane_id() & 15)) + ex;
+	const uint64_t off = wave_off[c >> 4];
+	const int64_t e0 = ev_base + (int64_t)(uint32_t)off + ex;
+	int64_t ir = r_base + (int64_t)(off >> 32) + exr, il = l_base + (int64_t)(uint32_t)off - (int64_t)(off >> 32) + (ex - exr);
 	for (int k = 0; k < n; ++k) {
-		const uint4 *p = reinterpret_cast<const uint4 *>(src + k);
-		const uint4 a = p[0], b = p[1], cc = p[2], d = p[3];
-		uint4 *q = reinterpret_cast<uint4 *>(L.ev + e0 + k);
-		q[0] = a; q[1] = b; q[2] = cc; q[3] = d;
+		const uint4 a = kv[s0 + k];
+		const uint32_t slot = (uint32_t)(slot_base + s0 + k);
+		L.meta[e0 + k] = make_uint2(a.z, a.w);
+		L.idx[e0 + k] = slot;
 		const uint64_t key = (uint64_t)a.x | ((uint64_t)a.y << 32);
-		if ((key >> 32) & 1ull) { L.key_r[ir] = key; L.val_r[ir] = (uint32_t)(e0 + k); ++ir; }
-		else { L.key_l[il] = key; L.val_l[il] = (uint32_t)(e0 + k); ++il; }
+		if ((key >> 32) & 1ull) { L.key_r[ir] = key; L.val_r[ir] = slot; ++ir; }
+		else { L.key_l[il] = key; L.val_l[il] = slot; ++il; }
 	}
 }
 
-// largest key / slice lengths / CIGAR length of the batch's events and their CIGAR operations in total: grid-stride partials, one atomic per wave
-__global__ __launch_bounds__(BLOCK) void k_event_max(const ClipEvent *__restrict__ ev, int64_t ev_base, ClipCounters *ctr)
+// longest read / CIGAR of the batch's events, their CIGAR operations in total, the reads too long for the dword path of the pack kernels:
+// grid-stride partials over the compact (l_qseq, n_cigar) pairs, reduced per workgroup; the maxima look before they touch the shared word
+// (same-address atomics run at ~90 per microsecond)
+__global__ __launch_bounds__(BLOCK) void k_event_max(const uint2 *__restrict__ meta, int64_t ev_base, ClipCounters *ctr)
 {
-	const int64_t n_new = (int64_t)(uint32_t)ctr->n_new; // written by the scan of the per-candidate counts
-	unsigned long long mk = 0, sc = 0, nl = 0;
-	int mll = 0, mlr = 0, mlq = 0, mnc = 0;
+	__shared__ unsigned long long s_sc[WAVES_PER_BLOCK], s_nl[WAVES_PER_BLOCK];
+	__shared__ int s_lq[WAVES_PER_BLOCK], s_nc[WAVES_PER_BLOCK];
+	const int64_t n_new = (int64_t)(uint32_t)ctr->n_new; // written by the scan of the per-wavefront counts
+	unsigned long long sc = 0, nl = 0;
+	int mlq = 0, mnc = 0;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_new; i += (int64_t)gridDim.x * blockDim.x) {
-		const uint4 *p = reinterpret_cast<const uint4 *>(ev + ev_base + i);
-		const uint4 a = p[0], b = p[1], c = p[2];
-		const unsigned long long k = (uint64_t)a.x | ((uint64_t)a.y << 32);
-		mk = k > mk ? k : mk;
-		mll = (int)b.w > mll ? (int)b.w : mll;
-		mlr = (int)c.x > mlr ? (int)c.x : mlr;
-		mlq = (int)c.y > mlq ? (int)c.y : mlq;
-		mnc = (int)c.z > mnc ? (int)c.z : mnc;
-		sc += c.z;
-		nl += (int)c.y > PACK_MAX_LQ ? 1u : 0u;
+		const uint2 v = meta[ev_base + i];
+		mlq = (int)v.x > mlq ? (int)v.x : mlq;
+		mnc = (int)v.y > mnc ? (int)v.y : mnc;
+		sc += v.y;
+		nl += (int)v.x > PACK_MAX_LQ ? 1u : 0u;
 	}
-	mk = wave_max(mk); mll = wave_max(mll); mlr = wave_max(mlr); mlq = wave_max(mlq); mnc = wave_max(mnc); sc = wave_sum(sc); nl = wave_sum(nl);
-	if (lane_id() == 0) {
-		atomicMax(&ctr->max_key, mk); atomicMax(&ctr->max_ll, mll); atomicMax(&ctr->max_lr, mlr); atomicMax(&ctr->max_lq, mlq); atomicMax(&ctr->max_ncig, mnc);
-		atomicAdd(&ctr->sum_ncig, sc);
+	mlq = wave_max(mlq); mnc = wave_max(mnc); sc = wave_sum(sc); nl = wave_sum(nl);
+	if (lane_id() == 0) { s_sc[wave_id()] = sc; s_nl[wave_id()] = nl; s_lq[wave_id()] = mlq; s_nc[wave_id()] = mnc; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < WAVES_PER_BLOCK; ++w) { sc += s_sc[w]; nl += s_nl[w]; mlq = s_lq[w] > mlq ? s_lq[w] : mlq; mnc = s_nc[w] > mnc ? s_nc[w] : mnc; }
+		if (mlq > __atomic_load_n(&ctr->max_lq, __ATOMIC_RELAXED)) atomicMax(&ctr->max_lq, mlq);
+		if (mnc > __atomic_load_n(&ctr->max_ncig, __ATOMIC_RELAXED)) atomicMax(&ctr->max_ncig, mnc);
+		if (sc) atomicAdd(&ctr->sum_ncig, sc);
 		if (nl) atomicAdd(&ctr->n_long, nl);
+	}
+}
+
+// largest key of a list (the '3' keys are not in order): *out = max
+__global__ __launch_bounds__(BLOCK) void k_key_max(const uint64_t *__restrict__ key, int64_t n, unsigned long long *__restrict__ out)
+{
+	__shared__ unsigned long long s_mk[WAVES_PER_BLOCK];
+	unsigned long long mk = 0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const unsigned long long k = key[i]; mk = k > mk ? k : mk; }
+	mk = wave_max(mk);
+	if (lane_id() == 0) s_mk[wave_id()] = mk;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < WAVES_PER_BLOCK; ++w) mk = s_mk[w] > mk ? s_mk[w] : mk;
+		if (mk > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, mk);
 	}
 }
 
@@ -475,25 +550,25 @@ constexpr int GROUPS_PER_WAVE = WAVE / GROUP;  // 4 items in flight per wavefron
 constexpr int GROUPS_PER_BLOCK = BLOCK / GROUP;
 
 // bytes to copy per new event: packed bases + qualities (padded to 4: entries of the context blob start 4-byte aligned), long CIGARs
-__global__ __launch_bounds__(BLOCK) void k_gather_sizes(const ClipEvent *__restrict__ ev, int64_t ev_base, int64_t n_new, uint32_t *__restrict__ seq_bytes, uint32_t *__restrict__ cig_ops)
+__global__ __launch_bounds__(BLOCK) void k_gather_sizes(const uint2 *__restrict__ meta, int64_t ev_base, int64_t n_new, uint32_t *__restrict__ seq_bytes, uint32_t *__restrict__ cig_ops)
 {
 	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n_new) return;
-	const uint4 c = reinterpret_cast<const uint4 *>(ev + ev_base + i)[2];
-	const uint32_t lq = c.y, nc = c.z;
+	const uint2 v = meta[ev_base + i];
+	const uint32_t lq = v.x, nc = v.y;
 	seq_bytes[i] = ((lq + 1) / 2 + lq + 3u) & ~3u;
 	cig_ops[i] = nc > 5 ? nc : 0u;
 }
 
 // 16 lanes per event copy its packed bases, qualities and (if longer than five operations) CIGAR into the context blobs and point the
 // event at the copies.  The source may start anywhere, so every lane assembles aligned output dwords from two aligned source dwords.
-__global__ __launch_bounds__(BLOCK) void k_clip_gather(ClipEvent *__restrict__ ev, int64_t ev_base, int64_t n_new, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ cig_off,
+__global__ __launch_bounds__(BLOCK) void k_clip_gather(ClipEvent *__restrict__ ev, const uint32_t *__restrict__ ev_idx, int64_t ev_base, int64_t n_new, const uint64_t *__restrict__ seq_off, const uint64_t *__restrict__ cig_off,
                                                        uint8_t *__restrict__ seq_blob, uint32_t *__restrict__ cig_blob)
 {
 	const int64_t w = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
 	if (w >= n_new) return;
 	const uint32_t gl = threadIdx.x % GROUP;
-	ClipEvent *E = ev + ev_base + w;
+	ClipEvent *E = ev + ev_idx[ev_base + w];
 	const uint4 *p = reinterpret_cast<const uint4 *>(E);
 	const uint4 a = p[0], b = p[1], c = p[2];
 	const uint8_t *src = reinterpret_cast<const uint8_t *>((uintptr_t)((uint64_t)a.z | ((uint64_t)a.w << 32)));
@@ -549,22 +624,36 @@ __global__ __launch_bounds__(BLOCK) void k_side_bounds(const uint64_t *__restric
 	cum_r[t] = t >= (1ll << 31) ? (uint32_t)nr : (uint32_t)lower(key_r, nr);
 }
 
-// (contig, side, position) order = per contig: its '5' events, then its '3' events
+// (contig, side, position) order = per contig: its '5' events, then its '3' events.  The events' lines move into that order too (one
+// nearly sequential copy): everything downstream then reads slot j's line at evs[j] - coalesced, and one dependent load less per item than
+// through a permutation.
 __global__ __launch_bounds__(BLOCK) void k_merge_sides(const uint64_t *__restrict__ key_l, const uint32_t *__restrict__ val_l, int64_t nl, const uint64_t *__restrict__ key_r,
                                                        const uint32_t *__restrict__ val_r, int64_t nr, const uint32_t *__restrict__ cum_l, const uint32_t *__restrict__ cum_r,
-                                                       uint64_t *__restrict__ skey, uint32_t *__restrict__ perm)
+                                                       const ClipEvent *__restrict__ ev, uint64_t *__restrict__ skey, ClipEvent *__restrict__ evs)
 {
-	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (i < nl) {
-		const uint64_t k = key_l[i];
-		const int64_t o = i + cum_r[k >> 33];
-		skey[o] = k; perm[o] = val_l[i];
-	} else if (i < nl + nr) {
-		const int64_t j = i - nl;
-		const uint64_t k = key_r[j];
-		const int64_t o = j + cum_l[(k >> 33) + 1];
-		skey[o] = k; perm[o] = val_r[j];
-	}
+	// four lanes per event, each moves a quarter of the line: whole 64-byte lines per memory instruction on both sides
+	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const int64_t i = t >> 2;
+	const int q = (int)(t & 3);
+	if (i >= nl + nr) return;
+	uint64_t k;
+	uint32_t v;
+	int64_t o;
+	if (i < nl) { k = key_l[i]; v = val_l[i]; o = i + cum_r[k >> 33]; }
+	else { const int64_t j = i - nl; k = key_r[j]; v = val_r[j]; o = j + cum_l[(k >> 33) + 1]; }
+	const uint4 w = reinterpret_cast<const uint4 *>(ev + v)[q];
+	if (q == 0) skey[o] = k;
+	reinterpret_cast<uint4 *>(evs + o)[q] = w;
+}
+
+// the same after the full sort (unsorted input)
+__global__ __launch_bounds__(BLOCK) void k_gather_lines(const uint32_t *__restrict__ perm, int64_t n, const ClipEvent *__restrict__ ev, ClipEvent *__restrict__ evs)
+{
+	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const int64_t j = t >> 2;
+	const int q = (int)(t & 3);
+	if (j >= n) return;
+	reinterpret_cast<uint4 *>(evs + j)[q] = reinterpret_cast<const uint4 *>(ev + perm[j])[q];
 }
 
 // unsorted input: both lists, '5' first, into one array for the full sort (equal keys are on one side, so BAM order inside a bin is kept)
@@ -585,24 +674,34 @@ __device__ __constant__ char NT16[16] = {'=', 'A', 'C', 'M', 'G', 'R', 'S', 'V',
 struct ClusterArgs {
 	// sorted events
 	const uint64_t *skey;  // [E] sorted keys
-	const uint32_t *perm;  // [E] sorted position -> event index
 	int64_t E;
-	const ClipEvent *ev;
+	const ClipEvent *ev;   // [E] the events' lines in sorted order
 	double match_rate;
 	// per sorted slot outputs
 	int32_t *support;      // [E]; > 0 marks a cluster created by the event at this slot (single-event bins: 1, set by k_bin_mark)
 	int32_t *c_ll, *c_lr;  // [E] clusters of multi-event bins only
-	uint32_t *c_cig_ev;    // [E] event whose CIGAR the cluster carries (multi-event bins only)
+	uint32_t *c_cig_ev;    // [E] sorted slot of the event whose CIGAR the cluster carries (multi-event bins only)
 	uint8_t *c_qmiss;      // [E] (multi-event bins only)
 	const uint32_t *mflag; // [E] 1: the slot belongs to a bin with more than one event
 	const uint32_t *mslot; // [E] exclusive scan of mflag: index of the slot's string storage
 	const uint32_t *mlist; // [M] the slots with mflag set, ascending (inverse of mslot)
 	int64_t M;
+	const uint32_t *blist; // the first slot of every multi-event bin
+	const uint32_t *n_bins; // (device) their number
 	uint8_t *strings;      // [M * stride]: left seq (reversed), left qual (reversed), right seq, right qual - multi-event bins only
 	int32_t SL, SR;        // capacity of a left / right string
 };
 
 constexpr int CL_CACHE = 64; // clusters of the current bin tracked in LDS; deeper bins fall back to scanning the slots
+
+// bam_nt16_rev_table "=ACMGRSVTWYHKDBN" as two little-endian 64-bit words: nibble -> ASCII without touching memory
+__device__ __forceinline__ uint32_t nt16_char(uint32_t nib)
+{
+	const uint64_t LO = ((uint64_t)'=') | ((uint64_t)'A' << 8) | ((uint64_t)'C' << 16) | ((uint64_t)'M' << 24) | ((uint64_t)'G' << 32) | ((uint64_t)'R' << 40) | ((uint64_t)'S' << 48) | ((uint64_t)'V' << 56);
+	const uint64_t HI = ((uint64_t)'T') | ((uint64_t)'W' << 8) | ((uint64_t)'Y' << 16) | ((uint64_t)'H' << 24) | ((uint64_t)'K' << 32) | ((uint64_t)'D' << 40) | ((uint64_t)'B' << 48) | ((uint64_t)'N' << 56);
+	return (uint32_t)(((nib & 8u) ? HI : LO) >> (8u * (nib & 7u))) & 0xffu;
+}
+
 
 struct EventView {
 	const uint8_t *sp, *qp;
@@ -611,7 +710,8 @@ struct EventView {
 	// i-th base of seq_left counted from its END (i = 0 is adjacent to the breakpoint side of the compare)
 	__device__ __forceinline__ int lpos(int i) const { return begin + ll - 1 - i; }
 	__device__ __forceinline__ int rpos(int i) const { return begin + ll + i; }
-	__device__ __forceinline__ char base(int p) const { return NT16[(sp[p >> 1] >> ((~p & 1) << 2)) & 15]; }
+	// (arithmetic, not the NT16 table: a table in memory makes every base two dependent loads, and the per-bin walk is one long dependent chain)
+	__device__ __forceinline__ char base(int p) const { return (char)nt16_char((uint32_t)(sp[p >> 1] >> ((~p & 1) << 2)) & 15u); }
 	__device__ __forceinline__ char qual(int p) const { return qmiss ? '*' : (char)(qp[p] + 33); }
 };
 
@@ -634,105 +734,198 @@ __global__ void k_multi_list(const uint32_t *__restrict__ mflag, const uint32_t 
 	if (j < E && mflag[j]) mlist[mslot[j]] = (uint32_t)j;
 }
 
-// One wavefront per bin (= run of equal keys in the sorted event list).  The wave walks the bin's events in BAM order -
-// the order the reference's multimap::equal_range scan sees them - and keeps the evolving clusters in HBM; lanes are
-// spread over bases, match counts come from ballots.  Bins are independent, so there is no cross-wave communication.
+// which entries of mlist start a bin (bflag), and after the scan of bflag (boff): the starts, densely - one wavefront of k_cluster_bins each
+__global__ void k_bin_start_flags(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ mlist, int64_t M, uint32_t *__restrict__ bflag)
+{
+	int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= M) return;
+	const int64_t j = mlist[m];
+	bflag[m] = (j == 0 || skey[j - 1] != skey[j]) ? 1u : 0u;
+}
+
+__global__ void k_bin_start_list(const uint32_t *__restrict__ mlist, const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ boff, int64_t M, uint32_t *__restrict__ blist)
+{
+	int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (m < M && bflag[m]) blist[boff[m]] = mlist[m];
+}
+
+// One wavefront per bin (= run of equal keys in the sorted event list).  The wave walks the bin's events in BAM order - the order the
+// reference's multimap::equal_range scan sees them - and keeps the evolving clusters; lanes are spread over bases, match counts come from
+// ballots.  Bins are independent, so there is no cross-wave communication.
+// The walk is one long dependent chain (event -> its bytes -> compares against the clusters so far -> consensus update -> next event), and
+// the kernel lasts as long as the longest bin (PMC: waves parked 85 % of their cycles).  So the chain stays on chip: the first BIN_KLDS
+// clusters of a bin keep their consensus strings, and the first CL_CACHE their lengths / support, in LDS; an event's bytes are staged in
+// LDS from loads issued one event ahead, its line is requested two events ahead.  Global memory sees the results once, at the end of the bin.
+constexpr int BIN_ENT = 512;         // bytes of a read's entry staged in LDS (reads of up to PACK_MAX_LQ bases + misalignment)
+constexpr int BIN_KLDS = 4;          // clusters per bin with LDS-resident strings (later ones: global storage)
+constexpr int BIN_SL = PACK_MAX_LQ;  // capacity of an LDS-resident left / right string
+
+struct BinMeta { int32_t ll, lr, support; uint32_t cig_ev; };
+
 __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 {
 	__shared__ int32_t s_slot[WAVES_PER_BLOCK][CL_CACHE];
+	__shared__ BinMeta s_meta[WAVES_PER_BLOCK][CL_CACHE];
+	__shared__ uint32_t s_ent[WAVES_PER_BLOCK][BIN_ENT / 4 + 4];
+	__shared__ uint8_t s_str[WAVES_PER_BLOCK][BIN_KLDS][4 * BIN_SL];
 	const int64_t m0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
-	if (m0 >= a.M) return;
-	const int64_t j0 = a.mlist[m0];                // slots of multi-event bins only (single-event bins were finished by k_bin_mark)
+	if (m0 >= (int64_t)*a.n_bins) return;         // the grid is an upper bound (every second slot of a multi-event bin could start one)
+	const int64_t j0 = a.blist[m0];                // multi-event bins only (single-event bins were finished by k_bin_mark)
 	const uint64_t key0 = a.skey[j0];
-	if (j0 > 0 && a.skey[j0 - 1] == key0) return; // not the start of a bin
 	const int lane = lane_id();
 	const int w = wave_id();
 	const bool left_clipped = ((key0 >> 32) & 1ull) == 0; // side '5' = breakpoint2read_l = LEFT_CLIPPED
 	const int64_t stride = 2ll * (a.SL + a.SR);
+	const bool lds_strings = a.SL <= BIN_SL && a.SR <= BIN_SL;
+	// storage of cluster number k (creation order) created at `slot`: its four strings and their capacities
+	struct Str { uint8_t *cs, *cq, *rs, *rq; };
+	auto storage = [&](int k, int64_t slot) -> Str {
+		Str t;
+		if (lds_strings && k < BIN_KLDS) { t.cs = s_str[w][k]; t.cq = t.cs + BIN_SL; t.rs = t.cs + 2 * BIN_SL; t.rq = t.cs + 3 * BIN_SL; }
+		else { t.cs = a.strings + (int64_t)a.mslot[slot] * stride; t.cq = t.cs + a.SL; t.rs = t.cs + 2 * a.SL; t.rq = t.rs + a.SR; }
+		return t;
+	};
+	// per-cluster lengths / support / CIGAR carrier: LDS for the first CL_CACHE clusters, the per-slot arrays beyond
+	auto get_ll = [&](int k, int64_t slot) -> int { return k < CL_CACHE ? s_meta[w][k].ll : a.c_ll[slot]; };
+	auto get_lr = [&](int k, int64_t slot) -> int { return k < CL_CACHE ? s_meta[w][k].lr : a.c_lr[slot]; };
 	int nclu = 0;
-	for (int64_t jj = j0; jj < a.E && a.skey[jj] == key0; ++jj) {
-		const uint32_t e = a.perm[jj];
-		const uint4 *ep = reinterpret_cast<const uint4 *>(a.ev + e); // one line, the same address in every lane
-		const uint4 ea = ep[0], eb = ep[1], ec = ep[2];
+	// pipeline: line of event jj + 1 and bytes of event jj are in flight when event jj - 1 is being compared
+	auto line_load = [&](int64_t j, uint4 &la, uint4 &lb, uint4 &lc) { const uint4 *ep = reinterpret_cast<const uint4 *>(a.ev + j); la = ep[0]; lb = ep[1]; lc = ep[2]; };
+	auto bytes_load = [&](const uint4 &la, const uint4 &lc, uint32_t &b0, uint32_t &b1) {
+		const uint64_t src = (uint64_t)la.z | ((uint64_t)la.w << 32);
+		const int lq = (int)lc.y, mis = (int)(src & 3ull);
+		const int nraw = (mis + (lq + 1) / 2 + lq + 3) / 4;
+		const uint32_t *g4 = reinterpret_cast<const uint32_t *>((uintptr_t)(src - (uint64_t)mis));
+		const bool staged = nraw <= BIN_ENT / 4;
+		b0 = staged && lane < nraw ? g4[lane] : 0u;
+		b1 = staged && lane + WAVE < nraw ? g4[lane + WAVE] : 0u;
+	};
+	uint4 ca, cb, cc, na, nb_, nc_;
+	uint32_t b0, b1, nb0 = 0, nb1 = 0;
+	line_load(j0, ca, cb, cc);
+	bytes_load(ca, cc, b0, b1);
+	bool more = j0 + 1 < a.E && a.skey[j0 + 1] == key0;
+	if (more) line_load(j0 + 1, na, nb_, nc_);
+	for (int64_t jj = j0;; ++jj) {
+		const uint32_t e = (uint32_t)jj;
+		const bool more2 = more && jj + 2 < a.E && a.skey[jj + 2] == key0;
+		uint4 fa, fb, fc; // line of event jj + 2
+		if (more) bytes_load(na, nc_, nb0, nb1);
+		if (more2) line_load(jj + 2, fa, fb, fc);
 		EventView v;
-		const int lq = (int)ec.y;
-		v.sp = reinterpret_cast<const uint8_t *>((uintptr_t)((uint64_t)ea.z | ((uint64_t)ea.w << 32)));
+		const int lq = (int)cc.y;
+		const uint64_t src = (uint64_t)ca.z | ((uint64_t)ca.w << 32);
+		const int mis = (int)(src & 3ull);
+		const bool staged = (mis + (lq + 1) / 2 + lq + 3) / 4 <= BIN_ENT / 4;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the previous event's readers of s_ent are done
+		if (staged) {
+			s_ent[w][lane] = b0; s_ent[w][lane + WAVE] = b1;
+			v.sp = reinterpret_cast<const uint8_t *>(s_ent[w]) + mis;
+		} else v.sp = reinterpret_cast<const uint8_t *>((uintptr_t)src);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		v.qp = v.sp + (lq + 1) / 2;
-		v.begin = (int)eb.z; v.ll = (int)eb.w; v.lr = (int)ec.x;
+		v.begin = (int)cb.z; v.ll = (int)cb.w; v.lr = (int)cc.x;
 		v.qmiss = lq > 0 && v.qp[0] == 0xff; // no qualities: the row prints "*" (clip_reads.cpp:296)
 		// ---- find the first cluster of the bin that absorbs this event (clip_reads.cpp:262-273) ----
-		auto absorbs = [&](int64_t slot) -> bool {
-			const uint8_t *cs = a.strings + (int64_t)a.mslot[slot] * stride;
-			const int cll = a.c_ll[slot], clr = a.c_lr[slot];
+		auto absorbs = [&](int k, int64_t slot) -> bool {
+			const Str t = storage(k, slot);
+			const int cll = get_ll(k, slot), clr = get_lr(k, slot);
 			const int n1 = v.ll < cll ? v.ll : cll;
 			int m1 = 0;
 			for (int i0 = 0; i0 < n1; i0 += WAVE) {
 				int i = i0 + lane;
-				bool eq = i < n1 && v.base(v.lpos(i)) == (char)cs[i];
+				bool eq = i < n1 && v.base(v.lpos(i)) == (char)t.cs[i];
 				m1 += (int)__popcll(__ballot(eq));
 			}
 			if (!((double)m1 / (double)n1 >= a.match_rate)) return false; // n1 == 0 -> NaN -> false, like the reference
 			const int n2 = v.lr < clr ? v.lr : clr;
 			int m2 = 0;
-			const uint8_t *csr = cs + 2 * a.SL;
 			for (int i0 = 0; i0 < n2; i0 += WAVE) {
 				int i = i0 + lane;
-				bool eq = i < n2 && v.base(v.rpos(i)) == (char)csr[i];
+				bool eq = i < n2 && v.base(v.rpos(i)) == (char)t.rs[i];
 				m2 += (int)__popcll(__ballot(eq));
 			}
 			return (double)m2 / (double)n2 >= a.match_rate;
 		};
+		int hit_k = -1;
 		int64_t hit = -1;
 		const int kmax = nclu < CL_CACHE ? nclu : CL_CACHE;
 		for (int k = 0; k < kmax && hit < 0; ++k) {
-			int64_t slot = j0 + s_slot[w][k];
-			if (absorbs(slot)) hit = slot;
+			const int64_t slot = j0 + s_slot[w][k];
+			if (absorbs(k, slot)) { hit = slot; hit_k = k; }
 		}
 		if (hit < 0 && nclu > CL_CACHE) {
 			// clusters beyond the LDS cache: they were created after the last cached one, i.e. at later slots
-			for (int64_t s = j0 + s_slot[w][CL_CACHE - 1] + 1; s < jj && hit < 0; ++s)
-				if (a.support[s] > 0 && absorbs(s)) hit = s;
+			for (int64_t s_ = j0 + s_slot[w][CL_CACHE - 1] + 1; s_ < jj && hit < 0; ++s_)
+				if (a.support[s_] > 0 && absorbs(CL_CACHE, s_)) { hit = s_; hit_k = CL_CACHE; }
 		}
 		if (hit >= 0) {
 			// ---- ReadsInfo::ChangeSeqAndQual (clip_reads.cpp:57-108) on the reversed-left / forward-right storage ----
-			uint8_t *cs = a.strings + (int64_t)a.mslot[hit] * stride;
-			uint8_t *cq = cs + a.SL, *rs = cs + 2 * a.SL, *rq = rs + a.SR;
-			const int cll = a.c_ll[hit], clr = a.c_lr[hit];
+			const Str t = storage(hit_k, hit);
+			const int cll = get_ll(hit_k, hit), clr = get_lr(hit_k, hit);
 			const int n1 = v.ll < cll ? v.ll : cll;
 			for (int i = lane; i < v.ll; i += WAVE) {
 				int p = v.lpos(i);
 				char q = v.qual(p);
 				if (i < n1) {
-					if ((signed char)cq[i] < (signed char)q) { cq[i] = (uint8_t)q; cs[i] = (uint8_t)v.base(p); }
-				} else if (cll <= v.ll) { cs[i] = (uint8_t)v.base(p); cq[i] = (uint8_t)q; } // prepend the extra prefix
-			}
-			if (cll <= v.ll) {
-				a.c_ll[hit] = v.ll;
-				if (!left_clipped) a.c_cig_ev[hit] = e;  // aa == RIGHT_CLIPPED (also when the lengths are equal)
+					if ((signed char)t.cq[i] < (signed char)q) { t.cq[i] = (uint8_t)q; t.cs[i] = (uint8_t)v.base(p); }
+				} else if (cll <= v.ll) { t.cs[i] = (uint8_t)v.base(p); t.cq[i] = (uint8_t)q; } // prepend the extra prefix
 			}
 			const int n2 = v.lr < clr ? v.lr : clr;
 			for (int i = lane; i < v.lr; i += WAVE) {
 				int p = v.rpos(i);
 				char q = v.qual(p);
 				if (i < n2) {
-					if ((signed char)rq[i] < (signed char)q) { rq[i] = (uint8_t)q; rs[i] = (uint8_t)v.base(p); }
-				} else if (clr < v.lr) { rs[i] = (uint8_t)v.base(p); rq[i] = (uint8_t)q; } // append the extra suffix
+					if ((signed char)t.rq[i] < (signed char)q) { t.rq[i] = (uint8_t)q; t.rs[i] = (uint8_t)v.base(p); }
+				} else if (clr < v.lr) { t.rs[i] = (uint8_t)v.base(p); t.rq[i] = (uint8_t)q; } // append the extra suffix
 			}
-			if (clr < v.lr) {
-				a.c_lr[hit] = v.lr;
-				if (left_clipped) a.c_cig_ev[hit] = e;   // aa == LEFT_CLIPPED
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			if (hit_k < CL_CACHE) {
+				if (lane == 0) {
+					BinMeta &mt = s_meta[w][hit_k];
+					if (cll <= v.ll) { mt.ll = v.ll; if (!left_clipped) mt.cig_ev = e; } // aa == RIGHT_CLIPPED (also when the lengths are equal)
+					if (clr < v.lr) { mt.lr = v.lr; if (left_clipped) mt.cig_ev = e; }    // aa == LEFT_CLIPPED
+					mt.support += 1;
+				}
+			} else {
+				if (cll <= v.ll) { a.c_ll[hit] = v.ll; if (!left_clipped) a.c_cig_ev[hit] = e; }
+				if (clr < v.lr) { a.c_lr[hit] = v.lr; if (left_clipped) a.c_cig_ev[hit] = e; }
+				a.support[hit] += 1; // every lane stores the same value; each lane later reads back what it stored
 			}
-			a.support[hit] += 1; // every lane stores the same value; each lane later reads back what it stored
 		} else {
 			// ---- new cluster at this event's slot (clip_reads.cpp:276-281) ----
-			uint8_t *cs = a.strings + (int64_t)a.mslot[jj] * stride;
-			uint8_t *cq = cs + a.SL, *rs = cs + 2 * a.SL, *rq = rs + a.SR;
-			for (int i = lane; i < v.ll; i += WAVE) { int p = v.lpos(i); cs[i] = (uint8_t)v.base(p); cq[i] = (uint8_t)v.qual(p); }
-			for (int i = lane; i < v.lr; i += WAVE) { int p = v.rpos(i); rs[i] = (uint8_t)v.base(p); rq[i] = (uint8_t)v.qual(p); }
-			a.c_ll[jj] = v.ll; a.c_lr[jj] = v.lr; a.c_cig_ev[jj] = e; a.c_qmiss[jj] = v.qmiss ? 1 : 0;
-			a.support[jj] = 1;
-			if (nclu < CL_CACHE) s_slot[w][nclu] = (int32_t)(jj - j0);
+			const int k = nclu < CL_CACHE ? nclu : CL_CACHE;
+			const Str t = storage(k, jj);
+			for (int i = lane; i < v.ll; i += WAVE) { int p = v.lpos(i); t.cs[i] = (uint8_t)v.base(p); t.cq[i] = (uint8_t)v.qual(p); }
+			for (int i = lane; i < v.lr; i += WAVE) { int p = v.rpos(i); t.rs[i] = (uint8_t)v.base(p); t.rq[i] = (uint8_t)v.qual(p); }
+			a.c_qmiss[jj] = v.qmiss ? 1 : 0;
+			if (nclu < CL_CACHE) {
+				if (lane == 0) { s_slot[w][nclu] = (int32_t)(jj - j0); BinMeta &mt = s_meta[w][nclu]; mt.ll = v.ll; mt.lr = v.lr; mt.support = 1; mt.cig_ev = e; }
+			} else { a.c_ll[jj] = v.ll; a.c_lr[jj] = v.lr; a.c_cig_ev[jj] = e; a.support[jj] = 1; }
 			++nclu;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		if (!more) break;
+		ca = na; cb = nb_; cc = nc_; b0 = nb0; b1 = nb1;
+		more = more2;
+		if (more2) { na = fa; nb_ = fb; nc_ = fc; }
+	}
+	// ---- the bin's results to global memory: lengths / support / CIGAR carrier of the cached clusters, strings of the LDS-resident ones ----
+	const int kc = nclu < CL_CACHE ? nclu : CL_CACHE;
+	for (int k = lane; k < kc; k += WAVE) {
+		const int64_t slot = j0 + s_slot[w][k];
+		const BinMeta mt = s_meta[w][k];
+		a.c_ll[slot] = mt.ll; a.c_lr[slot] = mt.lr; a.c_cig_ev[slot] = mt.cig_ev; a.support[slot] = mt.support;
+	}
+	if (lds_strings) {
+		const int ks = nclu < BIN_KLDS ? nclu : BIN_KLDS;
+		for (int k = 0; k < ks; ++k) {
+			const int64_t slot = j0 + s_slot[w][k];
+			const int ll = s_meta[w][k].ll, lr = s_meta[w][k].lr;
+			uint8_t *g = a.strings + (int64_t)a.mslot[slot] * stride;
+			const uint8_t *l = s_str[w][k];
+			for (int i = lane; i < ll; i += WAVE) { g[i] = l[i]; g[a.SL + i] = l[BIN_SL + i]; }
+			for (int i = lane; i < lr; i += WAVE) { g[2 * a.SL + i] = l[2 * BIN_SL + i]; g[2 * a.SL + a.SR + i] = l[3 * BIN_SL + i]; }
 		}
 	}
 }
@@ -744,28 +937,23 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 struct PackArgs {
 	ClusterArgs c;
 	// per sorted slot: what the scans turn into dense positions
-	uint64_t *slot_cnt;       // [E] cluster at this slot ? 1 | CIGAR operations << 32 : 0          -> exclusive scan: cidx | cig_off << 32
+	uint64_t *slot_cnt;       // [E] cluster at this slot ? 1 | CIGAR operations << 32 : 0          -> exclusive scan: cluster index | cig_off << 32
 	uint64_t *slot_bytes;     // [E] bytes of the cluster's string block (0 when there is none)      -> exclusive scan: str_off
-	// dense outputs [n_clusters]
+	// dense outputs [n_clusters]: written by the pack kernels themselves (a slot's lanes know everything about its cluster)
 	int32_t *tid, *pos;
 	uint8_t *side;
 	int32_t *support, *ll, *lr;
 	uint8_t *qmiss;
 	int32_t *ncig;
 	uint64_t *str_off, *cig_off;
-	uint32_t *slot;           // dense index -> sorted slot
 	int packed;               // 1: sequences as 4-bit codes (ssv_cluster_table.seq_packed)
 	int qual_bits;            // 8: quality characters; 1, 2, 3, 4: indices into the table's quality alphabet
 	const uint8_t *qlut;      // [256] phred -> index (0xff: not in the alphabet), when qual_bits < 8
-	uint32_t *qual_seen;      // [8] bit set of the phred values met while packing (which alphabet the table really needs)
-	// where a cluster's characters come from, resolved once per cluster by k_cluster_cols so that the pack kernel starts with
-	// independent loads instead of a slot -> event -> address chain: src_lq >= 0: single-event cluster, the read's packed bases start at
-	// address src_ptr, its seq_left at base src_begin; src_lq < 0: consensus storage of a multi-event bin
-	uint64_t *src_ptr;
-	int32_t *src_begin, *src_lq;
-	uint32_t *cig_ev;         // the event whose CIGAR the cluster carries
-	// clusters that need the bytewise path of the packed kernel (multi-event bins, reads longer than PACK_MAX_LQ), listed by k_cluster_cols:
-	// they are packed by a launch of their own, so that a wavefront of the main launch never runs the long path for one of its four clusters
+	uint32_t *qual_seen;      // [8] bit set of the phred values met while packing (TRACK launches: which alphabet the table really needs)
+	int *lut_miss;            // raised when a quality outside the alphabet is met (qual_bits < 8)
+	// slots whose cluster needs the bytewise path of the packed kernel (multi-event bins, reads longer than PACK_MAX_LQ), listed by
+	// k_cluster_meta: they are packed by a launch of their own, so that a wavefront of the main launch never runs the long path for one of
+	// its four clusters
 	uint32_t *slow_list;
 	unsigned int *slow_count;
 };
@@ -775,64 +963,43 @@ __host__ __device__ __forceinline__ uint64_t table_block_bytes(uint64_t L, uint6
 	return ((packed ? (L + 1) / 2 + (L * W + 7) / 8 + (R + 1) / 2 + (R * W + 7) / 8 : 2 * (L + R)) + 3ull) & ~3ull; // blocks start 4-byte aligned
 }
 
-// per sorted slot: is there a cluster, how many bytes / CIGAR operations does it put into the table
+// per sorted slot: is there a cluster, how many bytes / CIGAR operations does it put into the table; single-event clusters of reads too
+// long for the dword path are listed (the slots of multi-event bins, the other users of the bytewise path, are listed already: mlist)
 __global__ __launch_bounds__(BLOCK) void k_cluster_meta(PackArgs p)
 {
 	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= p.c.E) return;
 	uint64_t cnt = 0, bytes = 0;
-	if (p.c.support[j] > 0) {
+	bool lng = false;
+	if (j < p.c.E && p.c.support[j] > 0) {
 		const bool single = !p.c.mflag[j];
-		const uint32_t e = single ? p.c.perm[j] : p.c.c_cig_ev[j];
+		const uint32_t e = single ? (uint32_t)j : p.c.c_cig_ev[j];
 		const uint4 *ep = reinterpret_cast<const uint4 *>(p.c.ev + e);
 		const uint4 eb = ep[1], ec = ep[2];
 		const int ll = single ? (int)eb.w : p.c.c_ll[j], lr = single ? (int)ec.x : p.c.c_lr[j];
 		cnt = 1ull | ((uint64_t)ec.z << 32);
 		bytes = table_block_bytes((uint64_t)ll, (uint64_t)lr, p.packed, (uint64_t)p.qual_bits);
+		lng = p.packed && single && (int)ec.y > PACK_MAX_LQ;
 	}
-	p.slot_cnt[j] = cnt; p.slot_bytes[j] = bytes;
-}
-
-// per cluster slot: the dense columns (slot_cnt / slot_bytes now hold their exclusive scans)
-__global__ __launch_bounds__(BLOCK) void k_cluster_cols(PackArgs p)
-{
-	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= p.c.E || !(p.c.support[j] > 0)) return;
-	const uint64_t sc = p.slot_cnt[j];
-	const uint32_t c = (uint32_t)sc;
-	const uint64_t key = p.c.skey[j];
-	const bool single = !p.c.mflag[j];
-	const uint32_t e = single ? p.c.perm[j] : p.c.c_cig_ev[j];
-	const uint4 *ep = reinterpret_cast<const uint4 *>(p.c.ev + e);
-	const uint4 ea = ep[0], eb = ep[1], ec = ep[2];
-	const int ll = single ? (int)eb.w : p.c.c_ll[j], lr = single ? (int)ec.x : p.c.c_lr[j];
-	const int lq = (int)ec.y;
-	p.tid[c] = (int32_t)(key >> 33);
-	p.pos[c] = (int32_t)(uint32_t)key;
-	p.side[c] = ((key >> 32) & 1ull) ? '3' : '5';
-	p.support[c] = p.c.support[j];
-	p.ll[c] = ll; p.lr[c] = lr;
-	p.ncig[c] = (int32_t)ec.z;
-	p.str_off[c] = p.slot_bytes[j];
-	p.cig_off[c] = sc >> 32;
-	p.slot[c] = (uint32_t)j;
-	p.cig_ev[c] = e;
-	p.src_ptr[c] = single ? ((uint64_t)ea.z | ((uint64_t)ea.w << 32)) : 0ull;
-	p.src_begin[c] = single ? (int32_t)eb.z : 0;
-	p.src_lq[c] = single ? lq : -1;
-	if (!single) p.qmiss[c] = p.c.c_qmiss[j]; // single-event clusters: the pack kernel sees the read's first quality byte and writes it
-	if (!(single && lq <= PACK_MAX_LQ && ll + lr <= PACK_MAX_LQ)) p.slow_list[atomicAdd(p.slow_count, 1u)] = c; // a few thousand of millions: no hot spot
+	// one atomic per wavefront that holds long reads (same-address atomics run at ~90 per microsecond: with long-read data every slot is listed)
+	const uint64_t lm = __ballot(lng);
+	if (lm) {
+		uint32_t base = 0;
+		if (lane_id() == 0) base = atomicAdd(p.slow_count, (unsigned int)__popcll(lm));
+		base = __shfl(base, 0, WAVE);
+		if (lng) p.slow_list[base + (uint32_t)__popcll(lm & lanemask_lt())] = (uint32_t)j;
+	}
+	if (j < p.c.E) { p.slot_cnt[j] = cnt; p.slot_bytes[j] = bytes; }
 }
 
 // which phred values occur among the qualities of the first events (BAM order): the first guess of the table's quality alphabet
-__global__ __launch_bounds__(BLOCK) void k_qual_sample(const ClipEvent *__restrict__ ev, int64_t n, uint32_t *__restrict__ seen)
+__global__ __launch_bounds__(BLOCK) void k_qual_sample(const ClipEvent *__restrict__ ev, const uint32_t *__restrict__ ev_idx, int64_t n, uint32_t *__restrict__ seen)
 {
 	__shared__ uint32_t s_seen[8];
 	if (threadIdx.x < 8) s_seen[threadIdx.x] = 0;
 	__syncthreads();
-	const int64_t e = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
-	if (e < n) {
-		const uint4 *ep = reinterpret_cast<const uint4 *>(ev + e);
+	const int64_t o = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	if (o < n) {
+		const uint4 *ep = reinterpret_cast<const uint4 *>(ev + ev_idx[o]);
 		const uint4 ea = ep[0], ec = ep[2];
 		const int lq = (int)ec.y;
 		const uint8_t *qp = reinterpret_cast<const uint8_t *>((uintptr_t)((uint64_t)ea.z | ((uint64_t)ea.w << 32))) + (lq + 1) / 2;
@@ -843,64 +1010,109 @@ __global__ __launch_bounds__(BLOCK) void k_qual_sample(const ClipEvent *__restri
 	if (threadIdx.x < 8 && s_seen[threadIdx.x]) atomicOr(&seen[threadIdx.x], s_seen[threadIdx.x]);
 }
 
-// bam_nt16_rev_table "=ACMGRSVTWYHKDBN" as two little-endian 64-bit words: nibble -> ASCII without touching memory
-__device__ __forceinline__ uint32_t nt16_char(uint32_t nib)
-{
-	const uint64_t LO = ((uint64_t)'=') | ((uint64_t)'A' << 8) | ((uint64_t)'C' << 16) | ((uint64_t)'M' << 24) | ((uint64_t)'G' << 32) | ((uint64_t)'R' << 40) | ((uint64_t)'S' << 48) | ((uint64_t)'V' << 56);
-	const uint64_t HI = ((uint64_t)'T') | ((uint64_t)'W' << 8) | ((uint64_t)'Y' << 16) | ((uint64_t)'H' << 24) | ((uint64_t)'K' << 32) | ((uint64_t)'D' << 40) | ((uint64_t)'B' << 48) | ((uint64_t)'N' << 56);
-	return (uint32_t)(((nib & 8u) ? HI : LO) >> (8u * (nib & 7u))) & 0xffu;
-}
-
 // the inverse as a table (ASCII -> 4-bit code, anything else N): a compare chain costs 32 instructions per character, and a wavefront with
 // one cluster of a multi-event bin runs its path for all its lanes
-__device__ __constant__ uint8_t NT16_CODE_OF[256] = {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 0, 15, 15, 15, 1, 14, 2, 13, 15, 15, 4, 11, 15, 15, 12, 15, 3, 15, 15, 15, 15, 5, 6, 8, 15, 7, 9, 15, 10, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};
+__device__ __constant__ uint8_t NT16_CODE_OF[256] = {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 0, 15, 15, 15, 1, 14, 2, 13, 15, 15, 4, 11, 15, 15, 12, 15, 3, 15, 15, 15, 15, 5, 6, 8, 15, 7, 9, 15, 10, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};
 
-// the CIGAR the cluster carries: the event's line holds the first five operations, its cig_ptr all of them
-__device__ __forceinline__ void pack_copy_cigar(const ClipEvent *ev, uint32_t e, int ncg, int gl, uint32_t *dc)
+// What a table row needs of the cluster at sorted slot j: its per-slot words and the carrying event's line.
+struct SlotCluster {
+	bool cluster, single;
+	uint32_t c;             // dense cluster index
+	uint64_t str_off, cig_off, key;
+	int support, ll, lr, lq, begin, ncg;
+	uint64_t src, cig_ptr;
+	uint32_t cg0, cg1, cg2, cg3, cg4;
+	uint8_t qmiss_multi;
+};
+
+__device__ __forceinline__ SlotCluster slot_cluster_load(const PackArgs &p, int64_t j)
 {
-	const uint4 *ep = reinterpret_cast<const uint4 *>(ev + e);
-	if (ncg <= 5) {
-		const uint4 c = ep[2], d = ep[3];
-		const uint32_t op = gl == 0 ? c.w : gl == 1 ? d.x : gl == 2 ? d.y : gl == 3 ? d.z : d.w;
-		if (gl < ncg) dc[gl] = op;
-	} else {
-		const uint4 b = ep[1];
-		const uint32_t *src = reinterpret_cast<const uint32_t *>((uintptr_t)((uint64_t)b.x | ((uint64_t)b.y << 32)));
-		for (int i = gl; i < ncg; i += GROUP) dc[i] = src[i];
-	}
+	SlotCluster s;
+	s.support = p.c.support[j];
+	s.cluster = s.support > 0;
+	s.single = !p.c.mflag[j];
+	const uint64_t sc = p.slot_cnt[j];
+	s.c = (uint32_t)sc; s.cig_off = sc >> 32; s.str_off = p.slot_bytes[j]; s.key = p.c.skey[j];
+	const uint32_t e = s.single ? (uint32_t)j : p.c.c_cig_ev[j];
+	const uint4 *ep = reinterpret_cast<const uint4 *>(p.c.ev + (s.cluster ? e : 0u));
+	const uint4 ea = ep[0], eb = ep[1], ec = ep[2], ed = ep[3];
+	s.src = (uint64_t)ea.z | ((uint64_t)ea.w << 32); s.cig_ptr = (uint64_t)eb.x | ((uint64_t)eb.y << 32);
+	s.begin = s.single ? (int)eb.z : 0;
+	s.ll = s.single ? (int)eb.w : p.c.c_ll[j]; s.lr = s.single ? (int)ec.x : p.c.c_lr[j];
+	s.lq = s.single ? (int)ec.y : -1; s.ncg = (int)ec.z;
+	s.cg0 = ec.w; s.cg1 = ed.x; s.cg2 = ed.y; s.cg3 = ed.z; s.cg4 = ed.w;
+	s.qmiss_multi = s.single ? 0 : p.c.c_qmiss[j];
+	return s;
 }
 
-// 16 lanes per cluster, four clusters per wavefront: strings and the CIGAR of the carrying event into dense blobs.  Every lane
-// assembles whole output dwords (a cluster's block starts 4-byte aligned and is zero padded to a multiple of 4 bytes):
-// [seq_left | qual_left | seq_right | qual_right].  Single-event clusters (97 %) are decoded from the read's packed bases /
-// qualities where the batch (or the context's copy) holds them (GetSeq, clip_reads.cpp:286-306): the group expands the read once into
-// LDS with dword loads (8 bases per packed dword, 4 qualities per dword via alignbyte and a packed +33) and then composes the output
-// dwords from LDS bytes.  Clusters of multi-event bins come from their consensus storage (left part un-reversed); reads longer than
-// PACK_MAX_LQ take the per-byte path.
-// This is the ASCII layout (ssv_clip_table_format 0, the C ABI's default); the packed layouts have their own kernel below.
-__global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
+// What the string kernels need of a cluster, dense by cluster index: 32 bytes, read coalesced.  lq < 0: a cluster of a multi-event bin
+// (consensus storage; `begin` then holds its sorted slot).
+struct PackDesc {
+	uint64_t src, str_off;
+	int32_t lq, ll, lr, begin;
+};
+static_assert(sizeof(PackDesc) == 32, "PackDesc is half a line");
+
+// one thread per sorted slot: the row's fixed columns, its CIGAR, and the descriptor for the string kernels (the `qual_missing` column
+// of single-event clusters is theirs: it takes the read's first quality byte)
+__global__ __launch_bounds__(BLOCK) void k_cluster_cols(PackArgs p, PackDesc *__restrict__ desc, uint32_t *__restrict__ out_cig)
 {
-	const int64_t n_clusters = (int64_t)*n_clusters_dev; // the grid is an upper bound (one group per event)
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= p.c.E) return;
+	const SlotCluster s = slot_cluster_load(p, j);
+	if (!s.cluster) return;
+	const uint32_t c = s.c;
+	p.tid[c] = (int32_t)(s.key >> 33);
+	p.pos[c] = (int32_t)(uint32_t)s.key;
+	p.side[c] = ((s.key >> 32) & 1ull) ? '3' : '5';
+	p.support[c] = s.support;
+	p.ll[c] = s.ll; p.lr[c] = s.lr;
+	p.ncig[c] = s.ncg;
+	p.str_off[c] = s.str_off;
+	p.cig_off[c] = s.cig_off;
+	if (!s.single) p.qmiss[c] = s.qmiss_multi;
+	uint32_t *dc = out_cig + s.cig_off;
+	if (s.ncg <= 5) {
+		if (s.ncg > 0) dc[0] = s.cg0;
+		if (s.ncg > 1) dc[1] = s.cg1;
+		if (s.ncg > 2) dc[2] = s.cg2;
+		if (s.ncg > 3) dc[3] = s.cg3;
+		if (s.ncg > 4) dc[4] = s.cg4;
+	} else {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>((uintptr_t)s.cig_ptr);
+		for (int i = 0; i < s.ncg; ++i) dc[i] = src[i];
+	}
+	uint4 *dd = reinterpret_cast<uint4 *>(desc + c);
+	dd[0] = make_uint4((uint32_t)s.src, (uint32_t)(s.src >> 32), (uint32_t)s.str_off, (uint32_t)(s.str_off >> 32));
+	dd[1] = make_uint4((uint32_t)s.lq, (uint32_t)s.ll, (uint32_t)s.lr, s.single ? (uint32_t)s.begin : (uint32_t)j);
+}
+
+// 16 lanes per sorted slot, four slots per wavefront: the strings of the slot's cluster (if it has one) into the dense blob.  Every lane
+// assembles whole output dwords (a cluster's block starts 4-byte aligned and is zero padded to a multiple of 4 bytes):
+// [seq_left | qual_left | seq_right | qual_right].  Single-event clusters (97 %) are decoded from the read's packed bases / qualities
+// where the batch (or the context's copy) holds them (GetSeq, clip_reads.cpp:286-306): the group expands the read once into LDS with dword
+// loads (8 bases per packed dword, 4 qualities per dword via alignbyte and a packed +33) and then composes the output dwords from LDS
+// bytes.  Clusters of multi-event bins come from their consensus storage (left part un-reversed); reads longer than PACK_MAX_LQ take the
+// per-byte path.  This is the ASCII layout (ssv_clip_table_format 0, the C ABI's default); the packed layouts have their own kernels below.
+__global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, uint8_t *__restrict__ out_str)
+{
 	__shared__ uint32_t s_seq[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 4];
 	__shared__ uint32_t s_qual[GROUPS_PER_BLOCK][PACK_MAX_LQ / 4 + 4];
 	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
-	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
-	const bool active = c < n_clusters;
-	int64_t j = 0;
-	int ll = 0, lr = 0, lq = -1, begin = 0;
-	bool single = false, staged = false, qmiss = false;
+	const int64_t j = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	SlotCluster sc = {};
+	if (j < p.c.E) sc = slot_cluster_load(p, j);
+	const bool active = sc.cluster;
+	const int ll = sc.ll, lr = sc.lr, lq = sc.lq, begin = sc.begin;
+	const bool single = active && sc.single;
+	bool staged = false, qmiss = false;
 	const uint8_t *sp = nullptr;
-	if (active) {
-		j = p.slot[c]; ll = p.ll[c]; lr = p.lr[c]; lq = p.src_lq[c];
-		single = lq >= 0;
-		if (single) {
-			sp = reinterpret_cast<const uint8_t *>((uintptr_t)p.src_ptr[c]);
-			begin = p.src_begin[c];
-			qmiss = lq > 0 && sp[(lq + 1) / 2] == 0xff;
-			staged = lq <= PACK_MAX_LQ;
-		}
-	}
+	if (single) {
+		sp = reinterpret_cast<const uint8_t *>((uintptr_t)sc.src);
+		qmiss = lq > 0 && sp[(lq + 1) / 2] == 0xff;
+		staged = lq <= PACK_MAX_LQ;
+	} else if (active) qmiss = sc.qmiss_multi != 0;
 	if (staged) {
 		// the read's packed bases start at any byte: aligned dword loads + alignbyte
 		const uint32_t smis = (uint32_t)(reinterpret_cast<uintptr_t>(sp) & 3u);
@@ -931,11 +1143,11 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, const 
 	}
 	__syncthreads();
 	if (!active) return;
-	if (single && gl == 0) p.qmiss[c] = qmiss ? 1 : 0;
+	if (single && gl == 0) p.qmiss[sc.c] = qmiss ? 1 : 0;
 	// one block = four pieces: sequence / quality of the left part, sequence / quality of the right part.  A piece position maps to a
 	// character through seq_at / qual_at below (three sources: the LDS stage, the read's packed bytes, the consensus storage).
 	const int total = 2 * (ll + lr);
-	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + p.str_off[c]);
+	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + sc.str_off);
 	EventView v;
 	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
 	const uint8_t *sq = reinterpret_cast<const uint8_t *>(s_seq[grp]);
@@ -972,7 +1184,6 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, const 
 		}
 		d[w] = word;
 	}
-	pack_copy_cigar(p.c.ev, p.cig_ev[c], p.ncig[c], gl, out_cig + p.cig_off[c]);
 }
 
 // ---- packed table (ssv_clip_table_format 1 / 2): sequences as 4-bit codes, qualities W bits each ----
@@ -987,205 +1198,273 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, const 
 //      Tails are zeroed, and every piece sits between zero guard dwords.
 //   2. output dword at block byte o = OR over the (1, rarely 2-3) pieces it overlaps of that piece's bytes [o - start, o - start + 4):
 //      two LDS dwords and one alignbyte each; the guards supply the zeros on either side of a piece.
-// 16 lanes per cluster.  Clusters of multi-event bins (consensus storage) and reads longer than PACK_MAX_LQ take the bytewise path.
+// 16 lanes per cluster.  The kernel is bound by memory LATENCY, not by bytes or instructions (PMC: waves parked 68 % of their cycles,
+// VALU busy 11 %, at full occupancy): per cluster it is descriptor -> read bytes -> LDS -> output, two dependent round trips to HBM.  So
+// the grid is persistent and every group of lanes runs a software pipeline over its clusters: while cluster t is composed, the bytes of
+// cluster t + 1 and the descriptor of cluster t + 2 are already on their way.
 constexpr int PACK_RAW_DWORDS = (PACK_MAX_LQ / 2 + PACK_MAX_LQ) / 4 + 3; // entry of a PACK_MAX_LQ read + misalignment + read-ahead
 constexpr int PACK_LDS_DWORDS = (PACK_MAX_LQ / 8 + 2) + (PACK_MAX_LQ / 4 + 2) + 5 + 1; // two sequence + two quality pieces of left_len + right_len <= PACK_MAX_LQ (W = 8 worst case) + guards
+constexpr int PACK_RAW_PER_LANE = PACK_RAW_DWORDS / GROUP + 1;
 
-template <int W, bool SLOW> // SLOW: the launch over p.slow_list (bytewise path); otherwise every cluster takes the dword path or is skipped
-__global__ __launch_bounds__(BLOCK) void k_cluster_pack_codes(PackArgs p, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str, uint32_t *__restrict__ out_cig)
+struct PackDescR { uint64_t src, str_off; int lq, ll, lr, begin; };
+
+__device__ __forceinline__ PackDescR pack_desc_load(const PackDesc *desc, int64_t c, int64_t nc)
 {
-	const int64_t n_clusters = (int64_t)*n_clusters_dev; // the grid is an upper bound (clusters: one group per event; slow list: multi-event slots + long reads)
+	PackDescR d;
+	d.src = 0; d.str_off = 0; d.lq = -1; d.ll = 0; d.lr = 0; d.begin = 0;
+	if (c < nc) {
+		const uint4 *p = reinterpret_cast<const uint4 *>(desc + c);
+		const uint4 a = p[0], b = p[1];
+		d.src = (uint64_t)a.x | ((uint64_t)a.y << 32); d.str_off = (uint64_t)a.z | ((uint64_t)a.w << 32);
+		d.lq = (int)b.x; d.ll = (int)b.y; d.lr = (int)b.z; d.begin = (int)b.w;
+	}
+	return d;
+}
+
+__device__ __forceinline__ bool pack_desc_fast(const PackDescR &d) { return d.lq >= 0 && d.lq <= PACK_MAX_LQ; }
+
+// the read's entry from the dword-aligned address below it: this lane's share of the loads, all issued at once
+__device__ __forceinline__ void pack_entry_load(const PackDescR &d, int gl, uint32_t (&r)[PACK_RAW_PER_LANE])
+{
+	const int mis = (int)(d.src & 3ull);
+	const uint32_t *g4 = reinterpret_cast<const uint32_t *>((uintptr_t)(d.src - (uint64_t)mis));
+	const int nraw = pack_desc_fast(d) ? (mis + (d.lq + 1) / 2 + d.lq + 3) / 4 + 1 : 0; // + one dword of read-ahead for the unaligned windows (8 bytes of slack behind seqqual, seeksv_hip.h)
+#pragma unroll
+	for (int u = 0; u < PACK_RAW_PER_LANE; ++u) { const int i = gl + GROUP * u; r[u] = i < nraw && i < PACK_RAW_DWORDS ? g4[i] : 0u; }
+}
+
+// TRACK: also note every phred value met in p.qual_seen (the rare second launch after a quality outside the guessed alphabet turned up).
+// PIPE: the persistent, software-pipelined form (88 registers: five wavefronts per SIMD); without it one cluster per group of lanes and the
+// grid covers all clusters (58 registers: eight wavefronts per SIMD).
+template <int W, bool TRACK, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_cluster_pack_stream(PackArgs p, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str)
+{
 	__shared__ uint32_t s_piece[GROUPS_PER_BLOCK][PACK_LDS_DWORDS];
 	__shared__ uint32_t s_raw[GROUPS_PER_BLOCK][PACK_RAW_DWORDS]; // the read's entry (packed bases, qualities) as it lies in memory, from the aligned address below it
 	__shared__ uint8_t s_lut[256]; // phred -> alphabet index
-	__shared__ uint8_t s_code[256]; // character -> 4-bit code (bytewise path)
 	__shared__ uint32_t s_seen[8];  // phred values met (bit set)
 	if (W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256
-	if (SLOW) s_code[threadIdx.x] = NT16_CODE_OF[threadIdx.x];
 	if (threadIdx.x < 8) s_seen[threadIdx.x] = 0;
 	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
-	const int64_t k_ = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
-	const int64_t c = SLOW ? (k_ < n_clusters ? (int64_t)p.slow_list[k_] : 0) : k_; // SLOW: n_clusters = entries of the list
-	bool active = k_ < n_clusters;
-	int ll = 0, lr = 0, lq = -1, begin = 0;
-	uint64_t sptr = 0;
-	int ncg = 0;
-	uint32_t cev = 0;
-	uint64_t dcig = 0, doff = 0;
-	if (active) { ll = p.ll[c]; lr = p.lr[c]; lq = p.src_lq[c]; begin = p.src_begin[c]; sptr = p.src_ptr[c]; ncg = p.ncig[c]; cev = p.cig_ev[c]; dcig = p.cig_off[c]; doff = p.str_off[c]; }
-	const bool fast = !SLOW && active && lq >= 0 && lq <= PACK_MAX_LQ && ll + lr <= PACK_MAX_LQ;
-	if (!SLOW) active = fast; // the others are on the slow list
-	// piece k: 0 seq_left, 1 qual_left, 2 seq_right, 3 qual_right; nB bytes, nD dwords, at block byte oP, at LDS dword st
-	int nB[4], nD[4], oP[4], st[4];
-	nB[0] = (ll + 1) / 2; nB[1] = (ll * W + 7) / 8; nB[2] = (lr + 1) / 2; nB[3] = (lr * W + 7) / 8;
-	{
-		int o = 0, s_ = 1;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { nD[k] = (nB[k] + 3) / 4; oP[k] = o; st[k] = s_; o += nB[k]; s_ += nD[k] + 1; }
-	}
-	const int total = oP[3] + nB[3];
+	const int64_t nc = (int64_t)*n_clusters_dev;
+	const int64_t step = (int64_t)gridDim.x * GROUPS_PER_BLOCK;
+	int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
 	uint32_t *L = s_piece[grp];
 	const uint32_t *s4 = s_raw[grp];
-	const int mis = (int)(sptr & 3ull);     // the entry starts mis bytes into s_raw
-	const int qb = mis + (lq + 1) / 2;      // first quality byte of the entry inside s_raw
-	if (fast) {
-		// 0. the whole entry into LDS with one batch of independent loads (one memory round trip per cluster; everything after reads LDS)
-		const uint32_t *g4 = reinterpret_cast<const uint32_t *>((uintptr_t)(sptr - (uint64_t)mis));
-		const int nraw = (qb + lq + 3) / 4 + 1; // + one dword of read-ahead for the unaligned windows below (8 bytes of slack behind seqqual, seeksv_hip.h)
-		uint32_t r[PACK_RAW_DWORDS / GROUP + 1];
-#pragma unroll
-		for (int u = 0; u < PACK_RAW_DWORDS / GROUP + 1; ++u) { const int i = gl + GROUP * u; r[u] = i < nraw && i < PACK_RAW_DWORDS ? g4[i] : 0u; }
-#pragma unroll
-		for (int u = 0; u < PACK_RAW_DWORDS / GROUP + 1; ++u) { const int i = gl + GROUP * u; if (i < nraw && i < PACK_RAW_DWORDS) s_raw[grp][i] = r[u]; }
-	}
-	__syncthreads(); // s_raw, s_lut
-	bool qmiss = false;
-	if (fast) {
-		qmiss = lq > 0 && ((s4[qb >> 2] >> (8 * (qb & 3))) & 0xffu) == 0xffu;
-		if (gl == 0) { L[0] = 0u; p.qmiss[c] = qmiss ? 1 : 0; } // guards: before the first piece and after each piece
-#pragma unroll
-		for (int k = 0; k < 4; ++k) if (gl == k + 1) L[st[k] + nD[k]] = 0u;
-		// sequence pieces (the dwords of both pieces share one index space: with 16 lanes and ~10 dwords per piece, a loop per piece
-		// would leave half the lanes idle in each - and this kernel is VALU bound, 93 % busy in the PMC pass)
-		for (int tt = gl; tt < nD[0] + nD[2]; tt += GROUP) {
-			const bool h = tt >= nD[0];
-			const int t = h ? tt - nD[0] : tt;
-			const int nib0 = begin + (h ? ll : 0), len = h ? lr : ll;
-			{
-				const int B = mis + (nib0 >> 1) + 4 * t;
-				const uint32_t d0 = s4[B >> 2], d1 = s4[(B >> 2) + 1];
-				const uint64_t X = (((uint64_t)d1 << 32) | d0) >> (8 * (B & 3));
-				const uint32_t lo = (uint32_t)X, nx = (uint32_t)(X >> 8);
-				uint32_t v = (nib0 & 1) ? (((lo & 0x0f0f0f0fu) << 4) | ((nx >> 4) & 0x0f0f0f0fu)) : lo;
-				const int rem = len - 8 * t; // nibbles of the piece in this dword
-				if (rem < 8) v &= ((1u << (8 * (rem >> 1))) - 1u) | ((rem & 1) ? 0xf0u << (8 * (rem >> 1)) : 0u);
-				L[(h ? st[2] : st[0]) + t] = v;
-			}
+	// pipeline prologue
+	PackDescR d0 = pack_desc_load(desc, c, nc), d1 = d0, d2 = d0;
+	if (PIPE) d1 = pack_desc_load(desc, c + step, nc);
+	uint32_t r[PACK_RAW_PER_LANE], rn[PACK_RAW_PER_LANE];
+	pack_entry_load(d0, gl, r);
+	for (int64_t cb = (int64_t)blockIdx.x * GROUPS_PER_BLOCK; cb < nc; cb += step) { // the workgroup's trip count is uniform: barriers inside
+		if (PIPE) {
+			d2 = pack_desc_load(desc, c + 2 * step, nc); // cluster t + 2: its descriptor
+			pack_entry_load(d1, gl, rn);                  // cluster t + 1: its bytes
 		}
-		// quality pieces: a piece is the bit stream of its W-bit indices, quality i at stream bit i * W (for W = 3 an index can straddle
-		// a byte or a dword); dword t of the piece = stream bits [32 t, 32 t + 32) = the CNT qualities from i0 = 32 t / W on, shifted
-		uint32_t seen_lo = 0, seen_hi = 0; // phred 0..63 as a bit set in registers (anything higher goes straight to LDS)
-		for (int tt = gl; tt < nD[1] + nD[3]; tt += GROUP) {
-			const bool h = tt >= nD[1];
-			const int t = h ? tt - nD[1] : tt;
-			const int q0 = begin + (h ? ll : 0), len = h ? lr : ll;
-			{
-				constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
-				const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
-				const int a = qb + q0 + i0;                            // first source byte
-				const uint32_t *q4 = s4 + (a >> 2);
-				const int sh = a & 3;
-				const int rem = len - i0;                              // qualities of the piece from i0 on
-				uint64_t acc = 0;
-				uint32_t prev = q4[0];
+		const bool fast = pack_desc_fast(d0);
+		const int ll = d0.ll, lr = d0.lr, lq = d0.lq, begin = d0.begin;
+		const int mis = (int)(d0.src & 3ull);     // the entry starts mis bytes into s_raw
+		const int qb = mis + (lq + 1) / 2;        // first quality byte of the entry inside s_raw
+		// piece k: 0 seq_left, 1 qual_left, 2 seq_right, 3 qual_right; nB bytes, nD dwords, at block byte oP, at LDS dword st
+		int nB[4], nD[4], oP[4], st[4];
+		nB[0] = (ll + 1) / 2; nB[1] = (ll * W + 7) / 8; nB[2] = (lr + 1) / 2; nB[3] = (lr * W + 7) / 8;
+		{
+			int o = 0, s_ = 1;
 #pragma unroll
-				for (int g = 0; g < (CNT + 3) / 4; ++g) {
-					if (4 * g >= rem) break; // nothing of the piece left (also keeps the reads inside the staged entry)
-					const uint32_t next = q4[g + 1];
-					const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
-					prev = next;
-					if (W == 8) acc = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
-					else {
+			for (int k = 0; k < 4; ++k) { nD[k] = (nB[k] + 3) / 4; oP[k] = o; st[k] = s_; o += nB[k]; s_ += nD[k] + 1; }
+		}
+		const int total = oP[3] + nB[3];
+		if (fast) {
+			// 0. the whole entry into LDS (its loads were issued one cluster ago)
+			const int nraw = (qb + lq + 3) / 4 + 1;
 #pragma unroll
-						for (int b = 0; b < 4; ++b) {
-							const int j = 4 * g + b;
-							const uint32_t ph = (four >> (8 * b)) & 0xffu;
-							// every quality is encoded by exactly one dword of its piece's stream (the one holding its first bit): j < CNT' where CNT' stops
-							// at the next dword's first quality; marking it "seen" here covers each quality at least once
-							if (j < CNT && j < rem && !qmiss) {
-								acc |= (uint64_t)(s_lut[ph] & ((1u << W) - 1u)) << (j * W);
-								if (ph < 32) seen_lo |= 1u << ph; else if (ph < 64) seen_hi |= 1u << (ph - 32); else atomicOr(&s_seen[ph >> 5], 1u << (ph & 31));
+			for (int u = 0; u < PACK_RAW_PER_LANE; ++u) { const int i = gl + GROUP * u; if (i < nraw && i < PACK_RAW_DWORDS) s_raw[grp][i] = r[u]; }
+		}
+		__syncthreads(); // s_raw (and s_lut the first time)
+		bool qmiss = false;
+		if (fast) {
+			qmiss = lq > 0 && ((s4[qb >> 2] >> (8 * (qb & 3))) & 0xffu) == 0xffu;
+			if (gl == 0) { L[0] = 0u; p.qmiss[c] = qmiss ? 1 : 0; } // guards: before the first piece and after each piece
+#pragma unroll
+			for (int k = 0; k < 4; ++k) if (gl == k + 1) L[st[k] + nD[k]] = 0u;
+			// sequence pieces (the dwords of both pieces share one index space: with 16 lanes and ~10 dwords per piece, a loop per piece
+			// would leave half the lanes idle in each)
+			for (int tt = gl; tt < nD[0] + nD[2]; tt += GROUP) {
+				const bool h = tt >= nD[0];
+				const int t = h ? tt - nD[0] : tt;
+				const int nib0 = begin + (h ? ll : 0), len = h ? lr : ll;
+				{
+					const int B = mis + (nib0 >> 1) + 4 * t;
+					const uint32_t w0 = s4[B >> 2], w1 = s4[(B >> 2) + 1];
+					const uint64_t X = (((uint64_t)w1 << 32) | w0) >> (8 * (B & 3));
+					const uint32_t lo = (uint32_t)X, nx = (uint32_t)(X >> 8);
+					uint32_t v = (nib0 & 1) ? (((lo & 0x0f0f0f0fu) << 4) | ((nx >> 4) & 0x0f0f0f0fu)) : lo;
+					const int rem = len - 8 * t; // nibbles of the piece in this dword
+					if (rem < 8) v &= ((1u << (8 * (rem >> 1))) - 1u) | ((rem & 1) ? 0xf0u << (8 * (rem >> 1)) : 0u);
+					L[(h ? st[2] : st[0]) + t] = v;
+				}
+			}
+			// quality pieces: a piece is the bit stream of its W-bit indices, quality i at stream bit i * W (for W = 3 an index can straddle
+			// a byte or a dword); dword t of the piece = stream bits [32 t, 32 t + 32) = the CNT qualities from i0 = 32 t / W on, shifted
+			uint32_t seen_lo = 0, seen_hi = 0; // TRACK: phred 0..63 as a bit set in registers (anything higher goes straight to LDS)
+			uint32_t miss = 0;                 // OR of the table look-ups: 0xff marks a value outside the alphabet
+			for (int tt = gl; tt < nD[1] + nD[3]; tt += GROUP) {
+				const bool h = tt >= nD[1];
+				const int t = h ? tt - nD[1] : tt;
+				const int q0 = begin + (h ? ll : 0), len = h ? lr : ll;
+				{
+					constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
+					const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
+					const int a = qb + q0 + i0;                            // first source byte
+					const uint32_t *q4 = s4 + (a >> 2);
+					const int sh = a & 3;
+					const int rem = len - i0;                              // qualities of the piece from i0 on
+					uint64_t acc = 0;
+					uint32_t prev = q4[0];
+#pragma unroll
+					for (int g = 0; g < (CNT + 3) / 4; ++g) {
+						if (4 * g >= rem) break; // nothing of the piece left (also keeps the reads inside the staged entry)
+						const uint32_t next = q4[g + 1];
+						const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
+						prev = next;
+						if (W == 8) acc = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
+						else {
+#pragma unroll
+							for (int b = 0; b < 4; ++b) {
+								const int jq = 4 * g + b;
+								const uint32_t ph = (four >> (8 * b)) & 0xffu;
+								const uint32_t idx = s_lut[ph];
+								const bool ok = jq < CNT && jq < rem;
+								acc |= ok ? (uint64_t)(idx & ((1u << W) - 1u)) << (jq * W) : 0ull;
+								miss |= ok ? idx : 0u;
+								if (TRACK && ok) { if (ph < 32) seen_lo |= 1u << ph; else if (ph < 64) seen_hi |= 1u << (ph - 32); else atomicOr(&s_seen[ph >> 5], 1u << (ph & 31)); }
 							}
 						}
 					}
+					uint32_t v = qmiss && W < 8 ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
+					if (W == 8 && rem < 4) v &= (1u << (8 * rem)) - 1u;
+					L[(h ? st[3] : st[1]) + t] = v;
 				}
-				uint32_t v = (uint32_t)(acc >> off);
-				if (W == 8 && rem < 4) v &= (1u << (8 * rem)) - 1u;
-				L[(h ? st[3] : st[1]) + t] = v;
+			}
+			if (W < 8 && !qmiss) {
+				if (miss & 0x80u) *p.lut_miss = 1;
+				if (TRACK) {
+					if (seen_lo) atomicOr(&s_seen[0], seen_lo);
+					if (seen_hi) atomicOr(&s_seen[1], seen_hi);
+				}
 			}
 		}
-		if (W < 8) {
-			if (seen_lo) atomicOr(&s_seen[0], seen_lo);
-			if (seen_hi) atomicOr(&s_seen[1], seen_hi);
+		__syncthreads();
+		if (fast) {
+			uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
+			for (int w = gl; 4 * w < total; w += GROUP) {
+				const int o = 4 * w;
+				uint32_t word = 0;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					if (o + 4 > oP[k] && o < oP[k] + nB[k]) {
+						const int r0 = o - oP[k];     // -3 .. nB - 1
+						const int i = st[k] + (r0 >> 2); // floor: -1 reads the guard in front of the piece
+						word |= __builtin_amdgcn_alignbyte(L[i + 1], L[i], (uint32_t)(r0 & 3));
+					}
+				}
+				d[w] = word;
+			}
 		}
+		if (!PIPE) break;
+		// next cluster of this group
+		d0 = d1; d1 = d2;
+#pragma unroll
+		for (int u = 0; u < PACK_RAW_PER_LANE; ++u) r[u] = rn[u];
+		c += step;
 	}
 	__syncthreads();
-	if (W < 8 && threadIdx.x < 8 && s_seen[threadIdx.x] && !SLOW) { // one look per workgroup; an atomic only while the set still grows
+	if (TRACK && W < 8 && threadIdx.x < 8 && s_seen[threadIdx.x]) { // one look per workgroup; an atomic only while the set still grows
 		const uint32_t have = __atomic_load_n(&p.qual_seen[threadIdx.x], __ATOMIC_RELAXED);
 		if (s_seen[threadIdx.x] & ~have) atomicOr(&p.qual_seen[threadIdx.x], s_seen[threadIdx.x]);
 	}
-	if (!active) return;
-	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + doff);
-	if (fast) {
-		for (int w = gl; 4 * w < total; w += GROUP) {
-			const int o = 4 * w;
-			uint32_t word = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				if (o + 4 > oP[k] && o < oP[k] + nB[k]) {
-					const int r0 = o - oP[k];     // -3 .. nB - 1
-					const int i = st[k] + (r0 >> 2); // floor: -1 reads the guard in front of the piece
-					word |= __builtin_amdgcn_alignbyte(L[i + 1], L[i], (uint32_t)(r0 & 3));
-				}
-			}
-			d[w] = word;
-		}
-	} else if (SLOW) {
-		// bytewise: from the read's packed bytes (long reads) or from the consensus storage (left part kept reversed)
-		const int64_t j = p.slot[c];
-		const bool single = lq >= 0;
-		EventView v;
-		const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
-		bool qm;
-		if (single) {
-			v.sp = reinterpret_cast<const uint8_t *>((uintptr_t)sptr); v.qp = v.sp + (lq + 1) / 2; v.begin = begin; v.ll = ll; v.lr = lr; v.qmiss = lq > 0 && v.qp[0] == 0xff;
-			qm = v.qmiss;
-			if (gl == 0) p.qmiss[c] = qm ? 1 : 0;
-		} else {
-			const int64_t stride = 2ll * (p.c.SL + p.c.SR);
-			cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
-			cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
-			qm = p.c.c_qmiss[j] != 0;
-		}
-		auto seq_at = [&](bool right, int i) -> uint32_t {
-			return s_code[single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i])];
-		};
-		auto qual_at = [&](bool right, int i) -> uint32_t { // character
-			return single ? (uint32_t)(uint8_t)v.qual(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rq[i] : cq[ll - 1 - i]);
-		};
-		auto qual_index = [&](bool right, int i) -> uint32_t { // W < 8: alphabet index of quality i (0 when the cluster has no qualities)
-			if (qm) return 0u;
-			const uint32_t ph = (qual_at(right, i) - 33u) & 255u;
-			atomicOr(&p.qual_seen[ph >> 5], 1u << (ph & 31)); // the slow list is a few thousand clusters
-			return (uint32_t)(s_lut[ph] & ((1u << W) - 1u));
-		};
-		const int A = nB[0], QA = nB[1], C = nB[2];
-		for (int w = gl; w * 4 < total; w += GROUP) {
-			uint32_t word = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const int q = w * 4 + k;
-				uint32_t ch = 0;
-				if (q < total) {
-					const bool right = q >= A + QA;
-					const int r = right ? q - A - QA : q, S = right ? C : A, n = right ? lr : ll;
-					if (r >= S) {
-						if (W == 8) ch = qual_at(right, r - S);
-						else { // stream bits [8 r', 8 r' + 8) of the quality piece
-							const int bit0 = 8 * (r - S), i0 = bit0 / W, off = bit0 - W * i0;
-							uint32_t acc = 0;
-							for (int jq = 0, i = i0; W * jq < off + 8 && i < n; ++jq, ++i) acc |= qual_index(right, i) << (W * jq);
-							ch = (acc >> off) & 0xffu;
-						}
-					} else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
-				}
-				word |= ch << (8 * k);
-			}
-			d[w] = word;
-		}
+}
+
+// The bytewise path: the slots of multi-event bins (mlist; those without a cluster leave at once: consensus storage, left part kept
+// reversed), then the listed single-event clusters of reads longer than PACK_MAX_LQ (the grid is an upper bound of that list's length).
+template <int W, bool TRACK>
+__global__ __launch_bounds__(BLOCK) void k_cluster_pack_slow(PackArgs p, uint8_t *__restrict__ out_str)
+{
+	__shared__ uint8_t s_lut[256];  // phred -> alphabet index
+	__shared__ uint8_t s_code[256]; // character -> 4-bit code
+	__shared__ uint32_t s_seen[8];  // phred values met (bit set)
+	if (W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256
+	s_code[threadIdx.x] = NT16_CODE_OF[threadIdx.x];
+	if (threadIdx.x < 8) s_seen[threadIdx.x] = 0;
+	__syncthreads();
+	const int grp = (int)(threadIdx.x / GROUP);
+	const int gl = (int)(threadIdx.x % GROUP);
+	const int64_t k_ = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const int64_t n_items = p.c.M + (int64_t)*p.slow_count;
+	if (k_ >= n_items) return;
+	const int64_t j = k_ < p.c.M ? (int64_t)p.c.mlist[k_] : (int64_t)p.slow_list[k_ - p.c.M];
+	const SlotCluster sc = slot_cluster_load(p, j);
+	if (!sc.cluster) return;
+	const int ll = sc.ll, lr = sc.lr, lq = sc.lq, begin = sc.begin;
+	const bool single = lq >= 0;
+	const int nB0 = (ll + 1) / 2, nB1 = (ll * W + 7) / 8, nB2 = (lr + 1) / 2, nB3 = (lr * W + 7) / 8;
+	const int total = nB0 + nB1 + nB2 + nB3;
+	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + sc.str_off);
+	EventView v;
+	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+	bool qm;
+	if (single) {
+		v.sp = reinterpret_cast<const uint8_t *>((uintptr_t)sc.src); v.qp = v.sp + (lq + 1) / 2; v.begin = begin; v.ll = ll; v.lr = lr; v.qmiss = lq > 0 && v.qp[0] == 0xff;
+		qm = v.qmiss;
+		if (gl == 0) p.qmiss[sc.c] = qm ? 1 : 0;
+	} else {
+		const int64_t stride = 2ll * (p.c.SL + p.c.SR);
+		cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
+		cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
+		qm = sc.qmiss_multi != 0;
 	}
-	pack_copy_cigar(p.c.ev, cev, ncg, gl, out_cig + dcig);
+	auto seq_at = [&](bool right, int i) -> uint32_t {
+		return s_code[single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i])];
+	};
+	auto qual_at = [&](bool right, int i) -> uint32_t { // character
+		return single ? (uint32_t)(uint8_t)v.qual(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rq[i] : cq[ll - 1 - i]);
+	};
+	auto qual_index = [&](bool right, int i) -> uint32_t { // W < 8: alphabet index of quality i (0 when the cluster has no qualities)
+		if (qm) return 0u;
+		const uint32_t ph = (qual_at(right, i) - 33u) & 255u;
+		if (TRACK) {
+			const uint32_t bit = 1u << (ph & 31);
+			if (!(atomicOr(&s_seen[ph >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph >> 5], bit); // the first time this workgroup meets the value (millions of atomics on two words would take ~10 ns each)
+		}
+		const uint32_t idx = s_lut[ph];
+		if (idx & 0x80u) *p.lut_miss = 1;
+		return idx & ((1u << W) - 1u);
+	};
+	const int A = nB0, QA = nB1, C = nB2;
+	for (int w = gl; w * 4 < total; w += GROUP) {
+		uint32_t word = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int q = w * 4 + k;
+			uint32_t ch = 0;
+			if (q < total) {
+				const bool right = q >= A + QA;
+				const int r = right ? q - A - QA : q, S = right ? C : A, n = right ? lr : ll;
+				if (r >= S) {
+					if (W == 8) ch = qual_at(right, r - S);
+					else { // stream bits [8 r', 8 r' + 8) of the quality piece
+						const int bit0 = 8 * (r - S), i0 = bit0 / W, off = bit0 - W * i0;
+						uint32_t acc = 0;
+						for (int jq = 0, i = i0; W * jq < off + 8 && i < n; ++jq, ++i) acc |= qual_index(right, i) << (W * jq);
+						ch = (acc >> off) & 0xffu;
+					}
+				} else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
+			}
+			word |= ch << (8 * k);
+		}
+		d[w] = word;
+	}
 }
 
 } // namespace ssv

@@ -24,7 +24,7 @@ __device__ __forceinline__ bool is_hard_clip(const DevBatch &b, const RecLine &r
 // K4 insert-size statistics
 // ---------------------------------------------------------------------------------------------------------------------
 
-constexpr int ISZ_ITEMS = 4;
+constexpr int ISZ_ITEMS = 1;           // one record line per lane: consecutive lanes read consecutive 64-byte lines
 constexpr int ISZ_TILE = BLOCK * ISZ_ITEMS;
 
 // cluster.cpp:51-67: MAPQ >= q, not hard clipped, PAIRED && PROPER_PAIR && !DUP && isize > 0
@@ -72,9 +72,11 @@ __global__ __launch_bounds__(BLOCK) void k_isize_collect(DevBatch b, int min_map
 }
 
 // sum of vals (mode 0) or of the int-wrapped squared deviations from mean (mode 1, cluster.cpp:77) into *acc
-__global__ __launch_bounds__(BLOCK) void k_isize_reduce(const int32_t *__restrict__ vals, int64_t n, int mode, int mean, long long *__restrict__ acc)
+// mode 1: the mean is formed on the device from the sum the mode-0 launch left in mean_from[0] (cluster.cpp:72: unsigned long division)
+__global__ __launch_bounds__(BLOCK) void k_isize_reduce(const int32_t *__restrict__ vals, int64_t n, int mode, const long long *__restrict__ mean_from, long long *__restrict__ acc)
 {
 	__shared__ long long lds[WAVES_PER_BLOCK];
+	const int mean = mode ? (int)((unsigned long)*mean_from / (unsigned long)n) : 0;
 	long long s = 0;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		int x = vals[i];

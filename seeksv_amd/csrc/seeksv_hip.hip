@@ -71,17 +71,18 @@ struct ssv_ctx {
 	// ---- getclip ----
 	bool clip_active = false;
 	ssv_clip_params clip_p{};
-	DBuf d_last_tid, stage, cand, cand_cnt, cand_off, stash;
+	DBuf d_last_tid, stage, cand, cand_cnt, cand_off, kv_stage;
 	int64_t stage_cap = 0;
-	DBuf ev, key_l, val_l, key_r[2], val_r[2];  // the pass's events (BAM order) and the sort keys / event indices of the two sides
+	DBuf ev, ev_meta, ev_idx, key_l, val_l, key_r[2], val_r[2];  // the pass's event lines (slots, with holes), per event in BAM order (l_qseq, n_cigar) and slot, and the sort keys / slots of the two sides
+	int64_t ev_slots = 0;                                        // slots handed out so far
 	int64_t ev_cap = 0, n_events = 0, n_l = 0, n_r = 0, n_long = 0;
 	DBuf g_seq_bytes, g_cig_ops, g_seq_off, g_cig_off; // the copying path (batches without SSV_MEM_PERSISTENT)
 	Arena blob;
-	uint64_t max_key = 0, sum_ncig = 0;
-	int max_ll = 0, max_lr = 0;
+	uint64_t sum_ncig = 0;
+	int max_lq = 0;
 	// clustering temporaries / outputs
-	DBuf keys2[2], vals2[2], cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_strings, slot_cnt, slot_bytes;
-	DBuf o_slot, o_srcptr, o_srcbegin, o_srclq, o_cigev, o_slowlist, totals;
+	DBuf keys2[2], vals2[2], evs, cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_bflag, c_boff, c_blist, c_strings, slot_cnt, slot_bytes;
+	DBuf o_slowlist, o_desc, totals;
 	HBuf h_totals;
 	// the dense cluster table: device columns + pinned host copy, double buffered so that the PCIe copy of one table can overlap
 	// with whatever the caller runs next (ssv_clip_cluster_async / ssv_clip_table_wait)
@@ -317,7 +318,8 @@ int ensure_events(ssv_ctx *c, int64_t need)
 	if (need <= c->ev_cap) return SSV_OK;
 	int64_t ncap = std::max<int64_t>(need, c->ev_cap + c->ev_cap / 2);
 	ncap = std::max<int64_t>(ncap, 1 << 16);
-	CHECK(ensure(c, c->ev, (size_t)ncap * sizeof(ClipEvent), true, (size_t)c->n_events * sizeof(ClipEvent)));
+	CHECK(ensure(c, c->ev_meta, (size_t)ncap * 8, true, (size_t)c->n_events * 8));
+	CHECK(ensure(c, c->ev_idx, (size_t)ncap * 4, true, (size_t)c->n_events * 4));
 	CHECK(ensure(c, c->key_l, (size_t)ncap * 8, true, (size_t)c->n_l * 8));
 	CHECK(ensure(c, c->val_l, (size_t)ncap * 4, true, (size_t)c->n_l * 4));
 	CHECK(ensure(c, c->key_r[0], (size_t)ncap * 8, true, (size_t)c->n_r * 8));
@@ -385,10 +387,10 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
 	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
 	// every DBuf / HBuf member
-	DBuf *dbufs[] = {&c->sb_rec, &c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->stash,
-	                 &c->ev, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_strings,
-	                 &c->slot_cnt, &c->slot_bytes, &c->o_slot, &c->o_srcptr, &c->o_srcbegin, &c->o_srclq, &c->o_cigev, &c->o_slowlist, &c->totals, &c->qual_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc,
+	DBuf *dbufs[] = {&c->sb_rec, &c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage,
+	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_strings,
+	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc,
 	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry,
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
@@ -432,7 +434,7 @@ int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 	HIPCHECK(c, hipSetDevice(c->device));
 	c->clip_p = *p;
 	c->clip_active = true;
-	c->n_events = 0; c->n_l = 0; c->n_r = 0; c->n_long = 0; c->max_key = 0; c->sum_ncig = 0; c->max_ll = 0; c->max_lr = 0;
+	c->n_events = 0; c->n_l = 0; c->n_r = 0; c->n_long = 0; c->sum_ncig = 0; c->max_lq = 0; c->ev_slots = 0;
 	c->blob.cur = 0; c->blob.used = 0;
 	CHECK(ensure(c, c->d_last_tid, 16));
 	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
@@ -487,12 +489,17 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 	}
 	const int64_t ncand = (int64_t)(uint32_t)hc->n_cand;
 	if (ncand > 0) {
-		int64_t nb = 0;
+		int64_t nb = 0, slot_base = 0;
+		(void)slot_base;
 		{
 			ProfScope ps(c, P_CLIP_PLACE, ncand);
-			CHECK(ensure(c, c->cand, ncand * 4)); CHECK(ensure(c, c->cand_cnt, ncand * 8)); CHECK(ensure(c, c->cand_off, ncand * 8));
-			CHECK(ensure(c, c->stash, (size_t)(ncand + WAVE) * 2 * sizeof(ClipEvent)));
-			CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(ncand) * 8));
+			const int64_t nwave = (ncand + 15) / 16; // k_clip_filter: four lanes per candidate, 16 candidates per wavefront
+			CHECK(ensure(c, c->cand, ncand * 4)); CHECK(ensure(c, c->cand_cnt, ncand + 64)); CHECK(ensure(c, c->cand_off, nwave * 8));
+			const int64_t nslot = 2 * (((ncand + 63) / 64) * 64); // two per candidate, whole workgroups (64 candidates each)
+			if (c->ev_slots + nslot >= (1ll << 32) - 1) { c->err = "more than 2^32 event slots in one pass (the sorted permutation is 32 bits wide)"; return SSV_E_RANGE; }
+			CHECK(ensure(c, c->ev, (size_t)(c->ev_slots + nslot) * sizeof(ClipEvent), true, (size_t)c->ev_slots * sizeof(ClipEvent)));
+			CHECK(ensure(c, c->kv_stage, (size_t)nslot * 16));
+			CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nwave) * 8));
 			CHECK(ensure_events(c, c->n_events + 2 * ncand));
 			k_cand_place<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<uint32_t>(c->stage), P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_off), P<uint32_t>(c->tile_base), ntiles,
 			                                                                    P<uint32_t>(c->cand));
@@ -501,24 +508,26 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			f.use_ownership = c->clip_p.use_ownership;
 			f.own_lo = ((long long)c->clip_p.own_lo_tid << 32) | (long long)(uint32_t)c->clip_p.own_lo_pos;
 			f.own_hi = ((long long)c->clip_p.own_hi_tid << 32) | (long long)(uint32_t)c->clip_p.own_hi_pos;
-			k_clip_filter<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(f, P<uint32_t>(c->cand), ncand, P<ClipEvent>(c->stash), P<uint64_t>(c->cand_cnt));
-			exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->cand_cnt), P<uint64_t>(c->cand_off), ncand, 0ull, P<uint64_t>(c->scan_scratch64), reinterpret_cast<uint64_t *>(&dc->n_new));
+			k_clip_filter<<<grid_for(ncand, BLOCK / 4), BLOCK, 0, c->st>>>(f, P<uint32_t>(c->cand), ncand, P<ClipEvent>(c->ev) + c->ev_slots, P<uint4>(c->kv_stage), P<uint8_t>(c->cand_cnt), P<uint64_t>(c->cand_off));
+			exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->cand_off), P<uint64_t>(c->cand_off), nwave, 0ull, P<uint64_t>(c->scan_scratch64), reinterpret_cast<uint64_t *>(&dc->n_new));
 			EventLists L;
-			L.ev = P<ClipEvent>(c->ev); L.key_l = P<uint64_t>(c->key_l); L.val_l = P<uint32_t>(c->val_l); L.key_r = P<uint64_t>(c->key_r[0]); L.val_r = P<uint32_t>(c->val_r[0]);
-			k_clip_place<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(P<ClipEvent>(c->stash), P<uint64_t>(c->cand_cnt), P<uint64_t>(c->cand_off), ncand, L, c->n_events, c->n_l, c->n_r);
-			k_event_max<<<256, BLOCK, 0, c->st>>>(P<ClipEvent>(c->ev), c->n_events, dc);
+			L.key_l = P<uint64_t>(c->key_l); L.val_l = P<uint32_t>(c->val_l); L.key_r = P<uint64_t>(c->key_r[0]); L.val_r = P<uint32_t>(c->val_r[0]);
+			L.meta = P<uint2>(c->ev_meta); L.idx = P<uint32_t>(c->ev_idx);
+			k_clip_place<<<grid_for(ncand, BLOCK), BLOCK, 0, c->st>>>(P<uint4>(c->kv_stage), P<uint8_t>(c->cand_cnt), P<uint64_t>(c->cand_off), ncand, L, c->n_events, c->n_l, c->n_r, c->ev_slots);
+			k_event_max<<<512, BLOCK, 0, c->st>>>(P<uint2>(c->ev_meta), c->n_events, dc);
 			HIPCHECK(c, hipGetLastError());
 			HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
 			HIPCHECK(c, hipStreamSynchronize(c->st));
 			nb = (int64_t)(uint32_t)hc->n_new;
-			if (c->n_events + nb >= (1ll << 32) - 1) { c->err = "more than 2^32 clip events in one pass (the sorted permutation is 32 bits wide)"; return SSV_E_RANGE; }
+			slot_base = c->ev_slots;
+			c->ev_slots += nslot;
 		}
 		if (nb > 0 && !persistent) {
 			// the batch's buffers may be recycled after this call: the bytes its events point at move into context memory
 			ProfScope ps(c, P_CLIP_GATHER, nb);
 			CHECK(ensure(c, c->g_seq_bytes, nb * 4)); CHECK(ensure(c, c->g_cig_ops, nb * 4)); CHECK(ensure(c, c->g_seq_off, nb * 8)); CHECK(ensure(c, c->g_cig_off, nb * 8));
 			CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(nb) * 8));
-			k_gather_sizes<<<grid_for(nb, BLOCK), BLOCK, 0, c->st>>>(P<ClipEvent>(c->ev), c->n_events, nb, P<uint32_t>(c->g_seq_bytes), P<uint32_t>(c->g_cig_ops));
+			k_gather_sizes<<<grid_for(nb, BLOCK), BLOCK, 0, c->st>>>(P<uint2>(c->ev_meta), c->n_events, nb, P<uint32_t>(c->g_seq_bytes), P<uint32_t>(c->g_cig_ops));
 			exclusive_scan<uint32_t, uint64_t>(c->st, P<uint32_t>(c->g_seq_bytes), P<uint64_t>(c->g_seq_off), nb, 0ull, P<uint64_t>(c->scan_scratch64), reinterpret_cast<uint64_t *>(&dc->seq_total));
 			exclusive_scan<uint32_t, uint64_t>(c->st, P<uint32_t>(c->g_cig_ops), P<uint64_t>(c->g_cig_off), nb, 0ull, P<uint64_t>(c->scan_scratch64), reinterpret_cast<uint64_t *>(&dc->cig_total));
 			HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
@@ -526,14 +535,14 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			void *seq_dst = nullptr, *cig_dst = nullptr;
 			CHECK(arena_alloc(c, c->blob, (size_t)hc->seq_total + 16, &seq_dst));
 			CHECK(arena_alloc(c, c->blob, (size_t)hc->cig_total * 4 + 16, &cig_dst));
-			k_clip_gather<<<grid_for(nb, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(P<ClipEvent>(c->ev), c->n_events, nb, P<uint64_t>(c->g_seq_off), P<uint64_t>(c->g_cig_off),
+			k_clip_gather<<<grid_for(nb, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(P<ClipEvent>(c->ev), P<uint32_t>(c->ev_idx), c->n_events, nb, P<uint64_t>(c->g_seq_off), P<uint64_t>(c->g_cig_off),
 			                                                                          reinterpret_cast<uint8_t *>(seq_dst), reinterpret_cast<uint32_t *>(cig_dst));
 			HIPCHECK(c, hipGetLastError());
 		}
 		if (nb > 0) {
 			const int64_t nbr = (int64_t)(hc->n_new >> 32);
 			c->n_events += nb; c->n_r += nbr; c->n_l += nb - nbr; c->n_long += (int64_t)hc->n_long;
-			c->max_key = std::max<uint64_t>(c->max_key, hc->max_key); c->max_ll = std::max(c->max_ll, hc->max_ll); c->max_lr = std::max(c->max_lr, hc->max_lr);
+			c->max_lq = std::max(c->max_lq, hc->max_lq);
 			c->sum_ncig += hc->sum_ncig;
 		}
 	}
@@ -577,21 +586,24 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	int cur = 0;
 	{
 		ProfScope ps(c, P_SORT, E);
-		HIPCHECK(c, hipMemsetAsync(&dc->l_unsorted, 0, 4, c->st));
+		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
 		if (EL > 1) k_check_sorted<<<grid_for(EL, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, &dc->l_unsorted);
+		if (EL > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(EL, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, &dc->max_key);
+		if (ER > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(ER, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_r[0]), ER, &dc->max_key);
 		uint32_t *h_seen = reinterpret_cast<uint32_t *>(P<uint8_t>(c->h_totals) + 64);
 		if (c->table_mode == 2) {
 			// first guess of the table's quality alphabet: the qualities of the first events
 			HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
 			const int64_t ns = std::min<int64_t>(E, 16384);
-			k_qual_sample<<<grid_for(ns, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ev, ns, P<uint32_t>(c->qual_seen));
+			k_qual_sample<<<grid_for(ns, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ev, P<uint32_t>(c->ev_idx), ns, P<uint32_t>(c->qual_seen));
 			HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
 		}
 		HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
 		HIPCHECK(c, hipStreamSynchronize(c->st));
+		const uint64_t max_key = hc->max_key;
 		int key_bits = 1;
-		while (key_bits < 64 && (c->max_key >> key_bits)) ++key_bits;
-		CHECK(ensure(c, c->keys2[0], E * 8)); CHECK(ensure(c, c->vals2[0], E * 4));
+		while (key_bits < 64 && (max_key >> key_bits)) ++key_bits;
+		CHECK(ensure(c, c->keys2[0], E * 8)); CHECK(ensure(c, c->evs, (size_t)E * sizeof(ClipEvent)));
 		if (!hc->l_unsorted) {
 			int rcur = 0;
 			if (ER > 0) {
@@ -603,14 +615,14 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				uint32_t *vals[2] = {P<uint32_t>(c->val_r[0]), P<uint32_t>(c->val_r[1])};
 				rcur = radix_sort_pairs(c->st, keys, vals, ER, key_bits, P<uint32_t>(c->ghist), P<uint32_t>(c->scan_scratch));
 			}
-			const int64_t Tn = (int64_t)(c->max_key >> 33) + 1;
+			const int64_t Tn = (int64_t)(max_key >> 33) + 1;
 			CHECK(ensure(c, c->cum_l, (size_t)(Tn + 2) * 4)); CHECK(ensure(c, c->cum_r, (size_t)(Tn + 2) * 4));
 			k_side_bounds<<<grid_for(Tn + 1, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, P<uint64_t>(c->key_r[rcur]), ER, Tn, P<uint32_t>(c->cum_l), P<uint32_t>(c->cum_r));
-			k_merge_sides<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), P<uint32_t>(c->val_l), EL, P<uint64_t>(c->key_r[rcur]), P<uint32_t>(c->val_r[rcur]), ER,
-			                                                       P<uint32_t>(c->cum_l), P<uint32_t>(c->cum_r), P<uint64_t>(c->keys2[0]), P<uint32_t>(c->vals2[0]));
+			k_merge_sides<<<grid_for(E, BLOCK / 4), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), P<uint32_t>(c->val_l), EL, P<uint64_t>(c->key_r[rcur]), P<uint32_t>(c->val_r[rcur]), ER,
+			                                                       P<uint32_t>(c->cum_l), P<uint32_t>(c->cum_r), ev, P<uint64_t>(c->keys2[0]), P<ClipEvent>(c->evs));
 			cur = 0;
 		} else {
-			CHECK(ensure(c, c->keys2[1], E * 8)); CHECK(ensure(c, c->vals2[1], E * 4));
+			CHECK(ensure(c, c->keys2[1], E * 8)); CHECK(ensure(c, c->vals2[0], E * 4)); CHECK(ensure(c, c->vals2[1], E * 4));
 			const int64_t nt = rs_tiles(E);
 			CHECK(ensure(c, c->ghist, 256 * nt * 4));
 			CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(256 * nt) * 4));
@@ -619,14 +631,15 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			uint64_t *keys[2] = {P<uint64_t>(c->keys2[0]), P<uint64_t>(c->keys2[1])};
 			uint32_t *vals[2] = {P<uint32_t>(c->vals2[0]), P<uint32_t>(c->vals2[1])};
 			cur = radix_sort_pairs(c->st, keys, vals, E, key_bits, P<uint32_t>(c->ghist), P<uint32_t>(c->scan_scratch));
+			k_gather_lines<<<grid_for(E, BLOCK / 4), BLOCK, 0, c->st>>>(vals[cur], E, ev, P<ClipEvent>(c->evs));
 		}
 		HIPCHECK(c, hipGetLastError());
 	}
 	// ---- greedy consensus clustering, one wavefront per multi-event bin ----
 	ClusterArgs ca;
-	ca.skey = P<uint64_t>(c->keys2[cur]); ca.perm = P<uint32_t>(c->vals2[cur]); ca.E = E; ca.ev = ev;
+	ca.skey = P<uint64_t>(c->keys2[cur]); ca.E = E; ca.ev = P<ClipEvent>(c->evs);
 	ca.match_rate = c->clip_p.match_rate;
-	ca.SL = std::max(1, c->max_ll); ca.SR = std::max(1, c->max_lr);
+	ca.SL = std::max(1, c->max_lq); ca.SR = std::max(1, c->max_lq); // |seq_left|, |seq_right| <= l_qseq, also after consensus growth
 	const size_t stride = 2 * ((size_t)ca.SL + (size_t)ca.SR);
 	int64_t M = 0;
 	{
@@ -643,13 +656,19 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		M = *P<uint32_t>(c->h_totals); // events in multi-event bins: only they need consensus storage
 		CHECK(ensure(c, c->c_strings, (size_t)std::max<int64_t>(M, 1) * stride));
 		ca.strings = P<uint8_t>(c->c_strings);
-		ca.M = M; ca.mlist = nullptr;
+		ca.M = M; ca.mlist = nullptr; ca.blist = nullptr; ca.n_bins = nullptr;
 		if (M > 0) {
 			// one wavefront per slot of a multi-event bin (3 % of the slots; the waves that do not sit on a bin start leave at once)
 			CHECK(ensure(c, c->c_mlist, M * 4));
 			ca.mlist = P<uint32_t>(c->c_mlist);
 			k_multi_list<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.mflag, ca.mslot, E, P<uint32_t>(c->c_mlist));
-			k_cluster_bins<<<grid_for(M, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
+			// the bins' first slots, densely: every wavefront of the clustering kernel then has a bin (a bin has at least two slots)
+			CHECK(ensure(c, c->c_bflag, M * 4)); CHECK(ensure(c, c->c_boff, M * 4)); CHECK(ensure(c, c->c_blist, (M / 2 + 1) * 4));
+			k_bin_start_flags<<<grid_for(M, BLOCK), BLOCK, 0, c->st>>>(ca.skey, ca.mlist, M, P<uint32_t>(c->c_bflag));
+			exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_bflag), P<uint32_t>(c->c_boff), M, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals) + 2);
+			k_bin_start_list<<<grid_for(M, BLOCK), BLOCK, 0, c->st>>>(ca.mlist, P<uint32_t>(c->c_bflag), P<uint32_t>(c->c_boff), M, P<uint32_t>(c->c_blist));
+			ca.blist = P<uint32_t>(c->c_blist); ca.n_bins = P<uint32_t>(c->totals) + 2;
+			k_cluster_bins<<<grid_for(M / 2 + 1, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
 		}
 		HIPCHECK(c, hipGetLastError());
 	}
@@ -675,13 +694,15 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		if (c->table_mode == 2) { memcpy(guess, h_seen, 32); set_alphabet(guess); }
 		CHECK(ensure(c, c->slot_cnt, E * 8)); CHECK(ensure(c, c->slot_bytes, E * 8));
 		CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(E) * 8));
-		DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &T.o_ncig, &c->o_slot, &c->o_srcbegin, &c->o_srclq, &c->o_cigev, &c->o_slowlist};
+		DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &T.o_ncig, &c->o_slowlist};
 		for (DBuf *b : d4) CHECK(ensure(c, *b, E * 4 + 16));
 		CHECK(ensure(c, T.o_side, E + 16)); CHECK(ensure(c, T.o_qmiss, E + 16));
-		DBuf *d8[] = {&T.o_stroff, &T.o_cigoff, &c->o_srcptr};
+		DBuf *d8[] = {&T.o_stroff, &T.o_cigoff};
 		for (DBuf *b : d8) CHECK(ensure(c, *b, E * 8 + 16));
+		CHECK(ensure(c, c->o_desc, (size_t)E * sizeof(PackDesc) + 64));
 		CHECK(ensure(c, T.o_cig, (size_t)c->sum_ncig * 4 + 16));
-		uint64_t *tot = P<uint64_t>(c->totals); // [0] clusters | CIGAR operations << 32, [1] string bytes, [2] slow-list length
+		uint64_t *tot = P<uint64_t>(c->totals); // [0] clusters | CIGAR operations << 32, [1] string bytes, [2] slow-list length, [3] "a quality outside the alphabet" flag
+		bool track = false;
 		for (int attempt = 0;; ++attempt) {
 			const size_t str_cap = (size_t)E * (size_t)table_block_bytes((uint64_t)ca.SL, (uint64_t)ca.SR, T.packed, (uint64_t)T.qual_bits);
 			CHECK(ensure(c, T.o_str, str_cap + 16));
@@ -689,37 +710,48 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			pa.c = ca; pa.slot_cnt = P<uint64_t>(c->slot_cnt); pa.slot_bytes = P<uint64_t>(c->slot_bytes);
 			pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
 			pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.ncig = P<int32_t>(T.o_ncig); pa.str_off = P<uint64_t>(T.o_stroff); pa.cig_off = P<uint64_t>(T.o_cigoff);
-			pa.slot = P<uint32_t>(c->o_slot); pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
-			pa.src_ptr = P<uint64_t>(c->o_srcptr); pa.src_begin = P<int32_t>(c->o_srcbegin); pa.src_lq = P<int32_t>(c->o_srclq); pa.cig_ev = P<uint32_t>(c->o_cigev);
+			pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
+			pa.lut_miss = reinterpret_cast<int *>(tot + 3);
 			pa.slow_list = P<uint32_t>(c->o_slowlist); pa.slow_count = reinterpret_cast<unsigned int *>(tot + 2);
 			HIPCHECK(c, hipMemsetAsync(tot, 0, 32, c->st));
-			HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
+			if (track) HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
 			if (T.packed && T.qual_bits < 8) HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, c->h_qual_lut.p, 256, hipMemcpyHostToDevice, c->st));
 			k_cluster_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
 			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_cnt, pa.slot_cnt, E, 0ull, P<uint64_t>(c->scan_scratch64), tot);
 			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_bytes, pa.slot_bytes, E, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
-			k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
-			const uint32_t *nc_dev = reinterpret_cast<const uint32_t *>(tot);
-			const dim3 g(grid_for(E, GROUPS_PER_BLOCK));                    // upper bound: the kernels read the cluster count themselves
-			const dim3 gs(grid_for(std::max<int64_t>(M + c->n_long, 1), GROUPS_PER_BLOCK)); // multi-event bins + reads too long for the dword path
 			uint8_t *os = P<uint8_t>(T.o_str);
-			uint32_t *oc = P<uint32_t>(T.o_cig);
-			if (!pa.packed) k_cluster_pack_ascii<<<g, BLOCK, 0, c->st>>>(pa, nc_dev, os, oc);
+			PackDesc *dsc = P<PackDesc>(c->o_desc);
+			k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, dsc, P<uint32_t>(T.o_cig));
+			const unsigned int *nc_dev = reinterpret_cast<const unsigned int *>(tot);
+			const dim3 gs(grid_for(std::max<int64_t>(M + c->n_long, 1), GROUPS_PER_BLOCK)); // slots of multi-event bins + reads too long for the dword path
+			if (!pa.packed) k_cluster_pack_ascii<<<grid_for(E, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, os);
 			else {
-				// the dword path for (nearly) all clusters, then the bytewise path for the listed ones
-#define SSV_PACK(W_) do { k_cluster_pack_codes<W_, false><<<g, BLOCK, 0, c->st>>>(pa, nc_dev, os, oc); \
-			k_cluster_pack_codes<W_, true><<<gs, BLOCK, 0, c->st>>>(pa, pa.slow_count, os, oc); } while (0)
-				if (pa.qual_bits == 8) SSV_PACK(8); else if (pa.qual_bits == 4) SSV_PACK(4); else if (pa.qual_bits == 3) SSV_PACK(3); else if (pa.qual_bits == 2) SSV_PACK(2); else SSV_PACK(1);
+				// the dword path for (nearly) all clusters (one group of lanes per cluster; the grid is an upper bound, the kernel reads the cluster
+				// count itself), then the bytewise path.  SSV_PACK_BLOCKS=n: the persistent, software-pipelined form of the kernel on n workgroups
+				// (measured slower: the kernel is bound by its vector instructions, and the pipeline's registers cost three of eight wavefronts).
+				static const unsigned pack_blocks = []() { const char *e = getenv("SSV_PACK_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
+				const dim3 g(pack_blocks ? (unsigned)std::max<int64_t>(1, std::min<int64_t>(pack_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)) : grid_for(E, GROUPS_PER_BLOCK));
+#define SSV_PACK2(W_, T_) do { if (pack_blocks) k_cluster_pack_stream<W_, T_, true><<<g, BLOCK, 0, c->st>>>(pa, dsc, nc_dev, os); else k_cluster_pack_stream<W_, T_, false><<<g, BLOCK, 0, c->st>>>(pa, dsc, nc_dev, os); \
+			k_cluster_pack_slow<W_, T_><<<gs, BLOCK, 0, c->st>>>(pa, os); } while (0)
+#define SSV_PACK(W_) do { if (track) SSV_PACK2(W_, true); else SSV_PACK2(W_, false); } while (0)
+				if (pa.qual_bits == 8) SSV_PACK2(8, false); else if (pa.qual_bits == 4) SSV_PACK(4); else if (pa.qual_bits == 3) SSV_PACK(3); else if (pa.qual_bits == 2) SSV_PACK(2); else SSV_PACK(1);
 #undef SSV_PACK
+#undef SSV_PACK2
 			}
 			HIPCHECK(c, hipGetLastError());
 			HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 32, hipMemcpyDeviceToHost, c->st));
-			HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
+			if (track) HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
 			HIPCHECK(c, hipStreamSynchronize(c->st));
-			if (c->table_mode == 2 && T.qual_bits < 8 && memcmp(h_seen, guess, 32) != 0 && attempt == 0) {
-				// the table's strings hold other quality values than the first events did: pack again with the alphabet they really need
+			if (track) { // the launch above met every quality value of the table's strings: that is the alphabet; pack once more with it
 				memcpy(guess, h_seen, 32);
 				set_alphabet(guess);
+				track = false;
+				continue;
+			}
+			if (c->table_mode == 2 && T.qual_bits < 8 && (int)P<uint64_t>(c->h_totals)[3] != 0) {
+				// the table's strings hold a quality value that the first events did not show: find out which values there are
+				if (attempt > 2) { c->err = "quality alphabet did not settle"; return SSV_E_HIP; }
+				track = true;
 				continue;
 			}
 			break;
@@ -858,17 +890,15 @@ int ssv_isize_finish(ssv_ctx *c, int64_t *n_pairs, int32_t *mean, int32_t *sd)
 	long long *acc = P<long long>(c->isz_acc);
 	unsigned grid = (unsigned)std::min<int64_t>(1024, (n + BLOCK - 1) / BLOCK);
 	HIPCHECK(c, hipMemsetAsync(acc, 0, 16, c->st));
-	k_isize_reduce<<<grid, BLOCK, 0, c->st>>>(P<int32_t>(c->isz_vals), n, 0, 0, acc);
-	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, acc, 8, hipMemcpyDeviceToHost, c->st));
+	k_isize_reduce<<<grid, BLOCK, 0, c->st>>>(P<int32_t>(c->isz_vals), n, 0, nullptr, acc);
+	k_isize_reduce<<<grid, BLOCK, 0, c->st>>>(P<int32_t>(c->isz_vals), n, 1, acc, acc + 1);
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, acc, 16, hipMemcpyDeviceToHost, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
-	const unsigned long total = (unsigned long)*P<long long>(c->h_totals);
+	const unsigned long total = (unsigned long)P<long long>(c->h_totals)[0];
 	const int m = (int)(total / (unsigned long)n); // cluster.cpp:72
-	k_isize_reduce<<<grid, BLOCK, 0, c->st>>>(P<int32_t>(c->isz_vals), n, 1, m, acc + 1);
-	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, acc + 1, 8, hipMemcpyDeviceToHost, c->st));
-	HIPCHECK(c, hipStreamSynchronize(c->st));
 	// cluster.cpp:73-80 adds the (int) squares one by one into a double; the exact integer sum is the same value as long as it
 	// stays below 2^53 (5e6 pairs * 2^31 is ~2^53.2: only reachable with absurd insert sizes)
-	const double dsum = (double)*P<long long>(c->h_totals);
+	const double dsum = (double)P<long long>(c->h_totals)[1];
 	*mean = m;
 	*sd = (int)std::sqrt(dsum / (double)n);
 	return SSV_OK;
@@ -1069,33 +1099,36 @@ int ssv_getsv_finish(ssv_ctx *c, int32_t *counts, const ssv_interval *ranges, in
 	const int64_t nw = (int64_t)c->gs_win.size(), nj = (int64_t)c->gs_junc.size();
 	ProfScope ps(c, P_DEPTH_FINISH, nw);
 	if (nw) k_depth_prefix<<<grid_for(nw, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<int64_t>(c->gs_woff), nw, P<int32_t>(c->gs_diff), P<int32_t>(c->gs_maxdepth));
-	const int64_t nq = std::max(n_ranges, n_points);
-	CHECK(ensure(c, c->q_tid, nq * 4 + 16)); CHECK(ensure(c, c->q_beg, nq * 4 + 16)); CHECK(ensure(c, c->q_end, nq * 4 + 16));
-	CHECK(ensure(c, c->q_out64, n_ranges * 8 + 16)); CHECK(ensure(c, c->q_out32, n_points * 4 + 16));
-	std::vector<int32_t> t((size_t)nq), bg((size_t)nq), en((size_t)nq);
-	if (n_ranges) {
-		for (int64_t k = 0; k < n_ranges; ++k) { t[(size_t)k] = ranges[k].tid; bg[(size_t)k] = ranges[k].beg; en[(size_t)k] = ranges[k].end; }
-		HIPCHECK(c, hipMemcpyAsync(c->q_tid.p, t.data(), n_ranges * 4, hipMemcpyHostToDevice, c->st));
-		HIPCHECK(c, hipMemcpyAsync(c->q_beg.p, bg.data(), n_ranges * 4, hipMemcpyHostToDevice, c->st));
-		HIPCHECK(c, hipMemcpyAsync(c->q_end.p, en.data(), n_ranges * 4, hipMemcpyHostToDevice, c->st));
-		k_range_sum<<<grid_for(n_ranges, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<int32_t>(c->gs_wtid), P<int32_t>(c->gs_wbeg), P<int32_t>(c->gs_wend), P<int64_t>(c->gs_woff), nw,
-		                                                                      P<int32_t>(c->gs_diff), P<int32_t>(c->q_tid), P<int32_t>(c->q_beg), P<int32_t>(c->q_end), n_ranges,
-		                                                                      P<unsigned long long>(c->q_out64));
-		HIPCHECK(c, hipMemcpyAsync(range_sum, c->q_out64.p, n_ranges * 8, hipMemcpyDeviceToHost, c->st));
-		HIPCHECK(c, hipStreamSynchronize(c->st)); // t/bg/en are reused for the points
-	}
-	if (n_points) {
-		for (int64_t k = 0; k < n_points; ++k) { t[(size_t)k] = points[k].tid; bg[(size_t)k] = points[k].beg; }
-		HIPCHECK(c, hipMemcpyAsync(c->q_tid.p, t.data(), n_points * 4, hipMemcpyHostToDevice, c->st));
-		HIPCHECK(c, hipMemcpyAsync(c->q_beg.p, bg.data(), n_points * 4, hipMemcpyHostToDevice, c->st));
-		k_point_depth<<<grid_for(n_points, BLOCK), BLOCK, 0, c->st>>>(P<int32_t>(c->gs_wtid), P<int32_t>(c->gs_wbeg), P<int32_t>(c->gs_wend), P<int64_t>(c->gs_woff), nw,
-		                                                              P<int32_t>(c->gs_diff), P<int32_t>(c->q_tid), P<int32_t>(c->q_beg), n_points, P<int32_t>(c->q_out32));
-		HIPCHECK(c, hipMemcpyAsync(point_depth, c->q_out32.p, n_points * 4, hipMemcpyDeviceToHost, c->st));
-	}
-	if (counts && nj) HIPCHECK(c, hipMemcpyAsync(counts, c->gs_counts.p, nj * 4, hipMemcpyDeviceToHost, c->st));
-	if (max_depth) HIPCHECK(c, hipMemcpyAsync(max_depth, c->gs_maxdepth.p, 4, hipMemcpyDeviceToHost, c->st));
+	// queries up, answers down: one pinned buffer each way, one synchronisation
+	//   up:   [range tid | range beg | range end | point tid | point beg]        (int32 each)
+	//   down: [range sums u64 | point depths i32 | counts i32 | max depth i32]
+	const size_t up_bytes = ((size_t)n_ranges * 3 + (size_t)n_points * 2) * 4;
+	const size_t o_pd = (size_t)n_ranges * 8, o_cnt = o_pd + (size_t)n_points * 4, o_max = o_cnt + (size_t)nj * 4, down_bytes = o_max + 4;
+	CHECK(ensure_host(c, c->h_q, up_bytes + down_bytes + 64));
+	CHECK(ensure(c, c->q_tid, up_bytes + 16)); CHECK(ensure(c, c->q_out64, down_bytes + 16));
+	int32_t *up = P<int32_t>(c->h_q);
+	uint8_t *down = P<uint8_t>(c->h_q) + ((up_bytes + 15) & ~(size_t)15);
+	int32_t *rt = up, *rb = rt + n_ranges, *re = rb + n_ranges, *pt = re + n_ranges, *pb = pt + n_points;
+	for (int64_t k = 0; k < n_ranges; ++k) { rt[k] = ranges[k].tid; rb[k] = ranges[k].beg; re[k] = ranges[k].end; }
+	for (int64_t k = 0; k < n_points; ++k) { pt[k] = points[k].tid; pb[k] = points[k].beg; }
+	int32_t *d_up = P<int32_t>(c->q_tid);
+	uint8_t *d_down = P<uint8_t>(c->q_out64);
+	if (up_bytes) HIPCHECK(c, hipMemcpyAsync(d_up, up, up_bytes, hipMemcpyHostToDevice, c->st));
+	if (n_ranges) k_range_sum<<<grid_for(n_ranges, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(P<int32_t>(c->gs_wtid), P<int32_t>(c->gs_wbeg), P<int32_t>(c->gs_wend), P<int64_t>(c->gs_woff), nw,
+	                                                                                  P<int32_t>(c->gs_diff), d_up, d_up + n_ranges, d_up + 2 * n_ranges, n_ranges,
+	                                                                                  reinterpret_cast<unsigned long long *>(d_down));
+	if (n_points) k_point_depth<<<grid_for(n_points, BLOCK), BLOCK, 0, c->st>>>(P<int32_t>(c->gs_wtid), P<int32_t>(c->gs_wbeg), P<int32_t>(c->gs_wend), P<int64_t>(c->gs_woff), nw,
+	                                                                          P<int32_t>(c->gs_diff), d_up + 3 * n_ranges, d_up + 3 * n_ranges + n_points, n_points,
+	                                                                          reinterpret_cast<int32_t *>(d_down + o_pd));
+	if (nj) HIPCHECK(c, hipMemcpyAsync(d_down + o_cnt, c->gs_counts.p, (size_t)nj * 4, hipMemcpyDeviceToDevice, c->st));
+	HIPCHECK(c, hipMemcpyAsync(d_down + o_max, c->gs_maxdepth.p, 4, hipMemcpyDeviceToDevice, c->st));
 	HIPCHECK(c, hipGetLastError());
+	HIPCHECK(c, hipMemcpyAsync(down, d_down, down_bytes, hipMemcpyDeviceToHost, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
+	if (n_ranges) memcpy(range_sum, down, (size_t)n_ranges * 8);
+	if (n_points) memcpy(point_depth, down + o_pd, (size_t)n_points * 4);
+	if (counts && nj) memcpy(counts, down + o_cnt, (size_t)nj * 4);
+	if (max_depth) memcpy(max_depth, down + o_max, 4);
 	return SSV_OK;
 }
 
