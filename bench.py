@@ -26,20 +26,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-# HBM bytes each kernel group must move per unit with the implemented algorithm (DESIGN.md "Kernels"); unit = what the group's
-# launch processes (records for the streaming passes, clip events / clusters for the rest).
-#   clip_scan   : n_cigar 2 per record - only records with >= 2 CIGAR ops (~3 %) can carry a usable soft clip and go on to       = 2.0 B/record
-#                 clip_filter (SURVEY 8d's eager figure is 21 B/record: everything else is evaluated lazily, per candidate)
-#   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                        = 8.0 B/record
-#   clip_gather : packed bases+qualities 228 read + 228 written, CIGAR 8 + 8                                             = 472 B/event
-#   event_sort  : 5 radix passes x (12 B histogram read + 12 B read + 12 B written)                                       = 180 B/event
-#   cluster_pack: 228 read + 7/8 (ll+lr) ~ 131 written (4-bit sequence codes + 3-bit quality indices) + ~70 B of per-cluster columns = 430 B/cluster-slot
-ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_gather": 472.0, "event_sort": 180.0, "cluster_pack": 430.0}
 # minimum traffic of the whole path if every field of a record were read once by one fused pass (33 B fixed part +
-# 4.1 B CIGAR + 1 % x 225 B bases/qualities + ~0.7 B out).  The implemented path reads far less per record (the streaming passes touch
-# 2 + 8 B; everything else is evaluated lazily for ~1-3 % of the records), so this figure over the sum of ALL device kernels of a step
-# is the whole-path view of the same roofline: "path" in the bench line.
+# 4.1 B CIGAR + 1 % x 225 B bases/qualities + ~0.7 B out).  `roofline` in the bench line prices ALL device kernels of one step with it:
+# achieved = 40 B x records / (sum of the kernels' time).
 PATH_BYTES_PER_RECORD = 40.0
+# HBM bytes each kernel group must move per unit with the implemented algorithm; unit = what the group's launches process.
+#   clip_scan   : n_cigar 2 per record - only records with >= 2 CIGAR ops (~3 %) can carry a usable soft clip and go on             = 2 B/record
+#   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                                   = 8 B/record
+#   clip_place  : per candidate: staged index 4 + 4, record line 64, count 1; per event (0.31 per candidate): line 64 + staged key 16 written,
+#                 staged key 16 read, side-list key 12 + (l_qseq, n_cigar) 8 + slot 4 written                                        = 110 B/candidate
+#   event_sort  : '3' events (half): 5 radix passes x (8 histogram read + 12 read + 12 written); all: key 12 + line 64 read, 8 + 64 written = 230 B/event
+#   cluster_pack: per sorted slot: line 32 + 9, sizes 16 (meta); two scans 48; line 64 + 30, row 42 + descriptor 32 + CIGAR 10 (cols);
+#                 descriptor 32 + read 228 + block 132 (strings)                                                                      = 675 B/slot
+ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_place": 110.0, "event_sort": 230.0, "cluster_pack": 675.0}
+DEVICE_GROUPS = ("clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish")
 
 
 def main():
@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--ref-sample", type=int, default=3_000_000, help="records of the sample the real reference binary (oracle/_ref, if it travelled) is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--file-frac", type=float, default=1 / 16, help="genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
+                    "inflate + decode -> scans -> tables on the host); 0 = skip")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
     ap.add_argument("--no-overlap", action="store_true", help="collect every cluster table in its own step (no copy in flight while other kernels run); use under rocprofv3, which serialises dispatches of different streams")
     args = ap.parse_args()
@@ -243,30 +245,46 @@ def main():
         assert state["tables"] >= args.steps, "every step's cluster table must have reached the host"
         total_records = w.n_total
         ms_per_step = dt / args.steps * 1e3
-        # Roofline: the two kernels that touch EVERY record (clip_scan, getsv_scan) are the HBM-streaming kernels the per-record byte
-        # figures apply to; the longer of the two is reported as the dominant one.  The per-event kernels (1 % of the records: sparse
-        # 64-byte-sector gathers, latency bound) are listed with their own byte models under "other", and "kernel_ms_one_step" has every
-        # group's time - nothing is hidden: the longest group overall is named in "longest_group".
-        cand = {k: v for k, v in allprof.items() if k in ALGO_BYTES and v["launches"]}
-        streaming = {k: v for k, v in cand.items() if k in ("clip_scan", "getsv_scan")}
-        dom = max(streaming, key=lambda k: streaming[k]["total_ms"] / streaming[k]["launches"])
-        longest = max((k for k in allprof if allprof[k]["launches"] and k not in ("table_d2h", "h2d")), key=lambda k: allprof[k]["total_ms"])
-        # the kernel's average launch duration over the TIMED region (HIP events on the context's stream around every launch of the K steps,
-        # the table copy of the previous step in flight beside it); the extra step's single launch without a copy in flight is listed too
-        src = prof[dom] if prof.get(dom, {}).get("launches") else allprof[dom]
-        launches = max(src["launches"], 1)
-        avg_ms = src["total_ms"] / launches
-        units = src["units"] / launches
-        achieved = ALGO_BYTES[dom] * units / (avg_ms * 1e-3) / 1e9
-        quiet_ms = allprof[dom]["total_ms"] / max(allprof[dom]["launches"], 1)
-        traffic = None
+        # Roofline: the whole path.  achieved = SURVEY 8(d)'s 40 B/record x this rank's records / the sum of ALL device kernels of one step
+        # (HIP events on the context's stream around every kernel group, nothing else in flight: the extra breakdown steps above); every
+        # group is listed with its own time, its byte model where it has one and - from the committed PMC passes (profiles/traffic.json) - the
+        # HBM bytes it really moved; the longest group is named.  The two streaming kernels (the only ones that touch every record) are also
+        # timed inside the K timed steps, the table copy of the previous step in flight beside them.
+        dev = {k: v for k, v in allprof.items() if k in DEVICE_GROUPS and v["launches"]}
+        dev_ms = sum(v["total_ms"] for v in dev.values())
+        longest = max(dev, key=lambda k: dev[k]["total_ms"])
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_record")
-                traffic = traffic * units if traffic is not None else None
+                traffic = json.load(open(tpath))
             except Exception:
-                traffic = None
+                traffic = {}
+        scale = n_own / traffic["records"] if traffic.get("records") else None   # the PMC passes ran the default workload
+
+        def group_entry(k, v):
+            per = v["total_ms"]
+            units = v["units"] / max(v["launches"], 1) if k in ("clip_scan", "getsv_scan", "clip_place", "event_sort", "cluster_pack") else None
+            e = {"ms": round(per, 4)}
+            if k in ALGO_BYTES and units:
+                e["units"] = int(units)
+                e["algorithmic_bytes_per_unit"] = ALGO_BYTES[k]
+                e["achieved_GBs"] = round(ALGO_BYTES[k] * units / (per * 1e-3) / 1e9, 1)
+                e["frac"] = round(e["achieved_GBs"] / HBM_PEAK_GBS, 3)
+            t = traffic.get("groups", {}).get(k)
+            if t is not None and scale is not None and abs(scale - 1.0) < 0.02:
+                e["traffic_bytes"] = t
+            return e
+
+        groups = {k: group_entry(k, v) for k, v in dev.items()}
+        path_bytes = PATH_BYTES_PER_RECORD * n_own
+        achieved = path_bytes / (dev_ms * 1e-3) / 1e9
+        total_traffic = traffic.get("path_bytes_per_step") if (scale is not None and abs(scale - 1.0) < 0.02) else None
+        timed = {}
+        for k in ("clip_scan", "getsv_scan"):
+            if prof.get(k, {}).get("launches"):
+                timed[k] = {"avg_launch_ms": round(prof[k]["total_ms"] / prof[k]["launches"], 4), "launches_timed": int(prof[k]["launches"]),
+                            "achieved_GBs": round(ALGO_BYTES[k] * (prof[k]["units"] / prof[k]["launches"]) / (prof[k]["total_ms"] / prof[k]["launches"] * 1e-3) / 1e9, 1)}
         line = {
             "metric": "BAM records/sec through getclip+getsv",
             "value": total_records * args.steps / dt,
@@ -276,25 +294,24 @@ def main():
             "config": {"workload": f"synthetic {args.depth:g}x-per-GPU WGS, 150 bp PE, 1% random soft clips, {len(w.junctions)} planted DEL/INV/TRA (VAF 0.5), "
                                    f"genome_frac {args.genome_frac:g}, {n_own} records/GPU resident in HBM",
                        "records_total": total_records, "records_per_gpu": n_own, "junctions": len(w.junctions), "parallelism": f"range-partition x{world}",
+                       "multi_gpu": "weak scaling: 30x per GPU over the same genome (N GPUs = 30N x), not BASELINE config 4's fixed 300x BAM split N ways",
+                       "batch_layout": "hot columns tid/pos/n_cigar + one 64-byte line per record (ssv_record) + CIGARs + packed bases/qualities of soft-clipped records; SSV_MEM_PERSISTENT",
                        "generation_s": round(gen_s, 2)},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_record": ALGO_BYTES[dom], "records_per_launch": units, "avg_launch_ms": avg_ms,
-                         "launches_timed": int(src["launches"]), "launch_ms_no_copy_in_flight": quiet_ms,
-                         "longest_group": {"name": longest, "ms": round(allprof[longest]["total_ms"], 4)},
-                         "device_kernels_ms_per_step": round(sum(v["total_ms"] for k, v in allprof.items() if k not in ("table_d2h", "h2d")), 3),
-                         "other": {k: {"avg_launch_ms": round(v["total_ms"] / v["launches"], 4), "units": v["units"] // v["launches"],
-                                       "achieved_GBs": round(ALGO_BYTES[k] * (v["units"] / v["launches"]) / (v["total_ms"] / v["launches"] * 1e-3) / 1e9, 1)}
-                                   for k, v in cand.items()}},
-            "path": {"algorithmic_bytes_per_record": PATH_BYTES_PER_RECORD, "device_kernels_ms": round(sum(v["total_ms"] for k, v in allprof.items() if k not in ("table_d2h", "h2d")), 3),
-                     "achieved": PATH_BYTES_PER_RECORD * n_own / (sum(v["total_ms"] for k, v in allprof.items() if k not in ("table_d2h", "h2d")) * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": PATH_BYTES_PER_RECORD * n_own / (sum(v["total_ms"] for k, v in allprof.items() if k not in ("table_d2h", "h2d")) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "note": "SURVEY 8(d)'s fused-pass figure x this rank's records / the sum of every device kernel of one step (getclip + insert size + getsv passes; PCIe copy excluded)"},
+            "roofline": {"kernel": "path: all device kernels of one step (getclip + insert size + getsv passes; PCIe copy excluded)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": total_traffic,
+                         "algorithmic_bytes_per_record": PATH_BYTES_PER_RECORD, "records_per_launch": float(n_own), "avg_launch_ms": round(dev_ms, 4),
+                         "launches_timed": BREAKDOWN_STEPS, "dominant_group": {"name": longest, **groups[longest]},
+                         "groups": groups, "streaming_kernels_in_timed_region": timed},
             "kernel_ms_one_step": breakdown,
             "wall_ms_one_step": {k: round(v, 3) for k, v in wall.items()},
             "wall_ms_timed_steps": step_walls,
             "result": res,
         }
+        if world == 1 and args.file_frac > 0:
+            try:
+                line["file_path"] = file_path_leg(ctx, args, local_rank)
+            except Exception as e:  # the leg is a report beside the headline, never a reason to lose the line
+                line["file_path"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(w, hdr, min(args.cpu_sample, w.n_total))
             ref = cpu_reference(w, min(args.ref_sample, w.n_total))
@@ -307,6 +324,125 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def file_path_leg(ctx, args, device):
+    """The same workload from a BAM FILE: a smaller genome fraction of the same synthetic 30x sample is written as a real BAM by the
+    repository's writer (libseeksv_host: BGZF level 6 like samtools), its compressed bytes are put into pinned host memory in chunks of
+    whole BGZF blocks, and the timed region runs what `seeksv getclip` + `seeksv getsv` do with a file: per chunk H2D of the compressed
+    bytes -> device BGZF inflate + BAM decode (ssv_bamdec_*) -> scans; pass 1 = getclip (clip events -> cluster table on the host), pass 2 =
+    insert-size statistics on the first chunk, then the fused discordant + depth scan of every chunk (the first chunk is decoded once
+    for both) -> counts / depths on the host.  Rate = records / (pass 1 + pass 2)."""
+    import ctypes as C
+    import tempfile
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from seeksv_amd import _abi, host, synth
+    w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, int(args.n_sv * args.file_frac)))
+    d = tempfile.mkdtemp(prefix="ssv_file_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.perf_counter()
+        chunk = 2_000_000
+        starts = list(range(0, w.n_total, chunk))
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:   # the generator is a C loop (GIL released)
+            batches = list(ex.map(lambda g: w.generate_host(g, min(chunk, w.n_total - g)), starts))
+        bam = os.path.join(d, "sample.bam")
+        host.write_bam(bam, w.names, w.lens, batches)
+        del batches
+        bam_bytes = os.path.getsize(bam)
+        make_s = time.perf_counter() - t0
+        # the file's BGZF blocks into pinned host memory, in chunks of ~2 GB of inflated data
+        hl = _abi.host_lib()
+        chunks = []
+        with host.BamReader(bam) as r:
+            first = C.c_uint64()
+            if hl.ssvh_bam_raw_begin(r.handle, C.byref(first)) != 0:
+                raise IOError(hl.ssvh_last_error().decode())
+            n_targets = len(r.target_names)
+            max_blocks = 1 << 17
+            cap = 192 << 20
+            while True:
+                buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                blocks = (_abi.BgzfBlock * max_blocks)()
+                nb, nbytes = C.c_int64(), C.c_size_t()
+                if hl.ssvh_bam_read_blocks(r.handle, C.c_void_p(buf.data_ptr()), cap, 2 << 30, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
+                    raise IOError(hl.ssvh_last_error().decode())
+                if nb.value == 0:
+                    break
+                chunks.append((buf, blocks, nb.value, nbytes.value))
+        hdr = host.Header(w.names, w.lens)
+        jtable = host.JunctionTable(w.junctions)
+        lib = ctx._lib
+
+        def decode(k, keep_all_seq=0):
+            buf, blocks, nb, nbytes = chunks[k]
+            b = _abi.Batch()
+            ctx._check(lib.ssv_bamdec_decode(ctx._h, C.c_void_p(buf.data_ptr()), nbytes, blocks, nb, keep_all_seq, C.byref(b)), "ssv_bamdec_decode")
+            return b
+
+        def end_of_input():
+            b = _abi.Batch()
+            ctx._check(lib.ssv_bamdec_decode(ctx._h, None, 0, None, 0, 0, C.byref(b)), "ssv_bamdec_decode")
+
+        def one_run():
+            t = {}
+            t0 = time.perf_counter()
+            # ---- pass 1: seeksv getclip ----
+            ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
+            ctx.clip_begin(0.9, 1, False, None, 0)
+            n = 0
+            for k in range(len(chunks)):
+                b = decode(k)
+                n += b.n
+                ctx.clip_scan(b)
+            end_of_input()
+            nc, ne = ctx.clip_cluster_async()
+            tab = ctx.clip_table_wait()
+            ssum = int(np.ctypeslib.as_array(tab.support, shape=(tab.n_clusters,)).sum()) if tab.n_clusters else 0
+            assert ssum == tab.n_events == ne and n == w.n_total
+            t["getclip_s"] = time.perf_counter() - t0
+            # ---- pass 2: seeksv getsv (insert size on the file's first chunk, then discordant pairs + depth of every chunk) ----
+            t1 = time.perf_counter()
+            ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
+            b0 = decode(0)
+            rc, npairs, mean, sd = ctx.isize_stats([b0], 20, 5000000)
+            plan = host.Plan(hdr, jtable, mean, sd)
+            ctx.getsv_begin(plan.junctions, plan.windows, mean, sd, hdr.target_lens, 4, 20, 20)
+            ctx.getsv_scan(b0)
+            for k in range(1, len(chunks)):
+                ctx.getsv_scan(decode(k))
+            end_of_input()
+            counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
+            folded = plan.fold(counts, rs, pd)
+            plan.close()
+            t["getsv_s"] = time.perf_counter() - t1
+            t["total_s"] = time.perf_counter() - t0
+            t["result"] = dict(n_clusters=int(nc), n_events=int(ne), mean=int(mean), sd=int(sd), pairs_used=int(npairs), abnormal_sum=int(folded["abnormal"].sum()),
+                               depth_sum=int(folded["up_depth"].sum() + folded["down_depth"].sum()), max_depth=int(max_depth))
+            return t
+
+        one_run()                      # warm-up: buffers grow to size
+        ctx.prof_reset(); ctx.prof_enable(1)
+        runs = [one_run() for _ in range(3)]
+        prof = ctx.prof_all()
+        ctx.prof_enable(0)
+        best = min(runs, key=lambda t: t["total_s"])
+        inflated = None
+        kernel_ms = {k: round(v["total_ms"] / len(runs), 3) for k, v in prof.items() if v["launches"]}
+        out = {"value": w.n_total / best["total_s"], "unit": "records/s",
+               "workload": f"synthetic {args.depth:g}x WGS, genome_frac {args.file_frac:g}: {w.n_total} records as a BAM file of {bam_bytes} bytes (BGZF level 6, written by libseeksv_host), "
+                           f"{len(chunks)} chunks of whole BGZF blocks in pinned host memory",
+               "records": w.n_total, "bam_bytes": bam_bytes, "chunks": len(chunks),
+               "getclip_s": round(best["getclip_s"], 4), "getsv_s": round(best["getsv_s"], 4), "total_s": round(best["total_s"], 4),
+               "runs_total_s": [round(t["total_s"], 4) for t in runs],
+               "pcie_in_GBs": round(2 * bam_bytes / best["total_s"] / 1e9, 2),
+               "kernel_ms_per_run": kernel_ms, "result": best["result"],
+               "note": "both passes read the whole file (two commands in the reference: getclip, getsv); file creation (%.1f s) is outside the timed region" % make_s}
+        hdr.close()
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(w, hdr, n_sample, min_seconds=10.0):

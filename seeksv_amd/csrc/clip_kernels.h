@@ -1404,8 +1404,8 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_slow(PackArgs p, uint8_t
 	const int64_t n_items = p.c.M + (int64_t)*p.slow_count;
 	if (k_ >= n_items) return;
 	const int64_t j = k_ < p.c.M ? (int64_t)p.c.mlist[k_] : (int64_t)p.slow_list[k_ - p.c.M];
+	if (p.c.support[j] <= 0) return; // five of six slots of multi-event bins hold no cluster
 	const SlotCluster sc = slot_cluster_load(p, j);
-	if (!sc.cluster) return;
 	const int ll = sc.ll, lr = sc.lr, lq = sc.lq, begin = sc.begin;
 	const bool single = lq >= 0;
 	const int nB0 = (ll + 1) / 2, nB1 = (ll * W + 7) / 8, nB2 = (lr + 1) / 2, nB3 = (lr * W + 7) / 8;

@@ -24,14 +24,11 @@ __device__ __forceinline__ bool is_hard_clip(const DevBatch &b, const RecLine &r
 // K4 insert-size statistics
 // ---------------------------------------------------------------------------------------------------------------------
 
-constexpr int ISZ_ITEMS = 1;           // one record line per lane: consecutive lanes read consecutive 64-byte lines
-constexpr int ISZ_TILE = BLOCK * ISZ_ITEMS;
+constexpr int ISZ_TILE = BLOCK;         // records per workgroup
 
 // cluster.cpp:51-67: MAPQ >= q, not hard clipped, PAIRED && PROPER_PAIR && !DUP && isize > 0
-__device__ __forceinline__ bool isize_qualifies(const DevBatch &b, int64_t i, int min_mapq, int *isize)
+__device__ __forceinline__ bool isize_qualifies(const DevBatch &b, const RecLine &r, int min_mapq)
 {
-	const RecLine r = rec_load(b.rec, i); // the pass covers a bounded prefix of the file (the first -n qualifying records): whole lines are fine
-	*isize = r.isize();
 	if (r.mapq() < min_mapq) return false;
 	const int f = r.flag();
 	if (!((f & F_PAIRED) && (f & F_PROPER) && !(f & F_DUP))) return false;
@@ -39,14 +36,22 @@ __device__ __forceinline__ bool isize_qualifies(const DevBatch &b, int64_t i, in
 	return !is_hard_clip(b, r);
 }
 
-// pass A: qualifying records per tile
-__global__ __launch_bounds__(BLOCK) void k_isize_count(DevBatch b, int min_mapq, uint32_t *__restrict__ tile_cnt)
+// pass A: four lanes fetch a record's line (the pass covers a bounded prefix of the file - the first -n qualifying records - so whole lines
+// are fine); val[i] = its insert size when it qualifies, else 0 (a qualifying insert size is > 0); qualifying records per tile of 256
+__global__ __launch_bounds__(BLOCK) void k_isize_count(DevBatch b, int min_mapq, int32_t *__restrict__ val, uint32_t *__restrict__ tile_cnt)
 {
 	__shared__ uint32_t lds[WAVES_PER_BLOCK];
-	int64_t i0 = (int64_t)blockIdx.x * ISZ_TILE + (int64_t)threadIdx.x * ISZ_ITEMS;
+	const int q = (int)(threadIdx.x & 3);
 	uint32_t c = 0;
 #pragma unroll
-	for (int k = 0; k < ISZ_ITEMS; ++k) { int v; if (i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq, &v)) ++c; }
+	for (int k = 0; k < 4; ++k) {
+		const int64_t i = (int64_t)blockIdx.x * ISZ_TILE + k * (BLOCK / 4) + (threadIdx.x >> 2);
+		if (i < b.n) {
+			const RecLine r = rec_load_quad(b.rec, i, q);
+			const bool ok = isize_qualifies(b, r, min_mapq);
+			if (q == 0) { val[i] = ok ? r.isize() : 0; c += ok ? 1u : 0u; }
+		}
+	}
 	c = wave_sum(c);
 	if (lane_id() == 0) lds[wave_id()] = c;
 	__syncthreads();
@@ -54,21 +59,16 @@ __global__ __launch_bounds__(BLOCK) void k_isize_count(DevBatch b, int min_mapq,
 }
 
 // pass B: the qualifying record with file-order ordinal o < max_pairs stores its isize at vals[o]
-__global__ __launch_bounds__(BLOCK) void k_isize_collect(DevBatch b, int min_mapq, const uint32_t *__restrict__ tile_base, int64_t count_before, int64_t max_pairs,
+__global__ __launch_bounds__(BLOCK) void k_isize_collect(const int32_t *__restrict__ val, int64_t n, const uint32_t *__restrict__ tile_base, int64_t count_before, int64_t max_pairs,
                                                          int32_t *__restrict__ vals)
 {
 	__shared__ uint32_t lds[WAVES_PER_BLOCK + 1];
-	int64_t i0 = (int64_t)blockIdx.x * ISZ_TILE + (int64_t)threadIdx.x * ISZ_ITEMS;
-	bool q[ISZ_ITEMS];
-	int val[ISZ_ITEMS];
-	uint32_t c = 0;
-#pragma unroll
-	for (int k = 0; k < ISZ_ITEMS; ++k) { val[k] = 0; q[k] = i0 + k < b.n && isize_qualifies(b, i0 + k, min_mapq, &val[k]); c += q[k]; }
+	const int64_t i = (int64_t)blockIdx.x * ISZ_TILE + threadIdx.x;
+	const int v = i < n ? val[i] : 0;
 	uint32_t tot;
-	uint32_t ex = block_exclusive_sum(c, lds, &tot);
-	int64_t o = count_before + tile_base[blockIdx.x] + ex;
-#pragma unroll
-	for (int k = 0; k < ISZ_ITEMS; ++k) if (q[k]) { if (o < max_pairs) vals[o] = val[k]; ++o; }
+	const uint32_t ex = block_exclusive_sum(v > 0 ? 1u : 0u, lds, &tot);
+	const int64_t o = count_before + tile_base[blockIdx.x] + ex;
+	if (v > 0 && o < max_pairs) vals[o] = v;
 }
 
 // sum of vals (mode 0) or of the int-wrapped squared deviations from mean (mode 1, cluster.cpp:77) into *acc

@@ -43,16 +43,20 @@ struct PlainTab {
 
 struct BitReader {
 	const uint8_t *p;   // address of `ahead`
+	const uint8_t *lim; // loads start below this address: the stream's end + 4 (buffers keep 8 spare bytes behind the last stream)
 	uint64_t bb = 0;    // bit buffer, LSB first
 	int bc = 0;         // valid bits in bb
 	uint32_t ahead;     // the next 32 input bits, loaded one refill early: its latency hides behind the symbols decoded meanwhile
-	SSV_HD explicit BitReader(const uint8_t *in) : p(in) { memcpy(&ahead, p, 4); }
+	SSV_HD BitReader(const uint8_t *in, uint32_t in_len) : p(in), lim(in + in_len + 4) { fetch(); }
+	// a damaged or crafted stream can ask for more input than it has: past the end it is fed zero bits (which every path of the decoder
+	// turns into an error or into output that hits the output bound) instead of whatever lies behind the buffer
+	SSV_HD void fetch() { if (p < lim) memcpy(&ahead, p, 4); else ahead = 0; }
 	SSV_HD void refill() // afterwards bc >= 32 (looks up to 8 bytes past the data: buffers are padded)
 	{
 		if (bc < 32) {
 			bb |= (uint64_t)ahead << bc;
 			bc += 32; p += 4;
-			memcpy(&ahead, p, 4);
+			fetch();
 		}
 	}
 	SSV_HD uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
@@ -164,7 +168,7 @@ SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCount
 template <class Tab>
 SSV_HD int inflate_stream(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tab &tab)
 {
-	BitReader br(in);
+	BitReader br(in, in_len);
 	uint32_t o = 0;
 	int last;
 	do {

@@ -105,7 +105,7 @@ struct ssv_ctx {
 	bool isz_active = false;
 	int isz_min_mapq = 0;
 	int64_t isz_max = 0, isz_count = 0;
-	DBuf isz_vals, isz_acc;
+	DBuf isz_vals, isz_acc, isz_tmp;
 
 	// ---- getsv ----
 	bool gs_active = false;
@@ -390,7 +390,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	DBuf *dbufs[] = {&c->sb_rec, &c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage,
 	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_strings,
-	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc,
+	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
 	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry,
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
@@ -865,9 +865,10 @@ int ssv_isize_accumulate(ssv_ctx *c, const ssv_batch_t *b, int32_t *done)
 	CHECK(ensure(c, c->totals, 64)); CHECK(ensure_host(c, c->h_totals, 64));
 	const int64_t need = std::min<int64_t>(c->isz_max, c->isz_count + d.n);
 	CHECK(ensure(c, c->isz_vals, (size_t)need * 4 + 16, true, (size_t)c->isz_count * 4));
-	k_isize_count<<<(unsigned)ntiles, BLOCK, 0, c->st>>>(d, c->isz_min_mapq, P<uint32_t>(c->tile_cnt));
+	CHECK(ensure(c, c->isz_tmp, (size_t)d.n * 4 + 16));
+	k_isize_count<<<(unsigned)ntiles, BLOCK, 0, c->st>>>(d, c->isz_min_mapq, P<int32_t>(c->isz_tmp), P<uint32_t>(c->tile_cnt));
 	exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->tile_cnt), P<uint32_t>(c->tile_base), ntiles, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals));
-	k_isize_collect<<<(unsigned)ntiles, BLOCK, 0, c->st>>>(d, c->isz_min_mapq, P<uint32_t>(c->tile_base), c->isz_count, c->isz_max, P<int32_t>(c->isz_vals));
+	k_isize_collect<<<(unsigned)ntiles, BLOCK, 0, c->st>>>(P<int32_t>(c->isz_tmp), d.n, P<uint32_t>(c->tile_base), c->isz_count, c->isz_max, P<int32_t>(c->isz_vals));
 	HIPCHECK(c, hipGetLastError());
 	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 4, hipMemcpyDeviceToHost, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st));

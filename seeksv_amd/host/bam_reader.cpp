@@ -149,12 +149,13 @@ struct Bgzf {
 		int bsize = -1;
 		for (size_t off = 0; off + 4 <= xlen;) {
 			unsigned slen = extra[off + 2] | (extra[off + 3] << 8);
+			if (off + 4 + slen > xlen) break; // a subfield that runs past the extra field: malformed, stop here
 			if (extra[off] == 'B' && extra[off + 1] == 'C' && slen == 2) bsize = extra[off + 4] | (extra[off + 5] << 8);
 			off += 4 + slen;
 		}
 		if (bsize < 0) { g_err = "BGZF block without BC field"; eof = true; return false; }
+		if ((size_t)bsize + 1 < 12 + (size_t)xlen + 8) { g_err = "bad BGZF block size"; eof = true; return false; } // (the subtraction below would wrap)
 		size_t clen = (size_t)bsize + 1 - 12 - xlen; // deflate data + crc32 + isize
-		if (clen < 8) { g_err = "bad BGZF block size"; eof = true; return false; }
 		blk.c.resize(clen);
 		if (fread(blk.c.data(), 1, clen, fp) != clen) { g_err = "truncated BGZF block"; eof = true; return false; }
 		memcpy(&blk.isize, blk.c.data() + clen - 4, 4);
@@ -177,12 +178,13 @@ struct Bgzf {
 		int bsize = -1;
 		for (size_t off = 0; off + 4 <= xlen;) {
 			unsigned slen = extra[off + 2] | (extra[off + 3] << 8);
+			if (off + 4 + slen > xlen) break; // a subfield that runs past the extra field: malformed, stop here
 			if (extra[off] == 'B' && extra[off + 1] == 'C' && slen == 2) bsize = extra[off + 4] | (extra[off + 5] << 8);
 			off += 4 + slen;
 		}
 		if (bsize < 0) { g_err = "BGZF block without BC field"; eof = true; return -1; }
+		if ((size_t)bsize + 1 < 12 + (size_t)xlen + 8) { g_err = "bad BGZF block size"; eof = true; return -1; } // (the subtraction below would wrap)
 		const size_t clen = (size_t)bsize + 1 - 12 - xlen;
-		if (clen < 8) { g_err = "bad BGZF block size"; eof = true; return -1; }
 		if (clen - 8 + 8 > room) { fseek(fp, at, SEEK_SET); return 2; } // 8 spare bytes: the device bit reader looks 4 bytes ahead
 		uint8_t tail[8];
 		if (fread(dst, 1, clen - 8, fp) != clen - 8 || fread(tail, 1, 8, fp) != 8) { g_err = "truncated BGZF block"; eof = true; return -1; }
@@ -467,6 +469,7 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 		if (rc == 0 || rc == 2) break;
 		if (n > 0 && inflated + isize > max_inflated) { fseek(b->z.fp, at, SEEK_SET); break; }
 		if (isize == 0) continue; // empty blocks (the EOF marker) carry nothing
+		if (isize > 65536) { g_err = "BGZF block that claims to inflate to more than 64 KB"; return -1; }
 		blocks[n].c_off = used; blocks[n].c_len = payload; blocks[n].u_len = isize;
 		used += payload; inflated += isize;
 		++n;
@@ -648,7 +651,7 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 			if (flag & (4 | 8)) {
 				// GetSeqAndQual (clip_reads.cpp:375-388): bases as stored, qualities +33, "*" when absent
 				Unmapped u;
-				u.qname.assign((const char *)r + o_name);
+				u.qname.assign((const char *)r + o_name, strnlen((const char *)r + o_name, l_read_name ? (size_t)l_read_name - 1 : 0)); // bounded by l_read_name: a name without its NUL must not run on
 				u.seq.resize((size_t)l_seq);
 				for (int32_t k = 0; k < l_seq; ++k) u.seq[(size_t)k] = NT16[(r[o_seq + (k >> 1)] >> ((~k & 1) << 2)) & 15];
 				if (l_seq > 0 && r[o_qual] == 0xff) u.qual = "*";
@@ -885,7 +888,7 @@ size_t ssvh_raw_record_fastq(const uint8_t *raw, size_t raw_bytes, size_t offset
 	memcpy(&ncig, r + 12, 2); memcpy(&flag, r + 14, 2); memcpy(&l_seq, r + 16, 4);
 	const size_t o_seq = 32 + (size_t)r[8] + 4 * (size_t)ncig, o_qual = o_seq + ((size_t)l_seq + 1) / 2;
 	if (l_seq < 0 || o_qual + (size_t)l_seq > bs) return 0;
-	u.qname.assign((const char *)r + 32);
+	u.qname.assign((const char *)r + 32, strnlen((const char *)r + 32, r[8] ? (size_t)r[8] - 1 : 0));
 	u.seq.resize((size_t)l_seq);
 	for (int32_t k = 0; k < l_seq; ++k) u.seq[(size_t)k] = NT16[(r[o_seq + (k >> 1)] >> ((~k & 1) << 2)) & 15];
 	if (l_seq > 0 && r[o_qual] == 0xff) u.qual = "*";

@@ -296,3 +296,39 @@ def test_pileup_read_cap_synthetic_12000x(ctx):
     assert np.array_equal(c2, oc) and np.array_equal(r2, ors) and np.array_equal(p2, opd)
     plan.close()
     hdr.close()
+
+
+def _with_cigar(hb, k, ops):
+    """copy of a host batch whose record k carries the CIGAR `ops` (list of (len, op)) instead of its own"""
+    out = {n: (v.copy() if isinstance(v, np.ndarray) else v) for n, v in hb.items()}
+    off, nc = hb["cigar_off"].astype(np.int64), hb["n_cigar"].astype(np.int64)
+    new = np.array([(l << 4) | o for l, o in ops], dtype=np.uint32)
+    out["cigar"] = np.concatenate([hb["cigar"][:off[k]], new, hb["cigar"][off[k] + nc[k]:]])
+    out["n_cigar"][k] = len(new)
+    out["cigar_off"] = np.concatenate([[0], np.cumsum(out["n_cigar"].astype(np.int64))[:-1]]).astype(np.uint32)
+    return out
+
+
+def test_pileup_ring_grows_with_a_later_long_read(ctx):
+    """the ring of read ends behind the pileup's read cap is sized by the longest reference span seen so far: a first batch of plain 150 bp
+    reads (ring of 8192 columns), then a batch holding a read with a 20 kb `N` skip in the middle of a >8000x stack, while the cap's
+    sweep is running across the batch boundary.  The pass used to fail with SSV_E_RANGE here; now the ring grows and the live entries move."""
+    from seeksv_amd import synth
+    from test_oracle_golden import split_batch
+    w = synth.Workload(genome_frac=1 / 65536, depth=12000, n_sv=6, n_contigs=3, min_contig=12000)
+    hdr = host.Header(w.names, w.lens)
+    hb = w.generate_host(0, w.n_total)
+    cut = w.n_total // 2 + 7
+    k = next(i for i in range(cut + 5000, w.n_total) if hb["n_cigar"][i] == 1 and hb["mapq"][i] >= 20 and not (hb["flag"][i] & 0x704) and hb["tid"][i] == hb["tid"][cut])
+    hb2 = _with_cigar(hb, k, [(50, 0), (20000, 3), (100, 0)])
+    stats = O.isize_stats([hb2], 20, 100000)
+    plan = host.Plan(hdr, w.junctions, stats[2], stats[3])
+    oc = O.discordant([hb2], plan.junctions, stats[2], stats[3], 4, 20)
+    ors, opd, omax = O.depth([hb2], plan.windows, plan.ranges, plan.points, 20)
+    a, b = split_batch(hb2, 0, cut), split_batch(hb2, cut, w.n_total)
+    a["max_ref_span"], b["max_ref_span"] = 158, 20150
+    c, r, p = ctx.discordant_and_depth([a, b], plan, stats[2], stats[3], 20, hdr.target_lens)
+    assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd)
+    assert 7800 < int(opd.max()) < 8100
+    plan.close()
+    hdr.close()

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 PMC passes of bench.py (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; the TCC block cannot hold both)
-into profiles/r01_pmc_fetch_write.csv (per kernel) and profiles/traffic.json (HBM bytes per unit for the kernel groups bench.py prices).
+into profiles/<tag>_pmc_fetch_write.csv (per kernel) and profiles/traffic.json (HBM bytes per step: per kernel group and for the whole path).
 
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <records> <events>
-  each dir holds <something>_counter_collection.csv and <something>_kernel_trace.csv as written by
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <records> <steps> [tag]
+  each dir holds <something>_counter_collection.csv as written by
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dir> -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap
+  (steps = the steps that run of bench.py executed: timed + breakdown = 1 + 3)
 FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE shows exactly half the bytes of a
 wide coalesced streaming read (16 B/lane), so it is doubled for the two streaming scans, whose loads are all of that kind; other
-kernels' loads are narrower or scattered and are taken as reported."""
+kernels' loads are scattered 16-byte quarters of 64-byte lines or narrower and are taken as reported (uncalibrated)."""
 import collections
 import csv
 import glob
@@ -18,73 +19,91 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# kernel -> group of bench.py (ssv_prof_*); the device-wide scans and fills belong to whatever named kernel ran before them
+GROUP_OF = {
+    "k_clip_scan": "clip_scan", "k_cand_place": "clip_place", "k_clip_filter": "clip_place", "k_clip_place": "clip_place", "k_event_max": "clip_place", "k_last_tid": "clip_place",
+    "k_gather_sizes": "clip_gather", "k_clip_gather": "clip_gather",
+    "k_check_sorted": "event_sort", "k_key_max": "event_sort", "k_qual_sample": "event_sort", "k_rs_hist": "event_sort", "k_rs_scatter": "event_sort", "k_side_bounds": "event_sort",
+    "k_merge_sides": "event_sort", "k_concat_sides": "event_sort", "k_gather_lines": "event_sort", "k_iota": "event_sort",
+    "k_bin_mark": "cluster_bins", "k_multi_list": "cluster_bins", "k_bin_start_flags": "cluster_bins", "k_bin_start_list": "cluster_bins", "k_cluster_bins": "cluster_bins",
+    "k_cluster_meta": "cluster_pack", "k_cluster_cols": "cluster_pack", "k_cluster_pack_stream": "cluster_pack", "k_cluster_pack_slow": "cluster_pack", "k_cluster_pack_ascii": "cluster_pack",
+    "k_isize_count": "isize_stats", "k_isize_collect": "isize_stats", "k_isize_reduce": "isize_stats",
+    "k_tile_mark_windows": "getsv_scan", "k_tile_mark_junctions": "getsv_scan", "k_getsv_scan": "getsv_scan", "k_max_span": "getsv_scan",
+    "k_getsv_cand": "getsv_cand", "k_cap_mark": "getsv_cand", "k_cap_sweep": "getsv_cand", "k_cap_tail": "getsv_cand", "k_cap_regrow": "getsv_cand",
+    "k_depth_prefix": "depth_finish", "k_range_sum": "depth_finish", "k_point_depth": "depth_finish",
+    "k_build_rec": "h2d",
+}
+DOUBLE_FETCH = {"k_clip_scan", "k_getsv_scan"}
+
 
 def short(name):
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
-    return name.replace("ssv::", "")
+    name = name.replace("ssv::", "")
+    return name
+
+
+def base(name):
+    return re.sub(r"<.*$", "", name)
 
 
 def load(d, counter):
-    per_dispatch = collections.defaultdict(float)
-    kern = {}
-    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*counter_collection.csv"))[0])):
-        if r["Counter_Name"] == counter:
-            per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
-            kern[r["Dispatch_Id"]] = short(r["Kernel_Name"])
-    out = collections.defaultdict(list)
-    for k, v in per_dispatch.items():
-        out[kern[k]].append(v)
-    dur = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*kernel_trace.csv"))[0])):
-        dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    return out, dur
+    per = collections.OrderedDict()
+    rows = list(csv.DictReader(open(glob.glob(os.path.join(d, "*counter_collection.csv"))[0])))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        if r["Counter_Name"] != counter:
+            continue
+        k = int(r["Dispatch_Id"])
+        e = per.setdefault(k, [short(r["Kernel_Name"]), 0.0, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3])
+        e[1] += float(r["Counter_Value"])
+    return list(per.values())
 
 
 def main():
-    fetch_dir, write_dir, records, events = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-    fetch, dur = load(fetch_dir, "FETCH_SIZE")
-    write, _ = load(write_dir, "WRITE_SIZE")
-    rows = []
-    for k in sorted(set(fetch) | set(write)):
-        if k.startswith(("k_sy_", "__amd")):
-            continue  # the synthetic generator and runtime copies are not part of the path
-        f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
-        rows.append((k, len(f), sum(f) / len(f), sum(w) / len(w), sum(dur[k]) / max(1, len(dur[k]))))
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.csv"), "w") as o:
-        o.write(f"# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap` ({records:,} records, {events:,} clip events)\n")
+    fetch_dir, write_dir, records, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    tag = sys.argv[5] if len(sys.argv) > 5 else "r02"
+    fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+
+    def per_kernel(disp):
+        out, dur, cnt = collections.defaultdict(float), collections.defaultdict(float), collections.Counter()
+        for name, v, d in disp:
+            out[name] += v; dur[name] += d; cnt[name] += 1
+        return out, dur, cnt
+
+    def per_group(disp, fetch_side):
+        g, cur = collections.defaultdict(float), None
+        for name, v, _ in disp:
+            b = base(name)
+            if b.startswith(("k_sy_", "__amd_rocclr_copy")):
+                continue  # the synthetic generator and runtime copies are not part of the path
+            if b in GROUP_OF:
+                cur = GROUP_OF[b]
+            if cur is None:
+                continue
+            g[cur] += v * 1024 * (2 if fetch_side and b in DOUBLE_FETCH else 1)
+        return g
+
+    fk, fd, fc = per_kernel(fetch)
+    wk, _, _ = per_kernel(write)
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_write.csv"), "w") as o:
+        o.write(f"# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap` ({records:,} records, {steps} steps run)\n")
         o.write("# values in KB as reported, averaged over the kernel's dispatches. gfx950: FETCH_SIZE counts a 16-B/lane coalesced stream at HALF its bytes (MI355X_MICROARCH.md, HBM); other widths are uncalibrated\n")
         o.write("kernel,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,avg_duration_us_in_pmc_run\n")
-        for k, n, f, w, d in rows:
-            o.write(f"{k},{n},{f:.1f},{w:.1f},{d:.1f}\n")
-    by = {k: (n, f * 1024, w * 1024) for k, n, f, w, d in rows}
-
-    def total(names, per_launch_mult=None):
-        fb = wb = 0.0
-        for nm in names:
-            for k, (n, f, w) in by.items():
-                if k == nm or k.startswith(nm + "<"):
-                    m = n if per_launch_mult is None else per_launch_mult
-                    fb += f * m
-                    wb += w * m
-        return fb, wb
-
-    t = {"_note": "HBM bytes per unit from the rocprofv3 PMC passes in profiles/r01_pmc_fetch_write.csv: (2 x FETCH_SIZE for kernels whose streams are 16-B/lane loads, "
-                  "the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, divided by the units of one launch; regenerate with tools/pmc_traffic.py"}
-    f, w = total(["k_clip_scan"], 1)
-    t["clip_scan"] = {"bytes_per_record": (2 * f + w) / records, "fetch_raw_bytes": f, "write_bytes": w}
-    f, w = total(["k_getsv_scan"], 1)
-    t["getsv_scan"] = {"bytes_per_record": (2 * f + w) / records, "fetch_raw_bytes": f, "write_bytes": w}
-    f, w = total(["k_clip_gather"], 1)
-    t["clip_gather"] = {"bytes_per_record": (f + w) / events, "_unit": "event", "_correction": "none (4-B/lane loads: FETCH_SIZE taken as reported)"}
-    f, w = total(["k_cluster_pack_meta", "k_cluster_pack_codes", "k_cluster_pack_ascii"], 1)  # both launches of k_cluster_pack_codes (dword path + bytewise list)
-    t["cluster_pack"] = {"bytes_per_record": (f + w) / events, "_unit": "event slot", "_correction": "none"}
-    n_steps = by["k_clip_scan"][0]  # steps in the profiled run (the sort kernels run several passes per step)
-    f, w = total(["k_rs_hist", "k_rs_scatter"])
-    f, w = f / n_steps, w / n_steps
-    t["event_sort"] = {"bytes_per_record": (f + w) / events, "_unit": "event", "_correction": "none; all passes of k_rs_hist + k_rs_scatter of one step, histogram scans not included"}
+        for k in sorted(set(fk) | set(wk)):
+            if k.startswith(("k_sy_", "__amd")):
+                continue
+            n = max(fc.get(k, 0), 1)
+            o.write(f"{k},{n},{fk.get(k, 0.0) / n:.1f},{wk.get(k, 0.0) / n:.1f},{fd.get(k, 0.0) / n:.1f}\n")
+    gf, gw = per_group(fetch, True), per_group(write, False)
+    groups = {g: (gf.get(g, 0.0) + gw.get(g, 0.0)) / steps for g in sorted(set(gf) | set(gw)) if g != "h2d"}
+    t = {"_note": f"HBM bytes per step from the rocprofv3 PMC passes in profiles/{tag}_pmc_fetch_write.csv: FETCH_SIZE (doubled for the two streaming scans, whose 16-B/lane loads gfx950 counts at "
+                  "half: MI355X_MICROARCH.md) + WRITE_SIZE per kernel group of bench.py, device-wide scans and fills counted with the kernel they follow; regenerate with tools/pmc_traffic.py",
+         "records": records, "groups": groups, "path_bytes_per_step": sum(groups.values()),
+         "path_bytes_per_record": sum(groups.values()) / records}
     json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-    print(json.dumps({k: v["bytes_per_record"] for k, v in t.items() if isinstance(v, dict)}))
+    print(json.dumps(t, indent=1))
 
 
 if __name__ == "__main__":
