@@ -360,13 +360,16 @@ def file_path_leg(ctx, args, device):
             if hl.ssvh_bam_raw_begin(r.handle, C.byref(first)) != 0:
                 raise IOError(hl.ssvh_last_error().decode())
             n_targets = len(r.target_names)
-            max_blocks = 1 << 17
-            cap = 192 << 20
+            # chunks of ~6 GB of inflated data (about 100 K BGZF blocks each): the inflate kernel decodes one block per lane and needs that many
+            # to fill the chip
+            chunk_inflated = 6 << 30
+            max_blocks = 1 << 18
+            cap = min(bam_bytes + (1 << 20), 1 << 30)
             while True:
                 buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
                 blocks = (_abi.BgzfBlock * max_blocks)()
                 nb, nbytes = C.c_int64(), C.c_size_t()
-                if hl.ssvh_bam_read_blocks(r.handle, C.c_void_p(buf.data_ptr()), cap, 2 << 30, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
+                if hl.ssvh_bam_read_blocks(r.handle, C.c_void_p(buf.data_ptr()), cap, chunk_inflated, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
                     raise IOError(hl.ssvh_last_error().decode())
                 if nb.value == 0:
                     break
@@ -405,12 +408,26 @@ def file_path_leg(ctx, args, device):
             # ---- pass 2: seeksv getsv (insert size on the file's first chunk, then discordant pairs + depth of every chunk) ----
             t1 = time.perf_counter()
             ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
-            b0 = decode(0)
-            rc, npairs, mean, sd = ctx.isize_stats([b0], 20, 5000000)
+            # CalculateInsertsizeDeviation reads the file until it has its 5,000,000 pairs (cluster.cpp:68): usually inside the first chunk,
+            # which then serves the scan as well; if it took more chunks, decoding starts over for the scan
+            ctx._check(lib.ssv_isize_begin(ctx._h, 20, 5000000), "ssv_isize_begin")
+            done, used, b0 = C.c_int32(0), 0, None
+            while used < len(chunks) and not done.value:
+                b0 = decode(used)
+                used += 1
+                ctx._check(lib.ssv_isize_accumulate(ctx._h, C.byref(b0), C.byref(done)), "ssv_isize_accumulate")
+            npairs, mean, sd = C.c_int64(), C.c_int32(0), C.c_int32(0)
+            ctx._check(lib.ssv_isize_finish(ctx._h, C.byref(npairs), C.byref(mean), C.byref(sd)), "ssv_isize_finish")
+            npairs, mean, sd = npairs.value, mean.value, sd.value
             plan = host.Plan(hdr, jtable, mean, sd)
             ctx.getsv_begin(plan.junctions, plan.windows, mean, sd, hdr.target_lens, 4, 20, 20)
-            ctx.getsv_scan(b0)
-            for k in range(1, len(chunks)):
+            if used == 1:
+                ctx.getsv_scan(b0)
+                first_k = 1
+            else:
+                ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
+                first_k = 0
+            for k in range(first_k, len(chunks)):
                 ctx.getsv_scan(decode(k))
             end_of_input()
             counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
