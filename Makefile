@@ -7,7 +7,7 @@ CXXFLAGS = -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude
 HIPFLAGS = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Wall -Wno-unused-result
 
 LIBDIR = seeksv_amd/lib
-HOST_SRC = seeksv_amd/host/bam_reader.cpp seeksv_amd/host/getsv_plan.cpp
+HOST_SRC = seeksv_amd/host/bam_reader.cpp seeksv_amd/host/bam_partition.cpp seeksv_amd/host/getsv_plan.cpp
 HIP_SRC  = seeksv_amd/csrc/seeksv_hip.hip
 HIP_DEPS = $(wildcard seeksv_amd/csrc/*.h) $(wildcard seeksv_amd/csrc/*.hip) include/seeksv_hip.h
 

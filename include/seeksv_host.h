@@ -39,6 +39,35 @@ const int32_t *ssvh_bam_target_lens(const ssvh_bam *b);
  */
 int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_batch_t *out);
 
+/*
+ * Range-partitioned reading (the reference reaches a region through the .bai: seeksv.cpp:272-280 bam_index_load,
+ * getsv.cpp:1063-1067 bam_iter_query / bam_iter_read; here the FILE is cut into N contiguous runs of records, one per GPU, and no index
+ * is needed).  Positions are BGZF virtual offsets given as (file offset of the block, offset inside its inflated bytes).
+ *   ssvh_bam_partition   n_parts runs balanced by inflated bytes; every boundary is the exact start of a record (found by speculation inside
+ *                        the block and verified by following the block_size chain over >= 8 records).  For the getclip pass a part also
+ *                        knows where its HALO begins: the first record that starts within halo_bp before the part's first record on
+ *                        the same contig - a right-clipped read's breakpoint lies at its start + reference span, so such a record can own
+ *                        a breakpoint inside the part (halo_bp >= the longest reference span of a read) - and the contig of the last
+ *                        mapped-pair record before the halo (the contig-switch rule of clip_reads.h:423-438 needs it).
+ *   ssvh_bam_walk_back   the record n_back records before a position (the first record of the file if there are fewer): where the replay
+ *                        of the pileup's read cap starts (bam2depth.cpp:72-75, libbam's bam_plp_push).
+ *   ssvh_bam_set_range   ssvh_bam_read_batch / ssvh_bam_unmapped_* then yield exactly the records that start in [start, end)
+ *                        (end_coff = UINT64_MAX: to the end of the file).
+ */
+typedef struct {
+	uint64_t scan_coff; uint32_t scan_uoff;  /* getclip: first record to scan (halo start; = own for part 0) */
+	uint64_t own_coff; uint32_t own_uoff;    /* first record of the part */
+	uint64_t end_coff; uint32_t end_uoff;    /* first record of the next part (UINT64_MAX, 0 for the last part) */
+	int32_t own_tid, own_pos;                /* contig and 0-based position of the part's first record (own_tid = n_targets when it is unplaced or the part is empty) */
+	int32_t initial_last_tid;                /* contig of the last record without UNMAP|MUNMAP before the scan start (0 at the start of the file) */
+	int32_t pad;
+	int64_t halo_records;                    /* records in [scan, own) */
+} ssvh_bam_part;
+int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_bam_part *parts);
+int ssvh_bam_walk_back(const char *path, uint64_t coff, uint32_t uoff, int64_t n_back, uint64_t *out_coff, uint32_t *out_uoff, int64_t *n_found);
+int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff);
+const char *ssvh_partition_last_error(void); /* message of the last failed ssvh_bam_partition / ssvh_bam_walk_back of this thread */
+
 /* on != 0: after handing out a batch, ssvh_bam_read_batch decodes the following one on a background thread into a second set
  * of arrays, so that inflate + decode overlap whatever the caller does with the current batch (upload, kernels, output).  While
  * it is on, every read_batch call must pass the same max_records / keep_all_seq, and ssvh_bam_next_record is refused. */

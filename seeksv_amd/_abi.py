@@ -182,6 +182,12 @@ def _load(name):
     return _libs[name]
 
 
+class BamPart(C.Structure):
+    """ssvh_bam_part"""
+    _fields_ = [("scan_coff", C.c_uint64), ("scan_uoff", C.c_uint32), ("own_coff", C.c_uint64), ("own_uoff", C.c_uint32), ("end_coff", C.c_uint64), ("end_uoff", C.c_uint32),
+                ("own_tid", C.c_int32), ("own_pos", C.c_int32), ("initial_last_tid", C.c_int32), ("pad", C.c_int32), ("halo_records", C.c_int64)]
+
+
 def host_lib():
     lib = _load("libseeksv_host.so")
     if not getattr(lib, "_typed", False):
@@ -204,6 +210,10 @@ def host_lib():
         lib.ssvh_bam_unmapped_count.argtypes = [C.c_void_p]
         lib.ssvh_bam_unmapped_count.restype = C.c_int64
         lib.ssvh_bam_unmapped_get.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        lib.ssvh_bam_partition.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(BamPart)]
+        lib.ssvh_bam_walk_back.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
+        lib.ssvh_bam_set_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
+        lib.ssvh_partition_last_error.restype = C.c_char_p
         lib.ssvh_plan_create.argtypes = [C.c_void_p, C.POINTER(JunctionIn), C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int64,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         lib.ssvh_plan_destroy.argtypes = [C.c_void_p]

@@ -30,6 +30,12 @@ class BamReader:
     def handle(self):
         return self._h
 
+    def set_range(self, start, end=None):
+        """read_batch then yields the records that start in [start, end): (block file offset, offset inside the block) pairs from partition()"""
+        ec, eu = ((1 << 64) - 1, 0) if end is None else end
+        if self._lib.ssvh_bam_set_range(self._h, start[0], start[1], ec, eu) != 0:
+            raise IOError(self._lib.ssvh_last_error().decode())
+
     def read_batch(self, max_records=1 << 20, keep_all_seq=False):
         """Next batch as a dict of owned numpy arrays (None at EOF)."""
         b = _abi.Batch()
@@ -82,6 +88,26 @@ class Header:
         if self._h:
             self._lib.ssvh_bam_close(self._h)
             self._h = None
+
+
+def partition(path, n_parts, halo_bp=1000):
+    """ssvh_bam_partition: list of dicts (scan / own / end = (block file offset, offset inside the block); end None = end of file)"""
+    lib = _abi.host_lib()
+    parts = (_abi.BamPart * n_parts)()
+    if lib.ssvh_bam_partition(path.encode(), n_parts, halo_bp, parts) != 0:
+        raise IOError(lib.ssvh_partition_last_error().decode())
+    return [dict(scan=(p.scan_coff, p.scan_uoff), own=(p.own_coff, p.own_uoff), end=None if p.end_coff == (1 << 64) - 1 else (p.end_coff, p.end_uoff),
+                 own_tid=p.own_tid, own_pos=p.own_pos, initial_last_tid=p.initial_last_tid, halo_records=p.halo_records) for p in parts]
+
+
+def walk_back(path, at, n_back):
+    """ssvh_bam_walk_back: -> ((block file offset, offset inside the block), records walked)"""
+    lib = _abi.host_lib()
+    co, uo, n = C.c_uint64(), C.c_uint32(), C.c_int64()
+    ec, eu = ((1 << 64) - 1, 0) if at is None else at
+    if lib.ssvh_bam_walk_back(path.encode(), ec, eu, n_back, C.byref(co), C.byref(uo), C.byref(n)) != 0:
+        raise IOError(lib.ssvh_partition_last_error().decode())
+    return (co.value, uo.value), n.value
 
 
 def write_bam(path, names, lens, batches, qname_prefix="s"):

@@ -112,7 +112,11 @@ static Pool &wpool() // the writing side (deflate), so that a read-ahead in flig
 struct Bgzf {
 	FILE *fp = nullptr;
 	static constexpr int CHUNK_BLOCKS = 1024; // up to 64 MB of uncompressed data per refill
-	struct Block { std::vector<uint8_t> c; uint32_t isize = 0; size_t uoff = 0; bool ok = true; };
+	struct Block { std::vector<uint8_t> c; uint32_t isize = 0, use = 0; size_t uoff = 0; bool ok = true; }; // use: bytes of the inflated block that count (all of them, except in the block a range ends in)
+	// a range of the file (ssvh_bam_set_range): reading stops at the record that starts end_uoff bytes into the block at file offset end_coff
+	long end_coff = -1;
+	uint32_t end_uoff = 0;
+	bool end_seen = false;
 	std::vector<Block> blocks;
 	// the inflated window: a plain malloc'd buffer, never value-initialised (fresh pages are touched only by the inflating threads) and
 	// reserved once at its working size so that growing it does not copy
@@ -138,6 +142,12 @@ struct Bgzf {
 	bool read_block(Block &blk)
 	{
 		uint8_t hdr[18];
+		bool last_of_range = false;
+		if (end_coff >= 0) {
+			const long at = ftell(fp);
+			if (at > end_coff || (at == end_coff && (end_uoff == 0 || end_seen))) { eof = true; return false; }
+			if (at == end_coff) { end_seen = true; last_of_range = true; }
+		}
 		size_t got = fread(hdr, 1, 18, fp);
 		if (got == 0) { eof = true; return false; }
 		if (got < 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { g_err = "not a BGZF block"; eof = true; return false; }
@@ -159,6 +169,7 @@ struct Bgzf {
 		blk.c.resize(clen);
 		if (fread(blk.c.data(), 1, clen, fp) != clen) { g_err = "truncated BGZF block"; eof = true; return false; }
 		memcpy(&blk.isize, blk.c.data() + clen - 4, 4);
+		blk.use = last_of_range ? std::min(blk.isize, end_uoff) : blk.isize;
 		return true;
 	}
 
@@ -202,12 +213,12 @@ struct Bgzf {
 		while (nb < CHUNK_BLOCKS) {
 			if (!read_block(blocks[(size_t)nb])) break;
 			blocks[(size_t)nb].uoff = total;
-			total += blocks[(size_t)nb].isize;
+			total += blocks[(size_t)nb].use;
 			++nb;
 		}
 		if (!g_err.empty()) return false;
 		if (nb == 0) return false;
-		ubuf.reserve_keep(total + 1, 0);
+		ubuf.reserve_keep(total + 65536 + 1, 0);
 		uint8_t *out = ubuf.data();
 		std::vector<Block> &bl = blocks;
 		pool().run(nb, [&bl, out](int i) {
@@ -269,11 +280,11 @@ struct Bgzf {
 		while (nb < CHUNK_BLOCKS) {
 			if (!read_block(blocks[(size_t)nb])) break;
 			blocks[(size_t)nb].uoff = ulen + total;
-			total += blocks[(size_t)nb].isize;
+			total += blocks[(size_t)nb].use;
 			++nb;
 		}
 		if (!g_err.empty() || nb == 0) return 0;
-		ubuf.reserve_keep(std::max(ulen + total + 1, window_reserve), ulen);
+		ubuf.reserve_keep(std::max(ulen + total + 65536 + 1, window_reserve), ulen);
 		uint8_t *out = ubuf.data();
 		std::vector<Block> &bl = blocks;
 		const int nseg = (nb + SEG_BLOCKS - 1) / SEG_BLOCKS;
@@ -293,7 +304,7 @@ struct Bgzf {
 				inflateEnd(&zs);
 				if (rc != Z_STREAM_END || zs.total_out != b.isize) b.ok = ok = false;
 			}
-			if (ok) scan(sg, bl[(size_t)b0].uoff, bl[(size_t)b1 - 1].uoff + bl[(size_t)b1 - 1].isize);
+			if (ok) scan(sg, bl[(size_t)b0].uoff, bl[(size_t)b1 - 1].uoff + bl[(size_t)b1 - 1].use);
 		});
 		for (int i = 0; i < nb; ++i) if (!blocks[(size_t)i].ok) { g_err = "BGZF inflate failed"; eof = true; return 0; }
 		ulen += total;
@@ -452,6 +463,24 @@ int ssvh_bam_raw_begin(ssvh_bam *b, uint64_t *first_record_offset)
 	if (fseek(b->z.fp, 0, SEEK_SET) != 0) { g_err = "cannot seek"; return -1; }
 	b->z.eof = false; b->z.upos = b->z.ulen = 0; b->found.clear(); b->found_pos = 0;
 	*first_record_offset = b->header_len;
+	return 0;
+}
+
+int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff)
+{
+	g_err.clear();
+	if (!b->z.fp) { g_err = "no file behind this handle"; return -1; }
+	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight"; return -1; }
+	b->z.upos = b->z.ulen = 0; b->found.clear(); b->found_pos = 0; b->chain_cur = 0;
+	if (start_coff == UINT64_MAX) { b->z.eof = true; return 0; } // a range that starts at the end of the file: empty
+	if (fseek(b->z.fp, (long)start_coff, SEEK_SET) != 0) { g_err = "cannot seek"; return -1; }
+	b->z.eof = false;
+	b->z.end_coff = end_coff == UINT64_MAX ? -1 : (long)end_coff; b->z.end_uoff = end_uoff; b->z.end_seen = false;
+	if (start_coff == end_coff && start_uoff >= end_uoff && end_coff != UINT64_MAX) { b->z.eof = true; return 0; } // empty range
+	// the first chunk of blocks is inflated here, so that the range's first record is where the window begins
+	if (!b->z.refill()) { if (!g_err.empty()) return -1; b->z.eof = true; return 0; }
+	if ((size_t)start_uoff > b->z.ulen) { g_err = "range start outside its block"; return -1; }
+	b->z.upos = start_uoff;
 	return 0;
 }
 
