@@ -113,6 +113,8 @@ int ssv_sync(ssv_ctx *ctx);
 /* Text of the last error on this context (or of the last failed ssv_ctx_create when ctx == NULL). */
 const char *ssv_last_error(const ssv_ctx *ctx);
 int ssv_abi_version(void);
+/* GPUs this process can see (0 when there is none or the HIP runtime is not usable). */
+int ssv_device_count(void);
 /* The hipStream_t the context launches on (for callers that time with HIP events). */
 void *ssv_stream(ssv_ctx *ctx);
 
@@ -250,6 +252,14 @@ int ssv_getsv_begin(ssv_ctx *ctx, const ssv_getsv_params *p);
 /* One fused pass over a batch: discordant-pair tally per junction + coverage of the windows. */
 int ssv_getsv_scan(ssv_ctx *ctx, const ssv_batch_t *b);
 /*
+ * Range-partitioned runs (one GPU per run of records): the reference's pileup keeps at most ~8000 reads alive (bam_plp_push), a rule that
+ * depends on the records BEFORE a rank's first one.  Right after ssv_getsv_begin a rank replays the last records before its range through
+ * the pileup's bookkeeping only (nothing of them is counted: they belong to the rank before).  *sufficient = 0: the replayed batch itself
+ * begins inside a > 8000x stack (or is shorter than 16,384 records without starting at the file's first record - the caller knows): call
+ * ssv_getsv_begin again and replay a longer run.  At WGS depths the first 24,576 records before the range always suffice.
+ */
+int ssv_getsv_prime(ssv_ctx *ctx, const ssv_batch_t *b, int32_t *sufficient);
+/*
  * counts[n_junctions]      = abnormal_read_pair_no per junction (getsv.cpp:1116)
  * range_sum[n_ranges]      = sum over the interval of per-column depth (bam2depth.cpp:101-122);
  *                            each range must lie inside one window
@@ -262,6 +272,18 @@ int ssv_getsv_finish(ssv_ctx *ctx, int32_t *counts,
                      const ssv_interval *ranges, int64_t n_ranges, uint64_t *range_sum,
                      const ssv_interval *points, int64_t n_points, int32_t *point_depth,
                      int32_t *max_depth);
+
+/* ---- range-partitioned runs: the one exchange step ------------------------------------------------------------------
+ * One context per GPU, one host thread per context.  Each rank scans its own run of records (libseeksv_host's ssvh_bam_partition cuts the
+ * file) for ALL junctions and windows; the per-rank result vectors - discordant counts, depth sums, point depths: KBs to a few MB - are
+ * all-gathered and added up by every rank.  RCCL (ncclAllGather over xGMI, loaded on first use) when the ranks sit on different GPUs;
+ * ranks that share a GPU (tests on a one-GPU box) exchange through host memory. */
+typedef struct ssv_group ssv_group;
+int ssv_group_create(ssv_ctx **ctxs, int n, ssv_group **out);
+void ssv_group_destroy(ssv_group *g);
+int ssv_group_uses_rccl(const ssv_group *g);
+/* Called by every rank from its own thread: send = this rank's `bytes` bytes (host memory), recv = n * bytes, rank order. */
+int ssv_group_allgather(ssv_group *g, int rank, const void *send, size_t bytes, void *recv);
 
 /* ---- device-side BGZF inflate + BAM record decode ---------------------------- */
 

@@ -60,7 +60,7 @@ typedef struct {
 	uint64_t end_coff; uint32_t end_uoff;    /* first record of the next part (UINT64_MAX, 0 for the last part) */
 	int32_t own_tid, own_pos;                /* contig and 0-based position of the part's first record (own_tid = n_targets when it is unplaced or the part is empty) */
 	int32_t initial_last_tid;                /* contig of the last record without UNMAP|MUNMAP before the scan start (0 at the start of the file) */
-	int32_t pad;
+	int32_t before_own_tid;                  /* the same before the part's first record */
 	int64_t halo_records;                    /* records in [scan, own) */
 } ssvh_bam_part;
 int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_bam_part *parts);

@@ -185,7 +185,7 @@ def _load(name):
 class BamPart(C.Structure):
     """ssvh_bam_part"""
     _fields_ = [("scan_coff", C.c_uint64), ("scan_uoff", C.c_uint32), ("own_coff", C.c_uint64), ("own_uoff", C.c_uint32), ("end_coff", C.c_uint64), ("end_uoff", C.c_uint32),
-                ("own_tid", C.c_int32), ("own_pos", C.c_int32), ("initial_last_tid", C.c_int32), ("pad", C.c_int32), ("halo_records", C.c_int64)]
+                ("own_tid", C.c_int32), ("own_pos", C.c_int32), ("initial_last_tid", C.c_int32), ("before_own_tid", C.c_int32), ("halo_records", C.c_int64)]
 
 
 def host_lib():

@@ -552,6 +552,7 @@ struct CapArgs {
 	int32_t *ntail_tid, *ntail_pos, *ntail_end;
 	uint8_t *ntail_pass;
 	int32_t ntail_n;
+	int32_t prime;                // ssv_getsv_prime: the batch only rebuilds the pileup's state (it was counted by another rank): dropped reads give nothing back
 };
 
 __device__ __forceinline__ bool cap_pass(const GetsvArgs &a, const RecLine &r) // the depth pass's read filter (read_bam + BAM_DEF_MASK)
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(WAVE) void k_cap_sweep(CapArgs c)
 			}
 			dropped = __ballot((dropped >> lane) & 1ull); // every lane decided for itself above
 			// a dropped read never reached the pileup: take its coverage out of the difference arrays again
-			if (i >= 0 && ((dropped >> lane) & 1ull)) {
+			if (!c.prime && i >= 0 && ((dropped >> lane) & 1ull)) {
 				int64_t tile;
 				const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
 				if (m & TM_DEPTH) depth_record(a, cand_load(a.b, i), tid, pos, tile, -1);

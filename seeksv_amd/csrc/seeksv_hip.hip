@@ -3,8 +3,11 @@
 #include "seeksv_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -349,6 +352,12 @@ __global__ void k_max_span(DevBatch b, int *out)
 extern "C" {
 
 int ssv_abi_version(void) { return SSV_ABI_VERSION; }
+
+int ssv_device_count(void)
+{
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 int ssv_ctx_create(int device, ssv_ctx **out)
 {
@@ -983,6 +992,45 @@ int ssv_getsv_begin(ssv_ctx *c, const ssv_getsv_params *p)
 	return SSV_OK;
 }
 
+// the read cap of the reference's pileup: three small launches that leave at once unless >= 8000 reads can be alive somewhere.
+// prime != 0 (ssv_getsv_prime): the batch only rebuilds the bookkeeping (ring of read ends, live count, the stream's last records).
+static int cap_launches(ssv_ctx *c, const GetsvArgs &a, const DevBatch &d, int64_t ntiles, int prime)
+{
+	ProfScope ps(c, P_GETSV_CAND, 0);
+	// the ring of read ends covers one reference span; a later batch with a longer read (a long N skip or deletion) makes it grow: the
+	// live entries of a sweep that is carried across the batch boundary move to their slots in the larger ring
+	if (c->cap_ring_mask == 0 || (int64_t)c->gs_map_span + 2 > (int64_t)c->cap_ring_mask + 1) {
+		int64_t e = CAP_LDS_RING;
+		while (e < (int64_t)c->gs_map_span + 2) e <<= 1;
+		if (e > (1ll << 30)) { c->err = "reference span of a read beyond 2^30"; return SSV_E_RANGE; }
+		if (c->cap_ring_mask == 0) CHECK(ensure(c, c->cap_ring, (size_t)e * 4));
+		else {
+			CHECK(ensure(c, c->cap_ring_tmp, (size_t)e * 4));
+			HIPCHECK(c, hipMemsetAsync(c->cap_ring_tmp.p, 0, (size_t)e * 4, c->st));
+			k_cap_regrow<<<64, BLOCK, 0, c->st>>>(P<CapCarry>(c->cap_carry), P<int32_t>(c->cap_ring), c->cap_ring_mask, P<int32_t>(c->cap_ring_tmp), (int32_t)(e - 1));
+			HIPCHECK(c, hipGetLastError());
+			std::swap(c->cap_ring, c->cap_ring_tmp);
+		}
+		c->cap_ring_mask = (int32_t)(e - 1);
+	}
+	CHECK(ensure(c, c->cap_deep, (size_t)ntiles + 16));
+	for (int s_ = 0; s_ < 2; ++s_) { CHECK(ensure(c, c->cap_tail[s_][0], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][1], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][2], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][3], CAP_TAIL)); }
+	CapArgs ca;
+	ca.g = a; ca.span = c->gs_map_span; ca.prime = prime;
+	DBuf *ot = c->cap_tail[c->cap_tail_cur], *nt = c->cap_tail[c->cap_tail_cur ^ 1];
+	ca.tail_tid = P<int32_t>(ot[0]); ca.tail_pos = P<int32_t>(ot[1]); ca.tail_end = P<int32_t>(ot[2]); ca.tail_pass = P<uint8_t>(ot[3]); ca.tail_n = c->cap_tail_n;
+	ca.deep = P<uint8_t>(c->cap_deep); ca.ntiles = ntiles; ca.flags = P<int>(c->cap_flags); ca.carry = P<CapCarry>(c->cap_carry);
+	ca.ring = P<int32_t>(c->cap_ring); ca.ring_mask = c->cap_ring_mask;
+	ca.ntail_tid = P<int32_t>(nt[0]); ca.ntail_pos = P<int32_t>(nt[1]); ca.ntail_end = P<int32_t>(nt[2]); ca.ntail_pass = P<uint8_t>(nt[3]);
+	ca.ntail_n = (int32_t)std::min<int64_t>(CAP_TAIL, (int64_t)c->cap_tail_n + d.n);
+	k_cap_mark<<<(unsigned)std::min<int64_t>(ntiles, 1024), BLOCK, 0, c->st>>>(ca);
+	k_cap_sweep<<<1, WAVE, 0, c->st>>>(ca);
+	k_cap_tail<<<grid_for(ca.ntail_n, BLOCK), BLOCK, 0, c->st>>>(ca);
+	HIPCHECK(c, hipGetLastError());
+	c->cap_tail_n = ca.ntail_n; c->cap_tail_cur ^= 1;
+	return SSV_OK;
+}
+
 int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 {
 	if (!c || !b) return SSV_E_ARG;
@@ -1052,41 +1100,51 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 		k_getsv_cand<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(a, g);
 	}
 	HIPCHECK(c, hipGetLastError());
-	if (a.n_win > 0) {
-		// the read cap of the reference's pileup: three small launches that leave at once unless >= 8000 reads can be alive somewhere
-		ProfScope ps(c, P_GETSV_CAND, 0);
-		// the ring of read ends covers one reference span; a later batch with a longer read (a long N skip or deletion) makes it grow: the
-		// live entries of a sweep that is carried across the batch boundary move to their slots in the larger ring
-		if (c->cap_ring_mask == 0 || (int64_t)c->gs_map_span + 2 > (int64_t)c->cap_ring_mask + 1) {
-			int64_t e = CAP_LDS_RING;
-			while (e < (int64_t)c->gs_map_span + 2) e <<= 1;
-			if (e > (1ll << 30)) { c->err = "reference span of a read beyond 2^30"; return SSV_E_RANGE; }
-			if (c->cap_ring_mask == 0) CHECK(ensure(c, c->cap_ring, (size_t)e * 4));
-			else {
-				CHECK(ensure(c, c->cap_ring_tmp, (size_t)e * 4));
-				HIPCHECK(c, hipMemsetAsync(c->cap_ring_tmp.p, 0, (size_t)e * 4, c->st));
-				k_cap_regrow<<<64, BLOCK, 0, c->st>>>(P<CapCarry>(c->cap_carry), P<int32_t>(c->cap_ring), c->cap_ring_mask, P<int32_t>(c->cap_ring_tmp), (int32_t)(e - 1));
-				HIPCHECK(c, hipGetLastError());
-				std::swap(c->cap_ring, c->cap_ring_tmp);
-			}
-			c->cap_ring_mask = (int32_t)(e - 1);
-		}
-		CHECK(ensure(c, c->cap_deep, (size_t)ntiles + 16));
-		for (int s_ = 0; s_ < 2; ++s_) { CHECK(ensure(c, c->cap_tail[s_][0], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][1], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][2], CAP_TAIL * 4)); CHECK(ensure(c, c->cap_tail[s_][3], CAP_TAIL)); }
-		CapArgs ca;
-		ca.g = a; ca.span = c->gs_map_span;
-		DBuf *ot = c->cap_tail[c->cap_tail_cur], *nt = c->cap_tail[c->cap_tail_cur ^ 1];
-		ca.tail_tid = P<int32_t>(ot[0]); ca.tail_pos = P<int32_t>(ot[1]); ca.tail_end = P<int32_t>(ot[2]); ca.tail_pass = P<uint8_t>(ot[3]); ca.tail_n = c->cap_tail_n;
-		ca.deep = P<uint8_t>(c->cap_deep); ca.ntiles = ntiles; ca.flags = P<int>(c->cap_flags); ca.carry = P<CapCarry>(c->cap_carry);
-		ca.ring = P<int32_t>(c->cap_ring); ca.ring_mask = c->cap_ring_mask;
-		ca.ntail_tid = P<int32_t>(nt[0]); ca.ntail_pos = P<int32_t>(nt[1]); ca.ntail_end = P<int32_t>(nt[2]); ca.ntail_pass = P<uint8_t>(nt[3]);
-		ca.ntail_n = (int32_t)std::min<int64_t>(CAP_TAIL, (int64_t)c->cap_tail_n + d.n);
-		k_cap_mark<<<(unsigned)std::min<int64_t>(ntiles, 1024), BLOCK, 0, c->st>>>(ca);
-		k_cap_sweep<<<1, WAVE, 0, c->st>>>(ca);
-		k_cap_tail<<<grid_for(ca.ntail_n, BLOCK), BLOCK, 0, c->st>>>(ca);
-		HIPCHECK(c, hipGetLastError());
-		c->cap_tail_n = ca.ntail_n; c->cap_tail_cur ^= 1;
+	if (a.n_win > 0) CHECK(cap_launches(c, a, d, ntiles, 0));
+	return SSV_OK;
+}
+
+int ssv_getsv_prime(ssv_ctx *c, const ssv_batch_t *b, int32_t *sufficient)
+{
+	if (!c || !b || !sufficient) return SSV_E_ARG;
+	if (!c->gs_active) { c->err = "ssv_getsv_prime before ssv_getsv_begin"; return SSV_E_STATE; }
+	if (c->cap_tail_n != 0) { c->err = "ssv_getsv_prime after records were scanned"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	*sufficient = 1;
+	if (b->n == 0 || c->gs_win.empty()) return SSV_OK; // no depth pass: nothing to rebuild
+	DevBatch d;
+	CHECK(stage_batch(c, b, d));
+	int32_t span = d.max_ref_span;
+	if (span <= 0) {
+		HIPCHECK(c, hipMemsetAsync(c->gs_span.p, 0, 16, c->st));
+		k_max_span<<<grid_for(d.n, BLOCK), BLOCK, 0, c->st>>>(d, P<int>(c->gs_span));
+		CHECK(ensure_host(c, c->h_totals, 128));
+		HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->gs_span.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+		span = std::max(1, *P<int>(c->h_totals));
 	}
+	if (span > c->gs_map_span) CHECK(gs_build_tilemap(c, span));
+	GetsvArgs a;
+	memset(&a, 0, sizeof(a));
+	a.b = d; a.depth_min_mapq = c->gs_p.depth_min_mapq; a.n_targets = c->gs_p.n_targets; a.cap_span = c->gs_map_span;
+	a.tilemap = P<uint8_t>(c->gs_tilemap); a.tile_win = P<uint32_t>(c->gs_tile_win); a.ctg_tile_off = P<int64_t>(c->gs_ctgoff);
+	a.win_tid = P<int32_t>(c->gs_wtid); a.win_beg = P<int32_t>(c->gs_wbeg); a.win_end = P<int32_t>(c->gs_wend); a.win_off = P<int64_t>(c->gs_woff);
+	a.n_win = (int64_t)c->gs_win.size(); a.diff = P<int32_t>(c->gs_diff);
+	// every tile is looked at (the streaming pass that usually raises this flag does not run over a replayed batch)
+	int one[4] = {1, 0, 0, 0};
+	HIPCHECK(c, hipMemcpyAsync(c->cap_flags.p, one, 16, hipMemcpyHostToDevice, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st)); // (`one` lives on this stack)
+	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
+	CHECK(cap_launches(c, a, d, ntiles, 1));
+	// The replay leaves the right state if it started from one: a sweep that begins >= 7,999 records before the first "deep" record does
+	// (getsv_kernels.h).  A record can be judged from index 7,998 of the batch on; so the records [7998, 15997) - inside tiles 1..3 - must not
+	// be deep.  A batch that starts at the file's first record is exact anyway: the caller knows that case and ignores the answer.
+	CHECK(ensure_host(c, c->h_totals, 128));
+	const int64_t nt = std::min<int64_t>(ntiles, 4);
+	HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->cap_deep.p, (size_t)nt, hipMemcpyDeviceToHost, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	for (int64_t t = 1; t < nt; ++t) if (P<uint8_t>(c->h_totals)[t]) *sufficient = 0;
+	if (ntiles < 4) *sufficient = 0; // too short to tell
 	return SSV_OK;
 }
 
@@ -1172,5 +1230,6 @@ const char *ssv_prof_names(void) { return kProfNameList; }
 
 #include "bamdec_api.inc"
 #include "realign_api.inc"
+#include "group_api.inc"
 
 } // extern "C"

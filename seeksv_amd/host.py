@@ -97,7 +97,7 @@ def partition(path, n_parts, halo_bp=1000):
     if lib.ssvh_bam_partition(path.encode(), n_parts, halo_bp, parts) != 0:
         raise IOError(lib.ssvh_partition_last_error().decode())
     return [dict(scan=(p.scan_coff, p.scan_uoff), own=(p.own_coff, p.own_uoff), end=None if p.end_coff == (1 << 64) - 1 else (p.end_coff, p.end_uoff),
-                 own_tid=p.own_tid, own_pos=p.own_pos, initial_last_tid=p.initial_last_tid, halo_records=p.halo_records) for p in parts]
+                 own_tid=p.own_tid, own_pos=p.own_pos, initial_last_tid=p.initial_last_tid, before_own_tid=p.before_own_tid, halo_records=p.halo_records) for p in parts]
 
 
 def walk_back(path, at, n_back):

@@ -283,7 +283,7 @@ int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_
 		to_voffset(f, g, &p.own_coff, &p.own_uoff);
 		to_voffset(f, ge, &p.end_coff, &p.end_uoff);
 		p.scan_coff = p.own_coff; p.scan_uoff = p.own_uoff;
-		p.own_tid = f.n_targets; p.own_pos = 0; p.initial_last_tid = 0;
+		p.own_tid = f.n_targets; p.own_pos = 0; p.initial_last_tid = 0; p.before_own_tid = 0;
 		if (g >= total) continue;
 		{ // the part's first record
 			Window w(f);
@@ -298,9 +298,10 @@ int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_
 		// mapped-pair record before them
 		uint64_t scan = g;
 		int64_t halo = 0;
-		bool in_halo = p.own_tid < f.n_targets, have_last = false;
+		bool in_halo = p.own_tid < f.n_targets, have_last = false, have_before = false;
 		const int32_t t0 = p.own_tid, p0 = p.own_pos;
 		const bool ok = walk_back(f, g, [&](const RecHead &h) {
+			if (!have_before && !(h.flag & (4 | 8))) { p.before_own_tid = h.tid; have_before = true; }
 			if (in_halo) {
 				if (h.tid == t0 && (int64_t)h.pos >= (int64_t)p0 - halo_bp) { scan = h.g; ++halo; return true; }
 				in_halo = false;

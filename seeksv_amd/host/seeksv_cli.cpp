@@ -85,7 +85,9 @@ struct PhaseTimer {
 	     << "         -q <int>              Minimum mapping quality of soft-clipped reads [1]\n"
 	     << "         -s                    Save the low quality sequence clipped before alignment by bwa.\n"
 	     << "         -o <string>           Prefix of output files [output]\n"
-	     << "         -G <int>              GPU ordinal [0]\n"
+	     << "         -G <int>[,<int>...]   GPU ordinal(s) [0; with -N: all GPUs of the machine in order]\n"
+	     << "         -N <int>              cut the BAM into N runs of records, one per GPU (ranks share GPUs when there are fewer) [1]\n"
+	     << "         -H <int>              with -N: halo in bp before a run's first record (>= the longest reference span of a read) [65536]\n"
 	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
 	exit(1);
 }
@@ -107,7 +109,8 @@ struct PhaseTimer {
 	     << "         -i <int>              Maximum indel number of up_seq / down_seq when no read pair supports the junction [1]\n"
 	     << "         -L <int>              Flank length for the average depths [200]\n"
 	     << "         -t <double> -Q <int> -w <int>   accepted for compatibility\n"
-	     << "         -G <int>              GPU ordinal [0]\n"
+	     << "         -G <int>[,<int>...]   GPU ordinal(s) [0; with -N: all GPUs of the machine in order]\n"
+	     << "         -N <int>              cut the BAM into N runs of records, one per GPU; the ranks' tallies and depths meet in one RCCL all-gather [1]\n"
 	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
 	exit(1);
 }
@@ -275,29 +278,100 @@ struct BatchSource {
 
 static bool device_inflate_default() { const char *e = getenv("SSV_DEVICE_INFLATE"); return e && atoi(e) != 0; }
 
+static vector<int> parse_devices(const char *s) // "-G 0,2,5"
+{
+	vector<int> d;
+	for (const char *p = s; *p;) { d.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+	return d;
+}
+
+// GPU of rank r: the -G list (cycled) or the machine's GPUs in order (cycled: more ranks than GPUs is allowed - a one-GPU box runs every
+// rank on its one GPU, one after the other in effect)
+static int device_of_rank(int r, const vector<int> &devices)
+{
+	if (!devices.empty()) return devices[(size_t)r % devices.size()];
+	const int n = ssv_device_count();
+	return n > 0 ? r % n : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // getclip
 // ---------------------------------------------------------------------------------------------------------------------
 
+// DisplaySClipReadsAndClipFq (clip_reads.h:300-345) for the clusters [k0, k1) of a table: their clip.gz rows and clip.fq records
+static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k0, int64_t k1, string &row, string &fq)
+{
+		row.reserve(row.size() + (size_t)(k1 - k0) * 480); fq.reserve(fq.size() + (size_t)(k1 - k0) * 200);
+		char num[16];
+		string seqbuf;
+		for (int64_t k = k0; k < k1; ++k) {
+			const char *name = ssvh_bam_target_name(bam, t.tid[k]);
+			const uint8_t *s = t.str + t.str_off[k];
+			const size_t ll = (size_t)t.left_len[k], lr = (size_t)t.right_len[k];
+			const char *sl, *ql, *sr, *qr;
+			if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right], qualities possibly as alphabet indices
+				const size_t W = (size_t)t.qual_bits, a = (ll + 1) / 2, c2 = (lr + 1) / 2, qa = (ll * W + 7) / 8;
+				seqbuf.resize(2 * (ll + lr));
+				for (size_t i = 0; i < ll; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((~i & 1) << 2)) & 15];
+				for (size_t i = 0; i < lr; ++i) seqbuf[ll + i] = "=ACMGRSVTWYHKDBN"[(s[a + qa + (i >> 1)] >> ((~i & 1) << 2)) & 15];
+				sl = seqbuf.data(); sr = seqbuf.data() + ll;
+				if (W == 8) { ql = (const char *)s + a; qr = (const char *)s + a + qa + c2; }
+				else {
+					const uint8_t *pl = s + a, *pr = s + a + qa + c2;
+					const unsigned mask = (1u << W) - 1u;
+					char *dl = &seqbuf[ll + lr], *dr = dl + ll;
+					// stream bit i * W; a 3-bit index can straddle two bytes (the byte after a piece is the next piece or the block's padding)
+					for (size_t i = 0; i < ll; ++i) { const size_t b = (i * W) >> 3; dl[i] = (char)t.qual_alphabet[((pl[b] | (unsigned)pl[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
+					for (size_t i = 0; i < lr; ++i) { const size_t b = (i * W) >> 3; dr[i] = (char)t.qual_alphabet[((pr[b] | (unsigned)pr[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
+					ql = dl; qr = dr;
+				}
+			} else { sl = (const char *)s; ql = sl + ll; sr = sl + 2 * ll; qr = sl + 2 * ll + lr; }
+			size_t lql = ll, lqr = lr;
+			if (t.qual_missing[k]) { ql = qr = "*"; lql = lqr = 1; }
+			row += name ? name : ""; row += '\t';
+			row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.pos[k])); row += '\t'; row += (char)t.side[k]; row += '\t';
+			for (int q = 0; q < t.n_cigar[k]; ++q) {
+				uint32_t op = t.cigar[t.cigar_off[k] + q];
+				if ((op & 15) == 4 || (op & 15) == 5) continue;
+				row.append(num, (size_t)snprintf(num, sizeof(num), "%u", op >> 4)); row += CIGAR_CHARS[op & 15];
+			}
+			row += '\t';
+			if (t.side[k] == '5') {
+				row.append(sr, lr); row += '\t'; row.append(qr, lqr); row += '\t'; row.append(sl, ll); row += '\t'; row.append(ql, lql);
+				fq += '@'; fq.append(sl, ll); fq += '\n'; fq.append(sl, ll); fq += "\n+\n"; fq.append(ql, lql); fq += '\n';
+			} else {
+				row.append(sl, ll); row += '\t'; row.append(ql, lql); row += '\t'; row.append(sr, lr); row += '\t'; row.append(qr, lqr);
+				fq += '@'; fq.append(sr, lr); fq += '\n'; fq.append(sr, lr); fq += "\n+\n"; fq.append(qr, lqr); fq += '\n';
+			}
+			row += '\t'; row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.support[k])); row += '\n';
+		}
+}
+
+static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp);
+
 static int cmd_getclip(int argc, char **argv)
 {
-	int c, min_mapQ = 1, device = 0;
+	int c, min_mapQ = 1, device = 0, n_ranks = 1, halo_bp = 65536;
 	double threshold = 0.9;
 	string prefix = "output";
 	bool save_low_quality = false, device_inflate = device_inflate_default();
-	while ((c = getopt(argc, argv, "t:q:o:sG:Z")) >= 0) {
+	vector<int> devices;
+	while ((c = getopt(argc, argv, "t:q:o:sG:ZN:H:")) >= 0) {
 		switch (c) {
 		case 't': threshold = atof(optarg); break;
 		case 'q': min_mapQ = atoi(optarg); break;
 		case 's': save_low_quality = true; break;
 		case 'o': prefix = optarg; break;
-		case 'G': device = atoi(optarg); break;
+		case 'G': devices = parse_devices(optarg); device = devices.empty() ? 0 : devices[0]; break;
 		case 'Z': device_inflate = true; break;
+		case 'N': n_ranks = atoi(optarg); break;
+		case 'H': halo_bp = atoi(optarg); break;
 		default: usage_getclip();
 		}
 	}
-	if (argc != optind + 1) usage_getclip();
+	if (argc != optind + 1 || n_ranks < 1 || halo_bp < 0) usage_getclip();
 	const string bamfile = argv[optind];
+	if (n_ranks > 1) return getclip_ranks(bamfile, prefix, threshold, min_mapQ, save_low_quality, n_ranks, devices, halo_bp);
 
 	PhaseTimer pt;
 	{ // like the reference: complain about the input before anything is created
@@ -372,51 +446,7 @@ static int cmd_getclip(int argc, char **argv)
 	vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
 	auto format_range = [&](int w) {
 		const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
-		string &row = rows[(size_t)w], &fq = fqs[(size_t)w];
-		row.reserve((size_t)(k1 - k0) * 480); fq.reserve((size_t)(k1 - k0) * 200);
-		char num[16];
-		string seqbuf;
-		for (int64_t k = k0; k < k1; ++k) {
-			const char *name = ssvh_bam_target_name(bam, t.tid[k]);
-			const uint8_t *s = t.str + t.str_off[k];
-			const size_t ll = (size_t)t.left_len[k], lr = (size_t)t.right_len[k];
-			const char *sl, *ql, *sr, *qr;
-			if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right], qualities possibly as alphabet indices
-				const size_t W = (size_t)t.qual_bits, a = (ll + 1) / 2, c2 = (lr + 1) / 2, qa = (ll * W + 7) / 8;
-				seqbuf.resize(2 * (ll + lr));
-				for (size_t i = 0; i < ll; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((~i & 1) << 2)) & 15];
-				for (size_t i = 0; i < lr; ++i) seqbuf[ll + i] = "=ACMGRSVTWYHKDBN"[(s[a + qa + (i >> 1)] >> ((~i & 1) << 2)) & 15];
-				sl = seqbuf.data(); sr = seqbuf.data() + ll;
-				if (W == 8) { ql = (const char *)s + a; qr = (const char *)s + a + qa + c2; }
-				else {
-					const uint8_t *pl = s + a, *pr = s + a + qa + c2;
-					const unsigned mask = (1u << W) - 1u;
-					char *dl = &seqbuf[ll + lr], *dr = dl + ll;
-					// stream bit i * W; a 3-bit index can straddle two bytes (the byte after a piece is the next piece or the block's padding)
-					for (size_t i = 0; i < ll; ++i) { const size_t b = (i * W) >> 3; dl[i] = (char)t.qual_alphabet[((pl[b] | (unsigned)pl[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
-					for (size_t i = 0; i < lr; ++i) { const size_t b = (i * W) >> 3; dr[i] = (char)t.qual_alphabet[((pr[b] | (unsigned)pr[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
-					ql = dl; qr = dr;
-				}
-			} else { sl = (const char *)s; ql = sl + ll; sr = sl + 2 * ll; qr = sl + 2 * ll + lr; }
-			size_t lql = ll, lqr = lr;
-			if (t.qual_missing[k]) { ql = qr = "*"; lql = lqr = 1; }
-			row += name ? name : ""; row += '\t';
-			row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.pos[k])); row += '\t'; row += (char)t.side[k]; row += '\t';
-			for (int q = 0; q < t.n_cigar[k]; ++q) {
-				uint32_t op = t.cigar[t.cigar_off[k] + q];
-				if ((op & 15) == 4 || (op & 15) == 5) continue;
-				row.append(num, (size_t)snprintf(num, sizeof(num), "%u", op >> 4)); row += CIGAR_CHARS[op & 15];
-			}
-			row += '\t';
-			if (t.side[k] == '5') {
-				row.append(sr, lr); row += '\t'; row.append(qr, lqr); row += '\t'; row.append(sl, ll); row += '\t'; row.append(ql, lql);
-				fq += '@'; fq.append(sl, ll); fq += '\n'; fq.append(sl, ll); fq += "\n+\n"; fq.append(ql, lql); fq += '\n';
-			} else {
-				row.append(sl, ll); row += '\t'; row.append(ql, lql); row += '\t'; row.append(sr, lr); row += '\t'; row.append(qr, lqr);
-				fq += '@'; fq.append(sr, lr); fq += '\n'; fq.append(sr, lr); fq += "\n+\n"; fq.append(qr, lqr); fq += '\n';
-			}
-			row += '\t'; row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.support[k])); row += '\n';
-		}
+		format_clusters(t, bam, k0, k1, rows[(size_t)w], fqs[(size_t)w]);
 	};
 	{
 		vector<std::thread> th;
@@ -432,6 +462,147 @@ static int cmd_getclip(int argc, char **argv)
 	src.close();
 	ssv_ctx_destroy(ctx);
 	pt.lap("teardown");
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// getclip over N runs of records, one per GPU (-N): the file is cut at record starts (ssvh_bam_partition); a rank scans its run plus the
+// halo of records before it that can own a breakpoint inside it, keeps the clip events whose breakpoint lies in its interval, and clusters
+// them: every (contig, side, position) bin lives on exactly one rank with its reads in file order, so the tables need no exchange - the
+// rows are put together per contig: the '5' rows of all ranks in rank order, then the '3' rows (clip_reads.h:432-433).
+// ---------------------------------------------------------------------------------------------------------------------
+
+struct UnmappedRec { string qname, seq, qual; int is_read1; };
+
+struct ClipRank {
+	vector<int32_t> run_tids;                       // contig runs among the rank's own mapped-pair records
+	int32_t last_tid = 0;
+	vector<UnmappedRec> unmapped;                   // UNMAP|MUNMAP records of the rank's own run, in file order
+	map<pair<int32_t, char>, pair<string, string>> seg; // (contig, side) -> rows, fastq records
+	int32_t max_span = 0;
+	string err;
+};
+
+static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp)
+{
+	PhaseTimer pt;
+	ssvh_bam *bam = nullptr;
+	if (ssvh_bam_open(bamfile.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
+	GzOut softfout, fqfout, fuout1, fuout2;
+	const string f_clip = prefix + ".clip.gz", f_fq = prefix + ".clip.fq.gz", f_u1 = prefix + ".unmapped_1.fq.gz", f_u2 = prefix + ".unmapped_2.fq.gz";
+	if (!softfout.open(f_clip)) die("Cannot open file " + f_clip);
+	if (!fqfout.open(f_fq)) die("Cannot open file " + f_fq);
+	if (!fuout1.open(f_u1)) die("Cannot open file " + f_u1);
+	if (!fuout2.open(f_u2)) die("Cannot open file " + f_u2);
+	vector<ssvh_bam_part> parts((size_t)n_ranks);
+	if (ssvh_bam_partition(bamfile.c_str(), n_ranks, halo_bp, parts.data()) != 0) die(string("[seeksv] ") + ssvh_partition_last_error());
+	pt.lap("open+partition");
+	const int32_t n_targets = ssvh_bam_n_targets(bam);
+	vector<ClipRank> R((size_t)n_ranks);
+	auto rank_main = [&](int r) {
+		ClipRank &out = R[(size_t)r];
+		const ssvh_bam_part &P = parts[(size_t)r];
+		ssv_ctx *ctx = nullptr;
+		if (ssv_ctx_create(device_of_rank(r, devices), &ctx) != SSV_OK) { out.err = string("[seeksv] ") + ssv_last_error(nullptr); return; }
+		ssv_clip_params p;
+		memset(&p, 0, sizeof(p));
+		p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
+		// breakpoints (contig, 1-based position) owned by this rank: from its first record's start + 1 up to the next rank's
+		p.use_ownership = 1; p.initial_last_tid = P.initial_last_tid;
+		p.own_lo_tid = r == 0 ? 0 : P.own_tid; p.own_lo_pos = r == 0 ? 0 : P.own_pos + 1;
+		if (r + 1 < n_ranks) { p.own_hi_tid = parts[(size_t)r + 1].own_tid; p.own_hi_pos = parts[(size_t)r + 1].own_tid < n_targets ? parts[(size_t)r + 1].own_pos + 1 : 0; }
+		else { p.own_hi_tid = INT32_MAX; p.own_hi_pos = 0; }
+		if (ssv_clip_begin(ctx, &p) != SSV_OK) { out.err = string("[seeksv] ") + ssv_last_error(ctx); ssv_ctx_destroy(ctx); return; }
+		ssv_clip_table_format(ctx, 2);
+		ssvh_bam *rb = nullptr;
+		if (ssvh_bam_open(bamfile.c_str(), &rb) != 0) { out.err = "[main_samview] fail to open file for reading."; ssv_ctx_destroy(ctx); return; }
+		// the contig of the last mapped-pair record before the rank's OWN run (its run list continues from there)
+		out.last_tid = r == 0 ? 0 : P.before_own_tid;
+		for (int phase = 0; phase < 2 && out.err.empty(); ++phase) { // 0: the halo (scanned, nothing else), 1: the rank's own records
+			if (phase == 0 && (P.scan_coff != P.own_coff || P.scan_uoff != P.own_uoff)) { if (ssvh_bam_set_range(rb, P.scan_coff, P.scan_uoff, P.own_coff, P.own_uoff) != 0) out.err = string("[seeksv] ") + ssvh_last_error(); }
+			else if (phase == 0) continue;
+			else if (ssvh_bam_set_range(rb, P.own_coff, P.own_uoff, P.end_coff, P.end_uoff) != 0) out.err = string("[seeksv] ") + ssvh_last_error();
+			while (out.err.empty()) {
+				ssv_batch_t b;
+				if (ssvh_bam_read_batch(rb, 1 << 22, 0, &b) != 0) { out.err = string("[seeksv] ") + ssvh_last_error(); break; }
+				if (b.n == 0) break;
+				out.max_span = std::max(out.max_span, b.max_ref_span);
+				if (phase == 1) {
+					const char *qname, *seq, *qual; int is_read1;
+					for (int64_t k = 0, nu = ssvh_bam_unmapped_count(rb); k < nu; ++k) { ssvh_bam_unmapped_get(rb, k, &qname, &seq, &qual, &is_read1); out.unmapped.push_back(UnmappedRec{qname, seq, qual, is_read1}); }
+					for (int64_t i = 0; i < b.n; ++i) {
+						if (b.flag[i] & (4 | 8)) continue;
+						if (b.tid[i] != out.last_tid) { out.run_tids.push_back(out.last_tid); out.last_tid = b.tid[i]; }
+					}
+				}
+				if (ssv_clip_scan(ctx, &b) != SSV_OK) { out.err = string("[seeksv] ") + ssv_last_error(ctx); break; }
+				ssv_sync(ctx);
+			}
+		}
+		ssv_cluster_table t;
+		if (out.err.empty() && ssv_clip_cluster(ctx, &t) != SSV_OK) out.err = string("[seeksv] ") + ssv_last_error(ctx);
+		if (out.err.empty()) {
+			for (int64_t k0 = 0; k0 < t.n_clusters;) { // the table is in (contig, side, position) order
+				int64_t k1 = k0;
+				while (k1 < t.n_clusters && t.tid[k1] == t.tid[k0] && t.side[k1] == t.side[k0]) ++k1;
+				auto &sg = out.seg[make_pair(t.tid[k0], (char)t.side[k0])];
+				format_clusters(t, rb, k0, k1, sg.first, sg.second);
+				k0 = k1;
+			}
+		}
+		ssvh_bam_close(rb);
+		ssv_ctx_destroy(ctx);
+	};
+	{
+		vector<std::thread> th;
+		for (int r = 1; r < n_ranks; ++r) th.emplace_back(rank_main, r);
+		rank_main(0);
+		for (auto &x : th) x.join();
+	}
+	pt.lap("ranks(scan+cluster+format)");
+	int32_t max_span = 0;
+	for (auto &o : R) { if (!o.err.empty()) die(o.err); max_span = std::max(max_span, o.max_span); }
+	if (max_span > halo_bp) die("[seeksv] a read spans " + to_string(max_span) + " reference bases, more than the halo of " + to_string(halo_bp) + " bp before a run of records: rerun with -H " + to_string(max_span));
+	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219): sequential over the file, i.e. over the ranks in order
+	map<string, pair<pair<string, string>, char>> id2seq_qual;
+	for (auto &o : R) for (auto &u : o.unmapped) {
+		auto it = id2seq_qual.find(u.qname);
+		if (it != id2seq_qual.end()) {
+			if (u.is_read1 && it->second.second == '2') {
+				fuout1.write(string("@") + it->first + "/1\n" + u.seq + "\n+\n" + u.qual + "\n");
+				fuout2.write(string("@") + it->first + "/2\n" + it->second.first.first + "\n+\n" + it->second.first.second + "\n");
+				id2seq_qual.erase(it);
+			} else if (!u.is_read1 && it->second.second == '1') {
+				fuout1.write(string("@") + it->first + "/1\n" + it->second.first.first + "\n+\n" + it->second.first.second + "\n");
+				fuout2.write(string("@") + it->first + "/2\n" + u.seq + "\n+\n" + u.qual + "\n");
+				id2seq_qual.erase(it);
+			}
+		} else id2seq_qual.insert(make_pair(u.qname, make_pair(make_pair(u.seq, u.qual), u.is_read1 ? '1' : '2')));
+	}
+	// the flush sequence of the whole file: the ranks' run lists one after the other (a rank's list continues the previous rank's)
+	vector<int32_t> run_tids;
+	for (auto &o : R) run_tids.insert(run_tids.end(), o.run_tids.begin(), o.run_tids.end());
+	int32_t last_tid = 0;
+	for (int r = n_ranks - 1; r >= 0; --r) if (parts[(size_t)r].own_coff != UINT64_MAX || r == 0) { last_tid = R[(size_t)r].last_tid; break; }
+	run_tids.push_back(last_tid);
+	for (size_t k = 1; k < run_tids.size(); ++k)
+		if (run_tids[k] <= run_tids[k - 1]) die("[seeksv] the BAM is not coordinate sorted (contig " + string(ssvh_bam_target_name(bam, run_tids[k]) ? ssvh_bam_target_name(bam, run_tids[k]) : "?") + " appears out of order)");
+	vector<string> rows, fqs;
+	for (int32_t tid : run_tids) {
+		const char *name = ssvh_bam_target_name(bam, tid);
+		cerr << "Output merged soft-clipped reads of " << (name ? name : "") << endl;
+		for (char side : {'5', '3'})
+			for (auto &o : R) {
+				auto it = o.seg.find(make_pair(tid, side));
+				if (it == o.seg.end()) continue;
+				rows.push_back(std::move(it->second.first)); fqs.push_back(std::move(it->second.second));
+			}
+	}
+	softfout.write_parts(rows); fqfout.write_parts(fqs);
+	cerr << "[GetSClipReads] finished!" << endl;
+	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
+	pt.lap("output");
+	ssvh_bam_close(bam);
 	return 0;
 }
 
@@ -493,10 +664,11 @@ static int cmd_getsv(int argc, char **argv)
 	string connect_bam, temp_breakpoint, dump_junctions;
 	double frequency = 0.1;
 	int c, min_mapQ = 20, read_pair_used = 5000000, sum_min_no_both_clipped_reads = 3, min_distance = 50, microhomology_length = 50, times = 4, device = 0,
-	       min_abnormal_read_pair_no = 0, flank_length = 200, min_seq_len = 30, max_seq_indel_no = 1, flank = 50;
+	       min_abnormal_read_pair_no = 0, flank_length = 200, min_seq_len = 30, max_seq_indel_no = 1, flank = 50, n_ranks = 1;
 	bool output_depth = true, device_inflate = device_inflate_default();
+	vector<int> devices;
 	PhaseTimer pt;
-	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:Z")) >= 0) {
+	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:ZN:")) >= 0) {
 		switch (c) {
 		case 'F': connect_bam = optarg; break;
 		case 'B': temp_breakpoint = optarg; break;
@@ -512,14 +684,15 @@ static int cmd_getsv(int argc, char **argv)
 		case 'f': frequency = atof(optarg); break;
 		case 'T': microhomology_length = atoi(optarg); break;
 		case 'L': flank_length = atoi(optarg); break;
-		case 'G': device = atoi(optarg); break;
+		case 'G': devices = parse_devices(optarg); device = devices.empty() ? 0 : devices[0]; break;
 		case 'Z': device_inflate = true; break;
+		case 'N': n_ranks = atoi(optarg); break;
 		case 'J': dump_junctions = optarg; break;
 		default: break; // -t -Q -w -a -R -r: accepted, unused (as in the reference, where -t / -Q no longer reach the join)
 		}
 	}
 	if (argc != optind + 5) usage_getsv();
-	if (flank > 90 || flank < 0 || min_seq_len < 0) usage_getsv();
+	if (flank > 90 || flank < 0 || min_seq_len < 0 || n_ranks < 1) usage_getsv();
 	const string clip_bam = argv[optind], original_bam = argv[optind + 1], clipfile = argv[optind + 2], breakpoint_file = argv[optind + 3], clip_unmap_fq_file = argv[optind + 4];
 	if (!connect_bam.empty()) die("[seeksv] -F (bwasw read-through input) is not supported by this build");
 
@@ -595,7 +768,91 @@ static int cmd_getsv(int argc, char **argv)
 	pt.lap("plan");
 	vector<int32_t> counts((size_t)nj + 1, 0), pdepth((size_t)np + 1, 0);
 	vector<uint64_t> rsum((size_t)nr + 1, 0);
-	if (do_discordant || output_depth) {
+	if ((do_discordant || output_depth) && n_ranks > 1) {
+		// ---- N runs of records, one per GPU: every rank scans its own records for ALL junctions and windows; the partial tallies, depth sums
+		//      and point depths of the ranks meet in one all-gather (RCCL over xGMI between different GPUs) and are added up.  A rank replays
+		//      the records before its run through the pileup's read-cap bookkeeping first (ssv_getsv_prime). ----
+		vector<ssvh_bam_part> parts((size_t)n_ranks);
+		if (ssvh_bam_partition(original_bam.c_str(), n_ranks, 0, parts.data()) != 0) die(string("[seeksv] ") + ssvh_partition_last_error());
+		vector<ssv_ctx *> ctxs((size_t)n_ranks, nullptr);
+		ctxs[0] = ctx;
+		for (int r = 1; r < n_ranks; ++r) if (ssv_ctx_create(device_of_rank(r, devices), &ctxs[(size_t)r]) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+		ssv_group *group = nullptr;
+		if (ssv_group_create(ctxs.data(), n_ranks, &group) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+		const size_t n_cnt = do_discordant ? (size_t)nj : 0, n_rs = output_depth ? (size_t)nr : 0, n_pd = output_depth ? (size_t)np : 0;
+		const size_t vec_bytes = n_rs * 8 + (n_cnt + n_pd + 2) * 4; // [range sums u64 | counts i32 | point depths i32 | max depth, pad]
+		vector<string> errs((size_t)n_ranks);
+		vector<vector<uint8_t>> gathered((size_t)n_ranks);
+		auto rank_main = [&](int r) {
+			string &err = errs[(size_t)r];
+			ssv_ctx *rc = ctxs[(size_t)r];
+			const ssvh_bam_part &P = parts[(size_t)r];
+			ssv_getsv_params gp;
+			memset(&gp, 0, sizeof(gp));
+			gp.junctions = dj; gp.n_junctions = do_discordant ? nj : 0;
+			gp.mean = mean_insert_size; gp.sd = deviation; gp.times = times; gp.disc_min_mapq = min_mapQ;
+			gp.windows = dw; gp.n_windows = output_depth ? nw : 0; gp.depth_min_mapq = min_mapQ;
+			gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
+			ssvh_bam *rb = nullptr;
+			if (ssvh_bam_open(original_bam.c_str(), &rb) != 0) { err = "[main_samview] fail to open file for reading."; }
+			// the pileup's state at the rank's first record: replay the records before it (more of them while the replay itself starts inside a
+			// > 8000x stack; back to the file's first record at most)
+			for (int64_t back = 24576; err.empty(); back *= 4) {
+				if (ssv_getsv_begin(rc, &gp) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
+				if (r == 0 || !output_depth || P.own_coff == UINT64_MAX) break;
+				uint64_t co; uint32_t uo; int64_t found = 0;
+				if (ssvh_bam_walk_back(original_bam.c_str(), P.own_coff, P.own_uoff, back, &co, &uo, &found) != 0) { err = string("[seeksv] ") + ssvh_partition_last_error(); break; }
+				if (found == 0) break;
+				if (ssvh_bam_set_range(rb, co, uo, P.own_coff, P.own_uoff) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
+				ssv_batch_t hb;
+				if (ssvh_bam_read_batch(rb, found + 16, 0, &hb) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
+				int32_t sufficient = 1;
+				if (ssv_getsv_prime(rc, &hb, &sufficient) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
+				if (sufficient || found < back || back > (1ll << 26)) break; // (found < back: the replay began at the file's first record)
+			}
+			if (err.empty() && ssvh_bam_set_range(rb, P.own_coff, P.own_uoff, P.end_coff, P.end_uoff) != 0) err = string("[seeksv] ") + ssvh_last_error();
+			while (err.empty()) {
+				ssv_batch_t b;
+				if (ssvh_bam_read_batch(rb, 1 << 22, 0, &b) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
+				if (b.n == 0) break;
+				if (ssv_getsv_scan(rc, &b) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
+				ssv_sync(rc);
+			}
+			vector<uint8_t> mine(vec_bytes, 0);
+			uint64_t *v_rs = reinterpret_cast<uint64_t *>(mine.data());
+			int32_t *v_cnt = reinterpret_cast<int32_t *>(mine.data() + n_rs * 8), *v_pd = v_cnt + n_cnt, *v_max = v_pd + n_pd;
+			vector<int32_t> tmp_cnt(n_cnt + 1), tmp_pd(n_pd + 1);
+			vector<uint64_t> tmp_rs(n_rs + 1);
+			if (err.empty() && ssv_getsv_finish(rc, do_discordant ? tmp_cnt.data() : nullptr, dr, (int64_t)n_rs, tmp_rs.data(), dp, (int64_t)n_pd, tmp_pd.data(), v_max) != SSV_OK)
+				err = string("[seeksv] ") + ssv_last_error(rc);
+			if (n_rs) memcpy(v_rs, tmp_rs.data(), n_rs * 8);
+			if (n_cnt) memcpy(v_cnt, tmp_cnt.data(), n_cnt * 4);
+			if (n_pd) memcpy(v_pd, tmp_pd.data(), n_pd * 4);
+			// the exchange: every rank takes part, also one that failed (its vector is zero; the error is reported afterwards)
+			gathered[(size_t)r].assign(vec_bytes * (size_t)n_ranks, 0);
+			if (ssv_group_allgather(group, r, mine.data(), vec_bytes, gathered[(size_t)r].data()) != SSV_OK && err.empty()) err = string("[seeksv] ") + ssv_last_error(rc);
+			if (rb) ssvh_bam_close(rb);
+		};
+		{
+			vector<std::thread> th;
+			for (int r = 1; r < n_ranks; ++r) th.emplace_back(rank_main, r);
+			rank_main(0);
+			for (auto &x : th) x.join();
+		}
+		for (auto &e : errs) if (!e.empty()) die(e);
+		// rank 0's copy of the gathered vectors: the sums are the whole file's tallies and depths
+		for (int r = 0; r < n_ranks; ++r) {
+			const uint8_t *v = gathered[0].data() + (size_t)r * vec_bytes;
+			const uint64_t *v_rs = reinterpret_cast<const uint64_t *>(v);
+			const int32_t *v_cnt = reinterpret_cast<const int32_t *>(v + n_rs * 8), *v_pd = v_cnt + n_cnt;
+			for (size_t k = 0; k < n_rs; ++k) rsum[k] += v_rs[k];
+			for (size_t k = 0; k < n_cnt; ++k) counts[k] += v_cnt[k];
+			for (size_t k = 0; k < n_pd; ++k) pdepth[k] += v_pd[k];
+		}
+		if (getenv("SSV_TIMING")) cerr << "[timing] exchange over " << (ssv_group_uses_rccl(group) ? "RCCL (ncclAllGather)" : "host memory (ranks share a GPU)") << ", " << vec_bytes << " bytes per rank" << endl;
+		ssv_group_destroy(group);
+		for (int r = 1; r < n_ranks; ++r) ssv_ctx_destroy(ctxs[(size_t)r]);
+	} else if (do_discordant || output_depth) {
 		ssv_getsv_params gp;
 		memset(&gp, 0, sizeof(gp));
 		gp.junctions = dj; gp.n_junctions = do_discordant ? nj : 0;

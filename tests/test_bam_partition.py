@@ -76,6 +76,10 @@ def _check(path, whole, n_parts, halo_bp):
         while j >= 0 and (flag[j] & 12):
             j -= 1
         assert p["initial_last_tid"] == (int(tid[j]) if j >= 0 else 0)
+        j = i0 - 1
+        while j >= 0 and (flag[j] & 12):
+            j -= 1
+        assert p["before_own_tid"] == (int(tid[j]) if j >= 0 else 0)
         # walking back from the part's first record
         for nb in (1, 7, 1000, 10 ** 9):
             at, walked = host.walk_back(path, p["own"], nb)
