@@ -118,6 +118,22 @@ int ssv_device_count(void);
 /* The hipStream_t the context launches on (for callers that time with HIP events). */
 void *ssv_stream(ssv_ctx *ctx);
 
+/* ---- host batches: pinned memory and the copy that runs ahead -------------------------------- */
+/*
+ * The reference's record loops read one bam1_t at a time through samread() (clip_reads.h:410, cluster.cpp:48, getsv.cpp:1067,
+ * bam2depth.h:29); here the batcher decodes whole batches into two alternating sets of arrays and the library copies batch k+1 to HBM
+ * while the kernels of batch k run:
+ *     ssv_batch_prefetch(ctx, &b[1]);  ssv_clip_scan(ctx, &b[0]);  ssv_batch_prefetch(ctx, &b[2]);  ssv_clip_scan(ctx, &b[1]); ...
+ * ssv_host_alloc hands out page-locked host memory (usable from every GPU); only copies out of such memory run asynchronously.
+ * ssv_batch_prefetch starts copying a SSV_MEM_HOST batch on the context's upload stream into one of two staging sets and returns at once;
+ * at most two batches may be announced and not yet scanned.  The scan calls (ssv_clip_scan, ssv_isize_scan, ssv_getsv_scan,
+ * ssv_getsv_prime) must then be given exactly the announced batches, in that order (SSV_E_STATE otherwise).  With or without prefetch:
+ * when a scan call returns, the batch's host arrays have been read and may be reused.
+ */
+int ssv_host_alloc(size_t bytes, void **p);
+int ssv_host_free(void *p);
+int ssv_batch_prefetch(ssv_ctx *ctx, const ssv_batch_t *b);
+
 /* ---- getclip: replaces InputBamOutputReads<>'s record loop (clip_reads.h:363, 410-446) ------ */
 
 typedef struct {
@@ -140,8 +156,8 @@ int ssv_clip_begin(ssv_ctx *ctx, const ssv_clip_params *p);
 /*
  * Scan one batch (GetSClipReads, clip_reads.cpp:112-192, incl. the contig-switch rule of
  * clip_reads.h:423-438): appends the batch's clip events - key, slice lengths, CIGAR, where the read's packed bases and
- * qualities lie - to context-owned HBM.  The batch buffers may be reused after ssv_sync(), except the `cigar` and `seqqual`
- * arrays of a SSV_MEM_PERSISTENT batch (see ssv_mem).
+ * qualities lie - to context-owned HBM.  A host batch's arrays may be reused when the call returns, a device batch's after ssv_sync(), except
+ * the `cigar` and `seqqual` arrays of a SSV_MEM_PERSISTENT batch (see ssv_mem).
  */
 int ssv_clip_scan(ssv_ctx *ctx, const ssv_batch_t *b);
 /* Events collected so far (synchronises). */

@@ -68,10 +68,14 @@ int ssvh_bam_walk_back(const char *path, uint64_t coff, uint32_t uoff, int64_t n
 int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff);
 const char *ssvh_partition_last_error(void); /* message of the last failed ssvh_bam_partition / ssvh_bam_walk_back of this thread */
 
-/* on != 0: after handing out a batch, ssvh_bam_read_batch decodes the following one on a background thread into a second set
- * of arrays, so that inflate + decode overlap whatever the caller does with the current batch (upload, kernels, output).  While
- * it is on, every read_batch call must pass the same max_records / keep_all_seq, and ssvh_bam_next_record is refused. */
+/* on != 0: after handing out a batch, ssvh_bam_read_batch decodes the following one on a background thread into another set
+ * of arrays, so that inflate + decode overlap whatever the caller does with the current batch (upload, kernels, output); there are
+ * three sets: a batch stays valid until the SECOND read_batch call after the one that returned it (its copy to the GPU may still be
+ * running while the next batch is handed out).  While it is on, every read_batch call must pass the same max_records / keep_all_seq, and ssvh_bam_next_record is refused. */
 int ssvh_bam_set_readahead(ssvh_bam *b, int on);
+/* Where the batch arrays of ssvh_bam_read_batch live: pass the device library's page-locked allocator (ssv_host_alloc / ssv_host_free
+ * behind two plain functions) so that the copies to the GPU run asynchronously; NULL, NULL = malloc / free (the default). */
+int ssvh_bam_set_allocator(ssvh_bam *b, void *(*alloc)(size_t), void (*release)(void *));
 
 /* Raw mode, for the device-side decoder (ssv_bamdec_*, seeksv_hip.h): rewind to the first BGZF block and hand out COMPRESSED blocks.
  * *first_record_offset = length of the BAM header inside the inflated stream.  Not to be mixed with read_batch / next_record. */

@@ -243,6 +243,9 @@ def hip_lib():
         lib.ssv_last_error.restype = C.c_char_p
         lib.ssv_stream.argtypes = [V]
         lib.ssv_stream.restype = V
+        lib.ssv_host_alloc.argtypes = [C.c_size_t, C.POINTER(V)]
+        lib.ssv_host_free.argtypes = [V]
+        lib.ssv_batch_prefetch.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_clip_begin.argtypes = [V, C.POINTER(ClipParams)]
         lib.ssv_clip_scan.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_clip_event_count.argtypes = [V, C.POINTER(C.c_int64)]

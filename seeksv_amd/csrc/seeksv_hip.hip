@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "bamdec_kernels.h"
@@ -65,7 +66,14 @@ struct ssv_ctx {
 	std::string err;
 
 	// staging of host batches, and the record lines built for batches that come without them
-	DBuf sb[14], sb_rec;
+	// host batches are copied into one of three staging sets: 0 and 1 take the batches announced with ssv_batch_prefetch (copied on st_h2d while
+	// the kernels of the batch before run on st), 2 the ones that come unannounced (copied on st itself)
+	struct StageSet { DBuf col[14], rec; hipEvent_t ready = nullptr; } ss[3];
+	struct Prefetched { ssv_batch_t b; int set; };
+	std::deque<Prefetched> pf;
+	uint64_t pf_count = 0;
+	hipStream_t st_h2d = nullptr;
+	hipEvent_t ev_st = nullptr;
 
 	// scratch shared by the passes
 	DBuf tile_cnt, tile_off, tile_base, scan_scratch, scan_scratch64, counters;
@@ -263,19 +271,58 @@ inline unsigned grid_for(int64_t n, int per_block) { return (unsigned)std::max<i
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool aligned64(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 63) == 0; }
 
-// Make the batch visible to the kernels: device batches are used in place, host batches are copied to HBM; a batch that comes as
-// structure-of-arrays columns only is transposed into record lines (ssv_record) on the device.
-int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
+// Copies of a host batch into staging set `set`, issued on `st`: with `rec` the batch ships lines + hot columns + variable parts; without,
+// the classic columns (the lines are then built on the device, k_build_rec).
+static int upload_host_batch(ssv_ctx *c, const ssv_batch_t *b, int set, hipStream_t st)
+{
+	const size_t n = (size_t)b->n;
+	ssv_ctx::StageSet &S = c->ss[set];
+	struct { const void *src; size_t bytes; } f[14] = {
+		{b->tid, n * 4}, {b->pos, n * 4}, {b->rec ? nullptr : b->flag, n * 2}, {b->rec ? nullptr : b->mapq, n}, {b->n_cigar, n * 2}, {b->rec ? nullptr : b->l_qseq, n * 4},
+		{b->rec ? nullptr : b->mtid, n * 4}, {b->rec ? nullptr : b->mpos, n * 4}, {b->rec ? nullptr : b->isize, n * 4}, {b->rec ? nullptr : b->cigar_off, n * 4},
+		{b->cigar, (size_t)b->n_cigar_total * 4}, {b->rec ? nullptr : b->xc, b->xc ? n : 0}, {b->rec ? nullptr : b->seq_off, n * 8}, {b->seqqual, (size_t)b->seqqual_bytes}};
+	for (int k = 0; k < 14; ++k) {
+		if (!f[k].src) continue;
+		CHECK(ensure(c, S.col[k], f[k].bytes + 16));
+		if (f[k].bytes) HIPCHECK(c, hipMemcpyAsync(S.col[k].p, f[k].src, f[k].bytes, hipMemcpyHostToDevice, st));
+	}
+	CHECK(ensure(c, S.col[10], 16)); CHECK(ensure(c, S.col[13], 16));
+	CHECK(ensure(c, S.rec, n * sizeof(ssv_record) + 64));
+	if (b->rec && n) HIPCHECK(c, hipMemcpyAsync(S.rec.p, b->rec, n * sizeof(ssv_record), hipMemcpyHostToDevice, st));
+	return SSV_OK;
+}
+
+// the device view of a host batch staged in set `set`
+static void staged_view(ssv_ctx *c, const ssv_batch_t *b, int set, DevBatch &d, SoaCols &s)
+{
+	ssv_ctx::StageSet &S = c->ss[set];
+	d.tid = P<int32_t>(S.col[0]); d.pos = P<int32_t>(S.col[1]); d.n_cigar = P<uint16_t>(S.col[4]); d.cigar = P<uint32_t>(S.col[10]); d.seqqual = P<uint8_t>(S.col[13]);
+	d.rec = P<ssv_record>(S.rec);
+	s.tid = d.tid; s.pos = d.pos; s.flag = P<uint16_t>(S.col[2]); s.mapq = P<uint8_t>(S.col[3]); s.n_cigar = d.n_cigar; s.l_qseq = P<int32_t>(S.col[5]); s.mtid = P<int32_t>(S.col[6]);
+	s.mpos = P<int32_t>(S.col[7]); s.isize = P<int32_t>(S.col[8]); s.cigar_off = P<uint32_t>(S.col[9]); s.cigar = d.cigar; s.xc = b->xc ? P<uint8_t>(S.col[11]) : nullptr;
+	s.seq_off = P<uint64_t>(S.col[12]);
+}
+
+static int check_batch(ssv_ctx *c, const ssv_batch_t *b)
 {
 	if (!b || b->n < 0 || b->n >= (1ll << 31)) { c->err = "bad batch"; return SSV_E_ARG; }
 	const bool has_soa = b->flag && b->mapq && b->l_qseq && b->mtid && b->mpos && b->isize && b->cigar_off && b->seq_off;
 	if (b->n > 0 && (!b->tid || !b->pos || !b->n_cigar || (!b->rec && !has_soa))) { c->err = "batch with null arrays"; return SSV_E_ARG; }
 	const int mem = b->mem & ~(int)SSV_MEM_PERSISTENT;
 	if (mem != SSV_MEM_DEVICE && b->mem != SSV_MEM_HOST) { c->err = "bad batch.mem"; return SSV_E_ARG; }
+	return SSV_OK;
+}
+
+// Make the batch visible to the kernels: device batches are used in place, host batches are copied to HBM (or were, ssv_batch_prefetch); a
+// batch that comes as structure-of-arrays columns only is transposed into record lines (ssv_record) on the device.
+int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
+{
+	CHECK(check_batch(c, b));
 	d.n = b->n; d.max_ref_span = b->max_ref_span;
 	const size_t n = (size_t)b->n;
 	SoaCols s{};
-	if (mem == SSV_MEM_DEVICE) {
+	ssv_record *rec_dst = nullptr;
+	if ((b->mem & ~(int)SSV_MEM_PERSISTENT) == SSV_MEM_DEVICE) {
 		if (!aligned16(b->tid) || !aligned16(b->pos) || !aligned16(b->n_cigar) || (b->rec && !aligned64(b->rec))) {
 			c->err = "device batch arrays must be 16-byte aligned (rec: 64-byte aligned)"; return SSV_E_ARG;
 		}
@@ -283,36 +330,28 @@ int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
 		if (d.rec || n == 0) return SSV_OK;
 		s.tid = b->tid; s.pos = b->pos; s.flag = b->flag; s.mapq = b->mapq; s.n_cigar = b->n_cigar; s.l_qseq = b->l_qseq; s.mtid = b->mtid; s.mpos = b->mpos; s.isize = b->isize;
 		s.cigar_off = b->cigar_off; s.cigar = b->cigar; s.xc = b->xc; s.seq_off = b->seq_off;
+		CHECK(ensure(c, c->ss[2].rec, n * sizeof(ssv_record) + 64));
+		rec_dst = P<ssv_record>(c->ss[2].rec);
 	} else {
-		ProfScope ps(c, P_H2D, b->n);
-		// with `rec` the host batch ships lines + hot columns + variable parts; without, the classic columns
-		struct { const void *src; size_t bytes; } f[14] = {
-			{b->tid, n * 4}, {b->pos, n * 4}, {b->rec ? nullptr : b->flag, n * 2}, {b->rec ? nullptr : b->mapq, n}, {b->n_cigar, n * 2}, {b->rec ? nullptr : b->l_qseq, n * 4},
-			{b->rec ? nullptr : b->mtid, n * 4}, {b->rec ? nullptr : b->mpos, n * 4}, {b->rec ? nullptr : b->isize, n * 4}, {b->rec ? nullptr : b->cigar_off, n * 4},
-			{b->cigar, (size_t)b->n_cigar_total * 4}, {b->rec ? nullptr : b->xc, b->xc ? n : 0}, {b->rec ? nullptr : b->seq_off, n * 8}, {b->seqqual, (size_t)b->seqqual_bytes}};
-		for (int k = 0; k < 14; ++k) {
-			if (!f[k].src) continue;
-			CHECK(ensure(c, c->sb[k], f[k].bytes + 16));
-			if (f[k].bytes) HIPCHECK(c, hipMemcpyAsync(c->sb[k].p, f[k].src, f[k].bytes, hipMemcpyHostToDevice, c->st));
+		if (!c->pf.empty()) {
+			// announced batches are consumed in the order they were announced
+			const ssv_ctx::Prefetched f = c->pf.front();
+			if (memcmp(&f.b, b, sizeof(*b)) != 0) { c->err = "a prefetched batch is pending: the next scan call must be given that batch"; return SSV_E_STATE; }
+			c->pf.pop_front();
+			staged_view(c, b, f.set, d, s);
+			HIPCHECK(c, hipEventSynchronize(c->ss[f.set].ready)); // the caller may recycle the host arrays once the scan call returns
+		} else {
+			ProfScope ps(c, P_H2D, b->n);
+			CHECK(upload_host_batch(c, b, 2, c->st));
+			staged_view(c, b, 2, d, s);
+			HIPCHECK(c, hipStreamSynchronize(c->st)); // same promise (copies from pinned host arrays are asynchronous)
 		}
-		CHECK(ensure(c, c->sb[10], 16)); CHECK(ensure(c, c->sb[13], 16));
-		d.tid = P<int32_t>(c->sb[0]); d.pos = P<int32_t>(c->sb[1]); d.n_cigar = P<uint16_t>(c->sb[4]); d.cigar = P<uint32_t>(c->sb[10]); d.seqqual = P<uint8_t>(c->sb[13]);
-		d.rec = nullptr;
-		if (b->rec) {
-			CHECK(ensure(c, c->sb_rec, n * sizeof(ssv_record) + 64));
-			if (n) HIPCHECK(c, hipMemcpyAsync(c->sb_rec.p, b->rec, n * sizeof(ssv_record), hipMemcpyHostToDevice, c->st));
-			d.rec = P<ssv_record>(c->sb_rec);
-			return SSV_OK;
-		}
-		if (n == 0) return SSV_OK;
-		s.tid = d.tid; s.pos = d.pos; s.flag = P<uint16_t>(c->sb[2]); s.mapq = P<uint8_t>(c->sb[3]); s.n_cigar = d.n_cigar; s.l_qseq = P<int32_t>(c->sb[5]); s.mtid = P<int32_t>(c->sb[6]);
-		s.mpos = P<int32_t>(c->sb[7]); s.isize = P<int32_t>(c->sb[8]); s.cigar_off = P<uint32_t>(c->sb[9]); s.cigar = d.cigar; s.xc = b->xc ? P<uint8_t>(c->sb[11]) : nullptr;
-		s.seq_off = P<uint64_t>(c->sb[12]);
+		if (b->rec || n == 0) return SSV_OK;
+		rec_dst = const_cast<ssv_record *>(d.rec);
 	}
-	CHECK(ensure(c, c->sb_rec, n * sizeof(ssv_record) + 64));
-	k_build_rec<<<grid_for(b->n, BLOCK), BLOCK, 0, c->st>>>(s, b->n, P<ssv_record>(c->sb_rec));
+	k_build_rec<<<grid_for(b->n, BLOCK), BLOCK, 0, c->st>>>(s, b->n, rec_dst);
 	HIPCHECK(c, hipGetLastError());
-	d.rec = P<ssv_record>(c->sb_rec);
+	d.rec = rec_dst;
 	return SSV_OK;
 }
 
@@ -374,7 +413,9 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 	ssv_ctx *c = new ssv_ctx();
 	c->device = device;
 	if ((e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return SSV_E_NODEVICE; }
-	if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
+	if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->st_h2d, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->ev_st, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ss[0].ready, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->ss[1].ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->tab[0].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->tab[1].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess) {
 		g_create_error = "cannot create the copy stream / events"; ssv_ctx_destroy(c); return SSV_E_NODEVICE;
@@ -396,7 +437,8 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
 	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
 	// every DBuf / HBuf member
-	DBuf *dbufs[] = {&c->sb_rec, &c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage,
+	if (c->st_h2d) { (void)hipStreamSynchronize(c->st_h2d); (void)hipStreamDestroy(c->st_h2d); }
+	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage,
 	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_strings,
 	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
@@ -404,7 +446,12 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
-	for (DBuf &b : c->sb) if (b.p) (void)hipFree(b.p);
+	for (auto &S : c->ss) {
+		for (DBuf &b : S.col) if (b.p) (void)hipFree(b.p);
+		if (S.rec.p) (void)hipFree(S.rec.p);
+		if (S.ready) (void)hipEventDestroy(S.ready);
+	}
+	if (c->ev_st) (void)hipEventDestroy(c->ev_st);
 	for (DBuf &b : c->blob.chunks) if (b.p) (void)hipFree(b.p);
 	HBuf *hbufs[] = {&c->h_counters, &c->h_totals, &c->h_q};
 	for (HBuf *b : hbufs) if (b->p) (void)hipHostFree(b->p);
@@ -430,6 +477,39 @@ int ssv_sync(ssv_ctx *c)
 	return SSV_OK;
 }
 
+int ssv_host_alloc(size_t bytes, void **p)
+{
+	if (!p) return SSV_E_ARG;
+	*p = nullptr;
+	hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable);
+	if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); *p = nullptr; return SSV_E_NOMEM; }
+	return SSV_OK;
+}
+
+int ssv_host_free(void *p)
+{
+	if (p && hipHostFree(p) != hipSuccess) return SSV_E_HIP;
+	return SSV_OK;
+}
+
+int ssv_batch_prefetch(ssv_ctx *c, const ssv_batch_t *b)
+{
+	if (!c || !b) return SSV_E_ARG;
+	CHECK(check_batch(c, b));
+	if (b->mem != SSV_MEM_HOST) { c->err = "ssv_batch_prefetch takes host batches"; return SSV_E_ARG; }
+	if (c->pf.size() >= 2) { c->err = "two prefetched batches are pending already"; return SSV_E_STATE; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	const int set = (int)(c->pf_count & 1);
+	// the set was last read by the kernels of the batch two announcements ago, all of them launched on st by now
+	HIPCHECK(c, hipEventRecord(c->ev_st, c->st));
+	HIPCHECK(c, hipStreamWaitEvent(c->st_h2d, c->ev_st, 0));
+	CHECK(upload_host_batch(c, b, set, c->st_h2d));
+	HIPCHECK(c, hipEventRecord(c->ss[set].ready, c->st_h2d));
+	c->pf.push_back(ssv_ctx::Prefetched{*b, set});
+	++c->pf_count;
+	return SSV_OK;
+}
+
 const char *ssv_last_error(const ssv_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 void *ssv_stream(ssv_ctx *c) { return c ? (void *)c->st : nullptr; }
 
@@ -440,6 +520,7 @@ void *ssv_stream(ssv_ctx *c) { return c ? (void *)c->st : nullptr; }
 int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 {
 	if (!c || !p) return SSV_E_ARG;
+	c->pf.clear(); // batches announced and never scanned are dropped
 	HIPCHECK(c, hipSetDevice(c->device));
 	c->clip_p = *p;
 	c->clip_active = true;
@@ -854,6 +935,7 @@ int ssv_isize_begin(ssv_ctx *c, int32_t min_mapq, int64_t max_pairs)
 {
 	if (!c) return SSV_E_ARG;
 	HIPCHECK(c, hipSetDevice(c->device));
+	c->pf.clear();
 	c->isz_active = true; c->isz_min_mapq = min_mapq; c->isz_max = max_pairs; c->isz_count = 0;
 	return SSV_OK;
 }
@@ -939,6 +1021,7 @@ int ssv_getsv_begin(ssv_ctx *c, const ssv_getsv_params *p)
 {
 	if (!c || !p || p->n_targets < 0 || p->n_junctions < 0 || p->n_windows < 0) return SSV_E_ARG;
 	if ((p->n_targets && !p->target_len) || (p->n_junctions && !p->junctions) || (p->n_windows && !p->windows)) return SSV_E_ARG;
+	c->pf.clear();
 	HIPCHECK(c, hipSetDevice(c->device));
 	c->gs_p = *p;
 	c->gs_tlen.assign(p->target_len, p->target_len + p->n_targets);

@@ -50,6 +50,11 @@ class Context:
     def sync(self):
         self._check(self._lib.ssv_sync(self._h), "ssv_sync")
 
+    def prefetch(self, batch):
+        """announce a host batch (an _abi.Batch over arrays that stay alive - best page-locked, see PinnedArrays): its copy to HBM starts on
+        the upload stream now; the next scan call must be given this batch"""
+        self._check(self._lib.ssv_batch_prefetch(self._h, C.byref(batch)), "ssv_batch_prefetch")
+
     @staticmethod
     def _as_batch(b):
         if isinstance(b, _abi.Batch):
@@ -111,8 +116,6 @@ class Context:
     def clip_scan(self, batch):
         b, keep = self._as_batch(batch)
         self._check(self._lib.ssv_clip_scan(self._h, C.byref(b)), "ssv_clip_scan")
-        if keep is not None:
-            self.sync()  # host arrays may go away
 
     def clip_event_count(self):
         n = C.c_int64()
@@ -177,8 +180,6 @@ class Context:
     def getsv_scan(self, batch):
         b, keep = self._as_batch(batch)
         self._check(self._lib.ssv_getsv_scan(self._h, C.byref(b)), "ssv_getsv_scan")
-        if keep is not None:
-            self.sync()
 
     def getsv_finish(self, ranges, points):
         r = np.ascontiguousarray(ranges, dtype=_abi.INTERVAL_DTYPE)
@@ -231,3 +232,40 @@ class Context:
 
     def prof_all(self):
         return {n: self.prof_get(n) for n in self._lib.ssv_prof_names().decode().split("\n")}
+
+
+class PinnedArrays:
+    """numpy arrays in page-locked host memory (ssv_host_alloc): only out of such memory do the copies of a host batch run asynchronously"""
+
+    def __init__(self):
+        self._lib = _abi.hip_lib()
+        self._ptrs = []
+
+    def empty(self, n, dtype):
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        if self._lib.ssv_host_alloc(max(1, int(n) * dt.itemsize), C.byref(p)) != 0:
+            raise SeeksvError("ssv_host_alloc failed")
+        self._ptrs.append(p)
+        return np.frombuffer((C.c_uint8 * (int(n) * dt.itemsize)).from_address(p.value), dtype=dt, count=int(n))
+
+    def copy(self, a):
+        a = np.ascontiguousarray(a)
+        out = self.empty(a.size * a.dtype.itemsize, np.uint8).view(a.dtype) if a.dtype.fields else self.empty(a.size, a.dtype)
+        out[...] = a.reshape(-1)
+        return out
+
+    def batch(self, arrays):
+        """a host batch (dict of numpy arrays, as synth.Workload.generate_host gives) copied into page-locked memory"""
+        return {k: (self.copy(v) if isinstance(v, np.ndarray) else v) for k, v in arrays.items()}
+
+    def close(self):
+        for p in self._ptrs:
+            self._lib.ssv_host_free(p)
+        self._ptrs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -362,20 +362,58 @@ static void find_records(const uint8_t *u, size_t begin, size_t end, int32_t n_t
 	S.exit = o;
 }
 
+// Batch arrays: grown, never shrunk, contents not kept across a growth (every batch writes all it hands out).  With an allocator set
+// (ssvh_bam_set_allocator: page-locked memory from the device library) the arrays can be copied to the GPU asynchronously.
+struct HostAlloc { void *(*alloc)(size_t) = nullptr; void (*release)(void *) = nullptr; };
+
+template <class T> struct Col {
+	T *p = nullptr;
+	size_t n = 0, cap = 0;
+	const HostAlloc *a = nullptr;
+	void (*release)(void *) = nullptr; // of the allocator `p` came from
+	Col() = default;
+	Col(const Col &) = delete;
+	Col &operator=(const Col &) = delete;
+	~Col() { drop(); }
+	void drop() { if (p) { if (release) release(p); else free(p); } p = nullptr; cap = 0; }
+	void resize(size_t m)
+	{
+		if (m > cap) {
+			const size_t nc = std::max(m, cap + cap / 2);
+			drop();
+			release = nullptr;
+			if (a && a->alloc && a->release && (p = (T *)a->alloc(nc * sizeof(T))) != nullptr) release = a->release;
+			if (!p) p = (T *)malloc(nc * sizeof(T)); // (also when the page-locked allocator is exhausted: the copies then run synchronously)
+			if (!p) throw std::bad_alloc();
+			memset(p, 0, nc * sizeof(T));
+			cap = nc;
+		}
+		n = m;
+	}
+	void assign(size_t m, T v) { resize(m); for (size_t i = 0; i < m; ++i) p[i] = v; }
+	size_t size() const { return n; }
+	T *data() { return p; }
+	const T *data() const { return p; }
+	T &operator[](size_t i) { return p[i]; }
+};
+
 struct ssvh_bam {
 	Bgzf z;
 	std::vector<std::string> names;
 	std::vector<int32_t> lens, name_field_len;
 	uint64_t header_len = 0; // bytes of the inflated stream before the first record
-	// batch storage: two sets, so that with read-ahead the next batch is decoded while the caller still uses the current one
+	// batch storage: three sets, so that with read-ahead the next batch is decoded while the caller still uses the current one AND the one
+	// before it (whose copy to the GPU may still be running)
 	struct BatchBuf {
-		std::vector<int32_t> tid, pos, l_qseq, mtid, mpos, isize;
-		std::vector<uint16_t> flag, n_cigar;
-		std::vector<uint8_t> mapq, xc, seqqual;
-		std::vector<uint32_t> cigar_off, cigar;
-		std::vector<uint64_t> seq_off;
+		Col<int32_t> tid, pos, l_qseq, mtid, mpos, isize;
+		Col<uint16_t> flag, n_cigar;
+		Col<uint8_t> mapq, xc, seqqual;
+		Col<uint32_t> cigar_off, cigar;
+		Col<uint64_t> seq_off;
 		std::vector<Unmapped> unmapped;
-	} buf[2];
+		void use(const HostAlloc *a) { tid.a = pos.a = l_qseq.a = mtid.a = mpos.a = isize.a = a; flag.a = n_cigar.a = a; mapq.a = xc.a = seqqual.a = a; cigar_off.a = cigar.a = a; seq_off.a = a; }
+	} buf[3];
+	HostAlloc alloc;
 	int cur = 0;
 	bool readahead = false;
 	std::thread ra_thread;
@@ -718,17 +756,25 @@ int ssvh_bam_read_batch(ssvh_bam *b, int64_t max_records, int keep_all_seq, ssv_
 	if (b->ra_thread.joinable()) {
 		b->ra_thread.join();
 		if (b->ra_max != max_records || b->ra_keep != keep_all_seq) { g_err = "read-ahead is on: every ssvh_bam_read_batch call must ask for the same batch"; return -1; }
-		b->cur ^= 1;
+		b->cur = (b->cur + 1) % 3;
 		rc = b->ra_rc; g_err = b->ra_err; *out = b->ra_batch;
 	} else rc = decode_batch(b, b->buf[b->cur], max_records, keep_all_seq, out);
 	if (rc == 0 && out->n > 0) {
 		b->ra_max = max_records; b->ra_keep = keep_all_seq;
 		b->ra_thread = std::thread([b] {
-			b->ra_rc = decode_batch(b, b->buf[b->cur ^ 1], b->ra_max, b->ra_keep, &b->ra_batch);
+			b->ra_rc = decode_batch(b, b->buf[(b->cur + 1) % 3], b->ra_max, b->ra_keep, &b->ra_batch);
 			b->ra_err = g_err;
 		});
 	}
 	return rc;
+}
+
+int ssvh_bam_set_allocator(ssvh_bam *b, void *(*alloc)(size_t), void (*release)(void *))
+{
+	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight"; return -1; }
+	b->alloc.alloc = alloc; b->alloc.release = release;
+	for (auto &B : b->buf) B.use(&b->alloc); // arrays that exist keep their memory until they have to grow
+	return 0;
 }
 
 int ssvh_bam_set_readahead(ssvh_bam *b, int on)

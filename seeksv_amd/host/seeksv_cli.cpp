@@ -168,6 +168,38 @@ struct GzOut {
 // thread fills one pinned staging buffer while the chunk in the other one is being decoded.
 // ---------------------------------------------------------------------------------------------------------------------
 
+// Page-locked batch arrays for the host reader (copies to the GPU out of them run asynchronously); SSV_PAGEABLE=1 keeps malloc.
+static void *pinned_alloc(size_t n) { void *p = nullptr; return ssv_host_alloc(n, &p) == SSV_OK ? p : nullptr; }
+static void pinned_release(void *p) { ssv_host_free(p); }
+static void use_pinned_batches(ssvh_bam *b)
+{
+	static const bool pageable = getenv("SSV_PAGEABLE") != nullptr;
+	if (!pageable) ssvh_bam_set_allocator(b, pinned_alloc, pinned_release);
+	ssvh_bam_set_readahead(b, 1);
+}
+
+// The batches of a host reader (read-ahead on: three sets of arrays) through a context: batch k+1 is decoded, announced and on its way to the
+// GPU (ssv_batch_prefetch, the upload stream) while batch k is scanned; `side` sees every batch right after it was read (the reader's
+// per-batch side channel - unmapped reads - is valid only then), `scan` gets them in order.  Returns "" or the error text.
+template <class Side, class Scan> static string pump_host_batches(ssvh_bam *rb, ssv_ctx *ctx, int keep_all_seq, Side side, Scan scan)
+{
+	ssv_batch_t b[2];
+	auto read = [&](ssv_batch_t *out) -> string {
+		if (ssvh_bam_read_batch(rb, 1 << 22, keep_all_seq, out) != 0) return string("[seeksv] ") + ssvh_last_error();
+		if (out->n == 0) return "";
+		side(*out);
+		if (ssv_batch_prefetch(ctx, out) != SSV_OK) return string("[seeksv] ") + ssv_last_error(ctx);
+		return "";
+	};
+	string err = read(&b[0]);
+	for (int k = 0; err.empty() && b[k & 1].n != 0; ++k) {
+		err = read(&b[(k + 1) & 1]);
+		if (!err.empty()) break;
+		err = scan(b[k & 1]);
+	}
+	return err;
+}
+
 struct BatchSource {
 	ssvh_bam *bam = nullptr;
 	ssv_ctx *ctx = nullptr;
@@ -190,7 +222,7 @@ struct BatchSource {
 	{
 		ctx = c; on_device = device_inflate;
 		if (ssvh_bam_open(path.c_str(), &bam) != 0) die(open_error);
-		if (!on_device) { ssvh_bam_set_readahead(bam, 1); return; }
+		if (!on_device) { use_pinned_batches(bam); return; }
 		const char *e1 = getenv("SSV_CHUNK_INFLATED_MB"), *e2 = getenv("SSV_STAGE_MB");
 		chunk_inflated = (uint64_t)(e1 ? atoll(e1) : 4096) << 20;
 		stage_bytes = (size_t)(e2 ? atoll(e2) : 1536) << 20;
@@ -245,6 +277,17 @@ struct BatchSource {
 			ssv_bamdec_last(ctx, &info);
 			if (b->n) return true; // (a chunk can hold only the middle of one huge record)
 		}
+	}
+	// every batch through side(b) (right after it was read) and scan(b); with the host reader the copy of the next batch runs ahead
+	template <class Side, class Scan> void pump(int keep_all_seq, Side side, Scan scan)
+	{
+		if (!on_device) {
+			const string err = pump_host_batches(bam, ctx, keep_all_seq, side, [&](const ssv_batch_t &b) { scan(b); return string(); });
+			if (!err.empty()) die(err);
+			return;
+		}
+		ssv_batch_t b;
+		while (next(&b, keep_all_seq)) { side(b); scan(b); }
 	}
 	// UNMAP|MUNMAP records of the current batch, in order
 	template <class F> void for_each_unmapped(F fn)
@@ -402,11 +445,8 @@ static int cmd_getclip(int argc, char **argv)
 	map<string, pair<pair<string, string>, char>> id2seq_qual;
 	vector<int32_t> run_tids; // contig of every flush, in order (clip_reads.h:428-438, :442)
 	int32_t last_tid = 0;
-	for (;;) {
-		ssv_batch_t b;
-		const bool more = src.next(&b, 0);
-		pt.lap(device_inflate ? "bam_read(wait)+gpu_inflate+decode" : "bam_read");
-		if (!more) break;
+	src.pump(0, [&](const ssv_batch_t &b) {
+		pt.lap(device_inflate ? "bam_read(wait)+gpu_inflate+decode" : "bam_read(wait)");
 		src.for_each_unmapped([&](const char *qname, const char *seq, const char *qual, int is_read1) {
 			auto it = id2seq_qual.find(qname);
 			if (it != id2seq_qual.end()) {
@@ -423,10 +463,10 @@ static int cmd_getclip(int argc, char **argv)
 		});
 		src.contig_runs(b, last_tid, run_tids); // the flush sequence, for the stderr messages and the order check
 		pt.lap("host_side_channel");
+	}, [&](const ssv_batch_t &b) {
 		if (ssv_clip_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		ssv_sync(ctx);
-		pt.lap("gpu_scan(h2d+kernels)");
-	}
+		pt.lap("gpu_scan(wait h2d+kernels)");
+	});
 	run_tids.push_back(last_tid);
 	for (size_t k = 1; k < run_tids.size(); ++k)
 		if (run_tids[k] <= run_tids[k - 1]) die("[seeksv] the BAM is not coordinate sorted (contig " + string(ssvh_bam_target_name(bam, run_tids[k]) ? ssvh_bam_target_name(bam, run_tids[k]) : "?") + " appears out of order)");
@@ -516,28 +556,24 @@ static int getclip_ranks(const string &bamfile, const string &prefix, double thr
 		ssv_clip_table_format(ctx, 2);
 		ssvh_bam *rb = nullptr;
 		if (ssvh_bam_open(bamfile.c_str(), &rb) != 0) { out.err = "[main_samview] fail to open file for reading."; ssv_ctx_destroy(ctx); return; }
+		use_pinned_batches(rb);
 		// the contig of the last mapped-pair record before the rank's OWN run (its run list continues from there)
 		out.last_tid = r == 0 ? 0 : P.before_own_tid;
 		for (int phase = 0; phase < 2 && out.err.empty(); ++phase) { // 0: the halo (scanned, nothing else), 1: the rank's own records
 			if (phase == 0 && (P.scan_coff != P.own_coff || P.scan_uoff != P.own_uoff)) { if (ssvh_bam_set_range(rb, P.scan_coff, P.scan_uoff, P.own_coff, P.own_uoff) != 0) out.err = string("[seeksv] ") + ssvh_last_error(); }
 			else if (phase == 0) continue;
 			else if (ssvh_bam_set_range(rb, P.own_coff, P.own_uoff, P.end_coff, P.end_uoff) != 0) out.err = string("[seeksv] ") + ssvh_last_error();
-			while (out.err.empty()) {
-				ssv_batch_t b;
-				if (ssvh_bam_read_batch(rb, 1 << 22, 0, &b) != 0) { out.err = string("[seeksv] ") + ssvh_last_error(); break; }
-				if (b.n == 0) break;
+			if (!out.err.empty()) break;
+			out.err = pump_host_batches(rb, ctx, 0, [&](const ssv_batch_t &b) {
 				out.max_span = std::max(out.max_span, b.max_ref_span);
-				if (phase == 1) {
-					const char *qname, *seq, *qual; int is_read1;
-					for (int64_t k = 0, nu = ssvh_bam_unmapped_count(rb); k < nu; ++k) { ssvh_bam_unmapped_get(rb, k, &qname, &seq, &qual, &is_read1); out.unmapped.push_back(UnmappedRec{qname, seq, qual, is_read1}); }
-					for (int64_t i = 0; i < b.n; ++i) {
-						if (b.flag[i] & (4 | 8)) continue;
-						if (b.tid[i] != out.last_tid) { out.run_tids.push_back(out.last_tid); out.last_tid = b.tid[i]; }
-					}
+				if (phase != 1) return;
+				const char *qname, *seq, *qual; int is_read1;
+				for (int64_t k = 0, nu = ssvh_bam_unmapped_count(rb); k < nu; ++k) { ssvh_bam_unmapped_get(rb, k, &qname, &seq, &qual, &is_read1); out.unmapped.push_back(UnmappedRec{qname, seq, qual, is_read1}); }
+				for (int64_t i = 0; i < b.n; ++i) {
+					if (b.flag[i] & (4 | 8)) continue;
+					if (b.tid[i] != out.last_tid) { out.run_tids.push_back(out.last_tid); out.last_tid = b.tid[i]; }
 				}
-				if (ssv_clip_scan(ctx, &b) != SSV_OK) { out.err = string("[seeksv] ") + ssv_last_error(ctx); break; }
-				ssv_sync(ctx);
-			}
+			}, [&](const ssv_batch_t &b) { return ssv_clip_scan(ctx, &b) != SSV_OK ? string("[seeksv] ") + ssv_last_error(ctx) : string(); });
 		}
 		ssv_cluster_table t;
 		if (out.err.empty() && ssv_clip_cluster(ctx, &t) != SSV_OK) out.err = string("[seeksv] ") + ssv_last_error(ctx);
@@ -811,12 +847,9 @@ static int cmd_getsv(int argc, char **argv)
 				if (sufficient || found < back || back > (1ll << 26)) break; // (found < back: the replay began at the file's first record)
 			}
 			if (err.empty() && ssvh_bam_set_range(rb, P.own_coff, P.own_uoff, P.end_coff, P.end_uoff) != 0) err = string("[seeksv] ") + ssvh_last_error();
-			while (err.empty()) {
-				ssv_batch_t b;
-				if (ssvh_bam_read_batch(rb, 1 << 22, 0, &b) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
-				if (b.n == 0) break;
-				if (ssv_getsv_scan(rc, &b) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
-				ssv_sync(rc);
+			if (err.empty()) {
+				use_pinned_batches(rb); // (the replay above read single batches of its own sizes: read-ahead only from here on)
+				err = pump_host_batches(rb, rc, 0, [](const ssv_batch_t &) {}, [&](const ssv_batch_t &b) { return ssv_getsv_scan(rc, &b) != SSV_OK ? string("[seeksv] ") + ssv_last_error(rc) : string(); });
 			}
 			vector<uint8_t> mine(vec_bytes, 0);
 			uint64_t *v_rs = reinterpret_cast<uint64_t *>(mine.data());
@@ -862,12 +895,9 @@ static int cmd_getsv(int argc, char **argv)
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		BatchSource src; // a second handle: `bam` keeps serving the header
 		src.open(original_bam, ctx, device_inflate, "[main_samview] fail to open file for reading.");
-		for (;;) {
-			ssv_batch_t b;
-			if (!src.next(&b, 0)) break;
+		src.pump(0, [](const ssv_batch_t &) {}, [&](const ssv_batch_t &b) {
 			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-			ssv_sync(ctx);
-		}
+		});
 		src.close();
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, do_discordant ? counts.data() : nullptr, dr, output_depth ? nr : 0, rsum.data(), dp, output_depth ? np : 0, pdepth.data(), &maxd) != SSV_OK)
@@ -1030,12 +1060,9 @@ static int cmd_somatic(int argc, char **argv)
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		BatchSource src; // a second handle: `bam` keeps serving the header
 		src.open(normal_bam_file, ctx, device_inflate, "[main_samview] fail to open file for reading.");
-		for (;;) {
-			ssv_batch_t b;
-			if (!src.next(&b, 0)) break;
+		src.pump(0, [](const ssv_batch_t &) {}, [&](const ssv_batch_t &b) {
 			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-			ssv_sync(ctx);
-		}
+		});
 		src.close();
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, counts.data(), nullptr, 0, nullptr, nullptr, 0, nullptr, &maxd) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
