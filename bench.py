@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--file-frac", type=float, default=1 / 16, help="genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
                     "inflate + decode -> scans -> tables on the host); 0 = skip")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
+    ap.add_argument("--table-format", type=int, default=3, help="ssv_clip_table_format: 3 = the compact table (default), 2 = four-piece blocks with 4-bit bases, 0 = ASCII")
     ap.add_argument("--no-overlap", action="store_true", help="collect every cluster table in its own step (no copy in flight while other kernels run); use under rocprofv3, which serialises dispatches of different streams")
     args = ap.parse_args()
 
@@ -121,7 +122,10 @@ def main():
     gen_s = time.time() - t0
 
     ctx = Context(local_rank)
-    ctx.clip_table_format(0 if args.ascii_table else 2)  # sequences cross PCIe as 4-bit codes, qualities as alphabet indices (the CLI expands them while it formats the rows)
+    table_format = 0 if args.ascii_table else args.table_format
+    # the table is the getclip stage's output and PCIe bounds the step: the compact format ships 12 bytes of fixed columns per cluster, bases
+    # at 2 bits, qualities as alphabet indices; the host rebuilds contig / side / offsets (ssv_clip_table_expand, inside the timed step)
+    ctx.clip_table_format(table_format)
     hdr = host.Header(w.names, w.lens)
     own = sp["own"] if world > 1 else None
     jtable = host.JunctionTable(w.junctions)
@@ -131,7 +135,14 @@ def main():
 
     def collect_table(prev):
         t = ctx.clip_table_wait(prev=prev)
-        ssum = int(np.ctypeslib.as_array(t.support, shape=(t.n_clusters,)).sum()) if t.n_clusters else 0
+        n = t.n_clusters
+        if t.format == 3:
+            ctx.clip_table_expand(t, 16)
+            state["table_bytes"] = n * (4 + 2 * t.len_bytes + t.support_bytes + t.ncig_bytes + 1) + t.str_bytes + 4 * t.cigar_ops + 16 * t.n_runs + 8 * t.n_base_exc
+        else:
+            state["table_bytes"] = n * 42 + t.str_bytes + 4 * t.cigar_ops
+        state["table_info"] = dict(format=int(t.format), qual_bits=int(t.qual_bits), base_bits=int(t.base_bits), base_exceptions=int(t.n_base_exc))
+        ssum = int(np.ctypeslib.as_array(t.support, shape=(n,)).sum()) if n else 0
         assert ssum == t.n_events, "clip events were lost or duplicated"
         assert bool(t.seq_packed) == (not args.ascii_table)
         state["support_sum"] = ssum
@@ -306,6 +317,8 @@ def main():
             "wall_ms_one_step": {k: round(v, 3) for k, v in wall.items()},
             "wall_ms_timed_steps": step_walls,
             "result": res,
+            "table": dict(state.get("table_info", {}), bytes=int(state.get("table_bytes", 0)), bytes_per_cluster=round(state.get("table_bytes", 0) / max(1, res["n_clusters"]), 1),
+                          note="what crosses PCIe per step; format 3: contig / side / offsets are rebuilt on the host inside the step (ssv_clip_table_expand)"),
         }
         if world == 1 and args.file_frac > 0:
             try:
@@ -402,6 +415,8 @@ def file_path_leg(ctx, args, device):
             end_of_input()
             nc, ne = ctx.clip_cluster_async()
             tab = ctx.clip_table_wait()
+            if tab.format == 3:
+                ctx.clip_table_expand(tab, 16)
             ssum = int(np.ctypeslib.as_array(tab.support, shape=(tab.n_clusters,)).sum()) if tab.n_clusters else 0
             assert ssum == tab.n_events == ne and n == w.n_total
             t["getclip_s"] = time.perf_counter() - t0

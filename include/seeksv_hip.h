@@ -171,6 +171,13 @@ int ssv_clip_event_count(ssv_ctx *ctx, int64_t *n_events);
  * next ssv_clip_begin / ssv_ctx_destroy.
  */
 typedef struct {
+	int32_t tid;
+	uint8_t side;              /* '5' or '3' */
+	uint8_t pad[3];
+	int64_t first;             /* index of the run's first cluster */
+} ssv_table_run;
+
+typedef struct {
 	int64_t n_clusters;
 	int64_t n_events;
 	const int32_t *tid;        /* [n_clusters] */
@@ -197,11 +204,46 @@ typedef struct {
 	                              ceil(n * qual_bits / 8) bytes, unused bits are 0.  Lossless: base qualities are most of the table's bytes
 	                              and come from a handful of values on current sequencers. */
 	uint8_t qual_alphabet[16]; /* index -> quality character */
+	/* ---- format 3, the compact table: what the host can rebuild does not cross PCIe ----
+	 * Handed out by ssv_clip_table_wait: pos, cigar, str and the fields below; tid, side, support, left_len, right_len, qual_missing,
+	 * n_cigar, str_off and cigar_off are NULL until ssv_clip_table_expand() has rebuilt them on the host.
+	 *   c_len      [n_clusters][2] left_len, right_len, len_bytes (2 or 4) wide each
+	 *   c_support  [n_clusters] support_bytes (2 or 4) wide;  c_ncig [n_clusters] ncig_bytes (1 or 2) wide;  c_flags bit 0 = qual_missing
+	 *   runs       the table is a sequence of (contig, side) runs; run r covers clusters [runs[r].first, runs[r + 1].first)
+	 *   a cluster's string block = [base stream | quality stream], each zero padded to whole 32-bit words; blocks follow each other in
+	 *   cluster order (str_off = running sum of ssv_table_block_bytes3), CIGARs likewise (cigar_off = running sum of n_cigar):
+	 *     base stream     the n = left_len + right_len bases of seq_left then seq_right, base_bits each, base i at stream bits
+	 *                     [i * base_bits, +base_bits) (bit b of a stream = bit b % 8 of byte b / 8).  base_bits 2: index into "ACGT", and
+	 *                     every base that is something else is listed in base_exc (the stream holds 0 there); base_bits 4 (only when
+	 *                     that list would be too long): index into "=ACMGRSVTWYHKDBN"
+	 *     quality stream  the n qualities the same way at qual_bits each (8: characters), all zero when qual_missing
+	 *   base_exc   sorted; cluster << 28 | base index << 4 | index into "=ACMGRSVTWYHKDBN" */
+	int32_t format;            /* the ssv_clip_table_format the table was built with */
+	int32_t base_bits;
+	int32_t len_bytes, support_bytes, ncig_bytes, pad3;
+	const void *c_len;
+	const void *c_support;
+	const void *c_ncig;
+	const uint8_t *c_flags;
+	const ssv_table_run *runs;
+	int64_t n_runs;
+	const uint64_t *base_exc;
+	int64_t n_base_exc;
+	uint64_t str_bytes;        /* bytes of str / operations of cigar (all formats) */
+	uint64_t cigar_ops;
 } ssv_cluster_table;
 
 /* Table format of the following ssv_clip_cluster[_async] calls: 0 ASCII (default), 1 sequences as 4-bit codes, 2 the same plus
- * qualities as alphabet indices when the pass's quality alphabet is small enough (else they stay bytes: qual_bits tells). */
+ * qualities as alphabet indices when the pass's quality alphabet is small enough (else they stay bytes: qual_bits tells), 3 the
+ * compact table (see ssv_cluster_table: ~110 instead of ~170 bytes per 150-base cluster; the table is the path's output and PCIe
+ * bounds the step). */
 int ssv_clip_table_format(ssv_ctx *ctx, int format);
+/* Format 3: rebuild the columns that did not cross PCIe (contig and side from the runs, the widened support / lengths / flags, string
+ * and CIGAR offsets as running sums) into context-owned host memory, on n_threads host threads (0: as many as the machine has), and
+ * set the pointers in *t.  Valid as long as the table. */
+int ssv_clip_table_expand(ssv_ctx *ctx, ssv_cluster_table *t, int32_t n_threads);
+/* Bytes of one cluster's string block in format 3 (n_bases = left_len + right_len). */
+uint64_t ssv_table_block_bytes3(int64_t n_bases, int32_t base_bits, int32_t qual_bits);
 /* Bytes of one cluster's string block (a multiple of 4). */
 uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits);
 

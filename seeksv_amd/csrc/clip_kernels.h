@@ -947,6 +947,7 @@ struct PackArgs {
 	int32_t *ncig;
 	uint64_t *str_off, *cig_off;
 	int packed;               // 1: sequences as 4-bit codes (ssv_cluster_table.seq_packed)
+	int format3, base_bits;   // the compact layout (table3_kernels.h): one base stream + one quality stream per block
 	int qual_bits;            // 8: quality characters; 1, 2, 3, 4: indices into the table's quality alphabet
 	const uint8_t *qlut;      // [256] phred -> index (0xff: not in the alphabet), when qual_bits < 8
 	uint32_t *qual_seen;      // [8] bit set of the phred values met while packing (TRACK launches: which alphabet the table really needs)
@@ -977,7 +978,8 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_meta(PackArgs p)
 		const uint4 eb = ep[1], ec = ep[2];
 		const int ll = single ? (int)eb.w : p.c.c_ll[j], lr = single ? (int)ec.x : p.c.c_lr[j];
 		cnt = 1ull | ((uint64_t)ec.z << 32);
-		bytes = table_block_bytes((uint64_t)ll, (uint64_t)lr, p.packed, (uint64_t)p.qual_bits);
+		bytes = p.format3 ? 4ull * (((uint64_t)(ll + lr) * (uint64_t)p.base_bits + 31) / 32 + ((uint64_t)(ll + lr) * (uint64_t)p.qual_bits + 31) / 32)
+		                  : table_block_bytes((uint64_t)ll, (uint64_t)lr, p.packed, (uint64_t)p.qual_bits);
 		lng = p.packed && single && (int)ec.y > PACK_MAX_LQ;
 	}
 	// one atomic per wavefront that holds long reads (same-address atomics run at ~90 per microsecond: with long-read data every slot is listed)

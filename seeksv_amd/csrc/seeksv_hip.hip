@@ -13,12 +13,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <deque>
 #include <vector>
 
 #include "bamdec_kernels.h"
 #include "realign_kernels.h"
 #include "clip_kernels.h"
+#include "table3_kernels.h"
 #include "common.h"
 #include "getsv_kernels.h"
 #include "radix_sort.h"
@@ -90,7 +92,7 @@ struct ssv_ctx {
 	DBuf g_seq_bytes, g_cig_ops, g_seq_off, g_cig_off; // the copying path (batches without SSV_MEM_PERSISTENT)
 	Arena blob;
 	uint64_t sum_ncig = 0;
-	int max_lq = 0;
+	int max_lq = 0, max_ncig = 0;
 	// clustering temporaries / outputs
 	DBuf keys2[2], vals2[2], evs, cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_bflag, c_boff, c_blist, c_strings, slot_cnt, slot_bytes;
 	DBuf o_slowlist, o_desc, totals;
@@ -100,6 +102,17 @@ struct ssv_ctx {
 	struct TableSet {
 		DBuf o_tid, o_pos, o_side, o_support, o_ll, o_lr, o_qmiss, o_ncig, o_stroff, o_cigoff, o_str, o_cig;
 		HBuf h_tid, h_pos, h_side, h_support, h_ll, h_lr, h_qmiss, h_stroff, h_cigoff, h_ncig, h_str, h_cig;
+		// format 3 (compact): pos, flags (in o_qmiss / h_qmiss), str, cig as above, plus
+		DBuf o_len, o_sup, o_nc, o_runs, o_exc;
+		HBuf h_len, h_sup, h_nc, h_runs, h_exc;
+		int format = 0, base_bits = 4, len_bytes = 4, support_bytes = 4, ncig_bytes = 4;
+		int64_t n_runs = 0, n_exc = 0;
+		uint64_t str_bytes = 0, cig_ops = 0;
+		// the columns ssv_clip_table_expand rebuilds on the host
+		std::vector<int32_t> x_tid, x_support, x_ll, x_lr, x_ncig;
+		std::vector<uint8_t> x_side, x_qmiss;
+		std::vector<uint64_t> x_stroff, x_cigoff;
+		bool expanded = false, ordered = false;
 		hipEvent_t copied = nullptr, started = nullptr; // `started` only with SSV_DEBUG_COPY (times the copy on its stream)
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
@@ -107,7 +120,7 @@ struct ssv_ctx {
 		uint8_t qual_alphabet[16] = {0};
 	} tab[2];
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
-	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices
+	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices, 3 compact
 	DBuf qual_lut, qual_seen; HBuf h_qual_lut;
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
@@ -456,8 +469,8 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	HBuf *hbufs[] = {&c->h_counters, &c->h_totals, &c->h_q};
 	for (HBuf *b : hbufs) if (b->p) (void)hipHostFree(b->p);
 	for (auto &t : c->tab) {
-		DBuf *td[] = {&t.o_tid, &t.o_pos, &t.o_side, &t.o_support, &t.o_ll, &t.o_lr, &t.o_qmiss, &t.o_ncig, &t.o_stroff, &t.o_cigoff, &t.o_str, &t.o_cig};
-		HBuf *th[] = {&t.h_tid, &t.h_pos, &t.h_side, &t.h_support, &t.h_ll, &t.h_lr, &t.h_qmiss, &t.h_stroff, &t.h_cigoff, &t.h_ncig, &t.h_str, &t.h_cig};
+		DBuf *td[] = {&t.o_tid, &t.o_pos, &t.o_side, &t.o_support, &t.o_ll, &t.o_lr, &t.o_qmiss, &t.o_ncig, &t.o_stroff, &t.o_cigoff, &t.o_str, &t.o_cig, &t.o_len, &t.o_sup, &t.o_nc, &t.o_runs, &t.o_exc};
+		HBuf *th[] = {&t.h_tid, &t.h_pos, &t.h_side, &t.h_support, &t.h_ll, &t.h_lr, &t.h_qmiss, &t.h_stroff, &t.h_cigoff, &t.h_ncig, &t.h_str, &t.h_cig, &t.h_len, &t.h_sup, &t.h_nc, &t.h_runs, &t.h_exc};
 		for (DBuf *b : td) if (b->p) (void)hipFree(b->p);
 		for (HBuf *b : th) if (b->p) (void)hipHostFree(b->p);
 		if (t.copied) (void)hipEventDestroy(t.copied);
@@ -524,7 +537,7 @@ int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 	HIPCHECK(c, hipSetDevice(c->device));
 	c->clip_p = *p;
 	c->clip_active = true;
-	c->n_events = 0; c->n_l = 0; c->n_r = 0; c->n_long = 0; c->sum_ncig = 0; c->max_lq = 0; c->ev_slots = 0;
+	c->n_events = 0; c->n_l = 0; c->n_r = 0; c->n_long = 0; c->sum_ncig = 0; c->max_lq = 0; c->max_ncig = 0; c->ev_slots = 0;
 	c->blob.cur = 0; c->blob.used = 0;
 	CHECK(ensure(c, c->d_last_tid, 16));
 	CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
@@ -633,6 +646,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			const int64_t nbr = (int64_t)(hc->n_new >> 32);
 			c->n_events += nb; c->n_r += nbr; c->n_l += nb - nbr; c->n_long += (int64_t)hc->n_long;
 			c->max_lq = std::max(c->max_lq, hc->max_lq);
+			c->max_ncig = std::max(c->max_ncig, hc->max_ncig);
 			c->sum_ncig += hc->sum_ncig;
 		}
 	}
@@ -649,6 +663,13 @@ int ssv_clip_event_count(ssv_ctx *c, int64_t *n)
 	return SSV_OK;
 }
 
+// entries of the list of bases outside A/C/G/T that a compact table may carry before it falls back to 4-bit bases
+static int64_t exc_cap_of(int64_t E)
+{
+	const char *e = getenv("SSV_EXC_CAP"); // (tests: a tiny list)
+	return e ? (int64_t)atoll(e) : std::min<int64_t>(E / 2 + 65536, 0xffffffffll);
+}
+
 int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 {
 	if (!c) return SSV_E_ARG;
@@ -662,6 +683,9 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	const int64_t E = c->n_events, EL = c->n_l, ER = c->n_r;
 	T.n_events = E; T.n_clusters = 0;
 	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
+	const bool fmt3 = c->table_mode == 3;
+	T.format = c->table_mode; T.base_bits = fmt3 ? 2 : 4; T.n_runs = 0; T.n_exc = 0; T.expanded = false; T.ordered = false;
+	T.len_bytes = fmt3 && c->max_lq < 65536 ? 2 : 4; T.support_bytes = fmt3 ? 2 : 4; T.ncig_bytes = fmt3 ? (c->max_ncig < 256 ? 1 : 2) : 4;
 	if (n_events) *n_events = E;
 	if (n_clusters) *n_clusters = 0;
 	if (E == 0) { HIPCHECK(c, hipStreamSynchronize(c->st)); return SSV_OK; }
@@ -681,7 +705,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		if (EL > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(EL, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, &dc->max_key);
 		if (ER > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(ER, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_r[0]), ER, &dc->max_key);
 		uint32_t *h_seen = reinterpret_cast<uint32_t *>(P<uint8_t>(c->h_totals) + 64);
-		if (c->table_mode == 2) {
+		if (c->table_mode >= 2) {
 			// first guess of the table's quality alphabet: the qualities of the first events
 			HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
 			const int64_t ns = std::min<int64_t>(E, 16384);
@@ -781,7 +805,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) { T.qual_alphabet[k] = (uint8_t)(v + 33); lut[v] = (uint8_t)k; ++k; } // increasing order; the table shows characters (phred + 33)
 		};
 		uint32_t guess[8] = {0};
-		if (c->table_mode == 2) { memcpy(guess, h_seen, 32); set_alphabet(guess); }
+		if (c->table_mode >= 2) { memcpy(guess, h_seen, 32); set_alphabet(guess); }
 		CHECK(ensure(c, c->slot_cnt, E * 8)); CHECK(ensure(c, c->slot_bytes, E * 8));
 		CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(E) * 8));
 		DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &T.o_ncig, &c->o_slowlist};
@@ -791,10 +815,18 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		for (DBuf *b : d8) CHECK(ensure(c, *b, E * 8 + 16));
 		CHECK(ensure(c, c->o_desc, (size_t)E * sizeof(PackDesc) + 64));
 		CHECK(ensure(c, T.o_cig, (size_t)c->sum_ncig * 4 + 16));
-		uint64_t *tot = P<uint64_t>(c->totals); // [0] clusters | CIGAR operations << 32, [1] string bytes, [2] slow-list length, [3] "a quality outside the alphabet" flag
+		const int64_t exc_cap = exc_cap_of(E);
+		if (fmt3) {
+			CHECK(ensure(c, T.o_len, (size_t)E * 8 + 16)); CHECK(ensure(c, T.o_sup, (size_t)E * 4 + 16)); CHECK(ensure(c, T.o_nc, (size_t)E * 2 + 16));
+			CHECK(ensure(c, T.o_runs, (size_t)E * sizeof(TableRun) + 16)); CHECK(ensure(c, T.o_exc, (size_t)exc_cap * 8 + 16));
+		}
+		// [0] clusters | CIGAR operations << 32, [1] string bytes, [2] slow-list length, [3] "a quality outside the alphabet" flag,
+		// format 3: [4] runs | base exceptions << 32, [5] "a support count too wide" | "too many base exceptions" << 32
+		uint64_t *tot = P<uint64_t>(c->totals);
 		bool track = false;
 		for (int attempt = 0;; ++attempt) {
-			const size_t str_cap = (size_t)E * (size_t)table_block_bytes((uint64_t)ca.SL, (uint64_t)ca.SR, T.packed, (uint64_t)T.qual_bits);
+			const size_t str_cap = (size_t)E * (size_t)(fmt3 ? table3_block_bytes((uint64_t)ca.SL + (uint64_t)ca.SR, T.base_bits, T.qual_bits)
+			                                             : table_block_bytes((uint64_t)ca.SL, (uint64_t)ca.SR, T.packed, (uint64_t)T.qual_bits));
 			CHECK(ensure(c, T.o_str, str_cap + 16));
 			PackArgs pa;
 			pa.c = ca; pa.slot_cnt = P<uint64_t>(c->slot_cnt); pa.slot_bytes = P<uint64_t>(c->slot_bytes);
@@ -803,7 +835,16 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
 			pa.lut_miss = reinterpret_cast<int *>(tot + 3);
 			pa.slow_list = P<uint32_t>(c->o_slowlist); pa.slow_count = reinterpret_cast<unsigned int *>(tot + 2);
-			HIPCHECK(c, hipMemsetAsync(tot, 0, 32, c->st));
+			pa.format3 = fmt3 ? 1 : 0; pa.base_bits = T.base_bits;
+			Pack3Args p3{};
+			if (fmt3) {
+				p3.pos = P<int32_t>(T.o_pos); p3.len = T.o_len.p; p3.support = T.o_sup.p; p3.ncig = T.o_nc.p; p3.flags = P<uint8_t>(T.o_qmiss);
+				p3.len_bytes = T.len_bytes; p3.support_bytes = T.support_bytes; p3.ncig_bytes = T.ncig_bytes; p3.base_bits = T.base_bits;
+				p3.runs = P<TableRun>(T.o_runs); p3.run_count = reinterpret_cast<unsigned int *>(tot + 4);
+				p3.exc = P<uint64_t>(T.o_exc); p3.exc_count = reinterpret_cast<unsigned int *>(tot + 4) + 1; p3.exc_cap = (uint32_t)exc_cap;
+				p3.support_miss = reinterpret_cast<int *>(tot + 5); p3.exc_miss = reinterpret_cast<int *>(tot + 5) + 1;
+			}
+			HIPCHECK(c, hipMemsetAsync(tot, 0, 64, c->st));
 			if (track) HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
 			if (T.packed && T.qual_bits < 8) HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, c->h_qual_lut.p, 256, hipMemcpyHostToDevice, c->st));
 			k_cluster_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
@@ -811,10 +852,21 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_bytes, pa.slot_bytes, E, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
 			uint8_t *os = P<uint8_t>(T.o_str);
 			PackDesc *dsc = P<PackDesc>(c->o_desc);
-			k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, dsc, P<uint32_t>(T.o_cig));
+			if (fmt3) k_cluster_cols3<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, p3, dsc, P<uint32_t>(T.o_cig));
+			else k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, dsc, P<uint32_t>(T.o_cig));
 			const unsigned int *nc_dev = reinterpret_cast<const unsigned int *>(tot);
 			const dim3 gs(grid_for(std::max<int64_t>(M + c->n_long, 1), GROUPS_PER_BLOCK)); // slots of multi-event bins + reads too long for the dword path
-			if (!pa.packed) k_cluster_pack_ascii<<<grid_for(E, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, os);
+			if (fmt3) {
+				// one group of lanes per cluster (the grid is an upper bound, the kernel reads the cluster count itself), then the base-by-base path
+				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
+#define SSV_P3B(W_, B_, T_) do { k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
+#define SSV_P3T(W_, T_) do { if (T.base_bits == 2) SSV_P3B(W_, 2, T_); else SSV_P3B(W_, 4, T_); } while (0)
+#define SSV_P3(W_) do { if (track) SSV_P3T(W_, true); else SSV_P3T(W_, false); } while (0)
+				if (pa.qual_bits == 8) SSV_P3T(8, false); else if (pa.qual_bits == 4) SSV_P3(4); else if (pa.qual_bits == 3) SSV_P3(3); else if (pa.qual_bits == 2) SSV_P3(2); else SSV_P3(1);
+#undef SSV_P3
+#undef SSV_P3T
+#undef SSV_P3B
+			} else if (!pa.packed) k_cluster_pack_ascii<<<grid_for(E, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, os);
 			else {
 				// the dword path for (nearly) all clusters (one group of lanes per cluster; the grid is an upper bound, the kernel reads the cluster
 				// count itself), then the bytewise path.  SSV_PACK_BLOCKS=n: the persistent, software-pipelined form of the kernel on n workgroups
@@ -829,18 +881,25 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 #undef SSV_PACK2
 			}
 			HIPCHECK(c, hipGetLastError());
-			HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 32, hipMemcpyDeviceToHost, c->st));
+			HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 64, hipMemcpyDeviceToHost, c->st));
 			if (track) HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
 			HIPCHECK(c, hipStreamSynchronize(c->st));
+			if (fmt3 && attempt <= 6) {
+				// (rare) a cluster with more than 65535 reads: the support column as u32; more bases outside A/C/G/T than the exception list takes:
+				// the base streams at 4 bits
+				const uint64_t m = P<uint64_t>(c->h_totals)[5];
+				if ((uint32_t)m && T.support_bytes == 2) { T.support_bytes = 4; continue; }
+				if ((uint32_t)(m >> 32) && T.base_bits == 2) { T.base_bits = 4; continue; }
+			}
 			if (track) { // the launch above met every quality value of the table's strings: that is the alphabet; pack once more with it
 				memcpy(guess, h_seen, 32);
 				set_alphabet(guess);
 				track = false;
 				continue;
 			}
-			if (c->table_mode == 2 && T.qual_bits < 8 && (int)P<uint64_t>(c->h_totals)[3] != 0) {
+			if (c->table_mode >= 2 && T.qual_bits < 8 && (int)P<uint64_t>(c->h_totals)[3] != 0) {
 				// the table's strings hold a quality value that the first events did not show: find out which values there are
-				if (attempt > 2) { c->err = "quality alphabet did not settle"; return SSV_E_HIP; }
+				if (attempt > 8) { c->err = "quality alphabet did not settle"; return SSV_E_HIP; }
 				track = true;
 				continue;
 			}
@@ -849,14 +908,21 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		nc = (int64_t)(uint32_t)P<uint64_t>(c->h_totals)[0];
 		cig_total = P<uint64_t>(c->h_totals)[0] >> 32;
 		str_total = P<uint64_t>(c->h_totals)[1];
+		if (fmt3) { T.n_runs = (int64_t)(uint32_t)P<uint64_t>(c->h_totals)[4]; T.n_exc = (int64_t)(P<uint64_t>(c->h_totals)[4] >> 32); }
 	}
-	T.n_clusters = nc;
+	T.n_clusters = nc; T.str_bytes = str_total; T.cig_ops = cig_total;
 	if (n_clusters) *n_clusters = nc;
 	if (nc == 0) return SSV_OK;
-	struct { HBuf *h; DBuf *d; size_t bytes; } cp[] = {
-		{&T.h_tid, &T.o_tid, (size_t)nc * 4}, {&T.h_pos, &T.o_pos, (size_t)nc * 4}, {&T.h_side, &T.o_side, (size_t)nc}, {&T.h_support, &T.o_support, (size_t)nc * 4},
-		{&T.h_ll, &T.o_ll, (size_t)nc * 4}, {&T.h_lr, &T.o_lr, (size_t)nc * 4}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_stroff, &T.o_stroff, (size_t)nc * 8},
-		{&T.h_cigoff, &T.o_cigoff, (size_t)nc * 8}, {&T.h_ncig, &T.o_ncig, (size_t)nc * 4}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * 4}};
+	struct CopyItem { HBuf *h; DBuf *d; size_t bytes; };
+	std::vector<CopyItem> cp;
+	if (fmt3)
+		cp = {{&T.h_pos, &T.o_pos, (size_t)nc * 4}, {&T.h_len, &T.o_len, (size_t)nc * 2 * (size_t)T.len_bytes}, {&T.h_sup, &T.o_sup, (size_t)nc * (size_t)T.support_bytes},
+		      {&T.h_nc, &T.o_nc, (size_t)nc * (size_t)T.ncig_bytes}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * 4},
+		      {&T.h_runs, &T.o_runs, (size_t)T.n_runs * sizeof(TableRun)}, {&T.h_exc, &T.o_exc, (size_t)T.n_exc * 8}};
+	else
+		cp = {{&T.h_tid, &T.o_tid, (size_t)nc * 4}, {&T.h_pos, &T.o_pos, (size_t)nc * 4}, {&T.h_side, &T.o_side, (size_t)nc}, {&T.h_support, &T.o_support, (size_t)nc * 4},
+		      {&T.h_ll, &T.o_ll, (size_t)nc * 4}, {&T.h_lr, &T.o_lr, (size_t)nc * 4}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_stroff, &T.o_stroff, (size_t)nc * 8},
+		      {&T.h_cigoff, &T.o_cigoff, (size_t)nc * 8}, {&T.h_ncig, &T.o_ncig, (size_t)nc * 4}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * 4}};
 	// the table goes to pinned host memory on the copy stream, behind the pack kernels; ssv_clip_table_wait() waits for it
 	HIPCHECK(c, hipEventRecord(c->ev_packed, c->st));
 	HIPCHECK(c, hipStreamWaitEvent(c->st_copy, c->ev_packed, 0));
@@ -875,7 +941,16 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			{&O.h_ll, &O.o_ll, (size_t)nc * 4, (size_t)E * 4}, {&O.h_lr, &O.o_lr, (size_t)nc * 4, (size_t)E * 4}, {&O.h_qmiss, &O.o_qmiss, (size_t)nc, (size_t)E}, {&O.h_stroff, &O.o_stroff, (size_t)nc * 8, (size_t)E * 8},
 			{&O.h_cigoff, &O.o_cigoff, (size_t)nc * 8, (size_t)E * 8}, {&O.h_ncig, &O.o_ncig, (size_t)nc * 4, (size_t)E * 4}, {&O.h_str, &O.o_str, (size_t)str_total, T.o_str.cap - 16},
 			{&O.h_cig, &O.o_cig, (size_t)cig_total * 4, (size_t)c->sum_ncig * 4}};
-		for (auto &x : oc) {
+		struct { HBuf *h; DBuf *d; size_t bytes, dbytes; } oc3[] = {
+			{&O.h_pos, &O.o_pos, (size_t)nc * 4, (size_t)E * 4}, {&O.h_len, &O.o_len, (size_t)nc * 2 * (size_t)T.len_bytes, (size_t)E * 8}, {&O.h_sup, &O.o_sup, (size_t)nc * (size_t)T.support_bytes, (size_t)E * 4},
+			{&O.h_nc, &O.o_nc, (size_t)nc * (size_t)T.ncig_bytes, (size_t)E * 2}, {&O.h_qmiss, &O.o_qmiss, (size_t)nc, (size_t)E}, {&O.h_str, &O.o_str, (size_t)str_total, T.o_str.cap - 16},
+			{&O.h_cig, &O.o_cig, (size_t)cig_total * 4, (size_t)c->sum_ncig * 4}, {&O.h_runs, &O.o_runs, (size_t)T.n_runs * sizeof(TableRun), (size_t)E * sizeof(TableRun)},
+			{&O.h_exc, &O.o_exc, (size_t)T.n_exc * 8, (size_t)exc_cap_of(E) * 8}};
+		if (fmt3) for (auto &x : oc3) {
+			if (x.h->cap < x.bytes + 16) CHECK(ensure_host(c, *x.h, x.bytes + 16));
+			if (x.d->cap < x.dbytes + 16) { void *np = nullptr; HIPCHECK(c, hipMalloc(&np, x.dbytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.dbytes + 16; }
+		}
+		else for (auto &x : oc) {
 			if (x.h->cap < x.bytes + 16) CHECK(ensure_host(c, *x.h, x.bytes + 16));
 			if (x.d->cap < x.dbytes + 16) { void *np = nullptr; HIPCHECK(c, hipMalloc(&np, x.dbytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.dbytes + 16; }
 		}
@@ -884,6 +959,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 }
 
 static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out);
+static void table_expanded_view(ssv_ctx::TableSet &T, ssv_cluster_table *out);
 
 uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits)
 {
@@ -893,7 +969,7 @@ uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_
 int ssv_clip_table_format(ssv_ctx *c, int packed)
 {
 	if (!c) return SSV_E_ARG;
-	if (packed < 0 || packed > 2) return SSV_E_ARG;
+	if (packed < 0 || packed > 3) return SSV_E_ARG;
 	c->table_mode = packed;
 	return SSV_OK;
 }
@@ -913,12 +989,97 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 		if (T.started) { float ms = 0; if (hipEventElapsedTime(&ms, T.started, T.copied) == hipSuccess) fprintf(stderr, "[ssv debug] table copy on its stream: %.2f ms\n", ms); }
 	}
 	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
+	out->format = T.format; out->base_bits = T.base_bits;
 	if (T.n_clusters == 0) return SSV_OK;
+	if (T.format == 3) {
+		out->len_bytes = T.len_bytes; out->support_bytes = T.support_bytes; out->ncig_bytes = T.ncig_bytes;
+		out->pos = P<int32_t>(T.h_pos); out->c_len = T.h_len.p; out->c_support = T.h_sup.p; out->c_ncig = T.h_nc.p; out->c_flags = P<uint8_t>(T.h_qmiss);
+		out->str = P<uint8_t>(T.h_str); out->cigar = P<uint32_t>(T.h_cig); out->str_bytes = T.str_bytes; out->cigar_ops = T.cig_ops;
+		out->runs = reinterpret_cast<const ssv_table_run *>(T.h_runs.p); out->n_runs = T.n_runs;
+		out->base_exc = P<uint64_t>(T.h_exc); out->n_base_exc = T.n_exc;
+		if (!T.ordered) { // once per table: put the runs (appended by whichever thread came first) and the exceptions in order
+			ssv_table_run *r = reinterpret_cast<ssv_table_run *>(T.h_runs.p);
+			std::sort(r, r + T.n_runs, [](const ssv_table_run &a, const ssv_table_run &b) { return a.first < b.first; });
+			uint64_t *e = P<uint64_t>(T.h_exc);
+			std::sort(e, e + T.n_exc);
+			T.ordered = true;
+		}
+		if (T.expanded) table_expanded_view(T, out);
+		return SSV_OK;
+	}
+	out->str_bytes = T.str_bytes; out->cigar_ops = T.cig_ops;
 	out->tid = P<int32_t>(T.h_tid); out->pos = P<int32_t>(T.h_pos); out->side = P<uint8_t>(T.h_side); out->support = P<int32_t>(T.h_support);
 	out->left_len = P<int32_t>(T.h_ll); out->right_len = P<int32_t>(T.h_lr); out->qual_missing = P<uint8_t>(T.h_qmiss); out->str_off = P<uint64_t>(T.h_stroff);
 	out->str = P<uint8_t>(T.h_str); out->cigar_off = P<uint64_t>(T.h_cigoff); out->n_cigar = P<int32_t>(T.h_ncig); out->cigar = P<uint32_t>(T.h_cig);
 	return SSV_OK;
 }
+
+// ---- the columns a compact table leaves to the host ----
+
+static void table_expanded_view(ssv_ctx::TableSet &T, ssv_cluster_table *out)
+{
+	out->tid = T.x_tid.data(); out->side = T.x_side.data(); out->support = T.x_support.data(); out->left_len = T.x_ll.data(); out->right_len = T.x_lr.data();
+	out->qual_missing = T.x_qmiss.data(); out->n_cigar = T.x_ncig.data(); out->str_off = T.x_stroff.data(); out->cigar_off = T.x_cigoff.data();
+}
+
+int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
+{
+	if (!c || !t) return SSV_E_ARG;
+	ssv_ctx::TableSet *Tp = nullptr;
+	for (auto &x : c->tab) if (x.format == 3 && !x.in_flight && x.n_clusters == t->n_clusters && (t->n_clusters == 0 || t->pos == P<int32_t>(x.h_pos))) Tp = &x;
+	if (t->format != 3 || !Tp) { c->err = "ssv_clip_table_expand takes a compact (format 3) table handed out by ssv_clip_table_wait"; return SSV_E_ARG; }
+	ssv_ctx::TableSet &T = *Tp;
+	const int64_t n = T.n_clusters;
+	if (n == 0 || T.expanded) { if (n) table_expanded_view(T, t); return SSV_OK; }
+	T.x_tid.resize((size_t)n); T.x_side.resize((size_t)n); T.x_support.resize((size_t)n); T.x_ll.resize((size_t)n); T.x_lr.resize((size_t)n); T.x_qmiss.resize((size_t)n);
+	T.x_ncig.resize((size_t)n); T.x_stroff.resize((size_t)n); T.x_cigoff.resize((size_t)n);
+	const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(n_threads > 0 ? n_threads : (int32_t)std::thread::hardware_concurrency()), 64, n / 65536 + 1}));
+	const ssv_table_run *runs = reinterpret_cast<const ssv_table_run *>(T.h_runs.p);
+	const int64_t n_runs = T.n_runs;
+	const int lb = T.len_bytes, sb = T.support_bytes, nb = T.ncig_bytes, bb = T.base_bits, qb = T.qual_bits;
+	const uint8_t *len = P<uint8_t>(T.h_len), *sup = P<uint8_t>(T.h_sup), *ncg = P<uint8_t>(T.h_nc), *fl = P<uint8_t>(T.h_qmiss);
+	std::vector<uint64_t> part_str((size_t)nt + 1, 0), part_cig((size_t)nt + 1, 0);
+	auto range = [&](int w, int64_t &k0, int64_t &k1) { k0 = n * w / nt; k1 = n * (w + 1) / nt; };
+	// pass 1: the widened columns and each range's string bytes / CIGAR operations; pass 2: the offsets
+	auto pass = [&](int w, bool second) {
+		int64_t k0, k1; range(w, k0, k1);
+		uint64_t so = second ? part_str[(size_t)w] : 0, co = second ? part_cig[(size_t)w] : 0;
+		int64_t ri = 0;
+		if (!second) { // the run that holds k0
+			int64_t lo = 0, hi = n_runs;
+			while (hi - lo > 1) { const int64_t m = (lo + hi) / 2; if (runs[m].first <= k0) lo = m; else hi = m; }
+			ri = lo;
+		}
+		for (int64_t k = k0; k < k1; ++k) {
+			uint32_t ll, lr;
+			if (lb == 2) { uint16_t v[2]; memcpy(v, len + 4 * k, 4); ll = v[0]; lr = v[1]; } else { uint32_t v[2]; memcpy(v, len + 8 * k, 8); ll = v[0]; lr = v[1]; }
+			uint32_t nc1;
+			if (nb == 1) nc1 = ncg[k]; else { uint16_t v; memcpy(&v, ncg + 2 * k, 2); nc1 = v; }
+			if (!second) {
+				while (ri + 1 < n_runs && runs[ri + 1].first <= k) ++ri;
+				T.x_tid[(size_t)k] = runs[ri].tid; T.x_side[(size_t)k] = runs[ri].side;
+				uint32_t s1;
+				if (sb == 2) { uint16_t v; memcpy(&v, sup + 2 * k, 2); s1 = v; } else memcpy(&s1, sup + 4 * k, 4);
+				T.x_support[(size_t)k] = (int32_t)s1; T.x_ll[(size_t)k] = (int32_t)ll; T.x_lr[(size_t)k] = (int32_t)lr; T.x_qmiss[(size_t)k] = fl[k] & 1; T.x_ncig[(size_t)k] = (int32_t)nc1;
+			} else { T.x_stroff[(size_t)k] = so; T.x_cigoff[(size_t)k] = co; }
+			so += table3_block_bytes((uint64_t)ll + lr, bb, qb); co += nc1;
+		}
+		if (!second) { part_str[(size_t)w + 1] = so; part_cig[(size_t)w + 1] = co; }
+	};
+	for (int second = 0; second < 2; ++second) {
+		std::vector<std::thread> th;
+		for (int w = 1; w < nt; ++w) th.emplace_back(pass, w, second != 0);
+		pass(0, second != 0);
+		for (auto &x : th) x.join();
+		if (!second) for (int w = 0; w < nt; ++w) { part_str[(size_t)w + 1] += part_str[(size_t)w]; part_cig[(size_t)w + 1] += part_cig[(size_t)w]; }
+	}
+	if (part_str[(size_t)nt] != T.str_bytes || part_cig[(size_t)nt] != T.cig_ops) { c->err = "compact table: the rebuilt offsets do not add up to the blob sizes"; return SSV_E_HIP; }
+	T.expanded = true;
+	table_expanded_view(T, t);
+	return SSV_OK;
+}
+
+uint64_t ssv_table_block_bytes3(int64_t n_bases, int32_t base_bits, int32_t qual_bits) { return table3_block_bytes((uint64_t)n_bases, base_bits, qual_bits); }
 
 int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
 {

@@ -1,0 +1,327 @@
+// table3_kernels.h - the compact cluster table (ssv_clip_table_format 3): what crosses PCIe at the end of getclip, cut to what the host
+// cannot rebuild.  The reference holds this state in two multimaps of strings (clip_reads.cpp:57-108, 260-283) and prints it
+// (clip_reads.h:300-345); here it is, per cluster:
+//   fixed columns   pos i32 | left_len, right_len (u16 or u32 each) | support (u16 or u32) | n_cigar (u8 or u16) | flags u8  = 12 bytes
+//                   (contig and side come from a handful of (contig, side, first cluster) runs; string / CIGAR offsets are prefix sums)
+//   CIGAR           n_cigar operations
+//   string block    [base stream | quality stream], each a whole number of dwords: the n = left_len + right_len bases of seq_left + seq_right
+//                   at base_bits (2: index into "ACGT"; 4: BAM's code) each, base i at stream bits [i * base_bits, +base_bits) (bit b of a
+//                   stream = bit b % 32 of dword b / 32), then the n qualities at qual_bits each the same way (8: characters, phred + 33)
+//   exceptions      with 2-bit bases, every base that is not A/C/G/T: (cluster, base index, BAM code) - the stream holds 0 there
+// A single-event cluster (97 % of a WGS sample) is a contiguous piece of its read: n nibbles from nibble `begin` of the packed bases and n
+// bytes from quality `begin`.  No piece of the block starts inside a dword, so every lane composes whole output dwords straight from the
+// staged read: no second staging, no byte merging - half the instructions of the four-piece layout of formats 1 and 2, and 60 % of the bytes.
+#pragma once
+
+#include "clip_kernels.h"
+
+namespace ssv {
+
+struct TableRun {
+	int32_t tid;
+	uint8_t side, pad[3];
+	int64_t first; // dense index of the run's first cluster
+};
+static_assert(sizeof(TableRun) == 16, "ssv_table_run");
+
+struct Pack3Args {
+	int32_t *pos;
+	void *len;                // [n][2] u16 or u32
+	void *support;            // [n] u16 or u32
+	void *ncig;               // [n] u8 or u16
+	uint8_t *flags;           // [n] bit 0: the reference prints "*" for the qualities
+	int len_bytes, support_bytes, ncig_bytes, base_bits;
+	TableRun *runs;
+	unsigned int *run_count;
+	uint64_t *exc;            // cluster << 28 | base index << 4 | code
+	unsigned int *exc_count;
+	uint32_t exc_cap;
+	int *support_miss;        // a support count that does not fit support_bytes
+	int *exc_miss;            // more exceptions than exc_cap (or a base index / cluster index beyond the entry's fields)
+};
+
+__host__ __device__ __forceinline__ uint64_t table3_block_bytes(uint64_t n, int base_bits, int qual_bits)
+{
+	return 4ull * ((n * (uint64_t)base_bits + 31) / 32 + (n * (uint64_t)qual_bits + 31) / 32);
+}
+
+// one thread per sorted slot: the row's fixed columns, its CIGAR, the descriptor for the string kernels, and the (contig, side) runs
+__global__ __launch_bounds__(BLOCK) void k_cluster_cols3(PackArgs p, Pack3Args q, PackDesc *__restrict__ desc, uint32_t *__restrict__ out_cig)
+{
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= p.c.E) return;
+	const uint64_t key = p.c.skey[j];
+	if (j == 0 || (p.c.skey[j - 1] >> 32) != (key >> 32)) { // first slot of a (contig, side): the next cluster at or after it starts the run
+		TableRun r;
+		r.tid = (int32_t)(key >> 33); r.side = ((key >> 32) & 1ull) ? '3' : '5'; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+		r.first = (int64_t)(uint32_t)p.slot_cnt[j];
+		q.runs[atomicAdd(q.run_count, 1u)] = r; // (a few per contig; the host orders them by `first`)
+	}
+	const SlotCluster s = slot_cluster_load(p, j);
+	if (!s.cluster) return;
+	const uint32_t c = s.c;
+	q.pos[c] = (int32_t)(uint32_t)s.key;
+	if (q.len_bytes == 2) reinterpret_cast<uint32_t *>(q.len)[c] = (uint32_t)s.ll | ((uint32_t)s.lr << 16);
+	else reinterpret_cast<uint2 *>(q.len)[c] = make_uint2((uint32_t)s.ll, (uint32_t)s.lr);
+	if (q.support_bytes == 2) {
+		if (s.support > 0xffff) *q.support_miss = 1;
+		reinterpret_cast<uint16_t *>(q.support)[c] = (uint16_t)s.support;
+	} else reinterpret_cast<uint32_t *>(q.support)[c] = (uint32_t)s.support;
+	if (q.ncig_bytes == 1) reinterpret_cast<uint8_t *>(q.ncig)[c] = (uint8_t)s.ncg;
+	else reinterpret_cast<uint16_t *>(q.ncig)[c] = (uint16_t)s.ncg;
+	if (!s.single) q.flags[c] = s.qmiss_multi ? 1 : 0;
+	uint32_t *dc = out_cig + s.cig_off;
+	if (s.ncg <= 5) {
+		if (s.ncg > 0) dc[0] = s.cg0;
+		if (s.ncg > 1) dc[1] = s.cg1;
+		if (s.ncg > 2) dc[2] = s.cg2;
+		if (s.ncg > 3) dc[3] = s.cg3;
+		if (s.ncg > 4) dc[4] = s.cg4;
+	} else {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>((uintptr_t)s.cig_ptr);
+		for (int i = 0; i < s.ncg; ++i) dc[i] = src[i];
+	}
+	uint4 *dd = reinterpret_cast<uint4 *>(desc + c);
+	dd[0] = make_uint4((uint32_t)s.src, (uint32_t)(s.src >> 32), (uint32_t)s.str_off, (uint32_t)(s.str_off >> 32));
+	dd[1] = make_uint4((uint32_t)s.lq, (uint32_t)s.ll, (uint32_t)s.lr, s.single ? (uint32_t)s.begin : (uint32_t)j);
+}
+
+__device__ __forceinline__ void exc_append(const Pack3Args &q, uint64_t cluster, int base, uint32_t code)
+{
+	if (base >= (1 << 24) || cluster >= (1ull << 36)) { *q.exc_miss = 1; return; }
+	const uint32_t k = atomicAdd(q.exc_count, 1u);
+	if (k < q.exc_cap) q.exc[k] = (cluster << 28) | ((uint64_t)(uint32_t)base << 4) | (uint64_t)code;
+	else *q.exc_miss = 1;
+}
+
+// eight BAM codes (nibble k of w = base k) -> eight 2-bit indices into "ACGT" (bits [2k, 2k + 2) of the result); A = 1, C = 2, G = 4, T = 8
+__device__ __forceinline__ uint32_t acgt2(uint32_t w)
+{
+	const uint32_t b0 = ((w >> 1) | (w >> 3)) & 0x11111111u; // C or T
+	const uint32_t b1 = ((w >> 2) | (w >> 3)) & 0x11111111u; // G or T
+	uint32_t x = b0 | (b1 << 1);
+	x = (x | (x >> 2)) & 0x0f0f0f0fu;
+	x = (x | (x >> 4)) & 0x00ff00ffu;
+	return (x | (x >> 8)) & 0xffffu;
+}
+
+// nibbles of w (under `valid`, a mask of whole nibbles) that are not exactly one of A, C, G, T
+__device__ __forceinline__ bool not_acgt(uint32_t w, uint32_t valid)
+{
+	const uint32_t M = 0x11111111u;
+	const uint32_t s = (w & M) + ((w >> 1) & M) + ((w >> 2) & M) + ((w >> 3) & M); // bits set per nibble (<= 4: no carries)
+	return s != (valid & M);
+}
+
+// the rare dword with something else in it: base by base (the stream gets 0 for such a base, the exception list says what it was)
+__device__ __forceinline__ uint32_t acgt2_slow(const Pack3Args &q, uint64_t cluster, int base0, uint32_t w, int count)
+{
+	uint32_t out = 0;
+	for (int k = 0; k < count; ++k) {
+		const uint32_t n = (w >> (4 * k)) & 15u;
+		if (n == 1u || n == 2u || n == 4u || n == 8u) out |= (uint32_t)(__ffs((int)n) - 1) << (2 * k);
+		else exc_append(q, cluster, base0 + k, n);
+	}
+	return out;
+}
+
+__device__ __forceinline__ uint32_t swap_nibbles(uint32_t x) { return ((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu); }
+
+// 16 lanes per cluster, four clusters per wavefront.  Single-event clusters of reads up to PACK_MAX_LQ bases: the read's entry (packed bases,
+// qualities) goes into LDS from the dword-aligned address below it, then every lane composes output dwords:
+//   base dword t   = bases [16 t, 16 t + 16) (BB = 2; 8 t .. for BB = 4) = a 9-byte window of the packed bases, nibbles swapped into stream order
+//                    and shifted by the odd nibble, then eight codes -> 16 bits twice
+//   quality dword t = stream bits [32 t, 32 t + 32) of the W-bit alphabet indices = up to 12 source bytes through the look-up table
+// and stores them: the block is its own staging.  TRACK: also note every phred value met (the second launch after a quality outside the guessed
+// alphabet turned up).
+template <int W, int BB, bool TRACK>
+__global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str)
+{
+	__shared__ uint32_t s_raw[GROUPS_PER_BLOCK][PACK_RAW_DWORDS];
+	__shared__ uint8_t s_lut[256]; // phred -> alphabet index
+	__shared__ uint32_t s_seen[8];  // phred values met (bit set)
+	if (W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256
+	if (threadIdx.x < 8) s_seen[threadIdx.x] = 0;
+	const int grp = (int)(threadIdx.x / GROUP);
+	const int gl = (int)(threadIdx.x % GROUP);
+	const int64_t nc = (int64_t)*n_clusters_dev;
+	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const uint32_t *s4 = s_raw[grp];
+	const PackDescR d0 = pack_desc_load(desc, c, nc);
+	const bool fast = pack_desc_fast(d0);
+	{
+		uint32_t r[PACK_RAW_PER_LANE];
+		pack_entry_load(d0, gl, r);
+		const int mis0 = (int)(d0.src & 3ull);
+		const int nraw = fast ? (mis0 + (d0.lq + 1) / 2 + d0.lq + 3) / 4 + 1 : 0;
+#pragma unroll
+		for (int u = 0; u < PACK_RAW_PER_LANE; ++u) { const int i = gl + GROUP * u; if (i < nraw && i < PACK_RAW_DWORDS) s_raw[grp][i] = r[u]; }
+	}
+	__syncthreads(); // s_raw, s_lut, s_seen
+	if (fast) {
+		const int n = d0.ll + d0.lr, lq = d0.lq, begin = d0.begin;
+		const int mis = (int)(d0.src & 3ull);     // the entry starts mis bytes into s_raw
+		const int qb = mis + (lq + 1) / 2;        // first quality byte of the entry inside s_raw
+		const bool qmiss = lq > 0 && ((s4[qb >> 2] >> (8 * (qb & 3))) & 0xffu) == 0xffu;
+		if (gl == 0) q.flags[c] = qmiss ? 1 : 0;
+		constexpr int PER = 32 / BB; // bases per dword
+		const int nDb = (n * BB + 31) / 32;
+		const int nDq = (n * W + 31) / 32;
+		uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
+		for (int t = gl; t < nDb; t += GROUP) {
+			const int nb0 = begin + PER * t;                  // first nibble of the read
+			const int B = mis + (nb0 >> 1);
+			const uint32_t *w = s4 + (B >> 2);
+			const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];     // (s_raw holds one dword of read-ahead; beyond it stale LDS, masked below)
+			const uint32_t sh = (uint32_t)(B & 3);
+			uint32_t lo = swap_nibbles(__builtin_amdgcn_alignbyte(w1, w0, sh));
+			uint32_t hi = swap_nibbles(__builtin_amdgcn_alignbyte(w2, w1, sh));
+			if (nb0 & 1) {
+				const uint32_t ex = BB == 2 ? (w2 >> (8 * sh)) >> 4 : 0u; // high nibble of byte B + 8 (sh <= 3: still inside w2)
+				lo = __builtin_amdgcn_alignbit(hi, lo, 4);
+				hi = (hi >> 4) | (ex << 28);
+			}
+			const int rem = n - PER * t; // bases of the stream from this dword on
+			if (BB == 4) {
+				if (rem < 8) lo &= (1u << (4 * rem)) - 1u;
+				d[t] = lo;
+			} else {
+				const uint32_t vlo = rem >= 8 ? 0xffffffffu : (1u << (4 * rem)) - 1u;
+				const uint32_t vhi = rem >= 16 ? 0xffffffffu : rem > 8 ? (1u << (4 * (rem - 8))) - 1u : 0u;
+				lo &= vlo; hi &= vhi;
+				uint32_t a = acgt2(lo), b = acgt2(hi);
+				if (not_acgt(lo, vlo)) a = acgt2_slow(q, (uint64_t)c, PER * t, lo, rem < 8 ? rem : 8);
+				if (not_acgt(hi, vhi)) b = acgt2_slow(q, (uint64_t)c, PER * t + 8, hi, rem < 16 ? rem - 8 : 8);
+				d[t] = a | (b << 16);
+			}
+		}
+		uint32_t seen_lo = 0, seen_hi = 0; // TRACK: phred 0..63 as a bit set in registers (anything higher goes straight to LDS)
+		uint32_t miss = 0;                 // OR of the table look-ups: 0xff marks a value outside the alphabet
+		for (int t = gl; t < nDq; t += GROUP) {
+			constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
+			const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
+			const int a = qb + begin + i0;                         // first source byte
+			const uint32_t *q4 = s4 + (a >> 2);
+			const int sh = a & 3;
+			const int rem = n - i0;                                // qualities of the stream from i0 on
+			uint64_t acc = 0;
+			uint32_t prev = q4[0];
+#pragma unroll
+			for (int g = 0; g < (CNT + 3) / 4; ++g) {
+				if (4 * g >= rem) break; // nothing of the stream left (also keeps the reads inside the staged entry)
+				const uint32_t next = q4[g + 1];
+				const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
+				prev = next;
+				if (W == 8) acc = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
+				else {
+#pragma unroll
+					for (int b = 0; b < 4; ++b) {
+						const int jq = 4 * g + b;
+						const uint32_t ph = (four >> (8 * b)) & 0xffu;
+						const uint32_t idx = s_lut[ph];
+						const bool ok = jq < CNT && jq < rem;
+						acc |= ok ? (uint64_t)(idx & ((1u << W) - 1u)) << (jq * W) : 0ull;
+						miss |= ok ? idx : 0u;
+						if (TRACK && ok) { if (ph < 32) seen_lo |= 1u << ph; else if (ph < 64) seen_hi |= 1u << (ph - 32); else atomicOr(&s_seen[ph >> 5], 1u << (ph & 31)); }
+					}
+				}
+			}
+			uint32_t v = qmiss && W < 8 ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
+			if (W == 8 && rem < 4) v &= (1u << (8 * rem)) - 1u;
+			d[nDb + t] = v;
+		}
+		if (W < 8 && !qmiss) {
+			if (miss & 0x80u) *p.lut_miss = 1;
+			if (TRACK) {
+				if (seen_lo) atomicOr(&s_seen[0], seen_lo);
+				if (seen_hi) atomicOr(&s_seen[1], seen_hi);
+			}
+		}
+	}
+	if (!TRACK || W == 8) return;
+	__syncthreads();
+	if (threadIdx.x < 8 && s_seen[threadIdx.x]) { // one look per workgroup; an atomic only while the set still grows
+		const uint32_t have = __atomic_load_n(&p.qual_seen[threadIdx.x], __ATOMIC_RELAXED);
+		if (s_seen[threadIdx.x] & ~have) atomicOr(&p.qual_seen[threadIdx.x], s_seen[threadIdx.x]);
+	}
+}
+
+// The base-by-base path: the slots of multi-event bins (mlist; those without a cluster leave at once: consensus storage, left part kept
+// reversed), then the listed single-event clusters of reads longer than PACK_MAX_LQ.
+template <int W, int BB, bool TRACK>
+__global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, uint8_t *__restrict__ out_str)
+{
+	__shared__ uint8_t s_lut[256];  // phred -> alphabet index
+	__shared__ uint8_t s_code[256]; // character -> 4-bit code
+	__shared__ uint32_t s_seen[8];  // phred values met (bit set)
+	if (W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256
+	s_code[threadIdx.x] = NT16_CODE_OF[threadIdx.x];
+	if (threadIdx.x < 8) s_seen[threadIdx.x] = 0;
+	__syncthreads();
+	const int grp = (int)(threadIdx.x / GROUP);
+	const int gl = (int)(threadIdx.x % GROUP);
+	const int64_t k_ = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const int64_t n_items = p.c.M + (int64_t)*p.slow_count;
+	if (k_ >= n_items) return;
+	const int64_t j = k_ < p.c.M ? (int64_t)p.c.mlist[k_] : (int64_t)p.slow_list[k_ - p.c.M];
+	if (p.c.support[j] <= 0) return; // five of six slots of multi-event bins hold no cluster
+	const SlotCluster sc = slot_cluster_load(p, j);
+	const int ll = sc.ll, lr = sc.lr, lq = sc.lq, begin = sc.begin, n = ll + lr;
+	const bool single = lq >= 0;
+	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + sc.str_off);
+	const uint8_t *sp = nullptr, *qp = nullptr, *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+	bool qm;
+	if (single) {
+		sp = reinterpret_cast<const uint8_t *>((uintptr_t)sc.src); qp = sp + (lq + 1) / 2;
+		qm = lq > 0 && qp[0] == 0xff;
+		if (gl == 0) q.flags[sc.c] = qm ? 1 : 0;
+	} else {
+		const int64_t stride = 2ll * (p.c.SL + p.c.SR);
+		cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
+		cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
+		qm = sc.qmiss_multi != 0;
+	}
+	auto code_at = [&](int i) -> uint32_t { // BAM code of base i of seq_left + seq_right
+		if (single) { const int pn = begin + i; return (uint32_t)(sp[pn >> 1] >> ((~pn & 1) << 2)) & 15u; }
+		return s_code[i < ll ? cs[ll - 1 - i] : rs[i - ll]];
+	};
+	auto phred_at = [&](int i) -> uint32_t {
+		if (single) return qp[begin + i];
+		return ((uint32_t)(i < ll ? cq[ll - 1 - i] : rq[i - ll]) - 33u) & 255u;
+	};
+	constexpr int PER = 32 / BB;
+	const int nDb = (n * BB + 31) / 32, nDq = (n * W + 31) / 32;
+	for (int t = gl; t < nDb; t += GROUP) {
+		uint32_t word = 0;
+		for (int k = 0; k < PER && PER * t + k < n; ++k) {
+			const uint32_t code = code_at(PER * t + k);
+			if (BB == 4) word |= code << (4 * k);
+			else if (code == 1u || code == 2u || code == 4u || code == 8u) word |= (uint32_t)(__ffs((int)code) - 1) << (2 * k);
+			else exc_append(q, (uint64_t)sc.c, PER * t + k, code);
+		}
+		d[t] = word;
+	}
+	for (int t = gl; t < nDq; t += GROUP) {
+		uint32_t word = 0;
+		if (W == 8) {
+			for (int k = 0; k < 4 && 4 * t + k < n; ++k) word |= (qm ? 0x2au : phred_at(4 * t + k) + 33u) << (8 * k);
+		} else if (!qm) {
+			const int i0 = (32 * t) / W, off = 32 * t - W * i0;
+			uint64_t acc = 0;
+			for (int jq = 0, i = i0; W * jq < off + 32 && i < n; ++jq, ++i) {
+				const uint32_t ph = phred_at(i);
+				if (TRACK) {
+					const uint32_t bit = 1u << (ph & 31);
+					if (!(atomicOr(&s_seen[ph >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph >> 5], bit); // the first time this workgroup meets the value
+				}
+				const uint32_t idx = s_lut[ph];
+				if (idx & 0x80u) *p.lut_miss = 1;
+				acc |= (uint64_t)(idx & ((1u << W) - 1u)) << (W * jq);
+			}
+			word = (uint32_t)(acc >> off);
+		}
+		d[nDb + t] = word;
+	}
+}
+
+} // namespace ssv

@@ -139,6 +139,11 @@ class Context:
         self._check(fn(self._h, C.byref(t)), "ssv_clip_table_wait")
         return table_to_dict(t) if as_dict else t
 
+    def clip_table_expand(self, t, n_threads=0):
+        """format 3: rebuild the columns that did not cross PCIe (ssv_clip_table_expand) - sets t's pointers"""
+        self._check(self._lib.ssv_clip_table_expand(self._h, C.byref(t), int(n_threads)), "ssv_clip_table_expand")
+        return t
+
     def getclip(self, batches, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
         """InputBamOutputReads' record loop over a list of batches -> cluster table dict."""
         self.clip_begin(match_rate, min_mapq, save_low_quality, own, initial_last_tid)

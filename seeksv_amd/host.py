@@ -236,6 +236,8 @@ def table_to_dict(t):
     packed = int(getattr(t, "seq_packed", 0))
     qbits = int(getattr(t, "qual_bits", 8)) if packed else 8
     d = dict(n_clusters=n, n_events=t.n_events, seq_packed=packed, qual_bits=qbits, qual_alphabet=bytes(getattr(t, "qual_alphabet", b"")))
+    if int(getattr(t, "format", 0)) == 3:
+        return _compact_to_dict(t, d)
     for name, dt in (("tid", np.int32), ("pos", np.int32), ("side", np.uint8), ("support", np.int32), ("left_len", np.int32),
                      ("right_len", np.int32), ("qual_missing", np.uint8), ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
         d[name] = arr(getattr(t, name), n, dt)
@@ -246,6 +248,44 @@ def table_to_dict(t):
         sb = cb = 0
     d["str"] = arr(t.str, sb, np.uint8)
     d["cigar"] = arr(t.cigar, cb, np.uint32)
+    return d
+
+
+def _compact_to_dict(t, d):
+    """the compact table (ssv_clip_table_format 3, include/seeksv_hip.h): the columns that did not cross PCIe are rebuilt here with numpy - the
+    same arithmetic as ssv_clip_table_expand, written independently (the tests hold the two against each other)"""
+    import ctypes as C
+    from . import _abi
+    n = t.n_clusters
+    bb, qb = int(t.base_bits), d["qual_bits"]
+    d.update(format=3, base_bits=bb, len_bytes=int(t.len_bytes), support_bytes=int(t.support_bytes), ncig_bytes=int(t.ncig_bytes))
+
+    def raw(ptr, nbytes, dt):
+        if nbytes == 0 or not ptr:
+            return np.zeros(0, dtype=dt)
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value), dtype=dt).copy()
+    ln = raw(t.c_len, n * 2 * t.len_bytes, np.uint16 if t.len_bytes == 2 else np.uint32).reshape(n, 2).astype(np.int32)
+    d["left_len"], d["right_len"] = np.ascontiguousarray(ln[:, 0]), np.ascontiguousarray(ln[:, 1])
+    d["support"] = raw(t.c_support, n * t.support_bytes, np.uint16 if t.support_bytes == 2 else np.uint32).astype(np.int32)
+    d["n_cigar"] = raw(t.c_ncig, n * t.ncig_bytes, np.uint8 if t.ncig_bytes == 1 else np.uint16).astype(np.int32)
+    d["qual_missing"] = raw(t.c_flags, n, np.uint8) & 1
+    d["pos"] = raw(t.pos, n * 4, np.int32)
+    runs = raw(t.runs, t.n_runs * _abi.TABLE_RUN_DTYPE.itemsize, _abi.TABLE_RUN_DTYPE)
+    d["runs"] = runs
+    counts = np.diff(np.append(runs["first"], n)) if len(runs) else np.zeros(0, np.int64)
+    assert (counts > 0).all() and int(counts.sum()) == n and (len(runs) == 0 or runs["first"][0] == 0)
+    d["tid"] = np.repeat(runs["tid"], counts).astype(np.int32)
+    d["side"] = np.repeat(runs["side"], counts).astype(np.uint8)
+    nn = (d["left_len"] + d["right_len"]).astype(np.int64)
+    blk = 4 * ((nn * bb + 31) // 32 + (nn * qb + 31) // 32)
+    d["str_off"] = (np.cumsum(blk) - blk).astype(np.uint64)
+    nc = d["n_cigar"].astype(np.int64)
+    d["cigar_off"] = (np.cumsum(nc) - nc).astype(np.uint64)
+    sb, cb = int(blk.sum()), int(nc.sum())
+    assert sb == t.str_bytes and cb == t.cigar_ops
+    d["str"] = raw(t.str, sb, np.uint8)
+    d["cigar"] = raw(t.cigar, cb * 4, np.uint32)
+    d["base_exc"] = raw(t.base_exc, t.n_base_exc * 8, np.uint64)
     return d
 
 
@@ -262,7 +302,25 @@ def cluster_strings(d, k):
     """(seq_left, qual_left, seq_right, qual_right, cigar_text) of cluster k."""
     o, ll, lr = int(d["str_off"][k]), int(d["left_len"][k]), int(d["right_len"][k])
     s = d["str"]
-    if d.get("seq_packed"):
+    if d.get("format") == 3:
+        n, bb, w = ll + lr, int(d["base_bits"]), int(d["qual_bits"])
+        nb, nq = 4 * ((n * bb + 31) // 32), 4 * ((n * w + 31) // 32)
+        alphabet = d.get("qual_alphabet", b"")
+
+        def field(buf, i, width):  # stream bits [i * width, +width); bit b = bit b % 8 of byte b / 8
+            b = (i * width) >> 3
+            word = int(buf[b]) | ((int(buf[b + 1]) << 8) if b + 1 < len(buf) else 0)
+            return (word >> ((i * width) & 7)) & ((1 << width) - 1)
+        bs, qs = s[o:o + nb], s[o + nb:o + nb + nq]
+        seq = ["ACGT"[field(bs, i, 2)] if bb == 2 else NT16[field(bs, i, 4)] for i in range(n)]
+        if bb == 2 and len(d["base_exc"]):
+            e = d["base_exc"]
+            for x in e[np.searchsorted(e >> np.uint64(28), np.uint64(k), "left"):np.searchsorted(e >> np.uint64(28), np.uint64(k), "right")]:
+                seq[(int(x) >> 4) & 0xFFFFFF] = NT16[int(x) & 15]
+        seq = "".join(seq)
+        q = qs[:n].tobytes().decode("latin-1") if w == 8 else "".join(chr(alphabet[field(qs, i, w)]) for i in range(n))
+        sl, sr, ql, qr = seq[:ll], seq[ll:], q[:ll], q[ll:]
+    elif d.get("seq_packed"):
         a, c, w = (ll + 1) // 2, (lr + 1) // 2, int(d.get("qual_bits", 8))
         qa, qc = (ll * w + 7) // 8, (lr * w + 7) // 8
         alphabet = d.get("qual_alphabet", b"")

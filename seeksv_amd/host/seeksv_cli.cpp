@@ -342,6 +342,9 @@ static int device_of_rank(int r, const vector<int> &devices)
 // ---------------------------------------------------------------------------------------------------------------------
 
 // DisplaySClipReadsAndClipFq (clip_reads.h:300-345) for the clusters [k0, k1) of a table: their clip.gz rows and clip.fq records
+// SSV_TABLE_FORMAT=0..3 picks another wire format for the cluster table (the text written is the same)
+static int table_format_default() { const char *e = getenv("SSV_TABLE_FORMAT"); return e ? atoi(e) : 3; }
+
 static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k0, int64_t k1, string &row, string &fq)
 {
 		row.reserve(row.size() + (size_t)(k1 - k0) * 480); fq.reserve(fq.size() + (size_t)(k1 - k0) * 200);
@@ -352,7 +355,26 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 			const uint8_t *s = t.str + t.str_off[k];
 			const size_t ll = (size_t)t.left_len[k], lr = (size_t)t.right_len[k];
 			const char *sl, *ql, *sr, *qr;
-			if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right], qualities possibly as alphabet indices
+			if (t.format == 3) { // compact: [base stream | quality stream] over seq_left + seq_right, whole 32-bit words each (seeksv_hip.h)
+				const size_t n = ll + lr, W = (size_t)t.qual_bits, BBITS = (size_t)t.base_bits;
+				const uint8_t *bs = s, *qs = s + 4 * ((n * BBITS + 31) / 32);
+				seqbuf.resize(2 * n);
+				if (BBITS == 2) {
+					for (size_t i = 0; i < n; ++i) seqbuf[i] = "ACGT"[(bs[i >> 2] >> ((i & 3) << 1)) & 3];
+					// the bases that are not A/C/G/T (sorted list; cluster << 28 | base index << 4 | code)
+					const uint64_t *e0 = t.base_exc, *e1 = t.base_exc + t.n_base_exc;
+					for (const uint64_t *e = std::lower_bound(e0, e1, (uint64_t)k << 28); e < e1 && (*e >> 28) == (uint64_t)k; ++e) seqbuf[(size_t)((*e >> 4) & 0xffffff)] = "=ACMGRSVTWYHKDBN"[*e & 15];
+				} else for (size_t i = 0; i < n; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(bs[i >> 1] >> ((i & 1) << 2)) & 15];
+				sl = seqbuf.data(); sr = seqbuf.data() + ll;
+				if (W == 8) { ql = (const char *)qs; qr = ql + ll; }
+				else {
+					const unsigned mask = (1u << W) - 1u;
+					char *dq = &seqbuf[n];
+					const size_t qbytes = 4 * ((n * W + 31) / 32);
+					for (size_t i = 0; i < n; ++i) { const size_t b = (i * W) >> 3; dq[i] = (char)t.qual_alphabet[((qs[b] | (b + 1 < qbytes ? (unsigned)qs[b + 1] << 8 : 0u)) >> ((i * W) & 7)) & mask]; }
+					ql = dq; qr = dq + ll;
+				}
+			} else if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right], qualities possibly as alphabet indices
 				const size_t W = (size_t)t.qual_bits, a = (ll + 1) / 2, c2 = (lr + 1) / 2, qa = (ll * W + 7) / 8;
 				seqbuf.resize(2 * (ll + lr));
 				for (size_t i = 0; i < ll; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((~i & 1) << 2)) & 15];
@@ -435,7 +457,7 @@ static int cmd_getclip(int argc, char **argv)
 	memset(&p, 0, sizeof(p));
 	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
 	if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-	ssv_clip_table_format(ctx, 2); // sequences as 4-bit codes, qualities as alphabet indices over PCIe; expanded by the formatting threads below
+	ssv_clip_table_format(ctx, table_format_default()); // the compact table over PCIe; expanded by the formatting threads below
 	BatchSource src;
 	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 	ssvh_bam *bam = src.bam;
@@ -473,6 +495,7 @@ static int cmd_getclip(int argc, char **argv)
 
 	ssv_cluster_table t;
 	if (ssv_clip_cluster(ctx, &t) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+	if (t.format == 3 && ssv_clip_table_expand(ctx, &t, 0) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 	pt.lap("gpu_cluster+table");
 	// DisplaySClipReadsAndClipFq ('5' rows then '3' rows per contig run), clip_reads.h:300-345.  The rows of one cluster depend on nothing
 	// else, so cluster ranges are formatted by several host threads and written out in order.
@@ -553,7 +576,7 @@ static int getclip_ranks(const string &bamfile, const string &prefix, double thr
 		if (r + 1 < n_ranks) { p.own_hi_tid = parts[(size_t)r + 1].own_tid; p.own_hi_pos = parts[(size_t)r + 1].own_tid < n_targets ? parts[(size_t)r + 1].own_pos + 1 : 0; }
 		else { p.own_hi_tid = INT32_MAX; p.own_hi_pos = 0; }
 		if (ssv_clip_begin(ctx, &p) != SSV_OK) { out.err = string("[seeksv] ") + ssv_last_error(ctx); ssv_ctx_destroy(ctx); return; }
-		ssv_clip_table_format(ctx, 2);
+		ssv_clip_table_format(ctx, table_format_default());
 		ssvh_bam *rb = nullptr;
 		if (ssvh_bam_open(bamfile.c_str(), &rb) != 0) { out.err = "[main_samview] fail to open file for reading."; ssv_ctx_destroy(ctx); return; }
 		use_pinned_batches(rb);
@@ -577,6 +600,7 @@ static int getclip_ranks(const string &bamfile, const string &prefix, double thr
 		}
 		ssv_cluster_table t;
 		if (out.err.empty() && ssv_clip_cluster(ctx, &t) != SSV_OK) out.err = string("[seeksv] ") + ssv_last_error(ctx);
+		if (out.err.empty() && t.format == 3 && ssv_clip_table_expand(ctx, &t, 2) != SSV_OK) out.err = string("[seeksv] ") + ssv_last_error(ctx);
 		if (out.err.empty()) {
 			for (int64_t k0 = 0; k0 < t.n_clusters;) { // the table is in (contig, side, position) order
 				int64_t k1 = k0;

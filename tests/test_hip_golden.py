@@ -8,7 +8,7 @@ import pytest
 
 import golden_util as G
 import oracle_lib as O
-from seeksv_amd import host
+from seeksv_amd import _abi, host
 from test_oracle_golden import GETCLIP_CASES, GETSV_CASES
 
 pytestmark = pytest.mark.gpu
@@ -65,6 +65,150 @@ def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw, fmt):
         assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))
     clip, fq = host.format_clip_outputs(d, names)
     assert clip == G.read_text(sub, prefix + ".clip.txt") and fq == G.read_text(sub, prefix + ".clip.fq.txt")
+
+
+def _compact_checks(ctx, d, ref, t):
+    """a format-3 table against the ASCII table of the same input: every rebuilt column, every decoded string, the C-side rebuild
+    (ssv_clip_table_expand) against the numpy one, and the size of what crossed PCIe"""
+    assert d["format"] == 3 and d["n_clusters"] == ref["n_clusters"] and d["n_events"] == ref["n_events"]
+    for k in ("tid", "pos", "side", "support", "left_len", "right_len", "qual_missing", "cigar_off", "n_cigar", "cigar"):
+        assert np.array_equal(d[k], ref[k]), k
+    assert all(host.cluster_strings(d, k) == host.cluster_strings(ref, k) for k in range(d["n_clusters"]))
+    n = d["n_clusters"]
+    if n == 0:
+        return
+    ctx.clip_table_expand(t, 3)
+    for name, dt in (("tid", np.int32), ("side", np.uint8), ("support", np.int32), ("left_len", np.int32), ("right_len", np.int32), ("qual_missing", np.uint8),
+                     ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
+        assert np.array_equal(np.ctypeslib.as_array(getattr(t, name), shape=(n,)), d[name].astype(dt)), name
+    lib = _abi.hip_lib()
+    assert all(lib.ssv_table_block_bytes3(int(a) + int(b), d["base_bits"], d["qual_bits"]) ==
+               (int(d["str_off"][k + 1]) if k + 1 < n else len(d["str"])) - int(d["str_off"][k]) for k, (a, b) in enumerate(zip(d["left_len"], d["right_len"])))
+    wire = n * (4 + 2 * d["len_bytes"] + d["support_bytes"] + d["ncig_bytes"] + 1) + len(d["str"]) + 4 * len(d["cigar"]) + 16 * len(d["runs"]) + 8 * len(d["base_exc"])
+    wire_ascii = n * 42 + len(ref["str"]) + 4 * len(ref["cigar"])
+    assert wire < 0.45 * wire_ascii or n < 50
+
+
+@pytest.mark.parametrize("sub,bam,prefix,kw", GETCLIP_CASES, ids=[c[2] for c in GETCLIP_CASES])
+def test_getclip_compact_table_format(ctx, sub, bam, prefix, kw):
+    """ssv_clip_table_format 3, the compact table: 12 bytes of fixed columns per cluster, contig / side as runs, no offsets, one 2-bit base
+    stream and one quality stream per cluster, bases outside A/C/G/T as exceptions; rebuilt on the host it is the ASCII table (and the
+    reference's rows)"""
+    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, sub, bam), 1 << 20)
+    ref = ctx.getclip(batches, **kw)
+    ctx.clip_table_format(3)
+    try:
+        ctx.clip_begin(**kw)
+        for b in batches:
+            ctx.clip_scan(b)
+        t = ctx.clip_cluster(as_dict=False)
+        d = host.table_to_dict(t)
+        _compact_checks(ctx, d, ref, t)
+    finally:
+        ctx.clip_table_format(0)
+    clip, fq = host.format_clip_outputs(d, names)
+    assert clip == G.read_text(sub, prefix + ".clip.txt") and fq == G.read_text(sub, prefix + ".clip.fq.txt")
+
+
+def _with_bases(b, code_of):
+    """a copy of a host batch whose packed bases were rewritten: code_of(record, i, code) -> new 4-bit code"""
+    b = dict(b)
+    sq = b["seqqual"].copy()
+    for r in np.nonzero(b["seq_off"] != np.uint64(0xFFFFFFFFFFFFFFFF))[0]:
+        o, lq = int(b["seq_off"][r]), int(b["l_qseq"][r])
+        for i in range(lq):
+            sh = 0 if i & 1 else 4
+            c = (int(sq[o + (i >> 1)]) >> sh) & 15
+            sq[o + (i >> 1)] = (int(sq[o + (i >> 1)]) & ~(15 << sh)) | (code_of(int(r), i, c) << sh)
+    b["seqqual"] = sq
+    return b
+
+
+@pytest.mark.parametrize("source", ["stress1", "stress2", "filters", "synth150", "synth400"])
+@pytest.mark.parametrize("mode", ["acgt", "some_n", "iupac", "overflow"])
+def test_compact_table_bases(ctx, source, mode, monkeypatch):
+    """the 2-bit base streams: reads of only A/C/G/T (no exceptions), scattered N (exceptions), every IUPAC code and '=' (exceptions on nearly
+    every base), and more exceptions than the list takes (SSV_EXC_CAP: the pass falls back to 4-bit streams) - decoded == ASCII == oracle"""
+    if source.startswith("synth"):
+        from seeksv_amd import synth
+        w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, read_len=int(source[5:]))
+        batches = [w.generate_host(0, w.n_total)]
+    else:
+        batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", source + ".bam"))[2]
+    acgt = [1, 2, 4, 8]
+    f = {"acgt": lambda r, i, c: c if c in acgt else acgt[(r + i) & 3],
+         "some_n": lambda r, i, c: 15 if (r * 31 + i * 7) % 23 == 0 else (c if c in acgt else acgt[(r + i) & 3]),
+         "iupac": lambda r, i, c: (r * 5 + i * 3) % 16,
+         "overflow": lambda r, i, c: 15 if (r + i) % 3 == 0 else (c if c in acgt else 1)}[mode]
+    batches = [_with_bases(b, f) for b in batches]
+    ref = ctx.getclip(batches)
+    assert_tables_equal(ref, O.getclip(batches))
+    if mode == "overflow":
+        monkeypatch.setenv("SSV_EXC_CAP", "64")
+    ctx.clip_table_format(3)
+    try:
+        ctx.clip_begin()
+        for b in batches:
+            ctx.clip_scan(b)
+        t = ctx.clip_cluster(as_dict=False)
+        d = host.table_to_dict(t)
+        _compact_checks(ctx, d, ref, t)
+    finally:
+        ctx.clip_table_format(0)
+    assert d["base_bits"] == (4 if mode == "overflow" else 2)
+    assert (len(d["base_exc"]) == 0) == (mode in ("acgt", "overflow"))
+    if mode == "iupac":
+        assert len(d["base_exc"]) > d["n_clusters"]
+
+
+@pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (4, 2), (5, 3), (8, 3), (16, 4), (17, 8)])
+@pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300", "synth400"])
+def test_compact_table_quality_alphabets(ctx, source, n_values, bits):
+    """format 3 with every quality index width, on deep bins (consensus storage), odd clip offsets, reads longer than the kernel's LDS-staged
+    limit, missing qualities"""
+    if source.startswith("synth"):
+        from seeksv_amd import synth
+        w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, read_len=int(source[5:]))
+        batches = [w.generate_host(0, w.n_total)]
+    else:
+        batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", source + ".bam"))[2]
+    alphabet = [(3 + 5 * k) % 94 for k in range(n_values)]
+    batches = [_remap_qualities(b, alphabet) for b in batches]
+    ref = ctx.getclip(batches)
+    ctx.clip_table_format(3)
+    try:
+        ctx.clip_begin()
+        for b in batches:
+            ctx.clip_scan(b)
+        t = ctx.clip_cluster(as_dict=False)
+        d = host.table_to_dict(t)
+        assert d["qual_bits"] == bits, (d["qual_bits"], bits)
+        _compact_checks(ctx, d, ref, t)
+    finally:
+        ctx.clip_table_format(0)
+
+
+def test_compact_table_wide_support(ctx):
+    """a bin with more than 65535 identical reads: the support column switches to 32 bits"""
+    n, lq = 70000, 50
+    packed = np.array([0x12, 0x48] * 12 + [0x12], np.uint8)   # ACGT x 12, AC
+    entry = np.concatenate([packed, np.full(lq, 30, np.uint8)])
+    b = dict(tid=np.zeros(n, np.int32), pos=np.full(n, 1000, np.int32), flag=np.full(n, 99, np.uint16), mapq=np.full(n, 60, np.uint8), n_cigar=np.full(n, 2, np.uint16),
+             l_qseq=np.full(n, lq, np.int32), mtid=np.zeros(n, np.int32), mpos=np.full(n, 1200, np.int32), isize=np.full(n, 250, np.int32), xc=np.zeros(n, np.uint8),
+             cigar=np.tile(np.array([(20 << 4) | 4, (30 << 4) | 0], np.uint32), n), cigar_off=(2 * np.arange(n)).astype(np.uint32),
+             seq_off=(np.arange(n) * len(entry)).astype(np.uint64), seqqual=np.concatenate([np.tile(entry, n), np.zeros(16, np.uint8)]), max_ref_span=30)
+    ref = ctx.getclip([b])
+    assert ref["support"].max() == 70000
+    ctx.clip_table_format(3)
+    try:
+        ctx.clip_begin()
+        ctx.clip_scan(b)
+        t = ctx.clip_cluster(as_dict=False)
+        d = host.table_to_dict(t)
+        assert d["support_bytes"] == 4
+        _compact_checks(ctx, d, ref, t)
+    finally:
+        ctx.clip_table_format(0)
 
 
 @pytest.mark.parametrize("sample", ["cancer", "normal"])

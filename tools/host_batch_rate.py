@@ -65,7 +65,6 @@ def main():
     hb.pop("rec", None)
     n = w.n_total
     cuts = list(range(0, n, a.batch)) + [n]
-    per_record = sum(v.nbytes for k, v in hb.items() if isinstance(v, np.ndarray)) / n
 
     def cut(i0, i1):
         out = {}
@@ -76,13 +75,28 @@ def main():
                 c0, c1 = int(hb["cigar_off"][i0]), (int(hb["cigar_off"][i1]) if i1 < n else len(v))
                 out[k] = v[c0:c1]
             elif k == "seqqual":
-                out[k] = v
+                continue
             else:
                 out[k] = v[i0:i1]
-        if "cigar" in out:
-            out["cigar_off"] = out["cigar_off"] - np.uint32(int(hb["cigar_off"][i0]))
+        out["cigar_off"] = out["cigar_off"] - np.uint32(int(hb["cigar_off"][i0]))
+        # the bases / qualities of the cut's clipped records (offsets grow with the record index)
+        so = out["seq_off"]
+        have = np.nonzero(so != NO_SEQ)[0]
+        if len(have):
+            s0 = int(so[have[0]])
+            later = np.nonzero(hb["seq_off"][i1:] != NO_SEQ)[0]
+            s1 = int(hb["seq_off"][i1 + later[0]]) if len(later) else len(hb["seqqual"])
+            out["seqqual"] = hb["seqqual"][s0:s1]
+            out["seq_off"] = np.where(so != NO_SEQ, so - np.uint64(s0), so)
+            out["seqqual_bytes"] = s1 - s0
+        else:
+            out["seqqual"] = hb["seqqual"][:0]
+            out["seqqual_bytes"] = 0
+        out["n_cigar_total"] = len(out["cigar"])
         return out
+    NO_SEQ = np.uint64(0xFFFFFFFFFFFFFFFF)
     parts = [cut(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+    per_record = sum(v.nbytes for p in parts for k, v in p.items() if isinstance(v, np.ndarray)) / n
     res = {"records": n, "batches": len(parts), "host_bytes_per_record": round(per_record, 1)}
 
     def run(batches, prefetch, scan):
