@@ -137,12 +137,12 @@ def main():
         t = ctx.clip_table_wait(prev=prev)
         n = t.n_clusters
         if t.format == 3:
-            ctx.clip_table_expand(t, 16)
+            ctx.clip_table_expand(t, 0)
             state["table_bytes"] = n * (4 + 2 * t.len_bytes + t.support_bytes + t.ncig_bytes + 1) + t.str_bytes + 4 * t.cigar_ops + 16 * t.n_runs + 8 * t.n_base_exc
         else:
             state["table_bytes"] = n * 42 + t.str_bytes + 4 * t.cigar_ops
         state["table_info"] = dict(format=int(t.format), qual_bits=int(t.qual_bits), base_bits=int(t.base_bits), base_exceptions=int(t.n_base_exc))
-        ssum = int(np.ctypeslib.as_array(t.support, shape=(n,)).sum()) if n else 0
+        ssum = int(t.support_sum) if t.format == 3 else (int(np.ctypeslib.as_array(t.support, shape=(n,)).sum()) if n else 0)
         assert ssum == t.n_events, "clip events were lost or duplicated"
         assert bool(t.seq_packed) == (not args.ascii_table)
         state["support_sum"] = ssum
@@ -416,7 +416,7 @@ def file_path_leg(ctx, args, device):
             nc, ne = ctx.clip_cluster_async()
             tab = ctx.clip_table_wait()
             if tab.format == 3:
-                ctx.clip_table_expand(tab, 16)
+                ctx.clip_table_expand(tab, 0)
             ssum = int(np.ctypeslib.as_array(tab.support, shape=(tab.n_clusters,)).sum()) if tab.n_clusters else 0
             assert ssum == tab.n_events == ne and n == w.n_total
             t["getclip_s"] = time.perf_counter() - t0

@@ -231,6 +231,7 @@ typedef struct {
 	int64_t n_base_exc;
 	uint64_t str_bytes;        /* bytes of str / operations of cigar (all formats) */
 	uint64_t cigar_ops;
+	int64_t support_sum;       /* format 3, after ssv_clip_table_expand: sum of the support column (= n_events: every clip event is in one cluster) */
 } ssv_cluster_table;
 
 /* Table format of the following ssv_clip_cluster[_async] calls: 0 ASCII (default), 1 sequences as 4-bit codes, 2 the same plus

@@ -108,6 +108,7 @@ struct ssv_ctx {
 		int format = 0, base_bits = 4, len_bytes = 4, support_bytes = 4, ncig_bytes = 4;
 		int64_t n_runs = 0, n_exc = 0;
 		uint64_t str_bytes = 0, cig_ops = 0;
+		int64_t support_sum = 0;
 		// the columns ssv_clip_table_expand rebuilds on the host
 		std::vector<int32_t> x_tid, x_support, x_ll, x_lr, x_ncig;
 		std::vector<uint8_t> x_side, x_qmiss;
@@ -1004,7 +1005,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 			std::sort(e, e + T.n_exc);
 			T.ordered = true;
 		}
-		if (T.expanded) table_expanded_view(T, out);
+		if (T.expanded) { table_expanded_view(T, out); out->support_sum = T.support_sum; }
 		return SSV_OK;
 	}
 	out->str_bytes = T.str_bytes; out->cigar_ops = T.cig_ops;
@@ -1022,6 +1023,40 @@ static void table_expanded_view(ssv_ctx::TableSet &T, ssv_cluster_table *out)
 	out->qual_missing = T.x_qmiss.data(); out->n_cigar = T.x_ncig.data(); out->str_off = T.x_stroff.data(); out->cigar_off = T.x_cigoff.data();
 }
 
+} // extern "C"
+
+// one range of clusters: the widened columns (pass 1, also the range's string bytes / CIGAR operations / support sum), then the offsets (pass 2)
+template <class LenT, class SupT, class NcT>
+static void expand_range(ssv_ctx::TableSet &T, int64_t k0, int64_t k1, bool second, uint64_t &so, uint64_t &co, int64_t &ssum)
+{
+	const LenT *len = reinterpret_cast<const LenT *>(T.h_len.p);
+	const SupT *sup = reinterpret_cast<const SupT *>(T.h_sup.p);
+	const NcT *ncg = reinterpret_cast<const NcT *>(T.h_nc.p);
+	const uint8_t *fl = P<uint8_t>(T.h_qmiss);
+	const uint64_t bb = (uint64_t)T.base_bits, qb = (uint64_t)T.qual_bits;
+	int32_t *x_ll = T.x_ll.data(), *x_lr = T.x_lr.data(), *x_sup = T.x_support.data(), *x_nc = T.x_ncig.data();
+	uint8_t *x_qm = T.x_qmiss.data();
+	uint64_t *x_so = T.x_stroff.data(), *x_co = T.x_cigoff.data();
+	if (!second) {
+		int64_t sum = 0;
+		for (int64_t k = k0; k < k1; ++k) {
+			const uint32_t ll = len[2 * k], lr = len[2 * k + 1], nc1 = ncg[k], s1 = sup[k];
+			x_ll[k] = (int32_t)ll; x_lr[k] = (int32_t)lr; x_sup[k] = (int32_t)s1; x_nc[k] = (int32_t)nc1; x_qm[k] = fl[k] & 1;
+			const uint64_t n = (uint64_t)ll + lr;
+			so += 4ull * ((n * bb + 31) / 32 + (n * qb + 31) / 32); co += nc1; sum += s1;
+		}
+		ssum = sum;
+		return;
+	}
+	for (int64_t k = k0; k < k1; ++k) {
+		x_so[k] = so; x_co[k] = co;
+		const uint64_t n = (uint64_t)(uint32_t)x_ll[k] + (uint32_t)x_lr[k];
+		so += 4ull * ((n * bb + 31) / 32 + (n * qb + 31) / 32); co += (uint32_t)x_nc[k];
+	}
+}
+
+extern "C" {
+
 int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
 {
 	if (!c || !t) return SSV_E_ARG;
@@ -1030,52 +1065,56 @@ int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
 	if (t->format != 3 || !Tp) { c->err = "ssv_clip_table_expand takes a compact (format 3) table handed out by ssv_clip_table_wait"; return SSV_E_ARG; }
 	ssv_ctx::TableSet &T = *Tp;
 	const int64_t n = T.n_clusters;
-	if (n == 0 || T.expanded) { if (n) table_expanded_view(T, t); return SSV_OK; }
+	if (n == 0 || T.expanded) { if (n) table_expanded_view(T, t); t->support_sum = T.support_sum; return SSV_OK; }
 	T.x_tid.resize((size_t)n); T.x_side.resize((size_t)n); T.x_support.resize((size_t)n); T.x_ll.resize((size_t)n); T.x_lr.resize((size_t)n); T.x_qmiss.resize((size_t)n);
 	T.x_ncig.resize((size_t)n); T.x_stroff.resize((size_t)n); T.x_cigoff.resize((size_t)n);
-	const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(n_threads > 0 ? n_threads : (int32_t)std::thread::hardware_concurrency()), 64, n / 65536 + 1}));
+	const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(n_threads > 0 ? n_threads : (int32_t)std::thread::hardware_concurrency()), 64, n / 32768 + 1}));
 	const ssv_table_run *runs = reinterpret_cast<const ssv_table_run *>(T.h_runs.p);
 	const int64_t n_runs = T.n_runs;
-	const int lb = T.len_bytes, sb = T.support_bytes, nb = T.ncig_bytes, bb = T.base_bits, qb = T.qual_bits;
-	const uint8_t *len = P<uint8_t>(T.h_len), *sup = P<uint8_t>(T.h_sup), *ncg = P<uint8_t>(T.h_nc), *fl = P<uint8_t>(T.h_qmiss);
 	std::vector<uint64_t> part_str((size_t)nt + 1, 0), part_cig((size_t)nt + 1, 0);
-	auto range = [&](int w, int64_t &k0, int64_t &k1) { k0 = n * w / nt; k1 = n * (w + 1) / nt; };
-	// pass 1: the widened columns and each range's string bytes / CIGAR operations; pass 2: the offsets
-	auto pass = [&](int w, bool second) {
-		int64_t k0, k1; range(w, k0, k1);
-		uint64_t so = second ? part_str[(size_t)w] : 0, co = second ? part_cig[(size_t)w] : 0;
-		int64_t ri = 0;
-		if (!second) { // the run that holds k0
+	std::vector<int64_t> part_sup((size_t)nt, 0);
+	// the workers run pass 1, meet, and run pass 2 (worker 0 turns the per-range sums into starting offsets in between)
+	std::mutex mu; std::condition_variable cv; int arrived = 0; bool go = false;
+	auto work = [&](int w) {
+		const int64_t k0 = n * w / nt, k1 = n * (w + 1) / nt;
+		for (int second = 0; second < 2; ++second) {
+			uint64_t so = second ? part_str[(size_t)w] : 0, co = second ? part_cig[(size_t)w] : 0;
+			int64_t ssum = 0;
+			if (T.len_bytes == 2) {
+				if (T.support_bytes == 2) { if (T.ncig_bytes == 1) expand_range<uint16_t, uint16_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint16_t, uint16_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+				else { if (T.ncig_bytes == 1) expand_range<uint16_t, uint32_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint16_t, uint32_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+			} else {
+				if (T.support_bytes == 2) { if (T.ncig_bytes == 1) expand_range<uint32_t, uint16_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint32_t, uint16_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+				else { if (T.ncig_bytes == 1) expand_range<uint32_t, uint32_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint32_t, uint32_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+			}
+			if (second) break;
+			part_str[(size_t)w + 1] = so; part_cig[(size_t)w + 1] = co; part_sup[(size_t)w] = ssum;
+			// contig / side of the range: whole runs at a time
 			int64_t lo = 0, hi = n_runs;
 			while (hi - lo > 1) { const int64_t m = (lo + hi) / 2; if (runs[m].first <= k0) lo = m; else hi = m; }
-			ri = lo;
+			for (int64_t r = lo; r < n_runs && runs[r].first < k1; ++r) {
+				const int64_t a = std::max(k0, runs[r].first), b = std::min(k1, r + 1 < n_runs ? runs[r + 1].first : n);
+				if (b > a) { std::fill(T.x_tid.begin() + a, T.x_tid.begin() + b, runs[r].tid); std::fill(T.x_side.begin() + a, T.x_side.begin() + b, runs[r].side); }
+			}
+			std::unique_lock<std::mutex> lk(mu);
+			if (++arrived == nt) {
+				for (int v = 0; v < nt; ++v) { part_str[(size_t)v + 1] += part_str[(size_t)v]; part_cig[(size_t)v + 1] += part_cig[(size_t)v]; }
+				go = true; cv.notify_all();
+			} else cv.wait(lk, [&] { return go; });
 		}
-		for (int64_t k = k0; k < k1; ++k) {
-			uint32_t ll, lr;
-			if (lb == 2) { uint16_t v[2]; memcpy(v, len + 4 * k, 4); ll = v[0]; lr = v[1]; } else { uint32_t v[2]; memcpy(v, len + 8 * k, 8); ll = v[0]; lr = v[1]; }
-			uint32_t nc1;
-			if (nb == 1) nc1 = ncg[k]; else { uint16_t v; memcpy(&v, ncg + 2 * k, 2); nc1 = v; }
-			if (!second) {
-				while (ri + 1 < n_runs && runs[ri + 1].first <= k) ++ri;
-				T.x_tid[(size_t)k] = runs[ri].tid; T.x_side[(size_t)k] = runs[ri].side;
-				uint32_t s1;
-				if (sb == 2) { uint16_t v; memcpy(&v, sup + 2 * k, 2); s1 = v; } else memcpy(&s1, sup + 4 * k, 4);
-				T.x_support[(size_t)k] = (int32_t)s1; T.x_ll[(size_t)k] = (int32_t)ll; T.x_lr[(size_t)k] = (int32_t)lr; T.x_qmiss[(size_t)k] = fl[k] & 1; T.x_ncig[(size_t)k] = (int32_t)nc1;
-			} else { T.x_stroff[(size_t)k] = so; T.x_cigoff[(size_t)k] = co; }
-			so += table3_block_bytes((uint64_t)ll + lr, bb, qb); co += nc1;
-		}
-		if (!second) { part_str[(size_t)w + 1] = so; part_cig[(size_t)w + 1] = co; }
 	};
-	for (int second = 0; second < 2; ++second) {
+	{
 		std::vector<std::thread> th;
-		for (int w = 1; w < nt; ++w) th.emplace_back(pass, w, second != 0);
-		pass(0, second != 0);
+		for (int w = 1; w < nt; ++w) th.emplace_back(work, w);
+		work(0);
 		for (auto &x : th) x.join();
-		if (!second) for (int w = 0; w < nt; ++w) { part_str[(size_t)w + 1] += part_str[(size_t)w]; part_cig[(size_t)w + 1] += part_cig[(size_t)w]; }
 	}
 	if (part_str[(size_t)nt] != T.str_bytes || part_cig[(size_t)nt] != T.cig_ops) { c->err = "compact table: the rebuilt offsets do not add up to the blob sizes"; return SSV_E_HIP; }
+	T.support_sum = 0;
+	for (int64_t v : part_sup) T.support_sum += v;
 	T.expanded = true;
 	table_expanded_view(T, t);
+	t->support_sum = T.support_sum;
 	return SSV_OK;
 }
 

@@ -86,7 +86,8 @@ def _compact_checks(ctx, d, ref, t):
                (int(d["str_off"][k + 1]) if k + 1 < n else len(d["str"])) - int(d["str_off"][k]) for k, (a, b) in enumerate(zip(d["left_len"], d["right_len"])))
     wire = n * (4 + 2 * d["len_bytes"] + d["support_bytes"] + d["ncig_bytes"] + 1) + len(d["str"]) + 4 * len(d["cigar"]) + 16 * len(d["runs"]) + 8 * len(d["base_exc"])
     wire_ascii = n * 42 + len(ref["str"]) + 4 * len(ref["cigar"])
-    assert wire < 0.45 * wire_ascii or n < 50
+    assert wire < 0.7 * wire_ascii or n < 50
+    assert t.support_sum == d["n_events"] == int(d["support"].sum())
 
 
 @pytest.mark.parametrize("sub,bam,prefix,kw", GETCLIP_CASES, ids=[c[2] for c in GETCLIP_CASES])
