@@ -134,10 +134,14 @@ def main():
     state = {"pending": False, "support_sum": 0, "tables": 0}
 
     def collect_table(prev):
+        tw = time.perf_counter()
         t = ctx.clip_table_wait(prev=prev)
         n = t.n_clusters
         if t.format == 3:
+            te = time.perf_counter()
             ctx.clip_table_expand(t, 0)
+            state.setdefault("expand_ms", []).append((time.perf_counter() - te) * 1e3)
+            state.setdefault("wait_ms", []).append((te - tw) * 1e3)
             state["table_bytes"] = n * (4 + 2 * t.len_bytes + t.support_bytes + t.ncig_bytes + 1) + t.str_bytes + 4 * t.cigar_ops + 16 * t.n_runs + 8 * t.n_base_exc
         else:
             state["table_bytes"] = n * 42 + t.str_bytes + 4 * t.cigar_ops
@@ -317,7 +321,7 @@ def main():
             "wall_ms_one_step": {k: round(v, 3) for k, v in wall.items()},
             "wall_ms_timed_steps": step_walls,
             "result": res,
-            "table": dict(state.get("table_info", {}), bytes=int(state.get("table_bytes", 0)), bytes_per_cluster=round(state.get("table_bytes", 0) / max(1, res["n_clusters"]), 1),
+            "table": dict(state.get("table_info", {}), host_expand_ms=[round(x, 2) for x in state.get("expand_ms", [])[-6:]], wait_ms=[round(x, 2) for x in state.get("wait_ms", [])[-6:]], bytes=int(state.get("table_bytes", 0)), bytes_per_cluster=round(state.get("table_bytes", 0) / max(1, res["n_clusters"]), 1),
                           note="what crosses PCIe per step; format 3: contig / side / offsets are rebuilt on the host inside the step (ssv_clip_table_expand)"),
         }
         if world == 1 and args.file_frac > 0:

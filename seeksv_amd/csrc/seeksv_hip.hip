@@ -15,6 +15,7 @@
 #include <string>
 #include <thread>
 #include <deque>
+#include <functional>
 #include <vector>
 
 #include "bamdec_kernels.h"
@@ -61,6 +62,55 @@ struct ProfRec {
 };
 
 } // namespace
+
+// A few host threads that stay around (the compact table's columns are rebuilt on them once per table: starting 64 threads costs more than
+// the work they do).  run(n, fn) calls fn(0..n-1), fn(0) on the caller's thread, and returns when all are done.
+struct HostPool {
+	std::vector<std::thread> th;
+	std::mutex mu;
+	std::condition_variable cv_go, cv_done;
+	const std::function<void(int)> *fn = nullptr;
+	uint64_t generation = 0;
+	int n_jobs = 0, n_left = 0;
+	bool quit = false;
+	void worker(int id)
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			const std::function<void(int)> *f;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv_go.wait(lk, [&] { return quit || generation != seen; });
+				if (quit) return;
+				seen = generation;
+				if (id >= n_jobs) continue;
+				f = fn;
+			}
+			(*f)(id);
+			std::unique_lock<std::mutex> lk(mu);
+			if (--n_left == 0) cv_done.notify_all();
+		}
+	}
+	void run(int n, const std::function<void(int)> &f)
+	{
+		if (n <= 1) { f(0); return; }
+		while ((int)th.size() < n - 1) { const int id = (int)th.size() + 1; th.emplace_back([this, id] { worker(id); }); }
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			fn = &f; n_jobs = n; n_left = n - 1; ++generation;
+		}
+		cv_go.notify_all();
+		f(0);
+		std::unique_lock<std::mutex> lk(mu);
+		cv_done.wait(lk, [&] { return n_left == 0; });
+	}
+	~HostPool()
+	{
+		{ std::unique_lock<std::mutex> lk(mu); quit = true; }
+		cv_go.notify_all();
+		for (auto &t : th) t.join();
+	}
+};
 
 struct ssv_ctx {
 	int device = 0;
@@ -120,6 +170,7 @@ struct ssv_ctx {
 		int packed = 0, qual_bits = 8;
 		uint8_t qual_alphabet[16] = {0};
 	} tab[2];
+	HostPool pool;
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
 	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices, 3 compact
 	DBuf qual_lut, qual_seen; HBuf h_qual_lut;
@@ -1073,42 +1124,31 @@ int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
 	const int64_t n_runs = T.n_runs;
 	std::vector<uint64_t> part_str((size_t)nt + 1, 0), part_cig((size_t)nt + 1, 0);
 	std::vector<int64_t> part_sup((size_t)nt, 0);
-	// the workers run pass 1, meet, and run pass 2 (worker 0 turns the per-range sums into starting offsets in between)
-	std::mutex mu; std::condition_variable cv; int arrived = 0; bool go = false;
-	auto work = [&](int w) {
+	// pass 1 (widened columns, per-range sums, contig / side), the ranges' starting offsets, pass 2 (offsets)
+	auto pass = [&](int w, int second) {
 		const int64_t k0 = n * w / nt, k1 = n * (w + 1) / nt;
-		for (int second = 0; second < 2; ++second) {
-			uint64_t so = second ? part_str[(size_t)w] : 0, co = second ? part_cig[(size_t)w] : 0;
-			int64_t ssum = 0;
-			if (T.len_bytes == 2) {
-				if (T.support_bytes == 2) { if (T.ncig_bytes == 1) expand_range<uint16_t, uint16_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint16_t, uint16_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
-				else { if (T.ncig_bytes == 1) expand_range<uint16_t, uint32_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint16_t, uint32_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
-			} else {
-				if (T.support_bytes == 2) { if (T.ncig_bytes == 1) expand_range<uint32_t, uint16_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint32_t, uint16_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
-				else { if (T.ncig_bytes == 1) expand_range<uint32_t, uint32_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint32_t, uint32_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
-			}
-			if (second) break;
-			part_str[(size_t)w + 1] = so; part_cig[(size_t)w + 1] = co; part_sup[(size_t)w] = ssum;
-			// contig / side of the range: whole runs at a time
-			int64_t lo = 0, hi = n_runs;
-			while (hi - lo > 1) { const int64_t m = (lo + hi) / 2; if (runs[m].first <= k0) lo = m; else hi = m; }
-			for (int64_t r = lo; r < n_runs && runs[r].first < k1; ++r) {
-				const int64_t a = std::max(k0, runs[r].first), b = std::min(k1, r + 1 < n_runs ? runs[r + 1].first : n);
-				if (b > a) { std::fill(T.x_tid.begin() + a, T.x_tid.begin() + b, runs[r].tid); std::fill(T.x_side.begin() + a, T.x_side.begin() + b, runs[r].side); }
-			}
-			std::unique_lock<std::mutex> lk(mu);
-			if (++arrived == nt) {
-				for (int v = 0; v < nt; ++v) { part_str[(size_t)v + 1] += part_str[(size_t)v]; part_cig[(size_t)v + 1] += part_cig[(size_t)v]; }
-				go = true; cv.notify_all();
-			} else cv.wait(lk, [&] { return go; });
+		uint64_t so = second ? part_str[(size_t)w] : 0, co = second ? part_cig[(size_t)w] : 0;
+		int64_t ssum = 0;
+		if (T.len_bytes == 2) {
+			if (T.support_bytes == 2) { if (T.ncig_bytes == 1) expand_range<uint16_t, uint16_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint16_t, uint16_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+			else { if (T.ncig_bytes == 1) expand_range<uint16_t, uint32_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint16_t, uint32_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+		} else {
+			if (T.support_bytes == 2) { if (T.ncig_bytes == 1) expand_range<uint32_t, uint16_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint32_t, uint16_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+			else { if (T.ncig_bytes == 1) expand_range<uint32_t, uint32_t, uint8_t>(T, k0, k1, second, so, co, ssum); else expand_range<uint32_t, uint32_t, uint16_t>(T, k0, k1, second, so, co, ssum); }
+		}
+		if (second) return;
+		part_str[(size_t)w + 1] = so; part_cig[(size_t)w + 1] = co; part_sup[(size_t)w] = ssum;
+		// contig / side of the range: whole runs at a time
+		int64_t lo = 0, hi = n_runs;
+		while (hi - lo > 1) { const int64_t m = (lo + hi) / 2; if (runs[m].first <= k0) lo = m; else hi = m; }
+		for (int64_t r = lo; r < n_runs && runs[r].first < k1; ++r) {
+			const int64_t a = std::max(k0, runs[r].first), b = std::min(k1, r + 1 < n_runs ? runs[r + 1].first : n);
+			if (b > a) { std::fill(T.x_tid.begin() + a, T.x_tid.begin() + b, runs[r].tid); std::fill(T.x_side.begin() + a, T.x_side.begin() + b, runs[r].side); }
 		}
 	};
-	{
-		std::vector<std::thread> th;
-		for (int w = 1; w < nt; ++w) th.emplace_back(work, w);
-		work(0);
-		for (auto &x : th) x.join();
-	}
+	c->pool.run(nt, [&](int w) { pass(w, 0); });
+	for (int v = 0; v < nt; ++v) { part_str[(size_t)v + 1] += part_str[(size_t)v]; part_cig[(size_t)v + 1] += part_cig[(size_t)v]; }
+	c->pool.run(nt, [&](int w) { pass(w, 1); });
 	if (part_str[(size_t)nt] != T.str_bytes || part_cig[(size_t)nt] != T.cig_ops) { c->err = "compact table: the rebuilt offsets do not add up to the blob sizes"; return SSV_E_HIP; }
 	T.support_sum = 0;
 	for (int64_t v : part_sup) T.support_sum += v;

@@ -67,7 +67,7 @@ def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw, fmt):
     assert clip == G.read_text(sub, prefix + ".clip.txt") and fq == G.read_text(sub, prefix + ".clip.fq.txt")
 
 
-def _compact_checks(ctx, d, ref, t):
+def _compact_checks(ctx, d, ref, t, check_size=True):
     """a format-3 table against the ASCII table of the same input: every rebuilt column, every decoded string, the C-side rebuild
     (ssv_clip_table_expand) against the numpy one, and the size of what crossed PCIe"""
     assert d["format"] == 3 and d["n_clusters"] == ref["n_clusters"] and d["n_events"] == ref["n_events"]
@@ -86,7 +86,7 @@ def _compact_checks(ctx, d, ref, t):
                (int(d["str_off"][k + 1]) if k + 1 < n else len(d["str"])) - int(d["str_off"][k]) for k, (a, b) in enumerate(zip(d["left_len"], d["right_len"])))
     wire = n * (4 + 2 * d["len_bytes"] + d["support_bytes"] + d["ncig_bytes"] + 1) + len(d["str"]) + 4 * len(d["cigar"]) + 16 * len(d["runs"]) + 8 * len(d["base_exc"])
     wire_ascii = n * 42 + len(ref["str"]) + 4 * len(ref["cigar"])
-    assert wire < 0.7 * wire_ascii or n < 50
+    assert wire < 0.7 * wire_ascii or n < 50 or not check_size
     assert t.support_sum == d["n_events"] == int(d["support"].sum())
 
 
@@ -153,7 +153,7 @@ def test_compact_table_bases(ctx, source, mode, monkeypatch):
             ctx.clip_scan(b)
         t = ctx.clip_cluster(as_dict=False)
         d = host.table_to_dict(t)
-        _compact_checks(ctx, d, ref, t)
+        _compact_checks(ctx, d, ref, t, check_size=mode != "iupac")   # (an exception costs 8 bytes: a small table of reads without A/C/G/T is bigger than ASCII)
     finally:
         ctx.clip_table_format(0)
     assert d["base_bits"] == (4 if mode == "overflow" else 2)
