@@ -156,10 +156,11 @@ def test_compact_table_bases(ctx, source, mode, monkeypatch):
         _compact_checks(ctx, d, ref, t, check_size=mode != "iupac")   # (an exception costs 8 bytes: a small table of reads without A/C/G/T is bigger than ASCII)
     finally:
         ctx.clip_table_format(0)
-    assert d["base_bits"] == (4 if mode == "overflow" else 2)
-    assert (len(d["base_exc"]) == 0) == (mode in ("acgt", "overflow"))
-    if mode == "iupac":
-        assert len(d["base_exc"]) > d["n_clusters"]
+    if mode == "iupac":   # nearly every base is an exception: a big enough sample overflows the list by itself
+        assert (d["base_bits"] == 2 and len(d["base_exc"]) > d["n_clusters"]) or (d["base_bits"] == 4 and len(d["base_exc"]) == 0)
+    else:
+        assert d["base_bits"] == (4 if mode == "overflow" else 2)
+        assert (len(d["base_exc"]) == 0) == (mode in ("acgt", "overflow"))
 
 
 @pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (4, 2), (5, 3), (8, 3), (16, 4), (17, 8)])
