@@ -173,7 +173,7 @@ struct ssv_ctx {
 	HostPool pool;
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
 	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices, 3 compact
-	DBuf qual_lut, qual_seen; HBuf h_qual_lut;
+	DBuf qual_lut, qual_seen, pair_lut; HBuf h_qual_lut, h_pair_lut;
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
 
@@ -501,12 +501,13 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	realign_free(c);
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
 	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
+	if (c->h_pair_lut.p) (void)hipHostFree(c->h_pair_lut.p);
 	// every DBuf / HBuf member
 	if (c->st_h2d) { (void)hipStreamSynchronize(c->st_h2d); (void)hipStreamDestroy(c->st_h2d); }
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage,
 	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_strings,
-	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
+	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->pair_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
 	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry,
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
@@ -746,6 +747,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	const ClipEvent *ev = P<ClipEvent>(c->ev);
 	CHECK(ensure(c, c->totals, 128)); CHECK(ensure_host(c, c->h_totals, 128));
 	CHECK(ensure(c, c->qual_seen, 32)); CHECK(ensure(c, c->qual_lut, 256)); CHECK(ensure_host(c, c->h_qual_lut, 256));
+	CHECK(ensure(c, c->pair_lut, 8192)); CHECK(ensure_host(c, c->h_pair_lut, 8192));
 	// ---- bin the events by (contig, side, position), BAM order inside a bin.  A coordinate-sorted BAM emits its '5' events in key order
 	//      already (key = start + 1): that is checked, not assumed; only the '3' events (key = start + reference span) need the sort, and
 	//      the two sorted lists interleave per contig.  Unsorted input takes the full sort. ----
@@ -899,6 +901,18 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			HIPCHECK(c, hipMemsetAsync(tot, 0, 64, c->st));
 			if (track) HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
 			if (T.packed && T.qual_bits < 8) HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, c->h_qual_lut.p, 256, hipMemcpyHostToDevice, c->st));
+			// format 3, the kernel without the LDS stage: two qualities per table look-up - for alphabets below phred 64 (every sequencer's)
+			bool direct = fmt3 && !track && !getenv("SSV_PACK3_STAGED");
+			if (direct && T.qual_bits < 8) {
+				const uint8_t *lut = P<uint8_t>(c->h_qual_lut);
+				for (int v = 64; v < 256; ++v) if (lut[v] != 0xff) direct = false;
+				if (direct) {
+					uint16_t *pl = P<uint16_t>(c->h_pair_lut);
+					for (int q1 = 0; q1 < 64; ++q1)
+						for (int q0 = 0; q0 < 64; ++q0) pl[q0 | (q1 << 6)] = lut[q0] == 0xff || lut[q1] == 0xff ? (uint16_t)0x8000 : (uint16_t)(lut[q0] | (lut[q1] << T.qual_bits));
+					HIPCHECK(c, hipMemcpyAsync(c->pair_lut.p, c->h_pair_lut.p, 8192, hipMemcpyHostToDevice, c->st));
+				}
+			}
 			k_cluster_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
 			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_cnt, pa.slot_cnt, E, 0ull, P<uint64_t>(c->scan_scratch64), tot);
 			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_bytes, pa.slot_bytes, E, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
@@ -911,7 +925,8 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			if (fmt3) {
 				// one group of lanes per cluster (the grid is an upper bound, the kernel reads the cluster count itself), then the base-by-base path
 				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
-#define SSV_P3B(W_, B_, T_) do { k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
+#define SSV_P3B(W_, B_, T_) do { if (direct) k_pack3_direct<W_, B_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
+			k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 #define SSV_P3T(W_, T_) do { if (T.base_bits == 2) SSV_P3B(W_, 2, T_); else SSV_P3B(W_, 4, T_); } while (0)
 #define SSV_P3(W_) do { if (track) SSV_P3T(W_, true); else SSV_P3T(W_, false); } while (0)
 				if (pa.qual_bits == 8) SSV_P3T(8, false); else if (pa.qual_bits == 4) SSV_P3(4); else if (pa.qual_bits == 3) SSV_P3(3); else if (pa.qual_bits == 2) SSV_P3(2); else SSV_P3(1);

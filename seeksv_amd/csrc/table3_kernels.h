@@ -137,7 +137,7 @@ __device__ __forceinline__ uint32_t swap_nibbles(uint32_t x) { return ((x & 0x0f
 template <int W, int BB, bool TRACK>
 __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str)
 {
-	__shared__ uint32_t s_raw[GROUPS_PER_BLOCK][PACK_RAW_DWORDS];
+	__shared__ uint32_t s_raw[GROUPS_PER_BLOCK][PACK_RAW_DWORDS + 12]; // (+ what the unconditional look-ahead of the last dwords can touch)
 	__shared__ uint8_t s_lut[256]; // phred -> alphabet index
 	__shared__ uint32_t s_seen[8];  // phred values met (bit set)
 	if (W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256
@@ -199,35 +199,36 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q,
 		uint32_t miss = 0;                 // OR of the table look-ups: 0xff marks a value outside the alphabet
 		for (int t = gl; t < nDq; t += GROUP) {
 			constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
+			constexpr int NSRC = (CNT + 3) / 4;                      // source dwords they lie in, once aligned
 			const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
 			const int a = qb + begin + i0;                         // first source byte
 			const uint32_t *q4 = s4 + (a >> 2);
-			const int sh = a & 3;
-			const int rem = n - i0;                                // qualities of the stream from i0 on
-			uint64_t acc = 0;
-			uint32_t prev = q4[0];
+			const uint32_t sh = (uint32_t)(a & 3);
+			const int rem = n - i0;                                // qualities of the stream from i0 on (>= 1)
+			// no branches: all CNT look-ups are made (what lies behind the stream's end is stale LDS inside the array) and the tail is masked off
+			uint32_t src[NSRC];
+			{
+				uint32_t prev = q4[0];
 #pragma unroll
-			for (int g = 0; g < (CNT + 3) / 4; ++g) {
-				if (4 * g >= rem) break; // nothing of the stream left (also keeps the reads inside the staged entry)
-				const uint32_t next = q4[g + 1];
-				const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
-				prev = next;
-				if (W == 8) acc = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
-				else {
-#pragma unroll
-					for (int b = 0; b < 4; ++b) {
-						const int jq = 4 * g + b;
-						const uint32_t ph = (four >> (8 * b)) & 0xffu;
-						const uint32_t idx = s_lut[ph];
-						const bool ok = jq < CNT && jq < rem;
-						acc |= ok ? (uint64_t)(idx & ((1u << W) - 1u)) << (jq * W) : 0ull;
-						miss |= ok ? idx : 0u;
-						if (TRACK && ok) { if (ph < 32) seen_lo |= 1u << ph; else if (ph < 64) seen_hi |= 1u << (ph - 32); else atomicOr(&s_seen[ph >> 5], 1u << (ph & 31)); }
-					}
-				}
+				for (int g = 0; g < NSRC; ++g) { const uint32_t next = q4[g + 1]; src[g] = __builtin_amdgcn_alignbyte(next, prev, sh); prev = next; }
 			}
-			uint32_t v = qmiss && W < 8 ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
-			if (W == 8 && rem < 4) v &= (1u << (8 * rem)) - 1u;
+			uint32_t v;
+			if (W == 8) {
+				v = qmiss ? 0x2a2a2a2au : src[0] + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
+				if (rem < 4) v &= (1u << (8 * rem)) - 1u;
+			} else {
+				uint64_t acc = 0;
+#pragma unroll
+				for (int jq = 0; jq < CNT; ++jq) {
+					const uint32_t ph = (src[jq >> 2] >> (8 * (jq & 3))) & 0xffu;
+					const uint32_t idx = s_lut[ph];
+					acc |= (uint64_t)(idx & ((1u << W) - 1u)) << (jq * W);
+					miss |= jq < rem ? idx : 0u;
+					if (TRACK && jq < rem) { if (ph < 32) seen_lo |= 1u << ph; else if (ph < 64) seen_hi |= 1u << (ph - 32); else atomicOr(&s_seen[ph >> 5], 1u << (ph & 31)); }
+				}
+				if (rem < CNT) acc &= (1ull << (W * rem)) - 1ull;
+				v = qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
+			}
 			d[nDb + t] = v;
 		}
 		if (W < 8 && !qmiss) {
@@ -244,6 +245,137 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q,
 		const uint32_t have = __atomic_load_n(&p.qual_seen[threadIdx.x], __ATOMIC_RELAXED);
 		if (s_seen[threadIdx.x] & ~have) atomicOr(&p.qual_seen[threadIdx.x], s_seen[threadIdx.x]);
 	}
+}
+
+// ---- the same blocks without the LDS stage: every lane reads the few source dwords of its output dwords itself ----
+//
+// k_pack3_stream above is bound by its vector instructions (eight wavefronts per SIMD, each ~400 instructions of 4 cycles; PMC: VALU busy, memory
+// idle).  Most of them shuffle bytes: stage the entry, pick bytes out of LDS dwords, one table look-up per quality, SWAR per 8 bases.  Here
+//   - a lane loads the 3 (bases) / up to 5 (qualities) aligned dwords its output dword is made of straight from the batch (the read's
+//     225 bytes are four lines in L1 for all 16 lanes), nothing is staged and no barrier is needed;
+//   - bases go through a 256-entry table: a BAM byte (two bases) -> their two 2-bit codes, bit 7 when one of them is not A/C/G/T;
+//   - qualities go through a 4096-entry table indexed by TWO phred values (6 bits each): both alphabet indices at once, bit 15 when
+//     one is outside the alphabet.  (A phred value >= 64 has no place in that table: the host then launches k_pack3_stream instead.)
+// Half the instructions per block.
+
+// pair table entry e = q0 | q1 << 6: index(q0) | index(q1) << W, or 0x8000
+__device__ __forceinline__ uint32_t pair_index(uint32_t halfword) { return (halfword & 0x3fu) | ((halfword >> 2) & 0xfc0u); }
+
+template <int W, int BB>
+__global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str,
+                                                        const uint16_t *__restrict__ pair_lut)
+{
+	__shared__ uint16_t s_pair[4096];
+	__shared__ uint8_t s_base[256];
+	if (W < 8) {
+		const uint4 *g = reinterpret_cast<const uint4 *>(pair_lut);
+		uint4 *l = reinterpret_cast<uint4 *>(s_pair);
+		l[threadIdx.x] = g[threadIdx.x]; l[threadIdx.x + BLOCK] = g[threadIdx.x + BLOCK]; // 8 KB = 512 x 16 B, BLOCK == 256
+	}
+	if (BB == 2) { // BAM byte -> code(high nibble) | code(low nibble) << 2, bit 7: not both of A, C, G, T
+		const uint32_t hi = threadIdx.x >> 4, lo = threadIdx.x & 15u;
+		const bool ok = __popc(hi) == 1 && __popc(lo) == 1;
+		s_base[threadIdx.x] = ok ? (uint8_t)((uint32_t)(__ffs((int)hi) - 1) | ((uint32_t)(__ffs((int)lo) - 1) << 2)) : (uint8_t)0x80;
+	}
+	__syncthreads();
+	const int grp = (int)(threadIdx.x / GROUP);
+	const int gl = (int)(threadIdx.x % GROUP);
+	const int64_t nc = (int64_t)*n_clusters_dev;
+	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const PackDescR d0 = pack_desc_load(desc, c, nc);
+	if (!pack_desc_fast(d0)) return;
+	const int n = d0.ll + d0.lr, lq = d0.lq, begin = d0.begin;
+	constexpr int PER = 32 / BB; // bases per dword
+	const int nDb = (n * BB + 31) / 32;
+	const int nDq = (n * W + 31) / 32;
+	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
+	for (int t = gl; t < nDb; t += GROUP) {
+		const int nb0 = begin + PER * t;                       // first nibble of the read
+		const uint64_t A = d0.src + (uint64_t)(nb0 >> 1);
+		const uint32_t *w = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
+		const uint32_t sh = (uint32_t)(A & 3ull);
+		const int rem = n - PER * t;                           // bases of the stream from this dword on
+		const int need = (int)sh + (((rem < PER ? rem : PER) + (nb0 & 1) + 1) >> 1); // bytes from w[0] on that hold them
+		const uint32_t w0 = w[0], w1 = need > 4 ? w[1] : 0u, w2 = need > 8 ? w[2] : 0u;
+		uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+		if (BB == 4) {
+			lo = swap_nibbles(lo);
+			if (nb0 & 1) lo = __builtin_amdgcn_alignbit(swap_nibbles(hi), lo, 4);
+			if (rem < 8) lo &= (1u << (4 * rem)) - 1u;
+			d[t] = lo;
+			continue;
+		}
+		if (nb0 & 1) { // pair the nibbles anew: byte k = low nibble of byte k, high nibble of byte k + 1
+			const uint32_t ex = (w2 >> (8 * sh)) & 0xffu;       // byte 8
+			const uint32_t lo12 = __builtin_amdgcn_alignbit(hi, lo, 12), hi12 = (hi >> 12) | (ex << 20);
+			lo = ((lo & 0x0f0f0f0fu) << 4) | (lo12 & 0x0f0f0f0fu);
+			hi = ((hi & 0x0f0f0f0fu) << 4) | (hi12 & 0x0f0f0f0fu);
+		}
+		if (rem < 16) { // behind the stream's end: make it 'A' (valid for the table), cut the result below
+			const int nb = (rem + 1) >> 1;                    // bytes that hold stream bases
+			const uint64_t keep = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1ull;
+			uint64_t Y = ((uint64_t)hi << 32) | lo;
+			Y = (Y & keep) | (0x1111111111111111ull & ~keep);
+			if (rem & 1) Y = (Y & ~(0x0full << (8 * (nb - 1)))) | (0x01ull << (8 * (nb - 1)));
+			lo = (uint32_t)Y; hi = (uint32_t)(Y >> 32);
+		}
+		uint32_t out = 0, inv = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t e0 = s_base[(lo >> (8 * k)) & 0xffu], e1 = s_base[(hi >> (8 * k)) & 0xffu];
+			out |= ((e0 & 15u) << (4 * k)) | ((e1 & 15u) << (4 * k + 16));
+			inv |= e0 | e1;
+		}
+		if (inv & 0x80u) { // something else than A/C/G/T among the 16: base by base (nibbles into stream order first)
+			const uint32_t slo = swap_nibbles(lo), shi = swap_nibbles(hi);
+			const uint32_t a = acgt2_slow(q, (uint64_t)c, PER * t, slo, rem < 8 ? rem : 8);
+			const uint32_t b = rem > 8 ? acgt2_slow(q, (uint64_t)c, PER * t + 8, shi, rem < 16 ? rem - 8 : 8) : 0u;
+			out = a | (b << 16);
+		} else if (rem < 16) out &= (1u << (2 * rem)) - 1u;
+		d[t] = out;
+	}
+	uint32_t miss = 0;
+	for (int t = gl; t < nDq; t += GROUP) {
+		constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
+		constexpr int NSRC = (CNT + 3) / 4;                      // source dwords they lie in, once aligned
+		const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
+		const uint64_t A = d0.src + (uint64_t)((lq + 1) / 2 + begin + i0); // first source byte
+		const uint32_t *q4 = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
+		const uint32_t sh = (uint32_t)(A & 3ull);
+		const int rem = n - i0;                                // qualities of the stream from i0 on (>= 1)
+		uint32_t raw[NSRC + 1];
+#pragma unroll
+		for (int g = 0; g <= NSRC; ++g) raw[g] = 4 * g < (int)sh + rem ? q4[g] : 0u; // (nothing is read beyond the dword that holds the stream's last byte)
+		uint32_t src[NSRC];
+#pragma unroll
+		for (int g = 0; g < NSRC; ++g) src[g] = __builtin_amdgcn_alignbyte(raw[g + 1], raw[g], sh);
+		const bool qmiss = (src[0] & 0xffu) == 0xffu; // a read without qualities has 0xff in all of them
+		const uint32_t fill = (src[0] & 0xffu) * 0x01010101u; // behind the stream's end: the first quality again (so that the pair table sees alphabet members only)
+		if (t == 0) q.flags[c] = qmiss ? 1 : 0;
+		uint32_t v;
+		if (W == 8) {
+			v = qmiss ? 0x2a2a2a2au : src[0] + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
+			if (rem < 4) v &= (1u << (8 * rem)) - 1u;
+		} else {
+			uint64_t acc = 0;
+			uint32_t bad = 0;
+#pragma unroll
+			for (int g = 0; g < NSRC; ++g) {
+				const uint32_t valid = rem >= 4 * g + 4 ? 0xffffffffu : rem > 4 * g ? (1u << (8 * (rem - 4 * g))) - 1u : 0u;
+				const uint32_t x = (src[g] & valid) | (fill & ~valid);
+				const uint32_t e0 = s_pair[pair_index(x)], e1 = s_pair[pair_index(x >> 16)];
+				acc |= (uint64_t)(e0 & 0xffu) << (4 * g * W);
+				acc |= (uint64_t)(e1 & 0xffu) << ((4 * g + 2) * W);
+				// the table knows nothing of phred >= 64, and says 0x8000 for a pair with a value outside the alphabet
+				bad |= (x & 0xc0c0c0c0u) | ((e0 | e1) & 0x8000u);
+			}
+			if (rem < CNT) acc &= (1ull << (W * rem)) - 1ull;
+			v = qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
+			miss |= qmiss ? 0u : bad;
+		}
+		d[nDb + t] = v;
+	}
+	if (W < 8 && miss) *p.lut_miss = 1;
 }
 
 // The base-by-base path: the slots of multi-event bins (mlist; those without a cluster leave at once: consensus storage, left part kept

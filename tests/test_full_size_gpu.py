@@ -20,7 +20,7 @@ MARGIN = 2000   # bp kept away from a slice's first / last record: reads outside
 def ctx():
     from seeksv_amd.device import Context
     c = Context(0)
-    c.clip_table_format(2)
+    c.clip_table_format(3)   # the bench's wire format
     yield c
     c.close()
 
@@ -40,7 +40,7 @@ def _sha(d):
     h = hashlib.sha256()
     for k in ("tid", "pos", "side", "support", "left_len", "right_len", "qual_missing", "str_off", "str", "cigar_off", "n_cigar", "cigar"):
         h.update(np.ascontiguousarray(d[k]).tobytes())
-    h.update(bytes([d["qual_bits"]]) + d["qual_alphabet"])
+    h.update(bytes([d["qual_bits"], d.get("base_bits", 4)]) + d["qual_alphabet"] + np.ascontiguousarray(d.get("base_exc", np.zeros(0, np.uint64))).tobytes())
     return h.hexdigest()
 
 
