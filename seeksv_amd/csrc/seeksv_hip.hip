@@ -925,7 +925,9 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			if (fmt3) {
 				// one group of lanes per cluster (the grid is an upper bound, the kernel reads the cluster count itself), then the base-by-base path
 				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
-#define SSV_P3B(W_, B_, T_) do { if (direct) k_pack3_direct<W_, B_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
+				static const unsigned p3_blocks = []() { const char *e = getenv("SSV_PACK3_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 10u; }(); // persistent: two rounds of what is resident at once (82 registers: five wavefronts per SIMD = five workgroups per CU); measured best
+				const dim3 gd((unsigned)std::max<int64_t>(1, std::min<int64_t>(p3_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)));
+#define SSV_P3B(W_, B_, T_) do { if (direct) k_pack3_direct<W_, B_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 #define SSV_P3T(W_, T_) do { if (T.base_bits == 2) SSV_P3B(W_, 2, T_); else SSV_P3B(W_, 4, T_); } while (0)
 #define SSV_P3(W_) do { if (track) SSV_P3T(W_, true); else SSV_P3T(W_, false); } while (0)

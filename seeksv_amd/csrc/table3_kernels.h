@@ -261,6 +261,128 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q,
 // pair table entry e = q0 | q1 << 6: index(q0) | index(q1) << W, or 0x8000
 __device__ __forceinline__ uint32_t pair_index(uint32_t halfword) { return (halfword & 0x3fu) | ((halfword >> 2) & 0xfc0u); }
 
+template <int W> struct Q3 {
+	static constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
+	static constexpr int NSRC = (CNT + 3) / 4;                      // source dwords they lie in, once aligned
+};
+
+// what one lane reads for base dword t and quality dword t of a cluster: aligned dwords, nothing beyond the one that holds the last byte
+template <int W, int BB> struct Src3 {
+	uint32_t w[3];
+	uint32_t raw[Q3<W>::NSRC + 1];
+};
+
+template <int W, int BB>
+__device__ __forceinline__ void src3_load_bases(const PackDescR &d0, int t, uint32_t (&w)[3])
+{
+	constexpr int PER = 32 / BB;
+	const int n = d0.ll + d0.lr;
+	const int nb0 = d0.begin + PER * t;
+	const uint64_t A = d0.src + (uint64_t)(nb0 >> 1);
+	const uint32_t *p = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
+	const int rem = n - PER * t;
+	const int need = (int)(A & 3ull) + (((rem < PER ? rem : PER) + (nb0 & 1) + 1) >> 1); // bytes from p[0] on that hold the dword's bases
+	w[0] = p[0]; w[1] = need > 4 ? p[1] : 0u; w[2] = need > 8 ? p[2] : 0u;
+}
+
+template <int W, int BB>
+__device__ __forceinline__ void src3_load_quals(const PackDescR &d0, int t, uint32_t (&raw)[Q3<W>::NSRC + 1])
+{
+	const int n = d0.ll + d0.lr;
+	const int i0 = (32 * t) / W;
+	const uint64_t A = d0.src + (uint64_t)((d0.lq + 1) / 2 + d0.begin + i0); // first source byte
+	const uint32_t *q4 = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
+	const int bytes = (int)(A & 3ull) + (n - i0);
+#pragma unroll
+	for (int g = 0; g <= Q3<W>::NSRC; ++g) raw[g] = 4 * g < bytes ? q4[g] : 0u;
+}
+
+// base dword t of the cluster's block from its three source dwords
+template <int BB>
+__device__ __forceinline__ uint32_t base_dword3(const Pack3Args &q, const uint8_t *s_base, const PackDescR &d0, int64_t c, int t, const uint32_t (&w)[3])
+{
+	constexpr int PER = 32 / BB;
+	const int n = d0.ll + d0.lr;
+	const int nb0 = d0.begin + PER * t;                       // first nibble of the read
+	const uint32_t sh = (uint32_t)((d0.src + (uint64_t)(nb0 >> 1)) & 3ull);
+	uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], sh), hi = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
+	const int rem = n - PER * t;                              // bases of the stream from this dword on
+	if (BB == 4) {
+		lo = swap_nibbles(lo);
+		if (nb0 & 1) lo = __builtin_amdgcn_alignbit(swap_nibbles(hi), lo, 4);
+		if (rem < 8) lo &= (1u << (4 * rem)) - 1u;
+		return lo;
+	}
+	if (nb0 & 1) { // pair the nibbles anew: byte k = low nibble of byte k, high nibble of byte k + 1
+		const uint32_t ex = (w[2] >> (8 * sh)) & 0xffu;       // byte 8
+		const uint32_t lo12 = __builtin_amdgcn_alignbit(hi, lo, 12), hi12 = (hi >> 12) | (ex << 20);
+		lo = ((lo & 0x0f0f0f0fu) << 4) | (lo12 & 0x0f0f0f0fu);
+		hi = ((hi & 0x0f0f0f0fu) << 4) | (hi12 & 0x0f0f0f0fu);
+	}
+	if (rem < 16) { // behind the stream's end: make it 'A' (valid for the table), cut the result below
+		const int nb = (rem + 1) >> 1;                    // bytes that hold stream bases
+		const uint64_t keep = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1ull;
+		uint64_t Y = ((uint64_t)hi << 32) | lo;
+		Y = (Y & keep) | (0x1111111111111111ull & ~keep);
+		if (rem & 1) Y = (Y & ~(0x0full << (8 * (nb - 1)))) | (0x01ull << (8 * (nb - 1)));
+		lo = (uint32_t)Y; hi = (uint32_t)(Y >> 32);
+	}
+	uint32_t out = 0, inv = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const uint32_t e0 = s_base[(lo >> (8 * k)) & 0xffu], e1 = s_base[(hi >> (8 * k)) & 0xffu];
+		out |= ((e0 & 15u) << (4 * k)) | ((e1 & 15u) << (4 * k + 16));
+		inv |= e0 | e1;
+	}
+	if (inv & 0x80u) { // something else than A/C/G/T among the 16: base by base (nibbles into stream order first)
+		const uint32_t slo = swap_nibbles(lo), shi = swap_nibbles(hi);
+		const uint32_t a = acgt2_slow(q, (uint64_t)c, PER * t, slo, rem < 8 ? rem : 8);
+		const uint32_t b = rem > 8 ? acgt2_slow(q, (uint64_t)c, PER * t + 8, shi, rem < 16 ? rem - 8 : 8) : 0u;
+		out = a | (b << 16);
+	} else if (rem < 16) out &= (1u << (2 * rem)) - 1u;
+	return out;
+}
+
+// quality dword t of the cluster's block from its source dwords; `miss` collects what the pair table could not place
+template <int W>
+__device__ __forceinline__ uint32_t qual_dword3(const Pack3Args &q, const uint16_t *s_pair, const PackDescR &d0, int64_t c, int t, const uint32_t (&raw)[Q3<W>::NSRC + 1], uint32_t &miss)
+{
+	constexpr int CNT = Q3<W>::CNT, NSRC = Q3<W>::NSRC;
+	const int n = d0.ll + d0.lr;
+	const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
+	const uint32_t sh = (uint32_t)((d0.src + (uint64_t)((d0.lq + 1) / 2 + d0.begin + i0)) & 3ull);
+	const int rem = n - i0;                                // qualities of the stream from i0 on (>= 1)
+	uint32_t src[NSRC];
+#pragma unroll
+	for (int g = 0; g < NSRC; ++g) src[g] = __builtin_amdgcn_alignbyte(raw[g + 1], raw[g], sh);
+	const bool qmiss = (src[0] & 0xffu) == 0xffu; // a read without qualities has 0xff in all of them
+	if (t == 0) q.flags[c] = qmiss ? 1 : 0;
+	if (W == 8) {
+		uint32_t v = qmiss ? 0x2a2a2a2au : src[0] + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
+		if (rem < 4) v &= (1u << (8 * rem)) - 1u;
+		return v;
+	}
+	const uint32_t fill = (src[0] & 0xffu) * 0x01010101u; // behind the stream's end: the first quality again (so that the pair table sees alphabet members only)
+	uint64_t acc = 0;
+	uint32_t bad = 0;
+#pragma unroll
+	for (int g = 0; g < NSRC; ++g) {
+		const uint32_t valid = rem >= 4 * g + 4 ? 0xffffffffu : rem > 4 * g ? (1u << (8 * (rem - 4 * g))) - 1u : 0u;
+		const uint32_t x = (src[g] & valid) | (fill & ~valid);
+		const uint32_t e0 = s_pair[pair_index(x)], e1 = s_pair[pair_index(x >> 16)];
+		acc |= (uint64_t)(e0 & 0xffu) << (4 * g * W);
+		acc |= (uint64_t)(e1 & 0xffu) << ((4 * g + 2) * W);
+		bad |= (x & 0xc0c0c0c0u) | ((e0 | e1) & 0x8000u); // the table knows nothing of phred >= 64, and says 0x8000 for a pair with a value outside the alphabet
+	}
+	if (rem < CNT) acc &= (1ull << (W * rem)) - 1ull;
+	miss |= qmiss ? 0u : bad;
+	return qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
+}
+
+// Persistent grid; every group of 16 lanes walks its clusters with a two-deep software pipeline: while the dwords of cluster i are composed
+// and stored, the source dwords of cluster i + 1 and the descriptor of cluster i + 2 are on their way (a cluster is descriptor -> source
+// bytes -> output: two dependent trips to memory that a wavefront would otherwise sit out; at eight wavefronts per SIMD that wait,
+// not the instructions, is what the unpipelined form spends its time on).
 template <int W, int BB>
 __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str,
                                                         const uint16_t *__restrict__ pair_lut)
@@ -281,99 +403,36 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 	const int grp = (int)(threadIdx.x / GROUP);
 	const int gl = (int)(threadIdx.x % GROUP);
 	const int64_t nc = (int64_t)*n_clusters_dev;
-	const int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
-	const PackDescR d0 = pack_desc_load(desc, c, nc);
-	if (!pack_desc_fast(d0)) return;
-	const int n = d0.ll + d0.lr, lq = d0.lq, begin = d0.begin;
-	constexpr int PER = 32 / BB; // bases per dword
-	const int nDb = (n * BB + 31) / 32;
-	const int nDq = (n * W + 31) / 32;
-	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
-	for (int t = gl; t < nDb; t += GROUP) {
-		const int nb0 = begin + PER * t;                       // first nibble of the read
-		const uint64_t A = d0.src + (uint64_t)(nb0 >> 1);
-		const uint32_t *w = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
-		const uint32_t sh = (uint32_t)(A & 3ull);
-		const int rem = n - PER * t;                           // bases of the stream from this dword on
-		const int need = (int)sh + (((rem < PER ? rem : PER) + (nb0 & 1) + 1) >> 1); // bytes from w[0] on that hold them
-		const uint32_t w0 = w[0], w1 = need > 4 ? w[1] : 0u, w2 = need > 8 ? w[2] : 0u;
-		uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-		if (BB == 4) {
-			lo = swap_nibbles(lo);
-			if (nb0 & 1) lo = __builtin_amdgcn_alignbit(swap_nibbles(hi), lo, 4);
-			if (rem < 8) lo &= (1u << (4 * rem)) - 1u;
-			d[t] = lo;
-			continue;
-		}
-		if (nb0 & 1) { // pair the nibbles anew: byte k = low nibble of byte k, high nibble of byte k + 1
-			const uint32_t ex = (w2 >> (8 * sh)) & 0xffu;       // byte 8
-			const uint32_t lo12 = __builtin_amdgcn_alignbit(hi, lo, 12), hi12 = (hi >> 12) | (ex << 20);
-			lo = ((lo & 0x0f0f0f0fu) << 4) | (lo12 & 0x0f0f0f0fu);
-			hi = ((hi & 0x0f0f0f0fu) << 4) | (hi12 & 0x0f0f0f0fu);
-		}
-		if (rem < 16) { // behind the stream's end: make it 'A' (valid for the table), cut the result below
-			const int nb = (rem + 1) >> 1;                    // bytes that hold stream bases
-			const uint64_t keep = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1ull;
-			uint64_t Y = ((uint64_t)hi << 32) | lo;
-			Y = (Y & keep) | (0x1111111111111111ull & ~keep);
-			if (rem & 1) Y = (Y & ~(0x0full << (8 * (nb - 1)))) | (0x01ull << (8 * (nb - 1)));
-			lo = (uint32_t)Y; hi = (uint32_t)(Y >> 32);
-		}
-		uint32_t out = 0, inv = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const uint32_t e0 = s_base[(lo >> (8 * k)) & 0xffu], e1 = s_base[(hi >> (8 * k)) & 0xffu];
-			out |= ((e0 & 15u) << (4 * k)) | ((e1 & 15u) << (4 * k + 16));
-			inv |= e0 | e1;
-		}
-		if (inv & 0x80u) { // something else than A/C/G/T among the 16: base by base (nibbles into stream order first)
-			const uint32_t slo = swap_nibbles(lo), shi = swap_nibbles(hi);
-			const uint32_t a = acgt2_slow(q, (uint64_t)c, PER * t, slo, rem < 8 ? rem : 8);
-			const uint32_t b = rem > 8 ? acgt2_slow(q, (uint64_t)c, PER * t + 8, shi, rem < 16 ? rem - 8 : 8) : 0u;
-			out = a | (b << 16);
-		} else if (rem < 16) out &= (1u << (2 * rem)) - 1u;
-		d[t] = out;
-	}
+	const int64_t step = (int64_t)gridDim.x * GROUPS_PER_BLOCK;
+	int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
 	uint32_t miss = 0;
-	for (int t = gl; t < nDq; t += GROUP) {
-		constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
-		constexpr int NSRC = (CNT + 3) / 4;                      // source dwords they lie in, once aligned
-		const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
-		const uint64_t A = d0.src + (uint64_t)((lq + 1) / 2 + begin + i0); // first source byte
-		const uint32_t *q4 = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
-		const uint32_t sh = (uint32_t)(A & 3ull);
-		const int rem = n - i0;                                // qualities of the stream from i0 on (>= 1)
-		uint32_t raw[NSRC + 1];
+	auto counts = [](const PackDescR &d, int &nDb, int &nDq) {
+		const int n = d.ll + d.lr;
+		const bool fast = pack_desc_fast(d);
+		nDb = fast ? (n * BB + 31) / 32 : 0; nDq = fast ? (n * W + 31) / 32 : 0;
+	};
+	auto issue = [&](const PackDescR &d, Src3<W, BB> &S) {
+		int nDb, nDq; counts(d, nDb, nDq);
+		S.w[0] = S.w[1] = S.w[2] = 0u;
 #pragma unroll
-		for (int g = 0; g <= NSRC; ++g) raw[g] = 4 * g < (int)sh + rem ? q4[g] : 0u; // (nothing is read beyond the dword that holds the stream's last byte)
-		uint32_t src[NSRC];
-#pragma unroll
-		for (int g = 0; g < NSRC; ++g) src[g] = __builtin_amdgcn_alignbyte(raw[g + 1], raw[g], sh);
-		const bool qmiss = (src[0] & 0xffu) == 0xffu; // a read without qualities has 0xff in all of them
-		const uint32_t fill = (src[0] & 0xffu) * 0x01010101u; // behind the stream's end: the first quality again (so that the pair table sees alphabet members only)
-		if (t == 0) q.flags[c] = qmiss ? 1 : 0;
-		uint32_t v;
-		if (W == 8) {
-			v = qmiss ? 0x2a2a2a2au : src[0] + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
-			if (rem < 4) v &= (1u << (8 * rem)) - 1u;
-		} else {
-			uint64_t acc = 0;
-			uint32_t bad = 0;
-#pragma unroll
-			for (int g = 0; g < NSRC; ++g) {
-				const uint32_t valid = rem >= 4 * g + 4 ? 0xffffffffu : rem > 4 * g ? (1u << (8 * (rem - 4 * g))) - 1u : 0u;
-				const uint32_t x = (src[g] & valid) | (fill & ~valid);
-				const uint32_t e0 = s_pair[pair_index(x)], e1 = s_pair[pair_index(x >> 16)];
-				acc |= (uint64_t)(e0 & 0xffu) << (4 * g * W);
-				acc |= (uint64_t)(e1 & 0xffu) << ((4 * g + 2) * W);
-				// the table knows nothing of phred >= 64, and says 0x8000 for a pair with a value outside the alphabet
-				bad |= (x & 0xc0c0c0c0u) | ((e0 | e1) & 0x8000u);
-			}
-			if (rem < CNT) acc &= (1ull << (W * rem)) - 1ull;
-			v = qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
-			miss |= qmiss ? 0u : bad;
-		}
-		d[nDb + t] = v;
+		for (int g = 0; g <= Q3<W>::NSRC; ++g) S.raw[g] = 0u;
+		if (gl < nDb) src3_load_bases<W, BB>(d, gl, S.w);
+		if (gl < nDq) src3_load_quals<W, BB>(d, gl, S.raw);
+	};
+	PackDescR d0 = pack_desc_load(desc, c, nc), d1 = pack_desc_load(desc, c + step, nc);
+	Src3<W, BB> S0, S1;
+	issue(d0, S0);
+	for (; c < nc; c += step) {
+		const PackDescR d2 = pack_desc_load(desc, c + 2 * step, nc);
+		issue(d1, S1);
+		int nDb, nDq; counts(d0, nDb, nDq);
+		uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
+		if (gl < nDb) d[gl] = base_dword3<BB>(q, s_base, d0, c, gl, S0.w);
+		if (gl < nDq) d[nDb + gl] = qual_dword3<W>(q, s_pair, d0, c, gl, S0.raw, miss);
+		// clipped sequences longer than one round of the group (2-bit bases: 256; 3-bit qualities: 170): the rest, unpipelined
+		for (int t = gl + GROUP; t < nDb; t += GROUP) { uint32_t w[3]; src3_load_bases<W, BB>(d0, t, w); d[t] = base_dword3<BB>(q, s_base, d0, c, t, w); }
+		for (int t = gl + GROUP; t < nDq; t += GROUP) { uint32_t raw[Q3<W>::NSRC + 1]; src3_load_quals<W, BB>(d0, t, raw); d[nDb + t] = qual_dword3<W>(q, s_pair, d0, c, t, raw, miss); }
+		d0 = d1; d1 = d2; S0 = S1;
 	}
 	if (W < 8 && miss) *p.lut_miss = 1;
 }
