@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "inflate_core.h"
+#include "inflate_lanes.h"
 
 namespace ssv {
 
@@ -73,6 +74,198 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict
 	int rc = INF_OK;
 	if (blk.u_len) rc = inflate_stream(comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tab);
 	status[b] = rc;
+}
+
+// ---- the ring machine (inflate_lanes.h) ------------------------------------------------------------------------------------------
+//
+// Still one lane per BGZF block, but a lane's compressed bytes and its fresh output live in two LDS rings; the WAVEFRONT moves them between
+// the rings and memory, half a ring at a time: one coalesced load / store of 16 (8) lanes for every lane that asks, instead of 64 unrelated
+// addresses in every memory instruction of the symbol loop and a round trip to memory for every near match.  Per wavefront:
+// 22,784 B of Huffman tables + (IN_DW + OUT_DW) x 256 B of rings.
+template <class Cfg> struct LdsIo {
+	uint32_t *in_ring, *out_ring; // LDS, dword i of lane l at [i * 64 + l]
+	int lane;
+	const uint8_t *in_org;        // dword-aligned address at or below the stream's first byte
+	uint8_t *out_org;             // dword-aligned address at or below the block's first output byte
+	__device__ __forceinline__ uint32_t in_get(int slot) const { return in_ring[slot * 64 + lane]; }
+	__device__ __forceinline__ uint32_t in_stream32(uint32_t off) const { uint32_t v; memcpy(&v, in_org + off, 4); return v; } // below in_lim: inside the padded chunk buffer
+	__device__ __forceinline__ void out_set8(uint32_t idx, uint8_t v) { reinterpret_cast<uint8_t *>(out_ring + (idx >> 2) * 64 + lane)[idx & 3u] = v; }
+	__device__ __forceinline__ uint8_t out_get8(uint32_t idx) const { return reinterpret_cast<const uint8_t *>(out_ring + (idx >> 2) * 64 + lane)[idx & 3u]; }
+	__device__ __forceinline__ uint32_t out_get32(int slot) const { return out_ring[slot * 64 + lane]; }
+	__device__ __forceinline__ void out_set32(int slot, uint32_t v) { out_ring[slot * 64 + lane] = v; }
+	__device__ __forceinline__ uint32_t out_stream32(uint32_t pos) const { uint32_t v; memcpy(&v, out_org + pos, 4); return v; }
+};
+
+template <class Cfg> constexpr int inflate_rings_lds_bytes() { return INFLATE_LDS_BYTES + (Cfg::IN_DW + Cfg::OUT_DW) * 64 * 4; }
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
+{
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(WAVE) void k_bgzf_inflate_rings(const uint8_t *__restrict__ comp, uint64_t comp_bytes, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
+                                                             uint8_t *__restrict__ out, int *__restrict__ status, uint8_t *__restrict__ scratch, unsigned long long *__restrict__ dbg)
+{
+	extern __shared__ uint8_t lds_raw[];
+	LdsTab tab;
+	tab.lit8 = lds_raw;
+	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * 64);
+	tab.dst8 = lds_raw + 288 * 64 + 9 * 64 * 4;
+	tab.len8 = scratch + (size_t)blockIdx.x * INFLATE_SCRATCH_BYTES;
+	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * 64);
+	tab.lane = lane_id();
+	// dbg (tools/bamdec_bench.py --phases): cycles of this wavefront in its three phases, steps, and how the lanes spent them
+	unsigned long long t_in = 0, t_step = 0, t_out = 0, n_iter = 0, n_hdr = 0, n_sym = 0, n_copy = 0, n_far = 0, n_stall = 0;
+	LdsIo<Cfg> io;
+	io.in_ring = reinterpret_cast<uint32_t *>(lds_raw + INFLATE_LDS_BYTES);
+	io.out_ring = io.in_ring + Cfg::IN_DW * 64;
+	io.lane = lane_id();
+	const int lane = lane_id();
+	const int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+	LaneInflate<Cfg> L;
+	uint64_t in_org = 0, out_org = 0;
+	if (b < n_blocks) {
+		const BgzfBlock blk = blocks[b];
+		const uint64_t ia = reinterpret_cast<uint64_t>(comp + blk.c_off), oa = reinterpret_cast<uint64_t>(out + u_off[b]);
+		in_org = ia & ~3ull; out_org = oa & ~3ull;
+		L.start((uint32_t)(ia & 3ull), blk.c_len, (uint32_t)(oa & 3ull), blk.u_len);
+	}
+	io.in_org = reinterpret_cast<const uint8_t *>(in_org);
+	io.out_org = reinterpret_cast<uint8_t *>(out_org);
+	const uint64_t comp_end = reinterpret_cast<uint64_t>(comp) + comp_bytes + 8; // (the chunk buffer keeps spare bytes behind the last stream)
+	// Ring traffic is moved by groups of 16 lanes, up to four lanes' halves per instruction.  The input side runs one step ahead: the
+	// dwords loaded in step k are put into the ring at the start of step k + 1 (a lane asks for input while it still has half a ring).
+	static_assert(Cfg::REFILL_DW <= 16 && Cfg::FLUSH_DW <= 16, "a group of 16 lanes moves half a ring");
+	const int grp = lane >> 4, gl = lane & 15;
+	uint32_t pf_val = 0; int pf_idx = -1; // this helper lane's pending ring dword
+	bool rf_inflight = false;             // this lane's ring is being refilled
+	auto pick4 = [&](uint64_t m, int &T, bool &valid) { // the grp-th lowest lane of m
+		int t0 = __ffsll((unsigned long long)m) - 1; uint64_t m1 = m & (m - 1);
+		int t1 = __ffsll((unsigned long long)m1) - 1; uint64_t m2 = m1 & (m1 - 1);
+		int t2 = __ffsll((unsigned long long)m2) - 1; uint64_t m3 = m2 & (m2 - 1);
+		int t3 = __ffsll((unsigned long long)m3) - 1;
+		T = grp == 0 ? t0 : grp == 1 ? t1 : grp == 2 ? t2 : t3;
+		valid = T >= 0;
+		if (!valid) T = 0;
+	};
+	while (__any(L.state != ST_DONE)) {
+		unsigned long long t0 = dbg ? clock64() : 0;
+		// ---- input: what was loaded a step ago goes into the rings; then half a ring is requested for up to four lanes that have used up theirs ----
+		if (pf_idx >= 0) { io.in_ring[pf_idx] = pf_val; pf_idx = -1; }
+		if (rf_inflight) { L.rfill += Cfg::REFILL_DW; rf_inflight = false; }
+		{
+			const uint64_t m = __ballot(L.wants_refill());
+			if (m) {
+				int T; bool valid;
+				pick4(m, T, valid);
+				const uint32_t rf = (uint32_t)__shfl((int)L.rfill, T);
+				const uint64_t org = (uint64_t)(uint32_t)__shfl((int)(uint32_t)in_org, T) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(in_org >> 32), T) << 32);
+				if (valid && gl < Cfg::REFILL_DW) {
+					const uint32_t D = rf + (uint32_t)gl;
+					const uint64_t a = org + 4ull * D;
+					pf_val = a + 4 <= comp_end ? *reinterpret_cast<const uint32_t *>(a) : 0u;
+					pf_idx = (int)((D % Cfg::IN_DW) * 64) + T;
+				}
+				// the (up to four) chosen lanes
+				const uint64_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1), m4 = m3 & (m3 - 1);
+				rf_inflight = ((m & ~m4) >> lane) & 1ull;
+			}
+		}
+		// ---- one step of every stream ----
+		if (dbg) {
+			const unsigned long long t1 = clock64(); t_in += t1 - t0; t0 = t1; ++n_iter;
+			n_hdr += __popcll(__ballot(L.state == ST_HEADER)); n_sym += __popcll(__ballot(L.state == ST_SYMBOL && !L.wants_flush()));
+			n_copy += __popcll(__ballot(L.state == ST_COPY)); n_far += __popcll(__ballot(L.state == ST_FAR));
+			n_stall += __popcll(__ballot(L.state < ST_FINISH && L.wants_flush()));
+		}
+		if (L.state < ST_FINISH && !L.wants_flush()) L.step(io, tab);
+		if (dbg) { const unsigned long long t1 = clock64(); t_step += t1 - t0; t0 = t1; } // (a lane whose full half was not among the four written out last time waits: the ring's slack is one step's worth)
+		// ---- output: half a ring of up to four lanes that have filled one ----
+		{
+			const uint64_t m = __ballot(L.state < ST_FINISH && L.wants_flush());
+			if (m) {
+				int T; bool valid;
+				pick4(m, T, valid);
+				const uint32_t fT = (uint32_t)__shfl((int)L.f, T), ob = (uint32_t)__shfl((int)L.o_begin, T);
+				const uint64_t org = (uint64_t)(uint32_t)__shfl((int)(uint32_t)out_org, T) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(out_org >> 32), T) << 32);
+				if (valid && gl < Cfg::FLUSH_DW) {
+					const uint32_t q = fT + 4u * (uint32_t)gl; // (a half that is written out lies below o <= o_end)
+					const uint32_t v = io.out_ring[((q >> 2) % Cfg::OUT_DW) * 64 + T];
+					uint8_t *g = reinterpret_cast<uint8_t *>(org + q);
+					if (q >= ob) *reinterpret_cast<uint32_t *>(g) = v; // (the block's first dword may be shared with the block before)
+					else for (uint32_t k = 0; k < 4; ++k) if (q + k >= ob) g[k] = (uint8_t)(v >> (8 * k));
+				}
+				const uint64_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1), m4 = m3 & (m3 - 1);
+				if (((m & ~m4) >> lane) & 1ull) L.f += 4u * Cfg::FLUSH_DW;
+			}
+		}
+		// ---- far matches: the wavefront moves them, stream -> stream, a lane's match (and its unwritten ring bytes) in one coalesced load
+		//      and store of up to 64 dwords; up to four lanes per step, all loads before the first store ----
+		{
+			uint64_t m = __ballot(L.state == ST_FAR);
+			if (m) {
+				constexpr int K = 4;
+				FarMove<Cfg> fm[K]; int Tk[K]; uint64_t orgk[K]; uint32_t ringv[K], srcv[K]; bool act[K];
+#pragma unroll
+				for (int k = 0; k < K; ++k) {
+					Tk[k] = __ffsll((unsigned long long)m) - 1; m &= m - 1;
+					act[k] = false; ringv[k] = srcv[k] = 0; orgk[k] = 0;
+					if (Tk[k] < 0) continue;
+					const int T = Tk[k];
+					fm[k].f = (uint32_t)__builtin_amdgcn_readlane((int)L.f, T); fm[k].o = (uint32_t)__builtin_amdgcn_readlane((int)L.o, T);
+					fm[k].rem = (uint32_t)__builtin_amdgcn_readlane((int)L.rem, T); fm[k].dist = (uint32_t)__builtin_amdgcn_readlane((int)L.dist, T);
+					fm[k].o_begin = (uint32_t)__builtin_amdgcn_readlane((int)L.o_begin, T);
+					orgk[k] = readlane64(out_org, T);
+					act[k] = (uint32_t)lane < fm[k].dwords();
+					if (act[k]) {
+						const uint32_t q0 = fm[k].pos((uint32_t)lane);
+						ringv[k] = io.out_ring[((q0 >> 2) % Cfg::OUT_DW) * 64 + T];
+						if (fm[k].needs_src((uint32_t)lane)) {
+							const uint64_t a = orgk[k] + q0 - fm[k].dist;
+							if (a >= reinterpret_cast<uint64_t>(out)) memcpy(&srcv[k], reinterpret_cast<const uint8_t *>(a), 4);
+							else for (uint32_t bb2 = 0; bb2 < 4; ++bb2) if (a + bb2 >= reinterpret_cast<uint64_t>(out)) srcv[k] |= (uint32_t)*reinterpret_cast<const uint8_t *>(a + bb2) << (8 * bb2); // (the stream's very first bytes)
+						}
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < K; ++k) {
+					if (Tk[k] < 0) continue;
+					if (act[k]) {
+						const uint32_t q0 = fm[k].pos((uint32_t)lane);
+						uint32_t val;
+						const uint32_t mask = fm[k].merge((uint32_t)lane, ringv[k], srcv[k], val);
+						uint8_t *g = reinterpret_cast<uint8_t *>(orgk[k] + q0);
+						if (mask == 15u) *reinterpret_cast<uint32_t *>(g) = val;
+						else for (uint32_t bb2 = 0; bb2 < 4; ++bb2) if ((mask >> bb2) & 1u) g[bb2] = (uint8_t)(val >> (8 * bb2));
+						if (fm[k].to_ring((uint32_t)lane)) io.out_ring[((q0 >> 2) % Cfg::OUT_DW) * 64 + Tk[k]] = val;
+					}
+					if (lane == Tk[k]) L.far_done();
+				}
+			}
+		}
+		// ---- finished streams: everything that is left, one lane at a time ----
+		for (uint64_t m = __ballot(L.state == ST_FINISH); m; m &= m - 1) {
+			const int T = __ffsll((unsigned long long)m) - 1;
+			const uint32_t fT = (uint32_t)__builtin_amdgcn_readlane((int)L.f, T), oT = (uint32_t)__builtin_amdgcn_readlane((int)L.o, T);
+			const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int)L.o_begin, T);
+			const uint64_t org = readlane64(out_org, T);
+			const uint32_t q = fT + 4u * (uint32_t)lane;
+			if (q < oT) {
+				const uint32_t v = io.out_ring[((q >> 2) % Cfg::OUT_DW) * 64 + T];
+				uint8_t *g = reinterpret_cast<uint8_t *>(org + q);
+				if (q >= ob && q + 4 <= oT) *reinterpret_cast<uint32_t *>(g) = v;
+				else for (uint32_t k = 0; k < 4; ++k) if (q + k >= ob && q + k < oT) g[k] = (uint8_t)(v >> (8 * k));
+			}
+			if (lane == T) L.state = ST_DONE;
+		}
+		if (dbg) t_out += clock64() - t0;
+	}
+	if (dbg && lane == 0) {
+		unsigned long long *o9 = dbg + (size_t)blockIdx.x * 9;
+		o9[0] = t_in; o9[1] = t_step; o9[2] = t_out; o9[3] = n_iter; o9[4] = n_hdr; o9[5] = n_sym; o9[6] = n_copy; o9[7] = n_far; o9[8] = n_stall;
+	}
+	if (b < n_blocks) status[b] = L.verdict();
 }
 
 // ---- record boundaries ----------------------------------------------------------------------------------------------------------

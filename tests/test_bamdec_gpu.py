@@ -149,3 +149,18 @@ def test_device_decode_rejects_damage(ctx, ragged, tmp_path):
     open(bad, "wb").write(bytes(raw))
     with pytest.raises((device.SeeksvError, IOError)):
         _device_all(ctx, bad, 64 << 20, 1 << 16)
+
+
+@pytest.mark.parametrize("mode", ["rings", "rings8"])
+def test_ring_machine_inflate_modes(mode):
+    """SSV_INFLATE=rings...: the state-machine decoder with LDS rings and wavefront-cooperative far moves (inflate_lanes.h; not the default,
+    DESIGN.md section 9) through the same device-decode == host-reader checks (the mode is read once per process: a child pytest runs them)"""
+    import subprocess
+    import sys
+    if os.environ.get("SSV_INFLATE"):
+        pytest.skip("already inside a mode run")
+    env = dict(os.environ, SSV_INFLATE=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
