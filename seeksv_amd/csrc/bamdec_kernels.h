@@ -34,21 +34,22 @@ constexpr uint32_t BD_NONE = 0xffffffffu;
 // interleaving (coalesced 64-byte rows).
 struct LdsTab {
 	uint8_t *lit8; uint32_t *hi; uint8_t *dst8;  // LDS
-	uint8_t *len8; uint16_t *off16;              // global scratch of this wavefront: 320 x 64 bytes, 16 x 64 halves
+	uint8_t *len8; uint16_t *off16;              // global scratch of this wavefront: 320 x stride bytes, 16 x stride halves
 	int lane;
-	__device__ __forceinline__ uint16_t lit_get(int i) const { return (uint16_t)(lit8[i * 64 + lane] | (((hi[(i >> 5) * 64 + lane] >> (i & 31)) & 1u) << 8)); }
+	int stride = 64;                             // lanes that decode in this wavefront (element i of lane l at [i * stride + l])
+	__device__ __forceinline__ uint16_t lit_get(int i) const { return (uint16_t)(lit8[i * stride + lane] | (((hi[(i >> 5) * stride + lane] >> (i & 31)) & 1u) << 8)); }
 	__device__ __forceinline__ void lit_set(int i, uint16_t v)
 	{
-		lit8[i * 64 + lane] = (uint8_t)v;
-		uint32_t &w = hi[(i >> 5) * 64 + lane];
+		lit8[i * stride + lane] = (uint8_t)v;
+		uint32_t &w = hi[(i >> 5) * stride + lane];
 		w = (w & ~(1u << (i & 31))) | ((uint32_t)(v >> 8) << (i & 31));
 	}
-	__device__ __forceinline__ uint16_t dst_get(int i) const { return dst8[i * 64 + lane]; }
-	__device__ __forceinline__ void dst_set(int i, uint16_t v) { dst8[i * 64 + lane] = (uint8_t)v; }
-	__device__ __forceinline__ int len_get(int i) const { return len8[i * 64 + lane]; }
-	__device__ __forceinline__ void len_set(int i, int v) { len8[i * 64 + lane] = (uint8_t)v; }
-	__device__ __forceinline__ uint16_t off_get(int i) const { return off16[i * 64 + lane]; }
-	__device__ __forceinline__ void off_set(int i, uint16_t v) { off16[i * 64 + lane] = v; }
+	__device__ __forceinline__ uint16_t dst_get(int i) const { return dst8[i * stride + lane]; }
+	__device__ __forceinline__ void dst_set(int i, uint16_t v) { dst8[i * stride + lane] = (uint8_t)v; }
+	__device__ __forceinline__ int len_get(int i) const { return len8[i * stride + lane]; }
+	__device__ __forceinline__ void len_set(int i, int v) { len8[i * stride + lane] = (uint8_t)v; }
+	__device__ __forceinline__ uint16_t off_get(int i) const { return off16[i * stride + lane]; }
+	__device__ __forceinline__ void off_set(int i, uint16_t v) { off16[i * stride + lane] = v; }
 };
 
 constexpr int INFLATE_LDS_BYTES = 288 * 64 + 9 * 64 * 4 + 32 * 64;      // 22,784 B per wavefront
@@ -56,23 +57,65 @@ constexpr int INFLATE_SCRATCH_BYTES = 320 * 64 + 16 * 64 * 2;           // globa
 
 struct BgzfBlock { uint64_t c_off; uint32_t c_len, u_len; }; // deflate payload inside the chunk buffer; inflated size
 
-// One lane per BGZF block.  status[b] = 0 or the lane's error code.
+// One lane per BGZF block, LPW blocks per wavefront (64; fewer = more, narrower wavefronts: an experiment).
+// status[b] = 0 or the lane's error code.
+template <bool COPY2, int LPW>
 __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
                                                        uint8_t *__restrict__ out, int *__restrict__ status, uint8_t *__restrict__ scratch)
 {
 	extern __shared__ uint8_t lds_raw[];
+	if ((int)threadIdx.x >= LPW) return;
 	LdsTab tab;
+	tab.stride = LPW;
 	tab.lit8 = lds_raw;
-	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * 64);
-	tab.dst8 = lds_raw + 288 * 64 + 9 * 64 * 4;
-	tab.len8 = scratch + (size_t)blockIdx.x * INFLATE_SCRATCH_BYTES;
-	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * 64);
-	tab.lane = lane_id();
-	const int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
+	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;
+	tab.len8 = scratch + (size_t)blockIdx.x * (INFLATE_SCRATCH_BYTES / 64 * LPW);
+	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * LPW);
+	tab.lane = (int)threadIdx.x;
+	const int64_t b = (int64_t)blockIdx.x * LPW + threadIdx.x;
 	if (b >= n_blocks) return;
 	const BgzfBlock blk = blocks[b];
 	int rc = INF_OK;
-	if (blk.u_len) rc = inflate_stream(comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tab);
+	if (blk.u_len) rc = inflate_stream<LdsTab, COPY2>(comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tab);
+	status[b] = rc;
+}
+
+// The same decoder writing through a 64-byte line buffer per lane (LineOut, inflate_core.h): 64 x LPW bytes of LDS more per wavefront.
+struct LdsLine {
+	uint8_t *base; // this wavefront's lines: 16-byte group g of lane l at ((g * stride + l) * 16)
+	int lane, stride;
+	__device__ __forceinline__ uint8_t *grp(uint32_t g) const { return base + ((g * (uint32_t)stride + (uint32_t)lane) << 4); }
+	__device__ __forceinline__ uint8_t get8(uint32_t i) const { return grp(i >> 4)[i & 15u]; }
+	__device__ __forceinline__ void set8(uint32_t i, uint8_t v) { grp(i >> 4)[i & 15u] = v; }
+	__device__ __forceinline__ void set32(uint32_t di, uint32_t v) { *reinterpret_cast<uint32_t *>(grp(di >> 2) + 4 * (di & 3u)) = v; }
+	__device__ __forceinline__ void store16(uint8_t *dst, uint32_t g) const { *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(grp(g)); }
+};
+
+template <int LPW>
+__global__ __launch_bounds__(WAVE) void k_bgzf_inflate_wc(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
+                                                          uint8_t *__restrict__ out, int *__restrict__ status, uint8_t *__restrict__ scratch)
+{
+	extern __shared__ uint8_t lds_raw[];
+	if ((int)threadIdx.x >= LPW) return;
+	LdsTab tab;
+	tab.stride = LPW;
+	tab.lit8 = lds_raw;
+	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
+	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;
+	tab.len8 = scratch + (size_t)blockIdx.x * (INFLATE_SCRATCH_BYTES / 64 * LPW);
+	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * LPW);
+	tab.lane = (int)threadIdx.x;
+	const int64_t b = (int64_t)blockIdx.x * LPW + threadIdx.x;
+	if (b >= n_blocks) return;
+	const BgzfBlock blk = blocks[b];
+	LineOut<LdsLine> lo;
+	lo.out = out + u_off[b];
+	lo.a0 = (uint32_t)(reinterpret_cast<uintptr_t>(lo.out) & 63u);
+	lo.flushed = 0;
+	lo.line.base = lds_raw + INFLATE_LDS_BYTES / 64 * LPW; lo.line.lane = (int)threadIdx.x; lo.line.stride = LPW;
+	int rc = INF_OK;
+	if (blk.u_len) rc = inflate_stream_to(comp + blk.c_off, blk.c_len, lo, blk.u_len, tab);
 	status[b] = rc;
 }
 

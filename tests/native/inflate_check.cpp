@@ -114,6 +114,26 @@ int main()
 					std::vector<uint8_t> o(n + 8, 0x55);
 					int rc = ssv::inflate_stream(c.data(), clen, o.data(), (uint32_t)n, tab);
 					bool same = rc == ssv::INF_OK && memcmp(o.data(), d.data(), n) == 0 && o[n] == 0x55;
+					for (int mo = 0; mo < 2; ++mo) { // through the 64-byte line buffer, at two misalignments of the output
+						struct CpuLine {
+							uint8_t b[64];
+							uint8_t get8(uint32_t i) const { return b[i]; }
+							void set8(uint32_t i, uint8_t v) { b[i] = v; }
+							void set32(uint32_t di, uint32_t v) { memcpy(b + 4 * di, &v, 4); }
+							void store16(uint8_t *dst, uint32_t g) const { memcpy(dst, b + 16 * g, 16); }
+						};
+						std::vector<uint8_t> o3(n + 200, 0x55);
+						uint8_t *op = o3.data() + 64 + ((shape * 7 + (int)n + 13 * mo) % 64);
+						ssv::LineOut<CpuLine> lo;
+						lo.out = op; lo.a0 = (uint32_t)((uintptr_t)op & 63); lo.flushed = 0; memset(lo.line.b, 0xCC, 64);
+						int rc3 = ssv::inflate_stream_to(c.data(), clen, lo, (uint32_t)n, tab);
+						if (!(rc3 == ssv::INF_OK && memcmp(op, d.data(), n) == 0 && op[n] == 0x55 && op[-1] == 0x55)) { same = false; fprintf(stderr, "LINE sink: "); }
+					}
+					{ // the second copy routine (unaligned dword moves)
+						std::vector<uint8_t> o2(n + 8, 0x55);
+						int rc2 = ssv::inflate_stream<ssv::PlainTab, true>(c.data(), clen, o2.data(), (uint32_t)n, tab);
+						if (!(rc2 == ssv::INF_OK && memcmp(o2.data(), d.data(), n) == 0 && o2[n] == 0x55)) same = false;
+					}
 					if (same) ++n_ok;
 					else { ++n_bad; fprintf(stderr, "MISMATCH shape %d n %zu level %d strategy %d rc %d\n", shape, n, level, strategy, rc); }
 					// the same stream through the ring machine, at every misalignment of input and output, in several ring geometries
