@@ -32,11 +32,11 @@ constexpr uint32_t BD_NONE = 0xffffffffu;
 // = 356 B per lane, 22,784 B per wavefront: seven wavefronts per CU (the u16 table + lengths + offsets of the first version: three).
 // The code lengths and the running offsets are only touched while a block header is parsed: they live in global scratch, same
 // interleaving (coalesced 64-byte rows).
-struct LdsTab {
+template <int STRIDE> struct LdsTabT {
 	uint8_t *lit8; uint32_t *hi; uint8_t *dst8;  // LDS
 	uint8_t *len8; uint16_t *off16;              // global scratch of this wavefront: 320 x stride bytes, 16 x stride halves
 	int lane;
-	int stride = 64;                             // lanes that decode in this wavefront (element i of lane l at [i * stride + l])
+	static constexpr int stride = STRIDE;        // lanes that decode in this wavefront (element i of lane l at [i * stride + l])
 	__device__ __forceinline__ uint16_t lit_get(int i) const { return (uint16_t)(lit8[i * stride + lane] | (((hi[(i >> 5) * stride + lane] >> (i & 31)) & 1u) << 8)); }
 	__device__ __forceinline__ void lit_set(int i, uint16_t v)
 	{
@@ -51,6 +51,7 @@ struct LdsTab {
 	__device__ __forceinline__ uint16_t off_get(int i) const { return off16[i * stride + lane]; }
 	__device__ __forceinline__ void off_set(int i, uint16_t v) { off16[i * stride + lane] = v; }
 };
+using LdsTab = LdsTabT<64>;
 
 constexpr int INFLATE_LDS_BYTES = 288 * 64 + 9 * 64 * 4 + 32 * 64;      // 22,784 B per wavefront
 constexpr int INFLATE_SCRATCH_BYTES = 320 * 64 + 16 * 64 * 2;           // global scratch per wavefront
@@ -65,8 +66,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict
 {
 	extern __shared__ uint8_t lds_raw[];
 	if ((int)threadIdx.x >= LPW) return;
-	LdsTab tab;
-	tab.stride = LPW;
+	LdsTabT<LPW> tab;
 	tab.lit8 = lds_raw;
 	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
 	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict
 	if (b >= n_blocks) return;
 	const BgzfBlock blk = blocks[b];
 	int rc = INF_OK;
-	if (blk.u_len) rc = inflate_stream<LdsTab, COPY2>(comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tab);
+	if (blk.u_len) rc = inflate_stream<LdsTabT<LPW>, COPY2>(comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tab);
 	status[b] = rc;
 }
 
@@ -98,8 +98,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate_wc(const uint8_t *__restr
 {
 	extern __shared__ uint8_t lds_raw[];
 	if ((int)threadIdx.x >= LPW) return;
-	LdsTab tab;
-	tab.stride = LPW;
+	LdsTabT<LPW> tab;
 	tab.lit8 = lds_raw;
 	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
 	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;

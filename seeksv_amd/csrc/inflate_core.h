@@ -50,7 +50,13 @@ struct BitReader {
 	SSV_HD BitReader(const uint8_t *in, uint32_t in_len) : p(in), lim(in + in_len + 4) { fetch(); }
 	// a damaged or crafted stream can ask for more input than it has: past the end it is fed zero bits (which every path of the decoder
 	// turns into an error or into output that hits the output bound) instead of whatever lies behind the buffer
-	SSV_HD void fetch() { if (p < lim) memcpy(&ahead, p, 4); else ahead = 0; }
+	SSV_HD void fetch() // (no branch around the load: it is on every symbol's path)
+	{
+		const bool in = p < lim;
+		uint32_t v;
+		memcpy(&v, in ? p : lim - 4, 4); // lim - 4 = the stream's end: readable (the buffers keep spare bytes behind the last stream)
+		ahead = in ? v : 0u;
+	}
 	SSV_HD void refill() // afterwards bc >= 32 (looks up to 8 bytes past the data: buffers are padded)
 	{
 		if (bc < 32) {
