@@ -11,7 +11,8 @@ Every rank owns a contiguous slice of the records = a contiguous reference inter
 """
 import numpy as np
 
-HALO_BP = 1000  # >= read length + the longest deletion / ref-skip a clipped read can carry
+HALO_MIN_BP = 1000  # the halo is at least this long; it must reach the longest reference span a clipped read can carry (a '3' event's
+                    # breakpoint is its read's start + span): shard_plan takes it from the workload's max_ref_span and refuses less
 
 
 def shard_plan(workload, rank, world):
@@ -20,7 +21,9 @@ def shard_plan(workload, rank, world):
     per = (per + 7) // 8 * 8                       # keeps sub-batch pointers 16-byte aligned
     lo, hi = min(rank * per, n), min((rank + 1) * per, n)
     spacing = workload.cfg.spacing_fp / float(1 << 20)
-    halo = int(np.ceil(HALO_BP / max(spacing, 1e-9)))
+    halo_bp = max(HALO_MIN_BP, 2 * int(getattr(workload, "max_ref_span", 0)) + 16)
+    assert halo_bp > int(getattr(workload, "max_ref_span", 0)), "the halo must cover the longest reference span of a read"
+    halo = int(np.ceil(halo_bp / max(spacing, 1e-9)))
     halo = (halo + 7) // 8 * 8
     scan_lo = max(0, lo - halo) if rank > 0 else 0
 
