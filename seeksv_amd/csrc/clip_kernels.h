@@ -179,6 +179,7 @@ struct ClipCounters {
 	int max_lq, max_ncig;
 	int overflow;
 	int l_unsorted;                  // the '5' events did not come out in key order (unsorted input): the full sort takes over
+	int r_unsorted;                  // the '3' events are further from key order than the two-pass tile sort repairs: the radix sort takes over
 };
 
 // K1 clip_scan arguments: the streaming pass only needs n_cigar

@@ -22,6 +22,7 @@
 #include "realign_kernels.h"
 #include "clip_kernels.h"
 #include "table3_kernels.h"
+#include "tile_sort.h"
 #include "common.h"
 #include "getsv_kernels.h"
 #include "radix_sort.h"
@@ -758,11 +759,15 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		if (EL > 1) k_check_sorted<<<grid_for(EL, BLOCK), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, &dc->l_unsorted);
 		if (EL > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(EL, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, &dc->max_key);
 		if (ER > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(ER, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_r[0]), ER, &dc->max_key);
+		// the '3' list is sorted up to small displacements: one windowed rank pass, checked (tile_sort.h); SSV_RADIX_ONLY=1 skips the attempt
+		static const bool radix_only = getenv("SSV_RADIX_ONLY") != nullptr;
+		if (ER > 0) { CHECK(ensure(c, c->key_r[1], ER * 8)); CHECK(ensure(c, c->val_r[1], ER * 4)); }
+		if (ER > 0 && !radix_only) HIPCHECK(c, sort_nearly_sorted(c->st, P<uint64_t>(c->key_r[0]), P<uint32_t>(c->val_r[0]), P<uint64_t>(c->key_r[1]), P<uint32_t>(c->val_r[1]), ER, &dc->r_unsorted));
 		uint32_t *h_seen = reinterpret_cast<uint32_t *>(P<uint8_t>(c->h_totals) + 64);
 		if (c->table_mode >= 2) {
 			// first guess of the table's quality alphabet: the qualities of the first events
 			HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
-			const int64_t ns = std::min<int64_t>(E, 16384);
+			const int64_t ns = std::min<int64_t>(E, 4096); // (a value missed here is caught while packing, at the price of packing twice)
 			k_qual_sample<<<grid_for(ns, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ev, P<uint32_t>(c->ev_idx), ns, P<uint32_t>(c->qual_seen));
 			HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
 		}
@@ -773,9 +778,8 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		while (key_bits < 64 && (max_key >> key_bits)) ++key_bits;
 		CHECK(ensure(c, c->keys2[0], E * 8)); CHECK(ensure(c, c->evs, (size_t)E * sizeof(ClipEvent)));
 		if (!hc->l_unsorted) {
-			int rcur = 0;
-			if (ER > 0) {
-				CHECK(ensure(c, c->key_r[1], ER * 8)); CHECK(ensure(c, c->val_r[1], ER * 4));
+			int rcur = ER > 0 && !radix_only && !hc->r_unsorted ? 1 : 0;
+			if (ER > 0 && rcur == 0) {
 				const int64_t nt = rs_tiles(ER);
 				CHECK(ensure(c, c->ghist, 256 * nt * 4));
 				CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(256 * nt) * 4));

@@ -478,3 +478,38 @@ def test_pileup_ring_grows_with_a_later_long_read(ctx):
     assert 7800 < int(opd.max()) < 8100
     plan.close()
     hdr.close()
+
+
+@pytest.mark.parametrize("far", [False, True])
+def test_right_clip_list_sort_paths(ctx, far):
+    """the '3' events of a sorted BAM are nearly in key order (key = alignment end): 6000 right-clipped reads whose ends run backwards inside
+    windows of a few dozen reads are repaired by the windowed rank pass (tile_sort.h); with one read whose 2 Mb `N` skip throws its event
+    5000 places back the check fails and the radix sort takes over - both equal the oracle"""
+    n, lq = 6000, 60
+    rng = np.random.RandomState(11)
+    pos = np.sort(rng.randint(1000, 3_000_000, n)).astype(np.int32)
+    pos = np.maximum.accumulate(pos)
+    clip = rng.randint(5, 25, n)
+    m = lq - clip
+    dele = rng.randint(0, 60, n)                                   # a deletion: the end moves by up to 60 bp
+    cig, coff = [], []
+    for i in range(n):
+        coff.append(len(cig))
+        if i == 7 and far:
+            cig += [(20 << 4) | 0, (2_000_000 << 4) | 3, ((int(m[i]) - 20) << 4) | 0, (int(clip[i]) << 4) | 4]
+        else:
+            cig += [(20 << 4) | 0, (int(dele[i]) << 4) | 2, ((int(m[i]) - 20) << 4) | 0, (int(clip[i]) << 4) | 4]
+    ncig = np.full(n, 4, np.uint16)
+    bases = rng.randint(0, 4, (n, lq))
+    packed = ((1 << bases[:, 0::2]) << 4 | (1 << bases[:, 1::2])).astype(np.uint8)
+    qual = rng.choice([11, 25, 37], (n, lq)).astype(np.uint8)
+    entry = np.concatenate([packed, qual], axis=1)
+    b = dict(tid=np.zeros(n, np.int32), pos=pos, flag=np.full(n, 99, np.uint16), mapq=np.full(n, 60, np.uint8), n_cigar=ncig, l_qseq=np.full(n, lq, np.int32),
+             mtid=np.zeros(n, np.int32), mpos=pos + 200, isize=np.full(n, 260, np.int32), xc=np.zeros(n, np.uint8), cigar=np.array(cig, np.uint32),
+             cigar_off=np.array(coff, np.uint32), seq_off=(np.arange(n) * entry.shape[1]).astype(np.uint64),
+             seqqual=np.concatenate([entry.reshape(-1), np.zeros(16, np.uint8)]), max_ref_span=2_000_100 if far else 200)
+    want = O.getclip([b])
+    assert want["n_events"] == n and np.all(want["side"] == ord("3"))
+    ends = pos.astype(np.int64) + 20 + dele + (m - 20)
+    assert np.any(np.diff(ends) < 0)                               # the list really is out of key order
+    assert_tables_equal(ctx.getclip([b]), want)
