@@ -31,14 +31,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # achieved = 40 B x records / (sum of the kernels' time).
 PATH_BYTES_PER_RECORD = 40.0
 # HBM bytes each kernel group must move per unit with the implemented algorithm; unit = what the group's launches process.
-#   clip_scan   : n_cigar 2 per record - only records with >= 2 CIGAR ops (~3 %) can carry a usable soft clip and go on             = 2 B/record
+#   clip_scan   : cigar_ends 1 per record - only records with an S at either end of the CIGAR (~1 %) go on (without that column:
+#                 n_cigar 2 per record, ~3 % go on)                                                                                   = 1 B/record
 #   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                                   = 8 B/record
 #   clip_place  : per candidate: staged index 4 + 4, record line 64, count 1; per event (0.31 per candidate): line 64 + staged key 16 written,
 #                 staged key 16 read, side-list key 12 + (l_qseq, n_cigar) 8 + slot 4 written                                        = 110 B/candidate
-#   event_sort  : '3' events (half): 5 radix passes x (8 histogram read + 12 read + 12 written); all: key 12 + line 64 read, 8 + 64 written = 230 B/event
-#   cluster_pack: per sorted slot: line 32 + 9, sizes 16 (meta); two scans 48; line 64 + 30, row 42 + descriptor 32 + CIGAR 10 (cols);
-#                 descriptor 32 + read 228 + block 132 (strings)                                                                      = 675 B/slot
-ALGO_BYTES = {"clip_scan": 2.0, "getsv_scan": 8.0, "clip_place": 110.0, "event_sort": 230.0, "cluster_pack": 675.0}
+#   event_sort  : '3' events (half): one windowed rank pass (12 read + 12 written + check 12); all: key 12 + line 64 read, 8 + 64 written = 166 B/event
+#   cluster_pack: per sorted slot: line 32 + 9, sizes 16 (meta); two scans 48; line 64 + 30, row 12 + descriptor 32 + CIGAR 10 (cols);
+#                 descriptor 32 + read 228 + block 100 (strings)                                                                      = 613 B/slot
+ALGO_BYTES = {"clip_scan": 1.0, "getsv_scan": 8.0, "clip_place": 110.0, "event_sort": 166.0, "cluster_pack": 613.0}
 DEVICE_GROUPS = ("clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish")
 
 
@@ -310,7 +311,7 @@ def main():
                                    f"genome_frac {args.genome_frac:g}, {n_own} records/GPU resident in HBM",
                        "records_total": total_records, "records_per_gpu": n_own, "junctions": len(w.junctions), "parallelism": f"range-partition x{world}",
                        "multi_gpu": "weak scaling: 30x per GPU over the same genome (N GPUs = 30N x), not BASELINE config 4's fixed 300x BAM split N ways",
-                       "batch_layout": "hot columns tid/pos/n_cigar + one 64-byte line per record (ssv_record) + CIGARs + packed bases/qualities of soft-clipped records; SSV_MEM_PERSISTENT",
+                       "batch_layout": "hot columns tid/pos/n_cigar + cigar_ends (a one-byte copy of the first and last CIGAR operation codes: the getclip stream reads it instead of n_cigar and applies the soft-clip test to every record) + one 64-byte line per record (ssv_record) + CIGARs + packed bases/qualities of soft-clipped records; SSV_MEM_PERSISTENT",
                        "generation_s": round(gen_s, 2)},
             "roofline": {"kernel": "path: all device kernels of one step (getclip + insert size + getsv passes; PCIe copy excluded)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": total_traffic,

@@ -30,7 +30,7 @@ class Batch(C.Structure):
         ("isize", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("xc", C.c_void_p),
         ("seq_off", C.c_void_p), ("seqqual", C.c_void_p),
         ("n_cigar_total", C.c_int64), ("seqqual_bytes", C.c_int64),
-        ("rec", C.c_void_p),
+        ("rec", C.c_void_p), ("cigar_ends", C.c_void_p),
     ]
 
 
@@ -38,6 +38,7 @@ BATCH_FIELDS = [  # (name, numpy dtype) in struct order
     ("tid", np.int32), ("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("n_cigar", np.uint16),
     ("l_qseq", np.int32), ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32),
     ("cigar_off", np.uint32), ("cigar", np.uint32), ("xc", np.uint8), ("seq_off", np.uint64), ("seqqual", np.uint8),
+    ("cigar_ends", np.uint8),   # optional (after `rec` in the struct)
 ]
 
 
@@ -157,6 +158,8 @@ def batch_to_arrays(b):
     for name, dt in BATCH_FIELDS:
         cnt = sizes.get(name, n)
         ptr = getattr(b, name)
+        if not ptr and name == "cigar_ends":
+            continue                    # an optional column that is not there stays out (zeros would say "no soft clips")
         if not ptr or cnt == 0:
             out[name] = np.zeros(cnt, dtype=dt)
             continue

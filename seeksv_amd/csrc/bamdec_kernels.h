@@ -451,6 +451,7 @@ struct RecColumns {
 	int32_t *tid, *pos, *l_qseq, *mtid, *mpos, *isize;
 	uint16_t *flag, *n_cigar;
 	uint8_t *mapq, *xc;
+	uint8_t *ends;        // first | last << 4 CIGAR operation codes (ssv_batch_t.cigar_ends)
 	uint32_t *seq_bytes;  // bytes of packed bases + qualities to ship (0 when not shipped)
 	uint32_t *raw_bytes;  // 4 + block_size for UNMAP|MUNMAP records (else 0)
 	int32_t *max_span;    // one int: largest reference span (atomicMax)
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(BLOCK) void k_record_fields(const uint8_t *__restri
 		c.mtid[i] = ld_i32(r + 20); c.mpos[i] = ld_i32(r + 24); c.isize[i] = ld_i32(r + 28);
 		const uint64_t o_cig = 32ull + l_name, need = o_cig + 4ull * ncig + ((uint64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (uint64_t)(l_seq < 0 ? 0 : l_seq);
 		bool soft = false;
+		uint32_t ends = 0xffu;
 		if (l_seq < 0 || need > bs) { *c.bad = 1; c.seq_bytes[i] = 0; c.raw_bytes[i] = 0; c.n_cigar[i] = 0; }
 		else {
 			int s = 0;
@@ -478,11 +480,14 @@ __global__ __launch_bounds__(BLOCK) void k_record_fields(const uint8_t *__restri
 				const uint32_t t = op & 15u;
 				if (t == 0 || t == 2 || t == 3 || t == 7 || t == 8) s += (int)(op >> 4);
 				if ((k == 0 || k == ncig - 1) && t == 4) soft = true;
+				if (k == 0) ends = t | (t << 4);
+				if (k == ncig - 1) ends = (ends & 15u) | (t << 4);
 			}
 			if (s > span) span = s;
 			c.seq_bytes[i] = (soft || keep_all_seq) ? (uint32_t)(((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq) : 0u;
 			c.raw_bytes[i] = (flag & (F_UNMAP | F_MUNMAP)) ? 4u + bs : 0u;
 		}
+		c.ends[i] = (uint8_t)ends;
 		c.xc[i] = soft ? 2 : 0; // 2 = "soft clipped, aux not looked at yet": k_record_payload turns it into the XC flag
 	}
 	span = wave_max(span);

@@ -24,6 +24,7 @@ struct DevBatch {
 	int64_t n;
 	const int32_t *tid, *pos;   // hot columns (streamed)
 	const uint16_t *n_cigar;    // hot column (streamed)
+	const uint8_t *ends;        // hot column, optional: first | last << 4 CIGAR operation codes (ssv_batch_t.cigar_ends)
 	const ssv_record *rec;      // cold fields, one line per record
 	const uint32_t *cigar;      // all operations (a line holds the first five)
 	const uint8_t *seqqual;
@@ -185,6 +186,7 @@ struct ClipCounters {
 // K1 clip_scan arguments: the streaming pass only needs n_cigar
 struct ClipScanArgs {
 	const uint16_t *n_cigar;
+	const uint8_t *ends;     // when given, the pass reads this column instead (k_clip_scan_ends)
 	int64_t n;
 	uint32_t *tile_cnt;      // [ntiles] candidates per tile
 	uint32_t *tile_off;      // [ntiles] where the tile's candidates sit in stage[]
@@ -380,6 +382,65 @@ __global__ __launch_bounds__(BLOCK) void k_clip_scan(ClipScanArgs a)
 		stage_tile_candidates<CC_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, a.block_cap, a.tile_cnt, a.tile_off, a.stage, a.overflow);
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) v[sub] = nxt[sub];
+	}
+}
+
+// The same pass over the `cigar_ends` column (when the batch has one): 1 B/record, sixteen records per 16-byte load, two loads per lane
+// and tile (the same 8192-record tiles); a record goes on when the code of its first or of its last CIGAR operation is S - the soft-clip
+// test of GetSClipReads (clip_reads.cpp:124,150) applied to every record here instead of to the records with two or more operations later.
+constexpr int CE_ITEMS = 16, CE_SUB = 2;
+static_assert(BLOCK * CE_ITEMS * CE_SUB == CC_TILE, "both forms of the clip scan use the same tiles");
+
+__device__ __forceinline__ void clip_scan_ends_load(const ClipScanArgs &a, int64_t tile, uint4 (&v)[CE_SUB])
+{
+	const int64_t t0 = tile * CC_TILE + (int64_t)threadIdx.x * CE_ITEMS;
+	if ((tile + 1) * CC_TILE <= a.n) {
+#pragma unroll
+		for (int sub = 0; sub < CE_SUB; ++sub) v[sub] = stream_load_u4(a.ends + t0 + (int64_t)sub * (BLOCK * CE_ITEMS));
+	} else {
+#pragma unroll
+		for (int sub = 0; sub < CE_SUB; ++sub) {
+			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CE_ITEMS);
+			uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (int k = 0; k < CE_ITEMS; ++k) w[k >> 2] |= (i0 + k < a.n ? (uint32_t)a.ends[i0 + k] : 0u) << (8 * (k & 3));
+			v[sub] = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+	}
+}
+
+// bit k of the result: byte k of w has the code 4 (S) in its low or in its high nibble
+__device__ __forceinline__ uint32_t ends_have_s(uint32_t w)
+{
+	const uint32_t x = w ^ 0x44444444u;                                  // a nibble that was 4 is 0 now
+	const uint32_t z = ~(((x & 0x77777777u) + 0x77777777u) | x | 0x77777777u); // bit 3 of every zero nibble (exact, no borrows)
+	const uint32_t y = ((z | (z >> 4)) >> 3) & 0x01010101u;              // bit 0 of every byte with such a nibble
+	return (y * 0x01020408u) >> 24;                                      // gathered into four bits
+}
+
+__global__ __launch_bounds__(BLOCK) void k_clip_scan_ends(ClipScanArgs a)
+{
+	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
+	uint32_t cursor = 0;
+	int parity = 0;
+	const int64_t region = (int64_t)blockIdx.x * a.block_cap;
+	uint4 v[CE_SUB], nxt[CE_SUB];
+	if ((int64_t)blockIdx.x < a.ntiles) clip_scan_ends_load(a, blockIdx.x, v);
+	for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
+		const int64_t t0 = tile * CC_TILE + (int64_t)threadIdx.x * CE_ITEMS;
+		const int64_t next = tile + gridDim.x;
+		if (next < a.ntiles) clip_scan_ends_load(a, next, nxt);
+		uint32_t mask = 0;
+		uint64_t packed = 0;
+#pragma unroll
+		for (int sub = 0; sub < CE_SUB; ++sub) {
+			const uint32_t bits = ends_have_s(v[sub].x) | (ends_have_s(v[sub].y) << 4) | (ends_have_s(v[sub].z) << 8) | (ends_have_s(v[sub].w) << 12);
+			mask |= bits << (sub * CE_ITEMS);
+			packed += (uint64_t)__popc(bits) << (16 * sub);
+		}
+		stage_tile_candidates<CE_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, a.block_cap, a.tile_cnt, a.tile_off, a.stage, a.overflow);
+#pragma unroll
+		for (int sub = 0; sub < CE_SUB; ++sub) v[sub] = nxt[sub];
 	}
 }
 

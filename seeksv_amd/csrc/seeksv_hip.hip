@@ -121,7 +121,7 @@ struct ssv_ctx {
 	// staging of host batches, and the record lines built for batches that come without them
 	// host batches are copied into one of three staging sets: 0 and 1 take the batches announced with ssv_batch_prefetch (copied on st_h2d while
 	// the kernels of the batch before run on st), 2 the ones that come unannounced (copied on st itself)
-	struct StageSet { DBuf col[14], rec; hipEvent_t ready = nullptr; } ss[3];
+	struct StageSet { DBuf col[15], rec; hipEvent_t ready = nullptr; } ss[3];
 	struct Prefetched { ssv_batch_t b; int set; };
 	std::deque<Prefetched> pf;
 	uint64_t pf_count = 0;
@@ -343,11 +343,12 @@ static int upload_host_batch(ssv_ctx *c, const ssv_batch_t *b, int set, hipStrea
 {
 	const size_t n = (size_t)b->n;
 	ssv_ctx::StageSet &S = c->ss[set];
-	struct { const void *src; size_t bytes; } f[14] = {
+	struct { const void *src; size_t bytes; } f[15] = {
 		{b->tid, n * 4}, {b->pos, n * 4}, {b->rec ? nullptr : b->flag, n * 2}, {b->rec ? nullptr : b->mapq, n}, {b->n_cigar, n * 2}, {b->rec ? nullptr : b->l_qseq, n * 4},
 		{b->rec ? nullptr : b->mtid, n * 4}, {b->rec ? nullptr : b->mpos, n * 4}, {b->rec ? nullptr : b->isize, n * 4}, {b->rec ? nullptr : b->cigar_off, n * 4},
-		{b->cigar, (size_t)b->n_cigar_total * 4}, {b->rec ? nullptr : b->xc, b->xc ? n : 0}, {b->rec ? nullptr : b->seq_off, n * 8}, {b->seqqual, (size_t)b->seqqual_bytes}};
-	for (int k = 0; k < 14; ++k) {
+		{b->cigar, (size_t)b->n_cigar_total * 4}, {b->rec ? nullptr : b->xc, b->xc ? n : 0}, {b->rec ? nullptr : b->seq_off, n * 8}, {b->seqqual, (size_t)b->seqqual_bytes},
+		{b->cigar_ends, n}};
+	for (int k = 0; k < 15; ++k) {
 		if (!f[k].src) continue;
 		CHECK(ensure(c, S.col[k], f[k].bytes + 16));
 		if (f[k].bytes) HIPCHECK(c, hipMemcpyAsync(S.col[k].p, f[k].src, f[k].bytes, hipMemcpyHostToDevice, st));
@@ -363,6 +364,7 @@ static void staged_view(ssv_ctx *c, const ssv_batch_t *b, int set, DevBatch &d, 
 {
 	ssv_ctx::StageSet &S = c->ss[set];
 	d.tid = P<int32_t>(S.col[0]); d.pos = P<int32_t>(S.col[1]); d.n_cigar = P<uint16_t>(S.col[4]); d.cigar = P<uint32_t>(S.col[10]); d.seqqual = P<uint8_t>(S.col[13]);
+	d.ends = b->cigar_ends ? P<uint8_t>(S.col[14]) : nullptr;
 	d.rec = P<ssv_record>(S.rec);
 	s.tid = d.tid; s.pos = d.pos; s.flag = P<uint16_t>(S.col[2]); s.mapq = P<uint8_t>(S.col[3]); s.n_cigar = d.n_cigar; s.l_qseq = P<int32_t>(S.col[5]); s.mtid = P<int32_t>(S.col[6]);
 	s.mpos = P<int32_t>(S.col[7]); s.isize = P<int32_t>(S.col[8]); s.cigar_off = P<uint32_t>(S.col[9]); s.cigar = d.cigar; s.xc = b->xc ? P<uint8_t>(S.col[11]) : nullptr;
@@ -392,7 +394,8 @@ int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
 		if (!aligned16(b->tid) || !aligned16(b->pos) || !aligned16(b->n_cigar) || (b->rec && !aligned64(b->rec))) {
 			c->err = "device batch arrays must be 16-byte aligned (rec: 64-byte aligned)"; return SSV_E_ARG;
 		}
-		d.tid = b->tid; d.pos = b->pos; d.n_cigar = b->n_cigar; d.cigar = b->cigar; d.seqqual = b->seqqual; d.rec = b->rec;
+		if (b->cigar_ends && !aligned16(b->cigar_ends)) { c->err = "device batch arrays must be 16-byte aligned (rec: 64-byte aligned)"; return SSV_E_ARG; }
+		d.tid = b->tid; d.pos = b->pos; d.n_cigar = b->n_cigar; d.cigar = b->cigar; d.seqqual = b->seqqual; d.rec = b->rec; d.ends = b->cigar_ends;
 		if (d.rec || n == 0) return SSV_OK;
 		s.tid = b->tid; s.pos = b->pos; s.flag = b->flag; s.mapq = b->mapq; s.n_cigar = b->n_cigar; s.l_qseq = b->l_qseq; s.mtid = b->mtid; s.mpos = b->mpos; s.isize = b->isize;
 		s.cigar_off = b->cigar_off; s.cigar = b->cigar; s.xc = b->xc; s.seq_off = b->seq_off;
@@ -628,12 +631,12 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 		CHECK(ensure(c, c->stage, (size_t)block_cap * grid * 4));
 		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
 		ClipScanArgs a;
-		a.n_cigar = d.n_cigar; a.n = d.n;
+		a.n_cigar = d.n_cigar; a.ends = d.ends; a.n = d.n;
 		a.tile_cnt = P<uint32_t>(c->tile_cnt); a.tile_off = P<uint32_t>(c->tile_off); a.stage = P<uint32_t>(c->stage); a.block_cap = block_cap;
 		a.overflow = &dc->overflow; a.ntiles = ntiles;
 		{
 			ProfScope ps(c, P_CLIP_SCAN, d.n);
-			k_clip_scan<<<grid, BLOCK, 0, c->st>>>(a);
+			if (a.ends) k_clip_scan_ends<<<grid, BLOCK, 0, c->st>>>(a); else k_clip_scan<<<grid, BLOCK, 0, c->st>>>(a);
 		}
 		HIPCHECK(c, hipGetLastError());
 		// order across tiles: exclusive scan of the tile counts; its total is the number of candidates

@@ -34,7 +34,7 @@ __global__ void k_sy_fix(int64_t n, const uint32_t *seq_bytes, uint64_t *seq_off
 }
 
 __global__ void k_sy_fill(sy_config cfg, const sy_breakend *be, int64_t g0, int64_t n, int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *mapq, int32_t *l_qseq,
-                          int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar, const uint64_t *seq_off, uint8_t *seqqual, uint4 *rec)
+                          int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar, const uint64_t *seq_off, uint8_t *seqqual, uint4 *rec, uint8_t *ends)
 {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -48,6 +48,7 @@ __global__ void k_sy_fill(sy_config cfg, const sy_breakend *be, int64_t g0, int6
 	if (mpos) mpos[i] = r.mpos;
 	if (isize) isize[i] = r.isize;
 	for (int k = 0; k < r.n_cigar; ++k) cigar[cigar_off[i] + k] = r.cigar[k];
+	if (ends) ends[i] = r.n_cigar ? (uint8_t)((r.cigar[0] & 15u) | ((r.cigar[r.n_cigar - 1] & 15u) << 4)) : (uint8_t)0xff;
 	if (r.has_seq) sy_fill_seq(&cfg, be, g0 + i, &r, seqqual + seq_off[i]);
 	if (rec) {
 		uint32_t w[16];
@@ -103,11 +104,11 @@ int ssvs_plan(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n
 
 int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n, int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *mapq,
               const uint16_t *n_cigar, int32_t *l_qseq, int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar,
-              const uint64_t *seq_off, uint8_t *seqqual, void *rec)
+              const uint64_t *seq_off, uint8_t *seqqual, void *rec, uint8_t *cigar_ends)
 {
 	(void)n_cigar;
 	if (n <= 0) return 0;
-	k_sy_fill<<<(unsigned)((n + 255) / 256), 256, 0, nullptr>>>(*cfg, be, g0, n, tid, pos, flag, mapq, l_qseq, mtid, mpos, isize, cigar_off, cigar, seq_off, seqqual, reinterpret_cast<uint4 *>(rec));
+	k_sy_fill<<<(unsigned)((n + 255) / 256), 256, 0, nullptr>>>(*cfg, be, g0, n, tid, pos, flag, mapq, l_qseq, mtid, mpos, isize, cigar_off, cigar, seq_off, seqqual, reinterpret_cast<uint4 *>(rec), cigar_ends);
 	SY_CHECK(hipGetLastError());
 	SY_CHECK(hipDeviceSynchronize());
 	return 0;

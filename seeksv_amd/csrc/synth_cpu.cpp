@@ -28,7 +28,7 @@ int ssvs_plan(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n
 
 int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n, int32_t *tid, int32_t *pos, uint16_t *flag, uint8_t *mapq,
               const uint16_t *n_cigar, int32_t *l_qseq, int32_t *mtid, int32_t *mpos, int32_t *isize, const uint32_t *cigar_off, uint32_t *cigar,
-              const uint64_t *seq_off, uint8_t *seqqual, void *rec)
+              const uint64_t *seq_off, uint8_t *seqqual, void *rec, uint8_t *cigar_ends)
 {
 	(void)n_cigar;
 	for (int64_t i = 0; i < n; ++i) {
@@ -42,6 +42,7 @@ int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n
 		if (mpos) mpos[i] = r.mpos;
 		if (isize) isize[i] = r.isize;
 		for (int k = 0; k < r.n_cigar; ++k) cigar[cigar_off[i] + k] = r.cigar[k];
+		if (cigar_ends) cigar_ends[i] = r.n_cigar ? (uint8_t)((r.cigar[0] & 15u) | ((r.cigar[r.n_cigar - 1] & 15u) << 4)) : (uint8_t)0xff;
 		if (r.has_seq) sy_fill_seq(cfg, be, g0 + i, &r, seqqual + seq_off[i]);
 		if (rec) sy_fill_line(&r, cigar_off[i], seq_off[i], reinterpret_cast<uint32_t *>(rec) + 16 * i);
 	}

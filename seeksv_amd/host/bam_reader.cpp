@@ -407,11 +407,11 @@ struct ssvh_bam {
 	struct BatchBuf {
 		Col<int32_t> tid, pos, l_qseq, mtid, mpos, isize;
 		Col<uint16_t> flag, n_cigar;
-		Col<uint8_t> mapq, xc, seqqual;
+		Col<uint8_t> mapq, xc, seqqual, ends;
 		Col<uint32_t> cigar_off, cigar;
 		Col<uint64_t> seq_off;
 		std::vector<Unmapped> unmapped;
-		void use(const HostAlloc *a) { tid.a = pos.a = l_qseq.a = mtid.a = mpos.a = isize.a = a; flag.a = n_cigar.a = a; mapq.a = xc.a = seqqual.a = a; cigar_off.a = cigar.a = a; seq_off.a = a; }
+		void use(const HostAlloc *a) { tid.a = pos.a = l_qseq.a = mtid.a = mpos.a = isize.a = a; flag.a = n_cigar.a = a; mapq.a = xc.a = seqqual.a = ends.a = a; cigar_off.a = cigar.a = a; seq_off.a = a; }
 	} buf[3];
 	HostAlloc alloc;
 	int cur = 0;
@@ -651,7 +651,7 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 	const uint8_t *base = z.ubuf.data();
 	// ---- pass 1 (parallel over record ranges, header fields only): sizes of the variable-length parts, then their prefix ----
 	B.tid.resize((size_t)n); B.pos.resize((size_t)n); B.l_qseq.resize((size_t)n); B.mtid.resize((size_t)n); B.mpos.resize((size_t)n); B.isize.resize((size_t)n);
-	B.flag.resize((size_t)n); B.n_cigar.resize((size_t)n); B.mapq.resize((size_t)n); B.xc.resize((size_t)n); B.cigar_off.resize((size_t)n); B.seq_off.resize((size_t)n);
+	B.flag.resize((size_t)n); B.n_cigar.resize((size_t)n); B.mapq.resize((size_t)n); B.xc.resize((size_t)n); B.ends.resize((size_t)n); B.cigar_off.resize((size_t)n); B.seq_off.resize((size_t)n);
 	const int nt = (int)std::min<int64_t>(std::max<int64_t>(1, n / 8192), 128);
 	std::vector<uint64_t> c_of((size_t)nt + 1, 0), s_of((size_t)nt + 1, 0);
 	std::atomic<int> bad{0};
@@ -709,6 +709,7 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 			for (unsigned k = 0; k < ncig; ++k) { unsigned op = cd[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += cd[k] >> 4; }
 			if (span > max_span) max_span = span;
 			const bool soft = ncig && ((cd[0] & 15) == 4 || (cd[ncig - 1] & 15) == 4);
+			B.ends[(size_t)i] = ncig ? (uint8_t)((cd[0] & 15u) | ((cd[ncig - 1] & 15u) << 4)) : (uint8_t)0xff; // the hot copy of the CIGAR's end operations (ssv_batch_t.cigar_ends)
 			B.xc[(size_t)i] = soft ? (uint8_t)(aux_xc(r + o_aux, r + bs) != 0) : (uint8_t)0;
 			if (soft || keep_all_seq) {
 				B.seq_off[(size_t)i] = s_run;
@@ -744,7 +745,7 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 	out->tid = B.tid.data(); out->pos = B.pos.data(); out->flag = B.flag.data(); out->mapq = B.mapq.data();
 	out->n_cigar = B.n_cigar.data(); out->l_qseq = B.l_qseq.data(); out->mtid = B.mtid.data(); out->mpos = B.mpos.data();
 	out->isize = B.isize.data(); out->cigar_off = B.cigar_off.data(); out->cigar = B.cigar.data(); out->xc = B.xc.data();
-	out->seq_off = B.seq_off.data(); out->seqqual = B.seqqual.data();
+	out->seq_off = B.seq_off.data(); out->seqqual = B.seqqual.data(); out->cigar_ends = B.ends.data();
 	out->n_cigar_total = (int64_t)ctot; out->seqqual_bytes = (int64_t)stot;
 	return 0;
 }

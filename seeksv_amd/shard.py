@@ -18,13 +18,13 @@ HALO_MIN_BP = 1000  # the halo is at least this long; it must reach the longest 
 def shard_plan(workload, rank, world):
     n = workload.n_total
     per = -(-n // world)
-    per = (per + 7) // 8 * 8                       # keeps sub-batch pointers 16-byte aligned
+    per = (per + 15) // 16 * 16                    # keeps sub-batch pointers 16-byte aligned (the narrowest column is one byte per record)
     lo, hi = min(rank * per, n), min((rank + 1) * per, n)
     spacing = workload.cfg.spacing_fp / float(1 << 20)
     halo_bp = max(HALO_MIN_BP, 2 * int(getattr(workload, "max_ref_span", 0)) + 16)
     assert halo_bp > int(getattr(workload, "max_ref_span", 0)), "the halo must cover the longest reference span of a read"
     halo = int(np.ceil(halo_bp / max(spacing, 1e-9)))
-    halo = (halo + 7) // 8 * 8
+    halo = (halo + 15) // 16 * 16
     scan_lo = max(0, lo - halo) if rank > 0 else 0
 
     def coord(g):

@@ -42,7 +42,7 @@ def _lib(gpu):
         lib = C.CDLL(path)
         V = C.c_void_p
         lib.ssvs_plan.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64, V, V, V, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        lib.ssvs_fill.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64] + [V] * 14
+        lib.ssvs_fill.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64] + [V] * 15
         lib.ssvs_last_error.restype = C.c_char_p
         _synth_libs[name] = lib
     return _synth_libs[name]
@@ -231,9 +231,10 @@ class Workload:
         a["cigar"] = np.zeros(nct.value, np.uint32)
         a["seqqual"] = np.zeros(sqb.value, np.uint8)
         rec = np.zeros(n, _abi.RECORD_DTYPE) if with_rec else None
+        a["cigar_ends"] = np.zeros(n, np.uint8)
         lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, p(a["tid"]), p(a["pos"]), p(a["flag"]), p(a["mapq"]), p(a["n_cigar"]), p(a["l_qseq"]),
                       p(a["mtid"]), p(a["mpos"]), p(a["isize"]), p(a["cigar_off"]), p(a["cigar"]), p(a["seq_off"]), p(a["seqqual"]),
-                      p(rec) if with_rec else None)
+                      p(rec) if with_rec else None, p(a["cigar_ends"]))
         if with_rec:
             a["rec"] = rec
         a["xc"] = None
@@ -266,10 +267,11 @@ class Workload:
         t["cigar"] = torch.empty(max(nct.value, 4), dtype=torch.int32, device=dev)
         t["seqqual"] = torch.empty(sqb.value + 16, dtype=torch.uint8, device=dev)
         t["rec"] = torch.empty(max(n, 1) * 64, dtype=torch.uint8, device=dev)
+        t["cigar_ends"] = torch.empty(n + 16, dtype=torch.uint8, device=dev)
         ptr = lambda k: t[k].data_ptr() if k in t else None
         rc = lib.ssvs_fill(C.byref(self.cfg), bep, g0, n, ptr("tid"), ptr("pos"), ptr("flag"), ptr("mapq"),
                            ptr("n_cigar"), ptr("l_qseq"), ptr("mtid"), ptr("mpos"), ptr("isize"),
-                           ptr("cigar_off"), ptr("cigar"), ptr("seq_off"), ptr("seqqual"), ptr("rec"))
+                           ptr("cigar_off"), ptr("cigar"), ptr("seq_off"), ptr("seqqual"), ptr("rec"), ptr("cigar_ends"))
         if rc != 0:
             raise RuntimeError("ssvs_fill: " + lib.ssvs_last_error().decode())
         if not soa:  # the offsets live on in the lines

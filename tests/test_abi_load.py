@@ -23,7 +23,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ssv_abi_version() == 2
+    assert lib.ssv_abi_version() == 3
 
 
 def test_host_library_exports_every_declared_symbol():
@@ -35,7 +35,7 @@ def test_host_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_abi.Batch) == 8 + 4 + 4 + 14 * 8 + 16 + 8
+    assert C.sizeof(_abi.Batch) == 8 + 4 + 4 + 14 * 8 + 16 + 8 + 8   # ... + rec + cigar_ends
     assert _abi.RECORD_DTYPE.itemsize == 64
     assert C.sizeof(_abi.Junction) == 28
     assert C.sizeof(_abi.ClipParams) == 40

@@ -60,7 +60,7 @@ def _check_config(ctx, w):
     db, keep = w.generate_device(0, w.n_total, 0, soa=False, persistent=True)
     # ---- whole input at once, and cut into three batches at awkward places ----
     d = ctx.getclip([db])
-    cuts = [0, (w.n_total // 3 + 12345) & ~7, (2 * (w.n_total // 3) + 777) & ~7, w.n_total]   # (device arrays are used in place: 16-byte aligned starts)
+    cuts = [0, (w.n_total // 3 + 12345) & ~15, (2 * (w.n_total // 3) + 777) & ~15, w.n_total]   # (device arrays are used in place: 16-byte aligned starts, also of the one-byte column)
     d3 = ctx.getclip([_sub(db, cuts[i], cuts[i + 1] - cuts[i]) for i in range(3)])
     assert d["n_events"] == d3["n_events"] and d["n_clusters"] == d3["n_clusters"]
     assert _sha(d) == _sha(d3)

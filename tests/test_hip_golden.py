@@ -452,6 +452,7 @@ def _with_cigar(hb, k, ops):
     out["cigar"] = np.concatenate([hb["cigar"][:off[k]], new, hb["cigar"][off[k] + nc[k]:]])
     out["n_cigar"][k] = len(new)
     out["cigar_off"] = np.concatenate([[0], np.cumsum(out["n_cigar"].astype(np.int64))[:-1]]).astype(np.uint32)
+    out.pop("cigar_ends", None)   # (the optional hot copy of the CIGAR ends would be stale: without it the pass reads n_cigar)
     return out
 
 
