@@ -209,6 +209,23 @@ def crafted_getclip():
             gunzip_to(os.path.join(TMP, f"{pre}.clip.fq.gz"), os.path.join(out, f"{pre}.clip.fq.txt"))
 
 
+def lone_s_case():
+    """records whose whole CIGAR is one soft clip (`50S`) between ordinary clipped reads: the reference reads that single operation as BOTH
+    ends of the CIGAR (clip_reads.cpp:150-175: a negative "middle" length) and prints two rows with an empty aligned part for it.
+    The MI355X path emits nothing for such a record: the fixture pins that difference - all other rows are identical."""
+    out = os.path.join(HERE, "getclip")
+    seq = "ACGTTGCAAGCTTAGGCTAACGTAGCTAGGATCCGATAGCTAGCTAGGCTA"
+
+    def rec(name, pos, cigar):
+        return dict(qname=name, flag=99, tid=0, pos=pos, mapq=60, cigar=cigar, mtid=0, mpos=pos + 200, isize=300, seq=seq, qual=bytes([30] * len(seq)))
+    recs = [rec("a", 1000, "20S30M"), rec("lone1", 1500, "50S"), rec("b", 2000, "30M20S"), rec("lone2", 2500, "50S"), rec("c", 3000, "10S40M"), rec("d", 3000, "12S38M")]
+    bam = os.path.join(out, "lone_s.bam")
+    bamio.write_bam(bam, ["c1"], [100000], recs)
+    run([SEEKSV, "getclip", "-o", "lone_s", bam], cwd=TMP)
+    gunzip_to(os.path.join(TMP, "lone_s.clip.gz"), os.path.join(out, "lone_s.clip.txt"))
+    gunzip_to(os.path.join(TMP, "lone_s.clip.fq.gz"), os.path.join(out, "lone_s.clip.fq.txt"))
+
+
 # ------------------------------------------------------------------------------------------------
 # 3. getsv BAM passes through the -B junction-injection harness (SURVEY 8c)
 # ------------------------------------------------------------------------------------------------
@@ -601,8 +618,13 @@ if __name__ == "__main__":
     if not os.path.exists(SEEKSV):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     os.makedirs(TMP, exist_ok=True)
+    if len(sys.argv) > 1:   # only the named sections, e.g. `make_golden.py lone_s_case`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     example()
     crafted_getclip()
+    lone_s_case()
     crafted_getsv()
     synthetic()
     synthetic_full()

@@ -9,7 +9,7 @@ import pytest
 import golden_util as G
 import oracle_lib as O
 from seeksv_amd import _abi, host
-from test_oracle_golden import GETCLIP_CASES, GETSV_CASES
+from test_oracle_golden import GETCLIP_CASES, GETSV_CASES, lone_s_expected
 
 pytestmark = pytest.mark.gpu
 
@@ -514,3 +514,16 @@ def test_right_clip_list_sort_paths(ctx, far):
     ends = pos.astype(np.int64) + 20 + dele + (m - 20)
     assert np.any(np.diff(ends) < 0)                               # the list really is out of key order
     assert_tables_equal(ctx.getclip([b]), want)
+
+
+def test_getclip_lone_soft_clip_records(ctx):
+    """a record whose whole CIGAR is one soft clip yields no clip event here (the reference prints two rows with an empty aligned part for it):
+    everything else of tests/golden/getclip/lone_s.* is the reference's, byte for byte"""
+    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", "lone_s.bam"))
+    for fmt in (0, 3):
+        ctx.clip_table_format(fmt)
+        try:
+            d = ctx.getclip(batches)
+        finally:
+            ctx.clip_table_format(0)
+        assert host.format_clip_outputs(d, names) == lone_s_expected()

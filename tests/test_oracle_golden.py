@@ -56,6 +56,22 @@ def test_getclip_oracle_matches_reference(sub, bam, prefix, kw, batch_records):
     assert fq == G.read_text(sub, prefix + ".clip.fq.txt")
 
 
+def lone_s_expected():
+    """tests/golden/getclip/lone_s.*: the reference's rows minus the two it prints, with an empty aligned part, for every record whose whole
+    CIGAR is one soft clip (it reads that operation as both ends of the CIGAR); the documented difference"""
+    rows = [r for r in G.read_text("getclip", "lone_s.clip.txt").splitlines(True) if r.split("\t")[3] != ""]
+    fq = G.read_text("getclip", "lone_s.clip.fq.txt").split("@")[1:]
+    dropped = {r.split("\t")[6] for r in G.read_text("getclip", "lone_s.clip.txt").splitlines() if r.split("\t")[3] == ""}
+    assert len(dropped) == 2 and len(rows) == 4
+    return "".join(rows), "".join("@" + x for x in fq if x.split("\n")[0] not in dropped)
+
+
+def test_getclip_oracle_lone_soft_clip_records():
+    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", "lone_s.bam"))
+    clip, fq = host.format_clip_outputs(O.getclip(batches), names)
+    assert (clip, fq) == lone_s_expected()
+
+
 @pytest.mark.parametrize("sample", ["cancer", "normal"])
 def test_isize_oracle_matches_reference_example(sample):
     names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, "example", sample + ".sort.bam"))
