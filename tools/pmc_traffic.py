@@ -21,9 +21,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel -> group of bench.py (ssv_prof_*); the device-wide scans and fills belong to whatever named kernel ran before them
 GROUP_OF = {
-    "k_clip_scan": "clip_scan", "k_cand_place": "clip_place", "k_clip_filter": "clip_place", "k_clip_place": "clip_place", "k_event_max": "clip_place", "k_last_tid": "clip_place",
+    "k_clip_scan": "clip_scan", "k_clip_scan_ends": "clip_scan", "k_cand_place": "clip_place", "k_clip_filter": "clip_place", "k_clip_place": "clip_place", "k_event_max": "clip_place", "k_last_tid": "clip_place",
     "k_gather_sizes": "clip_gather", "k_clip_gather": "clip_gather",
-    "k_check_sorted": "event_sort", "k_key_max": "event_sort", "k_qual_sample": "event_sort", "k_rs_hist": "event_sort", "k_rs_scatter": "event_sort", "k_side_bounds": "event_sort",
+    "k_check_sorted": "event_sort", "k_check_sorted_pairs": "event_sort", "k_window_rank_sort": "event_sort", "k_key_max": "event_sort", "k_qual_sample": "event_sort", "k_rs_hist": "event_sort", "k_rs_scatter": "event_sort", "k_side_bounds": "event_sort",
     "k_merge_sides": "event_sort", "k_concat_sides": "event_sort", "k_gather_lines": "event_sort", "k_iota": "event_sort",
     "k_bin_mark": "cluster_bins", "k_multi_list": "cluster_bins", "k_bin_start_flags": "cluster_bins", "k_bin_start_list": "cluster_bins", "k_cluster_bins": "cluster_bins",
     "k_cluster_meta": "cluster_pack", "k_cluster_cols": "cluster_pack", "k_cluster_pack_stream": "cluster_pack", "k_cluster_pack_slow": "cluster_pack", "k_cluster_pack_ascii": "cluster_pack",
@@ -34,7 +34,7 @@ GROUP_OF = {
     "k_depth_prefix": "depth_finish", "k_range_sum": "depth_finish", "k_point_depth": "depth_finish",
     "k_build_rec": "h2d",
 }
-DOUBLE_FETCH = {"k_clip_scan", "k_getsv_scan"}
+DOUBLE_FETCH = {"k_clip_scan", "k_clip_scan_ends", "k_getsv_scan"}
 
 
 def short(name):
