@@ -382,6 +382,12 @@ typedef struct {
 /* Start a file: n_targets of its header (plausibility of speculated record starts), and the offset of the first record inside the
  * inflated stream of the first chunk (= the length of the BAM header: magic, text, reference list). */
 int ssv_bamdec_begin(ssv_ctx *ctx, int32_t n_targets, uint64_t first_record_offset);
+/* A run of records that ends inside the next chunk (one rank's share of a file, ssvh_bam_raw_begin_range): its records end `inflated_bytes`
+ * into the chunk's blocks - a record boundary; what the blocks hold behind it belongs to the next run.  Applies to the next decode call only. */
+int ssv_bamdec_limit(ssv_ctx *ctx, uint64_t inflated_bytes);
+/* ... and that starts inside the file: the contig of the last mapped-pair record before it (0 at the start of the file, clip_reads.h:407) -
+ * ssv_bamdec_info's contig-change list continues from there.  After ssv_bamdec_begin, before the first decode. */
+int ssv_bamdec_prev_tid(ssv_ctx *ctx, int32_t tid);
 /* Pinned host buffers (two, which = 0 | 1; grow-only, owned by the context) to read the compressed bytes of a chunk into, so that a
  * reader thread can fill one while the other is being decoded; any host memory works too.  A buffer is free again when the decode
  * call that was given it returns. */

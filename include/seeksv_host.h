@@ -66,6 +66,12 @@ typedef struct {
 int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_bam_part *parts);
 int ssvh_bam_walk_back(const char *path, uint64_t coff, uint32_t uoff, int64_t n_back, uint64_t *out_coff, uint32_t *out_uoff, int64_t *n_found);
 int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff);
+/* Raw mode (below) over the records of [start, end): read_blocks starts at the block at start_coff and stops behind the block that holds the
+ * range's last record; *first_record_offset = where the first record begins in the first block's inflated bytes.  After every
+ * ssvh_bam_read_blocks call ssvh_bam_raw_limit tells how many inflated bytes of that call's blocks belong to the range (UINT64_MAX: all):
+ * pass it to ssv_bamdec_limit before decoding the chunk. */
+int ssvh_bam_raw_begin_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff, uint64_t *first_record_offset);
+int ssvh_bam_raw_limit(const ssvh_bam *b, uint64_t *inflated_bytes);
 const char *ssvh_partition_last_error(void); /* message of the last failed ssvh_bam_partition / ssvh_bam_walk_back of this thread */
 
 /* on != 0: after handing out a batch, ssvh_bam_read_batch decodes the following one on a background thread into another set

@@ -418,6 +418,10 @@ struct ssvh_bam {
 	bool readahead = false;
 	std::thread ra_thread;
 	int ra_rc = 0; std::string ra_err; ssv_batch_t ra_batch; int64_t ra_max = 0; int ra_keep = 0;
+	long raw_end_coff = -1;      // raw mode over a range (ssvh_bam_raw_begin_range)
+	uint32_t raw_end_uoff = 0;
+	uint64_t raw_limit = UINT64_MAX;
+	bool raw_empty = false;
 	std::vector<uint8_t> rec;
 	std::vector<size_t> found; // located, not yet handed out record offsets in z.ubuf
 	size_t found_pos = 0, chain_cur = 0;
@@ -500,9 +504,30 @@ int ssvh_bam_raw_begin(ssvh_bam *b, uint64_t *first_record_offset)
 	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight"; return -1; }
 	if (fseek(b->z.fp, 0, SEEK_SET) != 0) { g_err = "cannot seek"; return -1; }
 	b->z.eof = false; b->z.upos = b->z.ulen = 0; b->found.clear(); b->found_pos = 0;
+	b->raw_end_coff = -1; b->raw_end_uoff = 0; b->raw_limit = UINT64_MAX; b->raw_empty = false;
 	*first_record_offset = b->header_len;
 	return 0;
 }
+
+// Raw mode over the records of [start, end) (virtual offsets as ssvh_bam_set_range takes them): ssvh_bam_read_blocks then starts at the block at
+// start_coff and stops behind the block that holds the range's last record; ssvh_bam_raw_limit tells how many inflated bytes of the blocks of
+// the latest read_blocks call belong to the range.
+int ssvh_bam_raw_begin_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff, uint64_t *first_record_offset)
+{
+	g_err.clear();
+	if (!b->z.fp) { g_err = "no file behind this handle"; return -1; }
+	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight"; return -1; }
+	b->z.upos = b->z.ulen = 0; b->found.clear(); b->found_pos = 0;
+	b->raw_end_coff = end_coff == UINT64_MAX ? -1 : (long)end_coff; b->raw_end_uoff = end_uoff; b->raw_limit = UINT64_MAX;
+	*first_record_offset = start_uoff;
+	if (start_coff == UINT64_MAX || (start_coff == end_coff && start_uoff >= end_uoff)) { b->z.eof = true; b->raw_empty = true; return 0; }
+	b->raw_empty = false;
+	if (fseek(b->z.fp, (long)start_coff, SEEK_SET) != 0) { g_err = "cannot seek"; return -1; }
+	b->z.eof = false;
+	return 0;
+}
+
+int ssvh_bam_raw_limit(const ssvh_bam *b, uint64_t *inflated_bytes) { *inflated_bytes = b->raw_limit; return 0; }
 
 int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff)
 {
@@ -528,9 +553,11 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 	size_t used = 0;
 	uint64_t inflated = 0;
 	int64_t n = 0;
+	b->raw_limit = UINT64_MAX;
 	while (n < max_blocks && !b->z.eof) {
 		uint32_t payload = 0, isize = 0;
 		const long at = ftell(b->z.fp);
+		if (b->raw_end_coff >= 0 && (at > b->raw_end_coff || (at == b->raw_end_coff && b->raw_end_uoff == 0))) { b->z.eof = true; if (b->raw_limit == UINT64_MAX) b->raw_limit = inflated; break; } // the range ends before this block
 		int rc = b->z.read_block_raw((uint8_t *)dst + used, dst_bytes - used, &payload, &isize);
 		if (rc < 0) return -1;
 		if (rc == 0 || rc == 2) break;
@@ -538,6 +565,7 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 		if (isize == 0) continue; // empty blocks (the EOF marker) carry nothing
 		if (isize > 65536) { g_err = "BGZF block that claims to inflate to more than 64 KB"; return -1; }
 		blocks[n].c_off = used; blocks[n].c_len = payload; blocks[n].u_len = isize;
+		if (b->raw_end_coff >= 0 && at == b->raw_end_coff) { b->raw_limit = inflated + b->raw_end_uoff; b->z.eof = true; } // the range ends inside this block
 		used += payload; inflated += isize;
 		++n;
 	}

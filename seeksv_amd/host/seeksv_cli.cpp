@@ -218,11 +218,23 @@ struct BatchSource {
 	uint64_t file_bytes = 0, consumed = 0;
 	ssv_bamdec_info info{};
 
+	// a run of records [start, end) of the file instead of all of it (virtual offsets of ssvh_bam_partition); before open()
+	bool ranged = false;
+	uint64_t r_start_coff = 0, r_end_coff = 0;
+	uint32_t r_start_uoff = 0, r_end_uoff = 0;
+	void set_range(uint64_t sc, uint32_t su, uint64_t ec, uint32_t eu) { ranged = true; r_start_coff = sc; r_start_uoff = su; r_end_coff = ec; r_end_uoff = eu; }
+	uint64_t limit[2] = {UINT64_MAX, UINT64_MAX};
+	int32_t r_prev_tid = 0; // contig of the last mapped-pair record before the range
+
 	void open(const string &path, ssv_ctx *c, bool device_inflate, const char *open_error)
 	{
 		ctx = c; on_device = device_inflate;
 		if (ssvh_bam_open(path.c_str(), &bam) != 0) die(open_error);
-		if (!on_device) { use_pinned_batches(bam); return; }
+		if (!on_device) {
+			if (ranged && ssvh_bam_set_range(bam, r_start_coff, r_start_uoff, r_end_coff, r_end_uoff) != 0) die(string("[seeksv] ") + ssvh_last_error());
+			use_pinned_batches(bam);
+			return;
+		}
 		const char *e1 = getenv("SSV_CHUNK_INFLATED_MB"), *e2 = getenv("SSV_STAGE_MB");
 		chunk_inflated = (uint64_t)(e1 ? atoll(e1) : 4096) << 20;
 		stage_bytes = (size_t)(e2 ? atoll(e2) : 1536) << 20;
@@ -232,8 +244,10 @@ struct BatchSource {
 			if (file_bytes && file_bytes + 65536 < stage_bytes) stage_bytes = (size_t)file_bytes + 65536;
 		}
 		uint64_t first = 0;
-		if (ssvh_bam_raw_begin(bam, &first) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		if (ranged) { if (ssvh_bam_raw_begin_range(bam, r_start_coff, r_start_uoff, r_end_coff, r_end_uoff, &first) != 0) die(string("[seeksv] ") + ssvh_last_error()); file_bytes = 0; }
+		else if (ssvh_bam_raw_begin(bam, &first) != 0) die(string("[seeksv] ") + ssvh_last_error());
 		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		if (ranged) ssv_bamdec_prev_tid(ctx, r_prev_tid);
 		start_read(0);
 	}
 	void start_read(int k)
@@ -245,6 +259,7 @@ struct BatchSource {
 		reader = std::thread([this, k] {
 			read_err[k].clear();
 			if (ssvh_bam_read_blocks(bam, stage[k], stage_bytes, chunk_inflated, blocks[k].data(), (int64_t)blocks[k].size(), &n_blocks[k], &n_bytes[k]) != 0) read_err[k] = ssvh_last_error();
+			ssvh_bam_raw_limit(bam, &limit[k]);
 		});
 		reader_running = true;
 	}
@@ -271,6 +286,7 @@ struct BatchSource {
 			consumed += n_bytes[k] + 26ull * (uint64_t)n_blocks[k];
 			const bool last_chunk = n_blocks[k] == 0 || (file_bytes && consumed + 28 >= file_bytes);
 			if (!last_chunk) { cur ^= 1; start_read(cur); } // the other buffer fills while this chunk is decoded
+			if (limit[k] != UINT64_MAX) ssv_bamdec_limit(ctx, limit[k]);
 			if (ssv_bamdec_decode(ctx, stage[k], n_bytes[k], blocks[k].data(), n_blocks[k], keep_all_seq, b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 			if (n_blocks[k] == 0) { at_end = true; return false; }
 			if (last_chunk) end_pending = true;
@@ -412,7 +428,7 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 		}
 }
 
-static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp);
+static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp, bool device_inflate);
 
 static int cmd_getclip(int argc, char **argv)
 {
@@ -436,7 +452,7 @@ static int cmd_getclip(int argc, char **argv)
 	}
 	if (argc != optind + 1 || n_ranks < 1 || halo_bp < 0) usage_getclip();
 	const string bamfile = argv[optind];
-	if (n_ranks > 1) return getclip_ranks(bamfile, prefix, threshold, min_mapQ, save_low_quality, n_ranks, devices, halo_bp);
+	if (n_ranks > 1) return getclip_ranks(bamfile, prefix, threshold, min_mapQ, save_low_quality, n_ranks, devices, halo_bp, device_inflate);
 
 	PhaseTimer pt;
 	{ // like the reference: complain about the input before anything is created
@@ -546,7 +562,7 @@ struct ClipRank {
 	string err;
 };
 
-static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp)
+static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp, bool device_inflate)
 {
 	PhaseTimer pt;
 	ssvh_bam *bam = nullptr;
@@ -577,26 +593,23 @@ static int getclip_ranks(const string &bamfile, const string &prefix, double thr
 		else { p.own_hi_tid = INT32_MAX; p.own_hi_pos = 0; }
 		if (ssv_clip_begin(ctx, &p) != SSV_OK) { out.err = string("[seeksv] ") + ssv_last_error(ctx); ssv_ctx_destroy(ctx); return; }
 		ssv_clip_table_format(ctx, table_format_default());
-		ssvh_bam *rb = nullptr;
+		ssvh_bam *rb = nullptr; // (the header: contig names for the rows)
 		if (ssvh_bam_open(bamfile.c_str(), &rb) != 0) { out.err = "[main_samview] fail to open file for reading."; ssv_ctx_destroy(ctx); return; }
-		use_pinned_batches(rb);
 		// the contig of the last mapped-pair record before the rank's OWN run (its run list continues from there)
 		out.last_tid = r == 0 ? 0 : P.before_own_tid;
 		for (int phase = 0; phase < 2 && out.err.empty(); ++phase) { // 0: the halo (scanned, nothing else), 1: the rank's own records
-			if (phase == 0 && (P.scan_coff != P.own_coff || P.scan_uoff != P.own_uoff)) { if (ssvh_bam_set_range(rb, P.scan_coff, P.scan_uoff, P.own_coff, P.own_uoff) != 0) out.err = string("[seeksv] ") + ssvh_last_error(); }
-			else if (phase == 0) continue;
-			else if (ssvh_bam_set_range(rb, P.own_coff, P.own_uoff, P.end_coff, P.end_uoff) != 0) out.err = string("[seeksv] ") + ssvh_last_error();
-			if (!out.err.empty()) break;
-			out.err = pump_host_batches(rb, ctx, 0, [&](const ssv_batch_t &b) {
+			if (phase == 0 && P.scan_coff == P.own_coff && P.scan_uoff == P.own_uoff) continue;
+			BatchSource src; // host threads or the GPU (-Z) inflate and decode the run's blocks
+			if (phase == 0) src.set_range(P.scan_coff, P.scan_uoff, P.own_coff, P.own_uoff);
+			else { src.set_range(P.own_coff, P.own_uoff, P.end_coff, P.end_uoff); src.r_prev_tid = out.last_tid; }
+			src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
+			src.pump(0, [&](const ssv_batch_t &b) {
 				out.max_span = std::max(out.max_span, b.max_ref_span);
 				if (phase != 1) return;
-				const char *qname, *seq, *qual; int is_read1;
-				for (int64_t k = 0, nu = ssvh_bam_unmapped_count(rb); k < nu; ++k) { ssvh_bam_unmapped_get(rb, k, &qname, &seq, &qual, &is_read1); out.unmapped.push_back(UnmappedRec{qname, seq, qual, is_read1}); }
-				for (int64_t i = 0; i < b.n; ++i) {
-					if (b.flag[i] & (4 | 8)) continue;
-					if (b.tid[i] != out.last_tid) { out.run_tids.push_back(out.last_tid); out.last_tid = b.tid[i]; }
-				}
-			}, [&](const ssv_batch_t &b) { return ssv_clip_scan(ctx, &b) != SSV_OK ? string("[seeksv] ") + ssv_last_error(ctx) : string(); });
+				src.for_each_unmapped([&](const char *qname, const char *seq, const char *qual, int is_read1) { out.unmapped.push_back(UnmappedRec{qname, seq, qual, is_read1}); });
+				src.contig_runs(b, out.last_tid, out.run_tids);
+			}, [&](const ssv_batch_t &b) { if (out.err.empty() && ssv_clip_scan(ctx, &b) != SSV_OK) out.err = string("[seeksv] ") + ssv_last_error(ctx); });
+			src.close();
 		}
 		ssv_cluster_table t;
 		if (out.err.empty() && ssv_clip_cluster(ctx, &t) != SSV_OK) out.err = string("[seeksv] ") + ssv_last_error(ctx);
@@ -870,10 +883,12 @@ static int cmd_getsv(int argc, char **argv)
 				if (ssv_getsv_prime(rc, &hb, &sufficient) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
 				if (sufficient || found < back || back > (1ll << 26)) break; // (found < back: the replay began at the file's first record)
 			}
-			if (err.empty() && ssvh_bam_set_range(rb, P.own_coff, P.own_uoff, P.end_coff, P.end_uoff) != 0) err = string("[seeksv] ") + ssvh_last_error();
-			if (err.empty()) {
-				use_pinned_batches(rb); // (the replay above read single batches of its own sizes: read-ahead only from here on)
-				err = pump_host_batches(rb, rc, 0, [](const ssv_batch_t &) {}, [&](const ssv_batch_t &b) { return ssv_getsv_scan(rc, &b) != SSV_OK ? string("[seeksv] ") + ssv_last_error(rc) : string(); });
+			if (err.empty()) { // the run itself: host threads or the GPU (-Z) inflate and decode its blocks
+				BatchSource src;
+				src.set_range(P.own_coff, P.own_uoff, P.end_coff, P.end_uoff);
+				src.open(original_bam, rc, device_inflate, "[main_samview] fail to open file for reading.");
+				src.pump(0, [](const ssv_batch_t &) {}, [&](const ssv_batch_t &b) { if (err.empty() && ssv_getsv_scan(rc, &b) != SSV_OK) err = string("[seeksv] ") + ssv_last_error(rc); });
+				src.close();
 			}
 			vector<uint8_t> mine(vec_bytes, 0);
 			uint64_t *v_rs = reinterpret_cast<uint64_t *>(mine.data());

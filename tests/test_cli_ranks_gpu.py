@@ -101,3 +101,51 @@ def test_synthetic_sample_ranks_equal_single(tmp_path):
         outs[n] = (gzip.open(o + ".clip.gz", "rb").read(), gzip.open(o + ".clip.fq.gz", "rb").read(), open(sv, "rb").read(), r2.stdout, r.stderr)
     assert len(outs[1][0]) > 100000 and outs[1][2].count(b"\n") > 10
     assert outs[4] == outs[1] and outs[8] == outs[1]
+
+
+# ---- the same with -Z: every rank's run of BGZF blocks is inflated and decoded on the GPU (ssvh_bam_raw_begin_range, ssv_bamdec_limit) ----
+
+@pytest.mark.parametrize("n", [2, 5])
+@pytest.mark.parametrize("sub,bam,prefix,flags", [c for c in GETCLIP if c[2] in ("cancer", "normal", "filters", "stress2")], ids=lambda v: v if isinstance(v, str) and "." not in v else None)
+def test_getclip_ranks_device_inflate(tmp_path, sub, bam, prefix, flags, n):
+    out = str(tmp_path / "o")
+    r = subprocess.run([SEEKSV, "getclip", "-Z", "-N", str(n), "-H", "300"] + flags + ["-o", out, os.path.join(G.GOLDEN, sub, bam)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(out + ".clip.gz", "rt").read() == G.read_text(sub, prefix + ".clip.txt")
+    assert gzip.open(out + ".clip.fq.gz", "rt").read() == G.read_text(sub, prefix + ".clip.fq.txt")
+    if sub == "example":
+        assert r.stderr == G.read_text(sub, prefix + ".getclip.stderr")
+
+
+@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("case,prefix,flags", [c for c in GETSV if c[1] in ("pairs1", "pairs3", "deep")], ids=lambda v: v if isinstance(v, str) else None)
+def test_getsv_ranks_device_inflate(tmp_path, case, prefix, flags, n):
+    base = os.path.join(G.GOLDEN, "getsv")
+    bam = os.path.join(base, case + ".bam")
+    with host.BamReader(bam) as r:
+        names, lens = r.target_names, [int(x) for x in r.target_lens]
+    empty_bam = str(tmp_path / "empty.clip.bam")
+    bamio.write_bam(empty_bam, names, lens, [])
+    empty_clip = str(tmp_path / "empty.clip")
+    open(empty_clip, "w").close()
+    sv = str(tmp_path / "out.sv")
+    r = subprocess.run([SEEKSV, "getsv", "-Z", "-N", str(n), "-d", "0", "-f", "0", "-b", "0", "-T", "100000"] + flags + ["-B", os.path.join(base, case + ".junctions.txt"), empty_bam, bam, empty_clip, sv,
+                        str(tmp_path / "x.fq")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(sv).read() == G.read_text("getsv", prefix + ".sv")
+    assert r.stdout == G.read_text("getsv", prefix + ".stdout")
+
+
+def test_synthetic_sample_ranks_device_inflate(tmp_path):
+    """1.2 M records (several BGZF chunks per rank are not needed: what counts are cuts inside blocks): -Z -N 4 equals the plain single run"""
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 512, depth=30, n_sv=60)
+    bam = str(tmp_path / "s.bam")
+    host.write_bam(bam, w.names, w.lens, [w.generate_host(0, w.n_total)])
+    outs = {}
+    for tag, extra in (("one", []), ("z4", ["-Z", "-N", "4"]), ("z7", ["-Z", "-N", "7"])):
+        o = str(tmp_path / tag)
+        r = subprocess.run([SEEKSV, "getclip"] + extra + ["-o", o, bam], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = (gzip.open(o + ".clip.gz", "rb").read(), gzip.open(o + ".clip.fq.gz", "rb").read(), r.stderr)
+    assert len(outs["one"][0]) > 200000 and outs["z4"] == outs["one"] and outs["z7"] == outs["one"]
