@@ -166,6 +166,8 @@ struct ssv_ctx {
 		std::vector<uint64_t> x_stroff, x_cigoff;
 		bool expanded = false, ordered = false;
 		hipEvent_t copied = nullptr, started = nullptr; // `started` only with SSV_DEBUG_COPY (times the copy on its stream)
+		hipEvent_t packed_ev = nullptr;                 // the set's pack kernels are done (its copy waits for it): one event per set - a copy that is
+		                                                // still queued behind the table before must not see the next pass's record of a shared event
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
 		int packed = 0, qual_bits = 8;
@@ -485,6 +487,7 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 	if (hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->st_h2d, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ev_st, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ss[0].ready, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ss[1].ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->tab[0].packed_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->tab[1].packed_ev, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->tab[0].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->tab[1].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess) {
 		g_create_error = "cannot create the copy stream / events"; ssv_ctx_destroy(c); return SSV_E_NODEVICE;
@@ -531,6 +534,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 		for (DBuf *b : td) if (b->p) (void)hipFree(b->p);
 		for (HBuf *b : th) if (b->p) (void)hipHostFree(b->p);
 		if (t.copied) (void)hipEventDestroy(t.copied);
+		if (t.packed_ev) (void)hipEventDestroy(t.packed_ev);
 	}
 	if (c->st_copy) { (void)hipStreamSynchronize(c->st_copy); (void)hipStreamDestroy(c->st_copy); }
 	if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
@@ -1000,8 +1004,8 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		      {&T.h_ll, &T.o_ll, (size_t)nc * 4}, {&T.h_lr, &T.o_lr, (size_t)nc * 4}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_stroff, &T.o_stroff, (size_t)nc * 8},
 		      {&T.h_cigoff, &T.o_cigoff, (size_t)nc * 8}, {&T.h_ncig, &T.o_ncig, (size_t)nc * 4}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * 4}};
 	// the table goes to pinned host memory on the copy stream, behind the pack kernels; ssv_clip_table_wait() waits for it
-	HIPCHECK(c, hipEventRecord(c->ev_packed, c->st));
-	HIPCHECK(c, hipStreamWaitEvent(c->st_copy, c->ev_packed, 0));
+	HIPCHECK(c, hipEventRecord(T.packed_ev, c->st));
+	HIPCHECK(c, hipStreamWaitEvent(c->st_copy, T.packed_ev, 0));
 	if (getenv("SSV_DEBUG_COPY")) { if (!T.started) HIPCHECK(c, hipEventCreate(&T.started)); HIPCHECK(c, hipEventRecord(T.started, c->st_copy)); }
 	for (auto &x : cp) {
 		CHECK(ensure_host(c, *x.h, x.bytes + 16));
@@ -1062,7 +1066,12 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 		ProfScope pd(c, P_TABLE_D2H, T.n_clusters); // what is left of the copy when the caller asks for the table
 		HIPCHECK(c, hipEventSynchronize(T.copied));
 		T.in_flight = false;
-		if (T.started) { float ms = 0; if (hipEventElapsedTime(&ms, T.started, T.copied) == hipSuccess) fprintf(stderr, "[ssv debug] table copy on its stream: %.2f ms\n", ms); }
+		if (T.started) {
+			float ms = 0, gap = -1;
+			ssv_ctx::TableSet &O = c->tab[which ^ 1];
+			if (O.started && !O.in_flight) (void)hipEventElapsedTime(&gap, O.copied, T.started); // the copy stream's idle time between the table before and this one
+			if (hipEventElapsedTime(&ms, T.started, T.copied) == hipSuccess) fprintf(stderr, "[ssv debug] table copy on its stream: %.2f ms, %.2f ms after the copy before it ended\n", ms, gap);
+		}
 	}
 	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
 	out->format = T.format; out->base_bits = T.base_bits;

@@ -13,6 +13,9 @@
 #include "seeksv_host.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +73,10 @@ int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int
 {
 	ssvh_plan *p = new ssvh_plan();
 	p->n_junctions = n_junctions;
+	static const bool timing = getenv("SSV_TIMING_PLAN") != nullptr;
+	auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double tl = tnow();
+	auto lap = [&](const char *what) { if (timing) { const double t = tnow(); fprintf(stderr, "[plan] %s %.2f ms\n", what, t - tl); tl = t; } };
 
 	// ---- contig names: header tid (StoreSeqName2Tid, cluster.cpp:206-216, first wins) and string rank ----
 	std::map<std::string, int> name2tid;
@@ -121,7 +128,9 @@ int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int
 		p->dev_junctions.push_back(d);
 		p->dev_chr_length.push_back((unsigned)ssvh_bam_target_len(bam, tid));
 	}
+	lap("names + device junctions");
 	ssvh_plan_update_isize(p, mean, sd, times);
+	lap("update_isize");
 
 	// ---- GetBreak, getsv.cpp:752-802: the four flank windows of every junction (unsigned arithmetic) ----
 	std::vector<RangeKey> jr((size_t)n_junctions * 4);
@@ -136,10 +145,20 @@ int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int
 		jr[(size_t)j * 4 + 2] = RangeKey(dr, (unsigned)(J.down_pos - l), (unsigned)(J.down_pos - 1));
 		jr[(size_t)j * 4 + 3] = RangeKey(dr, (unsigned)J.down_pos, (unsigned)(J.down_pos + l - 1));
 	}
-	p->ref_ranges = jr; // range2depth: the map's keys = sorted unique ranges
-	std::sort(p->ref_ranges.begin(), p->ref_ranges.end());
-	p->ref_ranges.erase(std::unique(p->ref_ranges.begin(), p->ref_ranges.end()), p->ref_ranges.end());
+	// range2depth: the map's keys = the sorted unique ranges.  Sorted as packed words with their origin beside them, so that the position of
+	// every junction's four windows among the unique ranges (flank_of) falls out of the same pass instead of 4 J binary searches over tuples.
+	struct Packed { uint64_t a; uint32_t e, idx; }; // a = rank << 32 | begin (ranks are >= 0): (a, e) orders like (rank, begin, end)
+	std::vector<Packed> pk(jr.size());
+	for (size_t k = 0; k < jr.size(); ++k) pk[k] = Packed{((uint64_t)(uint32_t)std::get<0>(jr[k]) << 32) | std::get<1>(jr[k]), std::get<2>(jr[k]), (uint32_t)k};
+	std::sort(pk.begin(), pk.end(), [](const Packed &x, const Packed &y) { return x.a != y.a ? x.a < y.a : x.e < y.e; });
+	p->flank_of.assign((size_t)n_junctions * 4, -1);
+	p->ref_ranges.clear(); p->ref_ranges.reserve(pk.size());
+	for (size_t k = 0; k < pk.size(); ++k) {
+		if (k == 0 || pk[k].a != pk[k - 1].a || pk[k].e != pk[k - 1].e) p->ref_ranges.push_back(jr[pk[k].idx]);
+		p->flank_of[pk[k].idx] = (int64_t)p->ref_ranges.size() - 1;
+	}
 	const std::vector<RangeKey> &rr = p->ref_ranges;
+	lap("flank ranges sorted");
 
 	// ---- MergeOverlap, getsv.cpp:804-835 -> begin2end (map::insert: the first entry with a key wins) ----
 	std::vector<Entry> entries;
@@ -177,6 +196,7 @@ int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int
 		return a == lo ? -1 : (int64_t)a - 1;
 	};
 
+	lap("entries");
 	// ---- reference ranges -> device pieces ----
 	std::vector<ssv_interval> need; // every interval whose depth the device must know
 	need.reserve(rr.size() + 2 * (size_t)n_junctions + (size_t)n_extra_points);
@@ -214,9 +234,9 @@ int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int
 		}
 	}
 	p->piece_first[rr.size()] = (int64_t)p->ranges.size();
-	p->flank_of.assign((size_t)n_junctions * 4, -1);
-	for (size_t k = 0; k < jr.size(); ++k) p->flank_of[k] = (int64_t)(std::lower_bound(rr.begin(), rr.end(), jr[k]) - rr.begin());
+	lap("pieces");
 
+	lap("flank_of");
 	// ---- points (pos2depth keys): depth is recorded only for columns inside their owning entry ----
 	auto add_point = [&](int32_t rank, int c) -> int64_t {
 		const int tid = tid_of_rank[(size_t)rank];
@@ -237,13 +257,21 @@ int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int
 	p->extra_point.assign((size_t)n_extra_points, -1);
 	for (int64_t k = 0; k < n_extra_points; ++k) p->extra_point[(size_t)k] = add_point(by_ptr.find(extra_point_chr[k])->second, extra_point_pos[k]);
 
+	lap("points");
 	// ---- device windows = union of everything that is queried, sorted and disjoint ----
-	std::sort(need.begin(), need.end(), [](const ssv_interval &a, const ssv_interval &b) { return a.tid != b.tid ? a.tid < b.tid : (a.beg != b.beg ? a.beg < b.beg : a.end < b.end); });
+	{ // sorted by (tid, beg, end) as one 64-bit word + end (tid >= 0, beg >= 1 here)
+		struct NeedKey { uint64_t a; int32_t end; };
+		std::vector<NeedKey> nk(need.size());
+		for (size_t k = 0; k < need.size(); ++k) nk[k] = NeedKey{((uint64_t)(uint32_t)need[k].tid << 32) | (uint32_t)need[k].beg, need[k].end};
+		std::sort(nk.begin(), nk.end(), [](const NeedKey &x, const NeedKey &y) { return x.a != y.a ? x.a < y.a : x.end < y.end; });
+		for (size_t k = 0; k < need.size(); ++k) { need[k].tid = (int32_t)(nk[k].a >> 32); need[k].beg = (int32_t)(uint32_t)nk[k].a; need[k].end = nk[k].end; }
+	}
 	for (const ssv_interval &iv : need) {
 		if (!p->windows.empty() && p->windows.back().tid == iv.tid && (int64_t)iv.beg <= (int64_t)p->windows.back().end + 1) {
 			if (iv.end > p->windows.back().end) p->windows.back().end = iv.end;
 		} else p->windows.push_back(iv);
 	}
+	lap("windows");
 	*out = p;
 	return 0;
 }
