@@ -747,6 +747,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	const bool fmt3 = c->table_mode == 3;
 	T.format = c->table_mode; T.base_bits = fmt3 ? 2 : 4; T.n_runs = 0; T.n_exc = 0; T.expanded = false; T.ordered = false;
 	T.len_bytes = fmt3 && c->max_lq < 65536 ? 2 : 4; T.support_bytes = fmt3 ? 2 : 4; T.ncig_bytes = fmt3 ? (c->max_ncig < 256 ? 1 : 2) : 4;
+	if (fmt3 && getenv("SSV_TABLE_WIDE_COLUMNS")) { T.len_bytes = 4; T.support_bytes = 4; T.ncig_bytes = 2; } // (tests: the widths that only reads > 64 kb, > 65535-read clusters, > 255-operation CIGARs ask for)
 	if (n_events) *n_events = E;
 	if (n_clusters) *n_clusters = 0;
 	if (E == 0) { HIPCHECK(c, hipStreamSynchronize(c->st)); return SSV_OK; }

@@ -527,3 +527,28 @@ def test_getclip_lone_soft_clip_records(ctx):
         finally:
             ctx.clip_table_format(0)
         assert host.format_clip_outputs(d, names) == lone_s_expected()
+
+
+@pytest.mark.parametrize("source", ["stress1", "filters", "synth150"])
+def test_compact_table_wide_columns(ctx, source, monkeypatch):
+    """the column widths of format 3 grow with the data (u32 lengths for reads over 64 kb, u32 support, u16 CIGAR counts): forced here
+    (SSV_TABLE_WIDE_COLUMNS), the rebuilt table is the same"""
+    if source.startswith("synth"):
+        from seeksv_amd import synth
+        w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, read_len=int(source[5:]))
+        batches = [w.generate_host(0, w.n_total)]
+    else:
+        batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", source + ".bam"))[2]
+    ref = ctx.getclip(batches)
+    monkeypatch.setenv("SSV_TABLE_WIDE_COLUMNS", "1")
+    ctx.clip_table_format(3)
+    try:
+        ctx.clip_begin()
+        for b in batches:
+            ctx.clip_scan(b)
+        t = ctx.clip_cluster(as_dict=False)
+        d = host.table_to_dict(t)
+        assert (d["len_bytes"], d["support_bytes"], d["ncig_bytes"]) == (4, 4, 2)
+        _compact_checks(ctx, d, ref, t, check_size=False)
+    finally:
+        ctx.clip_table_format(0)
