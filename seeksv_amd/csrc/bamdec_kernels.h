@@ -81,6 +81,80 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict
 	status[b] = rc;
 }
 
+// ---- decode and copy split in two (TokenOut, inflate_core.h) ------------------------------------------------------------------------
+//
+// Pass 1, k_bgzf_tokens: the decoder as above, one lane per block, but a match is only RECORDED (a 32-bit token) - the lane never reads the
+// block's output, so its chain per symbol is bits -> table -> store, no trip to memory to wait for.
+// Pass 2, k_bgzf_resolve: 16 lanes per block fill the holes in order: a match is one unaligned-dword load and store per four bytes, all of a match's
+// (up to 64 bytes per round) at once; the group waits for its own stores only when a match reads what an earlier match of this pass wrote.
+template <int LPW>
+__global__ __launch_bounds__(WAVE) void k_bgzf_tokens(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, const uint64_t *__restrict__ tok_off,
+                                                      int64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tokens, uint32_t *__restrict__ n_tok, int *__restrict__ status,
+                                                      uint8_t *__restrict__ scratch)
+{
+	extern __shared__ uint8_t lds_raw[];
+	if ((int)threadIdx.x >= LPW) return;
+	LdsTabT<LPW> tab;
+	tab.lit8 = lds_raw;
+	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
+	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;
+	tab.len8 = scratch + (size_t)blockIdx.x * (INFLATE_SCRATCH_BYTES / 64 * LPW);
+	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * LPW);
+	tab.lane = (int)threadIdx.x;
+	const int64_t b = (int64_t)blockIdx.x * LPW + threadIdx.x;
+	if (b >= n_blocks) return;
+	const BgzfBlock blk = blocks[b];
+	TokenOut to;
+	to.out = out + u_off[b];
+	to.tok = tokens + tok_off[b];
+	int rc = INF_OK;
+	if (blk.u_len) rc = inflate_stream_to(comp + blk.c_off, blk.c_len, to, blk.u_len, tab);
+	status[b] = rc;
+	n_tok[b] = rc == INF_OK ? to.n : 0u;
+}
+
+constexpr int RESOLVE_LANES = 16;
+
+__global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
+                                                        int64_t n_blocks, uint8_t *out)
+{
+	const int gl = (int)threadIdx.x % RESOLVE_LANES;
+	const int64_t b = (int64_t)blockIdx.x * (BLOCK / RESOLVE_LANES) + threadIdx.x / RESOLVE_LANES;
+	if (b >= n_blocks) return;
+	const uint32_t n = n_tok[b];
+	uint8_t *o = out + u_off[b];
+	const uint32_t *tk = tokens + tok_off[b];
+	uint32_t pos = 0;
+	uint32_t dirty = 0xffffffffu; // positions from here on may hold stores of this pass that have not been waited for
+	for (uint32_t t0 = 0; t0 < n; t0 += RESOLVE_LANES) {
+		const uint32_t mine = t0 + (uint32_t)gl < n ? tk[t0 + gl] : 0u; // sixteen tokens per load
+		const uint32_t cnt = n - t0 < (uint32_t)RESOLVE_LANES ? n - t0 : (uint32_t)RESOLVE_LANES;
+		for (uint32_t k = 0; k < cnt; ++k) {
+			const uint32_t w = (uint32_t)__shfl((int)mine, (int)k, RESOLVE_LANES);
+			if ((w >> 23) == 511u) { pos += w & 0x7fffffu; continue; }
+			pos += w >> 23;
+			const uint32_t len = (w & 255u) + 3u, dist = ((w >> 8) & 0x7fffu) + 1u;
+			const uint32_t src = pos - dist;
+			if (src + (len < dist ? len : dist) > dirty) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; } // it reads what this pass wrote
+			if (dist >= len) {
+				for (uint32_t base = 0; base < len; base += 4u * RESOLVE_LANES) {
+					const uint32_t off = base + 4u * (uint32_t)gl, left = len - base; // this round moves min(left, 64) bytes
+					if (off + 4u <= len) st32u(o + pos + off, ld32(o + src + off));
+					else if (off < len) { // the match ends inside this lane's dword
+						if (len >= 4u) st32u(o + pos + len - 4u, ld32(o + src + len - 4u)); // one dword that ends with the match (it overlaps the one before: same bytes)
+						else for (uint32_t i = off; i < len; ++i) o[pos + i] = o[src + i];
+					}
+					(void)left;
+				}
+			} else {
+				for (uint32_t i = (uint32_t)gl; i < len; i += RESOLVE_LANES) o[pos + i] = o[src + i % dist]; // a repeating pattern: all sources lie before the match
+			}
+			if (dirty > pos) dirty = pos;
+			pos += len;
+		}
+	}
+}
+
 // The same decoder writing through a 64-byte line buffer per lane (LineOut, inflate_core.h): 64 x LPW bytes of LDS more per wavefront.
 struct LdsLine {
 	uint8_t *base; // this wavefront's lines: 16-byte group g of lane l at ((g * stride + l) * 16)

@@ -226,6 +226,43 @@ template <class Line> struct LineOut {
 	SSV_HD void finish(uint32_t o) { flush_upto(o); }
 };
 
+// TokenOut: the decode split in two (SSV_INFLATE=two).  What makes a block slow is the chain decode -> copy -> decode: every match reads bytes of the
+// block's own output, a trip to memory that the next symbol has to wait for.  Pass 1 (this sink) only DECODES: literals go to their final place,
+// a match becomes a 32-bit token and leaves a hole; pass 2 (resolve_tokens / k_bgzf_resolve) fills the holes in order, several lanes per block.
+//   token = len - 3 | (dist - 1) << 8 | literals since the previous token << 23     (literals 0..510)
+//           0xff800000 | n: no match, n (< 2^23) more literals (a run of more than 510)
+struct TokenOut {
+	uint8_t *out;
+	uint32_t *tok;       // room for token_capacity(out_len) words
+	uint32_t n = 0;      // tokens written
+	uint32_t last = 0;   // position behind the last token's match
+	SSV_HD void put(uint32_t &o, uint8_t v) { out[o++] = v; }
+	SSV_HD void copy(uint32_t &o, uint32_t dist, uint32_t len)
+	{
+		uint32_t run = o - last;
+		while (run > 510u) { const uint32_t k = run - 510u < 0x7fffffu ? run - 510u : 0x7fffffu; tok[n++] = 0xff800000u | k; run -= k; }
+		tok[n++] = (len - 3u) | ((dist - 1u) << 8) | (run << 23);
+		o += len; last = o;
+	}
+	SSV_HD void finish(uint32_t) {}
+};
+// words a block of out_len bytes can need: a token per 3 bytes of output, an escape per 510 literals
+SSV_HD uint32_t token_capacity(uint32_t out_len) { return out_len / 3u + out_len / 510u + 4u; }
+
+// pass 2, one block, one thread (the CPU check; the kernel does the same with a group of lanes per block)
+inline void resolve_tokens(uint8_t *out, const uint32_t *tok, uint32_t n)
+{
+	uint32_t pos = 0;
+	for (uint32_t t = 0; t < n; ++t) {
+		const uint32_t w = tok[t];
+		if ((w >> 23) == 511u) { pos += w & 0x7fffffu; continue; }
+		pos += w >> 23;
+		const uint32_t len = (w & 255u) + 3u, dist = ((w >> 8) & 0x7fffu) + 1u;
+		for (uint32_t i = 0; i < len; ++i) out[pos + i] = out[pos + i - dist];
+		pos += len;
+	}
+}
+
 struct HuffCounts { uint32_t c[8]; }; // count of codes of length L in bits [16*(L&1), +16) of c[L>>1]
 
 // canonical decode: walk the lengths, one bit per step; the first length at which the code falls below first+count wins

@@ -129,6 +129,15 @@ int main()
 						int rc3 = ssv::inflate_stream_to(c.data(), clen, lo, (uint32_t)n, tab);
 						if (!(rc3 == ssv::INF_OK && memcmp(op, d.data(), n) == 0 && op[n] == 0x55 && op[-1] == 0x55)) { same = false; fprintf(stderr, "LINE sink: "); }
 					}
+					{ // decode and copy split in two: tokens, then the holes filled in order
+						std::vector<uint8_t> o4(n + 8, 0x55);
+						std::vector<uint32_t> tk(ssv::token_capacity((uint32_t)n) + 1, 0xdeadbeefu);
+						ssv::TokenOut to;
+						to.out = o4.data(); to.tok = tk.data();
+						int rc4 = ssv::inflate_stream_to(c.data(), clen, to, (uint32_t)n, tab);
+						if (rc4 == ssv::INF_OK) ssv::resolve_tokens(o4.data(), tk.data(), to.n);
+						if (!(rc4 == ssv::INF_OK && to.n <= ssv::token_capacity((uint32_t)n) && tk[ssv::token_capacity((uint32_t)n)] == 0xdeadbeefu && memcmp(o4.data(), d.data(), n) == 0 && o4[n] == 0x55)) { same = false; fprintf(stderr, "TOKEN sink: "); }
+					}
 					{ // the second copy routine (unaligned dword moves)
 						std::vector<uint8_t> o2(n + 8, 0x55);
 						int rc2 = ssv::inflate_stream<ssv::PlainTab, true>(c.data(), clen, o2.data(), (uint32_t)n, tab);
