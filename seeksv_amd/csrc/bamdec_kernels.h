@@ -87,6 +87,16 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict
 // block's output, so its chain per symbol is bits -> table -> store, no trip to memory to wait for.
 // Pass 2, k_bgzf_resolve: 16 lanes per block fill the holes in order: a match is one unaligned-dword load and store per four bytes, all of a match's
 // (up to 64 bytes per round) at once; the group waits for its own stores only when a match reads what an earlier match of this pass wrote.
+// the input window of one lane (RingReader, inflate_core.h): dword j of lane l at word j * LPW + l - a wavefront's lanes hit different banks
+template <int LPW>
+struct LdsRing {
+	uint32_t *w; // this lane's dword 0
+	__device__ __forceinline__ uint32_t get(uint32_t j) const { return w[j * LPW]; }
+	__device__ __forceinline__ void set(uint32_t j, uint32_t v) { w[j * LPW] = v; }
+	__device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
+};
+constexpr uint32_t TOKENS_WINDOW = 128; // bytes of input per lane in LDS
+
 template <int LPW>
 __global__ __launch_bounds__(WAVE) void k_bgzf_tokens(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, const uint64_t *__restrict__ tok_off,
                                                       int64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tokens, uint32_t *__restrict__ n_tok, int *__restrict__ status,
@@ -108,17 +118,45 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_tokens(const uint8_t *__restrict_
 	to.out = out + u_off[b];
 	to.tok = tokens + tok_off[b];
 	int rc = INF_OK;
-	if (blk.u_len) rc = inflate_stream_to(comp + blk.c_off, blk.c_len, to, blk.u_len, tab);
+	if (blk.u_len) {
+		LdsRing<LPW> ring{reinterpret_cast<uint32_t *>(lds_raw + INFLATE_LDS_BYTES / 64 * LPW) + threadIdx.x};
+		RingReader<LdsRing<LPW>, TOKENS_WINDOW> br(comp + blk.c_off, blk.c_len, ring);
+		rc = inflate_stream_from(br, comp + blk.c_off, blk.c_len, to, blk.u_len, tab);
+	}
 	status[b] = rc;
 	n_tok[b] = rc == INF_OK ? to.n : 0u;
 }
 
 constexpr int RESOLVE_LANES = 16;
+constexpr uint32_t TOKEN_NONE = 0xff800000u; // an escape that skips nothing
 
+// one match, all of the group's lanes on it (64 bytes per round); a repeating pattern (dist < len) goes byte by byte: all its sources lie before it
+__device__ __forceinline__ void resolve_one(uint8_t *o, uint32_t pos, uint32_t len, uint32_t dist, int gl)
+{
+	const uint32_t src = pos - dist;
+	if (dist >= len) {
+		for (uint32_t base = 0; base < len; base += 4u * RESOLVE_LANES) {
+			const uint32_t off = base + 4u * (uint32_t)gl;
+			if (off + 4u <= len) st32u(o + pos + off, ld32(o + src + off));
+			else if (off < len) { // the match ends inside this lane's dword
+				if (len >= 4u) st32u(o + pos + len - 4u, ld32(o + src + len - 4u)); // one dword that ends with the match (it overlaps the one before: same bytes)
+				else for (uint32_t i = off; i < len; ++i) o[pos + i] = o[src + i];
+			}
+		}
+	} else {
+		for (uint32_t i = (uint32_t)gl; i < len; i += RESOLVE_LANES) o[pos + i] = o[src + i % dist];
+	}
+}
+
+// Sixteen tokens per round, one per lane.  A match whose source lies wholly before the round's first byte cannot depend on another match of the
+// round: those are copied all at once, every lane its own match - the loads of all of them first, then the stores, so a round pays one trip to memory
+// instead of one per match.  The rest (a source inside the round, a repeating pattern) follow in order, the group's lanes together on each.  Stores
+// of this pass are waited for only when a source reaches above the watermark `dirty`.
 __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
                                                         int64_t n_blocks, uint8_t *out)
 {
 	const int gl = (int)threadIdx.x % RESOLVE_LANES;
+	const int grp_shift = (int)(threadIdx.x % WAVE) / RESOLVE_LANES * RESOLVE_LANES;
 	const int64_t b = (int64_t)blockIdx.x * (BLOCK / RESOLVE_LANES) + threadIdx.x / RESOLVE_LANES;
 	if (b >= n_blocks) return;
 	const uint32_t n = n_tok[b];
@@ -126,32 +164,53 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restri
 	const uint32_t *tk = tokens + tok_off[b];
 	uint32_t pos = 0;
 	uint32_t dirty = 0xffffffffu; // positions from here on may hold stores of this pass that have not been waited for
+	uint32_t next = (uint32_t)gl < n ? tk[gl] : TOKEN_NONE;
 	for (uint32_t t0 = 0; t0 < n; t0 += RESOLVE_LANES) {
-		const uint32_t mine = t0 + (uint32_t)gl < n ? tk[t0 + gl] : 0u; // sixteen tokens per load
-		const uint32_t cnt = n - t0 < (uint32_t)RESOLVE_LANES ? n - t0 : (uint32_t)RESOLVE_LANES;
-		for (uint32_t k = 0; k < cnt; ++k) {
-			const uint32_t w = (uint32_t)__shfl((int)mine, (int)k, RESOLVE_LANES);
-			if ((w >> 23) == 511u) { pos += w & 0x7fffffu; continue; }
-			pos += w >> 23;
-			const uint32_t len = (w & 255u) + 3u, dist = ((w >> 8) & 0x7fffu) + 1u;
-			const uint32_t src = pos - dist;
-			if (src + (len < dist ? len : dist) > dirty) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; } // it reads what this pass wrote
-			if (dist >= len) {
-				for (uint32_t base = 0; base < len; base += 4u * RESOLVE_LANES) {
-					const uint32_t off = base + 4u * (uint32_t)gl, left = len - base; // this round moves min(left, 64) bytes
-					if (off + 4u <= len) st32u(o + pos + off, ld32(o + src + off));
-					else if (off < len) { // the match ends inside this lane's dword
-						if (len >= 4u) st32u(o + pos + len - 4u, ld32(o + src + len - 4u)); // one dword that ends with the match (it overlaps the one before: same bytes)
-						else for (uint32_t i = off; i < len; ++i) o[pos + i] = o[src + i];
-					}
-					(void)left;
-				}
-			} else {
-				for (uint32_t i = (uint32_t)gl; i < len; i += RESOLVE_LANES) o[pos + i] = o[src + i % dist]; // a repeating pattern: all sources lie before the match
-			}
-			if (dirty > pos) dirty = pos;
-			pos += len;
+		const uint32_t w = next;
+		next = t0 + RESOLVE_LANES + (uint32_t)gl < n ? tk[t0 + RESOLVE_LANES + gl] : TOKEN_NONE; // the next round's tokens travel with this round's loads
+		const bool esc = (w >> 23) == 511u;
+		const uint32_t lit = esc ? (w & 0x7fffffu) : (w >> 23);
+		const uint32_t len = esc ? 0u : (w & 255u) + 3u, dist = ((w >> 8) & 0x7fffu) + 1u;
+		uint32_t inc = lit + len; // -> inclusive sum over the group: where this lane's token ends
+#pragma unroll
+		for (int d = 1; d < RESOLVE_LANES; d <<= 1) {
+			const uint32_t v = (uint32_t)__shfl_up((int)inc, d, RESOLVE_LANES);
+			if (gl >= d) inc += v;
 		}
+		const uint32_t total = (uint32_t)__shfl((int)inc, RESOLVE_LANES - 1, RESOLVE_LANES);
+		const uint32_t dst = pos + inc - len, src = dst - dist;
+		const bool alone = !esc && dist >= len && len <= 32u && src + len <= pos; // (a long match is quicker with all the lanes on it)
+		const bool later = !esc && !alone;
+		if (__any(alone && src + len > dirty)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; }
+		const uint32_t L = alone ? len : 0u;
+		if (L == 3u) { // one dword read (its fourth byte is the hole's first), three bytes written
+			const uint32_t v = ld32(o + src);
+			o[dst] = (uint8_t)v; o[dst + 1] = (uint8_t)(v >> 8); o[dst + 2] = (uint8_t)(v >> 16);
+		}
+		for (uint32_t done = 0; __any(L >= 4u && done < L); done += 16u) {
+			if (L >= 4u && done < L) { // up to four dwords; the last one ends with the match (it may overlap the one before: same bytes)
+				const uint32_t last = L - 4u;
+				const uint32_t q0 = done, q1 = done + 4u < last ? done + 4u : last, q2 = done + 8u < last ? done + 8u : last, q3 = done + 12u < last ? done + 12u : last;
+				const uint32_t r0 = ld32(o + src + (q0 < last ? q0 : last)), r1 = ld32(o + src + q1), r2 = ld32(o + src + q2), r3 = ld32(o + src + q3);
+				st32u(o + dst + (q0 < last ? q0 : last), r0);
+				if (done + 4u < L) st32u(o + dst + q1, r1);
+				if (done + 8u < L) st32u(o + dst + q2, r2);
+				if (done + 12u < L) st32u(o + dst + q3, r3);
+			}
+		}
+		if (dirty > pos) dirty = pos;
+		uint32_t m = (uint32_t)(__ballot(later) >> grp_shift) & 0xffffu;
+		while (__any(m != 0u)) {
+			if (m) {
+				const int k = __ffs((int)m) - 1;
+				m &= m - 1u;
+				const uint32_t kdst = (uint32_t)__shfl((int)dst, k, RESOLVE_LANES), klen = (uint32_t)__shfl((int)len, k, RESOLVE_LANES), kdist = (uint32_t)__shfl((int)dist, k, RESOLVE_LANES);
+				if (kdst - kdist + (klen < kdist ? klen : kdist) > dirty) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; }
+				resolve_one(o, kdst, klen, kdist, gl);
+				if (dirty > kdst) dirty = kdst;
+			}
+		}
+		pos += total;
 	}
 }
 

@@ -47,20 +47,20 @@ struct BitReader {
 	uint64_t bb = 0;    // bit buffer, LSB first
 	int bc = 0;         // valid bits in bb
 	uint32_t ahead;     // the next 32 input bits, loaded one refill early: its latency hides behind the symbols decoded meanwhile
+	bool ahead_in;      // ... and whether they lie inside the stream
 	SSV_HD BitReader(const uint8_t *in, uint32_t in_len) : p(in), lim(in + in_len + 4) { fetch(); }
 	// a damaged or crafted stream can ask for more input than it has: past the end it is fed zero bits (which every path of the decoder
 	// turns into an error or into output that hits the output bound) instead of whatever lies behind the buffer
 	SSV_HD void fetch() // (no branch around the load: it is on every symbol's path)
 	{
-		const bool in = p < lim;
-		uint32_t v;
-		memcpy(&v, in ? p : lim - 4, 4); // lim - 4 = the stream's end: readable (the buffers keep spare bytes behind the last stream)
-		ahead = in ? v : 0u;
+		ahead_in = p < lim;
+		memcpy(&ahead, ahead_in ? p : lim - 4, 4); // lim - 4 = the stream's end: readable (the buffers keep spare bytes behind the last stream)
+		// (whether the word counts is decided where it is USED: a select right here would make the lane wait for the load at once)
 	}
 	SSV_HD void refill() // afterwards bc >= 32 (looks up to 8 bytes past the data: buffers are padded)
 	{
 		if (bc < 32) {
-			bb |= (uint64_t)ahead << bc;
+			bb |= (uint64_t)(ahead_in ? ahead : 0u) << bc;
 			bc += 32; p += 4;
 			fetch();
 		}
@@ -69,6 +69,74 @@ struct BitReader {
 	SSV_HD void drop(int n) { bb >>= n; bc -= n; }
 	SSV_HD uint32_t take(int n) { uint32_t v = peek(n); drop(n); return v; }
 	SSV_HD uint32_t consumed(const uint8_t *in) const { return (uint32_t)(p - in) - (uint32_t)(bc >> 3); } // whole bytes taken from the input
+	SSV_HD void top_of_symbol() {}
+};
+
+// RingReader: the same bit buffer fed from a small window of the input that the lane keeps in fast storage (LDS on the device, `Ring` says where).
+// Why: on gfx950 a wavefront's loads and stores share ONE counter (vmcnt), so a lane that waits for its next input word also waits for every
+// store the wavefront has in flight - with BitReader that is each symbol's literal / token store, every step.  Here the symbol loop only touches
+// the window; the window is topped up from memory at the top of a symbol (top_of_symbol) by all lanes of the wavefront together whenever ANY of
+// them runs low, so the wait for memory comes once per a few dozen symbols instead of once per symbol.
+//   Ring: uint32_t get(uint32_t j), void set(uint32_t j, uint32_t v) for j < CAP / 4; bool any(bool) = "any lane of the wavefront" (identity on a CPU).
+// Loads are whole aligned 16-byte groups from the dword boundary below the stream's first byte and may reach 16 + 3 bytes past its end.
+template <class Ring, uint32_t CAP = 128>
+struct RingReader {
+	static_assert(CAP >= 64 && (CAP & (CAP - 1)) == 0, "the window is a power of two, at least four groups");
+	static constexpr uint32_t LOW = 24; // a symbol takes at most 48 bits: with this much left two symbols are safe
+	Ring ring;
+	const uint8_t *base; // the dword boundary at or below the stream's first byte
+	uint32_t lim;        // groups start below this offset from base; what lies behind is fed as zero bits (see BitReader)
+	uint32_t skew;       // bytes between base and the stream
+	uint32_t rd = 0;     // offset of the next dword for the bit buffer
+	uint32_t wr = 0;     // offset of the next group to load (wr - rd <= CAP)
+	uint64_t bb = 0;
+	int bc = 0;
+	SSV_HD RingReader(const uint8_t *in, uint32_t in_len, Ring r) : ring(r)
+	{
+		skew = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u);
+		base = in - skew;
+		lim = in_len + skew + 4u;
+		top_up();
+		refill();
+		drop(8 * (int)skew);
+	}
+	SSV_HD void group(uint32_t at, uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d) const
+	{
+		a = b = c = d = 0u;
+		if (at < lim) { const uint32_t *q = reinterpret_cast<const uint32_t *>(base + at); a = q[0]; b = q[1]; c = q[2]; d = q[3]; }
+	}
+	SSV_HD void put(uint32_t at, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+	{
+		const uint32_t j = (at >> 2) & (CAP / 4u - 1u);
+		ring.set(j, a); ring.set(j + 1u, b); ring.set(j + 2u, c); ring.set(j + 3u, d);
+	}
+	SSV_HD void top_up() // every group that fits, up to four: all the loads first
+	{
+		const uint32_t k = (CAP - (wr - rd)) >> 4;
+		uint32_t a0, b0, c0, d0, a1, b1, c1, d1, a2, b2, c2, d2, a3, b3, c3, d3;
+		if (k > 0u) group(wr, a0, b0, c0, d0);
+		if (k > 1u) group(wr + 16u, a1, b1, c1, d1);
+		if (k > 2u) group(wr + 32u, a2, b2, c2, d2);
+		if (k > 3u) group(wr + 48u, a3, b3, c3, d3);
+		if (k > 0u) put(wr, a0, b0, c0, d0);
+		if (k > 1u) put(wr + 16u, a1, b1, c1, d1);
+		if (k > 2u) put(wr + 32u, a2, b2, c2, d2);
+		if (k > 3u) put(wr + 48u, a3, b3, c3, d3);
+		wr += 16u * (k < 4u ? k : 4u);
+	}
+	SSV_HD void top_of_symbol() { if (ring.any(wr - rd < LOW)) top_up(); }
+	SSV_HD void refill()
+	{
+		if (bc < 32) {
+			if (rd == wr) { uint32_t a, b, c, d; group(wr, a, b, c, d); put(wr, a, b, c, d); wr += 16u; } // (outside the symbol loop: headers, stored blocks)
+			bb |= (uint64_t)ring.get((rd >> 2) & (CAP / 4u - 1u)) << bc;
+			bc += 32; rd += 4u;
+		}
+	}
+	SSV_HD uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+	SSV_HD void drop(int n) { bb >>= n; bc -= n; }
+	SSV_HD uint32_t take(int n) { uint32_t v = peek(n); drop(n); return v; }
+	SSV_HD uint32_t consumed(const uint8_t *) const { return rd - skew - (uint32_t)(bc >> 3); }
 };
 
 // LZ77 copy of len bytes from `dist` bytes back.  Measured on MI355X (profiles/r01_bamdec_*.json): the lane is latency bound and the
@@ -267,19 +335,24 @@ struct HuffCounts { uint32_t c[8]; }; // count of codes of length L in bits [16*
 
 // canonical decode: walk the lengths, one bit per step; the first length at which the code falls below first+count wins
 // LIT selects the literal/length table; otherwise the distance table at slot offset sym_base
-template <bool LIT, class Tab>
-SSV_HD int huff_decode(BitReader &br, const HuffCounts &h, const Tab &tab, int sym_base)
+template <bool LIT, class Tab, class Reader>
+SSV_HD int huff_decode(Reader &br, const HuffCounts &h, const Tab &tab, int sym_base)
 {
-	int code = 0, first = 0, index = 0;
+	int code = 0, first = 0, index = 0, used = 0;
 	uint32_t bits = (uint32_t)br.bb; // caller guarantees >= 15 valid bits
 #pragma unroll
 	for (int len = 1; len <= 15; ++len) {
 		code |= (int)(bits & 1u); bits >>= 1;
 		const int count = (int)((h.c[len >> 1] >> ((len & 1) * 16)) & 0xffffu);
-		if (code - count < first) { br.drop(len); const int k = sym_base + index + (code - first); return LIT ? tab.lit_get(k) : tab.dst_get(k); }
+		if (code - count < first) { used = len; break; }
 		index += count; first += count; first <<= 1; code <<= 1;
 	}
-	return -1;
+	// ONE table read behind the loop, whatever the length was: lanes of a wavefront leave the loop at different lengths, and a read inside each
+	// exit would be a trip to the table per distinct length
+	if (used == 0) return -1;
+	br.drop(used);
+	const int k = sym_base + index + (code - first);
+	return LIT ? tab.lit_get(k) : tab.dst_get(k);
 }
 
 // build the decoding tables of one code from the lengths at Tab::len[len_base, len_base + n): counts -> h, permutation -> Tab::sym[sym_base...)
@@ -312,10 +385,9 @@ SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCount
 }
 
 // Inflate one raw deflate stream of in_len bytes into exactly out_len bytes.  Returns INF_OK or an error (the lane's block is then bad).
-template <class Tab, class Out>
-SSV_HD int inflate_stream_to(const uint8_t *in, uint32_t in_len, Out &out, uint32_t out_len, Tab &tab)
+template <class Tab, class Out, class Reader>
+SSV_HD int inflate_stream_from(Reader &br, const uint8_t *in, uint32_t in_len, Out &out, uint32_t out_len, Tab &tab)
 {
-	BitReader br(in, in_len);
 	uint32_t o = 0;
 	int last;
 	do {
@@ -377,6 +449,7 @@ SSV_HD int inflate_stream_to(const uint8_t *in, uint32_t in_len, Out &out, uint3
 			if (rc != INF_OK) return rc;
 		}
 		for (;;) {
+			br.top_of_symbol();
 			br.refill();
 			int s = huff_decode<true>(br, lit, tab, 0);
 			if (s < 0) return INF_E_CODE;
@@ -408,6 +481,13 @@ SSV_HD int inflate_stream_to(const uint8_t *in, uint32_t in_len, Out &out, uint3
 	// bytes taken from the input: everything up to p except the whole bytes still in the buffer
 	if (br.consumed(in) > in_len) return INF_E_INPUT;
 	return INF_OK;
+}
+
+template <class Tab, class Out>
+SSV_HD int inflate_stream_to(const uint8_t *in, uint32_t in_len, Out &out, uint32_t out_len, Tab &tab)
+{
+	BitReader br(in, in_len);
+	return inflate_stream_from(br, in, in_len, out, out_len, tab);
 }
 
 template <class Tab, bool COPY2 = false>

@@ -35,9 +35,9 @@ namespace {
 std::string g_create_error;
 
 // timed kernel groups (ssv_prof_*)
-enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_BAM_INFLATE, P_BAM_RECORDS, P_BAM_DECODE, P_REALIGN_INDEX, P_REALIGN_QUERY, P_COUNT };
-const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "table_d2h", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish", "bam_inflate", "bam_records", "bam_decode", "realign_index", "realign_query"};
-const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\ntable_d2h\nisize_stats\ngetsv_scan\ngetsv_cand\ndepth_finish\nbam_inflate\nbam_records\nbam_decode\nrealign_index\nrealign_query";
+enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_BAM_INFLATE, P_BAM_RECORDS, P_BAM_DECODE, P_REALIGN_INDEX, P_REALIGN_QUERY, P_BAM_UPLOAD, P_BAM_RESOLVE, P_COUNT };
+const char *const kProfNames[P_COUNT] = {"h2d", "clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "table_d2h", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish", "bam_inflate", "bam_records", "bam_decode", "realign_index", "realign_query", "bam_upload", "bam_resolve"};
+const char kProfNameList[] = "h2d\nclip_scan\nclip_place\nclip_gather\nevent_sort\ncluster_bins\ncluster_pack\ntable_d2h\nisize_stats\ngetsv_scan\ngetsv_cand\ndepth_finish\nbam_inflate\nbam_records\nbam_decode\nrealign_index\nrealign_query\nbam_upload\nbam_resolve";
 
 struct DBuf { // grow-only device buffer
 	void *p = nullptr;

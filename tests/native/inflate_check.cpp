@@ -138,6 +138,31 @@ int main()
 						if (rc4 == ssv::INF_OK) ssv::resolve_tokens(o4.data(), tk.data(), to.n);
 						if (!(rc4 == ssv::INF_OK && to.n <= ssv::token_capacity((uint32_t)n) && tk[ssv::token_capacity((uint32_t)n)] == 0xdeadbeefu && memcmp(o4.data(), d.data(), n) == 0 && o4[n] == 0x55)) { same = false; fprintf(stderr, "TOKEN sink: "); }
 					}
+					for (int mi = 0; mi < 4; ++mi) { // the window reader (RingReader) in front of the token sink, at every misalignment of the input
+						struct CpuRing {
+							uint32_t a[32];
+							uint32_t get(uint32_t j) const { return a[j]; }
+							void set(uint32_t j, uint32_t v) { a[j] = v; }
+							bool any(bool c) const { return c; }
+						};
+						std::vector<uint8_t> cc(clen + 4 + 32, 0xAA); // (a group may reach 16 + 3 bytes past the stream's end)
+						memcpy(cc.data() + mi, c.data(), clen);
+						std::vector<uint8_t> o5(n + 8, 0x55);
+						std::vector<uint32_t> tk(ssv::token_capacity((uint32_t)n) + 1, 0xdeadbeefu);
+						ssv::TokenOut to;
+						to.out = o5.data(); to.tok = tk.data();
+						int rc5;
+						if (mi & 1) { ssv::RingReader<CpuRing, 64> br(cc.data() + mi, clen, CpuRing()); rc5 = ssv::inflate_stream_from(br, cc.data() + mi, clen, to, (uint32_t)n, tab); }
+						else { ssv::RingReader<CpuRing, 128> br(cc.data() + mi, clen, CpuRing()); rc5 = ssv::inflate_stream_from(br, cc.data() + mi, clen, to, (uint32_t)n, tab); }
+						if (rc5 == ssv::INF_OK) ssv::resolve_tokens(o5.data(), tk.data(), to.n);
+						if (!(rc5 == ssv::INF_OK && memcmp(o5.data(), d.data(), n) == 0 && o5[n] == 0x55)) { same = false; fprintf(stderr, "WINDOW reader (misalignment %d, rc %d): ", mi, rc5); }
+						if (n > 16 && level > 0 && shape != 5 && mi == 1) { // a stream cut short is refused (fed zero bits behind its end, not the next stream's bytes)
+							ssv::TokenOut t2;
+							t2.out = o5.data(); t2.tok = tk.data();
+							ssv::RingReader<CpuRing, 128> br(cc.data() + mi, clen - 3, CpuRing());
+							if (ssv::inflate_stream_from(br, cc.data() + mi, clen - 3, t2, (uint32_t)n, tab) == ssv::INF_OK) { same = false; fprintf(stderr, "WINDOW reader: truncated input accepted: "); }
+						}
+					}
 					{ // the second copy routine (unaligned dword moves)
 						std::vector<uint8_t> o2(n + 8, 0x55);
 						int rc2 = ssv::inflate_stream<ssv::PlainTab, true>(c.data(), clen, o2.data(), (uint32_t)n, tab);
