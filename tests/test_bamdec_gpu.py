@@ -151,16 +151,58 @@ def test_device_decode_rejects_damage(ctx, ragged, tmp_path):
         _device_all(ctx, bad, 64 << 20, 1 << 16)
 
 
-@pytest.mark.parametrize("mode", ["rings", "rings8"])
+def _pattern_records(n, seed):
+    """records whose bases and qualities are runs and repeating patterns of every period 1..70 and of every length up to a few hundred bytes -
+    in the deflate stream: matches with dist < len (a pattern that feeds itself), dist == len, long and short matches, next to plain literals"""
+    import random
+    rng = random.Random(seed)
+    recs = []
+    for i in range(n):
+        l = rng.choice([30, 76, 151, 151, 259, 600, 2000])
+        period = 1 + i % 70
+        unit_q = bytes(rng.randrange(42) for _ in range(period))
+        unit_s = "".join(rng.choice("ACGT") for _ in range(2 * period))
+        kind = i % 4
+        qual = (unit_q * (l // period + 1))[:l] if kind != 3 else bytes(rng.randrange(42) for _ in range(l))
+        seq = (unit_s * (l // (2 * period) + 1))[:l] if kind in (1, 2) else "".join(rng.choice("ACGTN") for _ in range(l))
+        if kind == 2 and l > 40:  # a pattern broken by a few literals every now and then
+            q = bytearray(qual)
+            for k in range(17, l, 37):
+                q[k] = rng.randrange(42)
+            qual = bytes(q)
+        recs.append(dict(qname=f"p{i}", flag=rng.choice([99, 147, 83, 163]), tid=0, pos=10 + 3 * i, mapq=60, cigar=f"12S{l - 12}M" if i % 3 else f"{l - 9}M9S",
+                         mtid=0, mpos=100 + 3 * i, isize=rng.randrange(-900, 900), seq=seq, qual=qual, aux=b"NMC\x01"))
+    return recs
+
+
+@pytest.mark.parametrize("chunk_bytes,max_blocks", [(64 << 20, 1 << 16), (64 << 20, 2)], ids=["one-chunk", "2blk"])
+def test_device_decode_match_shapes(ctx, tmp_path, chunk_bytes, max_blocks):
+    """the inflate kernels' copy paths one by one (k_bgzf_resolve: a round's independent matches, matches inside the round, repeating patterns,
+    long matches), on files written by zlib at level 6 (bamio) and by the repository's own writer"""
+    recs = _pattern_records(9000, 5)
+    p1 = str(tmp_path / "patterns.bam")
+    bamio.write_bam(p1, NAMES, [10_000_000] * len(NAMES), recs)
+    for path in (p1,):
+        hb, hunm = _host_all(path, True)
+        db, dunm, druns, _ = _device_all(ctx, path, chunk_bytes, max_blocks, True)
+        h, d = _flatten(hb), _flatten(db)
+        for k in KEYS + ("shipped",):
+            assert np.array_equal(h[k], d[k]), k
+        assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"]
+        assert len(h["seqs"]) == len(recs)
+
+
+@pytest.mark.parametrize("mode", ["plain", "rings", "rings8"])
 def test_ring_machine_inflate_modes(mode):
-    """SSV_INFLATE=rings...: the state-machine decoder with LDS rings and wavefront-cooperative far moves (inflate_lanes.h; not the default,
-    DESIGN.md section 9) through the same device-decode == host-reader checks (the mode is read once per process: a child pytest runs them)"""
+    """SSV_INFLATE=plain (one pass, a lane per block) / rings... (the state-machine decoder with LDS rings and wavefront-cooperative far moves,
+    inflate_lanes.h): not the default, kept correct - the same device-decode == host-reader checks run under each (the mode
+    is read once per process: a child pytest runs them)"""
     import subprocess
     import sys
     if os.environ.get("SSV_INFLATE"):
         pytest.skip("already inside a mode run")
     env = dict(os.environ, SSV_INFLATE=mode)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large"], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
