@@ -384,7 +384,7 @@ def file_path_leg(ctx, args, device):
     """The same workload from a BAM FILE: a smaller genome fraction of the same synthetic 30x sample is written as a real BAM by the
     repository's writer (libseeksv_host: BGZF level 6 like samtools), its compressed bytes are put into pinned host memory in chunks of
     whole BGZF blocks, and the timed region runs what `seeksv getclip` + `seeksv getsv` do with a file: per chunk H2D of the compressed
-    bytes -> device BGZF inflate + BAM decode (ssv_bamdec_*) -> scans; pass 1 = getclip (clip events -> cluster table on the host), pass 2 =
+    bytes (the next chunk's announced ahead, ssv_bamdec_prefetch, so it runs beside this chunk's kernels) -> device BGZF inflate + BAM decode (ssv_bamdec_*) -> scans; pass 1 = getclip (clip events -> cluster table on the host), pass 2 =
     insert-size statistics on the first chunk, then the fused discordant + depth scan of every chunk (the first chunk is decoded once
     for both) -> counts / depths on the host.  Rate = records / (pass 1 + pass 2)."""
     import ctypes as C
@@ -438,6 +438,12 @@ def file_path_leg(ctx, args, device):
             ctx._check(lib.ssv_bamdec_decode(ctx._h, C.c_void_p(buf.data_ptr()), nbytes, blocks, nb, keep_all_seq, C.byref(b)), "ssv_bamdec_decode")
             return b
 
+        def announce(k):
+            """chunk k's compressed bytes start for the GPU now (ssv_bamdec_prefetch): called before the chunk in front of it is decoded"""
+            if k < len(chunks):
+                buf, _, _, nbytes = chunks[k]
+                ctx._check(lib.ssv_bamdec_prefetch(ctx._h, C.c_void_p(buf.data_ptr()), nbytes), "ssv_bamdec_prefetch")
+
         def end_of_input():
             b = _abi.Batch()
             ctx._check(lib.ssv_bamdec_decode(ctx._h, None, 0, None, 0, 0, C.byref(b)), "ssv_bamdec_decode")
@@ -449,7 +455,9 @@ def file_path_leg(ctx, args, device):
             ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
             ctx.clip_begin(0.9, 1, False, None, 0)
             n = 0
+            announce(0)
             for k in range(len(chunks)):
+                announce(k + 1)
                 b = decode(k)
                 n += b.n
                 ctx.clip_scan(b)
@@ -468,7 +476,9 @@ def file_path_leg(ctx, args, device):
             # which then serves the scan as well; if it took more chunks, decoding starts over for the scan
             ctx._check(lib.ssv_isize_begin(ctx._h, 20, 5000000), "ssv_isize_begin")
             done, used, b0 = C.c_int32(0), 0, None
+            announce(0)
             while used < len(chunks) and not done.value:
+                announce(used + 1)
                 b0 = decode(used)
                 used += 1
                 ctx._check(lib.ssv_isize_accumulate(ctx._h, C.byref(b0), C.byref(done)), "ssv_isize_accumulate")
@@ -483,7 +493,9 @@ def file_path_leg(ctx, args, device):
             else:
                 ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
                 first_k = 0
+                announce(0)
             for k in range(first_k, len(chunks)):
+                announce(k + 1)
                 ctx.getsv_scan(decode(k))
             end_of_input()
             counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)

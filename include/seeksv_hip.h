@@ -392,6 +392,11 @@ int ssv_bamdec_prev_tid(ssv_ctx *ctx, int32_t tid);
  * reader thread can fill one while the other is being decoded; any host memory works too.  A buffer is free again when the decode
  * call that was given it returns. */
 int ssv_bamdec_staging(ssv_ctx *ctx, int which, size_t bytes, void **host_ptr);
+/* Optional: announce a chunk ahead.  Its compressed bytes start their way to the GPU at once, on the context's upload stream, while the chunk
+ * before it is being inflated (two chunks may be announced at any time); ssv_bamdec_decode of the same (comp, comp_bytes) then finds them there instead
+ * of copying.  The host buffer must stay untouched until that decode call returns; it should be page-locked (ssv_bamdec_staging, ssv_host_alloc) -
+ * out of pageable memory the copy is not asynchronous.  Typical loop: prefetch(0); for k: prefetch(k+1); decode(k); ... */
+int ssv_bamdec_prefetch(ssv_ctx *ctx, const void *comp, size_t comp_bytes);
 /* Inflate + decode one chunk.  *out is an SSV_MEM_DEVICE batch owned by the context, valid until the next decode on it (stream
  * ordered: kernels already enqueued on the context's stream may still read it).  n_blocks == 0 = end of input (fails if a record
  * is unfinished).  keep_all_seq as in ssvh_bam_read_batch.  Synchronises the stream. */

@@ -62,23 +62,39 @@ class Context:
         return _abi.make_batch(b)
 
     # ---- device-side BGZF inflate + BAM decode ----
-    def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False, chunk_inflated=1 << 31):
+    def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False, chunk_inflated=1 << 31, prefetch=True):
         """Generator over SSV_MEM_DEVICE batches of a whole BAM file (host.BamReader), decoded on the GPU: yields (Batch, info dict).
-        The batch is valid until the next iteration."""
+        The batch is valid until the next iteration.  prefetch: chunk k+1 is read into the second staging buffer and announced
+        (ssv_bamdec_prefetch) before chunk k is decoded, so its bytes cross PCIe while chunk k's kernels run."""
         hl = reader._lib
         first = C.c_uint64()
         if hl.ssvh_bam_raw_begin(reader.handle, C.byref(first)) != 0:
             raise IOError(hl.ssvh_last_error().decode())
         self._check(self._lib.ssv_bamdec_begin(self._h, len(reader.target_names), first.value), "ssv_bamdec_begin")
-        stage = C.c_void_p()
-        self._check(self._lib.ssv_bamdec_staging(self._h, 0, chunk_bytes, C.byref(stage)), "ssv_bamdec_staging")
-        blocks = (_abi.BgzfBlock * max_blocks)()
-        while True:
+        stages, blocks = [None, None], [None, None]
+
+        def read(k):
+            """chunk k into staging buffer k & 1; its compressed bytes leave for the GPU at once (ssv_bamdec_prefetch)"""
+            w = k & 1
+            if stages[w] is None:
+                stages[w] = C.c_void_p()
+                self._check(self._lib.ssv_bamdec_staging(self._h, w, chunk_bytes, C.byref(stages[w])), "ssv_bamdec_staging")
+                blocks[w] = (_abi.BgzfBlock * max_blocks)()
             nb, nbytes = C.c_int64(), C.c_size_t()
-            if hl.ssvh_bam_read_blocks(reader.handle, stage, chunk_bytes, chunk_inflated, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
+            if hl.ssvh_bam_read_blocks(reader.handle, stages[w], chunk_bytes, chunk_inflated, blocks[w], max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
                 raise IOError(hl.ssvh_last_error().decode())
+            if nb.value and prefetch:
+                self._check(self._lib.ssv_bamdec_prefetch(self._h, stages[w], nbytes.value), "ssv_bamdec_prefetch")
+            return nb, nbytes
+
+        ci, cur = 0, read(0)
+        while True:
+            nb, nbytes = cur
+            if nb.value:
+                cur = read(ci + 1)  # read (and announced) before this chunk's kernels start: its upload runs beside them
             b = _abi.Batch()
-            self._check(self._lib.ssv_bamdec_decode(self._h, stage, nbytes.value, blocks, nb.value, int(keep_all_seq), C.byref(b)), "ssv_bamdec_decode")
+            self._check(self._lib.ssv_bamdec_decode(self._h, stages[ci & 1], nbytes.value, blocks[ci & 1], nb.value, int(keep_all_seq), C.byref(b)), "ssv_bamdec_decode")
+            ci += 1
             if nb.value == 0:
                 return
             info = _abi.BamdecInfo()

@@ -113,6 +113,31 @@ def test_device_decode_equals_host_reader_goldens(ctx, sub, name, keep_all):
     assert druns == _runs_reference(h["flag"], h["tid"])
 
 
+def test_announced_chunks_equal_copied_chunks(ctx, ragged):
+    """ssv_bamdec_prefetch: chunks announced ahead (bytes on the upload stream into one of two device slots) decode to the same batches as
+    chunks copied by the decode call itself; announcing more than two, or a chunk that is never decoded, is harmless"""
+    a = _flatten(_device_all(ctx, ragged, 200_000, 7)[0])                      # bam_batches announces chunk k+1 before it decodes chunk k
+    import ctypes as C
+    out = []
+    with host.BamReader(ragged) as r:
+        for b, _ in ctx.bam_batches(r, chunk_bytes=200_000, max_blocks=7, prefetch=False):
+            if b.n:
+                out.append(ctx.batch_to_host(b))
+    c = _flatten(out)
+    for k in KEYS + ("shipped",):
+        assert np.array_equal(a[k], c[k]), k
+    assert a["cigars"] == c["cigars"] and a["seqs"] == c["seqs"]
+    # three announcements in a row (the third finds both slots taken and is left to its decode call), then a fresh file
+    pin = device.PinnedArrays()
+    bufs = [pin.empty(4096, np.uint8) for _ in range(3)]
+    for x in bufs:
+        x[:] = 7
+        assert ctx._lib.ssv_bamdec_prefetch(ctx._h, C.c_void_p(x.ctypes.data), x.size) == 0
+    b = _flatten(_device_all(ctx, ragged, 1 << 17, 1 << 16)[0])
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_device_decode_feeds_getclip(ctx):
     """BAM bytes -> device inflate/decode -> clip kernels, nothing decoded on the host: the reference's clip rows"""
     path = os.path.join(G.GOLDEN, "example", "cancer.sort.bam")
