@@ -87,6 +87,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_dev = dev if (world > 1 and backend == "nccl") else None
+    # N > 1: every rank keeps its threads - and with them the pinned buffers it allocates (the 0.66 GB table lands in them every step) - on the CPUs
+    # next to its own GPU, so that eight tables a step do not cross the sockets' link
+    near_cpus = bind_near_gpu(torch, local_rank) if world > 1 and os.environ.get("SSV_NO_CPU_BINDING") is None else 0
 
     from seeksv_amd import host, shard, synth
     from seeksv_amd.device import Context
@@ -343,7 +346,7 @@ def main():
                        "records_total": total_records, "records_per_gpu": n_own, "junctions": len(w.junctions), "parallelism": f"range-partition x{world}",
                        "multi_gpu": "weak scaling: 30x per GPU over the same genome (N GPUs = 30N x), not BASELINE config 4's fixed 300x BAM split N ways",
                        "batch_layout": "hot columns tid/pos/n_cigar + cigar_ends (a one-byte copy of the first and last CIGAR operation codes: the getclip stream reads it instead of n_cigar and applies the soft-clip test to every record) + one 64-byte line per record (ssv_record) + CIGARs + packed bases/qualities of soft-clipped records; SSV_MEM_PERSISTENT",
-                       "generation_s": round(gen_s, 2)},
+                       "host_cpus_bound_near_gpu": near_cpus, "generation_s": round(gen_s, 2)},
             "roofline": {"kernel": "path: all device kernels of one step (getclip + insert size + getsv passes; PCIe copy excluded)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": total_traffic,
                          "algorithmic_bytes_per_record": PATH_BYTES_PER_RECORD, "records_per_launch": float(n_own), "avg_launch_ms": round(dev_ms, 4),
@@ -378,6 +381,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bind_near_gpu(torch, index):
+    """sched_setaffinity to the GPU's local CPUs (sysfs local_cpulist of its PCI function); returns how many, 0 = left alone"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        cpus = set()
+        for part in open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) < 8:
+            return 0
+        os.sched_setaffinity(0, cpus)
+        return len(cpus)
+    except Exception:
+        return 0
 
 
 def file_path_leg(ctx, args, device):
