@@ -150,10 +150,39 @@ __device__ __forceinline__ void resolve_one(uint8_t *o, uint32_t pos, uint32_t l
 	}
 }
 
-// Sixteen tokens per round, one per lane.  A match whose source lies wholly before the round's first byte cannot depend on another match of the
-// round: those are copied all at once, every lane its own match - the loads of all of them first, then the stores, so a round pays one trip to memory
-// instead of one per match.  The rest (a source inside the round, a repeating pattern) follow in order, the group's lanes together on each.  Stores
-// of this pass are waited for only when a source reaches above the watermark `dirty`.
+// every lane its own short match (L = 0: none; else 3..32 bytes, source and destination disjoint): up to four dwords per turn, the loads before the stores.
+// (Tried: all eight dwords' loads before the first store, one turn whatever the lengths - 15.7 -> 23.7 ms: what this kernel pays for is the NUMBER of
+// scattered load / store instructions a wavefront issues, each one costs the CU's address path a cycle per lane, and eight + eight mostly empty ones
+// a phase are more than a second turn for the few long matches.)
+__device__ __forceinline__ void copy_own(uint8_t *o, uint32_t src, uint32_t dst, uint32_t L)
+{
+	if (L == 3u) { // one dword read (its fourth byte is the hole's first), three bytes written
+		const uint32_t v = ld32(o + src);
+		o[dst] = (uint8_t)v; o[dst + 1] = (uint8_t)(v >> 8); o[dst + 2] = (uint8_t)(v >> 16);
+	}
+	for (uint32_t at = 0; __any(L >= 4u && at < L); at += 16u) {
+		if (L >= 4u && at < L) { // the last dword ends with the match (it may overlap the one before: same bytes)
+			const uint32_t last = L - 4u;
+			const uint32_t q0 = at < last ? at : last, q1 = at + 4u < last ? at + 4u : last, q2 = at + 8u < last ? at + 8u : last, q3 = at + 12u < last ? at + 12u : last;
+			const bool h1 = at + 4u < L, h2 = at + 8u < L, h3 = at + 12u < L;
+			uint32_t r1 = 0, r2 = 0, r3 = 0;
+			const uint32_t r0 = ld32(o + src + q0);
+			if (h1) r1 = ld32(o + src + q1); // (only the lanes that have such a dword: a scattered access costs per lane)
+			if (h2) r2 = ld32(o + src + q2);
+			if (h3) r3 = ld32(o + src + q3);
+			st32u(o + dst + q0, r0);
+			if (at + 4u < L) st32u(o + dst + q1, r1);
+			if (at + 8u < L) st32u(o + dst + q2, r2);
+			if (at + 12u < L) st32u(o + dst + q3, r3);
+		}
+	}
+}
+
+// Sixteen tokens per round, one per lane; a prefix sum over the group gives every match its place.  The round is worked off in PHASES, each one
+// trip to memory: a match is ready when its source touches no hole of an earlier match of the round that is still open; all ready short matches
+// are copied at once, every lane its own - the loads of all of them, then the stores - and ready long matches / repeating patterns one after the
+// other with all lanes on each.  Phase one needs no look at the other lanes: a source that ends before the round's first byte is ready.  Typical:
+// two phases a round instead of a trip per match.  Stores of this pass are waited for only when a source reaches above the watermark `dirty`.
 __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
                                                         int64_t n_blocks, uint8_t *out)
 {
@@ -181,36 +210,36 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restri
 		}
 		const uint32_t total = (uint32_t)__shfl((int)inc, RESOLVE_LANES - 1, RESOLVE_LANES);
 		const uint32_t dst = pos + inc - len, src = dst - dist;
-		const bool alone = !esc && dist >= len && len <= 32u && src + len <= pos; // (a long match is quicker with all the lanes on it)
-		const bool later = !esc && !alone;
-		if (__any(alone && src + len > dirty)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; }
-		const uint32_t L = alone ? len : 0u;
-		if (L == 3u) { // one dword read (its fourth byte is the hole's first), three bytes written
-			const uint32_t v = ld32(o + src);
-			o[dst] = (uint8_t)v; o[dst + 1] = (uint8_t)(v >> 8); o[dst + 2] = (uint8_t)(v >> 16);
-		}
-		for (uint32_t done = 0; __any(L >= 4u && done < L); done += 16u) {
-			if (L >= 4u && done < L) { // up to four dwords; the last one ends with the match (it may overlap the one before: same bytes)
-				const uint32_t last = L - 4u;
-				const uint32_t q0 = done, q1 = done + 4u < last ? done + 4u : last, q2 = done + 8u < last ? done + 8u : last, q3 = done + 12u < last ? done + 12u : last;
-				const uint32_t r0 = ld32(o + src + (q0 < last ? q0 : last)), r1 = ld32(o + src + q1), r2 = ld32(o + src + q2), r3 = ld32(o + src + q3);
-				st32u(o + dst + (q0 < last ? q0 : last), r0);
-				if (done + 4u < L) st32u(o + dst + q1, r1);
-				if (done + 8u < L) st32u(o + dst + q2, r2);
-				if (done + 12u < L) st32u(o + dst + q3, r3);
+		const uint32_t need = len < dist ? len : dist; // the source's bytes: [src, src + need)
+		const bool small = !esc && dist >= len && len <= 32u; // copied by its own lane (a long match is quicker with all the lanes on it)
+		bool done = esc;
+		// ---- phase one ----
+		bool ready = !done && src + need <= pos;
+		for (;;) {
+			if (__any(ready && src + need > dirty)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; }
+			copy_own(o, src, dst, ready && small ? len : 0u);
+			uint32_t m = (uint32_t)(__ballot(ready && !small) >> grp_shift) & 0xffffu;
+			while (__any(m != 0u)) {
+				if (m) {
+					const int k = __ffs((int)m) - 1;
+					m &= m - 1u;
+					resolve_one(o, (uint32_t)__shfl((int)dst, k, RESOLVE_LANES), (uint32_t)__shfl((int)len, k, RESOLVE_LANES), (uint32_t)__shfl((int)dist, k, RESOLVE_LANES), gl);
+				}
 			}
-		}
-		if (dirty > pos) dirty = pos;
-		uint32_t m = (uint32_t)(__ballot(later) >> grp_shift) & 0xffffu;
-		while (__any(m != 0u)) {
-			if (m) {
-				const int k = __ffs((int)m) - 1;
-				m &= m - 1u;
-				const uint32_t kdst = (uint32_t)__shfl((int)dst, k, RESOLVE_LANES), klen = (uint32_t)__shfl((int)len, k, RESOLVE_LANES), kdist = (uint32_t)__shfl((int)dist, k, RESOLVE_LANES);
-				if (kdst - kdist + (klen < kdist ? klen : kdist) > dirty) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; }
-				resolve_one(o, kdst, klen, kdist, gl);
-				if (dirty > kdst) dirty = kdst;
-			}
+			if (dirty > pos) dirty = pos;
+			done = done || ready;
+			if (!__any(!done)) break;
+			// ---- the next phase: ready = no open hole of an earlier match of the round under the source ----
+			// (the group is one DPP row: fifteen rotations show every lane all the others - register moves, no trip through LDS; the rotated lane
+			// number says whose values they are)
+			bool blocked = false;
+			const int meta = gl | ((int)!done << 4);
+#define SSV_ROR(K) { const uint32_t hs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dst, 0x120 + K, 0xf, 0xf, false), hl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x120 + K, 0xf, 0xf, false); \
+				const int mt = __builtin_amdgcn_update_dpp(0, meta, 0x120 + K, 0xf, 0xf, false); \
+				blocked = blocked || ((mt & 15) < gl && (mt & 16) && src < hs + hl && hs < src + need); }
+			SSV_ROR(1) SSV_ROR(2) SSV_ROR(3) SSV_ROR(4) SSV_ROR(5) SSV_ROR(6) SSV_ROR(7) SSV_ROR(8) SSV_ROR(9) SSV_ROR(10) SSV_ROR(11) SSV_ROR(12) SSV_ROR(13) SSV_ROR(14) SSV_ROR(15)
+#undef SSV_ROR
+			ready = !done && !blocked;
 		}
 		pos += total;
 	}
