@@ -50,8 +50,17 @@ template <int STRIDE> struct LdsTabT {
 	__device__ __forceinline__ void len_set(int i, int v) { len8[i * stride + lane] = (uint8_t)v; }
 	__device__ __forceinline__ uint16_t off_get(int i) const { return off16[i * stride + lane]; }
 	__device__ __forceinline__ void off_set(int i, uint16_t v) { off16[i * stride + lane] = v; }
+	static constexpr bool has_base = false;
 };
 using LdsTab = LdsTabT<64>;
+// ... plus the two codes' base[length] for the decode by limit compares (huff_decode_lim, inflate_core.h): 2 x 16 halves per lane more in LDS
+template <int STRIDE> struct LdsTabLim : LdsTabT<STRIDE> {
+	int16_t *base16;
+	static constexpr bool has_base = true;
+	__device__ __forceinline__ int base_get(int set, int l) const { return base16[(set * 16 + l) * STRIDE + this->lane]; }
+	__device__ __forceinline__ void base_set(int set, int l, int v) { base16[(set * 16 + l) * STRIDE + this->lane] = (int16_t)v; }
+};
+constexpr int TOKENS_BASE_BYTES = 2 * 16 * 2; // per lane
 
 constexpr int INFLATE_LDS_BYTES = 288 * 64 + 9 * 64 * 4 + 32 * 64;      // 22,784 B per wavefront
 constexpr int INFLATE_SCRATCH_BYTES = 320 * 64 + 16 * 64 * 2;           // global scratch per wavefront
@@ -95,7 +104,7 @@ struct LdsRing {
 	__device__ __forceinline__ void set(uint32_t j, uint32_t v) { w[j * LPW] = v; }
 	__device__ __forceinline__ bool any(bool c) const { return __any(c) != 0; }
 };
-constexpr uint32_t TOKENS_WINDOW = 128; // bytes of input per lane in LDS
+constexpr uint32_t TOKENS_WINDOW = 64;  // bytes of input per lane in LDS
 
 template <int LPW>
 __global__ __launch_bounds__(WAVE) void k_bgzf_tokens(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, const uint64_t *__restrict__ tok_off,
@@ -104,10 +113,11 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_tokens(const uint8_t *__restrict_
 {
 	extern __shared__ uint8_t lds_raw[];
 	if ((int)threadIdx.x >= LPW) return;
-	LdsTabT<LPW> tab;
+	LdsTabLim<LPW> tab;
 	tab.lit8 = lds_raw;
 	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
 	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;
+	tab.base16 = reinterpret_cast<int16_t *>(lds_raw + (INFLATE_LDS_BYTES / 64 + TOKENS_WINDOW) * LPW);
 	tab.len8 = scratch + (size_t)blockIdx.x * (INFLATE_SCRATCH_BYTES / 64 * LPW);
 	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * LPW);
 	tab.lane = (int)threadIdx.x;

@@ -39,6 +39,13 @@ struct PlainTab {
 	SSV_HD void len_set(int i, int v) { len[i] = (uint8_t)v; }
 	SSV_HD uint16_t off_get(int i) const { return off[i]; }
 	SSV_HD void off_set(int i, uint16_t v) { off[i] = v; }
+	static constexpr bool has_base = false; // true: the table also keeps base[set][length] and symbols are decoded by limit compares (huff_decode_lim)
+};
+struct PlainTabLim : PlainTab {
+	int16_t base[2][16];
+	static constexpr bool has_base = true;
+	SSV_HD int base_get(int set, int l) const { return base[set][l]; }
+	SSV_HD void base_set(int set, int l, int v) { base[set][l] = (int16_t)v; }
 };
 
 struct BitReader {
@@ -355,6 +362,76 @@ SSV_HD int huff_decode(Reader &br, const HuffCounts &h, const Tab &tab, int sym_
 	return LIT ? tab.lit_get(k) : tab.dst_get(k);
 }
 
+SSV_HD uint32_t brev32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __brev(x);
+#else
+	x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+	x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+	x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+	x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+	return (x >> 16) | (x << 16);
+#endif
+}
+SSV_HD int popc32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __popc(x);
+#else
+	return __builtin_popcount(x);
+#endif
+}
+
+// The same decode without the walk.  A wavefront executes the union of its lanes' paths: the bit-by-bit walk above costs it every length up to the
+// longest code among 64 lanes plus an exit per distinct length (~140 instructions a symbol).  Canonical codes can be told apart by ONE comparison per
+// length instead: with the next 15 bits read MSB first (`rev`), a code of length L is present iff rev < limit[L] = (first[L] + count[L]) << (15 - L),
+// and the limits only grow with L - so the length is 1 + the number of limits <= rev.  The 15 limits (<= 0x8000) sit two to a register where the
+// counts were (slot 0 holds limit 0: it always counts, that is the "1 +"); (rev | 0x8000) - limit has bit 15 set iff rev >= limit, in both halves of
+// a register at once, no borrow between them; the 16 result bits are gathered and counted.  The symbol's index in the permutation is
+// code + base[L], base[L] = (symbols shorter than L) - first[L], one small table read (Tab::base_get).
+template <class Tab>
+SSV_HD void huff_limits(const HuffCounts &h, Tab &tab, int set, HuffCounts &lim)
+{
+	int first = 0, off = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) lim.c[k] = 0;
+#pragma unroll
+	for (int l = 1; l <= 15; ++l) {
+		const int count = (int)((h.c[l >> 1] >> ((l & 1) * 16)) & 0xffffu);
+		const int end = first + count; // one past the last code of this length (<= 2^l: huff_construct has refused over-subscribed codes)
+		lim.c[l >> 1] |= ((uint32_t)end << (15 - l)) << ((l & 1) * 16);
+		tab.base_set(set, l, off - first);
+		off += count; first = end << 1;
+	}
+}
+template <bool LIT, class Tab, class Reader>
+SSV_HD int huff_decode_lim(Reader &br, const HuffCounts &lim, const Tab &tab, int set, int sym_base)
+{
+	const uint32_t rev = brev32((uint32_t)br.bb) >> 17; // caller guarantees >= 15 valid bits
+	const uint32_t x = (rev * 0x00010001u) | 0x80008000u;
+	uint32_t m = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) m |= ((x - lim.c[k]) >> k) & (0x80008000u >> k);
+	const int used = popc32(m);
+	if (used > 15) return -1; // no code of any length: the code is incomplete and these bits are not in it
+	br.drop(used);
+	const int k = sym_base + (int)(rev >> (15 - used)) + tab.base_get(set, used);
+	return LIT ? tab.lit_get(k) : tab.dst_get(k);
+}
+// one symbol, by whichever decode the table supports (h holds limits when Tab::has_base, counts otherwise)
+template <bool LIT, class Tab, class Reader>
+SSV_HD int huff_next(Reader &br, const HuffCounts &h, const Tab &tab, int set, int sym_base)
+{
+	if constexpr (Tab::has_base) return huff_decode_lim<LIT>(br, h, tab, set, sym_base);
+	else return huff_decode<LIT>(br, h, tab, sym_base);
+}
+template <class Tab>
+SSV_HD void huff_ready(HuffCounts &h, Tab &tab, int set) // counts -> what huff_next wants
+{
+	if constexpr (Tab::has_base) { const HuffCounts counts = h; huff_limits(counts, tab, set, h); }
+}
+
 // build the decoding tables of one code from the lengths at Tab::len[len_base, len_base + n): counts -> h, permutation -> Tab::sym[sym_base...)
 template <bool LIT, class Tab>
 SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCounts &h)
@@ -413,6 +490,7 @@ SSV_HD int inflate_stream_from(Reader &br, const uint8_t *in, uint32_t in_len, O
 			for (int s = 0; s < 30; ++s) tab.len_set(288 + s, 5);
 			huff_construct<true>(tab, 0, 288, 0, lit);
 			huff_construct<false>(tab, 288, 30, 0, dist);
+			huff_ready(lit, tab, 0); huff_ready(dist, tab, 1);
 		} else {
 			const int nlen = (int)br.take(5) + 257, ndist = (int)br.take(5) + 1, ncode = (int)br.take(4) + 4;
 			if (nlen > 286 || ndist > 30) return INF_E_CODE;
@@ -426,10 +504,11 @@ SSV_HD int inflate_stream_from(Reader &br, const uint8_t *in, uint32_t in_len, O
 			HuffCounts cl;
 			int rc = huff_construct<false>(tab, 0, 19, 12, cl);
 			if (rc != INF_OK) return rc;
+			huff_ready(cl, tab, 1); // (the distance code's slots: it is built after the lengths have been read)
 			int idx = 0, prev = 0;
 			while (idx < nlen + ndist) {
 				br.refill();
-				int s = huff_decode<false>(br, cl, tab, 12);
+				int s = huff_next<false>(br, cl, tab, 1, 12);
 				if (s < 0) return INF_E_CODE;
 				if (s < 16) { tab.len_set(idx++, s); prev = s; continue; }
 				int rep, val = 0;
@@ -447,11 +526,12 @@ SSV_HD int inflate_stream_from(Reader &br, const uint8_t *in, uint32_t in_len, O
 			if (rc != INF_OK) return rc;
 			rc = huff_construct<true>(tab, 0, nlen, 0, lit);
 			if (rc != INF_OK) return rc;
+			huff_ready(lit, tab, 0); huff_ready(dist, tab, 1);
 		}
 		for (;;) {
 			br.top_of_symbol();
 			br.refill();
-			int s = huff_decode<true>(br, lit, tab, 0);
+			int s = huff_next<true>(br, lit, tab, 0, 0);
 			if (s < 0) return INF_E_CODE;
 			if (s < 256) {
 				if (o >= out_len) return INF_E_OUTPUT;
@@ -466,7 +546,7 @@ SSV_HD int inflate_stream_from(Reader &br, const uint8_t *in, uint32_t in_len, O
 			else if (s == 285) len = 258;
 			else { const int e = (s - 261) >> 2; len = ((4u + (uint32_t)((s - 265) & 3)) << e) + 3u + br.take(e); }
 			br.refill();
-			const int d = huff_decode<false>(br, dist, tab, 0);
+			const int d = huff_next<false>(br, dist, tab, 1, 0);
 			if (d < 0 || d > 29) return INF_E_CODE;
 			uint32_t dst;
 			if (d < 4) dst = (uint32_t)d + 1u;

@@ -98,6 +98,7 @@ int main()
 	const size_t sizes[] = {0, 1, 2, 3, 17, 255, 256, 257, 4096, 30000, 65280, 65536};
 	int n_ok = 0, n_bad = 0;
 	ssv::PlainTab tab;
+	ssv::PlainTabLim tabl; // the table of the two-pass kernel: symbols decoded by limit compares (huff_decode_lim)
 	for (int shape = 0; shape < 7; ++shape)
 		for (size_t n : sizes)
 			for (int level = 0; level <= 9; ++level)
@@ -153,14 +154,14 @@ int main()
 						to.out = o5.data(); to.tok = tk.data();
 						int rc5;
 						if (mi & 1) { ssv::RingReader<CpuRing, 64> br(cc.data() + mi, clen, CpuRing()); rc5 = ssv::inflate_stream_from(br, cc.data() + mi, clen, to, (uint32_t)n, tab); }
-						else { ssv::RingReader<CpuRing, 128> br(cc.data() + mi, clen, CpuRing()); rc5 = ssv::inflate_stream_from(br, cc.data() + mi, clen, to, (uint32_t)n, tab); }
+						else { ssv::RingReader<CpuRing, 128> br(cc.data() + mi, clen, CpuRing()); rc5 = ssv::inflate_stream_from(br, cc.data() + mi, clen, to, (uint32_t)n, tabl); } // (as the kernel does)
 						if (rc5 == ssv::INF_OK) ssv::resolve_tokens(o5.data(), tk.data(), to.n);
 						if (!(rc5 == ssv::INF_OK && memcmp(o5.data(), d.data(), n) == 0 && o5[n] == 0x55)) { same = false; fprintf(stderr, "WINDOW reader (misalignment %d, rc %d): ", mi, rc5); }
 						if (n > 16 && level > 0 && shape != 5 && mi == 1) { // a stream cut short is refused (fed zero bits behind its end, not the next stream's bytes)
 							ssv::TokenOut t2;
 							t2.out = o5.data(); t2.tok = tk.data();
 							ssv::RingReader<CpuRing, 128> br(cc.data() + mi, clen - 3, CpuRing());
-							if (ssv::inflate_stream_from(br, cc.data() + mi, clen - 3, t2, (uint32_t)n, tab) == ssv::INF_OK) { same = false; fprintf(stderr, "WINDOW reader: truncated input accepted: "); }
+							if (ssv::inflate_stream_from(br, cc.data() + mi, clen - 3, t2, (uint32_t)n, tabl) == ssv::INF_OK) { same = false; fprintf(stderr, "WINDOW reader: truncated input accepted: "); }
 						}
 					}
 					{ // the second copy routine (unaligned dword moves)
