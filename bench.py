@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--ref-sample", type=int, default=3_000_000, help="records of the sample the real reference binary (oracle/_ref, if it travelled) is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--file-frac", type=float, default=1 / 16, help="genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
+    ap.add_argument("--file-frac", type=float, default=-1.0, help="(default: --genome-frac, i.e. the bench workload itself = BASELINE config 2, 617 M records / 10.5 GB, where >= 128 host cores write the file in about a minute; a quarter of it from 32 cores; else 1/16) genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
                     "inflate + decode -> scans -> tables on the host); 0 = skip")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
     ap.add_argument("--table-format", type=int, default=3, help="ssv_clip_table_format: 3 = the compact table (default), 2 = four-piece blocks with 4-bit bases, 0 = ASCII")
@@ -359,6 +359,9 @@ def main():
             "table": dict(state.get("table_info", {}), host_expand_ms=[round(x, 2) for x in state.get("expand_ms", [])[-6:]], wait_ms=[round(x, 2) for x in state.get("wait_ms", [])[-6:]], bytes=int(state.get("table_bytes", 0)), bytes_per_cluster=round(state.get("table_bytes", 0) / max(1, res["n_clusters"]), 1),
                           note="what crosses PCIe per step; format 3: contig / side / offsets are rebuilt on the host inside the step (ssv_clip_table_expand)"),
         }
+        if args.file_frac < 0:
+            cores_here = os.cpu_count() or 1
+            args.file_frac = args.genome_frac * (1.0 if cores_here >= 128 else 0.25 if cores_here >= 32 else 1 / 16)
         if world == 1 and args.file_frac > 0:
             try:
                 line["file_path"] = file_path_leg(ctx, args, local_rank)
@@ -414,17 +417,18 @@ def file_path_leg(ctx, args, device):
     from concurrent.futures import ThreadPoolExecutor
     import torch
     from seeksv_amd import _abi, host, synth
-    w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, int(args.n_sv * args.file_frac)))
+    w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, round(args.n_sv * args.file_frac / args.genome_frac)))  # the same density of planted junctions
     d = tempfile.mkdtemp(prefix="ssv_file_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         t0 = time.perf_counter()
         chunk = 2_000_000
         starts = list(range(0, w.n_total, chunk))
-        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:   # the generator is a C loop (GIL released)
-            batches = list(ex.map(lambda g: w.generate_host(g, min(chunk, w.n_total - g)), starts))
+        def batches():  # 32 batches at a time (the generator is a C loop, GIL released): at most ~16 GB of records in host memory whatever the file's size
+            with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+                for i in range(0, len(starts), 32):
+                    yield from ex.map(lambda g: w.generate_host(g, min(chunk, w.n_total - g)), starts[i:i + 32])
         bam = os.path.join(d, "sample.bam")
-        host.write_bam(bam, w.names, w.lens, batches)
-        del batches
+        host.write_bam(bam, w.names, w.lens, batches())
         bam_bytes = os.path.getsize(bam)
         make_s = time.perf_counter() - t0
         # the file's BGZF blocks into pinned host memory, in chunks of ~2 GB of inflated data
@@ -435,9 +439,9 @@ def file_path_leg(ctx, args, device):
             if hl.ssvh_bam_raw_begin(r.handle, C.byref(first)) != 0:
                 raise IOError(hl.ssvh_last_error().decode())
             n_targets = len(r.target_names)
-            # chunks of ~6 GB of inflated data (about 100 K BGZF blocks each): the inflate kernel decodes one block per lane and needs that many
-            # to fill the chip
-            chunk_inflated = 6 << 30
+            # chunks of ~5 GB of inflated data (about 80 K BGZF blocks each): the inflate kernels decode one block per lane / per 16 lanes and need that
+            # many to fill the chip (pass 1 keeps 82 K blocks resident at once)
+            chunk_inflated = 5 << 30
             max_blocks = 1 << 18
             cap = min(bam_bytes + (1 << 20), 1 << 30)
             while True:
