@@ -146,7 +146,22 @@ constexpr uint32_t TOKEN_NONE = 0xff800000u; // an escape that skips nothing
 __device__ __forceinline__ void resolve_one(uint8_t *o, uint32_t pos, uint32_t len, uint32_t dist, int gl)
 {
 	const uint32_t src = pos - dist;
-	if (dist >= len) {
+	if (dist >= len && len > 4u * RESOLVE_LANES) {
+		// a long match (65..258 bytes; rare in real reads, 18 % of the matches of a low-entropy file): up to five dwords a lane, the loads of all of them
+		// before the first store - one trip instead of five.  Its own branch, so that the common short match does not pay for the extra instructions.
+		const uint32_t last = len - 4u, o0 = 4u * (uint32_t)gl;
+		uint32_t r[5], q[5];
+#pragma unroll
+		for (int i = 0; i < 5; ++i) {
+			const uint32_t off = o0 + 64u * (uint32_t)i;
+			q[i] = off < last ? off : last; // (a dword that would reach past the end is moved back to end with the match: same bytes)
+			r[i] = 0;
+			if (off < len) r[i] = ld32(o + src + q[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < 5; ++i)
+			if (o0 + 64u * (uint32_t)i < len) st32u(o + pos + q[i], r[i]);
+	} else if (dist >= len) {
 		for (uint32_t base = 0; base < len; base += 4u * RESOLVE_LANES) {
 			const uint32_t off = base + 4u * (uint32_t)gl;
 			if (off + 4u <= len) st32u(o + pos + off, ld32(o + src + off));
