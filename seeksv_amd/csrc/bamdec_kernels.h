@@ -9,7 +9,9 @@
 //                     following the chain by hand; carries the position across blocks -> exact record starts, whatever the guesses
 //   k_list_records    per block: write the record offsets at their ranks (exclusive scan of the counts)
 //   k_record_fields   per record: fixed fields -> structure-of-arrays columns; CIGAR count, soft-clip test, bytes to ship
-//   k_record_payload  per record: CIGAR ops, packed bases + qualities (soft-clipped records only), XC aux flag
+//   k_record_cigars   per record: CIGAR ops to their places (out of a two-operation stash the fields kernel left, or out of the stream); the list of records
+//                     that ship bases / owe an XC flag
+//   k_record_seqs     per listed record (16 lanes): packed bases + qualities, XC aux flag
 //   k_raw_copy        UNMAP|MUNMAP records as raw bytes for the host's unmapped-FASTQ side channel (clip_reads.h:415-419)
 //   k_tid_runs        contig changes among the mapped-pair records (the flush sequence of clip_reads.h:423-438) for the host
 // The chain of record starts is a dependent-load chain; the speculation makes all but the (tiny) stitch parallel, and the stitch
@@ -569,53 +571,61 @@ struct StitchOut { uint64_t tail; uint32_t n_records, n_repaired, corrupt, pad; 
 // One wavefront walks the blocks in order (64 at a time, lane-serial inside the wavefront): `cur` is the true position of the next record
 // start.  A block whose guess equals cur keeps its speculated count/exit; a block that cur has already passed holds no record start;
 // anything else is repaired by following the chain by hand from cur.  first[b] = first record start in block b (or ~0), count[b] fixed up.
+// one step of the stitch: the 64 blocks from `base` on, their guesses in c / end (one block a lane); cur = where the true chain stands (wave-uniform)
+__device__ __forceinline__ void stitch_step(const uint8_t *__restrict__ u, int64_t base, int64_t n_blocks, uint64_t total, const BlockChain &c, uint64_t end, BlockChain *__restrict__ chain,
+                                            uint32_t *__restrict__ count, uint64_t &cur, uint32_t &n_rec, uint32_t &n_rep, uint32_t &bad)
+{
+	const int64_t b = base + lane_id();
+	const int m = (int)(n_blocks - base < WAVE ? n_blocks - base : WAVE);
+	// the usual case, checked for all 64 blocks at once: every guess is the exit of the block before it
+	const uint64_t prev_exit = __shfl_up(c.exit, 1, 64);
+	const bool ok = b >= n_blocks || (c.guess != ~0ull && c.guess == (lane_id() == 0 ? cur : prev_exit));
+	if (__all(ok)) {
+		if (b < n_blocks) count[b] = c.count; // chain[b].guess already is the first record start
+		n_rec += wave_sum(b < n_blocks ? c.count : 0u);
+		cur = __shfl(c.exit, m - 1, 64);
+		return;
+	}
+	uint64_t my_first = ~0ull;
+	uint32_t my_count = 0;
+	for (int l = 0; l < m; ++l) {
+		const uint64_t g = __shfl(c.guess, l, 64), e = __shfl(c.exit, l, 64), bend = __shfl(end, l, 64);
+		const uint32_t cn = __shfl(c.count, l, 64);
+		uint64_t first = ~0ull, nxt = cur;
+		uint32_t cnt = 0;
+		if (cur < bend) {
+			if (g == cur) { first = cur; cnt = cn; nxt = e; }
+			else {
+				// wave-uniform branch: every lane follows the same chain (same addresses: one load per step)
+				bool corrupt = false;
+				first = cur;
+				cnt = follow_chain(u, cur, bend, total, &nxt, &corrupt);
+				if (cnt == 0) first = ~0ull;
+				if (corrupt) bad = 1;
+				++n_rep;
+			}
+		}
+		if (lane_id() == l) { my_first = first; my_count = cnt; }
+		n_rec += cnt;
+		cur = nxt;
+	}
+	if (b < n_blocks) { chain[b].guess = my_first; count[b] = my_count; }
+}
+
 __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
                                                         uint64_t total, BlockChain *__restrict__ chain, uint32_t *__restrict__ count, StitchOut *__restrict__ out)
 {
 	uint64_t cur = start; // wave-uniform
 	uint32_t n_rec = 0, n_rep = 0, bad = 0;
-	for (int64_t base = 0; base < n_blocks; base += WAVE) {
-		const int64_t b = base + lane_id();
-		BlockChain c;
-		uint64_t begin = 0, end = 0;
-		c.guess = ~0ull; c.exit = 0; c.count = 0;
-		if (b < n_blocks) { c = chain[b]; begin = u_off[b]; end = begin + blocks[b].u_len; }
-		uint64_t my_first = ~0ull;
-		uint32_t my_count = 0;
-		const int m = (int)(n_blocks - base < WAVE ? n_blocks - base : WAVE);
-		// the usual case, checked for all 64 blocks at once: every guess is the exit of the block before it
-		{
-			const uint64_t prev_exit = __shfl_up(c.exit, 1, 64);
-			const bool ok = b >= n_blocks || (c.guess != ~0ull && c.guess == (lane_id() == 0 ? cur : prev_exit));
-			if (__all(ok)) {
-				if (b < n_blocks) count[b] = c.count; // chain[b].guess already is the first record start
-				n_rec += wave_sum(b < n_blocks ? c.count : 0u);
-				cur = __shfl(c.exit, m - 1, 64);
-				continue;
-			}
-		}
-		for (int l = 0; l < m; ++l) {
-			const uint64_t g = __shfl(c.guess, l, 64), e = __shfl(c.exit, l, 64), bend = __shfl(end, l, 64);
-			const uint32_t cn = __shfl(c.count, l, 64);
-			uint64_t first = ~0ull, nxt = cur;
-			uint32_t cnt = 0;
-			if (cur < bend) {
-				if (g == cur) { first = cur; cnt = cn; nxt = e; }
-				else {
-					// wave-uniform branch: every lane follows the same chain (same addresses: one load per step)
-					bool corrupt = false;
-					first = cur;
-					cnt = follow_chain(u, cur, bend, total, &nxt, &corrupt);
-					if (cnt == 0) first = ~0ull;
-					if (corrupt) bad = 1;
-					++n_rep;
-				}
-			}
-			if (lane_id() == l) { my_first = first; my_count = cnt; }
-			n_rec += cnt;
-			cur = nxt;
-		}
-		if (b < n_blocks) { chain[b].guess = my_first; count[b] = my_count; }
+	// the kernel is one wavefront waiting for memory: the guesses of 8 x 64 blocks are loaded at once, then checked 64 at a time
+	for (int64_t base = 0; base < n_blocks; base += WAVE * 8) {
+#define SSV_LD(J) BlockChain c##J; uint64_t e##J = 0; { const int64_t b = base + (int64_t)J * WAVE + lane_id(); c##J.guess = ~0ull; c##J.exit = 0; c##J.count = 0; c##J.pad = 0; \
+			if (b < n_blocks) { c##J = chain[b]; e##J = u_off[b] + blocks[b].u_len; } }
+		SSV_LD(0) SSV_LD(1) SSV_LD(2) SSV_LD(3) SSV_LD(4) SSV_LD(5) SSV_LD(6) SSV_LD(7)
+#undef SSV_LD
+#define SSV_ST(J) if (base + (int64_t)J * WAVE < n_blocks) stitch_step(u, base + (int64_t)J * WAVE, n_blocks, total, c##J, e##J, chain, count, cur, n_rec, n_rep, bad);
+		SSV_ST(0) SSV_ST(1) SSV_ST(2) SSV_ST(3) SSV_ST(4) SSV_ST(5) SSV_ST(6) SSV_ST(7)
+#undef SSV_ST
 	}
 	if (lane_id() == 0) { out->tail = cur; out->n_records = n_rec; out->n_repaired = n_rep; out->corrupt = bad; out->pad = 0; }
 }
@@ -643,42 +653,56 @@ struct RecColumns {
 	uint8_t *ends;        // first | last << 4 CIGAR operation codes (ssv_batch_t.cigar_ends)
 	uint32_t *seq_bytes;  // bytes of packed bases + qualities to ship (0 when not shipped)
 	uint32_t *raw_bytes;  // 4 + block_size for UNMAP|MUNMAP records (else 0)
+	uint2 *stash;         // the first two CIGAR operations (k_record_cigars copies from here: most records have no more, and it need not touch the stream again)
 	int32_t *max_span;    // one int: largest reference span (atomicMax)
 	uint32_t *bad;        // one flag: a record whose fields overrun its block_size
 };
 
+// one record's fixed fields -> columns; returns its reference span.  rp = the record (its block_size word), in the stream or in a staged copy of it
+__device__ __forceinline__ int record_fields_of(const uint8_t *rp, int64_t i, int keep_all_seq, const RecColumns &c)
+{
+	int span = 1;
+	const uint8_t *r = rp + 4;
+	const uint32_t bs = ld_u32(rp);
+	const int32_t l_seq = ld_i32(r + 16);
+	const uint32_t l_name = r[8], ncig = ld_u16(r + 12), flag = ld_u16(r + 14);
+	c.tid[i] = ld_i32(r); c.pos[i] = ld_i32(r + 4); c.mapq[i] = r[9]; c.n_cigar[i] = (uint16_t)ncig; c.flag[i] = (uint16_t)flag; c.l_qseq[i] = l_seq;
+	c.mtid[i] = ld_i32(r + 20); c.mpos[i] = ld_i32(r + 24); c.isize[i] = ld_i32(r + 28);
+	const uint64_t o_cig = 32ull + l_name, need = o_cig + 4ull * ncig + ((uint64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (uint64_t)(l_seq < 0 ? 0 : l_seq);
+	bool soft = false;
+	uint32_t ends = 0xffu;
+	uint2 first2 = make_uint2(0u, 0u);
+	if (l_seq < 0 || need > bs) { *c.bad = 1; c.seq_bytes[i] = 0; c.raw_bytes[i] = 0; c.n_cigar[i] = 0; }
+	else {
+		int s = 0;
+		for (uint32_t k = 0; k < ncig; ++k) {
+			const uint32_t op = ld_u32(r + o_cig + 4ull * k);
+			const uint32_t t = op & 15u;
+			if (k == 0) first2.x = op;
+			if (k == 1) first2.y = op;
+			if (t == 0 || t == 2 || t == 3 || t == 7 || t == 8) s += (int)(op >> 4);
+			if ((k == 0 || k == ncig - 1) && t == 4) soft = true;
+			if (k == 0) ends = t | (t << 4);
+			if (k == ncig - 1) ends = (ends & 15u) | (t << 4);
+		}
+		if (s > span) span = s;
+		c.seq_bytes[i] = (soft || keep_all_seq) ? (uint32_t)(((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq) : 0u;
+		c.raw_bytes[i] = (flag & (F_UNMAP | F_MUNMAP)) ? 4u + bs : 0u;
+	}
+	c.ends[i] = (uint8_t)ends;
+	c.stash[i] = first2;
+	c.xc[i] = soft ? 2 : 0; // 2 = "soft clipped, aux not looked at yet": k_record_seqs turns it into the XC flag
+	return span;
+}
+
+// (Tried: a wavefront copies its 64 records' whole run of the stream into LDS with coalesced 16-byte loads and the lanes parse out of the copy - the stream
+// read once, in order: 3.5 -> 3.7 ms, with every load issued before the first LDS write 5.0 ms.  Lane-by-lane loads already pull each 128-byte line only
+// once - consecutive lanes, consecutive records - so the copy saves no bytes and adds a trip through LDS.)
 __global__ __launch_bounds__(BLOCK) void k_record_fields(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, int keep_all_seq, RecColumns c)
 {
 	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	int span = 1;
-	if (i < n) {
-		const uint8_t *r = u + rec_off[i] + 4;
-		const uint32_t bs = ld_u32(r - 4);
-		const int32_t l_seq = ld_i32(r + 16);
-		const uint32_t l_name = r[8], ncig = ld_u16(r + 12), flag = ld_u16(r + 14);
-		c.tid[i] = ld_i32(r); c.pos[i] = ld_i32(r + 4); c.mapq[i] = r[9]; c.n_cigar[i] = (uint16_t)ncig; c.flag[i] = (uint16_t)flag; c.l_qseq[i] = l_seq;
-		c.mtid[i] = ld_i32(r + 20); c.mpos[i] = ld_i32(r + 24); c.isize[i] = ld_i32(r + 28);
-		const uint64_t o_cig = 32ull + l_name, need = o_cig + 4ull * ncig + ((uint64_t)(l_seq < 0 ? 0 : l_seq) + 1) / 2 + (uint64_t)(l_seq < 0 ? 0 : l_seq);
-		bool soft = false;
-		uint32_t ends = 0xffu;
-		if (l_seq < 0 || need > bs) { *c.bad = 1; c.seq_bytes[i] = 0; c.raw_bytes[i] = 0; c.n_cigar[i] = 0; }
-		else {
-			int s = 0;
-			for (uint32_t k = 0; k < ncig; ++k) {
-				const uint32_t op = ld_u32(r + o_cig + 4ull * k);
-				const uint32_t t = op & 15u;
-				if (t == 0 || t == 2 || t == 3 || t == 7 || t == 8) s += (int)(op >> 4);
-				if ((k == 0 || k == ncig - 1) && t == 4) soft = true;
-				if (k == 0) ends = t | (t << 4);
-				if (k == ncig - 1) ends = (ends & 15u) | (t << 4);
-			}
-			if (s > span) span = s;
-			c.seq_bytes[i] = (soft || keep_all_seq) ? (uint32_t)(((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq) : 0u;
-			c.raw_bytes[i] = (flag & (F_UNMAP | F_MUNMAP)) ? 4u + bs : 0u;
-		}
-		c.ends[i] = (uint8_t)ends;
-		c.xc[i] = soft ? 2 : 0; // 2 = "soft clipped, aux not looked at yet": k_record_payload turns it into the XC flag
-	}
+	if (i < n) span = record_fields_of(u + rec_off[i], i, keep_all_seq, c);
 	span = wave_max(span);
 	if (lane_id() == 0 && span > 1) atomicMax(c.max_span, span);
 }
@@ -720,31 +744,76 @@ __device__ __forceinline__ int aux_xc_flag(const uint8_t *p, const uint8_t *end)
 }
 
 // 16 lanes per record: CIGAR ops and (for the records that ship them) packed bases + qualities, byte for byte as they lie in the record
-__global__ __launch_bounds__(BLOCK) void k_record_payload(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, const uint16_t *__restrict__ n_cigar,
-                                                         const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ seq_bytes, uint64_t *__restrict__ seq_off,
-                                                         uint32_t *__restrict__ cigar, uint8_t *__restrict__ seqqual, uint8_t *__restrict__ xc)
+// CIGARs to their places (exclusive scan of n_cigar), one lane per record: out of the stash when the record has at most two operations, out of the stream
+// otherwise.  Records that ship bases + qualities (or still owe their XC flag) go on a list for k_record_seqs - about one in a hundred.
+constexpr int CIGARS_PER_THREAD = 16; // a workgroup takes BLOCK x 16 consecutive records: ONE atomic on the list's counter per 4096 records
+__global__ __launch_bounds__(BLOCK) void k_record_cigars(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, const uint16_t *__restrict__ n_cigar,
+                                                        const uint32_t *__restrict__ cigar_off, const uint2 *__restrict__ stash, const uint32_t *__restrict__ seq_bytes,
+                                                        const uint8_t *__restrict__ xc, uint64_t *__restrict__ seq_off, uint32_t *__restrict__ cigar, uint32_t *__restrict__ list,
+                                                        uint32_t *__restrict__ n_list)
 {
-	const int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
+	__shared__ uint32_t mine[BLOCK * CIGARS_PER_THREAD];
+	__shared__ uint32_t n_mine, base;
+	if (threadIdx.x == 0) n_mine = 0;
+	__syncthreads();
+	const int64_t i0 = (int64_t)blockIdx.x * (BLOCK * CIGARS_PER_THREAD);
+	for (int t = 0; t < CIGARS_PER_THREAD; ++t) {
+		const int64_t i = i0 + (int64_t)t * BLOCK + threadIdx.x;
+		bool has = false;
+		if (i < n) {
+			const uint32_t ncig = n_cigar[i], co = cigar_off[i];
+			if (ncig <= 2u) {
+				const uint2 f = stash[i];
+				if (ncig > 0u) cigar[co] = f.x;
+				if (ncig > 1u) cigar[co + 1] = f.y;
+			} else {
+				const uint8_t *r = u + rec_off[i] + 4;
+				const uint64_t o_cig = 32ull + r[8];
+				for (uint32_t k = 0; k < ncig; ++k) cigar[co + k] = ld_u32(r + o_cig + 4ull * k);
+			}
+			const bool ships = seq_bytes[i] != 0u;
+			if (!ships) seq_off[i] = ~0ull; // SSV_NO_SEQ
+			has = ships || xc[i] == 2;
+		}
+		const uint64_t m = __ballot(has);
+		if (m) {
+			const int leader = __ffsll((long long)m) - 1;
+			uint32_t at = 0;
+			if (lane_id() == leader) at = atomicAdd(&n_mine, (uint32_t)__popcll(m)); // (LDS)
+			at = (uint32_t)__shfl((int)at, leader);
+			if (has) mine[at + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = (uint32_t)i;
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && n_mine) base = atomicAdd(n_list, n_mine);
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < n_mine; k += BLOCK) list[base + k] = mine[k];
+}
+
+// packed bases + qualities of the listed records (16 lanes a record), and their XC aux flag
+__global__ __launch_bounds__(BLOCK) void k_record_seqs(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, const uint16_t *__restrict__ n_cigar,
+                                                      const uint32_t *__restrict__ seq_bytes, const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ list,
+                                                      const uint32_t *__restrict__ n_list, uint8_t *__restrict__ seqqual, uint8_t *__restrict__ xc)
+{
+	const uint32_t total = *n_list;
 	const int sub = (int)(threadIdx.x & 15);
-	if (i >= n) return;
-	const uint8_t *r = u + rec_off[i] + 4;
-	const uint32_t bs = ld_u32(r - 4), l_name = r[8], ncig = n_cigar[i];
-	const uint64_t o_cig = 32ull + l_name, o_seq = o_cig + 4ull * ncig;
-	const uint32_t co = cigar_off[i];
-	for (uint32_t k = (uint32_t)sub; k < ncig; k += 16) cigar[co + k] = ld_u32(r + o_cig + 4ull * k);
-	const uint32_t sb = seq_bytes[i];
-	const uint64_t so = seq_off[i]; // exclusive scan of seq_bytes
-	if (sb) for (uint32_t k = (uint32_t)sub; k < sb; k += 16) seqqual[so + k] = r[o_seq + k];
-	if (sub == 0) {
-		if (!sb) seq_off[i] = ~0ull; // SSV_NO_SEQ
-		if (xc[i] == 2) {
+	for (uint32_t e = (blockIdx.x * BLOCK + threadIdx.x) >> 4; e < total; e += gridDim.x * (BLOCK / 16)) {
+		const uint32_t i = list[e];
+		const uint8_t *r = u + rec_off[i] + 4;
+		const uint32_t bs = ld_u32(r - 4), l_name = r[8], ncig = n_cigar[i];
+		const uint64_t o_seq = 32ull + l_name + 4ull * ncig;
+		const uint32_t sb = seq_bytes[i];
+		if (sb) {
+			const uint64_t so = seq_off[i]; // exclusive scan of seq_bytes
+			for (uint32_t k = (uint32_t)sub; k < sb; k += 16) seqqual[so + k] = r[o_seq + k];
+		}
+		if (sub == 0 && xc[i] == 2) {
 			const int32_t l_seq = ld_i32(r + 16);
 			xc[i] = (uint8_t)aux_xc_flag(r + o_seq + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq, r + bs);
 		}
 	}
 }
 
-// raw bytes of the UNMAP|MUNMAP records, in file order (16 lanes per record)
 __global__ __launch_bounds__(BLOCK) void k_raw_copy(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, const uint32_t *__restrict__ raw_bytes,
                                                    const uint64_t *__restrict__ raw_off, uint8_t *__restrict__ raw)
 {
@@ -783,9 +852,15 @@ __global__ __launch_bounds__(BLOCK) void k_tid_tile_last(const int32_t *__restri
 __global__ __launch_bounds__(WAVE) void k_tid_tile_carry(const int32_t *__restrict__ tile_last, int64_t n_tiles, int32_t prev_tid, int32_t *__restrict__ tile_prev, int32_t *__restrict__ last_tid)
 {
 	int32_t cur = prev_tid; // wave-uniform
-	for (int64_t base = 0; base < n_tiles; base += WAVE) {
-		const int64_t t = base + lane_id();
-		const int32_t mine = t < n_tiles ? tile_last[t] : TID_NONE;
+	constexpr int AHEAD = 16; // (one wavefront waiting for memory: sixteen steps' values are loaded at once)
+	for (int64_t base0 = 0; base0 < n_tiles; base0 += WAVE * AHEAD) {
+	int32_t vals[AHEAD];
+#pragma unroll
+	for (int j = 0; j < AHEAD; ++j) { const int64_t t = base0 + (int64_t)j * WAVE + lane_id(); vals[j] = t < n_tiles ? tile_last[t] : TID_NONE; }
+#pragma unroll
+	for (int j = 0; j < AHEAD; ++j) {
+		const int64_t t = base0 + (int64_t)j * WAVE + lane_id(); // (steps past the end see only TID_NONE: they change nothing)
+		const int32_t mine = vals[j];
 		// exclusive "last value that is not NONE" over the 64 lanes
 		const uint64_t have = __ballot(mine != TID_NONE);
 		const uint64_t below = have & lanemask_lt();
@@ -793,6 +868,7 @@ __global__ __launch_bounds__(WAVE) void k_tid_tile_carry(const int32_t *__restri
 		const int32_t got = __shfl(mine, src, 64);
 		if (t < n_tiles) tile_prev[t] = below ? got : cur;
 		if (have) cur = __shfl(mine, 63 - __clzll((long long)have), 64);
+	}
 	}
 	if (lane_id() == 0) *last_tid = cur;
 }
