@@ -573,17 +573,20 @@ struct StitchOut { uint64_t tail; uint32_t n_records, n_repaired, corrupt, pad; 
 // anything else is repaired by following the chain by hand from cur.  first[b] = first record start in block b (or ~0), count[b] fixed up.
 // one step of the stitch: the 64 blocks from `base` on, their guesses in c / end (one block a lane); cur = where the true chain stands (wave-uniform)
 __device__ __forceinline__ void stitch_step(const uint8_t *__restrict__ u, int64_t base, int64_t n_blocks, uint64_t total, const BlockChain &c, uint64_t end, BlockChain *__restrict__ chain,
-                                            uint32_t *__restrict__ count, uint64_t &cur, uint32_t &n_rec, uint32_t &n_rep, uint32_t &bad)
+                                            uint32_t *__restrict__ count, uint64_t &cur, uint32_t &n_rec, uint32_t &n_lane, uint32_t &n_rep, uint32_t &bad)
 {
 	const int64_t b = base + lane_id();
 	const int m = (int)(n_blocks - base < WAVE ? n_blocks - base : WAVE);
 	// the usual case, checked for all 64 blocks at once: every guess is the exit of the block before it
-	const uint64_t prev_exit = __shfl_up(c.exit, 1, 64);
+	// (this wavefront is alone and every step hangs on the one before: the lane crossings are register moves - a DPP wavefront shift, v_readlane - not
+	// trips through the LDS crossbar, and the record count is summed per lane, once at the end)
+	const uint32_t pe_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)c.exit, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	const uint32_t pe_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(c.exit >> 32), 0x138, 0xf, 0xf, false);
+	const uint64_t prev_exit = (uint64_t)pe_lo | ((uint64_t)pe_hi << 32);
 	const bool ok = b >= n_blocks || (c.guess != ~0ull && c.guess == (lane_id() == 0 ? cur : prev_exit));
 	if (__all(ok)) {
-		if (b < n_blocks) count[b] = c.count; // chain[b].guess already is the first record start
-		n_rec += wave_sum(b < n_blocks ? c.count : 0u);
-		cur = __shfl(c.exit, m - 1, 64);
+		if (b < n_blocks) { count[b] = c.count; n_lane += c.count; } // chain[b].guess already is the first record start
+		cur = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c.exit, m - 1) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(c.exit >> 32), m - 1) << 32);
 		return;
 	}
 	uint64_t my_first = ~0ull;
@@ -616,17 +619,18 @@ __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restric
                                                         uint64_t total, BlockChain *__restrict__ chain, uint32_t *__restrict__ count, StitchOut *__restrict__ out)
 {
 	uint64_t cur = start; // wave-uniform
-	uint32_t n_rec = 0, n_rep = 0, bad = 0;
+	uint32_t n_rec = 0, n_lane = 0, n_rep = 0, bad = 0; // records: counted wave-uniformly on the repair path, per lane on the usual one
 	// the kernel is one wavefront waiting for memory: the guesses of 8 x 64 blocks are loaded at once, then checked 64 at a time
 	for (int64_t base = 0; base < n_blocks; base += WAVE * 8) {
 #define SSV_LD(J) BlockChain c##J; uint64_t e##J = 0; { const int64_t b = base + (int64_t)J * WAVE + lane_id(); c##J.guess = ~0ull; c##J.exit = 0; c##J.count = 0; c##J.pad = 0; \
 			if (b < n_blocks) { c##J = chain[b]; e##J = u_off[b] + blocks[b].u_len; } }
 		SSV_LD(0) SSV_LD(1) SSV_LD(2) SSV_LD(3) SSV_LD(4) SSV_LD(5) SSV_LD(6) SSV_LD(7)
 #undef SSV_LD
-#define SSV_ST(J) if (base + (int64_t)J * WAVE < n_blocks) stitch_step(u, base + (int64_t)J * WAVE, n_blocks, total, c##J, e##J, chain, count, cur, n_rec, n_rep, bad);
+#define SSV_ST(J) if (base + (int64_t)J * WAVE < n_blocks) stitch_step(u, base + (int64_t)J * WAVE, n_blocks, total, c##J, e##J, chain, count, cur, n_rec, n_lane, n_rep, bad);
 		SSV_ST(0) SSV_ST(1) SSV_ST(2) SSV_ST(3) SSV_ST(4) SSV_ST(5) SSV_ST(6) SSV_ST(7)
 #undef SSV_ST
 	}
+	n_rec += wave_sum(n_lane);
 	if (lane_id() == 0) { out->tail = cur; out->n_records = n_rec; out->n_repaired = n_rep; out->corrupt = bad; out->pad = 0; }
 }
 
