@@ -708,7 +708,9 @@ __global__ __launch_bounds__(BLOCK) void k_record_fields(const uint8_t *__restri
 	int span = 1;
 	if (i < n) span = record_fields_of(u + rec_off[i], i, keep_all_seq, c);
 	span = wave_max(span);
-	if (lane_id() == 0 && span > 1) atomicMax(c.max_span, span);
+	// every wavefront has SOME span > 1, and 300 K atomics on one address are served one after the other (3 of this kernel's 3.5 ms were that): look first
+	// (a load that bypasses the CU's cache, or a stale small value would keep this CU's atomics coming), raise only what is not yet as large
+	if (lane_id() == 0 && span > 1 && span > __hip_atomic_load(c.max_span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(c.max_span, span);
 }
 
 // bam_aux_get(b, "XC") + bam_aux2i (clip_reads.cpp:126-127): integer value of the XC tag != 0

@@ -453,7 +453,7 @@ __global__ void k_max_span(DevBatch b, int *out)
 		span = s > 0x7fffffff ? 0x7fffffff : (int)s;
 	}
 	span = wave_max(span);
-	if (lane_id() == 0 && span > 0) atomicMax(out, span);
+	if (lane_id() == 0 && span > 0 && span > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, span); // (look first: one address, a wavefront each)
 }
 
 } // namespace
