@@ -361,7 +361,12 @@ def main():
         }
         if args.file_frac < 0:
             cores_here = os.cpu_count() or 1
-            args.file_frac = args.genome_frac * (1.0 if cores_here >= 128 else 0.25 if cores_here >= 32 else 1 / 16)
+            try:
+                avail_gb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")) / (1 << 20)
+            except Exception:
+                avail_gb = 0.0
+            # the full-size file wants ~40 GB of host memory for a minute (the file in /dev/shm, its pinned copy, 32 batches being written)
+            args.file_frac = args.genome_frac * (1.0 if cores_here >= 128 and avail_gb >= 128 else 0.25 if cores_here >= 32 and avail_gb >= 48 else 1 / 16)
         if world == 1 and args.file_frac > 0:
             try:
                 line["file_path"] = file_path_leg(ctx, args, local_rank)
@@ -418,7 +423,17 @@ def file_path_leg(ctx, args, device):
     import torch
     from seeksv_amd import _abi, host, synth
     w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, round(args.n_sv * args.file_frac / args.genome_frac)))  # the same density of planted junctions
-    d = tempfile.mkdtemp(prefix="ssv_file_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    need = int(w.n_total * 20)  # the file is ~17 bytes a record
+    def room(path):
+        try:
+            st = os.statvfs(path)
+            return st.f_bavail * st.f_frsize
+        except OSError:
+            return 0
+    where = next((p for p in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(p) and room(p) > need), None)
+    if where is None:
+        raise RuntimeError(f"no room for a {need >> 20} MB BAM file in /dev/shm or {tempfile.gettempdir()}")
+    d = tempfile.mkdtemp(prefix="ssv_file_", dir=where)
     try:
         t0 = time.perf_counter()
         chunk = 2_000_000
