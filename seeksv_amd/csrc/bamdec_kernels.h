@@ -537,18 +537,23 @@ __device__ __forceinline__ uint32_t follow_chain(const uint8_t *u, uint64_t o, u
 	return n;
 }
 
-struct BlockChain { uint64_t guess, exit; uint32_t count, pad; }; // guess == ~0: no plausible start found in the block
+struct BlockChain { uint64_t guess, exit; uint32_t count, listed; }; // guess == ~0: no plausible start found in the block; listed: rel[] holds its record starts
+// The record starts k_find_records walks over are kept, as 16-bit offsets from the block's first record, so that k_list_records need not walk the chain again:
+// record i of block b at rel[((b / 64) * REL_CAP + i) * 64 + b % 64] (the 64 lanes of a wavefront write 128 contiguous bytes a step).  A block whose chain
+// the stitch had to repair, or with more records / a longer reach than fits, is walked again instead (listed = 0).
+constexpr uint32_t REL_CAP = 1824; // 65536 / 36: the records a 64 KB block can hold
+__device__ __forceinline__ size_t rel_index(int64_t b, uint32_t i) { return ((size_t)(b >> 6) * REL_CAP + i) * 64 + (size_t)(b & 63); }
 
 // stream = [carry bytes | inflated blocks]; block b covers [u_off[b], u_off[b] + u_len)
 __global__ __launch_bounds__(BLOCK) void k_find_records(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
-                                                       uint64_t total, int32_t n_targets, BlockChain *__restrict__ chain)
+                                                       uint64_t total, int32_t n_targets, BlockChain *__restrict__ chain, uint16_t *__restrict__ rel)
 {
 	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (b >= n_blocks) return;
 	// the first block also stands for what lies before it (the carried-over head of a record, or the BAM header): its chain begins at `start`
 	const uint64_t begin = b == 0 ? start : u_off[b], end = u_off[b] + blocks[b].u_len;
 	BlockChain c;
-	c.guess = ~0ull; c.exit = begin; c.count = 0; c.pad = 0;
+	c.guess = ~0ull; c.exit = begin; c.count = 0; c.listed = 0;
 	uint64_t o = begin;
 	for (; o < end && o + 36 <= total; ++o) {
 		uint64_t q = o;
@@ -560,8 +565,20 @@ __global__ __launch_bounds__(BLOCK) void k_find_records(const uint8_t *__restric
 		if (k == 3 || (k > 0 && q + 36 > total)) { c.guess = o; break; }
 	}
 	if (c.guess != ~0ull) {
-		bool corrupt = false;
-		c.count = follow_chain(u, c.guess, end, total, &c.exit, &corrupt);
+		// follow_chain, keeping the record starts
+		uint32_t n = 0;
+		bool fits = true;
+		uint64_t q = c.guess;
+		while (q < end) {
+			if (q + 4 > total) break;
+			const uint32_t bs = ld_u32(u + q);
+			if (bs < 32) break; // (corrupt: the stitch walks this block again and reports it)
+			if (q + 4 + (uint64_t)bs > total) break;
+			if (n < REL_CAP && q - c.guess <= 0xffffull) rel[rel_index(b, n)] = (uint16_t)(q - c.guess); else fits = false;
+			++n;
+			q += 4 + (uint64_t)bs;
+		}
+		c.count = n; c.exit = q; c.listed = fits ? 1u : 0u;
 	}
 	chain[b] = c;
 }
@@ -612,7 +629,10 @@ __device__ __forceinline__ void stitch_step(const uint8_t *__restrict__ u, int64
 		n_rec += cnt;
 		cur = nxt;
 	}
-	if (b < n_blocks) { chain[b].guess = my_first; count[b] = my_count; }
+	if (b < n_blocks) {
+		chain[b].guess = my_first; count[b] = my_count;
+		if (my_first != c.guess || my_count != c.count) chain[b].listed = 0; // not the chain k_find_records walked: its list is of no use
+	}
 }
 
 __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
@@ -622,7 +642,7 @@ __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restric
 	uint32_t n_rec = 0, n_lane = 0, n_rep = 0, bad = 0; // records: counted wave-uniformly on the repair path, per lane on the usual one
 	// the kernel is one wavefront waiting for memory: the guesses of 8 x 64 blocks are loaded at once, then checked 64 at a time
 	for (int64_t base = 0; base < n_blocks; base += WAVE * 8) {
-#define SSV_LD(J) BlockChain c##J; uint64_t e##J = 0; { const int64_t b = base + (int64_t)J * WAVE + lane_id(); c##J.guess = ~0ull; c##J.exit = 0; c##J.count = 0; c##J.pad = 0; \
+#define SSV_LD(J) BlockChain c##J; uint64_t e##J = 0; { const int64_t b = base + (int64_t)J * WAVE + lane_id(); c##J.guess = ~0ull; c##J.exit = 0; c##J.count = 0; c##J.listed = 0; \
 			if (b < n_blocks) { c##J = chain[b]; e##J = u_off[b] + blocks[b].u_len; } }
 		SSV_LD(0) SSV_LD(1) SSV_LD(2) SSV_LD(3) SSV_LD(4) SSV_LD(5) SSV_LD(6) SSV_LD(7)
 #undef SSV_LD
@@ -636,12 +656,17 @@ __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restric
 
 // rec_off[rank] for every record: block b's records start at rank base[b]
 __global__ __launch_bounds__(BLOCK) void k_list_records(const uint8_t *__restrict__ u, const BlockChain *__restrict__ chain, const uint32_t *__restrict__ count, const uint32_t *__restrict__ base,
-                                                       int64_t n_blocks, uint64_t *__restrict__ rec_off)
+                                                       int64_t n_blocks, const uint16_t *__restrict__ rel, uint64_t *__restrict__ rec_off)
 {
 	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (b >= n_blocks) return;
-	uint64_t o = chain[b].guess;
+	const BlockChain c = chain[b];
 	const uint32_t n = count[b], r0 = base[b];
+	if (c.listed) { // independent, coalesced loads: no chain to wait for
+		for (uint32_t i = 0; i < n; ++i) rec_off[r0 + i] = c.guess + rel[rel_index(b, i)];
+		return;
+	}
+	uint64_t o = c.guess;
 	for (uint32_t i = 0; i < n; ++i) {
 		rec_off[r0 + i] = o;
 		o += 4 + (uint64_t)ld_u32(u + o);
