@@ -848,14 +848,19 @@ __global__ __launch_bounds__(BLOCK) void k_record_seqs(const uint8_t *__restrict
 __global__ __launch_bounds__(BLOCK) void k_raw_copy(const uint8_t *__restrict__ u, const uint64_t *__restrict__ rec_off, int64_t n, const uint32_t *__restrict__ raw_bytes,
                                                    const uint64_t *__restrict__ raw_off, uint8_t *__restrict__ raw)
 {
-	const int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
-	const int sub = (int)(threadIdx.x & 15);
-	if (i >= n) return;
-	const uint32_t nb = raw_bytes[i];
-	if (!nb) return;
-	const uint8_t *r = u + rec_off[i];
-	const uint64_t o = raw_off[i];
-	for (uint32_t k = (uint32_t)sub; k < nb; k += 16) raw[o + k] = r[k];
+	// a lane per record looks (such records are few: most wavefronts leave after one coalesced load); the wavefront then copies each one it found together
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t nb = i < n ? raw_bytes[i] : 0u;
+	uint64_t m = __ballot(nb != 0u);
+	while (m) {
+		const int l = __ffsll((long long)m) - 1;
+		m &= m - 1;
+		const uint32_t knb = (uint32_t)__shfl((int)nb, l);
+		const int64_t ki = i - lane_id() + l;
+		const uint8_t *r = u + rec_off[ki];
+		const uint64_t o = raw_off[ki];
+		for (uint32_t k = (uint32_t)lane_id(); k < knb; k += WAVE) raw[o + k] = r[k];
+	}
 }
 
 // The flush sequence of getclip's record loop (clip_reads.h:423-438) needs, in order, every change of contig among the records that
