@@ -370,6 +370,10 @@ def main():
         if world == 1 and args.file_frac > 0:
             try:
                 line["file_path"] = file_path_leg(ctx, args, local_rank)
+                if args.file_frac == args.genome_frac and isinstance(line.get("result"), dict):
+                    # the same sample once resident in HBM and once as a BAM file (written, inflated, decoded): every count both legs report must agree
+                    fr = line["file_path"]["result"]
+                    line["file_path"]["same_result_as_resident_path"] = all(fr[k] == line["result"][k] for k in fr if k in line["result"])
             except Exception as e:  # the leg is a report beside the headline, never a reason to lose the line
                 line["file_path"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:

@@ -34,6 +34,11 @@ def test_bench_line_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "records/s" and cb["value"] > 0 and cb["sample"]
     assert d["result"]["support_sum"] == d["result"]["n_events"] > 0
+    # the file leg (the same sample written as a BAM, inflated and decoded on the GPU) must report the counts of the resident leg
+    fp = d.get("file_path", {})
+    assert "error" not in fp, fp
+    if "same_result_as_resident_path" in fp:
+        assert fp["same_result_as_resident_path"] is True, (fp["result"], d["result"])
 
 
 def test_bench_two_ranks_equal_one():
