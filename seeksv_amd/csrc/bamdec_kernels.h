@@ -515,7 +515,7 @@ __device__ __forceinline__ bool plausible_record(const uint8_t *u, uint64_t o, u
 	const uint8_t *r = u + o + 4;
 	const int32_t refid = ld_i32(r), pos = ld_i32(r + 4), l_seq = ld_i32(r + 16), next_ref = ld_i32(r + 20), next_pos = ld_i32(r + 24);
 	const uint32_t l_name = r[8], ncig = ld_u16(r + 12);
-	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name == 0) return false;
+	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name < 2) return false; // (a read name is at least one character and its NUL)
 	if (32ull + l_name + 4ull * ncig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > bs) return false;
 	const uint64_t nul = o + 4 + 32 + l_name - 1;
 	return nul >= total || u[nul] == 0;
@@ -537,6 +537,11 @@ __device__ __forceinline__ uint32_t follow_chain(const uint8_t *u, uint64_t o, u
 	return n;
 }
 
+// plausible headers in a row that make a record start.  A wrong guess costs the stitch 0.6 ms of walking that block by hand (one lane-serial trip to HBM per
+// record).  What used to go wrong about once in 2,000 blocks of equal-sized records: two bytes BEFORE a true start, a word made of the previous record's last
+// bytes and the true block_size's low half reads as a 17 MB record with an empty name that ends, by the regular spacing, on a true start far ahead - hence the
+// name length test in plausible_record.
+constexpr int PLAUSIBLE_RUN = 3;
 struct BlockChain { uint64_t guess, exit; uint32_t count, listed; }; // guess == ~0: no plausible start found in the block; listed: rel[] holds its record starts
 // The record starts k_find_records walks over are kept, as 16-bit offsets from the block's first record, so that k_list_records need not walk the chain again:
 // record i of block b at rel[((b / 64) * REL_CAP + i) * 64 + b % 64] (the 64 lanes of a wavefront write 128 contiguous bytes a step).  A block whose chain
@@ -558,11 +563,11 @@ __global__ __launch_bounds__(BLOCK) void k_find_records(const uint8_t *__restric
 	for (; o < end && o + 36 <= total; ++o) {
 		uint64_t q = o;
 		int k = 0;
-		for (; k < 3 && q + 36 <= total; ++k) {
+		for (; k < PLAUSIBLE_RUN && q + 36 <= total; ++k) {
 			if (!plausible_record(u, q, total, n_targets)) break;
 			q += 4 + (uint64_t)ld_u32(u + q);
 		}
-		if (k == 3 || (k > 0 && q + 36 > total)) { c.guess = o; break; }
+		if (k == PLAUSIBLE_RUN || (k > 0 && q + 36 > total)) { c.guess = o; break; }
 	}
 	if (c.guess != ~0ull) {
 		// follow_chain, keeping the record starts
@@ -646,6 +651,27 @@ __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restric
 			if (b < n_blocks) { c##J = chain[b]; e##J = u_off[b] + blocks[b].u_len; } }
 		SSV_LD(0) SSV_LD(1) SSV_LD(2) SSV_LD(3) SSV_LD(4) SSV_LD(5) SSV_LD(6) SSV_LD(7)
 #undef SSV_LD
+		// all eight steps at once when nothing is wrong with any of them: step j's first block must start where step j-1's last block ends, and that is in
+		// a register already - no step has to wait for the one before
+		bool fine = true;
+		uint64_t prev_last = cur;
+#define SSV_OK(J) { const int64_t b = base + (int64_t)J * WAVE + lane_id(); \
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)c##J.exit, 0x138, 0xf, 0xf, false), hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(c##J.exit >> 32), 0x138, 0xf, 0xf, false); \
+			const uint64_t before = lane_id() == 0 ? prev_last : ((uint64_t)lo | ((uint64_t)hi << 32)); \
+			fine = fine && (b >= n_blocks || (c##J.guess != ~0ull && c##J.guess == before)); \
+			prev_last = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c##J.exit, 63) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(c##J.exit >> 32), 63) << 32); }
+		SSV_OK(0) SSV_OK(1) SSV_OK(2) SSV_OK(3) SSV_OK(4) SSV_OK(5) SSV_OK(6) SSV_OK(7)
+#undef SSV_OK
+		if (__all(fine)) {
+			int64_t last_b = base + (int64_t)WAVE * 8 - 1;
+			if (last_b >= n_blocks) last_b = n_blocks - 1; // the batch's last block: lane last_b % 64 of step (last_b - base) / 64
+			const int jl = (int)((last_b - base) >> 6), ll = (int)((last_b - base) & 63);
+#define SSV_FIN(J) { const int64_t b = base + (int64_t)J * WAVE + lane_id(); if (b < n_blocks) { count[b] = c##J.count; n_lane += c##J.count; } \
+			if (jl == J) cur = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)c##J.exit, ll) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(c##J.exit >> 32), ll) << 32); }
+			SSV_FIN(0) SSV_FIN(1) SSV_FIN(2) SSV_FIN(3) SSV_FIN(4) SSV_FIN(5) SSV_FIN(6) SSV_FIN(7)
+#undef SSV_FIN
+			continue;
+		}
 #define SSV_ST(J) if (base + (int64_t)J * WAVE < n_blocks) stitch_step(u, base + (int64_t)J * WAVE, n_blocks, total, c##J, e##J, chain, count, cur, n_rec, n_lane, n_rep, bad);
 		SSV_ST(0) SSV_ST(1) SSV_ST(2) SSV_ST(3) SSV_ST(4) SSV_ST(5) SSV_ST(6) SSV_ST(7)
 #undef SSV_ST

@@ -332,7 +332,7 @@ static inline bool plausible_record(const uint8_t *u, size_t o, size_t end, int3
 	const uint8_t *r = u + o + 4;
 	memcpy(&refid, r, 4); memcpy(&pos, r + 4, 4); memcpy(&ncig, r + 12, 2); memcpy(&l_seq, r + 16, 4); memcpy(&next_ref, r + 20, 4); memcpy(&next_pos, r + 24, 4);
 	const size_t l_name = r[8];
-	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name == 0) return false;
+	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name < 2) return false; // (a read name is at least one character and its NUL)
 	if (32 + l_name + 4 * (size_t)ncig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) return false;
 	const size_t nul = o + 4 + 32 + l_name - 1;
 	return nul >= end || u[nul] == 0;
