@@ -496,7 +496,7 @@ def file_path_leg(ctx, args, device):
             t = {}
             t0 = time.perf_counter()
             # ---- pass 1: seeksv getclip ----
-            ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
+            ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
             ctx.clip_begin(0.9, 1, False, None, 0)
             n = 0
             announce(0)
@@ -515,7 +515,7 @@ def file_path_leg(ctx, args, device):
             t["getclip_s"] = time.perf_counter() - t0
             # ---- pass 2: seeksv getsv (insert size on the file's first chunk, then discordant pairs + depth of every chunk) ----
             t1 = time.perf_counter()
-            ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
+            ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
             # CalculateInsertsizeDeviation reads the file until it has its 5,000,000 pairs (cluster.cpp:68): usually inside the first chunk,
             # which then serves the scan as well; if it took more chunks, decoding starts over for the scan
             ctx._check(lib.ssv_isize_begin(ctx._h, 20, 5000000), "ssv_isize_begin")
@@ -535,7 +535,7 @@ def file_path_leg(ctx, args, device):
                 ctx.getsv_scan(b0)
                 first_k = 1
             else:
-                ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin")
+                ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
                 first_k = 0
                 announce(0)
             for k in range(first_k, len(chunks)):

@@ -382,6 +382,10 @@ typedef struct {
 /* Start a file: n_targets of its header (plausibility of speculated record starts), and the offset of the first record inside the
  * inflated stream of the first chunk (= the length of the BAM header: magic, text, reference list). */
 int ssv_bamdec_begin(ssv_ctx *ctx, int32_t n_targets, uint64_t first_record_offset);
+/* Optional, after ssv_bamdec_begin: the lengths of the n_targets contigs (the BAM header's l_ref values).  Record starts inside a chunk are found by
+ * speculation and then verified; with the lengths a candidate whose position lies outside its contig is dismissed at once, which spares the verifier
+ * the rare block it would have to walk record by record.  Results do not depend on it. */
+int ssv_bamdec_target_lens(ssv_ctx *ctx, const int32_t *lens);
 /* A run of records that ends inside the next chunk (one rank's share of a file, ssvh_bam_raw_begin_range): its records end `inflated_bytes`
  * into the chunk's blocks - a record boundary; what the blocks hold behind it belongs to the next run.  Applies to the next decode call only. */
 int ssv_bamdec_limit(ssv_ctx *ctx, uint64_t inflated_bytes);

@@ -508,7 +508,7 @@ __device__ __forceinline__ int32_t ld_i32(const uint8_t *p) { int32_t v; memcpy(
 __device__ __forceinline__ uint16_t ld_u16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
 
 // could a BAM record start at u[o]?  (o + 36 <= total is the caller's business)
-__device__ __forceinline__ bool plausible_record(const uint8_t *u, uint64_t o, uint64_t total, int32_t n_targets)
+__device__ __forceinline__ bool plausible_record(const uint8_t *u, uint64_t o, uint64_t total, int32_t n_targets, const int32_t *__restrict__ tlen)
 {
 	const uint32_t bs = ld_u32(u + o);
 	if (bs < 32 || bs > (1u << 28)) return false;
@@ -516,6 +516,9 @@ __device__ __forceinline__ bool plausible_record(const uint8_t *u, uint64_t o, u
 	const int32_t refid = ld_i32(r), pos = ld_i32(r + 4), l_seq = ld_i32(r + 16), next_ref = ld_i32(r + 20), next_pos = ld_i32(r + 24);
 	const uint32_t l_name = r[8], ncig = ld_u16(r + 12);
 	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name < 2) return false; // (a read name is at least one character and its NUL)
+	// a position lies inside its contig (when the contig lengths are known: ssv_bamdec_target_lens) - what catches a word read two bytes ahead of a true
+	// record, whose "position" is the true one times 65536
+	if (tlen && refid >= 0 && pos >= tlen[refid]) return false; // (the mate's position is left alone: this test must never fail a true record)
 	if (32ull + l_name + 4ull * ncig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > bs) return false;
 	const uint64_t nul = o + 4 + 32 + l_name - 1;
 	return nul >= total || u[nul] == 0;
@@ -551,7 +554,7 @@ __device__ __forceinline__ size_t rel_index(int64_t b, uint32_t i) { return ((si
 
 // stream = [carry bytes | inflated blocks]; block b covers [u_off[b], u_off[b] + u_len)
 __global__ __launch_bounds__(BLOCK) void k_find_records(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
-                                                       uint64_t total, int32_t n_targets, BlockChain *__restrict__ chain, uint16_t *__restrict__ rel)
+                                                       uint64_t total, int32_t n_targets, const int32_t *__restrict__ tlen, BlockChain *__restrict__ chain, uint16_t *__restrict__ rel)
 {
 	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (b >= n_blocks) return;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) void k_find_records(const uint8_t *__restric
 		uint64_t q = o;
 		int k = 0;
 		for (; k < PLAUSIBLE_RUN && q + 36 <= total; ++k) {
-			if (!plausible_record(u, q, total, n_targets)) break;
+			if (!plausible_record(u, q, total, n_targets, tlen)) break;
 			q += 4 + (uint64_t)ld_u32(u + q);
 		}
 		if (k == PLAUSIBLE_RUN || (k > 0 && q + 36 > total)) { c.guess = o; break; }
@@ -640,9 +643,47 @@ __device__ __forceinline__ void stitch_step(const uint8_t *__restrict__ u, int64
 	}
 }
 
+// The stitch's usual case needs no walk at all: every block's guess is the exit of the block before it (the first one's is `start`; an empty block - the
+// BGZF end-of-file marker - has nothing to guess and is looked through).  One lane per block checks exactly that; only if some block fails (out->pad set) does the one-wavefront
+// walk below run, and then it redoes everything.
+__global__ __launch_bounds__(BLOCK) void k_stitch_check(const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start, const BlockChain *__restrict__ chain,
+                                                       uint32_t *__restrict__ count, StitchOut *__restrict__ out)
+{
+	__shared__ uint32_t s_sum[WAVES_PER_BLOCK];
+	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	bool ok = true;
+	uint32_t cnt = 0;
+	if (b < n_blocks) {
+		const BlockChain c = chain[b];
+		// blocks that hold no record start are looked through: empty ones (end-of-file markers, also inside files written in several goes) and a first block
+		// that is all BAM header
+		const bool header_only = start >= u_off[0] + blocks[0].u_len;
+		int64_t p = b - 1;
+		while (p >= 0 && (blocks[p].u_len == 0 || (p == 0 && header_only))) --p;
+		const uint64_t before = p < 0 ? start : chain[p].exit;
+		if (blocks[b].u_len == 0 || (b == 0 && header_only)) { count[b] = 0; if (b == n_blocks - 1) out->tail = before; }
+		else {
+			ok = c.guess != ~0ull && c.guess == before;
+			cnt = c.count;
+			if (ok) count[b] = cnt;
+			if (b == n_blocks - 1) out->tail = c.exit;
+		}
+	}
+	if (__any(!ok) && lane_id() == 0) atomicOr(&out->pad, 1u);
+	const uint32_t ws = wave_sum(cnt);
+	if (lane_id() == 0) s_sum[wave_id()] = ws;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t t = 0;
+		for (int w2 = 0; w2 < WAVES_PER_BLOCK; ++w2) t += s_sum[w2];
+		if (t) atomicAdd(&out->n_records, t);
+	}
+}
+
 __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
                                                         uint64_t total, BlockChain *__restrict__ chain, uint32_t *__restrict__ count, StitchOut *__restrict__ out)
 {
+	if (out->pad == 0) return; // k_stitch_check found every guess in place: counts, tail and record total are written
 	uint64_t cur = start; // wave-uniform
 	uint32_t n_rec = 0, n_lane = 0, n_rep = 0, bad = 0; // records: counted wave-uniformly on the repair path, per lane on the usual one
 	// the kernel is one wavefront waiting for memory: the guesses of 8 x 64 blocks are loaded at once, then checked 64 at a time

@@ -62,6 +62,11 @@ class Context:
         return _abi.make_batch(b)
 
     # ---- device-side BGZF inflate + BAM decode ----
+    def bamdec_target_lens(self, lens):
+        """after ssv_bamdec_begin: the contig lengths sharpen the speculation of record starts (results do not depend on it)"""
+        arr = (C.c_int32 * max(1, len(lens)))(*[int(x) for x in lens])
+        self._check(self._lib.ssv_bamdec_target_lens(self._h, arr), "ssv_bamdec_target_lens")
+
     def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False, chunk_inflated=1 << 31, prefetch=True):
         """Generator over SSV_MEM_DEVICE batches of a whole BAM file (host.BamReader), decoded on the GPU: yields (Batch, info dict).
         The batch is valid until the next iteration.  prefetch: chunk k+1 is read into the second staging buffer and announced
@@ -71,6 +76,7 @@ class Context:
         if hl.ssvh_bam_raw_begin(reader.handle, C.byref(first)) != 0:
             raise IOError(hl.ssvh_last_error().decode())
         self._check(self._lib.ssv_bamdec_begin(self._h, len(reader.target_names), first.value), "ssv_bamdec_begin")
+        self.bamdec_target_lens(reader.target_lens)
         stages, blocks = [None, None], [None, None]
 
         def read(k):

@@ -324,7 +324,7 @@ struct Unmapped {
 struct Segment { std::vector<size_t> list; size_t end = 0, exit = 0; };
 
 // does a BAM record header that could be real start at u[o]?  (o + 36 <= end is the caller's business)
-static inline bool plausible_record(const uint8_t *u, size_t o, size_t end, int32_t n_targets)
+static inline bool plausible_record(const uint8_t *u, size_t o, size_t end, int32_t n_targets, const int32_t *tlen)
 {
 	uint32_t bs; int32_t refid, pos, l_seq, next_ref, next_pos; uint16_t ncig;
 	memcpy(&bs, u + o, 4);
@@ -333,12 +333,13 @@ static inline bool plausible_record(const uint8_t *u, size_t o, size_t end, int3
 	memcpy(&refid, r, 4); memcpy(&pos, r + 4, 4); memcpy(&ncig, r + 12, 2); memcpy(&l_seq, r + 16, 4); memcpy(&next_ref, r + 20, 4); memcpy(&next_pos, r + 24, 4);
 	const size_t l_name = r[8];
 	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name < 2) return false; // (a read name is at least one character and its NUL)
+	if (refid >= 0 && pos >= tlen[refid]) return false; // a position lies inside its contig (the mate's is left alone: this test must never fail a true record)
 	if (32 + l_name + 4 * (size_t)ncig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) return false;
 	const size_t nul = o + 4 + 32 + l_name - 1;
 	return nul >= end || u[nul] == 0;
 }
 
-static void find_records(const uint8_t *u, size_t begin, size_t end, int32_t n_targets, Segment &S)
+static void find_records(const uint8_t *u, size_t begin, size_t end, int32_t n_targets, const int32_t *tlen, Segment &S)
 {
 	S.list.clear(); S.end = end;
 	size_t o = begin;
@@ -346,7 +347,7 @@ static void find_records(const uint8_t *u, size_t begin, size_t end, int32_t n_t
 	for (; o + 36 <= end; ++o) {
 		size_t q = o; int k = 0;
 		for (; k < 3 && q + 36 <= end; ++k) {
-			if (!plausible_record(u, q, end, n_targets)) break;
+			if (!plausible_record(u, q, end, n_targets, tlen)) break;
 			uint32_t bs; memcpy(&bs, u + q, 4);
 			q += 4 + (size_t)bs;
 		}
@@ -637,7 +638,8 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 		if (segs.size() < (size_t)(Bgzf::CHUNK_BLOCKS / Bgzf::SEG_BLOCKS + 1)) segs.resize((size_t)(Bgzf::CHUNK_BLOCKS / Bgzf::SEG_BLOCKS + 1));
 		Bgzf *zp = &z;
 		const double tg0 = now();
-		const int nseg = z.grow([&segs, zp, n_targets](int sg, size_t s0, size_t s1) { find_records(zp->ubuf.data(), s0, s1, n_targets, segs[(size_t)sg]); });
+		const int32_t *tlen = b->lens.data();
+		const int nseg = z.grow([&segs, zp, n_targets, tlen](int sg, size_t s0, size_t s1) { find_records(zp->ubuf.data(), s0, s1, n_targets, tlen, segs[(size_t)sg]); });
 		if (nseg == 0) {
 			if (!g_err.empty()) return -1;
 			break;

@@ -247,6 +247,7 @@ struct BatchSource {
 		if (ranged) { if (ssvh_bam_raw_begin_range(bam, r_start_coff, r_start_uoff, r_end_coff, r_end_uoff, &first) != 0) die(string("[seeksv] ") + ssvh_last_error()); file_bytes = 0; }
 		else if (ssvh_bam_raw_begin(bam, &first) != 0) die(string("[seeksv] ") + ssvh_last_error());
 		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		if (ssv_bamdec_target_lens(ctx, ssvh_bam_target_lens(bam)) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ranged) ssv_bamdec_prev_tid(ctx, r_prev_tid);
 		start_read(0);
 	}
