@@ -549,17 +549,33 @@ struct BlockChain { uint64_t guess, exit; uint32_t count, listed; }; // guess ==
 // The record starts k_find_records walks over are kept, as 16-bit offsets from the block's first record, so that k_list_records need not walk the chain again:
 // record i of block b at rel[((b / 64) * REL_CAP + i) * 64 + b % 64] (the 64 lanes of a wavefront write 128 contiguous bytes a step).  A block whose chain
 // the stitch had to repair, or with more records / a longer reach than fits, is walked again instead (listed = 0).
-constexpr uint32_t REL_CAP = 1824; // 65536 / 36: the records a 64 KB block can hold
-__device__ __forceinline__ size_t rel_index(int64_t b, uint32_t i) { return ((size_t)(b >> 6) * REL_CAP + i) * 64 + (size_t)(b & 63); }
 
-// stream = [carry bytes | inflated blocks]; block b covers [u_off[b], u_off[b] + u_len)
+// The record starts are searched in UNITS: a BGZF block each, or an n-th of one (unit s = part s % n of block s / n; a part behind the block's end is empty).
+// Measured with n = 4 (a lane's walk along the block_size chain ~60 dependent loads instead of ~240): k_find_records no faster (0.92 -> 0.98 ms per 19.3 M
+// records) - it is not the length of the chains but the number of scattered loads, one per record: 21 G a second is what the memory system gives for
+// lines touched once.  So n = 1.
+constexpr int UNITS_PER_BLOCK = 1;
+constexpr uint32_t REL_CAP = (65536 / UNITS_PER_BLOCK) / 36 + 4; // the records a unit can hold
+__device__ __forceinline__ size_t rel_index(int64_t b, uint32_t i) { return ((size_t)(b >> 6) * REL_CAP + i) * 64 + (size_t)(b & 63); }
+constexpr uint32_t UNIT_BYTES = 65536 / UNITS_PER_BLOCK;
+__device__ __forceinline__ void unit_range(const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t s, uint64_t &begin, uint64_t &end)
+{
+	const int64_t b = s / UNITS_PER_BLOCK;
+	const uint32_t j = (uint32_t)(s % UNITS_PER_BLOCK), len = blocks[b].u_len;
+	const uint32_t lo = j * UNIT_BYTES < len ? j * UNIT_BYTES : len;
+	const uint32_t hi = j == UNITS_PER_BLOCK - 1 || (j + 1) * UNIT_BYTES > len ? len : (j + 1) * UNIT_BYTES; // (the last quarter takes what a block of more than 64 KB has left)
+	begin = u_off[b] + lo; end = u_off[b] + hi;
+}
+// stream = [carry bytes | inflated blocks]; block b covers [u_off[b], u_off[b] + u_len); n_blocks below counts UNITS
 __global__ __launch_bounds__(BLOCK) void k_find_records(const uint8_t *__restrict__ u, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start,
                                                        uint64_t total, int32_t n_targets, const int32_t *__restrict__ tlen, BlockChain *__restrict__ chain, uint16_t *__restrict__ rel)
 {
 	const int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	if (b >= n_blocks) return;
 	// the first block also stands for what lies before it (the carried-over head of a record, or the BAM header): its chain begins at `start`
-	const uint64_t begin = b == 0 ? start : u_off[b], end = u_off[b] + blocks[b].u_len;
+	uint64_t begin, end;
+	unit_range(blocks, u_off, b, begin, end);
+	if (b == 0 || begin < start) begin = start < end || b == 0 ? start : end; // nothing starts before `start` (the BAM header may fill several units)
 	BlockChain c;
 	c.guess = ~0ull; c.exit = begin; c.count = 0; c.listed = 0;
 	uint64_t o = begin;
@@ -646,7 +662,7 @@ __device__ __forceinline__ void stitch_step(const uint8_t *__restrict__ u, int64
 // The stitch's usual case needs no walk at all: every block's guess is the exit of the block before it (the first one's is `start`; an empty block - the
 // BGZF end-of-file marker - has nothing to guess and is looked through).  One lane per block checks exactly that; only if some block fails (out->pad set) does the one-wavefront
 // walk below run, and then it redoes everything.
-__global__ __launch_bounds__(BLOCK) void k_stitch_check(const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start, const BlockChain *__restrict__ chain,
+__global__ __launch_bounds__(BLOCK) void k_stitch_check(const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks, uint64_t start, uint64_t total, const BlockChain *__restrict__ chain,
                                                        uint32_t *__restrict__ count, StitchOut *__restrict__ out)
 {
 	__shared__ uint32_t s_sum[WAVES_PER_BLOCK];
@@ -655,15 +671,17 @@ __global__ __launch_bounds__(BLOCK) void k_stitch_check(const BgzfBlock *__restr
 	uint32_t cnt = 0;
 	if (b < n_blocks) {
 		const BlockChain c = chain[b];
-		// blocks that hold no record start are looked through: empty ones (end-of-file markers, also inside files written in several goes) and a first block
-		// that is all BAM header
-		const bool header_only = start >= u_off[0] + blocks[0].u_len;
+		// a unit without a guess holds no record start if the chain is past its end when it gets there (empty units, a first unit that is all BAM header, units
+		// inside one long record); a unit with a guess must start exactly where the last unit with a guess lets the chain out
+		uint64_t begin, end;
+		unit_range(blocks, u_off, b, begin, end);
 		int64_t p = b - 1;
-		while (p >= 0 && (blocks[p].u_len == 0 || (p == 0 && header_only))) --p;
+		while (p >= 0 && chain[p].guess == ~0ull) --p;
 		const uint64_t before = p < 0 ? start : chain[p].exit;
-		if (blocks[b].u_len == 0 || (b == 0 && header_only)) { count[b] = 0; if (b == n_blocks - 1) out->tail = before; }
+		// (... or too close to the stream's end for a record header: the head of a record the next chunk completes)
+		if (c.guess == ~0ull) { ok = before >= end || before + 36 > total; if (ok) count[b] = 0; if (b == n_blocks - 1) out->tail = before; }
 		else {
-			ok = c.guess != ~0ull && c.guess == before;
+			ok = c.guess == before;
 			cnt = c.count;
 			if (ok) count[b] = cnt;
 			if (b == n_blocks - 1) out->tail = c.exit;
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(WAVE) void k_stitch_blocks(const uint8_t *__restric
 	// the kernel is one wavefront waiting for memory: the guesses of 8 x 64 blocks are loaded at once, then checked 64 at a time
 	for (int64_t base = 0; base < n_blocks; base += WAVE * 8) {
 #define SSV_LD(J) BlockChain c##J; uint64_t e##J = 0; { const int64_t b = base + (int64_t)J * WAVE + lane_id(); c##J.guess = ~0ull; c##J.exit = 0; c##J.count = 0; c##J.listed = 0; \
-			if (b < n_blocks) { c##J = chain[b]; e##J = u_off[b] + blocks[b].u_len; } }
+			if (b < n_blocks) { uint64_t bg##J; c##J = chain[b]; unit_range(blocks, u_off, b, bg##J, e##J); } }
 		SSV_LD(0) SSV_LD(1) SSV_LD(2) SSV_LD(3) SSV_LD(4) SSV_LD(5) SSV_LD(6) SSV_LD(7)
 #undef SSV_LD
 		// all eight steps at once when nothing is wrong with any of them: step j's first block must start where step j-1's last block ends, and that is in
