@@ -177,32 +177,31 @@ __device__ __forceinline__ void resolve_one(uint8_t *o, uint32_t pos, uint32_t l
 	}
 }
 
-// every lane its own short match (L = 0: none; else 3..32 bytes, source and destination disjoint): up to four dwords per turn, the loads before the stores.
-// (Tried: all eight dwords' loads before the first store, one turn whatever the lengths - 15.7 -> 23.7 ms: what this kernel pays for is the NUMBER of
-// scattered load / store instructions a wavefront issues, each one costs the CU's address path a cycle per lane, and eight + eight mostly empty ones
-// a phase are more than a second turn for the few long matches.)
-__device__ __forceinline__ void copy_own(uint8_t *o, uint32_t src, uint32_t dst, uint32_t L)
+// Every lane its own short match (L = 0: none; else 3..32 bytes, source and destination disjoint): a match of 5..32 bytes goes as a head and a tail of
+// 4 / 8 / 16 bytes that overlap (same bytes where they do) - two loads and two stores whatever the length, all loads first, one turn; three bytes: one dword
+// read (its fourth byte is the hole's first), a short and a byte written.
+// (Measured before this form, dword by dword with four dwords a turn: the same time on real reads, 5 % more on the low-entropy sample.  Also tried there:
+// all eight dwords' loads before the first store - 15.7 -> 23.7 ms.)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16u(uint8_t *p, uint32_t v) { asm volatile("global_store_short %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st64u(uint8_t *p, uint64_t v) { asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st128u(uint8_t *p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ u32x4 ld128(const uint8_t *p) { u32x4 v; memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void copy_own_wide(uint8_t *o, uint32_t src, uint32_t dst, uint32_t L)
 {
-	if (L == 3u) { // one dword read (its fourth byte is the hole's first), three bytes written
-		const uint32_t v = ld32(o + src);
-		o[dst] = (uint8_t)v; o[dst + 1] = (uint8_t)(v >> 8); o[dst + 2] = (uint8_t)(v >> 16);
-	}
-	for (uint32_t at = 0; __any(L >= 4u && at < L); at += 16u) {
-		if (L >= 4u && at < L) { // the last dword ends with the match (it may overlap the one before: same bytes)
-			const uint32_t last = L - 4u;
-			const uint32_t q0 = at < last ? at : last, q1 = at + 4u < last ? at + 4u : last, q2 = at + 8u < last ? at + 8u : last, q3 = at + 12u < last ? at + 12u : last;
-			const bool h1 = at + 4u < L, h2 = at + 8u < L, h3 = at + 12u < L;
-			uint32_t r1 = 0, r2 = 0, r3 = 0;
-			const uint32_t r0 = ld32(o + src + q0);
-			if (h1) r1 = ld32(o + src + q1); // (only the lanes that have such a dword: a scattered access costs per lane)
-			if (h2) r2 = ld32(o + src + q2);
-			if (h3) r3 = ld32(o + src + q3);
-			st32u(o + dst + q0, r0);
-			if (at + 4u < L) st32u(o + dst + q1, r1);
-			if (at + 8u < L) st32u(o + dst + q2, r2);
-			if (at + 12u < L) st32u(o + dst + q3, r3);
-		}
-	}
+	const bool c3 = L == 3u, c4 = L >= 4u && L <= 8u, c8 = L >= 9u && L <= 16u, c16 = L >= 17u;
+	uint32_t a0 = 0, a1 = 0;
+	uint64_t b0 = 0, b1 = 0;
+	u32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+	if (c3 || c4) a0 = ld32(o + src); // (three bytes: the dword's fourth byte is the hole's first)
+	if (c4 && L > 4u) a1 = ld32(o + src + L - 4u);
+	if (c8) { b0 = ld64(o + src); b1 = ld64(o + src + L - 8u); }
+	if (c16) { d0 = ld128(o + src); d1 = ld128(o + src + L - 16u); }
+	if (c3) { st16u(o + dst, a0); o[dst + 2u] = (uint8_t)(a0 >> 16); }
+	if (c4) { st32u(o + dst, a0); if (L > 4u) st32u(o + dst + L - 4u, a1); }
+	if (c8) { st64u(o + dst, b0); st64u(o + dst + L - 8u, b1); }
+	if (c16) { st128u(o + dst, d0); st128u(o + dst + L - 16u, d1); }
 }
 
 // Sixteen tokens per round, one per lane; a prefix sum over the group gives every match its place.  The round is worked off in PHASES, each one
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restri
 		bool ready = !done && src + need <= pos;
 		for (;;) {
 			if (__any(ready && src + need > dirty)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; }
-			copy_own(o, src, dst, ready && small ? len : 0u);
+			copy_own_wide(o, src, dst, ready && small ? len : 0u);
 			uint32_t m = (uint32_t)(__ballot(ready && !small) >> grp_shift) & 0xffffu;
 			while (__any(m != 0u)) {
 				if (m) {
