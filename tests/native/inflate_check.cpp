@@ -105,6 +105,7 @@ int main()
 				for (int strategy : {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY, Z_RLE}) {
 					if (strategy != Z_DEFAULT_STRATEGY && level != 6) continue;
 					std::vector<uint8_t> d = make_data(shape, n);
+					d.reserve(n + 1); // (data() of an empty vector may be null: memcmp does not take that, even for zero bytes)
 					z_stream zs = {};
 					if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) != Z_OK) return 2;
 					std::vector<uint8_t> c(2 * n + 1024, 0xAA); // Z_FIXED on noisy data exceeds deflateBound
