@@ -239,7 +239,7 @@ static void flush_run(clip_state *st, int32_t tid)
 	for (int side = 0; side < 2; ++side) {
 		posmap_t *m = &st->map[side];
 		g_sort_cl = st->cl;
-		qsort(m->members, (size_t)m->nmem, sizeof(int), cmp_member);
+		if (m->nmem) qsort(m->members, (size_t)m->nmem, sizeof(int), cmp_member); /* (an empty side has no array yet) */
 		for (int k = 0; k < m->nmem; ++k) {
 			if (st->nord == st->capord) {
 				st->capord = st->capord ? st->capord * 2 : 1024;
