@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SSV_ABI_VERSION 3
+#define SSV_ABI_VERSION 4
 
 typedef enum {
 	SSV_OK = 0,
@@ -101,8 +101,9 @@ typedef struct {
 	const ssv_record *rec;     /* [n] or NULL; when given, flag / mapq / l_qseq / mtid / mpos / isize / cigar_off / xc / seq_off may be NULL */
 	const uint8_t *cigar_ends; /* [n] or NULL: a hot copy of the two CIGAR operations the getclip pass looks at first - (code of the first
 	                              operation) | (code of the last operation) << 4, BAM's operation codes; 0xff for a record without CIGAR.
-	                              With it the streaming pass reads this byte instead of n_cigar and passes on only the records with an
-	                              `S` at either end (1 % of a WGS sample instead of the 3 % that have two or more operations). */
+	                              The streaming pass of getclip reads this byte per record and passes on the records with an `S` at either
+	                              end (1 % of a WGS sample).  NULL: the library builds the column from the record lines first (64 B/record
+	                              instead of 1: fill it where the records are parsed anyway). */
 } ssv_batch_t;
 
 typedef struct ssv_ctx ssv_ctx; /* opaque */
@@ -164,6 +165,16 @@ int ssv_clip_begin(ssv_ctx *ctx, const ssv_clip_params *p);
  * the `cigar` and `seqqual` arrays of a SSV_MEM_PERSISTENT batch (see ssv_mem).
  */
 int ssv_clip_scan(ssv_ctx *ctx, const ssv_batch_t *b);
+/*
+ * The same for the records [rec_begin, rec_end) of the batch only.  For input whose contigs come back (an unsorted BAM): the reference
+ * flushes and clears its maps at EVERY change of contig among the mapped-pair records (clip_reads.h:423-438), so the reads of two
+ * visits of one contig never share a cluster.  A pass of this library bins by (contig, side, position); a driver therefore ends the
+ * pass (ssv_clip_cluster) in front of the first record of a visit whose contig is not greater than every contig of the pass so far
+ * and starts the next one there (initial_last_tid = the contig before): scan [0, i) - cluster - begin - scan [i, n).  Records before
+ * rec_begin still count as "the record before" of the contig-switch rule.  A batch announced with ssv_batch_prefetch stays announced
+ * until a call with rec_end == n has consumed it.
+ */
+int ssv_clip_scan_range(ssv_ctx *ctx, const ssv_batch_t *b, int64_t rec_begin, int64_t rec_end);
 /* Events collected so far (synchronises). */
 int ssv_clip_event_count(ssv_ctx *ctx, int64_t *n_events);
 

@@ -278,7 +278,6 @@ static void get_sclip_reads(clip_state *st, const ssv_batch_t *b, int bi, int64_
 	if (op1 == C_H || op2 == C_H || (int)b->mapq[i] < p->min_mapq || (b->flag[i] & F_DUP)) return;
 	int s1 = op1 == C_S, s2 = op2 == C_S;
 	if (!s1 && !s2) return;
-	if (n == 1) return;                 /* a lone 'nS' CIGAR gives negative slice lengths in the reference; we emit nothing */
 	int xc = b->xc ? b->xc[i] : 0;
 	int lq = b->l_qseq[i];
 	int pos0 = b->pos[i];
@@ -301,18 +300,24 @@ static void get_sclip_reads(clip_state *st, const ssv_batch_t *b, int bi, int64_
 			insert_seq(st, 1, pos0 + ref_len, sl, ql, ll, sr, qr, lr, qm, bi, (int)i, p->match_rate);
 		}
 	} else {
+		/* A CIGAR that is one lone 'nS' lands here too: cig[0] and cig[n - 1] are the same operation (clip_reads.cpp:115,150).  The
+		 * "middle" length l_qseq - ll - rc is then negative and GetSeq's loops over it run zero times (clip_reads.cpp:293-294): the '5'
+		 * event is (seq_left = [0, ll), seq_right = ""), the '3' event (seq_left = "", seq_right = [l_qseq - rc, l_qseq)).  With an empty
+		 * part CompareString* divide 0 by 0 (NaN >= limit is false): such an event never joins a cluster and nothing ever joins its own.
+		 * Clips longer than the read make the reference read outside the record: undefined there, nothing here. */
 		int ll = (int)(cig[0] >> 4), rc = (int)(cig[n - 1] >> 4), mid = lq - ll - rc;
-		if (mid < 0) return;
+		if (ll > lq || rc > lq) return;
+		int midc = mid < 0 ? 0 : mid;
 		int ref_len = ref_len_generate_cigar(cig, n);
 		int do_l = 1, do_r = 1;
 		if (xc != 0 && !p->save_low_quality) { if (!(b->flag[i] & F_REV)) do_r = 0; else do_l = 0; }
 		if (do_l) {
-			get_seq(b, i, 0, ll, mid, sl, ql, sr, qr, &qm);
-			insert_seq(st, 0, pos0 + 1, sl, ql, ll, sr, qr, mid, qm, bi, (int)i, p->match_rate);
+			get_seq(b, i, 0, ll, midc, sl, ql, sr, qr, &qm);
+			insert_seq(st, 0, pos0 + 1, sl, ql, ll, sr, qr, midc, qm, bi, (int)i, p->match_rate);
 		}
 		if (do_r) {
-			get_seq(b, i, ll, mid, rc, sl, ql, sr, qr, &qm);
-			insert_seq(st, 1, pos0 + ref_len, sl, ql, mid, sr, qr, rc, qm, bi, (int)i, p->match_rate);
+			get_seq(b, i, ll + mid - midc, midc, rc, sl, ql, sr, qr, &qm); /* seq_right = [ll + mid, ll + mid + rc) whatever the sign of mid */
+			insert_seq(st, 1, pos0 + ref_len, sl, ql, midc, sr, qr, rc, qm, bi, (int)i, p->match_rate);
 		}
 	}
 }

@@ -128,8 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_rec(const ssv_record *__restri
 constexpr int CS_ITEMS = 4;                           // getsv scan: records per lane per sub-tile (two 16-byte loads per lane)
 constexpr int CS_SUB = 4;                             // sub-tiles per tile
 constexpr int CS_TILE = BLOCK * CS_ITEMS * CS_SUB;    // 4096 records per workgroup iteration, one barrier each
-constexpr int CC_ITEMS = 8;                           // clip scan: 8 x u16 = one 16-byte load per lane per sub-tile
-constexpr int CC_TILE = BLOCK * CC_ITEMS * CS_SUB;    // 8192 records per workgroup iteration
+constexpr int CC_TILE = BLOCK * 32;                   // clip scan: 8192 records per workgroup iteration
 constexpr int PACK_MAX_LQ = 320;                     // reads up to this length take the LDS-staged paths of the pack kernels
 constexpr int CS_MAX_BLOCKS = 8192;                   // upper bound of the persistent grid (private staging regions are sized by the actual grid)
 
@@ -183,10 +182,9 @@ struct ClipCounters {
 	int r_unsorted;                  // the '3' events are further from key order than the two-pass tile sort repairs: the radix sort takes over
 };
 
-// K1 clip_scan arguments: the streaming pass only needs n_cigar
+// K1 clip_scan arguments: the streaming pass only needs the cigar_ends column
 struct ClipScanArgs {
-	const uint16_t *n_cigar;
-	const uint8_t *ends;     // when given, the pass reads this column instead (k_clip_scan_ends)
+	const uint8_t *ends;     // the cigar_ends column (the batch's own, or built by k_build_ends)
 	int64_t n;
 	uint32_t *tile_cnt;      // [ntiles] candidates per tile
 	uint32_t *tile_off;      // [ntiles] where the tile's candidates sit in stage[]
@@ -204,6 +202,7 @@ struct ClipFilterArgs {
 	int use_ownership;       // range-partitioned runs: keep only events with own_lo <= (tid << 32 | pos1) < own_hi
 	long long own_lo, own_hi;
 	const int *last_tid_in;  // tid of the last mapped-pair record before this batch (clip_reads.h:407: starts at 0)
+	int64_t rec_begin;       // records before this index yield no events (ssv_clip_scan_range); they still count for the contig-switch rule
 };
 
 // GenerateCigar's l: M, D, =, N advance the reference; X does not (clip_reads.cpp:322)
@@ -220,8 +219,9 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 {
 	const DevBatch &b = a.b;
 	const int nc = r.n_cigar();
-	if (nc < 2) return 0;                               // a lone "nS" is skipped like in the oracle
-	const uint32_t c0 = r.head(0), cl = r.op(b.cigar, nc - 1);
+	if (nc < 1) return 0;                               // no CIGAR: the reference reads cigar[-1] (undefined there, nothing here)
+	if (i < a.rec_begin) return 0;                      // ssv_clip_scan_range: the records before the range belong to the pass before
+	const uint32_t c0 = r.head(0), cl = r.op(b.cigar, nc - 1); // (a lone "nS" is BOTH ends of its CIGAR, clip_reads.cpp:115)
 	const int op1 = (int)(c0 & 15u), op2 = (int)(cl & 15u);
 	if (op1 != C_S && op2 != C_S) return 0;             // clip_reads.cpp:124,150
 	const int flag = r.flag();
@@ -258,12 +258,17 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 			evr.key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); evr.begin = 0; evr.ll = ll; evr.lr = lr; m = 2;
 		}
 	} else {
+		// A negative middle (a lone "nS", or clips that overlap): GetSeq's loops over it run zero times (clip_reads.cpp:293-294), the '5' event
+		// is ([0, ll), ""), the '3' event ("", [l_qseq - rc, l_qseq)); an empty part makes every match rate 0 / 0 = NaN, so such an event
+		// neither joins a cluster nor is joined (k_cluster_bins divides like the reference).  Clips longer than the read: the reference reads
+		// outside the record (undefined there, nothing here).
 		const int ll = (int)(c0 >> 4), rc = (int)(cl >> 4), mid = lq - ll - rc;
-		if (mid < 0) return 0;
+		if (ll > lq || rc > lq) return 0;
+		const int midc = mid < 0 ? 0 : mid;
 		bool do_l = true, do_r = true;
 		if (xc != 0 && !a.save_low_quality) { if (!(flag & F_REV)) do_r = false; else do_l = false; } // clip_reads.cpp:160-175
-		if (do_l) { evl.key = tkey | (uint32_t)(pos0 + 1); evl.begin = 0; evl.ll = ll; evl.lr = mid; m |= 1; }
-		if (do_r) { evr.key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); evr.begin = ll; evr.ll = mid; evr.lr = rc; m |= 2; }
+		if (do_l) { evl.key = tkey | (uint32_t)(pos0 + 1); evl.begin = 0; evl.ll = ll; evl.lr = midc; m |= 1; }
+		if (do_r) { evr.key = tkey | (1ull << 32) | (uint32_t)(pos0 + ref_len); evr.begin = ll + mid - midc; evr.ll = midc; evr.lr = rc; m |= 2; }
 	}
 	if (a.use_ownership) {
 		const long long kl = ((long long)tid << 32) | (long long)(uint32_t)evl.key, kr = ((long long)tid << 32) | (long long)(uint32_t)evr.key;
@@ -330,66 +335,24 @@ __device__ __forceinline__ void stage_tile_candidates(uint32_t mask, uint64_t pa
 	if (fits) cursor += total;
 }
 
-// K1 clip_scan: the streaming pass.  A record can only carry a usable soft clip if its CIGAR has at least two operations (a lone
-// "nS" is skipped like in the oracle), so the pass reads nothing but n_cigar - 2 B/record, one 16-byte load per lane per 8 records,
-// four loads in flight per lane - and writes the indices of the records with n_cigar >= 2 (indels and clips: ~3 % of a WGS BAM).
-// Their lines are looked at by k_clip_filter, one thread per candidate.  Persistent workgroups, private staging, no atomics.
-__device__ __forceinline__ void clip_scan_load(const ClipScanArgs &a, int64_t tile, uint4 (&v)[CS_SUB])
+// A batch that comes without the `cigar_ends` column gets one built here (one thread per record: its line, and the cigar array for CIGARs of
+// more than five operations): the codes of the first and of the last operation, 0xff without CIGAR.  64 B/record instead of the 1 B/record
+// the column costs when the batcher fills it while it parses the record anyway - all three batchers of this repository do.
+__global__ __launch_bounds__(BLOCK) void k_build_ends(DevBatch b, uint8_t *__restrict__ ends)
 {
-	const int64_t t0 = tile * CC_TILE + (int64_t)threadIdx.x * CC_ITEMS;
-	if ((tile + 1) * CC_TILE <= a.n) { // workgroup-uniform: the whole tile is in range, all four loads issue back to back
-#pragma unroll
-		for (int sub = 0; sub < CS_SUB; ++sub) v[sub] = stream_load_u4(a.n_cigar + t0 + (int64_t)sub * (BLOCK * CC_ITEMS));
-	} else {
-#pragma unroll
-		for (int sub = 0; sub < CS_SUB; ++sub) {
-			const int64_t i0 = t0 + (int64_t)sub * (BLOCK * CC_ITEMS);
-			uint32_t h[CC_ITEMS];
-#pragma unroll
-			for (int k = 0; k < CC_ITEMS; ++k) h[k] = i0 + k < a.n ? a.n_cigar[i0 + k] : 0u;
-			v[sub] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-		}
-	}
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= b.n) return;
+	const RecLine r = rec_load(b.rec, i);
+	const int nc = r.n_cigar();
+	ends[i] = nc ? (uint8_t)((r.head(0) & 15u) | ((r.op(b.cigar, nc - 1) & 15u) << 4)) : (uint8_t)0xff;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_clip_scan(ClipScanArgs a)
-{
-	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
-	uint32_t cursor = 0;
-	int parity = 0;
-	const int64_t region = (int64_t)blockIdx.x * a.block_cap;
-	uint4 v[CS_SUB], nxt[CS_SUB];
-	if ((int64_t)blockIdx.x < a.ntiles) clip_scan_load(a, blockIdx.x, v);
-	for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
-		const int64_t t0 = tile * CC_TILE + (int64_t)threadIdx.x * CC_ITEMS;
-		// software pipeline: the next tile's loads are in flight while this tile is classified, scanned and staged
-		const int64_t next = tile + gridDim.x;
-		if (next < a.ntiles) clip_scan_load(a, next, nxt);
-		uint32_t mask = 0;
-		uint64_t packed = 0;
-#pragma unroll
-		for (int sub = 0; sub < CS_SUB; ++sub) {
-			const uint32_t w4[4] = {v[sub].x, v[sub].y, v[sub].z, v[sub].w};
-			uint32_t bits = 0;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				bits |= ((w4[k] & 0xffffu) >= 2u ? 1u : 0u) << (2 * k);
-				bits |= ((w4[k] >> 16) >= 2u ? 1u : 0u) << (2 * k + 1);
-			}
-			mask |= bits << (sub * CC_ITEMS);
-			packed += (uint64_t)__popc(bits) << (16 * sub);
-		}
-		stage_tile_candidates<CC_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, a.block_cap, a.tile_cnt, a.tile_off, a.stage, a.overflow);
-#pragma unroll
-		for (int sub = 0; sub < CS_SUB; ++sub) v[sub] = nxt[sub];
-	}
-}
-
-// The same pass over the `cigar_ends` column (when the batch has one): 1 B/record, sixteen records per 16-byte load, two loads per lane
-// and tile (the same 8192-record tiles); a record goes on when the code of its first or of its last CIGAR operation is S - the soft-clip
-// test of GetSClipReads (clip_reads.cpp:124,150) applied to every record here instead of to the records with two or more operations later.
+// K1 clip_scan: the streaming pass over the `cigar_ends` column: 1 B/record, sixteen records per 16-byte load, two loads per lane
+// and tile (8192-record tiles); a record goes on when the code of its first or of its last CIGAR operation is S - the soft-clip
+// test of GetSClipReads (clip_reads.cpp:124,150) applied to every record (a lone "nS" included: it is both ends of its CIGAR).
+// Their lines are looked at by k_clip_filter, four lanes per candidate.  Persistent workgroups, private staging, no atomics.
 constexpr int CE_ITEMS = 16, CE_SUB = 2;
-static_assert(BLOCK * CE_ITEMS * CE_SUB == CC_TILE, "both forms of the clip scan use the same tiles");
+static_assert(BLOCK * CE_ITEMS * CE_SUB == CC_TILE, "tile size of the clip scan");
 
 __device__ __forceinline__ void clip_scan_ends_load(const ClipScanArgs &a, int64_t tile, uint4 (&v)[CE_SUB])
 {
@@ -454,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void k_cand_place(const uint32_t *__restrict
 	for (uint32_t k = lane_id(); k < n; k += WAVE) cand[db + k] = stage[so + k];
 }
 
-// K1b clip_filter: one thread per candidate record (n_cigar >= 2) fetches the record's line - one 64-byte sector holds the CIGAR ends
+// K1b clip_filter: four lanes per candidate record (an S at either end of its CIGAR) fetch the record's line - one 64-byte sector holds the CIGAR ends
 // and every field of GetSClipReads' predicate chain (flag, MAPQ, DUP, XC, hard clips, lengths) - and leaves its 0, 1 or 2 events in the
 // candidate's two event slots.  The slots are the events' final place (the event array has holes; everything downstream goes through
 // indices), so an event line is written exactly once; what the ordered side lists need of an event - key, l_qseq, n_cigar: 16 bytes - is

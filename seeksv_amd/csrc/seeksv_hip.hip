@@ -135,7 +135,7 @@ struct ssv_ctx {
 	// ---- getclip ----
 	bool clip_active = false;
 	ssv_clip_params clip_p{};
-	DBuf d_last_tid, stage, cand, cand_cnt, cand_off, kv_stage;
+	DBuf d_last_tid, stage, cand, cand_cnt, cand_off, kv_stage, ends_buf;
 	int64_t stage_cap = 0;
 	DBuf ev, ev_meta, ev_idx, key_l, val_l, key_r[2], val_r[2];  // the pass's event lines (slots, with holes), per event in BAM order (l_qseq, n_cigar) and slot, and the sort keys / slots of the two sides
 	int64_t ev_slots = 0;                                        // slots handed out so far
@@ -385,7 +385,7 @@ static int check_batch(ssv_ctx *c, const ssv_batch_t *b)
 
 // Make the batch visible to the kernels: device batches are used in place, host batches are copied to HBM (or were, ssv_batch_prefetch); a
 // batch that comes as structure-of-arrays columns only is transposed into record lines (ssv_record) on the device.
-int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
+int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d, bool keep_announced = false)
 {
 	CHECK(check_batch(c, b));
 	d.n = b->n; d.max_ref_span = b->max_ref_span;
@@ -408,7 +408,7 @@ int stage_batch(ssv_ctx *c, const ssv_batch_t *b, DevBatch &d)
 			// announced batches are consumed in the order they were announced
 			const ssv_ctx::Prefetched f = c->pf.front();
 			if (memcmp(&f.b, b, sizeof(*b)) != 0) { c->err = "a prefetched batch is pending: the next scan call must be given that batch"; return SSV_E_STATE; }
-			c->pf.pop_front();
+			if (!keep_announced) c->pf.pop_front(); // (a scan of a leading part of the batch leaves it staged for the scan of the rest)
 			staged_view(c, b, f.set, d, s);
 			HIPCHECK(c, hipEventSynchronize(c->ss[f.set].ready)); // the caller may recycle the host arrays once the scan call returns
 		} else {
@@ -511,7 +511,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (c->h_pair_lut.p) (void)hipHostFree(c->h_pair_lut.p);
 	// every DBuf / HBuf member
 	if (c->st_h2d) { (void)hipStreamSynchronize(c->st_h2d); (void)hipStreamDestroy(c->st_h2d); }
-	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage,
+	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage, &c->ends_buf,
 	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_strings,
 	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->pair_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
@@ -611,15 +611,26 @@ int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 	return SSV_OK;
 }
 
-int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
+int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b) { return b ? ssv_clip_scan_range(c, b, 0, b->n) : SSV_E_ARG; }
+
+int ssv_clip_scan_range(ssv_ctx *c, const ssv_batch_t *b, int64_t rec_begin, int64_t rec_end)
 {
 	if (!c || !b) return SSV_E_ARG;
 	if (!c->clip_active) { c->err = "ssv_clip_scan before ssv_clip_begin"; return SSV_E_STATE; }
+	if (rec_begin < 0 || rec_begin > rec_end || rec_end > b->n) { c->err = "ssv_clip_scan_range: bad record range"; return SSV_E_ARG; }
 	HIPCHECK(c, hipSetDevice(c->device));
 	if (b->n == 0) return SSV_OK;
 	DevBatch d;
-	CHECK(stage_batch(c, b, d));
+	CHECK(stage_batch(c, b, d, rec_end < b->n));
 	if (!d.cigar) { c->err = "batch without cigar"; return SSV_E_ARG; }
+	d.n = rec_end; // what lies behind the range is not looked at (nor does it move the contig-switch state)
+	if (rec_end == 0) return SSV_OK;
+	if (!d.ends) { // the batcher did not fill the cigar_ends column: built from the lines
+		CHECK(ensure(c, c->ends_buf, (size_t)d.n + 16));
+		k_build_ends<<<grid_for(d.n, BLOCK), BLOCK, 0, c->st>>>(d, P<uint8_t>(c->ends_buf));
+		HIPCHECK(c, hipGetLastError());
+		d.ends = P<uint8_t>(c->ends_buf);
+	}
 	const bool persistent = b->mem == (SSV_MEM_DEVICE | SSV_MEM_PERSISTENT);
 	const int64_t ntiles = (d.n + CC_TILE - 1) / CC_TILE;
 	const unsigned grid = scan_blocks(ntiles, "SSV_CLIP_SCAN_BLOCKS", 256 * 6);
@@ -635,12 +646,12 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 		CHECK(ensure(c, c->stage, (size_t)block_cap * grid * 4));
 		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
 		ClipScanArgs a;
-		a.n_cigar = d.n_cigar; a.ends = d.ends; a.n = d.n;
+		a.ends = d.ends; a.n = d.n;
 		a.tile_cnt = P<uint32_t>(c->tile_cnt); a.tile_off = P<uint32_t>(c->tile_off); a.stage = P<uint32_t>(c->stage); a.block_cap = block_cap;
 		a.overflow = &dc->overflow; a.ntiles = ntiles;
 		{
 			ProfScope ps(c, P_CLIP_SCAN, d.n);
-			if (a.ends) k_clip_scan_ends<<<grid, BLOCK, 0, c->st>>>(a); else k_clip_scan<<<grid, BLOCK, 0, c->st>>>(a);
+			k_clip_scan_ends<<<grid, BLOCK, 0, c->st>>>(a);
 		}
 		HIPCHECK(c, hipGetLastError());
 		// order across tiles: exclusive scan of the tile counts; its total is the number of candidates
@@ -669,7 +680,7 @@ int ssv_clip_scan(ssv_ctx *c, const ssv_batch_t *b)
 			                                                                    P<uint32_t>(c->cand));
 			ClipFilterArgs f;
 			f.b = d; f.min_mapq = c->clip_p.min_mapq; f.save_low_quality = c->clip_p.save_low_quality; f.last_tid_in = P<int>(c->d_last_tid);
-			f.use_ownership = c->clip_p.use_ownership;
+			f.use_ownership = c->clip_p.use_ownership; f.rec_begin = rec_begin;
 			f.own_lo = ((long long)c->clip_p.own_lo_tid << 32) | (long long)(uint32_t)c->clip_p.own_lo_pos;
 			f.own_hi = ((long long)c->clip_p.own_hi_tid << 32) | (long long)(uint32_t)c->clip_p.own_hi_pos;
 			k_clip_filter<<<grid_for(ncand, BLOCK / 4), BLOCK, 0, c->st>>>(f, P<uint32_t>(c->cand), ncand, P<ClipEvent>(c->ev) + c->ev_slots, P<uint4>(c->kv_stage), P<uint8_t>(c->cand_cnt), P<uint64_t>(c->cand_off));

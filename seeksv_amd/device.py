@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from .host import table_to_dict
+from .host import concat_tables, host_tid_runs, table_to_dict
 
 
 class SeeksvError(RuntimeError):
@@ -166,12 +166,35 @@ class Context:
         self._check(self._lib.ssv_clip_table_expand(self._h, C.byref(t), int(n_threads)), "ssv_clip_table_expand")
         return t
 
-    def getclip(self, batches, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0):
-        """InputBamOutputReads' record loop over a list of batches -> cluster table dict."""
+    def clip_scan_range(self, batch, rec_begin, rec_end):
+        b, keep = self._as_batch(batch)
+        self._check(self._lib.ssv_clip_scan_range(self._h, C.byref(b), int(rec_begin), int(rec_end)), "ssv_clip_scan_range")
+
+    def getclip(self, batches, match_rate=0.9, min_mapq=1, save_low_quality=False, own=None, initial_last_tid=0, tid_runs=None):
+        """InputBamOutputReads' record loop over a list of batches -> cluster table dict.
+        Contigs that come back (unsorted input): the reference flushes its maps at every change of contig among the mapped-pair records
+        (clip_reads.h:423-438); a pass of the library bins by (contig, side, position), so the pass ends in front of a visit whose contig is
+        not greater than every contig the pass has seen, and the tables of the passes follow each other (see ssv_clip_scan_range).
+        tid_runs: per batch the list of (record index, contig) changes - computed here for batches given as arrays; a device batch without
+        it is taken as coordinate sorted."""
+        tables = []
         self.clip_begin(match_rate, min_mapq, save_low_quality, own, initial_last_tid)
-        for b in batches:
-            self.clip_scan(b)
-        return self.clip_cluster()
+        last_tid = pass_max = int(initial_last_tid)
+        for bi, b in enumerate(batches):
+            runs = tid_runs[bi] if tid_runs is not None else (host_tid_runs(b, last_tid) if isinstance(b, dict) and b.get("flag") is not None else [])
+            n = len(b["tid"]) if isinstance(b, dict) else int(b.n)
+            lo = 0
+            for i, tid in runs:
+                if tid <= pass_max and own is None:
+                    self.clip_scan_range(b, lo, i)
+                    tables.append(self.clip_cluster())
+                    self.clip_begin(match_rate, min_mapq, save_low_quality, own, last_tid)
+                    lo, pass_max = i, tid
+                pass_max = max(pass_max, tid)
+                last_tid = tid
+            self.clip_scan_range(b, lo, n)
+        tables.append(self.clip_cluster())
+        return tables[0] if len(tables) == 1 else concat_tables(tables)
 
     # ---- getsv pass 1 ----
     def isize_stats(self, batches, min_mapq=20, max_pairs=5000000):

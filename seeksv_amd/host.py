@@ -251,6 +251,33 @@ def table_to_dict(t):
     return d
 
 
+def host_tid_runs(b, last_tid):
+    """the changes of contig among the mapped-pair records of a batch given as arrays (clip_reads.h:415-438): [(record index, contig)],
+    continuing from `last_tid`, the contig of the last such record before the batch"""
+    keep = np.flatnonzero((np.asarray(b["flag"]) & 12) == 0)
+    if keep.size == 0:
+        return []
+    t = np.asarray(b["tid"])[keep]
+    prev = np.concatenate(([last_tid], t[:-1]))
+    ch = np.flatnonzero(t != prev)
+    return [(int(keep[k]), int(t[k])) for k in ch]
+
+
+def concat_tables(tables):
+    """cluster tables of consecutive getclip passes (dicts of table_to_dict, ASCII format) -> one"""
+    assert all(int(t.get("format", 0)) == 0 and not t["seq_packed"] for t in tables), "passes are put together in the ASCII format"
+    d = dict(n_clusters=sum(t["n_clusters"] for t in tables), n_events=sum(t["n_events"] for t in tables), seq_packed=0, qual_bits=8, qual_alphabet=tables[0]["qual_alphabet"])
+    for name in ("tid", "pos", "side", "support", "left_len", "right_len", "qual_missing", "n_cigar", "str", "cigar"):
+        d[name] = np.concatenate([t[name] for t in tables])
+    so = co = 0
+    offs, coffs = [], []
+    for t in tables:
+        offs.append(t["str_off"] + np.uint64(so)); coffs.append(t["cigar_off"] + np.uint64(co))
+        so += len(t["str"]); co += len(t["cigar"])
+    d["str_off"], d["cigar_off"] = np.concatenate(offs), np.concatenate(coffs)
+    return d
+
+
 def _compact_to_dict(t, d):
     """the compact table (ssv_clip_table_format 3, include/seeksv_hip.h): the columns that did not cross PCIe are rebuilt here with numpy - the
     same arithmetic as ssv_clip_table_expand, written independently (the tests hold the two against each other)"""

@@ -2,10 +2,14 @@
 //
 // The reference reaches a region of the BAM through its .bai (seeksv.cpp:272-280 bam_index_load, getsv.cpp:1063-1067 bam_iter_query /
 // bam_iter_read).  Here the file itself is partitioned: boundaries are BGZF virtual offsets of record starts, chosen so that the parts hold
-// about the same number of inflated bytes.  No index is read: a pass over the block headers (18 bytes each) gives every block's position and
-// inflated size; only the blocks around a boundary are inflated.  A record start inside a block is found by speculation (a position from
+// about the same number of inflated bytes.  No index is read: a pass over the block headers (18 bytes each, through a read-only mapping of
+// the file) gives every block's position and inflated size; only the blocks around a boundary are inflated.  A record start inside a block is found by speculation (a position from
 // which a chain of plausible record headers follows) and - when walking backwards from a known start - verified exactly: the chain must
 // land on the known start.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -21,29 +25,36 @@ namespace {
 struct BlockPos { uint64_t coff; uint32_t csize, isize; };
 
 struct BlockFile {
-	FILE *fp = nullptr;
+	int fd = -1;
+	const uint8_t *map = nullptr; // the whole file, read-only: the block headers are walked through the mapping (two touched pages per
+	size_t map_len = 0;           // block, no system call each), and a block's bytes are inflated from where they lie
 	std::vector<BlockPos> blocks;
 	std::vector<uint64_t> ucum; // inflated bytes before block k
 	int32_t n_targets = 0;
+	std::vector<int32_t> target_len;
 	uint64_t header_len = 0;    // inflated bytes before the first record
 	std::string err;
-	~BlockFile() { if (fp) fclose(fp); }
+	~BlockFile() { if (map && map_len) munmap(const_cast<uint8_t *>(map), map_len); if (fd >= 0) close(fd); }
 
 	bool open(const char *path)
 	{
-		fp = fopen(path, "rb");
-		if (!fp) { err = std::string("cannot open ") + path; return false; }
+		fd = ::open(path, O_RDONLY);
+		if (fd < 0) { err = std::string("cannot open ") + path; return false; }
+		struct stat st;
+		if (fstat(fd, &st) != 0) { err = "cannot stat"; return false; }
+		map_len = (size_t)st.st_size;
+		if (map_len) {
+			void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+			if (m == MAP_FAILED) { map_len = 0; err = "cannot map the file"; return false; }
+			map = static_cast<const uint8_t *>(m);
+		}
 		uint64_t at = 0;
-		for (;;) {
-			uint8_t hdr[18];
-			if (fseek(fp, (long)at, SEEK_SET) != 0) { err = "cannot seek"; return false; }
-			const size_t got = fread(hdr, 1, 18, fp);
-			if (got == 0) break;
-			if (got < 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { err = "not a BGZF block"; return false; }
+		while (at < map_len) {
+			const uint8_t *hdr = map + at;
+			if (at + 18 > map_len || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { err = "not a BGZF block"; return false; }
 			const unsigned xlen = hdr[10] | (hdr[11] << 8);
-			std::vector<uint8_t> extra(xlen);
-			memcpy(extra.data(), hdr + 12, xlen < 6 ? xlen : 6);
-			if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp) != xlen - 6) { err = "truncated BGZF header"; return false; }
+			if (at + 12 + xlen > map_len) { err = "truncated BGZF header"; return false; }
+			const uint8_t *extra = hdr + 12;
 			int bsize = -1;
 			for (size_t off = 0; off + 4 <= xlen;) {
 				const unsigned slen = extra[off + 2] | (extra[off + 3] << 8);
@@ -52,9 +63,8 @@ struct BlockFile {
 				off += 4 + slen;
 			}
 			if (bsize < 0 || (size_t)bsize + 1 < 12 + (size_t)xlen + 8) { err = "bad BGZF block"; return false; }
-			uint8_t tail[4];
-			if (fseek(fp, (long)(at + (uint64_t)bsize + 1 - 4), SEEK_SET) != 0 || fread(tail, 1, 4, fp) != 4) { err = "truncated BGZF block"; return false; }
-			uint32_t isize; memcpy(&isize, tail, 4);
+			if (at + (uint64_t)bsize + 1 > map_len) { err = "truncated BGZF block"; return false; }
+			uint32_t isize; memcpy(&isize, map + at + (uint64_t)bsize + 1 - 4, 4);
 			if (isize > 65536) { err = "BGZF block that claims to inflate to more than 64 KB"; return false; }
 			blocks.push_back(BlockPos{at, (uint32_t)bsize + 1, isize});
 			at += (uint64_t)bsize + 1;
@@ -67,11 +77,9 @@ struct BlockFile {
 	// inflated bytes of blocks [k0, k1) appended to out
 	bool inflate_blocks(size_t k0, size_t k1, std::vector<uint8_t> &out)
 	{
-		std::vector<uint8_t> c;
 		for (size_t k = k0; k < k1 && k < blocks.size(); ++k) {
 			const BlockPos &b = blocks[k];
-			c.resize(b.csize);
-			if (fseek(fp, (long)b.coff, SEEK_SET) != 0 || fread(c.data(), 1, b.csize, fp) != b.csize) { err = "truncated BGZF block"; return false; }
+			const uint8_t *c = map + b.coff;
 			const unsigned xlen = c[10] | (c[11] << 8);
 			const size_t at = out.size();
 			out.resize(at + b.isize);
@@ -79,7 +87,7 @@ struct BlockFile {
 			z_stream zs;
 			memset(&zs, 0, sizeof(zs));
 			if (inflateInit2(&zs, -15) != Z_OK) { err = "zlib"; return false; }
-			zs.next_in = c.data() + 12 + xlen; zs.avail_in = (uInt)(b.csize - 12 - xlen - 8);
+			zs.next_in = const_cast<Bytef *>(c + 12 + xlen); zs.avail_in = (uInt)(b.csize - 12 - xlen - 8);
 			zs.next_out = out.data() + at; zs.avail_out = b.isize;
 			const int rc = inflate(&zs, Z_FINISH);
 			inflateEnd(&zs);
@@ -103,6 +111,9 @@ struct BlockFile {
 			int32_t l_name; memcpy(&l_name, u.data() + o, 4);
 			if (l_name <= 0) { err = "bad BAM header"; return false; }
 			o += 8 + (size_t)l_name;
+			if (!need(o)) { if (err.empty()) err = "bad BAM header"; return false; }
+			int32_t l_ref; memcpy(&l_ref, u.data() + o - 4, 4);
+			target_len.push_back(l_ref);
 		}
 		if (!need(o)) { if (err.empty()) err = "bad BAM header"; return false; }
 		n_targets = n_ref; header_len = o;
@@ -113,7 +124,10 @@ struct BlockFile {
 	size_t block_of(uint64_t g) const { return (size_t)(std::upper_bound(ucum.begin(), ucum.end(), g) - ucum.begin()) - 1; }
 };
 
-bool plausible(const uint8_t *u, size_t o, size_t end, int32_t n_targets)
+// Could a record start at u + o?  The same predicate as the host reader's and the device decoder's (bam_reader.cpp, bamdec_kernels.h):
+// a read name of at least one character + NUL (two bytes ahead of a true start the previous record's tail and the low half of block_size
+// read as a ~17 MB record with an empty name, about once in 2,000 blocks of equal-sized records), and a position inside its contig.
+bool plausible(const uint8_t *u, size_t o, size_t end, int32_t n_targets, const int32_t *target_len)
 {
 	if (o + 36 > end) return false;
 	uint32_t bs; int32_t refid, pos, l_seq, next_ref, next_pos; uint16_t ncig;
@@ -122,7 +136,8 @@ bool plausible(const uint8_t *u, size_t o, size_t end, int32_t n_targets)
 	const uint8_t *r = u + o + 4;
 	memcpy(&refid, r, 4); memcpy(&pos, r + 4, 4); memcpy(&ncig, r + 12, 2); memcpy(&l_seq, r + 16, 4); memcpy(&next_ref, r + 20, 4); memcpy(&next_pos, r + 24, 4);
 	const size_t l_name = r[8];
-	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name == 0) return false;
+	if (refid < -1 || refid >= n_targets || next_ref < -1 || next_ref >= n_targets || pos < -1 || next_pos < -1 || l_seq < 0 || l_name < 2) return false;
+	if (refid >= 0 && target_len && pos >= target_len[refid]) return false; // (the mate's position is left alone: this test must never fail a true record)
 	if (32 + l_name + 4 * (size_t)ncig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > (size_t)bs) return false;
 	const size_t nul = o + 4 + 32 + l_name - 1;
 	return nul >= end || u[nul] == 0;
@@ -163,7 +178,7 @@ bool first_record_from(BlockFile &f, uint64_t g, int want, uint64_t *out)
 			if (q == total) break; // the chain ends exactly at the end of the file: good
 			if (q + 36 > total) { k = -1; break; }
 			w.need(std::min<uint64_t>(total, q + 4 + 36 + 256));
-			if (!plausible(w.u.data(), (size_t)(q - w.g0), w.u.size(), f.n_targets)) { k = -1; break; }
+			if (!plausible(w.u.data(), (size_t)(q - w.g0), w.u.size(), f.n_targets, f.target_len.data())) { k = -1; break; }
 			uint32_t bs; memcpy(&bs, w.u.data() + (q - w.g0), 4);
 			q += 4 + (uint64_t)bs;
 			if (q > total) { k = -1; break; }
@@ -171,6 +186,50 @@ bool first_record_from(BlockFile &f, uint64_t g, int want, uint64_t *out)
 		if (k >= 0) { *out = cand; return true; }
 		if (!f.err.empty()) return false;
 	}
+	return false;
+}
+
+// The first record that starts at or after g, VERIFIED.  A speculated start can be a false one whose chain joins the true records after a
+// hop: two bytes ahead of a true start, the previous record's last two bytes and the low half of block_size read as a ~17 MB record, and
+// with equal-sized records that hop can land exactly on a later true start - the boundary would sit two bytes off a record, or megabytes
+// late.  False starts are rare and unrelated to each other, the file's chain is unique: so the answer must be given by TWO chains that
+// were started independently - the local speculation from g and chains started 4, 8, 16 blocks (hundreds of records) earlier; each says
+// where its first record at or after g is, and the first position two of them agree on is taken.  A chain from the end of the BAM
+// header is the file's chain by definition and needs no second.
+bool first_record_verified(BlockFile &f, uint64_t g, uint64_t *out)
+{
+	const uint64_t total = f.ucum.back();
+	if (g < f.header_len) g = f.header_len;
+	if (g >= total) return false;
+	const size_t kb = f.block_of(g);
+	std::vector<uint64_t> votes;
+	bool any = false;
+	for (size_t back : {(size_t)0, (size_t)4, (size_t)8, (size_t)16, (size_t)32}) {
+		uint64_t from = back == 0 ? g : (kb > back ? f.ucum[kb - back] : f.header_len);
+		if (from < f.header_len) from = f.header_len;
+		uint64_t a = from;
+		if (from > f.header_len && !first_record_from(f, from, 8, &a)) { if (!f.err.empty()) return false; continue; }
+		any = true;
+		// follow the chain from a to its first record at or after g
+		Window w(f);
+		w.begin_at_block(f.block_of(a));
+		uint64_t q = a;
+		bool ok = true;
+		while (q < g) {
+			if (q + 36 > total) { ok = false; break; }
+			w.need(std::min<uint64_t>(total, q + 4 + 36 + 256));
+			if (!plausible(w.u.data(), (size_t)(q - w.g0), w.u.size(), f.n_targets, f.target_len.data())) { ok = false; break; }
+			uint32_t bs; memcpy(&bs, w.u.data() + (q - w.g0), 4);
+			q += 4 + (uint64_t)bs;
+		}
+		if (!f.err.empty()) return false;
+		if (!ok || q > total) continue; // a false anchor: its chain broke
+		if (from == f.header_len) { if (q >= total) return false; *out = q; return true; }
+		for (uint64_t v : votes) if (v == q) { if (q >= total) return false; *out = q; return true; }
+		votes.push_back(q);
+	}
+	if (!any) return false; // nothing that looks like a record at or after g
+	f.err = "no two record chains agree on the first record behind a partition boundary";
 	return false;
 }
 
@@ -191,7 +250,7 @@ bool records_before(BlockFile &f, uint64_t g_known, size_t k_from, std::vector<R
 		chain.clear();
 		uint64_t q = cand;
 		while (q < g_known) {
-			if (!plausible(u, (size_t)(q - w.g0), end, f.n_targets)) return false;
+			if (!plausible(u, (size_t)(q - w.g0), end, f.n_targets, f.target_len.data())) return false;
 			const uint8_t *r = u + (q - w.g0);
 			uint32_t bs; memcpy(&bs, r, 4);
 			RecHead h; h.g = q; memcpy(&h.tid, r + 4, 4); memcpy(&h.pos, r + 8, 4); memcpy(&h.flag, r + 18, 2);
@@ -208,7 +267,7 @@ bool records_before(BlockFile &f, uint64_t g_known, size_t k_from, std::vector<R
 		return true;
 	}
 	for (uint64_t cand = lo; cand + 36 <= g_known; ++cand) {
-		if (!plausible(u, (size_t)(cand - w.g0), end, f.n_targets)) continue;
+		if (!plausible(u, (size_t)(cand - w.g0), end, f.n_targets, f.target_len.data())) continue;
 		if (follow(cand, chain)) { out.swap(chain); return true; }
 	}
 	return true; // no record starts between the block's start and the known record
@@ -273,7 +332,7 @@ int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_
 	for (int32_t r = 1; r < n_parts; ++r) {
 		uint64_t g = f.header_len + body * (uint64_t)r / (uint64_t)n_parts, at = total;
 		if (g < own[(size_t)r - 1]) g = own[(size_t)r - 1];
-		if (g < total && !first_record_from(f, g, 8, &at)) { if (!f.err.empty()) { g_perr = f.err; return -1; } at = total; }
+		if (g < total && !first_record_verified(f, g, &at)) { if (!f.err.empty()) { g_perr = f.err; return -1; } at = total; }
 		own[(size_t)r] = g < total ? at : total;
 	}
 	for (int32_t r = 0; r < n_parts; ++r) {

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <deque>
 #include <map>
 #include <sstream>
 #include <string>
@@ -316,17 +317,22 @@ struct BatchSource {
 		}
 		for (size_t off = 0, nxt; (nxt = ssvh_raw_record_fastq(info.unmapped_raw, info.unmapped_bytes, off, &qname, &seq, &qual, &is_read1)) != 0; off = nxt) fn(qname, seq, qual, is_read1);
 	}
-	// the contig changes among the other records of the current batch (the flush sequence of clip_reads.h:423-438)
-	void contig_runs(const ssv_batch_t &b, int32_t &last_tid, vector<int32_t> &run_tids)
+	// the contig changes among the other records of the current batch (the flush sequence of clip_reads.h:423-438): fn(record index, new contig)
+	template <class F> void contig_changes(const ssv_batch_t &b, int32_t &last_tid, F fn)
 	{
 		if (!on_device) {
 			for (int64_t i = 0; i < b.n; ++i) {
 				if (b.flag[i] & (4 | 8)) continue;
-				if (b.tid[i] != last_tid) { run_tids.push_back(last_tid); last_tid = b.tid[i]; }
+				if (b.tid[i] != last_tid) { last_tid = b.tid[i]; fn(i, last_tid); }
 			}
 			return;
 		}
-		for (uint32_t k = 0; k < info.n_tid_runs; ++k) { run_tids.push_back(last_tid); last_tid = info.tid_run_tid[k]; }
+		for (uint32_t k = 0; k < info.n_tid_runs; ++k) { last_tid = info.tid_run_tid[k]; fn((int64_t)info.tid_run_index[k], last_tid); }
+	}
+	void contig_runs(const ssv_batch_t &b, int32_t &last_tid, vector<int32_t> &run_tids)
+	{
+		int32_t prev = last_tid;
+		contig_changes(b, last_tid, [&](int64_t, int32_t tid) { run_tids.push_back(prev); prev = tid; });
 	}
 	void close()
 	{
@@ -430,6 +436,7 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 }
 
 static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp, bool device_inflate);
+static int getclip_single(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int device, bool device_inflate);
 
 static int cmd_getclip(int argc, char **argv)
 {
@@ -454,7 +461,11 @@ static int cmd_getclip(int argc, char **argv)
 	if (argc != optind + 1 || n_ranks < 1 || halo_bp < 0) usage_getclip();
 	const string bamfile = argv[optind];
 	if (n_ranks > 1) return getclip_ranks(bamfile, prefix, threshold, min_mapQ, save_low_quality, n_ranks, devices, halo_bp, device_inflate);
+	return getclip_single(bamfile, prefix, threshold, min_mapQ, save_low_quality, device, device_inflate);
+}
 
+static int getclip_single(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int device, bool device_inflate)
+{
 	PhaseTimer pt;
 	{ // like the reference: complain about the input before anything is created
 		ssvh_bam *probe = nullptr;
@@ -482,8 +493,43 @@ static int cmd_getclip(int argc, char **argv)
 
 	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219)
 	map<string, pair<pair<string, string>, char>> id2seq_qual;
-	vector<int32_t> run_tids; // contig of every flush, in order (clip_reads.h:428-438, :442)
-	int32_t last_tid = 0;
+	// The flush sequence (clip_reads.h:428-438, :442): the reference writes out and clears its two maps at every change of contig among the
+	// mapped-pair records.  A pass of the library bins by (contig, side, position), which is the same thing as long as every contig of the
+	// pass is visited once, in ascending order - a coordinate-sorted BAM is ONE pass.  When a contig comes back (or one with a lower id
+	// follows) the pass ends in front of that record (ssv_clip_scan_range), its rows go out, and the next pass starts there.
+	vector<int32_t> pass_flushes;       // contigs flushed during the current pass, in order
+	int32_t last_tid = 0, scan_last_tid = 0, pass_max_tid = 0; // (last_tid: the reader's side, one batch ahead of the scans)
+	std::deque<vector<pair<int64_t, int32_t>>> changes_of; // per batch that was read and not yet scanned (the host reader runs one batch ahead)
+	auto emit_pass = [&](bool last) {
+		ssv_cluster_table t;
+		if (ssv_clip_cluster(ctx, &t) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		if (t.format == 3 && ssv_clip_table_expand(ctx, &t, 0) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		pt.lap("gpu_cluster+table");
+		// DisplaySClipReadsAndClipFq ('5' rows then '3' rows per contig run), clip_reads.h:300-345.  The rows of one cluster depend on nothing
+		// else, so cluster ranges are formatted by several host threads and written out in order.
+		int64_t k_end = 0;
+		for (int32_t tid : pass_flushes) {
+			const char *name = ssvh_bam_target_name(bam, tid);
+			cerr << "Output merged soft-clipped reads of " << (name ? name : "") << endl;
+			for (; k_end < t.n_clusters && t.tid[k_end] == tid; ++k_end) {}
+		}
+		const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, k_end / 4096}));
+		vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
+		auto format_range = [&](int w) {
+			const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
+			format_clusters(t, bam, k0, k1, rows[(size_t)w], fqs[(size_t)w]);
+		};
+		{
+			vector<std::thread> th;
+			for (int w = 1; w < n_fmt; ++w) th.emplace_back(format_range, w);
+			format_range(0);
+			for (auto &x : th) x.join();
+		}
+		pt.lap("format");
+		softfout.write_parts(rows); fqfout.write_parts(fqs);
+		pass_flushes.clear();
+		if (!last) pt.lap("gzip");
+	};
 	src.pump(0, [&](const ssv_batch_t &b) {
 		pt.lap(device_inflate ? "bam_read(wait)+gpu_inflate+decode" : "bam_read(wait)");
 		src.for_each_unmapped([&](const char *qname, const char *seq, const char *qual, int is_read1) {
@@ -500,42 +546,28 @@ static int cmd_getclip(int argc, char **argv)
 				}
 			} else id2seq_qual.insert(make_pair(string(qname), make_pair(make_pair(string(seq), string(qual)), is_read1 ? '1' : '2')));
 		});
-		src.contig_runs(b, last_tid, run_tids); // the flush sequence, for the stderr messages and the order check
+		changes_of.emplace_back();
+		src.contig_changes(b, last_tid, [&](int64_t i, int32_t tid) { changes_of.back().emplace_back(i, tid); });
 		pt.lap("host_side_channel");
 	}, [&](const ssv_batch_t &b) {
-		if (ssv_clip_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		int64_t lo = 0;
+		for (const auto &ch : changes_of.front()) {
+			pass_flushes.push_back(scan_last_tid); // the visit that ends here is flushed
+			if (ch.second <= pass_max_tid) {       // a contig that comes back: the pass ends in front of this record
+				if (ssv_clip_scan_range(ctx, &b, lo, ch.first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+				emit_pass(false);
+				p.initial_last_tid = scan_last_tid;
+				if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+				lo = ch.first;
+			}
+			pass_max_tid = scan_last_tid = ch.second;
+		}
+		changes_of.pop_front();
+		if (ssv_clip_scan_range(ctx, &b, lo, b.n) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		pt.lap("gpu_scan(wait h2d+kernels)");
 	});
-	run_tids.push_back(last_tid);
-	for (size_t k = 1; k < run_tids.size(); ++k)
-		if (run_tids[k] <= run_tids[k - 1]) die("[seeksv] the BAM is not coordinate sorted (contig " + string(ssvh_bam_target_name(bam, run_tids[k]) ? ssvh_bam_target_name(bam, run_tids[k]) : "?") + " appears out of order)");
-
-	ssv_cluster_table t;
-	if (ssv_clip_cluster(ctx, &t) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-	if (t.format == 3 && ssv_clip_table_expand(ctx, &t, 0) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-	pt.lap("gpu_cluster+table");
-	// DisplaySClipReadsAndClipFq ('5' rows then '3' rows per contig run), clip_reads.h:300-345.  The rows of one cluster depend on nothing
-	// else, so cluster ranges are formatted by several host threads and written out in order.
-	int64_t k_end = 0;
-	for (int32_t tid : run_tids) {
-		const char *name = ssvh_bam_target_name(bam, tid);
-		cerr << "Output merged soft-clipped reads of " << (name ? name : "") << endl;
-		for (; k_end < t.n_clusters && t.tid[k_end] == tid; ++k_end) {}
-	}
-	const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, k_end / 4096}));
-	vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
-	auto format_range = [&](int w) {
-		const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
-		format_clusters(t, bam, k0, k1, rows[(size_t)w], fqs[(size_t)w]);
-	};
-	{
-		vector<std::thread> th;
-		for (int w = 1; w < n_fmt; ++w) th.emplace_back(format_range, w);
-		format_range(0);
-		for (auto &x : th) x.join();
-	}
-	pt.lap("format");
-	softfout.write_parts(rows); fqfout.write_parts(fqs);
+	pass_flushes.push_back(scan_last_tid);
+	emit_pass(true);
 	cerr << "[GetSClipReads] finished!" << endl;
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
 	pt.lap("gzip");
@@ -587,10 +619,12 @@ static int getclip_ranks(const string &bamfile, const string &prefix, double thr
 		ssv_clip_params p;
 		memset(&p, 0, sizeof(p));
 		p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
-		// breakpoints (contig, 1-based position) owned by this rank: from its first record's start + 1 up to the next rank's
+		// breakpoints (contig, 1-based position) owned by this rank: from its first record's 0-based start taken as a 1-based position - the
+		// smallest key a record can give (a '5' event sits at start + 1, a '3' event at start + reference span, and the span is 0 for a CIGAR
+		// that is one lone soft clip, clip_reads.cpp:150-190) - up to the next rank's
 		p.use_ownership = 1; p.initial_last_tid = P.initial_last_tid;
-		p.own_lo_tid = r == 0 ? 0 : P.own_tid; p.own_lo_pos = r == 0 ? 0 : P.own_pos + 1;
-		if (r + 1 < n_ranks) { p.own_hi_tid = parts[(size_t)r + 1].own_tid; p.own_hi_pos = parts[(size_t)r + 1].own_tid < n_targets ? parts[(size_t)r + 1].own_pos + 1 : 0; }
+		p.own_lo_tid = r == 0 ? 0 : P.own_tid; p.own_lo_pos = r == 0 ? 0 : P.own_pos;
+		if (r + 1 < n_ranks) { p.own_hi_tid = parts[(size_t)r + 1].own_tid; p.own_hi_pos = parts[(size_t)r + 1].own_tid < n_targets ? parts[(size_t)r + 1].own_pos : 0; }
 		else { p.own_hi_tid = INT32_MAX; p.own_hi_pos = 0; }
 		if (ssv_clip_begin(ctx, &p) != SSV_OK) { out.err = string("[seeksv] ") + ssv_last_error(ctx); ssv_ctx_destroy(ctx); return; }
 		ssv_clip_table_format(ctx, table_format_default());
@@ -637,6 +671,19 @@ static int getclip_ranks(const string &bamfile, const string &prefix, double thr
 	int32_t max_span = 0;
 	for (auto &o : R) { if (!o.err.empty()) die(o.err); max_span = std::max(max_span, o.max_span); }
 	if (max_span > halo_bp) die("[seeksv] a read spans " + to_string(max_span) + " reference bases, more than the halo of " + to_string(halo_bp) + " bp before a run of records: rerun with -H " + to_string(max_span));
+	// the flush sequence of the whole file: the ranks' run lists one after the other (a rank's list continues the previous rank's)
+	vector<int32_t> run_tids;
+	for (auto &o : R) run_tids.insert(run_tids.end(), o.run_tids.begin(), o.run_tids.end());
+	int32_t last_tid = 0;
+	for (int r = n_ranks - 1; r >= 0; --r) if (parts[(size_t)r].own_coff != UINT64_MAX || r == 0) { last_tid = R[(size_t)r].last_tid; break; }
+	run_tids.push_back(last_tid);
+	for (size_t k = 1; k < run_tids.size(); ++k)
+		if (run_tids[k] <= run_tids[k - 1]) {
+			// Contigs that come back: the ranks' intervals of (contig, position) mean nothing for such a file.  The reference's result - one
+			// flush per visit of a contig (clip_reads.h:428-438) - comes from the single-GPU path, which ends a pass at every such visit.
+			ssvh_bam_close(bam);
+			return getclip_single(bamfile, prefix, threshold, min_mapQ, save_low_quality, device_of_rank(0, devices), device_inflate);
+		}
 	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219): sequential over the file, i.e. over the ranks in order
 	map<string, pair<pair<string, string>, char>> id2seq_qual;
 	for (auto &o : R) for (auto &u : o.unmapped) {
@@ -653,14 +700,6 @@ static int getclip_ranks(const string &bamfile, const string &prefix, double thr
 			}
 		} else id2seq_qual.insert(make_pair(u.qname, make_pair(make_pair(u.seq, u.qual), u.is_read1 ? '1' : '2')));
 	}
-	// the flush sequence of the whole file: the ranks' run lists one after the other (a rank's list continues the previous rank's)
-	vector<int32_t> run_tids;
-	for (auto &o : R) run_tids.insert(run_tids.end(), o.run_tids.begin(), o.run_tids.end());
-	int32_t last_tid = 0;
-	for (int r = n_ranks - 1; r >= 0; --r) if (parts[(size_t)r].own_coff != UINT64_MAX || r == 0) { last_tid = R[(size_t)r].last_tid; break; }
-	run_tids.push_back(last_tid);
-	for (size_t k = 1; k < run_tids.size(); ++k)
-		if (run_tids[k] <= run_tids[k - 1]) die("[seeksv] the BAM is not coordinate sorted (contig " + string(ssvh_bam_target_name(bam, run_tids[k]) ? ssvh_bam_target_name(bam, run_tids[k]) : "?") + " appears out of order)");
 	vector<string> rows, fqs;
 	for (int32_t tid : run_tids) {
 		const char *name = ssvh_bam_target_name(bam, tid);

@@ -35,13 +35,13 @@ def shard_plan(workload, rank, world):
         own_lo, last_tid = (0, 0), 0
     else:
         t, p = coord(lo)
-        own_lo = (t, p + 1)
+        own_lo = (t, p)   # the smallest key a record starting at p can give: start + reference span, 0 for a lone soft clip
         last_tid = coord(scan_lo - 1)[0] if scan_lo > 0 else 0
     if rank == world - 1 or hi >= n:
         own_hi = (int(workload.cfg.n_contigs), 0)
     else:
         t, p = coord(hi)
-        own_hi = (t, p + 1)
+        own_hi = (t, p)
     return dict(own_lo_rec=lo, own_hi_rec=hi, scan_lo_rec=scan_lo, own=(own_lo, own_hi), initial_last_tid=last_tid)
 
 

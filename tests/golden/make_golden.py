@@ -212,7 +212,7 @@ def crafted_getclip():
 def lone_s_case():
     """records whose whole CIGAR is one soft clip (`50S`) between ordinary clipped reads: the reference reads that single operation as BOTH
     ends of the CIGAR (clip_reads.cpp:150-175: a negative "middle" length) and prints two rows with an empty aligned part for it.
-    The MI355X path emits nothing for such a record: the fixture pins that difference - all other rows are identical."""
+    (The reads here have 51 bases under a 50S CIGAR: the '3' row's clipped part is bases [1, 51).)"""
     out = os.path.join(HERE, "getclip")
     seq = "ACGTTGCAAGCTTAGGCTAACGTAGCTAGGATCCGATAGCTAGCTAGGCTA"
 
@@ -224,6 +224,96 @@ def lone_s_case():
     run([SEEKSV, "getclip", "-o", "lone_s", bam], cwd=TMP)
     gunzip_to(os.path.join(TMP, "lone_s.clip.gz"), os.path.join(out, "lone_s.clip.txt"))
     gunzip_to(os.path.join(TMP, "lone_s.clip.fq.gz"), os.path.join(out, "lone_s.clip.fq.txt"))
+
+
+def lone_s2_case():
+    """more of the same: lone soft clips whose length equals the read's, several of them on one position (an empty part makes the match
+    rate 0/0 = NaN: they never merge, clip_reads.cpp:204,216,266), on the position of ordinary clipped reads, with an XC tag on either
+    strand (clip_reads.cpp:160-175), without qualities, duplicates / MAPQ 0 (dropped), as the first record of a contig (lost); under
+    the default flags, -s and -q 0"""
+    out = os.path.join(HERE, "getclip")
+    rng = random.Random(77)
+    names, lens = ["c1", "c2"], [50000, 20000]
+    recs = []
+    xc = b"XCi" + (5).to_bytes(4, "little")
+
+    def add(tid, pos, cigar, flag=0, mapq=60, aux=b"", qual="rand", seq=None, L=None):
+        if L is None:
+            L = sum(l for l, op in bamio.parse_cigar(cigar) if op in (0, 1, 4, 7, 8))
+        recs.append(dict(qname=f"r{len(recs)}", flag=flag, tid=tid, pos=pos, mapq=mapq, cigar=cigar, mtid=tid, mpos=pos + 200, isize=0,
+                         seq=seq or rnd_seq(rng, L), qual=rnd_qual(rng, L) if qual == "rand" else qual, aux=aux))
+    shared = rnd_seq(rng, 60)
+    add(0, 100, "60M")
+    add(0, 1000, "60S", seq=shared)                # two identical lone clips on one position: two clusters per side, support 1 each
+    add(0, 1000, "60S", seq=shared)
+    add(0, 1000, "20S40M", seq=shared)             # an ordinary left clip in the same '5' bin (1001): no merge with the lone ones either way
+    add(0, 1000, "20S40M", seq=shared)             # ... but with its twin
+    add(0, 1940, "60M20S")                         # '3' at 2000
+    add(0, 2000, "80S")                            # lone clip whose '3' key (pos + 0 = 2000) is the bin of the read above
+    add(0, 3000, "40S", aux=xc)                    # XC != 0, forward: the '5' row only (without -s)
+    add(0, 3100, "40S", aux=xc, flag=16)           # reverse: the '3' row only
+    add(0, 3200, "40S", qual=None)                 # no qualities: "*" also for the empty part
+    add(0, 3300, "40S", flag=1024)                 # duplicate: dropped
+    add(0, 3400, "40S", mapq=0)                    # MAPQ 0: dropped unless -q 0
+    add(0, 3500, "40S", flag=256)                  # secondary: kept
+    add(0, 3600, "30S", L=45)                      # read longer than the clip, shorter than twice the clip: middle = -15
+    add(0, 3700, "30S", L=75)                      # longer than twice the clip: middle = +15, an ordinary two-sided event
+    add(0, 3800, "1S")                             # one base
+    add(1, 10, "50S")                              # first record of contig c2: triggers the flush and is lost
+    add(1, 20, "50S")
+    add(1, 20, "25S25M")
+    bam = os.path.join(out, "lone_s2.bam")
+    bamio.write_bam(bam, names, lens, recs)
+    for tag, flags in (("", []), (".s", ["-s"]), (".q0", ["-q", "0"])):
+        pre = f"lone_s2{tag}"
+        run([SEEKSV, "getclip"] + flags + ["-o", pre, bam], cwd=TMP)
+        gunzip_to(os.path.join(TMP, f"{pre}.clip.gz"), os.path.join(out, f"{pre}.clip.txt"))
+        gunzip_to(os.path.join(TMP, f"{pre}.clip.fq.gz"), os.path.join(out, f"{pre}.clip.fq.txt"))
+
+
+def unsorted_case():
+    """a BAM whose contigs come back (c1, c2, c1, c3, c2, c2 after unmapped reads, c1): the reference flushes its two maps at EVERY change of
+    contig among the mapped-pair records (clip_reads.h:423-438), so reads of the two visits of c1 never share a cluster although they
+    share a position, every visit prints its own block of '5' then '3' rows (and its own stderr line), and the first record of every visit
+    is lost.  Positions also run backwards inside a visit (rows come out in map order: by position)."""
+    out = os.path.join(HERE, "getclip")
+    rng = random.Random(78)
+    names, lens = ["c1", "c2", "c3"], [50000, 20000, 9000]
+    recs = []
+    shared = rnd_seq(rng, 100)
+
+    def add(tid, pos, cigar, flag=0, mapq=60, seq=None):
+        L = sum(l for l, op in bamio.parse_cigar(cigar) if op in (0, 1, 4, 7, 8))
+        recs.append(dict(qname=f"r{len(recs)}", flag=flag, tid=tid, pos=pos, mapq=mapq, cigar=cigar, mtid=tid, mpos=pos + 200, isize=0,
+                         seq=(seq or rnd_seq(rng, 100))[:L], qual=rnd_qual(rng, L)))
+    add(0, 50, "100M")
+    for _ in range(3):
+        add(0, 1000, "30S70M", seq=shared)       # visit 1 of c1: one cluster of 3 at '5' 1001
+    add(0, 1930, "70M30S", seq=shared)           # '3' at 2000
+    add(0, 900, "20S80M")                        # positions going backwards inside the visit
+    add(1, 100, "30S70M", seq=shared)            # first record of c2: lost
+    add(1, 100, "30S70M", seq=shared)
+    add(1, 500, "80M20S")
+    add(0, 1000, "30S70M", seq=shared)           # c1 again: this record only triggers the flush
+    for _ in range(2):
+        add(0, 1000, "30S70M", seq=shared)       # visit 2 of c1: its own cluster of 2 on the same position
+    add(0, 1930, "70M30S", seq=shared)
+    add(0, 1930, "70M30S", seq=shared)
+    add(2, 10, "100M")
+    add(2, 20, "25S75M")
+    add(1, 100, "30S70M", seq=shared)            # c2 again (lost), then
+    add(1, 100, "30S70M", seq=shared)
+    add(1, 300, "40S60M", flag=4)                # unmapped-pair records do not touch last_tid ...
+    add(0, 400, "40S60M", flag=8)                # ... whatever contig they name
+    add(1, 100, "30S70M", seq=shared)            # so this one still belongs to the same visit of c2: cluster of 2
+    add(1, 640, "60M40S")
+    add(0, 1000, "30S70M", seq=shared)           # c1 a third time: lost
+    add(0, 1000, "10S90M", seq=shared[20:] + shared[:20])
+    bam = os.path.join(out, "unsorted.bam")
+    bamio.write_bam(bam, names, lens, recs)
+    run([SEEKSV, "getclip", "-o", "unsorted", bam], cwd=TMP, stderr=os.path.join(out, "unsorted.getclip.stderr"))
+    gunzip_to(os.path.join(TMP, "unsorted.clip.gz"), os.path.join(out, "unsorted.clip.txt"))
+    gunzip_to(os.path.join(TMP, "unsorted.clip.fq.gz"), os.path.join(out, "unsorted.clip.fq.txt"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -625,6 +715,8 @@ if __name__ == "__main__":
     example()
     crafted_getclip()
     lone_s_case()
+    lone_s2_case()
+    unsorted_case()
     crafted_getsv()
     synthetic()
     synthetic_full()

@@ -109,3 +109,43 @@ def test_partition_more_parts_than_records(tmp_path):
     names, lens, batches = host.read_bam(path)
     whole = {k: _cat(batches, k) for k in KEYS}
     _check(path, whole, 64, 100)
+
+
+def test_partition_false_record_start_two_bytes_early(tmp_path):
+    """Equal-sized records on contig 0, built so that two bytes ahead of EVERY record start a plausible header begins (the previous record's
+    last two bytes + the low half of block_size read as a 17.5 MB record with a 4-byte name and a position inside the contig) whose single
+    hop lands exactly on a true record start 64,573 records later: local speculation alone takes that false start.  The boundaries must
+    still be true record starts (two independently started chains have to agree), the parts must tile the file."""
+    import struct
+    import bamio
+    S = 32 + 2 + 4 + 75 + 150 + 5                        # block_size of every record
+    k = -(-((S << 16) + 2) // (S + 4))
+    tail2 = k * (S + 4) - 2 - (S << 16)                  # the u16 at the end of every record: 2 + (tail2 | S << 16) + 4 - 2 = k records
+    assert 0 <= tail2 < 65536
+    n = k + 40000
+    seq = "ACGT" * 37 + "AC"
+    recs = [dict(qname="a", flag=99, tid=0, pos=0x040000 + min(i, 30000), mapq=60, cigar="150M", mtid=0, mpos=0x040000 + min(i, 30000) + 100, isize=250, seq=seq,
+                 qual=bytes([30] * 150), aux=b"XXS" + struct.pack("<H", tail2)) for i in range(n)]
+    path = str(tmp_path / "equal.bam")
+    bamio.write_bam(path, ["c0"], [0x7fffffff], recs)
+    names, lens, batches = host.read_bam(path)
+    whole = {kk: _cat(batches, kk) for kk in KEYS}
+    assert len(whole["tid"]) == n
+    # the trap is there: the bytes two ahead of a record start pass for a record header whose hop ends on a record start
+    import gzip
+    raw = gzip.open(path, "rb").read()
+    first = raw.index(struct.pack("<I", S) + struct.pack("<i", 0))
+    t = first + 10 * (S + 4)
+    bs = struct.unpack_from("<I", raw, t - 2)[0]
+    assert (t - 2 + 4 + bs - first) % (S + 4) == 0 and raw[t - 2 + 4 + 8] == 4 and raw[t - 2 + 4 + 32 + 4 - 1] == 0
+    for n_parts in (3, 7, 13):
+        parts = host.partition(path, n_parts, 100)
+        n_seen = 0
+        for r, p in enumerate(parts):
+            bs_ = _read_range(path, p["own"], p["end"])
+            i0 = n_seen
+            n_seen += sum(len(b["tid"]) for b in bs_)
+            if i0 < n:
+                assert (p["own_tid"], p["own_pos"]) == (0, int(whole["pos"][i0]))
+            assert i0 == 0 or abs(i0 - n * r // n_parts) < 300       # and they are where the balance puts them, not a hop later
+        assert n_seen == n

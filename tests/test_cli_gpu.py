@@ -30,7 +30,10 @@ SEEKSV = os.environ.get("SSV_CLI") or os.path.join(ROOT, "seeksv_amd", "bin", "s
 
 GETCLIP = [("example", "cancer.sort.bam", "cancer", []), ("example", "normal.sort.bam", "normal", []), ("getclip", "filters.bam", "filters", []),
            ("getclip", "filters.bam", "filters.s", ["-s"]), ("getclip", "filters.bam", "filters.q30", ["-q", "30"]), ("getclip", "stress1.bam", "stress1.t08", ["-t", "0.8"]),
-           ("getclip", "stress2.bam", "stress2", []), ("getclip", "stress3.bam", "stress3", []), ("getclip", "stress3.bam", "stress3.t08", ["-t", "0.8"])]
+           ("getclip", "stress2.bam", "stress2", []), ("getclip", "stress3.bam", "stress3", []), ("getclip", "stress3.bam", "stress3.t08", ["-t", "0.8"]),
+           # records whose whole CIGAR is one soft clip (two rows with an empty aligned part), contigs that come back (one flush per visit)
+           ("getclip", "lone_s.bam", "lone_s", []), ("getclip", "lone_s2.bam", "lone_s2", []), ("getclip", "lone_s2.bam", "lone_s2.s", ["-s"]),
+           ("getclip", "lone_s2.bam", "lone_s2.q0", ["-q", "0"]), ("getclip", "unsorted.bam", "unsorted", [])]
 
 
 @pytest.mark.parametrize("sub,bam,prefix,flags", GETCLIP, ids=[c[2] for c in GETCLIP])
@@ -41,7 +44,7 @@ def test_cli_getclip(tmp_path, sub, bam, prefix, flags):
     assert gzip.open(out + ".clip.gz", "rt").read() == G.read_text(sub, prefix + ".clip.txt")
     assert gzip.open(out + ".clip.fq.gz", "rt").read() == G.read_text(sub, prefix + ".clip.fq.txt")
     assert gzip.open(out + ".unmapped_1.fq.gz", "rt").read() == "" and gzip.open(out + ".unmapped_2.fq.gz", "rt").read() == ""
-    if sub == "example":
+    if sub == "example" or prefix == "unsorted":
         assert r.stderr == G.read_text(sub, prefix + ".getclip.stderr")
 
 

@@ -18,7 +18,8 @@ SEEKSV = os.environ.get("SSV_CLI") or os.path.join(ROOT, "seeksv_amd", "bin", "s
 
 GETCLIP = [("example", "cancer.sort.bam", "cancer", []), ("example", "normal.sort.bam", "normal", []), ("getclip", "filters.bam", "filters", []),
            ("getclip", "filters.bam", "filters.q30", ["-q", "30"]), ("getclip", "stress1.bam", "stress1.t08", ["-t", "0.8"]), ("getclip", "stress2.bam", "stress2", []),
-           ("getclip", "stress3.bam", "stress3", [])]
+           ("getclip", "stress3.bam", "stress3", []), ("getclip", "lone_s2.bam", "lone_s2", []),
+           ("getclip", "unsorted.bam", "unsorted", [])]   # contigs that come back: the ranks give way to one GPU that ends a pass at every such visit
 
 
 @pytest.mark.parametrize("n", [2, 3, 7])

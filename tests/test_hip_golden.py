@@ -9,7 +9,7 @@ import pytest
 import golden_util as G
 import oracle_lib as O
 from seeksv_amd import _abi, host
-from test_oracle_golden import GETCLIP_CASES, GETSV_CASES, lone_s_expected
+from test_oracle_golden import GETCLIP_CASES, GETSV_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,8 @@ def test_getclip_hip_matches_reference(ctx, sub, bam, prefix, kw, batch_records)
 def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw, fmt):
     """ssv_clip_table_format: 1 = sequences leave the GPU as 4-bit codes, 2 = also qualities as indices into the pass's quality alphabet when
     it has at most 16 members; decoded, the table is the ASCII table (and the reference's rows)"""
+    if prefix == "unsorted":
+        pytest.skip("several passes: their tables are put together in the ASCII format (the CLI tests cover the compact one)")
     names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, sub, bam), 1 << 20)
     ref = ctx.getclip(batches, **kw)
     ctx.clip_table_format(fmt)
@@ -95,6 +97,8 @@ def test_getclip_compact_table_format(ctx, sub, bam, prefix, kw):
     """ssv_clip_table_format 3, the compact table: 12 bytes of fixed columns per cluster, contig / side as runs, no offsets, one 2-bit base
     stream and one quality stream per cluster, bases outside A/C/G/T as exceptions; rebuilt on the host it is the ASCII table (and the
     reference's rows)"""
+    if prefix == "unsorted":
+        pytest.skip("several passes: their tables are put together in the ASCII format (the CLI tests cover the compact one)")
     names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, sub, bam), 1 << 20)
     ref = ctx.getclip(batches, **kw)
     ctx.clip_table_format(3)
@@ -514,19 +518,6 @@ def test_right_clip_list_sort_paths(ctx, far):
     ends = pos.astype(np.int64) + 20 + dele + (m - 20)
     assert np.any(np.diff(ends) < 0)                               # the list really is out of key order
     assert_tables_equal(ctx.getclip([b]), want)
-
-
-def test_getclip_lone_soft_clip_records(ctx):
-    """a record whose whole CIGAR is one soft clip yields no clip event here (the reference prints two rows with an empty aligned part for it):
-    everything else of tests/golden/getclip/lone_s.* is the reference's, byte for byte"""
-    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", "lone_s.bam"))
-    for fmt in (0, 3):
-        ctx.clip_table_format(fmt)
-        try:
-            d = ctx.getclip(batches)
-        finally:
-            ctx.clip_table_format(0)
-        assert host.format_clip_outputs(d, names) == lone_s_expected()
 
 
 @pytest.mark.parametrize("source", ["stress1", "filters", "synth150"])

@@ -22,6 +22,11 @@ GETCLIP_CASES = [
     ("getclip", "stress2.bam", "stress2", {}),
     ("getclip", "stress3.bam", "stress3", {}),                          # thousands of reads per breakpoint, > 64 clusters per bin
     ("getclip", "stress3.bam", "stress3.t08", dict(match_rate=0.8)),
+    ("getclip", "lone_s.bam", "lone_s", {}),                            # records whose whole CIGAR is one soft clip: two rows with an empty aligned part
+    ("getclip", "lone_s2.bam", "lone_s2", {}),
+    ("getclip", "lone_s2.bam", "lone_s2.s", dict(save_low_quality=True)),
+    ("getclip", "lone_s2.bam", "lone_s2.q0", dict(min_mapq=0)),
+    ("getclip", "unsorted.bam", "unsorted", {}),                        # contigs that come back: one flush per visit (clip_reads.h:423-438)
 ]
 
 GETSV_CASES = [
@@ -57,13 +62,11 @@ def test_getclip_oracle_matches_reference(sub, bam, prefix, kw, batch_records):
 
 
 def lone_s_expected():
-    """tests/golden/getclip/lone_s.*: the reference's rows minus the two it prints, with an empty aligned part, for every record whose whole
-    CIGAR is one soft clip (it reads that operation as both ends of the CIGAR); the documented difference"""
-    rows = [r for r in G.read_text("getclip", "lone_s.clip.txt").splitlines(True) if r.split("\t")[3] != ""]
-    fq = G.read_text("getclip", "lone_s.clip.fq.txt").split("@")[1:]
-    dropped = {r.split("\t")[6] for r in G.read_text("getclip", "lone_s.clip.txt").splitlines() if r.split("\t")[3] == ""}
-    assert len(dropped) == 2 and len(rows) == 4
-    return "".join(rows), "".join("@" + x for x in fq if x.split("\n")[0] not in dropped)
+    """tests/golden/getclip/lone_s.*: the reference's output whole - a record whose CIGAR is one lone soft clip gives a '5' and a '3' row
+    with an empty aligned part (it reads that operation as both ends of the CIGAR, clip_reads.cpp:115,150-190)"""
+    rows = G.read_text("getclip", "lone_s.clip.txt")
+    assert sum(1 for r in rows.splitlines() if r.split("\t")[3] == "") == 4
+    return rows, G.read_text("getclip", "lone_s.clip.fq.txt")
 
 
 def test_getclip_oracle_lone_soft_clip_records():
