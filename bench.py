@@ -54,8 +54,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--ref-sample", type=int, default=3_000_000, help="records of the sample the real reference binary (oracle/_ref, if it travelled) is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--file-frac", type=float, default=-1.0, help="(default: --genome-frac, i.e. the bench workload itself = BASELINE config 2, 617 M records / 10.5 GB, where >= 128 host cores write the file in about a minute; a quarter of it from 32 cores; else 1/16) genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
+    ap.add_argument("--file-frac", type=float, default=-1.0, help="(default: --genome-frac, i.e. the bench workload itself = BASELINE config 2, 617 M records / 44 GB, where >= 192 host cores write the file in about a minute; a quarter of it from 64 cores; else 1/16 or 1/64) genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
                     "inflate + decode -> scans -> tables on the host); 0 = skip")
+    ap.add_argument("--file-level", type=int, default=-1, help="deflate level of the file leg's BAM (default: 6 = samtools' default where >= 64 CPUs write the file, else 4)")
+    ap.add_argument("--no-cli-leg", action="store_true", help="skip cli_path (the `seeksv` binary as child processes on the file leg's BAM)")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
     ap.add_argument("--table-format", type=int, default=3, help="ssv_clip_table_format: 3 = the compact table (default), 2 = four-piece blocks with 4-bit bases, 0 = ASCII")
     ap.add_argument("--no-overlap", action="store_true", help="collect every cluster table in its own step (no copy in flight while other kernels run); use under rocprofv3, which serialises dispatches of different streams")
@@ -365,8 +367,16 @@ def main():
                 avail_gb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")) / (1 << 20)
             except Exception:
                 avail_gb = 0.0
-            # the full-size file wants ~40 GB of host memory for a minute (the file in /dev/shm, its pinned copy, 32 batches being written)
-            args.file_frac = args.genome_frac * (1.0 if cores_here >= 128 and avail_gb >= 128 else 0.25 if cores_here >= 32 and avail_gb >= 48 else 1 / 16)
+            # Every record with its bases and qualities: 72-76 B/record in the file.  What bounds the leg's size is writing the file with zlib on the
+            # host (outside the timed region, but inside the run): level 6 deflates ~11 MB/s per core, level 4 (lazy matching too, 76 instead of
+            # 72 B/record) ~40 MB/s.  The driver's box grants 16 CPUs of time: an eighth of the sample (77 M records, 21 GB of records) at level 4
+            # takes about half a minute; >= 64 CPUs write a quarter at level 6; >= 192 the whole sample.
+            eff = effective_cpus()
+            args.file_frac = args.genome_frac * (1.0 if eff >= 192 and avail_gb >= 256 else 0.25 if eff >= 64 and avail_gb >= 64 else 0.125 if eff >= 12 and avail_gb >= 32 else 1 / 64)
+            if args.file_level < 0:
+                args.file_level = 6 if eff >= 64 else 4
+        if args.file_level < 0:
+            args.file_level = 6
         if world == 1 and args.file_frac > 0:
             try:
                 line["file_path"] = file_path_leg(ctx, args, local_rank)
@@ -393,6 +403,30 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def effective_cpus():
+    """CPUs this process can really use: the visible ones, the affinity mask, and the cgroup's CPU quota (a container may see 256 CPUs and be
+    granted the time of 16: more threads than that only queue behind the throttle)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:
+        q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return n
 
 
 def bind_near_gpu(torch, index):
@@ -427,7 +461,7 @@ def file_path_leg(ctx, args, device):
     import torch
     from seeksv_amd import _abi, host, synth
     w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, round(args.n_sv * args.file_frac / args.genome_frac)))  # the same density of planted junctions
-    need = int(w.n_total * 20)  # the file is ~17 bytes a record
+    need = int(w.n_total * 100)  # the file is ~72 bytes a record
     def room(path):
         try:
             st = os.statvfs(path)
@@ -440,12 +474,31 @@ def file_path_leg(ctx, args, device):
     d = tempfile.mkdtemp(prefix="ssv_file_", dir=where)
     try:
         t0 = time.perf_counter()
-        chunk = 2_000_000
+        # EVERY record carries its bases and qualities (reference bases at the record's position with 0.2 % substitutions, qualities
+        # from {2, 11, 25, 37, 40} with fixed weights), deflate level 6 like samtools: ~72 B/record compressed, ~275 B/record inflated.
+        # Records are generated by a pool of host threads (a C loop, GIL released) that runs ahead of the writer (which serialises and
+        # deflates a batch on all cores): a bounded queue keeps at most ~2 x cores batches of 0.5 M records (~120 MB each) in host memory.
+        os.environ["SSV_BGZF_LEVEL"] = str(args.file_level)
+        cores = effective_cpus()
+        os.environ.setdefault("SSV_WRITE_THREADS", str(cores))
+        chunk = 500_000
         starts = list(range(0, w.n_total, chunk))
-        def batches():  # 32 batches at a time (the generator is a C loop, GIL released): at most ~16 GB of records in host memory whatever the file's size
-            with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
-                for i in range(0, len(starts), 32):
-                    yield from ex.map(lambda g: w.generate_host(g, min(chunk, w.n_total - g)), starts[i:i + 32])
+        import queue
+        def batches():
+            n_gen = max(1, min(cores, len(starts)))
+            with ThreadPoolExecutor(max_workers=n_gen) as ex:
+                pending = queue.Queue()
+                it = iter(starts)
+                def submit():
+                    g = next(it, None)
+                    if g is not None:
+                        pending.put(ex.submit(w.generate_host, g, min(chunk, w.n_total - g), False, True))
+                for _ in range(2 * n_gen):
+                    submit()
+                while not pending.empty():
+                    f = pending.get()
+                    submit()
+                    yield f.result()
         bam = os.path.join(d, "sample.bam")
         host.write_bam(bam, w.names, w.lens, batches())
         bam_bytes = os.path.getsize(bam)
@@ -453,6 +506,7 @@ def file_path_leg(ctx, args, device):
         # the file's BGZF blocks into pinned host memory, in chunks of ~2 GB of inflated data
         hl = _abi.host_lib()
         chunks = []
+        t_read = time.perf_counter()
         with host.BamReader(bam) as r:
             first = C.c_uint64()
             if hl.ssvh_bam_raw_begin(r.handle, C.byref(first)) != 0:
@@ -462,7 +516,7 @@ def file_path_leg(ctx, args, device):
             # many to fill the chip (pass 1 keeps 82 K blocks resident at once)
             chunk_inflated = 5 << 30
             max_blocks = 1 << 18
-            cap = min(bam_bytes + (1 << 20), 1 << 30)
+            cap = min(bam_bytes + (1 << 20), 3 << 29)
             while True:
                 buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
                 blocks = (_abi.BgzfBlock * max_blocks)()
@@ -472,6 +526,9 @@ def file_path_leg(ctx, args, device):
                 if nb.value == 0:
                     break
                 chunks.append((buf, blocks, nb.value, nbytes.value))
+        read_s = time.perf_counter() - t_read
+        blk_dt = np.dtype([("c_off", np.uint64), ("c_len", np.uint32), ("u_len", np.uint32)])
+        inflated_total = sum(int(np.frombuffer(blk, dtype=blk_dt, count=nb_)["u_len"].sum()) for _, blk, nb_, _ in chunks)
         hdr = host.Header(w.names, w.lens)
         jtable = host.JunctionTable(w.junctions)
         lib = ctx._lib
@@ -560,18 +617,83 @@ def file_path_leg(ctx, args, device):
         inflated = None
         kernel_ms = {k: round(v["total_ms"] / len(runs), 3) for k, v in prof.items() if v["launches"]}
         out = {"value": w.n_total / best["total_s"], "unit": "records/s",
-               "workload": f"synthetic {args.depth:g}x WGS, genome_frac {args.file_frac:g}: {w.n_total} records as a BAM file of {bam_bytes} bytes (BGZF level 6, written by libseeksv_host), "
-                           f"{len(chunks)} chunks of whole BGZF blocks in pinned host memory",
-               "records": w.n_total, "bam_bytes": bam_bytes, "chunks": len(chunks),
+               "workload": f"synthetic {args.depth:g}x WGS, genome_frac {args.file_frac:g}: {w.n_total} records, every one with its bases (reference + 0.2 % substitutions) and qualities "
+                           f"(from {{2,11,25,37,40}}), as a BAM file of {bam_bytes} bytes = {bam_bytes / w.n_total:.1f} B/record (BGZF deflate level {args.file_level}, written by libseeksv_host; "
+                           f"{inflated_total / w.n_total:.1f} B/record inflated), {len(chunks)} chunks of whole BGZF blocks in pinned host memory",
+               "records": w.n_total, "bam_bytes": bam_bytes, "bam_bytes_per_record": round(bam_bytes / w.n_total, 2), "inflated_bytes_per_record": round(inflated_total / w.n_total, 2), "chunks": len(chunks),
+               "timed_region": "per pass and chunk: H2D of the compressed bytes out of pinned host memory -> device BGZF inflate -> BAM record decode -> scans -> tables / tallies on the host; "
+                               "NOT in it: reading the file from /dev/shm into the pinned buffers and the scan of its BGZF block headers (ssvh_bam_read_blocks, %.1f s here), file creation" % read_s,
                "getclip_s": round(best["getclip_s"], 4), "getsv_s": round(best["getsv_s"], 4), "total_s": round(best["total_s"], 4),
                "runs_total_s": [round(t["total_s"], 4) for t in runs],
                "pcie_in_GBs": round(2 * bam_bytes / best["total_s"] / 1e9, 2),
                "kernel_ms_per_run": kernel_ms, "result": best["result"],
                "note": "both passes read the whole file (two commands in the reference: getclip, getsv); file creation (%.1f s) is outside the timed region" % make_s}
         hdr.close()
+        if not args.no_cli_leg:
+            try:
+                out["cli_path"] = cli_path_leg(args, w, bam, d, out["result"])
+            except Exception as e:
+                out["cli_path"] = {"error": f"{type(e).__name__}: {e}"}
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def cli_path_leg(args, w, bam, d, expect):
+    """The product binary at scale (north_star: "a C++ host that keeps the seeksv getclip / seeksv getsv CLI"): `seeksv getclip -Z` and `seeksv getsv -Z -B`
+    as child processes on the file leg's BAM (in /dev/shm), wall clock from exec to exit - process start, HIP context, reading the file, device
+    inflate + decode, kernels, row formatting, gzip, every output file.  Junctions come in through the reference's own -B harness (the external
+    re-alignment step between the two commands is not part of the path)."""
+    import gzip
+    import subprocess
+    from seeksv_amd import host
+    exe = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
+    env = dict(os.environ, SSV_TIMING="1")
+
+    def phases(stderr):
+        out = {}
+        for line in stderr.splitlines():
+            if line.startswith("[timing] "):
+                name, sec, _ = line[9:].rsplit(" ", 2)
+                out[name] = round(float(sec), 3)
+        return out
+    jfile = os.path.join(d, "junctions.txt")
+    with open(jfile, "w") as f:
+        for j in w.junctions:
+            f.write("\t".join(str(x) for x in (j[0], j[1], j[2], 0, j[3], j[4], j[5], 0, 0, 0, "NA", 0, 0, 0, 0, 0, 0, 0, 0, "50M", "50M", "ACGT", "ACGT")) + "\n")
+    empty_bam = os.path.join(d, "empty.clip.bam")
+    host.write_bam(empty_bam, w.names, w.lens, [])
+    empty_clip = os.path.join(d, "empty.clip")
+    open(empty_clip, "w").close()
+    res = {}
+    best = None
+    for rep in range(2):  # the second run finds the binary, the libraries and the file's pages warm; the better one is reported
+        t0 = time.perf_counter()
+        r1 = subprocess.run([exe, "getclip", "-Z", "-o", os.path.join(d, "cli"), bam], capture_output=True, text=True, env=env)
+        t1 = time.perf_counter()
+        r2 = subprocess.run([exe, "getsv", "-Z", "-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip, os.path.join(d, "cli.sv"), os.path.join(d, "cli.x.fq")],
+                            capture_output=True, text=True, env=env)
+        t2 = time.perf_counter()
+        if r1.returncode != 0 or r2.returncode != 0:
+            raise RuntimeError((r1.stderr + r2.stderr)[-400:])
+        cur = dict(getclip_s=round(t1 - t0, 3), getsv_s=round(t2 - t1, 3), total_s=round(t2 - t0, 3), getclip_phases_s=phases(r1.stderr), getsv_phases_s=phases(r2.stderr))
+        if best is None or cur["total_s"] < best["total_s"]:
+            best = cur
+    res.update(best)
+    res["value"] = w.n_total / best["total_s"]
+    res["unit"] = "records/s"
+    # the same answers as the ABI path on the same file: one clip.gz row per cluster, the discordant pairs of the SV table
+    rows = 0
+    with gzip.open(os.path.join(d, "cli.clip.gz"), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            rows += chunk.count(b"\n")
+    abnormal = sum(int(l.split("\t")[9]) for l in open(os.path.join(d, "cli.sv")) if l and not l.startswith("@"))
+    abnormal += sum(int(l.split("\t")[10]) for l in r2.stdout.splitlines() if l.count("\t") >= 15)  # junctions the filter chain sent to stdout (reason + the 15 fields)
+    res["clip_rows"], res["abnormal_sum"] = rows, abnormal
+    res["same_result_as_abi_path"] = bool(rows == expect["n_clusters"] and abnormal == expect["abnormal_sum"])
+    res["outputs_bytes"] = {n: os.path.getsize(os.path.join(d, n)) for n in ("cli.clip.gz", "cli.clip.fq.gz", "cli.sv")}
+    res["what"] = "`seeksv getclip -Z` + `seeksv getsv -Z -B <planted junctions>` as child processes on the file leg's BAM in /dev/shm, wall clock exec to exit (two whole-file reads, two HIP contexts)"
+    return res
 
 
 def cpu_baseline(w, hdr, n_sample, min_seconds=10.0):

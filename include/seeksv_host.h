@@ -86,8 +86,10 @@ int ssvh_bam_set_allocator(ssvh_bam *b, void *(*alloc)(size_t), void (*release)(
 /* Raw mode, for the device-side decoder (ssv_bamdec_*, seeksv_hip.h): rewind to the first BGZF block and hand out COMPRESSED blocks.
  * *first_record_offset = length of the BAM header inside the inflated stream.  Not to be mixed with read_batch / next_record. */
 int ssvh_bam_raw_begin(ssvh_bam *b, uint64_t *first_record_offset);
-/* Read whole BGZF blocks: their deflate payloads back to back into dst (dst_bytes; 8 spare bytes are kept behind the last one), at most
- * max_blocks of them and about max_inflated bytes of inflated data; blocks[k] describes payload k.  *n_blocks == 0 at end of file. */
+/* Read whole BGZF blocks: the file's bytes as they are (block headers and trailers included; all host threads read at once) into dst
+ * (dst_bytes; 8 spare bytes are kept behind the last block), at most max_blocks non-empty blocks and about max_inflated bytes of inflated
+ * data; blocks[k].c_off / c_len = where block k's deflate payload lies in dst, u_len = what it inflates to; *n_bytes = bytes of dst in use.
+ * *n_blocks == 0 at end of file. */
 int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes);
 /* Decode the k-th record of a run of raw BAM records (block_size prefixed, as ssv_bamdec_info.unmapped_raw holds them) the way the
  * unmapped side channel wants it (GetSeqAndQual, clip_reads.cpp:375-388).  Returns the offset of the next record, 0 at the end. */
@@ -106,7 +108,8 @@ typedef struct {
 } ssvh_record;
 int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out);
 
-/* Tooling: write a structure-of-arrays batch (SSV_MEM_HOST) as a BAM file (BGZF, deflate level 1, blocks compressed in parallel).
+/* Tooling: write a structure-of-arrays batch (SSV_MEM_HOST) as a BAM file (BGZF, deflate level 1 - SSV_BGZF_LEVEL in the environment picks another -,
+ * records serialised and blocks compressed by all host threads).
  * Records without shipped bases get l_qseq 'A's with quality 30; read names are "<prefix><index>".  append != 0 continues a file
  * started by an earlier call (the header is written only when append == 0); finish != 0 writes the BGZF end-of-file block. */
 int ssvh_bam_write_batch(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,

@@ -24,6 +24,7 @@
 #include "table3_kernels.h"
 #include "tile_sort.h"
 #include "common.h"
+#include "cpus.h"
 #include "getsv_kernels.h"
 #include "radix_sort.h"
 #include "scan.h"
@@ -1164,7 +1165,7 @@ int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
 	if (n == 0 || T.expanded) { if (n) table_expanded_view(T, t); t->support_sum = T.support_sum; return SSV_OK; }
 	T.x_tid.resize((size_t)n); T.x_side.resize((size_t)n); T.x_support.resize((size_t)n); T.x_ll.resize((size_t)n); T.x_lr.resize((size_t)n); T.x_qmiss.resize((size_t)n);
 	T.x_ncig.resize((size_t)n); T.x_stroff.resize((size_t)n); T.x_cigoff.resize((size_t)n);
-	const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(n_threads > 0 ? n_threads : (int32_t)std::thread::hardware_concurrency()), 64, n / 32768 + 1}));
+	const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(n_threads > 0 ? n_threads : (int32_t)effective_cpus()), 64, n / 32768 + 1}));
 	const ssv_table_run *runs = reinterpret_cast<const ssv_table_run *>(T.h_runs.p);
 	const int64_t n_runs = T.n_runs;
 	std::vector<uint64_t> part_str((size_t)nt + 1, 0), part_cig((size_t)nt + 1, 0);

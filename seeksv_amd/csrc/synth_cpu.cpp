@@ -49,6 +49,20 @@ int ssvs_fill(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n
 	return 0;
 }
 
+// packed bases + qualities of EVERY record [g0, g0 + n), (read_len + 1) / 2 + read_len bytes each, one after the other: what a BAM file of the
+// sample holds (bench.py's file leg).  A soft-clipped record's bytes are the ones ssvs_fill ships for it; the others read the reference
+// at their position with the same 0.2 % substitutions and the same quality distribution ({2, 11, 25, 37, 40}).
+int ssvs_fill_seq_all(const sy_config *cfg, const sy_breakend *be, int64_t g0, int64_t n, uint8_t *seqqual)
+{
+	const size_t entry = (size_t)((cfg->read_len + 1) / 2 + cfg->read_len);
+	for (int64_t i = 0; i < n; ++i) {
+		sy_record r;
+		sy_decide(cfg, be, g0 + i, &r);
+		sy_fill_seq(cfg, be, g0 + i, &r, seqqual + (size_t)i * entry);
+	}
+	return 0;
+}
+
 // reference bases of a contig as ASCII (FASTA export of the hash-generated genome; golden generation only)
 int ssvs_ref_bases(const sy_config *cfg, int32_t tid, int64_t start, int64_t n, char *out)
 {

@@ -117,16 +117,20 @@ def write_bam(path, names, lens, batches, qname_prefix="s"):
     nb = (C.c_char_p * max(n, 1))(*[s.encode() for s in names])
     lb = (C.c_int32 * max(n, 1))(*[int(x) for x in lens])
     first = 0
-    batches = list(batches)
-    if not batches:
+    it = iter(batches)           # streamed: a batch is written (and may be freed) before the next one is asked for
+    cur = next(it, None)
+    if cur is None:
         assert lib.ssvh_bam_write_batch(path.encode(), nb, lb, n, None, qname_prefix.encode(), 0, 0, 1) == 0
         return
-    for i, b in enumerate(batches):
-        bb, keep = _abi.make_batch(b)
-        rc = lib.ssvh_bam_write_batch(path.encode(), nb, lb, n, C.byref(bb), qname_prefix.encode(), first, int(i > 0), int(i == len(batches) - 1))
+    i = 0
+    while cur is not None:
+        nxt = next(it, None)
+        bb, keep = _abi.make_batch(cur)
+        rc = lib.ssvh_bam_write_batch(path.encode(), nb, lb, n, C.byref(bb), qname_prefix.encode(), first, int(i > 0), int(nxt is None))
         if rc != 0:
             raise IOError(lib.ssvh_last_error().decode())
         first += bb.n
+        cur, i = nxt, i + 1
 
 
 def read_bam(path, batch_records=1 << 20):

@@ -3,6 +3,10 @@
 // Replaces, for the hot path, what the reference gets from samtools-0.1.16's libbam below its
 // record loops: samopen()/samread() (sam/sam.h:59,73) and the bam1_core_t accessors
 // (sam/bam.h:169-255).  Own implementation from the SAM/BAM specification; no libbam here.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../csrc/cpus.h"
 #include "seeksv_host.h"
 
 #include <zlib.h>
@@ -92,7 +96,7 @@ private:
 static int host_threads()
 {
 	const char *e = getenv("SSV_HOST_THREADS");
-	int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+	int n = e ? atoi(e) : ssv::effective_cpus();
 	if (n < 1) n = 1;
 	return n > 64 ? 64 : n;
 }
@@ -105,7 +109,8 @@ static Pool &pool() // the reading side (inflate + decode); may run on the read-
 
 static Pool &wpool() // the writing side (deflate), so that a read-ahead in flight and an output writer do not queue behind each other
 {
-	static Pool p(host_threads() - 1);
+	// SSV_WRITE_THREADS: beyond the readers' cap of 64 (writing a large BAM at deflate level 6 scales with every core of the box)
+	static Pool p([] { const char *e = getenv("SSV_WRITE_THREADS"); const int n = e ? atoi(e) : host_threads(); return (n < 1 ? 1 : n > 1024 ? 1024 : n) - 1; }());
 	return p;
 }
 
@@ -548,30 +553,98 @@ int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, ui
 	return 0;
 }
 
+// The file's bytes as they are - BGZF headers and trailers included - go into dst in large pieces, every piece read by all host threads at
+// once (pread into the caller's buffer, usually page-locked); the block table is then read off the headers where they lie in dst
+// (c_off = where a block's deflate payload starts inside dst).  A block at a time through stdio (four calls per block) fed the device
+// decoder at 2.8 GB/s - a fifth of what it inflates; the file's pages are in the page cache or on NVMe, and many readers are what both want.
 int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes)
 {
 	g_err.clear();
-	size_t used = 0;
+	*n_blocks = 0; *n_bytes = 0;
+	b->raw_limit = UINT64_MAX;
+	if (b->z.eof) return 0;
+	const int fd = fileno(b->z.fp);
+	struct stat st;
+	if (fstat(fd, &st) != 0) { g_err = "cannot stat the BAM file"; return -1; }
+	const uint64_t file_size = (uint64_t)st.st_size;
+	const long at0 = ftell(b->z.fp);
+	if (at0 < 0) { g_err = "cannot tell the file position"; return -1; }
+	uint8_t *d = static_cast<uint8_t *>(dst);
+	const size_t PIECE = (size_t)256 << 20, SLICE = (size_t)4 << 20;
+	size_t have = 0;      // bytes of the file (from at0) that are in dst
+	size_t p = 0;         // bytes of dst that whole, accepted blocks cover
 	uint64_t inflated = 0;
 	int64_t n = 0;
-	b->raw_limit = UINT64_MAX;
-	while (n < max_blocks && !b->z.eof) {
-		uint32_t payload = 0, isize = 0;
-		const long at = ftell(b->z.fp);
-		if (b->raw_end_coff >= 0 && (at > b->raw_end_coff || (at == b->raw_end_coff && b->raw_end_uoff == 0))) { b->z.eof = true; if (b->raw_limit == UINT64_MAX) b->raw_limit = inflated; break; } // the range ends before this block
-		int rc = b->z.read_block_raw((uint8_t *)dst + used, dst_bytes - used, &payload, &isize);
-		if (rc < 0) return -1;
-		if (rc == 0 || rc == 2) break;
-		if (n > 0 && inflated + isize > max_inflated) { fseek(b->z.fp, at, SEEK_SET); break; }
-		if (isize == 0) continue; // empty blocks (the EOF marker) carry nothing
-		if (isize > 65536) { g_err = "BGZF block that claims to inflate to more than 64 KB"; return -1; }
-		blocks[n].c_off = used; blocks[n].c_len = payload; blocks[n].u_len = isize;
-		if (b->raw_end_coff >= 0 && at == b->raw_end_coff) { b->raw_limit = inflated + b->raw_end_uoff; b->z.eof = true; } // the range ends inside this block
-		used += payload; inflated += isize;
-		++n;
+	bool stop = false, range_done = false;
+	while (!stop) {
+		// more of the file (leave 8 spare bytes in dst: the device bit reader looks 4 bytes past a payload)
+		const uint64_t left_in_file = file_size - ((uint64_t)at0 + have);
+		size_t want = (size_t)std::min<uint64_t>({(uint64_t)PIECE, left_in_file, dst_bytes > have + 8 ? (uint64_t)(dst_bytes - have - 8) : 0});
+		if (b->raw_end_coff >= 0) { // a range of the file: nothing behind the block its last record lies in is needed
+			const uint64_t last_needed = (uint64_t)b->raw_end_coff + 65536 + 1024;
+			if ((uint64_t)at0 + have + want > last_needed) want = (uint64_t)at0 + have < last_needed ? (size_t)(last_needed - (uint64_t)at0 - have) : 0;
+		}
+		if (want) {
+			const int ns = (int)((want + SLICE - 1) / SLICE);
+			std::vector<int> ok((size_t)ns, 1);
+			pool().run(ns, [&](int i) {
+				size_t off = (size_t)i * SLICE;
+				const size_t end = std::min(want, off + SLICE);
+				while (off < end) {
+					const ssize_t got = pread(fd, d + have + off, end - off, (off_t)((uint64_t)at0 + have + off));
+					if (got <= 0) { ok[(size_t)i] = 0; return; }
+					off += (size_t)got;
+				}
+			});
+			for (int v : ok) if (!v) { g_err = "read error on the BAM file"; b->z.eof = true; return -1; }
+			have += want;
+		}
+		// the blocks that are whole in dst
+		for (;;) {
+			if (n >= max_blocks) { stop = true; break; }
+			const uint64_t at = (uint64_t)at0 + p;
+			if (b->raw_end_coff >= 0 && ((long)at > b->raw_end_coff || ((long)at == b->raw_end_coff && b->raw_end_uoff == 0))) { // the range ends before this block
+				if (b->raw_limit == UINT64_MAX) b->raw_limit = inflated;
+				range_done = stop = true; break;
+			}
+			if (p == have && (uint64_t)at0 + have == file_size) { range_done = stop = true; break; } // end of the file
+			if (p + 18 > have) break;
+			const uint8_t *h = d + p;
+			if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { g_err = "not a BGZF block"; b->z.eof = true; return -1; }
+			const unsigned xlen = h[10] | (h[11] << 8);
+			if (p + 12 + xlen > have) break;
+			int bsize = -1;
+			for (size_t off = 0; off + 4 <= xlen;) {
+				const unsigned slen = h[12 + off + 2] | (h[12 + off + 3] << 8);
+				if (off + 4 + slen > xlen) break; // a subfield that runs past the extra field: malformed, stop here
+				if (h[12 + off] == 'B' && h[12 + off + 1] == 'C' && slen == 2) bsize = h[12 + off + 4] | (h[12 + off + 5] << 8);
+				off += 4 + slen;
+			}
+			if (bsize < 0) { g_err = "BGZF block without BC field"; b->z.eof = true; return -1; }
+			if ((size_t)bsize + 1 < 12 + (size_t)xlen + 8) { g_err = "bad BGZF block size"; b->z.eof = true; return -1; }
+			if (p + (size_t)bsize + 1 > have) break; // the block's tail is not in dst yet
+			uint32_t isize; memcpy(&isize, h + bsize + 1 - 4, 4);
+			if (isize > 65536) { g_err = "BGZF block that claims to inflate to more than 64 KB"; b->z.eof = true; return -1; }
+			if (n > 0 && inflated + isize > max_inflated) { stop = true; break; }
+			if (isize != 0) { // (empty blocks - the EOF marker - carry nothing)
+				blocks[n].c_off = p + 12 + xlen; blocks[n].c_len = (uint32_t)((size_t)bsize + 1 - 12 - xlen - 8); blocks[n].u_len = isize;
+				if (b->raw_end_coff >= 0 && (long)at == b->raw_end_coff) { b->raw_limit = inflated + b->raw_end_uoff; range_done = true; } // the range ends inside this block
+				inflated += isize;
+				++n;
+			}
+			p += (size_t)bsize + 1;
+			if (range_done) { stop = true; break; }
+		}
+		if (stop) break;
+		if (want == 0) { // nothing more can be read, and the next block is not whole
+			if ((uint64_t)at0 + have == file_size && p < have) { g_err = "truncated BGZF block"; b->z.eof = true; return -1; }
+			if (n == 0 && dst_bytes < 65536 + 1024) { g_err = "buffer smaller than one BGZF block"; return -1; }
+			break; // dst is full
+		}
 	}
-	if (n == 0 && !b->z.eof && used == 0 && dst_bytes < 65536 + 8) { g_err = "buffer smaller than one BGZF block"; return -1; }
-	*n_blocks = n; *n_bytes = used;
+	if (fseek(b->z.fp, (long)((uint64_t)at0 + p), SEEK_SET) != 0) { g_err = "cannot seek"; return -1; }
+	if (range_done) b->z.eof = true;
+	*n_blocks = n; *n_bytes = p;
 	return 0;
 }
 
@@ -843,23 +916,41 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 
 // ---- BAM writer (tooling) ----
 
+// deflate level of the BAM writer: 1 (fast; the CLI's clip.bam and the tests' fixtures) unless SSV_BGZF_LEVEL says otherwise (bench.py's file leg
+// writes level 6, samtools' default: real BAM files are what that leg stands for)
+static int bgzf_level()
+{
+	const char *e = getenv("SSV_BGZF_LEVEL");
+	const int l = e ? atoi(e) : 1;
+	return l < 0 ? 0 : l > 9 ? 9 : l;
+}
+
 static void bgzf_compress_blocks(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out)
 {
 	const size_t BS = 0xff00;
 	const size_t nb = (raw.size() + BS - 1) / BS;
 	std::vector<std::vector<uint8_t>> comp(nb);
+	const int level = bgzf_level();
 	wpool().run((int)nb, [&](int i) {
 		const size_t off = (size_t)i * BS, len = std::min(BS, raw.size() - off);
 		std::vector<uint8_t> &c = comp[(size_t)i];
 		c.resize(len + 1024);
-		z_stream zs;
-		memset(&zs, 0, sizeof(zs));
-		deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+		// one deflate state per thread, reset between blocks: deflateInit2 allocates ~270 KB in pieces that malloc serves by mmap, and a few
+		// hundred threads mapping and unmapping at once queue on the process's address-space lock (the writer ran at 1.4 M records/s whatever
+		// the thread count)
+		struct Deflater { z_stream zs; int level = -1; ~Deflater() { if (level >= 0) deflateEnd(&zs); } };
+		static thread_local Deflater D;
+		if (D.level != level) {
+			if (D.level >= 0) deflateEnd(&D.zs);
+			memset(&D.zs, 0, sizeof(D.zs));
+			deflateInit2(&D.zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+			D.level = level;
+		} else deflateReset(&D.zs);
+		z_stream &zs = D.zs;
 		zs.next_in = const_cast<uint8_t *>(raw.data() + off); zs.avail_in = (uInt)len;
 		zs.next_out = c.data() + 18; zs.avail_out = (uInt)(c.size() - 18 - 8);
 		deflate(&zs, Z_FINISH);
 		size_t clen = zs.total_out;
-		deflateEnd(&zs);
 		const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0};
 		memcpy(c.data(), hdr, 16);
 		uint16_t bsize = (uint16_t)(clen + 25);
@@ -917,24 +1008,50 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 		bgzf_compress_blocks(raw, out);
 		raw.clear();
 	}
-	for (int64_t i = 0; b && i < b->n; ++i) {
-		std::string qn = qnames ? std::string(qnames[i]) : std::string(qname_prefix ? qname_prefix : "r") + std::to_string(first_index + i);
-		const int lq = b->l_qseq[i], nc = b->n_cigar[i];
-		const uint32_t *cig = b->cigar + b->cigar_off[i];
-		int span = 0;
-		for (int k = 0; k < nc; ++k) { unsigned op = cig[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += (int)(cig[k] >> 4); }
-		const int32_t pos = b->pos[i];
-		const int bin = pos >= 0 ? reg2bin(pos, pos + (span > 0 ? span : 1)) : 4680;
-		const size_t body = 32 + qn.size() + 1 + 4 * (size_t)nc + ((size_t)lq + 1) / 2 + (size_t)lq;
-		put32((int32_t)body); put32(b->tid[i]); put32(pos);
-		uint8_t hdr8[8] = {(uint8_t)(qn.size() + 1), b->mapq[i], (uint8_t)(bin & 255), (uint8_t)(bin >> 8), (uint8_t)(nc & 255), (uint8_t)(nc >> 8), (uint8_t)(b->flag[i] & 255), (uint8_t)(b->flag[i] >> 8)};
-		raw.insert(raw.end(), hdr8, hdr8 + 8);
-		put32(lq); put32(b->mtid[i]); put32(b->mpos[i]); put32(b->isize[i]);
-		raw.insert(raw.end(), qn.c_str(), qn.c_str() + qn.size() + 1);
-		raw.insert(raw.end(), (const uint8_t *)cig, (const uint8_t *)(cig + nc));
-		if (b->seq_off[i] != SSV_NO_SEQ) raw.insert(raw.end(), b->seqqual + b->seq_off[i], b->seqqual + b->seq_off[i] + ((size_t)lq + 1) / 2 + (size_t)lq);
-		else { raw.insert(raw.end(), ((size_t)lq + 1) / 2, (uint8_t)0x11); raw.insert(raw.end(), (size_t)lq, (uint8_t)30); }
-		if (raw.size() >= (size_t)64 << 20) { bgzf_compress_blocks(raw, out); raw.clear(); fwrite(out.data(), 1, out.size(), f); out.clear(); }
+	// the records: sizes, their running sum, then every host thread serialises its share of the records straight into place
+	const int64_t n = b ? b->n : 0;
+	if (n > 0) {
+		const std::string prefix = qname_prefix ? qname_prefix : "r";
+		auto digits = [](int64_t v) { size_t d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
+		std::vector<uint64_t> at((size_t)n + 1);
+		const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n / 4096, 256));
+		wpool().run(nt, [&](int w) {
+			for (int64_t i = n * w / nt, e = n * (w + 1) / nt; i < e; ++i) {
+				const size_t ln = qnames ? strlen(qnames[i]) : prefix.size() + digits(first_index + i);
+				const size_t lq = (size_t)b->l_qseq[i];
+				at[(size_t)i + 1] = 4 + 32 + ln + 1 + 4 * (size_t)b->n_cigar[i] + (lq + 1) / 2 + lq;
+			}
+		});
+		at[0] = 0;
+		for (int64_t i = 0; i < n; ++i) at[(size_t)i + 1] += at[(size_t)i];
+		raw.resize((size_t)at[(size_t)n]);
+		wpool().run(nt, [&](int w) {
+			char num[24];
+			for (int64_t i = n * w / nt, e = n * (w + 1) / nt; i < e; ++i) {
+				uint8_t *d = raw.data() + at[(size_t)i];
+				const int lq = b->l_qseq[i], nc = b->n_cigar[i];
+				const uint32_t *cig = b->cigar + b->cigar_off[i];
+				int span = 0;
+				for (int k = 0; k < nc; ++k) { unsigned op = cig[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += (int)(cig[k] >> 4); }
+				const int32_t pos = b->pos[i];
+				const int bin = pos >= 0 ? reg2bin(pos, pos + (span > 0 ? span : 1)) : 4680;
+				const char *qn; size_t ln;
+				std::string tmp;
+				if (qnames) { qn = qnames[i]; ln = strlen(qn); }
+				else { tmp = prefix; tmp.append(num, (size_t)snprintf(num, sizeof(num), "%lld", (long long)(first_index + i))); qn = tmp.c_str(); ln = tmp.size(); }
+				const int32_t body = (int32_t)(at[(size_t)i + 1] - at[(size_t)i] - 4);
+				auto w32 = [&](int32_t v) { memcpy(d, &v, 4); d += 4; };
+				w32(body); w32(b->tid[i]); w32(pos);
+				const uint8_t hdr8[8] = {(uint8_t)(ln + 1), b->mapq[i], (uint8_t)(bin & 255), (uint8_t)(bin >> 8), (uint8_t)(nc & 255), (uint8_t)(nc >> 8), (uint8_t)(b->flag[i] & 255), (uint8_t)(b->flag[i] >> 8)};
+				memcpy(d, hdr8, 8); d += 8;
+				w32(lq); w32(b->mtid[i]); w32(b->mpos[i]); w32(b->isize[i]);
+				memcpy(d, qn, ln + 1); d += ln + 1;
+				memcpy(d, cig, 4 * (size_t)nc); d += 4 * (size_t)nc;
+				const size_t sq = ((size_t)lq + 1) / 2 + (size_t)lq;
+				if (b->seq_off[i] != SSV_NO_SEQ) memcpy(d, b->seqqual + b->seq_off[i], sq);
+				else { memset(d, 0x11, ((size_t)lq + 1) / 2); memset(d + ((size_t)lq + 1) / 2, 30, (size_t)lq); } // no bases shipped: l_qseq 'A's of quality 30
+			}
+		});
 	}
 	if (!raw.empty()) bgzf_compress_blocks(raw, out);
 	if (finish) {

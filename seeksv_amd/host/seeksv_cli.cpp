@@ -20,6 +20,8 @@
 #include <fstream>
 #include <iostream>
 #include <deque>
+#include <unistd.h>
+#include "../csrc/cpus.h"
 #include <map>
 #include <sstream>
 #include <string>
@@ -65,6 +67,16 @@ struct PhaseTimer {
 {
 	cerr << msg << endl;
 	exit(1);
+}
+
+// The end of a command: every output file is closed by now.  Handing multi-GB device buffers and page-locked staging memory back one
+// hipFree / hipHostFree at a time takes 0.3-0.4 s; the process is about to end and the driver reclaims all of it at once, so the context is
+// only drained (SSV_CLEAN_EXIT=1 - sanitizer and leak-check runs - destroys it the long way, and main() returns instead of _exit).
+static const bool kCleanExit = getenv("SSV_CLEAN_EXIT") != nullptr;
+static void release_ctx(ssv_ctx *ctx)
+{
+	if (kCleanExit) ssv_ctx_destroy(ctx);
+	else ssv_sync(ctx);
 }
 
 [[noreturn]] static void usage_top()
@@ -283,9 +295,9 @@ struct BatchSource {
 			if (reader_running) { reader.join(); reader_running = false; }
 			const int k = cur;
 			if (!read_err[k].empty()) die("[seeksv] " + read_err[k]);
-			// payload + 18-byte header + 8-byte trailer per block, 28 bytes for the empty end-of-file block: when nothing can be left, do not
-			// start (and allocate a second staging buffer for) another read
-			consumed += n_bytes[k] + 26ull * (uint64_t)n_blocks[k];
+			// (the chunk holds the file's bytes as they are, block headers and trailers included) when nothing but the 28-byte end-of-file block can
+			// be left, do not start (and allocate a second staging buffer for) another read
+			consumed += n_bytes[k];
 			const bool last_chunk = n_blocks[k] == 0 || (file_bytes && consumed + 28 >= file_bytes);
 			if (!last_chunk) { cur ^= 1; start_read(cur); } // the other buffer fills while this chunk is decoded
 			if (limit[k] != UINT64_MAX) ssv_bamdec_limit(ctx, limit[k]);
@@ -513,7 +525,7 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 			cerr << "Output merged soft-clipped reads of " << (name ? name : "") << endl;
 			for (; k_end < t.n_clusters && t.tid[k_end] == tid; ++k_end) {}
 		}
-		const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, k_end / 4096}));
+		const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 32, k_end / 4096}));
 		vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
 		auto format_range = [&](int w) {
 			const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
@@ -572,7 +584,7 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
 	pt.lap("gzip");
 	src.close();
-	ssv_ctx_destroy(ctx);
+	release_ctx(ctx);
 	pt.lap("teardown");
 	return 0;
 }
@@ -1044,7 +1056,7 @@ static int cmd_getsv(int argc, char **argv)
 	if (!foutuq) die("Cannot open file " + clip_unmap_fq_file);
 	pt.lap("fold+output");
 	ssvh_plan_destroy(plan);
-	ssv_ctx_destroy(ctx);
+	release_ctx(ctx);
 	ssvh_bam_close(bam);
 	pt.lap("teardown");
 	return 0;
@@ -1332,7 +1344,11 @@ int main(int argc, char **argv)
 	}
 	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else if (cmd == "getsv") usage_getsv(); else if (cmd == "realign") usage_realign(); else usage_somatic(); }
 	optind = 1; // like SelectStep (seeksv.cpp:444-452): the sub-command becomes argv[0]
-	if (cmd == "somatic") return cmd_somatic(argc - 1, argv + 1);
-	if (cmd == "realign") return cmd_realign(argc - 1, argv + 1);
-	return cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
+	int rc;
+	if (cmd == "somatic") rc = cmd_somatic(argc - 1, argv + 1);
+	else if (cmd == "realign") rc = cmd_realign(argc - 1, argv + 1);
+	else rc = cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
+	if (kCleanExit) return rc;
+	cout.flush(); cerr.flush(); fflush(nullptr);
+	_exit(rc); // (see release_ctx)
 }

@@ -44,6 +44,8 @@ def _lib(gpu):
         lib.ssvs_plan.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64, V, V, V, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.ssvs_fill.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64] + [V] * 15
         lib.ssvs_last_error.restype = C.c_char_p
+        if not gpu:
+            lib.ssvs_fill_seq_all.argtypes = [C.POINTER(SyConfig), V, C.c_int64, C.c_int64, V]
         _synth_libs[name] = lib
     return _synth_libs[name]
 
@@ -216,8 +218,10 @@ class Workload:
         return out, off
 
     # ---- record generation ----
-    def generate_host(self, g0, n, with_rec=False):
-        """records [g0, g0+n) as a dict of numpy arrays (a SSV_MEM_HOST batch).  with_rec: also the records' 64-byte lines (ssv_record)."""
+    def generate_host(self, g0, n, with_rec=False, all_seq=False):
+        """records [g0, g0+n) as a dict of numpy arrays (a SSV_MEM_HOST batch).  with_rec: also the records' 64-byte lines (ssv_record).
+        all_seq: packed bases and qualities for EVERY record (what a BAM file holds: reference bases at the record's position with 0.2 %
+        substitutions, qualities from {2, 11, 25, 37, 40}) instead of for the soft-clipped ones only - the writer of bench.py's file leg."""
         lib = _lib(False)
         be = self.breakends
         bep = be.ctypes.data if len(be) else None
@@ -237,6 +241,12 @@ class Workload:
                       p(rec) if with_rec else None, p(a["cigar_ends"]))
         if with_rec:
             a["rec"] = rec
+        if all_seq:
+            entry = (self.read_len + 1) // 2 + self.read_len
+            a["seqqual"] = np.empty(n * entry + 16, np.uint8)
+            a["seq_off"] = (np.arange(n, dtype=np.uint64) * np.uint64(entry))
+            lib.ssvs_fill_seq_all(C.byref(self.cfg), bep, C.c_int64(g0), C.c_int64(n), p(a["seqqual"]))
+            a["seqqual_bytes"] = n * entry
         a["xc"] = None
         a["max_ref_span"] = self.max_ref_span
         return a
