@@ -139,6 +139,18 @@ int ssv_host_alloc(size_t bytes, void **p);
 int ssv_host_free(void *p);
 int ssv_batch_prefetch(ssv_ctx *ctx, const ssv_batch_t *b);
 
+/* ---- batches that stay: one decode of the file for every pass ---------------------------------- */
+/*
+ * The reference reads the BAM once per command (getclip: clip_reads.h:410; getsv: cluster.cpp:48 for the insert sizes, getsv.cpp:1067 and
+ * bam2depth.h:29 through the index) because each command is a process of its own.  What the passes look at is 80 bytes a record - the
+ * hot columns, one 64-byte line, the CIGARs, the bases of the soft-clipped reads - so a 30x genome (617 M records) stays resident in 50 GB
+ * of HBM: ssv_batch_retain copies a device batch (the decoder's, valid only until the next decode) into device memory of its own -
+ * SSV_MEM_DEVICE | SSV_MEM_PERSISTENT, record lines built once - and every later pass scans it in place: the file is inflated once.
+ * ssv_batch_release frees it.  (`seeksv run` and bench.py's file leg work this way.)
+ */
+int ssv_batch_retain(ssv_ctx *ctx, const ssv_batch_t *device_batch, ssv_batch_t *out);
+int ssv_batch_release(ssv_ctx *ctx, ssv_batch_t *retained);
+
 /* ---- getclip: replaces InputBamOutputReads<>'s record loop (clip_reads.h:363, 410-446) ------ */
 
 typedef struct {

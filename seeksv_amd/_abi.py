@@ -259,6 +259,8 @@ def hip_lib():
         lib.ssv_clip_begin.argtypes = [V, C.POINTER(ClipParams)]
         lib.ssv_clip_scan.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_clip_scan_range.argtypes = [V, C.POINTER(Batch), C.c_int64, C.c_int64]
+        lib.ssv_batch_retain.argtypes = [V, C.POINTER(Batch), C.POINTER(Batch)]
+        lib.ssv_batch_release.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_clip_event_count.argtypes = [V, C.POINTER(C.c_int64)]
         lib.ssv_clip_cluster.argtypes = [V, C.POINTER(HipClusterTable)]
         lib.ssv_clip_table_format.argtypes = [V, C.c_int]

@@ -728,6 +728,48 @@ int ssv_clip_scan_range(ssv_ctx *c, const ssv_batch_t *b, int64_t rec_begin, int
 	return SSV_OK;
 }
 
+// ---- a batch kept: the decoded records of a file stay in HBM for the passes that follow ----
+int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
+{
+	if (!c || !b || !out) return SSV_E_ARG;
+	HIPCHECK(c, hipSetDevice(c->device));
+	if ((b->mem & ~(int)SSV_MEM_PERSISTENT) != SSV_MEM_DEVICE) { c->err = "ssv_batch_retain takes device batches"; return SSV_E_ARG; }
+	DevBatch d;
+	CHECK(stage_batch(c, b, d)); // (builds the record lines when the batch has none)
+	const size_t n = (size_t)b->n;
+	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t sz[7] = {up(n * 4 + 16), up(n * 4 + 16), up(n * 2 + 16), up(n + 16), up(n * sizeof(ssv_record) + 64), up((size_t)b->n_cigar_total * 4 + 64), up((size_t)b->seqqual_bytes + 64)};
+	size_t off[8]; off[0] = 0;
+	for (int k = 0; k < 7; ++k) off[k + 1] = off[k] + sz[k];
+	uint8_t *slab = nullptr;
+	HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&slab), off[7]));
+	const void *src[7] = {d.tid, d.pos, d.n_cigar, d.ends, d.rec, d.cigar, d.seqqual};
+	const size_t bytes[7] = {n * 4, n * 4, n * 2, n, n * sizeof(ssv_record), (size_t)b->n_cigar_total * 4, (size_t)b->seqqual_bytes};
+	if (!d.ends && n) { // no cigar_ends column: built from the lines, straight into the slab
+		k_build_ends<<<grid_for(d.n, BLOCK), BLOCK, 0, c->st>>>(d, slab + off[3]);
+		HIPCHECK(c, hipGetLastError());
+	}
+	for (int k = 0; k < 7; ++k) if (src[k] && bytes[k]) HIPCHECK(c, hipMemcpyAsync(slab + off[k], src[k], bytes[k], hipMemcpyDeviceToDevice, c->st));
+	HIPCHECK(c, hipStreamSynchronize(c->st)); // the source (the decoder's buffers) may be overwritten by the next decode
+	memset(out, 0, sizeof(*out));
+	out->n = b->n; out->mem = SSV_MEM_DEVICE | SSV_MEM_PERSISTENT; out->max_ref_span = b->max_ref_span;
+	out->tid = reinterpret_cast<const int32_t *>(slab + off[0]); out->pos = reinterpret_cast<const int32_t *>(slab + off[1]); out->n_cigar = reinterpret_cast<const uint16_t *>(slab + off[2]);
+	out->cigar_ends = slab + off[3]; out->rec = reinterpret_cast<const ssv_record *>(slab + off[4]); out->cigar = reinterpret_cast<const uint32_t *>(slab + off[5]);
+	out->seqqual = slab + off[6]; out->n_cigar_total = b->n_cigar_total; out->seqqual_bytes = b->seqqual_bytes;
+	return SSV_OK;
+}
+
+int ssv_batch_release(ssv_ctx *c, ssv_batch_t *b)
+{
+	if (!c || !b) return SSV_E_ARG;
+	if (b->mem != (SSV_MEM_DEVICE | SSV_MEM_PERSISTENT) || !b->tid) { c->err = "not a batch of ssv_batch_retain"; return SSV_E_ARG; }
+	HIPCHECK(c, hipSetDevice(c->device));
+	HIPCHECK(c, hipStreamSynchronize(c->st));
+	HIPCHECK(c, hipFree(const_cast<int32_t *>(b->tid))); // the slab starts with the tid column
+	memset(b, 0, sizeof(*b));
+	return SSV_OK;
+}
+
 int ssv_clip_event_count(ssv_ctx *c, int64_t *n)
 {
 	if (!c || !n) return SSV_E_ARG;

@@ -119,6 +119,16 @@ class Context:
             d["unmapped"] = unm
             yield b, d
 
+    def batch_retain(self, dev_batch):
+        """a device batch (the decoder's: valid until the next decode) copied into device memory of its own; -> Batch (SSV_MEM_DEVICE |
+        SSV_MEM_PERSISTENT), to be given back with batch_release"""
+        out = _abi.Batch()
+        self._check(self._lib.ssv_batch_retain(self._h, C.byref(dev_batch), C.byref(out)), "ssv_batch_retain")
+        return out
+
+    def batch_release(self, batch):
+        self._check(self._lib.ssv_batch_release(self._h, C.byref(batch)), "ssv_batch_release")
+
     def batch_to_host(self, dev_batch):
         """Device batch -> dict of owned numpy arrays (tests)."""
         h = _abi.Batch()

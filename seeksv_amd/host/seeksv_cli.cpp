@@ -73,11 +73,7 @@ struct PhaseTimer {
 // hipFree / hipHostFree at a time takes 0.3-0.4 s; the process is about to end and the driver reclaims all of it at once, so the context is
 // only drained (SSV_CLEAN_EXIT=1 - sanitizer and leak-check runs - destroys it the long way, and main() returns instead of _exit).
 static const bool kCleanExit = getenv("SSV_CLEAN_EXIT") != nullptr;
-static void release_ctx(ssv_ctx *ctx)
-{
-	if (kCleanExit) ssv_ctx_destroy(ctx);
-	else ssv_sync(ctx);
-}
+static void release_ctx(ssv_ctx *ctx);
 
 [[noreturn]] static void usage_top()
 {
@@ -87,7 +83,8 @@ static void release_ctx(ssv_ctx *ctx)
 	     << "Command: getclip\tget soft-clipped reads\n"
 	     << "         getsv  \tget final sv\n"
 	     << "         somatic\tget somatic sv\n"
-	     << "         realign\talign the clipped sequences of getclip to a reference (stand-in for the pipeline's external `bwa mem` step)" << endl;
+	     << "         realign\talign the clipped sequences of getclip to a reference (stand-in for the pipeline's external `bwa mem` step)\n"
+	     << "         run    \tgetclip + realign + getsv in one process: the BAM is decoded once and stays in GPU memory" << endl;
 	exit(1);
 }
 
@@ -213,10 +210,39 @@ template <class Side, class Scan> static string pump_host_batches(ssvh_bam *rb, 
 	return err;
 }
 
+// `seeksv run`: one process, one context, one decode of the BAM.  While getclip scans the file, every decoded batch is copied into device
+// memory of its own (ssv_batch_retain: hot columns, one 64-byte line per record, CIGARs, bases of the soft-clipped reads: 80 B/record -
+// a 30x genome is 50 GB of the GPU's 288); the getsv passes of the same process then find the file's records there instead of reading,
+// inflating and decoding the file a second and third time (the reference does: cluster.cpp:48, getsv.cpp:1067, bam2depth.h:29).
+struct ResidentBam {
+	string path;                 // the file these are the records of
+	ssv_ctx *ctx = nullptr;      // the context every command of the process shares
+	bool collect = false;        // getclip keeps what it decodes
+	vector<ssv_batch_t> batches; // in file order
+};
+static ResidentBam g_resident;
+
+static void release_ctx(ssv_ctx *ctx)
+{
+	if (ctx == g_resident.ctx) return; // shared by the commands of `seeksv run`, which lets go of it at its end
+	if (kCleanExit) ssv_ctx_destroy(ctx);
+	else ssv_sync(ctx);
+}
+
+static ssv_ctx *acquire_ctx(int device)
+{
+	if (g_resident.ctx) return g_resident.ctx;
+	ssv_ctx *ctx = nullptr;
+	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+	return ctx;
+}
+
 struct BatchSource {
 	ssvh_bam *bam = nullptr;
 	ssv_ctx *ctx = nullptr;
 	bool on_device = false;
+	bool resident = false;   // the records are in HBM already (g_resident)
+	size_t resident_next = 0;
 	// device mode
 	size_t stage_bytes = 0;
 	uint64_t chunk_inflated = 0;
@@ -243,6 +269,7 @@ struct BatchSource {
 	{
 		ctx = c; on_device = device_inflate;
 		if (ssvh_bam_open(path.c_str(), &bam) != 0) die(open_error);
+		if (!ranged && !g_resident.collect && g_resident.ctx == c && !g_resident.batches.empty() && path == g_resident.path) { resident = true; on_device = true; return; }
 		if (!on_device) {
 			if (ranged && ssvh_bam_set_range(bam, r_start_coff, r_start_uoff, r_end_coff, r_end_uoff) != 0) die(string("[seeksv] ") + ssvh_last_error());
 			use_pinned_batches(bam);
@@ -280,6 +307,11 @@ struct BatchSource {
 	// the next batch (valid until the following call); false at the end of the file
 	bool next(ssv_batch_t *b, int keep_all_seq)
 	{
+		if (resident) {
+			if (resident_next >= g_resident.batches.size()) return false;
+			*b = g_resident.batches[resident_next++];
+			return true;
+		}
 		if (!on_device) {
 			if (ssvh_bam_read_batch(bam, 1 << 22, keep_all_seq, b) != 0) die(string("[seeksv] ") + ssvh_last_error());
 			return b->n != 0;
@@ -491,8 +523,7 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	if (!fuout1.open(f_u1)) die("Cannot open file " + f_u1);
 	if (!fuout2.open(f_u2)) die("Cannot open file " + f_u2);
 
-	ssv_ctx *ctx = nullptr;
-	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+	ssv_ctx *ctx = acquire_ctx(device);
 	ssv_clip_params p;
 	memset(&p, 0, sizeof(p));
 	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
@@ -561,7 +592,12 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 		changes_of.emplace_back();
 		src.contig_changes(b, last_tid, [&](int64_t i, int32_t tid) { changes_of.back().emplace_back(i, tid); });
 		pt.lap("host_side_channel");
-	}, [&](const ssv_batch_t &b) {
+	}, [&](const ssv_batch_t &decoded) {
+		ssv_batch_t b = decoded;
+		if (g_resident.collect && g_resident.ctx == ctx) { // `seeksv run`: the batch stays in HBM for the getsv passes
+			if (ssv_batch_retain(ctx, &decoded, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			g_resident.batches.push_back(b);
+		}
 		int64_t lo = 0;
 		for (const auto &ch : changes_of.front()) {
 			pass_flushes.push_back(scan_last_tid); // the visit that ends here is flushed
@@ -863,8 +899,7 @@ static int cmd_getsv(int argc, char **argv)
 	pt.lap("junction_stage");
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file " + original_bam + "for reading.");
-	ssv_ctx *ctx = nullptr;
-	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+	ssv_ctx *ctx = acquire_ctx(device);
 
 	pt.lap("open+gpu_init");
 	int mean_insert_size = 0, deviation = 0;
@@ -1269,8 +1304,7 @@ static int cmd_realign(int argc, char **argv)
 	}
 	const int64_t n = (int64_t)seqs.size();
 	pt.lap("read fastq");
-	ssv_ctx *ctx = nullptr;
-	if (ssv_ctx_create(gpu, &ctx) != SSV_OK) die(string("[seeksv] GPU context: ") + ssv_last_error(nullptr));
+	ssv_ctx *ctx = acquire_ctx(gpu);
 	int64_t dropped = 0;
 	if (ssv_realign_index(ctx, words.data(), SSV_MEM_HOST, offs.back(), offs.data(), (int32_t)names.size(), &dropped) != SSV_OK) die(string("[seeksv] realign index: ") + ssv_last_error(ctx));
 	pt.lap("index");
@@ -1330,23 +1364,100 @@ static int cmd_realign(int argc, char **argv)
 	if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), lens.data(), (int32_t)names.size(), &b, qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
 	pt.lap("write bam");
 	cerr << "[seeksv realign] " << n << " clipped sequences, " << n_aligned << " aligned" << (dropped ? ", " + to_string(dropped) + " repetitive index positions dropped" : string()) << endl;
-	ssv_ctx_destroy(ctx);
+	ssv_realign_free(ctx);
+	release_ctx(ctx);
 	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// run: getclip -> realign -> getsv in one process (seeksv.cpp:128-329 + the pipeline's external aligner step, README.md:22-34)
+// ---------------------------------------------------------------------------------------------------------------------
+
+[[noreturn]] static void usage_run()
+{
+	cerr << "Usage: seeksv run [options] <input.sorted.bam> <reference fasta(.gz)> <output prefix>\n\n"
+	     << "The three steps of the pipeline in one process on one GPU: `getclip` (prefix.clip.gz, prefix.clip.fq.gz, prefix.unmapped_[12].fq.gz),\n"
+	     << "`realign` in the place of `bwa mem` (prefix.clip.bam), `getsv` (prefix.sv.txt, prefix.unmapped.clip.fq; filtered junctions on stdout).\n"
+	     << "Every file is what the three commands write one after the other; the BAM is read, inflated and decoded ONCE, on the GPU, and its\n"
+	     << "records stay in HBM for the getsv passes (80 bytes a record).\n\n"
+	     << "Options: -c <string>           options handed to getclip, e.g. -c \"-q 5 -s\"\n"
+	     << "         -v <string>           options handed to getsv, e.g. -v \"-b 5 -L 100\"\n"
+	     << "         -G <int>              GPU ordinal [0]" << endl;
+	exit(1);
+}
+
+static vector<string> split_words(const string &t)
+{
+	vector<string> w;
+	std::istringstream in(t);
+	for (string x; in >> x;) w.push_back(x);
+	return w;
+}
+
+static int cmd_run(int argc, char **argv)
+{
+	int c, device = 0;
+	string clip_opts, sv_opts;
+	while ((c = getopt(argc, argv, "c:v:G:")) >= 0) {
+		switch (c) {
+		case 'c': clip_opts = optarg; break;
+		case 'v': sv_opts = optarg; break;
+		case 'G': device = atoi(optarg); break;
+		default: usage_run();
+		}
+	}
+	if (argc != optind + 3) usage_run();
+	const string bam = argv[optind], fasta = argv[optind + 1], prefix = argv[optind + 2];
+	PhaseTimer pt;
+	g_resident.ctx = acquire_ctx(device);
+	g_resident.path = bam;
+	g_resident.collect = true;
+	pt.lap("run: gpu_init");
+	auto call = [&](int (*fn)(int, char **), vector<string> words) {
+		vector<char *> av;
+		for (auto &w : words) av.push_back(const_cast<char *>(w.c_str()));
+		av.push_back(nullptr);
+		optind = 1;
+		return fn((int)words.size(), av.data());
+	};
+	vector<string> a = {"getclip"};
+	for (auto &w : split_words(clip_opts)) a.push_back(w);
+	a.insert(a.end(), {"-Z", "-G", to_string(device), "-o", prefix, bam});
+	int rc = call(cmd_getclip, a);
+	g_resident.collect = false;
+	pt.lap("run: getclip (decode once, records kept in HBM)");
+	if (rc == 0) rc = call(cmd_realign, {"realign", "-G", to_string(device), fasta, prefix + ".clip.fq.gz", prefix + ".clip.bam"});
+	pt.lap("run: realign");
+	if (rc == 0) {
+		a = {"getsv"};
+		for (auto &w : split_words(sv_opts)) a.push_back(w);
+		a.insert(a.end(), {"-G", to_string(device), prefix + ".clip.bam", bam, prefix + ".clip.gz", prefix + ".sv.txt", prefix + ".unmapped.clip.fq"});
+		rc = call(cmd_getsv, a);
+	}
+	pt.lap("run: getsv (records in HBM)");
+	ssv_ctx *ctx = g_resident.ctx;
+	if (kCleanExit) {
+		for (auto &b : g_resident.batches) ssv_batch_release(ctx, &b);
+		g_resident.ctx = nullptr;
+		ssv_ctx_destroy(ctx);
+	} else ssv_sync(ctx);
+	return rc;
 }
 
 int main(int argc, char **argv)
 {
 	if (argc == 1) usage_top();
 	const string cmd = argv[1];
-	if (cmd != "getclip" && cmd != "getsv" && cmd != "somatic" && cmd != "realign") {
+	if (cmd != "getclip" && cmd != "getsv" && cmd != "somatic" && cmd != "realign" && cmd != "run") {
 		cerr << "[seeksv] unrecognized command '" << argv[1] << "'" << endl;
 		return 1;
 	}
-	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else if (cmd == "getsv") usage_getsv(); else if (cmd == "realign") usage_realign(); else usage_somatic(); }
+	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else if (cmd == "getsv") usage_getsv(); else if (cmd == "realign") usage_realign(); else if (cmd == "run") usage_run(); else usage_somatic(); }
 	optind = 1; // like SelectStep (seeksv.cpp:444-452): the sub-command becomes argv[0]
 	int rc;
 	if (cmd == "somatic") rc = cmd_somatic(argc - 1, argv + 1);
 	else if (cmd == "realign") rc = cmd_realign(argc - 1, argv + 1);
+	else if (cmd == "run") rc = cmd_run(argc - 1, argv + 1);
 	else rc = cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
 	if (kCleanExit) return rc;
 	cout.flush(); cerr.flush(); fflush(nullptr);

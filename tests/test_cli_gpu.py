@@ -214,3 +214,46 @@ def test_cli_realign_full_pipeline(tmp_path_factory, name):
     planted = {(j[0], j[1], j[2], j[3], j[4], j[5]) for j in w.junctions}
     found = {(c[0], int(c[1]), c[2], c[4], int(c[5]), c[6]) for c in got}
     assert len(found) == len(planted)
+
+
+@pytest.mark.parametrize("name", list(SYNTH_FULL))
+@pytest.mark.parametrize("opts", [[], ["-c", "-q 5 -t 0.85", "-v", "-b 2 -L 100 -q 10"]], ids=["defaults", "options"])
+def test_cli_run_equals_three_commands(tmp_path_factory, name, opts, inflate_mode):
+    """`seeksv run in.bam ref.fa prefix` (one process; the BAM inflated and decoded ONCE on the GPU, its records kept in HBM for the getsv
+    passes) writes, byte for byte, the files that `getclip`, `realign` and `getsv` write one after the other - and, under the default
+    options, the SV table the real reference makes from bwa mem's clip.bam (tests/golden/synth)."""
+    if inflate_mode != "device-inflate":
+        pytest.skip("`seeksv run` always decodes on the GPU")
+    from seeksv_amd import synth
+    bam, _, d = _synth_sample(tmp_path_factory, name, SYNTH_FULL[name])
+    w = synth.Workload(**SYNTH_FULL[name])
+    fa = str(d / "ref_run.fa")
+    with open(fa, "w") as f:
+        f.write(w.reference_fasta())
+    tag = "d" if not opts else "o"
+    clip_o = opts[1].split() if opts else []
+    sv_o = opts[3].split() if opts else []
+    a = str(d / f"three_{tag}")
+    r1 = subprocess.run([SEEKSV, "getclip"] + clip_o + ["-o", a, bam], capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stderr
+    r2 = subprocess.run([SEEKSV, "realign", fa, a + ".clip.fq.gz", a + ".clip.bam"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    r3 = subprocess.run([SEEKSV, "getsv"] + sv_o + [a + ".clip.bam", bam, a + ".clip.gz", a + ".sv.txt", a + ".unmapped.clip.fq"], capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stderr
+    b = str(d / f"one_{tag}")
+    r = subprocess.run([SEEKSV, "run"] + opts + [bam, fa, b], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for ext in (".clip.gz", ".clip.fq.gz", ".unmapped_1.fq.gz", ".unmapped_2.fq.gz"):
+        assert gzip.open(a + ext, "rb").read() == gzip.open(b + ext, "rb").read(), ext
+    for ext in (".sv.txt", ".unmapped.clip.fq"):
+        assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
+    with host.BamReader(a + ".clip.bam") as x, host.BamReader(b + ".clip.bam") as y:
+        ba, bb = x.read_batch(1 << 22, keep_all_seq=True), y.read_batch(1 << 22, keep_all_seq=True)
+        for k in ("tid", "pos", "flag", "mapq", "n_cigar", "l_qseq", "cigar"):
+            assert (ba[k] == bb[k]).all(), k
+    assert r.stdout == r3.stdout                                 # the filtered junctions
+    rows = [l.split("\t") for l in open(b + ".sv.txt").read().splitlines() if not l.startswith("@")]
+    assert len(rows) > 0
+    if not opts:
+        want = [l.split("\t") for l in G.read_text("synth", f"{name}.sv").splitlines() if not l.startswith("@")]
+        assert rows == want
