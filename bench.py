@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--no-cli-leg", action="store_true", help="skip cli_path (the `seeksv` binary as child processes on the file leg's BAM)")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
     ap.add_argument("--table-format", type=int, default=3, help="ssv_clip_table_format: 3 = the compact table (default), 2 = four-piece blocks with 4-bit bases, 0 = ASCII")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak (default): every GPU holds its own --depth sample, N GPUs = N x depth over the same genome.  "
+                    "strong = BASELINE config 4: ONE sample of --strong-depth (300x tumor WGS, 6.18 G records) range-partitioned N ways; refused where a rank's share does not fit its GPU")
+    ap.add_argument("--strong-depth", type=float, default=300.0, help="coverage of the one sample that --scaling strong splits over the GPUs")
     ap.add_argument("--no-overlap", action="store_true", help="collect every cluster table in its own step (no copy in flight while other kernels run); use under rocprofv3, which serialises dispatches of different streams")
     args = ap.parse_args()
 
@@ -96,11 +99,18 @@ def main():
     from seeksv_amd import host, shard, synth
     from seeksv_amd.device import Context
 
-    w = synth.Workload(genome_frac=args.genome_frac, depth=args.depth * world, n_sv=args.n_sv)
+    strong = args.scaling == "strong"
+    w = synth.Workload(genome_frac=args.genome_frac, depth=args.strong_depth if strong else args.depth * world, n_sv=args.n_sv)
     sp = shard.shard_plan(w, rank, world)
     t0 = time.time()
     n_scan = sp["own_hi_rec"] - sp["scan_lo_rec"]
     n_own = sp["own_hi_rec"] - sp["own_lo_rec"]
+    # a rank's records stay resident for the whole run: ~80 bytes each (hot columns 11, one 64-byte line, CIGAR 4, bases of the 1 % soft-clipped reads)
+    # plus the pass's events, tables and scratch; a batch holds fewer than 2^31 records (include/seeksv_hip.h)
+    hbm = torch.cuda.get_device_properties(local_rank).total_memory
+    if n_scan >= (1 << 31) - 64 or n_scan * 80.0 > 0.75 * hbm:
+        raise SystemExit(f"bench.py: a share of {n_scan} records ({n_scan * 80 / 1e9:.0f} GB resident) does not fit one GPU ({hbm / 1e9:.0f} GB, < 2^31 records per batch): "
+                         f"{'--scaling strong at ' + format(args.strong_depth, 'g') + 'x needs more GPUs (300x: 4 or 8) or a lower --strong-depth' if strong else 'lower --depth or --genome-frac'}")
     # the batch as the device decoder hands it over: hot columns (tid, pos, n_cigar), one 64-byte line per record with the cold fields, CIGARs,
     # packed bases + qualities of the soft-clipped records.  It stays resident and unchanged over the timed region (SSV_MEM_PERSISTENT):
     # clip events point at the reads' own bytes and the cluster table is cut straight out of them.
@@ -342,11 +352,12 @@ def main():
             "value": total_records * args.steps / dt,
             "unit": "records/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8 (fp64 match-rate compare)", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.depth:g}x-per-GPU WGS, 150 bp PE, 1% random soft clips, {len(w.junctions)} planted DEL/INV/TRA (VAF 0.5), "
-                                   f"genome_frac {args.genome_frac:g}, {n_own} records/GPU resident in HBM",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "i32/u8 (fp64 match-rate compare)", "data": "synthetic",
+            "config": {"workload": (f"synthetic {args.strong_depth:g}x WGS (BASELINE config 3/4), ONE sample range-partitioned over {world} GPU(s), " if strong else f"synthetic {args.depth:g}x-per-GPU WGS, ") +
+                                   f"150 bp PE, 1% random soft clips, {len(w.junctions)} planted DEL/INV/TRA (VAF 0.5), genome_frac {args.genome_frac:g}, {n_own} records/GPU resident in HBM",
                        "records_total": total_records, "records_per_gpu": n_own, "junctions": len(w.junctions), "parallelism": f"range-partition x{world}",
-                       "multi_gpu": "weak scaling: 30x per GPU over the same genome (N GPUs = 30N x), not BASELINE config 4's fixed 300x BAM split N ways",
+                       "multi_gpu": (f"strong scaling (--scaling strong): BASELINE config 4 - the fixed {args.strong_depth:g}x sample split {world} ways by reference interval, halo at the cuts, one all-gather" if strong else
+                                     "weak scaling (default): 30x per GPU over the same genome (N GPUs = 30N x); `--scaling strong` runs BASELINE config 4's fixed 300x sample split N ways"),
                        "batch_layout": "hot columns tid/pos/n_cigar + cigar_ends (a one-byte copy of the first and last CIGAR operation codes: the getclip stream reads it instead of n_cigar and applies the soft-clip test to every record) + one 64-byte line per record (ssv_record) + CIGARs + packed bases/qualities of soft-clipped records; SSV_MEM_PERSISTENT",
                        "host_cpus_bound_near_gpu": near_cpus, "generation_s": round(gen_s, 2)},
             "roofline": {"kernel": "path: all device kernels of one step (getclip + insert size + getsv passes; PCIe copy excluded)", "bound": "hbm",

@@ -271,6 +271,150 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restri
 	}
 }
 
+// ---- pass 2 with the block in LDS -----------------------------------------------------------------------------------------------------
+//
+// k_bgzf_resolve above fills a block's holes in global memory: every match source is a line touched at random somewhere in the last 32 KB
+// of one of the ~30 K blocks in flight - 0.43 G L2 misses per 4 GB of output, 14 x the output in fabric traffic, and no launch shape
+// changed its time.  Here a WORKGROUP takes a block: its bytes (literals in place, holes open) come into LDS with
+// coalesced 16-byte loads, the matches are resolved there, and the finished block leaves with coalesced 16-byte stores: two trips of the
+// block through memory plus its tokens, whatever the matches look like.
+//   Rounds of RL_T tokens (one per thread); a workgroup-wide prefix sum gives every match its place.
+//   What decides the time is the DEPTH of the copy chains, not the bytes: in a BAM the fixed fields of a record are a copy of the same
+//   fields of the record before, which are a copy of ... - hundreds of matches deep per block; worked off level by level (a match is
+//   ready when the matches its source touches are done) that is hundreds of barriers per block.  So chains are FLATTENED first, without
+//   any copying: while a match's source lies inside the hole of ONE earlier match j of the round, the bytes it wants are by definition
+//   the bytes j wants - its source moves to j's source (+ offset), and j publishes where its own source has moved to meanwhile, so
+//   chains collapse in a few steps, all threads at once, no barrier.  What is left - sources that straddle two tokens - goes level by
+//   level: a match is ready when every earlier match whose hole its source touches is done ([lo, hi]: two binary searches); all ready
+//   matches are copied at once: up to RL_OWN bytes by the match's own thread (all loads, then all stores), longer ones and repeating
+//   patterns by a whole wavefront each; two barriers a level.
+constexpr int RL_T = 512;                 // threads = tokens per round
+constexpr int RL_WAVES = RL_T / WAVE;
+constexpr int RL_OWN = 16;                // longest match a thread copies by itself
+constexpr int RL_FLAT_STEPS = 12;         // flattening steps per match and round (pointer jumping: 2^12 matches deep; what is left goes by readiness)
+constexpr uint32_t RL_WIN = 65536 + 64;   // the block's bytes from the 16-byte boundary below its first one
+constexpr size_t RL_LDS_BYTES = RL_WIN + (size_t)RL_T * (4 * 4 + 2 + 1) + 64 + 64;
+
+__global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
+                                                          const BgzfBlock *__restrict__ blocks, int64_t n_blocks, uint8_t *out)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t rl_lds[];
+	uint8_t *Wa = rl_lds;                                                   // the window, 16-byte groups as they lie in memory
+	uint32_t *s_dst = reinterpret_cast<uint32_t *>(rl_lds + RL_WIN);       // [RL_T] where token i's hole starts (block position)
+	uint32_t *s_end = s_dst + RL_T;                                         // [RL_T] ... and ends
+	uint32_t *s_src = s_end + RL_T;                                         // [RL_T] where its source starts NOW (moves back while chains are flattened)
+	uint32_t *s_dist = s_src + RL_T;                                        // [RL_T] the match's own distance (the period of a repeating pattern)
+	uint16_t *s_long = reinterpret_cast<uint16_t *>(s_dist + RL_T);         // [RL_T] the level's long matches (token numbers)
+	uint8_t *s_done = reinterpret_cast<uint8_t *>(s_long + RL_T);           // [RL_T]
+	uint32_t *s_misc = reinterpret_cast<uint32_t *>(rl_lds + RL_WIN + (size_t)RL_T * 19 + 64); // [0..7] wave sums, [8], [9] long counts (by level parity)
+	const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+	for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+		const uint32_t n = n_tok[b], ulen = blocks[b].u_len;
+		if (n == 0u || ulen == 0u) continue; // no match in the block: pass 1 has written all of it
+		uint8_t *a0 = out + u_off[b];
+		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 15u);
+		const uint4 *g16 = reinterpret_cast<const uint4 *>(a0 - mis);
+		const uint32_t ngroups = (mis + ulen + 15u) >> 4;
+		__syncthreads(); // (the block before has left the window)
+		for (uint32_t g = (uint32_t)tid; g < ngroups; g += RL_T) reinterpret_cast<uint4 *>(Wa)[g] = g16[g]; // (up to 15 bytes of the neighbours at either end: read, never written back)
+		uint8_t *W = Wa + mis; // block position p lives at W[p]
+		const uint32_t *tk = tokens + tok_off[b];
+		uint32_t P = 0;
+		uint32_t next = (uint32_t)tid < n ? tk[tid] : TOKEN_NONE;
+		for (uint32_t t0 = 0; t0 < n; t0 += RL_T) {
+			const uint32_t w = next;
+			next = t0 + RL_T + (uint32_t)tid < n ? tk[t0 + RL_T + tid] : TOKEN_NONE;
+			const bool esc = (w >> 23) == 511u;
+			const uint32_t lit = esc ? (w & 0x7fffffu) : (w >> 23);
+			const uint32_t len = esc ? 0u : (w & 255u) + 3u, dist = ((w >> 8) & 0x7fffu) + 1u;
+			// ---- places: inclusive sum of (literals + match) over the workgroup ----
+			const uint32_t inc_w = wave_inclusive_sum(lit + len);
+			if (lane == WAVE - 1) s_misc[wv] = inc_w;
+			__syncthreads();
+			uint32_t before = 0, total = 0;
+#pragma unroll
+			for (int k = 0; k < RL_WAVES; ++k) { const uint32_t x = s_misc[k]; if (k < wv) before += x; total += x; }
+			const uint32_t dst = P + before + inc_w - len, need = len < dist ? len : dist; // the source's bytes: [src, src + need)
+			uint32_t src = dst - dist;
+			s_dst[tid] = dst; s_end[tid] = dst + len; s_src[tid] = src; s_dist[tid] = dist;
+			bool done = len == 0u;
+			s_done[tid] = done ? 1 : 0;
+			__syncthreads();
+			// ---- flatten the chains: while the source lies inside ONE earlier hole of the round, take that match's source instead ----
+			if (!done) {
+				int top = tid; // the token under the source is searched among [0, top)
+				for (int step = 0; step < RL_FLAT_STEPS && src + need > P; ++step) {
+					int a = 0, z = top;             // last j in [0, top) with s_dst[j] <= src
+					while (a < z) { const int m = (a + z) >> 1; if (s_dst[m] <= src) a = m + 1; else z = m; }
+					const int j = a - 1;
+					if (j < 0) break;
+					const uint32_t dj = s_dst[j], ej = s_end[j];
+					if (src + need > ej) break;     // behind hole j (literals, maybe the next hole too) or across its end: the levels' business
+					const uint32_t o = src - dj, distj = s_dist[j], lenj = ej - dj, needj = lenj < distj ? lenj : distj;
+					if (o + need <= needj) src = s_src[j] + o;              // j's bytes [o, o + need) are its source's bytes [o, o + need)
+					else src -= (o / distj + 1u) * distj;                  // inside a repeating pattern: whole periods back, until in front of the hole
+					s_src[tid] = src;               // (whoever reads it meanwhile gets the old or the new place: both hold the same bytes)
+					top = j + 1;
+				}
+			}
+			// ---- whose holes does the source still touch?  earlier tokens [lo, hi] of this round (none: lo > hi) ----
+			int lo = 0, hi = -1;
+			if (!done && src + need > P) {
+				int a = 0, z = tid;                 // first j in [0, tid) with s_end[j] > src
+				while (a < z) { const int m = (a + z) >> 1; if (s_end[m] > src) z = m; else a = m + 1; }
+				lo = a;
+				a = lo; z = tid;                    // first j in [lo, tid) with s_dst[j] >= src + need
+				while (a < z) { const int m = (a + z) >> 1; if (s_dst[m] >= src + need) z = m; else a = m + 1; }
+				hi = a - 1;
+			}
+			// ---- the rest goes by readiness, every WAVEFRONT for itself: a match is ready when every earlier match whose hole its source touches
+			//      is done (flags in LDS); a wavefront copies what is ready among its 64 tokens, makes the bytes visible, raises the flags, and looks
+			//      again - no workgroup barrier inside a round: the token that is first in file order among the unfinished ones is always ready,
+			//      and all wavefronts of the workgroup are resident, so the spinning ones are always waited on by one that moves ----
+			volatile uint8_t *vdone = s_done;
+			while (__any(!done)) {
+				bool ready = !done;
+				for (int j = lo; ready && j <= hi; ++j) ready = vdone[j] != 0;
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // the bytes behind the flags just read
+				const bool own = ready && len <= (uint32_t)RL_OWN && dist >= len;
+				if (__any(own)) { // every thread its own short match: the loads, then the stores (the source is final and does not overlap the hole)
+					uint8_t v[RL_OWN];
+#pragma unroll
+					for (int k = 0; k < RL_OWN; ++k) v[k] = own && (uint32_t)k < len ? W[src + (uint32_t)k] : (uint8_t)0;
+#pragma unroll
+					for (int k = 0; k < RL_OWN; ++k) if (own && (uint32_t)k < len) W[dst + (uint32_t)k] = v[k];
+				}
+				// long matches and repeating patterns: the whole wavefront on each, 64 bytes a step; byte k of the hole is byte k mod dist of the source
+				for (uint64_t m = __ballot(ready && !own); m; m &= m - 1) {
+					const int k0 = __ffsll((long long)m) - 1;
+					const uint32_t d0 = (uint32_t)__shfl((int)dst, k0, WAVE), l0 = (uint32_t)__shfl((int)len, k0, WAVE), di = (uint32_t)__shfl((int)dist, k0, WAVE), s0 = (uint32_t)__shfl((int)src, k0, WAVE);
+					if (di >= l0) {
+						uint8_t v[5];
+#pragma unroll
+						for (int q = 0; q < 5; ++q) { const uint32_t k = (uint32_t)lane + 64u * (uint32_t)q; v[q] = k < l0 ? W[s0 + k] : (uint8_t)0; }
+#pragma unroll
+						for (int q = 0; q < 5; ++q) { const uint32_t k = (uint32_t)lane + 64u * (uint32_t)q; if (k < l0) W[d0 + k] = v[q]; }
+					} else {
+						for (uint32_t k = (uint32_t)lane; k < l0; k += WAVE) W[d0 + k] = W[s0 + k % di];
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the copies have landed in LDS before a flag says so
+				if (ready) { vdone[tid] = 1; done = true; }
+			}
+			__syncthreads(); // the round is resolved: the next round's sources may lie anywhere in it
+			P += total;
+		}
+		__syncthreads();
+		// ---- the finished block: whole 16-byte groups, the two ragged ends byte by byte ----
+		uint4 *o16 = reinterpret_cast<uint4 *>(a0 - mis);
+		for (uint32_t g = (uint32_t)tid; g < ngroups; g += RL_T) {
+			const uint32_t p0 = g << 4;
+			if (p0 >= mis && p0 + 16u <= mis + ulen) o16[g] = reinterpret_cast<const uint4 *>(Wa)[g];
+			else for (uint32_t k = 0; k < 16u; ++k) if (p0 + k >= mis && p0 + k < mis + ulen) (a0 - mis)[p0 + k] = Wa[p0 + k];
+		}
+	}
+}
+
 // The same decoder writing through a 64-byte line buffer per lane (LineOut, inflate_core.h): 64 x LPW bytes of LDS more per wavefront.
 struct LdsLine {
 	uint8_t *base; // this wavefront's lines: 16-byte group g of lane l at ((g * stride + l) * 16)

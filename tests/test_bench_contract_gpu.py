@@ -54,3 +54,23 @@ def test_bench_two_ranks_equal_one():
     b = _line(r1.stdout)
     assert a["n_gpus"] == 2 and a["config"]["records_total"] == b["config"]["records_total"]
     assert a["result"] == b["result"]
+
+
+def test_bench_strong_scaling_two_ranks_equal_one():
+    """--scaling strong (BASELINE config 4: ONE sample split N ways): two ranks on the same sample as one rank give the same counts, the line
+    says `strong`, and a share that cannot fit a GPU is refused with a message instead of an out-of-memory failure"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SSV_FORCE_DEVICE="0", SSV_DIST_BACKEND="gloo")
+    common = ["--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--strong-depth", "60", "--file-frac", "0", "--no-cpu-baseline"]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-800:]
+    a = _line(r2.stdout)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-600:]
+    b = _line(r1.stdout)
+    assert a["scaling"] == b["scaling"] == "strong" and a["n_gpus"] == 2
+    assert a["config"]["records_total"] == b["config"]["records_total"] and a["config"]["records_per_gpu"] < b["config"]["records_per_gpu"]
+    assert a["result"] == b["result"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", "strong", "--file-frac", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not fit one GPU" in r.stderr
