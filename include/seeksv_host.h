@@ -73,6 +73,9 @@ int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, ui
 int ssvh_bam_raw_begin_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, uint64_t end_coff, uint32_t end_uoff, uint64_t *first_record_offset);
 int ssvh_bam_raw_limit(const ssvh_bam *b, uint64_t *inflated_bytes);
 const char *ssvh_partition_last_error(void); /* message of the last failed ssvh_bam_partition / ssvh_bam_walk_back of this thread */
+/* 1 when this thread's last ssvh_bam_partition took its boundaries from the file's .bai (path + ".bai", or .bam replaced by .bai: the index
+ * the reference loads, seeksv.cpp:272-280) - the record starts of its linear index -, 0 when it found them by speculation in the file itself. */
+int ssvh_partition_used_index(void);
 
 /* on != 0: after handing out a batch, ssvh_bam_read_batch decodes the following one on a background thread into another set
  * of arrays, so that inflate + decode overlap whatever the caller does with the current batch (upload, kernels, output); there are

@@ -233,6 +233,55 @@ bool first_record_verified(BlockFile &f, uint64_t g, uint64_t *out)
 	return false;
 }
 
+bool from_voffset_of(const BlockFile &f, uint64_t coff, uint32_t uoff, uint64_t *g)
+{
+	auto it = std::lower_bound(f.blocks.begin(), f.blocks.end(), coff, [](const BlockPos &b, uint64_t c) { return b.coff < c; });
+	if (it == f.blocks.end() || it->coff != coff || uoff > it->isize) return false;
+	*g = f.ucum[(size_t)(it - f.blocks.begin())] + uoff;
+	return true;
+}
+
+// The .bai next to the file, when there is one (the reference reaches regions through it: seeksv.cpp:272-280 bam_index_load,
+// getsv.cpp:1063-1067 bam_iter_query): its LINEAR index holds, for every 16 kb window of every contig, the virtual offset of the first
+// record that overlaps the window - record starts that need no speculation.  -> their global inflated offsets, ascending.
+bool load_bai_starts(const char *bam_path, const BlockFile &f, std::vector<uint64_t> &starts)
+{
+	starts.clear();
+	FILE *fp = fopen((std::string(bam_path) + ".bai").c_str(), "rb");
+	if (!fp) {
+		std::string alt(bam_path);
+		if (alt.size() > 4 && alt.compare(alt.size() - 4, 4, ".bam") == 0) { alt.replace(alt.size() - 4, 4, ".bai"); fp = fopen(alt.c_str(), "rb"); }
+		if (!fp) return false;
+	}
+	auto rd = [&](void *p, size_t n) { return fread(p, 1, n, fp) == n; };
+	char magic[4]; int32_t n_ref = 0;
+	bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0 && n_ref == f.n_targets;
+	for (int32_t r = 0; ok && r < n_ref; ++r) {
+		int32_t n_bin = 0;
+		ok = rd(&n_bin, 4) && n_bin >= 0;
+		for (int32_t b = 0; ok && b < n_bin; ++b) {
+			uint32_t bin; int32_t n_chunk = 0;
+			ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && fseek(fp, (long)n_chunk * 16, SEEK_CUR) == 0;
+		}
+		int32_t n_intv = 0;
+		ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+		std::vector<uint64_t> io((size_t)n_intv);
+		ok = ok && (n_intv == 0 || rd(io.data(), (size_t)n_intv * 8));
+		for (uint64_t v : io) {
+			if (!v) continue; // a window no record overlaps
+			uint64_t g;
+			if (!from_voffset_of(f, v >> 16, (uint32_t)(v & 0xffff), &g)) { ok = false; break; } // not a block of THIS file: a stale index
+			starts.push_back(g);
+		}
+	}
+	fclose(fp);
+	if (!ok) { starts.clear(); return false; }
+	std::sort(starts.begin(), starts.end());
+	starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+	// a stale or foreign index must not cut the file inside a record: every start has to look like one
+	return !starts.empty();
+}
+
 struct RecHead { uint64_t g; int32_t tid, pos; uint16_t flag; };
 
 // the records that start in [g_lo_hint .. g_known), in order, where g_known is a KNOWN record start: a chain is speculated from the start
@@ -313,12 +362,14 @@ bool walk_back(BlockFile &f, uint64_t g_known, F visit)
 }
 
 thread_local std::string g_perr;
+thread_local bool g_used_index = false;
 
 } // namespace
 
 extern "C" {
 
 const char *ssvh_partition_last_error(void) { return g_perr.c_str(); }
+int ssvh_partition_used_index(void) { return g_used_index ? 1 : 0; }
 
 int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_bam_part *parts)
 {
@@ -329,10 +380,23 @@ int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_
 	const uint64_t total = f.ucum.back(), body = total > f.header_len ? total - f.header_len : 0;
 	std::vector<uint64_t> own((size_t)n_parts + 1, total);
 	own[0] = f.header_len < total ? f.header_len : total;
+	// boundaries: with a .bai the record starts of its linear index (one per 16 kb window that holds reads: exact, nothing to verify beyond
+	// a look at the header there); without one, speculation checked by two independent record chains (first_record_verified)
+	std::vector<uint64_t> bai;
+	g_used_index = getenv("SSV_NO_BAI") == nullptr && load_bai_starts(path, f, bai);
 	for (int32_t r = 1; r < n_parts; ++r) {
 		uint64_t g = f.header_len + body * (uint64_t)r / (uint64_t)n_parts, at = total;
 		if (g < own[(size_t)r - 1]) g = own[(size_t)r - 1];
-		if (g < total && !first_record_verified(f, g, &at)) { if (!f.err.empty()) { g_perr = f.err; return -1; } at = total; }
+		if (g < total && g_used_index) {
+			auto it = std::lower_bound(bai.begin(), bai.end(), g);
+			at = it == bai.end() ? total : *it;
+			if (at < total) { // (the index is the file's own if the bytes there are a record header; otherwise fall back)
+				Window w(f);
+				w.begin_at_block(f.block_of(at));
+				w.need(std::min<uint64_t>(total, at + 4 + 36 + 256));
+				if (!plausible(w.u.data(), (size_t)(at - w.g0), w.u.size(), f.n_targets, f.target_len.data())) { g_used_index = false; r = 0; continue; } // start over without the index
+			}
+		} else if (g < total && !first_record_verified(f, g, &at)) { if (!f.err.empty()) { g_perr = f.err; return -1; } at = total; }
 		own[(size_t)r] = g < total ? at : total;
 	}
 	for (int32_t r = 0; r < n_parts; ++r) {

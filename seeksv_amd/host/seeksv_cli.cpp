@@ -968,7 +968,7 @@ static int cmd_getsv(int argc, char **argv)
 				if (ssvh_bam_read_batch(rb, found + 16, 0, &hb) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
 				int32_t sufficient = 1;
 				if (ssv_getsv_prime(rc, &hb, &sufficient) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
-				if (sufficient || found < back || back > (1ll << 26)) break; // (found < back: the replay began at the file's first record)
+				if (sufficient || found < back) break; // (found < back: the replay began at the file's first record - as far back as a replay can start)
 			}
 			if (err.empty()) { // the run itself: host threads or the GPU (-Z) inflate and decode its blocks
 				BatchSource src;

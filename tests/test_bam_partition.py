@@ -149,3 +149,25 @@ def test_partition_false_record_start_two_bytes_early(tmp_path):
                 assert (p["own_tid"], p["own_pos"]) == (0, int(whole["pos"][i0]))
             assert i0 == 0 or abs(i0 - n * r // n_parts) < 300       # and they are where the balance puts them, not a hop later
         assert n_seen == n
+
+
+@pytest.mark.parametrize("n_parts", [2, 3, 5])
+def test_partition_with_bai(n_parts, monkeypatch):
+    """the bundled example BAMs come with their .bai (the index the reference loads, seeksv.cpp:272-280): the boundaries are then record starts of
+    its linear index - no speculation - and every property of the index-free cut holds for them too; SSV_NO_BAI switches back"""
+    from seeksv_amd import _abi
+    lib = _abi.host_lib()
+    for name in ("cancer.sort.bam", "normal.sort.bam"):
+        path = os.path.join(G.GOLDEN, "example", name)
+        assert os.path.exists(path + ".bai")
+        names, lens, batches = host.read_bam(path)
+        whole = {k: _cat(batches, k) for k in KEYS}
+        monkeypatch.delenv("SSV_NO_BAI", raising=False)
+        _check(path, whole, n_parts, 500)
+        assert lib.ssvh_partition_used_index() == 1
+        with_index = host.partition(path, n_parts, 500)
+        monkeypatch.setenv("SSV_NO_BAI", "1")
+        _check(path, whole, n_parts, 500)
+        assert lib.ssvh_partition_used_index() == 0
+        # both ways the parts tile the file; the cut points may differ (a window's first record vs the first record behind the balance point)
+        assert len(with_index) == len(host.partition(path, n_parts, 500))

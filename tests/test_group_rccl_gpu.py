@@ -1,0 +1,89 @@
+"""-m gpu: the one exchange step of a range-partitioned run (ssv_group_*, include/seeksv_hip.h) over REAL devices: with two or more GPUs the
+group is an RCCL communicator (ncclCommInitAll) and the ranks' vectors meet in ncclAllGather over xGMI; on a one-GPU box the test is
+skipped (tests/test_cli_ranks_gpu.py covers the host-memory exchange of ranks that share a GPU)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from seeksv_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _group(lib, devices):
+    ctxs = []
+    for d in devices:
+        h = C.c_void_p()
+        assert lib.ssv_ctx_create(d, C.byref(h)) == 0, lib.ssv_last_error(None)
+        ctxs.append(h)
+    arr = (C.c_void_p * len(ctxs))(*[h.value for h in ctxs])
+    g = C.c_void_p()
+    lib.ssv_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+    lib.ssv_group_allgather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.ssv_group_destroy.argtypes = [C.c_void_p]
+    lib.ssv_group_uses_rccl.argtypes = [C.c_void_p]
+    assert lib.ssv_group_create(arr, len(ctxs), C.byref(g)) == 0, lib.ssv_last_error(None)
+    return ctxs, g
+
+
+@pytest.mark.parametrize("n_bytes", [0, 8, 4096, 3 * 1024 * 1024 + 5])
+def test_allgather_over_rccl(n_bytes):
+    lib = _abi.hip_lib()
+    n_dev = lib.ssv_device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU: RCCL cannot put two ranks on one device")
+    n = min(n_dev, 8)
+    ctxs, g = _group(lib, list(range(n)))
+    try:
+        assert lib.ssv_group_uses_rccl(g) == 1
+        rng = np.random.default_rng(5)
+        send = [rng.integers(0, 256, n_bytes, dtype=np.uint8) for _ in range(n)]
+        recv = [np.zeros(n_bytes * n, dtype=np.uint8) for _ in range(n)]
+        rcs = [None] * n
+
+        def rank(r):
+            rcs[r] = lib.ssv_group_allgather(g, r, send[r].ctypes.data if n_bytes else None, n_bytes, recv[r].ctypes.data if n_bytes else None)
+        for rep in range(3):   # the communicator is reused
+            th = [threading.Thread(target=rank, args=(r,)) for r in range(n)]
+            [t.start() for t in th]
+            [t.join(timeout=120) for t in th]
+            assert all(not t.is_alive() for t in th), "a rank hangs in the exchange"
+            assert rcs == [0] * n
+            want = np.concatenate(send) if n_bytes else np.zeros(0, np.uint8)
+            for r in range(n):
+                assert np.array_equal(recv[r], want)
+    finally:
+        lib.ssv_group_destroy(g)
+        for h in ctxs:
+            lib.ssv_ctx_destroy(h)
+
+
+def test_cli_ranks_on_real_devices(tmp_path):
+    """`seeksv getsv -N n` with one rank per real GPU: the tallies and depths meet in ncclAllGather and equal the single-GPU table"""
+    import os
+    import subprocess
+    import bamio
+    import golden_util as G
+    from seeksv_amd import host
+    lib = _abi.hip_lib()
+    n_dev = lib.ssv_device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.environ.get("SSV_CLI") or os.path.join(root, "seeksv_amd", "bin", "seeksv")
+    base = os.path.join(G.GOLDEN, "getsv")
+    bam = os.path.join(base, "pairs1.bam")
+    with host.BamReader(bam) as r:
+        names, lens = r.target_names, [int(x) for x in r.target_lens]
+    empty_bam = str(tmp_path / "empty.clip.bam")
+    bamio.write_bam(empty_bam, names, lens, [])
+    empty_clip = str(tmp_path / "empty.clip")
+    open(empty_clip, "w").close()
+    sv = str(tmp_path / "out.sv")
+    r = subprocess.run([exe, "getsv", "-N", str(min(n_dev, 4)), "-d", "0", "-f", "0", "-b", "0", "-T", "100000", "-B", os.path.join(base, "pairs1.junctions.txt"), empty_bam, bam, empty_clip, sv,
+                        str(tmp_path / "x.fq")], capture_output=True, text=True, env=dict(os.environ, SSV_TIMING="1"))
+    assert r.returncode == 0, r.stderr
+    assert "exchange over RCCL" in r.stderr
+    assert open(sv).read() == G.read_text("getsv", "pairs1.sv")
