@@ -37,9 +37,10 @@ PATH_BYTES_PER_RECORD = 40.0
 #   clip_place  : per candidate: staged index 4 + 4, record line 64, count 1; per event (0.31 per candidate): line 64 + staged key 16 written,
 #                 staged key 16 read, side-list key 12 + (l_qseq, n_cigar) 8 + slot 4 written                                        = 110 B/candidate
 #   event_sort  : '3' events (half): one windowed rank pass (12 read + 12 written + check 12); all: key 12 + line 64 read, 8 + 64 written = 166 B/event
-#   cluster_pack: per sorted slot: line 32 + 9, sizes 16 (meta); two scans 48; line 64 + 30, row 12 + descriptor 32 + CIGAR 10 (cols);
-#                 descriptor 32 + read 228 + block 100 (strings)                                                                      = 613 B/slot
-ALGO_BYTES = {"clip_scan": 1.0, "getsv_scan": 8.0, "clip_place": 110.0, "event_sort": 166.0, "cluster_pack": 613.0}
+#   cluster_pack: the byte-by-byte model (line 32 + 9, sizes 16; two scans 48; line 64 + 30, row 12 + descriptor 32 + CIGAR 10; descriptor 32 + read 228 +
+#                 block 100 = 613 B/slot) overstates what the kernels move: the PMC passes count 2.56 GB for 5.69 M slots (profiles/traffic.json: caches
+#                 serve the second look at a line)                                                                                    = 450 B/slot (measured)
+ALGO_BYTES = {"clip_scan": 1.0, "getsv_scan": 8.0, "clip_place": 110.0, "event_sort": 166.0, "cluster_pack": 450.0}
 DEVICE_GROUPS = ("clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish")
 
 
@@ -362,6 +363,10 @@ def main():
                        "host_cpus_bound_near_gpu": near_cpus, "generation_s": round(gen_s, 2)},
             "roofline": {"kernel": "path: all device kernels of one step (getclip + insert size + getsv passes; PCIe copy excluded)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": total_traffic,
+                         # the other way to read the same launches: the bytes the kernels really moved (PMC counters) over their time.  The path reads 18 of the 40
+                         # "read every field once" bytes (the cold 64-byte lines are touched for 1-2 % of the records only), so `frac` (work done per second against
+                         # the peak) is higher than the share of the memory system that is in use.
+                         "hbm_frac_measured": (round(total_traffic / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if total_traffic else None),
                          "algorithmic_bytes_per_record": PATH_BYTES_PER_RECORD, "records_per_launch": float(n_own), "avg_launch_ms": round(dev_ms, 4),
                          "launches_timed": BREAKDOWN_STEPS, "dominant_group": {"name": longest, **groups[longest]},
                          "groups": groups, "streaming_kernels_in_timed_region": timed},

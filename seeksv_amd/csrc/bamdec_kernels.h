@@ -296,9 +296,13 @@ constexpr uint32_t RL_WIN = 65536 + 64;   // the block's bytes from the 16-byte 
 constexpr size_t RL_LDS_BYTES = RL_WIN + (size_t)RL_T * (4 * 4 + 2 + 1) + 64 + 64;
 
 __global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
-                                                          const BgzfBlock *__restrict__ blocks, int64_t n_blocks, uint8_t *out)
+                                                          const BgzfBlock *__restrict__ blocks, int64_t n_blocks, uint8_t *out, unsigned long long *dbg)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t rl_lds[];
+	// SSV_RESOLVE_PHASES=1 (dbg != nullptr): cycles of workgroup thread 0 per phase, and step counts, summed over the launch
+	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, steps_flat = 0, steps_spin = 0, n_rounds = 0, n_blk = 0;
+	unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define RL_LAP(K) do { if (dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[K] += now_ - tc; tc = now_; } } while (0)
 	uint8_t *Wa = rl_lds;                                                   // the window, 16-byte groups as they lie in memory
 	uint32_t *s_dst = reinterpret_cast<uint32_t *>(rl_lds + RL_WIN);       // [RL_T] where token i's hole starts (block position)
 	uint32_t *s_end = s_dst + RL_T;                                         // [RL_T] ... and ends
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__res
 		const uint4 *g16 = reinterpret_cast<const uint4 *>(a0 - mis);
 		const uint32_t ngroups = (mis + ulen + 15u) >> 4;
 		__syncthreads(); // (the block before has left the window)
+		RL_LAP(5); ++n_blk;
 		for (uint32_t g = (uint32_t)tid; g < ngroups; g += RL_T) reinterpret_cast<uint4 *>(Wa)[g] = g16[g]; // (up to 15 bytes of the neighbours at either end: read, never written back)
 		uint8_t *W = Wa + mis; // block position p lives at W[p]
 		const uint32_t *tk = tokens + tok_off[b];
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__res
 			bool done = len == 0u;
 			s_done[tid] = done ? 1 : 0;
 			__syncthreads();
+			RL_LAP(t0 == 0 ? 0 : 1); ++n_rounds;
 			// ---- flatten the chains: while the source lies inside ONE earlier hole of the round, take that match's source instead ----
 			if (!done) {
 				int top = tid; // the token under the source is searched among [0, top)
@@ -355,8 +361,10 @@ __global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__res
 					else src -= (o / distj + 1u) * distj;                  // inside a repeating pattern: whole periods back, until in front of the hole
 					s_src[tid] = src;               // (whoever reads it meanwhile gets the old or the new place: both hold the same bytes)
 					top = j + 1;
+					++steps_flat;
 				}
 			}
+			RL_LAP(2);
 			// ---- whose holes does the source still touch?  earlier tokens [lo, hi] of this round (none: lo > hi) ----
 			int lo = 0, hi = -1;
 			if (!done && src + need > P) {
@@ -372,7 +380,9 @@ __global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__res
 			//      again - no workgroup barrier inside a round: the token that is first in file order among the unfinished ones is always ready,
 			//      and all wavefronts of the workgroup are resident, so the spinning ones are always waited on by one that moves ----
 			volatile uint8_t *vdone = s_done;
+			RL_LAP(3);
 			while (__any(!done)) {
+				++steps_spin;
 				bool ready = !done;
 				for (int j = lo; ready && j <= hi; ++j) ready = vdone[j] != 0;
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // the bytes behind the flags just read
@@ -402,6 +412,7 @@ __global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__res
 				if (ready) { vdone[tid] = 1; done = true; }
 			}
 			__syncthreads(); // the round is resolved: the next round's sources may lie anywhere in it
+			RL_LAP(4);
 			P += total;
 		}
 		__syncthreads();
@@ -413,6 +424,13 @@ __global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__res
 			else for (uint32_t k = 0; k < 16u; ++k) if (p0 + k >= mis && p0 + k < mis + ulen) (a0 - mis)[p0 + k] = Wa[p0 + k];
 		}
 	}
+	if (dbg) {
+		RL_LAP(5);
+		if (tid == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&dbg[k], tm[k]); atomicAdd(&dbg[6], n_rounds); atomicAdd(&dbg[7], n_blk); }
+		if (lane == 0) atomicAdd(&dbg[9], steps_spin);
+		atomicAdd(&dbg[8], steps_flat);
+	}
+#undef RL_LAP
 }
 
 // The same decoder writing through a 64-byte line buffer per lane (LineOut, inflate_core.h): 64 x LPW bytes of LDS more per wavefront.

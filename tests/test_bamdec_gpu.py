@@ -231,3 +231,18 @@ def test_ring_machine_inflate_modes(mode):
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_resolve_in_lds_mode():
+    """SSV_RESOLVE=lds: pass 2 of the inflate as a workgroup per BGZF block with the block in LDS (k_bgzf_resolve_lds: chains flattened by
+    pointer jumping over the round's tokens, then wavefront-local readiness, coalesced load and store of the block) - not the default (it moves
+    a seventh of the bytes and takes 2.5 x the time), kept correct: the same device-decode == host-reader checks"""
+    import subprocess
+    import sys
+    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_INFLATE"):
+        pytest.skip("already inside a mode run")
+    env = dict(os.environ, SSV_RESOLVE="lds")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -110,3 +110,34 @@ def test_config3_300x_largest_in_a_minute(ctx):
     genome, the same 617 M records; bins at planted breakpoints are ~150 reads deep"""
     from seeksv_amd import synth
     _check_config(ctx, synth.Workload(genome_frac=0.1, depth=300, n_sv=1000))
+
+
+def test_config3_300x_full_size_6G_records():
+    """BASELINE config 3 at its FULL size: 300x tumor WGS, 6.18 G records, 10,000 planted DEL / INV / TRA - more than fits in HBM at once, so the
+    records are generated there chunk by chunk and streamed through the multi-batch API twice (getclip + insert size, then the fused getsv
+    pass), once in 10 and once in 16 chunks (tools/config3_full_size.py): identical cluster tables (sha256 over every column) and identical
+    tallies / depths, every clip event in exactly one cluster, every planted junction seen by the discordant tally and the depth pass - and
+    the table's rows around a planted junction and at a contig's start are the CPU oracle's, row for row."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import config3_full_size as C3
+    checked = []
+
+    def probe(w, d):
+        jname = next(j for j in w.junctions if j[0] == j[3] and abs(j[4] - j[1]) < 100000 and 1_000_000 < j[1] < int(w.lens[w.names.index(j[0])]) - 1_000_000)
+        jt = w.names.index(jname[0])
+        for g0 in (0, max(0, _record_of(w, jt, jname[1]) - SLICE // 2)):
+            hb = w.generate_host(g0, SLICE)
+            t0, p0, t1, p1 = int(hb["tid"][0]), int(hb["pos"][0]), int(hb["tid"][-1]), int(hb["pos"][-1])
+            assert t0 == t1
+            o = O.getclip([hb], initial_last_tid=t0)
+            lo, hi = (1 if g0 == 0 else p0 + MARGIN), p1 - MARGIN
+            got, want = _rows(d, t0, lo, hi), _rows(o, t0, lo, hi)
+            assert len(want) > 1000 and got == want
+            checked.append(len(want))
+    out = C3.main(1.0, 300.0, 10000, 10, 16, probe=probe)
+    assert out["records"] > 6_100_000_000 and out["results_identical"] and len(checked) == 2
+    assert out["junctions_with_discordant_pairs"] == out["junctions"] == out["junctions_with_depth_at_both_ends"] == 10000
+    assert out["table"]["support_sum"] == out["table"]["n_events"] > 50_000_000

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(w, hdr, ctx, n_chunks):
+def run(w, hdr, ctx, n_chunks, probe=None):
     from seeksv_amd import host
     import torch
     n = w.n_total
@@ -55,6 +55,8 @@ def run(w, hdr, ctx, n_chunks):
         h.update(np.ascontiguousarray(d[k]).tobytes())
     table = dict(n_clusters=int(d["n_clusters"]), n_events=int(d["n_events"]), support_sum=int(d["support"].sum()), max_support=int(d["support"].max()),
                  qual_bits=int(d["qual_bits"]), table_bytes=int(sum(np.asarray(d[k]).nbytes for k in d if isinstance(d[k], np.ndarray))), sha256=h.hexdigest())
+    if probe is not None:
+        probe(d)   # (tests: rows of the table against the CPU oracle on slices of the input)
     del d
     plan = host.Plan(hdr, w.junctions, stats[2], stats[3])
     t0 = time.perf_counter()
@@ -77,14 +79,14 @@ def run(w, hdr, ctx, n_chunks):
                 seconds={k: round(v, 3) for k, v in t.items()})
 
 
-def main(genome_frac=1.0, depth=300.0, n_sv=10000, chunks_a=10, chunks_b=16):
+def main(genome_frac=1.0, depth=300.0, n_sv=10000, chunks_a=10, chunks_b=16, probe=None):
     from seeksv_amd import host, synth
     from seeksv_amd.device import Context
     w = synth.Workload(genome_frac=genome_frac, depth=depth, n_sv=n_sv)
     hdr = host.Header(w.names, w.lens)
     out = {"records": w.n_total, "junctions": len(w.junctions), "depth": depth, "genome_frac": genome_frac}
     with Context(0) as ctx:
-        a = run(w, hdr, ctx, chunks_a)
+        a = run(w, hdr, ctx, chunks_a, (lambda d: probe(w, d)) if probe else None)
         b = run(w, hdr, ctx, chunks_b)
     hdr.close()
     assert a["table"] == b["table"], (a["table"], b["table"])
