@@ -23,10 +23,12 @@ def ctx():
     c.close()
 
 
-def random_sample(seed, n=1500, safe=False, want_records=False):
-    """safe: only inputs for which the REFERENCE's behaviour is defined (it reads out of bounds on missing qualities inside a multi-read bin)"""
+def random_sample(seed, n=1500, safe=False, want_records=False, unsorted=False):
+    """safe: only inputs for which the REFERENCE's behaviour is defined (it reads out of bounds on missing qualities inside a multi-read bin).
+    unsorted: the contigs' runs of records are cut in pieces and dealt out again, so that contigs come back (getclip flushes per visit,
+    clip_reads.h:423-438); positions inside a piece stay in order"""
     rng = np.random.RandomState(seed)
-    lens = [int(x) for x in rng.randint(3000, 9000, 3)]
+    lens = [int(x) for x in (rng.randint(1000, 2500, 6) if unsorted else rng.randint(3000, 9000, 3))]   # (unsorted: short contigs, so that every sample holds several)
     recs = []
     tid, pos = 0, int(rng.randint(0, 50))
     templates = ["".join("ACGT"[x] for x in rng.randint(0, 4, 400)) for _ in range(4)]
@@ -39,6 +41,8 @@ def random_sample(seed, n=1500, safe=False, want_records=False):
         ops = []
         if kind <= 3:
             ops = [(lq, "M")]
+        elif kind == 9 and rng.rand() < 0.4:
+            ops = [(lq, "S")]   # a CIGAR that is one lone soft clip: both ends of the CIGAR at once (clip_reads.cpp:115,150-190), two rows with an empty aligned part
         else:
             left = int(rng.randint(1, lq // 2)) if rng.rand() < 0.6 else 0
             right = int(rng.randint(1, lq // 2 - 1)) if rng.rand() < 0.5 else 0
@@ -93,6 +97,11 @@ def random_sample(seed, n=1500, safe=False, want_records=False):
                 recs.append(r2)
     order = sorted(range(len(recs)), key=lambda i: (recs[i]["tid"], recs[i]["pos"]))
     recs = [recs[i] for i in order if recs[i]["pos"] >= 0]
+    if unsorted:
+        cuts = sorted(set([0, len(recs)] + [int(x) for x in rng.randint(1, len(recs), 9)]))
+        pieces = [recs[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+        rng.shuffle(pieces)
+        recs = [r for piece in pieces for r in piece]
     b = dict(tid=np.array([r["tid"] for r in recs], np.int32), pos=np.array([r["pos"] for r in recs], np.int32),
              flag=np.array([r["flag"] for r in recs], np.uint16), mapq=np.array([r["mapq"] for r in recs], np.uint8),
              n_cigar=np.array([len(r["ops"]) for r in recs], np.uint16), l_qseq=np.array([r["lq"] for r in recs], np.int32),
@@ -165,3 +174,18 @@ def test_random_sample_hip_equals_oracle(ctx, seed):
             assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd)
     plan.close()
     hdr.close()
+
+
+@pytest.mark.parametrize("seed", list(range(200, 212)) + list(range(300, 306)))
+def test_random_unsorted_sample_hip_equals_oracle(ctx, seed):
+    """contigs that come back: one flush per visit (clip_reads.h:423-438) - the passes end where the driver sees a contig again (ssv_clip_scan_range);
+    seeds 300-305 are the samples tests/test_random_oracle_vs_reference.py runs through the REAL reference"""
+    names, lens, b, rng = random_sample(seed, safe=seed >= 300, unsorted=True)
+    n = len(b["tid"])
+    cuts = sorted(set([0, n] + [int(x) for x in rng.randint(1, n, 3)]))
+    parts = [split_batch(b, cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+    for kw in (dict(), dict(match_rate=0.8, min_mapq=0), dict(match_rate=1.0, save_low_quality=True, min_mapq=20)):
+        want = O.getclip([b], **kw)
+        assert_tables_equal(ctx.getclip([b], **kw), want)
+        assert_tables_equal(ctx.getclip(parts, **kw), want)
+    assert want["n_events"] > 50 and np.any(np.diff(want["tid"]) < 0)   # the table really holds a contig twice
