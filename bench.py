@@ -768,7 +768,7 @@ def cpu_baseline_all_cores(args, w, seconds=6.0, n_per_worker=2_000_000):
     plain child processes that never touch the GPU), each on its own slice of the workload, range-partitioned like the multi-GPU run.
     Aggregate records/s - what the host of this GPU box could do with the reference's algorithm if it were parallelised by contig range."""
     import subprocess
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()   # (a container that sees 256 CPUs may be granted the time of 16: that many workers, and `cores` says so)
     n = min(n_per_worker, max(1, w.n_total // cores))
     worker = os.path.join(ROOT, "tools", "cpu_baseline_worker.py")
     try:
@@ -785,7 +785,7 @@ def cpu_baseline_all_cores(args, w, seconds=6.0, n_per_worker=2_000_000):
         if not ok:
             return None
         return {"value": rate, "unit": "records/s", "cores": ok, "kind": "port",
-                "sample": f"{ok} single-threaded oracle processes at once, each {seconds:g} s of whole passes over its own {n}-record slice of the same workload"}
+                "sample": f"{ok} single-threaded oracle processes at once (the CPUs this process may use: {os.cpu_count()} visible, cgroup quota / affinity {cores}), each {seconds:g} s of whole passes over its own {n}-record slice of the same workload"}
     except Exception as e:  # a courtesy, like cpu_reference
         return {"value": None, "unit": "records/s", "cores": cores, "kind": "port", "sample": f"failed: {e}"}
 

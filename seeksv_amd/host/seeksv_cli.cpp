@@ -963,11 +963,27 @@ static int cmd_getsv(int argc, char **argv)
 				uint64_t co; uint32_t uo; int64_t found = 0;
 				if (ssvh_bam_walk_back(original_bam.c_str(), P.own_coff, P.own_uoff, back, &co, &uo, &found) != 0) { err = string("[seeksv] ") + ssvh_partition_last_error(); break; }
 				if (found == 0) break;
-				if (ssvh_bam_set_range(rb, co, uo, P.own_coff, P.own_uoff) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
-				ssv_batch_t hb;
-				if (ssvh_bam_read_batch(rb, found + 16, 0, &hb) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
 				int32_t sufficient = 1;
-				if (ssv_getsv_prime(rc, &hb, &sufficient) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
+				bool primed = false;
+				if (device_inflate && found <= (1 << 22)) {
+					// -Z: the replayed records are inflated and decoded on the rank's GPU like the run itself (one chunk: they are a few MB)
+					BatchSource rs;
+					rs.set_range(co, uo, P.own_coff, P.own_uoff);
+					rs.open(original_bam, rc, true, "[main_samview] fail to open file for reading.");
+					ssv_batch_t db, more;
+					if (rs.next(&db, 0)) {
+						if (ssv_getsv_prime(rc, &db, &sufficient) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); rs.close(); break; }
+						primed = !rs.next(&more, 0); // (a replay that spans chunks goes through the host reader below: the bookkeeping takes one batch)
+					}
+					rs.close();
+					if (!primed && ssv_getsv_begin(rc, &gp) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
+				}
+				if (!primed) {
+					if (ssvh_bam_set_range(rb, co, uo, P.own_coff, P.own_uoff) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
+					ssv_batch_t hb;
+					if (ssvh_bam_read_batch(rb, found + 16, 0, &hb) != 0) { err = string("[seeksv] ") + ssvh_last_error(); break; }
+					if (ssv_getsv_prime(rc, &hb, &sufficient) != SSV_OK) { err = string("[seeksv] ") + ssv_last_error(rc); break; }
+				}
 				if (sufficient || found < back) break; // (found < back: the replay began at the file's first record - as far back as a replay can start)
 			}
 			if (err.empty()) { // the run itself: host threads or the GPU (-Z) inflate and decode its blocks

@@ -131,14 +131,19 @@ int main()
 						int rc3 = ssv::inflate_stream_to(c.data(), clen, lo, (uint32_t)n, tab);
 						if (!(rc3 == ssv::INF_OK && memcmp(op, d.data(), n) == 0 && op[n] == 0x55 && op[-1] == 0x55)) { same = false; fprintf(stderr, "LINE sink: "); }
 					}
-					{ // decode and copy split in two: tokens, then the holes filled in order
-						std::vector<uint8_t> o4(n + 8, 0x55);
+					for (int mo = 0; mo < 4; ++mo) { // decode and copy split in two: tokens, then the holes filled in order; the output at every misalignment
+						// (literals leave as aligned dwords: nothing may be written in front of the block or behind it)
+						std::vector<uint8_t> o4(n + 24, 0x55);
+						uint8_t *op = o4.data() + 8 + mo;
 						std::vector<uint32_t> tk(ssv::token_capacity((uint32_t)n) + 1, 0xdeadbeefu);
 						ssv::TokenOut to;
-						to.out = o4.data(); to.tok = tk.data();
+						to.out = op; to.tok = tk.data();
 						int rc4 = ssv::inflate_stream_to(c.data(), clen, to, (uint32_t)n, tab);
-						if (rc4 == ssv::INF_OK) ssv::resolve_tokens(o4.data(), tk.data(), to.n);
-						if (!(rc4 == ssv::INF_OK && to.n <= ssv::token_capacity((uint32_t)n) && tk[ssv::token_capacity((uint32_t)n)] == 0xdeadbeefu && memcmp(o4.data(), d.data(), n) == 0 && o4[n] == 0x55)) { same = false; fprintf(stderr, "TOKEN sink: "); }
+						if (rc4 == ssv::INF_OK) ssv::resolve_tokens(op, tk.data(), to.n);
+						bool guard = true;
+						for (int g = 0; g < 8 + mo; ++g) guard = guard && o4[g] == 0x55;
+						for (size_t g = 8 + mo + n; g < o4.size(); ++g) guard = guard && o4[g] == 0x55;
+						if (!(rc4 == ssv::INF_OK && to.n <= ssv::token_capacity((uint32_t)n) && tk[ssv::token_capacity((uint32_t)n)] == 0xdeadbeefu && memcmp(op, d.data(), n) == 0 && guard)) { same = false; fprintf(stderr, "TOKEN sink (misalignment %d): ", mo); }
 					}
 					for (int mi = 0; mi < 4; ++mi) { // the window reader (RingReader) in front of the token sink, at every misalignment of the input
 						struct CpuRing {
