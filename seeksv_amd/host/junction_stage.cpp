@@ -215,6 +215,12 @@ std::string assemble_junctions(const std::string &clipfile, const std::string &c
 {
 	std::string text, err = slurp_gz(clipfile, text);
 	if (!err.empty()) return err;
+	return assemble_junctions_text(text, clip_bam, j2o);
+}
+
+// the same with the rows of clip.gz already in memory (`seeksv run`: getclip has just written them)
+std::string assemble_junctions_text(const std::string &text, const std::string &clip_bam, JunctionMap &j2o)
+{
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(clip_bam.c_str(), &bam) != 0) return "[main_samview] fail to open file for reading.";
 	std::istringstream fin(text);

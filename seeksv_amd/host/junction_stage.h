@@ -37,6 +37,7 @@ void reverse_complement(std::string &seq);       // GetReverseComplementSeq, cli
 
 // InputSoftInfoStoreBreakpoint (getsv.h:423-541) + GetAlignInfo (getsv.cpp:25) + GetJunction (getsv.cpp:1705).  Returns "" or an error text.
 std::string assemble_junctions(const std::string &clipfile, const std::string &clip_bam, JunctionMap &junction2other);
+std::string assemble_junctions_text(const std::string &clip_rows, const std::string &clip_bam, JunctionMap &junction2other); // the rows of clip.gz in memory
 // MergeJunction, getsv.cpp:1325-1482
 void merge_junctions(JunctionMap &junction2other, int search_length);
 

@@ -20,7 +20,11 @@
 #include <fstream>
 #include <iostream>
 #include <deque>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
+#include <atomic>
 #include "../csrc/cpus.h"
 #include <map>
 #include <sstream>
@@ -219,6 +223,9 @@ struct ResidentBam {
 	ssv_ctx *ctx = nullptr;      // the context every command of the process shares
 	bool collect = false;        // getclip keeps what it decodes
 	vector<ssv_batch_t> batches; // in file order
+	// what getclip wrote, still in memory for the steps that follow (the files are written all the same: they are outputs)
+	string clip_path, fq_path;   // prefix.clip.gz, prefix.clip.fq.gz
+	string clip_rows, fq_text;   // their decompressed contents
 };
 static ResidentBam g_resident;
 
@@ -570,6 +577,11 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 		}
 		pt.lap("format");
 		softfout.write_parts(rows); fqfout.write_parts(fqs);
+		if (g_resident.collect && g_resident.ctx == ctx) { // `seeksv run`: the aligner step and the junction stage read these from memory
+			g_resident.clip_path = f_clip; g_resident.fq_path = f_fq;
+			for (auto &r : rows) g_resident.clip_rows += r;
+			for (auto &r : fqs) g_resident.fq_text += r;
+		}
 		pass_flushes.clear();
 		if (!last) pt.lap("gzip");
 	};
@@ -880,7 +892,8 @@ static int cmd_getsv(int argc, char **argv)
 		cerr << "[ReadBreakpoint] finish" << endl;
 	}
 	{ // InputSoftInfoStoreBreakpoint + GetJunction (getsv.h:423, getsv.cpp:1705): clip clusters x re-alignments of their clipped sequences
-		string err = seeksv::assemble_junctions(clipfile, clip_bam, junction2other);
+		string err = g_resident.ctx && clipfile == g_resident.clip_path ? seeksv::assemble_junctions_text(g_resident.clip_rows, clip_bam, junction2other)
+		                                                               : seeksv::assemble_junctions(clipfile, clip_bam, junction2other);
 		if (!err.empty()) die(err);
 	}
 	cerr << "'InputSoftInfoStoreBreakpoint' finished" << endl;
@@ -1257,6 +1270,102 @@ static bool gz_getline(gzFile f, string &line)
 	return !line.empty();
 }
 
+// A plain (not gzip'ed) FASTA file through all host threads: the file is mapped, cut into pieces at line starts; every piece counts its bases,
+// a running sum gives each piece its first base index, then the pieces write their 2-bit codes (the words that two pieces share are OR-ed
+// in atomically).  One thread parsing character by character took 2.8 s for an eighth of a human genome.  Same result as the serial loop
+// (anything but ACGT becomes the same position-dependent pseudo-random base).  false: not a plain file (the caller reads it through zlib).
+static bool parse_fasta_parallel(const string &path, vector<string> &names, vector<int32_t> &lens, vector<int64_t> &offs, vector<uint64_t> &words)
+{
+	int fd = ::open(path.c_str(), O_RDONLY);
+	if (fd < 0) return false;
+	struct stat st;
+	if (fstat(fd, &st) != 0 || st.st_size < 2) { ::close(fd); return false; }
+	const size_t size = (size_t)st.st_size;
+	const char *t = static_cast<const char *>(mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0));
+	::close(fd);
+	if (t == MAP_FAILED) return false;
+	if ((unsigned char)t[0] == 0x1f && (unsigned char)t[1] == 0x8b) { munmap(const_cast<char *>(t), size); return false; } // gzip
+	const int nt = std::max(1, std::min(ssv::effective_cpus(), 64));
+	const size_t n_pieces = std::max<size_t>(1, std::min<size_t>((size_t)nt * 8, size / (1 << 20) + 1));
+	vector<size_t> cut(n_pieces + 1, size);
+	cut[0] = 0;
+	for (size_t k = 1; k < n_pieces; ++k) { // the line start at or behind the k-th share of the file
+		size_t p = size * k / n_pieces;
+		const void *nl = p < size ? memchr(t + p, '\n', size - p) : nullptr;
+		cut[k] = nl ? (size_t)(static_cast<const char *>(nl) - t) + 1 : size;
+	}
+	struct Hdr { size_t at; int64_t bases_before_in_piece; string name; };
+	vector<int64_t> n_bases(n_pieces, 0);
+	vector<vector<Hdr>> hdrs(n_pieces);
+	auto run = [&](auto fn) {
+		std::atomic<size_t> next{0};
+		vector<std::thread> th;
+		auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < n_pieces;) fn(k); };
+		for (int w = 1; w < nt; ++w) th.emplace_back(work);
+		work();
+		for (auto &x : th) x.join();
+	};
+	run([&](size_t k) { // pass 1: bases and header lines of piece k
+		int64_t nb = 0;
+		for (size_t p = cut[k]; p < cut[k + 1];) {
+			const void *nl = memchr(t + p, '\n', cut[k + 1] - p);
+			const size_t e = nl ? (size_t)(static_cast<const char *>(nl) - t) : cut[k + 1];
+			if (t[p] == '>') {
+				size_t w = p + 1;
+				while (w < e && t[w] != ' ' && t[w] != '\t' && t[w] != '\r') ++w;
+				hdrs[k].push_back(Hdr{p, nb, string(t + p + 1, w - p - 1)});
+			} else {
+				size_t len = e - p;
+				if (len && t[e - 1] == '\r') --len;
+				nb += (int64_t)len;
+			}
+			p = e + 1;
+		}
+		n_bases[k] = nb;
+	});
+	vector<int64_t> first(n_pieces + 1, 0);
+	for (size_t k = 0; k < n_pieces; ++k) first[k + 1] = first[k] + n_bases[k];
+	const int64_t total = first[n_pieces];
+	if (hdrs[0].empty() || hdrs[0][0].at != 0) { munmap(const_cast<char *>(t), size); if (total == 0 && hdrs[0].empty()) return false; die("Reference file " + path + " does not start with a '>' line"); }
+	for (size_t k = 0; k < n_pieces; ++k)
+		for (const Hdr &h : hdrs[k]) {
+			if (!names.empty()) { lens.push_back((int32_t)(first[k] + h.bases_before_in_piece - offs.back())); offs.push_back(first[k] + h.bases_before_in_piece); }
+			names.push_back(h.name);
+		}
+	lens.push_back((int32_t)(total - offs.back())); offs.push_back(total);
+	words.assign((size_t)((total + 31) / 32) + 1, 0);
+	run([&](size_t k) { // pass 2: the codes of piece k
+		int64_t n = first[k];
+		const int64_t n_end = first[k + 1];
+		uint64_t cur = 0;
+		auto flush = [&](int64_t word) { if (cur) { if (word == first[k] / 32 || word == (n_end - 1) / 32) __atomic_fetch_or(&words[(size_t)word], cur, __ATOMIC_RELAXED); else words[(size_t)word] = cur; cur = 0; } };
+		for (size_t p = cut[k]; p < cut[k + 1];) {
+			const void *nl = memchr(t + p, '\n', cut[k + 1] - p);
+			const size_t e = nl ? (size_t)(static_cast<const char *>(nl) - t) : cut[k + 1];
+			if (t[p] != '>') {
+				size_t stop = e;
+				if (stop > p && t[stop - 1] == '\r') --stop;
+				for (size_t i = p; i < stop; ++i, ++n) {
+					uint64_t two;
+					switch (t[i]) {
+					case 'A': case 'a': two = 0; break;
+					case 'C': case 'c': two = 1; break;
+					case 'G': case 'g': two = 2; break;
+					case 'T': case 't': two = 3; break;
+					default: { uint64_t h = (uint64_t)n * 0x9E3779B97F4A7C15ull; two = (h >> 61) & 3; }
+					}
+					cur |= two << (2 * (n & 31));
+					if ((n & 31) == 31) flush(n / 32);
+				}
+			}
+			p = e + 1;
+		}
+		if (n > first[k] && (n & 31) != 0) flush((n - 1) / 32);
+	});
+	munmap(const_cast<char *>(t), size);
+	return true;
+}
+
 static int cmd_realign(int argc, char **argv)
 {
 	int gpu = 0, c;
@@ -1271,7 +1380,11 @@ static int cmd_realign(int argc, char **argv)
 	vector<int32_t> lens;
 	vector<int64_t> offs(1, 0);
 	vector<uint64_t> words;
-	{
+	const bool fasta_check = getenv("SSV_FASTA_CHECK") != nullptr; // (tests: the serial reader runs too and must agree)
+	vector<string> p_names; vector<int32_t> p_lens; vector<int64_t> p_offs(1, 0); vector<uint64_t> p_words;
+	const bool parsed = parse_fasta_parallel(fasta, p_names, p_lens, p_offs, p_words);
+	if (parsed && !fasta_check) { names.swap(p_names); lens.swap(p_lens); offs.swap(p_offs); words.swap(p_words); }
+	else {
 		gzFile f = gzopen(fasta.c_str(), "rb");
 		if (!f) die("Cannot open reference file " + fasta);
 		string line;
@@ -1303,10 +1416,20 @@ static int cmd_realign(int argc, char **argv)
 		lens.push_back((int32_t)(n - offs.back())); offs.push_back(n);
 		words.push_back(0);
 	}
+	if (parsed && fasta_check && (names != p_names || lens != p_lens || offs != p_offs || words != p_words)) die("[seeksv] SSV_FASTA_CHECK: the parallel FASTA reader disagrees with the serial one");
 	pt.lap("read reference");
 	// ---- clipped sequences ----
 	vector<string> seqs, quals;
-	{
+	if (g_resident.ctx && fq == g_resident.fq_path) { // `seeksv run`: getclip's FASTQ text is still in memory
+		const string &t = g_resident.fq_text;
+		size_t at = 0;
+		auto line = [&](string &out) { if (at >= t.size()) return false; const size_t e = t.find('\n', at); out.assign(t, at, (e == string::npos ? t.size() : e) - at); at = e == string::npos ? t.size() : e + 1; return true; };
+		string l1, l2, l3, l4;
+		while (line(l1)) {
+			if (!line(l2) || !line(l3) || !line(l4)) die("Truncated FASTQ record in " + fq);
+			seqs.push_back(l2); quals.push_back(l4);
+		}
+	} else {
 		gzFile f = gzopen(fq.c_str(), "rb");
 		if (!f) die("Cannot open clipped reads file " + fq);
 		string l1, l2, l3, l4;

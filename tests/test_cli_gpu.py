@@ -241,7 +241,7 @@ def test_cli_run_equals_three_commands(tmp_path_factory, name, opts, inflate_mod
     r3 = subprocess.run([SEEKSV, "getsv"] + sv_o + [a + ".clip.bam", bam, a + ".clip.gz", a + ".sv.txt", a + ".unmapped.clip.fq"], capture_output=True, text=True)
     assert r3.returncode == 0, r3.stderr
     b = str(d / f"one_{tag}")
-    r = subprocess.run([SEEKSV, "run"] + opts + [bam, fa, b], capture_output=True, text=True)
+    r = subprocess.run([SEEKSV, "run"] + opts + [bam, fa, b], capture_output=True, text=True, env=dict(os.environ, SSV_FASTA_CHECK="1"))  # (the parallel FASTA reader against the serial one)
     assert r.returncode == 0, r.stderr
     for ext in (".clip.gz", ".clip.fq.gz", ".unmapped_1.fq.gz", ".unmapped_2.fq.gz"):
         assert gzip.open(a + ext, "rb").read() == gzip.open(b + ext, "rb").read(), ext
