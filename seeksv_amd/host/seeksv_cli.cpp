@@ -812,15 +812,24 @@ static double largest_base_frequency(const string &seq) // CountLargestBaseFrequ
 }
 
 // CalculateInsertsizeDeviation (cluster.cpp:15-83) over the head of a BAM, with the reference's stderr lines
-static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation)
+// CalculateInsertsizeDeviation (cluster.cpp:15-83) reads the file until it has its pairs - usually inside the first chunk.  With the records decoded on the
+// GPU (or resident there) that chunk's batch is still valid when the statistics are known: `keep` then holds the open source and the batch, and the
+// fused pass scans it and goes on from the second chunk instead of reading, inflating and decoding the first one again.
+struct IsizeCarry { BatchSource src; ssv_batch_t first; bool usable = false; };
+
+static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation, IsizeCarry *keep = nullptr)
 {
-	BatchSource src;
+	BatchSource local;
+	BatchSource &src = keep ? keep->src : local;
 	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 	ssv_isize_begin(ctx, min_mapQ, read_pair_used);
 	int32_t done = 0;
+	int chunks = 0;
+	ssv_batch_t b;
+	memset(&b, 0, sizeof(b));
 	while (!done) {
-		ssv_batch_t b;
 		if (!src.next(&b, 0)) break;
+		++chunks;
 		if (ssv_isize_accumulate(ctx, &b, &done) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 	}
 	int64_t n; int32_t m = 0, sd = 0;
@@ -829,6 +838,7 @@ static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_in
 		mean_insert_size = m; deviation = sd;
 		cerr << "Bam/sam " << bamfile << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << endl;
 	}
+	if (keep && src.on_device && chunks == 1) { keep->first = b; keep->usable = true; return; } // (a device batch stays valid until the next decode)
 	src.close();
 }
 
@@ -917,8 +927,9 @@ static int cmd_getsv(int argc, char **argv)
 	pt.lap("open+gpu_init");
 	int mean_insert_size = 0, deviation = 0;
 	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
+	IsizeCarry carry;
 	if (do_discordant) {
-		insert_size_pass(ctx, original_bam, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation);
+		insert_size_pass(ctx, original_bam, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation, n_ranks == 1 ? &carry : nullptr);
 		cerr << "'CalculateInsertsizeDeviation' finished" << endl;
 	} else min_abnormal_read_pair_no = 0; // seeksv.cpp:285
 
@@ -1048,16 +1059,23 @@ static int cmd_getsv(int argc, char **argv)
 		gp.windows = dw; gp.n_windows = output_depth ? nw : 0; gp.depth_min_mapq = min_mapQ;
 		gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		BatchSource src; // a second handle: `bam` keeps serving the header
-		src.open(original_bam, ctx, device_inflate, "[main_samview] fail to open file for reading.");
-		src.pump(0, [](const ssv_batch_t &) {}, [&](const ssv_batch_t &b) {
-			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		});
-		src.close();
+		auto scan = [&](const ssv_batch_t &b) { if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx)); };
+		if (carry.usable) { // the insert-size pass left its source open behind the file's first chunk, whose batch is still valid
+			scan(carry.first);
+			carry.src.pump(0, [](const ssv_batch_t &) {}, scan);
+			carry.src.close();
+			carry.usable = false;
+		} else {
+			BatchSource src; // a second handle: `bam` keeps serving the header
+			src.open(original_bam, ctx, device_inflate, "[main_samview] fail to open file for reading.");
+			src.pump(0, [](const ssv_batch_t &) {}, scan);
+			src.close();
+		}
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, do_discordant ? counts.data() : nullptr, dr, output_depth ? nr : 0, rsum.data(), dp, output_depth ? np : 0, pdepth.data(), &maxd) != SSV_OK)
 			die(string("[seeksv] ") + ssv_last_error(ctx));
 	}
+	if (carry.usable) { carry.src.close(); carry.usable = false; }
 	pt.lap("fused_pass");
 	if (do_discordant) { cerr << "'StoreSeqName2Tid' finished" << endl; cerr << "'FindDiscordantReadPairs' finished" << endl; }
 	if (output_depth) { cerr << "'MergeOverlap' finished" << endl; cerr << "'main_depth' finished" << endl; }

@@ -199,6 +199,28 @@ class Workload:
             out.append(f">{name}\n" + "\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)) + "\n")
         return "".join(out)
 
+    def write_fasta(self, path, threads=8):
+        """the hash-generated reference as a FASTA file, 80 columns, generated in pieces by `threads` host threads (the same text as reference_fasta())"""
+        from concurrent.futures import ThreadPoolExecutor
+        lib = _lib(False)
+        lib.ssvs_ref_bases.argtypes = [C.POINTER(SyConfig), C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
+        PIECE = 8_000_000   # a multiple of 80
+
+        def piece(args):
+            tid, start, n = args
+            buf = np.empty(n, np.uint8)
+            lib.ssvs_ref_bases(C.byref(self.cfg), tid, start, n, buf.ctypes.data)
+            full = n // 80 * 80
+            body = np.empty((full // 80, 81), np.uint8)
+            body[:, :80] = buf[:full].reshape(-1, 80)
+            body[:, 80] = 10
+            return body.tobytes() + buf[full:].tobytes() + (b"\n" if n > full else b"")
+        with open(path, "wb") as f, ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+            for tid, (name, ln) in enumerate(zip(self.names, self.lens)):
+                f.write(f">{name}\n".encode())
+                for chunk in ex.map(piece, [(tid, s, min(PIECE, int(ln) - s)) for s in range(0, int(ln), PIECE)]):
+                    f.write(chunk)
+
     def reference_2bit(self, device=None):
         """The reference in the re-aligner's layout (ssv_realign_index): -> (words, target_off).  device=None: numpy uint64 array;
         device=k: torch int64 tensor resident on GPU k (SSV_MEM_DEVICE), generated there."""

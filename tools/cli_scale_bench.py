@@ -32,31 +32,6 @@ def phases(stderr):
     return out
 
 
-def write_fasta(w, path):
-    """the hash-generated reference as FASTA, 80 columns (contigs generated by all CPUs at once)"""
-    import ctypes as C
-    lib = synth._lib(False)
-    lib.ssvs_ref_bases.argtypes = [C.POINTER(synth.SyConfig), C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
-    PIECE = 8_000_000   # a multiple of 80
-
-    def piece(args):
-        tid, start, n = args
-        buf = np.empty(n, np.uint8)
-        lib.ssvs_ref_bases(C.byref(w.cfg), tid, start, n, buf.ctypes.data)
-        full = n // 80 * 80
-        body = np.empty((full // 80, 81), np.uint8)
-        body[:, :80] = buf[:full].reshape(-1, 80)
-        body[:, 80] = 10
-        tail = buf[full:].tobytes() + (b"\n" if n > full else b"")
-        return body.tobytes() + tail
-    with open(path, "wb") as f, ThreadPoolExecutor(max_workers=bench.effective_cpus()) as ex:
-        for tid, (name, ln) in enumerate(zip(w.names, w.lens)):
-            f.write(f">{name}\n".encode())
-            jobs = [(tid, s, min(PIECE, int(ln) - s)) for s in range(0, int(ln), PIECE)]
-            for chunk in ex.map(piece, jobs):
-                f.write(chunk)
-
-
 def main():
     frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.125
     level = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -82,7 +57,7 @@ def main():
         out["bam_bytes_per_record"] = round(out["bam_bytes"] / w.n_total, 2)
         t0 = time.perf_counter()
         fa = os.path.join(d, "ref.fa")
-        write_fasta(w, fa)
+        w.write_fasta(fa, cores)
         out["write_fasta_s"] = round(time.perf_counter() - t0, 1)
         jfile = os.path.join(d, "junctions.txt")
         with open(jfile, "w") as f:
