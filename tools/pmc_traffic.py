@@ -5,7 +5,7 @@ into profiles/<tag>_pmc_fetch_write.csv (per kernel) and profiles/traffic.json (
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <records> <steps> [tag]
   each dir holds <something>_counter_collection.csv as written by
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dir> -o x -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap
-  (steps = the steps that run of bench.py executed: timed + breakdown = 1 + 3)
+  (steps = the steps that run of bench.py executed: setup 4 - warmup, timed, breakdown = 4 + 1 + 3 = 8 with --warmup 0 --steps 1: the dispatch count of k_getsv_scan in the trace)
 FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE shows exactly half the bytes of a
 wide coalesced streaming read (16 B/lane), so it is doubled for the two streaming scans, whose loads are all of that kind; other
 kernels' loads are scattered 16-byte quarters of 64-byte lines or narrower and are taken as reported (uncalibrated)."""
