@@ -33,14 +33,15 @@ PATH_BYTES_PER_RECORD = 40.0
 # HBM bytes each kernel group must move per unit with the implemented algorithm; unit = what the group's launches process.
 #   clip_scan   : cigar_ends 1 per record - only records with an S at either end of the CIGAR (~1 %) go on (without that column:
 #                 n_cigar 2 per record, ~3 % go on)                                                                                   = 1 B/record
-#   getsv_scan  : tid 4 + pos 4 per record (tile map stays in L2)                                                                   = 8 B/record
+#   getsv_scan  : pos 4 per record (tile map stays in L2); the tid column comes as runs with the batch (ssv_batch_t.tid_runs: one per contig) and is read
+#                 only in the tiles a run boundary falls into (without runs: tid 4 + pos 4 = 8 B/record)                             = 4 B/record
 #   clip_place  : per candidate: staged index 4 + 4, record line 64, count 1; per event (0.31 per candidate): line 64 + staged key 16 written,
 #                 staged key 16 read, side-list key 12 + (l_qseq, n_cigar) 8 + slot 4 written                                        = 110 B/candidate
 #   event_sort  : '3' events (half): one windowed rank pass (12 read + 12 written + check 12); all: key 12 + line 64 read, 8 + 64 written = 166 B/event
 #   cluster_pack: the byte-by-byte model (line 32 + 9, sizes 16; two scans 48; line 64 + 30, row 12 + descriptor 32 + CIGAR 10; descriptor 32 + read 228 +
 #                 block 100 = 613 B/slot) overstates what the kernels move: the PMC passes count 2.56 GB for 5.69 M slots (profiles/traffic.json: caches
 #                 serve the second look at a line)                                                                                    = 450 B/slot (measured)
-ALGO_BYTES = {"clip_scan": 1.0, "getsv_scan": 8.0, "clip_place": 110.0, "event_sort": 166.0, "cluster_pack": 450.0}
+ALGO_BYTES = {"clip_scan": 1.0, "getsv_scan": 4.0, "clip_place": 110.0, "event_sort": 166.0, "cluster_pack": 450.0}
 DEVICE_GROUPS = ("clip_scan", "clip_place", "clip_gather", "event_sort", "cluster_bins", "cluster_pack", "isize_stats", "getsv_scan", "getsv_cand", "depth_finish")
 
 
@@ -126,6 +127,7 @@ def main():
             arrays[name] = ptr if name in ("cigar", "seqqual", "xc") or ptr is None else ptr + first * np.dtype(dt).itemsize
         arrays["rec"] = batch.rec + first * 64 if batch.rec else None
         arrays["n_cigar_total"], arrays["seqqual_bytes"], arrays["max_ref_span"] = batch.n_cigar_total, batch.seqqual_bytes, batch.max_ref_span
+        arrays["tid_runs"] = _abi.rebase_runs(batch.get_tid_runs(), first, n)
         return _abi.make_batch(arrays, mem=batch.mem, n=n)[0]
 
     own_batch = sub_batch(scan_batch, sp["own_lo_rec"] - sp["scan_lo_rec"], n_own)
@@ -359,7 +361,7 @@ def main():
                        "records_total": total_records, "records_per_gpu": n_own, "junctions": len(w.junctions), "parallelism": f"range-partition x{world}",
                        "multi_gpu": (f"strong scaling (--scaling strong): BASELINE config 4 - the fixed {args.strong_depth:g}x sample split {world} ways by reference interval, halo at the cuts, one all-gather" if strong else
                                      "weak scaling (default): 30x per GPU over the same genome (N GPUs = 30N x); `--scaling strong` runs BASELINE config 4's fixed 300x sample split N ways"),
-                       "batch_layout": "hot columns tid/pos/n_cigar + cigar_ends (a one-byte copy of the first and last CIGAR operation codes: the getclip stream reads it instead of n_cigar and applies the soft-clip test to every record) + one 64-byte line per record (ssv_record) + CIGARs + packed bases/qualities of soft-clipped records; SSV_MEM_PERSISTENT",
+                       "batch_layout": "hot columns tid/pos/n_cigar + cigar_ends (a one-byte copy of the first and last CIGAR operation codes: the getclip stream reads it and applies the soft-clip test to every record) + the tid column also as runs (one per contig: the getsv stream reads pos only) + one 64-byte line per record (ssv_record) + CIGARs + packed bases/qualities of soft-clipped records; SSV_MEM_PERSISTENT",
                        "host_cpus_bound_near_gpu": near_cpus, "generation_s": round(gen_s, 2)},
             "roofline": {"kernel": "path: all device kernels of one step (getclip + insert size + getsv passes; PCIe copy excluded)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": total_traffic,

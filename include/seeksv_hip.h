@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SSV_ABI_VERSION 4
+#define SSV_ABI_VERSION 5
 
 typedef enum {
 	SSV_OK = 0,
@@ -104,7 +104,16 @@ typedef struct {
 	                              The streaming pass of getclip reads this byte per record and passes on the records with an `S` at either
 	                              end (1 % of a WGS sample).  NULL: the library builds the column from the record lines first (64 B/record
 	                              instead of 1: fill it where the records are parsed anyway). */
+	const struct ssv_tid_run *tid_runs; /* [n_tid_runs] or NULL, HOST memory whatever `mem` says (it is a handful of entries): the tid column as runs -
+	                              run k covers the records [tid_runs[k].first, tid_runs[k + 1].first) (the last one up to n), all on contig
+	                              tid_runs[k].tid; tid_runs[0].first == 0, firsts strictly increasing.  A coordinate-sorted BAM has one run per
+	                              contig, and the batcher sees the changes while it parses the records anyway.  With it (up to 48 runs) the
+	                              streaming pass of getsv does not read the tid column at all - 4 of its 8 bytes per record - except in the
+	                              few tiles a run boundary falls into; the column must still be there (other passes read single entries). */
+	int64_t n_tid_runs;
 } ssv_batch_t;
+
+typedef struct ssv_tid_run { int64_t first; int32_t tid; int32_t pad; } ssv_tid_run;
 
 typedef struct ssv_ctx ssv_ctx; /* opaque */
 

@@ -31,7 +31,47 @@ class Batch(C.Structure):
         ("seq_off", C.c_void_p), ("seqqual", C.c_void_p),
         ("n_cigar_total", C.c_int64), ("seqqual_bytes", C.c_int64),
         ("rec", C.c_void_p), ("cigar_ends", C.c_void_p),
+        ("tid_runs", C.c_void_p), ("n_tid_runs", C.c_int64),
     ]
+
+    def set_tid_runs(self, runs):
+        """runs: TID_RUN_DTYPE array (host memory, kept alive with the struct) or None"""
+        if runs is None or len(runs) == 0:
+            self.tid_runs, self.n_tid_runs, self._runs = None, 0, None
+        else:
+            self._runs = np.ascontiguousarray(runs, dtype=TID_RUN_DTYPE)
+            self.tid_runs, self.n_tid_runs = self._runs.ctypes.data, len(self._runs)
+
+    def get_tid_runs(self):
+        """-> TID_RUN_DTYPE array (a copy) or None"""
+        if not self.tid_runs or self.n_tid_runs <= 0:
+            return None
+        return np.frombuffer((C.c_uint8 * (16 * self.n_tid_runs)).from_address(self.tid_runs), dtype=TID_RUN_DTYPE).copy()
+
+
+TID_RUN_DTYPE = np.dtype([("first", np.int64), ("tid", np.int32), ("pad", np.int32)])   # ssv_tid_run
+
+
+def runs_of_tid(tid):
+    """the tid column (numpy array) as runs: ssv_batch_t.tid_runs"""
+    tid = np.asarray(tid)
+    if tid.size == 0:
+        return np.zeros(0, TID_RUN_DTYPE)
+    starts = np.concatenate(([0], np.flatnonzero(tid[1:] != tid[:-1]) + 1))
+    r = np.zeros(len(starts), TID_RUN_DTYPE)
+    r["first"], r["tid"] = starts, tid[starts]
+    return r
+
+
+def rebase_runs(runs, first, n):
+    """the runs of records [first, first + n) of a batch whose runs are `runs`"""
+    if runs is None or len(runs) == 0 or n <= 0:
+        return None
+    k0 = int(np.searchsorted(runs["first"], first, side="right")) - 1
+    k1 = int(np.searchsorted(runs["first"], first + n, side="left"))
+    r = runs[k0:k1].copy()
+    r["first"] = np.maximum(r["first"] - first, 0)
+    return r
 
 
 BATCH_FIELDS = [  # (name, numpy dtype) in struct order
@@ -146,6 +186,10 @@ def make_batch(arrays, mem=MEM_HOST, n=None):
     b.n = int(n)
     b.n_cigar_total = int(arrays["n_cigar_total"]) if "n_cigar_total" in arrays else int(len(arrays["cigar"]))
     b.seqqual_bytes = int(arrays["seqqual_bytes"]) if "seqqual_bytes" in arrays else (int(len(arrays["seqqual"])) if arrays.get("seqqual") is not None else 0)
+    runs = arrays.get("tid_runs")
+    if runs is None and isinstance(arrays.get("tid"), np.ndarray) and not arrays.get("no_tid_runs"):
+        runs = runs_of_tid(arrays["tid"][:b.n])     # a host batch: the batcher (here: this function) sees the column anyway
+    b.set_tid_runs(runs if runs is not None and len(runs) <= 48 else None)
     return b, keep
 
 

@@ -1116,6 +1116,20 @@ __global__ __launch_bounds__(BLOCK) void k_raw_copy(const uint8_t *__restrict__ 
 struct TidRun { uint32_t index; int32_t tid; };
 constexpr int32_t TID_NONE = INT32_MIN;
 
+// the tid column as runs (ssv_batch_t.tid_runs): the records where the contig changes, record 0 included; a handful in a sorted file
+// (*count may exceed cap: then the list is incomplete and is not handed out)
+__global__ __launch_bounds__(BLOCK) void k_tid_raw_runs(const int32_t *__restrict__ tid, int64_t n, TidRun *__restrict__ runs, uint32_t cap, uint32_t *__restrict__ count)
+{
+	const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const int32_t t = tid[i];
+	if (i == 0 || tid[i - 1] != t) {
+		const uint32_t k = atomicAdd(count, 1u);
+		if (k < cap) { runs[k].index = (uint32_t)i; runs[k].tid = t; }
+	}
+}
+
+
 __global__ __launch_bounds__(BLOCK) void k_tid_tile_last(const int32_t *__restrict__ tid, const uint16_t *__restrict__ flag, int64_t n, int32_t *__restrict__ tile_last)
 {
 	__shared__ int lds[WAVES_PER_BLOCK];

@@ -106,8 +106,17 @@ struct DevJunction { // sorted by (up_tid, beg)
 	int32_t orig; // index in the caller's junction array
 };
 
+// the batch's tid column as runs (ssv_batch_t.tid_runs), by value in the kernel arguments: run k = records [first[k], first[k + 1]) on contig tid[k]
+constexpr int RUN_MAX = 48;
+struct RunTab {
+	int32_t n;               // 0: no runs given (or more than RUN_MAX): the tid column is read
+	int32_t tid[RUN_MAX];
+	int64_t first[RUN_MAX + 1]; // first[n] = records of the batch
+};
+
 struct GetsvArgs {
 	DevBatch b;
+	RunTab runs;
 	// genome tile map: which 512-bp tiles can hold the START of a record that matters (windows are extended to the left by
 	// the longest reference span when the map is built, so one lookup per record is enough)
 	const uint8_t *tilemap;
@@ -326,10 +335,27 @@ struct GetsvStage {
 // the record's start tile up in the genome tile map (L2 resident, wave-coherent because the BAM is coordinate sorted) and writes the
 // indices of the ~1 % of records that start near a depth window or a junction window.  Same persistent, atomic-free structure as
 // k_clip_scan; the lookups are branch-free (clamped indices) so that they pipeline.
-__device__ __forceinline__ void getsv_scan_load(const DevBatch &b, int64_t tile, int4 (&t4)[CS_SUB], int4 (&p4)[CS_SUB])
+// Does the whole tile lie inside ONE run of the tid column (then its contig is known without reading the column)?  Workgroup-uniform: a binary
+// search over the <= 48 run starts in the kernel arguments (scalar loads).  -1: no (no runs given, or a run boundary falls into the tile).
+__device__ __forceinline__ int tile_run_tid(const RunTab &R, int64_t tile, int64_t n)
+{
+	if (R.n <= 0) return -1;
+	const int64_t i0 = tile * CS_TILE, i1 = (tile + 1) * CS_TILE < n ? (tile + 1) * CS_TILE : n;
+	int lo = 0, hi = R.n - 1;
+	while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (R.first[m] <= i0) lo = m; else hi = m - 1; }
+	return R.first[lo + 1] >= i1 && R.tid[lo] >= 0 ? R.tid[lo] : -1;
+}
+
+__device__ __forceinline__ void getsv_scan_load(const DevBatch &b, int64_t tile, int4 (&t4)[CS_SUB], int4 (&p4)[CS_SUB], int run_tid)
 {
 	const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
-	if ((tile + 1) * CS_TILE <= b.n) { // workgroup-uniform
+	if ((tile + 1) * CS_TILE <= b.n && run_tid >= 0) { // workgroup-uniform: the tile's contig is known from the runs: 4 B/record
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			t4[sub] = make_int4(run_tid, run_tid, run_tid, run_tid);
+			p4[sub] = stream_load_i4(b.pos + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
+		}
+	} else if ((tile + 1) * CS_TILE <= b.n) { // workgroup-uniform
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) {
 			t4[sub] = stream_load_i4(b.tid + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
@@ -356,11 +382,11 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 	const int64_t region = (int64_t)blockIdx.x * g.block_cap;
 	const int last_tid = a.n_targets - 1;
 	int4 t4[CS_SUB], p4[CS_SUB], nt4[CS_SUB], np4[CS_SUB];
-	if ((int64_t)blockIdx.x < g.ntiles) getsv_scan_load(b, blockIdx.x, t4, p4);
+	if ((int64_t)blockIdx.x < g.ntiles) getsv_scan_load(b, blockIdx.x, t4, p4, tile_run_tid(a.runs, blockIdx.x, b.n));
 	for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, parity ^= 1) {
 		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
 		const int64_t next = tile + gridDim.x;
-		if (next < g.ntiles) getsv_scan_load(b, next, nt4, np4); // software pipeline, as in k_clip_scan
+		if (next < g.ntiles) getsv_scan_load(b, next, nt4, np4, tile_run_tid(a.runs, next, b.n)); // software pipeline, as in k_clip_scan
 		uint32_t mask = 0;
 		uint64_t packed = 0;
 		// Fast path (coordinate-sorted input at WGS depth): every record of this wavefront's share of the tile is on one contig and

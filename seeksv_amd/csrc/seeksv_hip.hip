@@ -442,6 +442,22 @@ int ensure_events(ssv_ctx *c, int64_t need)
 	return SSV_OK;
 }
 
+// ssv_batch_t.tid_runs -> the kernel's table (checked: a wrong run list would silently move records to another contig)
+int fill_runs(ssv_ctx *c, const ssv_batch_t *b, RunTab &R)
+{
+	memset(&R, 0, sizeof(R));
+	if (!b->tid_runs || b->n_tid_runs <= 0 || b->n_tid_runs > RUN_MAX || getenv("SSV_NO_TID_RUNS")) return SSV_OK;
+	const int64_t k = b->n_tid_runs;
+	if (b->tid_runs[0].first != 0) { c->err = "tid_runs must start at record 0"; return SSV_E_ARG; }
+	for (int64_t i = 0; i < k; ++i) {
+		if (i && b->tid_runs[i].first <= b->tid_runs[i - 1].first) { c->err = "tid_runs must be strictly increasing"; return SSV_E_ARG; }
+		if (b->tid_runs[i].first >= b->n) { c->err = "tid_runs reach past the batch"; return SSV_E_ARG; }
+		R.first[i] = b->tid_runs[i].first; R.tid[i] = b->tid_runs[i].tid;
+	}
+	R.first[k] = b->n; R.n = (int32_t)k;
+	return SSV_OK;
+}
+
 __global__ void k_max_span(DevBatch b, int *out)
 {
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,6 +772,10 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 	out->tid = reinterpret_cast<const int32_t *>(slab + off[0]); out->pos = reinterpret_cast<const int32_t *>(slab + off[1]); out->n_cigar = reinterpret_cast<const uint16_t *>(slab + off[2]);
 	out->cigar_ends = slab + off[3]; out->rec = reinterpret_cast<const ssv_record *>(slab + off[4]); out->cigar = reinterpret_cast<const uint32_t *>(slab + off[5]);
 	out->seqqual = slab + off[6]; out->n_cigar_total = b->n_cigar_total; out->seqqual_bytes = b->seqqual_bytes;
+	if (b->tid_runs && b->n_tid_runs > 0) { // (host memory: a copy that lives as long as the batch)
+		ssv_tid_run *r = static_cast<ssv_tid_run *>(malloc((size_t)b->n_tid_runs * sizeof(ssv_tid_run)));
+		if (r) { memcpy(r, b->tid_runs, (size_t)b->n_tid_runs * sizeof(ssv_tid_run)); out->tid_runs = r; out->n_tid_runs = b->n_tid_runs; }
+	}
 	return SSV_OK;
 }
 
@@ -766,6 +786,7 @@ int ssv_batch_release(ssv_ctx *c, ssv_batch_t *b)
 	HIPCHECK(c, hipSetDevice(c->device));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
 	HIPCHECK(c, hipFree(const_cast<int32_t *>(b->tid))); // the slab starts with the tid column
+	free(const_cast<ssv_tid_run *>(b->tid_runs));
 	memset(b, 0, sizeof(*b));
 	return SSV_OK;
 }
@@ -1462,6 +1483,7 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	}
 	if (span > c->gs_map_span) CHECK(gs_build_tilemap(c, span));
 	GetsvArgs a;
+	CHECK(fill_runs(c, b, a.runs));
 	a.b = d; a.tilemap = P<uint8_t>(c->gs_tilemap); a.tile_win = P<uint32_t>(c->gs_tile_win); a.tile_junc = P<uint32_t>(c->gs_tile_junc); a.ctg_tile_off = P<int64_t>(c->gs_ctgoff); a.n_targets = c->gs_p.n_targets;
 	a.junc = P<DevJunction>(c->gs_djunc); a.n_junc = (int64_t)c->gs_junc.size(); a.junc_wmax = c->gs_wmax;
 	a.mean = c->gs_p.mean; a.sd = c->gs_p.sd; a.times = c->gs_p.times; a.disc_min_mapq = c->gs_p.disc_min_mapq;

@@ -417,6 +417,7 @@ struct ssvh_bam {
 		Col<uint32_t> cigar_off, cigar;
 		Col<uint64_t> seq_off;
 		std::vector<Unmapped> unmapped;
+		std::vector<ssv_tid_run> tid_runs; // the tid column as runs (ssv_batch_t.tid_runs)
 		void use(const HostAlloc *a) { tid.a = pos.a = l_qseq.a = mtid.a = mpos.a = isize.a = a; flag.a = n_cigar.a = a; mapq.a = xc.a = seqqual.a = ends.a = a; cigar_off.a = cigar.a = a; seq_off.a = a; }
 	} buf[3];
 	HostAlloc alloc;
@@ -850,6 +851,11 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 	out->isize = B.isize.data(); out->cigar_off = B.cigar_off.data(); out->cigar = B.cigar.data(); out->xc = B.xc.data();
 	out->seq_off = B.seq_off.data(); out->seqqual = B.seqqual.data(); out->cigar_ends = B.ends.data();
 	out->n_cigar_total = (int64_t)ctot; out->seqqual_bytes = (int64_t)stot;
+	// the tid column as runs: one per contig in a coordinate-sorted file (more than the consumer takes: left out, it then reads the column)
+	B.tid_runs.clear();
+	for (int64_t i = 0; i < n && B.tid_runs.size() <= 64; ++i)
+		if (i == 0 || B.tid.data()[i] != B.tid.data()[i - 1]) B.tid_runs.push_back(ssv_tid_run{i, B.tid.data()[i], 0});
+	if (!B.tid_runs.empty() && B.tid_runs.size() <= 64) { out->tid_runs = B.tid_runs.data(); out->n_tid_runs = (int64_t)B.tid_runs.size(); }
 	return 0;
 }
 

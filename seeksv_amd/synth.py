@@ -313,5 +313,17 @@ class Workload:
         arrays["n_cigar_total"] = nct.value
         arrays["seqqual_bytes"] = sqb.value
         arrays["max_ref_span"] = self.max_ref_span
+        # the tid column as runs (ssv_batch_t.tid_runs: a batcher sees the changes of contig while it writes the column)
+        if n > 1:
+            tt = t["tid"]
+            ch = (torch.nonzero(tt[1:] != tt[:-1]).flatten() + 1).cpu().numpy()
+            starts = np.concatenate(([0], ch)).astype(np.int64)
+            runs = np.zeros(len(starts), _abi.TID_RUN_DTYPE)
+            runs["first"], runs["tid"] = starts, tt[torch.from_numpy(starts).to(dev)].cpu().numpy()
+            arrays["tid_runs"] = runs
+        elif n == 1:
+            runs = np.zeros(1, _abi.TID_RUN_DTYPE)
+            runs["tid"] = int(t["tid"][0].item())
+            arrays["tid_runs"] = runs
         b, _ = _abi.make_batch(arrays, mem=_abi.MEM_DEVICE | (_abi.MEM_PERSISTENT if persistent else 0), n=n)
         return b, t

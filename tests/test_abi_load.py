@@ -23,7 +23,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ssv_abi_version() == 4
+    assert lib.ssv_abi_version() == 5
 
 
 def test_host_library_exports_every_declared_symbol():
@@ -35,7 +35,8 @@ def test_host_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_abi.Batch) == 8 + 4 + 4 + 14 * 8 + 16 + 8 + 8   # ... + rec + cigar_ends
+    assert C.sizeof(_abi.Batch) == 8 + 4 + 4 + 14 * 8 + 16 + 8 + 8 + 8 + 8   # ... + rec + cigar_ends + tid_runs + n_tid_runs
+    assert _abi.TID_RUN_DTYPE.itemsize == 16
     assert _abi.RECORD_DTYPE.itemsize == 64
     assert C.sizeof(_abi.Junction) == 28
     assert C.sizeof(_abi.ClipParams) == 40

@@ -33,6 +33,7 @@ def _sub(batch, first, n):
         arrays[name] = ptr if name in ("cigar", "seqqual", "xc") or ptr is None else ptr + first * np.dtype(dt).itemsize
     arrays["rec"] = batch.rec + first * 64 if batch.rec else None
     arrays["n_cigar_total"], arrays["seqqual_bytes"], arrays["max_ref_span"] = batch.n_cigar_total, batch.seqqual_bytes, batch.max_ref_span
+    arrays["tid_runs"] = _abi.rebase_runs(batch.get_tid_runs(), first, n)
     return _abi.make_batch(arrays, mem=batch.mem, n=n)[0]
 
 

@@ -543,3 +543,48 @@ def test_compact_table_wide_columns(ctx, source, monkeypatch):
         _compact_checks(ctx, d, ref, t, check_size=False)
     finally:
         ctx.clip_table_format(0)
+
+
+def test_getsv_scan_with_and_without_tid_runs(ctx, monkeypatch):
+    """ssv_batch_t.tid_runs (the tid column as runs: the streaming pass of getsv then reads pos only, 4 B/record instead of 8): same tallies and depths
+    as with the column read (SSV_NO_TID_RUNS), on a device batch of several contigs whose boundaries fall inside the kernel's 4096-record tiles,
+    whole and as sub-batches with rebased runs; malformed run lists are refused"""
+    import ctypes as C
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 2048, depth=30, n_sv=60, n_contigs=9, min_contig=20000)
+    db, keep = w.generate_device(0, w.n_total, 0)
+    runs = db.get_tid_runs()
+    assert runs is not None and len(runs) == 9 and runs["first"][0] == 0 and np.all(runs["first"][1:] % 4096 != 0)
+    hb = w.generate_host(0, w.n_total)
+    hdr = host.Header(w.names, w.lens)
+    stats = O.isize_stats([hb], 20, 5000000)
+    plan = host.Plan(hdr, w.junctions, stats[2], stats[3])
+    want = (O.discordant([hb], plan.junctions, stats[2], stats[3], 4, 20),) + O.depth([hb], plan.windows, plan.ranges, plan.points, 20)[:2]
+
+    def run(batches):
+        c, r, p = ctx.discordant_and_depth(batches, plan, stats[2], stats[3], 20, hdr.target_lens)
+        assert np.array_equal(c, want[0]) and np.array_equal(r, want[1]) and np.array_equal(p, want[2])
+    run([db])
+    monkeypatch.setenv("SSV_NO_TID_RUNS", "1")
+    run([db])
+    monkeypatch.delenv("SSV_NO_TID_RUNS")
+    # sub-batches (16-record aligned starts) with rebased runs
+    cuts = [0, 4096 * 3 + 16, (w.n_total // 2) & ~15, w.n_total]
+    parts = []
+    for i in range(3):
+        arrays = {name: (getattr(db, name) if name in ("cigar", "seqqual", "xc") or getattr(db, name) is None else getattr(db, name) + cuts[i] * np.dtype(dt).itemsize) for name, dt in _abi.BATCH_FIELDS}
+        arrays["rec"] = db.rec + cuts[i] * 64
+        arrays["n_cigar_total"], arrays["seqqual_bytes"], arrays["max_ref_span"] = db.n_cigar_total, db.seqqual_bytes, db.max_ref_span
+        arrays["tid_runs"] = _abi.rebase_runs(runs, cuts[i], cuts[i + 1] - cuts[i])
+        parts.append(_abi.make_batch(arrays, mem=db.mem, n=cuts[i + 1] - cuts[i])[0])
+        assert parts[-1].get_tid_runs()["first"][0] == 0
+    run(parts)
+    # malformed lists are refused, not believed
+    lib = _abi.hip_lib()
+    ctx.getsv_begin(plan.junctions, plan.windows, stats[2], stats[3], hdr.target_lens, 4, 20, 20)
+    for bad in (np.array([(5, 0, 0)], _abi.TID_RUN_DTYPE), np.array([(0, 0, 0), (0, 1, 0)], _abi.TID_RUN_DTYPE), np.array([(0, 0, 0), (w.n_total, 1, 0)], _abi.TID_RUN_DTYPE)):
+        db.set_tid_runs(bad)
+        assert lib.ssv_getsv_scan(ctx._h, C.byref(db)) == -3
+    db.set_tid_runs(runs)
+    plan.close()
+    hdr.close()
