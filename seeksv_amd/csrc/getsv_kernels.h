@@ -339,8 +339,8 @@ struct GetsvStage {
 // search over the <= 48 run starts in the kernel arguments (scalar loads).  -1: no (no runs given, or a run boundary falls into the tile).
 __device__ __forceinline__ int tile_run_tid(const RunTab &R, int64_t tile, int64_t n)
 {
-	if (R.n <= 0) return -1;
-	const int64_t i0 = tile * CS_TILE, i1 = (tile + 1) * CS_TILE < n ? (tile + 1) * CS_TILE : n;
+	if (R.n <= 0 || (tile + 1) * CS_TILE > n) return -1; // (the batch's last, partial tile reads the column)
+	const int64_t i0 = tile * CS_TILE, i1 = (tile + 1) * CS_TILE;
 	int lo = 0, hi = R.n - 1;
 	while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (R.first[m] <= i0) lo = m; else hi = m - 1; }
 	return R.first[lo + 1] >= i1 && R.tid[lo] >= 0 ? R.tid[lo] : -1;
@@ -349,7 +349,7 @@ __device__ __forceinline__ int tile_run_tid(const RunTab &R, int64_t tile, int64
 __device__ __forceinline__ void getsv_scan_load(const DevBatch &b, int64_t tile, int4 (&t4)[CS_SUB], int4 (&p4)[CS_SUB], int run_tid)
 {
 	const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
-	if ((tile + 1) * CS_TILE <= b.n && run_tid >= 0) { // workgroup-uniform: the tile's contig is known from the runs: 4 B/record
+	if (run_tid >= 0) { // workgroup-uniform: the tile's contig is known from the runs: 4 B/record
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) {
 			t4[sub] = make_int4(run_tid, run_tid, run_tid, run_tid);
@@ -382,29 +382,38 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 	const int64_t region = (int64_t)blockIdx.x * g.block_cap;
 	const int last_tid = a.n_targets - 1;
 	int4 t4[CS_SUB], p4[CS_SUB], nt4[CS_SUB], np4[CS_SUB];
-	if ((int64_t)blockIdx.x < g.ntiles) getsv_scan_load(b, blockIdx.x, t4, p4, tile_run_tid(a.runs, blockIdx.x, b.n));
+	int run = -1, nrun = -1; // the contig of the whole tile when the batch's runs say so (workgroup-uniform)
+	if ((int64_t)blockIdx.x < g.ntiles) { run = tile_run_tid(a.runs, blockIdx.x, b.n); getsv_scan_load(b, blockIdx.x, t4, p4, run); }
 	for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, parity ^= 1) {
 		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
 		const int64_t next = tile + gridDim.x;
-		if (next < g.ntiles) getsv_scan_load(b, next, nt4, np4, tile_run_tid(a.runs, next, b.n)); // software pipeline, as in k_clip_scan
+		if (next < g.ntiles) { nrun = tile_run_tid(a.runs, next, b.n); getsv_scan_load(b, next, nt4, np4, nrun); } // software pipeline, as in k_clip_scan
 		uint32_t mask = 0;
-		uint64_t packed = 0;
 		// Fast path (coordinate-sorted input at WGS depth): every record of this wavefront's share of the tile is on one contig and
 		// their start tiles span < 64 genome tiles.  Then 64 tile-map bytes are fetched once per wavefront (one byte per lane), turned
 		// into a wave-uniform 64-bit "tile is interesting" mask by a ballot, and each record only shifts that mask - no per-record
-		// memory access at all.
-		const int tid0 = __builtin_amdgcn_readfirstlane(t4[0].x);
+		// memory access at all: a shift, a subtract, a 64-bit shift and an and-or per record, plus a min / max for the span.
+		const int tid0 = run >= 0 ? run : __builtin_amdgcn_readfirstlane(t4[0].x);
 		bool same = true;
 		int pmin = 0x7fffffff, pmax = -1;
+		if (run >= 0) {
 #pragma unroll
-		for (int sub = 0; sub < CS_SUB; ++sub) {
-			const int tid[CS_ITEMS] = {t4[sub].x, t4[sub].y, t4[sub].z, t4[sub].w};
-			const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				pmin = min(pmin, min(min(p4[sub].x, p4[sub].y), min(p4[sub].z, p4[sub].w)));
+				pmax = max(pmax, max(max(p4[sub].x, p4[sub].y), max(p4[sub].z, p4[sub].w)));
+			}
+			same = pmin >= 0;
+		} else {
 #pragma unroll
-			for (int k = 0; k < CS_ITEMS; ++k) {
-				same = same && tid[k] == tid0 && pos[k] >= 0;
-				pmin = pos[k] < pmin ? pos[k] : pmin;
-				pmax = pos[k] > pmax ? pos[k] : pmax;
+			for (int sub = 0; sub < CS_SUB; ++sub) {
+				const int tid[CS_ITEMS] = {t4[sub].x, t4[sub].y, t4[sub].z, t4[sub].w};
+				const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
+#pragma unroll
+				for (int k = 0; k < CS_ITEMS; ++k) {
+					same = same && tid[k] == tid0 && pos[k] >= 0;
+					pmin = pos[k] < pmin ? pos[k] : pmin;
+					pmax = pos[k] > pmax ? pos[k] : pmax;
+				}
 			}
 		}
 		const bool uniform = __all(same) && tid0 >= 0 && tid0 <= last_tid;
@@ -419,18 +428,14 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 		if (uniform && wmax - wmin < WAVE) {
 			const int64_t lo = a.ctg_tile_off[tid0], hi = a.ctg_tile_off[tid0 + 1]; // wave-uniform addresses
 			const int64_t mine = lo + wmin + lane_id();
+			// (bit k = genome tile wmin + k of this contig; tiles past the contig's end stay 0, so a position beyond the contig is no candidate)
 			const uint64_t interesting = __ballot(mine < hi && a.tilemap[mine < hi ? mine : hi - 1] != 0);
-			const int ntile_ctg = (int)(hi - lo);
 #pragma unroll
 			for (int sub = 0; sub < CS_SUB; ++sub) {
 				const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
 #pragma unroll
-				for (int k = 0; k < CS_ITEMS; ++k) {
-					const int tl = pos[k] >> TILE_SHIFT;
-					const bool cand = tl < ntile_ctg && ((interesting >> (tl - wmin)) & 1ull);
-					mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
-					packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
-				}
+				for (int k = 0; k < CS_ITEMS; ++k) // 0 <= (pos >> 9) - wmin < 64 for every record of the wavefront
+					mask |= ((uint32_t)(interesting >> ((pos[k] >> TILE_SHIFT) - wmin)) & 1u) << (sub * CS_ITEMS + k);
 			}
 		} else {
 #pragma unroll
@@ -447,13 +452,16 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 					t = t < hi ? t : hi - 1;
 					const bool cand = valid && a.tilemap[t] != 0;
 					mask |= (cand ? 1u : 0u) << (sub * CS_ITEMS + k);
-					packed += (uint64_t)(cand ? 1u : 0u) << (16 * sub);
 				}
 			}
 		}
+		uint64_t packed = 0; // candidates per sub-tile, four 16-bit fields
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) packed |= (uint64_t)__popc((mask >> (sub * CS_ITEMS)) & ((1u << CS_ITEMS) - 1u)) << (16 * sub);
 		stage_tile_candidates<CS_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) { t4[sub] = nt4[sub]; p4[sub] = np4[sub]; }
+		run = nrun;
 	}
 }
 

@@ -550,7 +550,17 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	vector<int32_t> pass_flushes;       // contigs flushed during the current pass, in order
 	int32_t last_tid = 0, scan_last_tid = 0, pass_max_tid = 0; // (last_tid: the reader's side, one batch ahead of the scans)
 	std::deque<vector<pair<int64_t, int32_t>>> changes_of; // per batch that was read and not yet scanned (the host reader runs one batch ahead)
+	// The rows of a finished pass are formatted and compressed by a thread of their own while the main thread goes on reading and scanning the
+	// next pass (the table sits in one of the context's two table sets: the emitter of pass k is joined before pass k + 1 is clustered, which is
+	// when the library may touch that set again).  A coordinate-sorted BAM is one pass as far as the results go; it is cut at contig changes -
+	// where the reference flushes anyway - whenever SSV_PASS_RECORDS records (default 64 M) have gone into the pass, so that this overlap exists.
+	static const int64_t pass_records_max = [] { const char *e = getenv("SSV_PASS_RECORDS"); return e ? std::max<int64_t>(1, atoll(e)) : (int64_t)64 << 20; }();
+	int64_t pass_records = 0;
+	std::thread emitter;
+	double emit_format_s = 0, emit_gzip_s = 0;
 	auto emit_pass = [&](bool last) {
+		if (emitter.joinable()) emitter.join();
+		pt.lap("wait for the previous pass's output");
 		ssv_cluster_table t;
 		if (ssv_clip_cluster(ctx, &t) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (t.format == 3 && ssv_clip_table_expand(ctx, &t, 0) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
@@ -563,27 +573,33 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 			cerr << "Output merged soft-clipped reads of " << (name ? name : "") << endl;
 			for (; k_end < t.n_clusters && t.tid[k_end] == tid; ++k_end) {}
 		}
-		const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 32, k_end / 4096}));
-		vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
-		auto format_range = [&](int w) {
-			const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
-			format_clusters(t, bam, k0, k1, rows[(size_t)w], fqs[(size_t)w]);
-		};
-		{
-			vector<std::thread> th;
-			for (int w = 1; w < n_fmt; ++w) th.emplace_back(format_range, w);
-			format_range(0);
-			for (auto &x : th) x.join();
-		}
-		pt.lap("format");
-		softfout.write_parts(rows); fqfout.write_parts(fqs);
-		if (g_resident.collect && g_resident.ctx == ctx) { // `seeksv run`: the aligner step and the junction stage read these from memory
-			g_resident.clip_path = f_clip; g_resident.fq_path = f_fq;
-			for (auto &r : rows) g_resident.clip_rows += r;
-			for (auto &r : fqs) g_resident.fq_text += r;
-		}
 		pass_flushes.clear();
-		if (!last) pt.lap("gzip");
+		pass_records = 0;
+		emitter = std::thread([&, t, k_end] {
+			const auto t0 = std::chrono::steady_clock::now();
+			const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 32, k_end / 4096}));
+			vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
+			auto format_range = [&](int w) {
+				const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
+				format_clusters(t, bam, k0, k1, rows[(size_t)w], fqs[(size_t)w]);
+			};
+			{
+				vector<std::thread> th;
+				for (int w = 1; w < n_fmt; ++w) th.emplace_back(format_range, w);
+				format_range(0);
+				for (auto &x : th) x.join();
+			}
+			const auto t1 = std::chrono::steady_clock::now();
+			softfout.write_parts(rows); fqfout.write_parts(fqs);
+			if (g_resident.collect && g_resident.ctx == ctx) { // `seeksv run`: the aligner step and the junction stage read these from memory
+				g_resident.clip_path = f_clip; g_resident.fq_path = f_fq;
+				for (auto &r : rows) g_resident.clip_rows += r;
+				for (auto &r : fqs) g_resident.fq_text += r;
+			}
+			emit_format_s += std::chrono::duration<double>(t1 - t0).count();
+			emit_gzip_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+		});
+		if (last) { emitter.join(); pt.lap("wait for the last pass's output"); }
 	};
 	src.pump(0, [&](const ssv_batch_t &b) {
 		pt.lap(device_inflate ? "bam_read(wait)+gpu_inflate+decode" : "bam_read(wait)");
@@ -613,7 +629,7 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 		int64_t lo = 0;
 		for (const auto &ch : changes_of.front()) {
 			pass_flushes.push_back(scan_last_tid); // the visit that ends here is flushed
-			if (ch.second <= pass_max_tid) {       // a contig that comes back: the pass ends in front of this record
+			if (ch.second <= pass_max_tid || pass_records + (ch.first - lo) >= pass_records_max) { // a contig that comes back (or a pass that is long enough): the pass ends in front of this record
 				if (ssv_clip_scan_range(ctx, &b, lo, ch.first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 				emit_pass(false);
 				p.initial_last_tid = scan_last_tid;
@@ -624,6 +640,7 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 		}
 		changes_of.pop_front();
 		if (ssv_clip_scan_range(ctx, &b, lo, b.n) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		pass_records += b.n - lo;
 		pt.lap("gpu_scan(wait h2d+kernels)");
 	});
 	pass_flushes.push_back(scan_last_tid);
@@ -631,6 +648,7 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	cerr << "[GetSClipReads] finished!" << endl;
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
 	pt.lap("gzip");
+	if (pt.on) cerr << "[timing] (format, all passes, beside the reading: " << emit_format_s << " s; gzip: " << emit_gzip_s << " s)" << endl;
 	src.close();
 	release_ctx(ctx);
 	pt.lap("teardown");
@@ -1384,6 +1402,15 @@ static bool parse_fasta_parallel(const string &path, vector<string> &names, vect
 	return true;
 }
 
+// `seeksv run`: the reference is read (and packed to 2 bits) by a thread of its own while getclip runs
+struct PrereadFasta {
+	string path;
+	std::thread th;
+	bool ok = false;
+	vector<string> names; vector<int32_t> lens; vector<int64_t> offs; vector<uint64_t> words;
+};
+static PrereadFasta &g_preread = *new PrereadFasta; // (never destroyed: die() may exit while its thread runs)
+
 static int cmd_realign(int argc, char **argv)
 {
 	int gpu = 0, c;
@@ -1400,7 +1427,12 @@ static int cmd_realign(int argc, char **argv)
 	vector<uint64_t> words;
 	const bool fasta_check = getenv("SSV_FASTA_CHECK") != nullptr; // (tests: the serial reader runs too and must agree)
 	vector<string> p_names; vector<int32_t> p_lens; vector<int64_t> p_offs(1, 0); vector<uint64_t> p_words;
-	const bool parsed = parse_fasta_parallel(fasta, p_names, p_lens, p_offs, p_words);
+	bool parsed;
+	if (g_preread.th.joinable() && g_preread.path == fasta) { // `seeksv run` read the reference beside getclip
+		g_preread.th.join();
+		parsed = g_preread.ok;
+		p_names.swap(g_preread.names); p_lens.swap(g_preread.lens); p_offs.swap(g_preread.offs); p_words.swap(g_preread.words);
+	} else parsed = parse_fasta_parallel(fasta, p_names, p_lens, p_offs, p_words);
 	if (parsed && !fasta_check) { names.swap(p_names); lens.swap(p_lens); offs.swap(p_offs); words.swap(p_words); }
 	else {
 		gzFile f = gzopen(fasta.c_str(), "rb");
@@ -1570,6 +1602,8 @@ static int cmd_run(int argc, char **argv)
 	g_resident.path = bam;
 	g_resident.collect = true;
 	pt.lap("run: gpu_init");
+	g_preread.path = fasta; g_preread.offs.assign(1, 0);
+	g_preread.th = std::thread([] { g_preread.ok = parse_fasta_parallel(g_preread.path, g_preread.names, g_preread.lens, g_preread.offs, g_preread.words); });
 	auto call = [&](int (*fn)(int, char **), vector<string> words) {
 		vector<char *> av;
 		for (auto &w : words) av.push_back(const_cast<char *>(w.c_str()));
@@ -1583,6 +1617,7 @@ static int cmd_run(int argc, char **argv)
 	int rc = call(cmd_getclip, a);
 	g_resident.collect = false;
 	pt.lap("run: getclip (decode once, records kept in HBM)");
+	if (rc != 0 && g_preread.th.joinable()) g_preread.th.join();
 	if (rc == 0) rc = call(cmd_realign, {"realign", "-G", to_string(device), fasta, prefix + ".clip.fq.gz", prefix + ".clip.bam"});
 	pt.lap("run: realign");
 	if (rc == 0) {
