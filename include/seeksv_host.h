@@ -122,8 +122,10 @@ int ssvh_bam_write_batch(const char *path, const char *const *names, const int32
 int ssvh_bam_write_batch_named(const char *path, const char *const *names, const int32_t *lens, int32_t n_targets, const ssv_batch_t *b,
                                const char *const *qnames, int append, int finish);
 
-/* Append text to a .gz file as independent gzip members compressed in parallel (256 KiB of text each; zlib level 1, or SSV_GZ_LEVEL -
- * gzstream's default, the reference's, is 6: same bytes after decompression, 5 x the CPU time).  Concatenated members are a valid gzip stream: zlib's gzread (igzstream, bwa, zcat) decompresses them to exactly the bytes
+/* Append text to a .gz file as independent gzip members compressed in parallel (256 KiB of text each).  By default a member is one
+ * literal-only dynamic-Huffman block (seeksv_amd/host/huff_gz.h: the rows of getclip are text with a small alphabet and few repeats - 2.2-2.3 x
+ * at several hundred MB/s per core, where zlib level 1 gives 2.7 x at 50-60 MB/s and level 6 - gzstream's default, the reference's - 3.2 x at
+ * 10); SSV_GZ_LEVEL=0..9 selects zlib at that level.  The same bytes after decompression in every case.  Concatenated members are a valid gzip stream: zlib's gzread (igzstream, bwa, zcat) decompresses them to exactly the bytes
  * written.  append == 0 truncates the file first.  n == 0 with append == 0 creates an empty gzip stream like an ogzstream that is
  * closed without writes. */
 int ssvh_gz_append(const char *path, const char *text, size_t n, int append);

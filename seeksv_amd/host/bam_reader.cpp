@@ -11,6 +11,8 @@
 
 #include <zlib.h>
 
+#include "huff_gz.h"
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1073,7 +1075,7 @@ int ssvh_gz_append_v(const char *path, const char *const *texts, const size_t *l
 {
 	FILE *f = fopen(path, append ? "ab" : "wb");
 	if (!f) { g_err = std::string("cannot open ") + path; return -1; }
-	const size_t PIECE = 1 << 18;
+	static const size_t PIECE = [] { const char *e = getenv("SSV_GZ_PIECE_KB"); const long kb = e ? atol(e) : 256; return (size_t)(kb < 1 ? 1 : kb) << 10; }(); // (tests: many members from little text)
 	struct Piece { const char *p; size_t n; };
 	std::vector<Piece> pieces;
 	for (int k = 0; k < count; ++k)
@@ -1085,10 +1087,18 @@ int ssvh_gz_append_v(const char *path, const char *const *texts, const size_t *l
 	// deflate level of the .gz outputs: 1 by default (rows of random-looking bases and qualities: level 6 - gzstream's default, the
 	// reference's - packs them 3.4 x at 11 MB/s per core, level 1 2.9 x at 60; the files' decompressed bytes are what counts), SSV_GZ_LEVEL=6
 	// writes files of the reference's size
-	static const int level = [] { const char *e = getenv("SSV_GZ_LEVEL"); const int l = e ? atoi(e) : 1; return l < 0 ? 0 : l > 9 ? 9 : l; }();
+	// ... and by default no zlib at all: members of one literal-only Huffman block (huff_gz.h): 2.2-2.3 x at several hundred MB/s per core
+	static const int level = [] { const char *e = getenv("SSV_GZ_LEVEL"); const int l = e && *e ? atoi(e) : -1; return l < 0 ? -1 : l > 9 ? 9 : l; }();
 	wpool().run((int)np, [&](int i) {
 		const Piece &pc = pieces[(size_t)i];
 		std::vector<uint8_t> &c = comp[(size_t)i];
+		if (level < 0) {
+			static thread_local std::vector<uint8_t> room; // (sized once per thread: a fresh vector would be zero-filled for every member)
+			if (room.size() < ssvh_huff::member_bound(pc.n)) room.resize(ssvh_huff::member_bound(pc.n));
+			const size_t got = ssvh_huff::member(reinterpret_cast<const uint8_t *>(pc.p), pc.n, room.data());
+			c.assign(room.begin(), room.begin() + (ptrdiff_t)got);
+			return;
+		}
 		// one deflate state per thread (see bgzf_compress_blocks)
 		struct Deflater { z_stream zs; int level = -100; ~Deflater() { if (level != -100) deflateEnd(&zs); } };
 		static thread_local Deflater D;

@@ -8,10 +8,24 @@
 //   * hard-clipped records are skipped in the main loop but not in the tail loop (getsv.h:476 vs :512-527).
 #include "junction_stage.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <iostream>
+#include <memory>
+#include <climits>
 #include <cstdlib>
+#include <cstring>
 #include <sstream>
+#include <thread>
+
+#include "../csrc/cpus.h"
 
 #include "seeksv_host.h"
 
@@ -170,8 +184,83 @@ double match_begin_first(const std::string &a, const std::string &b) // CompareS
 	return (double)m / n;
 }
 
+// A .gz file written by ssvh_gz_append is a sequence of independent gzip members that all start with the same ten header bytes: the members
+// are found by that pattern, their inflated sizes read from their trailers (ISIZE), and they are inflated side by side straight into place.
+// Every member must end exactly where the next one starts, with its CRC and size right (zlib checks both) - otherwise, and for any other
+// gzip or plain file, false: the caller reads the file the ordinary way (gzread).
+// (the text lands in `buf`, allocated here without being cleared: its pages are first touched by the inflating threads, not by one thread's memset)
+static bool slurp_gz_members(const std::string &path, std::unique_ptr<char[]> &buf, size_t &buf_len)
+{
+	static const unsigned char head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+	const int fd = open(path.c_str(), O_RDONLY);
+	if (fd < 0) return false;
+	struct stat st;
+	if (fstat(fd, &st) != 0 || st.st_size < 36) { close(fd); return false; }
+	const size_t size = (size_t)st.st_size;
+	const unsigned char *raw = static_cast<const unsigned char *>(mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0));
+	close(fd);
+	if (raw == MAP_FAILED) return false;
+	bool ok = memcmp(raw, head, 10) == 0;
+	std::vector<size_t> start;
+	if (ok) {
+		const int nt = std::max(1, std::min(ssv::effective_cpus(), 64));
+		std::vector<std::vector<size_t>> found((size_t)nt);
+		std::vector<std::thread> th;
+		for (int w = 0; w < nt; ++w) th.emplace_back([&, w] {
+			const size_t lo = size * (size_t)w / (size_t)nt, hi = size * (size_t)(w + 1) / (size_t)nt;
+			for (const unsigned char *p = raw + lo; p < raw + hi && (p = static_cast<const unsigned char *>(memchr(p, 0x1f, (size_t)(raw + hi - p)))) != nullptr; ++p)
+				if ((size_t)(raw + size - p) >= 18 && memcmp(p, head, 10) == 0) found[(size_t)w].push_back((size_t)(p - raw));
+		});
+		for (auto &t : th) t.join();
+		for (auto &f : found) start.insert(start.end(), f.begin(), f.end());
+		if (start.size() < 2) ok = false; // one member: nothing to gain
+	}
+	if (ok) {
+		const size_t nm = start.size();
+		start.push_back(size);
+		std::vector<size_t> at(nm + 1, 0);
+		for (size_t k = 0; k < nm; ++k) {
+			if (start[k + 1] - start[k] < 20) { ok = false; break; }
+			uint32_t isize; memcpy(&isize, raw + start[k + 1] - 4, 4);
+			at[k + 1] = at[k] + isize;
+		}
+		if (ok) {
+			buf.reset(new char[at[nm] + 1]);
+			buf_len = at[nm];
+			char *const out = buf.get();
+			std::atomic<size_t> next{0};
+			std::atomic<bool> good{true};
+			const int nt = std::max(1, std::min<int>(ssv::effective_cpus(), 64));
+			std::vector<std::thread> th;
+			for (int w = 0; w < nt; ++w) th.emplace_back([&] {
+				z_stream zs;
+				memset(&zs, 0, sizeof(zs));
+				if (inflateInit2(&zs, 15 + 16) != Z_OK) { good = false; return; }
+				for (size_t k; good && (k = next++) < nm;) {
+					inflateReset(&zs);
+					zs.next_in = const_cast<Bytef *>(raw + start[k]); zs.avail_in = (uInt)(start[k + 1] - start[k]);
+					unsigned char dummy;
+					zs.next_out = at[k + 1] > at[k] ? reinterpret_cast<Bytef *>(out + at[k]) : &dummy; zs.avail_out = (uInt)(at[k + 1] - at[k]);
+					const int rc = inflate(&zs, Z_FINISH);
+					if (rc != Z_STREAM_END || zs.avail_in != 0 || zs.avail_out != 0) good = false; // (a false header match inside a member's data ends up here)
+				}
+				inflateEnd(&zs);
+			});
+			for (auto &t : th) t.join();
+			ok = good;
+			if (!ok) { buf.reset(); buf_len = 0; }
+		}
+	}
+	munmap(const_cast<unsigned char *>(raw), size);
+	return ok;
+}
+
 std::string slurp_gz(const std::string &path, std::string &out)
 {
+	static const bool serial = getenv("SSV_GZ_READ_SERIAL") != nullptr;
+	std::unique_ptr<char[]> whole;
+	size_t n_whole = 0;
+	if (!serial && slurp_gz_members(path, whole, n_whole)) { out.append(whole.get(), n_whole); return ""; }
 	gzFile f = gzopen(path.c_str(), "rb"); // reads plain files too
 	if (!f) return "Cannot open file " + path;
 	char buf[1 << 16];
@@ -211,31 +300,97 @@ void reverse_complement(std::string &seq)
 	if (n % 2) seq[n / 2] = comp(seq[n / 2]);
 }
 
-std::string assemble_junctions(const std::string &clipfile, const std::string &clip_bam, JunctionMap &j2o)
+// the same with the rows of clip.gz already in memory (`seeksv run`: getclip has just written them)
+// The rows of clip.gz, parsed by several threads: a row is a line of at least nine whitespace-separated fields whose second and ninth are plain
+// integers and whose third is one character - what getclip writes.  For such text this is what the reference's `fin >> chr >> pos >> ...;
+// getline(fin, rest)` loop (getsv.h:441-446) extracts; anything else (a short line would make operator>> run on into the next one, a field like
+// "12x" would split) returns false and the caller parses the text with that very stream loop.
+struct TextView { // (just enough of std::string for the parser)
+	const char *p; size_t n;
+	size_t size() const { return n; }
+	const char *data() const { return p; }
+	size_t find(char c, size_t from) const { const void *q = from < n ? memchr(p + from, c, n - from) : nullptr; return q ? (size_t)(static_cast<const char *>(q) - p) : std::string::npos; }
+};
+
+static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows)
 {
-	std::string text, err = slurp_gz(clipfile, text);
-	if (!err.empty()) return err;
-	return assemble_junctions_text(text, clip_bam, j2o);
+	static const bool off = getenv("SSV_ROWS_SERIAL") != nullptr;
+	if (off) return false;
+	static const size_t per_thread = [] { const char *e = getenv("SSV_ROWS_CHUNK_KB"); const long kb = e ? atol(e) : 64; return (size_t)(kb < 1 ? 1 : kb) << 10; }(); // (tests: several threads on little text)
+	const int nt = (int)std::max<size_t>(1, std::min<size_t>({(size_t)ssv::effective_cpus(), (size_t)64, text.size() / per_thread + 1}));
+	std::vector<std::vector<ClipRow>> part((size_t)nt);
+	std::vector<size_t> cut((size_t)nt + 1, text.size());
+	cut[0] = 0;
+	for (int w = 1; w < nt; ++w) {
+		const size_t guess = text.size() * (size_t)w / (size_t)nt;
+		const size_t nl = text.find('\n', std::max(guess, cut[(size_t)w - 1]));
+		cut[(size_t)w] = nl == std::string::npos ? text.size() : nl + 1;
+	}
+	std::atomic<bool> good{true};
+	auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+	auto to_int = [](const char *p, size_t n, int &v) -> bool { // what operator>>(int&) takes from a token that is nothing but [+-]digits
+		size_t i = 0;
+		bool neg = false;
+		if (n && (p[0] == '+' || p[0] == '-')) { neg = p[0] == '-'; i = 1; }
+		if (i == n || n - i > 10) return false;
+		long long x = 0;
+		for (; i < n; ++i) { if (p[i] < '0' || p[i] > '9') return false; x = x * 10 + (p[i] - '0'); }
+		if (neg) x = -x;
+		if (x < INT_MIN || x > INT_MAX) return false;
+		v = (int)x;
+		return true;
+	};
+	std::vector<std::thread> th;
+	for (int w = 0; w < nt; ++w) th.emplace_back([&, w] {
+		std::vector<ClipRow> &out = part[(size_t)w];
+		const char *p = text.data() + cut[(size_t)w], *end = text.data() + cut[(size_t)w + 1];
+		while (p < end && good) {
+			const char *eol = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+			if (!eol) eol = end;
+			const char *tok[9]; size_t len[9];
+			int nf = 0;
+			for (const char *q = p; q < eol && nf < 9;) {
+				while (q < eol && is_space(*q)) ++q;
+				if (q == eol) break;
+				const char *b = q;
+				while (q < eol && !is_space(*q)) ++q;
+				tok[nf] = b; len[nf] = (size_t)(q - b); ++nf;
+			}
+			if (nf == 9) {
+				ClipRow row;
+				if (len[2] != 1 || !to_int(tok[1], len[1], row.pos) || !to_int(tok[8], len[8], row.support)) { good = false; break; }
+				row.chr.assign(tok[0], len[0]); row.side = tok[2][0];
+				row.cigar_vec = parse_cigar(std::string(tok[3], len[3]));
+				row.aligned_seq.assign(tok[4], len[4]); row.clipped_seq.assign(tok[6], len[6]); row.clipped_qual.assign(tok[7], len[7]);
+				out.push_back(std::move(row));
+			} else if (nf != 0) { good = false; break; }
+			p = eol < end ? eol + 1 : end;
+		}
+	});
+	for (auto &t : th) t.join();
+	if (!good) return false;
+	size_t total = 0;
+	for (auto &v : part) total += v.size();
+	rows.reserve(total);
+	for (auto &v : part) { for (auto &r : v) rows.push_back(std::move(r)); std::vector<ClipRow>().swap(v); }
+	return true;
 }
 
-// the same with the rows of clip.gz already in memory (`seeksv run`: getclip has just written them)
-std::string assemble_junctions_text(const std::string &text, const std::string &clip_bam, JunctionMap &j2o)
+static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, JunctionMap &j2o);
+std::string assemble_junctions_text(const std::string &text, const std::string &clip_bam, JunctionMap &j2o) { return assemble_junctions_view(TextView{text.data(), text.size()}, clip_bam, j2o); }
+
+static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, JunctionMap &j2o)
 {
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(clip_bam.c_str(), &bam) != 0) return "[main_samview] fail to open file for reading.";
-	std::istringstream fin(text);
 	std::vector<ClipRow> rows; // the rows that share `current` (the reference's multimap is cleared at every group change)
 	AlignMap aligns;
 	std::string current;       // last_clipped_seq
 	ssvh_record rec;
-	std::string chr, cigar, aligned_qual, rest;
-	while (fin >> chr) {
-		ClipRow row;
-		row.chr = chr;
-		fin >> row.pos >> row.side >> cigar >> row.aligned_seq >> aligned_qual >> row.clipped_seq >> row.clipped_qual >> row.support;
-		std::getline(fin, rest);
-		row.cigar_vec = parse_cigar(cigar);
-		if (current.empty() || current == row.clipped_seq) { rows.push_back(row); current = row.clipped_seq; continue; }
+	std::string failure;
+	// one row of clip.gz, in file order (false: clip.bam could not be read)
+	auto on_row = [&](ClipRow &row) -> bool {
+		if (current.empty() || current == row.clipped_seq) { current = row.clipped_seq; rows.push_back(std::move(row)); return true; }
 		// a new clipped sequence: consume the alignments of the current group
 		int rc;
 		while ((rc = ssvh_bam_next_record(bam, &rec)) == 1) {
@@ -245,13 +400,35 @@ std::string assemble_junctions_text(const std::string &text, const std::string &
 			if (current == rec.qname) { aligns.insert(std::make_pair(std::make_pair(current, std::make_pair(a.chr, a.pos)), a)); continue; }
 			flush_group(rows, aligns, j2o);
 			rows.clear(); aligns.clear();
-			rows.push_back(row);
 			aligns.insert(std::make_pair(std::make_pair(current, std::make_pair(a.chr, a.pos)), a)); // filed under the OLD name
 			current = row.clipped_seq;
+			rows.push_back(std::move(row));
 			break;
 		}
-		if (rc < 0) { std::string e = ssvh_last_error(); ssvh_bam_close(bam); return e; }
+		if (rc < 0) { failure = ssvh_last_error(); return false; }
 		// clip.bam exhausted before the group ended: like the reference, the row is dropped and nothing changes
+		return true;
+	};
+	std::vector<ClipRow> parsed;
+	const bool timing = getenv("SSV_TIMING") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	if (parse_rows_parallel(text, parsed)) {
+		const auto t1 = std::chrono::steady_clock::now();
+		for (auto &row : parsed) if (!on_row(row)) { ssvh_bam_close(bam); return failure; }
+		if (timing) std::cerr << "[timing] (junction stage: " << parsed.size() << " rows parsed in " << std::chrono::duration<double>(t1 - t0).count() << " s, joined with clip.bam in "
+		                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() << " s)" << std::endl;
+		std::vector<ClipRow>().swap(parsed);
+	} else {
+		std::istringstream fin(std::string(text.data(), text.size()));
+		std::string chr, cigar, aligned_qual, rest;
+		while (fin >> chr) {
+			ClipRow row;
+			row.chr = chr;
+			fin >> row.pos >> row.side >> cigar >> row.aligned_seq >> aligned_qual >> row.clipped_seq >> row.clipped_qual >> row.support;
+			std::getline(fin, rest);
+			row.cigar_vec = parse_cigar(cigar);
+			if (!on_row(row)) { ssvh_bam_close(bam); return failure; }
+		}
 	}
 	int rc;
 	while ((rc = ssvh_bam_next_record(bam, &rec)) == 1) { // tail: no hard-clip test here
@@ -263,6 +440,24 @@ std::string assemble_junctions_text(const std::string &text, const std::string &
 	flush_group(rows, aligns, j2o);
 	ssvh_bam_close(bam);
 	return "";
+}
+
+std::string assemble_junctions(const std::string &clipfile, const std::string &clip_bam, JunctionMap &j2o)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	static const bool serial = getenv("SSV_GZ_READ_SERIAL") != nullptr;
+	std::unique_ptr<char[]> buf;
+	size_t n_buf = 0;
+	std::string text;
+	TextView view{nullptr, 0};
+	if (!serial && slurp_gz_members(clipfile, buf, n_buf)) view = TextView{buf.get(), n_buf};
+	else {
+		const std::string err = slurp_gz(clipfile, text);
+		if (!err.empty()) return err;
+		view = TextView{text.data(), text.size()};
+	}
+	if (getenv("SSV_TIMING")) std::cerr << "[timing] (junction stage: " << view.size() << " bytes of rows read in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s)" << std::endl;
+	return assemble_junctions_view(view, clip_bam, j2o);
 }
 
 void merge_junctions(JunctionMap &j2o, int search_length)

@@ -3,6 +3,7 @@
 written as a BAM in /dev/shm, then timed as child processes, wall clock exec to exit:
     seeksv getclip -Z            seeksv getsv -Z -B <planted junctions>            (the reference's two commands: two reads of the file)
     seeksv run <bam> <ref.fa>    (getclip + realign + getsv in one process: the file is decoded once, its records stay in HBM)
+    seeksv getclip -Z; seeksv realign; seeksv getsv -Z      (the reference's whole flow as three processes, the aligner step in bwa's place)
 usage: python tools/cli_scale_bench.py [genome_frac=0.125] [deflate_level=4]"""
 import gzip
 import json
@@ -92,6 +93,13 @@ def main():
                 best = cur
         best["records_per_s"] = round(w.n_total / best["total_s"])
         out["run"] = best
+        # the reference's whole flow as three processes: getclip, the aligner step (seeksv realign in bwa's place), getsv reading clip.gz + clip.bam from disk
+        t2, r2 = timed([EXE, "realign", fa, os.path.join(d, "two.clip.fq.gz"), os.path.join(d, "two.clip.bam")])
+        t3, r3 = timed([EXE, "getsv", "-Z", os.path.join(d, "two.clip.bam"), bam, os.path.join(d, "two.clip.gz"), os.path.join(d, "three.sv.txt"), os.path.join(d, "three.x.fq")])
+        t1 = out["two_commands"]["getclip_s"]
+        out["three_commands"] = dict(getclip_s=t1, realign_s=t2, getsv_s=t3, total_s=round(t1 + t2 + t3, 3), records_per_s=round(w.n_total / (t1 + t2 + t3)),
+                                     realign_phases_s=phases(r2.stderr), getsv_phases_s=phases(r3.stderr), getsv_notes=[l for l in r3.stderr.splitlines() if l.startswith("[timing] (")],
+                                     same_sv_table_as_run=open(os.path.join(d, "three.sv.txt")).read() == open(os.path.join(d, "one.sv.txt")).read())
         # the one-process run writes what the commands write
         for ext in (".clip.gz", ".clip.fq.gz"):
             a, b = gzip.open(os.path.join(d, "two" + ext), "rb"), gzip.open(os.path.join(d, "one" + ext), "rb")
