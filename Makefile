@@ -61,7 +61,7 @@ asan: $(LIBDIR)/libseeksv_hip.so
 		-L$(ASAN_DIR) -lseeksv_host -lseeksv_hip -lz -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,$(ROCM)/lib
 	$(CXX) $(ASAN_FLAGS) -std=c++17 -Iseeksv_amd/csrc tests/native/inflate_check.cpp -lz -o $(ASAN_DIR)/inflate_check && $(ASAN_DIR)/inflate_check
 	LD_PRELOAD=$$(gcc -print-file-name=libasan.so):$$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 SSV_CLEAN_EXIT=1 \
-		SSV_LIBDIR=$(abspath $(ASAN_DIR)) SSV_ORACLE_SO=$(abspath $(ASAN_DIR))/liboracle.so SSV_CLI=$(abspath $(ASAN_DIR))/seeksv \
+		SSV_TEST_CXXFLAGS="$(ASAN_FLAGS)" SSV_LIBDIR=$(abspath $(ASAN_DIR)) SSV_ORACLE_SO=$(abspath $(ASAN_DIR))/liboracle.so SSV_CLI=$(abspath $(ASAN_DIR))/seeksv \
 		python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
 
 clean:

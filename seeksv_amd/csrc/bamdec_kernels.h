@@ -836,11 +836,15 @@ __global__ __launch_bounds__(BLOCK) void k_stitch_check(const BgzfBlock *__restr
 		// inside one long record); a unit with a guess must start exactly where the last unit with a guess lets the chain out
 		uint64_t begin, end;
 		unit_range(blocks, u_off, b, begin, end);
+		// (the look back over units without a guess is bounded: a record longer than 64 units - 4 MB - sends the chunk to the walk below instead of
+		// making every lane inside it walk to its start, quadratic in the record's length)
 		int64_t p = b - 1;
-		while (p >= 0 && chain[p].guess == ~0ull) --p;
+		for (int steps = 0; p >= 0 && chain[p].guess == ~0ull && steps < 64; ++steps) --p;
+		const bool capped = p >= 0 && chain[p].guess == ~0ull;
 		const uint64_t before = p < 0 ? start : chain[p].exit;
 		// (... or too close to the stream's end for a record header: the head of a record the next chunk completes)
-		if (c.guess == ~0ull) { ok = before >= end || before + 36 > total; if (ok) count[b] = 0; if (b == n_blocks - 1) out->tail = before; }
+		if (capped) ok = false;
+		else if (c.guess == ~0ull) { ok = before >= end || before + 36 > total; if (ok) count[b] = 0; if (b == n_blocks - 1) out->tail = before; }
 		else {
 			ok = c.guess == before;
 			cnt = c.count;

@@ -244,6 +244,8 @@ static ssv_ctx *acquire_ctx(int device)
 	return ctx;
 }
 
+static const bool kTimingChunks = getenv("SSV_TIMING_CHUNKS") != nullptr;
+
 struct BatchSource {
 	ssvh_bam *bam = nullptr;
 	ssv_ctx *ctx = nullptr;
@@ -254,6 +256,11 @@ struct BatchSource {
 	size_t stage_bytes = 0;
 	uint64_t chunk_inflated = 0;
 	void *stage[2] = {nullptr, nullptr};
+	size_t stage_cap[2] = {0, 0};
+	size_t first_bytes = 0;      // the file's first chunk is a small one (see open())
+	bool first_read = true;
+	std::thread alloc2;          // pins the second staging buffer while the first chunk is read and decoded
+	string alloc2_err;
 	vector<ssv_bgzf_block> blocks[2];
 	int64_t n_blocks[2] = {0, 0};
 	size_t n_bytes[2] = {0, 0};
@@ -288,6 +295,14 @@ struct BatchSource {
 		{ // no more pinned memory than the file can fill (pinning costs ~0.2 s per GB, twice: at allocation and at release)
 			FILE *f = fopen(path.c_str(), "rb");
 			if (f) { fseek(f, 0, SEEK_END); file_bytes = (uint64_t)ftell(f); fclose(f); }
+			// What a command pays once grows with the chunk size - two pinned staging buffers, ~3.8 bytes of device memory per inflated byte
+			// (~20 ms per GB, at the first decode) - and what big chunks buy is inflate rate (more BGZF blocks in flight), which only
+			// matters once the file is long enough for the GPU to be the slower side of the pipeline: chunks of 1 GB inflated below 8 GB of
+			// file (6 GB file, getclip + getsv: 3.8 -> 2.3 s), 2 GB below 24 GB, 4 GB above.
+			if (!e1 && !e2 && file_bytes && !ranged) {
+				if (file_bytes <= ((uint64_t)8 << 30)) { chunk_inflated = (uint64_t)1024 << 20; stage_bytes = (size_t)384 << 20; }
+				else if (file_bytes <= ((uint64_t)24 << 30)) { chunk_inflated = (uint64_t)2048 << 20; stage_bytes = (size_t)768 << 20; }
+			}
 			if (file_bytes && file_bytes + 65536 < stage_bytes) stage_bytes = (size_t)file_bytes + 65536;
 		}
 		uint64_t first = 0;
@@ -296,17 +311,29 @@ struct BatchSource {
 		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ssv_bamdec_target_lens(ctx, ssvh_bam_target_lens(bam)) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ranged) ssv_bamdec_prev_tid(ctx, r_prev_tid);
+		// Pinning costs ~0.2 s per GB and the first decode cannot start before the first chunk is in: the file's first chunk goes through a smaller
+		// staging buffer (960 MB: what the insert-size pass of getsv needs for its 5 M pairs at 77 B a record), the second buffer is pinned at full
+		// size by a thread of its own meanwhile, and the first one grows to full size when its turn comes again - on the reader thread, beside the
+		// decode of the chunk before.
+		const char *e3 = getenv("SSV_STAGE_FIRST_MB");
+		first_bytes = std::min(stage_bytes, (size_t)(e3 ? atoll(e3) : 960) << 20);
+		if (file_bytes == 0 || file_bytes + 65536 > first_bytes) // (a file that fits the first buffer never needs the second)
+			alloc2 = std::thread([this] { if (ssv_bamdec_staging(ctx, 1, stage_bytes, &stage[1]) != SSV_OK) alloc2_err = ssv_last_error(ctx); else stage_cap[1] = stage_bytes; });
 		start_read(0);
 	}
 	void start_read(int k)
 	{
-		if (!stage[k]) { // the second buffer only exists for files that need a second chunk
-			if (ssv_bamdec_staging(ctx, k, stage_bytes, &stage[k]) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-			blocks[k].resize((size_t)(std::min<uint64_t>(chunk_inflated, file_bytes ? file_bytes * 64 : chunk_inflated) >> 12) + 1024); // blocks are <= 64 KB but may be much smaller
-		}
-		reader = std::thread([this, k] {
+		const size_t want = first_read ? first_bytes : stage_bytes;
+		first_read = false;
+		if (k == 1 && alloc2.joinable()) { alloc2.join(); if (!alloc2_err.empty()) die("[seeksv] " + alloc2_err); }
+		if (blocks[k].empty()) blocks[k].resize((size_t)(std::min<uint64_t>(chunk_inflated, file_bytes ? file_bytes * 64 : chunk_inflated) >> 12) + 1024); // blocks are <= 64 KB but may be much smaller
+		reader = std::thread([this, k, want] {
 			read_err[k].clear();
-			if (ssvh_bam_read_blocks(bam, stage[k], stage_bytes, chunk_inflated, blocks[k].data(), (int64_t)blocks[k].size(), &n_blocks[k], &n_bytes[k]) != 0) read_err[k] = ssvh_last_error();
+			if (stage_cap[k] < want) { // (the chunk that was in this buffer has been decoded: its bytes are on the device)
+				if (ssv_bamdec_staging(ctx, k, want, &stage[k]) != SSV_OK) { read_err[k] = ssv_last_error(ctx); return; }
+				stage_cap[k] = want;
+			}
+			if (ssvh_bam_read_blocks(bam, stage[k], stage_cap[k], chunk_inflated, blocks[k].data(), (int64_t)blocks[k].size(), &n_blocks[k], &n_bytes[k]) != 0) read_err[k] = ssvh_last_error();
 			ssvh_bam_raw_limit(bam, &limit[k]);
 		});
 		reader_running = true;
@@ -331,7 +358,9 @@ struct BatchSource {
 				at_end = true;
 				return false;
 			}
+			const auto tw0 = std::chrono::steady_clock::now();
 			if (reader_running) { reader.join(); reader_running = false; }
+			const auto tw1 = std::chrono::steady_clock::now();
 			const int k = cur;
 			if (!read_err[k].empty()) die("[seeksv] " + read_err[k]);
 			// (the chunk holds the file's bytes as they are, block headers and trailers included) when nothing but the 28-byte end-of-file block can
@@ -341,6 +370,8 @@ struct BatchSource {
 			if (!last_chunk) { cur ^= 1; start_read(cur); } // the other buffer fills while this chunk is decoded
 			if (limit[k] != UINT64_MAX) ssv_bamdec_limit(ctx, limit[k]);
 			if (ssv_bamdec_decode(ctx, stage[k], n_bytes[k], blocks[k].data(), n_blocks[k], keep_all_seq, b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			if (kTimingChunks) cerr << "[timing] (chunk of " << n_bytes[k] << " bytes, " << n_blocks[k] << " blocks: waited " << std::chrono::duration<double>(tw1 - tw0).count() << " s for the reader, decoded in "
+			                        << std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count() << " s)" << endl;
 			if (n_blocks[k] == 0) { at_end = true; return false; }
 			if (last_chunk) end_pending = true;
 			ssv_bamdec_last(ctx, &info);
@@ -388,6 +419,7 @@ struct BatchSource {
 	void close()
 	{
 		if (reader_running) { reader.join(); reader_running = false; }
+		if (alloc2.joinable()) alloc2.join();
 		if (bam) ssvh_bam_close(bam);
 		bam = nullptr;
 	}
@@ -830,10 +862,10 @@ static double largest_base_frequency(const string &seq) // CountLargestBaseFrequ
 }
 
 // CalculateInsertsizeDeviation (cluster.cpp:15-83) over the head of a BAM, with the reference's stderr lines
-// CalculateInsertsizeDeviation (cluster.cpp:15-83) reads the file until it has its pairs - usually inside the first chunk.  With the records decoded on the
-// GPU (or resident there) that chunk's batch is still valid when the statistics are known: `keep` then holds the open source and the batch, and the
-// fused pass scans it and goes on from the second chunk instead of reading, inflating and decoding the first one again.
-struct IsizeCarry { BatchSource src; ssv_batch_t first; bool usable = false; };
+// CalculateInsertsizeDeviation (cluster.cpp:15-83) reads the file until it has its pairs - the first chunk or the first few.  With the records decoded on the
+// GPU their batches are copied into memory that stays (ssv_batch_retain; resident ones stay anyway): `keep` then holds the open source and those batches, and the
+// fused pass scans them and goes on from the next chunk instead of reading, inflating and decoding the head of the file again.
+struct IsizeCarry { BatchSource src; vector<ssv_batch_t> kept; bool owned = false, usable = false; };
 
 static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation, IsizeCarry *keep = nullptr)
 {
@@ -849,6 +881,11 @@ static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_in
 		if (!src.next(&b, 0)) break;
 		++chunks;
 		if (ssv_isize_accumulate(ctx, &b, &done) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		if (keep && src.on_device) { // a decoder's batch is valid until the next decode: a copy that stays (80 B/record, device to device)
+			ssv_batch_t k = b;
+			if (!src.resident) { if (ssv_batch_retain(ctx, &b, &k) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx)); keep->owned = true; }
+			keep->kept.push_back(k);
+		}
 	}
 	int64_t n; int32_t m = 0, sd = 0;
 	ssv_isize_finish(ctx, &n, &m, &sd);
@@ -856,7 +893,7 @@ static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_in
 		mean_insert_size = m; deviation = sd;
 		cerr << "Bam/sam " << bamfile << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << endl;
 	}
-	if (keep && src.on_device && chunks == 1) { keep->first = b; keep->usable = true; return; } // (a device batch stays valid until the next decode)
+	if (keep && src.on_device && chunks >= 1) { keep->usable = true; return; }
 	src.close();
 }
 
@@ -1079,7 +1116,8 @@ static int cmd_getsv(int argc, char **argv)
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		auto scan = [&](const ssv_batch_t &b) { if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx)); };
 		if (carry.usable) { // the insert-size pass left its source open behind the file's first chunk, whose batch is still valid
-			scan(carry.first);
+			for (auto &k : carry.kept) { scan(k); if (carry.owned) ssv_batch_release(ctx, &k); }
+			carry.kept.clear();
 			carry.src.pump(0, [](const ssv_batch_t &) {}, scan);
 			carry.src.close();
 			carry.usable = false;
@@ -1093,7 +1131,7 @@ static int cmd_getsv(int argc, char **argv)
 		if (ssv_getsv_finish(ctx, do_discordant ? counts.data() : nullptr, dr, output_depth ? nr : 0, rsum.data(), dp, output_depth ? np : 0, pdepth.data(), &maxd) != SSV_OK)
 			die(string("[seeksv] ") + ssv_last_error(ctx));
 	}
-	if (carry.usable) { carry.src.close(); carry.usable = false; }
+	if (carry.usable) { if (carry.owned) for (auto &k : carry.kept) ssv_batch_release(ctx, &k); carry.kept.clear(); carry.src.close(); carry.usable = false; }
 	pt.lap("fused_pass");
 	if (do_discordant) { cerr << "'StoreSeqName2Tid' finished" << endl; cerr << "'FindDiscordantReadPairs' finished" << endl; }
 	if (output_depth) { cerr << "'MergeOverlap' finished" << endl; cerr << "'main_depth' finished" << endl; }

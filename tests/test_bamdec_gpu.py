@@ -246,3 +246,23 @@ def test_resolve_in_lds_mode():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("chunk_bytes", [64 << 20, 1 << 20], ids=["one-chunk", "1MB-chunks"])
+def test_device_decode_record_longer_than_64_blocks(ctx, tmp_path, chunk_bytes):
+    """a read of 5.5 M bases = one 8 MB record = ~130 BGZF blocks without a record start in them: the per-block check of the speculated record starts
+    looks back over at most 64 such blocks and then leaves the chunk to the sequential walk (k_stitch_check / k_stitch_blocks); same batches as the host reader's"""
+    rng = np.random.default_rng(9)
+    recs = _records(300, 21)
+    n = 5_500_000
+    long = dict(qname="ultralong", flag=0, tid=0, pos=1000, mapq=60, cigar=[(100, 0), (n - 100, 4)], mtid=-1, mpos=-1, isize=0,
+                seq="".join(np.array(list("ACGT"))[rng.integers(0, 4, n)]), qual=bytes(rng.integers(2, 41, n, dtype=np.uint8)))
+    path = str(tmp_path / "long.bam")
+    bamio.write_bam(path, NAMES, LENS, recs[:150] + [long] + recs[150:])
+    hb, hunm = _host_all(path)
+    db, dunm, druns, _ = _device_all(ctx, path, chunk_bytes, 1 << 16)
+    h, d = _flatten(hb), _flatten(db)
+    for k in KEYS + ("shipped",):
+        assert np.array_equal(h[k], d[k]), k
+    assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"] and hunm == dunm
+    assert int(np.max(h["l_qseq"])) == n and any(len(s) == (n + 1) // 2 + n for s in d["seqs"])

@@ -19,7 +19,8 @@ HEAD = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3])
 def exe(tmp_path_factory):
     from seeksv_amd import _abi
     out = str(tmp_path_factory.mktemp("jc") / "junction_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "junction_check.cpp"),
+    flags = os.environ.get("SSV_TEST_CXXFLAGS", "-O2").split()  # (make asan: the sanitizer flags)
+    subprocess.check_call(["g++"] + flags + ["-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "junction_check.cpp"),
                            os.path.join(ROOT, "seeksv_amd", "host", "junction_stage.cpp"), "-o", out, "-L" + _abi.LIBDIR, "-lseeksv_host", "-lz", "-lpthread", "-Wl,-rpath," + _abi.LIBDIR])
     return out
 
