@@ -1506,28 +1506,34 @@ static int cmd_realign(int argc, char **argv)
 	}
 	if (parsed && fasta_check && (names != p_names || lens != p_lens || offs != p_offs || words != p_words)) die("[seeksv] SSV_FASTA_CHECK: the parallel FASTA reader disagrees with the serial one");
 	pt.lap("read reference");
-	// ---- clipped sequences ----
-	vector<string> seqs, quals;
-	if (g_resident.ctx && fq == g_resident.fq_path) { // `seeksv run`: getclip's FASTQ text is still in memory
-		const string &t = g_resident.fq_text;
+	// ---- clipped sequences: the FASTQ text in memory (`seeksv run`: getclip's is still there; else the file, its gzip members inflated side by side),
+	//      cut into lines in place (the newline behind a line becomes its terminator: the sequences are the read names of the BAM records below) ----
+	struct Line { char *p; int n; };
+	vector<Line> seqs, quals;
+	string own_text;
+	{
+		string *t = &own_text;
+		if (g_resident.ctx && fq == g_resident.fq_path) t = &g_resident.fq_text;
+		else { const string err = seeksv::slurp_gz(fq, own_text); if (!err.empty()) die("Cannot open clipped reads file " + fq); }
+		char *base = t->empty() ? nullptr : &(*t)[0];
+		const size_t size = t->size();
 		size_t at = 0;
-		auto line = [&](string &out) { if (at >= t.size()) return false; const size_t e = t.find('\n', at); out.assign(t, at, (e == string::npos ? t.size() : e) - at); at = e == string::npos ? t.size() : e + 1; return true; };
-		string l1, l2, l3, l4;
+		auto line = [&](Line &out) { // like gz_getline: a line ends at '\n' (a '\r' in front of it is dropped); a last line without one counts when it is not empty
+			if (at >= size) return false;
+			char *b = base + at;
+			char *e = static_cast<char *>(memchr(b, '\n', size - at));
+			size_t len = e ? (size_t)(e - b) : size - at;
+			at += len + (e ? 1 : 0);
+			if (e) { *e = 0; if (len && b[len - 1] == '\r') b[--len] = 0; }
+			out.p = b; out.n = (int)len;
+			return e != nullptr || len != 0;
+		};
+		Line l1, l2, l3, l4;
 		while (line(l1)) {
 			if (!line(l2) || !line(l3) || !line(l4)) die("Truncated FASTQ record in " + fq);
+			if (l1.n == 0 || l1.p[0] != '@' || l3.n == 0 || l3.p[0] != '+') die("Malformed FASTQ record in " + fq);
 			seqs.push_back(l2); quals.push_back(l4);
 		}
-	} else {
-		gzFile f = gzopen(fq.c_str(), "rb");
-		if (!f) die("Cannot open clipped reads file " + fq);
-		string l1, l2, l3, l4;
-		while (gz_getline(f, l1)) {
-			if (!gz_getline(f, l2) || !gz_getline(f, l3) || !gz_getline(f, l4)) die("Truncated FASTQ record in " + fq);
-			if (l1.empty() || l1[0] != '@' || l3.empty() || l3[0] != '+') die("Malformed FASTQ record in " + fq);
-			seqs.push_back(l2);
-			quals.push_back(l4);
-		}
-		gzclose(f);
 	}
 	const int64_t n = (int64_t)seqs.size();
 	pt.lap("read fastq");
@@ -1537,7 +1543,13 @@ static int cmd_realign(int argc, char **argv)
 	pt.lap("index");
 	string blob;
 	vector<uint64_t> soff(1, 0);
-	for (const string &q : seqs) { blob += q; soff.push_back(blob.size()); }
+	{
+		size_t total = 0;
+		for (const Line &q : seqs) total += (size_t)q.n;
+		blob.reserve(total);
+		soff.reserve(seqs.size() + 1);
+		for (const Line &q : seqs) { blob.append(q.p, (size_t)q.n); soff.push_back(blob.size()); }
+	}
 	vector<ssv_realign_hit> hits((size_t)n);
 	if (ssv_realign_query(ctx, blob.data(), soff.data(), n, hits.data()) != SSV_OK) die(string("[seeksv] realign query: ") + ssv_last_error(ctx));
 	pt.lap("align");
@@ -1552,32 +1564,53 @@ static int cmd_realign(int argc, char **argv)
 		switch (ch) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4; case 'T': case 't': return 8; default: return 15; }
 	};
 	auto comp4 = [](uint8_t b) -> uint8_t { return (uint8_t)(((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3)); };
+	// sizes first (CIGAR operations and packed bytes per record, running sums), then every host thread fills its share of the records
 	int64_t n_aligned = 0;
-	for (int64_t i = 0; i < n; ++i) {
-		const ssv_realign_hit &h = hits[(size_t)i];
-		const string &s = seqs[(size_t)i], &q = quals[(size_t)i];
-		const int L = (int)s.size();
-		const bool al = h.tid >= 0, rev = al && h.reverse;
-		qn[(size_t)i] = s.c_str();
-		tid[(size_t)i] = al ? h.tid : -1; pos[(size_t)i] = al ? h.pos : -1; lq[(size_t)i] = L;
-		flag[(size_t)i] = (uint16_t)(al ? (rev ? 16 : 0) : 4); mapq[(size_t)i] = al ? h.mapq : 0;
-		cig_off[(size_t)i] = (uint32_t)cig.size();
-		if (al) {
-			++n_aligned;
-			if (h.q_beg > 0) cig.push_back(((uint32_t)h.q_beg << 4) | 4u);
-			cig.push_back(((uint32_t)(h.q_end - h.q_beg) << 4) | 0u);
-			if (h.q_end < L) cig.push_back(((uint32_t)(L - h.q_end) << 4) | 4u);
+	{
+		uint64_t so = 0;
+		uint32_t co = 0;
+		for (int64_t i = 0; i < n; ++i) {
+			const ssv_realign_hit &h = hits[(size_t)i];
+			const int L = seqs[(size_t)i].n;
+			const bool al = h.tid >= 0;
+			n_aligned += al ? 1 : 0;
+			cig_off[(size_t)i] = co; seq_off[(size_t)i] = so;
+			ncig[(size_t)i] = (uint16_t)(al ? 1 + (h.q_beg > 0 ? 1 : 0) + (h.q_end < L ? 1 : 0) : 0);
+			co += ncig[(size_t)i]; so += ((uint64_t)L + 1) / 2 + (uint64_t)L;
 		}
-		ncig[(size_t)i] = (uint16_t)(cig.size() - cig_off[(size_t)i]);
-		seq_off[(size_t)i] = seqqual.size();
-		seqqual.resize(seqqual.size() + ((size_t)L + 1) / 2 + (size_t)L, 0);
-		uint8_t *sp = seqqual.data() + seq_off[(size_t)i], *qp = sp + ((size_t)L + 1) / 2;
-		for (int k = 0; k < L; ++k) {
-			const uint8_t b = rev ? comp4(code4(s[(size_t)(L - 1 - k)])) : code4(s[(size_t)k]);
-			sp[k >> 1] |= (k & 1) ? b : (uint8_t)(b << 4);
-			const char qc = (int)q.size() == L ? (rev ? q[(size_t)(L - 1 - k)] : q[(size_t)k]) : '!';
-			qp[k] = (uint8_t)(qc - 33);
-		}
+		cig.assign(co, 0);
+		seqqual.assign(so, 0);
+	}
+	{
+		const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 64, n / 4096}));
+		auto fill = [&](int w) {
+			for (int64_t i = n * w / nt, e = n * (w + 1) / nt; i < e; ++i) {
+				const ssv_realign_hit &h = hits[(size_t)i];
+				const char *s = seqs[(size_t)i].p, *q = quals[(size_t)i].p;
+				const int L = seqs[(size_t)i].n;
+				const bool al = h.tid >= 0, rev = al && h.reverse, has_q = quals[(size_t)i].n == L;
+				qn[(size_t)i] = s;
+				tid[(size_t)i] = al ? h.tid : -1; pos[(size_t)i] = al ? h.pos : -1; lq[(size_t)i] = L;
+				flag[(size_t)i] = (uint16_t)(al ? (rev ? 16 : 0) : 4); mapq[(size_t)i] = al ? h.mapq : 0;
+				if (al) {
+					uint32_t *c = cig.data() + cig_off[(size_t)i];
+					if (h.q_beg > 0) *c++ = ((uint32_t)h.q_beg << 4) | 4u;
+					*c++ = ((uint32_t)(h.q_end - h.q_beg) << 4) | 0u;
+					if (h.q_end < L) *c++ = ((uint32_t)(L - h.q_end) << 4) | 4u;
+				}
+				uint8_t *sp = seqqual.data() + seq_off[(size_t)i], *qp = sp + ((size_t)L + 1) / 2;
+				for (int k = 0; k < L; ++k) {
+					const uint8_t b = rev ? comp4(code4(s[L - 1 - k])) : code4(s[k]);
+					sp[k >> 1] |= (k & 1) ? b : (uint8_t)(b << 4);
+					const char qc = has_q ? (rev ? q[L - 1 - k] : q[k]) : '!';
+					qp[k] = (uint8_t)(qc - 33);
+				}
+			}
+		};
+		vector<std::thread> th;
+		for (int w = 1; w < nt; ++w) th.emplace_back(fill, w);
+		fill(0);
+		for (auto &x : th) x.join();
 	}
 	seqqual.resize(seqqual.size() + 16, 0);
 	ssv_batch_t b;

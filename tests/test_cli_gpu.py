@@ -218,6 +218,19 @@ def test_cli_realign_full_pipeline(tmp_path_factory, name):
     planted = {(j[0], j[1], j[2], j[3], j[4], j[5]) for j in w.junctions}
     found = {(c[0], int(c[1]), c[2], c[4], int(c[5]), c[6]) for c in got}
     assert len(found) == len(planted)
+    # the FASTQ reader takes the file as one text (gzip members inflated side by side): the same clip.bam from a plain file, from CRLF line ends,
+    # from a file without its last newline and from somebody else's gzip; a truncated record is refused
+    text = gzip.open(clip_gz.replace(".clip.gz", ".clip.fq.gz"), "rb").read()
+    variants = {"plain.fq": text, "crlf.fq": text.replace(b"\n", b"\r\n"), "nonl.fq": text[:-1], "other.fq.gz": gzip.compress(text)}
+    for fn, data in variants.items():
+        open(str(d / fn), "wb").write(data)
+        out = str(d / (fn + ".bam"))
+        r = subprocess.run([SEEKSV, "realign", fa, str(d / fn), out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(out, "rb").read() == open(clip_bam, "rb").read(), fn
+    open(str(d / "cut.fq"), "wb").write(b"\n".join(text.split(b"\n")[:6]) + b"\n")
+    r = subprocess.run([SEEKSV, "realign", fa, str(d / "cut.fq"), str(d / "cut.bam")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Truncated FASTQ record" in r.stderr
 
 
 @pytest.mark.parametrize("name", list(SYNTH_FULL))
