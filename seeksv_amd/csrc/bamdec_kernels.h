@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "inflate_core.h"
+#include "inflate_wave.h"
 #include "inflate_lanes.h"
 
 namespace ssv {
@@ -137,6 +138,22 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_tokens(const uint8_t *__restrict_
 	}
 	status[b] = rc;
 	n_tok[b] = rc == INF_OK ? to.n : 0u;
+}
+
+// pass 1 with a wavefront per block (inflate_wave.h): same outputs as k_bgzf_tokens
+template <bool DBG>
+__global__ __launch_bounds__(WAVE, 4) void k_bgzf_tokens_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, const uint64_t *__restrict__ tok_off,
+                                                          int64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tokens, uint32_t *__restrict__ n_tok, int *__restrict__ status,
+                                                          unsigned long long *__restrict__ dbg)
+{
+	__shared__ WaveLds L;
+	const int64_t b = blockIdx.x;
+	if (b >= n_blocks) return;
+	const BgzfBlock blk = blocks[b];
+	uint32_t nt = 0;
+	int rc = INF_OK;
+	if (blk.u_len) rc = wave_inflate_tokens<DBG>(L, comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tokens + tok_off[b], nt, dbg);
+	if (threadIdx.x == 0) { status[b] = rc; n_tok[b] = rc == INF_OK ? nt : 0u; }
 }
 
 constexpr int RESOLVE_LANES = 16;

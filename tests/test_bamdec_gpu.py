@@ -266,3 +266,20 @@ def test_device_decode_record_longer_than_64_blocks(ctx, tmp_path, chunk_bytes):
         assert np.array_equal(h[k], d[k]), k
     assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"] and hunm == dunm
     assert int(np.max(h["l_qseq"])) == n and any(len(s) == (n + 1) // 2 + n for s in d["seqs"])
+
+
+@pytest.mark.parametrize("mode", ["wave", "lanes"])
+def test_tokens_modes(mode):
+    """Pass 1 of the inflate has two forms: a wavefront per BGZF block - 64 lanes decode the block's symbols speculatively from guessed bit offsets and
+    re-synchronise, tables shared in LDS (inflate_wave.h; the default up to 48 K blocks per chunk) - and a lane per block (the default above that).  Both,
+    forced, through the same device-decode == host-reader checks: stored, fixed and dynamic blocks, every match shape, records and blocks straddling
+    chunks, damaged input"""
+    import subprocess
+    import sys
+    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_INFLATE") or os.environ.get("SSV_TOKENS"):
+        pytest.skip("already inside a mode run")
+    env = dict(os.environ, SSV_TOKENS=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes or rejects_damage or longer_than"], env=env,
+                       capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
