@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_tokens(const uint8_t *__restrict_
 
 // pass 1 with a wavefront per block (inflate_wave.h): same outputs as k_bgzf_tokens
 template <bool DBG>
-__global__ __launch_bounds__(WAVE, 4) void k_bgzf_tokens_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, const uint64_t *__restrict__ tok_off,
+__global__ __launch_bounds__(WAVE, 5) void k_bgzf_tokens_wave(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, const uint64_t *__restrict__ tok_off,
                                                           int64_t n_blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ tokens, uint32_t *__restrict__ n_tok, int *__restrict__ status,
                                                           unsigned long long *__restrict__ dbg)
 {

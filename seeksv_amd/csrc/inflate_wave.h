@@ -2,8 +2,9 @@
 //
 // k_bgzf_tokens gives every lane its own block: 64 unrelated Huffman tables and input windows per wavefront (31 KB of LDS: five wavefronts per CU), every
 // memory instruction 64 unrelated addresses, every step the union of 64 lanes' paths.  Here the 64 lanes share one block, one set of tables (a 10-bit and an
-// 8-bit look-up table in LDS, canonical walk for longer codes) and one 4 KB window of the input, and decode it SPECULATIVELY in parallel:
-//   * the window is cut into 64 segments of 512 bits; lane 0 starts at the true position, lane i at the first bit of segment i (a guess);
+// 8-bit look-up table in LDS, canonical walk for longer codes) and one 3 KB window of the input (7 KB of LDS in all: 22 wavefronts per CU), and decode it
+// SPECULATIVELY in parallel:
+//   * the window is cut into 64 segments of 384 bits; lane 0 starts at the true position, lane i at the first bit of segment i (a guess);
 //   * every lane decodes symbols until it has left its segment and remembers where it ended (Huffman streams re-synchronise: a decoder that starts at a wrong
 //     bit falls into step with the true symbol boundaries after a few symbols, so most of these ends are right);
 //   * then lane i takes lane i-1's end as its start and decodes again if that differs from the start it used - repeated until no start changes.  Lane 0 is
@@ -20,9 +21,9 @@
 
 namespace ssv {
 
-constexpr int WV_SEG_BITS = 512;                        // input bits per lane and window
+constexpr int WV_SEG_BITS = 384;                        // input bits per lane and window
 #ifndef WV_TAIL_BITS
-#define WV_TAIL_BITS WV_SEG_BITS /* tried 160: the first round drops to a third, but with so short a run-in a third of the lanes end wrong and the later rounds grow by more (780 K -> 1,010 K cycles per block) */
+#define WV_TAIL_BITS WV_SEG_BITS
 #endif
 constexpr int WV_SEG_DW = WV_SEG_BITS / 32;
 constexpr int WV_WIN_DW = WAVE * WV_SEG_DW + 16;        // the window + room for the last lane's overshoot (a symbol is at most 48 bits)
@@ -30,11 +31,11 @@ constexpr int WV_LT = 10, WV_DT = 8, WV_CT = 7;         // look-up bits: literal
 
 struct WaveLds {
 	uint32_t win[WV_WIN_DW];
-	// look-up entries: bits 0-3 code length (0: no code of <= T bits starts like this), 4-7 extra bits, 8-9 kind (literal / length / end of block / invalid
-	// symbol), 16-31 the literal, the length's or distance's base, or the code-length symbol: a symbol step needs no arithmetic on the symbol
-	uint32_t lit[1 << WV_LT];
-	uint32_t dst[1 << WV_DT];
-	uint32_t clt[1 << WV_CT];
+	// look-up entries: (symbol << 4) | code length; 0: no code of <= T bits starts like this (a longer code - rare symbols: a short walk finds it - or none).
+	// Eleven bits for the literal / length code: with ten, one symbol in a hundred of a real BAM was longer, i.e. most steps of a 64-lane wavefront took the walk.
+	uint16_t lit[1 << WV_LT];
+	uint16_t dst[1 << WV_DT];
+	uint16_t clt[1 << WV_CT];
 	uint16_t perm0[288], perm1[32], perm2[32];          // symbols by (length, symbol): the slow path of codes longer than the look-up
 	__device__ __forceinline__ uint16_t *perm(int set) { return set == 0 ? perm0 : set == 1 ? perm1 : perm2; }
 	__device__ __forceinline__ const uint16_t *perm(int set) const { return set == 0 ? perm0 : set == 1 ? perm1 : perm2; }
@@ -94,31 +95,11 @@ __device__ __forceinline__ uint32_t wv_load_window(WaveLds &L, const uint8_t *in
 
 // One Huffman code from its lengths lens[0, n): look-up table of T bits (entries of longer codes stay 0) + counts / first codes / offsets / permutation.
 // All lanes call it together.  INF_E_OVERSUB for an over-subscribed code; an incomplete one is accepted (its unused bit patterns decode to "invalid").
-enum : uint32_t { WV_K_LIT = 0u << 8, WV_K_LEN = 1u << 8, WV_K_EOB = 2u << 8, WV_K_BAD = 3u << 8 };
-// what a symbol of code set `set` (0 literal/length, 1 distance, 2 code-length code) puts into its entries, without the code length
-__device__ __forceinline__ uint32_t wv_entry(int set, int s)
-{
-	if (set == 2) return (uint32_t)s << 16;
-	if (set == 1) {
-		if (s > 29) return WV_K_BAD;
-		if (s < 4) return (uint32_t)(s + 1) << 16;
-		const uint32_t e = (uint32_t)(s >> 1) - 1u;
-		return ((((2u + (uint32_t)(s & 1)) << e) + 1u) << 16) | (e << 4);
-	}
-	if (s < 256) return ((uint32_t)s << 16) | WV_K_LIT;
-	if (s == 256) return WV_K_EOB;
-	if (s > 285) return WV_K_BAD;
-	if (s < 265) return ((uint32_t)(s - 254) << 16) | WV_K_LEN;
-	if (s == 285) return (258u << 16) | WV_K_LEN;
-	const uint32_t e = (uint32_t)(s - 261) >> 2;
-	return ((((4u + (uint32_t)((s - 265) & 3)) << e) + 3u) << 16) | WV_K_LEN | (e << 4);
-}
-
 template <int T>
-__device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens, int n, uint32_t *tab)
+__device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens, int n, uint16_t *tab)
 {
 	const int lane = (int)threadIdx.x;
-	for (int i = lane; i < (1 << T); i += WAVE) tab[i] = 0u;
+	for (int i = lane; i < (1 << T) / 2; i += WAVE) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
 	uint32_t cnt[16];
 #pragma unroll
 	for (int l = 0; l < 16; ++l) cnt[l] = 0;
@@ -156,7 +137,7 @@ __device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens
 			if (l <= T) {
 				const uint32_t c = (uint32_t)L.first[set][l] + (idx - (uint32_t)L.off[set][l]);
 				const uint32_t rev = __brev(c) >> (32 - l);
-				const uint32_t ent = wv_entry(set, s) | (uint32_t)l;
+				const uint16_t ent = (uint16_t)((s << 4) | l);
 				for (uint32_t k = rev; k < (1u << T); k += 1u << l) tab[k] = ent;
 			}
 		}
@@ -167,14 +148,15 @@ __device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens
 
 // the entry of the code that starts the 32 bits `bits` (0: none); T = the look-up's bits
 template <int T>
-__device__ __forceinline__ uint32_t wv_lookup(const WaveLds &L, int set, const uint32_t *tab, uint32_t bits)
+__device__ __forceinline__ uint32_t wv_lookup(const WaveLds &L, int set, const uint16_t *tab, uint32_t bits)
 {
 	uint32_t e = tab[bits & ((1u << T) - 1u)];
-	if ((e & 15u) == 0u && T < 15) { // a code longer than the table's index (rare symbols), or none
+	if (e == 0u && T < 15) { // a code longer than the table's index, or none: the canonical walk over the remaining lengths (kept small: it is rarely taken)
 		const uint32_t rb = __brev(bits);
+#pragma unroll 1
 		for (int l = T + 1; l <= 15; ++l) {
 			const uint32_t d = (rb >> (32 - l)) - (uint32_t)L.first[set][l];
-			if (d < (uint32_t)L.cnt[set][l]) { e = wv_entry(set, (int)L.perm(set)[(uint32_t)L.off[set][l] + d]) | (uint32_t)l; break; }
+			if (d < (uint32_t)L.cnt[set][l]) { e = ((uint32_t)L.perm(set)[(uint32_t)L.off[set][l] + d] << 4) | (uint32_t)l; break; }
 		}
 	}
 	return e;
@@ -206,25 +188,29 @@ __device__ __forceinline__ WaveSeg wv_decode(const WaveLds &L, uint32_t w0_bits,
 		if (B.p >= lim_bits) { r.flag = WV_BAD; break; } // (a guessed start behind the payload, or a chain that runs off its end)
 		B.need(L);
 		const uint32_t e = wv_lookup<WV_LT>(L, 0, L.lit, B.peek());
-		if ((e & 15u) == 0u) { r.flag = WV_BAD; break; }
+		if (e == 0u) { r.flag = WV_BAD; break; }
 		B.drop((int)(e & 15u));
-		const uint32_t kind = e & (3u << 8);
-		if (kind == WV_K_LIT) {
-			if (EMIT) out[o0 + r.bytes] = (uint8_t)(e >> 16);
+		const uint32_t s = e >> 4;
+		if (s < 256u) {
+			if (EMIT) out[o0 + r.bytes] = (uint8_t)s;
 			++r.bytes; ++run;
 			continue;
 		}
-		if (kind != WV_K_LEN) { r.flag = kind == WV_K_EOB ? WV_EOB : WV_BAD; break; }
-		const int xb = (int)((e >> 4) & 15u);
-		const uint32_t mlen = (e >> 16) + (B.peek() & ((1u << xb) - 1u)); // (>= 18 bits were left: xb <= 5)
-		B.drop(xb);
+		if (s == 256u) { r.flag = WV_EOB; break; }
+		if (s > 285u) { r.flag = WV_BAD; break; }
+		// length: 257..264 -> 3..10; then groups of four symbols share an extra-bit count; 285 -> 258
+		uint32_t mlen;
+		if (s < 265u) mlen = s - 254u;
+		else if (s == 285u) mlen = 258u;
+		else { const int xb = (int)((s - 261u) >> 2); mlen = ((4u + ((s - 265u) & 3u)) << xb) + 3u + (B.peek() & ((1u << xb) - 1u)); B.drop(xb); } // (>= 18 bits were left: xb <= 5)
 		B.need(L);
 		const uint32_t e2 = wv_lookup<WV_DT>(L, 1, L.dst, B.peek());
-		if ((e2 & 15u) == 0u || (e2 & (3u << 8))) { r.flag = WV_BAD; break; }
+		const uint32_t ds = e2 >> 4;
+		if (e2 == 0u || ds > 29u) { r.flag = WV_BAD; break; }
 		B.drop((int)(e2 & 15u));
-		const int xd = (int)((e2 >> 4) & 15u);
-		const uint32_t dist = (e2 >> 16) + (B.peek() & ((1u << xd) - 1u)); // (>= 18 bits were left: xd <= 13)
-		B.drop(xd);
+		uint32_t dist;
+		if (ds < 4u) dist = ds + 1u;
+		else { const int xd = (int)(ds >> 1) - 1; dist = ((2u + (ds & 1u)) << xd) + 1u + (B.peek() & ((1u << xd) - 1u)); B.drop(xd); } // (>= 18 bits were left: xd <= 13)
 		const bool firstm = r.lead == ~0u;
 		if (firstm) r.lead = run;
 		uint32_t rr = run + (EMIT && firstm ? carry : 0u);
@@ -329,7 +315,7 @@ __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in
 				if (H.p >= lim_bits) return INF_E_INPUT;
 				H.need(L); // (the header of a block - at most 2,300 bits - lies inside the window that was loaded at its first bit)
 				const uint32_t e = L.clt[H.peek() & ((1u << WV_CT) - 1u)];
-				const int l = (int)(e & 15u), s = (int)(e >> 16);
+				const int l = (int)(e & 15u), s = (int)(e >> 4);
 				if (l == 0) return INF_E_CODE;
 				H.drop(l);
 				const uint32_t x = H.peek();
