@@ -22,6 +22,8 @@
 namespace ssv {
 
 constexpr int WV_SEG_BITS = 384;                        // input bits per lane and window
+// The first round's guesses start WV_TAIL_BITS before their segment's end.  A whole segment (the default) costs a full decode; 128-192 bits take a third to
+// a half of that, but with so short a run-in a third of the lanes end wrong and the later rounds grow by what the first one saved (measured: 14.6 -> 14.7 ms).
 #ifndef WV_TAIL_BITS
 #define WV_TAIL_BITS WV_SEG_BITS
 #endif
@@ -43,8 +45,6 @@ struct WaveLds {
 	uint8_t lens[320];
 	uint8_t cll[32];
 };
-
-struct WaveWin { uint32_t w0_bits; };                   // bit position (in the block's payload) of win[0]'s bit 0
 
 // Where dword j of the window lies in LDS: dword k of lane i's segment at k * 64 + i.  Lane i reads dwords 16 i + k; laid out as they come that is a stride of
 // 16 dwords between neighbouring lanes - a 16-way bank conflict on every read of the input, which was most of what the LDS did all day.
@@ -253,13 +253,13 @@ template <bool DBG>
 __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, uint32_t *tok, uint32_t &n_tok, unsigned long long *dbg_arg)
 {
 	unsigned long long *const dbg = DBG ? dbg_arg : nullptr;
-	unsigned long long d_blocks = 0, d_win = 0, d_rounds = 0, d_late = 0, c_load = 0, c_hdr = 0, c_r1 = 0, c_rn = 0, c_emit = 0, t0c = 0;
+	unsigned long long d_blocks = 0, d_win = 0, d_rounds = 0, d_late = 0, c_load = 0, c_hdr = 0, c_r1 = 0, c_rn = 0, c_emit = 0;
 	auto tick = [&]() { return dbg ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
 	struct Flush {
 		unsigned long long *dbg, *v[9];
 		__device__ ~Flush() { if (dbg && threadIdx.x == 0) for (int k = 0; k < 9; ++k) atomicAdd(dbg + k, *v[k]); }
 	} flush{dbg, {&d_blocks, &d_win, &d_rounds, &d_late, &c_load, &c_hdr, &c_r1, &c_rn, &c_emit}};
-	(void)t0c;
+
 	const int lane = (int)threadIdx.x;
 	const uint32_t lim_bits = in_len * 8u;
 	uint32_t cur = 0, o = 0, nt = 0, last = 0;
@@ -346,8 +346,6 @@ __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in
 			w0 = wv_load_window(L, in, in_len, cur);
 			c_load += tick() - tc; tc = tick();
 			const uint32_t seg_end = w0 + (uint32_t)(lane + 1) * WV_SEG_BITS;
-			// (the first round only has to find where a lane's segment ENDS: its guess starts WV_TAIL_BITS before that end - a decoder falls into step
-			// within a few symbols - and the round costs a fraction of a segment; the second round decodes whole segments from the ends found)
 			uint32_t start = lane == 0 ? cur : w0 + (uint32_t)lane * WV_SEG_BITS + (uint32_t)(WV_SEG_BITS - WV_TAIL_BITS);
 			WaveSeg r = wv_decode<false>(L, w0, start, seg_end, lim_bits, nullptr, 0, nullptr, 0, 0);
 			c_r1 += tick() - tc; tc = tick();
