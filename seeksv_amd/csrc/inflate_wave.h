@@ -170,6 +170,7 @@ struct WaveSeg {
 	uint32_t toks;     // tokens, the first match's run taken as the literals of THIS segment before it
 	uint32_t lead;     // literals before the first match (~0: no match in the segment)
 	uint32_t lastend;  // output bytes up to and including the last match
+	uint32_t steps;    // symbols decoded (the phase counters' view of how even the lanes' work is)
 	int flag;
 };
 
@@ -180,12 +181,13 @@ __device__ __forceinline__ WaveSeg wv_decode(const WaveLds &L, uint32_t w0_bits,
                                              uint32_t carry)
 {
 	WaveSeg r;
-	r.bytes = 0; r.toks = 0; r.lead = ~0u; r.lastend = 0; r.flag = WV_OK;
+	r.bytes = 0; r.toks = 0; r.lead = ~0u; r.lastend = 0; r.steps = 0; r.flag = WV_OK;
 	uint32_t run = 0;
 	WvBits B;
 	B.start(L, w0_bits, start);
 	while (B.p < seg_end) {
 		if (B.p >= lim_bits) { r.flag = WV_BAD; break; } // (a guessed start behind the payload, or a chain that runs off its end)
+		++r.steps;
 		B.need(L);
 		const uint32_t e = wv_lookup<WV_LT>(L, 0, L.lit, B.peek());
 		if (e == 0u) { r.flag = WV_BAD; break; }
@@ -349,6 +351,7 @@ __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in
 			uint32_t start = lane == 0 ? cur : w0 + (uint32_t)lane * WV_SEG_BITS + (uint32_t)(WV_SEG_BITS - WV_TAIL_BITS);
 			WaveSeg r = wv_decode<false>(L, w0, start, seg_end, lim_bits, nullptr, 0, nullptr, 0, 0);
 			c_r1 += tick() - tc; tc = tick();
+			if (DBG && dbg) { const uint32_t mx = wave_max(r.steps), sm = wave_sum(r.steps); if (lane == 0) { atomicAdd(dbg + 10, (unsigned long long)mx); atomicAdd(dbg + 11, (unsigned long long)sm); } }
 			int round = 1;
 			int t = WAVE - 1; // last lane whose symbols count
 			bool stop = false;
