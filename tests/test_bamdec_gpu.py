@@ -279,7 +279,67 @@ def test_tokens_modes(mode):
     if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_INFLATE") or os.environ.get("SSV_TOKENS"):
         pytest.skip("already inside a mode run")
     env = dict(os.environ, SSV_TOKENS=mode)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes or rejects_damage or longer_than"], env=env,
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes or rejects_damage or longer_than or every_deflate"], env=env,
                        capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def _bam_with_block_kinds(path, records, seed):
+    """a BAM whose BGZF blocks are compressed every which way zlib can: stored (level 0), fixed Huffman (Z_FIXED), Huffman only, run-length, levels 1-9,
+    and payloads of SEVERAL deflate blocks (full flushes inside a block: a dynamic block, an empty stored block, another dynamic block ...); block payloads
+    of 1 byte to 65280 bytes"""
+    import struct
+    import zlib
+    rng = np.random.default_rng(seed)
+    raw = bytearray()
+    text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(NAMES, LENS))
+    raw += b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(NAMES))
+    for n, l in zip(NAMES, LENS):
+        nb = n.encode() + b"\0"
+        raw += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    for r in records:
+        raw += bamio.encode_record(r)
+    kinds = [(0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (4, zlib.Z_FILTERED), "flushes"]
+    with open(path, "wb") as f:
+        at, k = 0, 0
+        while at < len(raw):
+            size = int(rng.choice([1, 7, 300, 4000, 30000, 0xff00]))
+            data = bytes(raw[at:at + size])
+            at += len(data)
+            kind = kinds[k % len(kinds)]
+            k += 1
+            if kind == "flushes":
+                c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                comp = b""
+                for j in range(0, len(data), 1500):
+                    comp += c.compress(data[j:j + 1500]) + c.flush(zlib.Z_FULL_FLUSH if (j // 1500) % 2 == 0 else zlib.Z_SYNC_FLUSH)
+                comp += c.flush()
+            else:
+                c = zlib.compressobj(kind[0], zlib.DEFLATED, -15, 8, kind[1])
+                comp = c.compress(data) + c.flush()
+            if len(comp) + 26 > 65536:  # (stored random-ish bytes can outgrow a BGZF block: halve it)
+                at -= len(data)
+                size = len(data) // 2
+                data = bytes(raw[at:at + size])
+                at += len(data)
+                c = zlib.compressobj(0, zlib.DEFLATED, -15)
+                comp = c.compress(data) + c.flush()
+            hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25)
+            f.write(hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+        f.write(bamio.BGZF_EOF)
+
+
+@pytest.mark.parametrize("chunk_bytes,max_blocks", [(64 << 20, 1 << 16), (1 << 18, 5)], ids=["one-chunk", "256KB-5blk"])
+def test_device_decode_every_deflate_block_kind(ctx, tmp_path, chunk_bytes, max_blocks):
+    """stored, fixed, dynamic, Huffman-only and run-length blocks, several deflate blocks inside one BGZF block (with empty stored blocks between them), tiny
+    and full-size payloads: both forms of pass 1 (this test runs again under SSV_TOKENS=wave and =lanes in test_tokens_modes) against the host reader"""
+    path = str(tmp_path / "kinds.bam")
+    _bam_with_block_kinds(path, _records(4000, 31) + _pattern_records(3000, 7), 3)
+    hb, hunm = _host_all(path, True)
+    db, dunm, druns, _ = _device_all(ctx, path, chunk_bytes, max_blocks, True)
+    h, d = _flatten(hb), _flatten(db)
+    for k in KEYS + ("shipped",):
+        assert np.array_equal(h[k], d[k]), k
+    assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"] and hunm == dunm
+    assert len(h["tid"]) == 7000
