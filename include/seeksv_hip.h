@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SSV_ABI_VERSION 5
+#define SSV_ABI_VERSION 6
 
 typedef enum {
 	SSV_OK = 0,
@@ -109,7 +109,9 @@ typedef struct {
 	                              tid_runs[k].tid; tid_runs[0].first == 0, firsts strictly increasing.  A coordinate-sorted BAM has one run per
 	                              contig, and the batcher sees the changes while it parses the records anyway.  With it (up to 48 runs) the
 	                              streaming pass of getsv does not read the tid column at all - 4 of its 8 bytes per record - except in the
-	                              few tiles a run boundary falls into; the column must still be there (other passes read single entries). */
+	                              few tiles a run boundary falls into; the column must still be there (other passes read single entries).
+	                              The list's shape is always checked (SSV_E_ARG); with SSV_VERIFY_RUNS=1 in the environment ssv_getsv_scan also
+	                              holds it against the tid column (one extra streaming pass) and refuses a list that disagrees. */
 	int64_t n_tid_runs;
 } ssv_batch_t;
 
@@ -143,10 +145,15 @@ void *ssv_stream(ssv_ctx *ctx);
  * at most two batches may be announced and not yet scanned.  The scan calls (ssv_clip_scan, ssv_isize_scan, ssv_getsv_scan,
  * ssv_getsv_prime) must then be given exactly the announced batches, in that order (SSV_E_STATE otherwise).  With or without prefetch:
  * when a scan call returns, the batch's host arrays have been read and may be reused.
+ * Announcements belong to the stream of batches, not to a pass: ssv_clip_begin leaves them alone (a driver ends a getclip pass and begins the
+ * next in the middle of a stream - and of a batch, ssv_clip_scan_range - while batch k+1 is on its way already).  ssv_isize_begin and
+ * ssv_getsv_begin start a new reading of the file and drop what is still announced; ssv_batch_prefetch_drop does so on request (a caller that
+ * gives up a stream early) and returns once the copies in flight have read their host arrays.
  */
 int ssv_host_alloc(size_t bytes, void **p);
 int ssv_host_free(void *p);
 int ssv_batch_prefetch(ssv_ctx *ctx, const ssv_batch_t *b);
+int ssv_batch_prefetch_drop(ssv_ctx *ctx);
 
 /* ---- batches that stay: one decode of the file for every pass ---------------------------------- */
 /*
@@ -377,7 +384,12 @@ typedef struct ssv_group ssv_group;
 int ssv_group_create(ssv_ctx **ctxs, int n, ssv_group **out);
 void ssv_group_destroy(ssv_group *g);
 int ssv_group_uses_rccl(const ssv_group *g);
-/* Called by every rank from its own thread: send = this rank's `bytes` bytes (host memory), recv = n * bytes, rank order. */
+/* Called by every rank from its own thread: send = this rank's `bytes` bytes (host memory), recv = n * bytes, rank order.
+ * No rank is ever left waiting: the ranks agree through the host - before anything is exchanged - that all of them arrived, prepared and
+ * bring vectors of one size; a rank whose ncclAllGather fails aborts the group's communicators (ncclCommAbort) so that its peers come back;
+ * a rank that does not arrive within SSV_GROUP_TIMEOUT_S (default 600) breaks the group.  In every such case EVERY rank returns an error
+ * (SSV_E_HIP / SSV_E_ARG for the rank at fault, SSV_E_STATE for the others) and nothing in `recv` may be used; after an abort or a timeout
+ * the group only answers SSV_E_STATE.  (SSV_GROUP_FAIL=<rank>:<1|2> injects a failure before / inside the exchange: tests.) */
 int ssv_group_allgather(ssv_group *g, int rank, const void *send, size_t bytes, void *recv);
 
 /* ---- device-side BGZF inflate + BAM record decode ---------------------------- */

@@ -300,6 +300,7 @@ def hip_lib():
         lib.ssv_host_alloc.argtypes = [C.c_size_t, C.POINTER(V)]
         lib.ssv_host_free.argtypes = [V]
         lib.ssv_batch_prefetch.argtypes = [V, C.POINTER(Batch)]
+        lib.ssv_batch_prefetch_drop.argtypes = [V]
         lib.ssv_clip_begin.argtypes = [V, C.POINTER(ClipParams)]
         lib.ssv_clip_scan.argtypes = [V, C.POINTER(Batch)]
         lib.ssv_clip_scan_range.argtypes = [V, C.POINTER(Batch), C.c_int64, C.c_int64]

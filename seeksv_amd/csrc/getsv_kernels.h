@@ -373,6 +373,29 @@ __device__ __forceinline__ void getsv_scan_load(const DevBatch &b, int64_t tile,
 	}
 }
 
+// SSV_VERIFY_RUNS=1 (always in the test suite): the batch's run list is the producer's statement about the tid column, and k_getsv_scan takes
+// a tile's contig from it without reading the column.  One streaming pass holds the column against the list: every record of run k must carry
+// tid[k].  *bad = 1 + index of a record that does not (any one of them).
+__global__ __launch_bounds__(BLOCK) void k_verify_runs(const int32_t *__restrict__ tid, int64_t n, RunTab runs, unsigned long long *bad)
+{
+	for (int64_t i0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * 4; i0 < n; i0 += (int64_t)gridDim.x * BLOCK * 4) {
+		int k = 0;
+		while (k + 1 < runs.n && runs.first[k + 1] <= i0) ++k;
+		if (i0 + 4 <= n) {
+			const int4 t = stream_load_i4(tid + i0);
+			const int v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				while (k + 1 < runs.n && runs.first[k + 1] <= i0 + j) ++k;
+				if (v[j] != runs.tid[k]) atomicMax(bad, (unsigned long long)(i0 + j + 1));
+			}
+		} else for (int64_t i = i0; i < n; ++i) {
+			while (k + 1 < runs.n && runs.first[k + 1] <= i) ++k;
+			if (tid[i] != runs.tid[k]) atomicMax(bad, (unsigned long long)(i + 1));
+		}
+	}
+}
+
 __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 {
 	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];

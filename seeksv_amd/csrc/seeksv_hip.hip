@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <cmath>
@@ -601,6 +602,15 @@ int ssv_batch_prefetch(ssv_ctx *c, const ssv_batch_t *b)
 	return SSV_OK;
 }
 
+int ssv_batch_prefetch_drop(ssv_ctx *c)
+{
+	if (!c) return SSV_E_ARG;
+	HIPCHECK(c, hipSetDevice(c->device));
+	if (!c->pf.empty()) HIPCHECK(c, hipStreamSynchronize(c->st_h2d)); // their host arrays are the caller's again when this returns
+	c->pf.clear();
+	return SSV_OK;
+}
+
 const char *ssv_last_error(const ssv_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 void *ssv_stream(ssv_ctx *c) { return c ? (void *)c->st : nullptr; }
 
@@ -611,7 +621,8 @@ void *ssv_stream(ssv_ctx *c) { return c ? (void *)c->st : nullptr; }
 int ssv_clip_begin(ssv_ctx *c, const ssv_clip_params *p)
 {
 	if (!c || !p) return SSV_E_ARG;
-	c->pf.clear(); // batches announced and never scanned are dropped
+	// (the announced batches stay announced: a pass may end and the next begin in the middle of a stream of batches - and of a batch,
+	// ssv_clip_scan_range; a caller that abandons a stream says so with ssv_batch_prefetch_drop)
 	HIPCHECK(c, hipSetDevice(c->device));
 	c->clip_p = *p;
 	c->clip_active = true;
@@ -1484,6 +1495,18 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	if (span > c->gs_map_span) CHECK(gs_build_tilemap(c, span));
 	GetsvArgs a;
 	CHECK(fill_runs(c, b, a.runs));
+	static const bool verify_runs = getenv("SSV_VERIFY_RUNS") && atoi(getenv("SSV_VERIFY_RUNS")) != 0;
+	if (verify_runs && a.runs.n > 0) { // the run list against the column it stands for (the scan below never reads that column where a run covers a tile)
+		CHECK(ensure(c, c->counters, sizeof(ClipCounters)));
+		CHECK(ensure_host(c, c->h_counters, sizeof(ClipCounters)));
+		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
+		k_verify_runs<<<(unsigned)std::min<int64_t>(256 * 8, (d.n + BLOCK * 4 - 1) / (BLOCK * 4)), BLOCK, 0, c->st>>>(d.tid, d.n, a.runs, &P<ClipCounters>(c->counters)->n_cand);
+		HIPCHECK(c, hipGetLastError());
+		HIPCHECK(c, hipMemcpyAsync(c->h_counters.p, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));
+		HIPCHECK(c, hipStreamSynchronize(c->st));
+		const unsigned long long badrec = P<ClipCounters>(c->h_counters)->n_cand;
+		if (badrec) { c->err = "tid_runs disagree with the tid column at record " + std::to_string(badrec - 1) + " (SSV_VERIFY_RUNS)"; return SSV_E_ARG; }
+	}
 	a.b = d; a.tilemap = P<uint8_t>(c->gs_tilemap); a.tile_win = P<uint32_t>(c->gs_tile_win); a.tile_junc = P<uint32_t>(c->gs_tile_junc); a.ctg_tile_off = P<int64_t>(c->gs_ctgoff); a.n_targets = c->gs_p.n_targets;
 	a.junc = P<DevJunction>(c->gs_djunc); a.n_junc = (int64_t)c->gs_junc.size(); a.junc_wmax = c->gs_wmax;
 	a.mean = c->gs_p.mean; a.sd = c->gs_p.sd; a.times = c->gs_p.times; a.disc_min_mapq = c->gs_p.disc_min_mapq;

@@ -55,6 +55,10 @@ class Context:
         the upload stream now; the next scan call must be given this batch"""
         self._check(self._lib.ssv_batch_prefetch(self._h, C.byref(batch)), "ssv_batch_prefetch")
 
+    def prefetch_drop(self):
+        """give up the announced batches (their host arrays may be reused when this returns)"""
+        self._check(self._lib.ssv_batch_prefetch_drop(self._h), "ssv_batch_prefetch_drop")
+
     @staticmethod
     def _as_batch(b):
         if isinstance(b, _abi.Batch):

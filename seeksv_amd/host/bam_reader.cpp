@@ -574,11 +574,16 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 	if (at0 < 0) { g_err = "cannot tell the file position"; return -1; }
 	uint8_t *d = static_cast<uint8_t *>(dst);
 	const size_t PIECE = (size_t)256 << 20, SLICE = (size_t)4 << 20;
+	static const bool timing = getenv("SSV_TIMING_CHUNKS") != nullptr;
+	double t_read = 0, t_walk = 0;
+	auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	struct Report { const bool on; double &r, &w; size_t &bytes; int64_t &nb; ~Report() { if (on) fprintf(stderr, "[timing] (read_blocks: %zu bytes, %lld blocks: pread %.4f s, header walk %.4f s)\n", bytes, (long long)nb, r, w); } };
 	size_t have = 0;      // bytes of the file (from at0) that are in dst
 	size_t p = 0;         // bytes of dst that whole, accepted blocks cover
 	uint64_t inflated = 0;
 	int64_t n = 0;
 	bool stop = false, range_done = false;
+	Report report{timing, t_read, t_walk, p, n};
 	while (!stop) {
 		// more of the file (leave 8 spare bytes in dst: the device bit reader looks 4 bytes past a payload)
 		const uint64_t left_in_file = file_size - ((uint64_t)at0 + have);
@@ -587,6 +592,7 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 			const uint64_t last_needed = (uint64_t)b->raw_end_coff + 65536 + 1024;
 			if ((uint64_t)at0 + have + want > last_needed) want = (uint64_t)at0 + have < last_needed ? (size_t)(last_needed - (uint64_t)at0 - have) : 0;
 		}
+		const double tr0 = timing ? clk() : 0;
 		if (want) {
 			const int ns = (int)((want + SLICE - 1) / SLICE);
 			std::vector<int> ok((size_t)ns, 1);
@@ -602,6 +608,9 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 			for (int v : ok) if (!v) { g_err = "read error on the BAM file"; b->z.eof = true; return -1; }
 			have += want;
 		}
+		const double tw0 = timing ? clk() : 0;
+		t_read += tw0 - tr0;
+		struct Lap { double &acc; double t0; bool on; std::function<double()> c; ~Lap() { if (on) acc += c() - t0; } } lap{t_walk, tw0, timing, clk};
 		// the blocks that are whole in dst
 		for (;;) {
 			if (n >= max_blocks) { stop = true; break; }

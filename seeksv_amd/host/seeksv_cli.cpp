@@ -195,11 +195,18 @@ static void use_pinned_batches(ssvh_bam *b)
 // The batches of a host reader (read-ahead on: three sets of arrays) through a context: batch k+1 is decoded, announced and on its way to the
 // GPU (ssv_batch_prefetch, the upload stream) while batch k is scanned; `side` sees every batch right after it was read (the reader's
 // per-batch side channel - unmapped reads - is valid only then), `scan` gets them in order.  Returns "" or the error text.
+// records per batch of the host reader (SSV_HOST_BATCH_RECORDS: tests cut small files into many batches)
+static int64_t host_batch_records()
+{
+	static const int64_t n = [] { const char *e = getenv("SSV_HOST_BATCH_RECORDS"); return e ? std::max<int64_t>(1, atoll(e)) : (int64_t)1 << 22; }();
+	return n;
+}
+
 template <class Side, class Scan> static string pump_host_batches(ssvh_bam *rb, ssv_ctx *ctx, int keep_all_seq, Side side, Scan scan)
 {
 	ssv_batch_t b[2];
 	auto read = [&](ssv_batch_t *out) -> string {
-		if (ssvh_bam_read_batch(rb, 1 << 22, keep_all_seq, out) != 0) return string("[seeksv] ") + ssvh_last_error();
+		if (ssvh_bam_read_batch(rb, host_batch_records(), keep_all_seq, out) != 0) return string("[seeksv] ") + ssvh_last_error();
 		if (out->n == 0) return "";
 		side(*out);
 		if (ssv_batch_prefetch(ctx, out) != SSV_OK) return string("[seeksv] ") + ssv_last_error(ctx);
@@ -347,7 +354,7 @@ struct BatchSource {
 			return true;
 		}
 		if (!on_device) {
-			if (ssvh_bam_read_batch(bam, 1 << 22, keep_all_seq, b) != 0) die(string("[seeksv] ") + ssvh_last_error());
+			if (ssvh_bam_read_batch(bam, host_batch_records(), keep_all_seq, b) != 0) die(string("[seeksv] ") + ssvh_last_error());
 			return b->n != 0;
 		}
 		for (;;) {

@@ -7,5 +7,9 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# every ssv_getsv_scan of the suite (and of the CLI processes it starts) holds the batch's tid_runs against its tid column first
+os.environ.setdefault("SSV_VERIFY_RUNS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

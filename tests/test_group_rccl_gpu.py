@@ -60,6 +60,86 @@ def test_allgather_over_rccl(n_bytes):
             lib.ssv_ctx_destroy(h)
 
 
+def _run_ranks(lib, g, n, sizes, skip=()):
+    """every rank's ssv_group_allgather on a thread of its own; returns (return codes, received arrays, hung?)"""
+    send = [np.full(max(1, sizes[r]), r + 1, dtype=np.uint8) for r in range(n)]
+    recv = [np.zeros(max(1, max(sizes) * n), dtype=np.uint8) for _ in range(n)]
+    rcs = [None] * n
+
+    def rank(r):
+        rcs[r] = lib.ssv_group_allgather(g, r, send[r].ctypes.data, sizes[r], recv[r].ctypes.data)
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(n) if r not in skip]
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    return rcs, recv, any(t.is_alive() for t in th)
+
+
+def _err(lib, h):
+    lib.ssv_last_error.restype = C.c_char_p
+    lib.ssv_last_error.argtypes = [C.c_void_p]
+    return lib.ssv_last_error(h).decode()
+
+
+@pytest.mark.parametrize("transport", ["host-exchange", "rccl"])
+def test_exchange_never_leaves_a_rank_waiting(transport, monkeypatch):
+    """whatever goes wrong on ONE rank - a vector of another size, a failure before the exchange, a failure inside it, a
+    thread that never arrives - every rank RETURNS, all with an error, and (unless the group was broken) the next exchange works."""
+    lib = _abi.hip_lib()
+    n_dev = lib.ssv_device_count()
+    if transport == "rccl":
+        if n_dev < 2:
+            pytest.skip("one GPU: RCCL cannot put two ranks on one device")
+        n, devices = min(n_dev, 4), list(range(min(n_dev, 4)))
+    else:
+        n, devices = 3, [0, 0, 0]
+    E_HIP, E_ARG, E_STATE = -2, -3, -4
+
+    def fresh(**env):
+        for k in ("SSV_GROUP_FAIL", "SSV_GROUP_TIMEOUT_S"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return _group(lib, devices)
+
+    def drop(ctxs, g):
+        lib.ssv_group_destroy(g)
+        for h in ctxs:
+            lib.ssv_ctx_destroy(h)
+
+    # vectors of different sizes: agreed on BEFORE anything is exchanged; the group stays usable
+    ctxs, g = fresh()
+    assert lib.ssv_group_uses_rccl(g) == (1 if transport == "rccl" else 0)
+    sizes = [4096] * n
+    sizes[n - 1] = 4000
+    rcs, _, hung = _run_ranks(lib, g, n, sizes)
+    assert not hung and rcs == [E_ARG] * n and "different sizes" in _err(lib, ctxs[0])
+    rcs, recv, hung = _run_ranks(lib, g, n, [4096] * n)
+    assert not hung and rcs == [0] * n
+    assert all(np.array_equal(recv[r][:4096 * n], np.repeat(np.arange(1, n + 1, dtype=np.uint8), 4096)) for r in range(n))
+    drop(ctxs, g)
+
+    # a rank that fails before the exchange (allocation, copy ...): it reports its own error, the others SSV_E_STATE; usable afterwards
+    ctxs, g = fresh(SSV_GROUP_FAIL="1:1")
+    rcs, _, hung = _run_ranks(lib, g, n, [512] * n)
+    assert not hung and rcs[1] == E_HIP and all(rcs[r] == E_STATE for r in range(n) if r != 1)
+    assert "injected" in _err(lib, ctxs[1]) and "another rank failed" in _err(lib, ctxs[0])
+    drop(ctxs, g)
+
+    # a rank that fails INSIDE the exchange (ncclAllGather returns an error on it alone): the peers come back too
+    ctxs, g = fresh(SSV_GROUP_FAIL="0:2", SSV_GROUP_TIMEOUT_S="20")
+    rcs, _, hung = _run_ranks(lib, g, n, [512] * n)
+    assert not hung and rcs[0] == E_HIP and all(rcs[r] in (E_STATE, E_HIP) for r in range(1, n)), rcs
+    drop(ctxs, g)
+
+    # a rank whose thread never arrives: the others give up after SSV_GROUP_TIMEOUT_S, and the group says so from then on
+    ctxs, g = fresh(SSV_GROUP_TIMEOUT_S="0.5")
+    rcs, _, hung = _run_ranks(lib, g, n, [512] * n, skip=(n - 1,))
+    assert not hung and all(rcs[r] == E_STATE for r in range(n - 1)) and "did not reach the exchange" in _err(lib, ctxs[0])
+    rcs, _, hung = _run_ranks(lib, g, n, [512] * n)
+    assert not hung and rcs == [E_STATE] * n
+    drop(ctxs, g)
+
+
 def test_cli_ranks_on_real_devices(tmp_path):
     """`seeksv getsv -N n` with one rank per real GPU: the tallies and depths meet in ncclAllGather and equal the single-GPU table"""
     import os

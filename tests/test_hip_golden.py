@@ -585,6 +585,17 @@ def test_getsv_scan_with_and_without_tid_runs(ctx, monkeypatch):
     for bad in (np.array([(5, 0, 0)], _abi.TID_RUN_DTYPE), np.array([(0, 0, 0), (0, 1, 0)], _abi.TID_RUN_DTYPE), np.array([(0, 0, 0), (w.n_total, 1, 0)], _abi.TID_RUN_DTYPE)):
         db.set_tid_runs(bad)
         assert lib.ssv_getsv_scan(ctx._h, C.byref(db)) == -3
+    # ... and so are well-formed lists that do not say what the tid column says (SSV_VERIFY_RUNS=1, set for the whole suite in conftest.py: one
+    # streaming pass holds the column against the list before the scan relies on it): a boundary one record late, one record early, a wrong
+    # contig for a run, a missing run
+    shifted, early, wrong, missing = runs.copy(), runs.copy(), runs.copy(), np.delete(runs, 4)
+    shifted["first"][3] += 1
+    early["first"][8] -= 1
+    wrong["tid"][5] = int(runs["tid"][5]) + 1
+    for bad in (shifted, early, wrong, missing):
+        db.set_tid_runs(bad)
+        assert lib.ssv_getsv_scan(ctx._h, C.byref(db)) == -3 and b"disagree with the tid column" in lib.ssv_last_error(ctx._h)
     db.set_tid_runs(runs)
+    assert lib.ssv_getsv_scan(ctx._h, C.byref(db)) == 0
     plan.close()
     hdr.close()

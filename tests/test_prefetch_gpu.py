@@ -82,10 +82,27 @@ def test_prefetch_order_is_enforced(ctx):
     ctx.clip_scan(bb[0])
     n2 = ctx.clip_cluster()["n_clusters"]
     assert n2 == ctx.getclip([a, b])["n_clusters"]
-    # a pass that ends with an announced batch left over: the next begin drops it
+    # an announcement belongs to the stream of batches, not to a pass: it survives ssv_clip_begin (a driver ends a pass in the middle of a
+    # batch while the next batch is on its way, seeksv_cli.cpp:getclip_single) ...
     ctx.clip_begin()
     ctx.prefetch(ba[0])
+    ctx.clip_begin()
+    with pytest.raises(SeeksvError, match="prefetched batch is pending"):
+        ctx.clip_scan(bb[0])
+    ctx.prefetch(bb[0])
+    ctx.clip_scan_range(ba[0], 0, 100)      # a leading part: the batch stays announced
+    ctx.clip_begin()
+    ctx.clip_scan_range(ba[0], 100, ba[0].n)
+    ctx.clip_scan(bb[0])
+    ctx.clip_cluster()
+    # ... until the caller gives the stream up
+    ctx.clip_begin()
+    ctx.prefetch(ba[0])
+    ctx.prefetch_drop()
     assert ctx.getclip([a, b])["n_clusters"] == n2
+    # ... or a new reading of the file starts (insert sizes, the fused getsv pass)
+    ctx.prefetch(ba[0])
+    assert ctx.isize_stats([a, b], 20, 5000000)[1] > 0
     dev, keep = w.generate_device(0, 1000, 0)
     with pytest.raises(SeeksvError, match="host batches"):
         ctx.prefetch(dev)
