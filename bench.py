@@ -365,6 +365,11 @@ def main():
                        "host_cpus_bound_near_gpu": near_cpus, "generation_s": round(gen_s, 2)},
             "roofline": {"kernel": "path: all device kernels of one step (getclip + insert size + getsv passes; PCIe copy excluded)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": total_traffic,
+                         # `traffic` is NOT measured in this run: PMC passes cannot run inside a bench line.  It is the committed counter file of the builder's
+                         # PMC passes over this same command; used only when this run's records per GPU equal that file's (within 2 %: the rank split), null otherwise
+                         "traffic_source": (f"profiles/traffic.json ({traffic.get('_round', 'builder-run')} rocprofv3 PMC passes over `bench.py --steps 1 --warmup 1 --no-overlap`, "
+                                            f"{traffic.get('records')} records; this run: {n_own} records per GPU)" if total_traffic else
+                                            f"none: profiles/traffic.json holds {traffic.get('records')} records per GPU, this run {n_own}"),
                          # the other way to read the same launches: the bytes the kernels really moved (PMC counters) over their time.  The path reads 18 of the 40
                          # "read every field once" bytes (the cold 64-byte lines are touched for 1-2 % of the records only), so `frac` (work done per second against
                          # the peak) is higher than the share of the memory system that is in use.
@@ -387,10 +392,11 @@ def main():
                 avail_gb = 0.0
             # Every record with its bases and qualities: 72-76 B/record in the file.  What bounds the leg's size is writing the file with zlib on the
             # host (outside the timed region, but inside the run): level 6 deflates ~11 MB/s per core, level 4 (lazy matching too, 76 instead of
-            # 72 B/record) ~40 MB/s.  The driver's box grants 16 CPUs of time: an eighth of the sample (77 M records, 21 GB of records) at level 4
-            # takes about half a minute; >= 64 CPUs write a quarter at level 6; >= 192 the whole sample.
+            # 72 B/record) ~40 MB/s.  The driver's box grants 16 CPUs of time: a QUARTER of the sample (154 M records, 42 GB of records, an 11.8 GB file)
+            # at level 4 takes about a minute (round 3 took an eighth: file-to-file rates of a 6 GB file are mostly start-up costs); >= 192 CPUs write
+            # the whole sample.
             eff = effective_cpus()
-            args.file_frac = args.genome_frac * (1.0 if eff >= 192 and avail_gb >= 256 else 0.25 if eff >= 64 and avail_gb >= 64 else 0.125 if eff >= 12 and avail_gb >= 32 else 1 / 64)
+            args.file_frac = args.genome_frac * (1.0 if eff >= 192 and avail_gb >= 256 else 0.25 if eff >= 12 and avail_gb >= 64 else 0.125 if eff >= 8 and avail_gb >= 32 else 1 / 64)
             if args.file_level < 0:
                 args.file_level = 6 if eff >= 64 else 4
         if args.file_level < 0:
@@ -551,25 +557,114 @@ def file_path_leg(ctx, args, device):
         jtable = host.JunctionTable(w.junctions)
         lib = ctx._lib
 
-        def decode(k, keep_all_seq=0):
-            buf, blocks, nb, nbytes = chunks[k]
-            b = _abi.Batch()
-            ctx._check(lib.ssv_bamdec_decode(ctx._h, C.c_void_p(buf.data_ptr()), nbytes, blocks, nb, keep_all_seq, C.byref(b)), "ssv_bamdec_decode")
-            return b
+        class Preloaded:
+            """the file's chunks as they lie in pinned host memory already (read before the timed region): round 3's footing, kept as `from_pinned`"""
+            def open(self):
+                return self
+            def get(self, k):
+                return chunks[k] if k < len(chunks) else None
+            def ready(self, k):
+                return k < len(chunks)
+            def release(self, k):
+                pass
+            def close(self):
+                pass
 
-        def announce(k):
-            """chunk k's compressed bytes start for the GPU now (ssv_bamdec_prefetch): called before the chunk in front of it is decoded"""
-            if k < len(chunks):
-                buf, _, _, nbytes = chunks[k]
-                ctx._check(lib.ssv_bamdec_prefetch(ctx._h, C.c_void_p(buf.data_ptr()), nbytes), "ssv_bamdec_prefetch")
+        class Streamed:
+            """the file read INSIDE the timed region, the way `seeksv`'s BatchSource reads it: a thread runs up to three chunks ahead of the decoder, every
+            chunk pread by all host threads (ssvh_bam_read_blocks) into one of three pinned buffers; a slot is the reader's again when its chunk is decoded"""
+            NS = 3
+
+            def __init__(self):
+                self.bufs = [torch.empty(cap, dtype=torch.uint8, pin_memory=True) for _ in range(self.NS)]   # (like the preloaded chunks: allocated outside the timed region)
+                self.blocks = [(_abi.BgzfBlock * max_blocks)() for _ in range(self.NS)]
+
+            def open(self):
+                self.cv = threading.Condition()
+                self.produced, self.released, self.stop, self.err, self.slots = 0, 0, False, None, [None] * self.NS
+                self.reader = host.BamReader(bam)
+                fo = C.c_uint64()
+                if hl.ssvh_bam_raw_begin(self.reader.handle, C.byref(fo)) != 0:
+                    raise IOError(hl.ssvh_last_error().decode())
+                self.th = threading.Thread(target=self._run)
+                self.th.start()
+                return self
+
+            def _run(self):
+                k = 0
+                while True:
+                    with self.cv:
+                        self.cv.wait_for(lambda: self.stop or k - self.released < self.NS)
+                        if self.stop:
+                            return
+                    buf, blocks = self.bufs[k % self.NS], self.blocks[k % self.NS]
+                    nb, nbytes = C.c_int64(), C.c_size_t()
+                    rc = hl.ssvh_bam_read_blocks(self.reader.handle, C.c_void_p(buf.data_ptr()), cap, chunk_inflated, blocks, max_blocks, C.byref(nb), C.byref(nbytes))
+                    with self.cv:
+                        if rc != 0:
+                            self.err = hl.ssvh_last_error().decode()
+                        self.slots[k % self.NS] = (buf, blocks, nb.value, nbytes.value) if rc == 0 and nb.value else None
+                        self.produced = k + 1
+                        self.cv.notify_all()
+                    if rc != 0 or nb.value == 0:
+                        return
+                    k += 1
+
+            def get(self, k):
+                with self.cv:
+                    self.cv.wait_for(lambda: self.produced > k)
+                    if self.err:
+                        raise IOError(self.err)
+                    return self.slots[k % self.NS]
+
+            def ready(self, k):
+                with self.cv:
+                    return self.produced > k and self.slots[k % self.NS] is not None and not self.err
+
+            def release(self, k):
+                with self.cv:
+                    self.released = k + 1
+                    self.cv.notify_all()
+
+            def close(self):
+                with self.cv:
+                    self.stop = True
+                    self.cv.notify_all()
+                self.th.join()
+                ctx._check(lib.ssv_bamdec_prefetch_drop(ctx._h), "ssv_bamdec_prefetch_drop")
+                self.reader.close()
+
+        def decoded_chunks(source, keep_all_seq=0):
+            """every chunk of the file through the device decoder, in order; chunk k+1 is announced (ssv_bamdec_prefetch: its compressed bytes start for the GPU)
+            before chunk k is decoded whenever it is there already"""
+            src = source.open()
+            try:
+                k, announced = 0, -1
+                c = src.get(0)
+                while c is not None:
+                    if announced < k + 1 and src.ready(k + 1):
+                        nbuf, _, _, nnbytes = src.get(k + 1)
+                        ctx._check(lib.ssv_bamdec_prefetch(ctx._h, C.c_void_p(nbuf.data_ptr()), nnbytes), "ssv_bamdec_prefetch")
+                        announced = k + 1
+                    buf, blocks, nb, nbytes = c
+                    b = _abi.Batch()
+                    ctx._check(lib.ssv_bamdec_decode(ctx._h, C.c_void_p(buf.data_ptr()), nbytes, blocks, nb, keep_all_seq, C.byref(b)), "ssv_bamdec_decode")
+                    yield b     # (valid until the next decode; the chunk's slot stays the decoder's until the consumer comes back)
+                    src.release(k)
+                    k += 1
+                    c = src.get(k)
+            finally:
+                src.close()
 
         def end_of_input():
             b = _abi.Batch()
             ctx._check(lib.ssv_bamdec_decode(ctx._h, None, 0, None, 0, 0, C.byref(b)), "ssv_bamdec_decode")
 
-        def one_run(single_decode=True):
+        def one_run(single_decode=True, source=None):
             """single_decode: every chunk is inflated and decoded ONCE; its records stay in HBM (ssv_batch_retain: 80 B/record) and the getsv
-            passes scan them there.  False: the two-command shape of the reference - getclip reads the file, getsv reads it again."""
+            passes scan them there.  False: the two-command shape of the reference - getclip reads the file, getsv reads it again.
+            source: where the chunks come from (Preloaded / Streamed: the file read inside the timed region)"""
+            source = source or preloaded
             t = {}
             t0 = time.perf_counter()
             kept = []
@@ -578,10 +673,7 @@ def file_path_leg(ctx, args, device):
                 ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
                 ctx.clip_begin(0.9, 1, False, None, 0)
                 n = 0
-                announce(0)
-                for k in range(len(chunks)):
-                    announce(k + 1)
-                    b = decode(k)
+                for b in decoded_chunks(source):
                     n += b.n
                     if single_decode:
                         b = ctx.batch_retain(b)
@@ -598,21 +690,24 @@ def file_path_leg(ctx, args, device):
                 # ---- pass 2: seeksv getsv (insert size on the file's first records, then discordant pairs + depth of every record) ----
                 t1 = time.perf_counter()
                 ctx._check(lib.ssv_isize_begin(ctx._h, 20, 5000000), "ssv_isize_begin")
-                done, used, b0 = C.c_int32(0), 0, None
+                done, used = C.c_int32(0), 0
+                head = []   # two_reads: the batches the insert-size pass decoded, kept for the scan (like the CLI's IsizeCarry)
+                stream = None
                 if single_decode:
                     while used < len(kept) and not done.value:
                         ctx._check(lib.ssv_isize_accumulate(ctx._h, C.byref(kept[used]), C.byref(done)), "ssv_isize_accumulate")
                         used += 1
                 else:
-                    # CalculateInsertsizeDeviation reads the file until it has its 5,000,000 pairs (cluster.cpp:68): usually inside the first chunk,
-                    # which then serves the scan as well; if it took more chunks, decoding starts over for the scan
+                    # CalculateInsertsizeDeviation reads the file until it has its 5,000,000 pairs (cluster.cpp:68): the first chunk or the first few; their
+                    # batches stay (ssv_batch_retain) and the fused scan goes on from the chunk behind them - the second reading of the file is ONE reading
                     ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
-                    announce(0)
-                    while used < len(chunks) and not done.value:
-                        announce(used + 1)
-                        b0 = decode(used)
-                        used += 1
+                    stream = decoded_chunks(source)
+                    for b0 in stream:
                         ctx._check(lib.ssv_isize_accumulate(ctx._h, C.byref(b0), C.byref(done)), "ssv_isize_accumulate")
+                        head.append(ctx.batch_retain(b0))
+                        kept.append(head[-1])
+                        if done.value:
+                            break
                 npairs, mean, sd = C.c_int64(), C.c_int32(0), C.c_int32(0)
                 ctx._check(lib.ssv_isize_finish(ctx._h, C.byref(npairs), C.byref(mean), C.byref(sd)), "ssv_isize_finish")
                 npairs, mean, sd = npairs.value, mean.value, sd.value
@@ -622,16 +717,10 @@ def file_path_leg(ctx, args, device):
                     for b in kept:
                         ctx.getsv_scan(b)
                 else:
-                    if used == 1:
-                        ctx.getsv_scan(b0)
-                        first_k = 1
-                    else:
-                        ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
-                        first_k = 0
-                        announce(0)
-                    for k in range(first_k, len(chunks)):
-                        announce(k + 1)
-                        ctx.getsv_scan(decode(k))
+                    for b in head:
+                        ctx.getsv_scan(b)
+                    for b in stream:
+                        ctx.getsv_scan(b)
                     end_of_input()
                 counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
                 folded = plan.fold(counts, rs, pd)
@@ -645,29 +734,41 @@ def file_path_leg(ctx, args, device):
                                depth_sum=int(folded["up_depth"].sum() + folded["down_depth"].sum()), max_depth=int(max_depth))
             return t
 
+        preloaded = Preloaded()
         one_run()                      # warm-up: buffers grow to size
         ctx.prof_reset(); ctx.prof_enable(1)
         runs = [one_run() for _ in range(3)]
         prof = ctx.prof_all()
         ctx.prof_enable(0)
-        best = min(runs, key=lambda t: t["total_s"])
-        two = min((one_run(False) for _ in range(2)), key=lambda t: t["total_s"])   # the reference's shape: each command reads the file
-        assert two["result"] == best["result"]
+        pinned_best = min(runs, key=lambda t: t["total_s"])
+        pinned_two = min((one_run(False) for _ in range(2)), key=lambda t: t["total_s"])   # the reference's shape: each command reads the file
+        assert pinned_two["result"] == pinned_best["result"]
+        # ... and with the FILE READ inside the timed region: the reader thread preads the file out of the page cache while the GPU decodes
+        streamed = Streamed()
+        one_run(True, streamed)
+        best = min((one_run(True, streamed) for _ in range(3)), key=lambda t: t["total_s"])
+        two = min((one_run(False, streamed) for _ in range(2)), key=lambda t: t["total_s"])
+        assert best["result"] == pinned_best["result"] and two["result"] == best["result"]
         inflated = None
         kernel_ms = {k: round(v["total_ms"] / len(runs), 3) for k, v in prof.items() if v["launches"]}
         out = {"value": w.n_total / best["total_s"], "unit": "records/s",
                "workload": f"synthetic {args.depth:g}x WGS, genome_frac {args.file_frac:g}: {w.n_total} records, every one with its bases (reference + 0.2 % substitutions) and qualities "
                            f"(from {{2,11,25,37,40}}), as a BAM file of {bam_bytes} bytes = {bam_bytes / w.n_total:.1f} B/record (BGZF deflate level {args.file_level}, written by libseeksv_host; "
-                           f"{inflated_total / w.n_total:.1f} B/record inflated), {len(chunks)} chunks of whole BGZF blocks in pinned host memory",
+                           f"{inflated_total / w.n_total:.1f} B/record inflated), read in {len(chunks)} chunks of whole BGZF blocks",
                "records": w.n_total, "bam_bytes": bam_bytes, "bam_bytes_per_record": round(bam_bytes / w.n_total, 2), "inflated_bytes_per_record": round(inflated_total / w.n_total, 2), "chunks": len(chunks),
-               "timed_region": "per pass and chunk: H2D of the compressed bytes out of pinned host memory -> device BGZF inflate -> BAM record decode -> scans -> tables / tallies on the host; "
-                               "NOT in it: reading the file from /dev/shm into the pinned buffers and the scan of its BGZF block headers (ssvh_bam_read_blocks, %.1f s here), file creation" % read_s,
+               "includes_file_read": True,
+               "timed_region": "opening the file, then per pass and chunk: the chunk pread out of the page cache (/dev/shm) into one of three pinned buffers by a reader thread that runs ahead "
+                               "(ssvh_bam_read_blocks: all host threads, block headers scanned there) -> H2D of the compressed bytes (the next chunk's announced ahead) -> device BGZF inflate -> BAM record "
+                               "decode -> scans -> tables / tallies on the host; NOT in it: file creation, allocating the three pinned buffers",
                "getclip_s": round(best["getclip_s"], 4), "getsv_s": round(best["getsv_s"], 4), "total_s": round(best["total_s"], 4),
                "runs_total_s": [round(t["total_s"], 4) for t in runs],
                "pcie_in_GBs": round(bam_bytes / best["total_s"] / 1e9, 2),   # (the compressed bytes cross PCIe once)
                "kernel_ms_per_run": kernel_ms, "result": best["result"],
                "two_reads": {"total_s": round(two["total_s"], 4), "getclip_s": round(two["getclip_s"], 4), "getsv_s": round(two["getsv_s"], 4), "value": w.n_total / two["total_s"],
-                             "what": "the same with the file inflated and decoded twice, once per command like the reference (seeksv.cpp:128,157): same counts"},
+                             "what": "the same with the file read, inflated and decoded twice, once per command like the reference (seeksv.cpp:128,157): same counts"},
+               "from_pinned": {"value": w.n_total / pinned_best["total_s"], "total_s": round(pinned_best["total_s"], 4), "getclip_s": round(pinned_best["getclip_s"], 4), "getsv_s": round(pinned_best["getsv_s"], 4),
+                               "two_reads_value": w.n_total / pinned_two["total_s"], "two_reads_total_s": round(pinned_two["total_s"], 4), "includes_file_read": False,
+                               "what": "round 3's footing: the whole file in pinned host memory before the clock starts (reading it there took %.1f s, outside); kernel_ms_per_run was measured on these runs" % read_s},
                "note": "the file is inflated and decoded ONCE: the decoded records (80 B each) stay in HBM (ssv_batch_retain) and the getsv passes scan them there - the reference reads the file once per command; file creation (%.1f s) is outside the timed region" % make_s}
         hdr.close()
         if not args.no_cli_leg:

@@ -152,6 +152,12 @@ void *ssv_stream(ssv_ctx *ctx);
  */
 int ssv_host_alloc(size_t bytes, void **p);
 int ssv_host_free(void *p);
+/* Page-lock memory the caller already has - e.g. a range of a read-only file mapping (ssvh_bam_map_blocks, seeksv_host.h): the chunks of a BAM then
+ * go from the page cache to the GPU by DMA, no staging copy (measured on the round-4 box: locking 0.03 s/GB on one thread, copies out of the locked
+ * mapping at PCIe rate, 57 GB/s; allocating page-locked staging memory costs 0.25 s/GB before a byte is read).  p and bytes are rounded outwards to
+ * whole pages by the caller.  SSV_E_HIP when the runtime refuses the range (callers fall back to staging buffers). */
+int ssv_host_register(void *p, size_t bytes);
+int ssv_host_unregister(void *p);
 int ssv_batch_prefetch(ssv_ctx *ctx, const ssv_batch_t *b);
 int ssv_batch_prefetch_drop(ssv_ctx *ctx);
 
@@ -433,18 +439,25 @@ int ssv_bamdec_target_lens(ssv_ctx *ctx, const int32_t *lens);
 /* A run of records that ends inside the next chunk (one rank's share of a file, ssvh_bam_raw_begin_range): its records end `inflated_bytes`
  * into the chunk's blocks - a record boundary; what the blocks hold behind it belongs to the next run.  Applies to the next decode call only. */
 int ssv_bamdec_limit(ssv_ctx *ctx, uint64_t inflated_bytes);
+/* Optional, after ssv_bamdec_begin: chunks that inflate to up to `inflated_bytes` will follow - the decoder's buffers are then sized for them by the
+ * first decode, however small its chunk (a driver starts a file with a small chunk so that the GPU gets to work early; growing ~40 buffers when the
+ * first full-size chunk arrives cost 0.2 s). */
+int ssv_bamdec_expect(ssv_ctx *ctx, uint64_t inflated_bytes);
 /* ... and that starts inside the file: the contig of the last mapped-pair record before it (0 at the start of the file, clip_reads.h:407) -
  * ssv_bamdec_info's contig-change list continues from there.  After ssv_bamdec_begin, before the first decode. */
 int ssv_bamdec_prev_tid(ssv_ctx *ctx, int32_t tid);
-/* Pinned host buffers (two, which = 0 | 1; grow-only, owned by the context) to read the compressed bytes of a chunk into, so that a
- * reader thread can fill one while the other is being decoded; any host memory works too.  A buffer is free again when the decode
- * call that was given it returns. */
+/* Pinned host buffers (three, which = 0 | 1 | 2; grow-only, owned by the context) to read the compressed bytes of a chunk into, so that a
+ * reader thread can fill one while the chunk in the second is on its way to the GPU and the one in the third is being decoded; any host memory
+ * works too (page-locked: ssv_host_register - e.g. the file's own pages in a mapping, no staging copy at all).  A buffer is free again when the
+ * decode call that was given it returns. */
 int ssv_bamdec_staging(ssv_ctx *ctx, int which, size_t bytes, void **host_ptr);
 /* Optional: announce a chunk ahead.  Its compressed bytes start their way to the GPU at once, on the context's upload stream, while the chunk
  * before it is being inflated (two chunks may be announced at any time); ssv_bamdec_decode of the same (comp, comp_bytes) then finds them there instead
  * of copying.  The host buffer must stay untouched until that decode call returns; it should be page-locked (ssv_bamdec_staging, ssv_host_alloc) -
  * out of pageable memory the copy is not asynchronous.  Typical loop: prefetch(0); for k: prefetch(k+1); decode(k); ... */
 int ssv_bamdec_prefetch(ssv_ctx *ctx, const void *comp, size_t comp_bytes);
+/* Give up chunks that were announced and will not be decoded (a pass that stops early): returns when their copies have left the host memory. */
+int ssv_bamdec_prefetch_drop(ssv_ctx *ctx);
 /* Inflate + decode one chunk.  *out is an SSV_MEM_DEVICE batch owned by the context, valid until the next decode on it (stream
  * ordered: kernels already enqueued on the context's stream may still read it).  n_blocks == 0 = end of input (fails if a record
  * is unfinished).  keep_all_seq as in ssvh_bam_read_batch.  Synchronises the stream. */

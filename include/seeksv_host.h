@@ -94,6 +94,13 @@ int ssvh_bam_raw_begin(ssvh_bam *b, uint64_t *first_record_offset);
  * data; blocks[k].c_off / c_len = where block k's deflate payload lies in dst, u_len = what it inflates to; *n_bytes = bytes of dst in use.
  * *n_blocks == 0 at end of file. */
 int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes);
+/* The same chunking without the copy: *ptr = the chunk's bytes (at most max_bytes) where they lie in a read-only mapping of the file - the page
+ * cache -, valid until the handle is closed; blocks[k].c_off counts from *ptr.  The caller page-locks the chunk's pages (ssv_host_register,
+ * seeksv_hip.h) and hands *ptr to ssv_bamdec_prefetch / ssv_bamdec_decode: the GPU's DMA engines fetch the file out of the page cache and no CPU
+ * copies it (libbam's reader: read(2) into a buffer, inflate from there, one block at a time - sam/bgzf.c).  Consecutive chunks come out of three
+ * mappings in turn, so the page ranges of up to three chunks in flight never overlap within one mapping.  Returns -2 when the file cannot be
+ * mapped (the caller then uses ssvh_bam_read_blocks). */
+int ssvh_bam_map_blocks(ssvh_bam *b, size_t max_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, const void **ptr, size_t *n_bytes);
 /* Decode the k-th record of a run of raw BAM records (block_size prefixed, as ssv_bamdec_info.unmapped_raw holds them) the way the
  * unmapped side channel wants it (GetSeqAndQual, clip_reads.cpp:375-388).  Returns the offset of the next record, 0 at the end. */
 size_t ssvh_raw_record_fastq(const uint8_t *raw, size_t raw_bytes, size_t offset, const char **qname, const char **seq, const char **qual, int *is_read1);

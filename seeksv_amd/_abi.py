@@ -325,6 +325,10 @@ def hip_lib():
         lib.ssv_bamdec_staging.argtypes = [V, C.c_int, C.c_size_t, C.POINTER(V)]
         lib.ssv_bamdec_decode.argtypes = [V, V, C.c_size_t, C.POINTER(BgzfBlock), C.c_int64, C.c_int, C.POINTER(Batch)]
         lib.ssv_bamdec_prefetch.argtypes = [V, V, C.c_size_t]
+        lib.ssv_bamdec_prefetch_drop.argtypes = [V]
+        lib.ssv_bamdec_expect.argtypes = [V, C.c_uint64]
+        lib.ssv_host_register.argtypes = [V, C.c_size_t]
+        lib.ssv_host_unregister.argtypes = [V]
         lib.ssv_bamdec_target_lens.argtypes = [V, C.POINTER(C.c_int32)]
         lib.ssv_bamdec_last.argtypes = [V, C.POINTER(BamdecInfo)]
         lib.ssv_batch_to_host.argtypes = [V, C.POINTER(Batch), C.POINTER(Batch)]

@@ -433,8 +433,13 @@ SSV_HD void huff_ready(HuffCounts &h, Tab &tab, int set) // counts -> what huff_
 }
 
 // build the decoding tables of one code from the lengths at Tab::len[len_base, len_base + n): counts -> h, permutation -> Tab::sym[sym_base...)
+// `rule`: what an INCOMPLETE code (bit patterns that belong to no symbol) means - zlib's inftrees.c: HUFF_ANY accepts it (the fixed distance code is
+// one), HUFF_DATA (literal/length and distance codes of a dynamic block) only a code of a single 1-bit symbol or of no symbol at all, HUFF_CODES (the
+// code-length code) only one of no symbol at all.  A damaged header rarely gives complete codes: refusing here is most of what stands between a
+// flipped bit and wrong output, since - like libbam 0.1.16's reader - nothing checks a block's CRC32.
+enum : int { HUFF_ANY = 0, HUFF_DATA = 1, HUFF_CODES = 2 };
 template <bool LIT, class Tab>
-SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCounts &h)
+SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCounts &h, int rule = HUFF_ANY)
 {
 	for (int l = 0; l < 16; ++l) tab.off_set(l, 0);
 	for (int s = 0; s < n; ++s) { const int l = tab.len_get(len_base + s); tab.off_set(l, (uint16_t)(tab.off_get(l) + 1)); }
@@ -450,6 +455,7 @@ SSV_HD int huff_construct(Tab &tab, int len_base, int n, int sym_base, HuffCount
 		tab.off_set(l, (uint16_t)run); // offset of the first symbol of this length in the permutation
 		run += count;
 	}
+	if (left > 0 && run > 0 && (rule == HUFF_CODES || (rule == HUFF_DATA && !(run == 1 && (h.c[0] >> 16) == 1u)))) return INF_E_CODE;
 	for (int s = 0; s < n; ++s) {
 		const int l = tab.len_get(len_base + s);
 		if (l) {
@@ -502,7 +508,7 @@ SSV_HD int inflate_stream_from(Reader &br, const uint8_t *in, uint32_t in_len, O
 				tab.len_set(s, (int)br.take(3));
 			}
 			HuffCounts cl;
-			int rc = huff_construct<false>(tab, 0, 19, 12, cl);
+			int rc = huff_construct<false>(tab, 0, 19, 12, cl, HUFF_CODES);
 			if (rc != INF_OK) return rc;
 			huff_ready(cl, tab, 1); // (the distance code's slots: it is built after the lengths have been read)
 			int idx = 0, prev = 0;
@@ -522,9 +528,9 @@ SSV_HD int inflate_stream_from(Reader &br, const uint8_t *in, uint32_t in_len, O
 			if (tab.len_get(256) == 0) return INF_E_CODE; // no end-of-block code
 			// the distance lengths sit right behind the literal/length lengths: build the distance code first (its lengths are read in
 			// place), then the literal/length code
-			rc = huff_construct<false>(tab, nlen, ndist, 0, dist);
+			rc = huff_construct<false>(tab, nlen, ndist, 0, dist, HUFF_DATA);
 			if (rc != INF_OK) return rc;
-			rc = huff_construct<true>(tab, 0, nlen, 0, lit);
+			rc = huff_construct<true>(tab, 0, nlen, 0, lit, HUFF_DATA);
 			if (rc != INF_OK) return rc;
 			huff_ready(lit, tab, 0); huff_ready(dist, tab, 1);
 		}

@@ -170,7 +170,7 @@ template <class Cfg> struct LaneInflate {
 				tab.len_set(s, (int)take(3));
 			}
 			HuffCounts cl;
-			int r = huff_construct<false>(tab, 0, 19, 12, cl);
+			int r = huff_construct<false>(tab, 0, 19, 12, cl, HUFF_CODES);
 			if (r != INF_OK) return fail(r);
 			int idx = 0, prev = 0;
 			while (idx < nlen + ndist) {
@@ -187,9 +187,9 @@ template <class Cfg> struct LaneInflate {
 				prev = val;
 			}
 			if (tab.len_get(256) == 0) return fail(INF_E_CODE); // no end-of-block code
-			r = huff_construct<false>(tab, nlen, ndist, 0, dst);
+			r = huff_construct<false>(tab, nlen, ndist, 0, dst, HUFF_DATA);
 			if (r != INF_OK) return fail(r);
-			r = huff_construct<true>(tab, 0, nlen, 0, lit);
+			r = huff_construct<true>(tab, 0, nlen, 0, lit, HUFF_DATA);
 			if (r != INF_OK) return fail(r);
 		}
 		state = ST_SYMBOL;

@@ -94,9 +94,10 @@ __device__ __forceinline__ uint32_t wv_load_window(WaveLds &L, const uint8_t *in
 }
 
 // One Huffman code from its lengths lens[0, n): look-up table of T bits (entries of longer codes stay 0) + counts / first codes / offsets / permutation.
-// All lanes call it together.  INF_E_OVERSUB for an over-subscribed code; an incomplete one is accepted (its unused bit patterns decode to "invalid").
+// All lanes call it together.  INF_E_OVERSUB for an over-subscribed code, INF_E_CODE for an incomplete one that `rule` does not allow (huff_construct's
+// rules, inflate_core.h: both forms of pass 1 refuse the same headers); where it is allowed, its unused bit patterns decode to "invalid".
 template <int T>
-__device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens, int n, uint16_t *tab)
+__device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens, int n, uint16_t *tab, int rule)
 {
 	const int lane = (int)threadIdx.x;
 	for (int i = lane; i < (1 << T) / 2; i += WAVE) reinterpret_cast<uint32_t *>(tab)[i] = 0u;
@@ -121,6 +122,7 @@ __device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens
 		code = (code + cnt[k]) << 1; offs += cnt[k];
 	}
 	if (over) return INF_E_OVERSUB;
+	if (left > 0 && offs > 0 && (rule == HUFF_CODES || (rule == HUFF_DATA && !(offs == 1 && cnt[1] == 1)))) return INF_E_CODE;
 	__syncthreads();
 	for (int r = 0; r < n; r += WAVE) {
 		const int s = r + lane;
@@ -162,7 +164,7 @@ __device__ __forceinline__ uint32_t wv_lookup(const WaveLds &L, int set, const u
 	return e;
 }
 
-enum : int { WV_OK = 0, WV_EOB = 1, WV_BAD = 2, WV_DIST = 3, WV_DEAD = 4 };
+enum : int { WV_OK = 0, WV_EOB = 1, WV_BAD = 2, WV_DIST = 3, WV_DEAD = 4, WV_END = 5 }; // WV_END: the input is over (INF_E_INPUT when the sequential decode gets there)
 
 struct WaveSeg {
 	uint32_t end;      // where the next symbol starts (behind the end-of-block code when flag == WV_EOB)
@@ -186,7 +188,7 @@ __device__ __forceinline__ WaveSeg wv_decode(const WaveLds &L, uint32_t w0_bits,
 	WvBits B;
 	B.start(L, w0_bits, start);
 	while (B.p < seg_end) {
-		if (B.p >= lim_bits) { r.flag = WV_BAD; break; } // (a guessed start behind the payload, or a chain that runs off its end)
+		if (B.p >= lim_bits) { r.flag = WV_END; break; } // (a guessed start behind the payload, or a chain that runs off its end)
 		++r.steps;
 		B.need(L);
 		const uint32_t e = wv_lookup<WV_LT>(L, 0, L.lit, B.peek());
@@ -307,7 +309,7 @@ __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in
 			}
 			cur += 3u * (uint32_t)ncode;
 			__syncthreads();
-			int rc = wv_build<WV_CT>(L, 2, L.cll, 19, L.clt);
+			int rc = wv_build<WV_CT>(L, 2, L.cll, 19, L.clt, HUFF_CODES);
 			if (rc != INF_OK) return rc;
 			// the code lengths: a chain (every code's place depends on the one before), walked by all lanes in step
 			int idx = 0, prev = 0;
@@ -336,9 +338,9 @@ __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in
 			__syncthreads();
 			if (L.lens[256] == 0) return INF_E_CODE; // no end-of-block code
 		}
-		int rc = wv_build<WV_DT>(L, 1, L.lens + nlen, ndist, L.dst);
+		int rc = wv_build<WV_DT>(L, 1, L.lens + nlen, ndist, L.dst, type == 1 ? HUFF_ANY : HUFF_DATA);
 		if (rc != INF_OK) return rc;
-		rc = wv_build<WV_LT>(L, 0, L.lens, nlen, L.lit);
+		rc = wv_build<WV_LT>(L, 0, L.lens, nlen, L.lit, type == 1 ? HUFF_ANY : HUFF_DATA);
 		if (rc != INF_OK) return rc;
 		c_hdr += tick() - tc;
 		// ---- the block's symbols, a window at a time ----
@@ -380,7 +382,7 @@ __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in
 			c_rn += tick() - tc; tc = tick();
 			if (dbg && lane == 0) atomicMax(dbg + 9, (unsigned long long)round);
 			const int tflag = __shfl(r.flag, t, WAVE);
-			if (stop && tflag != WV_EOB) return INF_E_CODE;
+			if (stop && tflag != WV_EOB) return tflag == WV_END ? INF_E_INPUT : INF_E_CODE;
 			const bool mine = lane <= t;
 			const uint32_t bytes = mine ? r.bytes : 0u;
 			uint32_t total;

@@ -34,7 +34,7 @@ using namespace ssv;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error; // (per thread: ssv_last_error(NULL) is asked by the thread whose call failed; rank and reader threads run side by side)
 
 // timed kernel groups (ssv_prof_*)
 enum ProfId { P_H2D, P_CLIP_SCAN, P_CLIP_PLACE, P_CLIP_GATHER, P_SORT, P_CLUSTER_BINS, P_CLUSTER_PACK, P_TABLE_D2H, P_ISIZE, P_GETSV_SCAN, P_GETSV_CAND, P_DEPTH_FINISH, P_BAM_INFLATE, P_BAM_RECORDS, P_BAM_DECODE, P_REALIGN_INDEX, P_REALIGN_QUERY, P_BAM_UPLOAD, P_BAM_RESOLVE, P_COUNT };
@@ -584,6 +584,20 @@ int ssv_host_free(void *p)
 	return SSV_OK;
 }
 
+int ssv_host_register(void *p, size_t bytes)
+{
+	if (!p || !bytes) return SSV_E_ARG;
+	const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+	if (e != hipSuccess) { (void)hipGetLastError(); g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e); return SSV_E_HIP; }
+	return SSV_OK;
+}
+
+int ssv_host_unregister(void *p)
+{
+	if (p && hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return SSV_E_HIP; }
+	return SSV_OK;
+}
+
 int ssv_batch_prefetch(ssv_ctx *c, const ssv_batch_t *b)
 {
 	if (!c || !b) return SSV_E_ARG;
@@ -760,7 +774,7 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 {
 	if (!c || !b || !out) return SSV_E_ARG;
 	HIPCHECK(c, hipSetDevice(c->device));
-	if ((b->mem & ~(int)SSV_MEM_PERSISTENT) != SSV_MEM_DEVICE) { c->err = "ssv_batch_retain takes device batches"; return SSV_E_ARG; }
+	if ((b->mem & ~(int)SSV_MEM_PERSISTENT) != SSV_MEM_DEVICE) { c->err = "ssv_batch_retain takes device batches"; return SSV_E_ARG; } // (so no announced host batch is consumed below)
 	DevBatch d;
 	CHECK(stage_batch(c, b, d)); // (builds the record lines when the batch has none)
 	const size_t n = (size_t)b->n;
@@ -769,6 +783,13 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 	size_t off[8]; off[0] = 0;
 	for (int k = 0; k < 7; ++k) off[k + 1] = off[k] + sz[k];
 	uint8_t *slab = nullptr;
+	ssv_tid_run *runs = nullptr;
+	if (b->tid_runs && b->n_tid_runs > 0) { // (host memory: a copy that lives as long as the batch)
+		runs = static_cast<ssv_tid_run *>(malloc((size_t)b->n_tid_runs * sizeof(ssv_tid_run)));
+		if (!runs) { c->err = "out of host memory (tid_runs)"; return SSV_E_NOMEM; }
+		memcpy(runs, b->tid_runs, (size_t)b->n_tid_runs * sizeof(ssv_tid_run));
+	}
+	struct Guard { uint8_t *&slab; ssv_tid_run *&runs; bool keep = false; ~Guard() { if (!keep) { if (slab) (void)hipFree(slab); free(runs); } } } guard{slab, runs};
 	HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&slab), off[7]));
 	const void *src[7] = {d.tid, d.pos, d.n_cigar, d.ends, d.rec, d.cigar, d.seqqual};
 	const size_t bytes[7] = {n * 4, n * 4, n * 2, n, n * sizeof(ssv_record), (size_t)b->n_cigar_total * 4, (size_t)b->seqqual_bytes};
@@ -778,15 +799,13 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 	}
 	for (int k = 0; k < 7; ++k) if (src[k] && bytes[k]) HIPCHECK(c, hipMemcpyAsync(slab + off[k], src[k], bytes[k], hipMemcpyDeviceToDevice, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st)); // the source (the decoder's buffers) may be overwritten by the next decode
+	guard.keep = true;
 	memset(out, 0, sizeof(*out));
 	out->n = b->n; out->mem = SSV_MEM_DEVICE | SSV_MEM_PERSISTENT; out->max_ref_span = b->max_ref_span;
 	out->tid = reinterpret_cast<const int32_t *>(slab + off[0]); out->pos = reinterpret_cast<const int32_t *>(slab + off[1]); out->n_cigar = reinterpret_cast<const uint16_t *>(slab + off[2]);
 	out->cigar_ends = slab + off[3]; out->rec = reinterpret_cast<const ssv_record *>(slab + off[4]); out->cigar = reinterpret_cast<const uint32_t *>(slab + off[5]);
 	out->seqqual = slab + off[6]; out->n_cigar_total = b->n_cigar_total; out->seqqual_bytes = b->seqqual_bytes;
-	if (b->tid_runs && b->n_tid_runs > 0) { // (host memory: a copy that lives as long as the batch)
-		ssv_tid_run *r = static_cast<ssv_tid_run *>(malloc((size_t)b->n_tid_runs * sizeof(ssv_tid_run)));
-		if (r) { memcpy(r, b->tid_runs, (size_t)b->n_tid_runs * sizeof(ssv_tid_run)); out->tid_runs = r; out->n_tid_runs = b->n_tid_runs; }
-	}
+	if (runs) { out->tid_runs = runs; out->n_tid_runs = b->n_tid_runs; }
 	return SSV_OK;
 }
 

@@ -389,8 +389,12 @@ int ssvh_bam_partition(const char *path, int32_t n_parts, int32_t halo_bp, ssvh_
 		if (g < own[(size_t)r - 1]) g = own[(size_t)r - 1];
 		if (g < total && g_used_index) {
 			auto it = std::lower_bound(bai.begin(), bai.end(), g);
-			at = it == bai.end() ? total : *it;
-			if (at < total) { // (the index is the file's own if the bytes there are a record header; otherwise fall back)
+			if (it == bai.end()) {
+				// behind the last window the linear index knows: the reads without a position at the end of the file have no entries there (and a
+				// long tail of them would all go to one rank): this boundary is found like in a file without an index
+				if (!first_record_verified(f, g, &at)) { if (!f.err.empty()) { g_perr = f.err; return -1; } at = total; }
+			} else at = *it;
+			if (it != bai.end() && at < total) { // (the index is the file's own if the bytes there are a record header; otherwise fall back)
 				Window w(f);
 				w.begin_at_block(f.block_of(at));
 				w.need(std::min<uint64_t>(total, at + 4 + 36 + 256));

@@ -3,6 +3,7 @@
 // Replaces, for the hot path, what the reference gets from samtools-0.1.16's libbam below its
 // record loops: samopen()/samread() (sam/sam.h:59,73) and the bam1_core_t accessors
 // (sam/bam.h:169-255).  Own implementation from the SAM/BAM specification; no libbam here.
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -15,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -431,6 +433,11 @@ struct ssvh_bam {
 	uint32_t raw_end_uoff = 0;
 	uint64_t raw_limit = UINT64_MAX;
 	bool raw_empty = false;
+	// ssvh_bam_map_blocks: the file mapped three times over (a chunk's bytes are handed out as a pointer into one of the mappings, in turn: a caller
+	// that page-locks the pages of the chunks it holds - three at most - never locks two ranges of ONE mapping that share a page)
+	uint8_t *map[3] = {nullptr, nullptr, nullptr};
+	size_t map_len = 0;
+	int map_turn = 0;
 	std::vector<uint8_t> rec;
 	std::vector<size_t> found; // located, not yet handed out record offsets in z.ubuf
 	size_t found_pos = 0, chain_cur = 0;
@@ -560,10 +567,14 @@ int ssvh_bam_set_range(ssvh_bam *b, uint64_t start_coff, uint32_t start_uoff, ui
 // once (pread into the caller's buffer, usually page-locked); the block table is then read off the headers where they lie in dst
 // (c_off = where a block's deflate payload starts inside dst).  A block at a time through stdio (four calls per block) fed the device
 // decoder at 2.8 GB/s - a fifth of what it inflates; the file's pages are in the page cache or on NVMe, and many readers are what both want.
-int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes)
+// dst == nullptr: the mapped form (ssvh_bam_map_blocks) - nothing is copied, the blocks are looked at where they lie in the mapping `mapped`, of which
+// at most dst_bytes are handed out
+static int read_blocks_impl(ssvh_bam *b, void *dst, const uint8_t *mapped, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes,
+                            const void **ptr)
 {
 	g_err.clear();
 	*n_blocks = 0; *n_bytes = 0;
+	if (ptr) *ptr = nullptr;
 	b->raw_limit = UINT64_MAX;
 	if (b->z.eof) return 0;
 	const int fd = fileno(b->z.fp);
@@ -572,7 +583,10 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 	const uint64_t file_size = (uint64_t)st.st_size;
 	const long at0 = ftell(b->z.fp);
 	if (at0 < 0) { g_err = "cannot tell the file position"; return -1; }
-	uint8_t *d = static_cast<uint8_t *>(dst);
+	if (mapped && file_size > b->map_len) { g_err = "the BAM file grew while it was being read"; return -1; }
+	const uint8_t *d = mapped ? mapped + at0 : static_cast<const uint8_t *>(dst);
+	uint8_t *const dw = static_cast<uint8_t *>(dst);
+	if (ptr) *ptr = d;
 	const size_t PIECE = (size_t)256 << 20, SLICE = (size_t)4 << 20;
 	static const bool timing = getenv("SSV_TIMING_CHUNKS") != nullptr;
 	double t_read = 0, t_walk = 0;
@@ -593,14 +607,15 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 			if ((uint64_t)at0 + have + want > last_needed) want = (uint64_t)at0 + have < last_needed ? (size_t)(last_needed - (uint64_t)at0 - have) : 0;
 		}
 		const double tr0 = timing ? clk() : 0;
-		if (want) {
+		if (mapped) have += want; // (the bytes are there already)
+		else if (want) {
 			const int ns = (int)((want + SLICE - 1) / SLICE);
 			std::vector<int> ok((size_t)ns, 1);
 			pool().run(ns, [&](int i) {
 				size_t off = (size_t)i * SLICE;
 				const size_t end = std::min(want, off + SLICE);
 				while (off < end) {
-					const ssize_t got = pread(fd, d + have + off, end - off, (off_t)((uint64_t)at0 + have + off));
+					const ssize_t got = pread(fd, dw + have + off, end - off, (off_t)((uint64_t)at0 + have + off));
 					if (got <= 0) { ok[(size_t)i] = 0; return; }
 					off += (size_t)got;
 				}
@@ -660,6 +675,41 @@ int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_
 	return 0;
 }
 
+int ssvh_bam_read_blocks(ssvh_bam *b, void *dst, size_t dst_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, size_t *n_bytes)
+{
+	if (!dst) { g_err = "ssvh_bam_read_blocks: no buffer"; return -1; }
+	return read_blocks_impl(b, dst, nullptr, dst_bytes, max_inflated, blocks, max_blocks, n_blocks, n_bytes, nullptr);
+}
+
+// The same chunking without the copy: the chunk's bytes are handed out where they lie in a read-only mapping of the file (the page cache: a caller
+// page-locks them and lets the GPU's DMA engines fetch them there - ssv_host_register, seeksv_hip.h - instead of copying 47 GB of a whole-genome
+// file into staging buffers first).  The file is mapped three times and the chunks go round the mappings, so that the ranges of three chunks in
+// flight never share a page of ONE mapping (page-locking works on whole pages, chunks end where BGZF blocks end).
+int ssvh_bam_map_blocks(ssvh_bam *b, size_t max_bytes, uint64_t max_inflated, ssv_bgzf_block *blocks, int64_t max_blocks, int64_t *n_blocks, const void **ptr, size_t *n_bytes)
+{
+	g_err.clear();
+	if (!b->z.fp || !ptr) { g_err = "no file behind this handle"; return -1; }
+	if (!b->map[0]) {
+		struct stat st;
+		const int fd = fileno(b->z.fp);
+		if (fstat(fd, &st) != 0 || st.st_size <= 0) { g_err = "cannot stat the BAM file"; return -1; }
+		for (int k = 0; k < 3; ++k) {
+			void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+			if (m == MAP_FAILED) {
+				for (int j = 0; j < k; ++j) { munmap(b->map[j], (size_t)st.st_size); b->map[j] = nullptr; }
+				g_err = std::string("cannot map the BAM file: ") + strerror(errno);
+				return -2; // (the caller falls back to ssvh_bam_read_blocks)
+			}
+			b->map[k] = static_cast<uint8_t *>(m);
+			(void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+		}
+		b->map_len = (size_t)st.st_size;
+	}
+	const uint8_t *m = b->map[b->map_turn];
+	b->map_turn = (b->map_turn + 1) % 3;
+	return read_blocks_impl(b, nullptr, m, max_bytes + 8, max_inflated, blocks, max_blocks, n_blocks, n_bytes, ptr);
+}
+
 int ssvh_bam_from_header(const char *const *names, const int32_t *lens, int32_t n, ssvh_bam **out)
 {
 	ssvh_bam *b = new ssvh_bam();
@@ -673,6 +723,7 @@ void ssvh_bam_close(ssvh_bam *b)
 {
 	if (!b) return;
 	if (b->ra_thread.joinable()) b->ra_thread.join();
+	for (uint8_t *m : b->map) if (m) munmap(m, b->map_len);
 	if (b->z.fp) fclose(b->z.fp);
 	delete b;
 }
@@ -935,11 +986,13 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 
 // deflate level of the BAM writer: 1 (fast; the CLI's clip.bam and the tests' fixtures) unless SSV_BGZF_LEVEL says otherwise (bench.py's file leg
 // writes level 6, samtools' default: real BAM files are what that leg stands for)
+// -1: no zlib at all - a block's payload is one literal-only Huffman block (huff_gz.h; what `seeksv realign` writes its clip.bam with unless the
+// variable says otherwise: 5.5 M short records that are read back once, by the next command)
 static int bgzf_level()
 {
 	const char *e = getenv("SSV_BGZF_LEVEL");
 	const int l = e ? atoi(e) : 1;
-	return l < 0 ? 0 : l > 9 ? 9 : l;
+	return l < -1 ? -1 : l > 9 ? 9 : l;
 }
 
 static void bgzf_compress_blocks(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out)
@@ -951,6 +1004,26 @@ static void bgzf_compress_blocks(const std::vector<uint8_t> &raw, std::vector<ui
 	wpool().run((int)nb, [&](int i) {
 		const size_t off = (size_t)i * BS, len = std::min(BS, raw.size() - off);
 		std::vector<uint8_t> &c = comp[(size_t)i];
+		const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0};
+		if (level < 0) { // literals only, or - when their codes do not even pay for the code table - stored (a block must stay below 64 KB)
+			static thread_local std::vector<uint8_t> room;
+			if (room.size() < ssvh_huff::member_bound(BS)) room.resize(ssvh_huff::member_bound(BS));
+			size_t clen = (size_t)(ssvh_huff::deflate_literals(raw.data() + off, len, room.data()) - room.data());
+			if (clen > len + 5) {
+				uint8_t *p = room.data();
+				const uint16_t l16 = (uint16_t)len, n16 = (uint16_t)~l16;
+				p[0] = 1; memcpy(p + 1, &l16, 2); memcpy(p + 3, &n16, 2); memcpy(p + 5, raw.data() + off, len);
+				clen = len + 5;
+			}
+			c.resize(18 + clen + 8);
+			memcpy(c.data(), hdr, 16);
+			const uint16_t bsize = (uint16_t)(clen + 25);
+			memcpy(c.data() + 16, &bsize, 2);
+			memcpy(c.data() + 18, room.data(), clen);
+			const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), raw.data() + off, (uInt)len), isz = (uint32_t)len;
+			memcpy(c.data() + 18 + clen, &crc, 4); memcpy(c.data() + 18 + clen + 4, &isz, 4);
+			return;
+		}
 		c.resize(len + 1024);
 		// one deflate state per thread, reset between blocks: deflateInit2 allocates ~270 KB in pieces that malloc serves by mmap, and a few
 		// hundred threads mapping and unmapping at once queue on the process's address-space lock (the writer ran at 1.4 M records/s whatever
@@ -968,7 +1041,6 @@ static void bgzf_compress_blocks(const std::vector<uint8_t> &raw, std::vector<ui
 		zs.next_out = c.data() + 18; zs.avail_out = (uInt)(c.size() - 18 - 8);
 		deflate(&zs, Z_FINISH);
 		size_t clen = zs.total_out;
-		const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0};
 		memcpy(c.data(), hdr, 16);
 		uint16_t bsize = (uint16_t)(clen + 25);
 		memcpy(c.data() + 16, &bsize, 2);
@@ -1013,6 +1085,11 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 {
 	FILE *f = fopen(path, append ? "ab" : "wb");
 	if (!f) { g_err = std::string("cannot open ") + path; return -1; }
+	static const bool timing = getenv("SSV_TIMING_WRITE") != nullptr;
+	double t_sizes = 0, t_fill = 0, t_comp = 0, t_io = 0;
+	auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double tl = clk();
+	auto lap = [&](double &acc) { const double now = clk(); acc += now - tl; tl = now; };
 	std::vector<uint8_t> raw, out;
 	auto put32 = [&](int32_t v) { uint8_t t[4]; memcpy(t, &v, 4); raw.insert(raw.end(), t, t + 4); };
 	if (!append) {
@@ -1022,7 +1099,7 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 		put32((int32_t)text.size()); raw.insert(raw.end(), text.begin(), text.end());
 		put32(n_targets);
 		for (int32_t i = 0; i < n_targets; ++i) { size_t l = strlen(names[i]) + 1; put32((int32_t)l); raw.insert(raw.end(), names[i], names[i] + l); put32(lens[i]); }
-		bgzf_compress_blocks(raw, out);
+		bgzf_compress_blocks(raw, out); // (the header in blocks of its own, as before)
 		raw.clear();
 	}
 	// the records: sizes, their running sum, then every host thread serialises its share of the records straight into place
@@ -1041,11 +1118,22 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 		});
 		at[0] = 0;
 		for (int64_t i = 0; i < n; ++i) at[(size_t)i + 1] += at[(size_t)i];
-		raw.resize((size_t)at[(size_t)n]);
-		wpool().run(nt, [&](int w) {
+		lap(t_sizes);
+		// slices of ~128 MB of serialised records (SSV_WRITE_SLICE_MB): serialise, compress, write, next - a multi-GB batch in one piece held twice
+		// its inflated size in memory (the records, the compressed blocks and their copy in `out`)
+		static const uint64_t slice_bytes = [] { const char *e = getenv("SSV_WRITE_SLICE_MB"); const long long mb = e ? atoll(e) : 128; return (uint64_t)(mb < 1 ? 1 : mb) << 20; }();
+		for (int64_t i0 = 0; i0 < n;) {
+			int64_t i1 = (int64_t)(std::upper_bound(at.begin() + i0 + 1, at.end(), at[(size_t)i0] + slice_bytes) - at.begin()) - 1;
+			if (i1 <= i0) i1 = i0 + 1; // (a single record larger than a slice)
+			const int64_t ns = i1 - i0;
+			const uint64_t base = at[(size_t)i0];
+			const size_t head = raw.size(); // (the BAM header of a fresh file travels with the first slice)
+			raw.resize(head + (size_t)(at[(size_t)i1] - base));
+			const int nts = (int)std::max<int64_t>(1, std::min<int64_t>(ns / 4096, 256));
+		wpool().run(nts, [&](int w) {
 			char num[24];
-			for (int64_t i = n * w / nt, e = n * (w + 1) / nt; i < e; ++i) {
-				uint8_t *d = raw.data() + at[(size_t)i];
+			for (int64_t i = i0 + ns * w / nts, e = i0 + ns * (w + 1) / nts; i < e; ++i) {
+				uint8_t *d = raw.data() + head + (at[(size_t)i] - base);
 				const int lq = b->l_qseq[i], nc = b->n_cigar[i];
 				const uint32_t *cig = b->cigar + b->cigar_off[i];
 				int span = 0;
@@ -1069,14 +1157,25 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 				else { memset(d, 0x11, ((size_t)lq + 1) / 2); memset(d + ((size_t)lq + 1) / 2, 30, (size_t)lq); } // no bases shipped: l_qseq 'A's of quality 30
 			}
 		});
+			lap(t_fill);
+			bgzf_compress_blocks(raw, out);
+			raw.clear();
+			lap(t_comp);
+			if (fwrite(out.data(), 1, out.size(), f) != out.size()) { fclose(f); g_err = std::string("write error on ") + path; return -1; }
+			out.clear();
+			lap(t_io);
+			i0 = i1;
+		}
 	}
 	if (!raw.empty()) bgzf_compress_blocks(raw, out);
 	if (finish) {
 		static const uint8_t eofb[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		out.insert(out.end(), eofb, eofb + 28);
 	}
-	fwrite(out.data(), 1, out.size(), f);
-	fclose(f);
+	if (fwrite(out.data(), 1, out.size(), f) != out.size()) { fclose(f); g_err = std::string("write error on ") + path; return -1; }
+	if (fclose(f) != 0) { g_err = std::string("write error on ") + path; return -1; }
+	lap(t_io);
+	if (timing) fprintf(stderr, "[timing] (write_batch: %lld records: sizes %.3f s, serialise %.3f s, compress %.3f s, write %.3f s)\n", (long long)n, t_sizes, t_fill, t_comp, t_io);
 	return 0;
 }
 

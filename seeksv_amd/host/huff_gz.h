@@ -83,12 +83,9 @@ struct BitSink {
 // upper bound of member(): header + block header + 15 bits a byte + trailer
 inline size_t member_bound(size_t n) { return n * 2 + 1024; }
 
-// one gzip member for text[0, n) into out (room for member_bound(n)); returns its size
-inline size_t member(const uint8_t *text, size_t n, uint8_t *out)
+// the raw deflate stream for text[0, n) - one final dynamic-Huffman block of literals - into o (room for member_bound(n)); returns its end
+inline uint8_t *deflate_literals(const uint8_t *text, size_t n, uint8_t *o)
 {
-	static const uint8_t gz_header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3}; // deflate, no flags, no time, OS = unix
-	memcpy(out, gz_header, 10);
-	uint8_t *o = out + 10;
 	if (n == 0) { *o++ = 0x03; *o++ = 0x00; } // a final fixed-Huffman block holding only the end-of-block symbol
 	else {
 		// literal / length alphabet: the 256 byte values + end of block (257 codes, HLIT = 0); four interleaved histograms so that runs of one
@@ -145,6 +142,15 @@ inline size_t member(const uint8_t *text, size_t n, uint8_t *out)
 		bs.put(code[256], len[256]);
 		o = bs.finish();
 	}
+	return o;
+}
+
+// one gzip member for text[0, n) into out (room for member_bound(n)); returns its size
+inline size_t member(const uint8_t *text, size_t n, uint8_t *out)
+{
+	static const uint8_t gz_header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3}; // deflate, no flags, no time, OS = unix
+	memcpy(out, gz_header, 10);
+	uint8_t *o = deflate_literals(text, n, out + 10);
 	const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), text, (uInt)n), isize = (uint32_t)n;
 	memcpy(o, &crc, 4); memcpy(o + 4, &isize, 4);
 	return (size_t)(o + 8 - out);

@@ -20,6 +20,7 @@
 #include <iostream>
 #include <memory>
 #include <climits>
+#include <deque>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -33,9 +34,19 @@ namespace seeksv {
 
 namespace {
 
-struct ClipRow { // one row of clip.gz as the join sees it: aligned part first, whatever the side (getsv.h:460-461)
-	std::string chr; int pos = 0; char side = 0; CigarVec cigar_vec;
-	std::string aligned_seq, clipped_seq, clipped_qual; int support = 0;
+// a piece of text that lives elsewhere (the rows of clip.gz in memory; the stream loop's strings in a store of their own)
+struct Str {
+	const char *p = nullptr; size_t n = 0;
+	std::string str() const { return std::string(p, n); }
+	bool operator==(const Str &o) const { return n == o.n && (n == 0 || memcmp(p, o.p, n) == 0); }
+	bool equals(const char *z) const { return strncmp(z, p, n) == 0 && z[n] == '\0'; }
+};
+
+// One row of clip.gz as the join sees it: aligned part first, whatever the side (getsv.h:460-461).  5.5 M rows of a whole-genome sample meet 20 K
+// alignments: a row is views into the text (no string is copied, its CIGAR is parsed) until an alignment turns it into a junction.
+struct ClipRow {
+	Str chr; int pos = 0; char side = 0; Str cigar;
+	Str aligned_seq, clipped_seq, clipped_qual; int support = 0;
 };
 
 struct AlignInfo { // getsv.h:27-44
@@ -97,9 +108,9 @@ void add_junction(const ClipRow &row, AlignInfo &c, JunctionMap &j2o)
 {
 	int uniq;
 	if (c.type == 'u') uniq = 2; else if (c.type == 'r') uniq = 1; else return; // type 'n': nothing is recorded at all
-	std::string aligned_seq = row.aligned_seq, clipped_seq = row.clipped_seq;
-	CigarVec cigar_vec = row.cigar_vec;
-	const std::string &chr = row.chr;
+	std::string aligned_seq = row.aligned_seq.str(), clipped_seq = row.clipped_seq.str();
+	CigarVec cigar_vec = parse_cigar(row.cigar.str());
+	const std::string chr = row.chr.str();
 	const int pos = row.pos, support = row.support;
 	Junction j;
 	SeqInfo up, down;
@@ -359,10 +370,10 @@ static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows
 			if (nf == 9) {
 				ClipRow row;
 				if (len[2] != 1 || !to_int(tok[1], len[1], row.pos) || !to_int(tok[8], len[8], row.support)) { good = false; break; }
-				row.chr.assign(tok[0], len[0]); row.side = tok[2][0];
-				row.cigar_vec = parse_cigar(std::string(tok[3], len[3]));
-				row.aligned_seq.assign(tok[4], len[4]); row.clipped_seq.assign(tok[6], len[6]); row.clipped_qual.assign(tok[7], len[7]);
-				out.push_back(std::move(row));
+				row.chr = Str{tok[0], len[0]}; row.side = tok[2][0];
+				row.cigar = Str{tok[3], len[3]};
+				row.aligned_seq = Str{tok[4], len[4]}; row.clipped_seq = Str{tok[6], len[6]}; row.clipped_qual = Str{tok[7], len[7]};
+				out.push_back(row);
 			} else if (nf != 0) { good = false; break; }
 			p = eol < end ? eol + 1 : end;
 		}
@@ -372,7 +383,7 @@ static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows
 	size_t total = 0;
 	for (auto &v : part) total += v.size();
 	rows.reserve(total);
-	for (auto &v : part) { for (auto &r : v) rows.push_back(std::move(r)); std::vector<ClipRow>().swap(v); }
+	for (auto &v : part) { rows.insert(rows.end(), v.begin(), v.end()); std::vector<ClipRow>().swap(v); }
 	return true;
 }
 
@@ -385,24 +396,32 @@ static std::string assemble_junctions_view(const TextView &text, const std::stri
 	if (ssvh_bam_open(clip_bam.c_str(), &bam) != 0) return "[main_samview] fail to open file for reading.";
 	std::vector<ClipRow> rows; // the rows that share `current` (the reference's multimap is cleared at every group change)
 	AlignMap aligns;
-	std::string current;       // last_clipped_seq
+	Str current;               // last_clipped_seq (a view: the rows' text outlives the join)
 	ssvh_record rec;
 	std::string failure;
+	// An alignment enters the group's map under (name, (chr, pos)).  An UNALIGNED record (flag 4: type 'n', "Exogenous" / -1) makes no junction
+	// (GetJunction returns at once, getsv.cpp:1726), shares its key with every other unaligned record of the group and with no aligned one - leaving
+	// it out of the map changes nothing in the table, and 5.5 M of a whole-genome sample's 5.52 M clipped sequences are of that kind: they only
+	// drive the group bookkeeping (names compared, nothing built).
+	auto file_under = [&](const Str &name) {
+		if (rec.flag & 4) return;
+		AlignInfo a;
+		align_info_of(bam, rec, a);
+		aligns.insert(std::make_pair(std::make_pair(name.str(), std::make_pair(a.chr, a.pos)), a));
+	};
 	// one row of clip.gz, in file order (false: clip.bam could not be read)
 	auto on_row = [&](ClipRow &row) -> bool {
-		if (current.empty() || current == row.clipped_seq) { current = row.clipped_seq; rows.push_back(std::move(row)); return true; }
+		if (current.n == 0 || current == row.clipped_seq) { current = row.clipped_seq; rows.push_back(row); return true; }
 		// a new clipped sequence: consume the alignments of the current group
 		int rc;
 		while ((rc = ssvh_bam_next_record(bam, &rec)) == 1) {
 			if (is_hard_clip(rec)) continue;
-			AlignInfo a;
-			align_info_of(bam, rec, a);
-			if (current == rec.qname) { aligns.insert(std::make_pair(std::make_pair(current, std::make_pair(a.chr, a.pos)), a)); continue; }
+			if (current.equals(rec.qname)) { file_under(current); continue; }
 			flush_group(rows, aligns, j2o);
 			rows.clear(); aligns.clear();
-			aligns.insert(std::make_pair(std::make_pair(current, std::make_pair(a.chr, a.pos)), a)); // filed under the OLD name
+			file_under(current); // filed under the OLD name
 			current = row.clipped_seq;
-			rows.push_back(std::move(row));
+			rows.push_back(row);
 			break;
 		}
 		if (rc < 0) { failure = ssvh_last_error(); return false; }
@@ -420,21 +439,20 @@ static std::string assemble_junctions_view(const TextView &text, const std::stri
 		std::vector<ClipRow>().swap(parsed);
 	} else {
 		std::istringstream fin(std::string(text.data(), text.size()));
-		std::string chr, cigar, aligned_qual, rest;
+		std::string chr, cigar, aligned_seq, aligned_qual, clipped_seq, clipped_qual, rest;
+		std::deque<std::string> store; // (the rows are views: what the stream extracts lives here until the join is over)
+		auto keep = [&](const std::string &v) { store.push_back(v); return Str{store.back().data(), store.back().size()}; };
 		while (fin >> chr) {
 			ClipRow row;
-			row.chr = chr;
-			fin >> row.pos >> row.side >> cigar >> row.aligned_seq >> aligned_qual >> row.clipped_seq >> row.clipped_qual >> row.support;
+			fin >> row.pos >> row.side >> cigar >> aligned_seq >> aligned_qual >> clipped_seq >> clipped_qual >> row.support;
 			std::getline(fin, rest);
-			row.cigar_vec = parse_cigar(cigar);
+			row.chr = keep(chr); row.cigar = keep(cigar); row.aligned_seq = keep(aligned_seq); row.clipped_seq = keep(clipped_seq); row.clipped_qual = keep(clipped_qual);
 			if (!on_row(row)) { ssvh_bam_close(bam); return failure; }
 		}
 	}
 	int rc;
 	while ((rc = ssvh_bam_next_record(bam, &rec)) == 1) { // tail: no hard-clip test here
-		AlignInfo a;
-		align_info_of(bam, rec, a);
-		if (current == rec.qname) aligns.insert(std::make_pair(std::make_pair(current, std::make_pair(a.chr, a.pos)), a));
+		if (current.equals(rec.qname)) file_under(current);
 		else break;
 	}
 	flush_group(rows, aligns, j2o);

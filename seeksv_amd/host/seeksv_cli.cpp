@@ -26,7 +26,9 @@
 #include <unistd.h>
 #include <atomic>
 #include "../csrc/cpus.h"
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -253,29 +255,108 @@ static ssv_ctx *acquire_ctx(int device)
 
 static const bool kTimingChunks = getenv("SSV_TIMING_CHUNKS") != nullptr;
 
+// Staging memory for the chunks of a file in copy mode.  hipHostMalloc hands out page-locked memory at 0.25 s/GB (it allocates, clears and locks on
+// one thread, and other HIP calls of the process queue behind it meanwhile): three 0.6-1.5 GB buffers were 0.5 s before the first kernel of a
+// command.  Here a buffer is plain anonymous memory; the reader threads' pread calls fault its pages in on all cores while they fill it for the
+// first time, and only then are the pages that hold bytes page-locked (ssv_host_register: 0.03 s/GB).  Buffers go back to a process-wide pool when a
+// source closes (`seeksv run`, the ranks' halo and own passes: the next source finds them locked already).
+struct StageBuf {
+	uint8_t *p = nullptr;
+	size_t cap = 0, locked = 0; // locked: bytes from p on that are page-locked
+	static size_t page() { static const size_t v = (size_t)sysconf(_SC_PAGESIZE); return v; }
+	bool reserve(size_t want)
+	{
+		if (cap >= want) return true;
+		release();
+		const size_t n = (want + page() - 1) & ~(page() - 1);
+		void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (m == MAP_FAILED) return false;
+		p = static_cast<uint8_t *>(m); cap = n;
+		return true;
+	}
+	// the first `filled` bytes have just been written: make sure they are page-locked (a buffer that is mostly full is locked whole, its tail
+	// touched on a few threads first, so that chunks of slightly different sizes do not lock again and again)
+	bool lock(size_t filled)
+	{
+		if (filled <= locked) return true;
+		if (locked) { ssv_host_unregister(p); locked = 0; }
+		size_t n = (filled + page() - 1) & ~(page() - 1);
+		if (filled * 2 > cap) {
+			const int nt = 8;
+			vector<std::thread> th;
+			for (int t = 0; t < nt; ++t) th.emplace_back([&, t] {
+				const size_t lo = n + (cap - n) / page() * (size_t)t / nt * page(), hi = n + (cap - n) / page() * (size_t)(t + 1) / nt * page();
+				for (size_t o = lo; o < hi; o += page()) p[o] = 0;
+			});
+			for (auto &x : th) x.join();
+			n = cap;
+		}
+		if (ssv_host_register(p, n) != SSV_OK) return false; // (the copies out of it then go through the runtime's own staging: slower, still right)
+		locked = n;
+		return true;
+	}
+	void release()
+	{
+		if (!p) return;
+		if (locked) ssv_host_unregister(p);
+		munmap(p, cap);
+		p = nullptr; cap = locked = 0;
+	}
+};
+static std::mutex g_stage_pool_mu;
+static vector<StageBuf> g_stage_pool;
+static StageBuf stage_from_pool(size_t want)
+{
+	std::lock_guard<std::mutex> lk(g_stage_pool_mu);
+	for (size_t k = 0; k < g_stage_pool.size(); ++k)
+		if (g_stage_pool[k].cap >= want) { StageBuf b = g_stage_pool[k]; g_stage_pool.erase(g_stage_pool.begin() + (long)k); return b; }
+	return StageBuf();
+}
+static void stage_to_pool(StageBuf &b)
+{
+	if (!b.p) return;
+	std::lock_guard<std::mutex> lk(g_stage_pool_mu);
+	if (g_stage_pool.size() < 8) g_stage_pool.push_back(b); else b.release();
+	b = StageBuf();
+}
+
 struct BatchSource {
 	ssvh_bam *bam = nullptr;
 	ssv_ctx *ctx = nullptr;
 	bool on_device = false;
 	bool resident = false;   // the records are in HBM already (g_resident)
 	size_t resident_next = 0;
-	// device mode
-	size_t stage_bytes = 0;
+	// ---- device mode: a reader thread runs up to three chunks ahead of the decoder ----
+	// A chunk = whole BGZF blocks, the file's bytes as they are.  Two ways to get them to the GPU:
+	//   copy (default): all host threads pread the chunk into one of three staging buffers (StageBuf above: locked after their first fill);
+	//   map  (SSV_READER=map): the file is mapped and the chunk's pages are page-locked where they lie in the page cache (ssv_host_register), the GPU's
+	//         DMA engines fetch them there and no CPU copies the file.  Measured on a 11.8 GB file (profiles/r04_cli_reader_modes.txt): locking a fresh
+	//         mapping's pages costs 0.04-0.1 s/GB on the one thread the driver lets do it (page-table entries for every 4 KB page first), i.e. 25-60 ms
+	//         per 0.6 GB chunk where the copy takes 14 ms on 16 threads, and unmapping the file at the end 0.19 s: slower, kept for boxes with few CPUs.
+	// Either way chunk k+1 is announced to the upload stream (ssv_bamdec_prefetch) before chunk k is decoded, so its bytes cross PCIe under chunk k's
+	// kernels, while the reader prepares chunk k+2.
+	static constexpr int NS = 3;
+	struct Slot {
+		StageBuf stage;                                       // copy mode: the slot's staging buffer
+		void *reg_base = nullptr; size_t reg_bytes = 0;       // map mode: the page range that is locked for this slot's chunk
+		const uint8_t *data = nullptr; size_t n_bytes = 0;    // the chunk
+		vector<ssv_bgzf_block> blocks; int64_t n_blocks = 0;
+		uint64_t limit = UINT64_MAX;                          // ssvh_bam_raw_limit: where a range of records ends inside the chunk
+		bool last = false;                                    // nothing but the end-of-file block can follow
+		double t_fill = 0;
+		string err;
+	} slot[NS];
+	size_t stage_bytes = 0, first_bytes = 0;
 	uint64_t chunk_inflated = 0;
-	void *stage[2] = {nullptr, nullptr};
-	size_t stage_cap[2] = {0, 0};
-	size_t first_bytes = 0;      // the file's first chunk is a small one (see open())
-	bool first_read = true;
-	std::thread alloc2;          // pins the second staging buffer while the first chunk is read and decoded
-	string alloc2_err;
-	vector<ssv_bgzf_block> blocks[2];
-	int64_t n_blocks[2] = {0, 0};
-	size_t n_bytes[2] = {0, 0};
-	string read_err[2];
-	int cur = 0;
+	bool map_mode = true;
 	std::thread reader;
-	bool reader_running = false, at_end = false, end_pending = false;
-	uint64_t file_bytes = 0, consumed = 0;
+	std::mutex mu;
+	std::condition_variable cv;
+	int64_t produced = 0, released = 0, cur = 0; // chunks the reader has finished / the decoder has let go of / next chunk to decode
+	bool reader_exit = false, stop_reader = false;
+	int64_t announced = -1;                      // highest chunk handed to ssv_bamdec_prefetch
+	bool at_end = false, end_pending = false;
+	uint64_t file_bytes = 0;
 	ssv_bamdec_info info{};
 
 	// a run of records [start, end) of the file instead of all of it (virtual offsets of ssvh_bam_partition); before open()
@@ -283,7 +364,6 @@ struct BatchSource {
 	uint64_t r_start_coff = 0, r_end_coff = 0;
 	uint32_t r_start_uoff = 0, r_end_uoff = 0;
 	void set_range(uint64_t sc, uint32_t su, uint64_t ec, uint32_t eu) { ranged = true; r_start_coff = sc; r_start_uoff = su; r_end_coff = ec; r_end_uoff = eu; }
-	uint64_t limit[2] = {UINT64_MAX, UINT64_MAX};
 	int32_t r_prev_tid = 0; // contig of the last mapped-pair record before the range
 
 	void open(const string &path, ssv_ctx *c, bool device_inflate, const char *open_error)
@@ -296,16 +376,16 @@ struct BatchSource {
 			use_pinned_batches(bam);
 			return;
 		}
-		const char *e1 = getenv("SSV_CHUNK_INFLATED_MB"), *e2 = getenv("SSV_STAGE_MB");
+		const char *e1 = getenv("SSV_CHUNK_INFLATED_MB"), *e2 = getenv("SSV_STAGE_MB"), *e4 = getenv("SSV_READER");
 		chunk_inflated = (uint64_t)(e1 ? atoll(e1) : 4096) << 20;
 		stage_bytes = (size_t)(e2 ? atoll(e2) : 1536) << 20;
-		{ // no more pinned memory than the file can fill (pinning costs ~0.2 s per GB, twice: at allocation and at release)
+		map_mode = e4 && !strcmp(e4, "map");
+		{
 			FILE *f = fopen(path.c_str(), "rb");
 			if (f) { fseek(f, 0, SEEK_END); file_bytes = (uint64_t)ftell(f); fclose(f); }
-			// What a command pays once grows with the chunk size - two pinned staging buffers, ~3.8 bytes of device memory per inflated byte
-			// (~20 ms per GB, at the first decode) - and what big chunks buy is inflate rate (more BGZF blocks in flight), which only
-			// matters once the file is long enough for the GPU to be the slower side of the pipeline: chunks of 1 GB inflated below 8 GB of
-			// file (6 GB file, getclip + getsv: 3.8 -> 2.3 s), 2 GB below 24 GB, 4 GB above.
+			// What a command pays once grows with the chunk size - ~3.8 bytes of device memory per inflated byte (~20 ms per GB, at the first decode), in
+			// copy mode three page-locked staging buffers at 0.25 s/GB - and what big chunks buy is inflate rate (more BGZF blocks in flight), which only
+			// matters once the file is long: chunks of 1 GB inflated below 8 GB of file, 2 GB below 24 GB, 4 GB above.
 			if (!e1 && !e2 && file_bytes && !ranged) {
 				if (file_bytes <= ((uint64_t)8 << 30)) { chunk_inflated = (uint64_t)1024 << 20; stage_bytes = (size_t)384 << 20; }
 				else if (file_bytes <= ((uint64_t)24 << 30)) { chunk_inflated = (uint64_t)2048 << 20; stage_bytes = (size_t)768 << 20; }
@@ -318,33 +398,82 @@ struct BatchSource {
 		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ssv_bamdec_target_lens(ctx, ssvh_bam_target_lens(bam)) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ranged) ssv_bamdec_prev_tid(ctx, r_prev_tid);
-		// Pinning costs ~0.2 s per GB and the first decode cannot start before the first chunk is in: the file's first chunk goes through a smaller
-		// staging buffer (960 MB: what the insert-size pass of getsv needs for its 5 M pairs at 77 B a record), the second buffer is pinned at full
-		// size by a thread of its own meanwhile, and the first one grows to full size when its turn comes again - on the reader thread, beside the
-		// decode of the chunk before.
-		const char *e3 = getenv("SSV_STAGE_FIRST_MB");
-		first_bytes = std::min(stage_bytes, (size_t)(e3 ? atoll(e3) : 960) << 20);
-		if (file_bytes == 0 || file_bytes + 65536 > first_bytes) // (a file that fits the first buffer never needs the second)
-			alloc2 = std::thread([this] { if (ssv_bamdec_staging(ctx, 1, stage_bytes, &stage[1]) != SSV_OK) alloc2_err = ssv_last_error(ctx); else stage_cap[1] = stage_bytes; });
-		start_read(0);
+		if (!file_bytes || file_bytes > first_bytes_default()) ssv_bamdec_expect(ctx, chunk_inflated);
+		// The file's first chunk is the one nothing overlaps with: a small one (128 MB: read and locked in ~10 ms), so that the GPU starts early
+		first_bytes = std::min(stage_bytes, first_bytes_default());
+		reader = std::thread([this] { reader_main(); });
 	}
-	void start_read(int k)
+	static size_t page_size() { static const size_t p = (size_t)sysconf(_SC_PAGESIZE); return p; }
+	static size_t first_bytes_default() { const char *e3 = getenv("SSV_STAGE_FIRST_MB"); return (size_t)(e3 ? atoll(e3) : 128) << 20; }
+	static bool take_stage(Slot &S, size_t want)
 	{
-		const size_t want = first_read ? first_bytes : stage_bytes;
-		first_read = false;
-		if (k == 1 && alloc2.joinable()) { alloc2.join(); if (!alloc2_err.empty()) die("[seeksv] " + alloc2_err); }
-		if (blocks[k].empty()) blocks[k].resize((size_t)(std::min<uint64_t>(chunk_inflated, file_bytes ? file_bytes * 64 : chunk_inflated) >> 12) + 1024); // blocks are <= 64 KB but may be much smaller
-		reader = std::thread([this, k, want] {
-			read_err[k].clear();
-			if (stage_cap[k] < want) { // (the chunk that was in this buffer has been decoded: its bytes are on the device)
-				if (ssv_bamdec_staging(ctx, k, want, &stage[k]) != SSV_OK) { read_err[k] = ssv_last_error(ctx); return; }
-				stage_cap[k] = want;
-			}
-			if (ssvh_bam_read_blocks(bam, stage[k], stage_cap[k], chunk_inflated, blocks[k].data(), (int64_t)blocks[k].size(), &n_blocks[k], &n_bytes[k]) != 0) read_err[k] = ssvh_last_error();
-			ssvh_bam_raw_limit(bam, &limit[k]);
-		});
-		reader_running = true;
+		if (S.stage.cap >= want) return true;
+		stage_to_pool(S.stage);
+		S.stage = stage_from_pool(want);
+		return S.stage.reserve(want);
 	}
+	// the reader thread: chunk k into slot k % NS as soon as the decoder has let go of chunk k - NS
+	void reader_main()
+	{
+		for (int64_t k = 0;; ++k) {
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return stop_reader || k - released < NS; });
+				if (stop_reader) break;
+			}
+			Slot &S = slot[k % NS];
+			const auto t0 = std::chrono::steady_clock::now();
+			if (S.reg_base) { ssv_host_unregister(S.reg_base); S.reg_base = nullptr; } // (the chunk that was here has been decoded)
+			S.err.clear(); S.n_blocks = 0; S.n_bytes = 0; S.data = nullptr; S.limit = UINT64_MAX; S.last = false;
+			const size_t want = k == 0 ? first_bytes : stage_bytes;
+			if (S.blocks.empty()) S.blocks.resize((size_t)(std::min<uint64_t>(chunk_inflated, file_bytes ? file_bytes * 64 : chunk_inflated) >> 12) + 1024); // blocks are <= 64 KB but may be much smaller
+			bool filled = false;
+			if (map_mode) {
+				const void *ptr = nullptr;
+				const int rc = ssvh_bam_map_blocks(bam, want, chunk_inflated, S.blocks.data(), (int64_t)S.blocks.size(), &S.n_blocks, &ptr, &S.n_bytes);
+				if (rc == -2) map_mode = false; // the file cannot be mapped: staging buffers from here on (nothing has been consumed)
+				else if (rc != 0) S.err = ssvh_last_error();
+				else {
+					filled = true;
+					S.data = static_cast<const uint8_t *>(ptr);
+					if (S.n_bytes) {
+						const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr) & ~(uintptr_t)(page_size() - 1);
+						const uintptr_t hi = (reinterpret_cast<uintptr_t>(ptr) + S.n_bytes + page_size() - 1) & ~(uintptr_t)(page_size() - 1);
+						if (ssv_host_register(reinterpret_cast<void *>(lo), (size_t)(hi - lo)) == SSV_OK) { S.reg_base = reinterpret_cast<void *>(lo); S.reg_bytes = (size_t)(hi - lo); }
+						else {
+							// the runtime will not lock these pages (a file system it cannot pin, a memory-lock limit): this chunk is copied out of the
+							// mapping, the following ones are read the other way
+							map_mode = false;
+							if (!take_stage(S, std::max(S.n_bytes + 64, stage_bytes))) S.err = "out of memory (staging buffer)";
+							else { memcpy(S.stage.p, ptr, S.n_bytes); S.stage.lock(S.n_bytes); S.data = S.stage.p; }
+						}
+					}
+				}
+			}
+			if (!filled && S.err.empty()) {
+				// (the chunk that was in this buffer has been decoded: its bytes are on the device)
+				if (!take_stage(S, stage_bytes)) S.err = "out of memory (staging buffer)";
+				if (S.err.empty() && ssvh_bam_read_blocks(bam, S.stage.p, std::min(S.stage.cap, want), chunk_inflated, S.blocks.data(), (int64_t)S.blocks.size(), &S.n_blocks, &S.n_bytes) != 0) S.err = ssvh_last_error();
+				if (S.err.empty() && S.n_bytes) S.stage.lock(S.n_bytes);
+				S.data = S.stage.p;
+			}
+			if (S.err.empty()) ssvh_bam_raw_limit(bam, &S.limit);
+			consumed_bytes += S.n_bytes;
+			// (the chunk holds the file's bytes as they are, block headers and trailers included) when nothing but the 28-byte end-of-file block can be
+			// left, no further chunk is read
+			S.last = S.n_blocks == 0 || (file_bytes && consumed_bytes + 28 >= file_bytes);
+			S.t_fill = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			const bool done = S.last || !S.err.empty();
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				produced = k + 1;
+				if (done) reader_exit = true;
+			}
+			cv.notify_all();
+			if (done) break;
+		}
+	}
+	uint64_t consumed_bytes = 0; // (reader thread)
 	// the next batch (valid until the following call); false at the end of the file
 	bool next(ssv_batch_t *b, int keep_all_seq)
 	{
@@ -366,20 +495,34 @@ struct BatchSource {
 				return false;
 			}
 			const auto tw0 = std::chrono::steady_clock::now();
-			if (reader_running) { reader.join(); reader_running = false; }
+			bool next_ready = false;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return produced > cur; });
+				next_ready = produced > cur + 1;
+			}
 			const auto tw1 = std::chrono::steady_clock::now();
-			const int k = cur;
-			if (!read_err[k].empty()) die("[seeksv] " + read_err[k]);
-			// (the chunk holds the file's bytes as they are, block headers and trailers included) when nothing but the 28-byte end-of-file block can
-			// be left, do not start (and allocate a second staging buffer for) another read
-			consumed += n_bytes[k];
-			const bool last_chunk = n_blocks[k] == 0 || (file_bytes && consumed + 28 >= file_bytes);
-			if (!last_chunk) { cur ^= 1; start_read(cur); } // the other buffer fills while this chunk is decoded
-			if (limit[k] != UINT64_MAX) ssv_bamdec_limit(ctx, limit[k]);
-			if (ssv_bamdec_decode(ctx, stage[k], n_bytes[k], blocks[k].data(), n_blocks[k], keep_all_seq, b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-			if (kTimingChunks) cerr << "[timing] (chunk of " << n_bytes[k] << " bytes, " << n_blocks[k] << " blocks: waited " << std::chrono::duration<double>(tw1 - tw0).count() << " s for the reader, decoded in "
+			Slot &S = slot[cur % NS];
+			if (!S.err.empty()) die("[seeksv] " + S.err);
+			const bool last_chunk = S.last;
+			// the chunk behind this one starts its way over PCIe now, under this chunk's kernels
+			if (!last_chunk && next_ready && announced < cur + 1) {
+				Slot &N = slot[(cur + 1) % NS];
+				if (N.err.empty() && N.n_blocks > 0 && ssv_bamdec_prefetch(ctx, N.data, N.n_bytes) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+				announced = cur + 1;
+			}
+			if (S.limit != UINT64_MAX) ssv_bamdec_limit(ctx, S.limit);
+			if (ssv_bamdec_decode(ctx, S.data, S.n_bytes, S.blocks.data(), S.n_blocks, keep_all_seq, b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+			if (kTimingChunks) cerr << "[timing] (chunk of " << S.n_bytes << " bytes, " << S.n_blocks << " blocks, " << (S.reg_base ? "page-locked in the mapping" : "copied to staging") << " in " << S.t_fill
+			                        << " s: waited " << std::chrono::duration<double>(tw1 - tw0).count() << " s for the reader, " << (announced >= cur && cur > 0 ? "announced ahead, " : "") << "decoded in "
 			                        << std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count() << " s)" << endl;
-			if (n_blocks[k] == 0) { at_end = true; return false; }
+			const int64_t nb = S.n_blocks;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				released = ++cur; // the chunk's bytes are on the device and decoded: its slot is the reader's again
+			}
+			cv.notify_all();
+			if (nb == 0) { at_end = true; return false; }
 			if (last_chunk) end_pending = true;
 			ssv_bamdec_last(ctx, &info);
 			if (b->n) return true; // (a chunk can hold only the middle of one huge record)
@@ -425,8 +568,13 @@ struct BatchSource {
 	}
 	void close()
 	{
-		if (reader_running) { reader.join(); reader_running = false; }
-		if (alloc2.joinable()) alloc2.join();
+		if (reader.joinable()) {
+			{ std::lock_guard<std::mutex> lk(mu); stop_reader = true; }
+			cv.notify_all();
+			reader.join();
+		}
+		if (announced >= cur && ctx) ssv_bamdec_prefetch_drop(ctx); // a chunk on its way that nobody will decode: its copy must have left the host pages
+		for (Slot &S : slot) { if (S.reg_base) { ssv_host_unregister(S.reg_base); S.reg_base = nullptr; } stage_to_pool(S.stage); }
 		if (bam) ssvh_bam_close(bam);
 		bam = nullptr;
 	}
@@ -1628,6 +1776,9 @@ static int cmd_realign(int argc, char **argv)
 	b.seq_off = seq_off.data(); b.seqqual = seqqual.data(); b.seqqual_bytes = (int64_t)seqqual.size() - 16;
 	vector<const char *> tn;
 	for (const string &x : names) tn.push_back(x.c_str());
+	// clip.bam is read back once, by getsv's join: its BGZF blocks are literal-only Huffman blocks (huff_gz.h: 4 x the speed of zlib level 1 on these
+	// records, 1.6 x the bytes) unless SSV_BGZF_LEVEL asks for zlib
+	setenv("SSV_BGZF_LEVEL", "-1", 0);
 	if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), lens.data(), (int32_t)names.size(), &b, qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
 	pt.lap("write bam");
 	cerr << "[seeksv realign] " << n << " clipped sequences, " << n_aligned << " aligned" << (dropped ? ", " + to_string(dropped) + " repetitive index positions dropped" : string()) << endl;

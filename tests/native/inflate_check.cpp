@@ -207,6 +207,45 @@ int main()
 						if (r2 == ssv::INF_OK) { ++n_bad; fprintf(stderr, "short output accepted: shape %d n %zu level %d\n", shape, n, level); }
 					}
 				}
+	// Damaged streams: whatever the decoder ACCEPTS, zlib accepts too, with the same bytes (the structural rules are zlib's: over-subscribed and
+	// incomplete codes, a missing end-of-block code, distances in front of the block, symbols that do not exist, input or output that ends early)
+	{
+		int accepted = 0, refused = 0;
+		for (int it = 0; it < 6000; ++it) {
+			const int shape = it % 7;
+			const size_t n = 200 + rnd() % 3000;
+			std::vector<uint8_t> d = make_data(shape, n);
+			z_stream zs = {};
+			if (deflateInit2(&zs, 1 + it % 9, Z_DEFLATED, -15, 8, it % 11 == 0 ? Z_FIXED : Z_DEFAULT_STRATEGY) != Z_OK) return 2;
+			std::vector<uint8_t> c(2 * n + 1024, 0);
+			zs.next_in = d.data(); zs.avail_in = (uInt)n; zs.next_out = c.data(); zs.avail_out = (uInt)c.size() - 8;
+			if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return 3;
+			const uint32_t clen = (uint32_t)zs.total_out;
+			deflateEnd(&zs);
+			// damage: mostly inside the first bytes (the block header with its code lengths), sometimes anywhere
+			const int flips = 1 + (int)(rnd() % 3);
+			for (int f = 0; f < flips; ++f) { const uint32_t at = (rnd() & 3) ? rnd() % (clen < 40 ? clen : 40) : rnd() % clen; c[at] ^= (uint8_t)(1u << (rnd() & 7)); }
+			std::vector<uint8_t> o(n + 8, 0x55), zo(n + 8, 0);
+			const int rc = ssv::inflate_stream(c.data(), clen, o.data(), (uint32_t)n, tab);
+			std::vector<uint32_t> tk(ssv::token_capacity((uint32_t)n) + 1);
+			std::vector<uint8_t> o2(n + 8, 0x55);
+			ssv::TokenOut to;
+			to.out = o2.data(); to.tok = tk.data();
+			const int rc2 = ssv::inflate_stream_to(c.data(), clen, to, (uint32_t)n, tab);
+			if ((rc == ssv::INF_OK) != (rc2 == ssv::INF_OK)) { ++n_bad; fprintf(stderr, "damaged stream %d: the two sinks disagree (%d, %d)\n", it, rc, rc2); }
+			if (rc != ssv::INF_OK) { ++refused; continue; }
+			++accepted;
+			z_stream is = {};
+			if (inflateInit2(&is, -15) != Z_OK) return 2;
+			is.next_in = c.data(); is.avail_in = clen; is.next_out = zo.data(); is.avail_out = (uInt)n + 8;
+			const int zr = inflate(&is, Z_FINISH);
+			const bool zok = zr == Z_STREAM_END && is.total_out == n && memcmp(zo.data(), o.data(), n) == 0;
+			inflateEnd(&is);
+			if (!zok) { ++n_bad; fprintf(stderr, "damaged stream %d (shape %d, n %zu): accepted, but zlib says %d with %lu bytes\n", it, shape, n, zr, (unsigned long)is.total_out); }
+		}
+		printf("damaged streams: %d refused, %d accepted (each of those as zlib decodes it)\n", refused, accepted);
+		if (refused < 1000) { ++n_bad; fprintf(stderr, "too few damaged streams refused\n"); }
+	}
 	printf("%d streams ok, %d bad\n", n_ok, n_bad);
 	return n_bad ? 1 : 0;
 }

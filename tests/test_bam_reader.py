@@ -118,3 +118,42 @@ def test_next_record_refused_during_readahead(bam):
         assert r.read_batch(100) is not None
         assert lib.ssvh_bam_next_record(r.handle, C.byref(rec)) == -1
         assert b"read-ahead" in lib.ssvh_last_error()
+
+
+def test_mapped_chunks_equal_copied_chunks(bam):
+    """ssvh_bam_map_blocks (the chunk's bytes handed out where they lie in a mapping of the file: what the device decoder's reader page-locks and
+    lets the GPU fetch by DMA) cuts the file into the same chunks, with the same block tables, as ssvh_bam_read_blocks (bytes copied into the
+    caller's buffer) - at chunk sizes from one block up, including sizes that end a chunk in the middle of a block header"""
+    import ctypes as C
+    from seeksv_amd import _abi
+    path, _ = bam
+    lib = _abi.host_lib()
+    lib.ssvh_bam_map_blocks.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(_abi.BgzfBlock), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    size = os.path.getsize(path)
+    for max_bytes, max_inflated, max_blocks in [(1 << 20, 1 << 30, 1 << 16), (70000, 1 << 30, 1 << 16), (1 << 20, 100000, 1 << 16), (1 << 20, 1 << 30, 3), (200001, 150000, 5), (size + 100, 1 << 40, 1 << 16)]:
+        chunks = []
+        for mapped in (False, True):
+            h = C.c_void_p()
+            assert lib.ssvh_bam_open(path.encode(), C.byref(h)) == 0
+            first = C.c_uint64()
+            assert lib.ssvh_bam_raw_begin(h, C.byref(first)) == 0
+            blocks = (_abi.BgzfBlock * max_blocks)() if max_blocks < 100 else (_abi.BgzfBlock * 4096)()
+            buf = (C.c_uint8 * (max_bytes + 8))()
+            got = []
+            while True:
+                nb, nbytes, ptr = C.c_int64(), C.c_size_t(), C.c_void_p()
+                if mapped:
+                    assert lib.ssvh_bam_map_blocks(h, max_bytes, max_inflated, blocks, min(max_blocks, 4096), C.byref(nb), C.byref(ptr), C.byref(nbytes)) == 0, lib.ssvh_last_error()
+                    data = C.string_at(ptr, nbytes.value) if nbytes.value else b""
+                else:
+                    assert lib.ssvh_bam_read_blocks(h, buf, max_bytes + 8, max_inflated, blocks, min(max_blocks, 4096), C.byref(nb), C.byref(nbytes)) == 0, lib.ssvh_last_error()
+                    data = bytes(buf[:nbytes.value])
+                if nb.value == 0:
+                    break
+                got.append((data, [(blocks[k].c_off, blocks[k].c_len, blocks[k].u_len) for k in range(nb.value)]))
+            lib.ssvh_bam_close(h)
+            chunks.append(got)
+        assert len(chunks[0]) == len(chunks[1]) and len(chunks[0]) >= 1
+        for (d0, b0), (d1, b1) in zip(*chunks):
+            assert b0 == b1 and d0 == d1
+        assert sum(len(d) for d, _ in chunks[1]) in (size, size - 28)  # (the end-of-file block may or may not be part of the last chunk)

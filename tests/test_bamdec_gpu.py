@@ -350,6 +350,7 @@ def test_device_decode_fuzzed_payloads(ctx, tmp_path):
     the file or - when the damage happens to decode to the same number of bytes - hand out batches, and never fault, hang or corrupt its own state: the
     undamaged file still decodes to the host reader's batches afterwards.  (Runs again under both forms of pass 1 in test_tokens_modes.)"""
     import struct
+    import zlib
     path = str(tmp_path / "f.bam")
     _bam_with_block_kinds(path, _records(1500, 5) + _pattern_records(800, 9), 11)
     raw = open(path, "rb").read()
@@ -368,8 +369,22 @@ def test_device_decode_fuzzed_payloads(ctx, tmp_path):
             b[int(rng.integers(lo, hi))] = int(rng.integers(0, 256))
         bad = str(tmp_path / "bad.bam")
         open(bad, "wb").write(bytes(b))
+        # zlib's verdict on every block of the damaged file: the device decoders apply zlib's rules to a block's structure (over-subscribed and
+        # incomplete codes, missing end-of-block code, distances in front of the block, symbols that do not exist, input or output that ends early),
+        # so whatever form of pass 1 runs refuses every file zlib refuses
+        zlib_ok, at = True, 0
+        while at < len(b) and zlib_ok:
+            bsize = struct.unpack_from("<H", b, at + 16)[0] + 1
+            isize = struct.unpack_from("<I", b, at + bsize - 4)[0]
+            try:
+                z = zlib.decompressobj(-15)
+                zlib_ok = len(z.decompress(bytes(b[at + 18:at + bsize - 8]))) == isize and z.eof
+            except zlib.error:
+                zlib_ok = False
+            at += bsize
         try:
             _device_all(ctx, bad, 1 << 19, 9)
+            assert zlib_ok, f"fuzz case {k}: the device decoder accepted a file zlib refuses"
         except (device.SeeksvError, IOError):
             refused += 1
     # (a byte that turns one literal into another - in a stored block, or a code of the same length - inflates to the same number of bytes: like libbam 0.1.16's

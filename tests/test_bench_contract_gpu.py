@@ -39,6 +39,11 @@ def test_bench_line_contract():
     assert "error" not in fp, fp
     if "same_result_as_resident_path" in fp:
         assert fp["same_result_as_resident_path"] is True, (fp["result"], d["result"])
+    # the file is read inside the leg's timed region; round 3's footing (the file in pinned memory beforehand) is reported beside it; the
+    # resident leg says where its counter bytes come from
+    assert fp["includes_file_read"] is True and fp["from_pinned"]["includes_file_read"] is False and fp["from_pinned"]["value"] > 0 and fp["two_reads"]["value"] > 0
+    assert "traffic_source" in rf and ("profiles/traffic.json" in rf["traffic_source"])
+    assert (rf["traffic"] is None) == rf["traffic_source"].startswith("none")
 
 
 def test_bench_two_ranks_equal_one():

@@ -101,7 +101,7 @@ def main():
     groups = {g: (gf.get(g, 0.0) + gw.get(g, 0.0)) / steps for g in sorted(set(gf) | set(gw)) if g != "h2d"}
     t = {"_note": f"HBM bytes per step from the rocprofv3 PMC passes in profiles/{tag}_pmc_fetch_write.csv: FETCH_SIZE (doubled for the two streaming scans, whose 16-B/lane loads gfx950 counts at "
                   "half: MI355X_MICROARCH.md) + WRITE_SIZE per kernel group of bench.py, device-wide scans and fills counted with the kernel they follow; regenerate with tools/pmc_traffic.py",
-         "records": records, "groups": groups, "path_bytes_per_step": sum(groups.values()),
+         "_round": tag, "records": records, "groups": groups, "path_bytes_per_step": sum(groups.values()),
          "path_bytes_per_record": sum(groups.values()) / records}
     json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(t, indent=1))
