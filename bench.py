@@ -392,11 +392,11 @@ def main():
                 avail_gb = 0.0
             # Every record with its bases and qualities: 72-76 B/record in the file.  What bounds the leg's size is writing the file with zlib on the
             # host (outside the timed region, but inside the run): level 6 deflates ~11 MB/s per core, level 4 (lazy matching too, 76 instead of
-            # 72 B/record) ~40 MB/s.  The driver's box grants 16 CPUs of time: a QUARTER of the sample (154 M records, 42 GB of records, an 11.8 GB file)
-            # at level 4 takes about a minute (round 3 took an eighth: file-to-file rates of a 6 GB file are mostly start-up costs); >= 192 CPUs write
-            # the whole sample.
+            # 72 B/record) ~40 MB/s.  The driver's box grants 16 CPUs of time: HALF of the sample (309 M records, 85 GB of records, a 23.7 GB file) at
+            # level 4 takes about two minutes (round 3 took an eighth: a command's 0.5 s of start-up - process, HIP runtime, first allocations - is
+            # as long as its work on a 6 GB file); >= 192 CPUs write the whole sample.
             eff = effective_cpus()
-            args.file_frac = args.genome_frac * (1.0 if eff >= 192 and avail_gb >= 256 else 0.25 if eff >= 12 and avail_gb >= 64 else 0.125 if eff >= 8 and avail_gb >= 32 else 1 / 64)
+            args.file_frac = args.genome_frac * (1.0 if eff >= 192 and avail_gb >= 256 else 0.5 if eff >= 16 and avail_gb >= 160 else 0.25 if eff >= 12 and avail_gb >= 64 else 0.125 if eff >= 8 and avail_gb >= 32 else 1 / 64)
             if args.file_level < 0:
                 args.file_level = 6 if eff >= 64 else 4
         if args.file_level < 0:
@@ -536,11 +536,11 @@ def file_path_leg(ctx, args, device):
             if hl.ssvh_bam_raw_begin(r.handle, C.byref(first)) != 0:
                 raise IOError(hl.ssvh_last_error().decode())
             n_targets = len(r.target_names)
-            # chunks of ~5 GB of inflated data (about 80 K BGZF blocks each): the inflate kernels decode one block per lane / per 16 lanes and need that
-            # many to fill the chip (pass 1 keeps 82 K blocks resident at once)
-            chunk_inflated = 5 << 30
-            max_blocks = 1 << 18
-            cap = min(bam_bytes + (1 << 20), 3 << 29)
+            # chunks of ~2 GB of inflated data (about 33 K BGZF blocks, 0.6 GB of file each): both inflate passes take a wavefront per block and run at
+            # the same rate whatever the chunk's size (round 3: 5 GB chunks, which the lane-per-block kernels needed to fill the chip)
+            chunk_inflated = 2 << 30
+            max_blocks = 1 << 17
+            cap = min(bam_bytes + (1 << 20), 3 << 28)
             while True:
                 buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
                 blocks = (_abi.BgzfBlock * max_blocks)()

@@ -60,8 +60,30 @@ void reverse_cigar(CigarVec &v) // ReverseCigar, getsv.cpp:453
 	for (size_t i = 0, n = v.size(); i < n / 2; ++i) std::swap(v[i], v[n - 1 - i]);
 }
 
+// where the join's alignment records come from: clip.bam through the host reader, or the aligner step's results still in memory
+struct RecSource {
+	ssvh_bam *bam = nullptr;
+	const AlnRecords *mem = nullptr;
+	int64_t at = 0;
+	int next(ssvh_record *out) // 1: a record, 0: the end, < 0: error (ssvh_last_error)
+	{
+		if (bam) return ssvh_bam_next_record(bam, out);
+		if (at >= mem->n) return 0;
+		const int64_t i = at++;
+		out->tid = mem->tid[i]; out->pos = mem->pos[i]; out->flag = mem->flag[i]; out->mapq = mem->mapq[i]; out->n_cigar = mem->n_cigar[i];
+		out->cigar = mem->cigar + mem->cigar_off[i]; out->qname = mem->qname[i];
+		out->l_qseq = 0; out->seq = nullptr; out->qual = nullptr;
+		return 1;
+	}
+	const char *target_name(int32_t tid) const
+	{
+		if (bam) return ssvh_bam_target_name(bam, tid);
+		return tid >= 0 && (size_t)tid < mem->target_names.size() ? mem->target_names[(size_t)tid].c_str() : nullptr;
+	}
+};
+
 // GetAlignInfo, getsv.cpp:25-71
-void align_info_of(const ssvh_bam *bam, const ssvh_record &r, AlignInfo &a)
+void align_info_of(const RecSource *bam, const ssvh_record &r, AlignInfo &a)
 {
 	if (r.flag & 4) {
 		a = AlignInfo();
@@ -86,7 +108,7 @@ void align_info_of(const ssvh_bam *bam, const ssvh_record &r, AlignInfo &a)
 		a.cigar_vec.push_back(std::make_pair(l, "MIDNSHP=X"[op]));
 	}
 	if (r.flag & 16) { a.strand = '-'; reverse_complement(a.seq); } else a.strand = '+';
-	const char *nm = ssvh_bam_target_name(bam, r.tid);
+	const char *nm = bam->target_name(r.tid);
 	a.chr = nm ? nm : "";
 	a.pos = r.pos + 1;
 }
@@ -387,13 +409,17 @@ static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows
 	return true;
 }
 
-static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, JunctionMap &j2o);
-std::string assemble_junctions_text(const std::string &text, const std::string &clip_bam, JunctionMap &j2o) { return assemble_junctions_view(TextView{text.data(), text.size()}, clip_bam, j2o); }
+static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o);
+std::string assemble_junctions_text(const std::string &text, const std::string &clip_bam, JunctionMap &j2o) { return assemble_junctions_view(TextView{text.data(), text.size()}, clip_bam, nullptr, j2o); }
+std::string assemble_junctions_records(const std::string &text, const AlnRecords &aln, JunctionMap &j2o) { return assemble_junctions_view(TextView{text.data(), text.size()}, "", &aln, j2o); }
 
-static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, JunctionMap &j2o)
+static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o)
 {
-	ssvh_bam *bam = nullptr;
-	if (ssvh_bam_open(clip_bam.c_str(), &bam) != 0) return "[main_samview] fail to open file for reading.";
+	RecSource source;
+	source.mem = mem;
+	if (!mem && ssvh_bam_open(clip_bam.c_str(), &source.bam) != 0) return "[main_samview] fail to open file for reading.";
+	RecSource *const bam = &source;
+	struct Closer { RecSource *s; ~Closer() { if (s->bam) ssvh_bam_close(s->bam); } } closer{bam};
 	std::vector<ClipRow> rows; // the rows that share `current` (the reference's multimap is cleared at every group change)
 	AlignMap aligns;
 	Str current;               // last_clipped_seq (a view: the rows' text outlives the join)
@@ -414,7 +440,7 @@ static std::string assemble_junctions_view(const TextView &text, const std::stri
 		if (current.n == 0 || current == row.clipped_seq) { current = row.clipped_seq; rows.push_back(row); return true; }
 		// a new clipped sequence: consume the alignments of the current group
 		int rc;
-		while ((rc = ssvh_bam_next_record(bam, &rec)) == 1) {
+		while ((rc = bam->next(&rec)) == 1) {
 			if (is_hard_clip(rec)) continue;
 			if (current.equals(rec.qname)) { file_under(current); continue; }
 			flush_group(rows, aligns, j2o);
@@ -433,7 +459,7 @@ static std::string assemble_junctions_view(const TextView &text, const std::stri
 	const auto t0 = std::chrono::steady_clock::now();
 	if (parse_rows_parallel(text, parsed)) {
 		const auto t1 = std::chrono::steady_clock::now();
-		for (auto &row : parsed) if (!on_row(row)) { ssvh_bam_close(bam); return failure; }
+		for (auto &row : parsed) if (!on_row(row)) return failure;
 		if (timing) std::cerr << "[timing] (junction stage: " << parsed.size() << " rows parsed in " << std::chrono::duration<double>(t1 - t0).count() << " s, joined with clip.bam in "
 		                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() << " s)" << std::endl;
 		std::vector<ClipRow>().swap(parsed);
@@ -447,16 +473,15 @@ static std::string assemble_junctions_view(const TextView &text, const std::stri
 			fin >> row.pos >> row.side >> cigar >> aligned_seq >> aligned_qual >> clipped_seq >> clipped_qual >> row.support;
 			std::getline(fin, rest);
 			row.chr = keep(chr); row.cigar = keep(cigar); row.aligned_seq = keep(aligned_seq); row.clipped_seq = keep(clipped_seq); row.clipped_qual = keep(clipped_qual);
-			if (!on_row(row)) { ssvh_bam_close(bam); return failure; }
+			if (!on_row(row)) return failure;
 		}
 	}
 	int rc;
-	while ((rc = ssvh_bam_next_record(bam, &rec)) == 1) { // tail: no hard-clip test here
+	while ((rc = bam->next(&rec)) == 1) { // tail: no hard-clip test here
 		if (current.equals(rec.qname)) file_under(current);
 		else break;
 	}
 	flush_group(rows, aligns, j2o);
-	ssvh_bam_close(bam);
 	return "";
 }
 
@@ -475,7 +500,7 @@ std::string assemble_junctions(const std::string &clipfile, const std::string &c
 		view = TextView{text.data(), text.size()};
 	}
 	if (getenv("SSV_TIMING")) std::cerr << "[timing] (junction stage: " << view.size() << " bytes of rows read in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s)" << std::endl;
-	return assemble_junctions_view(view, clip_bam, j2o);
+	return assemble_junctions_view(view, clip_bam, nullptr, j2o);
 }
 
 void merge_junctions(JunctionMap &j2o, int search_length)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <deque>
 #include <fcntl.h>
@@ -235,6 +236,16 @@ struct ResidentBam {
 	// what getclip wrote, still in memory for the steps that follow (the files are written all the same: they are outputs)
 	string clip_path, fq_path;   // prefix.clip.gz, prefix.clip.fq.gz
 	string clip_rows, fq_text;   // their decompressed contents
+	// what the aligner step made of fq_text (clip.bam is written all the same); the read names point into fq_text
+	struct Aligned {
+		string bam_path;
+		vector<int32_t> tid, pos;
+		vector<uint16_t> flag, n_cigar;
+		vector<uint8_t> mapq;
+		vector<uint32_t> cigar_off, cigar;
+		vector<const char *> qname;
+		vector<string> names;
+	} aln;
 };
 static ResidentBam g_resident;
 
@@ -245,9 +256,41 @@ static void release_ctx(ssv_ctx *ctx)
 	else ssv_sync(ctx);
 }
 
+// The HIP runtime takes 0.1-0.3 s to come up (first call of the process) - longer than a command spends on a 6 GB file's kernels.  main() starts the
+// context on a thread of its own before the command parses its arguments; opening files, the junction stage of getsv and the reader's first chunks
+// run beside it, and acquire_ctx joins it where the first kernel is needed.
+struct EarlyCtx {
+	std::thread th;
+	ssv_ctx *ctx = nullptr;
+	int device = -1, rc = SSV_OK;
+	string err;
+	bool started = false, taken = false;
+};
+static EarlyCtx g_early;
+static void early_ctx_join() { if (g_early.th.joinable()) g_early.th.join(); }
+static void early_ctx_start(int device)
+{
+	if (g_early.started || getenv("SSV_NO_EARLY_CTX")) return;
+	g_early.started = true; g_early.device = device;
+	atexit(early_ctx_join); // (usage errors leave through exit(): not while a thread is inside the runtime's start-up)
+	g_early.th = std::thread([] {
+		g_early.rc = ssv_ctx_create(g_early.device, &g_early.ctx);
+		if (g_early.rc != SSV_OK) g_early.err = ssv_last_error(nullptr);
+	});
+}
+
 static ssv_ctx *acquire_ctx(int device)
 {
 	if (g_resident.ctx) return g_resident.ctx;
+	if (g_early.started && !g_early.taken) {
+		early_ctx_join();
+		g_early.taken = true;
+		if (g_early.device == device) {
+			if (g_early.rc != SSV_OK) die(string("[seeksv] ") + g_early.err);
+			return g_early.ctx;
+		}
+		if (g_early.ctx) ssv_ctx_destroy(g_early.ctx); // (another -G than the one main() saw)
+	}
 	ssv_ctx *ctx = nullptr;
 	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
 	return ctx;
@@ -271,6 +314,7 @@ struct StageBuf {
 		const size_t n = (want + page() - 1) & ~(page() - 1);
 		void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
 		if (m == MAP_FAILED) return false;
+		(void)madvise(m, n, MADV_HUGEPAGE); // (2 MB pages where the kernel grants them: 512 x fewer faults while the first fill populates the buffer)
 		p = static_cast<uint8_t *>(m); cap = n;
 		return true;
 	}
@@ -366,42 +410,46 @@ struct BatchSource {
 	void set_range(uint64_t sc, uint32_t su, uint64_t ec, uint32_t eu) { ranged = true; r_start_coff = sc; r_start_uoff = su; r_end_coff = ec; r_end_uoff = eu; }
 	int32_t r_prev_tid = 0; // contig of the last mapped-pair record before the range
 
-	void open(const string &path, ssv_ctx *c, bool device_inflate, const char *open_error)
+	void open(const string &path, ssv_ctx *c, bool device_inflate, const char *open_error) { open(path, [c] { return c; }, device_inflate, open_error); }
+	// get_ctx: asked for the context as late as possible - the file is opened and the reader thread is on its first chunks before (the context of a
+	// fresh process may still be coming up, acquire_ctx)
+	void open(const string &path, const std::function<ssv_ctx *()> &get_ctx, bool device_inflate, const char *open_error)
 	{
-		ctx = c; on_device = device_inflate;
+		on_device = device_inflate;
 		if (ssvh_bam_open(path.c_str(), &bam) != 0) die(open_error);
-		if (!ranged && !g_resident.collect && g_resident.ctx == c && !g_resident.batches.empty() && path == g_resident.path) { resident = true; on_device = true; return; }
+		if (g_resident.ctx || !on_device) ctx = get_ctx();
+		ssv_ctx *const c = ctx;
+		if (!ranged && !g_resident.collect && c && g_resident.ctx == c && !g_resident.batches.empty() && path == g_resident.path) { resident = true; on_device = true; return; }
 		if (!on_device) {
 			if (ranged && ssvh_bam_set_range(bam, r_start_coff, r_start_uoff, r_end_coff, r_end_uoff) != 0) die(string("[seeksv] ") + ssvh_last_error());
 			use_pinned_batches(bam);
 			return;
 		}
 		const char *e1 = getenv("SSV_CHUNK_INFLATED_MB"), *e2 = getenv("SSV_STAGE_MB"), *e4 = getenv("SSV_READER");
-		chunk_inflated = (uint64_t)(e1 ? atoll(e1) : 4096) << 20;
-		stage_bytes = (size_t)(e2 ? atoll(e2) : 1536) << 20;
 		map_mode = e4 && !strcmp(e4, "map");
 		{
 			FILE *f = fopen(path.c_str(), "rb");
 			if (f) { fseek(f, 0, SEEK_END); file_bytes = (uint64_t)ftell(f); fclose(f); }
-			// What a command pays once grows with the chunk size - ~3.8 bytes of device memory per inflated byte (~20 ms per GB, at the first decode), in
-			// copy mode three page-locked staging buffers at 0.25 s/GB - and what big chunks buy is inflate rate (more BGZF blocks in flight), which only
-			// matters once the file is long: chunks of 1 GB inflated below 8 GB of file, 2 GB below 24 GB, 4 GB above.
-			if (!e1 && !e2 && file_bytes && !ranged) {
-				if (file_bytes <= ((uint64_t)8 << 30)) { chunk_inflated = (uint64_t)1024 << 20; stage_bytes = (size_t)384 << 20; }
-				else if (file_bytes <= ((uint64_t)24 << 30)) { chunk_inflated = (uint64_t)2048 << 20; stage_bytes = (size_t)768 << 20; }
-			}
+			// What a command pays once grows with the chunk size: ~3.8 bytes of device memory per inflated byte and three page-locked staging buffers, to set
+			// up AND to give back (the kernel takes 0.16-0.25 s to tear a process with 8 GB of device buffers and 2.3 GB of locked pages down, after exit and
+			// before the caller's wait returns).  Since round 4 both inflate passes are a wavefront per block and their rate does not depend on the blocks in
+			// flight: chunks of 1 GB inflated below 16 GB of file, 2 GB above (round 3: up to 4 GB, which the lane-per-block kernels needed).
+			chunk_inflated = (uint64_t)(e1 ? atoll(e1) : 2048) << 20;
+			stage_bytes = (size_t)(e2 ? atoll(e2) : 768) << 20;
+			if (!e1 && !e2 && file_bytes && !ranged && file_bytes <= ((uint64_t)16 << 30)) { chunk_inflated = (uint64_t)1024 << 20; stage_bytes = (size_t)384 << 20; }
 			if (file_bytes && file_bytes + 65536 < stage_bytes) stage_bytes = (size_t)file_bytes + 65536;
 		}
 		uint64_t first = 0;
 		if (ranged) { if (ssvh_bam_raw_begin_range(bam, r_start_coff, r_start_uoff, r_end_coff, r_end_uoff, &first) != 0) die(string("[seeksv] ") + ssvh_last_error()); file_bytes = 0; }
 		else if (ssvh_bam_raw_begin(bam, &first) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		// The file's first chunk is the one nothing overlaps with: a small one (128 MB: read and locked in ~10 ms), so that the GPU starts early
+		first_bytes = std::min(stage_bytes, first_bytes_default());
+		reader = std::thread([this] { reader_main(); }); // (reads, and locks its buffers: needs no context)
+		if (!ctx) ctx = get_ctx();
 		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ssv_bamdec_target_lens(ctx, ssvh_bam_target_lens(bam)) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ranged) ssv_bamdec_prev_tid(ctx, r_prev_tid);
 		if (!file_bytes || file_bytes > first_bytes_default()) ssv_bamdec_expect(ctx, chunk_inflated);
-		// The file's first chunk is the one nothing overlaps with: a small one (128 MB: read and locked in ~10 ms), so that the GPU starts early
-		first_bytes = std::min(stage_bytes, first_bytes_default());
-		reader = std::thread([this] { reader_main(); });
 	}
 	static size_t page_size() { static const size_t p = (size_t)sysconf(_SC_PAGESIZE); return p; }
 	static size_t first_bytes_default() { const char *e3 = getenv("SSV_STAGE_FIRST_MB"); return (size_t)(e3 ? atoll(e3) : 128) << 20; }
@@ -717,14 +765,14 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	if (!fuout1.open(f_u1)) die("Cannot open file " + f_u1);
 	if (!fuout2.open(f_u2)) die("Cannot open file " + f_u2);
 
-	ssv_ctx *ctx = acquire_ctx(device);
+	BatchSource src;
+	src.open(bamfile, [device] { return acquire_ctx(device); }, device_inflate, "[main_samview] fail to open file for reading.");
+	ssv_ctx *ctx = src.ctx;
 	ssv_clip_params p;
 	memset(&p, 0, sizeof(p));
 	p.match_rate = threshold; p.min_mapq = min_mapQ; p.save_low_quality = save_low_quality ? 1 : 0;
 	if (ssv_clip_begin(ctx, &p) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 	ssv_clip_table_format(ctx, table_format_default()); // the compact table over PCIe; expanded by the formatting threads below
-	BatchSource src;
-	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
 	ssvh_bam *bam = src.bam;
 	pt.lap("open+gpu_init");
 
@@ -740,8 +788,8 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	// The rows of a finished pass are formatted and compressed by a thread of their own while the main thread goes on reading and scanning the
 	// next pass (the table sits in one of the context's two table sets: the emitter of pass k is joined before pass k + 1 is clustered, which is
 	// when the library may touch that set again).  A coordinate-sorted BAM is one pass as far as the results go; it is cut at contig changes -
-	// where the reference flushes anyway - whenever SSV_PASS_RECORDS records (default 64 M) have gone into the pass, so that this overlap exists.
-	static const int64_t pass_records_max = [] { const char *e = getenv("SSV_PASS_RECORDS"); return e ? std::max<int64_t>(1, atoll(e)) : (int64_t)64 << 20; }();
+	// where the reference flushes anyway - whenever SSV_PASS_RECORDS records (default 16 M: about a contig of a 30x genome, so that only the last contig's rows are formatted after the last record) have gone into the pass, so that this overlap exists.
+	static const int64_t pass_records_max = [] { const char *e = getenv("SSV_PASS_RECORDS"); return e ? std::max<int64_t>(1, atoll(e)) : (int64_t)16 << 20; }();
 	int64_t pass_records = 0;
 	std::thread emitter;
 	double emit_format_s = 0, emit_gzip_s = 0;
@@ -1022,11 +1070,12 @@ static double largest_base_frequency(const string &seq) // CountLargestBaseFrequ
 // fused pass scans them and goes on from the next chunk instead of reading, inflating and decoding the head of the file again.
 struct IsizeCarry { BatchSource src; vector<ssv_batch_t> kept; bool owned = false, usable = false; };
 
-static void insert_size_pass(ssv_ctx *ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation, IsizeCarry *keep = nullptr)
+static void insert_size_pass(const std::function<ssv_ctx *()> &get_ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation, IsizeCarry *keep = nullptr)
 {
 	BatchSource local;
 	BatchSource &src = keep ? keep->src : local;
-	src.open(bamfile, ctx, device_inflate, "[main_samview] fail to open file for reading.");
+	src.open(bamfile, get_ctx, device_inflate, "[main_samview] fail to open file for reading.");
+	ssv_ctx *ctx = src.ctx ? src.ctx : get_ctx();
 	ssv_isize_begin(ctx, min_mapQ, read_pair_used);
 	int32_t done = 0;
 	int chunks = 0;
@@ -1112,8 +1161,15 @@ static int cmd_getsv(int argc, char **argv)
 		cerr << "[ReadBreakpoint] finish" << endl;
 	}
 	{ // InputSoftInfoStoreBreakpoint + GetJunction (getsv.h:423, getsv.cpp:1705): clip clusters x re-alignments of their clipped sequences
-		string err = g_resident.ctx && clipfile == g_resident.clip_path ? seeksv::assemble_junctions_text(g_resident.clip_rows, clip_bam, junction2other)
-		                                                               : seeksv::assemble_junctions(clipfile, clip_bam, junction2other);
+		string err;
+		if (g_resident.ctx && clipfile == g_resident.clip_path && clip_bam == g_resident.aln.bam_path && !getenv("SSV_RUN_REREAD")) {
+			const auto &A = g_resident.aln; // rows and alignments are both still in memory
+			seeksv::AlnRecords R;
+			R.n = (int64_t)A.tid.size(); R.tid = A.tid.data(); R.pos = A.pos.data(); R.flag = A.flag.data(); R.n_cigar = A.n_cigar.data(); R.mapq = A.mapq.data();
+			R.cigar_off = A.cigar_off.data(); R.cigar = A.cigar.data(); R.qname = A.qname.data(); R.target_names = A.names;
+			err = seeksv::assemble_junctions_records(g_resident.clip_rows, R, junction2other);
+		} else err = g_resident.ctx && clipfile == g_resident.clip_path ? seeksv::assemble_junctions_text(g_resident.clip_rows, clip_bam, junction2other)
+		                                                                : seeksv::assemble_junctions(clipfile, clip_bam, junction2other);
 		if (!err.empty()) die(err);
 	}
 	cerr << "'InputSoftInfoStoreBreakpoint' finished" << endl;
@@ -1132,18 +1188,19 @@ static int cmd_getsv(int argc, char **argv)
 	pt.lap("junction_stage");
 	ssvh_bam *bam = nullptr;
 	if (ssvh_bam_open(original_bam.c_str(), &bam) != 0) die("[main_samview] fail to open file " + original_bam + "for reading.");
-	ssv_ctx *ctx = acquire_ctx(device);
+	ssv_ctx *ctx = nullptr;
+	auto get_ctx = [&] { if (!ctx) ctx = acquire_ctx(device); return ctx; }; // (main() started it before the junction stage)
 
-	pt.lap("open+gpu_init");
 	int mean_insert_size = 0, deviation = 0;
 	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
 	IsizeCarry carry;
 	if (do_discordant) {
-		insert_size_pass(ctx, original_bam, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation, n_ranks == 1 ? &carry : nullptr);
+		insert_size_pass(get_ctx, original_bam, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation, n_ranks == 1 ? &carry : nullptr);
 		cerr << "'CalculateInsertsizeDeviation' finished" << endl;
 	} else min_abnormal_read_pair_no = 0; // seeksv.cpp:285
+	get_ctx();
 
-	pt.lap("isize_pass");
+	pt.lap("isize_pass (+ what was left of the context's start-up)");
 	// ---- the fused BAM pass: discordant tally + depth ----
 	vector<ssvh_junction_in> J;
 	vector<int32_t> prev;
@@ -1405,7 +1462,7 @@ static int cmd_somatic(int argc, char **argv)
 	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
 	pt.lap("gpu_init");
 	int mean_insert_size = 0, deviation = 0;
-	if (read_pair_used >= 100000) insert_size_pass(ctx, normal_bam_file, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation);
+	if (read_pair_used >= 100000) insert_size_pass([ctx] { return ctx; }, normal_bam_file, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation);
 	pt.lap("isize_pass");
 
 	ofstream fout(somatic_file.c_str());
@@ -1781,6 +1838,11 @@ static int cmd_realign(int argc, char **argv)
 	setenv("SSV_BGZF_LEVEL", "-1", 0);
 	if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), lens.data(), (int32_t)names.size(), &b, qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
 	pt.lap("write bam");
+	if (g_resident.ctx && fq == g_resident.fq_path) { // `seeksv run`: getsv's join takes the records from here instead of reading clip.bam back
+		auto &A = g_resident.aln;
+		A.bam_path = out_bam; A.tid.swap(tid); A.pos.swap(pos); A.flag.swap(flag); A.n_cigar.swap(ncig); A.mapq.swap(mapq); A.cigar_off.swap(cig_off); A.cigar.swap(cig); A.qname.swap(qn);
+		A.names = names;
+	}
 	cerr << "[seeksv realign] " << n << " clipped sequences, " << n_aligned << " aligned" << (dropped ? ", " + to_string(dropped) + " repetitive index positions dropped" : string()) << endl;
 	ssv_realign_free(ctx);
 	release_ctx(ctx);
@@ -1865,8 +1927,12 @@ static int cmd_run(int argc, char **argv)
 	return rc;
 }
 
+static double wall_now() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+
 int main(int argc, char **argv)
 {
+	const bool stamp = getenv("SSV_TIMING") != nullptr; // with the caller's own clock around the process: exec -> main, main -> exit, exit -> reaped
+	if (stamp) fprintf(stderr, "[timing] (wall clock at main: %.6f)\n", wall_now());
 	if (argc == 1) usage_top();
 	const string cmd = argv[1];
 	if (cmd != "getclip" && cmd != "getsv" && cmd != "somatic" && cmd != "realign" && cmd != "run") {
@@ -1874,6 +1940,13 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	if (argc == 2) { if (cmd == "getclip") usage_getclip(); else if (cmd == "getsv") usage_getsv(); else if (cmd == "realign") usage_realign(); else if (cmd == "run") usage_run(); else usage_somatic(); }
+	{ // the GPU context starts coming up now (the device: the first number behind a -G)
+		int dev = 0;
+		for (int k = 2; k + 1 < argc; ++k) if (!strcmp(argv[k], "-G")) { dev = atoi(argv[k + 1]); break; }
+		bool gpu_free = false; // getsv -J stops before any BAM pass (a test hook that needs no GPU)
+		for (int k = 2; k < argc; ++k) if (!strcmp(argv[k], "-J")) gpu_free = true;
+		if (!gpu_free && argc > 3) early_ctx_start(dev);
+	}
 	optind = 1; // like SelectStep (seeksv.cpp:444-452): the sub-command becomes argv[0]
 	int rc;
 	if (cmd == "somatic") rc = cmd_somatic(argc - 1, argv + 1);
@@ -1882,5 +1955,6 @@ int main(int argc, char **argv)
 	else rc = cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
 	if (kCleanExit) return rc;
 	cout.flush(); cerr.flush(); fflush(nullptr);
+	if (stamp) { fprintf(stderr, "[timing] (wall clock at exit: %.6f)\n", wall_now()); fflush(stderr); }
 	_exit(rc); // (see release_ctx)
 }

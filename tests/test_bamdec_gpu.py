@@ -248,6 +248,23 @@ def test_resolve_in_lds_mode():
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("mode", ["wave", "lanes16"])
+def test_resolve_modes(mode):
+    """Pass 2 of the inflate has two forms in global memory: a wavefront per BGZF block (k_bgzf_resolve_wave: rounds of 64 tokens, the earlier holes a source
+    touches as a lane range found by binary search, readiness by one AND with the ballot of the open lanes) and 16 lanes per block (k_bgzf_resolve).  Both,
+    forced, through the same device-decode == host-reader checks: every match shape (near, far, overlapping its own hole, 3..258 bytes), every kind of deflate
+    block, records and blocks straddling chunks, damaged input"""
+    import subprocess
+    import sys
+    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_INFLATE") or os.environ.get("SSV_TOKENS"):
+        pytest.skip("already inside a mode run")
+    env = dict(os.environ, SSV_RESOLVE=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes or rejects_damage or longer_than or every_deflate or fuzzed"], env=env,
+                       capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("chunk_bytes", [64 << 20, 1 << 20], ids=["one-chunk", "1MB-chunks"])
 def test_device_decode_record_longer_than_64_blocks(ctx, tmp_path, chunk_bytes):
     """a read of 5.5 M bases = one 8 MB record = ~130 BGZF blocks without a record start in them: the per-block check of the speculated record starts

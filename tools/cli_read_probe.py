@@ -51,10 +51,12 @@ def main():
             for name, cmd in (("getsv", [EXE, "getsv", "-Z", "-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip, os.path.join(d, "o.sv"), os.path.join(d, "o.fq")]),
                               ("getclip", [EXE, "getclip", "-Z", "-o", os.path.join(d, "o"), bam])):
                 for rep in range(2):
-                    t = time.perf_counter()
+                    t, w0 = time.perf_counter(), time.time()
                     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
-                    dt = time.perf_counter() - t
-                    print(f"## {name} {json.dumps(v)} rep {rep}: {dt:.3f} s = {w.n_total / dt / 1e6:.1f} M records/s (rc {r.returncode})", flush=True)
+                    dt, w1 = time.perf_counter() - t, time.time()
+                    stamps = [float(l.split(":")[1].strip(" )")) for l in r.stderr.splitlines() if l.startswith("[timing] (wall clock at")]
+                    where = f"; exec -> main {stamps[0] - w0:.3f} s, main -> exit {stamps[1] - stamps[0]:.3f} s, exit -> reaped {w1 - stamps[1]:.3f} s" if len(stamps) == 2 else ""
+                    print(f"## {name} {json.dumps(v)} rep {rep}: {dt:.3f} s = {w.n_total / dt / 1e6:.1f} M records/s (rc {r.returncode}){where}", flush=True)
                     if rep == 1 or r.returncode != 0:
                         print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[timing]") or r.returncode != 0), flush=True)
         rr = os.path.join(ROOT, "tools", "read_rate")
