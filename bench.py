@@ -791,13 +791,17 @@ def cli_path_leg(args, w, bam, d, expect):
     from seeksv_amd import host
     exe = os.path.join(ROOT, "seeksv_amd", "bin", "seeksv")
     env = dict(os.environ, SSV_TIMING="1")
+    env.pop("SSV_BGZF_LEVEL", None)   # (the file leg's own BAM writer: not what the commands write their clip.bam with)
 
     def phases(stderr):
         out = {}
         for line in stderr.splitlines():
             if line.startswith("[timing] "):
-                name, sec, _ = line[9:].rsplit(" ", 2)
-                out[name] = round(float(sec), 3)
+                try:
+                    name, sec, _ = line[9:].rsplit(" ", 2)
+                    out[name] = round(float(sec), 3)
+                except ValueError:
+                    pass
         return out
     jfile = os.path.join(d, "junctions.txt")
     with open(jfile, "w") as f:

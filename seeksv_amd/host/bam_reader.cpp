@@ -439,6 +439,7 @@ struct ssvh_bam {
 	size_t map_len = 0;
 	int map_turn = 0;
 	std::vector<uint8_t> rec;
+	uint32_t small_cigar[8];
 	std::vector<size_t> found; // located, not yet handed out record offsets in z.ubuf
 	size_t found_pos = 0, chain_cur = 0;
 	std::vector<Segment> segs;
@@ -962,12 +963,19 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 	if (b->ra_thread.joinable()) { g_err = "a read-ahead is in flight: record-at-a-time reads cannot be mixed in"; return -1; }
 	b->found.clear(); b->found_pos = 0; // record-at-a-time reads continue at z.upos; read_batch re-derives its chain from there
 	int32_t block_size;
-	size_t got = b->z.read(&block_size, 4);
-	if (got == 0) return g_err.empty() ? 0 : -1;
-	if (got != 4 || block_size < 32) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
-	b->rec.resize((size_t)block_size + 4);
-	if (b->z.read(b->rec.data(), (size_t)block_size) != (size_t)block_size) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
-	const uint8_t *r = b->rec.data();
+	const uint8_t *r;
+	if (b->z.ulen - b->z.upos >= 4 && (memcpy(&block_size, b->z.ubuf.data() + b->z.upos, 4), block_size >= 32) && b->z.ulen - b->z.upos - 4 >= (size_t)block_size) {
+		// the whole record lies in the inflated window (all but one in a few thousand do): handed out where it lies, valid until the next call
+		r = b->z.ubuf.data() + b->z.upos + 4;
+		b->z.upos += 4 + (size_t)block_size;
+	} else {
+		size_t got = b->z.read(&block_size, 4);
+		if (got == 0) return g_err.empty() ? 0 : -1;
+		if (got != 4 || block_size < 32) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
+		b->rec.resize((size_t)block_size + 4);
+		if (b->z.read(b->rec.data(), (size_t)block_size) != (size_t)block_size) { if (g_err.empty()) g_err = "truncated BAM record"; return -1; }
+		r = b->rec.data();
+	}
 	memcpy(&out->tid, r, 4); memcpy(&out->pos, r + 4, 4);
 	const uint8_t l_read_name = r[8];
 	out->mapq = r[9];
@@ -975,9 +983,14 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 	const size_t o_cig = 32 + (size_t)l_read_name, o_seq = o_cig + 4 * (size_t)out->n_cigar, o_qual = o_seq + ((size_t)out->l_qseq + 1) / 2;
 	if (out->l_qseq < 0 || o_qual + (size_t)out->l_qseq > (size_t)block_size) { g_err = "corrupt BAM record"; return -1; }
 	out->qname = (const char *)r + 32;
-	b->buf[0].cigar.assign((size_t)out->n_cigar, 0); // aligned copy
-	if (out->n_cigar) memcpy(b->buf[0].cigar.data(), r + o_cig, 4 * (size_t)out->n_cigar);
-	out->cigar = b->buf[0].cigar.data();
+	if (out->n_cigar <= 8) { // aligned copy (a few operations: no vector is touched)
+		if (out->n_cigar) memcpy(b->small_cigar, r + o_cig, 4 * (size_t)out->n_cigar);
+		out->cigar = b->small_cigar;
+	} else {
+		b->buf[0].cigar.assign((size_t)out->n_cigar, 0);
+		memcpy(b->buf[0].cigar.data(), r + o_cig, 4 * (size_t)out->n_cigar);
+		out->cigar = b->buf[0].cigar.data();
+	}
 	out->seq = r + o_seq; out->qual = r + o_qual;
 	return 1;
 }

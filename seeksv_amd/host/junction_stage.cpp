@@ -35,6 +35,19 @@ namespace seeksv {
 namespace {
 
 // a piece of text that lives elsewhere (the rows of clip.gz in memory; the stream loop's strings in a store of their own)
+// 64-bit hash of a piece of text.  The join compares every clipped sequence with the name of a re-alignment record - 5.5 M times on a whole-genome
+// sample, nearly always unequal: two hashes (computed where the text is parsed anyway, by all threads) settle that without touching 2.5 GB of text
+// on the one thread the join runs on; equal hashes are confirmed by comparing the text.
+static inline uint64_t text_hash(const char *p, size_t n)
+{
+	uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+	uint64_t w = 0;
+	if (i < n) { memcpy(&w, p + i, n - i); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+	return h * 0xC4CEB9FE1A85EC53ull;
+}
+
 struct Str {
 	const char *p = nullptr; size_t n = 0;
 	std::string str() const { return std::string(p, n); }
@@ -47,6 +60,7 @@ struct Str {
 struct ClipRow {
 	Str chr; int pos = 0; char side = 0; Str cigar;
 	Str aligned_seq, clipped_seq, clipped_qual; int support = 0;
+	uint64_t h = 0; // text_hash(clipped_seq)
 };
 
 struct AlignInfo { // getsv.h:27-44
@@ -65,11 +79,25 @@ struct RecSource {
 	ssvh_bam *bam = nullptr;
 	const AlnRecords *mem = nullptr;
 	int64_t at = 0;
+	std::vector<uint64_t> qhash; // mem: text_hash of every read name (made by all threads before the join starts)
+	uint64_t h = 0;              // ... of the record next() handed out last
+	void hash_names()
+	{
+		if (!mem || mem->n == 0) return;
+		qhash.resize((size_t)mem->n);
+		const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 64, mem->n / 65536 + 1}));
+		std::vector<std::thread> th;
+		for (int w = 0; w < nt; ++w) th.emplace_back([this, w, nt] {
+			for (int64_t i = mem->n * w / nt, e = mem->n * (w + 1) / nt; i < e; ++i) qhash[(size_t)i] = text_hash(mem->qname[i], strlen(mem->qname[i]));
+		});
+		for (auto &t : th) t.join();
+	}
 	int next(ssvh_record *out) // 1: a record, 0: the end, < 0: error (ssvh_last_error)
 	{
-		if (bam) return ssvh_bam_next_record(bam, out);
+		if (bam) { const int rc = ssvh_bam_next_record(bam, out); if (rc == 1) h = text_hash(out->qname, strlen(out->qname)); return rc; }
 		if (at >= mem->n) return 0;
 		const int64_t i = at++;
+		h = qhash[(size_t)i];
 		out->tid = mem->tid[i]; out->pos = mem->pos[i]; out->flag = mem->flag[i]; out->mapq = mem->mapq[i]; out->n_cigar = mem->n_cigar[i];
 		out->cigar = mem->cigar + mem->cigar_off[i]; out->qname = mem->qname[i];
 		out->l_qseq = 0; out->seq = nullptr; out->qual = nullptr;
@@ -395,6 +423,7 @@ static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows
 				row.chr = Str{tok[0], len[0]}; row.side = tok[2][0];
 				row.cigar = Str{tok[3], len[3]};
 				row.aligned_seq = Str{tok[4], len[4]}; row.clipped_seq = Str{tok[6], len[6]}; row.clipped_qual = Str{tok[7], len[7]};
+				row.h = text_hash(tok[6], len[6]);
 				out.push_back(row);
 			} else if (nf != 0) { good = false; break; }
 			p = eol < end ? eol + 1 : end;
@@ -409,20 +438,29 @@ static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows
 	return true;
 }
 
-static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o);
-std::string assemble_junctions_text(const std::string &text, const std::string &clip_bam, JunctionMap &j2o) { return assemble_junctions_view(TextView{text.data(), text.size()}, clip_bam, nullptr, j2o); }
-std::string assemble_junctions_records(const std::string &text, const AlnRecords &aln, JunctionMap &j2o) { return assemble_junctions_view(TextView{text.data(), text.size()}, "", &aln, j2o); }
+static std::string assemble_junctions_view(const std::vector<TextView> &texts, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o);
+static std::vector<TextView> views_of(const std::vector<std::string> &pieces)
+{
+	std::vector<TextView> v;
+	for (const std::string &p : pieces) v.push_back(TextView{p.data(), p.size()});
+	return v;
+}
+std::string assemble_junctions_text(const std::vector<std::string> &text, const std::string &clip_bam, JunctionMap &j2o) { return assemble_junctions_view(views_of(text), clip_bam, nullptr, j2o); }
+std::string assemble_junctions_records(const std::vector<std::string> &text, const AlnRecords &aln, JunctionMap &j2o) { return assemble_junctions_view(views_of(text), "", &aln, j2o); }
 
-static std::string assemble_junctions_view(const TextView &text, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o)
+// texts: the rows in file order, every piece whole rows
+static std::string assemble_junctions_view(const std::vector<TextView> &texts, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o)
 {
 	RecSource source;
 	source.mem = mem;
 	if (!mem && ssvh_bam_open(clip_bam.c_str(), &source.bam) != 0) return "[main_samview] fail to open file for reading.";
+	source.hash_names();
 	RecSource *const bam = &source;
 	struct Closer { RecSource *s; ~Closer() { if (s->bam) ssvh_bam_close(s->bam); } } closer{bam};
 	std::vector<ClipRow> rows; // the rows that share `current` (the reference's multimap is cleared at every group change)
 	AlignMap aligns;
 	Str current;               // last_clipped_seq (a view: the rows' text outlives the join)
+	uint64_t cur_h = 0;        // its hash
 	ssvh_record rec;
 	std::string failure;
 	// An alignment enters the group's map under (name, (chr, pos)).  An UNALIGNED record (flag 4: type 'n', "Exogenous" / -1) makes no junction
@@ -437,16 +475,16 @@ static std::string assemble_junctions_view(const TextView &text, const std::stri
 	};
 	// one row of clip.gz, in file order (false: clip.bam could not be read)
 	auto on_row = [&](ClipRow &row) -> bool {
-		if (current.n == 0 || current == row.clipped_seq) { current = row.clipped_seq; rows.push_back(row); return true; }
+		if (current.n == 0 || (cur_h == row.h && current == row.clipped_seq)) { current = row.clipped_seq; cur_h = row.h; rows.push_back(row); return true; }
 		// a new clipped sequence: consume the alignments of the current group
 		int rc;
 		while ((rc = bam->next(&rec)) == 1) {
 			if (is_hard_clip(rec)) continue;
-			if (current.equals(rec.qname)) { file_under(current); continue; }
+			if (cur_h == bam->h && current.equals(rec.qname)) { file_under(current); continue; }
 			flush_group(rows, aligns, j2o);
 			rows.clear(); aligns.clear();
 			file_under(current); // filed under the OLD name
-			current = row.clipped_seq;
+			current = row.clipped_seq; cur_h = row.h;
 			rows.push_back(row);
 			break;
 		}
@@ -455,30 +493,39 @@ static std::string assemble_junctions_view(const TextView &text, const std::stri
 		return true;
 	};
 	std::vector<ClipRow> parsed;
+	std::deque<std::string> store; // (the rows are views: what the stream loop below extracts lives here until the join is over - the last group is flushed at the end)
 	const bool timing = getenv("SSV_TIMING") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
-	if (parse_rows_parallel(text, parsed)) {
+	bool all_parsed = true;
+	for (const TextView &text : texts) { // (pieces one after the other, each by all threads: the rows stay in file order)
+		std::vector<ClipRow> part;
+		if (!parse_rows_parallel(text, part)) { all_parsed = false; break; }
+		if (parsed.empty()) parsed.swap(part); else parsed.insert(parsed.end(), part.begin(), part.end());
+	}
+	if (all_parsed) {
 		const auto t1 = std::chrono::steady_clock::now();
 		for (auto &row : parsed) if (!on_row(row)) return failure;
 		if (timing) std::cerr << "[timing] (junction stage: " << parsed.size() << " rows parsed in " << std::chrono::duration<double>(t1 - t0).count() << " s, joined with clip.bam in "
 		                      << std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() << " s)" << std::endl;
 		std::vector<ClipRow>().swap(parsed);
 	} else {
-		std::istringstream fin(std::string(text.data(), text.size()));
+		std::string whole;
+		for (const TextView &text : texts) whole.append(text.data(), text.size());
+		std::istringstream fin(whole);
 		std::string chr, cigar, aligned_seq, aligned_qual, clipped_seq, clipped_qual, rest;
-		std::deque<std::string> store; // (the rows are views: what the stream extracts lives here until the join is over)
 		auto keep = [&](const std::string &v) { store.push_back(v); return Str{store.back().data(), store.back().size()}; };
 		while (fin >> chr) {
 			ClipRow row;
 			fin >> row.pos >> row.side >> cigar >> aligned_seq >> aligned_qual >> clipped_seq >> clipped_qual >> row.support;
 			std::getline(fin, rest);
 			row.chr = keep(chr); row.cigar = keep(cigar); row.aligned_seq = keep(aligned_seq); row.clipped_seq = keep(clipped_seq); row.clipped_qual = keep(clipped_qual);
+			row.h = text_hash(row.clipped_seq.p, row.clipped_seq.n);
 			if (!on_row(row)) return failure;
 		}
 	}
 	int rc;
 	while ((rc = bam->next(&rec)) == 1) { // tail: no hard-clip test here
-		if (current.equals(rec.qname)) file_under(current);
+		if (cur_h == bam->h && current.equals(rec.qname)) file_under(current);
 		else break;
 	}
 	flush_group(rows, aligns, j2o);
@@ -500,7 +547,7 @@ std::string assemble_junctions(const std::string &clipfile, const std::string &c
 		view = TextView{text.data(), text.size()};
 	}
 	if (getenv("SSV_TIMING")) std::cerr << "[timing] (junction stage: " << view.size() << " bytes of rows read in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s)" << std::endl;
-	return assemble_junctions_view(view, clip_bam, nullptr, j2o);
+	return assemble_junctions_view(std::vector<TextView>(1, view), clip_bam, nullptr, j2o);
 }
 
 void merge_junctions(JunctionMap &j2o, int search_length)

@@ -37,7 +37,7 @@ void reverse_complement(std::string &seq);       // GetReverseComplementSeq, cli
 
 // InputSoftInfoStoreBreakpoint (getsv.h:423-541) + GetAlignInfo (getsv.cpp:25) + GetJunction (getsv.cpp:1705).  Returns "" or an error text.
 std::string assemble_junctions(const std::string &clipfile, const std::string &clip_bam, JunctionMap &junction2other);
-std::string assemble_junctions_text(const std::string &clip_rows, const std::string &clip_bam, JunctionMap &junction2other); // the rows of clip.gz in memory
+std::string assemble_junctions_text(const std::vector<std::string> &clip_rows, const std::string &clip_bam, JunctionMap &junction2other); // the rows of clip.gz in memory, in pieces of whole rows
 // ... and the re-alignments too (`seeksv run`: the aligner step has just made them): what ssvh_bam_next_record would hand out for clip.bam, record by
 // record in its order - only the fields GetAlignInfo looks at (getsv.cpp:25-71)
 struct AlnRecords {
@@ -49,7 +49,7 @@ struct AlnRecords {
 	const char *const *qname = nullptr;
 	std::vector<std::string> target_names;
 };
-std::string assemble_junctions_records(const std::string &clip_rows, const AlnRecords &aln, JunctionMap &junction2other);
+std::string assemble_junctions_records(const std::vector<std::string> &clip_rows, const AlnRecords &aln, JunctionMap &junction2other);
 // MergeJunction, getsv.cpp:1325-1482
 void merge_junctions(JunctionMap &junction2other, int search_length);
 

@@ -235,7 +235,8 @@ struct ResidentBam {
 	vector<ssv_batch_t> batches; // in file order
 	// what getclip wrote, still in memory for the steps that follow (the files are written all the same: they are outputs)
 	string clip_path, fq_path;   // prefix.clip.gz, prefix.clip.fq.gz
-	string clip_rows, fq_text;   // their decompressed contents
+	vector<string> clip_rows, fq_text; // their decompressed contents, in the pieces the formatting threads made (whole rows / whole records each; never glued
+	                                   // together: appending 2.5 GB to one string on one thread was a second of `seeksv run`)
 	// what the aligner step made of fq_text (clip.bam is written all the same); the read names point into fq_text
 	struct Aligned {
 		string bam_path;
@@ -828,8 +829,8 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 			softfout.write_parts(rows); fqfout.write_parts(fqs);
 			if (g_resident.collect && g_resident.ctx == ctx) { // `seeksv run`: the aligner step and the junction stage read these from memory
 				g_resident.clip_path = f_clip; g_resident.fq_path = f_fq;
-				for (auto &r : rows) g_resident.clip_rows += r;
-				for (auto &r : fqs) g_resident.fq_text += r;
+				for (auto &r : rows) if (!r.empty()) g_resident.clip_rows.push_back(std::move(r));
+				for (auto &r : fqs) if (!r.empty()) g_resident.fq_text.push_back(std::move(r));
 			}
 			emit_format_s += std::chrono::duration<double>(t1 - t0).count();
 			emit_gzip_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
@@ -1722,11 +1723,11 @@ static int cmd_realign(int argc, char **argv)
 	//      cut into lines in place (the newline behind a line becomes its terminator: the sequences are the read names of the BAM records below) ----
 	struct Line { char *p; int n; };
 	vector<Line> seqs, quals;
-	string own_text;
-	{
-		string *t = &own_text;
-		if (g_resident.ctx && fq == g_resident.fq_path) t = &g_resident.fq_text;
-		else { const string err = seeksv::slurp_gz(fq, own_text); if (!err.empty()) die("Cannot open clipped reads file " + fq); }
+	vector<string> own_text(1);
+	const bool fq_resident = g_resident.ctx && fq == g_resident.fq_path;
+	if (!fq_resident) { const string err = seeksv::slurp_gz(fq, own_text[0]); if (!err.empty()) die("Cannot open clipped reads file " + fq); }
+	for (string &piece : fq_resident ? g_resident.fq_text : own_text) { // (a piece holds whole records)
+		string *t = &piece;
 		char *base = t->empty() ? nullptr : &(*t)[0];
 		const size_t size = t->size();
 		size_t at = 0;
@@ -1932,7 +1933,7 @@ static double wall_now() { return std::chrono::duration<double>(std::chrono::sys
 int main(int argc, char **argv)
 {
 	const bool stamp = getenv("SSV_TIMING") != nullptr; // with the caller's own clock around the process: exec -> main, main -> exit, exit -> reaped
-	if (stamp) fprintf(stderr, "[timing] (wall clock at main: %.6f)\n", wall_now());
+	if (stamp) fprintf(stderr, "[stamp] wall clock at main: %.6f\n", wall_now());
 	if (argc == 1) usage_top();
 	const string cmd = argv[1];
 	if (cmd != "getclip" && cmd != "getsv" && cmd != "somatic" && cmd != "realign" && cmd != "run") {
@@ -1955,6 +1956,6 @@ int main(int argc, char **argv)
 	else rc = cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
 	if (kCleanExit) return rc;
 	cout.flush(); cerr.flush(); fflush(nullptr);
-	if (stamp) { fprintf(stderr, "[timing] (wall clock at exit: %.6f)\n", wall_now()); fflush(stderr); }
+	if (stamp) { fprintf(stderr, "[stamp] wall clock at exit: %.6f\n", wall_now()); fflush(stderr); }
 	_exit(rc); // (see release_ctx)
 }

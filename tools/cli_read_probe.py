@@ -54,7 +54,7 @@ def main():
                     t, w0 = time.perf_counter(), time.time()
                     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
                     dt, w1 = time.perf_counter() - t, time.time()
-                    stamps = [float(l.split(":")[1].strip(" )")) for l in r.stderr.splitlines() if l.startswith("[timing] (wall clock at")]
+                    stamps = [float(l.split(":")[1]) for l in r.stderr.splitlines() if l.startswith("[stamp] wall clock at")]
                     where = f"; exec -> main {stamps[0] - w0:.3f} s, main -> exit {stamps[1] - stamps[0]:.3f} s, exit -> reaped {w1 - stamps[1]:.3f} s" if len(stamps) == 2 else ""
                     print(f"## {name} {json.dumps(v)} rep {rep}: {dt:.3f} s = {w.n_total / dt / 1e6:.1f} M records/s (rc {r.returncode}){where}", flush=True)
                     if rep == 1 or r.returncode != 0:

@@ -28,8 +28,11 @@ def phases(stderr):
     out = {}
     for line in stderr.splitlines():
         if line.startswith("[timing] "):
-            name, sec, _ = line[9:].rsplit(" ", 2)
-            out[name] = round(out.get(name, 0.0) + float(sec), 3)
+            try:
+                name, sec, _ = line[9:].rsplit(" ", 2)
+                out[name] = round(out.get(name, 0.0) + float(sec), 3)
+            except ValueError:
+                pass
     return out
 
 
@@ -68,6 +71,7 @@ def main():
         host.write_bam(empty_bam, w.names, w.lens, [])
         open(empty_clip, "w").close()
         env = dict(os.environ, SSV_TIMING="1")
+        env.pop("SSV_BGZF_LEVEL", None)   # (this tool's own BAM writer: not what the commands write their clip.bam with)
 
         def timed(cmd):
             t = time.perf_counter()
@@ -89,6 +93,7 @@ def main():
         for rep in range(2):
             t, r = timed([EXE, "run", bam, fa, os.path.join(d, "one")])
             cur = dict(total_s=t, phases_s=phases(r.stderr), realign=[l for l in r.stderr.splitlines() if l.startswith("[seeksv realign]")][-1:])
+            run_stdout = r.stdout
             if best is None or cur["total_s"] < best["total_s"]:
                 best = cur
         best["records_per_s"] = round(w.n_total / best["total_s"])
@@ -112,6 +117,23 @@ def main():
         found = {(c[0], int(c[1]), c[2], c[4], int(c[5]), c[6]) for c in rows}
         planted = {tuple(j[:6]) for j in w.junctions}
         out["run"]["sv_rows"], out["run"]["planted"], out["run"]["planted_found"] = len(rows), len(planted), len(planted & found)
+        # a planted junction that is not in the table: was it filtered (getsv prints those on stdout with the reason, getsv.cpp:1848-1852), did it come out a
+        # few bases off (a microhomology shift, or merged into a neighbour: MergeJunction), or was it never assembled (no clipped read re-aligned there)?
+        missing = []
+        for j in sorted(planted - found):
+            why = None
+            for line in run_stdout.splitlines():
+                c = line.split("\t")
+                if len(c) >= 8 and c[1] == j[0] and c[5] == j[3] and c[3] == j[2] and c[7] == j[5] and abs(int(c[2]) - j[1]) <= 60 and abs(int(c[6]) - j[4]) <= 60:
+                    why = f"filtered: {c[0]} (as {c[1]}:{c[2]}{c[3]} -> {c[5]}:{c[6]}{c[7]}, clip reads {c[4]}+{c[8]}, abnormal pairs {c[10] if len(c) > 10 else '?'})"
+                    break
+            if why is None:
+                near = [c for c in rows if c[0] == j[0] and c[4] == j[3] and c[2] == j[2] and c[6] == j[5] and abs(int(c[1]) - j[1]) <= 60 and abs(int(c[5]) - j[4]) <= 60]
+                if near:
+                    c = near[0]
+                    why = f"in the table {int(c[1]) - j[1]:+d} / {int(c[5]) - j[4]:+d} bases off, as {c[0]}:{c[1]}{c[2]} -> {c[4]}:{c[5]}{c[6]} (microhomology {c[8]})"
+            missing.append({"planted": list(j), "found_as": why or "not assembled: no row and no filtered line within 60 bases of it"})
+        out["run"]["planted_missing"] = missing
         out["outputs_bytes"] = {n: os.path.getsize(os.path.join(d, n)) for n in ("one.clip.gz", "one.clip.fq.gz", "one.clip.bam", "one.sv.txt")}
         out["clip_outputs_identical"] = True
     finally:
