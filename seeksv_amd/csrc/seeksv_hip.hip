@@ -211,11 +211,6 @@ struct ssv_ctx {
 	struct ssv_realign_state *ra = nullptr;
 	HBuf h_batch;
 
-	// ---- ssv_batch_retain: the next slab is allocated beside the caller's work (hipMalloc maps ~20 ms per GB, and a whole-genome sample is 80 slabs of 0.6 GB) ----
-	std::thread slab_thread;
-	void *slab_next = nullptr;
-	size_t slab_next_bytes = 0;
-
 	// ---- profiling ----
 	int prof_mode = 0;
 	std::vector<ProfRec> prof_recs;
@@ -527,8 +522,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->st);
-	if (c->slab_thread.joinable()) c->slab_thread.join();
-	if (c->slab_next) (void)hipFree(c->slab_next);
+
 	bamdec_free(c);
 	realign_free(c);
 	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
@@ -797,23 +791,10 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 		memcpy(runs, b->tid_runs, (size_t)b->n_tid_runs * sizeof(ssv_tid_run));
 	}
 	struct Guard { uint8_t *&slab; ssv_tid_run *&runs; bool keep = false; ~Guard() { if (!keep) { if (slab) (void)hipFree(slab); free(runs); } } } guard{slab, runs};
-	// the slab: the one a helper thread allocated while the caller decoded this batch, if it is large enough; then the helper goes for the next one
-	// (same size: the batches of a file are chunks of one size)
-	if (c->slab_thread.joinable()) c->slab_thread.join();
-	if (c->slab_next && c->slab_next_bytes >= off[7]) { slab = static_cast<uint8_t *>(c->slab_next); c->slab_next = nullptr; }
-	else {
-		if (c->slab_next) { (void)hipFree(c->slab_next); c->slab_next = nullptr; }
-		HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&slab), off[7]));
-	}
-	{
-		static const bool ahead = getenv("SSV_RETAIN_AHEAD") == nullptr || atoi(getenv("SSV_RETAIN_AHEAD")) != 0;
-		const size_t want = off[7];
-		if (ahead && want >= ((size_t)64 << 20)) c->slab_thread = std::thread([c, want] {
-			void *p = nullptr;
-			if (hipSetDevice(c->device) == hipSuccess && hipMalloc(&p, want) == hipSuccess) { c->slab_next = p; c->slab_next_bytes = want; }
-			else (void)hipGetLastError();
-		});
-	}
+	static const bool timing = getenv("SSV_TIMING_CHUNKS") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&slab), off[7])); // (0.2 ms for 8 GB, tools/malloc_rate.cpp: nothing to hide)
+	const auto t1 = std::chrono::steady_clock::now();
 	const void *src[7] = {d.tid, d.pos, d.n_cigar, d.ends, d.rec, d.cigar, d.seqqual};
 	const size_t bytes[7] = {n * 4, n * 4, n * 2, n, n * sizeof(ssv_record), (size_t)b->n_cigar_total * 4, (size_t)b->seqqual_bytes};
 	if (!d.ends && n) { // no cigar_ends column: built from the lines, straight into the slab
@@ -822,6 +803,8 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 	}
 	for (int k = 0; k < 7; ++k) if (src[k] && bytes[k]) HIPCHECK(c, hipMemcpyAsync(slab + off[k], src[k], bytes[k], hipMemcpyDeviceToDevice, c->st));
 	HIPCHECK(c, hipStreamSynchronize(c->st)); // the source (the decoder's buffers) may be overwritten by the next decode
+	if (timing) fprintf(stderr, "[timing] (retain: %lld records, %zu bytes: hipMalloc %.4f s, copies + wait %.4f s)\n", (long long)b->n, off[7], std::chrono::duration<double>(t1 - t0).count(),
+	                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
 	guard.keep = true;
 	memset(out, 0, sizeof(*out));
 	out->n = b->n; out->mem = SSV_MEM_DEVICE | SSV_MEM_PERSISTENT; out->max_ref_span = b->max_ref_span;

@@ -373,20 +373,31 @@ struct TextView { // (just enough of std::string for the parser)
 	size_t find(char c, size_t from) const { const void *q = from < n ? memchr(p + from, c, n - from) : nullptr; return q ? (size_t)(static_cast<const char *>(q) - p) : std::string::npos; }
 };
 
-static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows)
+// texts: pieces of whole rows, in file order
+static bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow> &rows)
 {
 	static const bool off = getenv("SSV_ROWS_SERIAL") != nullptr;
 	if (off) return false;
 	static const size_t per_thread = [] { const char *e = getenv("SSV_ROWS_CHUNK_KB"); const long kb = e ? atol(e) : 64; return (size_t)(kb < 1 ? 1 : kb) << 10; }(); // (tests: several threads on little text)
-	const int nt = (int)std::max<size_t>(1, std::min<size_t>({(size_t)ssv::effective_cpus(), (size_t)64, text.size() / per_thread + 1}));
-	std::vector<std::vector<ClipRow>> part((size_t)nt);
-	std::vector<size_t> cut((size_t)nt + 1, text.size());
-	cut[0] = 0;
-	for (int w = 1; w < nt; ++w) {
-		const size_t guess = text.size() * (size_t)w / (size_t)nt;
-		const size_t nl = text.find('\n', std::max(guess, cut[(size_t)w - 1]));
-		cut[(size_t)w] = nl == std::string::npos ? text.size() : nl + 1;
+	size_t total_bytes = 0;
+	for (const TextView &t : texts) total_bytes += t.size();
+	const int nt = (int)std::max<size_t>(1, std::min<size_t>({(size_t)ssv::effective_cpus(), (size_t)64, total_bytes / per_thread + 1}));
+	// segments of whole lines, a few per thread, handed out in turn; their rows are put together in segment order
+	const size_t seg_bytes = std::max(per_thread, total_bytes / ((size_t)nt * 4) + 1);
+	struct Seg { const char *p, *end; };
+	std::vector<Seg> segs;
+	for (const TextView &text : texts) {
+		size_t at = 0;
+		while (at < text.size()) {
+			size_t stop = at + seg_bytes;
+			if (stop >= text.size()) stop = text.size();
+			else { const size_t nl = text.find('\n', stop); stop = nl == std::string::npos ? text.size() : nl + 1; }
+			segs.push_back(Seg{text.data() + at, text.data() + stop});
+			at = stop;
+		}
 	}
+	std::vector<std::vector<ClipRow>> part(segs.size());
+	std::atomic<size_t> next_seg{0};
 	std::atomic<bool> good{true};
 	auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
 	auto to_int = [](const char *p, size_t n, int &v) -> bool { // what operator>>(int&) takes from a token that is nothing but [+-]digits
@@ -402,9 +413,11 @@ static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows
 		return true;
 	};
 	std::vector<std::thread> th;
-	for (int w = 0; w < nt; ++w) th.emplace_back([&, w] {
-		std::vector<ClipRow> &out = part[(size_t)w];
-		const char *p = text.data() + cut[(size_t)w], *end = text.data() + cut[(size_t)w + 1];
+	for (int w = 0; w < nt; ++w) th.emplace_back([&] {
+	  for (size_t sg; good && (sg = next_seg.fetch_add(1)) < segs.size();) {
+		std::vector<ClipRow> &out = part[sg];
+		const char *p = segs[sg].p, *end = segs[sg].end;
+		out.reserve((size_t)(end - p) / 160 + 16); // (a row of getclip's is 300-500 bytes: no growing - a growing vector of this size is mapped, copied and unmapped again and again, under the address-space lock all threads share)
 		while (p < end && good) {
 			const char *eol = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
 			if (!eol) eol = end;
@@ -428,6 +441,7 @@ static bool parse_rows_parallel(const TextView &text, std::vector<ClipRow> &rows
 			} else if (nf != 0) { good = false; break; }
 			p = eol < end ? eol + 1 : end;
 		}
+	  }
 	});
 	for (auto &t : th) t.join();
 	if (!good) return false;
@@ -496,13 +510,7 @@ static std::string assemble_junctions_view(const std::vector<TextView> &texts, c
 	std::deque<std::string> store; // (the rows are views: what the stream loop below extracts lives here until the join is over - the last group is flushed at the end)
 	const bool timing = getenv("SSV_TIMING") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
-	bool all_parsed = true;
-	for (const TextView &text : texts) { // (pieces one after the other, each by all threads: the rows stay in file order)
-		std::vector<ClipRow> part;
-		if (!parse_rows_parallel(text, part)) { all_parsed = false; break; }
-		if (parsed.empty()) parsed.swap(part); else parsed.insert(parsed.end(), part.begin(), part.end());
-	}
-	if (all_parsed) {
+	if (parse_rows_parallel(texts, parsed)) {
 		const auto t1 = std::chrono::steady_clock::now();
 		for (auto &row : parsed) if (!on_row(row)) return failure;
 		if (timing) std::cerr << "[timing] (junction stage: " << parsed.size() << " rows parsed in " << std::chrono::duration<double>(t1 - t0).count() << " s, joined with clip.bam in "

@@ -315,7 +315,6 @@ struct StageBuf {
 		const size_t n = (want + page() - 1) & ~(page() - 1);
 		void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
 		if (m == MAP_FAILED) return false;
-		(void)madvise(m, n, MADV_HUGEPAGE); // (2 MB pages where the kernel grants them: 512 x fewer faults while the first fill populates the buffer)
 		p = static_cast<uint8_t *>(m); cap = n;
 		return true;
 	}
@@ -1561,6 +1560,9 @@ static bool gz_getline(gzFile f, string &line)
 // a running sum gives each piece its first base index, then the pieces write their 2-bit codes (the words that two pieces share are OR-ed
 // in atomically).  One thread parsing character by character took 2.8 s for an eighth of a human genome.  Same result as the serial loop
 // (anything but ACGT becomes the same position-dependent pseudo-random base).  false: not a plain file (the caller reads it through zlib).
+// base character -> 2-bit code, 4 for anything that is not A, C, G or T (either case)
+static const struct BaseCode { uint8_t v[256]; BaseCode() { memset(v, 4, sizeof(v)); v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } uint8_t operator[](unsigned char c) const { return v[c]; } } kBaseCode;
+
 static bool parse_fasta_parallel(const string &path, vector<string> &names, vector<int32_t> &lens, vector<int64_t> &offs, vector<uint64_t> &words)
 {
 	int fd = ::open(path.c_str(), O_RDONLY);
@@ -1632,15 +1634,11 @@ static bool parse_fasta_parallel(const string &path, vector<string> &names, vect
 			if (t[p] != '>') {
 				size_t stop = e;
 				if (stop > p && t[stop - 1] == '\r') --stop;
+				// (a table look-up per base: a switch on random bases is a mispredicted branch for three bases in four - 12 cycles a base, 14 CPU-seconds
+				// for a human genome, beside getclip on the same 16 CPUs in `seeksv run`)
 				for (size_t i = p; i < stop; ++i, ++n) {
-					uint64_t two;
-					switch (t[i]) {
-					case 'A': case 'a': two = 0; break;
-					case 'C': case 'c': two = 1; break;
-					case 'G': case 'g': two = 2; break;
-					case 'T': case 't': two = 3; break;
-					default: { uint64_t h = (uint64_t)n * 0x9E3779B97F4A7C15ull; two = (h >> 61) & 3; }
-					}
+					uint64_t two = kBaseCode[(unsigned char)t[i]];
+					if (two > 3) { const uint64_t h = (uint64_t)n * 0x9E3779B97F4A7C15ull; two = (h >> 61) & 3; }
 					cur |= two << (2 * (n & 31));
 					if ((n & 31) == 31) flush(n / 32);
 				}

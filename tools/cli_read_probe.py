@@ -59,7 +59,20 @@ def main():
                     print(f"## {name} {json.dumps(v)} rep {rep}: {dt:.3f} s = {w.n_total / dt / 1e6:.1f} M records/s (rc {r.returncode}){where}", flush=True)
                     if rep == 1 or r.returncode != 0:
                         print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[timing]") or r.returncode != 0), flush=True)
+        if os.environ.get("PROBE_RUN"):   # `seeksv run` on the same file: per-chunk retain timing, phases
+            fa = os.path.join(d, "ref.fa")
+            w.write_fasta(fa, cores)
+            env = dict(os.environ, SSV_TIMING="1", SSV_TIMING_CHUNKS="1")
+            env.pop("SSV_BGZF_LEVEL", None)
+            for rep in range(2):
+                t = time.perf_counter()
+                r = subprocess.run([EXE, "run", bam, fa, os.path.join(d, "one")], capture_output=True, text=True, env=env)
+                print(f"## run rep {rep}: {time.perf_counter() - t:.3f} s = {w.n_total / (time.perf_counter() - t) / 1e6:.1f} M records/s (rc {r.returncode})", flush=True)
+                if rep == 1 or r.returncode != 0:
+                    print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[timing]") or r.returncode != 0), flush=True)
         rr = os.path.join(ROOT, "tools", "read_rate")
+        if os.environ.get("PROBE_NO_READ_RATE"):
+            rr = ""
         if os.path.exists(rr):
             print(subprocess.run([rr, "8", "/dev/shm", bam], capture_output=True, text=True).stdout, flush=True)
     finally:
