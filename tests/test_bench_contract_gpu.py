@@ -46,6 +46,24 @@ def test_bench_line_contract():
     assert (rf["traffic"] is None) == rf["traffic_source"].startswith("none")
 
 
+def test_bench_under_torchrun_with_one_rank_is_the_plain_line():
+    """the driver's scaling run starts N = 1 through torch.distributed.run too: same footing as the plain `python bench.py` line (same workload, same legs
+    beside the headline, same counts) - SCALE's N = 1 must agree with BENCH"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    common = ["--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "2", "--warmup", "1", "--cpu-sample", "200000", "--ref-sample", "0"]
+    r1 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-800:]
+    a = _line(r1.stdout)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-600:]
+    b = _line(r2.stdout)
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["scaling"] == b["scaling"] and a["config"]["workload"] == b["config"]["workload"]
+    assert a["config"]["records_total"] == b["config"]["records_total"] and a["result"] == b["result"]
+    assert set(a) == set(b) and "file_path" in a and "cpu_baseline" in a
+    assert a["file_path"]["result"] == b["file_path"]["result"]
+
+
 def test_bench_two_ranks_equal_one():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SSV_FORCE_DEVICE="0", SSV_DIST_BACKEND="gloo")
