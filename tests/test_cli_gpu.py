@@ -56,6 +56,22 @@ def test_cli_getclip(tmp_path, sub, bam, prefix, flags, passes):
         assert r.stderr == G.read_text(sub, prefix + ".getclip.stderr")
 
 
+@pytest.mark.parametrize("sub,bam,prefix,flags", [c for c in GETCLIP if c[2] in ("cancer", "stress3", "unsorted", "lone_s2")], ids=lambda v: v if isinstance(v, str) else "")
+def test_cli_getclip_reader_maps_the_file(tmp_path, sub, bam, prefix, flags, inflate_mode, monkeypatch):
+    """SSV_READER=map (-Z only): the chunks are handed to the GPU where they lie in a mapping of the file, their pages page-locked there (ssvh_bam_map_blocks +
+    ssv_host_register) instead of being copied into staging buffers - not the default (slower on the boxes measured), same bytes out; chunks of
+    1 MB so that a file is several chunks from all three mappings"""
+    if inflate_mode != "device-inflate":
+        pytest.skip("the host reader does not read chunks")
+    monkeypatch.setenv("SSV_READER", "map")
+    out = str(tmp_path / "o")
+    r = subprocess.run([SEEKSV, "getclip"] + flags + ["-o", out, os.path.join(G.GOLDEN, sub, bam)], capture_output=True, text=True, env=dict(os.environ, SSV_TIMING_CHUNKS="1"))
+    assert r.returncode == 0, r.stderr
+    assert "page-locked in the mapping" in r.stderr or "copied to staging" in r.stderr   # (a file system the runtime cannot lock falls back to the copy, chunk by chunk)
+    assert gzip.open(out + ".clip.gz", "rt").read() == G.read_text(sub, prefix + ".clip.txt")
+    assert gzip.open(out + ".clip.fq.gz", "rt").read() == G.read_text(sub, prefix + ".clip.fq.txt")
+
+
 GETSV = [("pairs1", "pairs1", []), ("pairs1", "pairs1.q0", ["-q", "0"]), ("pairs1", "pairs1.L50", ["-L", "50"]), ("pairs1", "pairs1.L1", ["-L", "1"]),
          ("pairs2", "pairs2", []), ("pairs3", "pairs3", []), ("eqx", "eqx", []), ("deep", "deep", [])]
 
