@@ -70,10 +70,14 @@ struct PhaseTimer {
 	~PhaseTimer() { if (on) for (auto &n : order) std::cerr << "[timing] " << n << " " << acc[n] << " s" << std::endl; }
 };
 
+// A fatal error: the reference's message and exit status 1.  Reader, emitter and rank threads may be running (and the HIP context coming up on its own
+// thread): the process leaves through _exit - no static destructor pulls a buffer away under a thread that is still copying into it - after everything
+// written so far has been flushed.
 [[noreturn]] static void die(const string &msg)
 {
 	cerr << msg << endl;
-	exit(1);
+	cout.flush(); cerr.flush(); fflush(nullptr);
+	_exit(1);
 }
 
 // The end of a command: every output file is closed by now.  Handing multi-GB device buffers and page-locked staging memory back one
