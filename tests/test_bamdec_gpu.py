@@ -113,6 +113,55 @@ def test_device_decode_equals_host_reader_goldens(ctx, sub, name, keep_all):
     assert druns == _runs_reference(h["flag"], h["tid"])
 
 
+def test_chunks_out_of_a_locked_mapping_of_the_file(ctx, ragged):
+    """The no-copy way in (round 4): ssvh_bam_map_blocks hands a chunk out where it lies in a mapping of the file, the caller page-locks its pages (ssv_host_register:
+    whole pages around it) and gives that pointer to ssv_bamdec_prefetch / ssv_bamdec_decode - the GPU's DMA engines fetch the file out of the page cache.  With
+    ssv_bamdec_expect before the first (small) chunk.  Same batches as the host reader's; chunk sizes of a few blocks so that the three mappings take turns."""
+    import ctypes as C
+    from seeksv_amd import _abi
+    lib, hl = ctx._lib, _abi.host_lib()
+    hl.ssvh_bam_map_blocks.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(_abi.BgzfBlock), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    hb, _ = _host_all(ragged)
+    page = os.sysconf("SC_PAGESIZE")
+    out, locked = [], []
+    with host.BamReader(ragged) as r:
+        first = C.c_uint64()
+        assert hl.ssvh_bam_raw_begin(r.handle, C.byref(first)) == 0
+        ctx._check(lib.ssv_bamdec_begin(ctx._h, len(r.target_names), first.value), "ssv_bamdec_begin")
+        ctx._check(lib.ssv_bamdec_expect(ctx._h, 1 << 20), "ssv_bamdec_expect")
+        blocks = (_abi.BgzfBlock * 64)()
+        sizes = [70_000, 140_000, 200_000]
+        k = 0
+        while True:
+            nb, nbytes, ptr = C.c_int64(), C.c_size_t(), C.c_void_p()
+            assert hl.ssvh_bam_map_blocks(r.handle, sizes[k % 3], 1 << 30, blocks, 64, C.byref(nb), C.byref(ptr), C.byref(nbytes)) == 0, hl.ssvh_last_error()
+            if nb.value == 0:
+                break
+            lo = ptr.value & ~(page - 1)
+            hi = (ptr.value + nbytes.value + page - 1) & ~(page - 1)
+            rc = lib.ssv_host_register(C.c_void_p(lo), hi - lo)
+            if rc == 0:
+                locked.append(lo)
+                if k % 2:   # every other chunk announced first: its bytes travel on the upload stream
+                    ctx._check(lib.ssv_bamdec_prefetch(ctx._h, ptr, nbytes.value), "ssv_bamdec_prefetch")
+            b = _abi.Batch()
+            ctx._check(lib.ssv_bamdec_decode(ctx._h, ptr, nbytes.value, blocks, nb.value, 0, C.byref(b)), "ssv_bamdec_decode")
+            if b.n:
+                out.append(ctx.batch_to_host(b))
+            if rc == 0 and len(locked) > 2:   # (a chunk's pages are let go of once it is decoded; two stay for the overlap of neighbouring page ranges in other mappings)
+                assert lib.ssv_host_unregister(C.c_void_p(locked.pop(0))) == 0
+            k += 1
+        b = _abi.Batch()
+        ctx._check(lib.ssv_bamdec_decode(ctx._h, None, 0, None, 0, 0, C.byref(b)), "ssv_bamdec_decode")
+        for lo in locked:
+            assert lib.ssv_host_unregister(C.c_void_p(lo)) == 0
+    assert k >= 3
+    h, d = _flatten(hb), _flatten(out)
+    for key in KEYS + ("shipped",):
+        assert np.array_equal(h[key], d[key]), key
+    assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"]
+
+
 def test_announced_chunks_equal_copied_chunks(ctx, ragged):
     """ssv_bamdec_prefetch: chunks announced ahead (bytes on the upload stream into one of two device slots) decode to the same batches as
     chunks copied by the decode call itself; announcing more than two, or a chunk that is never decoded, is harmless"""
