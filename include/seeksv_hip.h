@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SSV_ABI_VERSION 6
+#define SSV_ABI_VERSION 7
 
 typedef enum {
 	SSV_OK = 0,
@@ -265,11 +265,16 @@ typedef struct {
 	 *                     [i * base_bits, +base_bits) (bit b of a stream = bit b % 8 of byte b / 8).  base_bits 2: index into "ACGT", and
 	 *                     every base that is something else is listed in base_exc (the stream holds 0 there); base_bits 4 (only when
 	 *                     that list would be too long): index into "=ACMGRSVTWYHKDBN"
-	 *     quality stream  the n qualities the same way at qual_bits each (8: characters), all zero when qual_missing
+	 *     quality stream  the n qualities the same way at qual_bits each (8: characters), all zero when qual_missing.  qual_group k > 1 (v7; alphabets
+	 *                     whose size R is far from a power of two - five values: k = 3, nine to eleven: k = 2, qual_bits = 7): the stream is
+	 *                     ceil(n / k) groups of qual_bits bits, group g at stream bits [g * qual_bits, +qual_bits), holding qualities
+	 *                     g k .. g k + k - 1 as the number i_0 + R i_1 + R^2 i_2 (i_j = index into qual_alphabet; places behind the stream's end: 0),
+	 *                     R = the number of qual_alphabet entries in use (they are characters, so non-zero)
 	 *   base_exc   sorted; cluster << 28 | base index << 4 | index into "=ACMGRSVTWYHKDBN" */
 	int32_t format;            /* the ssv_clip_table_format the table was built with */
 	int32_t base_bits;
-	int32_t len_bytes, support_bytes, ncig_bytes, pad3;
+	int32_t len_bytes, support_bytes, ncig_bytes;
+	int32_t qual_group;        /* format 3: qualities per group of qual_bits bits (1: every quality its own field) */
 	const void *c_len;
 	const void *c_support;
 	const void *c_ncig;
@@ -294,6 +299,8 @@ int ssv_clip_table_format(ssv_ctx *ctx, int format);
 int ssv_clip_table_expand(ssv_ctx *ctx, ssv_cluster_table *t, int32_t n_threads);
 /* Bytes of one cluster's string block in format 3 (n_bases = left_len + right_len). */
 uint64_t ssv_table_block_bytes3(int64_t n_bases, int32_t base_bits, int32_t qual_bits);
+/* The same for a table whose qualities go in groups (ssv_cluster_table.qual_group; 1 = the function above). */
+uint64_t ssv_table_block_bytes3g(int64_t n_bases, int32_t base_bits, int32_t qual_bits, int32_t qual_group);
 /* Bytes of one cluster's string block (a multiple of 4). */
 uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits);
 

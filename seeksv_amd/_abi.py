@@ -116,7 +116,7 @@ class HipClusterTable(C.Structure):
     """ssv_cluster_table as libseeksv_hip.so hands it out: the common part + the sequence format flag"""
     _fields_ = ClusterTable._fields_ + [("seq_packed", C.c_int32), ("qual_bits", C.c_int32), ("qual_alphabet", C.c_uint8 * 16),
                                         ("format", C.c_int32), ("base_bits", C.c_int32), ("len_bytes", C.c_int32), ("support_bytes", C.c_int32), ("ncig_bytes", C.c_int32),
-                                        ("pad3", C.c_int32), ("c_len", C.c_void_p), ("c_support", C.c_void_p), ("c_ncig", C.c_void_p), ("c_flags", C.c_void_p),
+                                        ("qual_group", C.c_int32), ("c_len", C.c_void_p), ("c_support", C.c_void_p), ("c_ncig", C.c_void_p), ("c_flags", C.c_void_p),
                                         ("runs", C.c_void_p), ("n_runs", C.c_int64), ("base_exc", C.c_void_p), ("n_base_exc", C.c_int64), ("str_bytes", C.c_uint64),
                                         ("cigar_ops", C.c_uint64), ("support_sum", C.c_int64)]
 
@@ -312,6 +312,8 @@ def hip_lib():
         lib.ssv_clip_table_expand.argtypes = [V, C.POINTER(HipClusterTable), C.c_int32]
         lib.ssv_table_block_bytes3.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.ssv_table_block_bytes3.restype = C.c_uint64
+        lib.ssv_table_block_bytes3g.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+        lib.ssv_table_block_bytes3g.restype = C.c_uint64
         lib.ssv_clip_cluster_async.argtypes = [V, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.ssv_clip_table_wait.argtypes = [V, C.POINTER(HipClusterTable)]
         lib.ssv_clip_table_wait_prev.argtypes = [V, C.POINTER(HipClusterTable)]

@@ -973,7 +973,10 @@ struct PackArgs {
 	uint64_t *str_off, *cig_off;
 	int packed;               // 1: sequences as 4-bit codes (ssv_cluster_table.seq_packed)
 	int format3, base_bits;   // the compact layout (table3_kernels.h): one base stream + one quality stream per block
-	int qual_bits;            // 8: quality characters; 1, 2, 3, 4: indices into the table's quality alphabet
+	int qual_bits;            // 8: quality characters; 1, 2, 3, 4: indices into the table's quality alphabet (format 3 with qual_group > 1: bits per GROUP)
+	int qual_group;           // format 3: qualities per group (1: every quality its own qual_bits; k > 1: k alphabet indices as digits of one number of qual_bits bits, radix qual_radix)
+	int qual_radix;           // the alphabet's size (the base of a group's number)
+	uint32_t qual_fill;       // phred value of alphabet index 0 in all four bytes (what the look-ups see behind a stream's end)
 	const uint8_t *qlut;      // [256] phred -> index (0xff: not in the alphabet), when qual_bits < 8
 	uint32_t *qual_seen;      // [8] bit set of the phred values met while packing (TRACK launches: which alphabet the table really needs)
 	int *lut_miss;            // raised when a quality outside the alphabet is met (qual_bits < 8)
@@ -983,6 +986,9 @@ struct PackArgs {
 	uint32_t *slow_list;
 	unsigned int *slow_count;
 };
+
+// bits of a format-3 quality stream of n qualities: qual_bits each, or per group of `group` qualities
+__host__ __device__ __forceinline__ uint64_t qual_stream_bits(uint64_t n, uint64_t bits, uint64_t group) { return group > 1 ? ((n + group - 1) / group) * bits : n * bits; }
 
 __host__ __device__ __forceinline__ uint64_t table_block_bytes(uint64_t L, uint64_t R, int packed, uint64_t W)
 {
@@ -1003,7 +1009,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_meta(PackArgs p)
 		const uint4 eb = ep[1], ec = ep[2];
 		const int ll = single ? (int)eb.w : p.c.c_ll[j], lr = single ? (int)ec.x : p.c.c_lr[j];
 		cnt = 1ull | ((uint64_t)ec.z << 32);
-		bytes = p.format3 ? 4ull * (((uint64_t)(ll + lr) * (uint64_t)p.base_bits + 31) / 32 + ((uint64_t)(ll + lr) * (uint64_t)p.qual_bits + 31) / 32)
+		bytes = p.format3 ? 4ull * (((uint64_t)(ll + lr) * (uint64_t)p.base_bits + 31) / 32 + (qual_stream_bits((uint64_t)(ll + lr), (uint64_t)p.qual_bits, (uint64_t)p.qual_group) + 31) / 32)
 		                  : table_block_bytes((uint64_t)ll, (uint64_t)lr, p.packed, (uint64_t)p.qual_bits);
 		lng = p.packed && single && (int)ec.y > PACK_MAX_LQ;
 	}

@@ -172,7 +172,7 @@ struct ssv_ctx {
 		                                                // still queued behind the table before must not see the next pass's record of a shared event
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
-		int packed = 0, qual_bits = 8;
+		int packed = 0, qual_bits = 8, qual_group = 1, qual_radix = 0; // qual_group > 1 (format 3): qual_bits per group of that many qualities, radix = the alphabet's size
 		uint8_t qual_alphabet[16] = {0};
 	} tab[2];
 	HostPool pool;
@@ -854,7 +854,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	c->tab_cur = s_;
 	const int64_t E = c->n_events, EL = c->n_l, ER = c->n_r;
 	T.n_events = E; T.n_clusters = 0;
-	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
+	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; T.qual_group = 1; T.qual_radix = 0; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
 	const bool fmt3 = c->table_mode == 3;
 	T.format = c->table_mode; T.base_bits = fmt3 ? 2 : 4; T.n_runs = 0; T.n_exc = 0; T.expanded = false; T.ordered = false;
 	T.len_bytes = fmt3 && c->max_lq < 65536 ? 2 : 4; T.support_bytes = fmt3 ? 2 : 4; T.ncig_bytes = fmt3 ? (c->max_ncig < 256 ? 1 : 2) : 4;
@@ -976,8 +976,15 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			memset(lut, 0xff, 256); memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
 			int n_vals = 0;
 			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) ++n_vals;
+			T.qual_group = 1; T.qual_radix = n_vals;
 			if (n_vals > 16) { T.qual_bits = 8; return; }
 			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : n_vals <= 8 ? 3 : 4;
+			// format 3: alphabets whose size is far from a power of two go in groups - five values: three qualities as one number below 5^3 in 7 bits (2.33
+			// bits a quality instead of 3), nine to eleven values: two in 7 bits (3.5 instead of 4); table3_kernels.h.  SSV_QUAL_GROUPS=0: one quality, one field.
+			const char *ge = getenv("SSV_QUAL_GROUPS");
+			const bool groups = !ge || atoi(ge) != 0;
+			if (fmt3 && groups && n_vals == 5) { T.qual_bits = 7; T.qual_group = 3; }
+			if (fmt3 && groups && n_vals >= 9 && n_vals <= 11) { T.qual_bits = 7; T.qual_group = 2; }
 			int k = 0;
 			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) { T.qual_alphabet[k] = (uint8_t)(v + 33); lut[v] = (uint8_t)k; ++k; } // increasing order; the table shows characters (phred + 33)
 		};
@@ -1002,14 +1009,15 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		uint64_t *tot = P<uint64_t>(c->totals);
 		bool track = false;
 		for (int attempt = 0;; ++attempt) {
-			const size_t str_cap = (size_t)E * (size_t)(fmt3 ? table3_block_bytes((uint64_t)ca.SL + (uint64_t)ca.SR, T.base_bits, T.qual_bits)
+			const size_t str_cap = (size_t)E * (size_t)(fmt3 ? table3_block_bytes((uint64_t)ca.SL + (uint64_t)ca.SR, T.base_bits, T.qual_bits, T.qual_group)
 			                                             : table_block_bytes((uint64_t)ca.SL, (uint64_t)ca.SR, T.packed, (uint64_t)T.qual_bits));
 			CHECK(ensure(c, T.o_str, str_cap + 16));
 			PackArgs pa;
 			pa.c = ca; pa.slot_cnt = P<uint64_t>(c->slot_cnt); pa.slot_bytes = P<uint64_t>(c->slot_bytes);
 			pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
 			pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.ncig = P<int32_t>(T.o_ncig); pa.str_off = P<uint64_t>(T.o_stroff); pa.cig_off = P<uint64_t>(T.o_cigoff);
-			pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
+			pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qual_group = T.qual_group; pa.qual_radix = T.qual_radix;
+			pa.qual_fill = T.qual_bits < 8 && T.qual_alphabet[0] ? (uint32_t)(T.qual_alphabet[0] - 33) * 0x01010101u : 0u; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
 			pa.lut_miss = reinterpret_cast<int *>(tot + 3);
 			pa.slow_list = P<uint32_t>(c->o_slowlist); pa.slow_count = reinterpret_cast<unsigned int *>(tot + 2);
 			pa.format3 = fmt3 ? 1 : 0; pa.base_bits = T.base_bits;
@@ -1032,7 +1040,11 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				if (direct) {
 					uint16_t *pl = P<uint16_t>(c->h_pair_lut);
 					for (int q1 = 0; q1 < 64; ++q1)
-						for (int q0 = 0; q0 < 64; ++q0) pl[q0 | (q1 << 6)] = lut[q0] == 0xff || lut[q1] == 0xff ? (uint16_t)0x8000 : (uint16_t)(lut[q0] | (lut[q1] << T.qual_bits));
+						for (int q0 = 0; q0 < 64; ++q0) {
+							const bool out = lut[q0] == 0xff || lut[q1] == 0xff;
+							if (T.qual_group > 1) pl[q0 | (q1 << 6)] = out ? (uint16_t)0x8000 : (uint16_t)(lut[q0] | (lut[q1] << 4) | ((lut[q0] + T.qual_radix * lut[q1]) << 8)); // qual_dword3g
+							else pl[q0 | (q1 << 6)] = out ? (uint16_t)0x8000 : (uint16_t)(lut[q0] | (lut[q1] << T.qual_bits));
+						}
 					HIPCHECK(c, hipMemcpyAsync(c->pair_lut.p, c->h_pair_lut.p, 8192, hipMemcpyHostToDevice, c->st));
 				}
 			}
@@ -1052,12 +1064,21 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				const dim3 gd((unsigned)std::max<int64_t>(1, std::min<int64_t>(p3_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)));
 #define SSV_P3B(W_, B_, T_) do { if (direct) k_pack3_direct<W_, B_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
+				// grouped qualities: the direct kernel knows the two shapes, the staged and the bytewise kernels take the shape at run time (W = 0)
+#define SSV_P3G(B_, T_) do { if (direct) { if (pa.qual_group == 3) k_pack3_direct<7, B_, 3><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); \
+				else k_pack3_direct<7, B_, 2><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); } \
+			else k_pack3_stream<0, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
+			k_pack3_slow<0, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
+#define SSV_P3GT(T_) do { if (T.base_bits == 2) SSV_P3G(2, T_); else SSV_P3G(4, T_); } while (0)
 #define SSV_P3T(W_, T_) do { if (T.base_bits == 2) SSV_P3B(W_, 2, T_); else SSV_P3B(W_, 4, T_); } while (0)
 #define SSV_P3(W_) do { if (track) SSV_P3T(W_, true); else SSV_P3T(W_, false); } while (0)
-				if (pa.qual_bits == 8) SSV_P3T(8, false); else if (pa.qual_bits == 4) SSV_P3(4); else if (pa.qual_bits == 3) SSV_P3(3); else if (pa.qual_bits == 2) SSV_P3(2); else SSV_P3(1);
+				if (pa.qual_group > 1) { if (track) SSV_P3GT(true); else SSV_P3GT(false); }
+				else if (pa.qual_bits == 8) SSV_P3T(8, false); else if (pa.qual_bits == 4) SSV_P3(4); else if (pa.qual_bits == 3) SSV_P3(3); else if (pa.qual_bits == 2) SSV_P3(2); else SSV_P3(1);
 #undef SSV_P3
 #undef SSV_P3T
 #undef SSV_P3B
+#undef SSV_P3G
+#undef SSV_P3GT
 			} else if (!pa.packed) k_cluster_pack_ascii<<<grid_for(E, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, os);
 			else {
 				// the dword path for (nearly) all clusters (one group of lanes per cluster; the grid is an upper bound, the kernel reads the cluster
@@ -1185,7 +1206,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 			if (hipEventElapsedTime(&ms, T.started, T.copied) == hipSuccess) fprintf(stderr, "[ssv debug] table copy on its stream: %.2f ms, %.2f ms after the copy before it ended\n", ms, gap);
 		}
 	}
-	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
+	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; out->qual_group = T.qual_group; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
 	out->format = T.format; out->base_bits = T.base_bits;
 	if (T.n_clusters == 0) return SSV_OK;
 	if (T.format == 3) {
@@ -1229,7 +1250,7 @@ static void expand_range(ssv_ctx::TableSet &T, int64_t k0, int64_t k1, bool seco
 	const SupT *sup = reinterpret_cast<const SupT *>(T.h_sup.p);
 	const NcT *ncg = reinterpret_cast<const NcT *>(T.h_nc.p);
 	const uint8_t *fl = P<uint8_t>(T.h_qmiss);
-	const uint64_t bb = (uint64_t)T.base_bits, qb = (uint64_t)T.qual_bits;
+	const uint64_t bb = (uint64_t)T.base_bits, qb = (uint64_t)T.qual_bits, qg = (uint64_t)T.qual_group;
 	int32_t *x_ll = T.x_ll.data(), *x_lr = T.x_lr.data(), *x_sup = T.x_support.data(), *x_nc = T.x_ncig.data();
 	uint8_t *x_qm = T.x_qmiss.data();
 	uint64_t *x_so = T.x_stroff.data(), *x_co = T.x_cigoff.data();
@@ -1239,7 +1260,7 @@ static void expand_range(ssv_ctx::TableSet &T, int64_t k0, int64_t k1, bool seco
 			const uint32_t ll = len[2 * k], lr = len[2 * k + 1], nc1 = ncg[k], s1 = sup[k];
 			x_ll[k] = (int32_t)ll; x_lr[k] = (int32_t)lr; x_sup[k] = (int32_t)s1; x_nc[k] = (int32_t)nc1; x_qm[k] = fl[k] & 1;
 			const uint64_t n = (uint64_t)ll + lr;
-			so += 4ull * ((n * bb + 31) / 32 + (n * qb + 31) / 32); co += nc1; sum += s1;
+			so += 4ull * ((n * bb + 31) / 32 + (qual_stream_bits(n, qb, qg) + 31) / 32); co += nc1; sum += s1;
 		}
 		ssum = sum;
 		return;
@@ -1247,7 +1268,7 @@ static void expand_range(ssv_ctx::TableSet &T, int64_t k0, int64_t k1, bool seco
 	for (int64_t k = k0; k < k1; ++k) {
 		x_so[k] = so; x_co[k] = co;
 		const uint64_t n = (uint64_t)(uint32_t)x_ll[k] + (uint32_t)x_lr[k];
-		so += 4ull * ((n * bb + 31) / 32 + (n * qb + 31) / 32); co += (uint32_t)x_nc[k];
+		so += 4ull * ((n * bb + 31) / 32 + (qual_stream_bits(n, qb, qg) + 31) / 32); co += (uint32_t)x_nc[k];
 	}
 }
 
@@ -1304,6 +1325,7 @@ int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
 }
 
 uint64_t ssv_table_block_bytes3(int64_t n_bases, int32_t base_bits, int32_t qual_bits) { return table3_block_bytes((uint64_t)n_bases, base_bits, qual_bits); }
+uint64_t ssv_table_block_bytes3g(int64_t n_bases, int32_t base_bits, int32_t qual_bits, int32_t qual_group) { return table3_block_bytes((uint64_t)n_bases, base_bits, qual_bits, qual_group > 1 ? qual_group : 1); }
 
 int ssv_clip_cluster(ssv_ctx *c, ssv_cluster_table *out)
 {

@@ -6,7 +6,8 @@
 //   CIGAR           n_cigar operations
 //   string block    [base stream | quality stream], each a whole number of dwords: the n = left_len + right_len bases of seq_left + seq_right
 //                   at base_bits (2: index into "ACGT"; 4: BAM's code) each, base i at stream bits [i * base_bits, +base_bits) (bit b of a
-//                   stream = bit b % 32 of dword b / 32), then the n qualities at qual_bits each the same way (8: characters, phred + 33)
+//                   stream = bit b % 32 of dword b / 32), then the n qualities at qual_bits each the same way (8: characters, phred + 33),
+//                   or in groups of qual_group qualities, qual_bits per group (below)
 //   exceptions      with 2-bit bases, every base that is not A/C/G/T: (cluster, base index, BAM code) - the stream holds 0 there
 // A single-event cluster (97 % of a WGS sample) is a contiguous piece of its read: n nibbles from nibble `begin` of the packed bases and n
 // bytes from quality `begin`.  No piece of the block starts inside a dword, so every lane composes whole output dwords straight from the
@@ -40,9 +41,27 @@ struct Pack3Args {
 	int *exc_miss;            // more exceptions than exc_cap (or a base index / cluster index beyond the entry's fields)
 };
 
-__host__ __device__ __forceinline__ uint64_t table3_block_bytes(uint64_t n, int base_bits, int qual_bits)
+__host__ __device__ __forceinline__ uint64_t table3_block_bytes(uint64_t n, int base_bits, int qual_bits, int qual_group = 1)
 {
-	return 4ull * ((n * (uint64_t)base_bits + 31) / 32 + (n * (uint64_t)qual_bits + 31) / 32);
+	return 4ull * ((n * (uint64_t)base_bits + 31) / 32 + (qual_stream_bits(n, (uint64_t)qual_bits, (uint64_t)qual_group) + 31) / 32);
+}
+
+// Grouped qualities (round 4): with an alphabet of R values, k alphabet indices i_0 .. i_(k-1) go into the stream as ONE number i_0 + R i_1 + R^2 i_2 + ...
+// of B bits - five values: three to 7 bits (2.33 bits a quality instead of 3), nine to eleven values: two to 7 bits (3.5 instead of 4).  Group g of a stream lies at stream bits [g B, g B + B); a last group that the qualities do not fill holds index 0
+// in its unused places.  The table is what crosses PCIe and qualities are half of it.
+// one group from its qualities, the generic way (the LDS-staged and the bytewise kernels): ph(i) = phred value of quality i of the stream
+template <class PhredAt, class Seen>
+__device__ __forceinline__ uint32_t qual_group_code(const uint8_t *s_lut, int K, uint32_t R, int i0, int n, uint32_t &miss, PhredAt ph, Seen seen)
+{
+	uint32_t code = 0, mul = 1;
+	for (int j = 0; j < K && i0 + j < n; ++j) {
+		const uint32_t v = ph(i0 + j), idx = s_lut[v];
+		seen(v);
+		miss |= idx;
+		code += (idx & 15u) * mul;
+		mul *= R;
+	}
+	return code;
 }
 
 // one thread per sorted slot: the row's fixed columns, its CIGAR, the descriptor for the string kernels, and the (contig, side) runs
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q,
 		if (gl == 0) q.flags[c] = qmiss ? 1 : 0;
 		constexpr int PER = 32 / BB; // bases per dword
 		const int nDb = (n * BB + 31) / 32;
-		const int nDq = (n * W + 31) / 32;
+		const int nDq = (int)((qual_stream_bits((uint64_t)n, W ? (uint64_t)W : (uint64_t)p.qual_bits, W ? 1ull : (uint64_t)p.qual_group) + 31) / 32); // W == 0: grouped qualities, shape at run time
 		uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
 		for (int t = gl; t < nDb; t += GROUP) {
 			const int nb0 = begin + PER * t;                  // first nibble of the read
@@ -197,6 +216,18 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q,
 		}
 		uint32_t seen_lo = 0, seen_hi = 0; // TRACK: phred 0..63 as a bit set in registers (anything higher goes straight to LDS)
 		uint32_t miss = 0;                 // OR of the table look-ups: 0xff marks a value outside the alphabet
+		if constexpr (W == 0) { // grouped qualities, group by group out of the staged bytes (this kernel is the direct one's stand-in for alphabets with a phred value >= 64 and the TRACK launch)
+			const int B = p.qual_bits, K = p.qual_group;
+			const uint8_t *qbytes = reinterpret_cast<const uint8_t *>(s4) + qb + begin;
+			for (int t = gl; t < nDq; t += GROUP) {
+				const int g0 = (32 * t) / B, off = 32 * t - B * g0;
+				uint64_t acc = 0;
+				for (int g = g0; B * g < 32 * t + 32 && K * g < n; ++g)
+					acc |= (uint64_t)qual_group_code(s_lut, K, (uint32_t)p.qual_radix, K * g, n, miss, [&](int i) { return (uint32_t)qbytes[i]; },
+					                                 [&](uint32_t ph) { if (TRACK) { if (ph < 32) seen_lo |= 1u << ph; else if (ph < 64) seen_hi |= 1u << (ph - 32); else atomicOr(&s_seen[ph >> 5], 1u << (ph & 31)); } }) << (B * (g - g0));
+				d[nDb + t] = qmiss ? 0u : (uint32_t)(acc >> off);
+			}
+		} else
 		for (int t = gl; t < nDq; t += GROUP) {
 			constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
 			constexpr int NSRC = (CNT + 3) / 4;                      // source dwords they lie in, once aligned
@@ -261,15 +292,21 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q,
 // pair table entry e = q0 | q1 << 6: index(q0) | index(q1) << W, or 0x8000
 __device__ __forceinline__ uint32_t pair_index(uint32_t halfword) { return (halfword & 0x3fu) | ((halfword >> 2) & 0xfc0u); }
 
-template <int W> struct Q3 {
-	static constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
+// W bits per quality (K == 1) or per group of K qualities (K > 1: W = 7)
+template <int W, int K = 1> struct Q3 {
+	static constexpr int CNTG = 32 % W == 0 ? 32 / W : (32 + 2 * (W - 1)) / W;     // groups that can touch one dword (a group may start up to W - 1 bits in front of it)
+	static constexpr int CNT = K > 1 ? K * CNTG : W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
 	static constexpr int NSRC = (CNT + 3) / 4;                      // source dwords they lie in, once aligned
+	static_assert(K == 1 || CNT % 2 == 0, "grouped qualities are looked up in pairs");
+	// first quality of the stream that touches dword t, and the dwords of a stream of n qualities
+	static __device__ __forceinline__ int first(int t) { return K > 1 ? K * ((32 * t) / W) : (32 * t) / W; }
+	static __device__ __forceinline__ int dwords(int n) { return K > 1 ? (((n + K - 1) / K) * W + 31) / 32 : (n * W + 31) / 32; }
 };
 
 // what one lane reads for base dword t and quality dword t of a cluster: aligned dwords, nothing beyond the one that holds the last byte
-template <int W, int BB> struct Src3 {
+template <int W, int BB, int K = 1> struct Src3 {
 	uint32_t w[3];
-	uint32_t raw[Q3<W>::NSRC + 1];
+	uint32_t raw[Q3<W, K>::NSRC + 1];
 };
 
 template <int W, int BB>
@@ -285,16 +322,16 @@ __device__ __forceinline__ void src3_load_bases(const PackDescR &d0, int t, uint
 	w[0] = p[0]; w[1] = need > 4 ? p[1] : 0u; w[2] = need > 8 ? p[2] : 0u;
 }
 
-template <int W, int BB>
-__device__ __forceinline__ void src3_load_quals(const PackDescR &d0, int t, uint32_t (&raw)[Q3<W>::NSRC + 1])
+template <int W, int BB, int K = 1>
+__device__ __forceinline__ void src3_load_quals(const PackDescR &d0, int t, uint32_t (&raw)[Q3<W, K>::NSRC + 1])
 {
 	const int n = d0.ll + d0.lr;
-	const int i0 = (32 * t) / W;
+	const int i0 = Q3<W, K>::first(t);
 	const uint64_t A = d0.src + (uint64_t)((d0.lq + 1) / 2 + d0.begin + i0); // first source byte
 	const uint32_t *q4 = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
 	const int bytes = (int)(A & 3ull) + (n - i0);
 #pragma unroll
-	for (int g = 0; g <= Q3<W>::NSRC; ++g) raw[g] = 4 * g < bytes ? q4[g] : 0u;
+	for (int g = 0; g <= Q3<W, K>::NSRC; ++g) raw[g] = 4 * g < bytes ? q4[g] : 0u;
 }
 
 // base dword t of the cluster's block from its three source dwords
@@ -379,11 +416,63 @@ __device__ __forceinline__ uint32_t qual_dword3(const Pack3Args &q, const uint16
 	return qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
 }
 
+// The same for grouped qualities (K alphabet indices as the digits of one W-bit number, radix R): the pair table's entry for two phred values is
+//   index(q0) | index(q1) << 4 | (index(q0) + R index(q1)) << 8, bit 15: one of them is outside the alphabet
+// and a group's number is put together from the pairs it is made of (two qualities: the pair's own sum; three: a pair and the half of the next one, ...).
+// `fill` = the phred value of alphabet index 0 in all four bytes: what stands in behind the stream's end, so that a last group's unused places hold 0.
+template <int W, int K>
+__device__ __forceinline__ uint32_t qual_dword3g(const Pack3Args &q, const uint16_t *s_pair, const PackDescR &d0, int64_t c, int t, const uint32_t (&raw)[Q3<W, K>::NSRC + 1], uint32_t &miss,
+                                                 uint32_t fill, uint32_t R)
+{
+	constexpr int CNTG = Q3<W, K>::CNTG, NSRC = Q3<W, K>::NSRC, NP = Q3<W, K>::CNT / 2;
+	static_assert(K == 2 || K == 3, "group shapes of set_alphabet (seeksv_hip.hip)");
+	static_assert(K == 2 || CNTG % 2 == 0, "odd groups are put together two at a time");
+	const int n = d0.ll + d0.lr;
+	const int g0 = (32 * t) / W, off = 32 * t - W * g0, i0 = K * g0;
+	const uint32_t sh = (uint32_t)((d0.src + (uint64_t)((d0.lq + 1) / 2 + d0.begin + i0)) & 3ull);
+	const int rem = n - i0;                                // qualities of the stream from i0 on (>= 1)
+	uint32_t src[NSRC];
+#pragma unroll
+	for (int g = 0; g < NSRC; ++g) src[g] = __builtin_amdgcn_alignbyte(raw[g + 1], raw[g], sh);
+	const bool qmiss = (src[0] & 0xffu) == 0xffu; // a read without qualities has 0xff in all of them
+	if (t == 0) q.flags[c] = qmiss ? 1 : 0;
+	uint32_t e[NP];
+	uint32_t bad = 0;
+#pragma unroll
+	for (int g = 0; g < NSRC; ++g) {
+		const uint32_t valid = rem >= 4 * g + 4 ? 0xffffffffu : rem > 4 * g ? (1u << (8 * (rem - 4 * g))) - 1u : 0u;
+		const uint32_t x = (src[g] & valid) | (fill & ~valid);
+		bad |= x & 0xc0c0c0c0u; // the table knows nothing of phred >= 64
+		e[2 * g] = s_pair[pair_index(x)];
+		bad |= e[2 * g] & 0x8000u;
+		if (2 * g + 1 < NP) { e[2 * g + 1] = s_pair[pair_index(x >> 16)]; bad |= e[2 * g + 1] & 0x8000u; }
+	}
+	auto sum = [](uint32_t v) { return (v >> 8) & 0x7fu; };
+	auto lo = [](uint32_t v) { return v & 15u; };
+	auto hi = [](uint32_t v) { return (v >> 4) & 15u; };
+	uint64_t acc = 0;
+	if (K == 2) {
+#pragma unroll
+		for (int j = 0; j < CNTG; ++j) acc |= (uint64_t)sum(e[j]) << (W * j);
+	} else {
+		const uint32_t R2 = R * R;
+#pragma unroll
+		for (int m = 0; m < CNTG / 2; ++m) {
+			const uint32_t a = sum(e[3 * m]) + R2 * lo(e[3 * m + 1]), b = hi(e[3 * m + 1]) + R * sum(e[3 * m + 2]);
+			acc |= ((uint64_t)a << (W * 2 * m)) | ((uint64_t)b << (W * (2 * m + 1)));
+		}
+	}
+	const int ng = (rem + K - 1) / K; // groups of the stream from g0 on
+	if (ng < CNTG) acc &= (1ull << (W * ng)) - 1ull;
+	miss |= qmiss ? 0u : bad;
+	return qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
+}
+
 // Persistent grid; every group of 16 lanes walks its clusters with a two-deep software pipeline: while the dwords of cluster i are composed
 // and stored, the source dwords of cluster i + 1 and the descriptor of cluster i + 2 are on their way (a cluster is descriptor -> source
 // bytes -> output: two dependent trips to memory that a wavefront would otherwise sit out; at eight wavefronts per SIMD that wait,
 // not the instructions, is what the unpipelined form spends its time on).
-template <int W, int BB>
+template <int W, int BB, int K = 1>
 __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str,
                                                         const uint16_t *__restrict__ pair_lut)
 {
@@ -409,18 +498,23 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 	auto counts = [](const PackDescR &d, int &nDb, int &nDq) {
 		const int n = d.ll + d.lr;
 		const bool fast = pack_desc_fast(d);
-		nDb = fast ? (n * BB + 31) / 32 : 0; nDq = fast ? (n * W + 31) / 32 : 0;
+		nDb = fast ? (n * BB + 31) / 32 : 0; nDq = fast ? Q3<W, K>::dwords(n) : 0;
 	};
-	auto issue = [&](const PackDescR &d, Src3<W, BB> &S) {
+	auto issue = [&](const PackDescR &d, Src3<W, BB, K> &S) {
 		int nDb, nDq; counts(d, nDb, nDq);
 		S.w[0] = S.w[1] = S.w[2] = 0u;
 #pragma unroll
-		for (int g = 0; g <= Q3<W>::NSRC; ++g) S.raw[g] = 0u;
+		for (int g = 0; g <= Q3<W, K>::NSRC; ++g) S.raw[g] = 0u;
 		if (gl < nDb) src3_load_bases<W, BB>(d, gl, S.w);
-		if (gl < nDq) src3_load_quals<W, BB>(d, gl, S.raw);
+		if (gl < nDq) src3_load_quals<W, BB, K>(d, gl, S.raw);
 	};
 	PackDescR d0 = pack_desc_load(desc, c, nc), d1 = pack_desc_load(desc, c + step, nc);
-	Src3<W, BB> S0, S1;
+	Src3<W, BB, K> S0, S1;
+	const uint32_t qfill = p.qual_fill, qradix = (uint32_t)p.qual_radix;
+	auto qual_dword = [&](const PackDescR &d, int64_t cc, int t, const uint32_t (&raw)[Q3<W, K>::NSRC + 1]) {
+		if constexpr (K > 1) return qual_dword3g<W, K>(q, s_pair, d, cc, t, raw, miss, qfill, qradix);
+		else return qual_dword3<W>(q, s_pair, d, cc, t, raw, miss);
+	};
 	issue(d0, S0);
 	for (; c < nc; c += step) {
 		const PackDescR d2 = pack_desc_load(desc, c + 2 * step, nc);
@@ -428,10 +522,10 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 		int nDb, nDq; counts(d0, nDb, nDq);
 		uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
 		if (gl < nDb) d[gl] = base_dword3<BB>(q, s_base, d0, c, gl, S0.w);
-		if (gl < nDq) d[nDb + gl] = qual_dword3<W>(q, s_pair, d0, c, gl, S0.raw, miss);
+		if (gl < nDq) d[nDb + gl] = qual_dword(d0, c, gl, S0.raw);
 		// clipped sequences longer than one round of the group (2-bit bases: 256; 3-bit qualities: 170): the rest, unpipelined
 		for (int t = gl + GROUP; t < nDb; t += GROUP) { uint32_t w[3]; src3_load_bases<W, BB>(d0, t, w); d[t] = base_dword3<BB>(q, s_base, d0, c, t, w); }
-		for (int t = gl + GROUP; t < nDq; t += GROUP) { uint32_t raw[Q3<W>::NSRC + 1]; src3_load_quals<W, BB>(d0, t, raw); d[nDb + t] = qual_dword3<W>(q, s_pair, d0, c, t, raw, miss); }
+		for (int t = gl + GROUP; t < nDq; t += GROUP) { uint32_t raw[Q3<W, K>::NSRC + 1]; src3_load_quals<W, BB, K>(d0, t, raw); d[nDb + t] = qual_dword(d0, c, t, raw); }
 		d0 = d1; d1 = d2; S0 = S1;
 	}
 	if (W < 8 && miss) *p.lut_miss = 1;
@@ -481,7 +575,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 		return ((uint32_t)(i < ll ? cq[ll - 1 - i] : rq[i - ll]) - 33u) & 255u;
 	};
 	constexpr int PER = 32 / BB;
-	const int nDb = (n * BB + 31) / 32, nDq = (n * W + 31) / 32;
+	const int nDb = (n * BB + 31) / 32, nDq = (int)((qual_stream_bits((uint64_t)n, W ? (uint64_t)W : (uint64_t)p.qual_bits, W ? 1ull : (uint64_t)p.qual_group) + 31) / 32);
 	for (int t = gl; t < nDb; t += GROUP) {
 		uint32_t word = 0;
 		for (int k = 0; k < PER && PER * t + k < n; ++k) {
@@ -494,7 +588,19 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 	}
 	for (int t = gl; t < nDq; t += GROUP) {
 		uint32_t word = 0;
-		if (W == 8) {
+		if constexpr (W == 0) { // grouped qualities (shape at run time)
+			if (!qm) {
+				const int B = p.qual_bits, K = p.qual_group;
+				const int g0 = (32 * t) / B, off = 32 * t - B * g0;
+				uint64_t acc = 0;
+				uint32_t miss = 0;
+				for (int g = g0; B * g < 32 * t + 32 && K * g < n; ++g)
+					acc |= (uint64_t)qual_group_code(s_lut, K, (uint32_t)p.qual_radix, K * g, n, miss, phred_at, [&](uint32_t ph) {
+						if (TRACK) { const uint32_t bit = 1u << (ph & 31); if (!(atomicOr(&s_seen[ph >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph >> 5], bit); } }) << (B * (g - g0));
+				if (miss & 0x80u) *p.lut_miss = 1;
+				word = (uint32_t)(acc >> off);
+			}
+		} else if (W == 8) {
 			for (int k = 0; k < 4 && 4 * t + k < n; ++k) word |= (qm ? 0x2au : phred_at(4 * t + k) + 33u) << (8 * k);
 		} else if (!qm) {
 			const int i0 = (32 * t) / W, off = 32 * t - W * i0;

@@ -288,8 +288,8 @@ def _compact_to_dict(t, d):
     import ctypes as C
     from . import _abi
     n = t.n_clusters
-    bb, qb = int(t.base_bits), d["qual_bits"]
-    d.update(format=3, base_bits=bb, len_bytes=int(t.len_bytes), support_bytes=int(t.support_bytes), ncig_bytes=int(t.ncig_bytes))
+    bb, qb, qg = int(t.base_bits), d["qual_bits"], max(1, int(t.qual_group))
+    d.update(format=3, base_bits=bb, qual_group=qg, len_bytes=int(t.len_bytes), support_bytes=int(t.support_bytes), ncig_bytes=int(t.ncig_bytes))
 
     def raw(ptr, nbytes, dt):
         if nbytes == 0 or not ptr:
@@ -308,7 +308,7 @@ def _compact_to_dict(t, d):
     d["tid"] = np.repeat(runs["tid"], counts).astype(np.int32)
     d["side"] = np.repeat(runs["side"], counts).astype(np.uint8)
     nn = (d["left_len"] + d["right_len"]).astype(np.int64)
-    blk = 4 * ((nn * bb + 31) // 32 + (nn * qb + 31) // 32)
+    blk = 4 * ((nn * bb + 31) // 32 + (((nn + qg - 1) // qg if qg > 1 else nn) * qb + 31) // 32)
     d["str_off"] = (np.cumsum(blk) - blk).astype(np.uint64)
     nc = d["n_cigar"].astype(np.int64)
     d["cigar_off"] = (np.cumsum(nc) - nc).astype(np.uint64)
@@ -334,9 +334,10 @@ def cluster_strings(d, k):
     o, ll, lr = int(d["str_off"][k]), int(d["left_len"][k]), int(d["right_len"][k])
     s = d["str"]
     if d.get("format") == 3:
-        n, bb, w = ll + lr, int(d["base_bits"]), int(d["qual_bits"])
-        nb, nq = 4 * ((n * bb + 31) // 32), 4 * ((n * w + 31) // 32)
+        n, bb, w, qg = ll + lr, int(d["base_bits"]), int(d["qual_bits"]), int(d.get("qual_group", 1))
+        nb, nq = 4 * ((n * bb + 31) // 32), 4 * ((((n + qg - 1) // qg if qg > 1 else n) * w + 31) // 32)
         alphabet = d.get("qual_alphabet", b"")
+        radix = sum(1 for c in alphabet if c)  # a group's number: i_0 + radix i_1 + radix^2 i_2 (include/seeksv_hip.h)
 
         def field(buf, i, width):  # stream bits [i * width, +width); bit b = bit b % 8 of byte b / 8
             b = (i * width) >> 3
@@ -349,7 +350,10 @@ def cluster_strings(d, k):
             for x in e[np.searchsorted(e >> np.uint64(28), np.uint64(k), "left"):np.searchsorted(e >> np.uint64(28), np.uint64(k), "right")]:
                 seq[(int(x) >> 4) & 0xFFFFFF] = NT16[int(x) & 15]
         seq = "".join(seq)
-        q = qs[:n].tobytes().decode("latin-1") if w == 8 else "".join(chr(alphabet[field(qs, i, w)]) for i in range(n))
+        if qg > 1:
+            q = "".join(chr(alphabet[(field(qs, i // qg, w) // radix ** (i % qg)) % radix]) for i in range(n))
+        else:
+            q = qs[:n].tobytes().decode("latin-1") if w == 8 else "".join(chr(alphabet[field(qs, i, w)]) for i in range(n))
         sl, sr, ql, qr = seq[:ll], seq[ll:], q[:ll], q[ll:]
     elif d.get("seq_packed"):
         a, c, w = (ll + 1) // 2, (lr + 1) // 2, int(d.get("qual_bits", 8))

@@ -663,13 +663,15 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 		row.reserve(row.size() + (size_t)(k1 - k0) * 480); fq.reserve(fq.size() + (size_t)(k1 - k0) * 200);
 		char num[16];
 		string seqbuf;
+		char group_lut[256][3];                       // grouped qualities: a group's number -> its (up to three) quality characters
+		const ssv_cluster_table *group_lut_for = nullptr;
 		for (int64_t k = k0; k < k1; ++k) {
 			const char *name = ssvh_bam_target_name(bam, t.tid[k]);
 			const uint8_t *s = t.str + t.str_off[k];
 			const size_t ll = (size_t)t.left_len[k], lr = (size_t)t.right_len[k];
 			const char *sl, *ql, *sr, *qr;
 			if (t.format == 3) { // compact: [base stream | quality stream] over seq_left + seq_right, whole 32-bit words each (seeksv_hip.h)
-				const size_t n = ll + lr, W = (size_t)t.qual_bits, BBITS = (size_t)t.base_bits;
+				const size_t n = ll + lr, W = (size_t)t.qual_bits, BBITS = (size_t)t.base_bits, QG = t.qual_group > 1 ? (size_t)t.qual_group : 1;
 				const uint8_t *bs = s, *qs = s + 4 * ((n * BBITS + 31) / 32);
 				seqbuf.resize(2 * n);
 				if (BBITS == 2) {
@@ -680,7 +682,23 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 				} else for (size_t i = 0; i < n; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(bs[i >> 1] >> ((i & 1) << 2)) & 15];
 				sl = seqbuf.data(); sr = seqbuf.data() + ll;
 				if (W == 8) { ql = (const char *)qs; qr = ql + ll; }
-				else {
+				else if (QG > 1) { // groups of QG qualities: one number of W bits, its digits (radix = the alphabet's size) are the alphabet indices
+					if (!group_lut_for || group_lut_for != &t) {
+						unsigned radix = 0;
+						while (radix < 16 && t.qual_alphabet[radix]) ++radix;
+						for (unsigned code = 0; code < (1u << W) && code < 256; ++code) { unsigned v = code; for (size_t j = 0; j < 3; ++j) { group_lut[code][j] = (char)t.qual_alphabet[radix ? v % radix : 0]; if (radix) v /= radix; } }
+						group_lut_for = &t;
+					}
+					char *dq = &seqbuf[n];
+					const unsigned mask = (1u << W) - 1u;
+					const size_t ng = (n + QG - 1) / QG, qbytes = 4 * ((ng * W + 31) / 32);
+					for (size_t g = 0; g < ng; ++g) {
+						const size_t b = (g * W) >> 3;
+						const unsigned code = ((qs[b] | (b + 1 < qbytes ? (unsigned)qs[b + 1] << 8 : 0u)) >> ((g * W) & 7)) & mask;
+						for (size_t j = 0; j < QG && g * QG + j < n; ++j) dq[g * QG + j] = group_lut[code][j];
+					}
+					ql = dq; qr = dq + ll;
+				} else {
 					const unsigned mask = (1u << W) - 1u;
 					char *dq = &seqbuf[n];
 					const size_t qbytes = 4 * ((n * W + 31) / 32);

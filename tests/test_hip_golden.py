@@ -84,7 +84,7 @@ def _compact_checks(ctx, d, ref, t, check_size=True):
                      ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
         assert np.array_equal(np.ctypeslib.as_array(getattr(t, name), shape=(n,)), d[name].astype(dt)), name
     lib = _abi.hip_lib()
-    assert all(lib.ssv_table_block_bytes3(int(a) + int(b), d["base_bits"], d["qual_bits"]) ==
+    assert all(lib.ssv_table_block_bytes3g(int(a) + int(b), d["base_bits"], d["qual_bits"], d["qual_group"]) ==
                (int(d["str_off"][k + 1]) if k + 1 < n else len(d["str"])) - int(d["str_off"][k]) for k, (a, b) in enumerate(zip(d["left_len"], d["right_len"])))
     wire = n * (4 + 2 * d["len_bytes"] + d["support_bytes"] + d["ncig_bytes"] + 1) + len(d["str"]) + 4 * len(d["cigar"]) + 16 * len(d["runs"]) + 8 * len(d["base_exc"])
     wire_ascii = n * 42 + len(ref["str"]) + 4 * len(ref["cigar"])
@@ -167,18 +167,22 @@ def test_compact_table_bases(ctx, source, mode, monkeypatch):
         assert (len(d["base_exc"]) == 0) == (mode in ("acgt", "overflow"))
 
 
-@pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (4, 2), (5, 3), (8, 3), (16, 4), (17, 8)])
+@pytest.mark.parametrize("n_values,bits,group,first", [(1, 1, 1, 3), (2, 1, 1, 3), (4, 2, 1, 3), (5, 7, 3, 3), (5, 7, 3, 47), (5, 3, 1, 3), (8, 3, 1, 3), (9, 7, 2, 3), (11, 7, 2, 3), (10, 7, 2, 40),
+                                                      (11, 4, 1, 3), (12, 4, 1, 3), (16, 4, 1, 3), (17, 8, 1, 3)])
 @pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300", "synth400"])
-def test_compact_table_quality_alphabets(ctx, source, n_values, bits):
-    """format 3 with every quality index width, on deep bins (consensus storage), odd clip offsets, reads longer than the kernel's LDS-staged
-    limit, missing qualities"""
+def test_compact_table_quality_alphabets(ctx, monkeypatch, source, n_values, bits, group, first):
+    """format 3 with every quality index width - and the grouped forms (five values: three qualities to 7 bits; nine to eleven: two to 7 bits; with
+    SSV_QUAL_GROUPS=0 one field per quality as before; an alphabet that reaches phred 64 takes the LDS-staged kernel) -, on deep bins (consensus
+    storage), odd clip offsets, reads longer than the kernel's LDS-staged limit, missing qualities"""
+    if group == 1 and n_values in (5, 9, 10, 11):
+        monkeypatch.setenv("SSV_QUAL_GROUPS", "0")
     if source.startswith("synth"):
         from seeksv_amd import synth
         w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, read_len=int(source[5:]))
         batches = [w.generate_host(0, w.n_total)]
     else:
         batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", source + ".bam"))[2]
-    alphabet = [(3 + 5 * k) % 94 for k in range(n_values)]
+    alphabet = [(first + 5 * k) % 94 for k in range(n_values)]
     batches = [_remap_qualities(b, alphabet) for b in batches]
     ref = ctx.getclip(batches)
     ctx.clip_table_format(3)
@@ -188,7 +192,7 @@ def test_compact_table_quality_alphabets(ctx, source, n_values, bits):
             ctx.clip_scan(b)
         t = ctx.clip_cluster(as_dict=False)
         d = host.table_to_dict(t)
-        assert d["qual_bits"] == bits, (d["qual_bits"], bits)
+        assert (d["qual_bits"], d["qual_group"]) == (bits, group), (d["qual_bits"], d["qual_group"], bits, group)
         _compact_checks(ctx, d, ref, t)
     finally:
         ctx.clip_table_format(0)
