@@ -161,10 +161,10 @@ def main():
             ctx.clip_table_expand(t, 0)
             state.setdefault("expand_ms", []).append((time.perf_counter() - te) * 1e3)
             state.setdefault("wait_ms", []).append((te - tw) * 1e3)
-            state["table_bytes"] = n * (4 + 2 * t.len_bytes + t.support_bytes + t.ncig_bytes + 1) + t.str_bytes + 4 * t.cigar_ops + 16 * t.n_runs + 8 * t.n_base_exc
+            state["table_bytes"] = n * (4 + 2 * t.len_bytes + t.support_bytes + t.ncig_bytes + 1) + t.str_bytes + t.cigar_bytes * t.cigar_ops + 16 * t.n_runs + 8 * t.n_base_exc
         else:
             state["table_bytes"] = n * 42 + t.str_bytes + 4 * t.cigar_ops
-        state["table_info"] = dict(format=int(t.format), qual_bits=int(t.qual_bits), qual_group=int(t.qual_group), base_bits=int(t.base_bits), base_exceptions=int(t.n_base_exc))
+        state["table_info"] = dict(format=int(t.format), qual_bits=int(t.qual_bits), qual_group=int(t.qual_group), cigar_bytes=int(t.cigar_bytes), base_bits=int(t.base_bits), base_exceptions=int(t.n_base_exc))
         ssum = int(t.support_sum) if t.format == 3 else (int(np.ctypeslib.as_array(t.support, shape=(n,)).sum()) if n else 0)
         assert ssum == t.n_events, "clip events were lost or duplicated"
         assert bool(t.seq_packed) == (not args.ascii_table)

@@ -254,7 +254,7 @@ typedef struct {
 	                              and come from a handful of values on current sequencers. */
 	uint8_t qual_alphabet[16]; /* index -> quality character */
 	/* ---- format 3, the compact table: what the host can rebuild does not cross PCIe ----
-	 * Handed out by ssv_clip_table_wait: pos, cigar, str and the fields below; tid, side, support, left_len, right_len, qual_missing,
+	 * Handed out by ssv_clip_table_wait: pos, c_cigar (cigar too when cigar_bytes is 4), str and the fields below; tid, side, support, left_len, right_len, qual_missing,
 	 * n_cigar, str_off and cigar_off are NULL until ssv_clip_table_expand() has rebuilt them on the host.
 	 *   c_len      [n_clusters][2] left_len, right_len, len_bytes (2 or 4) wide each
 	 *   c_support  [n_clusters] support_bytes (2 or 4) wide;  c_ncig [n_clusters] ncig_bytes (1 or 2) wide;  c_flags bit 0 = qual_missing
@@ -286,6 +286,9 @@ typedef struct {
 	uint64_t str_bytes;        /* bytes of str / operations of cigar (all formats) */
 	uint64_t cigar_ops;
 	int64_t support_sum;       /* format 3, after ssv_clip_table_expand: sum of the support column (= n_events: every clip event is in one cluster) */
+	const void *c_cigar;       /* format 3 (v7): the CIGAR operations as they crossed PCIe, cigar_bytes wide each - 2: length << 4 | code in 16 bits (every
+	                              length of the table is below 4096), `cigar` is then NULL until ssv_clip_table_expand has widened them; 4: = cigar */
+	int32_t cigar_bytes, pad4;
 } ssv_cluster_table;
 
 /* Table format of the following ssv_clip_cluster[_async] calls: 0 ASCII (default), 1 sequences as 4-bit codes, 2 the same plus

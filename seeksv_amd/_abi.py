@@ -118,7 +118,7 @@ class HipClusterTable(C.Structure):
                                         ("format", C.c_int32), ("base_bits", C.c_int32), ("len_bytes", C.c_int32), ("support_bytes", C.c_int32), ("ncig_bytes", C.c_int32),
                                         ("qual_group", C.c_int32), ("c_len", C.c_void_p), ("c_support", C.c_void_p), ("c_ncig", C.c_void_p), ("c_flags", C.c_void_p),
                                         ("runs", C.c_void_p), ("n_runs", C.c_int64), ("base_exc", C.c_void_p), ("n_base_exc", C.c_int64), ("str_bytes", C.c_uint64),
-                                        ("cigar_ops", C.c_uint64), ("support_sum", C.c_int64)]
+                                        ("cigar_ops", C.c_uint64), ("support_sum", C.c_int64), ("c_cigar", C.c_void_p), ("cigar_bytes", C.c_int32), ("pad4", C.c_int32)]
 
 
 TABLE_RUN_DTYPE = np.dtype([("tid", "<i4"), ("side", "u1"), ("pad", "u1", (3,)), ("first", "<i8")])  # ssv_table_run

@@ -166,13 +166,14 @@ struct ssv_ctx {
 		std::vector<int32_t> x_tid, x_support, x_ll, x_lr, x_ncig;
 		std::vector<uint8_t> x_side, x_qmiss;
 		std::vector<uint64_t> x_stroff, x_cigoff;
+		std::vector<uint32_t> x_cigar;   // the CIGAR operations widened to 32 bits (cig_bytes == 2)
 		bool expanded = false, ordered = false;
 		hipEvent_t copied = nullptr, started = nullptr; // `started` only with SSV_DEBUG_COPY (times the copy on its stream)
 		hipEvent_t packed_ev = nullptr;                 // the set's pack kernels are done (its copy waits for it): one event per set - a copy that is
 		                                                // still queued behind the table before must not see the next pass's record of a shared event
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
-		int packed = 0, qual_bits = 8, qual_group = 1, qual_radix = 0; // qual_group > 1 (format 3): qual_bits per group of that many qualities, radix = the alphabet's size
+		int packed = 0, qual_bits = 8, qual_group = 1, qual_radix = 0, cig_bytes = 4; // qual_group > 1 (format 3): qual_bits per group of that many qualities, radix = the alphabet's size
 		uint8_t qual_alphabet[16] = {0};
 	} tab[2];
 	HostPool pool;
@@ -857,7 +858,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; T.qual_group = 1; T.qual_radix = 0; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
 	const bool fmt3 = c->table_mode == 3;
 	T.format = c->table_mode; T.base_bits = fmt3 ? 2 : 4; T.n_runs = 0; T.n_exc = 0; T.expanded = false; T.ordered = false;
-	T.len_bytes = fmt3 && c->max_lq < 65536 ? 2 : 4; T.support_bytes = fmt3 ? 2 : 4; T.ncig_bytes = fmt3 ? (c->max_ncig < 256 ? 1 : 2) : 4;
+	T.cig_bytes = fmt3 && !(getenv("SSV_CIGAR_BYTES") && atoi(getenv("SSV_CIGAR_BYTES")) == 4) ? 2 : 4; T.len_bytes = fmt3 && c->max_lq < 65536 ? 2 : 4; T.support_bytes = fmt3 ? 2 : 4; T.ncig_bytes = fmt3 ? (c->max_ncig < 256 ? 1 : 2) : 4;
 	if (fmt3 && getenv("SSV_TABLE_WIDE_COLUMNS")) { T.len_bytes = 4; T.support_bytes = 4; T.ncig_bytes = 2; } // (tests: the widths that only reads > 64 kb, > 65535-read clusters, > 255-operation CIGARs ask for)
 	if (n_events) *n_events = E;
 	if (n_clusters) *n_clusters = 0;
@@ -1028,6 +1029,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				p3.runs = P<TableRun>(T.o_runs); p3.run_count = reinterpret_cast<unsigned int *>(tot + 4);
 				p3.exc = P<uint64_t>(T.o_exc); p3.exc_count = reinterpret_cast<unsigned int *>(tot + 4) + 1; p3.exc_cap = (uint32_t)exc_cap;
 				p3.support_miss = reinterpret_cast<int *>(tot + 5); p3.exc_miss = reinterpret_cast<int *>(tot + 5) + 1;
+				p3.cig_bytes = T.cig_bytes; p3.cig_miss = reinterpret_cast<int *>(tot + 6);
 			}
 			HIPCHECK(c, hipMemsetAsync(tot, 0, 64, c->st));
 			if (track) HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
@@ -1062,11 +1064,26 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
 				static const unsigned p3_blocks = []() { const char *e = getenv("SSV_PACK3_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 10u; }(); // persistent: two rounds of what is resident at once (82 registers: five wavefronts per SIMD = five workgroups per CU); measured best
 				const dim3 gd((unsigned)std::max<int64_t>(1, std::min<int64_t>(p3_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)));
-#define SSV_P3B(W_, B_, T_) do { if (direct) k_pack3_direct<W_, B_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
+				// the direct kernel with the lanes packed densely (SSV_PACK3=dense; measured slower, profiles/: twice the requests to the L2): lanes per cluster = the dwords of the pass's longest
+				// read, or that count in two or three rounds where one round would leave too many of the 64 lanes without work
+				const bool dense = direct && getenv("SSV_PACK3") && !strcmp(getenv("SSV_PACK3"), "dense");
+				auto lanes_for = [](int n_dwords) {
+					int best = 16; double best_u = 0;
+					for (int r = 1; r <= 3; ++r) {
+						const int L = std::max(1, std::min(WAVE, (n_dwords + r - 1) / r));
+						const double u = (double)n_dwords / (double)(((n_dwords + L - 1) / L) * L) * (double)((WAVE / L) * L) / WAVE;
+						if (u > best_u + 0.02) { best_u = u; best = L; }
+					}
+					return best;
+				};
+				const int n_fast = std::max(1, std::min(c->max_lq, PACK_MAX_LQ));
+				const int LB = lanes_for((n_fast * T.base_bits + 31) / 32), LQ = lanes_for((int)((qual_stream_bits((uint64_t)n_fast, (uint64_t)T.qual_bits, (uint64_t)T.qual_group) + 31) / 32));
+#define SSV_P3D(W_, B_, K_) do { if (dense) k_pack3_dense<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut), LB, LQ); \
+			else k_pack3_direct<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); } while (0)
+#define SSV_P3B(W_, B_, T_) do { if (direct) SSV_P3D(W_, B_, 1); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 				// grouped qualities: the direct kernel knows the two shapes, the staged and the bytewise kernels take the shape at run time (W = 0)
-#define SSV_P3G(B_, T_) do { if (direct) { if (pa.qual_group == 3) k_pack3_direct<7, B_, 3><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); \
-				else k_pack3_direct<7, B_, 2><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); } \
+#define SSV_P3G(B_, T_) do { if (direct) { if (pa.qual_group == 3) SSV_P3D(7, B_, 3); else SSV_P3D(7, B_, 2); } \
 			else k_pack3_stream<0, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<0, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 #define SSV_P3GT(T_) do { if (T.base_bits == 2) SSV_P3G(2, T_); else SSV_P3G(4, T_); } while (0)
@@ -1077,6 +1094,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 #undef SSV_P3
 #undef SSV_P3T
 #undef SSV_P3B
+#undef SSV_P3D
 #undef SSV_P3G
 #undef SSV_P3GT
 			} else if (!pa.packed) k_cluster_pack_ascii<<<grid_for(E, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, os);
@@ -1103,6 +1121,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				const uint64_t m = P<uint64_t>(c->h_totals)[5];
 				if ((uint32_t)m && T.support_bytes == 2) { T.support_bytes = 4; continue; }
 				if ((uint32_t)(m >> 32) && T.base_bits == 2) { T.base_bits = 4; continue; }
+				if ((uint32_t)P<uint64_t>(c->h_totals)[6] && T.cig_bytes == 2) { T.cig_bytes = 4; continue; } // an operation of 4096 bases or more (a long N / D)
 			}
 			if (track) { // the launch above met every quality value of the table's strings: that is the alphabet; pack once more with it
 				memcpy(guess, h_seen, 32);
@@ -1130,7 +1149,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	std::vector<CopyItem> cp;
 	if (fmt3)
 		cp = {{&T.h_pos, &T.o_pos, (size_t)nc * 4}, {&T.h_len, &T.o_len, (size_t)nc * 2 * (size_t)T.len_bytes}, {&T.h_sup, &T.o_sup, (size_t)nc * (size_t)T.support_bytes},
-		      {&T.h_nc, &T.o_nc, (size_t)nc * (size_t)T.ncig_bytes}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * 4},
+		      {&T.h_nc, &T.o_nc, (size_t)nc * (size_t)T.ncig_bytes}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * (size_t)T.cig_bytes},
 		      {&T.h_runs, &T.o_runs, (size_t)T.n_runs * sizeof(TableRun)}, {&T.h_exc, &T.o_exc, (size_t)T.n_exc * 8}};
 	else
 		cp = {{&T.h_tid, &T.o_tid, (size_t)nc * 4}, {&T.h_pos, &T.o_pos, (size_t)nc * 4}, {&T.h_side, &T.o_side, (size_t)nc}, {&T.h_support, &T.o_support, (size_t)nc * 4},
@@ -1212,7 +1231,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 	if (T.format == 3) {
 		out->len_bytes = T.len_bytes; out->support_bytes = T.support_bytes; out->ncig_bytes = T.ncig_bytes;
 		out->pos = P<int32_t>(T.h_pos); out->c_len = T.h_len.p; out->c_support = T.h_sup.p; out->c_ncig = T.h_nc.p; out->c_flags = P<uint8_t>(T.h_qmiss);
-		out->str = P<uint8_t>(T.h_str); out->cigar = P<uint32_t>(T.h_cig); out->str_bytes = T.str_bytes; out->cigar_ops = T.cig_ops;
+		out->str = P<uint8_t>(T.h_str); out->cigar = T.cig_bytes == 4 ? P<uint32_t>(T.h_cig) : nullptr; out->c_cigar = T.h_cig.p; out->cigar_bytes = T.cig_bytes; out->str_bytes = T.str_bytes; out->cigar_ops = T.cig_ops;
 		out->runs = reinterpret_cast<const ssv_table_run *>(T.h_runs.p); out->n_runs = T.n_runs;
 		out->base_exc = P<uint64_t>(T.h_exc); out->n_base_exc = T.n_exc;
 		if (!T.ordered) { // once per table: put the runs (appended by whichever thread came first) and the exceptions in order
@@ -1238,6 +1257,7 @@ static void table_expanded_view(ssv_ctx::TableSet &T, ssv_cluster_table *out)
 {
 	out->tid = T.x_tid.data(); out->side = T.x_side.data(); out->support = T.x_support.data(); out->left_len = T.x_ll.data(); out->right_len = T.x_lr.data();
 	out->qual_missing = T.x_qmiss.data(); out->n_cigar = T.x_ncig.data(); out->str_off = T.x_stroff.data(); out->cigar_off = T.x_cigoff.data();
+	if (T.cig_bytes == 2) out->cigar = T.x_cigar.data();
 }
 
 } // extern "C"
@@ -1265,6 +1285,13 @@ static void expand_range(ssv_ctx::TableSet &T, int64_t k0, int64_t k1, bool seco
 		ssum = sum;
 		return;
 	}
+	if (T.cig_bytes == 2 && k1 > k0) { // the range's CIGAR operations, widened: they start at the range's first offset
+		const uint16_t *c16 = reinterpret_cast<const uint16_t *>(T.h_cig.p);
+		uint32_t *c32 = T.x_cigar.data();
+		uint64_t ops = 0;
+		for (int64_t k = k0; k < k1; ++k) ops += (uint32_t)x_nc[k];
+		for (uint64_t i = co; i < co + ops; ++i) c32[i] = c16[i];
+	}
 	for (int64_t k = k0; k < k1; ++k) {
 		x_so[k] = so; x_co[k] = co;
 		const uint64_t n = (uint64_t)(uint32_t)x_ll[k] + (uint32_t)x_lr[k];
@@ -1285,6 +1312,7 @@ int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
 	if (n == 0 || T.expanded) { if (n) table_expanded_view(T, t); t->support_sum = T.support_sum; return SSV_OK; }
 	T.x_tid.resize((size_t)n); T.x_side.resize((size_t)n); T.x_support.resize((size_t)n); T.x_ll.resize((size_t)n); T.x_lr.resize((size_t)n); T.x_qmiss.resize((size_t)n);
 	T.x_ncig.resize((size_t)n); T.x_stroff.resize((size_t)n); T.x_cigoff.resize((size_t)n);
+	if (T.cig_bytes == 2) T.x_cigar.resize((size_t)T.cig_ops + 1);
 	const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(n_threads > 0 ? n_threads : (int32_t)effective_cpus()), 64, n / 32768 + 1}));
 	const ssv_table_run *runs = reinterpret_cast<const ssv_table_run *>(T.h_runs.p);
 	const int64_t n_runs = T.n_runs;

@@ -315,7 +315,8 @@ def _compact_to_dict(t, d):
     sb, cb = int(blk.sum()), int(nc.sum())
     assert sb == t.str_bytes and cb == t.cigar_ops
     d["str"] = raw(t.str, sb, np.uint8)
-    d["cigar"] = raw(t.cigar, cb * 4, np.uint32)
+    d["cigar_bytes"] = int(t.cigar_bytes)
+    d["cigar"] = raw(t.c_cigar, cb * t.cigar_bytes, np.uint16 if t.cigar_bytes == 2 else np.uint32).astype(np.uint32)  # (16 bits: length << 4 | code)
     d["base_exc"] = raw(t.base_exc, t.n_base_exc * 8, np.uint64)
     return d
 

@@ -86,7 +86,9 @@ def _compact_checks(ctx, d, ref, t, check_size=True):
     lib = _abi.hip_lib()
     assert all(lib.ssv_table_block_bytes3g(int(a) + int(b), d["base_bits"], d["qual_bits"], d["qual_group"]) ==
                (int(d["str_off"][k + 1]) if k + 1 < n else len(d["str"])) - int(d["str_off"][k]) for k, (a, b) in enumerate(zip(d["left_len"], d["right_len"])))
-    wire = n * (4 + 2 * d["len_bytes"] + d["support_bytes"] + d["ncig_bytes"] + 1) + len(d["str"]) + 4 * len(d["cigar"]) + 16 * len(d["runs"]) + 8 * len(d["base_exc"])
+    assert np.array_equal(np.ctypeslib.as_array(t.cigar, shape=(len(d["cigar"]),)), d["cigar"])   # (widened by the expand when it crossed PCIe in 16 bits)
+    assert d["cigar_bytes"] == (2 if int(d["cigar"].max(initial=0)) < 65536 else 4)
+    wire = n * (4 + 2 * d["len_bytes"] + d["support_bytes"] + d["ncig_bytes"] + 1) + len(d["str"]) + d["cigar_bytes"] * len(d["cigar"]) + 16 * len(d["runs"]) + 8 * len(d["base_exc"])
     wire_ascii = n * 42 + len(ref["str"]) + 4 * len(ref["cigar"])
     assert wire < 0.7 * wire_ascii or n < 50 or not check_size
     assert t.support_sum == d["n_events"] == int(d["support"].sum())
@@ -196,6 +198,31 @@ def test_compact_table_quality_alphabets(ctx, monkeypatch, source, n_values, bit
         _compact_checks(ctx, d, ref, t)
     finally:
         ctx.clip_table_format(0)
+
+
+def test_compact_table_wide_cigar(ctx):
+    """a CIGAR operation of 4096 bases or more (a long N): the table's operations stay 32 bits wide; without one they cross PCIe in 16"""
+    n, lq = 40, 50
+    packed = np.array([0x12, 0x48] * 12 + [0x12], np.uint8)   # ACGT x 12, AC
+    entry = np.concatenate([packed, np.full(lq, 30, np.uint8)])
+    for skip, width in ((4095, 2), (4096, 4), (70000, 4)):
+        cig = np.tile(np.array([(20 << 4) | 4, (10 << 4) | 0, (skip << 4) | 3, (20 << 4) | 0], np.uint32), n)
+        b = dict(tid=np.zeros(n, np.int32), pos=(1000 + 7 * np.arange(n)).astype(np.int32), flag=np.full(n, 99, np.uint16), mapq=np.full(n, 60, np.uint8), n_cigar=np.full(n, 4, np.uint16),
+                 l_qseq=np.full(n, lq, np.int32), mtid=np.zeros(n, np.int32), mpos=np.full(n, 1200, np.int32), isize=np.full(n, 250, np.int32), xc=np.zeros(n, np.uint8),
+                 cigar=cig, cigar_off=(4 * np.arange(n)).astype(np.uint32),
+                 seq_off=(np.arange(n) * len(entry)).astype(np.uint64), seqqual=np.concatenate([np.tile(entry, n), np.zeros(16, np.uint8)]), max_ref_span=30 + skip)
+        ref = ctx.getclip([b])
+        assert ref["n_clusters"] == n
+        ctx.clip_table_format(3)
+        try:
+            ctx.clip_begin()
+            ctx.clip_scan(b)
+            t = ctx.clip_cluster(as_dict=False)
+            d = host.table_to_dict(t)
+            assert d["cigar_bytes"] == width
+            _compact_checks(ctx, d, ref, t, check_size=False)
+        finally:
+            ctx.clip_table_format(0)
 
 
 def test_compact_table_wide_support(ctx):
