@@ -287,7 +287,7 @@ typedef struct {
 	uint64_t cigar_ops;
 	int64_t support_sum;       /* format 3, after ssv_clip_table_expand: sum of the support column (= n_events: every clip event is in one cluster) */
 	const void *c_cigar;       /* format 3 (v7): the CIGAR operations as they crossed PCIe, cigar_bytes wide each - 2: length << 4 | code in 16 bits (every
-	                              length of the table is below 4096), `cigar` is then NULL until ssv_clip_table_expand has widened them; 4: = cigar */
+	                              length of the table is below 4096; `cigar` is NULL then: read (const uint16_t *)c_cigar + cigar_off[k]); 4: = cigar */
 	int32_t cigar_bytes, pad4;
 } ssv_cluster_table;
 

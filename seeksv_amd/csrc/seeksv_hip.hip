@@ -166,7 +166,6 @@ struct ssv_ctx {
 		std::vector<int32_t> x_tid, x_support, x_ll, x_lr, x_ncig;
 		std::vector<uint8_t> x_side, x_qmiss;
 		std::vector<uint64_t> x_stroff, x_cigoff;
-		std::vector<uint32_t> x_cigar;   // the CIGAR operations widened to 32 bits (cig_bytes == 2)
 		bool expanded = false, ordered = false;
 		hipEvent_t copied = nullptr, started = nullptr; // `started` only with SSV_DEBUG_COPY (times the copy on its stream)
 		hipEvent_t packed_ev = nullptr;                 // the set's pack kernels are done (its copy waits for it): one event per set - a copy that is
@@ -1248,6 +1247,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 	out->tid = P<int32_t>(T.h_tid); out->pos = P<int32_t>(T.h_pos); out->side = P<uint8_t>(T.h_side); out->support = P<int32_t>(T.h_support);
 	out->left_len = P<int32_t>(T.h_ll); out->right_len = P<int32_t>(T.h_lr); out->qual_missing = P<uint8_t>(T.h_qmiss); out->str_off = P<uint64_t>(T.h_stroff);
 	out->str = P<uint8_t>(T.h_str); out->cigar_off = P<uint64_t>(T.h_cigoff); out->n_cigar = P<int32_t>(T.h_ncig); out->cigar = P<uint32_t>(T.h_cig);
+	out->c_cigar = T.h_cig.p; out->cigar_bytes = 4;
 	return SSV_OK;
 }
 
@@ -1257,7 +1257,6 @@ static void table_expanded_view(ssv_ctx::TableSet &T, ssv_cluster_table *out)
 {
 	out->tid = T.x_tid.data(); out->side = T.x_side.data(); out->support = T.x_support.data(); out->left_len = T.x_ll.data(); out->right_len = T.x_lr.data();
 	out->qual_missing = T.x_qmiss.data(); out->n_cigar = T.x_ncig.data(); out->str_off = T.x_stroff.data(); out->cigar_off = T.x_cigoff.data();
-	if (T.cig_bytes == 2) out->cigar = T.x_cigar.data();
 }
 
 } // extern "C"
@@ -1285,13 +1284,6 @@ static void expand_range(ssv_ctx::TableSet &T, int64_t k0, int64_t k1, bool seco
 		ssum = sum;
 		return;
 	}
-	if (T.cig_bytes == 2 && k1 > k0) { // the range's CIGAR operations, widened: they start at the range's first offset
-		const uint16_t *c16 = reinterpret_cast<const uint16_t *>(T.h_cig.p);
-		uint32_t *c32 = T.x_cigar.data();
-		uint64_t ops = 0;
-		for (int64_t k = k0; k < k1; ++k) ops += (uint32_t)x_nc[k];
-		for (uint64_t i = co; i < co + ops; ++i) c32[i] = c16[i];
-	}
 	for (int64_t k = k0; k < k1; ++k) {
 		x_so[k] = so; x_co[k] = co;
 		const uint64_t n = (uint64_t)(uint32_t)x_ll[k] + (uint32_t)x_lr[k];
@@ -1312,7 +1304,6 @@ int ssv_clip_table_expand(ssv_ctx *c, ssv_cluster_table *t, int32_t n_threads)
 	if (n == 0 || T.expanded) { if (n) table_expanded_view(T, t); t->support_sum = T.support_sum; return SSV_OK; }
 	T.x_tid.resize((size_t)n); T.x_side.resize((size_t)n); T.x_support.resize((size_t)n); T.x_ll.resize((size_t)n); T.x_lr.resize((size_t)n); T.x_qmiss.resize((size_t)n);
 	T.x_ncig.resize((size_t)n); T.x_stroff.resize((size_t)n); T.x_cigoff.resize((size_t)n);
-	if (T.cig_bytes == 2) T.x_cigar.resize((size_t)T.cig_ops + 1);
 	const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(n_threads > 0 ? n_threads : (int32_t)effective_cpus()), 64, n / 32768 + 1}));
 	const ssv_table_run *runs = reinterpret_cast<const ssv_table_run *>(T.h_runs.p);
 	const int64_t n_runs = T.n_runs;

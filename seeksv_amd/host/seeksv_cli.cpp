@@ -727,7 +727,7 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 			row += name ? name : ""; row += '\t';
 			row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.pos[k])); row += '\t'; row += (char)t.side[k]; row += '\t';
 			for (int q = 0; q < t.n_cigar[k]; ++q) {
-				uint32_t op = t.cigar[t.cigar_off[k] + q];
+				const uint32_t op = t.cigar ? t.cigar[t.cigar_off[k] + q] : (uint32_t)reinterpret_cast<const uint16_t *>(t.c_cigar)[t.cigar_off[k] + q]; // (compact table: 16 bits an operation)
 				if ((op & 15) == 4 || (op & 15) == 5) continue;
 				row.append(num, (size_t)snprintf(num, sizeof(num), "%u", op >> 4)); row += CIGAR_CHARS[op & 15];
 			}

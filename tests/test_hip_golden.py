@@ -86,7 +86,7 @@ def _compact_checks(ctx, d, ref, t, check_size=True):
     lib = _abi.hip_lib()
     assert all(lib.ssv_table_block_bytes3g(int(a) + int(b), d["base_bits"], d["qual_bits"], d["qual_group"]) ==
                (int(d["str_off"][k + 1]) if k + 1 < n else len(d["str"])) - int(d["str_off"][k]) for k, (a, b) in enumerate(zip(d["left_len"], d["right_len"])))
-    assert np.array_equal(np.ctypeslib.as_array(t.cigar, shape=(len(d["cigar"]),)), d["cigar"])   # (widened by the expand when it crossed PCIe in 16 bits)
+    assert bool(t.cigar) == (d["cigar_bytes"] == 4)   # 16-bit operations are read through c_cigar
     assert d["cigar_bytes"] == (2 if int(d["cigar"].max(initial=0)) < 65536 else 4)
     wire = n * (4 + 2 * d["len_bytes"] + d["support_bytes"] + d["ncig_bytes"] + 1) + len(d["str"]) + d["cigar_bytes"] * len(d["cigar"]) + 16 * len(d["runs"]) + 8 * len(d["base_exc"])
     wire_ascii = n * 42 + len(ref["str"]) + 4 * len(ref["cigar"])
