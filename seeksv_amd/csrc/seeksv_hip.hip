@@ -1063,22 +1063,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
 				static const unsigned p3_blocks = []() { const char *e = getenv("SSV_PACK3_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 10u; }(); // persistent: two rounds of what is resident at once (82 registers: five wavefronts per SIMD = five workgroups per CU); measured best
 				const dim3 gd((unsigned)std::max<int64_t>(1, std::min<int64_t>(p3_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)));
-				// the direct kernel with the lanes packed densely (SSV_PACK3=dense; measured slower, profiles/: twice the requests to the L2): lanes per cluster = the dwords of the pass's longest
-				// read, or that count in two or three rounds where one round would leave too many of the 64 lanes without work
-				const bool dense = direct && getenv("SSV_PACK3") && !strcmp(getenv("SSV_PACK3"), "dense");
-				auto lanes_for = [](int n_dwords) {
-					int best = 16; double best_u = 0;
-					for (int r = 1; r <= 3; ++r) {
-						const int L = std::max(1, std::min(WAVE, (n_dwords + r - 1) / r));
-						const double u = (double)n_dwords / (double)(((n_dwords + L - 1) / L) * L) * (double)((WAVE / L) * L) / WAVE;
-						if (u > best_u + 0.02) { best_u = u; best = L; }
-					}
-					return best;
-				};
-				const int n_fast = std::max(1, std::min(c->max_lq, PACK_MAX_LQ));
-				const int LB = lanes_for((n_fast * T.base_bits + 31) / 32), LQ = lanes_for((int)((qual_stream_bits((uint64_t)n_fast, (uint64_t)T.qual_bits, (uint64_t)T.qual_group) + 31) / 32));
-#define SSV_P3D(W_, B_, K_) do { if (dense) k_pack3_dense<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut), LB, LQ); \
-			else k_pack3_direct<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut)); } while (0)
+#define SSV_P3D(W_, B_, K_) k_pack3_direct<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut))
 #define SSV_P3B(W_, B_, T_) do { if (direct) SSV_P3D(W_, B_, 1); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 				// grouped qualities: the direct kernel knows the two shapes, the staged and the bytewise kernels take the shape at run time (W = 0)

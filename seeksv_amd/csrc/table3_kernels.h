@@ -549,89 +549,6 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 	if (W < 8 && miss) *p.lut_miss = 1;
 }
 
-// ---- the direct kernel with the lanes packed densely (round 4) ----
-//
-// k_pack3_direct gives every cluster 16 lanes: a 150-base read's block is 10 base dwords and 15 (grouped: 11) quality dwords, so 10 + 15 of 32 lane slots
-// work and - the kernel being bound by its vector instructions - a third of the issue cycles compose nothing.  Here the base streams and the quality
-// streams are two loops of their own, each with as many lanes per cluster as the pass's longest read has dwords of that kind (LB, LQ: 10 and 11 for 150
-// bases: six and five clusters per wavefront and round, 60 and 55 of 64 lanes busy); a cluster with more dwords than that (there is none among the
-// reads the pass has seen, the loop is for safety) takes further rounds.  Same two-deep pipeline per loop: descriptor two rounds ahead, source dwords one.
-template <int W, int BB, int K = 1>
-__global__ __launch_bounds__(BLOCK) void k_pack3_dense(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str,
-                                                       const uint16_t *__restrict__ pair_lut, int LB, int LQ)
-{
-	__shared__ uint16_t s_pair[4096];
-	__shared__ uint8_t s_base[256];
-	if (W < 8) {
-		const uint4 *g = reinterpret_cast<const uint4 *>(pair_lut);
-		uint4 *l = reinterpret_cast<uint4 *>(s_pair);
-		l[threadIdx.x] = g[threadIdx.x]; l[threadIdx.x + BLOCK] = g[threadIdx.x + BLOCK]; // 8 KB = 512 x 16 B, BLOCK == 256
-	}
-	if (BB == 2) { // BAM byte -> code(high nibble) | code(low nibble) << 2, bit 7: not both of A, C, G, T
-		const uint32_t hi = threadIdx.x >> 4, lo = threadIdx.x & 15u;
-		const bool ok = __popc(hi) == 1 && __popc(lo) == 1;
-		s_base[threadIdx.x] = ok ? (uint8_t)((uint32_t)(__ffs((int)hi) - 1) | ((uint32_t)(__ffs((int)lo) - 1) << 2)) : (uint8_t)0x80;
-	}
-	__syncthreads();
-	const int lane = lane_id();
-	const int64_t nc = (int64_t)*n_clusters_dev;
-	const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id(), n_waves = (int64_t)gridDim.x * WAVES_PER_BLOCK;
-	uint32_t miss = 0;
-	{ // ---- base streams: LB lanes per cluster ----
-		const int per = WAVE / LB, sub = lane / LB, t0 = lane - sub * LB;
-		const bool on = sub < per;
-		const int64_t step = n_waves * per;
-		int64_t c = wave * per + sub, first = wave * per; // this lane's cluster; the round's first
-		auto dwords = [](const PackDescR &d) { return pack_desc_fast(d) ? ((d.ll + d.lr) * BB + 31) / 32 : 0; };
-		auto issue = [&](const PackDescR &d, uint32_t (&w)[3]) { w[0] = w[1] = w[2] = 0u; if (t0 < dwords(d)) src3_load_bases<W, BB>(d, t0, w); };
-		PackDescR d0 = pack_desc_load(desc, on ? c : nc, nc), d1 = pack_desc_load(desc, on ? c + step : nc, nc);
-		uint32_t w0[3], w1[3];
-		issue(d0, w0);
-		for (; first < nc; first += step, c += step) {
-			const PackDescR d2 = pack_desc_load(desc, on ? c + 2 * step : nc, nc);
-			issue(d1, w1);
-			const int nDb = dwords(d0);
-			uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
-			if (t0 < nDb) d[t0] = base_dword3<BB>(q, s_base, d0, c, t0, w0);
-			for (int t = t0 + LB; t < nDb; t += LB) { uint32_t w[3]; src3_load_bases<W, BB>(d0, t, w); d[t] = base_dword3<BB>(q, s_base, d0, c, t, w); }
-			d0 = d1; d1 = d2; w0[0] = w1[0]; w0[1] = w1[1]; w0[2] = w1[2];
-		}
-	}
-	{ // ---- quality streams: LQ lanes per cluster ----
-		constexpr int NR = Q3<W, K>::NSRC + 1;
-		const int per = WAVE / LQ, sub = lane / LQ, t0 = lane - sub * LQ;
-		const bool on = sub < per;
-		const int64_t step = n_waves * per;
-		int64_t c = wave * per + sub, first = wave * per;
-		const uint32_t qfill = p.qual_fill, qradix = (uint32_t)p.qual_radix;
-		auto qual_dword = [&](const PackDescR &d, int64_t cc, int t, const uint32_t (&raw)[NR]) {
-			if constexpr (K > 1) return qual_dword3g<W, K>(q, s_pair, d, cc, t, raw, miss, qfill, qradix);
-			else return qual_dword3<W>(q, s_pair, d, cc, t, raw, miss);
-		};
-		auto dwords = [](const PackDescR &d) { return pack_desc_fast(d) ? Q3<W, K>::dwords(d.ll + d.lr) : 0; };
-		auto issue = [&](const PackDescR &d, uint32_t (&raw)[NR]) {
-#pragma unroll
-			for (int g = 0; g < NR; ++g) raw[g] = 0u;
-			if (t0 < dwords(d)) src3_load_quals<W, BB, K>(d, t0, raw);
-		};
-		PackDescR d0 = pack_desc_load(desc, on ? c : nc, nc), d1 = pack_desc_load(desc, on ? c + step : nc, nc);
-		uint32_t r0[NR], r1[NR];
-		issue(d0, r0);
-		for (; first < nc; first += step, c += step) {
-			const PackDescR d2 = pack_desc_load(desc, on ? c + 2 * step : nc, nc);
-			issue(d1, r1);
-			const int nDq = dwords(d0);
-			uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off) + (pack_desc_fast(d0) ? ((d0.ll + d0.lr) * BB + 31) / 32 : 0);
-			if (t0 < nDq) d[t0] = qual_dword(d0, c, t0, r0);
-			for (int t = t0 + LQ; t < nDq; t += LQ) { uint32_t raw[NR]; src3_load_quals<W, BB, K>(d0, t, raw); d[t] = qual_dword(d0, c, t, raw); }
-			d0 = d1; d1 = d2;
-#pragma unroll
-			for (int g = 0; g < NR; ++g) r0[g] = r1[g];
-		}
-	}
-	if (W < 8 && miss) *p.lut_miss = 1;
-}
-
 // The base-by-base path: the slots of multi-event bins (mlist; those without a cluster leave at once: consensus storage, left part kept
 // reversed), then the listed single-event clusters of reads longer than PACK_MAX_LQ.
 template <int W, int BB, bool TRACK>
