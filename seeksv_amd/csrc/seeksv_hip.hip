@@ -1061,9 +1061,18 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			if (fmt3) {
 				// one group of lanes per cluster (the grid is an upper bound, the kernel reads the cluster count itself), then the base-by-base path
 				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
-				static const unsigned p3_blocks = []() { const char *e = getenv("SSV_PACK3_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 10u; }(); // persistent: two rounds of what is resident at once (82 registers: five wavefronts per SIMD = five workgroups per CU); measured best
+				static const unsigned p3_blocks = []() { const char *e = getenv("SSV_PACK3_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 40u; }(); // persistent (80 registers: six workgroups per CU resident); 2560 / 5120 / 10240 / 20480 workgroups measured in round 4: 1.20 / 1.18 / 1.14 / 1.16 ms for the group
 				const dim3 gd((unsigned)std::max<int64_t>(1, std::min<int64_t>(p3_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)));
-#define SSV_P3D(W_, B_, K_) k_pack3_direct<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut))
+				// lanes per cluster of the direct kernel: as many as the longest read's base / quality stream has dwords, rounded up to the next whole share of a wavefront
+				// (150 bases, grouped qualities: 11 -> 12 lanes, five clusters a wavefront); streams of more than 32 dwords take 16 lanes and several rounds
+				int lpc = 16;
+				{
+					const int n_fast = std::max(1, std::min(c->max_lq, PACK_MAX_LQ));
+					const int nd = std::max((n_fast * T.base_bits + 31) / 32, (int)((qual_stream_bits((uint64_t)n_fast, (uint64_t)T.qual_bits, (uint64_t)T.qual_group) + 31) / 32));
+					if (nd <= 32) lpc = WAVE / (WAVE / nd);
+					if (const char *e = getenv("SSV_PACK3_LANES")) lpc = std::max(1, std::min(WAVE, atoi(e)));
+				}
+#define SSV_P3D(W_, B_, K_) k_pack3_direct<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut), lpc)
 #define SSV_P3B(W_, B_, T_) do { if (direct) SSV_P3D(W_, B_, 1); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 				// grouped qualities: the direct kernel knows the two shapes, the staged and the bytewise kernels take the shape at run time (W = 0)

@@ -486,13 +486,13 @@ __device__ __forceinline__ uint32_t qual_dword3g(const Pack3Args &q, const uint1
 	return qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
 }
 
-// Persistent grid; every group of 16 lanes walks its clusters with a two-deep software pipeline: while the dwords of cluster i are composed
+// Persistent grid; every group of LPC lanes walks its clusters with a two-deep software pipeline: while the dwords of cluster i are composed
 // and stored, the source dwords of cluster i + 1 and the descriptor of cluster i + 2 are on their way (a cluster is descriptor -> source
 // bytes -> output: two dependent trips to memory that a wavefront would otherwise sit out; at eight wavefronts per SIMD that wait,
 // not the instructions, is what the unpipelined form spends its time on).
 template <int W, int BB, int K = 1>
 __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str,
-                                                        const uint16_t *__restrict__ pair_lut)
+                                                        const uint16_t *__restrict__ pair_lut, int LPC)
 {
 	__shared__ uint16_t s_pair[4096];
 	__shared__ uint8_t s_base[256];
@@ -507,11 +507,16 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 		s_base[threadIdx.x] = ok ? (uint8_t)((uint32_t)(__ffs((int)hi) - 1) | ((uint32_t)(__ffs((int)lo) - 1) << 2)) : (uint8_t)0x80;
 	}
 	__syncthreads();
-	const int grp = (int)(threadIdx.x / GROUP);
-	const int gl = (int)(threadIdx.x % GROUP);
+	// LPC lanes per cluster (the host picks it from the dwords of the pass's longest read: 12 for 150 bases with grouped qualities - five clusters per wavefront
+	// and round instead of the four that 16 lanes each give: the kernel is bound by its vector instructions, and a round costs the same however many lanes work)
+	const int lane = lane_id(), per = WAVE / LPC;
+	const int grp = lane / LPC, gl = lane - grp * LPC;
+	const bool on = grp < per;
 	const int64_t nc = (int64_t)*n_clusters_dev;
-	const int64_t step = (int64_t)gridDim.x * GROUPS_PER_BLOCK;
-	int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
+	const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
+	const int64_t step = (int64_t)gridDim.x * WAVES_PER_BLOCK * per;
+	int64_t c = on ? wave * per + grp : (int64_t)1 << 40; // (lanes without a cluster: beyond every table, so that their descriptors come back empty)
+	int64_t first = wave * per;                          // the first cluster of the wavefront's round
 	uint32_t miss = 0;
 	auto counts = [](const PackDescR &d, int &nDb, int &nDq) {
 		const int n = d.ll + d.lr;
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 		else return qual_dword3<W>(q, s_pair, d, cc, t, raw, miss);
 	};
 	issue(d0, S0);
-	for (; c < nc; c += step) {
+	for (; first < nc; first += step, c += step) {
 		const PackDescR d2 = pack_desc_load(desc, c + 2 * step, nc);
 		issue(d1, S1);
 		int nDb, nDq; counts(d0, nDb, nDq);
@@ -542,8 +547,8 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 		if (gl < nDb) d[gl] = base_dword3<BB>(q, s_base, d0, c, gl, S0.w);
 		if (gl < nDq) d[nDb + gl] = qual_dword(d0, c, gl, S0.raw);
 		// clipped sequences longer than one round of the group (2-bit bases: 256; 3-bit qualities: 170): the rest, unpipelined
-		for (int t = gl + GROUP; t < nDb; t += GROUP) { uint32_t w[3]; src3_load_bases<W, BB>(d0, t, w); d[t] = base_dword3<BB>(q, s_base, d0, c, t, w); }
-		for (int t = gl + GROUP; t < nDq; t += GROUP) { uint32_t raw[Q3<W, K>::NSRC + 1]; src3_load_quals<W, BB, K>(d0, t, raw); d[nDb + t] = qual_dword(d0, c, t, raw); }
+		for (int t = gl + LPC; t < nDb; t += LPC) { uint32_t w[3]; src3_load_bases<W, BB>(d0, t, w); d[t] = base_dword3<BB>(q, s_base, d0, c, t, w); }
+		for (int t = gl + LPC; t < nDq; t += LPC) { uint32_t raw[Q3<W, K>::NSRC + 1]; src3_load_quals<W, BB, K>(d0, t, raw); d[nDb + t] = qual_dword(d0, c, t, raw); }
 		d0 = d1; d1 = d2; S0 = S1;
 	}
 	if (W < 8 && miss) *p.lut_miss = 1;
