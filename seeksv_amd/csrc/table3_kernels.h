@@ -599,10 +599,16 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 	};
 	constexpr int PER = 32 / BB;
 	const int nDb = (n * BB + 31) / 32, nDq = (int)((qual_stream_bits((uint64_t)n, W ? (uint64_t)W : (uint64_t)p.qual_bits, W ? 1ull : (uint64_t)p.qual_group) + 31) / 32);
+	// (all of a dword's byte loads first, then the look-ups: a loop that stops at the stream's end makes every load wait for the one before - the kernel's time was
+	// the latency of sixteen loads in a row, 0.12 ms for the 28 K clusters of a step's multi-event bins)
 	for (int t = gl; t < nDb; t += GROUP) {
-		uint32_t word = 0;
-		for (int k = 0; k < PER && PER * t + k < n; ++k) {
-			const uint32_t code = code_at(PER * t + k);
+		uint32_t word = 0, codes[PER];
+#pragma unroll
+		for (int k = 0; k < PER; ++k) codes[k] = PER * t + k < n ? code_at(PER * t + k) : 1u; // (behind the end: 'A', cut off below)
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const uint32_t code = codes[k];
+			if (PER * t + k >= n) continue;
 			if (BB == 4) word |= code << (4 * k);
 			else if (code == 1u || code == 2u || code == 4u || code == 8u) word |= (uint32_t)(__ffs((int)code) - 1) << (2 * k);
 			else exc_append(q, (uint64_t)sc.c, PER * t + k, code);
@@ -612,14 +618,24 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 	for (int t = gl; t < nDq; t += GROUP) {
 		uint32_t word = 0;
 		if constexpr (W == 0) { // grouped qualities (shape at run time)
-			if (!qm) {
-				const int B = p.qual_bits, K = p.qual_group;
-				const int g0 = (32 * t) / B, off = 32 * t - B * g0;
+			if (!qm) { // the (up to 18) qualities whose groups touch the dword: all loads first; a group's number is a sum, so its terms go into the stream one by one
+				const int B = p.qual_bits, K = p.qual_group; // K is 2 or 3 (set_alphabet, seeksv_hip.hip)
+				const uint32_t R = (uint32_t)p.qual_radix;
+				const int g0 = (32 * t) / B, off = 32 * t - B * g0, i0 = K * g0;
+				uint32_t ph[18];
+#pragma unroll
+				for (int jq = 0; jq < 18; ++jq) ph[jq] = i0 + jq < n && (K == 3 || jq < 12) ? phred_at(i0 + jq) : 0xffffffffu;
 				uint64_t acc = 0;
 				uint32_t miss = 0;
-				for (int g = g0; B * g < 32 * t + 32 && K * g < n; ++g)
-					acc |= (uint64_t)qual_group_code(s_lut, K, (uint32_t)p.qual_radix, K * g, n, miss, phred_at, [&](uint32_t ph) {
-						if (TRACK) { const uint32_t bit = 1u << (ph & 31); if (!(atomicOr(&s_seen[ph >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph >> 5], bit); } }) << (B * (g - g0));
+#pragma unroll
+				for (int jq = 0; jq < 18; ++jq) {
+					if (ph[jq] == 0xffffffffu) continue;
+					const int g = K == 3 ? jq / 3 : jq / 2, j = K == 3 ? jq % 3 : jq % 2;
+					if (TRACK) { const uint32_t bit = 1u << (ph[jq] & 31); if (!(atomicOr(&s_seen[ph[jq] >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph[jq] >> 5], bit); }
+					const uint32_t idx = s_lut[ph[jq]];
+					miss |= idx;
+					acc += (uint64_t)((idx & 15u) * (j == 0 ? 1u : j == 1 ? R : R * R)) << (B * g);
+				}
 				if (miss & 0x80u) *p.lut_miss = 1;
 				word = (uint32_t)(acc >> off);
 			}
@@ -627,9 +643,15 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 			for (int k = 0; k < 4 && 4 * t + k < n; ++k) word |= (qm ? 0x2au : phred_at(4 * t + k) + 33u) << (8 * k);
 		} else if (!qm) {
 			const int i0 = (32 * t) / W, off = 32 * t - W * i0;
+			constexpr int CNT = W == 3 ? 12 : 32 / W; // qualities that can touch one dword
+			uint32_t phs[CNT];
+#pragma unroll
+			for (int jq = 0; jq < CNT; ++jq) phs[jq] = i0 + jq < n && W * jq < off + 32 ? phred_at(i0 + jq) : 0xffffffffu;
 			uint64_t acc = 0;
-			for (int jq = 0, i = i0; W * jq < off + 32 && i < n; ++jq, ++i) {
-				const uint32_t ph = phred_at(i);
+#pragma unroll
+			for (int jq = 0; jq < CNT; ++jq) {
+				const uint32_t ph = phs[jq];
+				if (ph == 0xffffffffu) continue;
 				if (TRACK) {
 					const uint32_t bit = 1u << (ph & 31);
 					if (!(atomicOr(&s_seen[ph >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph >> 5], bit); // the first time this workgroup meets the value

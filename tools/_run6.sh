@@ -1,0 +1,1 @@
+timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -6
