@@ -1061,6 +1061,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			if (fmt3) {
 				// one group of lanes per cluster (the grid is an upper bound, the kernel reads the cluster count itself), then the base-by-base path
 				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
+				const dim3 gs3(grid_for(std::max<int64_t>(M + c->n_long, 1), BLOCK)); // k_pack3_slow: an item per lane (a wavefront then works off the ones with a cluster)
 				static const unsigned p3_blocks = []() { const char *e = getenv("SSV_PACK3_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 40u; }(); // persistent (80 registers: six workgroups per CU resident); 2560 / 5120 / 10240 / 20480 workgroups measured in round 4: 1.20 / 1.18 / 1.14 / 1.16 ms for the group
 				const dim3 gd((unsigned)std::max<int64_t>(1, std::min<int64_t>(p3_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)));
 				// lanes per cluster of the direct kernel: as many as the longest read's base / quality stream has dwords, rounded up to the next whole share of a wavefront
@@ -1074,11 +1075,11 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				}
 #define SSV_P3D(W_, B_, K_) k_pack3_direct<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut), lpc)
 #define SSV_P3B(W_, B_, T_) do { if (direct) SSV_P3D(W_, B_, 1); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
-			k_pack3_slow<W_, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
+			k_pack3_slow<W_, B_, T_><<<gs3, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 				// grouped qualities: the direct kernel knows the two shapes, the staged and the bytewise kernels take the shape at run time (W = 0)
 #define SSV_P3G(B_, T_) do { if (direct) { if (pa.qual_group == 3) SSV_P3D(7, B_, 3); else SSV_P3D(7, B_, 2); } \
 			else k_pack3_stream<0, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
-			k_pack3_slow<0, B_, T_><<<gs, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
+			k_pack3_slow<0, B_, T_><<<gs3, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 #define SSV_P3GT(T_) do { if (T.base_bits == 2) SSV_P3G(2, T_); else SSV_P3G(4, T_); } while (0)
 #define SSV_P3T(W_, T_) do { if (T.base_bits == 2) SSV_P3B(W_, 2, T_); else SSV_P3B(W_, 4, T_); } while (0)
 #define SSV_P3(W_) do { if (track) SSV_P3T(W_, true); else SSV_P3T(W_, false); } while (0)
