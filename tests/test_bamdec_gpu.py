@@ -297,10 +297,11 @@ def test_resolve_in_lds_mode():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("mode", ["wave", "lanes16"])
+@pytest.mark.parametrize("mode", ["wave", "lanes16", "win"])
 def test_resolve_modes(mode):
     """Pass 2 of the inflate has two forms in global memory: a wavefront per BGZF block (k_bgzf_resolve_wave: rounds of 64 tokens, the earlier holes a source
-    touches as a lane range found by binary search, readiness by one AND with the ballot of the open lanes) and 16 lanes per block (k_bgzf_resolve).  Both,
+    touches as a lane range found by binary search, readiness by one AND with the ballot of the open lanes) and 16 lanes per block (k_bgzf_resolve) - and the
+    wavefront form with a window of the block in LDS (k_bgzf_resolve_win: the round's bytes in and out with coalesced 16-byte accesses, matches copied inside the window).  All,
     forced, through the same device-decode == host-reader checks: every match shape (near, far, overlapping its own hole, 3..258 bytes), every kind of deflate
     block, records and blocks straddling chunks, damaged input"""
     import subprocess

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -64,13 +65,15 @@ static void run(uint8_t *buf, uint32_t mask_lines, int active, int waves_per_cu,
 	       waves_per_cu, ms * 1e6 / (instr / 256), ms * 1e6 / (instr / 256) * 2.4, instr * active / (ms * 1e-3) / 1e9);
 }
 
-int main()
+int main(int argc, char **argv)
 {
 	uint8_t *buf; unsigned *out;
-	const size_t bytes = 16u << 20;
+	// buffer size in KB (default 16 MB: larger than one XCD's 4 MB L2, inside the Infinity Cache; 1024: every XCD's L2 holds it; 16: a CU's L1 does)
+	const size_t bytes = (size_t)(argc > 1 ? atol(argv[1]) : 16384) << 10;
 	hipMalloc(&buf, bytes + 4096); hipMalloc(&out, 4);
 	hipMemset(buf, 1, bytes + 4096);
 	const uint32_t mask_lines = (uint32_t)(bytes / 64 - 1);
+	printf("buffer %zu KB\n", bytes >> 10);
 	for (int wpc : {8, 32})
 		for (int active : {1, 4, 16, 64}) {
 			run<4, false>(buf, mask_lines, active, wpc, out);
