@@ -274,15 +274,16 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve_wave(const uint32_t *__r
 }
 
 // ---- pass 2 with a window of the block in LDS, a wavefront per block (round 4, late; resolve_wave.h) ---------------------------------------
+template <bool DBG>
 __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve_win(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
-                                                            const BgzfBlock *__restrict__ blocks, int64_t n_blocks, uint8_t *out)
+                                                            const BgzfBlock *__restrict__ blocks, int64_t n_blocks, uint8_t *out, unsigned long long *dbg)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_win[WAVES_PER_BLOCK][RW_WIN + 64];
 	const int64_t b = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
 	if (b >= n_blocks) return;
 	const uint32_t n = n_tok[b];
 	if (n == 0u) return;
-	wave_resolve_tokens_win(out + u_off[b], blocks[b].u_len, tokens + tok_off[b], n, s_win[wave_id()], lane_id());
+	wave_resolve_tokens_win<DBG>(out + u_off[b], blocks[b].u_len, tokens + tok_off[b], n, s_win[wave_id()], lane_id(), dbg);
 }
 
 // ---- pass 2 with the block in LDS -----------------------------------------------------------------------------------------------------
