@@ -157,3 +157,58 @@ def test_mapped_chunks_equal_copied_chunks(bam):
         for (d0, b0), (d1, b1) in zip(*chunks):
             assert b0 == b1 and d0 == d1
         assert sum(len(d) for d, _ in chunks[1]) in (size, size - 28)  # (the end-of-file block may or may not be part of the last chunk)
+
+
+def _block_table_digest(path):
+    """sha256 over the block tables of the file read as ONE chunk (ssvh_bam_read_blocks), and the number of blocks"""
+    import ctypes as C
+    import hashlib
+    from seeksv_amd import _abi
+    lib = _abi.host_lib()
+    size = os.path.getsize(path)
+    h = C.c_void_p()
+    assert lib.ssvh_bam_open(path.encode(), C.byref(h)) == 0
+    first = C.c_uint64()
+    assert lib.ssvh_bam_raw_begin(h, C.byref(first)) == 0
+    max_blocks = size // 64 + 16
+    blocks = (_abi.BgzfBlock * max_blocks)()
+    buf = (C.c_uint8 * (size + 64))()
+    dig, n = hashlib.sha256(), 0
+    while True:
+        nb, nbytes = C.c_int64(), C.c_size_t()
+        assert lib.ssvh_bam_read_blocks(h, buf, size + 64, 1 << 40, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) == 0, lib.ssvh_last_error()
+        if nb.value == 0:
+            break
+        dig.update(np.ctypeslib.as_array(C.cast(blocks, C.POINTER(C.c_uint8)), shape=(nb.value * C.sizeof(_abi.BgzfBlock),)).tobytes())
+        dig.update(bytes(buf[:nbytes.value])[-64:])
+        n += nb.value
+    lib.ssvh_bam_close(h)
+    return dig.hexdigest(), n
+
+
+def test_parallel_header_walk_equals_serial_walk(tmp_path):
+    """ssvh_bam_read_blocks finds the headers of a chunk's BGZF blocks with all host threads at once (every thread looks for the first block that begins in
+    its segment and walks to the next segment; segments are taken over as far as they join) - on a file large enough for that path the block table is the one
+    the one-block-after-the-other walk (SSV_WALK=serial, in a process of its own) makes"""
+    import subprocess
+    import sys
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 2048, depth=30, n_sv=4)
+    path = str(tmp_path / "walk.bam")
+    old = os.environ.get("SSV_BGZF_LEVEL")
+    os.environ["SSV_BGZF_LEVEL"] = "1"
+    try:
+        host.write_bam(path, w.names, w.lens, [w.generate_host(0, w.n_total, all_seq=True)])
+    finally:
+        if old is None:
+            os.environ.pop("SSV_BGZF_LEVEL", None)
+        else:
+            os.environ["SSV_BGZF_LEVEL"] = old
+    assert os.path.getsize(path) > (20 << 20)   # (the parallel walk starts at 16 MB of chunk)
+    par = _block_table_digest(path)
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_bam_reader as t; print(*t._block_table_digest(%r))" % (
+        os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSV_WALK="serial"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ser = r.stdout.split()
+    assert (ser[0], int(ser[1])) == par and par[1] > 1000
