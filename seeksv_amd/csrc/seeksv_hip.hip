@@ -120,6 +120,11 @@ struct ssv_ctx {
 	hipStream_t st = nullptr;
 	std::string err;
 
+	// ssv_batch_retain's memory: batches are cut out of arenas (a few large allocations instead of one per batch - with 320 batches of a whole-genome file kept,
+	// `seeksv run` spent 0.9 s in allocations that grew slower with every one; an arena is given back when its last batch is released)
+	struct RetainArena { uint8_t *base = nullptr; size_t cap = 0, used = 0; int64_t live = 0; };
+	std::vector<RetainArena> arenas;
+
 	// staging of host batches, and the record lines built for batches that come without them
 	// host batches are copied into one of three staging sets: 0 and 1 take the batches announced with ssv_batch_prefetch (copied on st_h2d while
 	// the kernels of the batch before run on st), 2 the ones that come unannounced (copied on st itself)
@@ -538,6 +543,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
+	for (auto &a : c->arenas) if (a.base) (void)hipFree(a.base);
 	for (auto &S : c->ss) {
 		for (DBuf &b : S.col) if (b.p) (void)hipFree(b.p);
 		if (S.rec.p) (void)hipFree(S.rec.p);
@@ -790,10 +796,25 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 		if (!runs) { c->err = "out of host memory (tid_runs)"; return SSV_E_NOMEM; }
 		memcpy(runs, b->tid_runs, (size_t)b->n_tid_runs * sizeof(ssv_tid_run));
 	}
-	struct Guard { uint8_t *&slab; ssv_tid_run *&runs; bool keep = false; ~Guard() { if (!keep) { if (slab) (void)hipFree(slab); free(runs); } } } guard{slab, runs};
+	ssv_ctx::RetainArena *arena = nullptr;
+	struct Guard { ssv_ctx::RetainArena *&arena; size_t need; ssv_tid_run *&runs; bool keep = false; ~Guard() { if (!keep) { if (arena) { --arena->live; arena->used -= need; } free(runs); } } } guard{arena, off[7], runs};
 	static const bool timing = getenv("SSV_TIMING_CHUNKS") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
-	HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&slab), off[7])); // (0.2 ms for 8 GB, tools/malloc_rate.cpp: nothing to hide)
+	{ // room in the newest arena, or a new one: 256 MB first, doubling up to SSV_RETAIN_ARENA_MB (4 GB), never smaller than the batch
+		if (!c->arenas.empty() && c->arenas.back().cap - c->arenas.back().used >= off[7]) arena = &c->arenas.back();
+		else {
+			static const size_t arena_max = []() { const char *e = getenv("SSV_RETAIN_ARENA_MB"); return (size_t)(e ? atoll(e) : 4096) << 20; }();
+			size_t cap = c->arenas.empty() ? (size_t)256 << 20 : std::min(arena_max, c->arenas.back().cap * 2);
+			if (cap < off[7]) cap = off[7];
+			ssv_ctx::RetainArena a;
+			HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&a.base), cap));
+			a.cap = cap;
+			c->arenas.push_back(a);
+			arena = &c->arenas.back();
+		}
+		slab = arena->base + arena->used;
+		arena->used += off[7]; ++arena->live; // (off[] are multiples of 256: every batch starts 256-byte aligned)
+	}
 	const auto t1 = std::chrono::steady_clock::now();
 	const void *src[7] = {d.tid, d.pos, d.n_cigar, d.ends, d.rec, d.cigar, d.seqqual};
 	const size_t bytes[7] = {n * 4, n * 4, n * 2, n, n * sizeof(ssv_record), (size_t)b->n_cigar_total * 4, (size_t)b->seqqual_bytes};
@@ -821,7 +842,16 @@ int ssv_batch_release(ssv_ctx *c, ssv_batch_t *b)
 	if (b->mem != (SSV_MEM_DEVICE | SSV_MEM_PERSISTENT) || !b->tid) { c->err = "not a batch of ssv_batch_retain"; return SSV_E_ARG; }
 	HIPCHECK(c, hipSetDevice(c->device));
 	HIPCHECK(c, hipStreamSynchronize(c->st));
-	HIPCHECK(c, hipFree(const_cast<int32_t *>(b->tid))); // the slab starts with the tid column
+	{ // the batch's arena (the slab starts with the tid column): given back to the device when its last batch goes, unless it is the newest one - that one starts over
+		const uint8_t *at = reinterpret_cast<const uint8_t *>(b->tid);
+		size_t k = 0;
+		while (k < c->arenas.size() && !(at >= c->arenas[k].base && at < c->arenas[k].base + c->arenas[k].cap)) ++k;
+		if (k == c->arenas.size()) { c->err = "not a batch of ssv_batch_retain (no arena holds it)"; return SSV_E_ARG; }
+		if (--c->arenas[k].live == 0) {
+			if (k + 1 == c->arenas.size()) c->arenas[k].used = 0;
+			else { HIPCHECK(c, hipFree(c->arenas[k].base)); c->arenas.erase(c->arenas.begin() + (long)k); }
+		}
+	}
 	free(const_cast<ssv_tid_run *>(b->tid_runs));
 	memset(b, 0, sizeof(*b));
 	return SSV_OK;
