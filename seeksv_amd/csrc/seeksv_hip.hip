@@ -804,7 +804,7 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 		if (!c->arenas.empty() && c->arenas.back().cap - c->arenas.back().used >= off[7]) arena = &c->arenas.back();
 		else {
 			static const size_t arena_max = []() { const char *e = getenv("SSV_RETAIN_ARENA_MB"); return (size_t)(e ? atoll(e) : 4096) << 20; }();
-			size_t cap = c->arenas.empty() ? (size_t)256 << 20 : std::min(arena_max, c->arenas.back().cap * 2);
+			size_t cap = c->arenas.empty() ? std::min(arena_max, (size_t)256 << 20) : std::min(arena_max, c->arenas.back().cap * 2);
 			if (cap < off[7]) cap = off[7];
 			ssv_ctx::RetainArena a;
 			HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&a.base), cap));
