@@ -147,7 +147,10 @@ constexpr uint32_t RW_WIN = RW_WIN_BYTES;        // window bytes per wavefront
 constexpr uint32_t RW_KEEP = RW_KEEP_BYTES;      // history kept in front of the round when the window moves
 constexpr uint32_t RW_ROUND = RW_WIN - RW_KEEP - 64; // bytes of a round
 constexpr uint32_t RW_SKIP = 256;                // literals in front of a round's first match beyond this are stepped over
-constexpr uint32_t RW_SMALL = 79;                // a match of up to this many bytes is copied by its own lane (four whole 16-byte pieces and one that ends with the match)
+#ifndef RW_SMALL_BYTES
+#define RW_SMALL_BYTES 79
+#endif
+constexpr uint32_t RW_SMALL = RW_SMALL_BYTES;    // a match of up to this many bytes is copied by its own lane (four whole 16-byte pieces and one that ends with the match)
 static_assert(RW_KEEP + RW_ROUND + 64 <= RW_WIN && RW_ROUND >= 1024 && RW_KEEP % 16 == 0, "a round and its history fit the window");
 
 __device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)p; } // (the low half of a shared pointer is the LDS address)
