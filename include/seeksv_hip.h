@@ -395,7 +395,8 @@ int ssv_getsv_finish(ssv_ctx *ctx, int32_t *counts,
  * One context per GPU, one host thread per context.  Each rank scans its own run of records (libseeksv_host's ssvh_bam_partition cuts the
  * file) for ALL junctions and windows; the per-rank result vectors - discordant counts, depth sums, point depths: KBs to a few MB - are
  * all-gathered and added up by every rank.  RCCL (ncclAllGather over xGMI, loaded on first use) when the ranks sit on different GPUs;
- * ranks that share a GPU (tests on a one-GPU box) exchange through host memory. */
+ * ranks that share a GPU (tests on a one-GPU box) exchange through host memory.  SSV_GROUP_RCCL_ONE=1 makes a group of ONE rank an RCCL
+ * communicator as well (ncclCommInitAll over one device), so that the RCCL branch runs end to end where there is a single GPU. */
 typedef struct ssv_group ssv_group;
 int ssv_group_create(ssv_ctx **ctxs, int n, ssv_group **out);
 void ssv_group_destroy(ssv_group *g);
@@ -405,7 +406,8 @@ int ssv_group_uses_rccl(const ssv_group *g);
  * bring vectors of one size; a rank whose ncclAllGather fails aborts the group's communicators (ncclCommAbort) so that its peers come back;
  * a rank that does not arrive within SSV_GROUP_TIMEOUT_S (default 600) breaks the group.  In every such case EVERY rank returns an error
  * (SSV_E_HIP / SSV_E_ARG for the rank at fault, SSV_E_STATE for the others) and nothing in `recv` may be used; after an abort or a timeout
- * the group only answers SSV_E_STATE.  (SSV_GROUP_FAIL=<rank>:<1|2> injects a failure before / inside the exchange: tests.) */
+ * the group only answers SSV_E_STATE.  (SSV_GROUP_FAIL=<rank>:<1|2|3> injects a failure before the exchange / in the
+ * collective's call / behind an issued collective: tests.) */
 int ssv_group_allgather(ssv_group *g, int rank, const void *send, size_t bytes, void *recv);
 
 /* ---- device-side BGZF inflate + BAM record decode ---------------------------- */

@@ -1216,8 +1216,11 @@ static int cmd_getsv(int argc, char **argv)
 	int mean_insert_size = 0, deviation = 0;
 	const bool do_discordant = read_pair_used >= 100000; // seeksv.cpp:246
 	IsizeCarry carry;
+	// SSV_GROUP_RCCL_ONE=1: `-N 1` takes the ranks' path too - one run of records, its vector through a one-rank RCCL communicator (what a
+	// one-GPU box can execute of the exchange)
+	const bool ranks_path = n_ranks > 1 || getenv("SSV_GROUP_RCCL_ONE");
 	if (do_discordant) {
-		insert_size_pass(get_ctx, original_bam, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation, n_ranks == 1 ? &carry : nullptr);
+		insert_size_pass(get_ctx, original_bam, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation, !ranks_path ? &carry : nullptr);
 		cerr << "'CalculateInsertsizeDeviation' finished" << endl;
 	} else min_abnormal_read_pair_no = 0; // seeksv.cpp:285
 	get_ctx();
@@ -1241,7 +1244,7 @@ static int cmd_getsv(int argc, char **argv)
 	pt.lap("plan");
 	vector<int32_t> counts((size_t)nj + 1, 0), pdepth((size_t)np + 1, 0);
 	vector<uint64_t> rsum((size_t)nr + 1, 0);
-	if ((do_discordant || output_depth) && n_ranks > 1) {
+	if ((do_discordant || output_depth) && ranks_path) {
 		// ---- N runs of records, one per GPU: every rank scans its own records for ALL junctions and windows; the partial tallies, depth sums
 		//      and point depths of the ranks meet in one all-gather (RCCL over xGMI between different GPUs) and are added up.  A rank replays
 		//      the records before its run through the pileup's read-cap bookkeeping first (ssv_getsv_prime). ----

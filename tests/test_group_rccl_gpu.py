@@ -1,6 +1,7 @@
 """-m gpu: the one exchange step of a range-partitioned run (ssv_group_*, include/seeksv_hip.h) over REAL devices: with two or more GPUs the
-group is an RCCL communicator (ncclCommInitAll) and the ranks' vectors meet in ncclAllGather over xGMI; on a one-GPU box the test is
-skipped (tests/test_cli_ranks_gpu.py covers the host-memory exchange of ranks that share a GPU)."""
+group is an RCCL communicator (ncclCommInitAll) and the ranks' vectors meet in ncclAllGather over xGMI; on a one-GPU box the group is ONE
+rank under SSV_GROUP_RCCL_ONE=1, which is still an RCCL communicator: dlopen, ncclCommInitAll, ncclAllGather, the polled stream, the copy
+back, ncclCommAbort and ncclCommDestroy all run (tests/test_cli_ranks_gpu.py covers the host-memory exchange of ranks that share a GPU)."""
 import ctypes as C
 import threading
 
@@ -29,11 +30,11 @@ def _group(lib, devices):
 
 
 @pytest.mark.parametrize("n_bytes", [0, 8, 4096, 3 * 1024 * 1024 + 5])
-def test_allgather_over_rccl(n_bytes):
+def test_allgather_over_rccl(n_bytes, monkeypatch):
     lib = _abi.hip_lib()
     n_dev = lib.ssv_device_count()
     if n_dev < 2:
-        pytest.skip("one GPU: RCCL cannot put two ranks on one device")
+        monkeypatch.setenv("SSV_GROUP_RCCL_ONE", "1")   # RCCL cannot put two ranks on one device: a communicator of one
     n = min(n_dev, 8)
     ctxs, g = _group(lib, list(range(n)))
     try:
@@ -74,6 +75,43 @@ def _run_ranks(lib, g, n, sizes, skip=()):
     return rcs, recv, any(t.is_alive() for t in th)
 
 
+def drop_group(lib, ctxs, g):
+    lib.ssv_group_destroy(g)
+    for h in ctxs:
+        lib.ssv_ctx_destroy(h)
+
+
+def _one_rank_rccl_failures(lib, fresh, drop, E_HIP, E_STATE):
+    """what a communicator of one rank can show of the failure paths: the injected failures of every stage, ncclCommAbort on a live
+    communicator (before and behind an issued collective), the broken group's answer afterwards, and a working exchange in between"""
+    # a failure before the exchange: reported, nothing aborted, the group works afterwards
+    ctxs, g = fresh(SSV_GROUP_FAIL="0:1")
+    assert lib.ssv_group_uses_rccl(g) == 1
+    rcs, _, hung = _run_ranks(lib, g, 1, [512])
+    assert not hung and rcs == [E_HIP] and "injected" in _err(lib, ctxs[0])
+    drop(lib, ctxs, g)
+    # the collective's call fails: the communicator is aborted (ncclCommAbort), the group only answers SSV_E_STATE from then on
+    ctxs, g = fresh(SSV_GROUP_FAIL="0:2", SSV_GROUP_TIMEOUT_S="20")
+    rcs, _, hung = _run_ranks(lib, g, 1, [512])
+    assert not hung and rcs == [E_HIP] and "ncclAllGather" in _err(lib, ctxs[0])
+    rcs, _, hung = _run_ranks(lib, g, 1, [512])
+    assert not hung and rcs == [E_STATE] and "aborted" in _err(lib, ctxs[0])
+    drop(lib, ctxs, g)
+    # the collective is issued for real and the communicator aborted behind it
+    ctxs, g = fresh(SSV_GROUP_FAIL="0:3", SSV_GROUP_TIMEOUT_S="20")
+    rcs, _, hung = _run_ranks(lib, g, 1, [3 * 1024 * 1024])
+    assert not hung and rcs == [E_STATE] and "aborted" in _err(lib, ctxs[0])
+    rcs, _, hung = _run_ranks(lib, g, 1, [512])
+    assert not hung and rcs == [E_STATE]
+    drop(lib, ctxs, g)
+    # and an undisturbed group: several exchanges of different sizes over one communicator
+    ctxs, g = fresh()
+    for size in (512, 4096, 1, 100000):
+        rcs, recv, hung = _run_ranks(lib, g, 1, [size])
+        assert not hung and rcs == [0] and np.array_equal(recv[0][:size], np.full(size, 1, np.uint8))
+    drop(lib, ctxs, g)
+
+
 def _err(lib, h):
     lib.ssv_last_error.restype = C.c_char_p
     lib.ssv_last_error.argtypes = [C.c_void_p]
@@ -87,19 +125,23 @@ def test_exchange_never_leaves_a_rank_waiting(transport, monkeypatch):
     lib = _abi.hip_lib()
     n_dev = lib.ssv_device_count()
     if transport == "rccl":
-        if n_dev < 2:
-            pytest.skip("one GPU: RCCL cannot put two ranks on one device")
         n, devices = min(n_dev, 4), list(range(min(n_dev, 4)))
     else:
         n, devices = 3, [0, 0, 0]
     E_HIP, E_ARG, E_STATE = -2, -3, -4
 
     def fresh(**env):
-        for k in ("SSV_GROUP_FAIL", "SSV_GROUP_TIMEOUT_S"):
+        for k in ("SSV_GROUP_FAIL", "SSV_GROUP_TIMEOUT_S", "SSV_GROUP_RCCL_ONE"):
             monkeypatch.delenv(k, raising=False)
+        if transport == "rccl" and n == 1:
+            monkeypatch.setenv("SSV_GROUP_RCCL_ONE", "1")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         return _group(lib, devices)
+
+    if n == 1:
+        _one_rank_rccl_failures(lib, fresh, drop_group, E_HIP, E_STATE)
+        return
 
     def drop(ctxs, g):
         lib.ssv_group_destroy(g)
@@ -140,7 +182,8 @@ def test_exchange_never_leaves_a_rank_waiting(transport, monkeypatch):
     drop(ctxs, g)
 
 
-def test_cli_ranks_on_real_devices(tmp_path):
+@pytest.mark.parametrize("inflate", ["host", "-Z"])
+def test_cli_ranks_on_real_devices(tmp_path, inflate):
     """`seeksv getsv -N n` with one rank per real GPU: the tallies and depths meet in ncclAllGather and equal the single-GPU table"""
     import os
     import subprocess
@@ -149,8 +192,6 @@ def test_cli_ranks_on_real_devices(tmp_path):
     from seeksv_amd import host
     lib = _abi.hip_lib()
     n_dev = lib.ssv_device_count()
-    if n_dev < 2:
-        pytest.skip("one GPU")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.environ.get("SSV_CLI") or os.path.join(root, "seeksv_amd", "bin", "seeksv")
     base = os.path.join(G.GOLDEN, "getsv")
@@ -162,8 +203,11 @@ def test_cli_ranks_on_real_devices(tmp_path):
     empty_clip = str(tmp_path / "empty.clip")
     open(empty_clip, "w").close()
     sv = str(tmp_path / "out.sv")
-    r = subprocess.run([exe, "getsv", "-N", str(min(n_dev, 4)), "-d", "0", "-f", "0", "-b", "0", "-T", "100000", "-B", os.path.join(base, "pairs1.junctions.txt"), empty_bam, bam, empty_clip, sv,
-                        str(tmp_path / "x.fq")], capture_output=True, text=True, env=dict(os.environ, SSV_TIMING="1"))
+    env = dict(os.environ, SSV_TIMING="1")
+    if n_dev < 2:
+        env["SSV_GROUP_RCCL_ONE"] = "1"   # one run of records, its vector through a one-rank RCCL communicator
+    r = subprocess.run([exe, "getsv"] + ([inflate] if inflate != "host" else []) + ["-N", str(min(n_dev, 4)), "-d", "0", "-f", "0", "-b", "0", "-T", "100000", "-B", os.path.join(base, "pairs1.junctions.txt"), empty_bam, bam, empty_clip, sv,
+                        str(tmp_path / "x.fq")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert "exchange over RCCL" in r.stderr
     assert open(sv).read() == G.read_text("getsv", "pairs1.sv")
