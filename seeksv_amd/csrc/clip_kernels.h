@@ -712,7 +712,10 @@ struct ClusterArgs {
 	const uint32_t *mlist; // [M] the slots with mflag set, ascending (inverse of mslot)
 	int64_t M;
 	const uint32_t *blist; // the first slot of every multi-event bin
-	const uint32_t *n_bins; // (device) their number
+	const uint32_t *n_bins; // (device) their number; n_bins[1]: the number of deep bins
+	const uint32_t *dlist; // the first slot of every bin of B4_DEEP events or more (k_cluster_bins4 starts these first)
+	const uint16_t *tab4;  // k_bins4_tables' two tables
+	int64_t deep_cap;      // workgroups of k_cluster_bins4 reserved for the deep list (an upper bound of its length)
 	uint8_t *strings;      // [M * stride]: left seq (reversed), left qual (reversed), right seq, right qual - multi-event bins only
 	int32_t SL, SR;        // capacity of a left / right string
 };
@@ -759,19 +762,30 @@ __global__ void k_multi_list(const uint32_t *__restrict__ mflag, const uint32_t 
 	if (j < E && mflag[j]) mlist[mslot[j]] = (uint32_t)j;
 }
 
-// which entries of mlist start a bin (bflag), and after the scan of bflag (boff): the starts, densely - one wavefront of k_cluster_bins each
-__global__ void k_bin_start_flags(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ mlist, int64_t M, uint32_t *__restrict__ bflag)
+// which entries of mlist start a bin (bflag), and after the scan of bflag (boff): the starts, densely - one wavefront of k_cluster_bins each.
+// The flag is two counters in one 64-bit word: bin starts in the low half, starts of DEEP bins (B4_DEEP events or more: the planted
+// breakpoints of a 300x sample) in the high half - one scan numbers both, and k_cluster_bins4 starts the deep list first.
+constexpr int B4_DEEP = 16;
+__global__ void k_bin_start_flags(const uint64_t *__restrict__ skey, int64_t E, const uint32_t *__restrict__ mlist, int64_t M, uint64_t *__restrict__ bflag)
 {
 	int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= M) return;
 	const int64_t j = mlist[m];
-	bflag[m] = (j == 0 || skey[j - 1] != skey[j]) ? 1u : 0u;
+	const uint64_t k = skey[j];
+	const bool start = j == 0 || skey[j - 1] != k;
+	const bool deep = start && j + B4_DEEP - 1 < E && skey[j + B4_DEEP - 1] == k;
+	bflag[m] = (start ? 1ull : 0ull) | (deep ? 1ull << 32 : 0ull);
 }
 
-__global__ void k_bin_start_list(const uint32_t *__restrict__ mlist, const uint32_t *__restrict__ bflag, const uint32_t *__restrict__ boff, int64_t M, uint32_t *__restrict__ blist)
+__global__ void k_bin_start_list(const uint32_t *__restrict__ mlist, const uint64_t *__restrict__ bflag, const uint64_t *__restrict__ boff, int64_t M, uint32_t *__restrict__ blist, uint32_t *__restrict__ dlist)
 {
 	int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (m < M && bflag[m]) blist[boff[m]] = mlist[m];
+	if (m >= M) return;
+	const uint64_t f = bflag[m];
+	if (f == 0) return;
+	const uint64_t o = boff[m];
+	blist[(uint32_t)o] = mlist[m];
+	if (f >> 32) dlist[o >> 32] = mlist[m];
 }
 
 // One wavefront per bin (= run of equal keys in the sorted event list).  The wave walks the bin's events in BAM order - the order the
@@ -955,6 +969,274 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_bins(ClusterArgs a)
 	}
 }
 
+// ---- k_cluster_bins4: the same walk with FOUR positions per lane (round 5) ----
+// At 300x (BASELINE config 3) a planted breakpoint's bin holds 50-150 reads and the walk above is bound by its vector instructions: a lane
+// per base, every base a byte read through a pointer that may be LDS or global (flat instructions), three rounds per side for a 150-base
+// read, two fp64 divides per compare - about a thousand instructions per event.  Here a lane owns the positions 4 lane .. 4 lane + 3 of
+// either side (reads of up to B4_CAP = 256 bases: one round), an event's bases and qualities come out of its staged entry ONCE - one
+// unaligned dword of packed bases through a byte -> two-characters table, one unaligned dword of qualities, +33 on all four at once - into
+// four registers that every compare and the update share; the consensus strings are dwords in LDS, compared with an XOR and a zero-byte
+// test, updated with a four-byte signed compare and a bit-field insert; the match counts are ballots over the bits of the lanes' counts;
+// and `(double) m / (double) n >= rate` is looked up: the smallest m that passes for every n, found with that very division when the
+// workgroup starts (the quotient grows with m, so the table says exactly what the division would).  Clusters beyond the B4_KLDS-th of a
+// bin keep their strings in global memory as before (same code, instantiated for that address space).  The results are bit-identical to
+// k_cluster_bins, which stays for passes with a read longer than 256 bases.
+constexpr int B4_CAP = 256;   // positions of a side that one round of 64 lanes covers
+constexpr int B4_KLDS = 3;    // clusters per bin with LDS-resident strings
+constexpr int B4_ENT = 132;   // dwords of a staged entry: one in front (a left part's dword may begin up to three bases before the read), 3 + 128 + 256 bytes, slack behind
+
+__device__ __forceinline__ uint32_t b4_below(int L, int lane) // byte k is 0xff where position 4 lane + k < L
+{
+	const int r = L - 4 * lane;
+	return r >= 4 ? 0xffffffffu : r <= 0 ? 0u : (1u << (8 * r)) - 1u;
+}
+__device__ __forceinline__ uint32_t b4_zero_bytes(uint32_t x) { return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu); } // 0x80 in every byte that is 0
+__device__ __forceinline__ uint32_t b4_lt_s8(uint32_t a, uint32_t b) // 0xff in every byte where (signed char) a < (signed char) b
+{
+	const uint32_t x = a ^ 0x80808080u, y = b ^ 0x80808080u; // signed order -> unsigned order
+	const uint32_t d = (x | 0x80808080u) - (y & 0x7f7f7f7fu); // per byte 128 + low7(x) - low7(y): no borrow between bytes
+	const uint32_t lt = ((~x & y) | (~(x ^ y) & ~d)) & 0x80808080u;
+	return (lt << 1) - (lt >> 7);
+}
+__device__ __forceinline__ uint32_t b4_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+__device__ __forceinline__ uint32_t b4_lds_u32(const uint32_t *ent, int byte_off) // four bytes at any byte offset of a dword array
+{
+	const int d = byte_off >> 2;
+	return __builtin_amdgcn_alignbyte(ent[d + 1], ent[d], (uint32_t)(byte_off & 3));
+}
+
+struct Ev4 { uint32_t lb, lq, rb, rq; int ll, lr; bool qmiss; };
+
+constexpr int B4_TAB = 256 + B4_CAP + 2; // 16-bit entries: a BAM byte -> its two bases as characters (first base in the low byte) | the smallest m that passes for n = 0 .. 256
+// the two tables of a pass, once: what the compare `(double) m / (double) n >= match_rate` says for every n, found with that division
+__global__ __launch_bounds__(BLOCK) void k_bins4_tables(double match_rate, uint16_t *__restrict__ tab)
+{
+	const int t = (int)threadIdx.x;
+	tab[t] = (uint16_t)(nt16_char((uint32_t)t >> 4) | (nt16_char((uint32_t)t & 15u) << 8));
+	for (int n = t; n <= B4_CAP; n += BLOCK) {
+		const double r = match_rate;
+		int m = 0xffff;                                    // n == 0: 0 / 0 is NaN and compares false, like the reference's division
+		if (n > 0 && r == r) {
+			const double g = ceil(r * (double)n);
+			m = g < 0.0 ? 0 : g > (double)(n + 1) ? n + 1 : (int)g;
+			while (m > 0 && (double)(m - 1) / (double)n >= r) --m;
+			while (m <= n && !((double)m / (double)n >= r)) ++m;
+		}
+		tab[256 + n] = (uint16_t)m;
+	}
+	if (t == 0) tab[B4_TAB - 1] = 0;
+}
+
+// One wavefront = one workgroup = one bin: a workgroup of four held its LDS until its deepest bin was done, and at 300x every sixth
+// workgroup has a deep one.  The first deep_cap workgroups take the list of deep bins (they start first: the kernel ends with the shallow
+// bins, not with a 150-event walk that began late), the others the list of all bins and leave when theirs is deep.  (Measured and
+// dropped, profiles/r05_config3_notes.txt: a persistent grid whose wavefronts request the next bin's keys, lines and first bytes while
+// they walk the present one - 1.06 against 0.95 ms at 300x: the kernel is bound by its vector instructions, not by a bin's start-up
+// latency, which the other wavefronts of the CU cover, and the bookkeeping of the second bin in flight costs more than it hides.)
+__global__ __launch_bounds__(WAVE) void k_cluster_bins4(ClusterArgs a)
+{
+	__shared__ int32_t s_slot[CL_CACHE];
+	__shared__ BinMeta s_meta[CL_CACHE];
+	__shared__ uint32_t s_ent[B4_ENT];
+	__shared__ uint32_t s_str[B4_KLDS][4][WAVE]; // per cluster: left bases (reversed), left qualities (reversed), right bases, right qualities
+	__shared__ uint32_t s_tab[B4_TAB / 2];
+	const uint16_t *s_lut2 = reinterpret_cast<const uint16_t *>(s_tab), *s_minm = s_lut2 + 256;
+	const int lane = lane_id();
+	const bool deep_role = (int64_t)blockIdx.x < a.deep_cap;
+	const int64_t m = deep_role ? (int64_t)blockIdx.x : (int64_t)blockIdx.x - a.deep_cap;
+	if (m >= (int64_t)a.n_bins[deep_role ? 1 : 0]) return; // the grid is an upper bound (every second slot of a multi-event bin could start one)
+	struct Line { uint2 s, bl, rq; };            // src | begin, ll | lr, lq of an event line
+	struct Bin { int64_t j0; uint64_t key0, keys_after; Line L0, L1, L2; };
+	auto line_load = [&](int64_t j, Line &L) { const uint2 *ep = reinterpret_cast<const uint2 *>(a.ev + j); L.s = ep[1]; L.bl = ep[3]; L.rq = ep[4]; };
+	auto bin_request = [&](int64_t j0, Bin &B) {
+		B.j0 = j0;
+		B.key0 = a.skey[j0];
+		B.keys_after = j0 + 1 + lane < a.E ? a.skey[j0 + 1 + lane] : ~0ull;
+		line_load(j0, B.L0);
+		line_load(j0 + 1, B.L1); // (a bin has at least two events)
+		B.L2.s = B.L2.bl = B.L2.rq = make_uint2(0u, 0u);
+		if (j0 + 2 < a.E) line_load(j0 + 2, B.L2);
+	};
+	const int64_t stride = 2ll * (a.SL + a.SR);            // (SL = SR = a multiple of four: the dwords of a string never reach into the next one)
+	uint32_t *ent = s_ent;
+	auto bytes_load = [&](const Line &L, uint32_t &b0, uint32_t &b1) {
+		const uint64_t src = (uint64_t)L.s.x | ((uint64_t)L.s.y << 32);
+		const int lq = (int)L.rq.y, mis = (int)(src & 3ull);
+		const int nraw = (mis + (lq + 1) / 2 + lq + 3) / 4;   // <= 97 dwords for a read of 256 bases
+		const gptr<uint32_t> g4 = global_at<uint32_t>(src - (uint64_t)mis);
+		b0 = lane < nraw ? g4[lane] : 0u;
+		b1 = lane + WAVE < nraw ? g4[lane + WAVE] : 0u;
+	};
+	// the event's four registers out of its staged entry (GetSeq, clip_reads.cpp:286-306, four positions at a time)
+	auto extract = [&](const Line &L) -> Ev4 {
+		Ev4 v;
+		const int begin = (int)L.bl.x, lq = (int)L.rq.y;
+		v.ll = (int)L.bl.y; v.lr = (int)L.rq.x;
+		const int eb = 4 + (int)(L.s.x & 3u), nbytes = (lq + 1) / 2;
+		v.qmiss = lq > 0 && (b4_lds_u32(ent, eb + nbytes) & 0xffu) == 0xffu; // no qualities: the row prints "*" (clip_reads.cpp:296)
+		// right part, ascending: positions begin + ll + 4 lane + k
+		const int p0 = 4 * lane < v.lr ? begin + v.ll + 4 * lane : begin;
+		uint32_t N = __builtin_bswap32(b4_lds_u32(ent, eb + (p0 >> 1))) << (4 * (p0 & 1));
+		v.rb = (uint32_t)s_lut2[N >> 24] | ((uint32_t)s_lut2[(N >> 16) & 0xffu] << 16);
+		uint32_t q = b4_lds_u32(ent, eb + nbytes + p0);
+		v.rq = v.qmiss ? 0x2a2a2a2au : (((q & 0x7f7f7f7fu) + 0x21212121u) ^ (q & 0x80808080u));
+		// left part, reversed: positions begin + ll - 1 - 4 lane - k, i.e. the four that END at begin + ll - 1 - 4 lane, byte-swapped
+		const int pb = 4 * lane < v.ll ? begin + v.ll - 4 - 4 * lane : begin; // (>= -3: the dword in front of the entry covers it)
+		N = __builtin_bswap32(b4_lds_u32(ent, eb + (pb >> 1))) << (4 * (pb & 1));
+		v.lb = __builtin_bswap32((uint32_t)s_lut2[N >> 24] | ((uint32_t)s_lut2[(N >> 16) & 0xffu] << 16));
+		q = __builtin_bswap32(b4_lds_u32(ent, eb + nbytes + pb));
+		v.lq = v.qmiss ? 0x2a2a2a2au : (((q & 0x7f7f7f7fu) + 0x21212121u) ^ (q & 0x80808080u));
+		return v;
+	};
+	// one cluster against the event: its four dwords of this lane (kept for the update) and the verdict (clip_reads.cpp:194-217, 262-273)
+	struct Clu { uint32_t cs, cq, rs, rq; };
+	auto absorbs = [&](const Ev4 &v, const uint32_t *cs, const uint32_t *cq, const uint32_t *rs, const uint32_t *rq, int cll, int clr, Clu &c) __attribute__((always_inline)) -> bool {
+		const bool inl = 4 * lane < cll, inr = 4 * lane < clr;
+		c.cs = inl ? cs[lane] : 0u; c.cq = inl ? cq[lane] : 0u;
+		c.rs = inr ? rs[lane] : 0u; c.rq = inr ? rq[lane] : 0u;
+		const int n1 = v.ll < cll ? v.ll : cll, n2 = v.lr < clr ? v.lr : clr;
+		const uint32_t zl = b4_zero_bytes(v.lb ^ c.cs) & b4_below(n1, lane), zr = b4_zero_bytes(v.rb ^ c.rs) & b4_below(n2, lane);
+		const uint32_t cnt = (uint32_t)__popc(zl) | ((uint32_t)__popc(zr) << 3);
+		const int m1 = (int)__popcll(__ballot((cnt & 1u) != 0)) + 2 * (int)__popcll(__ballot((cnt & 2u) != 0)) + 4 * (int)__popcll(__ballot((cnt & 4u) != 0));
+		const int m2 = (int)__popcll(__ballot((cnt & 8u) != 0)) + 2 * (int)__popcll(__ballot((cnt & 16u) != 0)) + 4 * (int)__popcll(__ballot((cnt & 32u) != 0));
+		return m1 >= (int)s_minm[n1] && m2 >= (int)s_minm[n2];
+	};
+	// ReadsInfo::ChangeSeqAndQual (clip_reads.cpp:57-108): below the shorter length the better quality wins, beyond it the longer string is taken over
+	auto merge = [&](const Ev4 &v, uint32_t *cs, uint32_t *cq, uint32_t *rs, uint32_t *rq, int cll, int clr, const Clu &c) __attribute__((always_inline)) {
+		const int n1 = v.ll < cll ? v.ll : cll, n2 = v.lr < clr ? v.lr : clr;
+		const uint32_t bl = b4_below(n1, lane), br = b4_below(n2, lane);
+		const uint32_t sl = (b4_lt_s8(c.cq, v.lq) & bl) | (b4_below(v.ll, lane) & ~bl);
+		const uint32_t sr = (b4_lt_s8(c.rq, v.rq) & br) | (b4_below(v.lr, lane) & ~br);
+		if (sl) { cs[lane] = b4_bfi(sl, v.lb, c.cs); cq[lane] = b4_bfi(sl, v.lq, c.cq); }
+		if (sr) { rs[lane] = b4_bfi(sr, v.rb, c.rs); rq[lane] = b4_bfi(sr, v.rq, c.rq); }
+	};
+	auto create = [&](const Ev4 &v, uint32_t *cs, uint32_t *cq, uint32_t *rs, uint32_t *rq) __attribute__((always_inline)) {
+		const uint32_t ml = b4_below(v.ll, lane), mr = b4_below(v.lr, lane);
+		if (ml) { cs[lane] = v.lb & ml; cq[lane] = v.lq & ml; }
+		if (mr) { rs[lane] = v.rb & mr; rq[lane] = v.rq & mr; }
+	};
+	auto gstr = [&](int64_t slot) -> uint32_t * { return reinterpret_cast<uint32_t *>(a.strings + (int64_t)a.mslot[slot] * stride); };
+	const int gl = a.SL / 4, gr = a.SR / 4; // a global string's dwords
+
+	// ---- start-up: the bin's keys and first lines, the two tables ----
+	Bin cur;
+	bin_request(deep_role ? (int64_t)a.dlist[m] : (int64_t)a.blist[m], cur);
+	{
+		const uint32_t *g = reinterpret_cast<const uint32_t *>(a.tab4);
+		for (int i = lane; i < B4_TAB / 2; i += WAVE) s_tab[i] = g[i];
+		if (lane == 0) ent[0] = 0u;
+	}
+	uint32_t f0, f1, b0, b1; // bytes of the bin's first and second event
+	bytes_load(cur.L0, f0, f1);
+	bytes_load(cur.L1, b0, b1);
+	{
+		const int64_t j0 = cur.j0;
+		const uint64_t key0 = cur.key0;
+		// the bin's extent: the keys behind its first slot, 64 at a time
+		int64_t nb = 1;
+		{
+			uint64_t keys_after = cur.keys_after;
+			for (;;) {
+				const uint64_t same = __ballot(keys_after == key0);
+				const int run = same == ~0ull ? WAVE : (int)__builtin_ctzll(~same);
+				nb += run;
+				if (run < WAVE || !deep_role) break; // (a shallow-list wavefront only needs to know that the bin is deep)
+				keys_after = j0 + nb + lane < a.E ? a.skey[j0 + nb + lane] : ~0ull;
+			}
+		}
+		if (deep_role || nb < B4_DEEP) { // (a deep bin met in the list of all bins belongs to the deep list's wavefronts)
+			const bool left_clipped = ((key0 >> 32) & 1ull) == 0; // side '5' = breakpoint2read_l = LEFT_CLIPPED
+			Line L1 = cur.L1, L2 = cur.L2;
+			ent[1 + lane] = f0; ent[1 + lane + WAVE] = f1;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			Ev4 v = extract(cur.L0);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			int nclu = 0;
+			for (int64_t t = 0; t < nb; ++t) {
+				const int64_t jj = j0 + t;
+				const uint32_t e = (uint32_t)jj;
+				// bytes of event t + 1 into the staging (event t lives in registers), bytes of t + 2 and the line of t + 3 requested
+				if (t + 1 < nb) { ent[1 + lane] = b0; ent[1 + lane + WAVE] = b1; }
+				Line L3;
+				L3.s = L3.bl = L3.rq = make_uint2(0u, 0u);
+				if (t + 2 < nb) bytes_load(L2, b0, b1);
+				if (t + 3 < nb) line_load(jj + 3, L3);
+				// ---- the first cluster of the bin that takes this event in ----
+				int hit_k = -1, hit_ll = 0, hit_lr = 0;
+				int64_t hit = -1;
+				Clu c;
+				c.cs = c.cq = c.rs = c.rq = 0u;
+				const int kmax = nclu < CL_CACHE ? nclu : CL_CACHE;
+				for (int k = 0; k < kmax && hit < 0; ++k) {
+					const int64_t slot = j0 + s_slot[k];
+					const int cll = s_meta[k].ll, clr = s_meta[k].lr;
+					bool ok;
+					if (k < B4_KLDS) ok = absorbs(v, s_str[k][0], s_str[k][1], s_str[k][2], s_str[k][3], cll, clr, c);
+					else { const uint32_t *g = gstr(slot); ok = absorbs(v, g, g + gl, g + 2 * gl, g + 2 * gl + gr, cll, clr, c); }
+					if (ok) { hit = slot; hit_k = k; hit_ll = cll; hit_lr = clr; }
+				}
+				if (hit < 0 && nclu > CL_CACHE) {
+					// clusters beyond the LDS cache: they were created after the last cached one, i.e. at later slots
+					for (int64_t s_ = j0 + s_slot[CL_CACHE - 1] + 1; s_ < jj && hit < 0; ++s_)
+						if (a.support[s_] > 0) {
+							const uint32_t *g = gstr(s_);
+							const int cll = a.c_ll[s_], clr = a.c_lr[s_];
+							if (absorbs(v, g, g + gl, g + 2 * gl, g + 2 * gl + gr, cll, clr, c)) { hit = s_; hit_k = CL_CACHE; hit_ll = cll; hit_lr = clr; }
+						}
+				}
+				if (hit >= 0) {
+					const int cll = hit_ll, clr = hit_lr;
+					if (hit_k < B4_KLDS) merge(v, s_str[hit_k][0], s_str[hit_k][1], s_str[hit_k][2], s_str[hit_k][3], cll, clr, c);
+					else { uint32_t *g = gstr(hit); merge(v, g, g + gl, g + 2 * gl, g + 2 * gl + gr, cll, clr, c); }
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					if (hit_k < CL_CACHE) {
+						if (lane == 0) {
+							BinMeta &mt = s_meta[hit_k];
+							if (cll <= v.ll) { mt.ll = v.ll; if (!left_clipped) mt.cig_ev = e; } // aa == RIGHT_CLIPPED (also when the lengths are equal)
+							if (clr < v.lr) { mt.lr = v.lr; if (left_clipped) mt.cig_ev = e; }    // aa == LEFT_CLIPPED
+							mt.support += 1;
+						}
+					} else {
+						if (cll <= v.ll) { a.c_ll[hit] = v.ll; if (!left_clipped) a.c_cig_ev[hit] = e; }
+						if (clr < v.lr) { a.c_lr[hit] = v.lr; if (left_clipped) a.c_cig_ev[hit] = e; }
+						a.support[hit] += 1; // every lane stores the same value; each lane later reads back what it stored
+					}
+				} else {
+					// ---- new cluster at this event's slot (clip_reads.cpp:276-281) ----
+					const int k = nclu < CL_CACHE ? nclu : CL_CACHE;
+					if (k < B4_KLDS) create(v, s_str[k][0], s_str[k][1], s_str[k][2], s_str[k][3]);
+					else { uint32_t *g = gstr(jj); create(v, g, g + gl, g + 2 * gl, g + 2 * gl + gr); }
+					a.c_qmiss[jj] = v.qmiss ? 1 : 0;
+					if (nclu < CL_CACHE) {
+						if (lane == 0) { s_slot[nclu] = (int32_t)t; BinMeta &mt = s_meta[nclu]; mt.ll = v.ll; mt.lr = v.lr; mt.support = 1; mt.cig_ev = e; }
+					} else { a.c_ll[jj] = v.ll; a.c_lr[jj] = v.lr; a.c_cig_ev[jj] = e; a.support[jj] = 1; }
+					++nclu;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				if (t + 1 < nb) v = extract(L1);
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				L1 = L2; L2 = L3;
+			}
+			// ---- the bin's results to global memory: lengths / support / CIGAR carrier of the cached clusters, strings of the LDS-resident ones ----
+			const int kc = nclu < CL_CACHE ? nclu : CL_CACHE;
+			for (int k = lane; k < kc; k += WAVE) {
+				const int64_t slot = j0 + s_slot[k];
+				const BinMeta mt = s_meta[k];
+				a.c_ll[slot] = mt.ll; a.c_lr[slot] = mt.lr; a.c_cig_ev[slot] = mt.cig_ev; a.support[slot] = mt.support;
+			}
+			// (a cluster that stayed alone IS its event: the pack kernels cut it out of the read like the cluster of a single-event bin - no strings)
+			const int ks = nclu < B4_KLDS ? nclu : B4_KLDS;
+			for (int k = 0; k < ks; ++k) {
+				if (s_meta[k].support == 1) continue;
+				uint32_t *g = gstr(j0 + s_slot[k]);
+				const int ll = s_meta[k].ll, lr = s_meta[k].lr;
+				if (4 * lane < ll) { g[lane] = s_str[k][0][lane]; g[gl + lane] = s_str[k][1][lane]; }
+				if (4 * lane < lr) { g[2 * gl + lane] = s_str[k][2][lane]; g[2 * gl + gr + lane] = s_str[k][3][lane]; }
+			}
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // cluster table packing
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1003,7 +1285,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_meta(PackArgs p)
 	uint64_t cnt = 0, bytes = 0;
 	bool lng = false;
 	if (j < p.c.E && p.c.support[j] > 0) {
-		const bool single = !p.c.mflag[j];
+		const bool single = !p.c.mflag[j] || p.c.support[j] == 1; // (a cluster of a multi-event bin that nothing joined is its event, like a single-event bin's)
 		const uint32_t e = single ? (uint32_t)j : p.c.c_cig_ev[j];
 		const uint4 *ep = reinterpret_cast<const uint4 *>(p.c.ev + e);
 		const uint4 eb = ep[1], ec = ep[2];
@@ -1063,7 +1345,7 @@ __device__ __forceinline__ SlotCluster slot_cluster_load(const PackArgs &p, int6
 	SlotCluster s;
 	s.support = p.c.support[j];
 	s.cluster = s.support > 0;
-	s.single = !p.c.mflag[j];
+	s.single = !p.c.mflag[j] || s.support == 1;
 	const uint64_t sc = p.slot_cnt[j];
 	s.c = (uint32_t)sc; s.cig_off = sc >> 32; s.str_off = p.slot_bytes[j]; s.key = p.c.skey[j];
 	const uint32_t e = s.single ? (uint32_t)j : p.c.c_cig_ev[j];
@@ -1439,6 +1721,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_slow(PackArgs p, uint8_t
 	const int64_t j = k_ < p.c.M ? (int64_t)p.c.mlist[k_] : (int64_t)p.slow_list[k_ - p.c.M];
 	if (p.c.support[j] <= 0) return; // five of six slots of multi-event bins hold no cluster
 	const SlotCluster sc = slot_cluster_load(p, j);
+	if (k_ < p.c.M && sc.single) return; // (a lone cluster of a multi-event bin is a single: the stream kernel's, or - a long read - listed in slow_list)
 	const int ll = sc.ll, lr = sc.lr, lq = sc.lq, begin = sc.begin;
 	const bool single = lq >= 0;
 	const int nB0 = (ll + 1) / 2, nB1 = (ll * W + 7) / 8, nB2 = (lr + 1) / 2, nB3 = (lr * W + 7) / 8;

@@ -25,6 +25,14 @@ __device__ __forceinline__ int4 stream_load_i4(const void *p)
 	return make_int4(v.x, v.y, v.z, v.w);
 }
 
+// A pointer that was an integer (an event's `src`, a batch address plus an offset) is a FLAT pointer to the compiler: its loads are
+// flat_load instructions, which count on BOTH memory counters - every wait for an LDS result (lgkmcnt) then also waits for the loads from
+// memory still in flight, and a software pipeline that keeps loads in flight across LDS work does not overlap anything.  These say
+// "global memory" explicitly: global_load, vmcnt only.
+template <typename T> using gptr = const T __attribute__((address_space(1))) *;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(const T *p) { return (gptr<T>)p; }
+template <typename T> __device__ __forceinline__ gptr<T> global_at(uint64_t addr) { return (gptr<T>)(uintptr_t)addr; }
+
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;            // 4 waves per workgroup
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;

@@ -152,7 +152,7 @@ struct ssv_ctx {
 	uint64_t sum_ncig = 0;
 	int max_lq = 0, max_ncig = 0;
 	// clustering temporaries / outputs
-	DBuf keys2[2], vals2[2], evs, cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_bflag, c_boff, c_blist, c_strings, slot_cnt, slot_bytes;
+	DBuf keys2[2], vals2[2], evs, cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_bflag, c_boff, c_blist, c_dlist, bins4_tab, c_strings, slot_cnt, slot_bytes;
 	DBuf o_slowlist, o_desc, totals;
 	HBuf h_totals;
 	// the dense cluster table: device columns + pinned host copy, double buffered so that the PCIe copy of one table can overlap
@@ -537,7 +537,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (c->st_h2d) { (void)hipStreamSynchronize(c->st_h2d); (void)hipStreamDestroy(c->st_h2d); }
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage, &c->ends_buf,
 	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
-	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_strings,
+	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_dlist, &c->bins4_tab, &c->c_strings,
 	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->pair_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
 	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry,
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
@@ -960,7 +960,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	ClusterArgs ca;
 	ca.skey = P<uint64_t>(c->keys2[cur]); ca.E = E; ca.ev = P<ClipEvent>(c->evs);
 	ca.match_rate = c->clip_p.match_rate;
-	ca.SL = std::max(1, c->max_lq); ca.SR = std::max(1, c->max_lq); // |seq_left|, |seq_right| <= l_qseq, also after consensus growth
+	ca.SL = ca.SR = (std::max(1, c->max_lq) + 3) & ~3; // |seq_left|, |seq_right| <= l_qseq, also after consensus growth; a multiple of four: k_cluster_bins4 moves dwords
 	const size_t stride = 2 * ((size_t)ca.SL + (size_t)ca.SR);
 	int64_t M = 0;
 	{
@@ -977,19 +977,28 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		M = *P<uint32_t>(c->h_totals); // events in multi-event bins: only they need consensus storage
 		CHECK(ensure(c, c->c_strings, (size_t)std::max<int64_t>(M, 1) * stride));
 		ca.strings = P<uint8_t>(c->c_strings);
-		ca.M = M; ca.mlist = nullptr; ca.blist = nullptr; ca.n_bins = nullptr;
+		ca.M = M; ca.mlist = nullptr; ca.blist = nullptr; ca.n_bins = nullptr; ca.dlist = nullptr; ca.tab4 = nullptr; ca.deep_cap = 0;
 		if (M > 0) {
 			// one wavefront per slot of a multi-event bin (3 % of the slots; the waves that do not sit on a bin start leave at once)
 			CHECK(ensure(c, c->c_mlist, M * 4));
 			ca.mlist = P<uint32_t>(c->c_mlist);
 			k_multi_list<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(ca.mflag, ca.mslot, E, P<uint32_t>(c->c_mlist));
 			// the bins' first slots, densely: every wavefront of the clustering kernel then has a bin (a bin has at least two slots)
-			CHECK(ensure(c, c->c_bflag, M * 4)); CHECK(ensure(c, c->c_boff, M * 4)); CHECK(ensure(c, c->c_blist, (M / 2 + 1) * 4));
-			k_bin_start_flags<<<grid_for(M, BLOCK), BLOCK, 0, c->st>>>(ca.skey, ca.mlist, M, P<uint32_t>(c->c_bflag));
-			exclusive_scan<uint32_t, uint32_t>(c->st, P<uint32_t>(c->c_bflag), P<uint32_t>(c->c_boff), M, 0u, P<uint32_t>(c->scan_scratch), P<uint32_t>(c->totals) + 2);
-			k_bin_start_list<<<grid_for(M, BLOCK), BLOCK, 0, c->st>>>(ca.mlist, P<uint32_t>(c->c_bflag), P<uint32_t>(c->c_boff), M, P<uint32_t>(c->c_blist));
-			ca.blist = P<uint32_t>(c->c_blist); ca.n_bins = P<uint32_t>(c->totals) + 2;
-			k_cluster_bins<<<grid_for(M / 2 + 1, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
+			// (two counters in one 64-bit scan: the bins, and the deep ones among them - totals[1] = bins | deep bins << 32)
+			ca.deep_cap = M / B4_DEEP + 1;
+			CHECK(ensure(c, c->c_bflag, M * 8)); CHECK(ensure(c, c->c_boff, M * 8)); CHECK(ensure(c, c->c_blist, (M / 2 + 1) * 4)); CHECK(ensure(c, c->c_dlist, (size_t)ca.deep_cap * 4));
+			CHECK(ensure(c, c->scan_scratch, scan_scratch_elems(M) * 8));
+			k_bin_start_flags<<<grid_for(M, BLOCK), BLOCK, 0, c->st>>>(ca.skey, E, ca.mlist, M, P<uint64_t>(c->c_bflag));
+			exclusive_scan<uint64_t, uint64_t>(c->st, P<uint64_t>(c->c_bflag), P<uint64_t>(c->c_boff), M, 0ull, P<uint64_t>(c->scan_scratch), P<uint64_t>(c->totals) + 1);
+			k_bin_start_list<<<grid_for(M, BLOCK), BLOCK, 0, c->st>>>(ca.mlist, P<uint64_t>(c->c_bflag), P<uint64_t>(c->c_boff), M, P<uint32_t>(c->c_blist), P<uint32_t>(c->c_dlist));
+			ca.blist = P<uint32_t>(c->c_blist); ca.dlist = P<uint32_t>(c->c_dlist); ca.n_bins = P<uint32_t>(c->totals) + 2;
+			// reads of up to 256 bases: four positions per lane, a wavefront = a workgroup, deep bins first; longer ones: a base per lane
+			if (c->max_lq <= B4_CAP && !getenv("SSV_BINS_BYTEWISE")) {
+				CHECK(ensure(c, c->bins4_tab, B4_TAB * 2));
+				ca.tab4 = P<uint16_t>(c->bins4_tab);
+				k_bins4_tables<<<1, BLOCK, 0, c->st>>>(ca.match_rate, P<uint16_t>(c->bins4_tab));
+				k_cluster_bins4<<<(unsigned)(ca.deep_cap + M / 2 + 1), WAVE, 0, c->st>>>(ca);
+			} else k_cluster_bins<<<grid_for(M / 2 + 1, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(ca);
 		}
 		HIPCHECK(c, hipGetLastError());
 	}

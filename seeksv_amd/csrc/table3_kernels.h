@@ -101,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_cols3(PackArgs p, Pack3Args q
 			if (s.ncg > 3) { dc[3] = (uint16_t)s.cg3; wide |= s.cg3; }
 			if (s.ncg > 4) { dc[4] = (uint16_t)s.cg4; wide |= s.cg4; }
 		} else {
-			const uint32_t *src = reinterpret_cast<const uint32_t *>((uintptr_t)s.cig_ptr);
+			const gptr<uint32_t> src = global_at<uint32_t>(s.cig_ptr);
 			for (int i = 0; i < s.ncg; ++i) { dc[i] = (uint16_t)src[i]; wide |= src[i]; }
 		}
 		if (wide >> 16) *q.cig_miss = 1;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_cols3(PackArgs p, Pack3Args q
 			if (s.ncg > 3) dc[3] = s.cg3;
 			if (s.ncg > 4) dc[4] = s.cg4;
 		} else {
-			const uint32_t *src = reinterpret_cast<const uint32_t *>((uintptr_t)s.cig_ptr);
+			const gptr<uint32_t> src = global_at<uint32_t>(s.cig_ptr);
 			for (int i = 0; i < s.ncg; ++i) dc[i] = src[i];
 		}
 	}
@@ -334,7 +334,7 @@ __device__ __forceinline__ void src3_load_bases(const PackDescR &d0, int t, uint
 	const int n = d0.ll + d0.lr;
 	const int nb0 = d0.begin + PER * t;
 	const uint64_t A = d0.src + (uint64_t)(nb0 >> 1);
-	const uint32_t *p = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
+	const gptr<uint32_t> p = global_at<uint32_t>(A & ~3ull); // (global_load, not flat_load: the pair tables live in LDS - common.h)
 	const int rem = n - PER * t;
 	const int need = (int)(A & 3ull) + (((rem < PER ? rem : PER) + (nb0 & 1) + 1) >> 1); // bytes from p[0] on that hold the dword's bases
 	w[0] = p[0]; w[1] = need > 4 ? p[1] : 0u; w[2] = need > 8 ? p[2] : 0u;
@@ -346,7 +346,7 @@ __device__ __forceinline__ void src3_load_quals(const PackDescR &d0, int t, uint
 	const int n = d0.ll + d0.lr;
 	const int i0 = Q3<W, K>::first(t);
 	const uint64_t A = d0.src + (uint64_t)((d0.lq + 1) / 2 + d0.begin + i0); // first source byte
-	const uint32_t *q4 = reinterpret_cast<const uint32_t *>((uintptr_t)(A & ~3ull));
+	const gptr<uint32_t> q4 = global_at<uint32_t>(A & ~3ull);
 	const int bytes = (int)(A & 3ull) + (n - i0);
 #pragma unroll
 	for (int g = 0; g <= Q3<W, K>::NSRC; ++g) raw[g] = 4 * g < bytes ? q4[g] : 0u;
@@ -574,7 +574,8 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 	uint32_t mine = 0xffffffffu;
 	if (k_ < n_items) {
 		mine = k_ < p.c.M ? p.c.mlist[k_] : p.slow_list[k_ - p.c.M];
-		if (p.c.support[mine] <= 0) mine = 0xffffffffu;
+		const int sup = p.c.support[mine];
+		if (sup <= 0 || (k_ < p.c.M && sup == 1)) mine = 0xffffffffu; // (a lone cluster of a multi-event bin is a single: the dword path's, or - a long read - listed in slow_list)
 	}
 	for (uint64_t todo = __ballot(mine != 0xffffffffu); todo;) {
 	int pick = -1;
@@ -585,10 +586,11 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 	const int ll = sc.ll, lr = sc.lr, lq = sc.lq, begin = sc.begin, n = ll + lr;
 	const bool single = lq >= 0;
 	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + sc.str_off);
-	const uint8_t *sp = nullptr, *qp = nullptr, *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
+	gptr<uint8_t> sp = nullptr, qp = nullptr;
+	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
 	bool qm;
 	if (single) {
-		sp = reinterpret_cast<const uint8_t *>((uintptr_t)sc.src); qp = sp + (lq + 1) / 2;
+		sp = global_at<uint8_t>(sc.src); qp = sp + (lq + 1) / 2;
 		qm = lq > 0 && qp[0] == 0xff;
 		if (gl == 0) q.flags[sc.c] = qm ? 1 : 0;
 	} else {
