@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--file-frac", type=float, default=-1.0, help="(default: --genome-frac, i.e. the bench workload itself = BASELINE config 2, 617 M records / 44 GB, where >= 192 host cores write the file in about a minute; a quarter of it from 64 cores; else 1/16 or 1/64) genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
                     "inflate + decode -> scans -> tables on the host); 0 = skip")
     ap.add_argument("--file-level", type=int, default=-1, help="deflate level of the file leg's BAM (default: 6 = samtools' default where >= 64 CPUs write the file, else 4)")
+    ap.add_argument("--no-config3", action="store_true", help="skip config3_path (BASELINE config 3's shape: 300x over a tenth of the genome, the same number of records, resident in HBM)")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip cli_path (the `seeksv` binary as child processes on the file leg's BAM)")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
     ap.add_argument("--table-format", type=int, default=3, help="ssv_clip_table_format: 3 = the compact table (default), 2 = four-piece blocks with 4-bit bases, 0 = ASCII")
@@ -101,210 +102,220 @@ def main():
     from seeksv_amd import host, shard, synth
     from seeksv_amd.device import Context
 
-    strong = args.scaling == "strong"
-    w = synth.Workload(genome_frac=args.genome_frac, depth=args.strong_depth if strong else args.depth * world, n_sv=args.n_sv)
-    sp = shard.shard_plan(w, rank, world)
-    t0 = time.time()
-    n_scan = sp["own_hi_rec"] - sp["scan_lo_rec"]
-    n_own = sp["own_hi_rec"] - sp["own_lo_rec"]
-    # a rank's records stay resident for the whole run: ~80 bytes each (hot columns 11, one 64-byte line, CIGAR 4, bases of the 1 % soft-clipped reads)
-    # plus the pass's events, tables and scratch; a batch holds fewer than 2^31 records (include/seeksv_hip.h)
-    hbm = torch.cuda.get_device_properties(local_rank).total_memory
-    if n_scan >= (1 << 31) - 64 or n_scan * 80.0 > 0.75 * hbm:
-        raise SystemExit(f"bench.py: a share of {n_scan} records ({n_scan * 80 / 1e9:.0f} GB resident) does not fit one GPU ({hbm / 1e9:.0f} GB, < 2^31 records per batch): "
-                         f"{'--scaling strong at ' + format(args.strong_depth, 'g') + 'x needs more GPUs (300x: 4 or 8) or a lower --strong-depth' if strong else 'lower --depth or --genome-frac'}")
-    # the batch as the device decoder hands it over: hot columns (tid, pos, n_cigar), one 64-byte line per record with the cold fields, CIGARs,
-    # packed bases + qualities of the soft-clipped records.  It stays resident and unchanged over the timed region (SSV_MEM_PERSISTENT):
-    # clip events point at the reads' own bytes and the cluster table is cut straight out of them.
-    scan_batch, scan_t = w.generate_device(sp["scan_lo_rec"], n_scan, local_rank, soa=False, persistent=True)
-    # the rank's own records = the scan batch minus the leading halo (same cigar / seqqual blobs, offsets are absolute)
-    from seeksv_amd import _abi
+    def resident(args, ctx=None):
+        """the resident-input leg on one workload (args.depth / args.genome_frac / args.n_sv): generation, K timed steps, the breakdown steps"""
 
-    def sub_batch(batch, first, n):
-        arrays = {}
-        for name, dt in _abi.BATCH_FIELDS:
-            ptr = getattr(batch, name)
-            arrays[name] = ptr if name in ("cigar", "seqqual", "xc") or ptr is None else ptr + first * np.dtype(dt).itemsize
-        arrays["rec"] = batch.rec + first * 64 if batch.rec else None
-        arrays["n_cigar_total"], arrays["seqqual_bytes"], arrays["max_ref_span"] = batch.n_cigar_total, batch.seqqual_bytes, batch.max_ref_span
-        arrays["tid_runs"] = _abi.rebase_runs(batch.get_tid_runs(), first, n)
-        return _abi.make_batch(arrays, mem=batch.mem, n=n)[0]
+        strong = args.scaling == "strong"
+        w = synth.Workload(genome_frac=args.genome_frac, depth=args.strong_depth if strong else args.depth * world, n_sv=args.n_sv)
+        sp = shard.shard_plan(w, rank, world)
+        t0 = time.time()
+        n_scan = sp["own_hi_rec"] - sp["scan_lo_rec"]
+        n_own = sp["own_hi_rec"] - sp["own_lo_rec"]
+        # a rank's records stay resident for the whole run: ~80 bytes each (hot columns 11, one 64-byte line, CIGAR 4, bases of the 1 % soft-clipped reads)
+        # plus the pass's events, tables and scratch; a batch holds fewer than 2^31 records (include/seeksv_hip.h)
+        hbm = torch.cuda.get_device_properties(local_rank).total_memory
+        if n_scan >= (1 << 31) - 64 or n_scan * 80.0 > 0.75 * hbm:
+            raise SystemExit(f"bench.py: a share of {n_scan} records ({n_scan * 80 / 1e9:.0f} GB resident) does not fit one GPU ({hbm / 1e9:.0f} GB, < 2^31 records per batch): "
+                             f"{'--scaling strong at ' + format(args.strong_depth, 'g') + 'x needs more GPUs (300x: 4 or 8) or a lower --strong-depth' if strong else 'lower --depth or --genome-frac'}")
+        # the batch as the device decoder hands it over: hot columns (tid, pos, n_cigar), one 64-byte line per record with the cold fields, CIGARs,
+        # packed bases + qualities of the soft-clipped records.  It stays resident and unchanged over the timed region (SSV_MEM_PERSISTENT):
+        # clip events point at the reads' own bytes and the cluster table is cut straight out of them.
+        scan_batch, scan_t = w.generate_device(sp["scan_lo_rec"], n_scan, local_rank, soa=False, persistent=True)
+        # the rank's own records = the scan batch minus the leading halo (same cigar / seqqual blobs, offsets are absolute)
+        from seeksv_amd import _abi
 
-    own_batch = sub_batch(scan_batch, sp["own_lo_rec"] - sp["scan_lo_rec"], n_own)
-    # global file prefix for the insert-size statistics (cluster.cpp:68 stops after 5 M qualifying records)
-    n_prefix = min(w.n_total, 6_500_000)
-    if sp["scan_lo_rec"] == 0 and n_prefix <= n_scan:
-        prefix_batch, prefix_t = sub_batch(scan_batch, 0, n_prefix), None
-    else:
-        prefix_batch, prefix_t = w.generate_device(0, n_prefix, local_rank, soa=False)
-    torch.cuda.synchronize()
-    gen_s = time.time() - t0
+        def sub_batch(batch, first, n):
+            arrays = {}
+            for name, dt in _abi.BATCH_FIELDS:
+                ptr = getattr(batch, name)
+                arrays[name] = ptr if name in ("cigar", "seqqual", "xc") or ptr is None else ptr + first * np.dtype(dt).itemsize
+            arrays["rec"] = batch.rec + first * 64 if batch.rec else None
+            arrays["n_cigar_total"], arrays["seqqual_bytes"], arrays["max_ref_span"] = batch.n_cigar_total, batch.seqqual_bytes, batch.max_ref_span
+            arrays["tid_runs"] = _abi.rebase_runs(batch.get_tid_runs(), first, n)
+            return _abi.make_batch(arrays, mem=batch.mem, n=n)[0]
 
-    ctx = Context(local_rank)
-    table_format = 0 if args.ascii_table else args.table_format
-    # the table is the getclip stage's output and PCIe bounds the step: the compact format ships 12 bytes of fixed columns per cluster, bases
-    # at 2 bits, qualities as alphabet indices; the host rebuilds contig / side / offsets (ssv_clip_table_expand, inside the timed step)
-    ctx.clip_table_format(table_format)
-    hdr = host.Header(w.names, w.lens)
-    own = sp["own"] if world > 1 else None
-    jtable = host.JunctionTable(w.junctions)
-
-    wall = {}
-    state = {"pending": False, "support_sum": 0, "tables": 0}
-
-    def collect_table(prev):
-        tw = time.perf_counter()
-        t = ctx.clip_table_wait(prev=prev)
-        n = t.n_clusters
-        if t.format == 3:
-            te = time.perf_counter()
-            ctx.clip_table_expand(t, 0)
-            state.setdefault("expand_ms", []).append((time.perf_counter() - te) * 1e3)
-            state.setdefault("wait_ms", []).append((te - tw) * 1e3)
-            state["table_bytes"] = n * (4 + 2 * t.len_bytes + t.support_bytes + t.ncig_bytes + 1) + t.str_bytes + t.cigar_bytes * t.cigar_ops + 16 * t.n_runs + 8 * t.n_base_exc
+        own_batch = sub_batch(scan_batch, sp["own_lo_rec"] - sp["scan_lo_rec"], n_own)
+        # global file prefix for the insert-size statistics (cluster.cpp:68 stops after 5 M qualifying records)
+        n_prefix = min(w.n_total, 6_500_000)
+        if sp["scan_lo_rec"] == 0 and n_prefix <= n_scan:
+            prefix_batch, prefix_t = sub_batch(scan_batch, 0, n_prefix), None
         else:
-            state["table_bytes"] = n * 42 + t.str_bytes + 4 * t.cigar_ops
-        state["table_info"] = dict(format=int(t.format), qual_bits=int(t.qual_bits), qual_group=int(t.qual_group), cigar_bytes=int(t.cigar_bytes), base_bits=int(t.base_bits), base_exceptions=int(t.n_base_exc))
-        ssum = int(t.support_sum) if t.format == 3 else (int(np.ctypeslib.as_array(t.support, shape=(n,)).sum()) if n else 0)
-        assert ssum == t.n_events, "clip events were lost or duplicated"
-        assert bool(t.seq_packed) == (not args.ascii_table)
-        state["support_sum"] = ssum
-        state["tables"] += 1
+            prefix_batch, prefix_t = w.generate_device(0, n_prefix, local_rank, soa=False)
+        torch.cuda.synchronize()
+        gen_s = time.time() - t0
 
-    def start_plan_worker():
-        box = {}
-        th = threading.Thread(target=lambda: box.setdefault("plan", host.Plan(hdr, jtable, 0, 0)))
-        th.start()
-        state["plan_worker"], state["plan_box"] = th, box
+        if ctx is None:
+            ctx = Context(local_rank)
+        table_format = 0 if args.ascii_table else args.table_format
+        # the table is the getclip stage's output and PCIe bounds the step: the compact format ships 12 bytes of fixed columns per cluster, bases
+        # at 2 bits, qualities as alphabet indices; the host rebuilds contig / side / offsets (ssv_clip_table_expand, inside the timed step)
+        ctx.clip_table_format(table_format)
+        hdr = host.Header(w.names, w.lens)
+        own = sp["own"] if world > 1 else None
+        jtable = host.JunctionTable(w.junctions)
 
-    def drain():
-        if state["pending"]:
-            collect_table(prev=False)
-            state["pending"] = False
+        wall = {}
+        state = {"pending": False, "support_sum": 0, "tables": 0}
 
+        def collect_table(prev):
+            tw = time.perf_counter()
+            t = ctx.clip_table_wait(prev=prev)
+            n = t.n_clusters
+            if t.format == 3:
+                te = time.perf_counter()
+                ctx.clip_table_expand(t, 0)
+                state.setdefault("expand_ms", []).append((time.perf_counter() - te) * 1e3)
+                state.setdefault("wait_ms", []).append((te - tw) * 1e3)
+                state["table_bytes"] = n * (4 + 2 * t.len_bytes + t.support_bytes + t.ncig_bytes + 1) + t.str_bytes + t.cigar_bytes * t.cigar_ops + 16 * t.n_runs + 8 * t.n_base_exc
+            else:
+                state["table_bytes"] = n * 42 + t.str_bytes + 4 * t.cigar_ops
+            state["table_info"] = dict(format=int(t.format), qual_bits=int(t.qual_bits), qual_group=int(t.qual_group), cigar_bytes=int(t.cigar_bytes), base_bits=int(t.base_bits), base_exceptions=int(t.n_base_exc))
+            ssum = int(t.support_sum) if t.format == 3 else (int(np.ctypeslib.as_array(t.support, shape=(n,)).sum()) if n else 0)
+            assert ssum == t.n_events, "clip events were lost or duplicated"
+            assert bool(t.seq_packed) == (not args.ascii_table)
+            state["support_sum"] = ssum
+            state["tables"] += 1
 
-    trace = [] if os.environ.get("SSV_BENCH_TRACE") else None   # debugging: wall-clock laps of every step on stderr
+        def start_plan_worker():
+            box = {}
+            th = threading.Thread(target=lambda: box.setdefault("plan", host.Plan(hdr, jtable, 0, 0)))
+            th.start()
+            state["plan_worker"], state["plan_box"] = th, box
 
-    def step(timed=None):
-        t = [time.perf_counter()]
-        if trace is not None and timed is None:
-            timed = {}
-            trace.append(timed)
-
-        def lap(name):
-            if timed is not None:
-                now = time.perf_counter()
-                timed[name] = timed.get(name, 0.0) + (now - t[0]) * 1e3
-                t[0] = now
-
-        # host bookkeeping that does not depend on the insert-size statistics (flank windows, depth ranges, points: ~8 ms on one host core for
-        # 10 k junctions) is built by a worker thread beside the GPU work; only the junction windows are refreshed once mean / sd are known.
-        # Like the table copy, it runs one step ahead: the plan a step consumes was started when the step before began its getsv pass (every
-        # step still builds exactly one plan).
-        if state.get("plan_worker") is None:
-            start_plan_worker()
-        worker, box = state["plan_worker"], state["plan_box"]
-        ctx.clip_begin(0.9, 1, False, own, sp["initial_last_tid"])
-        ctx.clip_scan(scan_batch)
-        lap("clip_scan+events")
-        # the cluster table's copy to the host (1.8 GB over PCIe) is queued on a second stream and collected one step later, so it
-        # overlaps with the getsv passes and with the next step's kernels; every table is collected before the timed region ends
-        n_clusters, n_events = ctx.clip_cluster_async()
-        lap("clip_cluster(kernels)")
-        if args.no_overlap or (timed is not None and trace is None):
-            collect_table(prev=False)   # the per-kernel breakdown step and --no-overlap runs: nothing else in flight
-            lap("table_d2h(wait)")
-        rc, npairs, mean, sd = ctx.isize_stats([prefix_batch], 20, 5000000)
-        lap("isize_stats")
-        worker.join()
-        plan = box["plan"]
-        start_plan_worker()   # the next step's
-        plan.update_isize(mean, sd)
-        lap("host_plan(wait)")
-        ctx.getsv_begin(plan.junctions, plan.windows, mean, sd, hdr.target_lens, 4, 20, 20)
-        lap("getsv_begin")
-        ctx.getsv_scan(own_batch)
-        counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
-        lap("getsv_scan+finish")
-        if not (args.no_overlap or (timed is not None and trace is None)):
+        def drain():
             if state["pending"]:
-                collect_table(prev=True)
-            state["pending"] = True
-            lap("table_wait(previous step)")
-        vec = shard.pack_results(counts, rs, pd, n_clusters, n_events, state["support_sum"])
-        stacked = shard.all_gather_vector(vec, coll_dev)
-        merged = shard.merge_results(stacked, len(counts), len(rs), len(pd))
-        lap("exchange")
-        folded = plan.fold(merged[0], merged[1], merged[2])
-        plan.close()
-        lap("host_fold")
-        return dict(n_clusters=merged[3], n_events=merged[4], support_sum=merged[5], mean=mean, sd=sd, abnormal_sum=int(folded["abnormal"].sum()),
-                    depth_sum=int(folded["up_depth"].sum() + folded["down_depth"].sum()), flank_sum=int(folded["flank"].sum()), max_depth=max_depth)
+                collect_table(prev=False)
+                state["pending"] = False
 
-    def barrier():
-        drain()
-        torch.cuda.synchronize()
-        ctx.sync()
+
+        trace = [] if os.environ.get("SSV_BENCH_TRACE") else None   # debugging: wall-clock laps of every step on stderr
+
+        def step(timed=None):
+            t = [time.perf_counter()]
+            if trace is not None and timed is None:
+                timed = {}
+                trace.append(timed)
+
+            def lap(name):
+                if timed is not None:
+                    now = time.perf_counter()
+                    timed[name] = timed.get(name, 0.0) + (now - t[0]) * 1e3
+                    t[0] = now
+
+            # host bookkeeping that does not depend on the insert-size statistics (flank windows, depth ranges, points: ~8 ms on one host core for
+            # 10 k junctions) is built by a worker thread beside the GPU work; only the junction windows are refreshed once mean / sd are known.
+            # Like the table copy, it runs one step ahead: the plan a step consumes was started when the step before began its getsv pass (every
+            # step still builds exactly one plan).
+            if state.get("plan_worker") is None:
+                start_plan_worker()
+            worker, box = state["plan_worker"], state["plan_box"]
+            ctx.clip_begin(0.9, 1, False, own, sp["initial_last_tid"])
+            ctx.clip_scan(scan_batch)
+            lap("clip_scan+events")
+            # the cluster table's copy to the host (1.8 GB over PCIe) is queued on a second stream and collected one step later, so it
+            # overlaps with the getsv passes and with the next step's kernels; every table is collected before the timed region ends
+            n_clusters, n_events = ctx.clip_cluster_async()
+            lap("clip_cluster(kernels)")
+            if args.no_overlap or (timed is not None and trace is None):
+                collect_table(prev=False)   # the per-kernel breakdown step and --no-overlap runs: nothing else in flight
+                lap("table_d2h(wait)")
+            rc, npairs, mean, sd = ctx.isize_stats([prefix_batch], 20, 5000000)
+            lap("isize_stats")
+            worker.join()
+            plan = box["plan"]
+            start_plan_worker()   # the next step's
+            plan.update_isize(mean, sd)
+            lap("host_plan(wait)")
+            ctx.getsv_begin(plan.junctions, plan.windows, mean, sd, hdr.target_lens, 4, 20, 20)
+            lap("getsv_begin")
+            ctx.getsv_scan(own_batch)
+            counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
+            lap("getsv_scan+finish")
+            if not (args.no_overlap or (timed is not None and trace is None)):
+                if state["pending"]:
+                    collect_table(prev=True)
+                state["pending"] = True
+                lap("table_wait(previous step)")
+            vec = shard.pack_results(counts, rs, pd, n_clusters, n_events, state["support_sum"])
+            stacked = shard.all_gather_vector(vec, coll_dev)
+            merged = shard.merge_results(stacked, len(counts), len(rs), len(pd))
+            lap("exchange")
+            folded = plan.fold(merged[0], merged[1], merged[2])
+            plan.close()
+            lap("host_fold")
+            return dict(n_clusters=merged[3], n_events=merged[4], support_sum=merged[5], mean=mean, sd=sd, abnormal_sum=int(folded["abnormal"].sum()),
+                        depth_sum=int(folded["up_depth"].sum() + folded["down_depth"].sum()), flank_sum=int(folded["flank"].sum()), max_depth=max_depth)
+
+        def barrier():
+            drain()
+            torch.cuda.synchronize()
+            ctx.sync()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        res = None
+        # setup, not warmup: both table sets (device + pinned host buffers), both sets of host rebuild buffers and the host thread pool only exist
+        # after four passes have gone through the two-deep table pipeline (the first use of each costs page faults and pinning: 5-10 ms);
+        # whatever W the caller asks for, the timed steps then find them in place
+        for _ in range(max(0, 4 - args.warmup)):
+            step()
+        for _ in range(args.warmup):
+            res = step()
+        import gc
+        gc.collect()
+        gc.disable()   # (a collection inside a 12 ms step is a visible outlier)
+        ctx.prof_reset()
+        ctx.prof_enable(2)  # HIP events around the two streaming kernels only, on the context's stream
+        barrier()
+        t0 = time.perf_counter()
+        step_walls = []
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            res = step()
+            step_walls.append(round((time.perf_counter() - ts) * 1e3, 2))
+        tb = time.perf_counter()
+        barrier()
+        gc.enable()
+        if state.get("plan_worker") is not None:   # the plan built ahead for a step that does not come
+            state["plan_worker"].join()
+            state["plan_box"]["plan"].close()
+            state["plan_worker"] = None
+        if trace is not None:
+            for k, tr in enumerate(trace[-(args.steps):]):
+                print("[bench trace] step", k, {a: round(b, 2) for a, b in tr.items()}, file=sys.stderr)
+            trace = None
+        step_walls.append(("final_barrier", round((time.perf_counter() - tb) * 1e3, 2)))
+        dt = time.perf_counter() - t0
+        prof = {k: ctx.prof_get(k) for k in ("clip_scan", "getsv_scan")}
+        ctx.prof_enable(0)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        # three extra, untimed steps with every kernel group bracketed by events, nothing else in flight: the per-kernel breakdown (per-step means:
+        # one launch of a sub-millisecond kernel varies by a few percent)
+        BREAKDOWN_STEPS = 3
+        ctx.prof_reset()
+        ctx.prof_enable(1)
+        for _ in range(BREAKDOWN_STEPS):
+            step(wall)
+            drain()
+        allprof = ctx.prof_all()
+        for v in allprof.values():   # per step
+            v["total_ms"] /= BREAKDOWN_STEPS
+            v["launches"] = v["launches"] // BREAKDOWN_STEPS if v["launches"] >= BREAKDOWN_STEPS else v["launches"]
+            v["units"] = v["units"] // BREAKDOWN_STEPS
+        for k in list(wall):
+            wall[k] /= BREAKDOWN_STEPS
+        breakdown = {k: round(v["total_ms"], 4) for k, v in allprof.items() if v["launches"]}
+        ctx.prof_enable(0)
+        del scan_batch, scan_t, own_batch, prefix_batch, prefix_t   # (the sample leaves HBM with the leg)
+        return dict(locals())
 
-    res = None
-    # setup, not warmup: both table sets (device + pinned host buffers), both sets of host rebuild buffers and the host thread pool only exist
-    # after four passes have gone through the two-deep table pipeline (the first use of each costs page faults and pinning: 5-10 ms);
-    # whatever W the caller asks for, the timed steps then find them in place
-    for _ in range(max(0, 4 - args.warmup)):
-        step()
-    for _ in range(args.warmup):
-        res = step()
-    import gc
-    gc.collect()
-    gc.disable()   # (a collection inside a 12 ms step is a visible outlier)
-    ctx.prof_reset()
-    ctx.prof_enable(2)  # HIP events around the two streaming kernels only, on the context's stream
-    barrier()
-    t0 = time.perf_counter()
-    step_walls = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        res = step()
-        step_walls.append(round((time.perf_counter() - ts) * 1e3, 2))
-    tb = time.perf_counter()
-    barrier()
-    gc.enable()
-    if state.get("plan_worker") is not None:   # the plan built ahead for a step that does not come
-        state["plan_worker"].join()
-        state["plan_box"]["plan"].close()
-        state["plan_worker"] = None
-    if trace is not None:
-        for k, tr in enumerate(trace[-(args.steps):]):
-            print("[bench trace] step", k, {a: round(b, 2) for a, b in tr.items()}, file=sys.stderr)
-        trace = None
-    step_walls.append(("final_barrier", round((time.perf_counter() - tb) * 1e3, 2)))
-    dt = time.perf_counter() - t0
-    prof = {k: ctx.prof_get(k) for k in ("clip_scan", "getsv_scan")}
-    ctx.prof_enable(0)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    # three extra, untimed steps with every kernel group bracketed by events, nothing else in flight: the per-kernel breakdown (per-step means:
-    # one launch of a sub-millisecond kernel varies by a few percent)
-    BREAKDOWN_STEPS = 3
-    ctx.prof_reset()
-    ctx.prof_enable(1)
-    for _ in range(BREAKDOWN_STEPS):
-        step(wall)
-        drain()
-    allprof = ctx.prof_all()
-    for v in allprof.values():   # per step
-        v["total_ms"] /= BREAKDOWN_STEPS
-        v["launches"] = v["launches"] // BREAKDOWN_STEPS if v["launches"] >= BREAKDOWN_STEPS else v["launches"]
-        v["units"] = v["units"] // BREAKDOWN_STEPS
-    for k in list(wall):
-        wall[k] /= BREAKDOWN_STEPS
-    breakdown = {k: round(v["total_ms"], 4) for k, v in allprof.items() if v["launches"]}
-    ctx.prof_enable(0)
+    R = resident(args)
+    (w, sp, n_own, hdr, ctx, strong, gen_s, state, res, dt, prof, allprof, breakdown, wall, step_walls, BREAKDOWN_STEPS) = (R[k] for k in (
+        "w", "sp", "n_own", "hdr", "ctx", "strong", "gen_s", "state", "res", "dt", "prof", "allprof", "breakdown", "wall", "step_walls", "BREAKDOWN_STEPS"))
 
     if rank == 0:
         assert state["tables"] >= args.steps, "every step's cluster table must have reached the host"
@@ -384,6 +395,33 @@ def main():
             "table": dict(state.get("table_info", {}), host_expand_ms=[round(x, 2) for x in state.get("expand_ms", [])[-6:]], wait_ms=[round(x, 2) for x in state.get("wait_ms", [])[-6:]], bytes=int(state.get("table_bytes", 0)), bytes_per_cluster=round(state.get("table_bytes", 0) / max(1, res["n_clusters"]), 1),
                           note="what crosses PCIe per step; format 3: contig / side / offsets are rebuilt on the host inside the step (ssv_clip_table_expand)"),
         }
+        if world == 1 and not args.no_config3 and not strong:
+            # BASELINE config 3's shape on one GPU: ten times the depth over a tenth of the genome - the same number of records resident in HBM, the
+            # same 10,000 planted SVs, but every planted breakpoint's bin holds 50-150 clipped reads and every junction window ten times the records
+            # (the full 6.18 G-record sample does not fit one GPU at once: tests/test_full_size_gpu.py streams it).  Same step, same timing rules.
+            try:
+                a3 = argparse.Namespace(**vars(args))
+                a3.depth, a3.genome_frac, a3.steps, a3.warmup = args.depth * 10.0, args.genome_frac * 0.1, 5, 2
+                R3 = resident(a3, ctx=ctx)
+                dev3 = {k: v for k, v in R3["allprof"].items() if k in DEVICE_GROUPS and v["launches"]}
+                dev3_ms = sum(v["total_ms"] for v in dev3.values())
+                n3 = R3["n_own"]
+                ev3 = int(R3["res"]["n_events"])
+                line["config3_path"] = {
+                    "workload": f"synthetic {a3.depth:g}x WGS (BASELINE config 3's depth) over genome_frac {a3.genome_frac:g}, 150 bp PE, 1% random soft clips, {len(R3['w'].junctions)} planted DEL/INV/TRA (VAF 0.5), {n3} records resident in HBM",
+                    "records": n3, "steps": a3.steps, "warmup": a3.warmup, "ms_per_step": R3["dt"] / a3.steps * 1e3, "value": R3["w"].n_total * a3.steps / R3["dt"], "unit": "records/s",
+                    "kernel_ms_one_step": R3["breakdown"], "device_kernels_ms": round(dev3_ms, 4),
+                    "roofline": {"bound": "hbm", "achieved": PATH_BYTES_PER_RECORD * n3 / (dev3_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": PATH_BYTES_PER_RECORD * n3 / (dev3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_record": PATH_BYTES_PER_RECORD, "groups": {k: round(v["total_ms"], 4) for k, v in dev3.items()},
+                                 "dominant_group": max(dev3, key=lambda k: dev3[k]["total_ms"])},
+                    "cluster_bins_ns_per_event": round(dev3["cluster_bins"]["total_ms"] * 1e6 / max(1, ev3), 3) if "cluster_bins" in dev3 else None,
+                    "cluster_bins_ns_per_event_default_workload": round(dev["cluster_bins"]["total_ms"] * 1e6 / max(1, int(res["n_events"])), 3) if "cluster_bins" in dev else None,
+                    "table": dict(R3["state"].get("table_info", {}), bytes=int(R3["state"].get("table_bytes", 0)), bytes_per_cluster=round(R3["state"].get("table_bytes", 0) / max(1, R3["res"]["n_clusters"]), 1)),
+                    "result": R3["res"], "generation_s": round(R3["gen_s"], 2)}
+                del R3
+            except BaseException as e:  # (SystemExit too: a report beside the headline)
+                line["config3_path"] = {"error": f"{type(e).__name__}: {e}"}
         if args.file_frac < 0:
             cores_here = os.cpu_count() or 1
             try:

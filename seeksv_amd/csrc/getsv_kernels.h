@@ -488,21 +488,27 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 	}
 }
 
-// the slow paths, one thread per staged record (a wavefront walks one tile's candidates): discordant tally and / or depth coverage
+// the slow paths, one thread per staged record: discordant tally and / or depth coverage.  A workgroup takes four tiles of the scan and all
+// its wavefronts walk each tile's candidates together: candidates come in runs - a tile near a junction holds hundreds (30x) or all of its 4096
+// records (300x, BASELINE config 3), its neighbours none - and with a wavefront per tile the kernel lasted as long as 64 dependent rounds of
+// (record line -> look-up -> junctions / windows -> atomics) on the few wavefronts that had work (300x: 2.32 ms, 91 % of the wave cycles waiting).
 __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 {
-	int64_t t = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
-	if (t >= g.ntiles) return;
-	const uint32_t n = g.tile_cnt[t], so = g.tile_off[t];
-	for (uint32_t k = lane_id(); k < n; k += WAVE) {
-		const int64_t i = g.stage[so + k];
-		const CandRec r = cand_load(a.b, i);
-		const int tid = r.line.tid(), pos = r.line.pos();
-		int64_t tile;
-		const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
-		if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
-		if (m & TM_DEPTH) depth_record(a, r, tid, pos, tile);
-	}
+	const int64_t t0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK;
+	uint32_t n[WAVES_PER_BLOCK], so[WAVES_PER_BLOCK];
+#pragma unroll
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w) { const bool in = t0 + w < g.ntiles; n[w] = in ? g.tile_cnt[t0 + w] : 0u; so[w] = in ? g.tile_off[t0 + w] : 0u; }
+#pragma unroll
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w)
+		for (uint32_t k = threadIdx.x; k < n[w]; k += BLOCK) {
+			const int64_t i = g.stage[so[w] + k];
+			const CandRec r = cand_load(a.b, i);
+			const int tid = r.line.tid(), pos = r.line.pos();
+			int64_t tile;
+			const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
+			if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
+			if (m & TM_DEPTH) depth_record(a, r, tid, pos, tile);
+		}
 }
 
 // K8: per window, running sum of the difference array -> per-column depth (in place); one wavefront per window

@@ -152,6 +152,7 @@ constexpr uint32_t RW_SKIP = 256;                // literals in front of a round
 #endif
 constexpr uint32_t RW_SMALL = RW_SMALL_BYTES;    // a match of up to this many bytes is copied by its own lane (four whole 16-byte pieces and one that ends with the match)
 static_assert(RW_KEEP + RW_ROUND + 64 <= RW_WIN && RW_ROUND >= 1024 && RW_KEEP % 16 == 0, "a round and its history fit the window");
+static_assert(RW_SMALL >= 3 && RW_SMALL <= 79, "the own-lane copy is four 16-byte pieces and one that ends with the match (<= 79 bytes); a deflate match is 3 bytes or more");
 
 __device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)p; } // (the low half of a shared pointer is the LDS address)
 // unaligned LDS accesses (the waits are the caller's: lds_wait makes the registers depend on it)

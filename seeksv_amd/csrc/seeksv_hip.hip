@@ -122,7 +122,7 @@ struct ssv_ctx {
 
 	// ssv_batch_retain's memory: batches are cut out of arenas (a few large allocations instead of one per batch - with 320 batches of a whole-genome file kept,
 	// `seeksv run` spent 0.9 s in allocations that grew slower with every one; an arena is given back when its last batch is released)
-	struct RetainArena { uint8_t *base = nullptr; size_t cap = 0, used = 0; int64_t live = 0; };
+	struct RetainArena { uint8_t *base = nullptr; size_t cap = 0, used = 0; int64_t live = 0; std::vector<size_t> slabs; }; // slabs: where the arena's live batches begin
 	std::vector<RetainArena> arenas;
 
 	// staging of host batches, and the record lines built for batches that come without them
@@ -797,7 +797,7 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 		memcpy(runs, b->tid_runs, (size_t)b->n_tid_runs * sizeof(ssv_tid_run));
 	}
 	ssv_ctx::RetainArena *arena = nullptr;
-	struct Guard { ssv_ctx::RetainArena *&arena; size_t need; ssv_tid_run *&runs; bool keep = false; ~Guard() { if (!keep) { if (arena) { --arena->live; arena->used -= need; } free(runs); } } } guard{arena, off[7], runs};
+	struct Guard { ssv_ctx::RetainArena *&arena; size_t need; ssv_tid_run *&runs; bool keep = false; ~Guard() { if (!keep) { if (arena) { --arena->live; arena->used -= need; arena->slabs.pop_back(); } free(runs); } } } guard{arena, off[7], runs};
 	static const bool timing = getenv("SSV_TIMING_CHUNKS") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
 	{ // room in the newest arena, or a new one: 256 MB first, doubling up to SSV_RETAIN_ARENA_MB (4 GB), never smaller than the batch
@@ -813,6 +813,7 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 			arena = &c->arenas.back();
 		}
 		slab = arena->base + arena->used;
+		arena->slabs.push_back(arena->used);
 		arena->used += off[7]; ++arena->live; // (off[] are multiples of 256: every batch starts 256-byte aligned)
 	}
 	const auto t1 = std::chrono::steady_clock::now();
@@ -847,6 +848,12 @@ int ssv_batch_release(ssv_ctx *c, ssv_batch_t *b)
 		size_t k = 0;
 		while (k < c->arenas.size() && !(at >= c->arenas[k].base && at < c->arenas[k].base + c->arenas[k].cap)) ++k;
 		if (k == c->arenas.size()) { c->err = "not a batch of ssv_batch_retain (no arena holds it)"; return SSV_E_ARG; }
+		// ... and the slab must be one that is live: a copy of a batch released before (or any pointer into an arena) would count the arena down a second
+		// time and hand its memory back while other batches still live in it
+		auto &slabs = c->arenas[k].slabs;
+		const auto it = std::find(slabs.begin(), slabs.end(), (size_t)(at - c->arenas[k].base));
+		if (it == slabs.end()) { c->err = "not a live batch of ssv_batch_retain (released before, or not the start of a batch)"; return SSV_E_ARG; }
+		slabs.erase(it);
 		if (--c->arenas[k].live == 0) {
 			if (k + 1 == c->arenas.size()) c->arenas[k].used = 0;
 			else { HIPCHECK(c, hipFree(c->arenas[k].base)); c->arenas.erase(c->arenas.begin() + (long)k); }

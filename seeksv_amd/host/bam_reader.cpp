@@ -653,7 +653,10 @@ static int read_blocks_impl(ssvh_bam *b, void *dst, const uint8_t *mapped, size_
 	const uint64_t file_size = (uint64_t)st.st_size;
 	const long at0 = ftell(b->z.fp);
 	if (at0 < 0) { g_err = "cannot tell the file position"; return -1; }
-	if (mapped && file_size > b->map_len) { g_err = "the BAM file grew while it was being read"; return -1; }
+	if (mapped && file_size != b->map_len) { // (a mapping past the file's present end faults - SIGBUS - where the header walk or the DMA touches it: refuse before)
+		g_err = file_size > b->map_len ? "the BAM file grew while it was being read" : "the BAM file was truncated while it was being read";
+		return -1;
+	}
 	const uint8_t *d = mapped ? mapped + at0 : static_cast<const uint8_t *>(dst);
 	uint8_t *const dw = static_cast<uint8_t *>(dst);
 	if (ptr) *ptr = d;

@@ -159,6 +159,31 @@ def test_mapped_chunks_equal_copied_chunks(bam):
         assert sum(len(d) for d, _ in chunks[1]) in (size, size - 28)  # (the end-of-file block may or may not be part of the last chunk)
 
 
+def test_mapped_reader_refuses_a_truncated_file(bam, tmp_path):
+    """a file cut short (or replaced by a shorter one) while the mapped reader works on it: its next chunk would touch pages of the mapping behind the
+    file's end - SIGBUS in the header walk or the DMA; the reader notices the size before and reports an error"""
+    import ctypes as C
+    import shutil
+    from seeksv_amd import _abi
+    path, _ = bam
+    lib = _abi.host_lib()
+    lib.ssvh_bam_map_blocks.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(_abi.BgzfBlock), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.ssvh_last_error.restype = C.c_char_p
+    mine = str(tmp_path / "cut.bam")
+    shutil.copy(path, mine)
+    h = C.c_void_p()
+    assert lib.ssvh_bam_open(mine.encode(), C.byref(h)) == 0
+    first = C.c_uint64()
+    assert lib.ssvh_bam_raw_begin(h, C.byref(first)) == 0
+    blocks = (_abi.BgzfBlock * 4096)()
+    nb, nbytes, ptr = C.c_int64(), C.c_size_t(), C.c_void_p()
+    assert lib.ssvh_bam_map_blocks(h, 70000, 1 << 30, blocks, 4096, C.byref(nb), C.byref(ptr), C.byref(nbytes)) == 0 and nb.value >= 1
+    os.truncate(mine, os.path.getsize(mine) // 2)
+    assert lib.ssvh_bam_map_blocks(h, 1 << 20, 1 << 30, blocks, 4096, C.byref(nb), C.byref(ptr), C.byref(nbytes)) != 0
+    assert b"truncated" in lib.ssvh_last_error()
+    lib.ssvh_bam_close(h)
+
+
 def _block_table_digest(path):
     """sha256 over the block tables of the file read as ONE chunk (ssvh_bam_read_blocks), and the number of blocks"""
     import ctypes as C

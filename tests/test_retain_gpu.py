@@ -33,7 +33,16 @@ part = ctx.getclip(rest)
 assert 0 < part["n_clusters"] < want["n_clusters"]
 again = [ctx.batch_retain(k) for k in rest]              # a copy of a kept batch, in room that was given back or in a new arena
 assert ctx.getclip(again)["n_clusters"] == part["n_clusters"]
-for k in rest + again:
+import ctypes
+dup = type(again[0]).from_buffer_copy(again[0])         # a by-value copy of a handle: released once through the original ...
+ctx.batch_release(again[0])
+try:
+    ctx.batch_release(dup)                                # ... and refused through the copy: its slab is no longer live (the arena's count stays right,
+    raise SystemExit("the copy of a released handle was accepted")   # the batches that still live in it keep their memory)
+except RuntimeError:
+    pass
+assert ctx.getclip(again[1:])["n_clusters"] > 0
+for k in rest + again[1:]:
     ctx.batch_release(k)
 bad = rest[0]
 try:
