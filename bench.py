@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip config3_path (BASELINE config 3's shape: 300x over a tenth of the genome, the same number of records, resident in HBM)")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip cli_path (the `seeksv` binary as child processes on the file leg's BAM)")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
-    ap.add_argument("--table-format", type=int, default=3, help="ssv_clip_table_format: 3 = the compact table (default), 2 = four-piece blocks with 4-bit bases, 0 = ASCII")
+    ap.add_argument("--table-format", type=int, default=3, help="ssv_clip_table_format: 3 = the compact table (default), 0 = ASCII")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak (default): every GPU holds its own --depth sample, N GPUs = N x depth over the same genome.  "
                     "strong = BASELINE config 4: ONE sample of --strong-depth (300x tumor WGS, 6.18 G records) range-partitioned N ways; refused where a rank's share does not fit its GPU")
     ap.add_argument("--strong-depth", type=float, default=300.0, help="coverage of the one sample that --scaling strong splits over the GPUs")

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SSV_ABI_VERSION 7
+#define SSV_ABI_VERSION 8 /* v8: table formats 1 and 2 (four-piece blocks with 4-bit bases) removed - 0 ASCII or 3 compact; ssv_group with SSV_GROUP_RCCL_ONE */
 
 typedef enum {
 	SSV_OK = 0,
@@ -242,16 +242,10 @@ typedef struct {
 	const uint64_t *cigar_off; /* [n_clusters] offset into cigar */
 	const int32_t *n_cigar;    /* [n_clusters] ops of the record whose CIGAR the cluster carries */
 	const uint32_t *cigar;     /* BAM-encoded ops INCLUDING S/H (GenerateCigar drops those when printing) */
-	int32_t seq_packed;        /* 0: the layout above.  1 (ssv_clip_table_format): a block is
-	                              [seq_left ceil(left_len/2) B | qual_left | seq_right ceil(right_len/2) B | qual_right]
-	                              with the sequences as 4-bit codes, two per byte, first base in the high nibble, index into
-	                              "=ACMGRSVTWYHKDBN" (BAM's own packing).  The table is the path's output and it crosses PCIe. */
-	int32_t qual_bits;         /* 8: qualities are characters (phred + 33), one byte each.  1, 2, 3, 4 (format 2 only, when at most 2, 4, 8,
-	                              16 distinct quality values occur in the pass): a piece of n qualities is the stream of their indices
-	                              into qual_alphabet, qual_bits wide each, quality i at stream bit i * qual_bits (bit b of the stream = bit
-	                              b % 8 of byte b / 8; with 3 bits an index can straddle two bytes); the piece takes
-	                              ceil(n * qual_bits / 8) bytes, unused bits are 0.  Lossless: base qualities are most of the table's bytes
-	                              and come from a handful of values on current sequencers. */
+	int32_t seq_packed;        /* 0: the layout above (format 0).  1: format 3, below. */
+	int32_t qual_bits;         /* 8: qualities are characters (phred + 33), one byte each; format 3: bits per quality (or per group of qualities) in the
+	                              quality stream, below.  Lossless: base qualities are most of the table's bytes and come from a handful of values
+	                              on current sequencers. */
 	uint8_t qual_alphabet[16]; /* index -> quality character */
 	/* ---- format 3, the compact table: what the host can rebuild does not cross PCIe ----
 	 * Handed out by ssv_clip_table_wait: pos, c_cigar (cigar too when cigar_bytes is 4), str and the fields below; tid, side, support, left_len, right_len, qual_missing,
@@ -291,10 +285,9 @@ typedef struct {
 	int32_t cigar_bytes, pad4;
 } ssv_cluster_table;
 
-/* Table format of the following ssv_clip_cluster[_async] calls: 0 ASCII (default), 1 sequences as 4-bit codes, 2 the same plus
- * qualities as alphabet indices when the pass's quality alphabet is small enough (else they stay bytes: qual_bits tells), 3 the
- * compact table (see ssv_cluster_table: ~110 instead of ~170 bytes per 150-base cluster; the table is the path's output and PCIe
- * bounds the step). */
+/* Table format of the following ssv_clip_cluster[_async] calls: 0 ASCII (default), 3 the compact table (see ssv_cluster_table: ~100
+ * instead of ~330 bytes per 150-base cluster; the table is the path's output and PCIe bounds the step).  (1 and 2, the four-piece blocks
+ * with 4-bit bases of ABI versions below 8, are gone: SSV_E_ARG.) */
 int ssv_clip_table_format(ssv_ctx *ctx, int format);
 /* Format 3: rebuild the columns that did not cross PCIe (contig and side from the runs, the widened support / lengths / flags, string
  * and CIGAR offsets as running sums) into context-owned host memory, on n_threads host threads (0: as many as the machine has), and
@@ -304,7 +297,7 @@ int ssv_clip_table_expand(ssv_ctx *ctx, ssv_cluster_table *t, int32_t n_threads)
 uint64_t ssv_table_block_bytes3(int64_t n_bases, int32_t base_bits, int32_t qual_bits);
 /* The same for a table whose qualities go in groups (ssv_cluster_table.qual_group; 1 = the function above). */
 uint64_t ssv_table_block_bytes3g(int64_t n_bases, int32_t base_bits, int32_t qual_bits, int32_t qual_group);
-/* Bytes of one cluster's string block (a multiple of 4). */
+/* Bytes of one cluster's string block in format 0 (a multiple of 4; seq_packed = 0, qual_bits = 8). */
 uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits);
 
 /* Sort events into (contig, side, position) bins and run the greedy consensus clustering. */

@@ -2,7 +2,8 @@
 //
 // Replaces, for whole-file passes, libbam's samread() (sam/sam.h:73: bgzf inflate + bam_read1) that the reference calls once per
 // record on one core.  Data flow of one chunk (a run of whole BGZF blocks, compressed bytes already in HBM):
-//   k_bgzf_inflate    one LANE per BGZF block (independent deflate streams), Huffman tables in LDS interleaved by lane
+//   k_bgzf_tokens(_wave) + k_bgzf_resolve_win   the inflate as two passes: a wavefront per BGZF block decodes its symbols (literals in place, a 32-bit token per
+//                     match; a lane per block above 64 K blocks a chunk), a wavefront per block then fills the matches' holes inside a window of the block in LDS
 //   k_find_records    one lane per block: speculate the first record start inside the block (three plausible headers in a row), follow
 //                     the block_size chain to the block end: guess, exit offset, record count
 //   k_stitch_blocks   one wavefront: verify every guess against the true chain (exit of the previous block), repair wrong ones by
@@ -22,7 +23,6 @@
 #include "inflate_core.h"
 #include "resolve_wave.h"
 #include "inflate_wave.h"
-#include "inflate_lanes.h"
 
 namespace ssv {
 
@@ -71,35 +71,13 @@ constexpr int INFLATE_SCRATCH_BYTES = 320 * 64 + 16 * 64 * 2;           // globa
 
 struct BgzfBlock { uint64_t c_off; uint32_t c_len, u_len; }; // deflate payload inside the chunk buffer; inflated size
 
-// One lane per BGZF block, LPW blocks per wavefront (64; fewer = more, narrower wavefronts: an experiment).
-// status[b] = 0 or the lane's error code.
-template <bool COPY2, int LPW>
-__global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
-                                                       uint8_t *__restrict__ out, int *__restrict__ status, uint8_t *__restrict__ scratch)
-{
-	extern __shared__ uint8_t lds_raw[];
-	if ((int)threadIdx.x >= LPW) return;
-	LdsTabT<LPW> tab;
-	tab.lit8 = lds_raw;
-	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
-	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;
-	tab.len8 = scratch + (size_t)blockIdx.x * (INFLATE_SCRATCH_BYTES / 64 * LPW);
-	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * LPW);
-	tab.lane = (int)threadIdx.x;
-	const int64_t b = (int64_t)blockIdx.x * LPW + threadIdx.x;
-	if (b >= n_blocks) return;
-	const BgzfBlock blk = blocks[b];
-	int rc = INF_OK;
-	if (blk.u_len) rc = inflate_stream<LdsTabT<LPW>, COPY2>(comp + blk.c_off, blk.c_len, out + u_off[b], blk.u_len, tab);
-	status[b] = rc;
-}
-
 // ---- decode and copy split in two (TokenOut, inflate_core.h) ------------------------------------------------------------------------
 //
 // Pass 1, k_bgzf_tokens: the decoder as above, one lane per block, but a match is only RECORDED (a 32-bit token) - the lane never reads the
 // block's output, so its chain per symbol is bits -> table -> store, no trip to memory to wait for.
-// Pass 2, k_bgzf_resolve: 16 lanes per block fill the holes in order: a match is one unaligned-dword load and store per four bytes, all of a match's
-// (up to 64 bytes per round) at once; the group waits for its own stores only when a match reads what an earlier match of this pass wrote.
+// Pass 2 (k_bgzf_resolve_win / k_bgzf_resolve_wave, resolve_wave.h) fills the holes.  The forms that lost - one pass with every lane loading and storing for
+// itself, a 64-byte line buffer per lane, LDS rings moved by the wavefront, pass 2 with 16 lanes per block or a workgroup per block in LDS - are in the history
+// (HISTORY.md, git: rounds 1-4).
 // the input window of one lane (RingReader, inflate_core.h): dword j of lane l at word j * LPW + l - a wavefront's lanes hit different banks
 template <int LPW>
 struct LdsRing {
@@ -157,110 +135,6 @@ __global__ __launch_bounds__(WAVE, 5) void k_bgzf_tokens_wave(const uint8_t *__r
 	if (threadIdx.x == 0) { status[b] = rc; n_tok[b] = rc == INF_OK ? nt : 0u; }
 }
 
-constexpr int RESOLVE_LANES = 16;
-
-// one match, all of the group's lanes on it (64 bytes per round); a repeating pattern (dist < len) goes byte by byte: all its sources lie before it.
-// (Tried: all loads of a long match / of a pattern before the first store, five dwords a lane - more instructions on a path that every group of
-// the wavefront walks whenever one of them has such a match: pass 2 went from 15.5 to 26.7 ms on real reads.)
-__device__ __forceinline__ void resolve_one(uint8_t *o, uint32_t pos, uint32_t len, uint32_t dist, int gl)
-{
-	const uint32_t src = pos - dist;
-	if (dist >= len && len > 4u * RESOLVE_LANES) {
-		// a long match (65..258 bytes; rare in real reads, 18 % of the matches of a low-entropy file): up to five dwords a lane, the loads of all of them
-		// before the first store - one trip instead of five.  Its own branch, so that the common short match does not pay for the extra instructions.
-		const uint32_t last = len - 4u, o0 = 4u * (uint32_t)gl;
-		uint32_t r[5], q[5];
-#pragma unroll
-		for (int i = 0; i < 5; ++i) {
-			const uint32_t off = o0 + 64u * (uint32_t)i;
-			q[i] = off < last ? off : last; // (a dword that would reach past the end is moved back to end with the match: same bytes)
-			r[i] = 0;
-			if (off < len) r[i] = ld32(o + src + q[i]);
-		}
-#pragma unroll
-		for (int i = 0; i < 5; ++i)
-			if (o0 + 64u * (uint32_t)i < len) st32u(o + pos + q[i], r[i]);
-	} else if (dist >= len) {
-		for (uint32_t base = 0; base < len; base += 4u * RESOLVE_LANES) {
-			const uint32_t off = base + 4u * (uint32_t)gl;
-			if (off + 4u <= len) st32u(o + pos + off, ld32(o + src + off));
-			else if (off < len) { // the match ends inside this lane's dword
-				if (len >= 4u) st32u(o + pos + len - 4u, ld32(o + src + len - 4u)); // one dword that ends with the match (it overlaps the one before: same bytes)
-				else for (uint32_t i = off; i < len; ++i) o[pos + i] = o[src + i];
-			}
-		}
-	} else {
-		for (uint32_t i = (uint32_t)gl; i < len; i += RESOLVE_LANES) o[pos + i] = o[src + i % dist];
-	}
-}
-
-// Sixteen tokens per round, one per lane; a prefix sum over the group gives every match its place.  The round is worked off in PHASES, each one
-// trip to memory: a match is ready when its source touches no hole of an earlier match of the round that is still open; all ready short matches
-// are copied at once, every lane its own - the loads of all of them, then the stores - and ready long matches / repeating patterns one after the
-// other with all lanes on each.  Phase one needs no look at the other lanes: a source that ends before the round's first byte is ready.  Typical:
-// two phases a round instead of a trip per match.  Stores of this pass are waited for only when a source reaches above the watermark `dirty`.
-__global__ __launch_bounds__(BLOCK) void k_bgzf_resolve(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
-                                                        int64_t n_blocks, uint8_t *out)
-{
-	const int gl = (int)threadIdx.x % RESOLVE_LANES;
-	const int grp_shift = (int)(threadIdx.x % WAVE) / RESOLVE_LANES * RESOLVE_LANES;
-	const int64_t b = (int64_t)blockIdx.x * (BLOCK / RESOLVE_LANES) + threadIdx.x / RESOLVE_LANES;
-	if (b >= n_blocks) return;
-	const uint32_t n = n_tok[b];
-	uint8_t *o = out + u_off[b];
-	const uint32_t *tk = tokens + tok_off[b];
-	uint32_t pos = 0;
-	uint32_t dirty = 0xffffffffu; // positions from here on may hold stores of this pass that have not been waited for
-	uint32_t next = (uint32_t)gl < n ? tk[gl] : TOKEN_NONE;
-	for (uint32_t t0 = 0; t0 < n; t0 += RESOLVE_LANES) {
-		const uint32_t w = next;
-		next = t0 + RESOLVE_LANES + (uint32_t)gl < n ? tk[t0 + RESOLVE_LANES + gl] : TOKEN_NONE; // the next round's tokens travel with this round's loads
-		const bool esc = (w >> 23) == 511u;
-		const uint32_t lit = esc ? (w & 0x7fffffu) : (w >> 23);
-		const uint32_t len = esc ? 0u : (w & 255u) + 3u, dist = ((w >> 8) & 0x7fffu) + 1u;
-		uint32_t inc = lit + len; // -> inclusive sum over the group: where this lane's token ends
-#pragma unroll
-		for (int d = 1; d < RESOLVE_LANES; d <<= 1) {
-			const uint32_t v = (uint32_t)__shfl_up((int)inc, d, RESOLVE_LANES);
-			if (gl >= d) inc += v;
-		}
-		const uint32_t total = (uint32_t)__shfl((int)inc, RESOLVE_LANES - 1, RESOLVE_LANES);
-		const uint32_t dst = pos + inc - len, src = dst - dist;
-		const uint32_t need = len < dist ? len : dist; // the source's bytes: [src, src + need)
-		const bool small = !esc && dist >= len && len <= 32u; // copied by its own lane (a long match is quicker with all the lanes on it)
-		bool done = esc;
-		// ---- phase one ----
-		bool ready = !done && src + need <= pos;
-		for (;;) {
-			if (__any(ready && src + need > dirty)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dirty = 0xffffffffu; }
-			copy_own_wide(o, src, dst, ready && small ? len : 0u);
-			uint32_t m = (uint32_t)(__ballot(ready && !small) >> grp_shift) & 0xffffu;
-			while (__any(m != 0u)) {
-				if (m) {
-					const int k = __ffs((int)m) - 1;
-					m &= m - 1u;
-					resolve_one(o, (uint32_t)__shfl((int)dst, k, RESOLVE_LANES), (uint32_t)__shfl((int)len, k, RESOLVE_LANES), (uint32_t)__shfl((int)dist, k, RESOLVE_LANES), gl);
-				}
-			}
-			if (dirty > pos) dirty = pos;
-			done = done || ready;
-			if (!__any(!done)) break;
-			// ---- the next phase: ready = no open hole of an earlier match of the round under the source ----
-			// (the group is one DPP row: fifteen rotations show every lane all the others - register moves, no trip through LDS; the rotated lane
-			// number says whose values they are)
-			bool blocked = false;
-			const int meta = gl | ((int)!done << 4);
-#define SSV_ROR(K) { const uint32_t hs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dst, 0x120 + K, 0xf, 0xf, false), hl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)len, 0x120 + K, 0xf, 0xf, false); \
-				const int mt = __builtin_amdgcn_update_dpp(0, meta, 0x120 + K, 0xf, 0xf, false); \
-				blocked = blocked || ((mt & 15) < gl && (mt & 16) && src < hs + hl && hs < src + need); }
-			SSV_ROR(1) SSV_ROR(2) SSV_ROR(3) SSV_ROR(4) SSV_ROR(5) SSV_ROR(6) SSV_ROR(7) SSV_ROR(8) SSV_ROR(9) SSV_ROR(10) SSV_ROR(11) SSV_ROR(12) SSV_ROR(13) SSV_ROR(14) SSV_ROR(15)
-#undef SSV_ROR
-			ready = !done && !blocked;
-		}
-		pos += total;
-	}
-}
-
 // ---- pass 2 with ONE WAVEFRONT per block (round 4; resolve_wave.h) ----------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve_wave(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
                                                              int64_t n_blocks, uint8_t *out)
@@ -284,397 +158,6 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve_win(const uint32_t *__re
 	const uint32_t n = n_tok[b];
 	if (n == 0u) return;
 	wave_resolve_tokens_win<DBG>(out + u_off[b], blocks[b].u_len, tokens + tok_off[b], n, s_win[wave_id()], lane_id(), dbg);
-}
-
-// ---- pass 2 with the block in LDS -----------------------------------------------------------------------------------------------------
-//
-// k_bgzf_resolve above fills a block's holes in global memory: every match source is a line touched at random somewhere in the last 32 KB
-// of one of the ~30 K blocks in flight - 0.43 G L2 misses per 4 GB of output, 14 x the output in fabric traffic, and no launch shape
-// changed its time.  Here a WORKGROUP takes a block: its bytes (literals in place, holes open) come into LDS with
-// coalesced 16-byte loads, the matches are resolved there, and the finished block leaves with coalesced 16-byte stores: two trips of the
-// block through memory plus its tokens, whatever the matches look like.
-//   Rounds of RL_T tokens (one per thread); a workgroup-wide prefix sum gives every match its place.
-//   What decides the time is the DEPTH of the copy chains, not the bytes: in a BAM the fixed fields of a record are a copy of the same
-//   fields of the record before, which are a copy of ... - hundreds of matches deep per block; worked off level by level (a match is
-//   ready when the matches its source touches are done) that is hundreds of barriers per block.  So chains are FLATTENED first, without
-//   any copying: while a match's source lies inside the hole of ONE earlier match j of the round, the bytes it wants are by definition
-//   the bytes j wants - its source moves to j's source (+ offset), and j publishes where its own source has moved to meanwhile, so
-//   chains collapse in a few steps, all threads at once, no barrier.  What is left - sources that straddle two tokens - goes level by
-//   level: a match is ready when every earlier match whose hole its source touches is done ([lo, hi]: two binary searches); all ready
-//   matches are copied at once: up to RL_OWN bytes by the match's own thread (all loads, then all stores), longer ones and repeating
-//   patterns by a whole wavefront each; two barriers a level.
-constexpr int RL_T = 512;                 // threads = tokens per round
-constexpr int RL_WAVES = RL_T / WAVE;
-constexpr int RL_OWN = 16;                // longest match a thread copies by itself
-constexpr int RL_FLAT_STEPS = 12;         // flattening steps per match and round (pointer jumping: 2^12 matches deep; what is left goes by readiness)
-constexpr uint32_t RL_WIN = 65536 + 64;   // the block's bytes from the 16-byte boundary below its first one
-constexpr size_t RL_LDS_BYTES = RL_WIN + (size_t)RL_T * (4 * 4 + 2 + 1) + 64 + 64;
-
-__global__ __launch_bounds__(RL_T) void k_bgzf_resolve_lds(const uint32_t *__restrict__ tokens, const uint64_t *__restrict__ tok_off, const uint32_t *__restrict__ n_tok, const uint64_t *__restrict__ u_off,
-                                                          const BgzfBlock *__restrict__ blocks, int64_t n_blocks, uint8_t *out, unsigned long long *dbg)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t rl_lds[];
-	// SSV_RESOLVE_PHASES=1 (dbg != nullptr): cycles of workgroup thread 0 per phase, and step counts, summed over the launch
-	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, steps_flat = 0, steps_spin = 0, n_rounds = 0, n_blk = 0;
-	unsigned long long tc = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-#define RL_LAP(K) do { if (dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[K] += now_ - tc; tc = now_; } } while (0)
-	uint8_t *Wa = rl_lds;                                                   // the window, 16-byte groups as they lie in memory
-	uint32_t *s_dst = reinterpret_cast<uint32_t *>(rl_lds + RL_WIN);       // [RL_T] where token i's hole starts (block position)
-	uint32_t *s_end = s_dst + RL_T;                                         // [RL_T] ... and ends
-	uint32_t *s_src = s_end + RL_T;                                         // [RL_T] where its source starts NOW (moves back while chains are flattened)
-	uint32_t *s_dist = s_src + RL_T;                                        // [RL_T] the match's own distance (the period of a repeating pattern)
-	uint16_t *s_long = reinterpret_cast<uint16_t *>(s_dist + RL_T);         // [RL_T] the level's long matches (token numbers)
-	uint8_t *s_done = reinterpret_cast<uint8_t *>(s_long + RL_T);           // [RL_T]
-	uint32_t *s_misc = reinterpret_cast<uint32_t *>(rl_lds + RL_WIN + (size_t)RL_T * 19 + 64); // [0..7] wave sums, [8], [9] long counts (by level parity)
-	const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
-	for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-		const uint32_t n = n_tok[b], ulen = blocks[b].u_len;
-		if (n == 0u || ulen == 0u) continue; // no match in the block: pass 1 has written all of it
-		uint8_t *a0 = out + u_off[b];
-		const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(a0) & 15u);
-		const uint4 *g16 = reinterpret_cast<const uint4 *>(a0 - mis);
-		const uint32_t ngroups = (mis + ulen + 15u) >> 4;
-		__syncthreads(); // (the block before has left the window)
-		RL_LAP(5); ++n_blk;
-		for (uint32_t g = (uint32_t)tid; g < ngroups; g += RL_T) reinterpret_cast<uint4 *>(Wa)[g] = g16[g]; // (up to 15 bytes of the neighbours at either end: read, never written back)
-		uint8_t *W = Wa + mis; // block position p lives at W[p]
-		const uint32_t *tk = tokens + tok_off[b];
-		uint32_t P = 0;
-		uint32_t next = (uint32_t)tid < n ? tk[tid] : TOKEN_NONE;
-		for (uint32_t t0 = 0; t0 < n; t0 += RL_T) {
-			const uint32_t w = next;
-			next = t0 + RL_T + (uint32_t)tid < n ? tk[t0 + RL_T + tid] : TOKEN_NONE;
-			const bool esc = (w >> 23) == 511u;
-			const uint32_t lit = esc ? (w & 0x7fffffu) : (w >> 23);
-			const uint32_t len = esc ? 0u : (w & 255u) + 3u, dist = ((w >> 8) & 0x7fffu) + 1u;
-			// ---- places: inclusive sum of (literals + match) over the workgroup ----
-			const uint32_t inc_w = wave_inclusive_sum(lit + len);
-			if (lane == WAVE - 1) s_misc[wv] = inc_w;
-			__syncthreads();
-			uint32_t before = 0, total = 0;
-#pragma unroll
-			for (int k = 0; k < RL_WAVES; ++k) { const uint32_t x = s_misc[k]; if (k < wv) before += x; total += x; }
-			const uint32_t dst = P + before + inc_w - len, need = len < dist ? len : dist; // the source's bytes: [src, src + need)
-			uint32_t src = dst - dist;
-			s_dst[tid] = dst; s_end[tid] = dst + len; s_src[tid] = src; s_dist[tid] = dist;
-			bool done = len == 0u;
-			s_done[tid] = done ? 1 : 0;
-			__syncthreads();
-			RL_LAP(t0 == 0 ? 0 : 1); ++n_rounds;
-			// ---- flatten the chains: while the source lies inside ONE earlier hole of the round, take that match's source instead ----
-			if (!done) {
-				int top = tid; // the token under the source is searched among [0, top)
-				for (int step = 0; step < RL_FLAT_STEPS && src + need > P; ++step) {
-					int a = 0, z = top;             // last j in [0, top) with s_dst[j] <= src
-					while (a < z) { const int m = (a + z) >> 1; if (s_dst[m] <= src) a = m + 1; else z = m; }
-					const int j = a - 1;
-					if (j < 0) break;
-					const uint32_t dj = s_dst[j], ej = s_end[j];
-					if (src + need > ej) break;     // behind hole j (literals, maybe the next hole too) or across its end: the levels' business
-					const uint32_t o = src - dj, distj = s_dist[j], lenj = ej - dj, needj = lenj < distj ? lenj : distj;
-					if (o + need <= needj) src = s_src[j] + o;              // j's bytes [o, o + need) are its source's bytes [o, o + need)
-					else src -= (o / distj + 1u) * distj;                  // inside a repeating pattern: whole periods back, until in front of the hole
-					s_src[tid] = src;               // (whoever reads it meanwhile gets the old or the new place: both hold the same bytes)
-					top = j + 1;
-					++steps_flat;
-				}
-			}
-			RL_LAP(2);
-			// ---- whose holes does the source still touch?  earlier tokens [lo, hi] of this round (none: lo > hi) ----
-			int lo = 0, hi = -1;
-			if (!done && src + need > P) {
-				int a = 0, z = tid;                 // first j in [0, tid) with s_end[j] > src
-				while (a < z) { const int m = (a + z) >> 1; if (s_end[m] > src) z = m; else a = m + 1; }
-				lo = a;
-				a = lo; z = tid;                    // first j in [lo, tid) with s_dst[j] >= src + need
-				while (a < z) { const int m = (a + z) >> 1; if (s_dst[m] >= src + need) z = m; else a = m + 1; }
-				hi = a - 1;
-			}
-			// ---- the rest goes by readiness, every WAVEFRONT for itself: a match is ready when every earlier match whose hole its source touches
-			//      is done (flags in LDS); a wavefront copies what is ready among its 64 tokens, makes the bytes visible, raises the flags, and looks
-			//      again - no workgroup barrier inside a round: the token that is first in file order among the unfinished ones is always ready,
-			//      and all wavefronts of the workgroup are resident, so the spinning ones are always waited on by one that moves ----
-			volatile uint8_t *vdone = s_done;
-			RL_LAP(3);
-			while (__any(!done)) {
-				++steps_spin;
-				bool ready = !done;
-				for (int j = lo; ready && j <= hi; ++j) ready = vdone[j] != 0;
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // the bytes behind the flags just read
-				const bool own = ready && len <= (uint32_t)RL_OWN && dist >= len;
-				if (__any(own)) { // every thread its own short match: the loads, then the stores (the source is final and does not overlap the hole)
-					uint8_t v[RL_OWN];
-#pragma unroll
-					for (int k = 0; k < RL_OWN; ++k) v[k] = own && (uint32_t)k < len ? W[src + (uint32_t)k] : (uint8_t)0;
-#pragma unroll
-					for (int k = 0; k < RL_OWN; ++k) if (own && (uint32_t)k < len) W[dst + (uint32_t)k] = v[k];
-				}
-				// long matches and repeating patterns: the whole wavefront on each, 64 bytes a step; byte k of the hole is byte k mod dist of the source
-				for (uint64_t m = __ballot(ready && !own); m; m &= m - 1) {
-					const int k0 = __ffsll((long long)m) - 1;
-					const uint32_t d0 = (uint32_t)__shfl((int)dst, k0, WAVE), l0 = (uint32_t)__shfl((int)len, k0, WAVE), di = (uint32_t)__shfl((int)dist, k0, WAVE), s0 = (uint32_t)__shfl((int)src, k0, WAVE);
-					if (di >= l0) {
-						uint8_t v[5];
-#pragma unroll
-						for (int q = 0; q < 5; ++q) { const uint32_t k = (uint32_t)lane + 64u * (uint32_t)q; v[q] = k < l0 ? W[s0 + k] : (uint8_t)0; }
-#pragma unroll
-						for (int q = 0; q < 5; ++q) { const uint32_t k = (uint32_t)lane + 64u * (uint32_t)q; if (k < l0) W[d0 + k] = v[q]; }
-					} else {
-						for (uint32_t k = (uint32_t)lane; k < l0; k += WAVE) W[d0 + k] = W[s0 + k % di];
-					}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the copies have landed in LDS before a flag says so
-				if (ready) { vdone[tid] = 1; done = true; }
-			}
-			__syncthreads(); // the round is resolved: the next round's sources may lie anywhere in it
-			RL_LAP(4);
-			P += total;
-		}
-		__syncthreads();
-		// ---- the finished block: whole 16-byte groups, the two ragged ends byte by byte ----
-		uint4 *o16 = reinterpret_cast<uint4 *>(a0 - mis);
-		for (uint32_t g = (uint32_t)tid; g < ngroups; g += RL_T) {
-			const uint32_t p0 = g << 4;
-			if (p0 >= mis && p0 + 16u <= mis + ulen) o16[g] = reinterpret_cast<const uint4 *>(Wa)[g];
-			else for (uint32_t k = 0; k < 16u; ++k) if (p0 + k >= mis && p0 + k < mis + ulen) (a0 - mis)[p0 + k] = Wa[p0 + k];
-		}
-	}
-	if (dbg) {
-		RL_LAP(5);
-		if (tid == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&dbg[k], tm[k]); atomicAdd(&dbg[6], n_rounds); atomicAdd(&dbg[7], n_blk); }
-		if (lane == 0) atomicAdd(&dbg[9], steps_spin);
-		atomicAdd(&dbg[8], steps_flat);
-	}
-#undef RL_LAP
-}
-
-// The same decoder writing through a 64-byte line buffer per lane (LineOut, inflate_core.h): 64 x LPW bytes of LDS more per wavefront.
-struct LdsLine {
-	uint8_t *base; // this wavefront's lines: 16-byte group g of lane l at ((g * stride + l) * 16)
-	int lane, stride;
-	__device__ __forceinline__ uint8_t *grp(uint32_t g) const { return base + ((g * (uint32_t)stride + (uint32_t)lane) << 4); }
-	__device__ __forceinline__ uint8_t get8(uint32_t i) const { return grp(i >> 4)[i & 15u]; }
-	__device__ __forceinline__ void set8(uint32_t i, uint8_t v) { grp(i >> 4)[i & 15u] = v; }
-	__device__ __forceinline__ void set32(uint32_t di, uint32_t v) { *reinterpret_cast<uint32_t *>(grp(di >> 2) + 4 * (di & 3u)) = v; }
-	__device__ __forceinline__ void store16(uint8_t *dst, uint32_t g) const { *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(grp(g)); }
-};
-
-template <int LPW>
-__global__ __launch_bounds__(WAVE) void k_bgzf_inflate_wc(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
-                                                          uint8_t *__restrict__ out, int *__restrict__ status, uint8_t *__restrict__ scratch)
-{
-	extern __shared__ uint8_t lds_raw[];
-	if ((int)threadIdx.x >= LPW) return;
-	LdsTabT<LPW> tab;
-	tab.lit8 = lds_raw;
-	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * LPW);
-	tab.dst8 = lds_raw + 288 * LPW + 9 * LPW * 4;
-	tab.len8 = scratch + (size_t)blockIdx.x * (INFLATE_SCRATCH_BYTES / 64 * LPW);
-	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * LPW);
-	tab.lane = (int)threadIdx.x;
-	const int64_t b = (int64_t)blockIdx.x * LPW + threadIdx.x;
-	if (b >= n_blocks) return;
-	const BgzfBlock blk = blocks[b];
-	LineOut<LdsLine> lo;
-	lo.out = out + u_off[b];
-	lo.a0 = (uint32_t)(reinterpret_cast<uintptr_t>(lo.out) & 63u);
-	lo.flushed = 0;
-	lo.line.base = lds_raw + INFLATE_LDS_BYTES / 64 * LPW; lo.line.lane = (int)threadIdx.x; lo.line.stride = LPW;
-	int rc = INF_OK;
-	if (blk.u_len) rc = inflate_stream_to(comp + blk.c_off, blk.c_len, lo, blk.u_len, tab);
-	status[b] = rc;
-}
-
-// ---- the ring machine (inflate_lanes.h) ------------------------------------------------------------------------------------------
-//
-// Still one lane per BGZF block, but a lane's compressed bytes and its fresh output live in two LDS rings; the WAVEFRONT moves them between
-// the rings and memory, half a ring at a time: one coalesced load / store of 16 (8) lanes for every lane that asks, instead of 64 unrelated
-// addresses in every memory instruction of the symbol loop and a round trip to memory for every near match.  Per wavefront:
-// 22,784 B of Huffman tables + (IN_DW + OUT_DW) x 256 B of rings.
-template <class Cfg> struct LdsIo {
-	uint32_t *in_ring, *out_ring; // LDS, dword i of lane l at [i * 64 + l]
-	int lane;
-	const uint8_t *in_org;        // dword-aligned address at or below the stream's first byte
-	uint8_t *out_org;             // dword-aligned address at or below the block's first output byte
-	__device__ __forceinline__ uint32_t in_get(int slot) const { return in_ring[slot * 64 + lane]; }
-	__device__ __forceinline__ uint32_t in_stream32(uint32_t off) const { uint32_t v; memcpy(&v, in_org + off, 4); return v; } // below in_lim: inside the padded chunk buffer
-	__device__ __forceinline__ void out_set8(uint32_t idx, uint8_t v) { reinterpret_cast<uint8_t *>(out_ring + (idx >> 2) * 64 + lane)[idx & 3u] = v; }
-	__device__ __forceinline__ uint8_t out_get8(uint32_t idx) const { return reinterpret_cast<const uint8_t *>(out_ring + (idx >> 2) * 64 + lane)[idx & 3u]; }
-	__device__ __forceinline__ uint32_t out_get32(int slot) const { return out_ring[slot * 64 + lane]; }
-	__device__ __forceinline__ void out_set32(int slot, uint32_t v) { out_ring[slot * 64 + lane] = v; }
-	__device__ __forceinline__ uint32_t out_stream32(uint32_t pos) const { uint32_t v; memcpy(&v, out_org + pos, 4); return v; }
-};
-
-template <class Cfg> constexpr int inflate_rings_lds_bytes() { return INFLATE_LDS_BYTES + (Cfg::IN_DW + Cfg::OUT_DW) * 64 * 4; }
-
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
-{
-	return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
-}
-
-template <class Cfg>
-__global__ __launch_bounds__(WAVE) void k_bgzf_inflate_rings(const uint8_t *__restrict__ comp, uint64_t comp_bytes, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
-                                                             uint8_t *__restrict__ out, int *__restrict__ status, uint8_t *__restrict__ scratch, unsigned long long *__restrict__ dbg)
-{
-	extern __shared__ uint8_t lds_raw[];
-	LdsTab tab;
-	tab.lit8 = lds_raw;
-	tab.hi = reinterpret_cast<uint32_t *>(lds_raw + 288 * 64);
-	tab.dst8 = lds_raw + 288 * 64 + 9 * 64 * 4;
-	tab.len8 = scratch + (size_t)blockIdx.x * INFLATE_SCRATCH_BYTES;
-	tab.off16 = reinterpret_cast<uint16_t *>(tab.len8 + 320 * 64);
-	tab.lane = lane_id();
-	// dbg (tools/bamdec_bench.py --phases): cycles of this wavefront in its three phases, steps, and how the lanes spent them
-	unsigned long long t_in = 0, t_step = 0, t_out = 0, n_iter = 0, n_hdr = 0, n_sym = 0, n_copy = 0, n_far = 0, n_stall = 0;
-	LdsIo<Cfg> io;
-	io.in_ring = reinterpret_cast<uint32_t *>(lds_raw + INFLATE_LDS_BYTES);
-	io.out_ring = io.in_ring + Cfg::IN_DW * 64;
-	io.lane = lane_id();
-	const int lane = lane_id();
-	const int64_t b = (int64_t)blockIdx.x * WAVE + threadIdx.x;
-	LaneInflate<Cfg> L;
-	uint64_t in_org = 0, out_org = 0;
-	if (b < n_blocks) {
-		const BgzfBlock blk = blocks[b];
-		const uint64_t ia = reinterpret_cast<uint64_t>(comp + blk.c_off), oa = reinterpret_cast<uint64_t>(out + u_off[b]);
-		in_org = ia & ~3ull; out_org = oa & ~3ull;
-		L.start((uint32_t)(ia & 3ull), blk.c_len, (uint32_t)(oa & 3ull), blk.u_len);
-	}
-	io.in_org = reinterpret_cast<const uint8_t *>(in_org);
-	io.out_org = reinterpret_cast<uint8_t *>(out_org);
-	const uint64_t comp_end = reinterpret_cast<uint64_t>(comp) + comp_bytes + 8; // (the chunk buffer keeps spare bytes behind the last stream)
-	// Ring traffic is moved by groups of 16 lanes, up to four lanes' halves per instruction.  The input side runs one step ahead: the
-	// dwords loaded in step k are put into the ring at the start of step k + 1 (a lane asks for input while it still has half a ring).
-	static_assert(Cfg::REFILL_DW <= 16 && Cfg::FLUSH_DW <= 16, "a group of 16 lanes moves half a ring");
-	const int grp = lane >> 4, gl = lane & 15;
-	uint32_t pf_val = 0; int pf_idx = -1; // this helper lane's pending ring dword
-	bool rf_inflight = false;             // this lane's ring is being refilled
-	auto pick4 = [&](uint64_t m, int &T, bool &valid) { // the grp-th lowest lane of m
-		int t0 = __ffsll((unsigned long long)m) - 1; uint64_t m1 = m & (m - 1);
-		int t1 = __ffsll((unsigned long long)m1) - 1; uint64_t m2 = m1 & (m1 - 1);
-		int t2 = __ffsll((unsigned long long)m2) - 1; uint64_t m3 = m2 & (m2 - 1);
-		int t3 = __ffsll((unsigned long long)m3) - 1;
-		T = grp == 0 ? t0 : grp == 1 ? t1 : grp == 2 ? t2 : t3;
-		valid = T >= 0;
-		if (!valid) T = 0;
-	};
-	while (__any(L.state != ST_DONE)) {
-		unsigned long long t0 = dbg ? clock64() : 0;
-		// ---- input: what was loaded a step ago goes into the rings; then half a ring is requested for up to four lanes that have used up theirs ----
-		if (pf_idx >= 0) { io.in_ring[pf_idx] = pf_val; pf_idx = -1; }
-		if (rf_inflight) { L.rfill += Cfg::REFILL_DW; rf_inflight = false; }
-		{
-			const uint64_t m = __ballot(L.wants_refill());
-			if (m) {
-				int T; bool valid;
-				pick4(m, T, valid);
-				const uint32_t rf = (uint32_t)__shfl((int)L.rfill, T);
-				const uint64_t org = (uint64_t)(uint32_t)__shfl((int)(uint32_t)in_org, T) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(in_org >> 32), T) << 32);
-				if (valid && gl < Cfg::REFILL_DW) {
-					const uint32_t D = rf + (uint32_t)gl;
-					const uint64_t a = org + 4ull * D;
-					pf_val = a + 4 <= comp_end ? *reinterpret_cast<const uint32_t *>(a) : 0u;
-					pf_idx = (int)((D % Cfg::IN_DW) * 64) + T;
-				}
-				// the (up to four) chosen lanes
-				const uint64_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1), m4 = m3 & (m3 - 1);
-				rf_inflight = ((m & ~m4) >> lane) & 1ull;
-			}
-		}
-		// ---- one step of every stream ----
-		if (dbg) {
-			const unsigned long long t1 = clock64(); t_in += t1 - t0; t0 = t1; ++n_iter;
-			n_hdr += __popcll(__ballot(L.state == ST_HEADER)); n_sym += __popcll(__ballot(L.state == ST_SYMBOL && !L.wants_flush()));
-			n_copy += __popcll(__ballot(L.state == ST_COPY)); n_far += __popcll(__ballot(L.state == ST_FAR));
-			n_stall += __popcll(__ballot(L.state < ST_FINISH && L.wants_flush()));
-		}
-		if (L.state < ST_FINISH && !L.wants_flush()) L.step(io, tab);
-		if (dbg) { const unsigned long long t1 = clock64(); t_step += t1 - t0; t0 = t1; } // (a lane whose full half was not among the four written out last time waits: the ring's slack is one step's worth)
-		// ---- output: half a ring of up to four lanes that have filled one ----
-		{
-			const uint64_t m = __ballot(L.state < ST_FINISH && L.wants_flush());
-			if (m) {
-				int T; bool valid;
-				pick4(m, T, valid);
-				const uint32_t fT = (uint32_t)__shfl((int)L.f, T), ob = (uint32_t)__shfl((int)L.o_begin, T);
-				const uint64_t org = (uint64_t)(uint32_t)__shfl((int)(uint32_t)out_org, T) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(out_org >> 32), T) << 32);
-				if (valid && gl < Cfg::FLUSH_DW) {
-					const uint32_t q = fT + 4u * (uint32_t)gl; // (a half that is written out lies below o <= o_end)
-					const uint32_t v = io.out_ring[((q >> 2) % Cfg::OUT_DW) * 64 + T];
-					uint8_t *g = reinterpret_cast<uint8_t *>(org + q);
-					if (q >= ob) *reinterpret_cast<uint32_t *>(g) = v; // (the block's first dword may be shared with the block before)
-					else for (uint32_t k = 0; k < 4; ++k) if (q + k >= ob) g[k] = (uint8_t)(v >> (8 * k));
-				}
-				const uint64_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1), m4 = m3 & (m3 - 1);
-				if (((m & ~m4) >> lane) & 1ull) L.f += 4u * Cfg::FLUSH_DW;
-			}
-		}
-		// ---- far matches: the wavefront moves them, stream -> stream, a lane's match (and its unwritten ring bytes) in one coalesced load
-		//      and store of up to 64 dwords; up to four lanes per step, all loads before the first store ----
-		{
-			uint64_t m = __ballot(L.state == ST_FAR);
-			if (m) {
-				constexpr int K = 4;
-				FarMove<Cfg> fm[K]; int Tk[K]; uint64_t orgk[K]; uint32_t ringv[K], srcv[K]; bool act[K];
-#pragma unroll
-				for (int k = 0; k < K; ++k) {
-					Tk[k] = __ffsll((unsigned long long)m) - 1; m &= m - 1;
-					act[k] = false; ringv[k] = srcv[k] = 0; orgk[k] = 0;
-					if (Tk[k] < 0) continue;
-					const int T = Tk[k];
-					fm[k].f = (uint32_t)__builtin_amdgcn_readlane((int)L.f, T); fm[k].o = (uint32_t)__builtin_amdgcn_readlane((int)L.o, T);
-					fm[k].rem = (uint32_t)__builtin_amdgcn_readlane((int)L.rem, T); fm[k].dist = (uint32_t)__builtin_amdgcn_readlane((int)L.dist, T);
-					fm[k].o_begin = (uint32_t)__builtin_amdgcn_readlane((int)L.o_begin, T);
-					orgk[k] = readlane64(out_org, T);
-					act[k] = (uint32_t)lane < fm[k].dwords();
-					if (act[k]) {
-						const uint32_t q0 = fm[k].pos((uint32_t)lane);
-						ringv[k] = io.out_ring[((q0 >> 2) % Cfg::OUT_DW) * 64 + T];
-						if (fm[k].needs_src((uint32_t)lane)) {
-							const uint64_t a = orgk[k] + q0 - fm[k].dist;
-							if (a >= reinterpret_cast<uint64_t>(out)) memcpy(&srcv[k], reinterpret_cast<const uint8_t *>(a), 4);
-							else for (uint32_t bb2 = 0; bb2 < 4; ++bb2) if (a + bb2 >= reinterpret_cast<uint64_t>(out)) srcv[k] |= (uint32_t)*reinterpret_cast<const uint8_t *>(a + bb2) << (8 * bb2); // (the stream's very first bytes)
-						}
-					}
-				}
-#pragma unroll
-				for (int k = 0; k < K; ++k) {
-					if (Tk[k] < 0) continue;
-					if (act[k]) {
-						const uint32_t q0 = fm[k].pos((uint32_t)lane);
-						uint32_t val;
-						const uint32_t mask = fm[k].merge((uint32_t)lane, ringv[k], srcv[k], val);
-						uint8_t *g = reinterpret_cast<uint8_t *>(orgk[k] + q0);
-						if (mask == 15u) *reinterpret_cast<uint32_t *>(g) = val;
-						else for (uint32_t bb2 = 0; bb2 < 4; ++bb2) if ((mask >> bb2) & 1u) g[bb2] = (uint8_t)(val >> (8 * bb2));
-						if (fm[k].to_ring((uint32_t)lane)) io.out_ring[((q0 >> 2) % Cfg::OUT_DW) * 64 + Tk[k]] = val;
-					}
-					if (lane == Tk[k]) L.far_done();
-				}
-			}
-		}
-		// ---- finished streams: everything that is left, one lane at a time ----
-		for (uint64_t m = __ballot(L.state == ST_FINISH); m; m &= m - 1) {
-			const int T = __ffsll((unsigned long long)m) - 1;
-			const uint32_t fT = (uint32_t)__builtin_amdgcn_readlane((int)L.f, T), oT = (uint32_t)__builtin_amdgcn_readlane((int)L.o, T);
-			const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int)L.o_begin, T);
-			const uint64_t org = readlane64(out_org, T);
-			const uint32_t q = fT + 4u * (uint32_t)lane;
-			if (q < oT) {
-				const uint32_t v = io.out_ring[((q >> 2) % Cfg::OUT_DW) * 64 + T];
-				uint8_t *g = reinterpret_cast<uint8_t *>(org + q);
-				if (q >= ob && q + 4 <= oT) *reinterpret_cast<uint32_t *>(g) = v;
-				else for (uint32_t k = 0; k < 4; ++k) if (q + k >= ob && q + k < oT) g[k] = (uint8_t)(v >> (8 * k));
-			}
-			if (lane == T) L.state = ST_DONE;
-		}
-		if (dbg) t_out += clock64() - t0;
-	}
-	if (dbg && lane == 0) {
-		unsigned long long *o9 = dbg + (size_t)blockIdx.x * 9;
-		o9[0] = t_in; o9[1] = t_step; o9[2] = t_out; o9[3] = n_iter; o9[4] = n_hdr; o9[5] = n_sym; o9[6] = n_copy; o9[7] = n_far; o9[8] = n_stall;
-	}
-	if (b < n_blocks) status[b] = L.verdict();
 }
 
 // ---- record boundaries ----------------------------------------------------------------------------------------------------------

@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_pack_ascii(PackArgs p, uint8_
 	}
 }
 
-// ---- packed table (ssv_clip_table_format 1 / 2): sequences as 4-bit codes, qualities W bits each ----
+// ---- the LDS-staged composition of a packed block (round 1-2: table formats 1 / 2, removed in round 5; what k_pack3_stream, table3_kernels.h, still builds on) ----
 //
 // A cluster's block is four pieces [seq_left | qual_left | seq_right | qual_right] at byte offsets that are not dword aligned, cut
 // out of a read at arbitrary nibble / byte offsets.  Composing the block byte by byte costs ~100 instructions per byte; here every
@@ -1546,241 +1546,6 @@ __device__ __forceinline__ void pack_entry_load(const PackDescR &d, int gl, uint
 	const int nraw = pack_desc_fast(d) ? (mis + (d.lq + 1) / 2 + d.lq + 3) / 4 + 1 : 0; // + one dword of read-ahead for the unaligned windows (8 bytes of slack behind seqqual, seeksv_hip.h)
 #pragma unroll
 	for (int u = 0; u < PACK_RAW_PER_LANE; ++u) { const int i = gl + GROUP * u; r[u] = i < nraw && i < PACK_RAW_DWORDS ? g4[i] : 0u; }
-}
-
-// TRACK: also note every phred value met in p.qual_seen (the rare second launch after a quality outside the guessed alphabet turned up).
-// PIPE: the persistent, software-pipelined form (88 registers: five wavefronts per SIMD); without it one cluster per group of lanes and the
-// grid covers all clusters (58 registers: eight wavefronts per SIMD).
-template <int W, bool TRACK, bool PIPE>
-__global__ __launch_bounds__(BLOCK) void k_cluster_pack_stream(PackArgs p, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str)
-{
-	__shared__ uint32_t s_piece[GROUPS_PER_BLOCK][PACK_LDS_DWORDS];
-	__shared__ uint32_t s_raw[GROUPS_PER_BLOCK][PACK_RAW_DWORDS]; // the read's entry (packed bases, qualities) as it lies in memory, from the aligned address below it
-	__shared__ uint8_t s_lut[256]; // phred -> alphabet index
-	__shared__ uint32_t s_seen[8];  // phred values met (bit set)
-	if (W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256
-	if (threadIdx.x < 8) s_seen[threadIdx.x] = 0;
-	const int grp = (int)(threadIdx.x / GROUP);
-	const int gl = (int)(threadIdx.x % GROUP);
-	const int64_t nc = (int64_t)*n_clusters_dev;
-	const int64_t step = (int64_t)gridDim.x * GROUPS_PER_BLOCK;
-	int64_t c = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
-	uint32_t *L = s_piece[grp];
-	const uint32_t *s4 = s_raw[grp];
-	// pipeline prologue
-	PackDescR d0 = pack_desc_load(desc, c, nc), d1 = d0, d2 = d0;
-	if (PIPE) d1 = pack_desc_load(desc, c + step, nc);
-	uint32_t r[PACK_RAW_PER_LANE], rn[PACK_RAW_PER_LANE];
-	pack_entry_load(d0, gl, r);
-	for (int64_t cb = (int64_t)blockIdx.x * GROUPS_PER_BLOCK; cb < nc; cb += step) { // the workgroup's trip count is uniform: barriers inside
-		if (PIPE) {
-			d2 = pack_desc_load(desc, c + 2 * step, nc); // cluster t + 2: its descriptor
-			pack_entry_load(d1, gl, rn);                  // cluster t + 1: its bytes
-		}
-		const bool fast = pack_desc_fast(d0);
-		const int ll = d0.ll, lr = d0.lr, lq = d0.lq, begin = d0.begin;
-		const int mis = (int)(d0.src & 3ull);     // the entry starts mis bytes into s_raw
-		const int qb = mis + (lq + 1) / 2;        // first quality byte of the entry inside s_raw
-		// piece k: 0 seq_left, 1 qual_left, 2 seq_right, 3 qual_right; nB bytes, nD dwords, at block byte oP, at LDS dword st
-		int nB[4], nD[4], oP[4], st[4];
-		nB[0] = (ll + 1) / 2; nB[1] = (ll * W + 7) / 8; nB[2] = (lr + 1) / 2; nB[3] = (lr * W + 7) / 8;
-		{
-			int o = 0, s_ = 1;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { nD[k] = (nB[k] + 3) / 4; oP[k] = o; st[k] = s_; o += nB[k]; s_ += nD[k] + 1; }
-		}
-		const int total = oP[3] + nB[3];
-		if (fast) {
-			// 0. the whole entry into LDS (its loads were issued one cluster ago)
-			const int nraw = (qb + lq + 3) / 4 + 1;
-#pragma unroll
-			for (int u = 0; u < PACK_RAW_PER_LANE; ++u) { const int i = gl + GROUP * u; if (i < nraw && i < PACK_RAW_DWORDS) s_raw[grp][i] = r[u]; }
-		}
-		__syncthreads(); // s_raw (and s_lut the first time)
-		bool qmiss = false;
-		if (fast) {
-			qmiss = lq > 0 && ((s4[qb >> 2] >> (8 * (qb & 3))) & 0xffu) == 0xffu;
-			if (gl == 0) { L[0] = 0u; p.qmiss[c] = qmiss ? 1 : 0; } // guards: before the first piece and after each piece
-#pragma unroll
-			for (int k = 0; k < 4; ++k) if (gl == k + 1) L[st[k] + nD[k]] = 0u;
-			// sequence pieces (the dwords of both pieces share one index space: with 16 lanes and ~10 dwords per piece, a loop per piece
-			// would leave half the lanes idle in each)
-			for (int tt = gl; tt < nD[0] + nD[2]; tt += GROUP) {
-				const bool h = tt >= nD[0];
-				const int t = h ? tt - nD[0] : tt;
-				const int nib0 = begin + (h ? ll : 0), len = h ? lr : ll;
-				{
-					const int B = mis + (nib0 >> 1) + 4 * t;
-					const uint32_t w0 = s4[B >> 2], w1 = s4[(B >> 2) + 1];
-					const uint64_t X = (((uint64_t)w1 << 32) | w0) >> (8 * (B & 3));
-					const uint32_t lo = (uint32_t)X, nx = (uint32_t)(X >> 8);
-					uint32_t v = (nib0 & 1) ? (((lo & 0x0f0f0f0fu) << 4) | ((nx >> 4) & 0x0f0f0f0fu)) : lo;
-					const int rem = len - 8 * t; // nibbles of the piece in this dword
-					if (rem < 8) v &= ((1u << (8 * (rem >> 1))) - 1u) | ((rem & 1) ? 0xf0u << (8 * (rem >> 1)) : 0u);
-					L[(h ? st[2] : st[0]) + t] = v;
-				}
-			}
-			// quality pieces: a piece is the bit stream of its W-bit indices, quality i at stream bit i * W (for W = 3 an index can straddle
-			// a byte or a dword); dword t of the piece = stream bits [32 t, 32 t + 32) = the CNT qualities from i0 = 32 t / W on, shifted
-			uint32_t seen_lo = 0, seen_hi = 0; // TRACK: phred 0..63 as a bit set in registers (anything higher goes straight to LDS)
-			uint32_t miss = 0;                 // OR of the table look-ups: 0xff marks a value outside the alphabet
-			for (int tt = gl; tt < nD[1] + nD[3]; tt += GROUP) {
-				const bool h = tt >= nD[1];
-				const int t = h ? tt - nD[1] : tt;
-				const int q0 = begin + (h ? ll : 0), len = h ? lr : ll;
-				{
-					constexpr int CNT = W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
-					const int i0 = (32 * t) / W, off = 32 * t - W * i0;   // off != 0 only for W = 3
-					const int a = qb + q0 + i0;                            // first source byte
-					const uint32_t *q4 = s4 + (a >> 2);
-					const int sh = a & 3;
-					const int rem = len - i0;                              // qualities of the piece from i0 on
-					uint64_t acc = 0;
-					uint32_t prev = q4[0];
-#pragma unroll
-					for (int g = 0; g < (CNT + 3) / 4; ++g) {
-						if (4 * g >= rem) break; // nothing of the piece left (also keeps the reads inside the staged entry)
-						const uint32_t next = q4[g + 1];
-						const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
-						prev = next;
-						if (W == 8) acc = qmiss ? 0x2a2a2a2au : four + 0x21212121u; // phred + 33 (no carries: qualities <= 93); '*' when absent
-						else {
-#pragma unroll
-							for (int b = 0; b < 4; ++b) {
-								const int jq = 4 * g + b;
-								const uint32_t ph = (four >> (8 * b)) & 0xffu;
-								const uint32_t idx = s_lut[ph];
-								const bool ok = jq < CNT && jq < rem;
-								acc |= ok ? (uint64_t)(idx & ((1u << W) - 1u)) << (jq * W) : 0ull;
-								miss |= ok ? idx : 0u;
-								if (TRACK && ok) { if (ph < 32) seen_lo |= 1u << ph; else if (ph < 64) seen_hi |= 1u << (ph - 32); else atomicOr(&s_seen[ph >> 5], 1u << (ph & 31)); }
-							}
-						}
-					}
-					uint32_t v = qmiss && W < 8 ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
-					if (W == 8 && rem < 4) v &= (1u << (8 * rem)) - 1u;
-					L[(h ? st[3] : st[1]) + t] = v;
-				}
-			}
-			if (W < 8 && !qmiss) {
-				if (miss & 0x80u) *p.lut_miss = 1;
-				if (TRACK) {
-					if (seen_lo) atomicOr(&s_seen[0], seen_lo);
-					if (seen_hi) atomicOr(&s_seen[1], seen_hi);
-				}
-			}
-		}
-		__syncthreads();
-		if (fast) {
-			uint32_t *d = reinterpret_cast<uint32_t *>(out_str + d0.str_off);
-			for (int w = gl; 4 * w < total; w += GROUP) {
-				const int o = 4 * w;
-				uint32_t word = 0;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					if (o + 4 > oP[k] && o < oP[k] + nB[k]) {
-						const int r0 = o - oP[k];     // -3 .. nB - 1
-						const int i = st[k] + (r0 >> 2); // floor: -1 reads the guard in front of the piece
-						word |= __builtin_amdgcn_alignbyte(L[i + 1], L[i], (uint32_t)(r0 & 3));
-					}
-				}
-				d[w] = word;
-			}
-		}
-		if (!PIPE) break;
-		// next cluster of this group
-		d0 = d1; d1 = d2;
-#pragma unroll
-		for (int u = 0; u < PACK_RAW_PER_LANE; ++u) r[u] = rn[u];
-		c += step;
-	}
-	__syncthreads();
-	if (TRACK && W < 8 && threadIdx.x < 8 && s_seen[threadIdx.x]) { // one look per workgroup; an atomic only while the set still grows
-		const uint32_t have = __atomic_load_n(&p.qual_seen[threadIdx.x], __ATOMIC_RELAXED);
-		if (s_seen[threadIdx.x] & ~have) atomicOr(&p.qual_seen[threadIdx.x], s_seen[threadIdx.x]);
-	}
-}
-
-// The bytewise path: the slots of multi-event bins (mlist; those without a cluster leave at once: consensus storage, left part kept
-// reversed), then the listed single-event clusters of reads longer than PACK_MAX_LQ (the grid is an upper bound of that list's length).
-template <int W, bool TRACK>
-__global__ __launch_bounds__(BLOCK) void k_cluster_pack_slow(PackArgs p, uint8_t *__restrict__ out_str)
-{
-	__shared__ uint8_t s_lut[256];  // phred -> alphabet index
-	__shared__ uint8_t s_code[256]; // character -> 4-bit code
-	__shared__ uint32_t s_seen[8];  // phred values met (bit set)
-	if (W < 8) s_lut[threadIdx.x] = p.qlut[threadIdx.x]; // BLOCK == 256
-	s_code[threadIdx.x] = NT16_CODE_OF[threadIdx.x];
-	if (threadIdx.x < 8) s_seen[threadIdx.x] = 0;
-	__syncthreads();
-	const int grp = (int)(threadIdx.x / GROUP);
-	const int gl = (int)(threadIdx.x % GROUP);
-	const int64_t k_ = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + grp;
-	const int64_t n_items = p.c.M + (int64_t)*p.slow_count;
-	if (k_ >= n_items) return;
-	const int64_t j = k_ < p.c.M ? (int64_t)p.c.mlist[k_] : (int64_t)p.slow_list[k_ - p.c.M];
-	if (p.c.support[j] <= 0) return; // five of six slots of multi-event bins hold no cluster
-	const SlotCluster sc = slot_cluster_load(p, j);
-	if (k_ < p.c.M && sc.single) return; // (a lone cluster of a multi-event bin is a single: the stream kernel's, or - a long read - listed in slow_list)
-	const int ll = sc.ll, lr = sc.lr, lq = sc.lq, begin = sc.begin;
-	const bool single = lq >= 0;
-	const int nB0 = (ll + 1) / 2, nB1 = (ll * W + 7) / 8, nB2 = (lr + 1) / 2, nB3 = (lr * W + 7) / 8;
-	const int total = nB0 + nB1 + nB2 + nB3;
-	uint32_t *d = reinterpret_cast<uint32_t *>(out_str + sc.str_off);
-	EventView v;
-	const uint8_t *cs = nullptr, *cq = nullptr, *rs = nullptr, *rq = nullptr;
-	bool qm;
-	if (single) {
-		v.sp = reinterpret_cast<const uint8_t *>((uintptr_t)sc.src); v.qp = v.sp + (lq + 1) / 2; v.begin = begin; v.ll = ll; v.lr = lr; v.qmiss = lq > 0 && v.qp[0] == 0xff;
-		qm = v.qmiss;
-		if (gl == 0) p.qmiss[sc.c] = qm ? 1 : 0;
-	} else {
-		const int64_t stride = 2ll * (p.c.SL + p.c.SR);
-		cs = p.c.strings + (int64_t)p.c.mslot[j] * stride;
-		cq = cs + p.c.SL; rs = cs + 2 * p.c.SL; rq = rs + p.c.SR;
-		qm = sc.qmiss_multi != 0;
-	}
-	auto seq_at = [&](bool right, int i) -> uint32_t {
-		return s_code[single ? (uint32_t)(uint8_t)v.base(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rs[i] : cs[ll - 1 - i])];
-	};
-	auto qual_at = [&](bool right, int i) -> uint32_t { // character
-		return single ? (uint32_t)(uint8_t)v.qual(v.begin + (right ? ll : 0) + i) : (uint32_t)(right ? rq[i] : cq[ll - 1 - i]);
-	};
-	auto qual_index = [&](bool right, int i) -> uint32_t { // W < 8: alphabet index of quality i (0 when the cluster has no qualities)
-		if (qm) return 0u;
-		const uint32_t ph = (qual_at(right, i) - 33u) & 255u;
-		if (TRACK) {
-			const uint32_t bit = 1u << (ph & 31);
-			if (!(atomicOr(&s_seen[ph >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph >> 5], bit); // the first time this workgroup meets the value (millions of atomics on two words would take ~10 ns each)
-		}
-		const uint32_t idx = s_lut[ph];
-		if (idx & 0x80u) *p.lut_miss = 1;
-		return idx & ((1u << W) - 1u);
-	};
-	const int A = nB0, QA = nB1, C = nB2;
-	for (int w = gl; w * 4 < total; w += GROUP) {
-		uint32_t word = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int q = w * 4 + k;
-			uint32_t ch = 0;
-			if (q < total) {
-				const bool right = q >= A + QA;
-				const int r = right ? q - A - QA : q, S = right ? C : A, n = right ? lr : ll;
-				if (r >= S) {
-					if (W == 8) ch = qual_at(right, r - S);
-					else { // stream bits [8 r', 8 r' + 8) of the quality piece
-						const int bit0 = 8 * (r - S), i0 = bit0 / W, off = bit0 - W * i0;
-						uint32_t acc = 0;
-						for (int jq = 0, i = i0; W * jq < off + 8 && i < n; ++jq, ++i) acc |= qual_index(right, i) << (W * jq);
-						ch = (acc >> off) & 0xffu;
-					}
-				} else ch = (seq_at(right, 2 * r) << 4) | (2 * r + 1 < n ? seq_at(right, 2 * r + 1) : 0u);
-			}
-			word |= ch << (8 * k);
-		}
-		d[w] = word;
-	}
 }
 
 } // namespace ssv

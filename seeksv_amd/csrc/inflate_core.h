@@ -181,33 +181,6 @@ SSV_HD void st32u(uint8_t *p, uint32_t v)
 #endif
 }
 
-// LZ77 copy, second form (SSV_INFLATE=plain2): a match whose source and destination are disjoint is moved in unaligned dwords - all loads of
-// up to 16 bytes, then their stores, the last dword placed so that it ends with the match (it may overlap the one before) - no head, no tail.
-// A typical BAM match (10 bytes from a few hundred back) is three loads and three stores instead of a dozen single bytes.
-SSV_HD void lz_copy2(uint8_t *to, uint32_t dist, uint32_t len)
-{
-	const uint8_t *from = to - dist;
-	if (dist >= len && len >= 4) {
-		uint32_t i = 0;
-		for (; i + 16 <= len; i += 16) {
-			const uint32_t a = ld32(from + i), b = ld32(from + i + 4), c = ld32(from + i + 8), d = ld32(from + i + 12);
-			st32u(to + i, a); st32u(to + i + 4, b); st32u(to + i + 8, c); st32u(to + i + 12, d);
-		}
-		const uint32_t r = len - i; // 0..15 bytes left
-		if (r) {
-			// dwords at i, i + 4, i + 8 as far as they fit, and one that ends at len (when r is not a multiple of 4)
-			const uint32_t last = len - 4;
-			const uint32_t a = r >= 4 ? ld32(from + i) : 0u, b = r >= 8 ? ld32(from + i + 4) : 0u, c = r >= 12 ? ld32(from + i + 8) : 0u, e = (r & 3u) ? ld32(from + last) : 0u;
-			if (r >= 4) st32u(to + i, a);
-			if (r >= 8) st32u(to + i + 4, b);
-			if (r >= 12) st32u(to + i + 8, c);
-			if (r & 3u) st32u(to + last, e);
-		}
-		return;
-	}
-	lz_copy(to, dist, len);
-}
-
 SSV_HD void lz_copy(uint8_t *to_, uint32_t dist, uint32_t len)
 {
 	uint32_t head = (uint32_t)(0u - (uint32_t)(uintptr_t)to_) & 3u;
@@ -238,70 +211,14 @@ SSV_HD void lz_copy(uint8_t *to_, uint32_t dist, uint32_t len)
 
 // ---- where the decoded bytes go ----
 // DirectOut: straight into the inflated stream (a byte store per literal, lz_copy per match).
-template <bool COPY2> struct DirectOut {
+struct DirectOut {
 	uint8_t *out;
 	SSV_HD void put(uint32_t &o, uint8_t v) { out[o++] = v; }
-	SSV_HD void copy(uint32_t &o, uint32_t dist, uint32_t len) { if (COPY2) lz_copy2(out + o, dist, len); else lz_copy(out + o, dist, len); o += len; }
+	SSV_HD void copy(uint32_t &o, uint32_t dist, uint32_t len) { lz_copy(out + o, dist, len); o += len; }
 	SSV_HD void finish(uint32_t) {}
 };
 
-// LineOut: through a 64-byte line buffer (SSV_INFLATE=wc).  PMC on the direct form (profiles/r02_inflate_pmc.txt): a 2 GB chunk of real reads
-// costs 1.9 G requests to L2 - 1.2 G of them writes, i.e. one request per 1.6 bytes of output - at the ~22 G requests/s that the chip sustains
-// for such traffic, whatever the kernel's instructions or occupancy.  Here the bytes of a lane collect in its line (`Line`: 64 bytes of LDS on
-// the GPU) and leave as aligned 16-byte stores when the line is full: four requests per 64 bytes.  A match reads memory in dwords where its
-// source has been written out, and the line where it has not.
-template <class Line> struct LineOut {
-	uint8_t *out;        // the block's first output byte
-	uint32_t a0 = 0;     // its address modulo 64: position q sits at line index (a0 + q) % 64
-	uint32_t flushed = 0; // positions below have been stored
-	Line line;
-	SSV_HD uint32_t idx(uint32_t q) const { return (a0 + q) & 63u; }
-	SSV_HD void flush_upto(uint32_t o) // positions [flushed, o) (within one line): bytes up to a 16-byte boundary of the address, 16-byte groups, bytes
-	{
-		uint32_t q = flushed;
-		for (; q < o && (idx(q) & 15u); ++q) out[q] = line.get8(idx(q));
-		for (; q + 16 <= o; q += 16) line.store16(out + q, idx(q) >> 4);
-		for (; q < o; ++q) out[q] = line.get8(idx(q));
-		flushed = o;
-	}
-	SSV_HD void put(uint32_t &o, uint8_t v)
-	{
-		line.set8(idx(o), v);
-		++o;
-		if (idx(o) == 0) flush_upto(o);
-	}
-	SSV_HD void put32(uint32_t &o, uint32_t v, uint32_t n) // n <= 4 bytes
-	{
-		const uint32_t i = idx(o);
-		if (n == 4 && (i & 3u) == 0) { line.set32(i >> 2, v); o += 4; if (idx(o) == 0) flush_upto(o); }
-		else for (uint32_t b = 0; b < n; ++b) put(o, (uint8_t)(v >> (8 * b)));
-	}
-	SSV_HD uint8_t at(uint32_t q) const { return q < flushed ? out[q] : line.get8(idx(q)); }
-	SSV_HD void copy(uint32_t &o, uint32_t dist, uint32_t len)
-	{
-		// the part of the match whose source lies in what has been stored, away from what this round writes: up to 16 bytes per round, all
-		// loads first (the last dword may reach up to three bytes past what is used: inside the stream buffer, value ignored)
-		for (;;) {
-			const uint32_t s = o - dist;
-			uint32_t n = len < 16u ? len : 16u;
-			if (n > dist) n = dist;
-			if (s >= flushed) break;
-			if (n > flushed - s) n = flushed - s;
-			if (n == 0) break;
-			const uint32_t v0 = ld32(out + s), v1 = n > 4 ? ld32(out + s + 4) : 0u, v2 = n > 8 ? ld32(out + s + 8) : 0u, v3 = n > 12 ? ld32(out + s + 12) : 0u;
-			put32(o, v0, n < 4 ? n : 4u);
-			if (n > 4) put32(o, v1, n < 8 ? n - 4 : 4u);
-			if (n > 8) put32(o, v2, n < 12 ? n - 8 : 4u);
-			if (n > 12) put32(o, v3, n - 12);
-			len -= n;
-			if (!len) return;
-		}
-		for (; len; --len) put(o, at(o - dist)); // the source is (partly) in the line: byte by byte
-	}
-	SSV_HD void finish(uint32_t o) { flush_upto(o); }
-};
-
-// TokenOut: the decode split in two (SSV_INFLATE=two).  What makes a block slow is the chain decode -> copy -> decode: every match reads bytes of the
+// TokenOut: the decode split in two.  What makes a block slow is the chain decode -> copy -> decode: every match reads bytes of the
 // block's own output, a trip to memory that the next symbol has to wait for.  Pass 1 (this sink) only DECODES: literals go to their final place,
 // a match becomes a 32-bit token and leaves a hole; pass 2 (resolve_tokens / k_bgzf_resolve) fills the holes in order, several lanes per block.
 //   token = len - 3 | (dist - 1) << 8 | literals since the previous token << 23     (literals 0..510)
@@ -576,10 +493,10 @@ SSV_HD int inflate_stream_to(const uint8_t *in, uint32_t in_len, Out &out, uint3
 	return inflate_stream_from(br, in, in_len, out, out_len, tab);
 }
 
-template <class Tab, bool COPY2 = false>
+template <class Tab>
 SSV_HD int inflate_stream(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, Tab &tab)
 {
-	DirectOut<COPY2> d{out};
+	DirectOut d{out};
 	return inflate_stream_to(in, in_len, d, out_len, tab);
 }
 

@@ -1,6 +1,5 @@
 // resolve_wave.h - pass 2 of the device inflate by ONE WAVEFRONT per BGZF block: the holes that pass 1 left for the matches are filled from the block's own
-// earlier bytes.  Used two ways: k_bgzf_resolve_wave (bamdec_kernels.h) walks a block's whole token stream; the fused form of pass 1 (inflate_wave.h,
-// SSV_INFLATE_FUSED) calls wave_resolve_tokens for the tokens of every window right after it wrote them.
+// earlier bytes: k_bgzf_resolve_wave (bamdec_kernels.h) walks a block's whole token stream in global memory, k_bgzf_resolve_win inside a window of the block in LDS.
 #pragma once
 
 #include "common.h"

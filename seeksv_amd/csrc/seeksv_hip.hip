@@ -172,7 +172,7 @@ struct ssv_ctx {
 		std::vector<uint8_t> x_side, x_qmiss;
 		std::vector<uint64_t> x_stroff, x_cigoff;
 		bool expanded = false, ordered = false;
-		hipEvent_t copied = nullptr, started = nullptr; // `started` only with SSV_DEBUG_COPY (times the copy on its stream)
+		hipEvent_t copied = nullptr;
 		hipEvent_t packed_ev = nullptr;                 // the set's pack kernels are done (its copy waits for it): one event per set - a copy that is
 		                                                // still queued behind the table before must not see the next pass's record of a shared event
 		bool in_flight = false;
@@ -182,7 +182,7 @@ struct ssv_ctx {
 	} tab[2];
 	HostPool pool;
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
-	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 1 sequences as 4-bit codes, 2 = 1 + qualities as alphabet indices, 3 compact
+	int table_mode = 0;        // ssv_clip_table_format: 0 ASCII, 3 compact
 	DBuf qual_lut, qual_seen, pair_lut; HBuf h_qual_lut, h_pair_lut;
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
@@ -511,8 +511,8 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 	    hipEventCreateWithFlags(&c->ev_st, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ss[0].ready, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->ss[1].ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->tab[0].packed_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->tab[1].packed_ev, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->tab[0].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->tab[1].copied, getenv("SSV_DEBUG_COPY") ? 0 : hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&c->tab[0].copied, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->tab[1].copied, hipEventDisableTiming) != hipSuccess) {
 		g_create_error = "cannot create the copy stream / events"; ssv_ctx_destroy(c); return SSV_E_NODEVICE;
 	}
 	*out = c;
@@ -798,7 +798,7 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 	}
 	ssv_ctx::RetainArena *arena = nullptr;
 	struct Guard { ssv_ctx::RetainArena *&arena; size_t need; ssv_tid_run *&runs; bool keep = false; ~Guard() { if (!keep) { if (arena) { --arena->live; arena->used -= need; arena->slabs.pop_back(); } free(runs); } } } guard{arena, off[7], runs};
-	static const bool timing = getenv("SSV_TIMING_CHUNKS") != nullptr;
+	static const bool timing = [] { const char *e = getenv("SSV_TIMING"); return e ? atoi(e) : 0; }() >= 2; // SSV_TIMING=2: per-chunk detail
 	const auto t0 = std::chrono::steady_clock::now();
 	{ // room in the newest arena, or a new one: 256 MB first, doubling up to SSV_RETAIN_ARENA_MB (4 GB), never smaller than the batch
 		if (!c->arenas.empty() && c->arenas.back().cap - c->arenas.back().used >= off[7]) arena = &c->arenas.back();
@@ -894,7 +894,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	T.packed = c->table_mode ? 1 : 0; T.qual_bits = 8; T.qual_group = 1; T.qual_radix = 0; memset(T.qual_alphabet, 0, sizeof(T.qual_alphabet));
 	const bool fmt3 = c->table_mode == 3;
 	T.format = c->table_mode; T.base_bits = fmt3 ? 2 : 4; T.n_runs = 0; T.n_exc = 0; T.expanded = false; T.ordered = false;
-	T.cig_bytes = fmt3 && !(getenv("SSV_CIGAR_BYTES") && atoi(getenv("SSV_CIGAR_BYTES")) == 4) ? 2 : 4; T.len_bytes = fmt3 && c->max_lq < 65536 ? 2 : 4; T.support_bytes = fmt3 ? 2 : 4; T.ncig_bytes = fmt3 ? (c->max_ncig < 256 ? 1 : 2) : 4;
+	T.cig_bytes = fmt3 ? 2 : 4; T.len_bytes = fmt3 && c->max_lq < 65536 ? 2 : 4; T.support_bytes = fmt3 ? 2 : 4; T.ncig_bytes = fmt3 ? (c->max_ncig < 256 ? 1 : 2) : 4;
 	if (fmt3 && getenv("SSV_TABLE_WIDE_COLUMNS")) { T.len_bytes = 4; T.support_bytes = 4; T.ncig_bytes = 2; } // (tests: the widths that only reads > 64 kb, > 65535-read clusters, > 255-operation CIGARs ask for)
 	if (n_events) *n_events = E;
 	if (n_clusters) *n_clusters = 0;
@@ -916,11 +916,10 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		if (EL > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(EL, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_l), EL, &dc->max_key);
 		if (ER > 0) k_key_max<<<(unsigned)std::min<int64_t>(512, grid_for(ER, BLOCK)), BLOCK, 0, c->st>>>(P<uint64_t>(c->key_r[0]), ER, &dc->max_key);
 		// the '3' list is sorted up to small displacements: one windowed rank pass, checked (tile_sort.h); SSV_RADIX_ONLY=1 skips the attempt
-		static const bool radix_only = getenv("SSV_RADIX_ONLY") != nullptr;
 		if (ER > 0) { CHECK(ensure(c, c->key_r[1], ER * 8)); CHECK(ensure(c, c->val_r[1], ER * 4)); }
-		if (ER > 0 && !radix_only) HIPCHECK(c, sort_nearly_sorted(c->st, P<uint64_t>(c->key_r[0]), P<uint32_t>(c->val_r[0]), P<uint64_t>(c->key_r[1]), P<uint32_t>(c->val_r[1]), ER, &dc->r_unsorted));
+		if (ER > 0) HIPCHECK(c, sort_nearly_sorted(c->st, P<uint64_t>(c->key_r[0]), P<uint32_t>(c->val_r[0]), P<uint64_t>(c->key_r[1]), P<uint32_t>(c->val_r[1]), ER, &dc->r_unsorted));
 		uint32_t *h_seen = reinterpret_cast<uint32_t *>(P<uint8_t>(c->h_totals) + 64);
-		if (c->table_mode >= 2) {
+		if (fmt3) {
 			// first guess of the table's quality alphabet: the qualities of the first events
 			HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
 			const int64_t ns = std::min<int64_t>(E, 4096); // (a value missed here is caught while packing, at the price of packing twice)
@@ -934,7 +933,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		while (key_bits < 64 && (max_key >> key_bits)) ++key_bits;
 		CHECK(ensure(c, c->keys2[0], E * 8)); CHECK(ensure(c, c->evs, (size_t)E * sizeof(ClipEvent)));
 		if (!hc->l_unsorted) {
-			int rcur = ER > 0 && !radix_only && !hc->r_unsorted ? 1 : 0;
+			int rcur = ER > 0 && !hc->r_unsorted ? 1 : 0;
 			if (ER > 0 && rcur == 0) {
 				const int64_t nt = rs_tiles(ER);
 				CHECK(ensure(c, c->ghist, 256 * nt * 4));
@@ -1000,7 +999,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			k_bin_start_list<<<grid_for(M, BLOCK), BLOCK, 0, c->st>>>(ca.mlist, P<uint64_t>(c->c_bflag), P<uint64_t>(c->c_boff), M, P<uint32_t>(c->c_blist), P<uint32_t>(c->c_dlist));
 			ca.blist = P<uint32_t>(c->c_blist); ca.dlist = P<uint32_t>(c->c_dlist); ca.n_bins = P<uint32_t>(c->totals) + 2;
 			// reads of up to 256 bases: four positions per lane, a wavefront = a workgroup, deep bins first; longer ones: a base per lane
-			if (c->max_lq <= B4_CAP && !getenv("SSV_BINS_BYTEWISE")) {
+			if (c->max_lq <= B4_CAP) {
 				CHECK(ensure(c, c->bins4_tab, B4_TAB * 2));
 				ca.tab4 = P<uint16_t>(c->bins4_tab);
 				k_bins4_tables<<<1, BLOCK, 0, c->st>>>(ca.match_rate, P<uint16_t>(c->bins4_tab));
@@ -1035,7 +1034,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) { T.qual_alphabet[k] = (uint8_t)(v + 33); lut[v] = (uint8_t)k; ++k; } // increasing order; the table shows characters (phred + 33)
 		};
 		uint32_t guess[8] = {0};
-		if (c->table_mode >= 2) { memcpy(guess, h_seen, 32); set_alphabet(guess); }
+		if (fmt3) { memcpy(guess, h_seen, 32); set_alphabet(guess); }
 		CHECK(ensure(c, c->slot_cnt, E * 8)); CHECK(ensure(c, c->slot_bytes, E * 8));
 		CHECK(ensure(c, c->scan_scratch64, scan_scratch_elems(E) * 8));
 		DBuf *d4[] = {&T.o_tid, &T.o_pos, &T.o_support, &T.o_ll, &T.o_lr, &T.o_ncig, &c->o_slowlist};
@@ -1080,7 +1079,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			if (track) HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
 			if (T.packed && T.qual_bits < 8) HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, c->h_qual_lut.p, 256, hipMemcpyHostToDevice, c->st));
 			// format 3, the kernel without the LDS stage: two qualities per table look-up - for alphabets below phred 64 (every sequencer's)
-			bool direct = fmt3 && !track && !getenv("SSV_PACK3_STAGED");
+			bool direct = fmt3 && !track;
 			if (direct && T.qual_bits < 8) {
 				const uint8_t *lut = P<uint8_t>(c->h_qual_lut);
 				for (int v = 64; v < 256; ++v) if (lut[v] != 0xff) direct = false;
@@ -1103,12 +1102,11 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			if (fmt3) k_cluster_cols3<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, p3, dsc, P<uint32_t>(T.o_cig));
 			else k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, dsc, P<uint32_t>(T.o_cig));
 			const unsigned int *nc_dev = reinterpret_cast<const unsigned int *>(tot);
-			const dim3 gs(grid_for(std::max<int64_t>(M + c->n_long, 1), GROUPS_PER_BLOCK)); // slots of multi-event bins + reads too long for the dword path
 			if (fmt3) {
 				// one group of lanes per cluster (the grid is an upper bound, the kernel reads the cluster count itself), then the base-by-base path
 				const dim3 g(grid_for(E, GROUPS_PER_BLOCK));
 				const dim3 gs3(grid_for(std::max<int64_t>(M + c->n_long, 1), BLOCK)); // k_pack3_slow: an item per lane (a wavefront then works off the ones with a cluster)
-				static const unsigned p3_blocks = []() { const char *e = getenv("SSV_PACK3_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 40u; }(); // persistent (80 registers: six workgroups per CU resident); 2560 / 5120 / 10240 / 20480 workgroups measured in round 4: 1.20 / 1.18 / 1.14 / 1.16 ms for the group
+				const unsigned p3_blocks = 256u * 40u; // persistent (80 registers: six workgroups per CU resident); 2560 / 5120 / 10240 / 20480 workgroups measured in round 4: 1.20 / 1.18 / 1.14 / 1.16 ms for the group
 				const dim3 gd((unsigned)std::max<int64_t>(1, std::min<int64_t>(p3_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)));
 				// lanes per cluster of the direct kernel: as many as the longest read's base / quality stream has dwords, rounded up to the next whole share of a wavefront
 				// (150 bases, grouped qualities: 11 -> 12 lanes, five clusters a wavefront); streams of more than 32 dwords take 16 lanes and several rounds
@@ -1117,7 +1115,6 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 					const int n_fast = std::max(1, std::min(c->max_lq, PACK_MAX_LQ));
 					const int nd = std::max((n_fast * T.base_bits + 31) / 32, (int)((qual_stream_bits((uint64_t)n_fast, (uint64_t)T.qual_bits, (uint64_t)T.qual_group) + 31) / 32));
 					if (nd <= 32) lpc = WAVE / (WAVE / nd);
-					if (const char *e = getenv("SSV_PACK3_LANES")) lpc = std::max(1, std::min(WAVE, atoi(e)));
 				}
 #define SSV_P3D(W_, B_, K_) k_pack3_direct<W_, B_, K_><<<gd, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os, P<uint16_t>(c->pair_lut), lpc)
 #define SSV_P3B(W_, B_, T_) do { if (direct) SSV_P3D(W_, B_, 1); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
@@ -1137,20 +1134,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 #undef SSV_P3D
 #undef SSV_P3G
 #undef SSV_P3GT
-			} else if (!pa.packed) k_cluster_pack_ascii<<<grid_for(E, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, os);
-			else {
-				// the dword path for (nearly) all clusters (one group of lanes per cluster; the grid is an upper bound, the kernel reads the cluster
-				// count itself), then the bytewise path.  SSV_PACK_BLOCKS=n: the persistent, software-pipelined form of the kernel on n workgroups
-				// (measured slower: the kernel is bound by its vector instructions, and the pipeline's registers cost three of eight wavefronts).
-				static const unsigned pack_blocks = []() { const char *e = getenv("SSV_PACK_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
-				const dim3 g(pack_blocks ? (unsigned)std::max<int64_t>(1, std::min<int64_t>(pack_blocks, (E + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)) : grid_for(E, GROUPS_PER_BLOCK));
-#define SSV_PACK2(W_, T_) do { if (pack_blocks) k_cluster_pack_stream<W_, T_, true><<<g, BLOCK, 0, c->st>>>(pa, dsc, nc_dev, os); else k_cluster_pack_stream<W_, T_, false><<<g, BLOCK, 0, c->st>>>(pa, dsc, nc_dev, os); \
-			k_cluster_pack_slow<W_, T_><<<gs, BLOCK, 0, c->st>>>(pa, os); } while (0)
-#define SSV_PACK(W_) do { if (track) SSV_PACK2(W_, true); else SSV_PACK2(W_, false); } while (0)
-				if (pa.qual_bits == 8) SSV_PACK2(8, false); else if (pa.qual_bits == 4) SSV_PACK(4); else if (pa.qual_bits == 3) SSV_PACK(3); else if (pa.qual_bits == 2) SSV_PACK(2); else SSV_PACK(1);
-#undef SSV_PACK
-#undef SSV_PACK2
-			}
+			} else k_cluster_pack_ascii<<<grid_for(E, GROUPS_PER_BLOCK), BLOCK, 0, c->st>>>(pa, os);
 			HIPCHECK(c, hipGetLastError());
 			HIPCHECK(c, hipMemcpyAsync(c->h_totals.p, c->totals.p, 64, hipMemcpyDeviceToHost, c->st));
 			if (track) HIPCHECK(c, hipMemcpyAsync(h_seen, c->qual_seen.p, 32, hipMemcpyDeviceToHost, c->st));
@@ -1169,7 +1153,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				track = false;
 				continue;
 			}
-			if (c->table_mode >= 2 && T.qual_bits < 8 && (int)P<uint64_t>(c->h_totals)[3] != 0) {
+			if (fmt3 && T.qual_bits < 8 && (int)P<uint64_t>(c->h_totals)[3] != 0) {
 				// the table's strings hold a quality value that the first events did not show: find out which values there are
 				if (attempt > 8) { c->err = "quality alphabet did not settle"; return SSV_E_HIP; }
 				track = true;
@@ -1198,7 +1182,6 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	// the table goes to pinned host memory on the copy stream, behind the pack kernels; ssv_clip_table_wait() waits for it
 	HIPCHECK(c, hipEventRecord(T.packed_ev, c->st));
 	HIPCHECK(c, hipStreamWaitEvent(c->st_copy, T.packed_ev, 0));
-	if (getenv("SSV_DEBUG_COPY")) { if (!T.started) HIPCHECK(c, hipEventCreate(&T.started)); HIPCHECK(c, hipEventRecord(T.started, c->st_copy)); }
 	for (auto &x : cp) {
 		CHECK(ensure_host(c, *x.h, x.bytes + 16));
 		if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st_copy));
@@ -1241,7 +1224,7 @@ uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_
 int ssv_clip_table_format(ssv_ctx *c, int packed)
 {
 	if (!c) return SSV_E_ARG;
-	if (packed < 0 || packed > 3) return SSV_E_ARG;
+	if (packed != 0 && packed != 3) { c->err = "ssv_clip_table_format: 0 (ASCII) or 3 (compact); the four-piece packed formats 1 and 2 of ABI versions < 8 are gone"; return SSV_E_ARG; }
 	c->table_mode = packed;
 	return SSV_OK;
 }
@@ -1258,12 +1241,6 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 		ProfScope pd(c, P_TABLE_D2H, T.n_clusters); // what is left of the copy when the caller asks for the table
 		HIPCHECK(c, hipEventSynchronize(T.copied));
 		T.in_flight = false;
-		if (T.started) {
-			float ms = 0, gap = -1;
-			ssv_ctx::TableSet &O = c->tab[which ^ 1];
-			if (O.started && !O.in_flight) (void)hipEventElapsedTime(&gap, O.copied, T.started); // the copy stream's idle time between the table before and this one
-			if (hipEventElapsedTime(&ms, T.started, T.copied) == hipSuccess) fprintf(stderr, "[ssv debug] table copy on its stream: %.2f ms, %.2f ms after the copy before it ended\n", ms, gap);
-		}
 	}
 	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; out->qual_group = T.qual_group; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
 	out->format = T.format; out->base_bits = T.base_bits;
@@ -1649,14 +1626,6 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 		if (!hc->overflow) break;
 		if (attempt > 6) { c->err = "getsv staging overflow"; return SSV_E_HIP; }
 		c->stage_cap *= 4; // a workgroup's private region was too small for the records near its windows
-	}
-	if (getenv("SSV_DEBUG")) {
-		std::vector<uint32_t> tc((size_t)ntiles), to((size_t)ntiles);
-		(void)hipMemcpy(tc.data(), c->tile_cnt.p, ntiles * 4, hipMemcpyDeviceToHost);
-		(void)hipMemcpy(to.data(), c->tile_off.p, ntiles * 4, hipMemcpyDeviceToHost);
-		uint64_t sum = 0; for (uint32_t x : tc) sum += x;
-		fprintf(stderr, "[ssv debug] getsv_scan: n=%lld ntiles=%lld grid=%u block_cap=%lld candidates=%llu first cnt/off=%u/%u span=%d ntargets=%d nwin=%lld njunc=%lld\n", (long long)d.n, (long long)ntiles, grid,
-		        (long long)g.block_cap, (unsigned long long)sum, tc[0], to[0], span, a.n_targets, (long long)a.n_win, (long long)a.n_junc);
 	}
 	{
 		ProfScope ps(c, P_GETSV_CAND, d.n);

@@ -145,8 +145,8 @@ class Context:
         self._check(self._lib.ssv_clip_begin(self._h, C.byref(p)), "ssv_clip_begin")
 
     def clip_table_format(self, packed):
-        """0 / False: ASCII; 1 / True: sequences as 4-bit codes; 2: also qualities as indices into the pass's quality alphabet when it is
-        small (fewer table bytes over PCIe); host.cluster_strings decodes all three"""
+        """0 / False: ASCII; 3: the compact table (2-bit bases, qualities as alphabet indices, contig / side as runs: a third of the bytes over
+        PCIe); host.cluster_strings decodes both"""
         self._check(self._lib.ssv_clip_table_format(self._h, int(packed)), "ssv_clip_table_format")
 
     def clip_scan(self, batch):

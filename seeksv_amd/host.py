@@ -246,7 +246,7 @@ def table_to_dict(t):
                      ("right_len", np.int32), ("qual_missing", np.uint8), ("str_off", np.uint64), ("cigar_off", np.uint64), ("n_cigar", np.int32)):
         d[name] = arr(getattr(t, name), n, dt)
     if n:
-        sb = int(d["str_off"][-1]) + block_bytes(int(d["left_len"][-1]), int(d["right_len"][-1]), packed, qbits)
+        sb = int(d["str_off"][-1]) + block_bytes(int(d["left_len"][-1]), int(d["right_len"][-1]))
         cb = int(d["cigar_off"][-1]) + int(d["n_cigar"][-1])
     else:
         sb = cb = 0
@@ -324,10 +324,9 @@ def _compact_to_dict(t, d):
 NT16 = "=ACMGRSVTWYHKDBN"
 
 
-def block_bytes(ll, lr, packed, qual_bits=8):
-    """ssv_table_block_bytes (include/seeksv_hip.h)"""
-    w = qual_bits if packed else 8
-    return (((ll + 1) // 2 + (ll * w + 7) // 8 + (lr + 1) // 2 + (lr * w + 7) // 8 if packed else 2 * (ll + lr)) + 3) & ~3
+def block_bytes(ll, lr):
+    """ssv_table_block_bytes (include/seeksv_hip.h): a cluster's string block in the ASCII table"""
+    return (2 * (ll + lr) + 3) & ~3
 
 
 def cluster_strings(d, k):
@@ -356,23 +355,6 @@ def cluster_strings(d, k):
         else:
             q = qs[:n].tobytes().decode("latin-1") if w == 8 else "".join(chr(alphabet[field(qs, i, w)]) for i in range(n))
         sl, sr, ql, qr = seq[:ll], seq[ll:], q[:ll], q[ll:]
-    elif d.get("seq_packed"):
-        a, c, w = (ll + 1) // 2, (lr + 1) // 2, int(d.get("qual_bits", 8))
-        qa, qc = (ll * w + 7) // 8, (lr * w + 7) // 8
-        alphabet = d.get("qual_alphabet", b"")
-
-        def unpack(buf, n):
-            return "".join(NT16[(int(buf[i >> 1]) >> (0 if i & 1 else 4)) & 15] for i in range(n))
-
-        def quals(buf, n):
-            if w == 8:
-                return buf[:n].tobytes().decode("latin-1")
-            word = lambda b: int(buf[b]) | ((int(buf[b + 1]) << 8) if b + 1 < len(buf) else 0)  # a 3-bit index can straddle two bytes
-            return "".join(chr(alphabet[(word((i * w) >> 3) >> ((i * w) & 7)) & ((1 << w) - 1)]) for i in range(n))
-        sl = unpack(s[o:o + a], ll)
-        ql = quals(s[o + a:o + a + qa], ll)
-        sr = unpack(s[o + a + qa:o + a + qa + c], lr)
-        qr = quals(s[o + a + qa + c:o + a + qa + c + qc], lr)
     else:
         sl = s[o:o + ll].tobytes().decode("latin-1")
         ql = s[o + ll:o + 2 * ll].tobytes().decode("latin-1")

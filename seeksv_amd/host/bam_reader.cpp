@@ -661,7 +661,7 @@ static int read_blocks_impl(ssvh_bam *b, void *dst, const uint8_t *mapped, size_
 	uint8_t *const dw = static_cast<uint8_t *>(dst);
 	if (ptr) *ptr = d;
 	const size_t PIECE = (size_t)256 << 20, SLICE = (size_t)4 << 20;
-	static const bool timing = getenv("SSV_TIMING_CHUNKS") != nullptr;
+	static const bool timing = [] { const char *e = getenv("SSV_TIMING"); return e ? atoi(e) : 0; }() >= 2; // SSV_TIMING=2: per-chunk detail
 	double t_read = 0, t_walk = 0;
 	auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	struct Report { const bool on; double &r, &w; size_t &bytes; int64_t &nb; ~Report() { if (on) fprintf(stderr, "[timing] (read_blocks: %zu bytes, %lld blocks: pread %.4f s, header walk %.4f s)\n", bytes, (long long)nb, r, w); } };
@@ -703,7 +703,7 @@ static int read_blocks_impl(ssvh_bam *b, void *dst, const uint8_t *mapped, size_
 		// and parses by itself whatever that did not cover
 		std::vector<BgzfAt> pre;
 		size_t pi = 0;
-		static const bool par_walk = !(getenv("SSV_WALK") && !strcmp(getenv("SSV_WALK"), "serial"));
+		static const bool par_walk = !(getenv("SSV_SERIAL") && strstr(getenv("SSV_SERIAL"), "walk")); // SSV_SERIAL=walk (tests): one header after the other
 		if (par_walk) bgzf_blocks_parallel(d, p, have, pre);
 		for (;;) {
 			if (n >= max_blocks) { stop = true; break; }
@@ -810,7 +810,7 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 	g_err.clear();
 	B.unmapped.clear();
 	Bgzf &z = b->z;
-	static const bool timing = getenv("SSV_TIMING_READ") != nullptr;
+	static const bool timing = [] { const char *e = getenv("SSV_TIMING"); return e ? atoi(e) : 0; }() >= 3; // SSV_TIMING=3: per-batch detail of the host reader
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t0 = now();
 	// ---- record boundaries.  Walking the block_size chain is a chain of dependent cache misses, so it is done speculatively per
@@ -853,7 +853,7 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 			break;
 		}
 		const double tg1 = now();
-		if (timing && getenv("SSV_TIMING_GROW")) fprintf(stderr, "  grow %.4f s nseg %d ulen %zu cap %zu found %zu\n", tg1 - tg0, nseg, z.ulen, z.ubuf.size(), found.size());
+		if (timing) fprintf(stderr, "  grow %.4f s nseg %d ulen %zu cap %zu found %zu\n", tg1 - tg0, nseg, z.ulen, z.ubuf.size(), found.size());
 		const uint8_t *u = z.ubuf.data();
 		size_t cur = b->chain_cur;
 		bool window_end = false;
@@ -1169,7 +1169,7 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 {
 	FILE *f = fopen(path, append ? "ab" : "wb");
 	if (!f) { g_err = std::string("cannot open ") + path; return -1; }
-	static const bool timing = getenv("SSV_TIMING_WRITE") != nullptr;
+	static const bool timing = [] { const char *e = getenv("SSV_TIMING"); return e ? atoi(e) : 0; }() >= 3; // SSV_TIMING=3: the writer's phases
 	double t_sizes = 0, t_fill = 0, t_comp = 0, t_io = 0;
 	auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double tl = clk();
@@ -1203,9 +1203,9 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 		at[0] = 0;
 		for (int64_t i = 0; i < n; ++i) at[(size_t)i + 1] += at[(size_t)i];
 		lap(t_sizes);
-		// slices of ~128 MB of serialised records (SSV_WRITE_SLICE_MB): serialise, compress, write, next - a multi-GB batch in one piece held twice
+		// slices of ~128 MB of serialised records: serialise, compress, write, next - a multi-GB batch in one piece held twice
 		// its inflated size in memory (the records, the compressed blocks and their copy in `out`)
-		static const uint64_t slice_bytes = [] { const char *e = getenv("SSV_WRITE_SLICE_MB"); const long long mb = e ? atoll(e) : 128; return (uint64_t)(mb < 1 ? 1 : mb) << 20; }();
+		const uint64_t slice_bytes = (uint64_t)128 << 20;
 		for (int64_t i0 = 0; i0 < n;) {
 			int64_t i1 = (int64_t)(std::upper_bound(at.begin() + i0 + 1, at.end(), at[(size_t)i0] + slice_bytes) - at.begin()) - 1;
 			if (i1 <= i0) i1 = i0 + 1; // (a single record larger than a slice)

@@ -73,7 +73,7 @@ int ssvh_plan_create(const ssvh_bam *bam, const ssvh_junction_in *junctions, int
 {
 	ssvh_plan *p = new ssvh_plan();
 	p->n_junctions = n_junctions;
-	static const bool timing = getenv("SSV_TIMING_PLAN") != nullptr;
+	static const bool timing = [] { const char *e = getenv("SSV_TIMING"); return e ? atoi(e) : 0; }() >= 3; // SSV_TIMING=3: the plan's phases
 	auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double tl = tnow();
 	auto lap = [&](const char *what) { if (timing) { const double t = tnow(); fprintf(stderr, "[plan] %s %.2f ms\n", what, t - tl); tl = t; } };

@@ -318,7 +318,7 @@ static bool slurp_gz_members(const std::string &path, std::unique_ptr<char[]> &b
 
 std::string slurp_gz(const std::string &path, std::string &out)
 {
-	static const bool serial = getenv("SSV_GZ_READ_SERIAL") != nullptr;
+	static const bool serial = getenv("SSV_SERIAL") && strstr(getenv("SSV_SERIAL"), "gz"); // SSV_SERIAL=gz (tests): one inflate stream
 	std::unique_ptr<char[]> whole;
 	size_t n_whole = 0;
 	if (!serial && slurp_gz_members(path, whole, n_whole)) { out.append(whole.get(), n_whole); return ""; }
@@ -376,7 +376,7 @@ struct TextView { // (just enough of std::string for the parser)
 // texts: pieces of whole rows, in file order
 static bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow> &rows)
 {
-	static const bool off = getenv("SSV_ROWS_SERIAL") != nullptr;
+	static const bool off = getenv("SSV_SERIAL") && strstr(getenv("SSV_SERIAL"), "rows"); // SSV_SERIAL=rows (tests): the stream loop
 	if (off) return false;
 	static const size_t per_thread = [] { const char *e = getenv("SSV_ROWS_CHUNK_KB"); const long kb = e ? atol(e) : 64; return (size_t)(kb < 1 ? 1 : kb) << 10; }(); // (tests: several threads on little text)
 	size_t total_bytes = 0;
@@ -543,7 +543,7 @@ static std::string assemble_junctions_view(const std::vector<TextView> &texts, c
 std::string assemble_junctions(const std::string &clipfile, const std::string &clip_bam, JunctionMap &j2o)
 {
 	const auto t0 = std::chrono::steady_clock::now();
-	static const bool serial = getenv("SSV_GZ_READ_SERIAL") != nullptr;
+	static const bool serial = getenv("SSV_SERIAL") && strstr(getenv("SSV_SERIAL"), "gz"); // SSV_SERIAL=gz (tests): one inflate stream
 	std::unique_ptr<char[]> buf;
 	size_t n_buf = 0;
 	std::string text;

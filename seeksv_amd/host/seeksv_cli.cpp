@@ -189,13 +189,12 @@ struct GzOut {
 // thread fills one pinned staging buffer while the chunk in the other one is being decoded.
 // ---------------------------------------------------------------------------------------------------------------------
 
-// Page-locked batch arrays for the host reader (copies to the GPU out of them run asynchronously); SSV_PAGEABLE=1 keeps malloc.
+// Page-locked batch arrays for the host reader (copies to the GPU out of them run asynchronously).
 static void *pinned_alloc(size_t n) { void *p = nullptr; return ssv_host_alloc(n, &p) == SSV_OK ? p : nullptr; }
 static void pinned_release(void *p) { ssv_host_free(p); }
 static void use_pinned_batches(ssvh_bam *b)
 {
-	static const bool pageable = getenv("SSV_PAGEABLE") != nullptr;
-	if (!pageable) ssvh_bam_set_allocator(b, pinned_alloc, pinned_release);
+	ssvh_bam_set_allocator(b, pinned_alloc, pinned_release);
 	ssvh_bam_set_readahead(b, 1);
 }
 
@@ -275,7 +274,7 @@ static EarlyCtx g_early;
 static void early_ctx_join() { if (g_early.th.joinable()) g_early.th.join(); }
 static void early_ctx_start(int device)
 {
-	if (g_early.started || getenv("SSV_NO_EARLY_CTX")) return;
+	if (g_early.started) return;
 	g_early.started = true; g_early.device = device;
 	atexit(early_ctx_join); // (usage errors leave through exit(): not while a thread is inside the runtime's start-up)
 	g_early.th = std::thread([] {
@@ -301,7 +300,7 @@ static ssv_ctx *acquire_ctx(int device)
 	return ctx;
 }
 
-static const bool kTimingChunks = getenv("SSV_TIMING_CHUNKS") != nullptr;
+static const bool kTimingChunks = [] { const char *e = getenv("SSV_TIMING"); return e ? atoi(e) : 0; }() >= 2; // SSV_TIMING=2: per-chunk detail
 
 // Staging memory for the chunks of a file in copy mode.  hipHostMalloc hands out page-locked memory at 0.25 s/GB (it allocates, clears and locks on
 // one thread, and other HIP calls of the process queue behind it meanwhile): three 0.6-1.5 GB buffers were 0.5 s before the first kernel of a
@@ -456,7 +455,7 @@ struct BatchSource {
 		if (!file_bytes || file_bytes > first_bytes_default()) ssv_bamdec_expect(ctx, chunk_inflated);
 	}
 	static size_t page_size() { static const size_t p = (size_t)sysconf(_SC_PAGESIZE); return p; }
-	static size_t first_bytes_default() { const char *e3 = getenv("SSV_STAGE_FIRST_MB"); return (size_t)(e3 ? atoll(e3) : 128) << 20; }
+	static size_t first_bytes_default() { return (size_t)128 << 20; }
 	static bool take_stage(Slot &S, size_t want)
 	{
 		if (S.stage.cap >= want) return true;
@@ -656,7 +655,7 @@ static int device_of_rank(int r, const vector<int> &devices)
 
 // DisplaySClipReadsAndClipFq (clip_reads.h:300-345) for the clusters [k0, k1) of a table: their clip.gz rows and clip.fq records
 // SSV_TABLE_FORMAT=0..3 picks another wire format for the cluster table (the text written is the same)
-static int table_format_default() { const char *e = getenv("SSV_TABLE_FORMAT"); return e ? atoi(e) : 3; }
+static int table_format_default() { return 3; }
 
 static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k0, int64_t k1, string &row, string &fq)
 {
@@ -1184,7 +1183,7 @@ static int cmd_getsv(int argc, char **argv)
 	}
 	{ // InputSoftInfoStoreBreakpoint + GetJunction (getsv.h:423, getsv.cpp:1705): clip clusters x re-alignments of their clipped sequences
 		string err;
-		if (g_resident.ctx && clipfile == g_resident.clip_path && clip_bam == g_resident.aln.bam_path && !getenv("SSV_RUN_REREAD")) {
+		if (g_resident.ctx && clipfile == g_resident.clip_path && clip_bam == g_resident.aln.bam_path) {
 			const auto &A = g_resident.aln; // rows and alignments are both still in memory
 			seeksv::AlnRecords R;
 			R.n = (int64_t)A.tid.size(); R.tid = A.tid.data(); R.pos = A.pos.data(); R.flag = A.flag.data(); R.n_cigar = A.n_cigar.data(); R.mapq = A.mapq.data();

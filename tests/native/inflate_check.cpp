@@ -7,7 +7,6 @@
 #include <zlib.h>
 
 #include "inflate_core.h"
-#include "inflate_lanes.h"
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
@@ -30,67 +29,6 @@ static std::vector<uint8_t> make_data(int shape, size_t n)
 	default: for (size_t i = 0; i < n; ++i) d[i] = (uint8_t)(rnd() % (1 + i % 251)); break;
 	}
 	return d;
-}
-
-// The ring-based state machine (inflate_lanes.h) driven the way the kernel drives it: refill the input ring when the lane asks, one step,
-// write out half an output ring when the lane asks.  Rings and streams live in plain memory here.
-template <class Cfg> struct CpuIo {
-	uint32_t in_ring[Cfg::IN_DW];
-	uint8_t out_ring[4 * Cfg::OUT_DW];
-	const uint8_t *in_org, *in_end; // loads stay below in_end
-	uint8_t *out_org;
-	uint32_t in_get(int slot) const { return in_ring[slot]; }
-	uint32_t in_stream32(uint32_t off) const { uint32_t v = 0; for (int b = 0; b < 4; ++b) if (in_org + off + b < in_end) v |= (uint32_t)in_org[off + b] << (8 * b); return v; }
-	void out_set8(uint32_t idx, uint8_t v) { out_ring[idx] = v; }
-	uint8_t out_get8(uint32_t idx) const { return out_ring[idx]; }
-	uint32_t out_get32(int slot) const { uint32_t v; memcpy(&v, out_ring + 4 * slot, 4); return v; }
-	void out_set32(int slot, uint32_t v) { memcpy(out_ring + 4 * slot, &v, 4); }
-	uint32_t out_stream32(uint32_t pos) const { uint32_t v; memcpy(&v, out_org + pos, 4); return v; }
-};
-
-template <class Cfg> static int lane_inflate(const uint8_t *in, uint32_t in_len, const uint8_t *in_buf_end, uint8_t *out, uint32_t out_len, ssv::PlainTab &tab, long *steps)
-{
-	CpuIo<Cfg> io;
-	const uint32_t mi = (uint32_t)((uintptr_t)in & 3), mo = (uint32_t)((uintptr_t)out & 3);
-	io.in_org = in - mi; io.in_end = in_buf_end; io.out_org = out - mo;
-	memset(io.in_ring, 0xEE, sizeof(io.in_ring)); memset(io.out_ring, 0xDD, sizeof(io.out_ring));
-	ssv::LaneInflate<Cfg> L;
-	L.start(mi, in_len, mo, out_len);
-	while (L.state != ssv::ST_DONE) {
-		if (L.wants_refill()) {
-			for (int j = 0; j < Cfg::REFILL_DW; ++j) { const uint32_t D = L.rfill + (uint32_t)j; io.in_ring[D % Cfg::IN_DW] = io.in_stream32(4 * D); }
-			L.rfill += Cfg::REFILL_DW;
-		}
-		L.step(io, tab);
-		++*steps;
-		if (L.state == ssv::ST_FAR) { // the far move, the way the wavefront makes it: every helper reads, then every helper writes
-			const ssv::FarMove<Cfg> m = L.far_view();
-			const uint32_t nd = m.dwords();
-			if (nd > ssv::FarMove<Cfg>::FAR_DW || m.chunk() == 0) return -102;
-			std::vector<uint32_t> val(nd), msk(nd);
-			for (uint32_t j = 0; j < nd; ++j) {
-				const uint32_t q0 = m.pos(j);
-				uint32_t srcv = 0;
-				if (m.needs_src(j)) for (int b2 = 0; b2 < 4; ++b2) { const int64_t sp = (int64_t)q0 + b2 - (int64_t)m.dist; if (sp >= (int64_t)L.o_begin) srcv |= (uint32_t)io.out_org[sp] << (8 * b2); }
-				msk[j] = m.merge(j, io.out_get32((int)((q0 >> 2) % Cfg::OUT_DW)), srcv, val[j]);
-			}
-			for (uint32_t j = 0; j < nd; ++j) {
-				const uint32_t q0 = m.pos(j);
-				for (int b2 = 0; b2 < 4; ++b2) if (msk[j] >> b2 & 1) io.out_org[q0 + b2] = (uint8_t)(val[j] >> (8 * b2));
-				if (m.to_ring(j)) io.out_set32((int)((q0 >> 2) % Cfg::OUT_DW), val[j]);
-			}
-			L.far_done();
-		}
-		if (L.wants_flush()) {
-			const bool fin = L.state == ssv::ST_FINISH;
-			const uint32_t hi = fin ? L.o : L.f + 4u * Cfg::FLUSH_DW;
-			if (!fin && hi > L.o) return -100; // a unit is only written out when it is complete
-			for (uint32_t q = L.f; q < hi; ++q) if (q >= L.o_begin && q < L.o_end) io.out_org[q] = io.out_ring[q % (4u * Cfg::OUT_DW)];
-			if (fin) L.state = ssv::ST_DONE; else L.f += 4u * Cfg::FLUSH_DW;
-		}
-		if (L.o - L.f > 4u * Cfg::OUT_DW) return -101; // the ring overflowed
-	}
-	return L.verdict();
 }
 
 int main()
@@ -116,21 +54,6 @@ int main()
 					std::vector<uint8_t> o(n + 8, 0x55);
 					int rc = ssv::inflate_stream(c.data(), clen, o.data(), (uint32_t)n, tab);
 					bool same = rc == ssv::INF_OK && memcmp(o.data(), d.data(), n) == 0 && o[n] == 0x55;
-					for (int mo = 0; mo < 2; ++mo) { // through the 64-byte line buffer, at two misalignments of the output
-						struct CpuLine {
-							uint8_t b[64];
-							uint8_t get8(uint32_t i) const { return b[i]; }
-							void set8(uint32_t i, uint8_t v) { b[i] = v; }
-							void set32(uint32_t di, uint32_t v) { memcpy(b + 4 * di, &v, 4); }
-							void store16(uint8_t *dst, uint32_t g) const { memcpy(dst, b + 16 * g, 16); }
-						};
-						std::vector<uint8_t> o3(n + 200, 0x55);
-						uint8_t *op = o3.data() + 64 + ((shape * 7 + (int)n + 13 * mo) % 64);
-						ssv::LineOut<CpuLine> lo;
-						lo.out = op; lo.a0 = (uint32_t)((uintptr_t)op & 63); lo.flushed = 0; memset(lo.line.b, 0xCC, 64);
-						int rc3 = ssv::inflate_stream_to(c.data(), clen, lo, (uint32_t)n, tab);
-						if (!(rc3 == ssv::INF_OK && memcmp(op, d.data(), n) == 0 && op[n] == 0x55 && op[-1] == 0x55)) { same = false; fprintf(stderr, "LINE sink: "); }
-					}
 					for (int mo = 0; mo < 4; ++mo) { // decode and copy split in two: tokens, then the holes filled in order; the output at every misalignment
 						// (literals leave as aligned dwords: nothing may be written in front of the block or behind it)
 						std::vector<uint8_t> o4(n + 24, 0x55);
@@ -170,37 +93,8 @@ int main()
 							if (ssv::inflate_stream_from(br, cc.data() + mi, clen - 3, t2, (uint32_t)n, tabl) == ssv::INF_OK) { same = false; fprintf(stderr, "WINDOW reader: truncated input accepted: "); }
 						}
 					}
-					{ // the second copy routine (unaligned dword moves)
-						std::vector<uint8_t> o2(n + 8, 0x55);
-						int rc2 = ssv::inflate_stream<ssv::PlainTab, true>(c.data(), clen, o2.data(), (uint32_t)n, tab);
-						if (!(rc2 == ssv::INF_OK && memcmp(o2.data(), d.data(), n) == 0 && o2[n] == 0x55)) same = false;
-					}
 					if (same) ++n_ok;
 					else { ++n_bad; fprintf(stderr, "MISMATCH shape %d n %zu level %d strategy %d rc %d\n", shape, n, level, strategy, rc); }
-					// the same stream through the ring machine, at every misalignment of input and output, in several ring geometries
-					for (int variant = 0; variant < 4; ++variant) {
-						const int mi = (variant * 3 + shape) & 3, mo = (variant + (int)n) & 3;
-						std::vector<uint8_t> cc(c.size() + 8, 0xAA), oo(n + 16, 0x55);
-						memcpy(cc.data() + mi, c.data(), clen + 8);
-						long steps = 0;
-						int r3;
-						uint8_t *op = oo.data() + 4 + mo;
-						const uint8_t *ie = cc.data() + cc.size();
-						if (variant == 0) r3 = lane_inflate<ssv::RingCfg<32, 32, 16>>(cc.data() + mi, clen, ie, op, (uint32_t)n, tab, &steps);
-						else if (variant == 1) r3 = lane_inflate<ssv::RingCfg<16, 32, 16>>(cc.data() + mi, clen, ie, op, (uint32_t)n, tab, &steps);
-						else if (variant == 2) r3 = lane_inflate<ssv::RingCfg<8, 16, 8>>(cc.data() + mi, clen, ie, op, (uint32_t)n, tab, &steps);
-						else r3 = lane_inflate<ssv::RingCfg<64, 64, 16>>(cc.data() + mi, clen, ie, op, (uint32_t)n, tab, &steps);
-						bool ok3 = r3 == ssv::INF_OK && memcmp(op, d.data(), n) == 0 && op[n] == 0x55 && op[-1] == 0x55;
-						if (ok3) ++n_ok;
-						else { ++n_bad; fprintf(stderr, "RING MISMATCH variant %d shape %d n %zu level %d strategy %d rc %d\n", variant, shape, n, level, strategy, r3); }
-						if (n > 16 && variant == 0) {
-							std::vector<uint8_t> o2(n + 16, 0x55);
-							int r4 = lane_inflate<ssv::RingCfg<32, 32, 16>>(cc.data() + mi, clen, ie, o2.data() + 4, (uint32_t)n - 1, tab, &steps);
-							if (r4 == ssv::INF_OK || o2[4 + n - 1] != 0x55) { ++n_bad; fprintf(stderr, "ring: short output accepted or overrun: shape %d n %zu level %d rc %d\n", shape, n, level, r4); }
-							int r5 = lane_inflate<ssv::RingCfg<32, 32, 16>>(cc.data() + mi, clen > 4 ? clen - 3 : 0, ie, o2.data() + 4, (uint32_t)n, tab, &steps);
-							if (r5 == ssv::INF_OK && level > 0 && shape != 5) { ++n_bad; fprintf(stderr, "ring: truncated input accepted: shape %d n %zu level %d\n", shape, n, level); }
-						}
-					}
 					// a stream cut short or an output size that is wrong must be refused, not overrun
 					if (n > 16) {
 						int r2 = ssv::inflate_stream(c.data(), clen, o.data(), (uint32_t)n - 1, tab);

@@ -23,7 +23,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ssv_abi_version() == 7
+    assert lib.ssv_abi_version() == 8
 
 
 def test_host_library_exports_every_declared_symbol():

@@ -214,7 +214,7 @@ def _block_table_digest(path):
 def test_parallel_header_walk_equals_serial_walk(tmp_path):
     """ssvh_bam_read_blocks finds the headers of a chunk's BGZF blocks with all host threads at once (every thread looks for the first block that begins in
     its segment and walks to the next segment; segments are taken over as far as they join) - on a file large enough for that path the block table is the one
-    the one-block-after-the-other walk (SSV_WALK=serial, in a process of its own) makes"""
+    the one-block-after-the-other walk (SSV_SERIAL=walk, in a process of its own) makes"""
     import subprocess
     import sys
     from seeksv_amd import synth
@@ -233,7 +233,7 @@ def test_parallel_header_walk_equals_serial_walk(tmp_path):
     par = _block_table_digest(path)
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_bam_reader as t; print(*t._block_table_digest(%r))" % (
         os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSV_WALK="serial"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSV_SERIAL="walk"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     ser = r.stdout.split()
     assert (ser[0], int(ser[1])) == par and par[1] > 1000

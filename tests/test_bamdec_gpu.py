@@ -266,47 +266,16 @@ def test_device_decode_match_shapes(ctx, tmp_path, chunk_bytes, max_blocks):
         assert len(h["seqs"]) == len(recs)
 
 
-@pytest.mark.parametrize("mode", ["plain", "rings", "rings8"])
-def test_ring_machine_inflate_modes(mode):
-    """SSV_INFLATE=plain (one pass, a lane per block) / rings... (the state-machine decoder with LDS rings and wavefront-cooperative far moves,
-    inflate_lanes.h): not the default, kept correct - the same device-decode == host-reader checks run under each (the mode
-    is read once per process: a child pytest runs them)"""
-    import subprocess
-    import sys
-    if os.environ.get("SSV_INFLATE"):
-        pytest.skip("already inside a mode run")
-    env = dict(os.environ, SSV_INFLATE=mode)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes"], env=env, capture_output=True, text=True,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
-def test_resolve_in_lds_mode():
-    """SSV_RESOLVE=lds: pass 2 of the inflate as a workgroup per BGZF block with the block in LDS (k_bgzf_resolve_lds: chains flattened by
-    pointer jumping over the round's tokens, then wavefront-local readiness, coalesced load and store of the block) - not the default (it moves
-    a seventh of the bytes and takes 2.5 x the time), kept correct: the same device-decode == host-reader checks"""
-    import subprocess
-    import sys
-    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_INFLATE"):
-        pytest.skip("already inside a mode run")
-    env = dict(os.environ, SSV_RESOLVE="lds")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes"], env=env, capture_output=True, text=True,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
-@pytest.mark.parametrize("mode", ["wave", "lanes16", "win"])
+@pytest.mark.parametrize("mode", ["wave", "win"])
 def test_resolve_modes(mode):
-    """Pass 2 of the inflate has two forms in global memory: a wavefront per BGZF block (k_bgzf_resolve_wave: rounds of 64 tokens, the earlier holes a source
-    touches as a lane range found by binary search, readiness by one AND with the ballot of the open lanes) and 16 lanes per block (k_bgzf_resolve) - and the
-    wavefront form with a window of the block in LDS (k_bgzf_resolve_win: the round's bytes in and out with coalesced 16-byte accesses, matches copied inside the window).  All,
+    """Pass 2 of the inflate, a wavefront per BGZF block, in its two forms: working in global memory (k_bgzf_resolve_wave: rounds of 64 tokens, the earlier holes a
+    source touches as a lane range found by binary search, readiness by one AND with the ballot of the open lanes - the reference form) and with a window of the
+    block in LDS (k_bgzf_resolve_win, the default: the round's bytes in and out with coalesced 16-byte accesses, matches copied inside the window).  Both,
     forced, through the same device-decode == host-reader checks: every match shape (near, far, overlapping its own hole, 3..258 bytes), every kind of deflate
     block, records and blocks straddling chunks, damaged input"""
     import subprocess
     import sys
-    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_INFLATE") or os.environ.get("SSV_TOKENS"):
+    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_TOKENS"):
         pytest.skip("already inside a mode run")
     env = dict(os.environ, SSV_RESOLVE=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes or rejects_damage or longer_than or every_deflate or fuzzed"], env=env,
@@ -343,7 +312,7 @@ def test_tokens_modes(mode):
     chunks, damaged input"""
     import subprocess
     import sys
-    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_INFLATE") or os.environ.get("SSV_TOKENS"):
+    if os.environ.get("SSV_RESOLVE") or os.environ.get("SSV_TOKENS"):
         pytest.skip("already inside a mode run")
     env = dict(os.environ, SSV_TOKENS=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "ragged or goldens or synthetic_large or match_shapes or rejects_damage or longer_than or every_deflate or fuzzed"], env=env,

@@ -65,7 +65,7 @@ def test_cli_getclip_reader_maps_the_file(tmp_path, sub, bam, prefix, flags, inf
         pytest.skip("the host reader does not read chunks")
     monkeypatch.setenv("SSV_READER", "map")
     out = str(tmp_path / "o")
-    r = subprocess.run([SEEKSV, "getclip"] + flags + ["-o", out, os.path.join(G.GOLDEN, sub, bam)], capture_output=True, text=True, env=dict(os.environ, SSV_TIMING_CHUNKS="1"))
+    r = subprocess.run([SEEKSV, "getclip"] + flags + ["-o", out, os.path.join(G.GOLDEN, sub, bam)], capture_output=True, text=True, env=dict(os.environ, SSV_TIMING="2"))
     assert r.returncode == 0, r.stderr
     assert "page-locked in the mapping" in r.stderr or "copied to staging" in r.stderr   # (a file system the runtime cannot lock falls back to the copy, chunk by chunk)
     assert gzip.open(out + ".clip.gz", "rt").read() == G.read_text(sub, prefix + ".clip.txt")

@@ -42,33 +42,6 @@ def test_getclip_hip_matches_reference(ctx, sub, bam, prefix, kw, batch_records)
     assert_tables_equal(d, O.getclip(batches, **kw))
 
 
-@pytest.mark.parametrize("sub,bam,prefix,kw", GETCLIP_CASES, ids=[c[2] for c in GETCLIP_CASES])
-@pytest.mark.parametrize("fmt", [1, 2])
-def test_getclip_packed_table_format(ctx, sub, bam, prefix, kw, fmt):
-    """ssv_clip_table_format: 1 = sequences leave the GPU as 4-bit codes, 2 = also qualities as indices into the pass's quality alphabet when
-    it has at most 16 members; decoded, the table is the ASCII table (and the reference's rows)"""
-    if prefix == "unsorted":
-        pytest.skip("several passes: their tables are put together in the ASCII format (the CLI tests cover the compact one)")
-    names, lens, batches = host.read_bam(os.path.join(G.GOLDEN, sub, bam), 1 << 20)
-    ref = ctx.getclip(batches, **kw)
-    ctx.clip_table_format(fmt)
-    try:
-        d = ctx.getclip(batches, **kw)
-    finally:
-        ctx.clip_table_format(False)
-    assert d["seq_packed"] == 1 and ref["seq_packed"] == 0
-    for k in ("tid", "pos", "side", "support", "left_len", "right_len", "qual_missing", "cigar_off", "n_cigar", "cigar"):
-        assert np.array_equal(d[k], ref[k]), k
-    assert all(host.cluster_strings(d, k) == host.cluster_strings(ref, k) for k in range(d["n_clusters"]))
-    if d["n_clusters"]:
-        assert len(d["str"]) < len(ref["str"])
-        assert d["qual_bits"] in ((8,) if fmt == 1 else (1, 2, 3, 4, 8))
-        offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1, d["qual_bits"]) for a, b in zip(d["left_len"], d["right_len"])])])
-        assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))
-    clip, fq = host.format_clip_outputs(d, names)
-    assert clip == G.read_text(sub, prefix + ".clip.txt") and fq == G.read_text(sub, prefix + ".clip.fq.txt")
-
-
 def _compact_checks(ctx, d, ref, t, check_size=True):
     """a format-3 table against the ASCII table of the same input: every rebuilt column, every decoded string, the C-side rebuild
     (ssv_clip_table_expand) against the numpy one, and the size of what crossed PCIe"""
@@ -361,37 +334,6 @@ def _remap_qualities(batch, alphabet):
         sq[q0:q0 + lq] = alphabet[(old * 7 + np.arange(lq)) % len(alphabet)]
     b["seqqual"] = sq
     return b
-
-
-@pytest.mark.parametrize("n_values,bits", [(1, 1), (2, 1), (3, 2), (4, 2), (5, 3), (8, 3), (9, 4), (16, 4), (17, 8)])
-@pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300", "synth400"])
-def test_packed_table_quality_alphabets(ctx, source, n_values, bits):
-    """format 2 with every index width: the decoded packed table equals the ASCII table and the oracle's, on deep bins (consensus
-    storage), odd clip offsets, reads longer than the kernel's LDS-staged limit, missing qualities"""
-    if source.startswith("synth"):
-        from seeksv_amd import synth
-        w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, read_len=int(source[5:]))
-        batches = [w.generate_host(0, w.n_total)]
-    else:
-        batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", source + ".bam"))[2]
-    alphabet = [(3 + 5 * k) % 94 for k in range(n_values)]
-    batches = [_remap_qualities(b, alphabet) for b in batches]
-    ref = ctx.getclip(batches)
-    assert_tables_equal(ref, O.getclip(batches))
-    ctx.clip_table_format(2)
-    try:
-        d = ctx.getclip(batches)
-    finally:
-        ctx.clip_table_format(0)
-    assert d["n_clusters"] == ref["n_clusters"] > 0
-    assert d["qual_bits"] == bits, (d["qual_bits"], bits)
-    for k in ("tid", "pos", "side", "support", "left_len", "right_len", "qual_missing", "cigar_off", "n_cigar", "cigar"):
-        assert np.array_equal(d[k], ref[k]), k
-    for k in range(d["n_clusters"]):
-        assert host.cluster_strings(d, k) == host.cluster_strings(ref, k), k
-    # the bytes of the packed table itself: every block zero padded, laid out back to back
-    offs = np.concatenate([[0], np.cumsum([host.block_bytes(int(a), int(b), 1, d["qual_bits"]) for a, b in zip(d["left_len"], d["right_len"])])])
-    assert np.array_equal(d["str_off"], offs[:-1].astype(np.uint64))
 
 
 @pytest.mark.parametrize("kw", [dict(genome_frac=1 / 4096, depth=60, n_sv=30), dict(genome_frac=1 / 8192, depth=60, n_sv=8, n_integrations=10)], ids=["wgs", "hbv"])

@@ -40,7 +40,7 @@ def write_gz(path, data, **env):
 
 def run(exe, args, **env):
     e = dict(os.environ)
-    for k in ("SSV_GZ_READ_SERIAL", "SSV_ROWS_SERIAL", "SSV_ROWS_CHUNK_KB"):
+    for k in ("SSV_SERIAL", "SSV_ROWS_CHUNK_KB"):
         e.pop(k, None)
     e.update(env)
     r = subprocess.run([exe] + args, capture_output=True, env=e)
@@ -57,14 +57,14 @@ def test_join_same_with_parallel_gunzip_and_parse(exe, tmp_path, sample):
     files["zlib6"] = str(tmp_path / "z.gz"); write_gz(files["zlib6"], rows, SSV_GZ_PIECE_KB="4", SSV_GZ_LEVEL="6")  # zlib members (same ten header bytes)
     files["gzip"] = str(tmp_path / "g.gz"); open(files["gzip"], "wb").write(gzip.compress(rows))                  # somebody else's gzip: one member
     files["plain"] = str(tmp_path / "p.txt"); open(files["plain"], "wb").write(rows)
-    want = run(exe, ["join", files["gzip"], bam, "20"], SSV_GZ_READ_SERIAL="1", SSV_ROWS_SERIAL="1")
+    want = run(exe, ["join", files["gzip"], bam, "20"], SSV_SERIAL="gz,rows")
     assert want.count(b"\n") >= 1
     for name, f in files.items():
         assert run(exe, ["slurp", f]) == rows, name
         assert run(exe, ["join", f, bam, "20"], SSV_ROWS_CHUNK_KB="1") == want, name    # ~50 parsing threads
         assert run(exe, ["join", f, bam, "20"]) == want, name
-        assert run(exe, ["join", f, bam, "20"], SSV_ROWS_SERIAL="1") == want, name
-    assert run(exe, ["join", files["members"], bam], SSV_ROWS_CHUNK_KB="1") == run(exe, ["join", files["gzip"], bam], SSV_GZ_READ_SERIAL="1", SSV_ROWS_SERIAL="1")
+        assert run(exe, ["join", f, bam, "20"], SSV_SERIAL="rows") == want, name
+    assert run(exe, ["join", files["members"], bam], SSV_ROWS_CHUNK_KB="1") == run(exe, ["join", files["gzip"], bam], SSV_SERIAL="gz,rows")
 
 
 def test_false_member_header_inside_a_member(exe, tmp_path):
@@ -83,12 +83,12 @@ def test_false_member_header_inside_a_member(exe, tmp_path):
     # and a member whose trailer size is wrong: serial too (gzread reports what it can; here: everything in front of the damage)
     bad = member(a, 6)[:-4] + struct.pack("<I", len(a) + 1) + member(b, 6)
     open(p, "wb").write(bad)
-    assert run(exe, ["slurp", p]) == run(exe, ["slurp", p], SSV_GZ_READ_SERIAL="1")
+    assert run(exe, ["slurp", p]) == run(exe, ["slurp", p], SSV_SERIAL="gz")
 
 
 @pytest.mark.parametrize("damage", ["short line", "number with a tail", "two-character side", "number out of range", "blank lines and CRLF"])
 def test_rows_the_parallel_parser_does_not_vouch_for(exe, tmp_path, damage):
-    """such text goes through the stream loop, whatever that makes of it (the same as with SSV_ROWS_SERIAL)"""
+    """such text goes through the stream loop, whatever that makes of it (the same as with SSV_SERIAL=rows)"""
     lines = open(os.path.join(EX, "cancer.clip.txt"), "rb").read().split(b"\n")
     k = len(lines) // 2
     f = lines[k].split(b"\t")
@@ -100,6 +100,6 @@ def test_rows_the_parallel_parser_does_not_vouch_for(exe, tmp_path, damage):
     p = str(tmp_path / "d.txt")
     open(p, "wb").write(b"\n".join(lines))
     bam = os.path.join(EX, "cancer.clip.bam")
-    want = run(exe, ["join", p, bam, "20"], SSV_ROWS_SERIAL="1")
+    want = run(exe, ["join", p, bam, "20"], SSV_SERIAL="rows")
     assert run(exe, ["join", p, bam, "20"], SSV_ROWS_CHUNK_KB="1") == want
     assert run(exe, ["join", p, bam, "20"]) == want

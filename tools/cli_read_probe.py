@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the time of the file-reading side go?  Writes a synthetic 30x sample (bases and qualities for every record) as a BAM in /dev/shm and runs
-`seeksv getsv -Z -B` / `seeksv getclip -Z` on it with SSV_TIMING=1 SSV_TIMING_CHUNKS=1 (per chunk: waited for the reader / decoded; per read_blocks call:
+`seeksv getsv -Z -B` / `seeksv getclip -Z` on it with SSV_TIMING=2 (per chunk: waited for the reader / decoded; per read_blocks call:
 pread / header walk), under the environment variants given on the command line, then tools/read_rate on the same file.
 usage: python tools/cli_read_probe.py [genome_frac=0.25] [VAR=VALUE,VAR=VALUE ...]   (each further argument is one variant)"""
 import json
@@ -47,7 +47,7 @@ def main():
         host.write_bam(empty_bam, w.names, w.lens, [])
         open(empty_clip, "w").close()
         for v in variants:
-            env = dict(os.environ, SSV_TIMING="1", SSV_TIMING_CHUNKS="1", **v)
+            env = dict(os.environ, SSV_TIMING="2", **v)
             for name, cmd in (("getsv", [EXE, "getsv", "-Z", "-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip, os.path.join(d, "o.sv"), os.path.join(d, "o.fq")]),
                               ("getclip", [EXE, "getclip", "-Z", "-o", os.path.join(d, "o"), bam])):
                 for rep in range(2):
@@ -62,7 +62,7 @@ def main():
         if os.environ.get("PROBE_RUN"):   # `seeksv run` on the same file: per-chunk retain timing, phases
             fa = os.path.join(d, "ref.fa")
             w.write_fasta(fa, cores)
-            env = dict(os.environ, SSV_TIMING="1", SSV_TIMING_CHUNKS="1")
+            env = dict(os.environ, SSV_TIMING="2")
             env.pop("SSV_BGZF_LEVEL", None)
             for rep in range(2):
                 t = time.perf_counter()

@@ -32,6 +32,13 @@ def phases(stderr):
     return out
 
 
+def sha(path):
+    """sha256 of a file's content - of the INFLATED text for a .gz (the two programs' gzip members differ, their text must not)"""
+    import hashlib
+    data = gzip.open(path).read() if path.endswith(".gz") else open(path, "rb").read()
+    return hashlib.sha256(data).hexdigest()
+
+
 def timed(cmd, **kw):
     t = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, **kw)
@@ -66,7 +73,16 @@ def main():
         out["ours_getclip_Z_phases_s"] = phases(r.stderr)
     for ext in ("clip.gz", "clip.fq.gz"):
         assert gzip.open(os.path.join(d, "ours." + ext)).read() == gzip.open(os.path.join(d, "oursz." + ext)).read(), ext
+    # ... and cut into three runs of records (three ranks on the box's one GPU), inflated on the device
+    out["ours_getclip_N3_Z_s"], r = timed([OURS, "getclip", "-Z", "-N", "3", "-o", os.path.join(d, "oursn"), bam])
+    assert r.returncode == 0, r.stderr
+    digests = out.setdefault("sha256", {})
+    for ext in ("clip.gz", "clip.fq.gz"):
+        digests[ext] = {who: sha(os.path.join(d, who_prefix + "." + ext)) for who, who_prefix in (("ours", "ours"), ("ours_Z", "oursz"), ("ours_N3_Z", "oursn"))}
+        assert len(set(digests[ext].values())) == 1, ext
     if have_ref:
+        for ext in ("clip.gz", "clip.fq.gz"):
+            digests[ext]["reference"] = sha(os.path.join(d, "ref." + ext))
         for ext in ("clip.gz", "clip.fq.gz"):
             assert gzip.open(os.path.join(d, "ref." + ext)).read() == gzip.open(os.path.join(d, "ours." + ext)).read(), ext
         out["getclip_outputs_identical"] = True
@@ -93,7 +109,13 @@ def main():
     if phases(rz.stderr):
         out["ours_getsv_Z_phases_s"] = phases(rz.stderr)
     assert open(os.path.join(d, "ours.sv")).read() == open(os.path.join(d, "oursz.sv")).read() and rz.stdout == r.stdout
+    out["ours_getsv_N3_Z_s"], rn = timed([OURS, "getsv", "-Z", "-N", "3"] + args + [os.path.join(d, "oursn.sv"), os.path.join(d, "n.fq")])
+    assert rn.returncode == 0, rn.stderr
+    assert rn.stdout == r.stdout
+    digests["getsv -B sv table"] = {who: sha(os.path.join(d, f + ".sv")) for who, f in (("ours", "ours"), ("ours_Z", "oursz"), ("ours_N3_Z", "oursn"))}
+    assert len(set(digests["getsv -B sv table"].values())) == 1
     if have_ref:
+        digests["getsv -B sv table"]["reference"] = sha(os.path.join(d, "ref.sv"))
         assert open(os.path.join(d, "ref.sv")).read() == open(os.path.join(d, "ours.sv")).read()
         assert ref_stdout == r.stdout
         out["getsv_outputs_identical"] = True
@@ -116,6 +138,12 @@ def main():
         assert r.returncode == 0, r.stderr
         if phases(r.stderr):
             out["ours_getsv_full_phases_s"] = phases(r.stderr)
+        out["ours_getsv_full_Z_s"], rz = timed([OURS, "getsv", "-Z"] + full + [os.path.join(d, "oursz.full.sv"), os.path.join(d, "u3.fq")])
+        assert rz.returncode == 0, rz.stderr
+        assert rz.stdout == r.stdout
+        digests["full pipeline sv table"] = {"ours": sha(os.path.join(d, "ours.full.sv")), "ours_Z": sha(os.path.join(d, "oursz.full.sv"))}
+        assert len(set(digests["full pipeline sv table"].values())) == 1
+        digests["full pipeline unmapped fq"] = {"ours": sha(os.path.join(d, "u1.fq")), "ours_Z": sha(os.path.join(d, "u3.fq"))}
         rows = [l.split("\t") for l in open(os.path.join(d, "ours.full.sv")) if not l.startswith("@")]
         found = {(c[0], int(c[1]), c[2], c[4], int(c[5]), c[6]) for c in rows}
         planted = {tuple(j[:6]) for j in w.junctions}
@@ -125,6 +153,9 @@ def main():
             assert rr.returncode == 0, rr.stderr
             assert open(os.path.join(d, "ref.full.sv")).read() == open(os.path.join(d, "ours.full.sv")).read()
             assert rr.stdout == r.stdout
+            digests["full pipeline sv table"]["reference"] = sha(os.path.join(d, "ref.full.sv"))
+            digests["full pipeline unmapped fq"]["reference"] = sha(os.path.join(d, "u2.fq"))
+            assert len(set(digests["full pipeline unmapped fq"].values())) == 1
             out["full_pipeline_sv_table_identical"] = True
             out["speedup_getsv_full"] = round(out["ref_getsv_full_s"] / out["ours_getsv_full_s"], 2)
     for k in list(out):

@@ -31,7 +31,7 @@ def run(w, hdr, ctx, n_chunks, probe=None):
         t["generate"] += time.perf_counter() - t0
         return b, keep
 
-    ctx.clip_table_format(2)
+    ctx.clip_table_format(3)
     ctx.clip_begin(0.9, 1, False, None, 0)
     stats = None
     for k, (g, m) in enumerate(cuts):
