@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--file-frac", type=float, default=-1.0, help="(default: --genome-frac, i.e. the bench workload itself = BASELINE config 2, 617 M records / 44 GB, where >= 192 host cores write the file in about a minute; a quarter of it from 64 cores; else 1/16 or 1/64) genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
                     "inflate + decode -> scans -> tables on the host); 0 = skip")
     ap.add_argument("--file-level", type=int, default=-1, help="deflate level of the file leg's BAM (default: 6 = samtools' default where >= 64 CPUs write the file, else 4)")
+    ap.add_argument("--qual-alphabet", choices=("binned5", "hiseq40"), default="binned5", help="the synthetic reads' base qualities: five binned values {2, 11, 25, 37, 40} (NovaSeq-like, the default) or forty values 2..41 (HiSeq-like: the compact table's 11-bit pairs, a file that deflates less)")
     ap.add_argument("--no-config3", action="store_true", help="skip config3_path (BASELINE config 3's shape: 300x over a tenth of the genome, the same number of records, resident in HBM)")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip cli_path (the `seeksv` binary as child processes on the file leg's BAM)")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
@@ -106,7 +107,7 @@ def main():
         """the resident-input leg on one workload (args.depth / args.genome_frac / args.n_sv): generation, K timed steps, the breakdown steps"""
 
         strong = args.scaling == "strong"
-        w = synth.Workload(genome_frac=args.genome_frac, depth=args.strong_depth if strong else args.depth * world, n_sv=args.n_sv)
+        w = synth.Workload(genome_frac=args.genome_frac, depth=args.strong_depth if strong else args.depth * world, n_sv=args.n_sv, qual_model=1 if args.qual_alphabet == "hiseq40" else 0)
         sp = shard.shard_plan(w, rank, world)
         t0 = time.time()
         n_scan = sp["own_hi_rec"] - sp["scan_lo_rec"]
@@ -368,7 +369,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "i32/u8 (fp64 match-rate compare)", "data": "synthetic",
             "config": {"workload": (f"synthetic {args.strong_depth:g}x WGS (BASELINE config 3/4), ONE sample range-partitioned over {world} GPU(s), " if strong else f"synthetic {args.depth:g}x-per-GPU WGS, ") +
-                                   f"150 bp PE, 1% random soft clips, {len(w.junctions)} planted DEL/INV/TRA (VAF 0.5), genome_frac {args.genome_frac:g}, {n_own} records/GPU resident in HBM",
+                                   f"150 bp PE, 1% random soft clips, {len(w.junctions)} planted DEL/INV/TRA (VAF 0.5), genome_frac {args.genome_frac:g}, {n_own} records/GPU resident in HBM" + (", forty-value base qualities (--qual-alphabet hiseq40)" if args.qual_alphabet == "hiseq40" else ""),
                        "records_total": total_records, "records_per_gpu": n_own, "junctions": len(w.junctions), "parallelism": f"range-partition x{world}",
                        "multi_gpu": (f"strong scaling (--scaling strong): BASELINE config 4 - the fixed {args.strong_depth:g}x sample split {world} ways by reference interval, halo at the cuts, one all-gather" if strong else
                                      "weak scaling (default): 30x per GPU over the same genome (N GPUs = 30N x); `--scaling strong` runs BASELINE config 4's fixed 300x sample split N ways"),
@@ -522,7 +523,7 @@ def file_path_leg(ctx, args, device):
     from concurrent.futures import ThreadPoolExecutor
     import torch
     from seeksv_amd import _abi, host, synth
-    w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, round(args.n_sv * args.file_frac / args.genome_frac)))  # the same density of planted junctions
+    w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, round(args.n_sv * args.file_frac / args.genome_frac)), qual_model=1 if args.qual_alphabet == "hiseq40" else 0)  # the same density of planted junctions
     need = int(w.n_total * 100)  # the file is ~72 bytes a record
     def room(path):
         try:

@@ -246,7 +246,7 @@ typedef struct {
 	int32_t qual_bits;         /* 8: qualities are characters (phred + 33), one byte each; format 3: bits per quality (or per group of qualities) in the
 	                              quality stream, below.  Lossless: base qualities are most of the table's bytes and come from a handful of values
 	                              on current sequencers. */
-	uint8_t qual_alphabet[16]; /* index -> quality character */
+	uint8_t qual_alphabet[64]; /* index -> quality character (v8: 64 places; the entries in use are non-zero and increasing) */
 	/* ---- format 3, the compact table: what the host can rebuild does not cross PCIe ----
 	 * Handed out by ssv_clip_table_wait: pos, c_cigar (cigar too when cigar_bytes is 4), str and the fields below; tid, side, support, left_len, right_len, qual_missing,
 	 * n_cigar, str_off and cigar_off are NULL until ssv_clip_table_expand() has rebuilt them on the host.
@@ -260,7 +260,8 @@ typedef struct {
 	 *                     every base that is something else is listed in base_exc (the stream holds 0 there); base_bits 4 (only when
 	 *                     that list would be too long): index into "=ACMGRSVTWYHKDBN"
 	 *     quality stream  the n qualities the same way at qual_bits each (8: characters), all zero when qual_missing.  qual_group k > 1 (v7; alphabets
-	 *                     whose size R is far from a power of two - five values: k = 3, nine to eleven: k = 2, qual_bits = 7): the stream is
+	 *                     whose size R is far from a power of two - five values: k = 3, qual_bits = 7; nine to eleven: k = 2, qual_bits = 7; v8: 17 to 45 values - a
+	 *                     HiSeq-style 40-value alphabet -: k = 2, qual_bits = 11, i.e. 5.5 bits a quality instead of 8): the stream is
 	 *                     ceil(n / k) groups of qual_bits bits, group g at stream bits [g * qual_bits, +qual_bits), holding qualities
 	 *                     g k .. g k + k - 1 as the number i_0 + R i_1 + R^2 i_2 (i_j = index into qual_alphabet; places behind the stream's end: 0),
 	 *                     R = the number of qual_alphabet entries in use (they are characters, so non-zero)

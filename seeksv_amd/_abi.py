@@ -114,7 +114,7 @@ class OrcClusterTable(C.Structure):
 
 class HipClusterTable(C.Structure):
     """ssv_cluster_table as libseeksv_hip.so hands it out: the common part + the sequence format flag"""
-    _fields_ = ClusterTable._fields_ + [("seq_packed", C.c_int32), ("qual_bits", C.c_int32), ("qual_alphabet", C.c_uint8 * 16),
+    _fields_ = ClusterTable._fields_ + [("seq_packed", C.c_int32), ("qual_bits", C.c_int32), ("qual_alphabet", C.c_uint8 * 64),
                                         ("format", C.c_int32), ("base_bits", C.c_int32), ("len_bytes", C.c_int32), ("support_bytes", C.c_int32), ("ncig_bytes", C.c_int32),
                                         ("qual_group", C.c_int32), ("c_len", C.c_void_p), ("c_support", C.c_void_p), ("c_ncig", C.c_void_p), ("c_flags", C.c_void_p),
                                         ("runs", C.c_void_p), ("n_runs", C.c_int64), ("base_exc", C.c_void_p), ("n_base_exc", C.c_int64), ("str_bytes", C.c_uint64),

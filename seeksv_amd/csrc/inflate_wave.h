@@ -28,13 +28,14 @@ constexpr int WV_SEG_BITS = 384;                        // input bits per lane a
 #define WV_TAIL_BITS WV_SEG_BITS
 #endif
 constexpr int WV_SEG_DW = WV_SEG_BITS / 32;
-constexpr int WV_WIN_DW = WAVE * WV_SEG_DW + 16;        // the window + room for the last lane's overshoot (a symbol is at most 48 bits)
+constexpr int WV_COLS = WAVE + 1;                       // the 64 lanes' segments side by side + one column for the last lane's overshoot (a symbol is at most 48 bits)
+constexpr int WV_WIN_DW = WV_COLS * WV_SEG_DW;
 constexpr int WV_LT = 10, WV_DT = 8, WV_CT = 7;         // look-up bits: literal/length, distance, code-length code
 
 struct WaveLds {
 	uint32_t win[WV_WIN_DW];
-	// look-up entries: (symbol << 4) | code length; 0: no code of <= T bits starts like this (a longer code - rare symbols: a short walk finds it - or none).
-	// Eleven bits for the literal / length code: with ten, one symbol in a hundred of a real BAM was longer, i.e. most steps of a 64-lane wavefront took the walk.
+	// look-up entries (wv_entry): the code's length in bits 0-3 and what the symbol MEANS, worked out once when the table is built instead of by every lane at
+	// every step; 0: no code of <= T bits starts like this (a longer code - rare symbols: a short walk finds it - or none).
 	uint16_t lit[1 << WV_LT];
 	uint16_t dst[1 << WV_DT];
 	uint16_t clt[1 << WV_CT];
@@ -46,9 +47,31 @@ struct WaveLds {
 	uint8_t cll[32];
 };
 
-// Where dword j of the window lies in LDS: dword k of lane i's segment at k * 64 + i.  Lane i reads dwords 16 i + k; laid out as they come that is a stride of
-// 16 dwords between neighbouring lanes - a 16-way bank conflict on every read of the input, which was most of what the LDS did all day.
-__device__ __forceinline__ uint32_t wv_at(uint32_t j) { return j < (uint32_t)(WAVE * WV_SEG_DW) ? ((j % WV_SEG_DW) * WAVE) | (j / WV_SEG_DW) : j; }
+// Where dword j of the window lies in LDS: dword k of lane i's segment at k * 65 + i (65 columns: the 65th is the room behind the last segment).  Lane i reads
+// dwords 12 i + k; laid out as they come that is a stride of 12 dwords between neighbouring lanes - a bank conflict on every read of the input.  A lane's reader
+// (WvBits) walks its column with an address and a row counter: no division per refill.
+__device__ __forceinline__ uint32_t wv_at(uint32_t j) { return (j % WV_SEG_DW) * WV_COLS + j / WV_SEG_DW; }
+
+// What a symbol of code `set` means, as a 16-bit table entry with the code's length l in bits 0-3:
+//   literal / length code: bit 4 = 0: a literal, the byte in bits 8-15.  bit 4 = 1: bits 5-7 = the length's extra bits (0..5; 6: the end-of-block code, 7: a
+//                          symbol that does not exist), bits 8-15 = the length's base - 3
+//   distance code:         bits 4-7 = the distance's extra bits (0..13; 15: a symbol that does not exist), bits 8-12 the symbol (its base is two shifts away)
+//   code-length code:      the symbol in bits 4-8
+__device__ __forceinline__ uint32_t wv_entry(int set, uint32_t s, uint32_t l)
+{
+	if (set == 0) {
+		if (s < 256u) return l | (s << 8);
+		if (s == 256u) return l | 16u | (6u << 5);
+		if (s > 285u) return l | 16u | (7u << 5);
+		uint32_t xb = 0, base;
+		if (s < 265u) base = s - 254u;
+		else if (s == 285u) base = 258u;
+		else { xb = (s - 261u) >> 2; base = ((4u + ((s - 265u) & 3u)) << xb) + 3u; }
+		return l | 16u | (xb << 5) | ((base - 3u) << 8);
+	}
+	if (set == 1) return l | ((s > 29u ? 15u : s < 4u ? 0u : (s >> 1) - 1u) << 4) | (s << 8);
+	return (s << 4) | l;
+}
 
 __device__ __forceinline__ uint32_t wv_fetch(const WaveLds &L, uint32_t w0_bits, uint32_t p) // the 32 bits from position p on
 {
@@ -61,16 +84,21 @@ __device__ __forceinline__ uint32_t wv_fetch(const WaveLds &L, uint32_t w0_bits,
 struct WvBits {
 	uint64_t bb;
 	int bc;
-	uint32_t idx, p; // next window dword; bit position of bb's bit 0
+	uint32_t a, k, p; // the next window dword's place in LDS and its row (dword of its segment); bit position of bb's bit 0
+	__device__ __forceinline__ void adv() { ++k; a += WV_COLS; if (k == (uint32_t)WV_SEG_DW) { k = 0; a -= (uint32_t)(WV_SEG_DW * WV_COLS - 1); } } // down the column, then the top of the next one
 	__device__ __forceinline__ void start(const WaveLds &L, uint32_t w0_bits, uint32_t at)
 	{
-		const uint32_t rel = at - w0_bits;
-		idx = rel >> 5; p = at;
+		const uint32_t rel = at - w0_bits, j = rel >> 5, col = j / WV_SEG_DW;
+		k = j - col * WV_SEG_DW; a = k * WV_COLS + col; p = at;
 		const uint32_t sh = rel & 31u;
-		bb = (((uint64_t)L.win[wv_at(idx + 1)] << 32) | (uint64_t)L.win[wv_at(idx)]) >> sh;
-		bc = 64 - (int)sh; idx += 2;
+		const uint32_t lo = L.win[a];
+		adv();
+		const uint32_t hi = L.win[a];
+		adv();
+		bb = (((uint64_t)hi << 32) | (uint64_t)lo) >> sh;
+		bc = 64 - (int)sh;
 	}
-	__device__ __forceinline__ void need(const WaveLds &L) { if (bc <= 32) { bb |= (uint64_t)L.win[wv_at(idx)] << bc; bc += 32; ++idx; } }
+	__device__ __forceinline__ void need(const WaveLds &L) { if (bc <= 32) { bb |= (uint64_t)L.win[a] << bc; bc += 32; adv(); } }
 	__device__ __forceinline__ uint32_t peek() const { return (uint32_t)bb; }
 	__device__ __forceinline__ void drop(int n) { bb >>= n; bc -= n; p += (uint32_t)n; }
 };
@@ -139,7 +167,7 @@ __device__ __forceinline__ int wv_build(WaveLds &L, int set, const uint8_t *lens
 			if (l <= T) {
 				const uint32_t c = (uint32_t)L.first[set][l] + (idx - (uint32_t)L.off[set][l]);
 				const uint32_t rev = __brev(c) >> (32 - l);
-				const uint16_t ent = (uint16_t)((s << 4) | l);
+				const uint16_t ent = (uint16_t)wv_entry(set, (uint32_t)s, (uint32_t)l);
 				for (uint32_t k = rev; k < (1u << T); k += 1u << l) tab[k] = ent;
 			}
 		}
@@ -158,7 +186,7 @@ __device__ __forceinline__ uint32_t wv_lookup(const WaveLds &L, int set, const u
 #pragma unroll 1
 		for (int l = T + 1; l <= 15; ++l) {
 			const uint32_t d = (rb >> (32 - l)) - (uint32_t)L.first[set][l];
-			if (d < (uint32_t)L.cnt[set][l]) { e = ((uint32_t)L.perm(set)[(uint32_t)L.off[set][l] + d] << 4) | (uint32_t)l; break; }
+			if (d < (uint32_t)L.cnt[set][l]) { e = wv_entry(set, (uint32_t)L.perm(set)[(uint32_t)L.off[set][l] + d], (uint32_t)l); break; }
 		}
 	}
 	return e;
@@ -194,27 +222,23 @@ __device__ __forceinline__ WaveSeg wv_decode(const WaveLds &L, uint32_t w0_bits,
 		const uint32_t e = wv_lookup<WV_LT>(L, 0, L.lit, B.peek());
 		if (e == 0u) { r.flag = WV_BAD; break; }
 		B.drop((int)(e & 15u));
-		const uint32_t s = e >> 4;
-		if (s < 256u) {
-			if (EMIT) out[o0 + r.bytes] = (uint8_t)s;
+		if (!(e & 16u)) { // a literal
+			if (EMIT) out[o0 + r.bytes] = (uint8_t)(e >> 8);
 			++r.bytes; ++run;
 			continue;
 		}
-		if (s == 256u) { r.flag = WV_EOB; break; }
-		if (s > 285u) { r.flag = WV_BAD; break; }
-		// length: 257..264 -> 3..10; then groups of four symbols share an extra-bit count; 285 -> 258
-		uint32_t mlen;
-		if (s < 265u) mlen = s - 254u;
-		else if (s == 285u) mlen = 258u;
-		else { const int xb = (int)((s - 261u) >> 2); mlen = ((4u + ((s - 265u) & 3u)) << xb) + 3u + (B.peek() & ((1u << xb) - 1u)); B.drop(xb); } // (>= 18 bits were left: xb <= 5)
+		const int xb = (int)((e >> 5) & 7u);
+		if (xb >= 6) { r.flag = xb == 6 ? WV_EOB : WV_BAD; break; }
+		const uint32_t mlen = (e >> 8) + 3u + (B.peek() & ((1u << xb) - 1u)); // (>= 18 bits were left: xb <= 5)
+		B.drop(xb);
 		B.need(L);
 		const uint32_t e2 = wv_lookup<WV_DT>(L, 1, L.dst, B.peek());
-		const uint32_t ds = e2 >> 4;
-		if (e2 == 0u || ds > 29u) { r.flag = WV_BAD; break; }
+		const int xd = (int)((e2 >> 4) & 15u);
+		if (e2 == 0u || xd == 15) { r.flag = WV_BAD; break; }
 		B.drop((int)(e2 & 15u));
-		uint32_t dist;
-		if (ds < 4u) dist = ds + 1u;
-		else { const int xd = (int)(ds >> 1) - 1; dist = ((2u + (ds & 1u)) << xd) + 1u + (B.peek() & ((1u << xd) - 1u)); B.drop(xd); } // (>= 18 bits were left: xd <= 13)
+		uint32_t dist = 0;
+		if (EMIT) { const uint32_t ds = e2 >> 8; dist = (ds < 4u ? ds : ((2u + (ds & 1u)) << xd)) + 1u + (B.peek() & ((1u << xd) - 1u)); } // (>= 18 bits were left: xd <= 13)
+		B.drop(xd);
 		const bool firstm = r.lead == ~0u;
 		if (firstm) r.lead = run;
 		uint32_t rr = run + (EMIT && firstm ? carry : 0u);

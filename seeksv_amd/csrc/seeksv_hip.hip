@@ -178,7 +178,7 @@ struct ssv_ctx {
 		bool in_flight = false;
 		int64_t n_clusters = 0, n_events = 0;
 		int packed = 0, qual_bits = 8, qual_group = 1, qual_radix = 0, cig_bytes = 4; // qual_group > 1 (format 3): qual_bits per group of that many qualities, radix = the alphabet's size
-		uint8_t qual_alphabet[16] = {0};
+		uint8_t qual_alphabet[64] = {0};
 	} tab[2];
 	HostPool pool;
 	int tab_cur = 0;           // set of the most recent ssv_clip_cluster[_async]
@@ -1022,14 +1022,16 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			int n_vals = 0;
 			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) ++n_vals;
 			T.qual_group = 1; T.qual_radix = n_vals;
-			if (n_vals > 16) { T.qual_bits = 8; return; }
+			const char *ge = getenv("SSV_QUAL_GROUPS");
+			const bool groups = !ge || atoi(ge) != 0;
+			if (n_vals > 45 || (n_vals > 16 && !(fmt3 && groups))) { T.qual_bits = 8; return; } // (bytes: no index table)
 			T.qual_bits = n_vals <= 2 ? 1 : n_vals <= 4 ? 2 : n_vals <= 8 ? 3 : 4;
 			// format 3: alphabets whose size is far from a power of two go in groups - five values: three qualities as one number below 5^3 in 7 bits (2.33
 			// bits a quality instead of 3), nine to eleven values: two in 7 bits (3.5 instead of 4); table3_kernels.h.  SSV_QUAL_GROUPS=0: one quality, one field.
-			const char *ge = getenv("SSV_QUAL_GROUPS");
-			const bool groups = !ge || atoi(ge) != 0;
 			if (fmt3 && groups && n_vals == 5) { T.qual_bits = 7; T.qual_group = 3; }
 			if (fmt3 && groups && n_vals >= 9 && n_vals <= 11) { T.qual_bits = 7; T.qual_group = 2; }
+			// 17 to 45 values (a HiSeq-style 40-value alphabet): two to a group of 11 bits (45 x 45 = 2025 <= 2048) - 5.5 bits a quality instead of a byte
+			if (fmt3 && groups && n_vals >= 17 && n_vals <= 45) { T.qual_bits = 11; T.qual_group = 2; }
 			int k = 0;
 			for (int v = 0; v < 256; ++v) if ((seen[v >> 5] >> (v & 31)) & 1u) { T.qual_alphabet[k] = (uint8_t)(v + 33); lut[v] = (uint8_t)k; ++k; } // increasing order; the table shows characters (phred + 33)
 		};
@@ -1062,7 +1064,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			pa.tid = P<int32_t>(T.o_tid); pa.pos = P<int32_t>(T.o_pos); pa.side = P<uint8_t>(T.o_side); pa.support = P<int32_t>(T.o_support); pa.ll = P<int32_t>(T.o_ll);
 			pa.lr = P<int32_t>(T.o_lr); pa.qmiss = P<uint8_t>(T.o_qmiss); pa.ncig = P<int32_t>(T.o_ncig); pa.str_off = P<uint64_t>(T.o_stroff); pa.cig_off = P<uint64_t>(T.o_cigoff);
 			pa.packed = T.packed; pa.qual_bits = T.qual_bits; pa.qual_group = T.qual_group; pa.qual_radix = T.qual_radix;
-			pa.qual_fill = T.qual_bits < 8 && T.qual_alphabet[0] ? (uint32_t)(T.qual_alphabet[0] - 33) * 0x01010101u : 0u; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
+			pa.qual_fill = T.qual_bits != 8 && T.qual_alphabet[0] ? (uint32_t)(T.qual_alphabet[0] - 33) * 0x01010101u : 0u; pa.qlut = P<uint8_t>(c->qual_lut); pa.qual_seen = P<uint32_t>(c->qual_seen);
 			pa.lut_miss = reinterpret_cast<int *>(tot + 3);
 			pa.slow_list = P<uint32_t>(c->o_slowlist); pa.slow_count = reinterpret_cast<unsigned int *>(tot + 2);
 			pa.format3 = fmt3 ? 1 : 0; pa.base_bits = T.base_bits;
@@ -1077,10 +1079,10 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			}
 			HIPCHECK(c, hipMemsetAsync(tot, 0, 64, c->st));
 			if (track) HIPCHECK(c, hipMemsetAsync(c->qual_seen.p, 0, 32, c->st));
-			if (T.packed && T.qual_bits < 8) HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, c->h_qual_lut.p, 256, hipMemcpyHostToDevice, c->st));
+			if (T.packed && T.qual_bits != 8) HIPCHECK(c, hipMemcpyAsync(c->qual_lut.p, c->h_qual_lut.p, 256, hipMemcpyHostToDevice, c->st));
 			// format 3, the kernel without the LDS stage: two qualities per table look-up - for alphabets below phred 64 (every sequencer's)
 			bool direct = fmt3 && !track;
-			if (direct && T.qual_bits < 8) {
+			if (direct && T.qual_bits != 8) {
 				const uint8_t *lut = P<uint8_t>(c->h_qual_lut);
 				for (int v = 64; v < 256; ++v) if (lut[v] != 0xff) direct = false;
 				if (direct) {
@@ -1088,7 +1090,8 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 					for (int q1 = 0; q1 < 64; ++q1)
 						for (int q0 = 0; q0 < 64; ++q0) {
 							const bool out = lut[q0] == 0xff || lut[q1] == 0xff;
-							if (T.qual_group > 1) pl[q0 | (q1 << 6)] = out ? (uint16_t)0x8000 : (uint16_t)(lut[q0] | (lut[q1] << 4) | ((lut[q0] + T.qual_radix * lut[q1]) << 8)); // qual_dword3g
+							if (T.qual_group == 2) pl[q0 | (q1 << 6)] = out ? (uint16_t)0x8000 : (uint16_t)(lut[q0] + T.qual_radix * lut[q1]); // qual_dword3g: a pair IS a group
+							else if (T.qual_group > 1) pl[q0 | (q1 << 6)] = out ? (uint16_t)0x8000 : (uint16_t)(lut[q0] | (lut[q1] << 4) | ((lut[q0] + T.qual_radix * lut[q1]) << 8));
 							else pl[q0 | (q1 << 6)] = out ? (uint16_t)0x8000 : (uint16_t)(lut[q0] | (lut[q1] << T.qual_bits));
 						}
 					HIPCHECK(c, hipMemcpyAsync(c->pair_lut.p, c->h_pair_lut.p, 8192, hipMemcpyHostToDevice, c->st));
@@ -1120,7 +1123,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 #define SSV_P3B(W_, B_, T_) do { if (direct) SSV_P3D(W_, B_, 1); else k_pack3_stream<W_, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<W_, B_, T_><<<gs3, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 				// grouped qualities: the direct kernel knows the two shapes, the staged and the bytewise kernels take the shape at run time (W = 0)
-#define SSV_P3G(B_, T_) do { if (direct) { if (pa.qual_group == 3) SSV_P3D(7, B_, 3); else SSV_P3D(7, B_, 2); } \
+#define SSV_P3G(B_, T_) do { if (direct) { if (pa.qual_group == 3) SSV_P3D(7, B_, 3); else if (pa.qual_bits == 11) SSV_P3D(11, B_, 2); else SSV_P3D(7, B_, 2); } \
 			else k_pack3_stream<0, B_, T_><<<g, BLOCK, 0, c->st>>>(pa, p3, dsc, nc_dev, os); \
 			k_pack3_slow<0, B_, T_><<<gs3, BLOCK, 0, c->st>>>(pa, p3, os); } while (0)
 #define SSV_P3GT(T_) do { if (T.base_bits == 2) SSV_P3G(2, T_); else SSV_P3G(4, T_); } while (0)
@@ -1153,7 +1156,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 				track = false;
 				continue;
 			}
-			if (fmt3 && T.qual_bits < 8 && (int)P<uint64_t>(c->h_totals)[3] != 0) {
+			if (fmt3 && T.qual_bits != 8 && (int)P<uint64_t>(c->h_totals)[3] != 0) {
 				// the table's strings hold a quality value that the first events did not show: find out which values there are
 				if (attempt > 8) { c->err = "quality alphabet did not settle"; return SSV_E_HIP; }
 				track = true;
@@ -1242,7 +1245,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 		HIPCHECK(c, hipEventSynchronize(T.copied));
 		T.in_flight = false;
 	}
-	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; out->qual_group = T.qual_group; memcpy(out->qual_alphabet, T.qual_alphabet, 16);
+	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; out->qual_group = T.qual_group; memcpy(out->qual_alphabet, T.qual_alphabet, sizeof(out->qual_alphabet));
 	out->format = T.format; out->base_bits = T.base_bits;
 	if (T.n_clusters == 0) return SSV_OK;
 	if (T.format == 3) {

@@ -31,7 +31,7 @@ typedef struct {
 	int32_t improper_permille;    // 20: background pairs that are not concordant
 	int32_t vaf_permille;         // 500
 	int32_t n_breakends;
-	int32_t pad;
+	int32_t qual_model;           // 0: five binned values {2, 11, 25, 37, 40} (NovaSeq-like); 1: forty values 2..41, skewed to the high end (HiSeq-like)
 } sy_config;
 
 // one side of a planted junction, sorted by lin
@@ -217,7 +217,8 @@ SY_HD void sy_fill_seq(const sy_config *c, const sy_breakend *be, int64_t g, con
 		if ((uint32_t)(hb % 1000u) < 2u) b = ((b << 1) | (b >> 3)) & 15u; // 0.2 % substitutions
 		if (i & 1) dst[i >> 1] = (uint8_t)(dst[i >> 1] | b); else dst[i >> 1] = (uint8_t)(b << 4);
 		const uint32_t uq = (uint32_t)((hb >> 12) % 100u);
-		q[i] = uq < 2 ? 2 : uq < 7 ? 11 : uq < 20 ? 25 : uq < 60 ? 37 : 40;
+		if (c->qual_model == 1) { const uint32_t v = (uint32_t)((hb >> 12) & 1023u); q[i] = (uint8_t)(41u - ((((v * v) >> 10) * 40u) >> 10)); } // 41 .. 2, a sixth of them 41
+		else q[i] = uq < 2 ? 2 : uq < 7 ? 11 : uq < 20 ? 25 : uq < 60 ? 37 : 40;
 	}
 }
 

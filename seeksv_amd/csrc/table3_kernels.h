@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t qual_group_code(const uint8_t *s_lut, int K,
 		const uint32_t v = ph(i0 + j), idx = s_lut[v];
 		seen(v);
 		miss |= idx;
-		code += (idx & 15u) * mul;
+		code += (idx & 0x7fu) * mul;
 		mul *= R;
 	}
 	return code;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_stream(PackArgs p, Pack3Args q,
 // pair table entry e = q0 | q1 << 6: index(q0) | index(q1) << W, or 0x8000
 __device__ __forceinline__ uint32_t pair_index(uint32_t halfword) { return (halfword & 0x3fu) | ((halfword >> 2) & 0xfc0u); }
 
-// W bits per quality (K == 1) or per group of K qualities (K > 1: W = 7)
+// W bits per quality (K == 1) or per group of K qualities (K > 1: W = 7, or 11 for two of 17 to 45 values)
 template <int W, int K = 1> struct Q3 {
 	static constexpr int CNTG = 32 % W == 0 ? 32 / W : (32 + 2 * (W - 1)) / W;     // groups that can touch one dword (a group may start up to W - 1 bits in front of it)
 	static constexpr int CNT = K > 1 ? K * CNTG : W == 8 ? 4 : (W == 3 ? 12 : 32 / W); // qualities that can touch one dword
@@ -465,7 +465,7 @@ __device__ __forceinline__ uint32_t qual_dword3g(const Pack3Args &q, const uint1
 		bad |= e[2 * g] & 0x8000u;
 		if (2 * g + 1 < NP) { e[2 * g + 1] = s_pair[pair_index(x >> 16)]; bad |= e[2 * g + 1] & 0x8000u; }
 	}
-	auto sum = [](uint32_t v) { return (v >> 8) & 0x7fu; };
+	auto sum = [](uint32_t v) { return K == 2 ? v & 0x7fffu : (v >> 8) & 0x7fu; }; // (two to a group: the entry IS the group's number; three: index | index << 4 | pair's sum << 8)
 	auto lo = [](uint32_t v) { return v & 15u; };
 	auto hi = [](uint32_t v) { return (v >> 4) & 15u; };
 	uint64_t acc = 0;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 {
 	__shared__ uint16_t s_pair[4096];
 	__shared__ uint8_t s_base[256];
-	if (W < 8) {
+	if (W != 8) {
 		const uint4 *g = reinterpret_cast<const uint4 *>(pair_lut);
 		uint4 *l = reinterpret_cast<uint4 *>(s_pair);
 		l[threadIdx.x] = g[threadIdx.x]; l[threadIdx.x + BLOCK] = g[threadIdx.x + BLOCK]; // 8 KB = 512 x 16 B, BLOCK == 256
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 		for (int t = gl + LPC; t < nDq; t += LPC) { uint32_t raw[Q3<W, K>::NSRC + 1]; src3_load_quals<W, BB, K>(d0, t, raw); d[nDb + t] = qual_dword(d0, c, t, raw); }
 		d0 = d1; d1 = d2; S0 = S1;
 	}
-	if (W < 8 && miss) *p.lut_miss = 1;
+	if (W != 8 && miss) *p.lut_miss = 1;
 }
 
 // The base-by-base path: the slots of multi-event bins (mlist; those without a cluster leave at once: consensus storage, left part kept
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_slow(PackArgs p, Pack3Args q, u
 					if (TRACK) { const uint32_t bit = 1u << (ph[jq] & 31); if (!(atomicOr(&s_seen[ph[jq] >> 5], bit) & bit)) atomicOr(&p.qual_seen[ph[jq] >> 5], bit); }
 					const uint32_t idx = s_lut[ph[jq]];
 					miss |= idx;
-					acc += (uint64_t)((idx & 15u) * (j == 0 ? 1u : j == 1 ? R : R * R)) << (B * g);
+					acc += (uint64_t)((idx & 0x7fu) * (j == 0 ? 1u : j == 1 ? R : R * R)) << (B * g);
 				}
 				if (miss & 0x80u) *p.lut_miss = 1;
 				word = (uint32_t)(acc >> off);

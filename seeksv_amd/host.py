@@ -341,7 +341,7 @@ def cluster_strings(d, k):
 
         def field(buf, i, width):  # stream bits [i * width, +width); bit b = bit b % 8 of byte b / 8
             b = (i * width) >> 3
-            word = int(buf[b]) | ((int(buf[b + 1]) << 8) if b + 1 < len(buf) else 0)
+            word = int(buf[b]) | ((int(buf[b + 1]) << 8) if b + 1 < len(buf) else 0) | ((int(buf[b + 2]) << 16) if b + 2 < len(buf) else 0)  # (11 bits can lie in three bytes)
             return (word >> ((i * width) & 7)) & ((1 << width) - 1)
         bs, qs = s[o:o + nb], s[o + nb:o + nb + nq]
         seq = ["ACGT"[field(bs, i, 2)] if bb == 2 else NT16[field(bs, i, 4)] for i in range(n)]

@@ -12,6 +12,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -662,7 +663,7 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 		row.reserve(row.size() + (size_t)(k1 - k0) * 480); fq.reserve(fq.size() + (size_t)(k1 - k0) * 200);
 		char num[16];
 		string seqbuf;
-		char group_lut[256][3];                       // grouped qualities: a group's number -> its (up to three) quality characters
+		std::vector<std::array<char, 3>> group_lut;   // grouped qualities: a group's number -> its (up to three) quality characters
 		const ssv_cluster_table *group_lut_for = nullptr;
 		for (int64_t k = k0; k < k1; ++k) {
 			const char *name = ssvh_bam_target_name(bam, t.tid[k]);
@@ -684,8 +685,9 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 				else if (QG > 1) { // groups of QG qualities: one number of W bits, its digits (radix = the alphabet's size) are the alphabet indices
 					if (!group_lut_for || group_lut_for != &t) {
 						unsigned radix = 0;
-						while (radix < 16 && t.qual_alphabet[radix]) ++radix;
-						for (unsigned code = 0; code < (1u << W) && code < 256; ++code) { unsigned v = code; for (size_t j = 0; j < 3; ++j) { group_lut[code][j] = (char)t.qual_alphabet[radix ? v % radix : 0]; if (radix) v /= radix; } }
+						while (radix < sizeof(t.qual_alphabet) && t.qual_alphabet[radix]) ++radix;
+						group_lut.resize((size_t)1 << W);
+						for (unsigned code = 0; code < (1u << W); ++code) { unsigned v = code; for (size_t j = 0; j < 3; ++j) { group_lut[code][j] = (char)t.qual_alphabet[radix ? v % radix : 0]; if (radix) v /= radix; } }
 						group_lut_for = &t;
 					}
 					char *dq = &seqbuf[n];
@@ -693,7 +695,7 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 					const size_t ng = (n + QG - 1) / QG, qbytes = 4 * ((ng * W + 31) / 32);
 					for (size_t g = 0; g < ng; ++g) {
 						const size_t b = (g * W) >> 3;
-						const unsigned code = ((qs[b] | (b + 1 < qbytes ? (unsigned)qs[b + 1] << 8 : 0u)) >> ((g * W) & 7)) & mask;
+						const unsigned code = ((qs[b] | (b + 1 < qbytes ? (unsigned)qs[b + 1] << 8 : 0u) | (b + 2 < qbytes ? (unsigned)qs[b + 2] << 16 : 0u)) >> ((g * W) & 7)) & mask; // (a group of 11 bits can lie in three bytes)
 						for (size_t j = 0; j < QG && g * QG + j < n; ++j) dq[g * QG + j] = group_lut[code][j];
 					}
 					ql = dq; qr = dq + ll;
@@ -703,22 +705,6 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 					const size_t qbytes = 4 * ((n * W + 31) / 32);
 					for (size_t i = 0; i < n; ++i) { const size_t b = (i * W) >> 3; dq[i] = (char)t.qual_alphabet[((qs[b] | (b + 1 < qbytes ? (unsigned)qs[b + 1] << 8 : 0u)) >> ((i * W) & 7)) & mask]; }
 					ql = dq; qr = dq + ll;
-				}
-			} else if (t.seq_packed) { // [codes of seq_left | qual_left | codes of seq_right | qual_right], qualities possibly as alphabet indices
-				const size_t W = (size_t)t.qual_bits, a = (ll + 1) / 2, c2 = (lr + 1) / 2, qa = (ll * W + 7) / 8;
-				seqbuf.resize(2 * (ll + lr));
-				for (size_t i = 0; i < ll; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(s[i >> 1] >> ((~i & 1) << 2)) & 15];
-				for (size_t i = 0; i < lr; ++i) seqbuf[ll + i] = "=ACMGRSVTWYHKDBN"[(s[a + qa + (i >> 1)] >> ((~i & 1) << 2)) & 15];
-				sl = seqbuf.data(); sr = seqbuf.data() + ll;
-				if (W == 8) { ql = (const char *)s + a; qr = (const char *)s + a + qa + c2; }
-				else {
-					const uint8_t *pl = s + a, *pr = s + a + qa + c2;
-					const unsigned mask = (1u << W) - 1u;
-					char *dl = &seqbuf[ll + lr], *dr = dl + ll;
-					// stream bit i * W; a 3-bit index can straddle two bytes (the byte after a piece is the next piece or the block's padding)
-					for (size_t i = 0; i < ll; ++i) { const size_t b = (i * W) >> 3; dl[i] = (char)t.qual_alphabet[((pl[b] | (unsigned)pl[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
-					for (size_t i = 0; i < lr; ++i) { const size_t b = (i * W) >> 3; dr[i] = (char)t.qual_alphabet[((pr[b] | (unsigned)pr[b + 1] << 8) >> ((i * W) & 7)) & mask]; }
-					ql = dl; qr = dr;
 				}
 			} else { sl = (const char *)s; ql = sl + ll; sr = sl + 2 * ll; qr = sl + 2 * ll + lr; }
 			size_t lql = ll, lqr = lr;

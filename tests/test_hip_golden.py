@@ -143,13 +143,15 @@ def test_compact_table_bases(ctx, source, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("n_values,bits,group,first", [(1, 1, 1, 3), (2, 1, 1, 3), (4, 2, 1, 3), (5, 7, 3, 3), (5, 7, 3, 47), (5, 3, 1, 3), (8, 3, 1, 3), (9, 7, 2, 3), (11, 7, 2, 3), (10, 7, 2, 40),
-                                                      (11, 4, 1, 3), (12, 4, 1, 3), (16, 4, 1, 3), (17, 8, 1, 3)])
+                                                      (11, 4, 1, 3), (12, 4, 1, 3), (16, 4, 1, 3), (17, 8, 1, 3), (17, 11, 2, 3), (17, 11, 2, -2), (40, 11, 2, 3), (40, 11, 2, -2), (41, 11, 2, -20),
+                                                      (45, 11, 2, -2), (45, 11, 2, 3), (46, 8, 1, 3)])
 @pytest.mark.parametrize("source", ["stress1", "filters", "synth150", "synth300", "synth400"])
 def test_compact_table_quality_alphabets(ctx, monkeypatch, source, n_values, bits, group, first):
-    """format 3 with every quality index width - and the grouped forms (five values: three qualities to 7 bits; nine to eleven: two to 7 bits; with
-    SSV_QUAL_GROUPS=0 one field per quality as before; an alphabet that reaches phred 64 takes the LDS-staged kernel) -, on deep bins (consensus
-    storage), odd clip offsets, reads longer than the kernel's LDS-staged limit, missing qualities"""
-    if group == 1 and n_values in (5, 9, 10, 11):
+    """format 3 with every quality index width - and the grouped forms (five values: three qualities to 7 bits; nine to eleven: two to 7 bits; 17 to 45 - a
+    HiSeq-style 40-value alphabet -: two to 11 bits; with SSV_QUAL_GROUPS=0 one field per quality as before; an alphabet that reaches phred 64 takes the
+    LDS-staged kernel, first < 0: consecutive values from -first on, all below 64: the direct kernel) -, on deep bins (consensus storage), odd clip offsets,
+    reads longer than the kernel's LDS-staged limit, missing qualities"""
+    if group == 1 and n_values in (5, 9, 10, 11, 17):
         monkeypatch.setenv("SSV_QUAL_GROUPS", "0")
     if source.startswith("synth"):
         from seeksv_amd import synth
@@ -157,7 +159,7 @@ def test_compact_table_quality_alphabets(ctx, monkeypatch, source, n_values, bit
         batches = [w.generate_host(0, w.n_total)]
     else:
         batches = host.read_bam(os.path.join(G.GOLDEN, "getclip", source + ".bam"))[2]
-    alphabet = [(first + 5 * k) % 94 for k in range(n_values)]
+    alphabet = [(first + 5 * k) % 94 for k in range(n_values)] if first >= 0 else [-first + k for k in range(n_values)]
     batches = [_remap_qualities(b, alphabet) for b in batches]
     ref = ctx.getclip(batches)
     ctx.clip_table_format(3)
