@@ -449,6 +449,10 @@ int ssv_bamdec_limit(ssv_ctx *ctx, uint64_t inflated_bytes);
  * first decode, however small its chunk (a driver starts a file with a small chunk so that the GPU gets to work early; growing ~40 buffers when the
  * first full-size chunk arrives cost 0.2 s). */
 int ssv_bamdec_expect(ssv_ctx *ctx, uint64_t inflated_bytes);
+/* Optional, after ssv_bamdec_begin: on != 0 makes every decode check each inflated block's CRC32 against the one in the block's BGZF trailer (one
+ * more pass over bytes that are in HBM anyway) and refuse the chunk on a mismatch.  Off by default, like libbam 0.1.16's reader (sam/sam.h:73), which
+ * checks no CRC: a block whose deflate structure is valid but whose bytes were damaged decodes silently there - and here, without this. */
+int ssv_bamdec_verify_crc(ssv_ctx *ctx, int on);
 /* ... and that starts inside the file: the contig of the last mapped-pair record before it (0 at the start of the file, clip_reads.h:407) -
  * ssv_bamdec_info's contig-change list continues from there.  After ssv_bamdec_begin, before the first decode. */
 int ssv_bamdec_prev_tid(ssv_ctx *ctx, int32_t tid);

@@ -329,6 +329,7 @@ def hip_lib():
         lib.ssv_bamdec_prefetch.argtypes = [V, V, C.c_size_t]
         lib.ssv_bamdec_prefetch_drop.argtypes = [V]
         lib.ssv_bamdec_expect.argtypes = [V, C.c_uint64]
+        lib.ssv_bamdec_verify_crc.argtypes = [V, C.c_int]
         lib.ssv_host_register.argtypes = [V, C.c_size_t]
         lib.ssv_host_unregister.argtypes = [V]
         lib.ssv_bamdec_target_lens.argtypes = [V, C.POINTER(C.c_int32)]

@@ -160,6 +160,63 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve_win(const uint32_t *__re
 	wave_resolve_tokens_win<DBG>(out + u_off[b], blocks[b].u_len, tokens + tok_off[b], n, s_win[wave_id()], lane_id(), dbg);
 }
 
+// ---- optional: every inflated block's CRC32 against the one in its BGZF trailer (ssv_bamdec_verify_crc; libbam 0.1.16 checks none) ----------
+//
+// A wavefront per block: lane i takes the CRC32 of its slice of the block's bytes (one table look-up per byte, a dword per load), and the slices' values
+// meet the way zlib's crc32_combine joins two: crc(A | B) = crc(A) x^(8 |B|) + crc(B) in GF(2)[x] mod the CRC's polynomial - every lane multiplies its
+// value by x^(8 x the bytes behind its slice) (square-and-multiply over a table of x^(2^k)) and the products are XORed over the wavefront.
+constexpr int INF_E_CRC = -9; // (beside inflate_core.h's codes: the block's structure was fine, its bytes are not what the writer checksummed)
+struct CrcTab { uint32_t byte[256]; uint32_t x2n[32]; }; // the reflected CRC-32's byte table; x^(2^k) mod P (built on the host, bamdec_api.inc)
+
+__device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) // a(x) b(x) mod P, reflected (zlib's multmodp)
+{
+	uint32_t m = 1u << 31, p = 0;
+	for (;;) {
+		if (a & m) { p ^= b; if ((a & (m - 1u)) == 0) break; }
+		m >>= 1;
+		b = (b & 1u) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+	}
+	return p;
+}
+
+__global__ __launch_bounds__(WAVE) void k_bgzf_crc(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
+                                                   const uint8_t *__restrict__ stream, const CrcTab *__restrict__ tab, int *__restrict__ status)
+{
+	__shared__ uint32_t s_t[256];
+	__shared__ uint32_t s_x[32];
+	const int lane = (int)threadIdx.x;
+	for (int i = lane; i < 256; i += WAVE) s_t[i] = tab->byte[i];
+	if (lane < 32) s_x[lane] = tab->x2n[lane];
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	const int64_t b = blockIdx.x;
+	if (b >= n_blocks) return;
+	const BgzfBlock blk = blocks[b];
+	const uint32_t len = blk.u_len;
+	const uint8_t *p = stream + u_off[b];
+	const uint32_t S = (((len + WAVE - 1) / WAVE) + 15u) & ~15u; // bytes per lane
+	const uint32_t lo = min((uint32_t)lane * S, len), hi = min(lo + S, len);
+	uint32_t c = 0xffffffffu;
+	uint32_t i = lo;
+	for (; i + 4 <= hi; i += 4) {
+		uint32_t v = ld32(p + i);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { c = s_t[(c ^ v) & 0xffu] ^ (c >> 8); v >>= 8; }
+	}
+	for (; i < hi; ++i) c = s_t[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+	c = hi > lo ? ~c : 0u; // (the CRC-32 of nothing is 0)
+	// x^(8 n) for the n bytes behind the slice: zlib's x2nmodp(n, 3)
+	uint32_t n = len - hi, k = 3, f = 1u << 31;
+	while (n) { if (n & 1u) f = crc_multmodp(s_x[k & 31u], f); n >>= 1; ++k; }
+	uint32_t term = hi < len ? crc_multmodp(f, c) : c;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) term ^= (uint32_t)__shfl_xor((int)term, d, WAVE);
+	if (lane == 0) {
+		const uint8_t *t = comp + blk.c_off + blk.c_len; // the trailer: CRC32, ISIZE
+		const uint32_t stored = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+		if (term != stored && status[b] == 0) status[b] = INF_E_CRC;
+	}
+}
+
 // ---- record boundaries ----------------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }

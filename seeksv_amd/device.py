@@ -71,7 +71,7 @@ class Context:
         arr = (C.c_int32 * max(1, len(lens)))(*[int(x) for x in lens])
         self._check(self._lib.ssv_bamdec_target_lens(self._h, arr), "ssv_bamdec_target_lens")
 
-    def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False, chunk_inflated=1 << 31, prefetch=True):
+    def bam_batches(self, reader, chunk_bytes=64 << 20, max_blocks=1 << 16, keep_all_seq=False, chunk_inflated=1 << 31, prefetch=True, verify_crc=False):
         """Generator over SSV_MEM_DEVICE batches of a whole BAM file (host.BamReader), decoded on the GPU: yields (Batch, info dict).
         The batch is valid until the next iteration.  prefetch: chunk k+1 is read into the second staging buffer and announced
         (ssv_bamdec_prefetch) before chunk k is decoded, so its bytes cross PCIe while chunk k's kernels run."""
@@ -81,6 +81,8 @@ class Context:
             raise IOError(hl.ssvh_last_error().decode())
         self._check(self._lib.ssv_bamdec_begin(self._h, len(reader.target_names), first.value), "ssv_bamdec_begin")
         self.bamdec_target_lens(reader.target_lens)
+        if verify_crc:   # every inflated block against the CRC32 in its BGZF trailer (off by default, like libbam 0.1.16)
+            self._check(self._lib.ssv_bamdec_verify_crc(self._h, 1), "ssv_bamdec_verify_crc")
         stages, blocks = [None, None], [None, None]
 
         def read(k):

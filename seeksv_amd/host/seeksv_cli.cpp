@@ -85,6 +85,7 @@ struct PhaseTimer {
 // hipFree / hipHostFree at a time takes 0.3-0.4 s; the process is about to end and the driver reclaims all of it at once, so the context is
 // only drained (SSV_CLEAN_EXIT=1 - sanitizer and leak-check runs - destroys it the long way, and main() returns instead of _exit).
 static const bool kCleanExit = getenv("SSV_CLEAN_EXIT") != nullptr;
+static bool g_verify_crc = false; // -C: the device decoder checks the CRC32 of every BGZF block it inflates
 static void release_ctx(ssv_ctx *ctx);
 
 [[noreturn]] static void usage_top()
@@ -110,7 +111,8 @@ static void release_ctx(ssv_ctx *ctx);
 	     << "         -G <int>[,<int>...]   GPU ordinal(s) [0; with -N: all GPUs of the machine in order]\n"
 	     << "         -N <int>              cut the BAM into N runs of records, one per GPU (ranks share GPUs when there are fewer) [1]\n"
 	     << "         -H <int>              with -N: halo in bp before a run's first record (>= the longest reference span of a read) [65536]\n"
-	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
+	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl
+	     << "         -C                    with -Z: check every BGZF block's CRC32 on the GPU (off: like libbam 0.1.16, which checks none)" << endl;
 	exit(1);
 }
 
@@ -133,7 +135,8 @@ static void release_ctx(ssv_ctx *ctx);
 	     << "         -t <double> -Q <int> -w <int>   accepted for compatibility\n"
 	     << "         -G <int>[,<int>...]   GPU ordinal(s) [0; with -N: all GPUs of the machine in order]\n"
 	     << "         -N <int>              cut the BAM into N runs of records, one per GPU; the ranks' tallies and depths meet in one RCCL all-gather [1]\n"
-	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
+	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl
+	     << "         -C                    with -Z: check every BGZF block's CRC32 on the GPU (off: like libbam 0.1.16, which checks none)" << endl;
 	exit(1);
 }
 
@@ -146,7 +149,8 @@ static void release_ctx(ssv_ctx *ctx);
 	     << "         -m <int>              Minimum length of the clipped sequence  in normal [10]\n"
 	     << "         -n <int>              Number of read pairs used to calculate insert size [5000000]; < 100000 switches the insert-size pass off\n"
 	     << "         -G <int>              GPU ordinal [0]\n"
-	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl;
+	     << "         -Z                    inflate and decode the BAM on the GPU (compressed blocks over PCIe) instead of on the host threads" << endl
+	     << "         -C                    with -Z: check every BGZF block's CRC32 on the GPU (off: like libbam 0.1.16, which checks none)" << endl;
 	exit(1);
 }
 
@@ -452,6 +456,7 @@ struct BatchSource {
 		if (!ctx) ctx = get_ctx();
 		if (ssv_bamdec_begin(ctx, ssvh_bam_n_targets(bam), first) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		if (ssv_bamdec_target_lens(ctx, ssvh_bam_target_lens(bam)) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
+		if (g_verify_crc) ssv_bamdec_verify_crc(ctx, 1);
 		if (ranged) ssv_bamdec_prev_tid(ctx, r_prev_tid);
 		if (!file_bytes || file_bytes > first_bytes_default()) ssv_bamdec_expect(ctx, chunk_inflated);
 	}
@@ -738,7 +743,7 @@ static int cmd_getclip(int argc, char **argv)
 	string prefix = "output";
 	bool save_low_quality = false, device_inflate = device_inflate_default();
 	vector<int> devices;
-	while ((c = getopt(argc, argv, "t:q:o:sG:ZN:H:")) >= 0) {
+	while ((c = getopt(argc, argv, "t:q:o:sG:ZCN:H:")) >= 0) {
 		switch (c) {
 		case 't': threshold = atof(optarg); break;
 		case 'q': min_mapQ = atoi(optarg); break;
@@ -746,6 +751,7 @@ static int cmd_getclip(int argc, char **argv)
 		case 'o': prefix = optarg; break;
 		case 'G': devices = parse_devices(optarg); device = devices.empty() ? 0 : devices[0]; break;
 		case 'Z': device_inflate = true; break;
+		case 'C': g_verify_crc = true; break;
 		case 'N': n_ranks = atoi(optarg); break;
 		case 'H': halo_bp = atoi(optarg); break;
 		default: usage_getclip();
@@ -1117,7 +1123,7 @@ static int cmd_getsv(int argc, char **argv)
 	bool output_depth = true, device_inflate = device_inflate_default();
 	vector<int> devices;
 	PhaseTimer pt;
-	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:ZN:")) >= 0) {
+	while ((c = getopt(argc, argv, "F:B:t:l:q:Q:w:n:a:b:d:e:m:i:R:f:T:L:rDG:J:ZCN:")) >= 0) {
 		switch (c) {
 		case 'F': connect_bam = optarg; break;
 		case 'B': temp_breakpoint = optarg; break;
@@ -1135,6 +1141,7 @@ static int cmd_getsv(int argc, char **argv)
 		case 'L': flank_length = atoi(optarg); break;
 		case 'G': devices = parse_devices(optarg); device = devices.empty() ? 0 : devices[0]; break;
 		case 'Z': device_inflate = true; break;
+		case 'C': g_verify_crc = true; break;
 		case 'N': n_ranks = atoi(optarg); break;
 		case 'J': dump_junctions = optarg; break;
 		default: break; // -t -Q -w -a -R -r: accepted, unused (as in the reference, where -t / -Q no longer reach the join)
@@ -1433,7 +1440,7 @@ static int cmd_somatic(int argc, char **argv)
 	string dump_lookups;
 	bool device_inflate = device_inflate_default();
 	PhaseTimer pt;
-	while ((c = getopt(argc, argv, "t:q:l:m:n:G:J:Z")) >= 0) {
+	while ((c = getopt(argc, argv, "t:q:l:m:n:G:J:ZC")) >= 0) {
 		switch (c) {
 		case 't': min_map_rate = atof(optarg); break;
 		case 'q': min_mapQ = atoi(optarg); break;
@@ -1442,6 +1449,7 @@ static int cmd_somatic(int argc, char **argv)
 		case 'n': read_pair_used = atoi(optarg); break;
 		case 'G': device = atoi(optarg); break;
 		case 'Z': device_inflate = true; break;
+		case 'C': g_verify_crc = true; break;
 		case 'J': dump_lookups = optarg; break; // test hook: the host look-ups only (no BAM pass, no GPU), one line per output row
 		}
 	}

@@ -56,10 +56,10 @@ def _runs_reference(flag, tid):
     return runs
 
 
-def _device_all(ctx, path, chunk_bytes, max_blocks, keep_all_seq=False):
+def _device_all(ctx, path, chunk_bytes, max_blocks, keep_all_seq=False, verify_crc=False):
     out, unm, runs, base, repaired = [], [], [], 0, 0
     with host.BamReader(path) as r:
-        for b, info in ctx.bam_batches(r, chunk_bytes=chunk_bytes, max_blocks=max_blocks, keep_all_seq=keep_all_seq):
+        for b, info in ctx.bam_batches(r, chunk_bytes=chunk_bytes, max_blocks=max_blocks, keep_all_seq=keep_all_seq, verify_crc=verify_crc):
             if b.n:
                 out.append(ctx.batch_to_host(b))
             unm += info["unmapped"]
@@ -379,6 +379,63 @@ def test_device_decode_every_deflate_block_kind(ctx, tmp_path, chunk_bytes, max_
         assert np.array_equal(h[k], d[k]), k
     assert h["cigars"] == d["cigars"] and h["seqs"] == d["seqs"] and hunm == dunm
     assert len(h["tid"]) == 7000
+
+
+def test_verify_crc_refuses_what_the_structure_hides(ctx, tmp_path):
+    """ssv_bamdec_verify_crc (`-C`): damage that leaves a block's deflate structure valid - one literal turned into another of the same code length, a byte of
+    a stored block - inflates to the right number of wrong bytes.  libbam 0.1.16 hands them out and so does the device decoder by default (the damaged file
+    decodes to what the host reader, which checks no CRC either, makes of it); with the check on, the decoder refuses the chunk and names the CRC32.  The
+    undamaged file passes with the check on, under every chunking."""
+    import struct
+    import zlib
+    path = str(tmp_path / "f.bam")
+    _bam_with_block_kinds(path, _records(1500, 5) + _pattern_records(800, 9), 11)
+    raw = open(path, "rb").read()
+    want = _flatten(_host_all(path, True)[0])
+    for chunk_bytes, max_blocks in ((64 << 20, 1 << 16), (1 << 17, 1 << 16), (64 << 20, 3)):
+        got = _flatten(_device_all(ctx, path, chunk_bytes, max_blocks, True, verify_crc=True)[0])
+        for k in KEYS + ("shipped",):
+            assert np.array_equal(want[k], got[k]), k
+    blocks, at = [], 0
+    while at < len(raw):
+        bsize = struct.unpack_from("<H", raw, at + 16)[0] + 1
+        if bsize > 28:
+            blocks.append((at, bsize))
+        at += bsize
+    rng = np.random.default_rng(23)
+    silent = 0
+    for _ in range(400):
+        at, bsize = blocks[int(rng.integers(1, len(blocks)))]   # (not the block with the BAM header)
+        b = bytearray(raw)
+        i = at + 18 + int(rng.integers(0, bsize - 26))
+        b[i] ^= 1 << int(rng.integers(0, 8))
+        isize, crc = struct.unpack_from("<I", b, at + bsize - 4)[0], struct.unpack_from("<I", b, at + bsize - 8)[0]
+        try:
+            z = zlib.decompressobj(-15)
+            data = z.decompress(bytes(b[at + 18:at + bsize - 8]))
+            if not (len(data) == isize and z.eof and zlib.crc32(data) != crc):
+                continue
+        except zlib.error:
+            continue
+        bad = str(tmp_path / "bad.bam")
+        open(bad, "wb").write(bytes(b))
+        try:
+            hb = _flatten(_host_all(bad, True)[0])
+        except Exception:
+            continue   # (the wrong bytes fell into a record's header: both readers refuse the record, CRC or not)
+        db = _flatten(_device_all(ctx, bad, 1 << 19, 9, True)[0])   # silently: the same wrong bytes as the host reader's
+        for k in KEYS + ("shipped",):
+            assert np.array_equal(hb[k], db[k]), k
+        assert hb["seqs"] == db["seqs"]
+        with pytest.raises(device.SeeksvError, match="CRC32"):
+            _device_all(ctx, bad, 1 << 19, 9, True, verify_crc=True)
+        silent += 1
+        if silent >= 12:
+            break
+    assert silent >= 6, "too few structure-valid damages found"
+    got = _flatten(_device_all(ctx, path, 1 << 19, 9, True, verify_crc=True)[0])   # the decoder's state is intact afterwards
+    for k in KEYS + ("shipped",):
+        assert np.array_equal(want[k], got[k]), k
 
 
 def test_device_decode_fuzzed_payloads(ctx, tmp_path):

@@ -72,6 +72,45 @@ def test_cli_getclip_reader_maps_the_file(tmp_path, sub, bam, prefix, flags, inf
     assert gzip.open(out + ".clip.fq.gz", "rt").read() == G.read_text(sub, prefix + ".clip.fq.txt")
 
 
+def test_cli_getclip_verifies_block_crcs(tmp_path, inflate_mode):
+    """`-Z -C`: the GPU checks every inflated BGZF block against the CRC32 in its trailer.  A good file gives the usual outputs; a file with one quality byte
+    changed inside a block whose deflate structure stays valid is refused with a CRC32 message - and, without -C, goes through like in libbam 0.1.16."""
+    import struct
+    import zlib
+    if inflate_mode != "device-inflate":
+        pytest.skip("the check belongs to the device decoder")
+    src = os.path.join(G.GOLDEN, "example", "cancer.sort.bam")
+    out = str(tmp_path / "o")
+    r = subprocess.run([SEEKSV, "getclip", "-Z", "-C", "-o", out, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(out + ".clip.gz", "rt").read() == G.read_text("example", "cancer.clip.txt")
+    raw = bytearray(open(src, "rb").read())
+    blocks, at = [], 0
+    while at < len(raw):
+        bsize = struct.unpack_from("<H", raw, at + 16)[0] + 1
+        blocks.append((at, bsize))
+        at += bsize
+    rng = __import__("numpy").random.default_rng(3)
+    for _ in range(2000):   # a flip that zlib still inflates to the block's size: only the CRC32 knows
+        at, bsize = blocks[int(rng.integers(1, len(blocks) - 1))]
+        i = at + 18 + int(rng.integers(0, bsize - 26))
+        b = bytearray(raw)
+        b[i] ^= 1 << int(rng.integers(0, 8))
+        try:
+            z = zlib.decompressobj(-15)
+            data = z.decompress(bytes(b[at + 18:at + bsize - 8]))
+        except zlib.error:
+            continue
+        if len(data) == struct.unpack_from("<I", b, at + bsize - 4)[0] and z.eof and zlib.crc32(data) != struct.unpack_from("<I", b, at + bsize - 8)[0]:
+            break
+    else:
+        pytest.skip("no structure-preserving flip found")
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(b))
+    r = subprocess.run([SEEKSV, "getclip", "-Z", "-C", "-o", out + "2", bad], capture_output=True, text=True)
+    assert r.returncode != 0 and "CRC32" in r.stderr, r.stderr[-500:]
+
+
 GETSV = [("pairs1", "pairs1", []), ("pairs1", "pairs1.q0", ["-q", "0"]), ("pairs1", "pairs1.L50", ["-L", "50"]), ("pairs1", "pairs1.L1", ["-L", "1"]),
          ("pairs2", "pairs2", []), ("pairs3", "pairs3", []), ("eqx", "eqx", []), ("deep", "deep", [])]
 
