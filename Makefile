@@ -18,7 +18,7 @@ hip: $(LIBDIR)/libseeksv_hip.so
 synth: $(LIBDIR)/libseeksv_synth.so $(LIBDIR)/libseeksv_synth_cpu.so
 cli: seeksv_amd/bin/seeksv
 
-$(LIBDIR)/libseeksv_host.so: $(HOST_SRC) include/seeksv_host.h include/seeksv_hip.h
+$(LIBDIR)/libseeksv_host.so: $(HOST_SRC) $(wildcard seeksv_amd/host/*.h) include/seeksv_host.h include/seeksv_hip.h
 	mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz -lpthread
 

@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--file-frac", type=float, default=-1.0, help="(default: --genome-frac, i.e. the bench workload itself = BASELINE config 2, 617 M records / 44 GB, where >= 192 host cores write the file in about a minute; a quarter of it from 64 cores; else 1/16 or 1/64) genome fraction of the BAM FILE leg (file_path in the bench line: compressed bytes in pinned host memory -> device "
                     "inflate + decode -> scans -> tables on the host); 0 = skip")
-    ap.add_argument("--file-level", type=int, default=-1, help="deflate level of the file leg's BAM (default: 6 = samtools' default where >= 64 CPUs write the file, else 4)")
+    ap.add_argument("--file-level", default="auto", help="deflate level of the file leg's BAM: 1..9 = zlib, fast = the repository's own single-probe LZ77 + Huffman coder (huff_gz.h: deflate_fast, "
+                    "~5 x zlib level 4's speed, 93 instead of 77 B/record); auto (default): 6 = samtools' default where >= 64 CPUs write the file, fast where 16 CPUs have to write the WHOLE sample, else 4")
     ap.add_argument("--qual-alphabet", choices=("binned5", "hiseq40"), default="binned5", help="the synthetic reads' base qualities: five binned values {2, 11, 25, 37, 40} (NovaSeq-like, the default) or forty values 2..41 (HiSeq-like: the compact table's 11-bit pairs, a file that deflates less)")
     ap.add_argument("--no-config3", action="store_true", help="skip config3_path (BASELINE config 3's shape: 300x over a tenth of the genome, the same number of records, resident in HBM)")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip cli_path (the `seeksv` binary as child processes on the file leg's BAM)")
@@ -315,6 +316,9 @@ def main():
         return dict(locals())
 
     R = resident(args)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     (w, sp, n_own, hdr, ctx, strong, gen_s, state, res, dt, prof, allprof, breakdown, wall, step_walls, BREAKDOWN_STEPS) = (R[k] for k in (
         "w", "sp", "n_own", "hdr", "ctx", "strong", "gen_s", "state", "res", "dt", "prof", "allprof", "breakdown", "wall", "step_walls", "BREAKDOWN_STEPS"))
 
@@ -421,6 +425,8 @@ def main():
                     "table": dict(R3["state"].get("table_info", {}), bytes=int(R3["state"].get("table_bytes", 0)), bytes_per_cluster=round(R3["state"].get("table_bytes", 0) / max(1, R3["res"]["n_clusters"]), 1)),
                     "result": R3["res"], "generation_s": round(R3["gen_s"], 2)}
                 del R3
+                gc.collect()
+                torch.cuda.empty_cache()   # (the 49 GB sample goes back to the device: the file leg below keeps its own 49 GB of decoded records)
             except BaseException as e:  # (SystemExit too: a report beside the headline)
                 line["config3_path"] = {"error": f"{type(e).__name__}: {e}"}
         if args.file_frac < 0:
@@ -435,11 +441,16 @@ def main():
             # level 4 takes about two minutes (round 3 took an eighth: a command's 0.5 s of start-up - process, HIP runtime, first allocations - is
             # as long as its work on a 6 GB file); >= 192 CPUs write the whole sample.
             eff = effective_cpus()
-            args.file_frac = args.genome_frac * (1.0 if eff >= 192 and avail_gb >= 256 else 0.5 if eff >= 16 and avail_gb >= 160 else 0.25 if eff >= 12 and avail_gb >= 64 else 0.125 if eff >= 8 and avail_gb >= 32 else 1 / 64)
-            if args.file_level < 0:
-                args.file_level = 6 if eff >= 64 else 4
-        if args.file_level < 0:
-            args.file_level = 6
+            # Round 5: the WHOLE sample (617.65 M records) also on a 16-CPU box - written with the repository's own fast deflate coder (a 4-byte hash with one
+            # candidate, greedy, then the tokens' two Huffman codes: 93 B/record instead of level 4's 77, at ~5 x its speed), where round 4 took half the sample
+            # at level 4.  The file (~58 GB) lives in /dev/shm: 160 GB of available memory are asked for.
+            whole_fast = eff >= 16 and eff < 192 and avail_gb >= 160 and args.file_level in ("auto", "fast")
+            args.file_frac = args.genome_frac * (1.0 if (eff >= 192 and avail_gb >= 256) or whole_fast else 0.5 if eff >= 16 and avail_gb >= 160 else 0.25 if eff >= 12 and avail_gb >= 64 else 0.125 if eff >= 8 and avail_gb >= 32 else 1 / 64)
+            if args.file_level == "auto":
+                args.file_level = "6" if eff >= 64 else "fast" if whole_fast else "4"
+        if args.file_level == "auto":
+            args.file_level = "6"
+        args.file_level = -2 if args.file_level == "fast" else int(args.file_level)
         if world == 1 and args.file_frac > 0:
             try:
                 line["file_path"] = file_path_leg(ctx, args, local_rank)
@@ -524,7 +535,7 @@ def file_path_leg(ctx, args, device):
     import torch
     from seeksv_amd import _abi, host, synth
     w = synth.Workload(genome_frac=args.file_frac, depth=args.depth, n_sv=max(1, round(args.n_sv * args.file_frac / args.genome_frac)), qual_model=1 if args.qual_alphabet == "hiseq40" else 0)  # the same density of planted junctions
-    need = int(w.n_total * 100)  # the file is ~72 bytes a record
+    need = int(w.n_total * 110)  # the file is 72-93 bytes a record
     def room(path):
         try:
             st = os.statvfs(path)
@@ -712,13 +723,20 @@ def file_path_leg(ctx, args, device):
                 ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
                 ctx.clip_begin(0.9, 1, False, None, 0)
                 n = 0
+                lap = {"decode(+reader wait)": 0.0, "retain": 0.0, "clip_scan": 0.0}   # SSV_BENCH_TRACE: where pass 1's wall time goes, summed over the chunks
+                tl = time.perf_counter()
                 for b in decoded_chunks(source):
                     n += b.n
+                    tn = time.perf_counter(); lap["decode(+reader wait)"] += tn - tl; tl = tn
                     if single_decode:
                         b = ctx.batch_retain(b)
                         kept.append(b)
+                        tn = time.perf_counter(); lap["retain"] += tn - tl; tl = tn
                     ctx.clip_scan(b)
+                    tn = time.perf_counter(); lap["clip_scan"] += tn - tl; tl = tn
                 end_of_input()
+                if os.environ.get("SSV_BENCH_TRACE"):
+                    print("[bench trace] file leg pass 1 (single_decode %s, %s):" % (single_decode, type(source).__name__), {k: round(v, 3) for k, v in lap.items()}, file=sys.stderr)
                 nc, ne = ctx.clip_cluster_async()
                 tab = ctx.clip_table_wait()
                 if tab.format == 3:
@@ -790,9 +808,10 @@ def file_path_leg(ctx, args, device):
         assert best["result"] == pinned_best["result"] and two["result"] == best["result"]
         inflated = None
         kernel_ms = {k: round(v["total_ms"] / len(runs), 3) for k, v in prof.items() if v["launches"]}
+        coder = "the repository's fast deflate coder (single-probe LZ77 + Huffman, huff_gz.h)" if args.file_level == -2 else "deflate level " + str(args.file_level)
         out = {"value": w.n_total / best["total_s"], "unit": "records/s",
                "workload": f"synthetic {args.depth:g}x WGS, genome_frac {args.file_frac:g}: {w.n_total} records, every one with its bases (reference + 0.2 % substitutions) and qualities "
-                           f"(from {{2,11,25,37,40}}), as a BAM file of {bam_bytes} bytes = {bam_bytes / w.n_total:.1f} B/record (BGZF deflate level {args.file_level}, written by libseeksv_host; "
+                           f"({'forty values 2..41' if args.qual_alphabet == 'hiseq40' else 'from {2,11,25,37,40}'}), as a BAM file of {bam_bytes} bytes = {bam_bytes / w.n_total:.1f} B/record (BGZF, {coder}, written by libseeksv_host; "
                            f"{inflated_total / w.n_total:.1f} B/record inflated), read in {len(chunks)} chunks of whole BGZF blocks",
                "records": w.n_total, "bam_bytes": bam_bytes, "bam_bytes_per_record": round(bam_bytes / w.n_total, 2), "inflated_bytes_per_record": round(inflated_total / w.n_total, 2), "chunks": len(chunks),
                "includes_file_read": True,

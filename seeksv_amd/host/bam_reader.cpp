@@ -1072,11 +1072,12 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 // writes level 6, samtools' default: real BAM files are what that leg stands for)
 // -1: no zlib at all - a block's payload is one literal-only Huffman block (huff_gz.h; what `seeksv realign` writes its clip.bam with unless the
 // variable says otherwise: 5.5 M short records that are read back once, by the next command)
+// -2: the same with string matching of the cheapest kind (huff_gz.h: deflate_fast; bench.py's whole-genome file where 16 CPUs have to write it)
 static int bgzf_level()
 {
 	const char *e = getenv("SSV_BGZF_LEVEL");
 	const int l = e ? atoi(e) : 1;
-	return l < -1 ? -1 : l > 9 ? 9 : l;
+	return l < -2 ? -2 : l > 9 ? 9 : l;
 }
 
 static void bgzf_compress_blocks(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out)
@@ -1092,7 +1093,7 @@ static void bgzf_compress_blocks(const std::vector<uint8_t> &raw, std::vector<ui
 		if (level < 0) { // literals only, or - when their codes do not even pay for the code table - stored (a block must stay below 64 KB)
 			static thread_local std::vector<uint8_t> room;
 			if (room.size() < ssvh_huff::member_bound(BS)) room.resize(ssvh_huff::member_bound(BS));
-			size_t clen = (size_t)(ssvh_huff::deflate_literals(raw.data() + off, len, room.data()) - room.data());
+			size_t clen = (size_t)((level == -2 ? ssvh_huff::deflate_fast(raw.data() + off, len, room.data()) : ssvh_huff::deflate_literals(raw.data() + off, len, room.data())) - room.data());
 			if (clen > len + 5) {
 				uint8_t *p = room.data();
 				const uint16_t l16 = (uint16_t)len, n16 = (uint16_t)~l16;

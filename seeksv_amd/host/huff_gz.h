@@ -145,6 +145,114 @@ inline uint8_t *deflate_literals(const uint8_t *text, size_t n, uint8_t *o)
 	return o;
 }
 
+// The same block WITH string matching of the cheapest kind (bench.py's whole-genome file on a 16-CPU box: zlib level 4 deflates 40 MB/s per core, this
+// several hundred): a hash of the four bytes at every position, ONE candidate per hash (the last position that hashed there), greedy, matches of 4..258
+// bytes, no hash insertions inside a match; then the two Huffman codes of the tokens that came out.  Any inflater reads it (tests/test_gz_writer.py: zlib;
+// the device decoder).  n < 65536 (a BGZF block).
+inline uint8_t *deflate_fast(const uint8_t *text, size_t n, uint8_t *o)
+{
+	if (n < 32 || n >= 65536) return deflate_literals(text, n, o);
+	constexpr int HB = 13;
+	struct Tok { uint16_t a, d; };                // d == 0: the literal a; else a match of a bytes, d back
+	struct Work { uint16_t head[1 << HB]; Tok toks[65536]; }; // head: position + 1 of the last occurrence of the hash (0: none)
+	static thread_local Work *tls_work = nullptr;
+	if (!tls_work) tls_work = new Work;           // (one per thread, kept; looked up ONCE per call: in a shared library every touch of a thread_local is a call)
+	Work &W = *tls_work;
+	uint16_t *const head = W.head;
+	memset(head, 0, sizeof(W.head));
+	Tok *const toks = W.toks;
+	size_t nt = 0;
+	uint32_t lcnt[286] = {0}, dcnt[30] = {0};
+	auto len_sym = [](uint32_t l, uint32_t &xb, uint32_t &xv) -> uint32_t {
+		const uint32_t y = l - 3;
+		if (y < 8) { xb = 0; xv = 0; return 257 + y; }
+		if (l == 258) { xb = 0; xv = 0; return 285; }
+		const uint32_t hb = 31u - (uint32_t)__builtin_clz(y);
+		xb = hb - 2; xv = y & ((1u << xb) - 1u);
+		return 257 + 4 * (hb - 1) + ((y >> (hb - 2)) & 3u);
+	};
+	auto dist_sym = [](uint32_t d, uint32_t &xb, uint32_t &xv) -> uint32_t {
+		const uint32_t x = d - 1;
+		if (x < 4) { xb = 0; xv = 0; return x; }
+		const uint32_t hb = 31u - (uint32_t)__builtin_clz(x);
+		xb = hb - 1; xv = x & ((1u << xb) - 1u);
+		return 2 * hb + ((x >> (hb - 1)) & 1u);
+	};
+	size_t i = 0;
+	while (i + 4 <= n) {
+		uint32_t v;
+		memcpy(&v, text + i, 4);
+		const uint32_t h = (v * 2654435761u) >> (32 - HB);
+		const size_t cand = head[h];
+		head[h] = (uint16_t)(i + 1);
+		if (cand) {
+			const size_t c = cand - 1;
+			uint32_t w;
+			memcpy(&w, text + c, 4);
+			if (w == v && i - c <= 32768) { // (deflate's window; a BGZF block is up to 65280 bytes)
+				const size_t maxl = std::min<size_t>(258, n - i);
+				size_t len = 4;
+				while (len + 8 <= maxl) {
+					uint64_t x, y;
+					memcpy(&x, text + c + len, 8); memcpy(&y, text + i + len, 8);
+					if (x != y) { len += (size_t)(__builtin_ctzll(x ^ y) >> 3); goto matched; }
+					len += 8;
+				}
+				while (len < maxl && text[c + len] == text[i + len]) ++len;
+			matched:
+				uint32_t xb, xv;
+				toks[nt++] = Tok{(uint16_t)len, (uint16_t)(i - c)};
+				lcnt[len_sym((uint32_t)len, xb, xv)]++; dcnt[dist_sym((uint32_t)(i - c), xb, xv)]++;
+				i += len;
+				continue;
+			}
+		}
+		toks[nt++] = Tok{text[i], 0};
+		lcnt[text[i]]++;
+		++i;
+	}
+	for (; i < n; ++i) { toks[nt++] = Tok{text[i], 0}; lcnt[text[i]]++; }
+	lcnt[256] = 1;
+	uint8_t llen[286], dlen[30];
+	uint16_t lcode[286], dcode[30];
+	code_lengths(lcnt, 286, 15, llen);
+	canonical_codes(llen, 286, lcode);
+	code_lengths(dcnt, 30, 15, dlen);
+	canonical_codes(dlen, 30, dcode);
+	int hlit = 286, hdist = 30;
+	while (hlit > 257 && llen[hlit - 1] == 0) --hlit;
+	while (hdist > 1 && dlen[hdist - 1] == 0) --hdist; // (no match at all: one distance code of zero bits - "the data is all literals", RFC 1951 3.2.7)
+	uint32_t ccnt[19] = {0};
+	for (int s = 0; s < hlit; ++s) ccnt[llen[s]]++;
+	for (int s = 0; s < hdist; ++s) ccnt[dlen[s]]++;
+	uint8_t clen[19];
+	uint16_t ccode[19];
+	code_lengths(ccnt, 19, 7, clen);
+	canonical_codes(clen, 19, ccode);
+	static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+	int hclen = 19;
+	while (hclen > 4 && clen[order[hclen - 1]] == 0) --hclen;
+	BitSink bs(o);
+	bs.put(1, 1); bs.put(2, 2); // BFINAL, BTYPE = dynamic
+	bs.put((uint32_t)(hlit - 257), 5); bs.put((uint32_t)(hdist - 1), 5); bs.put((uint32_t)(hclen - 4), 4);
+	for (int k = 0; k < hclen; ++k) bs.put(clen[order[k]], 3);
+	for (int s = 0; s < hlit; ++s) bs.put(ccode[llen[s]], clen[llen[s]]);
+	for (int s = 0; s < hdist; ++s) bs.put(ccode[dlen[s]], clen[dlen[s]]);
+	for (size_t k = 0; k < nt; ++k) {
+		const Tok t = toks[k];
+		if (t.d == 0) { bs.put(lcode[t.a], llen[t.a]); continue; }
+		uint32_t xb, xv;
+		const uint32_t ls = len_sym(t.a, xb, xv);
+		bs.put(lcode[ls], llen[ls]);
+		if (xb) bs.put(xv, (int)xb);
+		const uint32_t ds = dist_sym(t.d, xb, xv);
+		bs.put(dcode[ds], dlen[ds]);
+		if (xb) bs.put(xv, (int)xb);
+	}
+	bs.put(lcode[256], llen[256]);
+	return bs.finish();
+}
+
 // one gzip member for text[0, n) into out (room for member_bound(n)); returns its size
 inline size_t member(const uint8_t *text, size_t n, uint8_t *out)
 {

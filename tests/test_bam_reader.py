@@ -237,3 +237,33 @@ def test_parallel_header_walk_equals_serial_walk(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     ser = r.stdout.split()
     assert (ser[0], int(ser[1])) == par and par[1] > 1000
+
+
+@pytest.mark.parametrize("level", ["-2", "-1"])
+def test_writer_levels_without_zlib_give_the_same_records(tmp_path, level):
+    """SSV_BGZF_LEVEL=-1 (a literal-only Huffman block per BGZF block) and -2 (the same with the cheapest string matching: huff_gz.h's deflate_fast, what
+    bench.py writes its whole-genome file with on a 16-CPU box): zlib inflates every block to the bytes of the level-1 file, CRC32 and size right, and the
+    reader gives the same batches (the level is read per call: a child process per file is not needed)"""
+    import gzip
+    import hashlib
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 8192, depth=30, n_sv=4)
+    batch = w.generate_host(0, w.n_total, all_seq=True)
+    digests = {}
+    old = os.environ.get("SSV_BGZF_LEVEL")
+    try:
+        for lv in ("1", level):
+            os.environ["SSV_BGZF_LEVEL"] = lv
+            p = str(tmp_path / f"l{lv}.bam")
+            host.write_bam(p, w.names, w.lens, [batch])
+            digests[lv] = (hashlib.sha256(gzip.open(p, "rb").read()).hexdigest(), os.path.getsize(p))   # (gzip checks every member's CRC32 and ISIZE)
+    finally:
+        if old is None:
+            os.environ.pop("SSV_BGZF_LEVEL", None)
+        else:
+            os.environ["SSV_BGZF_LEVEL"] = old
+    assert digests["1"][0] == digests[level][0]
+    if level == "-2":
+        assert digests[level][1] < 1.25 * digests["1"][1]   # string matching pays: close to zlib level 1's size
+    names, lens, got = host.read_bam(str(tmp_path / f"l{level}.bam"))
+    assert sum(len(b["tid"]) for b in got) == w.n_total
