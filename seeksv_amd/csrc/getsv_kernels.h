@@ -226,13 +226,31 @@ __device__ __forceinline__ void discordant_record(const GetsvArgs &a, const Cand
 	}
 }
 
+// one covered stretch [s, e] (1-based columns) of a read into the windows it meets: +sign where it enters a window, -sign behind where it leaves it.
+// w: the caller's window cursor (-1: not looked up yet; the first window that ends at or after the tile's first column, then walked on)
+__device__ __forceinline__ void depth_segment(const GetsvArgs &a, int tid, int s, int e, int64_t tile, int64_t &w, int sign)
+{
+	if (w < 0) w = a.tile_win[tile];
+	while (w < a.n_win && a.win_tid[w] == tid && a.win_end[w] < s) ++w;
+	for (int64_t x = w; x < a.n_win && a.win_tid[x] == tid && a.win_beg[x] <= e; ++x) {
+		int wb = a.win_beg[x], we = a.win_end[x];
+		int lo = s > wb ? s : wb, hi = e < we ? e : we;
+		int32_t *d = a.diff + a.win_off[x];
+		atomicAdd(&d[lo - wb], sign);
+		atomicAdd(&d[hi + 1 - wb], -sign);
+	}
+}
+
 // sign -1: the correction pass of the read cap takes a dropped read's coverage out again (it has applied the filter already)
+__device__ __forceinline__ bool depth_counts(const GetsvArgs &a, const CandRec &r)
+{
+	if (r.mapq < a.depth_min_mapq) return false;                              // read_bam: MAPQ < mapQ -> treated as unmapped
+	return !(r.flag & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP));            // BAM_DEF_MASK
+}
+
 __device__ __forceinline__ void depth_record(const GetsvArgs &a, const CandRec &r, int tid, int pos, int64_t tile, int sign = 1)
 {
-	if (sign > 0) {
-		if (r.mapq < a.depth_min_mapq) return;                              // read_bam: MAPQ < mapQ -> treated as unmapped
-		if (r.flag & (F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP)) return;    // BAM_DEF_MASK
-	}
+	if (sign > 0 && !depth_counts(a, r)) return;
 	const int n = r.nc;
 	int col = pos + 1; // 1-based
 	int64_t w = -1;
@@ -240,18 +258,7 @@ __device__ __forceinline__ void depth_record(const GetsvArgs &a, const CandRec &
 		const uint32_t c = cand_op(r, k);
 		int op = (int)(c & 15u), len = (int)(c >> 4);
 		if (op == C_M) { // libbam 0.1.16 pileup: only M covers, only M / D / N advance; '=' and 'X' are skipped like padding (tests/golden/getsv/eqx.*)
-			if (len > 0) {
-				int s = col, e = col + len - 1;
-				if (w < 0) w = a.tile_win[tile]; // first window ending at or after the tile's first column (<= s): the loop below walks on
-				while (w < a.n_win && a.win_tid[w] == tid && a.win_end[w] < s) ++w;
-				for (int64_t x = w; x < a.n_win && a.win_tid[x] == tid && a.win_beg[x] <= e; ++x) {
-					int wb = a.win_beg[x], we = a.win_end[x];
-					int lo = s > wb ? s : wb, hi = e < we ? e : we;
-					int32_t *d = a.diff + a.win_off[x];
-					atomicAdd(&d[lo - wb], sign);
-					atomicAdd(&d[hi + 1 - wb], -sign);
-				}
-			}
+			if (len > 0) depth_segment(a, tid, col, col + len - 1, tile, w, sign);
 			col += len;
 		} else if (op == C_D || op == C_N) col += len;
 	}
@@ -492,12 +499,16 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 // its wavefronts walk each tile's candidates together: candidates come in runs - a tile near a junction holds hundreds (30x) or all of its 4096
 // records (300x, BASELINE config 3), its neighbours none - and with a wavefront per tile the kernel lasted as long as 64 dependent rounds of
 // (record line -> look-up -> junctions / windows -> atomics) on the few wavefronts that had work (300x: 2.32 ms, 91 % of the wave cycles waiting).
+constexpr uint32_t GC_DENSE_MIN = 2048; // candidates in a workgroup's four tiles from which on the depth pass goes through LDS (k_getsv_cand_dense)
+constexpr int GC_COLS = 8192;            // columns of the genome a dense workgroup's difference array in LDS covers
+
 __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 {
 	const int64_t t0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK;
-	uint32_t n[WAVES_PER_BLOCK], so[WAVES_PER_BLOCK];
+	uint32_t n[WAVES_PER_BLOCK], so[WAVES_PER_BLOCK], total = 0;
 #pragma unroll
-	for (int w = 0; w < WAVES_PER_BLOCK; ++w) { const bool in = t0 + w < g.ntiles; n[w] = in ? g.tile_cnt[t0 + w] : 0u; so[w] = in ? g.tile_off[t0 + w] : 0u; }
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w) { const bool in = t0 + w < g.ntiles; n[w] = in ? g.tile_cnt[t0 + w] : 0u; so[w] = in ? g.tile_off[t0 + w] : 0u; total += n[w]; }
+	if (a.n_win > 0 && total >= GC_DENSE_MIN) return; // (k_getsv_cand_dense's)
 #pragma unroll
 	for (int w = 0; w < WAVES_PER_BLOCK; ++w)
 		for (uint32_t k = threadIdx.x; k < n[w]; k += BLOCK) {
@@ -509,6 +520,94 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 			if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
 			if (m & TM_DEPTH) depth_record(a, r, tid, pos, tile);
 		}
+}
+
+// The same for a workgroup whose tiles are DENSE with candidates (300x, BASELINE config 3: all 16 K records of its tiles start inside junction or depth windows): there
+// the depth pass's two global atomics per read and window - 30 M reads a step, every one its own trips to the L2 - were a third of the kernel (profiles/r05_config3_notes.txt).
+// The records are position sorted, so a workgroup's reads cover a few thousand consecutive columns of one contig: their +1 / -1 go into a difference array over
+// COLUMNS in LDS (from the first candidate's column on, GC_COLS wide; LDS atomics), and when all reads are in, every window that reaches into the range gets what
+// the per-read scheme would have given it, one atomic per column that is not zero: its first column the running sum up to there (the reads that entered before
+// it), the columns behind it the array's own entries, the slot behind its last column minus the reads that leave beyond it.  A stretch that does not fit the range
+// (another contig, a long N skip) goes the per-read way.  Integer sums: the result is the same whatever the path.
+__global__ __launch_bounds__(BLOCK) void k_getsv_cand_dense(GetsvArgs a, GetsvStage g)
+{
+	__shared__ int32_t s_l[GC_COLS];
+	__shared__ int32_t s_chunk[BLOCK];       // running sum in front of every thread's 32 columns
+	__shared__ int32_t s_w[WAVES_PER_BLOCK + 1];
+	const int64_t t0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK;
+	uint32_t n[WAVES_PER_BLOCK], so[WAVES_PER_BLOCK], total = 0;
+#pragma unroll
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w) { const bool in = t0 + w < g.ntiles; n[w] = in ? g.tile_cnt[t0 + w] : 0u; so[w] = in ? g.tile_off[t0 + w] : 0u; total += n[w]; }
+	if (total < GC_DENSE_MIN) return;
+	// the range: from the first candidate's first column on (candidates are in file order: no later one starts before it on that contig)
+	int first_w = 0;
+#pragma unroll
+	for (int w = WAVES_PER_BLOCK - 1; w >= 0; --w) if (n[w]) first_w = w;
+	const int64_t i_first = g.stage[so[first_w]];
+	const RecLine l0 = rec_load(a.b.rec, i_first);
+	const int T0 = l0.tid(), C0 = l0.pos() + 1;
+	for (int i = (int)threadIdx.x; i < GC_COLS; i += BLOCK) s_l[i] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w)
+		for (uint32_t k = threadIdx.x; k < n[w]; k += BLOCK) {
+			const int64_t i = g.stage[so[w] + k];
+			const CandRec r = cand_load(a.b, i);
+			const int tid = r.line.tid(), pos = r.line.pos();
+			int64_t tile;
+			const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
+			if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
+			if (!(m & TM_DEPTH) || !depth_counts(a, r)) continue;
+			int col = pos + 1; // 1-based
+			int64_t wcur = -1;
+			for (int q = 0; q < r.nc; ++q) {
+				const uint32_t c = cand_op(r, q);
+				const int op = (int)(c & 15u), len = (int)(c >> 4);
+				if (op == C_M) {
+					if (len > 0) {
+						const int s = col, e = col + len - 1;
+						if (tid == T0 && s >= C0 && e + 1 - C0 < GC_COLS) { atomicAdd(&s_l[s - C0], 1); atomicAdd(&s_l[e + 1 - C0], -1); }
+						else depth_segment(a, tid, s, e, tile, wcur, 1);
+					}
+					col += len;
+				} else if (op == C_D || op == C_N) col += len;
+			}
+		}
+	__syncthreads();
+	// running sums: every thread its 32 columns, a scan over the threads' totals
+	constexpr int PER = GC_COLS / BLOCK;
+	int32_t mine = 0;
+#pragma unroll 8
+	for (int j = 0; j < PER; ++j) mine += s_l[(int)threadIdx.x * PER + j];
+	int32_t tot;
+	s_chunk[threadIdx.x] = block_exclusive_sum(mine, s_w, &tot);
+	__syncthreads();
+	auto pre = [&](int c) -> int32_t { // sum of the array up to and including column offset c
+		int32_t v = s_chunk[c / PER];
+		for (int j = (c / PER) * PER; j <= c; ++j) v += s_l[j];
+		return v;
+	};
+	// the windows that reach into [C0, C0 + GC_COLS) on T0
+	int64_t x = 0;
+	{ // the first window with (contig, last column) >= (T0, C0) (the tile look-up table only knows tiles that hold a depth window's records)
+		int64_t lo = 0, hi = a.n_win;
+		while (lo < hi) {
+			const int64_t mid = (lo + hi) >> 1;
+			const int wt = a.win_tid[mid];
+			if (wt < T0 || (wt == T0 && a.win_end[mid] < C0)) lo = mid + 1; else hi = mid;
+		}
+		x = lo;
+	}
+	for (; x < a.n_win && a.win_tid[x] == T0 && (int64_t)a.win_beg[x] < (int64_t)C0 + GC_COLS; ++x) {
+		const int wb = a.win_beg[x], we = a.win_end[x];
+		const int lo = wb > C0 ? wb : C0, hi = (int64_t)we < (int64_t)C0 + GC_COLS - 1 ? we : C0 + GC_COLS - 1;
+		int32_t *d = a.diff + a.win_off[x];
+		for (int c = lo + (int)threadIdx.x; c <= hi; c += BLOCK) {
+			const int32_t v = c == wb ? pre(c - C0) : s_l[c - C0];
+			if (v) atomicAdd(&d[c - wb], v);
+		}
+		if (threadIdx.x == 0 && hi == we) { const int32_t v = pre(we - C0); if (v) atomicAdd(&d[we + 1 - wb], -v); }
+	}
 }
 
 // K8: per window, running sum of the difference array -> per-column depth (in place); one wavefront per window

@@ -1633,6 +1633,7 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	{
 		ProfScope ps(c, P_GETSV_CAND, d.n);
 		k_getsv_cand<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(a, g);
+		if (a.n_win > 0) k_getsv_cand_dense<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(a, g); // (the workgroups whose tiles are dense with candidates: the other kernel left them alone)
 	}
 	HIPCHECK(c, hipGetLastError());
 	if (a.n_win > 0) CHECK(cap_launches(c, a, d, ntiles, 0));
