@@ -162,11 +162,20 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_resolve_win(const uint32_t *__re
 
 // ---- optional: every inflated block's CRC32 against the one in its BGZF trailer (ssv_bamdec_verify_crc; libbam 0.1.16 checks none) ----------
 //
-// A wavefront per block: lane i takes the CRC32 of its slice of the block's bytes (one table look-up per byte, a dword per load), and the slices' values
-// meet the way zlib's crc32_combine joins two: crc(A | B) = crc(A) x^(8 |B|) + crc(B) in GF(2)[x] mod the CRC's polynomial - every lane multiplies its
-// value by x^(8 x the bytes behind its slice) (square-and-multiply over a table of x^(2^k)) and the products are XORed over the wavefront.
+// A wavefront per block.  The block is read in 1 KB chunks, 16 bytes a lane (coalesced; the next chunk's load is in flight while this one is worked on - a lane
+// walking its own kilobyte four bytes at a time was a chain of 256 dependent trips to memory: 19.9 ms per 5.3 GB, as long as the inflate itself).  A lane's
+// pieces lie 1024 bytes apart, so its value is kept Horner-wise in GF(2)[x] mod the CRC's polynomial: acc = acc x^(8 x 1024) + crc(piece) - the multiplication
+// by that constant is four table look-ups (one per byte of acc), the piece's own value sixteen bytes through the slice-by-4 tables from a zero state.  At the
+// end every lane multiplies by x^(8 x the bytes behind its last piece), the products are XORed over the wavefront, and the initial state's share
+// (0xffffffff x^(8 len)) and the final complement make it the CRC-32 that zlib's crc32() gives.
 constexpr int INF_E_CRC = -9; // (beside inflate_core.h's codes: the block's structure was fine, its bytes are not what the writer checksummed)
-struct CrcTab { uint32_t byte[256]; uint32_t x2n[32]; }; // the reflected CRC-32's byte table; x^(2^k) mod P (built on the host, bamdec_api.inc)
+struct CrcTab {
+	uint32_t slice[4][256];  // slice-by-4 tables of the reflected CRC-32 (slice[0] = the byte table)
+	uint32_t adv[4][256];    // adv[k][v] = (v << 8 k) x^(8 x 1024): a state moved on by 1024 zero bytes, byte by byte of the state
+	uint32_t w16[129];       // x^(8 x 16 m), m = 0 .. 128
+	uint32_t xr[16];         // x^(8 r), r = 0 .. 15
+	uint32_t x2n[32];        // x^(2^k) (zlib's x2n_table): any other power by square-and-multiply
+};
 
 __device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) // a(x) b(x) mod P, reflected (zlib's multmodp)
 {
@@ -182,38 +191,54 @@ __device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) // a(x)
 __global__ __launch_bounds__(WAVE) void k_bgzf_crc(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks, const uint64_t *__restrict__ u_off, int64_t n_blocks,
                                                    const uint8_t *__restrict__ stream, const CrcTab *__restrict__ tab, int *__restrict__ status)
 {
-	__shared__ uint32_t s_t[256];
-	__shared__ uint32_t s_x[32];
+	__shared__ uint32_t s_sl[4][256];
+	__shared__ uint32_t s_adv[4][256];
 	const int lane = (int)threadIdx.x;
-	for (int i = lane; i < 256; i += WAVE) s_t[i] = tab->byte[i];
-	if (lane < 32) s_x[lane] = tab->x2n[lane];
+	for (int i = lane; i < 1024; i += WAVE) { (&s_sl[0][0])[i] = (&tab->slice[0][0])[i]; (&s_adv[0][0])[i] = (&tab->adv[0][0])[i]; }
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	const int64_t b = blockIdx.x;
 	if (b >= n_blocks) return;
 	const BgzfBlock blk = blocks[b];
 	const uint32_t len = blk.u_len;
 	const uint8_t *p = stream + u_off[b];
-	const uint32_t S = (((len + WAVE - 1) / WAVE) + 15u) & ~15u; // bytes per lane
-	const uint32_t lo = min((uint32_t)lane * S, len), hi = min(lo + S, len);
-	uint32_t c = 0xffffffffu;
-	uint32_t i = lo;
-	for (; i + 4 <= hi; i += 4) {
-		uint32_t v = ld32(p + i);
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { c = s_t[(c ^ v) & 0xffu] ^ (c >> 8); v >>= 8; }
+	auto word = [&](uint32_t c, uint32_t v) -> uint32_t { // four bytes into the state
+		c ^= v;
+		return s_sl[3][c & 0xffu] ^ s_sl[2][(c >> 8) & 0xffu] ^ s_sl[1][(c >> 16) & 0xffu] ^ s_sl[0][c >> 24];
+	};
+	auto advance = [&](uint32_t c) -> uint32_t { return s_adv[0][c & 0xffu] ^ s_adv[1][(c >> 8) & 0xffu] ^ s_adv[2][(c >> 16) & 0xffu] ^ s_adv[3][c >> 24]; };
+	const uint32_t full = len >> 10, tail = len & 1023u; // whole 1 KB chunks, bytes of the last partial one
+	uint32_t acc = 0, end = 0;                            // the lane's value so far; where its last piece ended
+	uint4 v = make_uint4(0u, 0u, 0u, 0u);
+	if (full) { const uint8_t *q = p + 16u * (uint32_t)lane; v = make_uint4(ld32(q), ld32(q + 4), ld32(q + 8), ld32(q + 12)); }
+	for (uint32_t j = 0; j < full; ++j) {
+		uint4 nv = make_uint4(0u, 0u, 0u, 0u);
+		if (j + 1 < full) { const uint8_t *q = p + 1024u * (j + 1) + 16u * (uint32_t)lane; nv = make_uint4(ld32(q), ld32(q + 4), ld32(q + 8), ld32(q + 12)); }
+		uint32_t c = word(0u, v.x);
+		c = word(c, v.y); c = word(c, v.z); c = word(c, v.w);
+		acc = (j ? advance(acc) : 0u) ^ c;
+		end = 1024u * j + 16u * (uint32_t)lane + 16u;
+		v = nv;
 	}
-	for (; i < hi; ++i) c = s_t[(c ^ p[i]) & 0xffu] ^ (c >> 8);
-	c = hi > lo ? ~c : 0u; // (the CRC-32 of nothing is 0)
-	// x^(8 n) for the n bytes behind the slice: zlib's x2nmodp(n, 3)
-	uint32_t n = len - hi, k = 3, f = 1u << 31;
-	while (n) { if (n & 1u) f = crc_multmodp(s_x[k & 31u], f); n >>= 1; ++k; }
-	uint32_t term = hi < len ? crc_multmodp(f, c) : c;
+	if (16u * (uint32_t)lane < tail) { // the last, partial chunk: this lane's piece of it (at most one lane's is shorter than 16 bytes)
+		const uint32_t at = 1024u * full + 16u * (uint32_t)lane, r = min(16u, tail - 16u * (uint32_t)lane);
+		uint32_t c = 0;
+		for (uint32_t i = 0; i < r; ++i) c = s_sl[0][(c ^ p[at + i]) & 0xffu] ^ (c >> 8);
+		if (full) acc = r == 16u ? advance(acc) : crc_multmodp(crc_multmodp(tab->w16[63], tab->xr[r]), acc); // the piece before ended 1008 + r bytes earlier
+		acc ^= c;
+		end = at + r;
+	}
+	// the bytes behind the lane's last piece: < 2048
+	const uint32_t after = end ? len - end : 0u;
+	uint32_t term = end ? crc_multmodp(crc_multmodp(tab->w16[after >> 4], tab->xr[after & 15u]), acc) : 0u;
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) term ^= (uint32_t)__shfl_xor((int)term, d, WAVE);
 	if (lane == 0) {
+		uint32_t n = len, k = 3, f = 1u << 31; // x^(8 len): zlib's x2nmodp(len, 3)
+		while (n) { if (n & 1u) f = crc_multmodp(tab->x2n[k & 31u], f); n >>= 1; ++k; }
+		const uint32_t crc = ~(term ^ crc_multmodp(f, 0xffffffffu));
 		const uint8_t *t = comp + blk.c_off + blk.c_len; // the trailer: CRC32, ISIZE
 		const uint32_t stored = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-		if (term != stored && status[b] == 0) status[b] = INF_E_CRC;
+		if (crc != stored && status[b] == 0) status[b] = INF_E_CRC;
 	}
 }
 

@@ -574,3 +574,27 @@ def test_getsv_scan_with_and_without_tid_runs(ctx, monkeypatch):
     assert lib.ssv_getsv_scan(ctx._h, C.byref(db)) == 0
     plan.close()
     hdr.close()
+
+
+@pytest.mark.parametrize("read_len", [31, 100, 251, 255, 256, 257, 300])
+@pytest.mark.parametrize("match_rate", [0.9, 0.8, 1.0])
+def test_deep_bins_at_the_edges_of_the_four_positions_per_lane_walk(ctx, read_len, match_rate):
+    """k_cluster_bins4 (round 5) walks a bin with four positions per lane for reads of up to 256 bases (one round of the 64 lanes; strings as dwords; the
+    match-rate compare as a table of the smallest passing count) and leaves longer reads to k_cluster_bins: deep bins (300x over a small genome: 50-150
+    clipped reads per planted breakpoint, and thousands of two- and three-event bins) of reads just below, at and above that length, of lengths that are
+    no multiple of four, under three match rates - tables equal to the oracle's, ASCII and compact"""
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 16384, depth=300, n_sv=6, read_len=read_len)
+    batches = [w.generate_host(0, w.n_total)]
+    want = O.getclip(batches, match_rate=match_rate)
+    assert want["n_events"] > 2000 and int(want["support"].max()) >= 20
+    got = ctx.getclip(batches, match_rate=match_rate)
+    assert_tables_equal(got, want)
+    ctx.clip_table_format(3)
+    try:
+        d = ctx.getclip(batches, match_rate=match_rate)
+    finally:
+        ctx.clip_table_format(0)
+    assert d["n_clusters"] == want["n_clusters"]
+    for k in range(0, d["n_clusters"], 7):
+        assert host.cluster_strings(d, k) == host.cluster_strings(got, k), k
