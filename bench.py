@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--file-level", default="auto", help="deflate level of the file leg's BAM: 1..9 = zlib, fast = the repository's own single-probe LZ77 + Huffman coder (huff_gz.h: deflate_fast, "
                     "~5 x zlib level 4's speed, 93 instead of 77 B/record); auto (default): 6 = samtools' default where >= 64 CPUs write the file, fast where 16 CPUs have to write the WHOLE sample, else 4")
     ap.add_argument("--qual-alphabet", choices=("binned5", "hiseq40"), default="binned5", help="the synthetic reads' base qualities: five binned values {2, 11, 25, 37, 40} (NovaSeq-like, the default) or forty values 2..41 (HiSeq-like: the compact table's 11-bit pairs, a file that deflates less)")
+    ap.add_argument("--no-host-batch", action="store_true", help="skip host_batch_path (the PCIe-inclusive rate: host SoA batches of a sixteenth of the sample through ssv_clip_scan)")
     ap.add_argument("--no-config3", action="store_true", help="skip config3_path (BASELINE config 3's shape: 300x over a tenth of the genome, the same number of records, resident in HBM)")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip cli_path (the `seeksv` binary as child processes on the file leg's BAM)")
     ap.add_argument("--ascii-table", action="store_true", help="cluster tables with ASCII sequences (the C ABI's default layout) instead of 4-bit codes")
@@ -460,6 +461,17 @@ def main():
                     line["file_path"]["same_result_as_resident_path"] = all(fr[k] == line["result"][k] for k in fr if k in line["result"])
             except Exception as e:  # the leg is a report beside the headline, never a reason to lose the line
                 line["file_path"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_host_batch and not strong:
+            # the boundary handing over HOST buffers (what libseeksv_host's reader produces): SoA batches, 49.5 B/record, through the staging path - never `value`
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import host_batch_rate
+                gc.collect(); torch.cuda.empty_cache()
+                hbp = host_batch_rate.measure(min(args.genome_frac, 1 / 16), 1 << 22, ctx)
+                hbp["what"] = "host SoA batches (4 M records each; pageable / page-locked / page-locked and announced one ahead) -> H2D staging -> ssv_clip_scan, best of 3; PCIe-inclusive, not `value`"
+                line["host_batch_path"] = hbp
+            except Exception as e:
+                line["host_batch_path"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
             # the three host legs are reports beside the headline; the two single-threaded ones (the oracle in this process, the real reference
             # binary as a child process) run side by side, then every core gets an oracle worker for a few seconds: ~20 s in all
@@ -1009,7 +1021,8 @@ def cpu_reference(w, n_sample):
         t1 = time.perf_counter()
         subprocess.run([ref, "getsv", "-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip, os.path.join(d, "ref.sv"), os.path.join(d, "x.fq")], check=True, capture_output=True)
         t2 = time.perf_counter()
-        return {"value": n_sample / (t2 - t0), "unit": "records/s", "cores": 1, "kind": "reference",
+        return {"value": n_sample / (t2 - t0), "unit": "records/s", "cores": 1, "kind": "reference", "junctions_served": len(rows),
+                "note": f"its getsv leg serves the {len(rows)} planted junctions that fall into its sample, the GPU legs all {len(w.junctions)}: a rate beside the others, not against them",
                 "sample": f"seeksv v1.2.3 binary on a BAM of the first {n_sample} records of the same workload ({os.path.getsize(bam) >> 20} MB): getclip {t1 - t0:.2f} s + "
                           f"getsv -B with {len(rows)} junctions {t2 - t1:.2f} s, file to file (BGZF inflate and BAM parse included)"}
     except Exception as e:  # the baseline is a courtesy: never fail the bench for it

@@ -203,27 +203,40 @@ __device__ __forceinline__ CandRec cand_load(const DevBatch &b, int64_t i)
 
 __device__ __forceinline__ uint32_t cand_op(const CandRec &r, int k) { return k < 5 ? r.line.head(k) : r.cig[k]; }
 
-__device__ __forceinline__ void discordant_record(const GetsvArgs &a, const CandRec &r, int tid, int pos, int64_t tile)
+// the read's own part of the discordant test (everything that does not look at a junction)
+__device__ __forceinline__ bool discordant_read(const GetsvArgs &a, const CandRec &r)
 {
-	if (r.mapq < a.disc_min_mapq) return;
+	if (r.mapq < a.disc_min_mapq) return false;
 	const int flag = r.flag;
-	if (flag & (F_DUP | F_UNMAP | F_MUNMAP)) return;
-	if (is_concordant(flag, r.isize, a.mean, a.sd, a.times)) return;
+	if (flag & (F_DUP | F_UNMAP | F_MUNMAP)) return false;
+	if (is_concordant(flag, r.isize, a.mean, a.sd, a.times)) return false;
 	const int n = r.nc;
-	if (n > 0 && ((cand_op(r, 0) & 15u) == C_H || (cand_op(r, n - 1) & 15u) == C_H)) return; // IsHardClip (n == 0: the reference reads cigar[-1]; "not hard clipped" like the oracle)
+	if (n > 0 && ((cand_op(r, 0) & 15u) == C_H || (cand_op(r, n - 1) & 15u) == C_H)) return false; // IsHardClip (n == 0: the reference reads cigar[-1]; "not hard clipped" like the oracle)
+	return true;
+}
+
+// junction windows that can overlap [pos, rend): beg in (pos - wmax, rend) on this contig.  `lo`: any junction index not behind the first of them
+// (the loop skips what ends before the read); junction_at(m): junction m, from wherever the caller keeps it; hit(m, j): the read counts for junction m.
+template <typename F, typename H> __device__ __forceinline__ void discordant_walk(const GetsvArgs &a, const CandRec &r, int tid, int pos, int64_t lo, F junction_at, H hit)
+{
 	// bam_calend of libbam 0.1.16: M, D, N advance; no CIGAR -> pos + 1
+	const int n = r.nc;
 	int rend = pos;
 	if (n == 0) rend = pos + 1;
 	else for (int k = 0; k < n; ++k) { const uint32_t c = cand_op(r, k); const int op = (int)(c & 15u); if (op == C_M || op == C_D || op == C_N) rend += (int)(c >> 4); }
-	// junction windows that can overlap [pos, rend): beg in (pos - wmax, rend) on this contig.  The tile of the record's start knows the
-	// first junction that begins after (tile start - wmax): a lower bound of the binary search's answer, the loop below skips the rest.
-	const int64_t lo = a.tile_junc[tile];
 	for (int64_t m = lo; m < a.n_junc; ++m) {
-		const DevJunction j = a.junc[m];
+		const DevJunction j = junction_at(m);
 		if (j.up_tid != tid || j.beg >= rend) break;
 		if (!(rend > j.beg && pos < j.end)) continue;
-		if (discordant_geometry(j, flag, pos, r.mpos, r.lq, r.mtid, a.min_ins, a.max_ins)) atomicAdd(&a.counts[j.orig], 1);
+		if (discordant_geometry(j, r.flag, pos, r.mpos, r.lq, r.mtid, a.min_ins, a.max_ins)) hit(m, j);
 	}
+}
+
+__device__ __forceinline__ void discordant_record(const GetsvArgs &a, const CandRec &r, int tid, int pos, int64_t tile)
+{
+	if (!discordant_read(a, r)) return;
+	// The tile of the record's start knows the first junction that begins after (tile start - wmax): a lower bound of the binary search's answer
+	discordant_walk(a, r, tid, pos, a.tile_junc[tile], [&](int64_t m) { return a.junc[m]; }, [&](int64_t, const DevJunction &j) { atomicAdd(&a.counts[j.orig], 1); });
 }
 
 // one covered stretch [s, e] (1-based columns) of a read into the windows it meets: +sign where it enters a window, -sign behind where it leaves it.
@@ -336,6 +349,9 @@ struct GetsvStage {
 	int64_t block_cap;
 	int *overflow;
 	int64_t ntiles;
+	struct DenseTile *dense_list; // the scan tiles that are dense with candidates (k_dense_tiles lists them, k_getsv_cand leaves them to k_getsv_cand_dense); null: none
+	int *dense_n;
+	unsigned long long *n_cand; // candidates staged by the scan (null: not counted)
 };
 
 // K5/K7 getsv_scan, the streaming pass: reads tid and pos of every record (8 B/record, eight 16-byte loads in flight per lane), looks
@@ -493,33 +509,87 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 		for (int sub = 0; sub < CS_SUB; ++sub) { t4[sub] = nt4[sub]; p4[sub] = np4[sub]; }
 		run = nrun;
 	}
+	if (g.n_cand && threadIdx.x == 0 && cursor) atomicAdd(g.n_cand, (unsigned long long)cursor); // (the host sizes the dense pass's grid by it)
 }
 
 // the slow paths, one thread per staged record: discordant tally and / or depth coverage.  A workgroup takes four tiles of the scan and all
 // its wavefronts walk each tile's candidates together: candidates come in runs - a tile near a junction holds hundreds (30x) or all of its 4096
 // records (300x, BASELINE config 3), its neighbours none - and with a wavefront per tile the kernel lasted as long as 64 dependent rounds of
 // (record line -> look-up -> junctions / windows -> atomics) on the few wavefronts that had work (300x: 2.32 ms, 91 % of the wave cycles waiting).
-constexpr uint32_t GC_DENSE_MIN = 2048; // candidates in a workgroup's four tiles from which on the depth pass goes through LDS (k_getsv_cand_dense)
-constexpr int GC_COLS = 8192;            // columns of the genome a dense workgroup's difference array in LDS covers
+constexpr uint32_t GC_DENSE_MIN = 128; // candidates in a scan tile from which on the tile is k_getsv_cand_dense's (its depth pass goes through LDS)
+constexpr int GC_COLS = 4096;            // columns of the genome a dense workgroup's difference array in LDS covers
+
+constexpr int GC_NTB = GC_COLS / (1 << TILE_SHIFT) + 1; // genome tiles a dense workgroup's range touches
+
+// What a dense tile's workgroup needs before it can look at a record, fetched by the listing pass - one THREAD per tile, 150 K chains of dependent loads side by
+// side - instead of by the workgroup, whose life is that chain (PMC at 300x: 89 % of the wave cycles waiting, a read request back after ~930 clocks).
+struct DenseTile {
+	uint32_t so, n;         // the tile's staged candidates
+	int32_t T0, P0;         // contig and position of the first of them: the workgroup's range starts there
+	int64_t tb0;            // the genome tile of P0 (index into the tile map)
+	uint32_t jlo, wlo;      // the first junction window / depth window a read that starts in the range can meet (n_junc / n_win: none)
+	uint8_t tb[GC_NTB + 7 - (GC_NTB + 7) % 8]; // tile bits of the range's tiles
+};
+
+// the scan tiles that hold GC_DENSE_MIN candidates or more, listed (in any order: integer sums downstream); one atomic per workgroup (one per wavefront: 2,356 atomics
+// with return on one address, 26 us)
+__global__ __launch_bounds__(BLOCK) void k_dense_tiles(GetsvArgs a, GetsvStage g)
+{
+	__shared__ int s_w[WAVES_PER_BLOCK + 1];
+	const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const uint32_t n = t < g.ntiles ? g.tile_cnt[t] : 0u;
+	const bool dense = n >= GC_DENSE_MIN;
+	int total;
+	const int at = block_exclusive_sum<int>(dense ? 1 : 0, s_w, &total);
+	if (!total) return;
+	if (threadIdx.x == 0) s_w[WAVES_PER_BLOCK] = atomicAdd(g.dense_n, total);
+	__syncthreads();
+	if (!dense) return;
+	DenseTile e;
+	e.so = g.tile_off[t]; e.n = n;
+	const RecLine l0 = rec_load(a.b.rec, g.stage[e.so]);
+	e.T0 = l0.tid(); e.P0 = l0.pos();
+	e.tb0 = a.ctg_tile_off[e.T0] + (e.P0 >> TILE_SHIFT);
+	const int64_t tb_end = a.ctg_tile_off[e.T0 + 1];
+	// The range's first tile with junction windows knows the first junction that begins after (its start - wmax): no read of this contig that starts in the
+	// range and has to look at junctions at all meets an earlier one.  The same for the depth windows: the first tile with any knows the first window that
+	// ends at or after its first column (an earlier window that reaches into the range would have marked an earlier tile of it).
+	int dj = -1, dd = -1;
+#pragma unroll
+	for (int i = GC_NTB - 1; i >= 0; --i) {
+		const uint8_t m = e.tb0 + i < tb_end ? a.tilemap[e.tb0 + i] : (uint8_t)0;
+		e.tb[i] = m;
+		if (m & TM_JUNC) dj = i;
+		if (m & TM_DEPTH) dd = i;
+	}
+	e.jlo = dj >= 0 ? a.tile_junc[e.tb0 + dj] : (uint32_t)a.n_junc;
+	e.wlo = dd >= 0 ? a.tile_win[e.tb0 + dd] : (uint32_t)a.n_win;
+	g.dense_list[s_w[WAVES_PER_BLOCK] + at] = e;
+}
 
 __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 {
 	const int64_t t0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK;
 	uint32_t n[WAVES_PER_BLOCK], so[WAVES_PER_BLOCK], total = 0;
 #pragma unroll
-	for (int w = 0; w < WAVES_PER_BLOCK; ++w) { const bool in = t0 + w < g.ntiles; n[w] = in ? g.tile_cnt[t0 + w] : 0u; so[w] = in ? g.tile_off[t0 + w] : 0u; total += n[w]; }
-	if (a.n_win > 0 && total >= GC_DENSE_MIN) return; // (k_getsv_cand_dense's)
-#pragma unroll
-	for (int w = 0; w < WAVES_PER_BLOCK; ++w)
-		for (uint32_t k = threadIdx.x; k < n[w]; k += BLOCK) {
-			const int64_t i = g.stage[so[w] + k];
-			const CandRec r = cand_load(a.b, i);
-			const int tid = r.line.tid(), pos = r.line.pos();
-			int64_t tile;
-			const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
-			if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
-			if (m & TM_DEPTH) depth_record(a, r, tid, pos, tile);
-		}
+	for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+		const bool in = t0 + w < g.ntiles;
+		n[w] = in ? g.tile_cnt[t0 + w] : 0u; so[w] = in ? g.tile_off[t0 + w] : 0u;
+		if (g.dense_list && n[w] >= GC_DENSE_MIN) n[w] = 0; // (k_getsv_cand_dense's)
+		total += n[w];
+	}
+	// the four tiles' candidates as ONE list: at 30x a tile holds ~40, and a pass per tile was four times the chain of dependent loads (line -> tile bits ->
+	// junctions / windows) with a sixth of the lanes at work
+	const uint32_t c1 = n[0], c2 = c1 + n[1], c3 = c2 + n[2];
+	for (uint32_t k = threadIdx.x; k < total; k += BLOCK) {
+		const uint32_t at = k < c1 ? so[0] + k : (k < c2 ? so[1] + (k - c1) : (k < c3 ? so[2] + (k - c2) : so[3] + (k - c3)));
+		const CandRec r = cand_load(a.b, g.stage[at]);
+		const int tid = r.line.tid(), pos = r.line.pos();
+		int64_t tile;
+		const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
+		if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
+		if (m & TM_DEPTH) depth_record(a, r, tid, pos, tile);
+	}
 }
 
 // The same for a workgroup whose tiles are DENSE with candidates (300x, BASELINE config 3: all 16 K records of its tiles start inside junction or depth windows): there
@@ -529,52 +599,81 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 // the per-read scheme would have given it, one atomic per column that is not zero: its first column the running sum up to there (the reads that entered before
 // it), the columns behind it the array's own entries, the slot behind its last column minus the reads that leave beyond it.  A stretch that does not fit the range
 // (another contig, a long N skip) goes the per-read way.  Integer sums: the result is the same whatever the path.
+constexpr int GC_JC = 32, GC_WC = 16;          // junction windows / depth windows a dense workgroup keeps in LDS (beyond: global memory)
+// measured at 300x (tools/gpu_variants.sh; us): one workgroup per group of four tiles, 8192 columns, one line in flight 1506; a workgroup per TILE, 4096 columns 1311,
+// two lines in flight 1160 (four: 1241); the tables in LDS and the first lines requested first 959; the junction counts summed in LDS 629.
+constexpr int GC_U = 2;     // record lines a thread has in flight
 __global__ __launch_bounds__(BLOCK) void k_getsv_cand_dense(GetsvArgs a, GetsvStage g)
 {
 	__shared__ int32_t s_l[GC_COLS];
-	__shared__ int32_t s_chunk[BLOCK];       // running sum in front of every thread's 32 columns
+	__shared__ DevJunction s_j[GC_JC];
+	__shared__ int32_t s_jc[GC_JC];          // reads counted for the junctions in s_j
+	__shared__ int32_t s_wtid[GC_WC], s_wbeg[GC_WC], s_wend[GC_WC];
+	__shared__ int64_t s_woff[GC_WC];
+	__shared__ uint8_t s_tb[GC_NTB];
+	__shared__ int32_t s_chunk[BLOCK];       // running sum in front of every thread's columns
 	__shared__ int32_t s_w[WAVES_PER_BLOCK + 1];
-	const int64_t t0 = (int64_t)blockIdx.x * WAVES_PER_BLOCK;
-	uint32_t n[WAVES_PER_BLOCK], so[WAVES_PER_BLOCK], total = 0;
+	if ((int)blockIdx.x >= *g.dense_n) return; // (the grid is sized by a bound of the list's length that the host knows)
+	const DenseTile *ep = g.dense_list + blockIdx.x;
+	const uint32_t n1 = ep->n, so1 = ep->so;
+	// the first records' lines are asked for before anything else; junction and depth windows come into LDS side by side
+	CandRec r[GC_U];
 #pragma unroll
-	for (int w = 0; w < WAVES_PER_BLOCK; ++w) { const bool in = t0 + w < g.ntiles; n[w] = in ? g.tile_cnt[t0 + w] : 0u; so[w] = in ? g.tile_off[t0 + w] : 0u; total += n[w]; }
-	if (total < GC_DENSE_MIN) return;
-	// the range: from the first candidate's first column on (candidates are in file order: no later one starts before it on that contig)
-	int first_w = 0;
-#pragma unroll
-	for (int w = WAVES_PER_BLOCK - 1; w >= 0; --w) if (n[w]) first_w = w;
-	const int64_t i_first = g.stage[so[first_w]];
-	const RecLine l0 = rec_load(a.b.rec, i_first);
-	const int T0 = l0.tid(), C0 = l0.pos() + 1;
+	for (int u = 0; u < GC_U; ++u) { const uint32_t k = u * BLOCK + threadIdx.x; r[u] = cand_load(a.b, g.stage[so1 + (k < n1 ? k : n1 - 1)]); }
 	for (int i = (int)threadIdx.x; i < GC_COLS; i += BLOCK) s_l[i] = 0;
+	// the range: from the first candidate's first column on (candidates are in file order: no later one starts before it on that contig)
+	const int T0 = ep->T0, P0 = ep->P0, C0 = P0 + 1;
+	const int64_t tb0 = ep->tb0, jlo = ep->jlo, wlo = ep->wlo;
+	if (threadIdx.x < GC_NTB) s_tb[threadIdx.x] = ep->tb[threadIdx.x];
+	if (threadIdx.x < GC_JC) { s_jc[threadIdx.x] = 0; if (jlo + threadIdx.x < a.n_junc) s_j[threadIdx.x] = a.junc[jlo + threadIdx.x]; }
+	else if (threadIdx.x < GC_JC + GC_WC) {
+		const int i = (int)threadIdx.x - GC_JC;
+		const int64_t x = wlo + i;
+		const bool in = x < a.n_win;
+		s_wtid[i] = in ? a.win_tid[x] : -1; s_wbeg[i] = in ? a.win_beg[x] : 0; s_wend[i] = in ? a.win_end[x] : 0; s_woff[i] = in ? a.win_off[x] : 0;
+	}
 	__syncthreads();
-#pragma unroll
-	for (int w = 0; w < WAVES_PER_BLOCK; ++w)
-		for (uint32_t k = threadIdx.x; k < n[w]; k += BLOCK) {
-			const int64_t i = g.stage[so[w] + k];
-			const CandRec r = cand_load(a.b, i);
-			const int tid = r.line.tid(), pos = r.line.pos();
-			int64_t tile;
-			const uint32_t m = getsv_tile_bits(a, tid, pos, tile);
-			if (m & TM_JUNC) discordant_record(a, r, tid, pos, tile);
-			if (!(m & TM_DEPTH) || !depth_counts(a, r)) continue;
-			int col = pos + 1; // 1-based
-			int64_t wcur = -1;
-			for (int q = 0; q < r.nc; ++q) {
-				const uint32_t c = cand_op(r, q);
-				const int op = (int)(c & 15u), len = (int)(c >> 4);
-				if (op == C_M) {
-					if (len > 0) {
-						const int s = col, e = col + len - 1;
-						if (tid == T0 && s >= C0 && e + 1 - C0 < GC_COLS) { atomicAdd(&s_l[s - C0], 1); atomicAdd(&s_l[e + 1 - C0], -1); }
-						else depth_segment(a, tid, s, e, tile, wcur, 1);
-					}
-					col += len;
-				} else if (op == C_D || op == C_N) col += len;
-			}
+	auto one = [&](const CandRec &r) {
+		const int tid = r.line.tid(), pos = r.line.pos();
+		int64_t tile;
+		uint32_t m;
+		const int dt = (pos >> TILE_SHIFT) - (P0 >> TILE_SHIFT);
+		const bool here = tid == T0 && pos >= P0 && dt < GC_NTB;
+		if (here) { m = s_tb[dt]; tile = tb0 + dt; }
+		else m = getsv_tile_bits(a, tid, pos, tile);
+		if ((m & TM_JUNC) && discordant_read(a, r)) {
+			// (a planted breakpoint's hundred-odd discordant pairs at 300x all count for ONE junction: as global atomics on one address they were 0.3 ms of this kernel)
+			if (here) discordant_walk(a, r, tid, pos, jlo, [&](int64_t x) { return x - jlo < GC_JC ? s_j[x - jlo] : a.junc[x]; },
+			                          [&](int64_t x, const DevJunction &j) { if (x - jlo < GC_JC) atomicAdd(&s_jc[x - jlo], 1); else atomicAdd(&a.counts[j.orig], 1); });
+			else discordant_record(a, r, tid, pos, tile);
 		}
+		if (!(m & TM_DEPTH) || !depth_counts(a, r)) return;
+		int col = pos + 1; // 1-based
+		int64_t wcur = -1;
+		for (int q = 0; q < r.nc; ++q) {
+			const uint32_t c = cand_op(r, q);
+			const int op = (int)(c & 15u), len = (int)(c >> 4);
+			if (op == C_M) {
+				if (len > 0) {
+					const int s = col, e = col + len - 1;
+					if (tid == T0 && s >= C0 && e + 1 - C0 < GC_COLS) { atomicAdd(&s_l[s - C0], 1); atomicAdd(&s_l[e + 1 - C0], -1); }
+					else depth_segment(a, tid, s, e, tile, wcur, 1);
+				}
+				col += len;
+			} else if (op == C_D || op == C_N) col += len;
+		}
+	};
+#pragma unroll
+	for (int u = 0; u < GC_U; ++u) if (u * BLOCK + threadIdx.x < n1) one(r[u]);
+	for (uint32_t k0 = BLOCK * GC_U; k0 < n1; k0 += BLOCK * GC_U) { // GC_U lines requested before the first is looked at
+#pragma unroll
+		for (int u = 0; u < GC_U; ++u) { const uint32_t k = k0 + u * BLOCK + threadIdx.x; r[u] = cand_load(a.b, g.stage[so1 + (k < n1 ? k : n1 - 1)]); }
+#pragma unroll
+		for (int u = 0; u < GC_U; ++u) if (k0 + u * BLOCK + threadIdx.x < n1) one(r[u]);
+	}
 	__syncthreads();
-	// running sums: every thread its 32 columns, a scan over the threads' totals
+	if (threadIdx.x < GC_JC && s_jc[threadIdx.x]) atomicAdd(&a.counts[s_j[threadIdx.x].orig], s_jc[threadIdx.x]);
+	// running sums: every thread its columns, a scan over the threads' totals
 	constexpr int PER = GC_COLS / BLOCK;
 	int32_t mine = 0;
 #pragma unroll 8
@@ -587,24 +686,18 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand_dense(GetsvArgs a, GetsvSt
 		for (int j = (c / PER) * PER; j <= c; ++j) v += s_l[j];
 		return v;
 	};
-	// the windows that reach into [C0, C0 + GC_COLS) on T0
-	int64_t x = 0;
-	{ // the first window with (contig, last column) >= (T0, C0) (the tile look-up table only knows tiles that hold a depth window's records)
-		int64_t lo = 0, hi = a.n_win;
-		while (lo < hi) {
-			const int64_t mid = (lo + hi) >> 1;
-			const int wt = a.win_tid[mid];
-			if (wt < T0 || (wt == T0 && a.win_end[mid] < C0)) lo = mid + 1; else hi = mid;
-		}
-		x = lo;
-	}
-	for (; x < a.n_win && a.win_tid[x] == T0 && (int64_t)a.win_beg[x] < (int64_t)C0 + GC_COLS; ++x) {
-		const int wb = a.win_beg[x], we = a.win_end[x];
+	// the windows that reach into [C0, C0 + GC_COLS) on T0 (from wlo on; the first GC_WC of them are in LDS)
+	for (int64_t x = wlo; x < a.n_win; ++x) {
+		const bool c = x - wlo < GC_WC;
+		const int i = (int)(x - wlo);
+		const int wt = c ? s_wtid[i] : a.win_tid[x], wb = c ? s_wbeg[i] : a.win_beg[x], we = c ? s_wend[i] : a.win_end[x];
+		if (wt != T0 || (int64_t)wb >= (int64_t)C0 + GC_COLS) break;
+		if (we < C0) continue;
 		const int lo = wb > C0 ? wb : C0, hi = (int64_t)we < (int64_t)C0 + GC_COLS - 1 ? we : C0 + GC_COLS - 1;
-		int32_t *d = a.diff + a.win_off[x];
-		for (int c = lo + (int)threadIdx.x; c <= hi; c += BLOCK) {
-			const int32_t v = c == wb ? pre(c - C0) : s_l[c - C0];
-			if (v) atomicAdd(&d[c - wb], v);
+		int32_t *d = a.diff + (c ? s_woff[i] : a.win_off[x]);
+		for (int col = lo + (int)threadIdx.x; col <= hi; col += BLOCK) {
+			const int32_t v = col == wb ? pre(col - C0) : s_l[col - C0];
+			if (v) atomicAdd(&d[col - wb], v);
 		}
 		if (threadIdx.x == 0 && hi == we) { const int32_t v = pre(we - C0); if (v) atomicAdd(&d[we + 1 - wb], -v); }
 	}

@@ -206,7 +206,7 @@ struct ssv_ctx {
 	DBuf gs_djunc, gs_counts, gs_wtid, gs_wbeg, gs_wend, gs_woff, gs_diff, gs_tilemap, gs_tile_win, gs_tile_junc, gs_ctgoff, gs_maxdepth, gs_span;
 	DBuf q_tid, q_beg, q_end, q_out64, q_out32;
 	// read cap of the reference's pileup (k_cap_*): flags, per-tile marks, carried sweep state + ring, the stream's last records (ping-pong)
-	DBuf cap_flags, cap_deep, cap_carry, cap_ring, cap_ring_tmp, cap_tail[2][4];
+	DBuf dense_list, cap_flags, cap_deep, cap_carry, cap_ring, cap_ring_tmp, cap_tail[2][4];
 	int32_t cap_tail_n = 0, cap_tail_cur = 0, cap_ring_mask = 0;
 	HBuf h_q;
 
@@ -539,7 +539,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_dlist, &c->bins4_tab, &c->c_strings,
 	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->pair_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
-	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->cap_flags, &c->cap_deep, &c->cap_carry,
+	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->dense_list, &c->cap_flags, &c->cap_deep, &c->cap_carry,
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
@@ -1602,7 +1602,8 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	a.win_tid = P<int32_t>(c->gs_wtid); a.win_beg = P<int32_t>(c->gs_wbeg); a.win_end = P<int32_t>(c->gs_wend); a.win_off = P<int64_t>(c->gs_woff);
 	a.n_win = (int64_t)c->gs_win.size(); a.depth_min_mapq = c->gs_p.depth_min_mapq; a.diff = P<int32_t>(c->gs_diff);
 	a.cap_flag = nullptr; a.cap_span = c->gs_map_span;
-	if (a.n_win > 0) { HIPCHECK(c, hipMemsetAsync(c->cap_flags.p, 0, 16, c->st)); a.cap_flag = P<int>(c->cap_flags); }
+	HIPCHECK(c, hipMemsetAsync(c->cap_flags.p, 0, 16, c->st)); // ([0], [1]: the read cap's flags, [2]: the length of the dense tiles' list)
+	if (a.n_win > 0) a.cap_flag = P<int>(c->cap_flags);
 	const int64_t ntiles = (d.n + CS_TILE - 1) / CS_TILE;
 	const unsigned grid = scan_blocks(ntiles, "SSV_GETSV_SCAN_BLOCKS", 256 * 4);
 	CHECK(ensure(c, c->tile_cnt, ntiles * 4));
@@ -1619,6 +1620,7 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 		HIPCHECK(c, hipMemsetAsync(c->counters.p, 0, sizeof(ClipCounters), c->st));
 		g.tile_cnt = P<uint32_t>(c->tile_cnt); g.tile_off = P<uint32_t>(c->tile_off); g.stage = P<uint32_t>(c->stage); g.block_cap = block_cap;
 		g.overflow = &dc->overflow; g.ntiles = ntiles;
+		g.dense_list = nullptr; g.dense_n = nullptr; g.n_cand = &dc->n_cand;
 		{
 			ProfScope ps(c, P_GETSV_SCAN, d.n);
 			k_getsv_scan<<<grid, BLOCK, 0, c->st>>>(a, g);
@@ -1632,8 +1634,15 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 	}
 	{
 		ProfScope ps(c, P_GETSV_CAND, d.n);
+		// tiles that are dense with candidates are listed and left to the second kernel; its grid: the scan's count bounds the list's length
+		const int64_t dense_max = std::min<int64_t>(ntiles, (int64_t)(hc->n_cand / GC_DENSE_MIN));
+		if (dense_max > 0) {
+			CHECK(ensure(c, c->dense_list, (size_t)dense_max * sizeof(DenseTile)));
+			g.dense_list = P<DenseTile>(c->dense_list); g.dense_n = P<int>(c->cap_flags) + 2; // (zeroed with the cap flags above)
+			k_dense_tiles<<<grid_for(ntiles, BLOCK), BLOCK, 0, c->st>>>(a, g);
+		}
 		k_getsv_cand<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(a, g);
-		if (a.n_win > 0) k_getsv_cand_dense<<<grid_for(ntiles, WAVES_PER_BLOCK), BLOCK, 0, c->st>>>(a, g); // (the workgroups whose tiles are dense with candidates: the other kernel left them alone)
+		if (g.dense_list) k_getsv_cand_dense<<<(unsigned)dense_max, BLOCK, 0, c->st>>>(a, g);
 	}
 	HIPCHECK(c, hipGetLastError());
 	if (a.n_win > 0) CHECK(cap_launches(c, a, d, ntiles, 0));

@@ -176,6 +176,80 @@ def test_random_sample_hip_equals_oracle(ctx, seed):
     hdr.close()
 
 
+def dense_sample(seed, n=40000):
+    """tens of thousands of records on three short contigs (several hundred-fold depth), every kind of CIGAR the getsv passes tell apart: the per-candidate
+    kernels' DENSE workgroups (k_getsv_cand_dense: >= 2048 candidates in a group of four scan tiles)"""
+    rng = np.random.RandomState(9000 + seed)
+    lens = [int(x) for x in rng.randint(2500, 7000, 3)]
+    tid = np.sort(rng.randint(0, 3, n)).astype(np.int32)
+    pos = np.concatenate([np.sort(rng.randint(0, lens[t] - 160, int((tid == t).sum()))) for t in range(3)]).astype(np.int32)
+    lq = rng.choice([50, 100, 150], n).astype(np.int32)
+    kind = rng.choice(7, n, p=[0.62, 0.1, 0.1, 0.06, 0.05, 0.04, 0.03])
+    cig, coff, ncig = [], [], []
+    span = 1
+    for i in range(n):
+        L, k = int(lq[i]), int(kind[i])
+        a = int(rng.randint(1, L - 1))
+        if k == 0: ops = [(L, "M")]
+        elif k == 1: ops = [(a, "S"), (L - a, "M")] if rng.rand() < 0.5 else [(a, "M"), (L - a, "S")]
+        elif k == 2: ops = [(a, "M"), (int(rng.randint(1, 60)), "D"), (L - a, "M")]
+        elif k == 3: ops = [(a, "M"), (int(rng.choice([5, 300, 3000, 9000])), "N"), (L - a, "M")]   # a skip that leaves the workgroup's columns
+        elif k == 4: ops = [(a, "M"), (1, "I"), (L - a - 1, "M")] if L - a > 1 else [(L, "M")]
+        elif k == 5:  # more operations than a record's line holds (the batch's cigar array is read)
+            q = L // 8
+            ops = [(q, "M"), (1, "I"), (q, "M"), (3, "D"), (q, "M"), (2, "I"), (q, "=" if rng.rand() < 0.3 else "M"), (7, "D"), (L - 4 * q - 3, "M")]
+        else: ops = [(3, "H"), (L, "M")] if rng.rand() < 0.5 else [(L, "M"), (2, "H")]
+        coff.append(len(cig)); ncig.append(len(ops))
+        cig += [(l << 4) | OPS.index(op) for l, op in ops]
+        span = max(span, sum(l for l, op in ops if op in "MDN=X"))
+    flag = rng.choice([99, 147, 83, 163, 97, 145, 65, 129, 113, 177, 73, 89, 133, 69], n).astype(np.uint16)
+    for bit, pr in ((256, 0.03), (512, 0.03), (1024, 0.06), (2048, 0.03)):
+        flag |= (rng.rand(n) < pr).astype(np.uint16) * np.uint16(bit)
+    mtid = np.where(rng.rand(n) < 0.8, tid, rng.randint(0, 3, n)).astype(np.int32)
+    mpos = np.maximum(0, pos + rng.randint(-700, 700, n)).astype(np.int32)
+    isz = np.choose(rng.randint(0, 4, n), [np.zeros(n, np.int64), mpos - pos, 300 + rng.randint(-60, 60, n), -(300 + rng.randint(-60, 60, n))]).astype(np.int32)
+    if seed & 1:  # contigs come back: pieces of the sorted file dealt out again (positions inside a piece stay in order)
+        cuts = sorted(set([0, n] + [int(x) for x in rng.randint(1, n, 5)]))
+        order = np.concatenate([np.arange(cuts[i], cuts[i + 1]) for i in rng.permutation(len(cuts) - 1)])
+    else:
+        order = np.arange(n)
+    flat, off2 = [], []
+    for i in order:
+        off2.append(len(flat)); flat += cig[coff[i]:coff[i] + ncig[i]]
+    b = dict(tid=tid[order], pos=pos[order], flag=flag[order], mapq=rng.choice([0, 1, 5, 19, 20, 30, 60, 60, 60], n).astype(np.uint8), n_cigar=np.array(ncig, np.uint16)[order],
+             l_qseq=lq[order], mtid=mtid[order], mpos=mpos[order], isize=isz[order], xc=np.zeros(n, np.uint8), cigar=np.array(flat, np.uint32), cigar_off=np.array(off2, np.uint32),
+             seq_off=np.full(n, 0xFFFFFFFFFFFFFFFF, np.uint64), seqqual=np.zeros(16, np.uint8), max_ref_span=int(span))
+    return [f"c{i}" for i in range(3)], lens, b, rng
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_candidates_hip_equals_oracle(ctx, seed):
+    """Workgroups whose tiles are dense with candidates keep their range's tile bits and junction windows in LDS and put the reads' depth into a difference array over
+    columns there (k_getsv_cand_dense): several hundred-fold depth, up to ~70 junction windows inside one workgroup's range (more than it keeps), reads that leave
+    the range (N skips), contigs that change inside a workgroup and (odd seeds) come back, CIGARs longer than the five operations of a record's line"""
+    names, lens, b, rng = dense_sample(seed)
+    n = len(b["tid"])
+    cuts = sorted(set([0, n] + [int(x) for x in rng.randint(1, n, 2)]))
+    parts = [split_batch(b, cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+    juncs = []
+    for _ in range(60 if seed < 4 else 400):
+        ta, tb = int(rng.randint(0, 3)), int(rng.randint(0, 3))
+        juncs.append((names[ta], int(rng.randint(1, lens[ta])), "+-"[int(rng.randint(0, 2))], names[tb], int(rng.randint(1, lens[tb])), "+-"[int(rng.randint(0, 2))]))
+    juncs = [j for j in juncs if not (j[2] == "-" and j[5] == "-")]
+    juncs.sort(key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
+    hdr = host.Header(names, lens)
+    plan = host.Plan(hdr, juncs, 300, 40, flank_length=int(rng.choice([1, 50, 200])))
+    for q in (20, 0):
+        oc = O.discordant([b], plan.junctions, 300, 40, 4, q)
+        ors, opd, _ = O.depth([b], plan.windows, plan.ranges, plan.points, q)
+        assert oc.sum() > 0 and ors.sum() > 0
+        for bs in ([b], parts):
+            c, r, p = ctx.discordant_and_depth(bs, plan, 300, 40, q, hdr.target_lens)
+            assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd)
+    plan.close()
+    hdr.close()
+
+
 @pytest.mark.parametrize("seed", list(range(200, 212)) + list(range(300, 306)))
 def test_random_unsorted_sample_hip_equals_oracle(ctx, seed):
     """contigs that come back: one flush per visit (clip_reads.h:423-438) - the passes end where the driver sees a contig again (ssv_clip_scan_range);

@@ -55,16 +55,21 @@ def main():
     if a.trace_dir:
         print(json.dumps(overlap_report(a.trace_dir)))
         return
+    print(json.dumps(measure(a.frac, a.batch)))
+
+
+def measure(frac, batch, ctx=None):
+    """the three rates as a dict (bench.py's `host_batch_path` leg calls this with its own context)"""
     from seeksv_amd import _abi, synth
     from seeksv_amd.device import Context, PinnedArrays
-    w = synth.Workload(genome_frac=a.frac, depth=30, n_sv=max(10, int(10000 * a.frac)))
-    ctx = Context(0)
+    w = synth.Workload(genome_frac=frac, depth=30, n_sv=max(10, int(10000 * frac)))
+    ctx = ctx or Context(0)
     db, keep = w.generate_device(0, w.n_total, 0, soa=True)
     hb = ctx.batch_to_host(db)     # dict of numpy arrays (pageable)
     del keep
     hb.pop("rec", None)
     n = w.n_total
-    cuts = list(range(0, n, a.batch)) + [n]
+    cuts = list(range(0, n, batch)) + [n]
 
     def cut(i0, i1):
         out = {}
@@ -121,7 +126,7 @@ def main():
                 ev = ctx.clip_event_count()
                 best = t if best is None else min(best, t)
             res["clip_scan_" + name] = {"s": round(best, 4), "records_per_s": round(n / best), "GB_per_s": round(n * per_record / best / 1e9, 2), "events": ev}
-    print(json.dumps(res))
+    return res
 
 
 if __name__ == "__main__":
