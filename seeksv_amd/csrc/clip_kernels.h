@@ -290,9 +290,10 @@ template <int ITEMS>
 __device__ __forceinline__ void stage_tile_candidates(uint32_t mask, uint64_t packed, int64_t tile, int64_t first_rec_of_lane, uint64_t (&lds)[2][WAVES_PER_BLOCK], int parity,
                                                       uint32_t &cursor, int64_t region, int64_t block_cap, uint32_t *tile_cnt, uint32_t *tile_off, uint32_t *stage, int *overflow)
 {
-	uint64_t inc = wave_inclusive_sum(packed);
+	// (a wavefront without a candidate - most of the getsv scan's: the candidates sit around the junctions - skips the scan's 64-bit DPP steps)
+	const uint64_t inc = __ballot(mask != 0) ? wave_inclusive_sum(packed) : 0ull;
 	if (lane_id() == 63) lds[parity][wave_id()] = inc;
-	__syncthreads();
+	lds_barrier(); // (not __syncthreads(): the caller's prefetched loads stay in flight; nothing written to global memory here is read by this workgroup)
 	uint64_t base = 0, tot = 0;
 #pragma unroll
 	for (int w = 0; w < WAVES_PER_BLOCK; ++w) {

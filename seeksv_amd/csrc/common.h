@@ -29,6 +29,15 @@ __device__ __forceinline__ int4 stream_load_i4(const void *p)
 // flat_load instructions, which count on BOTH memory counters - every wait for an LDS result (lgkmcnt) then also waits for the loads from
 // memory still in flight, and a software pipeline that keeps loads in flight across LDS work does not overlap anything.  These say
 // "global memory" explicitly: global_load, vmcnt only.
+// A workgroup barrier for data exchanged through LDS only.  __syncthreads() is also a fence for global memory: hipcc puts `s_waitcnt vmcnt(0)` in front of every
+// s_barrier, which ends every global load the wavefront has in flight - a streaming kernel's prefetched tiles (one barrier per tile: k_getsv_scan, k_clip_scan_ends).
+// The instruction itself needs no such wait; what the other wavefronts must see is the LDS write: lgkmcnt(0).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// A value every lane reads from the same address in memory that no kernel writes while this one runs, through the scalar cache (s_load, lgkmcnt): a plain
+// `p[i]` of a pointer the compiler cannot prove read-only is a VECTOR load even at a uniform address - and waiting for it (vmcnt counts in order) waits for every
+// vector load issued before it, e.g. a streaming kernel's prefetched next tiles.
+template <typename T> __device__ __forceinline__ T scalar_load(const T *p) { return *(const __attribute__((address_space(4))) T *)(uintptr_t)p; }
 template <typename T> using gptr = const T __attribute__((address_space(1))) *;
 template <typename T> __device__ __forceinline__ gptr<T> as_global(const T *p) { return (gptr<T>)p; }
 template <typename T> __device__ __forceinline__ gptr<T> global_at(uint64_t addr) { return (gptr<T>)(uintptr_t)addr; }

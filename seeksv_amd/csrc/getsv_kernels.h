@@ -472,16 +472,18 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 			if (a.cap_flag && wpmax - wpmin <= a.cap_span && lane_id() == 0) *a.cap_flag = 1;
 		}
 		if (uniform && wmax - wmin < WAVE) {
-			const int64_t lo = a.ctg_tile_off[tid0], hi = a.ctg_tile_off[tid0 + 1]; // wave-uniform addresses
+			const int64_t lo = scalar_load(a.ctg_tile_off + tid0), hi = scalar_load(a.ctg_tile_off + tid0 + 1); // (wave-uniform; NOT a vector load: see scalar_load)
 			const int64_t mine = lo + wmin + lane_id();
 			// (bit k = genome tile wmin + k of this contig; tiles past the contig's end stay 0, so a position beyond the contig is no candidate)
 			const uint64_t interesting = __ballot(mine < hi && a.tilemap[mine < hi ? mine : hi - 1] != 0);
+			if (interesting) { // (wave-uniform)
 #pragma unroll
-			for (int sub = 0; sub < CS_SUB; ++sub) {
-				const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
+				for (int sub = 0; sub < CS_SUB; ++sub) {
+					const int pos[CS_ITEMS] = {p4[sub].x, p4[sub].y, p4[sub].z, p4[sub].w};
 #pragma unroll
-				for (int k = 0; k < CS_ITEMS; ++k) // 0 <= (pos >> 9) - wmin < 64 for every record of the wavefront
-					mask |= ((uint32_t)(interesting >> ((pos[k] >> TILE_SHIFT) - wmin)) & 1u) << (sub * CS_ITEMS + k);
+					for (int k = 0; k < CS_ITEMS; ++k) // 0 <= (pos >> 9) - wmin < 64 for every record of the wavefront
+						mask |= ((uint32_t)(interesting >> ((pos[k] >> TILE_SHIFT) - wmin)) & 1u) << (sub * CS_ITEMS + k);
+				}
 			}
 		} else {
 #pragma unroll
@@ -510,6 +512,146 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 		run = nrun;
 	}
 	if (g.n_cand && threadIdx.x == 0 && cursor) atomicAdd(g.n_cand, (unsigned long long)cursor); // (the host sizes the dense pass's grid by it)
+}
+
+// The same pass for a batch that comes with its tid column as runs (ssv_batch_t.tid_runs: every batch of the product's own decoders): the column is never read - a
+// tile inside one run has its contig from the list; a tile with a run boundary in it (at most one per run) and the batch's last, partial tile work their records'
+// contigs out of the list, record by record - and a thread's prefetched tiles really stay in flight while it works.  k_getsv_scan took 3.4 us per tile and
+// workgroup whatever its prefetch depth, its vector work (skipping it changed nothing) or the bytes in flight (555 us at 1024 workgroups, 623 at 768, 808 at 512:
+// only more workgroups helped), because every tile ENDED the loads in flight (vmcnt counts in order, and the compiler's waits are static):
+//   * `cur = next` at the end of a turn reads `next`: a wait for the loads just issued.  Here: CS_AHEAD + 1 register buffers with fixed roles per unrolled step;
+//     the tile-map byte requested one tile ahead stays in its slot the same way;
+//   * __syncthreads() = `s_waitcnt vmcnt(0)` + s_barrier (hipcc fences global memory at every barrier).  Here: lds_barrier() (common.h);
+//   * a.ctg_tile_off[run] was a VECTOR load at a uniform address, waited for at once.  Here: scalar_load() (common.h);
+//   * loads only some paths issue (the partial last tile's, the look-up's) leave the wait-count pass without the number of loads behind a buffer, and it waits
+//     for all.  Here: every step issues the same four position loads and one tile-map byte (clamped addresses); the partial tile loads on demand;
+//   * a spilled value's scratch reload is one more vector load to wait for (the record-by-record path, sixteen times unrolled or as a call, cost 30 registers).
+//     Here: that path is a loop over the tile's positions parked in LDS.
+// What is left: the per-tile stores of tile_cnt / tile_off / candidates (a later write to one of their source registers waits for them: vmcnt(0) again, behind
+// the barrier).  Same box, same run: k_getsv_scan 542-552 us, this 404-439 us = 5.6-6.1 TB/s (the guide's float4 copy: 6.29).
+// (always the same four loads: the caller clamps the tile to the batch's last whole one)
+__device__ __forceinline__ void getsv_scan_load_pos(const DevBatch &b, int64_t tile, int4 (&p4)[CS_SUB])
+{
+	const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+#pragma unroll
+	for (int sub = 0; sub < CS_SUB; ++sub) p4[sub] = stream_load_i4(b.pos + t0 + (int64_t)sub * (BLOCK * CS_ITEMS));
+}
+
+constexpr int CS_AHEAD = 2; // tiles of positions a thread has on their way while it looks at one (1 with six workgroups per CU, 3: within the noise of this)
+
+__global__ __launch_bounds__(BLOCK, 4) void k_getsv_scan_runs(GetsvArgs a, GetsvStage g)
+{
+	__shared__ uint64_t lds[2][WAVES_PER_BLOCK];
+	__shared__ int s_pos[CS_SUB * CS_ITEMS][BLOCK]; // a tile's positions, for the record-by-record path's loop
+	const DevBatch &b = a.b;
+	uint32_t cursor = 0;
+	int parity = 0;
+	const int64_t region = (int64_t)blockIdx.x * g.block_cap;
+	const int last_tid = a.n_targets - 1;
+	// Record by record (a tile with a run boundary in it, the batch's last tile, wavefronts whose records span 64 genome tiles or more): the contig is the tile's
+	// run or the run the record's index falls into.  Rare, and the loop around it is unrolled over its buffers: a LOOP over the sixteen records, their positions
+	// through LDS (registers cannot be indexed), so that it costs the kernel neither registers nor code.
+	auto by_record = [&](const int4 (&q)[CS_SUB], int run_, int64_t tile, int64_t t0) -> uint32_t {
+		const bool partial = (tile + 1) * CS_TILE > b.n; // the batch's last tile: its positions were not prefetched
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			s_pos[sub * CS_ITEMS + 0][threadIdx.x] = q[sub].x; s_pos[sub * CS_ITEMS + 1][threadIdx.x] = q[sub].y;
+			s_pos[sub * CS_ITEMS + 2][threadIdx.x] = q[sub].z; s_pos[sub * CS_ITEMS + 3][threadIdx.x] = q[sub].w;
+		}
+		int r = 0;
+		if (run_ < 0) { int hi = a.runs.n - 1; const int64_t i0 = tile * CS_TILE; while (r < hi) { const int m = (r + hi + 1) >> 1; if (a.runs.first[m] <= i0) r = m; else hi = m - 1; } }
+		uint32_t mask = 0;
+#pragma nounroll
+		for (int j = 0; j < CS_SUB * CS_ITEMS; ++j) { // (records in increasing index order: the run cursor only moves forward)
+			const int64_t i = t0 + (int64_t)(j / CS_ITEMS) * (BLOCK * CS_ITEMS) + (j % CS_ITEMS);
+			const int pos = partial ? (i < b.n ? b.pos[i] : 0) : s_pos[j][threadIdx.x];
+			int tid = run_;
+			if (run_ < 0) {
+				while (r + 1 < a.runs.n && a.runs.first[r + 1] <= i) ++r;
+				tid = i < b.n ? a.runs.tid[r] : -1;
+			}
+			const int tc = tid < 0 ? 0 : (tid > last_tid ? last_tid : tid);
+			const int64_t lo = a.ctg_tile_off[tc], hi = a.ctg_tile_off[tc + 1];
+			int64_t t = lo + ((pos < 0 ? 0 : pos) >> TILE_SHIFT);
+			const bool valid = tid >= 0 && tid <= last_tid && pos >= 0 && t < hi;
+			t = t < hi ? t : hi - 1;
+			if (valid && a.tilemap[t] != 0) mask |= 1u << j;
+		}
+		return mask;
+	};
+	// CS_AHEAD + 1 buffers of positions in registers, their roles fixed per unrolled step: a buffer is never COPIED - a `cur = next` at the end of a turn reads
+	// `next`, so the turn ends by waiting for the loads it has just issued (vmcnt counts in order), and a tile then costs a memory round trip however far ahead
+	// its loads were issued (k_getsv_scan, round 1-4: 3.4 us a tile per workgroup at any prefetch depth).
+	constexpr int NB = CS_AHEAD + 1;
+	int4 pq[NB][CS_SUB];
+	// A tile's "head": its run, whether the wavefront's records start within 64 genome tiles of one contig (the fast path of k_getsv_scan), and then the request for
+	// the wavefront's 64 tile-map bytes - issued one tile AHEAD, beside the tile in front of it.
+	int run = -1, wmin = 0, nrun = -1, nwmin = 0;
+	bool fast = false, nfast = false;
+	bool cap_seen = false;
+	uint8_t tmq[NB];  // (a tile's byte stays in the slot its load was issued into: a copy would wait for the load, like a copy of a position buffer)
+	bool tm_in = false, ntm_in = false;
+	const int full_tiles = __builtin_amdgcn_readfirstlane((int)(b.n / CS_TILE)); // (> 0: the launcher sends batches of less than a tile to k_getsv_scan)
+	auto head = [&](int64_t tile, const int4 (&q)[CS_SUB], int &run_, bool &fast_, int &wmin_, uint8_t &tm_, bool &in_) {
+		run_ = tile < g.ntiles ? tile_run_tid(a.runs, tile, b.n) : -1; // (-1: a boundary inside, the partial last tile, or no such tile)
+		int pmin = 0x7fffffff, pmax = -1;
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) {
+			pmin = min(pmin, min(min(q[sub].x, q[sub].y), min(q[sub].z, q[sub].w)));
+			pmax = max(pmax, max(max(q[sub].x, q[sub].y), max(q[sub].z, q[sub].w)));
+		}
+		const bool ok = run_ >= 0 && run_ <= last_tid && __all(pmin >= 0);
+		const int wpmin = -wave_max(-pmin), wpmax = wave_max(pmax);
+		wmin_ = wpmin >> TILE_SHIFT;
+		cap_seen = cap_seen || (ok && wpmax - wpmin <= a.cap_span); // (see k_getsv_scan; stored once, at the end: a store in the loop is one more thing a wait can be for)
+		fast_ = ok && (wpmax >> TILE_SHIFT) - wmin_ < WAVE;
+		// the wavefront's 64 tile-map bytes: ALWAYS one load (an address inside the map when the tile takes the other path)
+		const int rc = ok ? run_ : 0;
+		const int64_t lo = scalar_load(a.ctg_tile_off + rc), hi = scalar_load(a.ctg_tile_off + rc + 1); // (wave-uniform; NOT a vector load: see scalar_load)
+		const int64_t mine = lo + (fast_ ? wmin_ : 0) + lane_id();
+		in_ = fast_ && mine < hi; // (tiles past the contig's end stay 0: a position beyond the contig is no candidate)
+		tm_ = a.tilemap[mine < hi ? mine : hi - 1];
+	};
+	auto step = [&](int64_t tile, const int4 (&cur)[CS_SUB], const int4 (&nxt)[CS_SUB], int4 (&far)[CS_SUB], const uint8_t &tm, uint8_t &ntm) {
+		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+		const int64_t next = tile + gridDim.x;
+		const int ahead = (int)tile + CS_AHEAD * (int)gridDim.x; // (tiles: < 2^31)
+		getsv_scan_load_pos(b, ahead < full_tiles ? ahead : full_tiles - 1, far);
+		head(next, nxt, nrun, nfast, nwmin, ntm, ntm_in);
+		uint32_t mask = 0;
+		if (fast) {
+			const uint64_t interesting = __ballot(tm_in && tm != 0);
+			if (interesting) { // (wave-uniform; most wavefronts' 64 genome tiles hold no window: nothing to do per record)
+#pragma unroll
+				for (int sub = 0; sub < CS_SUB; ++sub) {
+					const int pos[CS_ITEMS] = {cur[sub].x, cur[sub].y, cur[sub].z, cur[sub].w};
+#pragma unroll
+					for (int k = 0; k < CS_ITEMS; ++k) // 0 <= (pos >> 9) - wmin < 64 for every record of the wavefront
+						mask |= ((uint32_t)(interesting >> ((pos[k] >> TILE_SHIFT) - wmin)) & 1u) << (sub * CS_ITEMS + k);
+				}
+			}
+		} else mask = by_record(cur, run, tile, t0);
+		uint64_t packed = 0; // candidates per sub-tile, four 16-bit fields
+#pragma unroll
+		for (int sub = 0; sub < CS_SUB; ++sub) packed |= (uint64_t)__popc((mask >> (sub * CS_ITEMS)) & ((1u << CS_ITEMS) - 1u)) << (16 * sub);
+		stage_tile_candidates<CS_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
+		run = nrun; fast = nfast; wmin = nwmin; tm_in = ntm_in;
+		parity ^= 1;
+	};
+#pragma unroll
+	for (int d = 0; d < CS_AHEAD; ++d) { const int t = (int)blockIdx.x + d * (int)gridDim.x; getsv_scan_load_pos(b, t < full_tiles ? t : full_tiles - 1, pq[d]); }
+	head(blockIdx.x, pq[0], run, fast, wmin, tmq[0], tm_in);
+	int64_t tile = blockIdx.x;
+	while (tile < g.ntiles) {
+#pragma unroll
+		for (int j = 0; j < NB; ++j) {
+			if (tile >= g.ntiles) break;
+			step(tile, pq[j], pq[(j + 1) % NB], pq[(j + CS_AHEAD) % NB], tmq[j], tmq[(j + 1) % NB]);
+			tile += gridDim.x;
+		}
+	}
+	if (g.n_cand && threadIdx.x == 0 && cursor) atomicAdd(g.n_cand, (unsigned long long)cursor);
+	if (cap_seen && a.cap_flag && lane_id() == 0) *a.cap_flag = 1;
 }
 
 // the slow paths, one thread per staged record: discordant tally and / or depth coverage.  A workgroup takes four tiles of the scan and all

@@ -1623,7 +1623,8 @@ int ssv_getsv_scan(ssv_ctx *c, const ssv_batch_t *b)
 		g.dense_list = nullptr; g.dense_n = nullptr; g.n_cand = &dc->n_cand;
 		{
 			ProfScope ps(c, P_GETSV_SCAN, d.n);
-			k_getsv_scan<<<grid, BLOCK, 0, c->st>>>(a, g);
+			if (a.runs.n > 0 && d.n >= CS_TILE) k_getsv_scan_runs<<<grid, BLOCK, 0, c->st>>>(a, g); // (the tid column as runs: never read)
+			else k_getsv_scan<<<grid, BLOCK, 0, c->st>>>(a, g);
 		}
 		HIPCHECK(c, hipGetLastError());
 		HIPCHECK(c, hipMemcpyAsync(hc, c->counters.p, sizeof(ClipCounters), hipMemcpyDeviceToHost, c->st));

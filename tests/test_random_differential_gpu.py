@@ -176,11 +176,11 @@ def test_random_sample_hip_equals_oracle(ctx, seed):
     hdr.close()
 
 
-def dense_sample(seed, n=40000):
+def dense_sample(seed, n=40000, contig_lens=(2500, 7000)):
     """tens of thousands of records on three short contigs (several hundred-fold depth), every kind of CIGAR the getsv passes tell apart: the per-candidate
     kernels' DENSE workgroups (k_getsv_cand_dense: >= 2048 candidates in a group of four scan tiles)"""
     rng = np.random.RandomState(9000 + seed)
-    lens = [int(x) for x in rng.randint(2500, 7000, 3)]
+    lens = [int(x) for x in rng.randint(contig_lens[0], contig_lens[1], 3)]
     tid = np.sort(rng.randint(0, 3, n)).astype(np.int32)
     pos = np.concatenate([np.sort(rng.randint(0, lens[t] - 160, int((tid == t).sum()))) for t in range(3)]).astype(np.int32)
     lq = rng.choice([50, 100, 150], n).astype(np.int32)
@@ -246,6 +246,35 @@ def test_dense_candidates_hip_equals_oracle(ctx, seed):
         for bs in ([b], parts):
             c, r, p = ctx.discordant_and_depth(bs, plan, 300, 40, q, hdr.target_lens)
             assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd)
+    plan.close()
+    hdr.close()
+
+
+@pytest.mark.parametrize("seed,n", [(20, 20000), (21, 4096 * 3), (22, 4096 * 2 + 1), (23, 4097)])
+def test_sparse_records_with_tid_runs_hip_equals_oracle(ctx, seed, n):
+    """k_getsv_scan_runs (batches of a tile or more that come with their tid column as runs): records so sparse that a wavefront's 1024 start further apart than the
+    64 genome tiles of its fast path (the record-by-record path inside whole tiles), run boundaries inside tiles, contigs that come back (odd seeds), batches of a
+    whole number of tiles, of one record more, of a tile and a record"""
+    names, lens, b, rng = dense_sample(seed, n=n, contig_lens=(1500000, 4000000))
+    from seeksv_amd import _abi
+    assert len(_abi.runs_of_tid(b["tid"])) <= 48
+    juncs = []
+    for _ in range(300):
+        ta, tb = int(rng.randint(0, 3)), int(rng.randint(0, 3))
+        juncs.append((names[ta], int(rng.randint(1, lens[ta])), "+-"[int(rng.randint(0, 2))], names[tb], int(rng.randint(1, lens[tb])), "+-"[int(rng.randint(0, 2))]))
+    juncs = [j for j in juncs if not (j[2] == "-" and j[5] == "-")]
+    juncs.sort(key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
+    hdr = host.Header(names, lens)
+    plan = host.Plan(hdr, juncs, 300, 40, flank_length=200)
+    cuts = sorted(set([0, n] + [int(x) for x in rng.randint(1, n, 2)]))
+    parts = [split_batch(b, cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+    for q in (20, 0):
+        oc = O.discordant([b], plan.junctions, 300, 40, 4, q)
+        ors, opd, _ = O.depth([b], plan.windows, plan.ranges, plan.points, q)
+        for bs in ([b], parts):
+            c, r, p = ctx.discordant_and_depth(bs, plan, 300, 40, q, hdr.target_lens)
+            assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd)
+    assert ors.sum() > 0
     plan.close()
     hdr.close()
 
