@@ -286,14 +286,16 @@ __device__ __forceinline__ int clip_events_of(const ClipFilterArgs &a, int64_t i
 // Shared tail of the two streaming passes: given each lane's candidate bits (bit sub * ITEMS + k) and its per-sub-tile counts
 // packed as four 16-bit fields, give every candidate of the tile a slot in the workgroup's private staging region, in record order.
 // One barrier per tile (double-buffered LDS); the cursor is workgroup-uniform state that every thread tracks from the block totals.
-template <int ITEMS>
+// SPARSE (the getsv scans: most wavefronts hold no candidate, and the caller keeps prefetched tiles in flight): a wavefront without a candidate skips the scan's
+// 64-bit DPP steps, and the barrier is lds_barrier() - not __syncthreads(), which ends the loads in flight (nothing written to global memory here is read by this
+// workgroup).  The clip scans (a candidate in nearly every wavefront, one tile ahead) were 6 us slower that way and keep the plain form.
+template <int ITEMS, bool SPARSE = false>
 __device__ __forceinline__ void stage_tile_candidates(uint32_t mask, uint64_t packed, int64_t tile, int64_t first_rec_of_lane, uint64_t (&lds)[2][WAVES_PER_BLOCK], int parity,
                                                       uint32_t &cursor, int64_t region, int64_t block_cap, uint32_t *tile_cnt, uint32_t *tile_off, uint32_t *stage, int *overflow)
 {
-	// (a wavefront without a candidate - most of the getsv scan's: the candidates sit around the junctions - skips the scan's 64-bit DPP steps)
-	const uint64_t inc = __ballot(mask != 0) ? wave_inclusive_sum(packed) : 0ull;
+	const uint64_t inc = !SPARSE || __ballot(mask != 0) ? wave_inclusive_sum(packed) : 0ull;
 	if (lane_id() == 63) lds[parity][wave_id()] = inc;
-	lds_barrier(); // (not __syncthreads(): the caller's prefetched loads stay in flight; nothing written to global memory here is read by this workgroup)
+	if (SPARSE) lds_barrier(); else __syncthreads();
 	uint64_t base = 0, tot = 0;
 #pragma unroll
 	for (int w = 0; w < WAVES_PER_BLOCK; ++w) {

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 		uint64_t packed = 0; // candidates per sub-tile, four 16-bit fields
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) packed |= (uint64_t)__popc((mask >> (sub * CS_ITEMS)) & ((1u << CS_ITEMS) - 1u)) << (16 * sub);
-		stage_tile_candidates<CS_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
+		stage_tile_candidates<CS_ITEMS, true>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) { t4[sub] = nt4[sub]; p4[sub] = np4[sub]; }
 		run = nrun;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_getsv_scan_runs(GetsvArgs a, Getsv
 		uint64_t packed = 0; // candidates per sub-tile, four 16-bit fields
 #pragma unroll
 		for (int sub = 0; sub < CS_SUB; ++sub) packed |= (uint64_t)__popc((mask >> (sub * CS_ITEMS)) & ((1u << CS_ITEMS) - 1u)) << (16 * sub);
-		stage_tile_candidates<CS_ITEMS>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
+		stage_tile_candidates<CS_ITEMS, true>(mask, packed, tile, t0, lds, parity, cursor, region, g.block_cap, g.tile_cnt, g.tile_off, g.stage, g.overflow);
 		run = nrun; fast = nfast; wmin = nwmin; tm_in = ntm_in;
 		parity ^= 1;
 	};
@@ -845,7 +845,8 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand_dense(GetsvArgs a, GetsvSt
 	}
 }
 
-// K8: per window, running sum of the difference array -> per-column depth (in place); one wavefront per window
+// K8: per window, running sum of the difference array -> per-column depth (in place); one wavefront per window, 256 columns a round: four coalesced loads
+// issued together, then four scans chained through the carry (a round is a trip to memory and back; four columns per LANE - strided loads and stores - was slower)
 __global__ __launch_bounds__(BLOCK) void k_depth_prefix(const int64_t *__restrict__ win_off, int64_t n_win, int32_t *__restrict__ diff, int32_t *__restrict__ max_depth)
 {
 	int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
@@ -853,16 +854,40 @@ __global__ __launch_bounds__(BLOCK) void k_depth_prefix(const int64_t *__restric
 	int32_t *d = diff + win_off[w];
 	const int64_t len = win_off[w + 1] - win_off[w] - 1; // columns (the extra slot absorbs the closing -1)
 	int32_t carry = 0, mx = 0;
-	for (int64_t base = 0; base < len; base += WAVE) {
-		int64_t i = base + lane_id();
-		int32_t v = i < len ? d[i] : 0;
-		int32_t inc = wave_inclusive_sum(v) + carry;
-		if (i < len) { d[i] = inc; mx = inc > mx ? inc : mx; }
-		carry = __shfl(inc, 63, 64);
+	for (int64_t base = 0; base < len; base += WAVE * 4) {
+		int32_t v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const int64_t i = base + k * WAVE + lane_id(); v[k] = i < len ? d[i] : 0; }
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int64_t i = base + k * WAVE + lane_id();
+			const int32_t inc = wave_inclusive_sum(v[k]) + carry;
+			if (i < len) { d[i] = inc; mx = inc > mx ? inc : mx; }
+			carry = __shfl(inc, 63, 64);
+		}
 	}
 	mx = wave_max(mx);
 	// 20 K windows hitting one address with an atomic each cost 0.2 ms (~90 same-address atomics per microsecond): look first, most waves lose
 	if (lane_id() == 0 && mx > __atomic_load_n(max_depth, __ATOMIC_RELAXED)) atomicMax(max_depth, mx);
+}
+
+// the last window with (tid, beg) <= (tid, pos), or -1; the whole wavefront searches: 64 evenly spaced probes a round (three rounds for 20 K windows, where a
+// binary search is fifteen dependent loads)
+__device__ __forceinline__ int64_t window_at_or_before(const int32_t *__restrict__ win_tid, const int32_t *__restrict__ win_beg, int64_t n_win, int tid, int pos)
+{
+	int64_t lo = 0, hi = n_win; // the answer + 1 lies in [lo, hi]: windows below lo are <= the key, windows from hi on are greater
+	while (hi - lo > 0) {
+		const int64_t step = (hi - lo + WAVE - 1) / WAVE;
+		const int64_t m = lo + (int64_t)lane_id() * step; // probes lo, lo + step, ...
+		const bool le = m < hi && (win_tid[m] < tid || (win_tid[m] == tid && win_beg[m] <= pos));
+		const uint64_t b = __ballot(le); // a prefix of the lanes (the windows are sorted)
+		const int k = __popcll(b);       // probes that are <= the key
+		if (k == 0) { hi = lo; break; }
+		const int64_t last_le = lo + (int64_t)(k - 1) * step;
+		lo = last_le + 1;
+		hi = last_le + step < hi ? last_le + step : hi;
+	}
+	return lo - 1;
 }
 
 // one wavefront per query range: sum of depth over [beg, end] (the range lies inside one window)
@@ -874,21 +899,12 @@ __global__ __launch_bounds__(BLOCK) void k_range_sum(const int32_t *__restrict__
 	int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_id();
 	if (r >= n_q) return;
 	const int tid = q_tid[r], beg = q_beg[r], end = q_end[r];
-	// last window with (tid, beg) <= (tid, q.beg)
-	int64_t lo = 0, hi = n_win;
-	while (lo < hi) {
-		int64_t m = (lo + hi) >> 1;
-		int wt = win_tid[m];
-		if (wt < tid || (wt == tid && win_beg[m] <= beg)) lo = m + 1; else hi = m;
-	}
+	const int64_t w = window_at_or_before(win_tid, win_beg, n_win, tid, beg);
 	unsigned long long s = 0;
-	if (lo > 0) {
-		int64_t w = lo - 1;
-		if (win_tid[w] == tid && beg <= win_end[w]) {
-			int e = end < win_end[w] ? end : win_end[w];
-			const int32_t *d = depth + win_off[w] - win_beg[w];
-			for (int64_t c = (int64_t)beg + lane_id(); c <= e; c += WAVE) s += (unsigned long long)(uint32_t)d[c];
-		}
+	if (w >= 0 && win_tid[w] == tid && beg <= win_end[w]) {
+		int e = end < win_end[w] ? end : win_end[w];
+		const int32_t *d = depth + win_off[w] - win_beg[w];
+		for (int64_t c = (int64_t)beg + lane_id(); c <= e; c += WAVE) s += (unsigned long long)(uint32_t)d[c];
 	}
 	s = wave_sum(s);
 	if (lane_id() == 0) out[r] = s;

@@ -7,7 +7,7 @@ k=0
 for ctrs in "$@"; do
   k=$((k+1)); d=$out/p$k
   # PMC_CMD = the python command line to profile (default: one bench step)
-  rocprofv3 --kernel-trace --pmc $ctrs --kernel-include-regex "$re" --output-format csv -d $d -o x -- python3 ${PMC_CMD:-$GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-config3 --no-overlap --file-frac 0} > $d.json 2> $d.err
+  rocprofv3 --kernel-trace --pmc $ctrs --kernel-include-regex "$re" --output-format csv -d $d -o x -- python3 ${PMC_CMD:-$GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-config3 --no-host-batch --no-overlap --file-frac 0} > $d.json 2> $d.err
   find $d -name '*counter_collection.csv' -exec cp {} $out/pass$k.csv \;
   rm -rf $d
   python3 - $out/pass$k.csv <<'PY'

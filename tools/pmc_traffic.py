@@ -29,12 +29,12 @@ GROUP_OF = {
     "k_cluster_meta": "cluster_pack", "k_cluster_cols": "cluster_pack", "k_cluster_pack_ascii": "cluster_pack",
     "k_cluster_cols3": "cluster_pack", "k_pack3_direct": "cluster_pack", "k_pack3_stream": "cluster_pack", "k_pack3_slow": "cluster_pack",
     "k_isize_count": "isize_stats", "k_isize_collect": "isize_stats", "k_isize_reduce": "isize_stats",
-    "k_tile_mark_windows": "getsv_scan", "k_tile_mark_junctions": "getsv_scan", "k_getsv_scan": "getsv_scan", "k_max_span": "getsv_scan",
-    "k_getsv_cand": "getsv_cand", "k_getsv_cand_dense": "getsv_cand", "k_cap_mark": "getsv_cand", "k_cap_sweep": "getsv_cand", "k_cap_tail": "getsv_cand", "k_cap_regrow": "getsv_cand",
+    "k_tile_mark_windows": "getsv_scan", "k_tile_mark_junctions": "getsv_scan", "k_getsv_scan": "getsv_scan", "k_getsv_scan_runs": "getsv_scan", "k_max_span": "getsv_scan",
+    "k_getsv_cand": "getsv_cand", "k_getsv_cand_dense": "getsv_cand", "k_dense_tiles": "getsv_cand", "k_cap_mark": "getsv_cand", "k_cap_sweep": "getsv_cand", "k_cap_tail": "getsv_cand", "k_cap_regrow": "getsv_cand",
     "k_depth_prefix": "depth_finish", "k_range_sum": "depth_finish", "k_point_depth": "depth_finish",
     "k_build_rec": "h2d",
 }
-DOUBLE_FETCH = {"k_clip_scan", "k_clip_scan_ends", "k_getsv_scan"}
+DOUBLE_FETCH = {"k_clip_scan", "k_clip_scan_ends", "k_getsv_scan", "k_getsv_scan_runs"}
 
 
 def short(name):
