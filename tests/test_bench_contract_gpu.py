@@ -42,6 +42,13 @@ def test_bench_line_contract():
     # the file is read inside the leg's timed region; round 3's footing (the file in pinned memory beforehand) is reported beside it; the
     # resident leg says where its counter bytes come from
     assert fp["includes_file_read"] is True and fp["from_pinned"]["includes_file_read"] is False and fp["from_pinned"]["value"] > 0 and fp["two_reads"]["value"] > 0
+    # the PCIe-inclusive leg (host batches through the staging path) and BASELINE config 3's shape are in the same line, and say what they are
+    hb = d.get("host_batch_path", {})
+    assert "error" not in hb, hb
+    assert hb["clip_scan_pinned_prefetch"]["records_per_s"] > 0 and hb["clip_scan_pageable"]["events"] == hb["clip_scan_pinned"]["events"] > 0 and "not `value`" in hb["what"]
+    c3 = d.get("config3_path", {})
+    assert "error" not in c3, c3
+    assert c3["value"] > 0 and c3["device_kernels_ms"] > 0 and c3["records"] > 0
     assert "traffic_source" in rf and ("profiles/traffic.json" in rf["traffic_source"])
     assert (rf["traffic"] is None) == rf["traffic_source"].startswith("none")
 
