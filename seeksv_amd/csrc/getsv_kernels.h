@@ -528,7 +528,7 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_scan(GetsvArgs a, GetsvStage g)
 //   * a spilled value's scratch reload is one more vector load to wait for (the record-by-record path, sixteen times unrolled or as a call, cost 30 registers).
 //     Here: that path is a loop over the tile's positions parked in LDS.
 // What is left: the per-tile stores of tile_cnt / tile_off / candidates (a later write to one of their source registers waits for them: vmcnt(0) again, behind
-// the barrier).  Same box, same run: k_getsv_scan 542-552 us, this 404-439 us = 5.6-6.1 TB/s (the guide's float4 copy: 6.29).
+// the barrier) - taking that away too (the bookkeeping in LDS until the end) was 5 % SLOWER, profiles/r05_getsv_cand_notes.txt B.3.  Same box, same run: k_getsv_scan 542-552 us, this 404-439 us = 5.6-6.1 TB/s (the guide's float4 copy: 6.29).
 // (always the same four loads: the caller clamps the tile to the batch's last whole one)
 __device__ __forceinline__ void getsv_scan_load_pos(const DevBatch &b, int64_t tile, int4 (&p4)[CS_SUB])
 {
