@@ -239,6 +239,11 @@ def test_dense_candidates_hip_equals_oracle(ctx, seed):
     juncs.sort(key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
     hdr = host.Header(names, lens)
     plan = host.Plan(hdr, juncs, 300, 40, flank_length=int(rng.choice([1, 50, 200])))
+    if seed >= 4:   # more junction windows on one contig than a dense workgroup keeps in LDS (32); seed 4 (flank 1): more depth windows inside one 4096-column range than it keeps (16)
+        assert max(int((plan.junctions["up_tid"] == t).sum()) for t in range(3)) > 64
+    if seed == 4:
+        wb = np.sort(plan.windows["beg"][plan.windows["tid"] == 0])
+        assert max(int(((wb >= x) & (wb < x + 4096)).sum()) for x in wb) > 32
     for q in (20, 0):
         oc = O.discordant([b], plan.junctions, 300, 40, 4, q)
         ors, opd, _ = O.depth([b], plan.windows, plan.ranges, plan.points, q)
