@@ -255,6 +255,8 @@ struct ResidentBam {
 		vector<const char *> qname;
 		vector<string> names;
 	} aln;
+	std::thread bam_writer;      // clip.bam of `seeksv run`, written beside getsv
+	string bam_writer_err;
 };
 static ResidentBam g_resident;
 
@@ -1842,23 +1844,44 @@ static int cmd_realign(int argc, char **argv)
 		for (auto &x : th) x.join();
 	}
 	seqqual.resize(seqqual.size() + 16, 0);
-	ssv_batch_t b;
-	memset(&b, 0, sizeof(b));
-	b.n = n; b.mem = SSV_MEM_HOST;
-	b.tid = tid.data(); b.pos = pos.data(); b.flag = flag.data(); b.mapq = mapq.data(); b.n_cigar = ncig.data(); b.l_qseq = lq.data();
-	b.mtid = mtid.data(); b.mpos = mpos.data(); b.isize = isz.data(); b.cigar_off = cig_off.data(); b.cigar = cig.data(); b.n_cigar_total = (int64_t)cig.size();
-	b.seq_off = seq_off.data(); b.seqqual = seqqual.data(); b.seqqual_bytes = (int64_t)seqqual.size() - 16;
-	vector<const char *> tn;
-	for (const string &x : names) tn.push_back(x.c_str());
 	// clip.bam is read back once, by getsv's join: its BGZF blocks are literal-only Huffman blocks (huff_gz.h: 4 x the speed of zlib level 1 on these
 	// records, 1.6 x the bytes) unless SSV_BGZF_LEVEL asks for zlib
 	setenv("SSV_BGZF_LEVEL", "-1", 0);
-	if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), lens.data(), (int32_t)names.size(), &b, qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
-	pt.lap("write bam");
-	if (g_resident.ctx && fq == g_resident.fq_path) { // `seeksv run`: getsv's join takes the records from here instead of reading clip.bam back
+	if (g_resident.ctx && fq == g_resident.fq_path) {
+		// `seeksv run`: getsv's join takes the records from memory, nobody in this process reads clip.bam - it is written beside getsv, by a thread that cmd_run joins
+		// (0.5 s of the 4.2 s of a whole-genome run when it was written first)
 		auto &A = g_resident.aln;
 		A.bam_path = out_bam; A.tid.swap(tid); A.pos.swap(pos); A.flag.swap(flag); A.n_cigar.swap(ncig); A.mapq.swap(mapq); A.cigar_off.swap(cig_off); A.cigar.swap(cig); A.qname.swap(qn);
 		A.names = names;
+		struct Rest { vector<int32_t> lq, mtid, mpos, isz, lens; vector<uint64_t> seq_off; vector<uint8_t> seqqual; };
+		auto rest = std::make_shared<Rest>();
+		rest->lq.swap(lq); rest->mtid.swap(mtid); rest->mpos.swap(mpos); rest->isz.swap(isz); rest->lens = lens; rest->seq_off.swap(seq_off); rest->seqqual.swap(seqqual);
+		g_resident.bam_writer = std::thread([rest, n] {
+			const auto &A = g_resident.aln;
+			ssv_batch_t b;
+			memset(&b, 0, sizeof(b));
+			b.n = n; b.mem = SSV_MEM_HOST;
+			b.tid = const_cast<int32_t *>(A.tid.data()); b.pos = const_cast<int32_t *>(A.pos.data()); b.flag = const_cast<uint16_t *>(A.flag.data()); b.mapq = const_cast<uint8_t *>(A.mapq.data());
+			b.n_cigar = const_cast<uint16_t *>(A.n_cigar.data()); b.l_qseq = rest->lq.data(); b.mtid = rest->mtid.data(); b.mpos = rest->mpos.data(); b.isize = rest->isz.data();
+			b.cigar_off = const_cast<uint32_t *>(A.cigar_off.data()); b.cigar = const_cast<uint32_t *>(A.cigar.data()); b.n_cigar_total = (int64_t)A.cigar.size();
+			b.seq_off = rest->seq_off.data(); b.seqqual = rest->seqqual.data(); b.seqqual_bytes = (int64_t)rest->seqqual.size() - 16;
+			vector<const char *> tn;
+			for (const string &x : A.names) tn.push_back(x.c_str());
+			if (ssvh_bam_write_batch_named(A.bam_path.c_str(), tn.data(), rest->lens.data(), (int32_t)A.names.size(), &b, const_cast<const char **>(A.qname.data()), 0, 1) != 0)
+				g_resident.bam_writer_err = string("[seeksv] ") + ssvh_last_error();
+		});
+		pt.lap("clip.bam handed to its writer");
+	} else {
+		ssv_batch_t b;
+		memset(&b, 0, sizeof(b));
+		b.n = n; b.mem = SSV_MEM_HOST;
+		b.tid = tid.data(); b.pos = pos.data(); b.flag = flag.data(); b.mapq = mapq.data(); b.n_cigar = ncig.data(); b.l_qseq = lq.data();
+		b.mtid = mtid.data(); b.mpos = mpos.data(); b.isize = isz.data(); b.cigar_off = cig_off.data(); b.cigar = cig.data(); b.n_cigar_total = (int64_t)cig.size();
+		b.seq_off = seq_off.data(); b.seqqual = seqqual.data(); b.seqqual_bytes = (int64_t)seqqual.size() - 16;
+		vector<const char *> tn;
+		for (const string &x : names) tn.push_back(x.c_str());
+		if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), lens.data(), (int32_t)names.size(), &b, qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
+		pt.lap("write bam");
 	}
 	cerr << "[seeksv realign] " << n << " clipped sequences, " << n_aligned << " aligned" << (dropped ? ", " + to_string(dropped) + " repetitive index positions dropped" : string()) << endl;
 	ssv_realign_free(ctx);
@@ -1935,6 +1958,11 @@ static int cmd_run(int argc, char **argv)
 		rc = call(cmd_getsv, a);
 	}
 	pt.lap("run: getsv (records in HBM)");
+	if (g_resident.bam_writer.joinable()) {
+		g_resident.bam_writer.join();
+		if (!g_resident.bam_writer_err.empty()) die(g_resident.bam_writer_err);
+		pt.lap("run: clip.bam written");
+	}
 	ssv_ctx *ctx = g_resident.ctx;
 	if (kCleanExit) {
 		for (auto &b : g_resident.batches) ssv_batch_release(ctx, &b);
