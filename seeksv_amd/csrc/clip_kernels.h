@@ -1262,6 +1262,7 @@ struct PackArgs {
 	int qual_group;           // format 3: qualities per group (1: every quality its own qual_bits; k > 1: k alphabet indices as digits of one number of qual_bits bits, radix qual_radix)
 	int qual_radix;           // the alphabet's size (the base of a group's number)
 	uint32_t qual_fill;       // phred value of alphabet index 0 in all four bytes (what the look-ups see behind a stream's end)
+	uint32_t tri_mul;         // three qualities a group: the multiplier that hashes a triple of phred bytes into the table of k_pack3_direct (qual_dword3h)
 	const uint8_t *qlut;      // [256] phred -> index (0xff: not in the alphabet), when qual_bits < 8
 	uint32_t *qual_seen;      // [8] bit set of the phred values met while packing (TRACK launches: which alphabet the table really needs)
 	int *lut_miss;            // raised when a quality outside the alphabet is met (qual_bits < 8)

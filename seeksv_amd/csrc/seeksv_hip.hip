@@ -904,7 +904,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	const ClipEvent *ev = P<ClipEvent>(c->ev);
 	CHECK(ensure(c, c->totals, 128)); CHECK(ensure_host(c, c->h_totals, 128));
 	CHECK(ensure(c, c->qual_seen, 32)); CHECK(ensure(c, c->qual_lut, 256)); CHECK(ensure_host(c, c->h_qual_lut, 256));
-	CHECK(ensure(c, c->pair_lut, 8192)); CHECK(ensure_host(c, c->h_pair_lut, 8192));
+	CHECK(ensure(c, c->pair_lut, 16384)); CHECK(ensure_host(c, c->h_pair_lut, 16384)); // (pairs: 4096 halves; triples: 4096 dwords)
 	// ---- bin the events by (contig, side, position), BAM order inside a bin.  A coordinate-sorted BAM emits its '5' events in key order
 	//      already (key = start + 1): that is checked, not assumed; only the '3' events (key = start + reference span) need the sort, and
 	//      the two sorted lists interleave per contig.  Unsorted input takes the full sort. ----
@@ -1085,7 +1085,29 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			if (direct && T.qual_bits != 8) {
 				const uint8_t *lut = P<uint8_t>(c->h_qual_lut);
 				for (int v = 64; v < 256; ++v) if (lut[v] != 0xff) direct = false;
-				if (direct) {
+				pa.tri_mul = 0;
+				if (direct && T.qual_group == 3) {
+					// three to a group: ONE look-up per group (qual_dword3h) - the alphabet's R^3 triples of phred bytes hashed into 4096 slots by a multiplier under which
+					// no two of them meet (a few tries: 125 keys, 4096 slots); an entry = triple << 8 | the group's number, an empty slot matches no triple
+					uint32_t *tl = P<uint32_t>(c->h_pair_lut);
+					const int R = T.qual_radix;
+					uint32_t mul = 0;
+					for (uint32_t m = 0x9e3779u; m < 0x9e3779u + 4096u * 2u && !mul; m += 2u) {
+						for (int i = 0; i < (1 << TRI_BITS); ++i) tl[i] = 0xffffffffu;
+						bool ok = true;
+						for (int i2 = 0; i2 < R && ok; ++i2)
+							for (int i1 = 0; i1 < R && ok; ++i1)
+								for (int i0 = 0; i0 < R && ok; ++i0) {
+									const uint32_t tri = (uint32_t)(T.qual_alphabet[i0] - 33) | ((uint32_t)(T.qual_alphabet[i1] - 33) << 8) | ((uint32_t)(T.qual_alphabet[i2] - 33) << 16);
+									const uint32_t slot = (uint32_t)((uint64_t)tri * (m & 0xffffffu)) >> (32 - TRI_BITS); // (v_mul_u32_u24: the low 32 bits of the 24 x 24 bit product)
+									if (tl[slot] != 0xffffffffu) ok = false;
+									else tl[slot] = (tri << 8) | (uint32_t)(i0 + R * i1 + R * R * i2);
+								}
+						if (ok) mul = m & 0xffffffu;
+					}
+					if (mul) { pa.tri_mul = mul; HIPCHECK(c, hipMemcpyAsync(c->pair_lut.p, c->h_pair_lut.p, 16384, hipMemcpyHostToDevice, c->st)); }
+					else direct = false; // (never seen; the staged kernel takes the shape at run time)
+				} else if (direct) {
 					uint16_t *pl = P<uint16_t>(c->h_pair_lut);
 					for (int q1 = 0; q1 < 64; ++q1)
 						for (int q0 = 0; q0 < 64; ++q0) {

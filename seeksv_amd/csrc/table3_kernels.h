@@ -486,6 +486,47 @@ __device__ __forceinline__ uint32_t qual_dword3g(const Pack3Args &q, const uint1
 	return qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
 }
 
+// Three qualities a group of seven bits (five-value alphabets: every bench number), round 5: the group's number out of ONE look-up.  The three phred bytes are
+// hashed (a 24-bit multiply, the host found the multiplier) into a table of 4096 entries in which the alphabet's 125 triples have slots of their own; an entry
+// holds its triple beside the number, so a value outside the alphabet shows as a mismatch (-> miss, like the pair table's 0x8000).  Against qual_dword3g's nine
+// pair look-ups and the arithmetic that puts pairs together into threes: SQ_INSTS_VALU 390 -> 366 M a launch, LDS bank conflicts 56.7 -> 14.9 M cycles, the kernel
+// 655-660 -> 637-649 us (same box, same run) - most of its instructions are not the qualities' (addresses, descriptors, the pipeline's register copies).
+constexpr int TRI_BITS = 12;
+__device__ __forceinline__ uint32_t qual_dword3h(const Pack3Args &q, const uint32_t *s_tri, const PackDescR &d0, int64_t c, int t, const uint32_t (&raw)[Q3<7, 3>::NSRC + 1], uint32_t &miss,
+                                                 uint32_t fill, uint32_t mul)
+{
+	constexpr int W = 7, K = 3, CNTG = Q3<W, K>::CNTG, NSRC = Q3<W, K>::NSRC;
+	static_assert(CNTG == 6 && NSRC == 5, "six groups = eighteen qualities = five source dwords");
+	const int n = d0.ll + d0.lr;
+	const int g0 = (32 * t) / W, off = 32 * t - W * g0, i0 = K * g0;
+	const uint32_t sh = (uint32_t)((d0.src + (uint64_t)((d0.lq + 1) / 2 + d0.begin + i0)) & 3ull);
+	const int rem = n - i0;                                // qualities of the stream from i0 on (>= 1)
+	uint32_t x[NSRC];
+	bool qmiss = false;
+#pragma unroll
+	for (int g = 0; g < NSRC; ++g) {
+		const uint32_t src = __builtin_amdgcn_alignbyte(raw[g + 1], raw[g], sh);
+		if (g == 0) qmiss = (src & 0xffu) == 0xffu; // a read without qualities has 0xff in all of them
+		const uint32_t valid = rem >= 4 * g + 4 ? 0xffffffffu : rem > 4 * g ? (1u << (8 * (rem - 4 * g))) - 1u : 0u;
+		x[g] = (src & valid) | (fill & ~valid);
+	}
+	if (t == 0) q.flags[c] = qmiss ? 1 : 0;
+	uint64_t acc = 0;
+	uint32_t bad = 0;
+#pragma unroll
+	for (int j = 0; j < CNTG; ++j) {
+		const int k = (3 * j) >> 2, s = (3 * j) & 3; // (compile-time after unrolling; 3 j + 2 <= 17 < 20: x[k + 1] exists whenever s > 1)
+		const uint32_t tri = (s == 0 ? x[k] : __builtin_amdgcn_alignbyte(k + 1 < NSRC ? x[k + 1] : 0u, x[k], (uint32_t)s)) & 0xffffffu;
+		const uint32_t e = s_tri[(uint32_t)__umul24(tri, mul) >> (32 - TRI_BITS)]; // (__umul24 returns an int)
+		bad |= (e >> 8) ^ tri;
+		acc |= (uint64_t)(e & 0x7fu) << (W * j);
+	}
+	const int ng = (rem + K - 1) / K; // groups of the stream from g0 on
+	if (ng < CNTG) acc &= (1ull << (W * ng)) - 1ull;
+	miss |= qmiss ? 0u : bad;
+	return qmiss ? 0u : (uint32_t)(acc >> off); // no qualities: the row prints "*", the stream stays zero
+}
+
 // Persistent grid; every group of LPC lanes walks its clusters with a two-deep software pipeline: while the dwords of cluster i are composed
 // and stored, the source dwords of cluster i + 1 and the descriptor of cluster i + 2 are on their way (a cluster is descriptor -> source
 // bytes -> output: two dependent trips to memory that a wavefront would otherwise sit out; at eight wavefronts per SIMD that wait,
@@ -494,12 +535,15 @@ template <int W, int BB, int K = 1>
 __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q, const PackDesc *__restrict__ desc, const unsigned int *__restrict__ n_clusters_dev, uint8_t *__restrict__ out_str,
                                                         const uint16_t *__restrict__ pair_lut, int LPC)
 {
-	__shared__ uint16_t s_pair[4096];
+	constexpr bool TRI = W == 7 && K == 3; // (qual_dword3h: the table is 4096 dwords of triples instead of 4096 halves of pairs)
+	__shared__ __attribute__((aligned(16))) uint32_t s_tab[TRI ? (1 << TRI_BITS) : 2048];
+	const uint16_t *s_pair = reinterpret_cast<const uint16_t *>(s_tab);
 	__shared__ uint8_t s_base[256];
 	if (W != 8) {
 		const uint4 *g = reinterpret_cast<const uint4 *>(pair_lut);
-		uint4 *l = reinterpret_cast<uint4 *>(s_pair);
-		l[threadIdx.x] = g[threadIdx.x]; l[threadIdx.x + BLOCK] = g[threadIdx.x + BLOCK]; // 8 KB = 512 x 16 B, BLOCK == 256
+		uint4 *l = reinterpret_cast<uint4 *>(s_tab);
+#pragma unroll
+		for (int i = 0; i < (TRI ? 4 : 2); ++i) l[threadIdx.x + i * BLOCK] = g[threadIdx.x + i * BLOCK]; // 8 KB = 512 x 16 B (16 KB: 1024), BLOCK == 256
 	}
 	if (BB == 2) { // BAM byte -> code(high nibble) | code(low nibble) << 2, bit 7: not both of A, C, G, T
 		const uint32_t hi = threadIdx.x >> 4, lo = threadIdx.x & 15u;
@@ -535,7 +579,8 @@ __global__ __launch_bounds__(BLOCK) void k_pack3_direct(PackArgs p, Pack3Args q,
 	Src3<W, BB, K> S0, S1;
 	const uint32_t qfill = p.qual_fill, qradix = (uint32_t)p.qual_radix;
 	auto qual_dword = [&](const PackDescR &d, int64_t cc, int t, const uint32_t (&raw)[Q3<W, K>::NSRC + 1]) {
-		if constexpr (K > 1) return qual_dword3g<W, K>(q, s_pair, d, cc, t, raw, miss, qfill, qradix);
+		if constexpr (TRI) return qual_dword3h(q, s_tab, d, cc, t, raw, miss, qfill, p.tri_mul);
+		else if constexpr (K > 1) return qual_dword3g<W, K>(q, s_pair, d, cc, t, raw, miss, qfill, qradix);
 		else return qual_dword3<W>(q, s_pair, d, cc, t, raw, miss);
 	};
 	issue(d0, S0);
