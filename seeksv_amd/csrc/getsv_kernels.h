@@ -610,7 +610,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_getsv_scan_runs(GetsvArgs a, Getsv
 		const int64_t lo = scalar_load(a.ctg_tile_off + rc), hi = scalar_load(a.ctg_tile_off + rc + 1); // (wave-uniform; NOT a vector load: see scalar_load)
 		const int64_t mine = lo + (fast_ ? wmin_ : 0) + lane_id();
 		in_ = fast_ && mine < hi; // (tiles past the contig's end stay 0: a position beyond the contig is no candidate)
-		tm_ = a.tilemap[mine < hi ? mine : hi - 1];
+		tm_ = a.tilemap[mine < hi ? mine : (hi > 0 ? hi - 1 : 0)]; // (hi == 0: a header whose first contigs have no tiles; the map has 16 spare bytes)
 	};
 	auto step = [&](int64_t tile, const int4 (&cur)[CS_SUB], const int4 (&nxt)[CS_SUB], int4 (&far)[CS_SUB], const uint8_t &tm, uint8_t &ntm) {
 		const int64_t t0 = tile * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;

@@ -284,6 +284,29 @@ def test_sparse_records_with_tid_runs_hip_equals_oracle(ctx, seed, n):
     hdr.close()
 
 
+def test_scan_with_an_empty_first_contig(ctx):
+    """a header whose first contig has no bases (no genome tiles): the runs-only scan kernel's tile-map byte is loaded in every step, also for tiles that take
+    the other path - its address must stay inside the map"""
+    names, lens, b, rng = dense_sample(30, n=3 * 4096 + 7)
+    names, lens = ["empty"] + names, [0] + lens
+    for k in ("tid", "mtid"):
+        b[k] = (b[k] + 1).astype(np.int32)
+    juncs = []
+    for _ in range(80):
+        ta, tb = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+        juncs.append((names[ta], int(rng.randint(1, lens[ta])), "+-"[int(rng.randint(0, 2))], names[tb], int(rng.randint(1, lens[tb])), "+-"[int(rng.randint(0, 2))]))
+    juncs = [j for j in juncs if not (j[2] == "-" and j[5] == "-")]
+    juncs.sort(key=lambda j: (j[0], j[3], j[2], j[5], j[1], j[4]))
+    hdr = host.Header(names, lens)
+    plan = host.Plan(hdr, juncs, 300, 40, flank_length=50)
+    oc = O.discordant([b], plan.junctions, 300, 40, 4, 20)
+    ors, opd, _ = O.depth([b], plan.windows, plan.ranges, plan.points, 20)
+    c, r, p = ctx.discordant_and_depth([b], plan, 300, 40, 20, hdr.target_lens)
+    assert np.array_equal(c, oc) and np.array_equal(r, ors) and np.array_equal(p, opd) and ors.sum() > 0
+    plan.close()
+    hdr.close()
+
+
 @pytest.mark.parametrize("seed", list(range(200, 212)) + list(range(300, 306)))
 def test_random_unsorted_sample_hip_equals_oracle(ctx, seed):
     """contigs that come back: one flush per visit (clip_reads.h:423-438) - the passes end where the driver sees a contig again (ssv_clip_scan_range);
