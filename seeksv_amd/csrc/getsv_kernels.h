@@ -654,10 +654,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_getsv_scan_runs(GetsvArgs a, Getsv
 	if (cap_seen && a.cap_flag && lane_id() == 0) *a.cap_flag = 1;
 }
 
-// the slow paths, one thread per staged record: discordant tally and / or depth coverage.  A workgroup takes four tiles of the scan and all
-// its wavefronts walk each tile's candidates together: candidates come in runs - a tile near a junction holds hundreds (30x) or all of its 4096
-// records (300x, BASELINE config 3), its neighbours none - and with a wavefront per tile the kernel lasted as long as 64 dependent rounds of
-// (record line -> look-up -> junctions / windows -> atomics) on the few wavefronts that had work (300x: 2.32 ms, 91 % of the wave cycles waiting).
+// the slow paths, one thread per staged record: discordant tally and / or depth coverage.  Candidates come in runs - a scan tile near a junction holds hundreds
+// (30x) or all of its 4096 records (300x, BASELINE config 3), its neighbours none: the tiles with GC_DENSE_MIN candidates or more (80 % of the candidates at 30x, all at
+// 300x) are k_getsv_cand_dense's, one workgroup each, with what a record asks the tables for in LDS; k_getsv_cand walks what is left, a workgroup per four tiles.
+// (A wavefront per tile, round 4, lasted as long as 64 dependent rounds of record line -> look-up -> junctions / windows -> atomics on the few wavefronts with work.)
 constexpr uint32_t GC_DENSE_MIN = 128; // candidates in a scan tile from which on the tile is k_getsv_cand_dense's (its depth pass goes through LDS)
 constexpr int GC_COLS = 4096;            // columns of the genome a dense workgroup's difference array in LDS covers
 
@@ -734,8 +734,8 @@ __global__ __launch_bounds__(BLOCK) void k_getsv_cand(GetsvArgs a, GetsvStage g)
 	}
 }
 
-// The same for a workgroup whose tiles are DENSE with candidates (300x, BASELINE config 3: all 16 K records of its tiles start inside junction or depth windows): there
-// the depth pass's two global atomics per read and window - 30 M reads a step, every one its own trips to the L2 - were a third of the kernel (profiles/r05_config3_notes.txt).
+// A DENSE tile's candidates (k_dense_tiles lists the tiles with their context).  Depth: the per-read scheme's two global atomics per read and window - every one its
+// own trip to the L2 - were a third of the 300x kernel (profiles/r05_config3_notes.txt); tally: a planted breakpoint's discordant pairs are atomics on ONE count.
 // The records are position sorted, so a workgroup's reads cover a few thousand consecutive columns of one contig: their +1 / -1 go into a difference array over
 // COLUMNS in LDS (from the first candidate's column on, GC_COLS wide; LDS atomics), and when all reads are in, every window that reaches into the range gets what
 // the per-read scheme would have given it, one atomic per column that is not zero: its first column the running sum up to there (the reads that entered before
