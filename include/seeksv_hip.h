@@ -427,7 +427,8 @@ typedef struct {
 	uint64_t tail_offset;        /* internal: where the unfinished record starts */
 	uint32_t repaired_blocks;    /* blocks whose speculated first record start had to be corrected (diagnostic) */
 	int32_t last_tid;            /* contig of the last record without UNMAP|MUNMAP so far */
-	/* host-side lists of the last chunk (pinned memory owned by the context, valid until the next decode): */
+	/* host-side lists of the last chunk (pinned memory owned by the context, valid until the next decode; unmapped_raw: until the decode AFTER
+	 * the next one - two buffers in turn, so that a host thread can pair a chunk's reads up while the next chunk is decoded): */
 	const uint8_t *unmapped_raw; /* the UNMAP|MUNMAP records as they lie in the BAM stream (block_size prefixed), in order: */
 	uint64_t unmapped_bytes;     /*   the unmapped-pair FASTQ side channel of getclip (clip_reads.h:415-419) decodes them on the host */
 	uint32_t n_tid_runs;         /* contig changes among the other records, in order (the flush sequence of clip_reads.h:423-438): */

@@ -143,6 +143,9 @@ int ssvh_gz_append_v(const char *path, const char *const *texts, const size_t *l
  * unmapped-pair FASTQ side channel (clip_reads.h:415-419).  Index k in [0, n).  Host only. */
 int64_t ssvh_bam_unmapped_count(const ssvh_bam *b);
 int ssvh_bam_unmapped_get(const ssvh_bam *b, int64_t k, const char **qname, const char **seq, const char **qual, int *is_read1);
+/* The same records as they lie in the BAM stream (block_size prefixed, in order) - the form ssv_bamdec_info.unmapped_raw has, so that one consumer serves
+ * both readers.  With read-ahead on (three batch sets) the bytes stay valid until the read after the next one. */
+int ssvh_bam_unmapped_raw(const ssvh_bam *b, const uint8_t **raw, size_t *bytes);
 
 /* ---- getsv bookkeeping around the BAM passes -------------------------------------------------- */
 

@@ -32,6 +32,8 @@ typedef struct {
 	int32_t vaf_permille;         // 500
 	int32_t n_breakends;
 	int32_t qual_model;           // 0: five binned values {2, 11, 25, 37, 40} (NovaSeq-like); 1: forty values 2..41, skewed to the high end (HiSeq-like)
+	int32_t unmap_permille;       // records (g, g + 1), g even, that are a pair with ONE unmapped end: g the mapped read (MUNMAP), g + 1 its unmapped mate (UNMAP) placed
+	                              // beside it as aligners do - the input of getclip's unmapped-pair side channel (clip_reads.h:415-419); 0: none (real WGS BAMs: 10-30)
 } sy_config;
 
 // one side of a planted junction, sorted by lin
@@ -190,6 +192,16 @@ SY_HD void sy_decide(const sy_config *c, const sy_breakend *be, int64_t g, sy_re
 			if ((h2 >> 30) & 1u) { r->cigar[0] = ((uint32_t)a << 4) | 0u; r->cigar[1] = ((uint32_t)k << 4) | 1u; r->cigar[2] = ((uint32_t)(L - a - k) << 4) | 0u; }
 			else { r->cigar[0] = ((uint32_t)a << 4) | 0u; r->cigar[1] = ((uint32_t)k << 4) | 2u; r->cigar[2] = ((uint32_t)(L - a) << 4) | 0u; }
 		}
+	}
+	if (c->unmap_permille > 0 && (g | 1) < c->n_total && (int32_t)(sy_hash(c->seed ^ 0x554E4D4150ull, (uint64_t)(g >> 1), 9) % 1000u) < c->unmap_permille) {
+		// one end of the pair did not align: both records go to the side channel (neither is clipped-read material, whatever was decided above); the
+		// unmapped read keeps a plain CIGAR (a record without one makes the reference's hard-clip test read past its CIGAR: IsHardClip, clip_reads.cpp:247)
+		r->n_cigar = 1; r->cigar[0] = ((uint32_t)L << 4) | 0u; r->cigar[1] = r->cigar[2] = 0;
+		r->has_seq = 0; r->be_side = -1; r->clip_len = 0; r->be_index = -1;
+		const uint32_t strand = (uint32_t)(sy_hash(c->seed ^ 0x554E4D4150ull, (uint64_t)(g >> 1), 10) & 1u);
+		if (g & 1) { flag = 1u | 4u | (strand ? 32u : 0u) | 128u; mapq = 0; }
+		else flag = 1u | 8u | (strand ? 16u : 0u) | 64u | (flag & 1024u);
+		mtid = tid; mpos = (int32_t)p; isize = 0;
 	}
 	r->tid = tid; r->pos = (int32_t)p; r->l_qseq = L; r->mtid = mtid; r->mpos = mpos; r->isize = isize;
 	r->flag = (uint16_t)flag; r->mapq = (uint8_t)mapq;

@@ -420,7 +420,8 @@ struct ssvh_bam {
 		Col<uint8_t> mapq, xc, seqqual, ends;
 		Col<uint32_t> cigar_off, cigar;
 		Col<uint64_t> seq_off;
-		std::vector<Unmapped> unmapped;
+		std::vector<uint8_t> unmapped_raw;  // the UNMAP|MUNMAP records as they lie in the stream (block_size prefixed), in order
+		std::vector<size_t> unmapped_off;   // where each starts
 		std::vector<ssv_tid_run> tid_runs; // the tid column as runs (ssv_batch_t.tid_runs)
 		void use(const HostAlloc *a) { tid.a = pos.a = l_qseq.a = mtid.a = mpos.a = isize.a = a; flag.a = n_cigar.a = a; mapq.a = xc.a = seqqual.a = ends.a = a; cigar_off.a = cigar.a = a; seq_off.a = a; }
 	} buf[3];
@@ -808,7 +809,7 @@ const int32_t *ssvh_bam_target_lens(const ssvh_bam *b) { return b->lens.data(); 
 static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records, int keep_all_seq, ssv_batch_t *out)
 {
 	g_err.clear();
-	B.unmapped.clear();
+	B.unmapped_raw.clear(); B.unmapped_off.clear();
 	Bgzf &z = b->z;
 	static const bool timing = [] { const char *e = getenv("SSV_TIMING"); return e ? atoi(e) : 0; }() >= 3; // SSV_TIMING=3: per-batch detail of the host reader
 	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -922,7 +923,7 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 	const double t2 = now();
 	// ---- pass 2 (parallel): decode the records into the structure-of-arrays batch ----
 	std::vector<int64_t> span_of((size_t)nt, 1);
-	std::vector<std::vector<Unmapped>> un((size_t)nt);
+	std::vector<std::vector<uint8_t>> un((size_t)nt); // per thread: its share's UNMAP|MUNMAP records, raw
 	pool().run(nt, [&](int t) {
 		const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
 		int64_t max_span = 1;
@@ -955,23 +956,16 @@ static int decode_batch(ssvh_bam *b, ssvh_bam::BatchBuf &B, int64_t max_records,
 				s_run += o_aux - o_seq;
 			} else B.seq_off[(size_t)i] = SSV_NO_SEQ;
 			if (flag & (4 | 8)) {
-				// GetSeqAndQual (clip_reads.cpp:375-388): bases as stored, qualities +33, "*" when absent
-				Unmapped u;
-				u.qname.assign((const char *)r + o_name, strnlen((const char *)r + o_name, l_read_name ? (size_t)l_read_name - 1 : 0)); // bounded by l_read_name: a name without its NUL must not run on
-				u.seq.resize((size_t)l_seq);
-				for (int32_t k = 0; k < l_seq; ++k) u.seq[(size_t)k] = NT16[(r[o_seq + (k >> 1)] >> ((~k & 1) << 2)) & 15];
-				if (l_seq > 0 && r[o_qual] == 0xff) u.qual = "*";
-				else { u.qual.resize((size_t)l_seq); for (int32_t k = 0; k < l_seq; ++k) u.qual[(size_t)k] = (char)(r[o_qual + k] + 33); }
-				u.is_read1 = (flag & 64) ? 1 : 0;
-				un[(size_t)t].push_back(std::move(u));
+				un[(size_t)t].insert(un[(size_t)t].end(), r - 4, r + bs); // the unmapped-pair side channel decodes them (GetSeqAndQual, clip_reads.cpp:375-388): ssvh_raw_record_fastq
 			}
 		}
 		span_of[(size_t)t] = max_span;
 	});
 	int64_t max_span = 1;
+	{ size_t total = 0; for (auto &u : un) total += u.size(); B.unmapped_raw.reserve(total); }
 	for (int t = 0; t < nt; ++t) {
 		max_span = std::max(max_span, span_of[(size_t)t]);
-		for (auto &u : un[(size_t)t]) B.unmapped.push_back(std::move(u));
+		B.unmapped_raw.insert(B.unmapped_raw.end(), un[(size_t)t].begin(), un[(size_t)t].end());
 	}
 	if (timing) fprintf(stderr, "[read_batch] n=%lld inflate+find %.3f s, sizes %.3f s, decode %.3f s, window %zu MB\n", (long long)n, t1 - t0, t2 - t1, now() - t2, z.ulen >> 20);
 	// the batch's raw bytes are consumed; records already located behind them stay queued for the next call
@@ -1192,11 +1186,14 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 	if (n > 0) {
 		const std::string prefix = qname_prefix ? qname_prefix : "r";
 		auto digits = [](int64_t v) { size_t d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
+		// a read with an unmapped end shares its name with its mate (the side channel of getclip pairs by name, clip_reads.h:172-219): the generator plants
+		// such pairs on records 2k and 2k + 1 (synth_core.h: unmap_permille), and both are named after 2k
+		auto name_index = [&](int64_t i) { const int64_t g = first_index + i; return (b->flag[i] & (4 | 8)) ? (g & ~(int64_t)1) : g; };
 		std::vector<uint64_t> at((size_t)n + 1);
 		const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n / 4096, 256));
 		wpool().run(nt, [&](int w) {
 			for (int64_t i = n * w / nt, e = n * (w + 1) / nt; i < e; ++i) {
-				const size_t ln = qnames ? strlen(qnames[i]) : prefix.size() + digits(first_index + i);
+				const size_t ln = qnames ? strlen(qnames[i]) : prefix.size() + digits(name_index(i));
 				const size_t lq = (size_t)b->l_qseq[i];
 				at[(size_t)i + 1] = 4 + 32 + ln + 1 + 4 * (size_t)b->n_cigar[i] + (lq + 1) / 2 + lq;
 			}
@@ -1228,7 +1225,7 @@ static int write_batch_impl(const char *path, const char *const *names, const in
 				const char *qn; size_t ln;
 				std::string tmp;
 				if (qnames) { qn = qnames[i]; ln = strlen(qn); }
-				else { tmp = prefix; tmp.append(num, (size_t)snprintf(num, sizeof(num), "%lld", (long long)(first_index + i))); qn = tmp.c_str(); ln = tmp.size(); }
+				else { tmp = prefix; tmp.append(num, (size_t)snprintf(num, sizeof(num), "%lld", (long long)name_index(i))); qn = tmp.c_str(); ln = tmp.size(); }
 				const int32_t body = (int32_t)(at[(size_t)i + 1] - at[(size_t)i] - 4);
 				auto w32 = [&](int32_t v) { memcpy(d, &v, 4); d += 4; };
 				w32(body); w32(b->tid[i]); w32(pos);
@@ -1339,13 +1336,27 @@ size_t ssvh_raw_record_fastq(const uint8_t *raw, size_t raw_bytes, size_t offset
 	return offset + 4 + (size_t)bs;
 }
 
-int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { return (int64_t)b->buf[b->cur].unmapped.size(); }
+static void unmapped_index(const ssvh_bam *b)
+{
+	auto &B = const_cast<ssvh_bam *>(b)->buf[b->cur];
+	if (!B.unmapped_off.empty() || B.unmapped_raw.empty()) return;
+	for (size_t off = 0; off + 4 <= B.unmapped_raw.size();) { uint32_t bs; memcpy(&bs, B.unmapped_raw.data() + off, 4); B.unmapped_off.push_back(off); off += 4 + (size_t)bs; }
+}
+
+int64_t ssvh_bam_unmapped_count(const ssvh_bam *b) { unmapped_index(b); return (int64_t)b->buf[b->cur].unmapped_off.size(); }
 
 int ssvh_bam_unmapped_get(const ssvh_bam *b, int64_t k, const char **qname, const char **seq, const char **qual, int *is_read1)
 {
-	if (k < 0 || (size_t)k >= b->buf[b->cur].unmapped.size()) return -1;
-	const Unmapped &u = b->buf[b->cur].unmapped[(size_t)k];
-	*qname = u.qname.c_str(); *seq = u.seq.c_str(); *qual = u.qual.c_str(); *is_read1 = u.is_read1;
+	unmapped_index(b);
+	const auto &B = b->buf[b->cur];
+	if (k < 0 || (size_t)k >= B.unmapped_off.size()) return -1;
+	return ssvh_raw_record_fastq(B.unmapped_raw.data(), B.unmapped_raw.size(), B.unmapped_off[(size_t)k], qname, seq, qual, is_read1) ? 0 : -1;
+}
+
+int ssvh_bam_unmapped_raw(const ssvh_bam *b, const uint8_t **raw, size_t *bytes)
+{
+	const auto &B = b->buf[b->cur];
+	*raw = B.unmapped_raw.data(); *bytes = B.unmapped_raw.size();
 	return 0;
 }
 

@@ -48,21 +48,6 @@ static inline uint64_t text_hash(const char *p, size_t n)
 	return h * 0xC4CEB9FE1A85EC53ull;
 }
 
-struct Str {
-	const char *p = nullptr; size_t n = 0;
-	std::string str() const { return std::string(p, n); }
-	bool operator==(const Str &o) const { return n == o.n && (n == 0 || memcmp(p, o.p, n) == 0); }
-	bool equals(const char *z) const { return strncmp(z, p, n) == 0 && z[n] == '\0'; }
-};
-
-// One row of clip.gz as the join sees it: aligned part first, whatever the side (getsv.h:460-461).  5.5 M rows of a whole-genome sample meet 20 K
-// alignments: a row is views into the text (no string is copied, its CIGAR is parsed) until an alignment turns it into a junction.
-struct ClipRow {
-	Str chr; int pos = 0; char side = 0; Str cigar;
-	Str aligned_seq, clipped_seq, clipped_qual; int support = 0;
-	uint64_t h = 0; // text_hash(clipped_seq)
-};
-
 struct AlignInfo { // getsv.h:27-44
 	std::string chr; int pos = 0, len = 0; char strand = 0; CigarVec cigar_vec; std::string seq; int left_clipped = 0, right_clipped = 0; char type = 0;
 };
@@ -250,7 +235,7 @@ double match_begin_first(const std::string &a, const std::string &b) // CompareS
 // Every member must end exactly where the next one starts, with its CRC and size right (zlib checks both) - otherwise, and for any other
 // gzip or plain file, false: the caller reads the file the ordinary way (gzread).
 // (the text lands in `buf`, allocated here without being cleared: its pages are first touched by the inflating threads, not by one thread's memset)
-static bool slurp_gz_members(const std::string &path, std::unique_ptr<char[]> &buf, size_t &buf_len)
+bool slurp_gz_members(const std::string &path, std::unique_ptr<char[]> &buf, size_t &buf_len)
 {
 	static const unsigned char head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
 	const int fd = open(path.c_str(), O_RDONLY);
@@ -366,15 +351,9 @@ void reverse_complement(std::string &seq)
 // integers and whose third is one character - what getclip writes.  For such text this is what the reference's `fin >> chr >> pos >> ...;
 // getline(fin, rest)` loop (getsv.h:441-446) extracts; anything else (a short line would make operator>> run on into the next one, a field like
 // "12x" would split) returns false and the caller parses the text with that very stream loop.
-struct TextView { // (just enough of std::string for the parser)
-	const char *p; size_t n;
-	size_t size() const { return n; }
-	const char *data() const { return p; }
-	size_t find(char c, size_t from) const { const void *q = from < n ? memchr(p + from, c, n - from) : nullptr; return q ? (size_t)(static_cast<const char *>(q) - p) : std::string::npos; }
-};
 
 // texts: pieces of whole rows, in file order
-static bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow> &rows)
+bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow> &rows)
 {
 	static const bool off = getenv("SSV_SERIAL") && strstr(getenv("SSV_SERIAL"), "rows"); // SSV_SERIAL=rows (tests): the stream loop
 	if (off) return false;

@@ -3,7 +3,10 @@
 // Small, string-heavy, order-dependent work: stays on the host.
 #pragma once
 
+#include <cstdint>
+#include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -34,6 +37,31 @@ double match_begin_first(const std::string &a, const std::string &b); // Compare
 std::string slurp_gz(const std::string &path, std::string &out);      // whole file (gzip or plain) into out; "" or an error text
 CigarVec parse_cigar(const std::string &cigar);  // ChangeCigarType, getsv.cpp:433
 void reverse_complement(std::string &seq);       // GetReverseComplementSeq, clip_reads.cpp:414
+
+// A piece of text that lives elsewhere (the rows of clip.gz in memory).
+struct Str {
+	const char *p = nullptr; size_t n = 0;
+	std::string str() const { return std::string(p, n); }
+	bool operator==(const Str &o) const { return n == o.n && (n == 0 || memcmp(p, o.p, n) == 0); }
+	bool equals(const char *z) const { return strncmp(z, p, n) == 0 && z[n] == '\0'; }
+};
+// One row of clip.gz as views into the text: aligned part first, whatever the side (getsv.h:460-461; somatic.h:45-52 reads the same nine fields).
+struct ClipRow {
+	Str chr; int pos = 0; char side = 0; Str cigar;
+	Str aligned_seq, clipped_seq, clipped_qual; int support = 0;
+	uint64_t h = 0; // 64-bit hash of clipped_seq (the join's first compare)
+};
+struct TextView { // (just enough of std::string for the parser)
+	const char *p; size_t n;
+	size_t size() const { return n; }
+	const char *data() const { return p; }
+	size_t find(char c, size_t from) const { const void *q = from < n ? memchr(p + from, c, n - from) : nullptr; return q ? (size_t)(static_cast<const char *>(q) - p) : std::string::npos; }
+};
+// A .gz file of independent gzip members (what ssvh_gz_append writes) inflated by all threads straight into place; false: not such a file (read it with slurp_gz).
+bool slurp_gz_members(const std::string &path, std::unique_ptr<char[]> &buf, size_t &buf_len);
+// The rows of clip.gz parsed by all threads (texts: pieces of whole rows, in file order); false: text the reference's `fin >> ...` loop would not split the
+// same way (short lines, non-numeric fields) - the caller then runs that very stream loop.
+bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow> &rows);
 
 // InputSoftInfoStoreBreakpoint (getsv.h:423-541) + GetAlignInfo (getsv.cpp:25) + GetJunction (getsv.cpp:1705).  Returns "" or an error text.
 std::string assemble_junctions(const std::string &clipfile, const std::string &clip_bam, JunctionMap &junction2other);

@@ -38,6 +38,7 @@
 
 #include "junction_stage.h"
 #include "somatic_stage.h"
+#include "unmapped_pairs.h"
 #include "seeksv_hip.h"
 #include "seeksv_host.h"
 
@@ -47,9 +48,11 @@ using seeksv::JunctionMap;
 using seeksv::OtherInfo;
 using seeksv::SeqInfo;
 using seeksv::parse_cigar;
-using seeksv::ClusterMap;
+using seeksv::NormalClusters;
 using seeksv::SomaticRow;
 using seeksv::load_normal_clusters;
+using seeksv::parse_tumor_table;
+using seeksv::probe_normal_clusters;
 using seeksv::scan_tumor_table;
 
 static const char *kVersion = "1.2.3-mi355x";
@@ -598,7 +601,13 @@ struct BatchSource {
 		ssv_batch_t b;
 		while (next(&b, keep_all_seq)) { side(b); scan(b); }
 	}
-	// UNMAP|MUNMAP records of the current batch, in order
+	// UNMAP|MUNMAP records of the current batch as they lie in the BAM stream (block_size prefixed), in order; valid while the NEXT batch is read
+	void unmapped_raw(const uint8_t **raw, size_t *bytes)
+	{
+		if (!on_device) { ssvh_bam_unmapped_raw(bam, raw, bytes); return; }
+		*raw = info.unmapped_raw; *bytes = (size_t)info.unmapped_bytes;
+	}
+	// ... one by one, decoded
 	template <class F> void for_each_unmapped(F fn)
 	{
 		const char *qname, *seq, *qual; int is_read1;
@@ -791,8 +800,10 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	ssvh_bam *bam = src.bam;
 	pt.lap("open+gpu_init");
 
-	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219)
-	map<string, pair<pair<string, string>, char>> id2seq_qual;
+	// unmapped-pair side channel, StoreUnmapSeqAndQual (clip_reads.h:172-219): paired up, turned into FASTQ text and compressed by threads of its own
+	// (unmapped_pairs.h); this thread hands every batch's raw UNMAP|MUNMAP records over by pointer
+	seeksv::UnmappedPairs unmapped([&](vector<string> &parts) { fuout1.write_parts(parts); }, [&](vector<string> &parts) { fuout2.write_parts(parts); },
+	                               std::max(1, std::min(8, ssv::effective_cpus() / 2)));
 	// The flush sequence (clip_reads.h:428-438, :442): the reference writes out and clears its two maps at every change of contig among the
 	// mapped-pair records.  A pass of the library bins by (contig, side, position), which is the same thing as long as every contig of the
 	// pass is visited once, in ascending order - a coordinate-sorted BAM is ONE pass.  When a contig comes back (or one with a lower id
@@ -853,20 +864,7 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	};
 	src.pump(0, [&](const ssv_batch_t &b) {
 		pt.lap(device_inflate ? "bam_read(wait)+gpu_inflate+decode" : "bam_read(wait)");
-		src.for_each_unmapped([&](const char *qname, const char *seq, const char *qual, int is_read1) {
-			auto it = id2seq_qual.find(qname);
-			if (it != id2seq_qual.end()) {
-				if (is_read1 && it->second.second == '2') {
-					fuout1.write(string("@") + it->first + "/1\n" + seq + "\n+\n" + qual + "\n");
-					fuout2.write(string("@") + it->first + "/2\n" + it->second.first.first + "\n+\n" + it->second.first.second + "\n");
-					id2seq_qual.erase(it);
-				} else if (!is_read1 && it->second.second == '1') {
-					fuout1.write(string("@") + it->first + "/1\n" + it->second.first.first + "\n+\n" + it->second.first.second + "\n");
-					fuout2.write(string("@") + it->first + "/2\n" + seq + "\n+\n" + qual + "\n");
-					id2seq_qual.erase(it);
-				}
-			} else id2seq_qual.insert(make_pair(string(qname), make_pair(make_pair(string(seq), string(qual)), is_read1 ? '1' : '2')));
-		});
+		{ const uint8_t *raw = nullptr; size_t raw_bytes = 0; src.unmapped_raw(&raw, &raw_bytes); unmapped.submit(raw, raw_bytes); }
 		changes_of.emplace_back();
 		src.contig_changes(b, last_tid, [&](int64_t i, int32_t tid) { changes_of.back().emplace_back(i, tid); });
 		pt.lap("host_side_channel");
@@ -896,8 +894,10 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 	pass_flushes.push_back(scan_last_tid);
 	emit_pass(true);
 	cerr << "[GetSClipReads] finished!" << endl;
+	unmapped.finish();
 	softfout.close(); fqfout.close(); fuout1.close(); fuout2.close();
 	pt.lap("gzip");
+	if (pt.on) cerr << "[timing] (unmapped side channel, beside the reading: " << unmapped.records() << " records, " << unmapped.pairs() << " pairs written, its thread busy " << unmapped.busy_seconds() << " s)" << endl;
 	if (pt.on) cerr << "[timing] (format, all passes, beside the reading: " << emit_format_s << " s; gzip: " << emit_gzip_s << " s)" << endl;
 	src.close();
 	release_ctx(ctx);
@@ -1085,7 +1085,8 @@ static double largest_base_frequency(const string &seq) // CountLargestBaseFrequ
 // fused pass scans them and goes on from the next chunk instead of reading, inflating and decoding the head of the file again.
 struct IsizeCarry { BatchSource src; vector<ssv_batch_t> kept; bool owned = false, usable = false; };
 
-static void insert_size_pass(const std::function<ssv_ctx *()> &get_ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation, IsizeCarry *keep = nullptr)
+static void insert_size_pass(const std::function<ssv_ctx *()> &get_ctx, const string &bamfile, bool device_inflate, int min_mapQ, int read_pair_used, int &mean_insert_size, int &deviation, IsizeCarry *keep = nullptr,
+                             string *report = nullptr) // report: the pass's stderr lines go there instead (a caller that has earlier lines still to print)
 {
 	BatchSource local;
 	BatchSource &src = keep ? keep->src : local;
@@ -1110,7 +1111,9 @@ static void insert_size_pass(const std::function<ssv_ctx *()> &get_ctx, const st
 	ssv_isize_finish(ctx, &n, &m, &sd);
 	if (n > 0) {
 		mean_insert_size = m; deviation = sd;
-		cerr << "Bam/sam " << bamfile << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << endl;
+		std::ostringstream o;
+		o << "Bam/sam " << bamfile << "    Mean insert size : " << mean_insert_size << "\n" << "Mean deviation: " << deviation << "\n";
+		if (report) *report += o.str(); else { cerr << o.str(); cerr.flush(); }
 	}
 	if (keep && src.on_device && chunks >= 1) { keep->usable = true; return; }
 	src.close();
@@ -1459,16 +1462,18 @@ static int cmd_somatic(int argc, char **argv)
 	else if (offset >= 90 || offset < 0) { cerr << "Error: value of -l must in range [0, 90) " << endl; usage_somatic(); }
 	const string normal_bam_file = argv[optind++], clipped_file = argv[optind++], tumor_file = argv[optind++], somatic_file = argv[optind++];
 
-	ClusterMap clip3, clip5;
-	{
-		string warnings, err = load_normal_clusters(clipped_file, min_len_of_clipped_seq, clip3, clip5, warnings);
-		if (!err.empty()) die(err);
-		cerr << warnings;
-	}
-	pt.lap("normal_clusters");
+	// The normal sample's clusters (all host threads: inflate + parse of a 30x sample's 5.5 M rows) are read BESIDE the GPU's work: what a row of the
+	// tumor's table asks of the BAM (somatic.cpp:111,142: whether FindDiscordantReadPairs runs for it) depends on the insert size only, not on the look-ups.
+	NormalClusters normal;
+	string load_warnings, load_err;
+	auto load = [&] { load_err = load_normal_clusters(clipped_file, min_len_of_clipped_seq, normal, load_warnings); };
 	if (!dump_lookups.empty()) {
+		load();
+		if (!load_err.empty()) die(load_err);
+		cerr << load_warnings;
+		pt.lap("normal_clusters");
 		vector<SomaticRow> rows;
-		string err = scan_tumor_table(tumor_file, clip3, clip5, offset, min_map_rate, 1, rows);
+		string err = scan_tumor_table(tumor_file, normal.clip3, normal.clip5, offset, min_map_rate, 1, rows);
 		if (!err.empty()) die(err);
 		ofstream jd(dump_lookups.c_str());
 		for (auto &row : rows) {
@@ -1478,12 +1483,16 @@ static int cmd_somatic(int argc, char **argv)
 		}
 		return 0;
 	}
+	std::thread loader(load);
+	struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{loader}; // (die() leaves through _exit; a return must not leave the thread behind)
 	ssv_ctx *ctx = nullptr;
-	if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
-	pt.lap("gpu_init");
+	auto get_ctx = [&] { if (!ctx) ctx = acquire_ctx(device); return ctx; }; // (main() started it)
 	int mean_insert_size = 0, deviation = 0;
-	if (read_pair_used >= 100000) insert_size_pass([ctx] { return ctx; }, normal_bam_file, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation);
-	pt.lap("isize_pass");
+	IsizeCarry carry;
+	string isize_report; // ReadsClipReads' warnings come first on the reference's stderr (seeksv.cpp:392-398): the lines wait for the loader
+	if (read_pair_used >= 100000) insert_size_pass(get_ctx, normal_bam_file, device_inflate, min_mapQ, read_pair_used, mean_insert_size, deviation, &carry, &isize_report);
+	get_ctx();
+	pt.lap("isize_pass (+ what was left of the context's start-up)");
 
 	ofstream fout(somatic_file.c_str());
 	if (!fout) die("Error: Cannot open output file " + somatic_file);
@@ -1491,10 +1500,10 @@ static int cmd_somatic(int argc, char **argv)
 	if (ssvh_bam_open(normal_bam_file.c_str(), &bam) != 0) die("[main_samview] fail to open file for reading.");
 	vector<SomaticRow> rows;
 	{
-		string err = scan_tumor_table(tumor_file, clip3, clip5, offset, min_map_rate, mean_insert_size, rows);
-		if (!err.empty()) die(err);
+		string err = parse_tumor_table(tumor_file, mean_insert_size, rows);
+		if (!err.empty()) { loader.join(); if (!load_err.empty()) die(load_err); cerr << load_warnings << isize_report; die(err); }
 	}
-	pt.lap("cluster_lookups");
+	pt.lap("tumor_table");
 
 	// every row that asks for FindDiscordantReadPairs (getsv.cpp:1123-1247) becomes one junction of a single pass over the normal BAM
 	vector<ssvh_junction_in> J;
@@ -1519,18 +1528,33 @@ static int cmd_somatic(int argc, char **argv)
 		gp.n_windows = 0; gp.depth_min_mapq = min_mapQ;
 		gp.n_targets = ssvh_bam_n_targets(bam); gp.target_len = ssvh_bam_target_lens(bam);
 		if (ssv_getsv_begin(ctx, &gp) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		BatchSource src; // a second handle: `bam` keeps serving the header
-		src.open(normal_bam_file, ctx, device_inflate, "[main_samview] fail to open file for reading.");
-		src.pump(0, [](const ssv_batch_t &) {}, [&](const ssv_batch_t &b) {
-			if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
-		});
-		src.close();
+		auto scan = [&](const ssv_batch_t &b) { if (ssv_getsv_scan(ctx, &b) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx)); };
+		if (carry.usable) { // the insert-size pass left its source open behind the chunks it read, whose batches are still valid: ONE reading of the file
+			for (auto &k : carry.kept) { scan(k); if (carry.owned) ssv_batch_release(ctx, &k); }
+			carry.kept.clear();
+			carry.src.pump(0, [](const ssv_batch_t &) {}, scan);
+			carry.src.close();
+			carry.usable = false;
+		} else {
+			BatchSource src; // a second handle: `bam` keeps serving the header
+			src.open(normal_bam_file, ctx, device_inflate, "[main_samview] fail to open file for reading.");
+			src.pump(0, [](const ssv_batch_t &) {}, scan);
+			src.close();
+		}
 		int32_t maxd = 0;
 		if (ssv_getsv_finish(ctx, counts.data(), nullptr, 0, nullptr, nullptr, 0, nullptr, &maxd) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(ctx));
 		vector<int32_t> prev(J.size() + 1, 0); // a row whose left contig is not in the normal's header reports 0
 		ssvh_plan_fold(plan, counts.data(), prev.data(), nullptr, nullptr, abnormal.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
 		ssvh_plan_destroy(plan);
 	}
+	if (carry.usable) { if (carry.owned) for (auto &k : carry.kept) ssv_batch_release(ctx, &k); carry.kept.clear(); carry.src.close(); carry.usable = false; }
+	pt.lap("discordant_pass");
+	loader.join();
+	if (!load_err.empty()) die(load_err);
+	cerr << load_warnings << isize_report;
+	pt.lap("normal_clusters (wait: read beside the passes)");
+	probe_normal_clusters(rows, normal.clip3, normal.clip5, offset, min_map_rate);
+	pt.lap("cluster_lookups");
 	pt.lap("discordant_pass");
 	size_t k = 0;
 	for (size_t r = 0; r < rows.size(); ++r) {
@@ -1547,8 +1571,9 @@ static int cmd_somatic(int argc, char **argv)
 		fout << row.text << '\t' << row.normal_left_reads << '\t' << row.normal_right_reads << '\t' << normal_abnormal << endl;
 	}
 	pt.lap("output");
-	ssv_ctx_destroy(ctx);
+	release_ctx(ctx);
 	ssvh_bam_close(bam);
+	pt.lap("teardown");
 	return 0;
 }
 

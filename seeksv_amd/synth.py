@@ -23,7 +23,7 @@ class SyConfig(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_total", C.c_int64), ("n_contigs", C.c_int32), ("read_len", C.c_int32),
                 ("contig_off", C.c_int64 * (MAX_CONTIGS + 1)), ("contig_len", C.c_int32 * MAX_CONTIGS), ("spacing_fp", C.c_uint64),
                 ("clip_permille", C.c_int32), ("indel_permille", C.c_int32), ("dup_permille", C.c_int32), ("sec_permille", C.c_int32),
-                ("improper_permille", C.c_int32), ("vaf_permille", C.c_int32), ("n_breakends", C.c_int32), ("qual_model", C.c_int32)]
+                ("improper_permille", C.c_int32), ("vaf_permille", C.c_int32), ("n_breakends", C.c_int32), ("qual_model", C.c_int32), ("unmap_permille", C.c_int32)]
 
 
 BREAKEND_DTYPE = np.dtype([("lin", np.int64), ("tid", np.int32), ("q", np.int32), ("ptid", np.int32), ("ppos", np.int32),
@@ -53,7 +53,7 @@ def _lib(gpu):
 class Workload:
     def __init__(self, genome_frac=1.0, depth=30.0, n_sv=10000, seed=SEED, read_len=150, clip_permille=10, indel_permille=20,
                  dup_permille=80, sec_permille=2, improper_permille=20, vaf_permille=500, n_contigs=24, min_contig=30000,
-                 hbv=False, n_integrations=0, qual_model=0):
+                 hbv=False, n_integrations=0, qual_model=0, unmap_permille=0):
         """hbv / n_integrations (BASELINE config 5, SURVEY 8d "C5"): a hybrid reference - the human contigs plus an `HBV` contig of 3,215 bp -
         and n_integrations planted human<->HBV junctions in all three orientations the junction model has, some of them within 200 bp of
         the HBV contig's ends (the unsigned-wrap flank windows of getsv.cpp:760-777).  A normal sample of the same patient is the same
@@ -86,6 +86,7 @@ class Workload:
         cfg.clip_permille, cfg.indel_permille, cfg.dup_permille = clip_permille, indel_permille, dup_permille
         cfg.sec_permille, cfg.improper_permille, cfg.vaf_permille = sec_permille, improper_permille, vaf_permille
         cfg.qual_model = int(qual_model)   # 0: five binned quality values; 1: forty (HiSeq-like)
+        cfg.unmap_permille = int(unmap_permille)   # pairs with one unmapped end (records 2k, 2k + 1): getclip's unmapped-pair side channel; host.write_bam gives both the name of 2k
         self.cfg = cfg
         self.max_ref_span = read_len + 8
         self._plant(n_sv, seed)

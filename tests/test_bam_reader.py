@@ -267,3 +267,45 @@ def test_writer_levels_without_zlib_give_the_same_records(tmp_path, level):
         assert digests[level][1] < 1.25 * digests["1"][1]   # string matching pays: close to zlib level 1's size
     names, lens, got = host.read_bam(str(tmp_path / f"l{level}.bam"))
     assert sum(len(b["tid"]) for b in got) == w.n_total
+
+
+def test_generator_pairs_with_an_unmapped_end_reach_the_side_channel(tmp_path):
+    """synth_core.h's unmap_permille: records 2k / 2k + 1 as (mapped read with MUNMAP, unmapped mate), both named after 2k by the writer; the reader hands them
+    over raw (ssvh_bam_unmapped_raw, the form the device decoder uses) and decoded - the same records either way, in file order"""
+    import ctypes as C
+    from seeksv_amd import _abi, synth
+    w = synth.Workload(genome_frac=1 / 8192, depth=30, n_sv=4, unmap_permille=25)
+    b = w.generate_host(0, w.n_total, all_seq=True)
+    un = np.nonzero(b["flag"] & 12)[0]
+    assert len(un) > 100 and len(un) % 2 == 0 and (un[0::2] % 2 == 0).all() and (un[1::2] == un[0::2] + 1).all()
+    assert ((b["flag"][un[0::2]] & 0x4c) == 0x48).all() and ((b["flag"][un[1::2]] & 0x8c) == 0x84).all()
+    assert (np.diff(b["pos"].astype(np.int64) + (b["tid"].astype(np.int64) << 32)) >= 0).all()   # still coordinate sorted
+    w0 = synth.Workload(genome_frac=1 / 8192, depth=30, n_sv=4)
+    b0 = w0.generate_host(0, w0.n_total)
+    rest = np.setdiff1d(np.arange(w.n_total), un)
+    for k in ("tid", "pos", "flag", "mapq", "mpos", "isize"):
+        assert np.array_equal(b[k][rest], b0[k][rest]), k   # the other records are the workload without them
+    bam = str(tmp_path / "u.bam")
+    host.write_bam(bam, w.names, w.lens, [b])
+    lib = _abi.host_lib()
+    lib.ssvh_bam_unmapped_raw.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.ssvh_raw_record_fastq.restype = C.c_size_t
+    seen = []
+    with host.BamReader(bam) as r:
+        while r.read_batch(777) is not None:
+            dec = r.unmapped()
+            raw, nbytes = C.c_void_p(), C.c_size_t()
+            assert lib.ssvh_bam_unmapped_raw(r.handle, C.byref(raw), C.byref(nbytes)) == 0
+            off, k = 0, 0
+            q, s, u, r1 = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_int()
+            while nbytes.value:
+                nxt = lib.ssvh_raw_record_fastq(raw, nbytes, C.c_size_t(off), C.byref(q), C.byref(s), C.byref(u), C.byref(r1))
+                if not nxt:
+                    break
+                assert (q.value.decode(), s.value.decode(), u.value.decode(), bool(r1.value)) == dec[k]
+                off, k = nxt, k + 1
+            assert k == len(dec)
+            seen += dec
+    assert len(seen) == len(un)
+    assert [x[0] for x in seen] == [f"s{g & ~1}" for g in un]
+    assert all(a[3] and not c[3] for a, c in zip(seen[0::2], seen[1::2]))

@@ -161,3 +161,25 @@ def test_cli_getclip_equals_reference_on_random_samples(tmp_path, seed, mode):
         assert o.returncode == 0, o.stderr[-300:]
         for ext in ("clip.gz", "clip.fq.gz", "unmapped_1.fq.gz", "unmapped_2.fq.gz"):
             assert gzip.open(str(tmp_path / f"our{tag}.{ext}")).read() == gzip.open(str(tmp_path / f"ref{tag}.{ext}")).read(), (seed, tag, ext)
+
+
+@pytest.mark.parametrize("mode,env", [([], {}), (["-Z"], {}), (["-Z"], {"SSV_CHUNK_INFLATED_MB": "1"}), ([], {"SSV_HOST_BATCH_RECORDS": "997"})], ids=["host", "device", "device-small-chunks", "host-small-batches"])
+def test_cli_getclip_unmapped_pairs_of_the_synthetic_sample(tmp_path, mode, env):
+    """The generator's pairs with one unmapped end (synth_core.h: unmap_permille, 3 % here) through `seeksv getclip`: the side channel (unmapped_pairs.h: a
+    thread of its own over the readers' raw records) writes what the reference's std::map loop writes (clip_reads.h:172-219), mates a batch apart included."""
+    from seeksv_amd import synth
+    w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, unmap_permille=30)
+    b = w.generate_host(0, w.n_total, all_seq=True)
+    n_un = int(((b["flag"] & 12) != 0).sum())
+    assert 0.02 * w.n_total < n_un < 0.04 * w.n_total and n_un % 2 == 0
+    bam = str(tmp_path / "u.bam")
+    host.write_bam(bam, w.names, w.lens, [b])
+    r = subprocess.run([REF, "getclip", "-o", str(tmp_path / "ref"), bam], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    o = subprocess.run([SEEKSV, "getclip"] + mode + ["-o", str(tmp_path / "our"), bam], capture_output=True, text=True, env=dict(os.environ, **env))
+    assert o.returncode == 0, o.stderr[-300:]
+    for ext in ("clip.gz", "clip.fq.gz", "unmapped_1.fq.gz", "unmapped_2.fq.gz"):
+        want = gzip.open(str(tmp_path / f"ref.{ext}")).read()
+        assert gzip.open(str(tmp_path / f"our.{ext}")).read() == want, ext
+        if ext.startswith("unmapped"):
+            assert want.count(b"\n") == 4 * (n_un // 2)
