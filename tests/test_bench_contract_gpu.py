@@ -20,7 +20,7 @@ def _line(out):
 
 
 def test_bench_line_contract():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "3", "--warmup", "1", "--cpu-sample", "300000", "--ref-sample", "0"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "3", "--warmup", "1", "--cpu-sample", "300000", "--ref-sample", "0", "--config5-frac", "0.0009765625"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-600:]
     d = _line(r.stdout)
@@ -49,6 +49,11 @@ def test_bench_line_contract():
     c3 = d.get("config3_path", {})
     assert "error" not in c3, c3
     assert c3["value"] > 0 and c3["device_kernels_ms"] > 0 and c3["records"] > 0
+    # BASELINE config 5 through the product (tumor + normal on a human + HBV reference, pairs with an unmapped end): every planted integration is called, and called somatic
+    c5 = d.get("config5_path", {})
+    assert "error" not in c5, c5
+    assert c5["viral_planted"] > 0 and c5["viral_somatic"] == c5["viral_found"] >= c5["viral_planted"] - 2, c5
+    assert c5["germline_called_somatic"] * 10 <= c5["germline_found"] and c5["normal_unmapped_pairs_written"] > 0 and c5["somatic_s"] > 0 and c5["normal_cluster_rows"] > 0
     assert "traffic_source" in rf and ("profiles/traffic.json" in rf["traffic_source"])
     assert (rf["traffic"] is None) == rf["traffic_source"].startswith("none")
 
@@ -72,18 +77,40 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_line():
 
 
 def test_bench_two_ranks_equal_one():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    """`python bench.py --gpus 2` with no RANK in the environment starts its two ranks itself (torch.distributed.run as a child process, before the parent
+    touches the GPU) and relays rank 0's line - what the driver's `--gpus N` command does on an 8-GPU node; same counts as one rank on the same total
+    workload; ranks_path (the PRODUCT's `-N 2` on a file, its own exchange) is in the line and equals the product's one-rank outputs"""
     env = dict(os.environ, SSV_FORCE_DEVICE="0", SSV_DIST_BACKEND="gloo")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0, r2.stderr[-800:]
     a = _line(r2.stdout)
-    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--genome-frac", "0.00390625", "--n-sv", "200", "--depth", "60", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--genome-frac", "0.00390625", "--n-sv", "200", "--depth", "60", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--config5-frac", "0"],
                         capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-600:]
     b = _line(r1.stdout)
     assert a["n_gpus"] == 2 and a["config"]["records_total"] == b["config"]["records_total"]
     assert a["result"] == b["result"]
+    rp = a.get("ranks_path", {})
+    assert "error" not in rp, rp
+    assert rp["same_outputs_as_one_rank"] is True and rp["ranks"]["ranks"] == 2 and rp["one_rank"]["ranks"] == 1 and rp["value"] > 0
+    assert "exchange over" in (rp["ranks"]["exchange"] or ""), rp["ranks"]
+    assert "ranks_path" in a["config"]["multi_gpu"]
+
+
+def test_bench_eight_forced_ranks_strong_scaling_dry_run():
+    """the 8-GPU day's command, `python bench.py --gpus 8 --scaling strong`, as a dry run: eight ranks forced onto the one GPU of the box (gloo), a small
+    sample split eight ways: one line, n_gpus 8, strong"""
+    env = dict(os.environ, SSV_FORCE_DEVICE="0", SSV_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scaling", "strong", "--strong-depth", "60", "--genome-frac", "0.00390625", "--n-sv", "200", "--steps", "2", "--warmup", "1",
+                        "--ranks-frac", "0.5"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    a = _line(r.stdout)
+    assert a["n_gpus"] == 8 and a["scaling"] == "strong" and a["config"]["records_per_gpu"] * 7 < a["config"]["records_total"]
+    assert a["ranks_path"]["same_outputs_as_one_rank"] is True and a["ranks_path"]["ranks"]["ranks"] == 8
 
 
 def test_bench_strong_scaling_two_ranks_equal_one():

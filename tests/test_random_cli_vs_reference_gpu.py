@@ -167,7 +167,7 @@ def test_cli_getclip_equals_reference_on_random_samples(tmp_path, seed, mode):
 def test_cli_getclip_unmapped_pairs_of_the_synthetic_sample(tmp_path, mode, env):
     """The generator's pairs with one unmapped end (synth_core.h: unmap_permille, 3 % here) through `seeksv getclip`: the side channel (unmapped_pairs.h: a
     thread of its own over the readers' raw records) writes what the reference's std::map loop writes (clip_reads.h:172-219), mates a batch apart included."""
-    from seeksv_amd import synth
+    from seeksv_amd import host, synth
     w = synth.Workload(genome_frac=1 / 4096, depth=30, n_sv=12, unmap_permille=30)
     b = w.generate_host(0, w.n_total, all_seq=True)
     n_un = int(((b["flag"] & 12) != 0).sum())
