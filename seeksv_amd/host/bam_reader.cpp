@@ -1062,8 +1062,8 @@ int ssvh_bam_next_record(ssvh_bam *b, ssvh_record *out)
 
 // ---- BAM writer (tooling) ----
 
-// deflate level of the BAM writer: 1 (fast; the CLI's clip.bam and the tests' fixtures) unless SSV_BGZF_LEVEL says otherwise (bench.py's file leg
-// writes level 6, samtools' default: real BAM files are what that leg stands for)
+// deflate level of the BAM writer: 1 (fast; the tests' fixtures) unless SSV_BGZF_LEVEL says otherwise (bench.py's file legs: 6, samtools' default, where
+// >= 64 CPUs write the file; -2 where 16 CPUs have to write a whole-genome sample - the line's `coder` field says which)
 // -1: no zlib at all - a block's payload is one literal-only Huffman block (huff_gz.h; what `seeksv realign` writes its clip.bam with unless the
 // variable says otherwise: 5.5 M short records that are read back once, by the next command)
 // -2: the same with string matching of the cheapest kind (huff_gz.h: deflate_fast; bench.py's whole-genome file where 16 CPUs have to write it)

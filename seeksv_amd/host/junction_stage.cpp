@@ -39,7 +39,7 @@ namespace {
 // sample, nearly always unequal: two hashes (computed where the text is parsed anyway, by all threads) settle that without touching 2.5 GB of text
 // on the one thread the join runs on; equal hashes are confirmed by comparing the text.
 static inline uint64_t text_hash(const char *p, size_t n)
-{
+{ // (also clip_text_hash below)
 	uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
 	size_t i = 0;
 	for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
@@ -215,6 +215,8 @@ void flush_group(const std::vector<ClipRow> &rows, AlignMap &aligns, JunctionMap
 }
 
 } // namespace
+
+uint64_t clip_text_hash(const char *p, size_t n) { return text_hash(p, n); }
 
 double match_end_first(const std::string &a, const std::string &b) // CompareStringEndFirst, clip_reads.cpp:194
 {
@@ -431,18 +433,14 @@ bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow
 	return true;
 }
 
-static std::string assemble_junctions_view(const std::vector<TextView> &texts, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o);
-static std::vector<TextView> views_of(const std::vector<std::string> &pieces)
-{
-	std::vector<TextView> v;
-	for (const std::string &p : pieces) v.push_back(TextView{p.data(), p.size()});
-	return v;
-}
-std::string assemble_junctions_text(const std::vector<std::string> &text, const std::string &clip_bam, JunctionMap &j2o) { return assemble_junctions_view(views_of(text), clip_bam, nullptr, j2o); }
-std::string assemble_junctions_records(const std::vector<std::string> &text, const AlnRecords &aln, JunctionMap &j2o) { return assemble_junctions_view(views_of(text), "", &aln, j2o); }
+typedef std::vector<const std::vector<ClipRow> *> RowParts;
+static std::string assemble_junctions_view(const std::vector<TextView> &texts, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o, const RowParts *pre = nullptr);
+std::string assemble_junctions_text(const std::vector<TextView> &text, const std::string &clip_bam, JunctionMap &j2o) { return assemble_junctions_view(text, clip_bam, nullptr, j2o); }
+std::string assemble_junctions_records(const std::vector<TextView> &text, const AlnRecords &aln, JunctionMap &j2o) { return assemble_junctions_view(text, "", &aln, j2o); }
+std::string assemble_junctions_rows(const RowParts &rows, const AlnRecords &aln, JunctionMap &j2o) { return assemble_junctions_view(std::vector<TextView>(), "", &aln, j2o, &rows); }
 
-// texts: the rows in file order, every piece whole rows
-static std::string assemble_junctions_view(const std::vector<TextView> &texts, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o)
+// texts: the rows in file order, every piece whole rows; pre: the rows as their writer kept them (no text to parse)
+static std::string assemble_junctions_view(const std::vector<TextView> &texts, const std::string &clip_bam, const AlnRecords *mem, JunctionMap &j2o, const RowParts *pre)
 {
 	RecSource source;
 	source.mem = mem;
@@ -489,7 +487,10 @@ static std::string assemble_junctions_view(const std::vector<TextView> &texts, c
 	std::deque<std::string> store; // (the rows are views: what the stream loop below extracts lives here until the join is over - the last group is flushed at the end)
 	const bool timing = getenv("SSV_TIMING") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
-	if (parse_rows_parallel(texts, parsed)) {
+	if (pre) {
+		for (const std::vector<ClipRow> *part : *pre) for (const ClipRow &r : *part) { ClipRow row = r; if (!on_row(row)) return failure; }
+		if (timing) std::cerr << "[timing] (junction stage: rows as their writer kept them, joined with the re-alignments in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s)" << std::endl;
+	} else if (parse_rows_parallel(texts, parsed)) {
 		const auto t1 = std::chrono::steady_clock::now();
 		for (auto &row : parsed) if (!on_row(row)) return failure;
 		if (timing) std::cerr << "[timing] (junction stage: " << parsed.size() << " rows parsed in " << std::chrono::duration<double>(t1 - t0).count() << " s, joined with clip.bam in "

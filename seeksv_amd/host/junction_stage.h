@@ -65,7 +65,7 @@ bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow
 
 // InputSoftInfoStoreBreakpoint (getsv.h:423-541) + GetAlignInfo (getsv.cpp:25) + GetJunction (getsv.cpp:1705).  Returns "" or an error text.
 std::string assemble_junctions(const std::string &clipfile, const std::string &clip_bam, JunctionMap &junction2other);
-std::string assemble_junctions_text(const std::vector<std::string> &clip_rows, const std::string &clip_bam, JunctionMap &junction2other); // the rows of clip.gz in memory, in pieces of whole rows
+std::string assemble_junctions_text(const std::vector<TextView> &clip_rows, const std::string &clip_bam, JunctionMap &junction2other); // the rows of clip.gz in memory, in pieces of whole rows
 // ... and the re-alignments too (`seeksv run`: the aligner step has just made them): what ssvh_bam_next_record would hand out for clip.bam, record by
 // record in its order - only the fields GetAlignInfo looks at (getsv.cpp:25-71)
 struct AlnRecords {
@@ -77,7 +77,11 @@ struct AlnRecords {
 	const char *const *qname = nullptr;
 	std::vector<std::string> target_names;
 };
-std::string assemble_junctions_records(const std::vector<std::string> &clip_rows, const AlnRecords &aln, JunctionMap &junction2other);
+std::string assemble_junctions_records(const std::vector<TextView> &clip_rows, const AlnRecords &aln, JunctionMap &junction2other);
+// ... and the rows as the process that wrote clip.gz kept them (views into the text it wrote, h = clip_text_hash(clipped_seq)): nothing to parse.  Only for
+// rows the text parser would split the same way - nine non-empty fields without white space (the caller checks while it writes them).
+std::string assemble_junctions_rows(const std::vector<const std::vector<ClipRow> *> &rows, const AlnRecords &aln, JunctionMap &junction2other);
+uint64_t clip_text_hash(const char *p, size_t n);
 // MergeJunction, getsv.cpp:1325-1482
 void merge_junctions(JunctionMap &junction2other, int search_length);
 

@@ -246,20 +246,23 @@ struct ResidentBam {
 	vector<ssv_batch_t> batches; // in file order
 	// what getclip wrote, still in memory for the steps that follow (the files are written all the same: they are outputs)
 	string clip_path, fq_path;   // prefix.clip.gz, prefix.clip.fq.gz
-	vector<string> clip_rows, fq_text; // their decompressed contents, in the pieces the formatting threads made (whole rows / whole records each; never glued
-	                                   // together: appending 2.5 GB to one string on one thread was a second of `seeksv run`)
-	// what the aligner step made of fq_text (clip.bam is written all the same); the read names point into fq_text
+	// their decompressed contents, in the pieces the formatting threads made (whole rows / whole records each; never glued together: appending 2.5 GB to
+	// one string on one thread was a second of `seeksv run`) - and, since round 6, what the formatter knew while it wrote them: every row as views into
+	// its text (the junction stage parsed 5.5 M rows back out of it: 0.35 s) and where every FASTQ record's sequence and qualities lie (the aligner
+	// step cut the text into lines again: 0.2 s).  `clean`: every row is what the text parser would make of it (nine non-empty fields, no white space).
+	struct FqRef { uint32_t seq_off, seq_len, qual_off, qual_len; };
+	struct Piece { string rows, fq; vector<seeksv::ClipRow> parsed; vector<FqRef> reads; bool clean = true; };
+	std::deque<Piece> pieces;    // (a deque: a piece never moves, the views stay good)
+	std::function<void(const vector<Piece *> &)> on_pass; // called by getclip's output thread with the pieces of the pass it has just written
+	bool all_clean() const { for (const Piece &p : pieces) if (!p.clean) return false; return true; }
+	vector<seeksv::TextView> row_views() const { vector<seeksv::TextView> v; for (const Piece &p : pieces) v.push_back(seeksv::TextView{p.rows.data(), p.rows.size()}); return v; }
+	// what the aligner step made of the clipped sequences (clip.bam is written all the same); the read names point into the pieces' FASTQ text
 	struct Aligned {
 		string bam_path;
-		vector<int32_t> tid, pos;
-		vector<uint16_t> flag, n_cigar;
-		vector<uint8_t> mapq;
-		vector<uint32_t> cigar_off, cigar;
-		vector<const char *> qname;
+		const struct AlignedRecords *rec = nullptr; // (the run's aligner thread owns them)
 		vector<string> names;
 	} aln;
 	std::thread bam_writer;      // clip.bam of `seeksv run`, written beside getsv
-	string bam_writer_err;
 };
 static ResidentBam g_resident;
 
@@ -674,7 +677,9 @@ static int device_of_rank(int r, const vector<int> &devices)
 // SSV_TABLE_FORMAT=0..3 picks another wire format for the cluster table (the text written is the same)
 static int table_format_default() { return 3; }
 
-static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k0, int64_t k1, string &row, string &fq)
+// where a row's fields lie in the text (offsets: the strings still grow)
+struct RowAt { uint32_t row, chr_len, cigar, cigar_len, aligned, aligned_len, clipped, clipped_len, cqual, cqual_len, fq; int32_t pos, support; char side; };
+static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k0, int64_t k1, string &row, string &fq, vector<RowAt> *index = nullptr)
 {
 		row.reserve(row.size() + (size_t)(k1 - k0) * 480); fq.reserve(fq.size() + (size_t)(k1 - k0) * 200);
 		char num[16];
@@ -725,14 +730,24 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 			} else { sl = (const char *)s; ql = sl + ll; sr = sl + 2 * ll; qr = sl + 2 * ll + lr; }
 			size_t lql = ll, lqr = lr;
 			if (t.qual_missing[k]) { ql = qr = "*"; lql = lqr = 1; }
+			RowAt at;
+			at.row = (uint32_t)row.size(); at.fq = (uint32_t)fq.size(); at.pos = t.pos[k]; at.support = t.support[k]; at.side = (char)t.side[k];
 			row += name ? name : ""; row += '\t';
+			at.chr_len = (uint32_t)row.size() - 1 - at.row;
 			row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.pos[k])); row += '\t'; row += (char)t.side[k]; row += '\t';
+			at.cigar = (uint32_t)row.size();
 			for (int q = 0; q < t.n_cigar[k]; ++q) {
 				const uint32_t op = t.cigar ? t.cigar[t.cigar_off[k] + q] : (uint32_t)reinterpret_cast<const uint16_t *>(t.c_cigar)[t.cigar_off[k] + q]; // (compact table: 16 bits an operation)
 				if ((op & 15) == 4 || (op & 15) == 5) continue;
 				row.append(num, (size_t)snprintf(num, sizeof(num), "%u", op >> 4)); row += CIGAR_CHARS[op & 15];
 			}
+			at.cigar_len = (uint32_t)row.size() - at.cigar;
 			row += '\t';
+			at.aligned = (uint32_t)row.size();
+			if (t.side[k] == '5') { at.aligned_len = (uint32_t)lr; at.clipped = at.aligned + (uint32_t)(lr + 1 + lqr + 1); at.clipped_len = (uint32_t)ll; at.cqual_len = (uint32_t)lql; }
+			else { at.aligned_len = (uint32_t)ll; at.clipped = at.aligned + (uint32_t)(ll + 1 + lql + 1); at.clipped_len = (uint32_t)lr; at.cqual_len = (uint32_t)lqr; }
+			at.cqual = at.clipped + at.clipped_len + 1;
+			if (index) index->push_back(at);
 			if (t.side[k] == '5') {
 				row.append(sr, lr); row += '\t'; row.append(qr, lqr); row += '\t'; row.append(sl, ll); row += '\t'; row.append(ql, lql);
 				fq += '@'; fq.append(sl, ll); fq += '\n'; fq.append(sl, ll); fq += "\n+\n"; fq.append(ql, lql); fq += '\n';
@@ -742,6 +757,27 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 			}
 			row += '\t'; row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.support[k])); row += '\n';
 		}
+}
+
+// `seeksv run`: a formatted piece's rows and FASTQ records as views into its text (the strings do not change any more)
+static void index_piece(ResidentBam::Piece &p, const vector<RowAt> &ix)
+{
+	auto has_space = [](const char *q, size_t n) { for (size_t i = 0; i < n; ++i) if ((unsigned char)q[i] <= ' ') return true; return false; };
+	const char *r = p.rows.data();
+	p.parsed.reserve(ix.size()); p.reads.reserve(ix.size());
+	if (p.rows.size() >= 0xffffffffull || p.fq.size() >= 0xffffffffull) p.clean = false;
+	for (const RowAt &a : ix) {
+		seeksv::ClipRow row;
+		row.chr = seeksv::Str{r + a.row, a.chr_len}; row.pos = a.pos; row.side = a.side; row.cigar = seeksv::Str{r + a.cigar, a.cigar_len};
+		row.aligned_seq = seeksv::Str{r + a.aligned, a.aligned_len}; row.clipped_seq = seeksv::Str{r + a.clipped, a.clipped_len}; row.clipped_qual = seeksv::Str{r + a.cqual, a.cqual_len};
+		row.support = a.support;
+		row.h = seeksv::clip_text_hash(row.clipped_seq.p, row.clipped_seq.n);
+		// what `fin >> chr >> pos >> ...` (getsv.h:441-446) makes of the row's text: the same nine fields, unless one is empty or holds white space
+		if (!a.chr_len || !a.cigar_len || !a.aligned_len || !a.clipped_len || !a.cqual_len || has_space(row.chr.p, row.chr.n)) p.clean = false;
+		p.parsed.push_back(row);
+		// the record's FASTQ text: '@' name '\n' sequence "\n+\n" qualities '\n' (clip_reads.h:320-321) - name = sequence
+		p.reads.push_back(ResidentBam::FqRef{a.fq + 1 + a.clipped_len + 1, a.clipped_len, a.fq + 1 + a.clipped_len + 1 + a.clipped_len + 3, a.cqual_len});
+	}
 }
 
 static int getclip_ranks(const string &bamfile, const string &prefix, double threshold, int min_mapQ, bool save_low_quality, int n_ranks, const vector<int> &devices, int halo_bp, bool device_inflate);
@@ -840,9 +876,11 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 			const auto t0 = std::chrono::steady_clock::now();
 			const int n_fmt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 32, k_end / 4096}));
 			vector<string> rows((size_t)n_fmt), fqs((size_t)n_fmt);
+			const bool keep = g_resident.collect && g_resident.ctx == ctx; // `seeksv run`: the aligner step and the junction stage take these from memory
+			vector<vector<RowAt>> index(keep ? (size_t)n_fmt : 0);
 			auto format_range = [&](int w) {
 				const int64_t k0 = k_end * w / n_fmt, k1 = k_end * (w + 1) / n_fmt;
-				format_clusters(t, bam, k0, k1, rows[(size_t)w], fqs[(size_t)w]);
+				format_clusters(t, bam, k0, k1, rows[(size_t)w], fqs[(size_t)w], keep ? &index[(size_t)w] : nullptr);
 			};
 			{
 				vector<std::thread> th;
@@ -852,10 +890,23 @@ static int getclip_single(const string &bamfile, const string &prefix, double th
 			}
 			const auto t1 = std::chrono::steady_clock::now();
 			softfout.write_parts(rows); fqfout.write_parts(fqs);
-			if (g_resident.collect && g_resident.ctx == ctx) { // `seeksv run`: the aligner step and the junction stage read these from memory
+			if (keep) {
 				g_resident.clip_path = f_clip; g_resident.fq_path = f_fq;
-				for (auto &r : rows) if (!r.empty()) g_resident.clip_rows.push_back(std::move(r));
-				for (auto &r : fqs) if (!r.empty()) g_resident.fq_text.push_back(std::move(r));
+				vector<ResidentBam::Piece *> fresh;
+				vector<vector<RowAt> *> fresh_index;
+				for (int w = 0; w < n_fmt; ++w) if (!rows[(size_t)w].empty()) {
+					g_resident.pieces.emplace_back();
+					ResidentBam::Piece &p = g_resident.pieces.back();
+					p.rows = std::move(rows[(size_t)w]); p.fq = std::move(fqs[(size_t)w]);
+					fresh.push_back(&p); fresh_index.push_back(&index[(size_t)w]);
+				}
+				{ // views and hashes, by as many threads as formatted (5.5 M rows of a whole-genome sample in all)
+					vector<std::thread> th;
+					for (size_t k = 1; k < fresh.size(); ++k) th.emplace_back([&, k] { index_piece(*fresh[k], *fresh_index[k]); });
+					if (!fresh.empty()) index_piece(*fresh[0], *fresh_index[0]);
+					for (auto &x : th) x.join();
+				}
+				if (g_resident.on_pass) g_resident.on_pass(fresh); // the aligner step starts on this pass's clipped sequences while the next pass is read
 			}
 			emit_format_s += std::chrono::duration<double>(t1 - t0).count();
 			emit_gzip_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
@@ -1119,6 +1170,8 @@ static void insert_size_pass(const std::function<ssv_ctx *()> &get_ctx, const st
 	src.close();
 }
 
+static void resident_alignments(seeksv::AlnRecords &R); // `seeksv run`: the aligner step's records as the join reads them
+
 static int cmd_getsv(int argc, char **argv)
 {
 	string connect_bam, temp_breakpoint, dump_junctions;
@@ -1181,13 +1234,15 @@ static int cmd_getsv(int argc, char **argv)
 	}
 	{ // InputSoftInfoStoreBreakpoint + GetJunction (getsv.h:423, getsv.cpp:1705): clip clusters x re-alignments of their clipped sequences
 		string err;
-		if (g_resident.ctx && clipfile == g_resident.clip_path && clip_bam == g_resident.aln.bam_path) {
-			const auto &A = g_resident.aln; // rows and alignments are both still in memory
-			seeksv::AlnRecords R;
-			R.n = (int64_t)A.tid.size(); R.tid = A.tid.data(); R.pos = A.pos.data(); R.flag = A.flag.data(); R.n_cigar = A.n_cigar.data(); R.mapq = A.mapq.data();
-			R.cigar_off = A.cigar_off.data(); R.cigar = A.cigar.data(); R.qname = A.qname.data(); R.target_names = A.names;
-			err = seeksv::assemble_junctions_records(g_resident.clip_rows, R, junction2other);
-		} else err = g_resident.ctx && clipfile == g_resident.clip_path ? seeksv::assemble_junctions_text(g_resident.clip_rows, clip_bam, junction2other)
+		if (g_resident.ctx && clipfile == g_resident.clip_path && clip_bam == g_resident.aln.bam_path && g_resident.aln.rec) {
+			seeksv::AlnRecords R; // rows and alignments are both still in memory
+			resident_alignments(R);
+			if (g_resident.all_clean() && !getenv("SSV_RUN_PARSE_ROWS")) { // the rows as the formatter kept them: nothing is parsed (SSV_RUN_PARSE_ROWS, tests: the text is)
+				vector<const vector<seeksv::ClipRow> *> parts;
+				for (const auto &p : g_resident.pieces) parts.push_back(&p.parsed);
+				err = seeksv::assemble_junctions_rows(parts, R, junction2other);
+			} else err = seeksv::assemble_junctions_records(g_resident.row_views(), R, junction2other);
+		} else err = g_resident.ctx && clipfile == g_resident.clip_path ? seeksv::assemble_junctions_text(g_resident.row_views(), clip_bam, junction2other)
 		                                                                : seeksv::assemble_junctions(clipfile, clip_bam, junction2other);
 		if (!err.empty()) die(err);
 	}
@@ -1705,20 +1760,11 @@ struct PrereadFasta {
 };
 static PrereadFasta &g_preread = *new PrereadFasta; // (never destroyed: die() may exit while its thread runs)
 
-static int cmd_realign(int argc, char **argv)
+// the reference: names, lengths, 2-bit bases (anything but ACGT becomes a position-dependent pseudo-random base, like bwa's index)
+struct Reference { vector<string> names; vector<int32_t> lens; vector<int64_t> offs = vector<int64_t>(1, 0); vector<uint64_t> words; };
+static void read_reference(const string &fasta, Reference &R)
 {
-	int gpu = 0, c;
-	while ((c = getopt(argc, argv, "G:")) != -1) {
-		if (c == 'G') gpu = atoi(optarg); else usage_realign();
-	}
-	if (argc - optind != 3) usage_realign();
-	const string fasta = argv[optind], fq = argv[optind + 1], out_bam = argv[optind + 2];
-	PhaseTimer pt;
-	// ---- reference: names, lengths, 2-bit bases (anything but ACGT becomes a position-dependent pseudo-random base, like bwa's index) ----
-	vector<string> names;
-	vector<int32_t> lens;
-	vector<int64_t> offs(1, 0);
-	vector<uint64_t> words;
+	vector<string> &names = R.names; vector<int32_t> &lens = R.lens; vector<int64_t> &offs = R.offs; vector<uint64_t> &words = R.words;
 	const bool fasta_check = getenv("SSV_FASTA_CHECK") != nullptr; // (tests: the serial reader runs too and must agree)
 	vector<string> p_names; vector<int32_t> p_lens; vector<int64_t> p_offs(1, 0); vector<uint64_t> p_words;
 	bool parsed;
@@ -1761,18 +1807,142 @@ static int cmd_realign(int argc, char **argv)
 		words.push_back(0);
 	}
 	if (parsed && fasta_check && (names != p_names || lens != p_lens || offs != p_offs || words != p_words)) die("[seeksv] SSV_FASTA_CHECK: the parallel FASTA reader disagrees with the serial one");
+}
+
+// clip.bam's records as arrays (read name = sequence as given; SEQ / QUAL reverse-complemented / reversed for reverse-strand hits)
+struct Line { char *p; int n; }; // a NUL-terminated line of FASTQ text, where it lies
+struct AlignedRecords {
+	vector<int32_t> tid, pos, lq, mtid, mpos, isz;
+	vector<uint16_t> flag, ncig;
+	vector<uint8_t> mapq, seqqual;
+	vector<uint32_t> cig_off, cig;
+	vector<uint64_t> seq_off;
+	vector<const char *> qn;
+	int64_t n_aligned = 0;
+	int64_t size() const { return (int64_t)tid.size(); }
+};
+// the sequences through the aligner (ssv_realign_query) and their records appended to `out`
+static void align_lines(ssv_ctx *ctx, const vector<Line> &seqs, const vector<Line> &quals, AlignedRecords &out)
+{
+	const int64_t n = (int64_t)seqs.size();
+	if (!n) return;
+	string blob;
+	vector<uint64_t> soff(1, 0);
+	{
+		size_t total = 0;
+		for (const Line &q : seqs) total += (size_t)q.n;
+		blob.reserve(total);
+		soff.reserve(seqs.size() + 1);
+		for (const Line &q : seqs) { blob.append(q.p, (size_t)q.n); soff.push_back(blob.size()); }
+	}
+	vector<ssv_realign_hit> hits((size_t)n);
+	if (ssv_realign_query(ctx, blob.data(), soff.data(), n, hits.data()) != SSV_OK) die(string("[seeksv] realign query: ") + ssv_last_error(ctx));
+	const size_t at = (size_t)out.size();
+	for (auto *v : {&out.tid, &out.pos, &out.lq}) v->resize(at + (size_t)n);
+	out.mtid.resize(at + (size_t)n, -1); out.mpos.resize(at + (size_t)n, -1); out.isz.resize(at + (size_t)n, 0);
+	out.flag.resize(at + (size_t)n); out.ncig.resize(at + (size_t)n); out.mapq.resize(at + (size_t)n); out.cig_off.resize(at + (size_t)n); out.seq_off.resize(at + (size_t)n); out.qn.resize(at + (size_t)n);
+	int32_t *tid = out.tid.data() + at, *pos = out.pos.data() + at, *lq = out.lq.data() + at;
+	uint16_t *flag = out.flag.data() + at, *ncig = out.ncig.data() + at;
+	uint8_t *mapq = out.mapq.data() + at;
+	uint32_t *cig_off = out.cig_off.data() + at;
+	uint64_t *seq_off = out.seq_off.data() + at;
+	const char **qn = out.qn.data() + at;
+	auto code4 = [](char ch) -> uint8_t {
+		switch (ch) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4; case 'T': case 't': return 8; default: return 15; }
+	};
+	auto comp4 = [](uint8_t b) -> uint8_t { return (uint8_t)(((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3)); };
+	// sizes first (CIGAR operations and packed bytes per record, running sums), then every host thread fills its share of the records
+	{
+		uint64_t so = out.seqqual.size();
+		uint32_t co = (uint32_t)out.cig.size();
+		for (int64_t i = 0; i < n; ++i) {
+			const ssv_realign_hit &h = hits[(size_t)i];
+			const int L = seqs[(size_t)i].n;
+			const bool al = h.tid >= 0;
+			out.n_aligned += al ? 1 : 0;
+			cig_off[i] = co; seq_off[i] = so;
+			ncig[i] = (uint16_t)(al ? 1 + (h.q_beg > 0 ? 1 : 0) + (h.q_end < L ? 1 : 0) : 0);
+			co += ncig[i]; so += ((uint64_t)L + 1) / 2 + (uint64_t)L;
+		}
+		out.cig.resize(co, 0);
+		out.seqqual.resize(so, 0);
+	}
+	uint32_t *const cig = out.cig.data();
+	uint8_t *const seqqual = out.seqqual.data();
+	{
+		const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 64, n / 4096}));
+		auto fill = [&](int w) {
+			for (int64_t i = n * w / nt, e = n * (w + 1) / nt; i < e; ++i) {
+				const ssv_realign_hit &h = hits[(size_t)i];
+				const char *s = seqs[(size_t)i].p, *q = quals[(size_t)i].p;
+				const int L = seqs[(size_t)i].n;
+				const bool al = h.tid >= 0, rev = al && h.reverse, has_q = quals[(size_t)i].n == L;
+				qn[i] = s;
+				tid[i] = al ? h.tid : -1; pos[i] = al ? h.pos : -1; lq[i] = L;
+				flag[i] = (uint16_t)(al ? (rev ? 16 : 0) : 4); mapq[i] = al ? h.mapq : 0;
+				if (al) {
+					uint32_t *c = cig + cig_off[i];
+					if (h.q_beg > 0) *c++ = ((uint32_t)h.q_beg << 4) | 4u;
+					*c++ = ((uint32_t)(h.q_end - h.q_beg) << 4) | 0u;
+					if (h.q_end < L) *c++ = ((uint32_t)(L - h.q_end) << 4) | 4u;
+				}
+				uint8_t *sp = seqqual + seq_off[i], *qp = sp + ((size_t)L + 1) / 2;
+				for (int k = 0; k < L; ++k) {
+					const uint8_t b = rev ? comp4(code4(s[L - 1 - k])) : code4(s[k]);
+					sp[k >> 1] |= (k & 1) ? b : (uint8_t)(b << 4);
+					const char qc = has_q ? (rev ? q[L - 1 - k] : q[k]) : '!';
+					qp[k] = (uint8_t)(qc - 33);
+				}
+			}
+		};
+		vector<std::thread> th;
+		for (int w = 1; w < nt; ++w) th.emplace_back(fill, w);
+		fill(0);
+		for (auto &x : th) x.join();
+	}
+}
+
+static void write_clip_bam(const string &out_bam, const Reference &R, AlignedRecords &A)
+{
+	const int64_t n = A.size();
+	ssv_batch_t b;
+	memset(&b, 0, sizeof(b));
+	b.n = n; b.mem = SSV_MEM_HOST;
+	b.tid = A.tid.data(); b.pos = A.pos.data(); b.flag = A.flag.data(); b.mapq = A.mapq.data(); b.n_cigar = A.ncig.data(); b.l_qseq = A.lq.data();
+	b.mtid = A.mtid.data(); b.mpos = A.mpos.data(); b.isize = A.isz.data(); b.cigar_off = A.cig_off.data(); b.cigar = A.cig.data(); b.n_cigar_total = (int64_t)A.cig.size();
+	b.seq_off = A.seq_off.data(); b.seqqual = A.seqqual.data(); b.seqqual_bytes = (int64_t)A.seqqual.size() - 16;
+	vector<const char *> tn;
+	for (const string &x : R.names) tn.push_back(x.c_str());
+	if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), R.lens.data(), (int32_t)R.names.size(), &b, A.qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
+}
+
+static void resident_alignments(seeksv::AlnRecords &R)
+{
+	const AlignedRecords &A = *g_resident.aln.rec;
+	R.n = A.size(); R.tid = A.tid.data(); R.pos = A.pos.data(); R.flag = A.flag.data(); R.n_cigar = A.ncig.data(); R.mapq = A.mapq.data();
+	R.cigar_off = A.cig_off.data(); R.cigar = A.cig.data(); R.qname = A.qn.data(); R.target_names = g_resident.aln.names;
+}
+
+static int cmd_realign(int argc, char **argv)
+{
+	int gpu = 0, c;
+	while ((c = getopt(argc, argv, "G:")) != -1) {
+		if (c == 'G') gpu = atoi(optarg); else usage_realign();
+	}
+	if (argc - optind != 3) usage_realign();
+	const string fasta = argv[optind], fq = argv[optind + 1], out_bam = argv[optind + 2];
+	PhaseTimer pt;
+	Reference R;
+	read_reference(fasta, R);
 	pt.lap("read reference");
-	// ---- clipped sequences: the FASTQ text in memory (`seeksv run`: getclip's is still there; else the file, its gzip members inflated side by side),
-	//      cut into lines in place (the newline behind a line becomes its terminator: the sequences are the read names of the BAM records below) ----
-	struct Line { char *p; int n; };
+	// ---- clipped sequences: the FASTQ file (its gzip members inflated side by side), cut into lines in place (the newline behind a line becomes its
+	//      terminator: the sequences are the read names of the BAM records below) ----
 	vector<Line> seqs, quals;
-	vector<string> own_text(1);
-	const bool fq_resident = g_resident.ctx && fq == g_resident.fq_path;
-	if (!fq_resident) { const string err = seeksv::slurp_gz(fq, own_text[0]); if (!err.empty()) die("Cannot open clipped reads file " + fq); }
-	for (string &piece : fq_resident ? g_resident.fq_text : own_text) { // (a piece holds whole records)
-		string *t = &piece;
-		char *base = t->empty() ? nullptr : &(*t)[0];
-		const size_t size = t->size();
+	string text;
+	{ const string err = seeksv::slurp_gz(fq, text); if (!err.empty()) die("Cannot open clipped reads file " + fq); }
+	{
+		char *base = text.empty() ? nullptr : &text[0];
+		const size_t size = text.size();
 		size_t at = 0;
 		auto line = [&](Line &out) { // like gz_getline: a line ends at '\n' (a '\r' in front of it is dropped); a last line without one counts when it is not empty
 			if (at >= size) return false;
@@ -1795,124 +1965,87 @@ static int cmd_realign(int argc, char **argv)
 	pt.lap("read fastq");
 	ssv_ctx *ctx = acquire_ctx(gpu);
 	int64_t dropped = 0;
-	if (ssv_realign_index(ctx, words.data(), SSV_MEM_HOST, offs.back(), offs.data(), (int32_t)names.size(), &dropped) != SSV_OK) die(string("[seeksv] realign index: ") + ssv_last_error(ctx));
+	if (ssv_realign_index(ctx, R.words.data(), SSV_MEM_HOST, R.offs.back(), R.offs.data(), (int32_t)R.names.size(), &dropped) != SSV_OK) die(string("[seeksv] realign index: ") + ssv_last_error(ctx));
 	pt.lap("index");
-	string blob;
-	vector<uint64_t> soff(1, 0);
-	{
-		size_t total = 0;
-		for (const Line &q : seqs) total += (size_t)q.n;
-		blob.reserve(total);
-		soff.reserve(seqs.size() + 1);
-		for (const Line &q : seqs) { blob.append(q.p, (size_t)q.n); soff.push_back(blob.size()); }
-	}
-	vector<ssv_realign_hit> hits((size_t)n);
-	if (ssv_realign_query(ctx, blob.data(), soff.data(), n, hits.data()) != SSV_OK) die(string("[seeksv] realign query: ") + ssv_last_error(ctx));
+	AlignedRecords A;
+	align_lines(ctx, seqs, quals, A);
 	pt.lap("align");
-	// ---- BAM records (read name = sequence as given; SEQ / QUAL reverse-complemented / reversed for reverse-strand hits) ----
-	vector<int32_t> tid((size_t)n), pos((size_t)n), lq((size_t)n), mtid((size_t)n, -1), mpos((size_t)n, -1), isz((size_t)n, 0);
-	vector<uint16_t> flag((size_t)n), ncig((size_t)n);
-	vector<uint8_t> mapq((size_t)n), seqqual;
-	vector<uint32_t> cig_off((size_t)n), cig;
-	vector<uint64_t> seq_off((size_t)n);
-	vector<const char *> qn((size_t)n);
-	auto code4 = [](char ch) -> uint8_t {
-		switch (ch) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4; case 'T': case 't': return 8; default: return 15; }
-	};
-	auto comp4 = [](uint8_t b) -> uint8_t { return (uint8_t)(((b & 1) << 3) | ((b & 2) << 1) | ((b & 4) >> 1) | ((b & 8) >> 3)); };
-	// sizes first (CIGAR operations and packed bytes per record, running sums), then every host thread fills its share of the records
-	int64_t n_aligned = 0;
-	{
-		uint64_t so = 0;
-		uint32_t co = 0;
-		for (int64_t i = 0; i < n; ++i) {
-			const ssv_realign_hit &h = hits[(size_t)i];
-			const int L = seqs[(size_t)i].n;
-			const bool al = h.tid >= 0;
-			n_aligned += al ? 1 : 0;
-			cig_off[(size_t)i] = co; seq_off[(size_t)i] = so;
-			ncig[(size_t)i] = (uint16_t)(al ? 1 + (h.q_beg > 0 ? 1 : 0) + (h.q_end < L ? 1 : 0) : 0);
-			co += ncig[(size_t)i]; so += ((uint64_t)L + 1) / 2 + (uint64_t)L;
-		}
-		cig.assign(co, 0);
-		seqqual.assign(so, 0);
-	}
-	{
-		const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ssv::effective_cpus(), 64, n / 4096}));
-		auto fill = [&](int w) {
-			for (int64_t i = n * w / nt, e = n * (w + 1) / nt; i < e; ++i) {
-				const ssv_realign_hit &h = hits[(size_t)i];
-				const char *s = seqs[(size_t)i].p, *q = quals[(size_t)i].p;
-				const int L = seqs[(size_t)i].n;
-				const bool al = h.tid >= 0, rev = al && h.reverse, has_q = quals[(size_t)i].n == L;
-				qn[(size_t)i] = s;
-				tid[(size_t)i] = al ? h.tid : -1; pos[(size_t)i] = al ? h.pos : -1; lq[(size_t)i] = L;
-				flag[(size_t)i] = (uint16_t)(al ? (rev ? 16 : 0) : 4); mapq[(size_t)i] = al ? h.mapq : 0;
-				if (al) {
-					uint32_t *c = cig.data() + cig_off[(size_t)i];
-					if (h.q_beg > 0) *c++ = ((uint32_t)h.q_beg << 4) | 4u;
-					*c++ = ((uint32_t)(h.q_end - h.q_beg) << 4) | 0u;
-					if (h.q_end < L) *c++ = ((uint32_t)(L - h.q_end) << 4) | 4u;
-				}
-				uint8_t *sp = seqqual.data() + seq_off[(size_t)i], *qp = sp + ((size_t)L + 1) / 2;
-				for (int k = 0; k < L; ++k) {
-					const uint8_t b = rev ? comp4(code4(s[L - 1 - k])) : code4(s[k]);
-					sp[k >> 1] |= (k & 1) ? b : (uint8_t)(b << 4);
-					const char qc = has_q ? (rev ? q[L - 1 - k] : q[k]) : '!';
-					qp[k] = (uint8_t)(qc - 33);
-				}
-			}
-		};
-		vector<std::thread> th;
-		for (int w = 1; w < nt; ++w) th.emplace_back(fill, w);
-		fill(0);
-		for (auto &x : th) x.join();
-	}
-	seqqual.resize(seqqual.size() + 16, 0);
+	A.seqqual.resize(A.seqqual.size() + 16, 0);
 	// clip.bam is read back once, by getsv's join: its BGZF blocks are literal-only Huffman blocks (huff_gz.h: 4 x the speed of zlib level 1 on these
 	// records, 1.6 x the bytes) unless SSV_BGZF_LEVEL asks for zlib
 	setenv("SSV_BGZF_LEVEL", "-1", 0);
-	if (g_resident.ctx && fq == g_resident.fq_path) {
-		// `seeksv run`: getsv's join takes the records from memory, nobody in this process reads clip.bam - it is written beside getsv, by a thread that cmd_run joins
-		// (0.5 s of the 4.2 s of a whole-genome run when it was written first)
-		auto &A = g_resident.aln;
-		A.bam_path = out_bam; A.tid.swap(tid); A.pos.swap(pos); A.flag.swap(flag); A.n_cigar.swap(ncig); A.mapq.swap(mapq); A.cigar_off.swap(cig_off); A.cigar.swap(cig); A.qname.swap(qn);
-		A.names = names;
-		struct Rest { vector<int32_t> lq, mtid, mpos, isz, lens; vector<uint64_t> seq_off; vector<uint8_t> seqqual; };
-		auto rest = std::make_shared<Rest>();
-		rest->lq.swap(lq); rest->mtid.swap(mtid); rest->mpos.swap(mpos); rest->isz.swap(isz); rest->lens = lens; rest->seq_off.swap(seq_off); rest->seqqual.swap(seqqual);
-		g_resident.bam_writer = std::thread([rest, n] {
-			const auto &A = g_resident.aln;
-			ssv_batch_t b;
-			memset(&b, 0, sizeof(b));
-			b.n = n; b.mem = SSV_MEM_HOST;
-			b.tid = const_cast<int32_t *>(A.tid.data()); b.pos = const_cast<int32_t *>(A.pos.data()); b.flag = const_cast<uint16_t *>(A.flag.data()); b.mapq = const_cast<uint8_t *>(A.mapq.data());
-			b.n_cigar = const_cast<uint16_t *>(A.n_cigar.data()); b.l_qseq = rest->lq.data(); b.mtid = rest->mtid.data(); b.mpos = rest->mpos.data(); b.isize = rest->isz.data();
-			b.cigar_off = const_cast<uint32_t *>(A.cigar_off.data()); b.cigar = const_cast<uint32_t *>(A.cigar.data()); b.n_cigar_total = (int64_t)A.cigar.size();
-			b.seq_off = rest->seq_off.data(); b.seqqual = rest->seqqual.data(); b.seqqual_bytes = (int64_t)rest->seqqual.size() - 16;
-			vector<const char *> tn;
-			for (const string &x : A.names) tn.push_back(x.c_str());
-			if (ssvh_bam_write_batch_named(A.bam_path.c_str(), tn.data(), rest->lens.data(), (int32_t)A.names.size(), &b, const_cast<const char **>(A.qname.data()), 0, 1) != 0)
-				g_resident.bam_writer_err = string("[seeksv] ") + ssvh_last_error();
-		});
-		pt.lap("clip.bam handed to its writer");
-	} else {
-		ssv_batch_t b;
-		memset(&b, 0, sizeof(b));
-		b.n = n; b.mem = SSV_MEM_HOST;
-		b.tid = tid.data(); b.pos = pos.data(); b.flag = flag.data(); b.mapq = mapq.data(); b.n_cigar = ncig.data(); b.l_qseq = lq.data();
-		b.mtid = mtid.data(); b.mpos = mpos.data(); b.isize = isz.data(); b.cigar_off = cig_off.data(); b.cigar = cig.data(); b.n_cigar_total = (int64_t)cig.size();
-		b.seq_off = seq_off.data(); b.seqqual = seqqual.data(); b.seqqual_bytes = (int64_t)seqqual.size() - 16;
-		vector<const char *> tn;
-		for (const string &x : names) tn.push_back(x.c_str());
-		if (ssvh_bam_write_batch_named(out_bam.c_str(), tn.data(), lens.data(), (int32_t)names.size(), &b, qn.data(), 0, 1) != 0) die(string("[seeksv] ") + ssvh_last_error());
-		pt.lap("write bam");
-	}
-	cerr << "[seeksv realign] " << n << " clipped sequences, " << n_aligned << " aligned" << (dropped ? ", " + to_string(dropped) + " repetitive index positions dropped" : string()) << endl;
+	write_clip_bam(out_bam, R, A);
+	pt.lap("write bam");
+	cerr << "[seeksv realign] " << n << " clipped sequences, " << A.n_aligned << " aligned" << (dropped ? ", " + to_string(dropped) + " repetitive index positions dropped" : string()) << endl;
 	ssv_realign_free(ctx);
 	release_ctx(ctx);
 	return 0;
 }
+
+// `seeksv run`: the aligner step beside getclip.  A thread with a context of its own (a second stream on the same GPU) builds the index as soon as the
+// reference is read - getclip is still inflating the BAM then - and takes every pass's clipped sequences as getclip's output thread writes them out:
+// when the last record of the BAM has been scanned, all but the last pass's sequences are aligned (0.7 s of a 3.7 s whole-genome run came after getclip
+// before).  The records equal `seeksv realign`'s on the finished prefix.clip.fq.gz: same sequences, same order, one query per sequence.
+struct RunAligner {
+	std::thread th;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<vector<ResidentBam::Piece *>> todo;
+	bool done = false;
+	Reference R;
+	AlignedRecords A;
+	int64_t dropped = 0;
+	double t_index = 0, t_align = 0, t_wait_ref = 0;
+	void start(int device, const string &fasta)
+	{
+		th = std::thread([this, device, fasta] {
+			auto now = [] { return std::chrono::steady_clock::now(); };
+			auto t0 = now();
+			ssv_ctx *ctx = nullptr;
+			if (ssv_ctx_create(device, &ctx) != SSV_OK) die(string("[seeksv] ") + ssv_last_error(nullptr));
+			read_reference(fasta, R);
+			t_wait_ref = std::chrono::duration<double>(now() - t0).count();
+			t0 = now();
+			if (ssv_realign_index(ctx, R.words.data(), SSV_MEM_HOST, R.offs.back(), R.offs.data(), (int32_t)R.names.size(), &dropped) != SSV_OK) die(string("[seeksv] realign index: ") + ssv_last_error(ctx));
+			t_index = std::chrono::duration<double>(now() - t0).count();
+			for (;;) {
+				vector<ResidentBam::Piece *> pass;
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv.wait(lk, [this] { return !todo.empty() || done; });
+					if (todo.empty()) break;
+					pass.swap(todo.front());
+					todo.pop_front();
+				}
+				t0 = now();
+				vector<Line> seqs, quals;
+				for (ResidentBam::Piece *p : pass) {
+					char *base = p->fq.empty() ? nullptr : &p->fq[0];
+					for (const ResidentBam::FqRef &r : p->reads) {
+						base[r.seq_off + r.seq_len] = 0; base[r.qual_off + r.qual_len] = 0; // (the newline behind a line becomes its terminator: the file is written)
+						seqs.push_back(Line{base + r.seq_off, (int)r.seq_len}); quals.push_back(Line{base + r.qual_off, (int)r.qual_len});
+					}
+				}
+				align_lines(ctx, seqs, quals, A);
+				t_align += std::chrono::duration<double>(now() - t0).count();
+			}
+			A.seqqual.resize(A.seqqual.size() + 16, 0);
+			ssv_realign_free(ctx);
+			if (kCleanExit) ssv_ctx_destroy(ctx); else ssv_sync(ctx);
+		});
+	}
+	void submit(const vector<ResidentBam::Piece *> &pass)
+	{
+		{ std::lock_guard<std::mutex> lk(mu); todo.push_back(pass); }
+		cv.notify_all();
+	}
+	void finish()
+	{
+		{ std::lock_guard<std::mutex> lk(mu); done = true; }
+		cv.notify_all();
+		th.join();
+	}
+};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // run: getclip -> realign -> getsv in one process (seeksv.cpp:128-329 + the pipeline's external aligner step, README.md:22-34)
@@ -1960,6 +2093,9 @@ static int cmd_run(int argc, char **argv)
 	pt.lap("run: gpu_init");
 	g_preread.path = fasta; g_preread.offs.assign(1, 0);
 	g_preread.th = std::thread([] { g_preread.ok = parse_fasta_parallel(g_preread.path, g_preread.names, g_preread.lens, g_preread.offs, g_preread.words); });
+	RunAligner &aligner = *new RunAligner; // (never destroyed: die() may exit while its thread runs)
+	aligner.start(device, fasta);
+	g_resident.on_pass = [&aligner](const vector<ResidentBam::Piece *> &pass) { aligner.submit(pass); };
 	auto call = [&](int (*fn)(int, char **), vector<string> words) {
 		vector<char *> av;
 		for (auto &w : words) av.push_back(const_cast<char *>(w.c_str()));
@@ -1972,11 +2108,19 @@ static int cmd_run(int argc, char **argv)
 	a.insert(a.end(), {"-Z", "-G", to_string(device), "-o", prefix, bam});
 	int rc = call(cmd_getclip, a);
 	g_resident.collect = false;
+	g_resident.on_pass = nullptr;
 	pt.lap("run: getclip (decode once, records kept in HBM)");
-	if (rc != 0 && g_preread.th.joinable()) g_preread.th.join();
-	if (rc == 0) rc = call(cmd_realign, {"realign", "-G", to_string(device), fasta, prefix + ".clip.fq.gz", prefix + ".clip.bam"});
-	pt.lap("run: realign");
+	aligner.finish();
+	pt.lap("run: realign (what was left of it behind getclip)");
 	if (rc == 0) {
+		// clip.bam is read back by nobody in this process (getsv's join takes the records from memory): it is written beside getsv, by a thread that is joined below;
+		// its BGZF blocks are literal-only Huffman blocks (huff_gz.h) unless SSV_BGZF_LEVEL asks for zlib
+		setenv("SSV_BGZF_LEVEL", "-1", 0);
+		g_resident.aln.bam_path = prefix + ".clip.bam"; g_resident.aln.rec = &aligner.A; g_resident.aln.names = aligner.R.names;
+		// (written under a temporary name and renamed when it is whole: a run that dies in getsv must not leave half a clip.bam where `seeksv getsv` would find it)
+		g_resident.bam_writer = std::thread([&aligner] { write_clip_bam(g_resident.aln.bam_path + ".tmp", aligner.R, aligner.A); });
+		cerr << "[seeksv realign] " << aligner.A.size() << " clipped sequences, " << aligner.A.n_aligned << " aligned" << (aligner.dropped ? ", " + to_string(aligner.dropped) + " repetitive index positions dropped" : string()) << endl;
+		if (pt.on) cerr << "[timing] (aligner beside getclip: context + reference " << aligner.t_wait_ref << " s, index " << aligner.t_index << " s, align " << aligner.t_align << " s)" << endl;
 		a = {"getsv"};
 		for (auto &w : split_words(sv_opts)) a.push_back(w);
 		a.insert(a.end(), {"-G", to_string(device), prefix + ".clip.bam", bam, prefix + ".clip.gz", prefix + ".sv.txt", prefix + ".unmapped.clip.fq"});
@@ -1985,7 +2129,7 @@ static int cmd_run(int argc, char **argv)
 	pt.lap("run: getsv (records in HBM)");
 	if (g_resident.bam_writer.joinable()) {
 		g_resident.bam_writer.join();
-		if (!g_resident.bam_writer_err.empty()) die(g_resident.bam_writer_err);
+		if (rename((g_resident.aln.bam_path + ".tmp").c_str(), g_resident.aln.bam_path.c_str()) != 0) die("Cannot write file " + g_resident.aln.bam_path);
 		pt.lap("run: clip.bam written");
 	}
 	ssv_ctx *ctx = g_resident.ctx;

@@ -294,10 +294,13 @@ def test_cli_realign_full_pipeline(tmp_path_factory, name):
 
 @pytest.mark.parametrize("name", list(SYNTH_FULL))
 @pytest.mark.parametrize("opts", [[], ["-c", "-q 5 -t 0.85", "-v", "-b 2 -L 100 -q 10"]], ids=["defaults", "options"])
-def test_cli_run_equals_three_commands(tmp_path_factory, name, opts, inflate_mode):
+@pytest.mark.parametrize("run_env", [{}, {"SSV_PASS_RECORDS": "3000", "SSV_CHUNK_INFLATED_MB": "1"}, {"SSV_RUN_PARSE_ROWS": "1"}], ids=["one-pass", "many-passes", "rows-parsed"])
+def test_cli_run_equals_three_commands(tmp_path_factory, name, opts, inflate_mode, run_env):
     """`seeksv run in.bam ref.fa prefix` (one process; the BAM inflated and decoded ONCE on the GPU, its records kept in HBM for the getsv
     passes) writes, byte for byte, the files that `getclip`, `realign` and `getsv` write one after the other - and, under the default
-    options, the SV table the real reference makes from bwa mem's clip.bam (tests/golden/synth)."""
+    options, the SV table the real reference makes from bwa mem's clip.bam (tests/golden/synth).  Round 6: the aligner step runs beside getclip, pass
+    by pass (many-passes: a pass per 3000 records, so that it really does), and the junction stage takes the rows as getclip's formatter kept them
+    (rows-parsed: the text is parsed back instead, the form before)."""
     if inflate_mode != "device-inflate":
         pytest.skip("`seeksv run` always decodes on the GPU")
     from seeksv_amd import synth
@@ -306,7 +309,7 @@ def test_cli_run_equals_three_commands(tmp_path_factory, name, opts, inflate_mod
     fa = str(d / "ref_run.fa")
     with open(fa, "w") as f:
         f.write(w.reference_fasta())
-    tag = "d" if not opts else "o"
+    tag = ("d" if not opts else "o") + "".join(k[4] for k in sorted(run_env))
     clip_o = opts[1].split() if opts else []
     sv_o = opts[3].split() if opts else []
     a = str(d / f"three_{tag}")
@@ -317,7 +320,7 @@ def test_cli_run_equals_three_commands(tmp_path_factory, name, opts, inflate_mod
     r3 = subprocess.run([SEEKSV, "getsv"] + sv_o + [a + ".clip.bam", bam, a + ".clip.gz", a + ".sv.txt", a + ".unmapped.clip.fq"], capture_output=True, text=True)
     assert r3.returncode == 0, r3.stderr
     b = str(d / f"one_{tag}")
-    r = subprocess.run([SEEKSV, "run"] + opts + [bam, fa, b], capture_output=True, text=True, env=dict(os.environ, SSV_FASTA_CHECK="1"))  # (the parallel FASTA reader against the serial one)
+    r = subprocess.run([SEEKSV, "run"] + opts + [bam, fa, b], capture_output=True, text=True, env=dict(os.environ, SSV_FASTA_CHECK="1", **run_env))  # (the parallel FASTA reader against the serial one)
     assert r.returncode == 0, r.stderr
     for ext in (".clip.gz", ".clip.fq.gz", ".unmapped_1.fq.gz", ".unmapped_2.fq.gz"):
         assert gzip.open(a + ext, "rb").read() == gzip.open(b + ext, "rb").read(), ext
