@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define SSV_ABI_VERSION 8 /* v8: table formats 1 and 2 (four-piece blocks with 4-bit bases) removed - 0 ASCII or 3 compact; ssv_group with SSV_GROUP_RCCL_ONE */
+#define SSV_ABI_VERSION 9 /* v9: ssv_table_block_bytes(left_len, right_len) lost the parameters of the removed formats; ssv_bamdec_info.unmapped_raw stays valid for one more decode.
+                             v8: table formats 1 and 2 (four-piece blocks with 4-bit bases) removed - 0 ASCII or 3 compact; ssv_group with SSV_GROUP_RCCL_ONE */
 
 typedef enum {
 	SSV_OK = 0,
@@ -298,8 +299,8 @@ int ssv_clip_table_expand(ssv_ctx *ctx, ssv_cluster_table *t, int32_t n_threads)
 uint64_t ssv_table_block_bytes3(int64_t n_bases, int32_t base_bits, int32_t qual_bits);
 /* The same for a table whose qualities go in groups (ssv_cluster_table.qual_group; 1 = the function above). */
 uint64_t ssv_table_block_bytes3g(int64_t n_bases, int32_t base_bits, int32_t qual_bits, int32_t qual_group);
-/* Bytes of one cluster's string block in format 0 (a multiple of 4; seq_packed = 0, qual_bits = 8). */
-uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits);
+/* Bytes of one cluster's string block in format 0: seq_left, qual_left, seq_right, qual_right as characters, padded to a multiple of 4 (v9: two parameters). */
+uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len);
 
 /* Sort events into (contig, side, position) bins and run the greedy consensus clustering. */
 int ssv_clip_cluster(ssv_ctx *ctx, ssv_cluster_table *out);

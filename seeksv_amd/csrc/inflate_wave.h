@@ -275,7 +275,7 @@ __device__ __forceinline__ uint32_t wv_excl_max(uint32_t v) // max over the lane
 }
 
 // one raw deflate stream by one wavefront: literals to out, a token per match to tok (token_capacity(out_len) words); n_tok = tokens written
-// dbg (SSV_TOKENS_PHASES=1): [0] deflate blocks, [1] windows, [2] decode rounds before the chain stood, [3] lanes that decoded in rounds after the second,
+// dbg (SSV_INFLATE_PHASES=1): [0] deflate blocks, [1] windows, [2] decode rounds before the chain stood, [3] lanes that decoded in rounds after the second,
 // [4..8] cycles: window loads, headers + tables, first round, later rounds, emit
 template <bool DBG>
 __device__ __forceinline__ int wave_inflate_tokens(WaveLds &L, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, uint32_t *tok, uint32_t &n_tok, unsigned long long *dbg_arg)

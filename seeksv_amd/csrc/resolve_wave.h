@@ -180,7 +180,7 @@ __device__ __forceinline__ void lds_put_small(uint32_t a, uint32_t L, u32x4 h)
 }
 
 // the tokens tk[0, n) of one block (ulen bytes at o), all 64 lanes of the wavefront together; win = the wavefront's RW_WIN + 64 bytes of LDS
-// dbg (SSV_RESOLVE_PHASES=1): [0] rounds, [1] phases, [2] all-lanes matches, [3] tokens, [4] window moves, [5..9] cycles: window, dependencies, own-lane copies, all-lanes copies, store
+// dbg (SSV_INFLATE_PHASES=1): [0] rounds, [1] phases, [2] all-lanes matches, [3] tokens, [4] window moves, [5..9] cycles: window, dependencies, own-lane copies, all-lanes copies, store
 template <bool DBG>
 __device__ __forceinline__ void wave_resolve_tokens_win(uint8_t *o, uint32_t ulen, const uint32_t *tk, uint32_t n, uint8_t *win, int lane, unsigned long long *dbg)
 {

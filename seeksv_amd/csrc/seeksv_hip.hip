@@ -1241,10 +1241,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out);
 static void table_expanded_view(ssv_ctx::TableSet &T, ssv_cluster_table *out);
 
-uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len, int32_t seq_packed, int32_t qual_bits)
-{
-	return table_block_bytes((uint64_t)left_len, (uint64_t)right_len, seq_packed, seq_packed ? (uint64_t)qual_bits : 8);
-}
+uint64_t ssv_table_block_bytes(int32_t left_len, int32_t right_len) { return table_block_bytes((uint64_t)left_len, (uint64_t)right_len, 0, 8); }
 
 int ssv_clip_table_format(ssv_ctx *c, int packed)
 {

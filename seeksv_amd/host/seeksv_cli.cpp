@@ -674,7 +674,7 @@ static int device_of_rank(int r, const vector<int> &devices)
 // ---------------------------------------------------------------------------------------------------------------------
 
 // DisplaySClipReadsAndClipFq (clip_reads.h:300-345) for the clusters [k0, k1) of a table: their clip.gz rows and clip.fq records
-// SSV_TABLE_FORMAT=0..3 picks another wire format for the cluster table (the text written is the same)
+// (the cluster table crosses PCIe in the compact format 3, include/seeksv_hip.h; the text written is the ASCII table's)
 static int table_format_default() { return 3; }
 
 // where a row's fields lie in the text (offsets: the strings still grow)

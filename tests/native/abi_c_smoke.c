@@ -17,7 +17,7 @@ int main(void)
 	memset(&b, 0, sizeof(b)); memset(&t, 0, sizeof(t)); memset(&h, 0, sizeof(h));
 	if (ssv_abi_version() != SSV_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
 	if (sizeof(h) != 32) { fprintf(stderr, "ssv_realign_hit layout\n"); return 2; }
-	if (ssv_table_block_bytes(30, 120, 1, 3) != (((30 + 1) / 2 + (30 * 3 + 7) / 8 + (120 + 1) / 2 + (120 * 3 + 7) / 8 + 3) & ~3)) { fprintf(stderr, "block bytes\n"); return 2; }
+	if (ssv_table_block_bytes(30, 121) != ((2 * 30 + 2 * 121 + 3) & ~3)) { fprintf(stderr, "block bytes\n"); return 2; }
 	rc = ssv_ctx_create(0, &ctx);
 	if (rc == SSV_OK) {
 		if (ssv_clip_scan(ctx, NULL) != SSV_E_ARG) { fprintf(stderr, "NULL batch accepted\n"); return 3; }

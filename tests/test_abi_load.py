@@ -23,7 +23,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ssv_abi_version() == 8
+    assert lib.ssv_abi_version() == 9
 
 
 def test_host_library_exports_every_declared_symbol():
@@ -63,3 +63,24 @@ def test_headers_compile_as_c_and_link(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host: " in r.stdout and ("no device" in r.stdout or "gpu context ok" in r.stdout)
+
+
+def integration_snippet(tag, tmp_path):
+    """the fenced C block behind `<!-- snippet:<tag> -->` in INTEGRATION.md, compiled and linked as C99 -> path of the executable"""
+    import re
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"<!-- snippet:%s -->\s*```c\n(.*?)```" % re.escape(tag), text, re.S)
+    assert m, tag
+    src, exe = str(tmp_path / f"snippet_{tag}.c"), str(tmp_path / f"snippet_{tag}")
+    open(src, "w").write(m.group(1))
+    libdir = _abi.LIBDIR
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + libdir, "-lseeksv_hip",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_integration_snippet_compiles(tmp_path):
+    """what INTEGRATION.md tells an integrator to write is C that this ABI version compiles and links (its run needs a GPU: tests/test_integration_snippet_gpu.py)"""
+    assert os.path.exists(integration_snippet("formats", tmp_path))
