@@ -632,6 +632,20 @@ def timing_phases(stderr):
     return out
 
 
+def run_command(cmd, env):
+    """a command as a child process with SSV_TIMING=1: -> (CompletedProcess, dict(total_s, phases_s, exec_to_main_s, exit_to_reaped_s)) - the last two from the
+    command's own wall-clock stamps: what the process costs before main() and after its last statement (the kernel tearing its device memory down)"""
+    import subprocess
+    t0, w0 = time.perf_counter(), time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    dt, w1 = time.perf_counter() - t0, time.time()
+    out = dict(total_s=round(dt, 3), phases_s=timing_phases(r.stderr))
+    stamps = [float(l.split(":")[1]) for l in r.stderr.splitlines() if l.startswith("[stamp] wall clock at")]
+    if len(stamps) == 2:
+        out.update(exec_to_main_s=round(stamps[0] - w0, 3), exit_to_reaped_s=round(w1 - stamps[1], 3))
+    return r, out
+
+
 def room_for(need):
     """a directory with `need` bytes free: /dev/shm (the page cache), else the temp directory; None: neither"""
     import tempfile
@@ -918,6 +932,8 @@ def file_path_leg(ctx, args, device):
                            f"{inflated_total / w.n_total:.1f} B/record inflated), read in {len(chunks)} chunks of whole BGZF blocks",
                "records": w.n_total, "bam_bytes": bam_bytes, "bam_bytes_per_record": round(bam_bytes / w.n_total, 2), "inflated_bytes_per_record": round(inflated_total / w.n_total, 2), "chunks": len(chunks),
                "includes_file_read": True,
+               "coder": {"name": "deflate_fast (huff_gz.h: single-probe greedy LZ77 + Huffman)" if args.file_level == -2 else "zlib", "level": int(args.file_level),
+                         "note": "not samtools' level 6 unless level says 6: fewer and shorter matches inflate slower per output byte; inflate_level6 has the same records at level 6"},
                "timed_region": "opening the file, then per pass and chunk: the chunk pread out of the page cache (/dev/shm) into one of three pinned buffers by a reader thread that runs ahead "
                                "(ssvh_bam_read_blocks: all host threads, block headers scanned there) -> H2D of the compressed bytes (the next chunk's announced ahead) -> device BGZF inflate -> BAM record "
                                "decode -> scans -> tables / tallies on the host; NOT in it: file creation, allocating the three pinned buffers",
@@ -932,12 +948,84 @@ def file_path_leg(ctx, args, device):
                                "what": "round 3's footing: the whole file in pinned host memory before the clock starts (reading it there took %.1f s, outside); kernel_ms_per_run was measured on these runs" % read_s},
                "note": "the file is inflated and decoded ONCE: the decoded records (80 B each) stay in HBM (ssv_batch_retain) and the getsv passes scan them there - the reference reads the file once per command; file creation (%.1f s) is outside the timed region" % make_s}
         hdr.close()
+        if args.file_level != 6:
+            try:
+                out["inflate_level6"] = inflate_level6_leg(ctx, args)
+            except Exception as e:
+                out["inflate_level6"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cli_leg:
             try:
                 out["cli_path"] = cli_path_leg(args, w, bam, d, out["result"])
             except Exception as e:
                 out["cli_path"] = {"error": f"{type(e).__name__}: {e}"}
         return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def inflate_level6_leg(ctx, args):
+    """The device inflate on a file as samtools writes it (zlib level 6: longer matches, fewer literals than the fast coder the whole-sample file leg has to use where 16
+    CPUs write it): a slice of the same records, its chunks in pinned memory, decode only - the inflate kernels' rate in bytes of OUTPUT, and the PCIe floor beside it."""
+    import ctypes as C
+    import shutil
+    import tempfile
+    import torch
+    from seeksv_amd import _abi, host, synth
+    frac = args.genome_frac / 128
+    w = synth.Workload(genome_frac=frac, depth=args.depth, n_sv=max(1, round(args.n_sv / 128)), qual_model=1 if args.qual_alphabet == "hiseq40" else 0)
+    where = room_for(int(w.n_total * 110))
+    d = tempfile.mkdtemp(prefix="ssv_l6_", dir=where)
+    try:
+        bam = os.path.join(d, "l6.bam")
+        t0 = time.perf_counter()
+        write_workload_bam(w, bam, 6)
+        make_s = time.perf_counter() - t0
+        os.environ.pop("SSV_BGZF_LEVEL", None)
+        hl, lib = _abi.host_lib(), ctx._lib
+        chunks = []
+        with host.BamReader(bam) as r:
+            first = C.c_uint64()
+            if hl.ssvh_bam_raw_begin(r.handle, C.byref(first)) != 0:
+                raise IOError(hl.ssvh_last_error().decode())
+            n_targets = len(r.target_names)
+            cap, max_blocks = min(os.path.getsize(bam) + (1 << 20), 3 << 28), 1 << 17
+            while True:
+                buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                blocks = (_abi.BgzfBlock * max_blocks)()
+                nb, nbytes = C.c_int64(), C.c_size_t()
+                if hl.ssvh_bam_read_blocks(r.handle, C.c_void_p(buf.data_ptr()), cap, 1 << 30, blocks, max_blocks, C.byref(nb), C.byref(nbytes)) != 0:
+                    raise IOError(hl.ssvh_last_error().decode())
+                if nb.value == 0:
+                    break
+                chunks.append((buf, blocks, nb.value, nbytes.value))
+        blk_dt = np.dtype([("c_off", np.uint64), ("c_len", np.uint32), ("u_len", np.uint32)])
+        inflated = sum(int(np.frombuffer(blk, dtype=blk_dt, count=nb_)["u_len"].sum()) for _, blk, nb_, _ in chunks)
+
+        def run():
+            ctx._check(lib.ssv_bamdec_begin(ctx._h, n_targets, first.value), "ssv_bamdec_begin"); ctx.bamdec_target_lens(w.lens)
+            n = 0
+            for buf, blocks, nb, nbytes in chunks:
+                b = _abi.Batch()
+                ctx._check(lib.ssv_bamdec_decode(ctx._h, C.c_void_p(buf.data_ptr()), nbytes, blocks, nb, 0, C.byref(b)), "ssv_bamdec_decode")
+                n += b.n
+            b = _abi.Batch()
+            ctx._check(lib.ssv_bamdec_decode(ctx._h, None, 0, None, 0, 0, C.byref(b)), "ssv_bamdec_decode")
+            assert n == w.n_total
+        run()
+        ctx.prof_reset(); ctx.prof_enable(1)
+        REPS = 3
+        for _ in range(REPS):
+            run()
+        prof = ctx.prof_all()
+        ctx.prof_enable(0)
+        ms = {k: prof[k]["total_ms"] / REPS for k in ("bam_inflate", "bam_resolve", "bam_records", "bam_decode", "bam_upload") if prof.get(k, {}).get("launches")}
+        size = os.path.getsize(bam)
+        return {"coder": {"name": "zlib", "level": 6}, "records": w.n_total, "bam_bytes": size, "bam_bytes_per_record": round(size / w.n_total, 2), "inflated_bytes": inflated,
+                "kernel_ms": {k: round(v, 3) for k, v in ms.items()}, "inflate_GBs_of_output": round(inflated / (ms["bam_inflate"] * 1e-3) / 1e9, 1),
+                "whole_sample_at_this_rate": {"file_GB": round(size / w.n_total * args.genome_frac / frac * w.n_total / 1e9, 1), "pcie_floor_s_at_56_GBs": round(size / frac * args.genome_frac / 56e9, 3),
+                                              "inflate_s": round(ms["bam_inflate"] * 1e-3 / frac * args.genome_frac, 3), "decode_s": round((ms.get("bam_records", 0) + ms.get("bam_decode", 0)) * 1e-3 / frac * args.genome_frac, 3)},
+                "what": f"genome_frac {frac:g} of the same sample written with zlib level 6 like samtools ({make_s:.1f} s), {len(chunks)} chunk(s) out of pinned memory through ssv_bamdec_decode only, mean of {REPS} runs; "
+                        "bam_inflate holds both inflate passes (bam_resolve: pass 2's share)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -985,13 +1073,11 @@ def cli_path_leg(args, w, bam, d, expect):
         w.write_fasta(fa, effective_cpus())
         rbest = None
         for rep in range(2):
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, "run", bam, fa, os.path.join(d, "one")], capture_output=True, text=True, env=env)
-            dt = time.perf_counter() - t0
+            r, cur = run_command([exe, "run", bam, fa, os.path.join(d, "one")], env)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr[-400:])
-            if rbest is None or dt < rbest["total_s"]:
-                rbest = dict(total_s=round(dt, 3), phases_s=phases(r.stderr))
+            if rbest is None or cur["total_s"] < rbest["total_s"]:
+                rbest = cur
         rows_sv = [l.split("\t") for l in open(os.path.join(d, "one.sv.txt")) if not l.startswith("@")]
         found = {(c[0], int(c[1]), c[2], c[4], int(c[5]), c[6]) for c in rows_sv}
         planted = {tuple(j[:6]) for j in w.junctions}

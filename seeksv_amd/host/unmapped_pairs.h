@@ -8,9 +8,10 @@
 // A whole-genome BAM carries 1-3 % such records (6-18 M of 617 M): a string-keyed std::map and the FASTQ text built record by record on the thread
 // that hands chunks to the GPU was ~1 us a record.  Here the feeder thread only hands over a pointer: a batch's records stay where the
 // reader left them (raw BAM records, block_size prefixed: ssv_bamdec_info.unmapped_raw / ssvh_bam_unmapped_raw - both readers keep them valid while
-// the NEXT batch is read), a thread of its own walks them, pairs them through an open-addressing table keyed by a 64-bit hash of the name (the name is
-// compared on a hit; mates lie side by side in a coordinate-sorted BAM, so the table stays small), a few helper threads turn the pairs into FASTQ
-// text, and the text goes out as gzip members.  Only a record whose mate has not come by the end of its batch is copied (an arena of its own).
+// the NEXT batch is read); a first thread copies them (20 MB per 1 GB chunk at 2 %: the reader's buffer is free again within milliseconds, whatever
+// the threads behind are doing), a second walks the copy, pairs the records through an open-addressing table keyed by a 64-bit hash of the name (the
+// name is compared on a hit; mates lie side by side in a coordinate-sorted BAM, so the table stays small) and lets a few helper threads turn the pairs
+// into FASTQ text, a third hands the text to the gzip writer.  A record whose mate has not come by the end of its batch moves into an arena.
 #pragma once
 
 #include <algorithm>
@@ -20,6 +21,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -34,11 +36,12 @@ public:
 	UnmappedPairs(Sink sink1, Sink sink2, int format_threads) : sink1_(std::move(sink1)), sink2_(std::move(sink2)), nfmt_(format_threads < 1 ? 1 : format_threads)
 	{
 		table_.assign(1024, Slot{});
+		copier_ = std::thread([this] { copy_in(); });
 		worker_ = std::thread([this] { run(); });
 		writer_ = std::thread([this] { write_out(); });
 	}
 	~UnmappedPairs() { finish(); }
-	// The reader's thread: the UNMAP|MUNMAP records of the batch just read, in order.  Returns once the batch BEFORE this one is done with (its bytes may
+	// The reader's thread: the UNMAP|MUNMAP records of the batch just read, in order.  Returns once the batch BEFORE this one has been copied (its bytes may
 	// then be overwritten); this batch's bytes must stay valid until the next submit() or finish() returns.
 	void submit(const uint8_t *raw, size_t bytes)
 	{
@@ -57,6 +60,9 @@ public:
 			done_ = true;
 			cv_.notify_all();
 		}
+		copier_.join();
+		{ std::lock_guard<std::mutex> lk(in_mu_); in_done_ = true; }
+		in_cv_.notify_all();
 		worker_.join();
 		{ std::lock_guard<std::mutex> lk(out_mu_); out_done_ = true; }
 		out_cv_.notify_all();
@@ -220,7 +226,8 @@ private:
 		}
 	}
 
-	void run()
+	// the reader's bytes into memory of our own: the only thing the reader ever waits for
+	void copy_in()
 	{
 		for (;;) {
 			const uint8_t *raw; size_t bytes;
@@ -230,22 +237,39 @@ private:
 				if (!busy_) return;
 				raw = raw_; bytes = bytes_;
 			}
-			const auto t0 = std::chrono::steady_clock::now();
-			one_batch(raw, bytes);
-			busy_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-			{
-				std::lock_guard<std::mutex> lk(mu_);
-				busy_ = false;
-			}
+			std::unique_ptr<uint8_t[]> own(new uint8_t[bytes]);
+			memcpy(own.get(), raw, bytes);
+			{ std::lock_guard<std::mutex> lk(in_mu_); in_.emplace_back(std::move(own), bytes); }
+			in_cv_.notify_all();
+			{ std::lock_guard<std::mutex> lk(mu_); busy_ = false; }
 			cv_.notify_all();
+		}
+	}
+
+	void run()
+	{
+		for (;;) {
+			std::pair<std::unique_ptr<uint8_t[]>, size_t> batch;
+			{
+				std::unique_lock<std::mutex> lk(in_mu_);
+				in_cv_.wait(lk, [this] { return !in_.empty() || in_done_; });
+				if (in_.empty()) return;
+				batch = std::move(in_.front());
+				in_.pop_front();
+			}
+			const auto t0 = std::chrono::steady_clock::now();
+			one_batch(batch.first.get(), batch.second);
+			busy_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		}
 	}
 
 	Sink sink1_, sink2_;
 	int nfmt_;
-	std::thread worker_, writer_;
-	std::mutex mu_, out_mu_;
-	std::condition_variable cv_, out_cv_;
+	std::thread copier_, worker_, writer_;
+	std::mutex mu_, in_mu_, out_mu_;
+	std::condition_variable cv_, in_cv_, out_cv_;
+	std::deque<std::pair<std::unique_ptr<uint8_t[]>, size_t>> in_; // copied batches waiting for the pairing thread
+	bool in_done_ = false;
 	std::deque<std::pair<std::vector<std::string>, std::vector<std::string>>> out_;
 	bool out_done_ = false;
 	const uint8_t *raw_ = nullptr;
