@@ -155,9 +155,19 @@ private:
 	{
 		pairs_.clear();
 		batch_new_.clear();
-		Rec rec;
+		Rec rec, mate;
 		for (size_t off = 0, nxt = 0; parse(raw, bytes, off, rec, nxt); off = nxt) {
 			++n_records_;
+			// Mates lie side by side in a coordinate-sorted BAM (the unmapped end is placed on its mate): with nothing waiting in the table, a record followed by
+			// the other end of its own pair is exactly "insert, find, write, erase" - done here without the table (a whole-genome sample's 12-25 M such
+			// records were 100 ns each through it, on one thread)
+			size_t nxt2;
+			if (live_ == 0 && parse(raw, bytes, nxt, mate, nxt2) && mate.read1 != rec.read1 && mate.name_len == rec.name_len && memcmp(mate.name(), rec.name(), rec.name_len) == 0) {
+				pairs_.push_back(rec.read1 ? Pair{rec, mate} : Pair{mate, rec});
+				++n_records_;
+				nxt = nxt2;
+				continue;
+			}
 			const uint64_t h = hash_name(rec.name(), rec.name_len);
 			const size_t i = find(h, rec);
 			if (table_[i].used) {

@@ -23,12 +23,15 @@ def run(w, hdr, ctx, n_chunks, probe=None):
     per = (-(-n // n_chunks) + 7) // 8 * 8
     cuts = [(g, min(per, n - g)) for g in range(0, n, per)]
     t = {"generate": 0.0, "getclip": 0.0, "cluster": 0.0, "isize": 0.0, "getsv": 0.0}
+    per_chunk = {"generate": [], "getclip_scan": [], "getsv_scan": []}   # seconds, chunk by chunk (round 6: where a chunk's time goes)
+    ctx.prof_reset(); ctx.prof_enable(1)   # HIP events around every kernel group and the table's copy
 
     def chunk(g, m):
         t0 = time.perf_counter()
         b, keep = w.generate_device(g, m, 0)
         torch.cuda.synchronize()
         t["generate"] += time.perf_counter() - t0
+        per_chunk["generate"].append(round(time.perf_counter() - t0, 4))
         return b, keep
 
     ctx.clip_table_format(3)
@@ -40,6 +43,7 @@ def run(w, hdr, ctx, n_chunks, probe=None):
         ctx.clip_scan(b)
         ctx.sync()
         t["getclip"] += time.perf_counter() - t0
+        per_chunk["getclip_scan"].append(round(time.perf_counter() - t0, 4))
         if k == 0:
             t0 = time.perf_counter()
             pb, pkeep = w.generate_device(0, min(n, 6_500_000), 0)
@@ -68,13 +72,17 @@ def run(w, hdr, ctx, n_chunks, probe=None):
         ctx.getsv_scan(b)
         ctx.sync()
         t["getsv"] += time.perf_counter() - t0
+        per_chunk["getsv_scan"].append(round(time.perf_counter() - t0, 4))
         del b, keep
     t0 = time.perf_counter()
     counts, rs, pd, max_depth = ctx.getsv_finish(plan.ranges, plan.points)
     t["getsv"] += time.perf_counter() - t0
     folded = plan.fold(counts, rs, pd)
     plan.close()
-    return dict(chunks=len(cuts), table=table, mean=stats[2], sd=stats[3], counts=np.asarray(counts), rs=np.asarray(rs), pd=np.asarray(pd), max_depth=int(max_depth),
+    prof = {k: round(v["total_ms"], 3) for k, v in ctx.prof_all().items() if v["launches"]}
+    ctx.prof_enable(0)
+    per_chunk["generate"] = per_chunk["generate"][:len(cuts)] + ["second pass:"] + per_chunk["generate"][len(cuts):]
+    return dict(chunks=len(cuts), per_chunk_s=per_chunk, device_ms=prof, table=table, mean=stats[2], sd=stats[3], counts=np.asarray(counts), rs=np.asarray(rs), pd=np.asarray(pd), max_depth=int(max_depth),
                 abnormal=np.asarray(folded["abnormal"]), up_depth=np.asarray(folded["up_depth"]), down_depth=np.asarray(folded["down_depth"]),
                 seconds={k: round(v, 3) for k, v in t.items()})
 
@@ -98,7 +106,10 @@ def main(genome_frac=1.0, depth=300.0, n_sv=10000, chunks_a=10, chunks_b=16, pro
     covered = int(((a["up_depth"] > 0) & (a["down_depth"] > 0)).sum())
     out.update(chunkings=[a["chunks"], b["chunks"]], results_identical=True, table=a["table"], mean=a["mean"], sd=a["sd"], max_depth=a["max_depth"],
                junctions_with_discordant_pairs=seen, junctions_with_depth_at_both_ends=covered, discordant_pairs=int(a["abnormal"].sum()),
-               median_breakpoint_depth=float(np.median(np.concatenate([a["up_depth"], a["down_depth"]]))), seconds=[a["seconds"], b["seconds"]])
+               median_breakpoint_depth=float(np.median(np.concatenate([a["up_depth"], a["down_depth"]]))), seconds=[a["seconds"], b["seconds"]],
+               per_chunk_s=[a["per_chunk_s"], b["per_chunk_s"]], device_ms=[a["device_ms"], b["device_ms"]],
+               note="seconds: wall clock per phase, summed over the chunks (generate = the synthetic records made in HBM, not part of the path; cluster = sort + bins + pack kernels AND the table's copy to the host); "
+                    "device_ms: HIP events around every kernel group of the run (table_d2h = the copy); per_chunk_s: wall clock chunk by chunk")
     assert seen == len(w.junctions) and covered == len(w.junctions), (seen, covered, len(w.junctions))
     return out
 
