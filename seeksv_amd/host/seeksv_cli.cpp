@@ -683,8 +683,32 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 {
 		row.reserve(row.size() + (size_t)(k1 - k0) * 480); fq.reserve(fq.size() + (size_t)(k1 - k0) * 200);
 		char num[16];
+		// (decimal digits by hand: three snprintf calls a row were a tenth of the formatter's time on a whole-genome sample's 5.5 M rows)
+		auto put_int = [&num](long long v) -> size_t {
+			char tmp[24]; size_t n = 0;
+			const bool neg = v < 0;
+			unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+			do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+			size_t o = 0;
+			if (neg) num[o++] = '-';
+			while (n) num[o++] = tmp[--n];
+			return o;
+		};
 		string seqbuf;
-		std::vector<std::array<char, 3>> group_lut;   // grouped qualities: a group's number -> its (up to three) quality characters
+		// a byte of the 2-bit base stream -> its four characters; of the 4-bit stream -> its two
+		static const struct BaseTabs {
+			uint32_t b2[256]; uint16_t b4[256];
+			BaseTabs() {
+				for (unsigned v = 0; v < 256; ++v) {
+					char c[4];
+					for (int i = 0; i < 4; ++i) c[i] = "ACGT"[(v >> (2 * i)) & 3];
+					memcpy(&b2[v], c, 4);
+					const char d[2] = {"=ACMGRSVTWYHKDBN"[v & 15], "=ACMGRSVTWYHKDBN"[v >> 4]};
+					memcpy(&b4[v], d, 2);
+				}
+			}
+		} base_tabs;
+		std::vector<uint32_t> group_lut;   // grouped qualities: a group's number -> its (up to three) quality characters, as the low bytes of a dword
 		const ssv_cluster_table *group_lut_for = nullptr;
 		for (int64_t k = k0; k < k1; ++k) {
 			const char *name = ssvh_bam_target_name(bam, t.tid[k]);
@@ -694,35 +718,40 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 			if (t.format == 3) { // compact: [base stream | quality stream] over seq_left + seq_right, whole 32-bit words each (seeksv_hip.h)
 				const size_t n = ll + lr, W = (size_t)t.qual_bits, BBITS = (size_t)t.base_bits, QG = t.qual_group > 1 ? (size_t)t.qual_group : 1;
 				const uint8_t *bs = s, *qs = s + 4 * ((n * BBITS + 31) / 32);
-				seqbuf.resize(2 * n);
+				seqbuf.resize(2 * n + 16); // (+ room for the whole dwords the table-driven loops write behind the last character)
+				char *const sb = &seqbuf[0];
 				if (BBITS == 2) {
-					for (size_t i = 0; i < n; ++i) seqbuf[i] = "ACGT"[(bs[i >> 2] >> ((i & 3) << 1)) & 3];
+					for (size_t i = 0, b = 0; i < n; i += 4, ++b) memcpy(sb + i, &base_tabs.b2[bs[b]], 4); // (the stream is whole dwords: the last byte is there)
 					// the bases that are not A/C/G/T (sorted list; cluster << 28 | base index << 4 | code)
 					const uint64_t *e0 = t.base_exc, *e1 = t.base_exc + t.n_base_exc;
-					for (const uint64_t *e = std::lower_bound(e0, e1, (uint64_t)k << 28); e < e1 && (*e >> 28) == (uint64_t)k; ++e) seqbuf[(size_t)((*e >> 4) & 0xffffff)] = "=ACMGRSVTWYHKDBN"[*e & 15];
-				} else for (size_t i = 0; i < n; ++i) seqbuf[i] = "=ACMGRSVTWYHKDBN"[(bs[i >> 1] >> ((i & 1) << 2)) & 15];
-				sl = seqbuf.data(); sr = seqbuf.data() + ll;
+					if (e0 != e1) for (const uint64_t *e = std::lower_bound(e0, e1, (uint64_t)k << 28); e < e1 && (*e >> 28) == (uint64_t)k; ++e) sb[(size_t)((*e >> 4) & 0xffffff)] = "=ACMGRSVTWYHKDBN"[*e & 15];
+				} else for (size_t i = 0, b = 0; i < n; i += 2, ++b) memcpy(sb + i, &base_tabs.b4[bs[b]], 2);
+				sl = sb; sr = sb + ll;
 				if (W == 8) { ql = (const char *)qs; qr = ql + ll; }
 				else if (QG > 1) { // groups of QG qualities: one number of W bits, its digits (radix = the alphabet's size) are the alphabet indices
 					if (!group_lut_for || group_lut_for != &t) {
 						unsigned radix = 0;
 						while (radix < sizeof(t.qual_alphabet) && t.qual_alphabet[radix]) ++radix;
-						group_lut.resize((size_t)1 << W);
-						for (unsigned code = 0; code < (1u << W); ++code) { unsigned v = code; for (size_t j = 0; j < 3; ++j) { group_lut[code][j] = (char)t.qual_alphabet[radix ? v % radix : 0]; if (radix) v /= radix; } }
+						group_lut.assign((size_t)1 << W, 0u);
+						for (unsigned code = 0; code < (1u << W); ++code) { unsigned v = code; char c[4] = {0, 0, 0, 0}; for (size_t j = 0; j < 3; ++j) { c[j] = (char)t.qual_alphabet[radix ? v % radix : 0]; if (radix) v /= radix; } memcpy(&group_lut[code], c, 4); }
 						group_lut_for = &t;
 					}
-					char *dq = &seqbuf[n];
+					char *dq = sb + n;
 					const unsigned mask = (1u << W) - 1u;
 					const size_t ng = (n + QG - 1) / QG, qbytes = 4 * ((ng * W + 31) / 32);
+					// (a group of up to 11 bits lies in at most three bytes: one unaligned dword from its first byte - read with bounds only for the stream's last three bytes)
 					for (size_t g = 0; g < ng; ++g) {
-						const size_t b = (g * W) >> 3;
-						const unsigned code = ((qs[b] | (b + 1 < qbytes ? (unsigned)qs[b + 1] << 8 : 0u) | (b + 2 < qbytes ? (unsigned)qs[b + 2] << 16 : 0u)) >> ((g * W) & 7)) & mask; // (a group of 11 bits can lie in three bytes)
-						for (size_t j = 0; j < QG && g * QG + j < n; ++j) dq[g * QG + j] = group_lut[code][j];
+						const size_t bit = g * W, b = bit >> 3;
+						uint32_t w;
+						if (b + 4 <= qbytes) memcpy(&w, qs + b, 4);
+						else { w = 0; for (size_t x = b; x < qbytes; ++x) w |= (uint32_t)qs[x] << (8 * (x - b)); }
+						const uint32_t chars = group_lut[(w >> (bit & 7)) & mask];
+						memcpy(dq + g * QG, &chars, 4); // (the next group's characters overwrite the fourth byte; the last group's lands in the buffer's slack)
 					}
 					ql = dq; qr = dq + ll;
 				} else {
 					const unsigned mask = (1u << W) - 1u;
-					char *dq = &seqbuf[n];
+					char *dq = sb + n;
 					const size_t qbytes = 4 * ((n * W + 31) / 32);
 					for (size_t i = 0; i < n; ++i) { const size_t b = (i * W) >> 3; dq[i] = (char)t.qual_alphabet[((qs[b] | (b + 1 < qbytes ? (unsigned)qs[b + 1] << 8 : 0u)) >> ((i * W) & 7)) & mask]; }
 					ql = dq; qr = dq + ll;
@@ -734,12 +763,12 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 			at.row = (uint32_t)row.size(); at.fq = (uint32_t)fq.size(); at.pos = t.pos[k]; at.support = t.support[k]; at.side = (char)t.side[k];
 			row += name ? name : ""; row += '\t';
 			at.chr_len = (uint32_t)row.size() - 1 - at.row;
-			row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.pos[k])); row += '\t'; row += (char)t.side[k]; row += '\t';
+			row.append(num, put_int(t.pos[k])); row += '\t'; row += (char)t.side[k]; row += '\t';
 			at.cigar = (uint32_t)row.size();
 			for (int q = 0; q < t.n_cigar[k]; ++q) {
 				const uint32_t op = t.cigar ? t.cigar[t.cigar_off[k] + q] : (uint32_t)reinterpret_cast<const uint16_t *>(t.c_cigar)[t.cigar_off[k] + q]; // (compact table: 16 bits an operation)
 				if ((op & 15) == 4 || (op & 15) == 5) continue;
-				row.append(num, (size_t)snprintf(num, sizeof(num), "%u", op >> 4)); row += CIGAR_CHARS[op & 15];
+				row.append(num, put_int((long long)(op >> 4))); row += CIGAR_CHARS[op & 15];
 			}
 			at.cigar_len = (uint32_t)row.size() - at.cigar;
 			row += '\t';
@@ -755,7 +784,7 @@ static void format_clusters(const ssv_cluster_table &t, ssvh_bam *bam, int64_t k
 				row.append(sl, ll); row += '\t'; row.append(ql, lql); row += '\t'; row.append(sr, lr); row += '\t'; row.append(qr, lqr);
 				fq += '@'; fq.append(sr, lr); fq += '\n'; fq.append(sr, lr); fq += "\n+\n"; fq.append(qr, lqr); fq += '\n';
 			}
-			row += '\t'; row.append(num, (size_t)snprintf(num, sizeof(num), "%d", t.support[k])); row += '\n';
+			row += '\t'; row.append(num, put_int(t.support[k])); row += '\n';
 		}
 }
 

@@ -336,3 +336,29 @@ def test_cli_run_equals_three_commands(tmp_path_factory, name, opts, inflate_mod
     if not opts:
         want = [l.split("\t") for l in G.read_text("synth", f"{name}.sv").splitlines() if not l.startswith("@")]
         assert rows == want
+
+
+@pytest.mark.parametrize("n_values", [1, 2, 4, 5, 8, 9, 11, 16, 17, 40, 45, 46])
+def test_cli_getclip_formats_every_quality_alphabet(tmp_path, n_values):
+    """the CLI's row formatter reads the compact table with every shape of quality stream (1-4 bits a quality, three or two qualities a 7-bit group, two an 11-bit
+    group, bytes) and with bases outside A/C/G/T (the exception list): the rows and FASTQ records equal the oracle's on the same records (round 6: the formatter
+    decodes through byte tables and dword stores)"""
+    import numpy as np
+    import oracle_lib
+    from seeksv_amd import synth
+    from test_hip_golden import _remap_qualities, _with_bases
+    w = synth.Workload(genome_frac=1 / 8192, depth=40, n_sv=24)
+    b = w.generate_host(0, w.n_total)
+    alphabet = [(3 + 2 * k) % 94 for k in range(n_values)]
+    b = _remap_qualities(b, alphabet)
+    if n_values % 2 == 0:
+        b = _with_bases(b, lambda r, i, c: 15 if (r * 31 + i) % 53 == 0 else c)   # scattered N
+    bam = str(tmp_path / "q.bam")
+    host.write_bam(bam, w.names, w.lens, [b])
+    _, _, batches = host.read_bam(bam)
+    rows, fq = host.format_clip_outputs(oracle_lib.getclip(batches, 0.9, 1, False), w.names)
+    out = str(tmp_path / "o")
+    r = subprocess.run([SEEKSV, "getclip", "-o", out, bam], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(out + ".clip.gz", "rt").read() == rows
+    assert gzip.open(out + ".clip.fq.gz", "rt").read() == fq
