@@ -1058,14 +1058,14 @@ def cli_path_leg(args, w, bam, d, expect):
     best = None
     for rep in range(2):  # the second run finds the binary, the libraries and the file's pages warm; the better one is reported
         t0 = time.perf_counter()
-        r1 = subprocess.run([exe, "getclip", "-Z", "-o", os.path.join(d, "cli"), bam], capture_output=True, text=True, env=env)
+        r1, c1 = run_command([exe, "getclip", "-Z", "-o", os.path.join(d, "cli"), bam], env)
         t1 = time.perf_counter()
-        r2 = subprocess.run([exe, "getsv", "-Z", "-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip, os.path.join(d, "cli.sv"), os.path.join(d, "cli.x.fq")],
-                            capture_output=True, text=True, env=env)
+        r2, c2 = run_command([exe, "getsv", "-Z", "-d", "0", "-f", "0", "-b", "0", "-B", jfile, empty_bam, bam, empty_clip, os.path.join(d, "cli.sv"), os.path.join(d, "cli.x.fq")], env)
         t2 = time.perf_counter()
         if r1.returncode != 0 or r2.returncode != 0:
             raise RuntimeError((r1.stderr + r2.stderr)[-400:])
-        cur = dict(getclip_s=round(t1 - t0, 3), getsv_s=round(t2 - t1, 3), total_s=round(t2 - t0, 3), getclip_phases_s=phases(r1.stderr), getsv_phases_s=phases(r2.stderr))
+        cur = dict(getclip_s=round(t1 - t0, 3), getsv_s=round(t2 - t1, 3), total_s=round(t2 - t0, 3), getclip_phases_s=c1["phases_s"], getsv_phases_s=c2["phases_s"],
+                   process_s={"getclip": {k: c1.get(k) for k in ("exec_to_main_s", "exit_to_reaped_s")}, "getsv": {k: c2.get(k) for k in ("exec_to_main_s", "exit_to_reaped_s")}})
         if best is None or cur["total_s"] < best["total_s"]:
             best = cur
     res.update(best)

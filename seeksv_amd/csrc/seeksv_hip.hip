@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -15,6 +16,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <deque>
 #include <functional>
 #include <vector>
@@ -261,13 +263,68 @@ int ensure(ssv_ctx *c, DBuf &b, size_t bytes, bool keep = false, size_t keep_byt
 	return SSV_OK;
 }
 
+// Page-locked host memory.  hipHostMalloc hands out 4 KB pages: allocating, clearing and locking them runs on one thread at ~0.25 s/GB under the runtime's lock, and
+// when the process ends the kernel takes every page's lock back one by one - tools/exit_cost.cpp: 4 GB of such memory cost 0.18 s to lock and 0.41-0.45 s between
+// _exit and the parent's wait() returning, whatever else the process held (48 GB of device memory: 0.06 s).  That was the 0.2-0.6 s a `seeksv` command spent AFTER its
+// last statement (round 6, bench.py: exit_to_reaped_s).  Buffers of 2 MB and more are therefore anonymous memory on TRANSPARENT HUGE PAGES (madvise: 2 MB pages where
+// the kernel grants them - it falls back to 4 KB pages by itself), touched by a few threads, then registered with the runtime: 0.008 s to lock 4 GB, 0.001 s to leave.
+// SSV_PINNED=malloc: hipHostMalloc as before (the form the tests compare with).
+namespace {
+struct PinnedMaps { std::mutex mu; std::unordered_map<void *, std::pair<void *, size_t>> m; }; // user pointer -> (mapping, its length)
+PinnedMaps &pinned_maps() { static PinnedMaps *p = new PinnedMaps; return *p; } // (never destroyed: buffers may be freed from static destructors)
+constexpr size_t HUGE_PAGE = (size_t)2 << 20;
+}
+
+static hipError_t pinned_new(void **out, size_t bytes, unsigned malloc_flags)
+{
+	static const bool plain = [] { const char *e = getenv("SSV_PINNED"); return e && !strcmp(e, "malloc"); }();
+	*out = nullptr;
+	if (plain || bytes < HUGE_PAGE) return hipHostMalloc(out, bytes ? bytes : 1, malloc_flags);
+	const size_t n = (bytes + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1), len = n + HUGE_PAGE;
+	void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (m == MAP_FAILED) return hipHostMalloc(out, bytes, malloc_flags);
+	uint8_t *a = reinterpret_cast<uint8_t *>(((uintptr_t)m + HUGE_PAGE - 1) & ~(uintptr_t)(HUGE_PAGE - 1));
+	(void)madvise(a, n, MADV_HUGEPAGE);
+	{ // first touch on a few threads (a fault clears 2 MB - or 4 KB, 512 times as often - before the runtime's call locks the pages one after the other)
+		const int nt = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, n >> 25, (size_t)ssv::effective_cpus()}));
+		auto touch = [a, n, nt](int t) { for (size_t o = n / HUGE_PAGE * (size_t)t / (size_t)nt * HUGE_PAGE, e = n / HUGE_PAGE * (size_t)(t + 1) / (size_t)nt * HUGE_PAGE; o < e; o += 4096) a[o] = 0; };
+		std::vector<std::thread> th;
+		for (int t = 1; t < nt; ++t) th.emplace_back(touch, t);
+		touch(0);
+		for (auto &x : th) x.join();
+	}
+	if (hipHostRegister(a, n, hipHostRegisterPortable) != hipSuccess) { // (a kernel or limit that refuses: the runtime's own allocator)
+		(void)hipGetLastError();
+		munmap(m, len);
+		return hipHostMalloc(out, bytes, malloc_flags);
+	}
+	{ std::lock_guard<std::mutex> lk(pinned_maps().mu); pinned_maps().m[a] = std::make_pair(m, len); }
+	*out = a;
+	return hipSuccess;
+}
+
+static hipError_t pinned_delete(void *p)
+{
+	if (!p) return hipSuccess;
+	std::pair<void *, size_t> mapping(nullptr, 0);
+	{
+		std::lock_guard<std::mutex> lk(pinned_maps().mu);
+		auto it = pinned_maps().m.find(p);
+		if (it != pinned_maps().m.end()) { mapping = it->second; pinned_maps().m.erase(it); }
+	}
+	if (!mapping.first) return hipHostFree(p);
+	const hipError_t e = hipHostUnregister(p);
+	munmap(mapping.first, mapping.second);
+	return e;
+}
+
 int ensure_host(ssv_ctx *c, HBuf &b, size_t bytes)
 {
 	if (bytes <= b.cap) return SSV_OK;
-	if (b.p) HIPCHECK(c, hipHostFree(b.p));
+	if (b.p) HIPCHECK(c, pinned_delete(b.p));
 	size_t ncap = (std::max(bytes, b.cap + b.cap / 2) + 255) & ~(size_t)255;
 	b.p = nullptr; b.cap = 0;
-	HIPCHECK(c, hipHostMalloc(&b.p, ncap, hipHostMallocDefault));
+	HIPCHECK(c, pinned_new(&b.p, ncap, hipHostMallocDefault));
 	b.cap = ncap;
 	return SSV_OK;
 }
@@ -530,9 +587,9 @@ void ssv_ctx_destroy(ssv_ctx *c)
 
 	bamdec_free(c);
 	realign_free(c);
-	if (c->h_batch.p) (void)hipHostFree(c->h_batch.p);
-	if (c->h_qual_lut.p) (void)hipHostFree(c->h_qual_lut.p);
-	if (c->h_pair_lut.p) (void)hipHostFree(c->h_pair_lut.p);
+	if (c->h_batch.p) (void)pinned_delete(c->h_batch.p);
+	if (c->h_qual_lut.p) (void)pinned_delete(c->h_qual_lut.p);
+	if (c->h_pair_lut.p) (void)pinned_delete(c->h_pair_lut.p);
 	// every DBuf / HBuf member
 	if (c->st_h2d) { (void)hipStreamSynchronize(c->st_h2d); (void)hipStreamDestroy(c->st_h2d); }
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage, &c->ends_buf,
@@ -552,12 +609,12 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	if (c->ev_st) (void)hipEventDestroy(c->ev_st);
 	for (DBuf &b : c->blob.chunks) if (b.p) (void)hipFree(b.p);
 	HBuf *hbufs[] = {&c->h_counters, &c->h_totals, &c->h_q};
-	for (HBuf *b : hbufs) if (b->p) (void)hipHostFree(b->p);
+	for (HBuf *b : hbufs) if (b->p) (void)pinned_delete(b->p);
 	for (auto &t : c->tab) {
 		DBuf *td[] = {&t.o_tid, &t.o_pos, &t.o_side, &t.o_support, &t.o_ll, &t.o_lr, &t.o_qmiss, &t.o_ncig, &t.o_stroff, &t.o_cigoff, &t.o_str, &t.o_cig, &t.o_len, &t.o_sup, &t.o_nc, &t.o_runs, &t.o_exc};
 		HBuf *th[] = {&t.h_tid, &t.h_pos, &t.h_side, &t.h_support, &t.h_ll, &t.h_lr, &t.h_qmiss, &t.h_stroff, &t.h_cigoff, &t.h_ncig, &t.h_str, &t.h_cig, &t.h_len, &t.h_sup, &t.h_nc, &t.h_runs, &t.h_exc};
 		for (DBuf *b : td) if (b->p) (void)hipFree(b->p);
-		for (HBuf *b : th) if (b->p) (void)hipHostFree(b->p);
+		for (HBuf *b : th) if (b->p) (void)pinned_delete(b->p);
 		if (t.copied) (void)hipEventDestroy(t.copied);
 		if (t.packed_ev) (void)hipEventDestroy(t.packed_ev);
 	}
@@ -580,14 +637,14 @@ int ssv_host_alloc(size_t bytes, void **p)
 {
 	if (!p) return SSV_E_ARG;
 	*p = nullptr;
-	hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable);
-	if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); *p = nullptr; return SSV_E_NOMEM; }
+	hipError_t e = pinned_new(p, bytes ? bytes : 1, hipHostMallocPortable);
+	if (e != hipSuccess) { g_create_error = std::string("page-locked allocation: ") + hipGetErrorString(e); *p = nullptr; return SSV_E_NOMEM; }
 	return SSV_OK;
 }
 
 int ssv_host_free(void *p)
 {
-	if (p && hipHostFree(p) != hipSuccess) return SSV_E_HIP;
+	if (p && pinned_delete(p) != hipSuccess) return SSV_E_HIP;
 	return SSV_OK;
 }
 

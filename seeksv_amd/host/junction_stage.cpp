@@ -27,6 +27,7 @@
 #include <thread>
 
 #include "../csrc/cpus.h"
+#include "../csrc/thp.h"
 
 #include "seeksv_host.h"
 
@@ -274,6 +275,7 @@ bool slurp_gz_members(const std::string &path, std::unique_ptr<char[]> &buf, siz
 		}
 		if (ok) {
 			buf.reset(new char[at[nm] + 1]);
+			ssv::thp_advise(buf.get(), at[nm] + 1); // (GBs of inflated rows, first touched by the inflating threads: thp.h)
 			buf_len = at[nm];
 			char *const out = buf.get();
 			std::atomic<size_t> next{0};
@@ -429,6 +431,7 @@ bool parse_rows_parallel(const std::vector<TextView> &texts, std::vector<ClipRow
 	size_t total = 0;
 	for (auto &v : part) total += v.size();
 	rows.reserve(total);
+	ssv::thp_advise(rows.data(), rows.capacity() * sizeof(ClipRow));
 	for (auto &v : part) { rows.insert(rows.end(), v.begin(), v.end()); std::vector<ClipRow>().swap(v); }
 	return true;
 }

@@ -27,6 +27,8 @@
 #include <thread>
 #include <vector>
 
+#include "../csrc/thp.h"
+
 namespace seeksv {
 
 class UnmappedPairs {
@@ -194,6 +196,7 @@ private:
 				size_t need = 0;
 				for (size_t k = lo; k < hi; ++k) need += 2 * (size_t)pairs_[k].first.l_seq + pairs_[k].first.name_len + 16;
 				a.reserve(need); b.reserve(need);
+				ssv::thp_advise(a.data(), a.capacity()); ssv::thp_advise(b.data(), b.capacity());
 				for (size_t k = lo; k < hi; ++k) { fastq(pairs_[k].first, '1', a); fastq(pairs_[k].second, '2', b); }
 			};
 			std::vector<std::thread> th;
@@ -248,6 +251,7 @@ private:
 				raw = raw_; bytes = bytes_;
 			}
 			std::unique_ptr<uint8_t[]> own(new uint8_t[bytes]);
+			ssv::thp_advise(own.get(), bytes);
 			memcpy(own.get(), raw, bytes);
 			{ std::lock_guard<std::mutex> lk(in_mu_); in_.emplace_back(std::move(own), bytes); }
 			in_cv_.notify_all();
