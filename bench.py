@@ -108,7 +108,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_dev = dev if (world > 1 and backend == "nccl") else None
     # a host-side group for the waits around rank 0's reporting legs: a rank parked in an RCCL barrier keeps a kernel spinning on its GPU - the GPUs `seeksv -N` (ranks_path) runs on
-    wait_group = dist.new_group(backend="gloo") if world > 1 else None
+    wait_group = None
+    if world > 1:
+        try:
+            wait_group = dist.new_group(backend="gloo")
+        except Exception as e:   # (a host on which gloo finds no interface: the waits go through the job's own backend)
+            print(f"[bench] rank {rank}: no gloo group for the waits ({type(e).__name__}: {e})", file=sys.stderr)
     # N > 1: every rank keeps its threads - and with them the pinned buffers it allocates (the 0.66 GB table lands in them every step) - on the CPUs
     # next to its own GPU, so that eight tables a step do not cross the sockets' link
     near_cpus = bind_near_gpu(torch, local_rank) if world > 1 and os.environ.get("SSV_NO_CPU_BINDING") is None else 0
