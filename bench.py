@@ -753,7 +753,18 @@ def file_path_leg(ctx, args, device):
             NS = 3
 
             def __init__(self):
-                self.bufs = [torch.empty(cap, dtype=torch.uint8, pin_memory=True) for _ in range(self.NS)]   # (like the preloaded chunks: allocated outside the timed region)
+                # (like the preloaded chunks: allocated outside the timed region; from the library's own allocator - page-locked huge pages on the GPU's NUMA node, what the CLI's
+                # staging buffers are since round 6 - so that the leg's copies do not depend on which socket the pages happened to land on)
+                from seeksv_amd.device import PinnedArrays
+                self.pinned = PinnedArrays()
+
+                class Buf:
+                    def __init__(self, a):
+                        self.a = a
+
+                    def data_ptr(self):
+                        return self.a.ctypes.data
+                self.bufs = [Buf(self.pinned.empty(cap, np.uint8)) for _ in range(self.NS)]
                 self.blocks = [(_abi.BgzfBlock * max_blocks)() for _ in range(self.NS)]
 
             def open(self):
@@ -933,6 +944,8 @@ def file_path_leg(ctx, args, device):
         best = min((one_run(True, streamed) for _ in range(3)), key=lambda t: t["total_s"])
         two = min((one_run(False, streamed) for _ in range(2)), key=lambda t: t["total_s"])
         assert best["result"] == pinned_best["result"] and two["result"] == best["result"]
+        streamed.bufs = []
+        streamed.pinned.close()
         inflated = None
         kernel_ms = {k: round(v["total_ms"] / len(runs), 3) for k, v in prof.items() if v["launches"]}
         coder = "the repository's fast deflate coder (single-probe LZ77 + Huffman, huff_gz.h)" if args.file_level == -2 else "deflate level " + str(args.file_level)

@@ -159,6 +159,10 @@ int ssv_host_free(void *p);
  * whole pages by the caller.  SSV_E_HIP when the runtime refuses the range (callers fall back to staging buffers). */
 int ssv_host_register(void *p, size_t bytes);
 int ssv_host_unregister(void *p);
+/* Ask for the pages of [p, p + bytes) - anonymous memory that has not been touched yet - on the NUMA node GPU `device` hangs on (mbind, MPOL_PREFERRED): a copy between the GPU
+ * and host memory on the OTHER socket of a two-socket box crosses the sockets' link and runs at 60-70 % of the PCIe rate (round 6: the same 0.55 GB table took 9.7 or 13.8 ms
+ * depending on where its pages had landed).  ssv_host_alloc does this for what it hands out (the device current at the call).  Best effort: SSV_OK whatever the kernel says. */
+int ssv_host_bind_near(void *p, size_t bytes, int device);
 int ssv_batch_prefetch(ssv_ctx *ctx, const ssv_batch_t *b);
 int ssv_batch_prefetch_drop(ssv_ctx *ctx);
 

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -275,6 +277,34 @@ PinnedMaps &pinned_maps() { static PinnedMaps *p = new PinnedMaps; return *p; } 
 constexpr size_t HUGE_PAGE = (size_t)2 << 20;
 }
 
+// the NUMA node a GPU hangs on (sysfs numa_node of its PCI function; -1: unknown or a one-node box)
+static int device_numa_node(int device)
+{
+	static std::mutex mu;
+	static std::unordered_map<int, int> cache;
+	std::lock_guard<std::mutex> lk(mu);
+	auto it = cache.find(device);
+	if (it != cache.end()) return it->second;
+	int node = -1;
+	char bdf[64] = {0};
+	if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) == hipSuccess) {
+		for (char *q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);
+		const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+		if (FILE *f = fopen(path.c_str(), "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+	} else (void)hipGetLastError();
+	cache[device] = node;
+	return node;
+}
+
+static void bind_near(void *p, size_t bytes, int device)
+{
+	const int node = device_numa_node(device);
+	if (node < 0 || node >= 1024 || !p || !bytes) return;
+	unsigned long mask[16] = {0};
+	mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+	(void)syscall(SYS_mbind, p, (unsigned long)bytes, 1 /* MPOL_PREFERRED */, mask, (unsigned long)(8 * sizeof(mask)), 0u); // (refused by a cpuset that does not hold the node: the pages land where they land)
+}
+
 static hipError_t pinned_new(void **out, size_t bytes, unsigned malloc_flags)
 {
 	static const bool plain = [] { const char *e = getenv("SSV_PINNED"); return e && !strcmp(e, "malloc"); }();
@@ -285,6 +315,7 @@ static hipError_t pinned_new(void **out, size_t bytes, unsigned malloc_flags)
 	if (m == MAP_FAILED) return hipHostMalloc(out, bytes, malloc_flags);
 	uint8_t *a = reinterpret_cast<uint8_t *>(((uintptr_t)m + HUGE_PAGE - 1) & ~(uintptr_t)(HUGE_PAGE - 1));
 	(void)madvise(a, n, MADV_HUGEPAGE);
+	{ int dev = 0; if (hipGetDevice(&dev) == hipSuccess) bind_near(a, n, dev); else (void)hipGetLastError(); } // the pages on the GPU's own NUMA node, whichever CPUs touch them
 	{ // first touch on a few threads (a fault clears 2 MB - or 4 KB, 512 times as often - before the runtime's call locks the pages one after the other)
 		const int nt = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, n >> 25, (size_t)ssv::effective_cpus()}));
 		auto touch = [a, n, nt](int t) { for (size_t o = n / HUGE_PAGE * (size_t)t / (size_t)nt * HUGE_PAGE, e = n / HUGE_PAGE * (size_t)(t + 1) / (size_t)nt * HUGE_PAGE; o < e; o += 4096) a[o] = 0; };
@@ -653,6 +684,12 @@ int ssv_host_register(void *p, size_t bytes)
 	if (!p || !bytes) return SSV_E_ARG;
 	const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
 	if (e != hipSuccess) { (void)hipGetLastError(); g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e); return SSV_E_HIP; }
+	return SSV_OK;
+}
+
+int ssv_host_bind_near(void *p, size_t bytes, int device)
+{
+	bind_near(p, bytes, device);
 	return SSV_OK;
 }
 

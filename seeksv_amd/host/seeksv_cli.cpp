@@ -325,6 +325,7 @@ struct StageBuf {
 	uint8_t *p = nullptr;
 	size_t cap = 0, locked = 0; // locked: bytes from p on that are page-locked
 	void *map_base = nullptr; size_t map_len = 0; // the mapping p lies in (p is 2 MB aligned)
+	int near_device = 0;                          // the GPU its pages should lie beside
 	static size_t page() { static const size_t v = (size_t)sysconf(_SC_PAGESIZE); return v; }
 	bool reserve(size_t want)
 	{
@@ -339,6 +340,7 @@ struct StageBuf {
 		map_base = m; map_len = n + huge;
 		p = reinterpret_cast<uint8_t *>(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1)); cap = n;
 		(void)madvise(p, n, MADV_HUGEPAGE);
+		ssv_host_bind_near(p, n, near_device); // (the reader's pread threads run on any CPU: the pages still land beside the GPU that fetches them)
 		return true;
 	}
 	// the first `filled` bytes have just been written: make sure they are page-locked (a buffer that is mostly full is locked whole, its tail
@@ -370,6 +372,7 @@ struct StageBuf {
 		p = nullptr; cap = locked = 0; map_base = nullptr; map_len = 0;
 	}
 };
+static int g_near_device = 0; // the command's GPU (-G; main() sets it): where page-locked staging memory should lie
 static std::mutex g_stage_pool_mu;
 static vector<StageBuf> g_stage_pool;
 static StageBuf stage_from_pool(size_t want)
@@ -477,11 +480,13 @@ struct BatchSource {
 	}
 	static size_t page_size() { static const size_t p = (size_t)sysconf(_SC_PAGESIZE); return p; }
 	static size_t first_bytes_default() { return (size_t)128 << 20; }
-	static bool take_stage(Slot &S, size_t want)
+	int near_device = g_near_device; // the GPU that fetches this source's chunks: their staging pages are asked for on its NUMA node
+	bool take_stage(Slot &S, size_t want)
 	{
 		if (S.stage.cap >= want) return true;
 		stage_to_pool(S.stage);
 		S.stage = stage_from_pool(want);
+		S.stage.near_device = near_device;
 		return S.stage.reserve(want);
 	}
 	// the reader thread: chunk k into slot k % NS as soon as the decoder has let go of chunk k - NS
@@ -2197,6 +2202,7 @@ int main(int argc, char **argv)
 		for (int k = 2; k + 1 < argc; ++k) if (!strcmp(argv[k], "-G")) { dev = atoi(argv[k + 1]); break; }
 		bool gpu_free = false; // getsv -J stops before any BAM pass (a test hook that needs no GPU)
 		for (int k = 2; k < argc; ++k) if (!strcmp(argv[k], "-J")) gpu_free = true;
+		g_near_device = dev;
 		if (!gpu_free && argc > 3) early_ctx_start(dev);
 	}
 	optind = 1; // like SelectStep (seeksv.cpp:444-452): the sub-command becomes argv[0]
