@@ -332,7 +332,11 @@ def main():
         del scan_batch, scan_t, own_batch, prefix_batch, prefix_t   # (the sample leaves HBM with the leg)
         return dict(locals())
 
+    link = {"what": "device <-> pinned host, 256 MB, [median, slowest] GB/s of four copies, taken between the legs: a neighbour's traffic on a shared PCIe switch halves it (host_link_probe)"}
+    gpu_dev = dev
+    link["before"] = host_link_probe(torch, gpu_dev)
     R = resident(args)
+    link["after the resident leg"] = host_link_probe(torch, gpu_dev)
     import gc
     gc.collect()
     torch.cuda.empty_cache()
@@ -453,6 +457,7 @@ def main():
                     "table": dict(R3["state"].get("table_info", {}), bytes=int(R3["state"].get("table_bytes", 0)), bytes_per_cluster=round(R3["state"].get("table_bytes", 0) / max(1, R3["res"]["n_clusters"]), 1)),
                     "result": R3["res"], "generation_s": round(R3["gen_s"], 2)}
                 del R3
+                link["after config3_path"] = host_link_probe(torch, gpu_dev)
                 gc.collect()
                 torch.cuda.empty_cache()   # (the 49 GB sample goes back to the device: the file leg below keeps its own 49 GB of decoded records)
             except BaseException as e:  # (SystemExit too: a report beside the headline)
@@ -489,6 +494,8 @@ def main():
                     line["file_path"]["same_result_as_resident_path"] = all(fr[k] == line["result"][k] for k in fr if k in line["result"])
             except Exception as e:  # the leg is a report beside the headline, never a reason to lose the line
                 line["file_path"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.file_frac > 0:
+            link["after file_path + cli_path"] = host_link_probe(torch, gpu_dev)
         if world == 1 and args.config5_frac != 0 and not strong:
             try:
                 if args.config5_frac < 0:
@@ -526,10 +533,33 @@ def main():
             allc = cpu_baseline_all_cores(args, w, seconds=4.0)
             if allc:
                 line["cpu_baseline_all_cores"] = allc
+        line["host_link_GBs"] = link
         print(json.dumps(line))
     if world > 1:
         dist.barrier(group=wait_group)
         dist.destroy_process_group()
+
+
+def host_link_probe(torch, dev):
+    """what the host link gives RIGHT NOW: 256 MB device -> pinned host and back, four copies each way, (median, slowest) GB/s.  A box of the pool is one GPU of a node whose other
+    GPUs belong to other tenants; behind a shared PCIe switch a neighbour's transfers halve the rate for as long as they last (round 6, tools/d2h_probe.cpp / free_wipe_probe.cpp: the same
+    copy at 57 or at 30 GB/s from one second to the next, whatever the memory on either side) - the legs of this line that are bound by the link (the table's copy, the file legs) move with it."""
+    n = 256 << 20
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    h = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    out = {}
+    for name, (a, b) in (("d2h", (h, d)), ("h2d", (d, h))):
+        ms = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            a.copy_(b, non_blocking=True)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t) * 1e3)
+        ms = sorted(ms[1:])
+        out[name] = [round(n / ms[len(ms) // 2] / 1e6, 1), round(n / ms[-1] / 1e6, 1)]
+    del d, h
+    return out
 
 
 def launch_ranks(n, argv):

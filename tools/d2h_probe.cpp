@@ -6,6 +6,7 @@
 #include <sys/mman.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -42,7 +43,7 @@ static void run(const char *what, void *h, void *d, size_t n, hipStream_t st)
 {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	printf("%-78s", what);
+	printf("%-78s [dev %p]", what, d);
 	for (int rep = 0; rep < 5; ++rep) {
 		hipEventRecord(e0, st);
 		hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, st);
@@ -76,6 +77,31 @@ int main()
 			printf("-- the device buffer allocated anew, behind 48 GB that stay allocated --\n");
 		}
 	}
-	// with a kernel-free second copy in flight the other way (the resident leg's steady state has uploads and kernels beside the table's copy)
+	// the library's way: nine pieces (the table's columns and its string block) on a SECOND stream, behind an event of the first; host wall clock like ssv_clip_table_wait sees it
+	{
+		hipStream_t st2; hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
+		hipEvent_t packed, copied; hipEventCreateWithFlags(&packed, hipEventDisableTiming); hipEventCreateWithFlags(&copied, hipEventDisableTiming);
+		const size_t piece[9] = {22092000, 22092000, 11046000, 5523000, 5523000, 464930560, 26000000, 3200, 0};
+		std::vector<void *> hp(9, nullptr), dp(9, nullptr);
+		for (int k = 0; k < 9; ++k) if (piece[k]) { hp[k] = huge(piece[k] < ((size_t)2 << 20) ? ((size_t)2 << 20) : piece[k], node); hipMalloc(&dp[k], piece[k] + 4096); hipMemset(dp[k], k, piece[k]); }
+		hipDeviceSynchronize();
+		for (int variant = 0; variant < 3; ++variant) {
+			printf("%-78s", variant == 0 ? "nine pieces on a second stream behind an event" : variant == 1 ? "the same, the big piece first" : "the same as ONE piece of the same total");
+			for (int rep = 0; rep < 10; ++rep) {
+				hipMemsetAsync(d, rep, 1 << 20, st);
+				hipEventRecord(packed, st);
+				hipStreamSynchronize(st);
+				hipStreamWaitEvent(st2, packed, 0);
+				const auto t0 = std::chrono::steady_clock::now();
+				if (variant == 2) hipMemcpyAsync(any, d, n, hipMemcpyDeviceToHost, st2);
+				else for (int q = 0; q < 9; ++q) { const int k = variant == 1 ? (q == 0 ? 5 : q <= 5 ? q - 1 : q) : q; if (piece[k]) hipMemcpyAsync(hp[k], dp[k], piece[k], hipMemcpyDeviceToHost, st2); }
+				hipEventRecord(copied, st2);
+				hipEventSynchronize(copied);
+				printf(" %6.2f", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+			}
+			printf(" ms\n");
+			fflush(stdout);
+		}
+	}
 	return 0;
 }
