@@ -332,7 +332,7 @@ def main():
         del scan_batch, scan_t, own_batch, prefix_batch, prefix_t   # (the sample leaves HBM with the leg)
         return dict(locals())
 
-    link = {"what": "device <-> pinned host, 256 MB, [median, slowest] GB/s of four copies, taken between the legs: a neighbour's traffic on a shared PCIe switch halves it (host_link_probe)"}
+    link = {"what": "device <-> pinned host through hipMemcpyAsync (the runtime's choice of SDMA engine), 256 MB, [median, slowest] GB/s of four copies, taken between the legs (host_link_probe)"}
     gpu_dev = dev
     link["before"] = host_link_probe(torch, gpu_dev)
     R = resident(args)
@@ -541,9 +541,9 @@ def main():
 
 
 def host_link_probe(torch, dev):
-    """what the host link gives RIGHT NOW: 256 MB device -> pinned host and back, four copies each way, (median, slowest) GB/s.  A box of the pool is one GPU of a node whose other
-    GPUs belong to other tenants; behind a shared PCIe switch a neighbour's transfers halve the rate for as long as they last (round 6, tools/d2h_probe.cpp / free_wipe_probe.cpp: the same
-    copy at 57 or at 30 GB/s from one second to the next, whatever the memory on either side) - the legs of this line that are bound by the link (the table's copy, the file legs) move with it."""
+    """what the host link gives RIGHT NOW through the runtime's own choice of SDMA engine: 256 MB device -> pinned host and back, four copies each way, (median, slowest) GB/s.  One of the engines
+    hipMemcpyAsync alternates between is busy for seconds behind every large free of device memory (profiles/r06_host_link.txt) and a copy on it gets half the link: the library's large copies go
+    to an engine by name and move on when that happens (LinkCopy, seeksv_hip.hip); these numbers say what the box was like around the legs."""
     n = 256 << 20
     d = torch.empty(n, dtype=torch.uint8, device=dev)
     h = torch.empty(n, dtype=torch.uint8, pin_memory=True)

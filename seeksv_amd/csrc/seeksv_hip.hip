@@ -3,6 +3,8 @@
 #include "seeksv_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/syscall.h>
@@ -119,6 +121,31 @@ struct HostPool {
 	}
 };
 
+// ---- copies over the host link on an SDMA engine WE name ----
+// hipMemcpyAsync lets the runtime pick the engine, and an MI355X has sixteen of which only four sit beside the PCIe root (tools/sdma_engine_probe.cpp: a 0.55 GB device-to-host copy takes
+// 9.72 ms on engines 0-3, 43 ms on 4-7, 55-60 ms on 8-11, 72-78 ms on 12-15; host-to-device 9.65 / 10.9 / 13.7-15.2 / 18-19.5 ms).  On some boxes of the pool the runtime's choice (or the way
+// it splits a large copy over several engines) made the SAME cluster table cross PCIe in 9.7 or in 12-18 ms from one copy to the next, and the compressed chunks of a BAM at 36-46 GB/s instead
+// of 57 (round 6, profiles/r06_host_link.txt).  The two copies this path lives on - the cluster table to the host, a BAM's compressed chunks to the device - therefore go to the runtime's
+// layer below HIP (hsa_amd_memory_async_copy_on_engine, found with dlsym: no link-time dependency) on the engine hsa_amd_memory_get_preferred_copy_engine names for the direction, with an HSA
+// signal for the end.  Anything missing - the library, a symbol, the agents, a preferred engine - and the copy is hipMemcpyAsync's as before.  SSV_LINK_COPY=hip: that form always.
+struct LinkCopy {
+	bool ok = false;
+	hsa_agent_t gpu{}, cpu{};
+	uint32_t eng_to_host = 0, eng_to_device = 0; // the engine in use per direction, one bit each (hsa_amd_sdma_engine_id_t)
+	// An engine is not ours alone: the kernel driver wipes freed device memory on one of them - for seconds behind a free of tens of GB, ours or that of the process before us -, and a
+	// copy that shares it runs at half the link's rate (tools/free_wipe_probe.cpp, tools/sdma_engine_probe.cpp: engine 1 at 18.4 ms while 0, 2, 3 took 9.7).  So every large copy is
+	// timed (the runtime's async-copy timestamps) and a direction moves on to the next of its candidate engines when a copy came in well below the best rate seen.
+	struct Dir { std::vector<uint32_t> cand; std::vector<double> rate; size_t cur = 0; } to_host, to_device; // rate: GB/s of the candidate's last timed copy (0: not tried yet)
+	double ticks_per_s = 0;
+	decltype(&hsa_amd_profiling_get_async_copy_time) copy_time = nullptr;
+	decltype(&hsa_signal_create) signal_create = nullptr;
+	decltype(&hsa_signal_destroy) signal_destroy = nullptr;
+	decltype(&hsa_signal_store_relaxed) signal_store = nullptr;
+	decltype(&hsa_signal_wait_scacquire) signal_wait = nullptr;
+	decltype(&hsa_signal_load_relaxed) signal_load = nullptr;
+	decltype(&hsa_amd_memory_async_copy_on_engine) copy_on_engine = nullptr;
+};
+
 struct ssv_ctx {
 	int device = 0;
 	hipStream_t st = nullptr;
@@ -177,6 +204,9 @@ struct ssv_ctx {
 		std::vector<uint64_t> x_stroff, x_cigoff;
 		bool expanded = false, ordered = false;
 		hipEvent_t copied = nullptr;
+		hsa_signal_t copied_sig{};                      // ... or, when the copy went to a named SDMA engine (LinkCopy), its HSA signal: zero when every piece has landed
+		bool via_link = false;
+		hsa_signal_t big_sig{}; size_t big_bytes = 0;     // the largest piece (the string block) on a signal of its own: it is the one that is timed
 		hipEvent_t packed_ev = nullptr;                 // the set's pack kernels are done (its copy waits for it): one event per set - a copy that is
 		                                                // still queued behind the table before must not see the next pass's record of a shared event
 		bool in_flight = false;
@@ -190,6 +220,7 @@ struct ssv_ctx {
 	DBuf qual_lut, qual_seen, pair_lut; HBuf h_qual_lut, h_pair_lut;
 	hipStream_t st_copy = nullptr;
 	hipEvent_t ev_packed = nullptr;
+	LinkCopy link;             // the named SDMA engines of the host link (ok == false: hipMemcpyAsync)
 
 	// ---- isize ----
 	bool isz_active = false;
@@ -347,6 +378,135 @@ static hipError_t pinned_delete(void *p)
 	const hipError_t e = hipHostUnregister(p);
 	munmap(mapping.first, mapping.second);
 	return e;
+}
+
+// find the agents and the engines (once per context; quiet on failure: the context then copies the runtime's way)
+static void link_init(ssv_ctx *c)
+{
+	LinkCopy &L = c->link;
+	const char *e = getenv("SSV_LINK_COPY");
+	if (e && !strcmp(e, "hip")) return;
+	void *lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
+	if (!lib) lib = dlopen("libhsa-runtime64.so", RTLD_NOW | RTLD_GLOBAL);
+	if (!lib) return;
+	auto sym = [&](const char *name) { return dlsym(lib, name); };
+	auto f_init = reinterpret_cast<decltype(&hsa_init)>(sym("hsa_init"));
+	auto f_iter = reinterpret_cast<decltype(&hsa_iterate_agents)>(sym("hsa_iterate_agents"));
+	auto f_info = reinterpret_cast<decltype(&hsa_agent_get_info)>(sym("hsa_agent_get_info"));
+	auto f_pref = reinterpret_cast<decltype(&hsa_amd_memory_get_preferred_copy_engine)>(sym("hsa_amd_memory_get_preferred_copy_engine"));
+	auto f_stat = reinterpret_cast<decltype(&hsa_amd_memory_copy_engine_status)>(sym("hsa_amd_memory_copy_engine_status"));
+	L.signal_create = reinterpret_cast<decltype(L.signal_create)>(sym("hsa_signal_create"));
+	L.signal_destroy = reinterpret_cast<decltype(L.signal_destroy)>(sym("hsa_signal_destroy"));
+	L.signal_store = reinterpret_cast<decltype(L.signal_store)>(sym("hsa_signal_store_relaxed"));
+	L.signal_wait = reinterpret_cast<decltype(L.signal_wait)>(sym("hsa_signal_wait_scacquire"));
+	L.signal_load = reinterpret_cast<decltype(L.signal_load)>(sym("hsa_signal_load_relaxed"));
+	L.copy_on_engine = reinterpret_cast<decltype(L.copy_on_engine)>(sym("hsa_amd_memory_async_copy_on_engine"));
+	if (!f_init || !f_iter || !f_info || !f_pref || !f_stat || !L.signal_create || !L.signal_destroy || !L.signal_store || !L.signal_wait || !L.signal_load || !L.copy_on_engine) return;
+	if (f_init() != HSA_STATUS_SUCCESS) return; // (reference counted: HIP holds the runtime up already)
+	// the GPU agent with this device's PCI address, and a CPU agent
+	char bdf[64] = {0};
+	if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), c->device) != hipSuccess) { (void)hipGetLastError(); return; }
+	unsigned dom = 0, bus = 0, dev = 0, fn = 0;
+	if (sscanf(bdf, "%x:%x:%x.%x", &dom, &bus, &dev, &fn) != 4) return;
+	struct Find { decltype(f_info) info; uint32_t want_bdf, want_dom; hsa_agent_t gpu, cpu; bool have_gpu, have_cpu; } F{f_info, (bus << 8) | (dev << 3) | fn, dom, {}, {}, false, false};
+	f_iter([](hsa_agent_t a, void *p) -> hsa_status_t {
+		Find &F = *static_cast<Find *>(p);
+		hsa_device_type_t t;
+		if (F.info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+		if (t == HSA_DEVICE_TYPE_CPU && !F.have_cpu) { F.cpu = a; F.have_cpu = true; }
+		if (t == HSA_DEVICE_TYPE_GPU && !F.have_gpu) {
+			uint32_t b = 0, d = 0;
+			if (F.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &b) == HSA_STATUS_SUCCESS && F.info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &d) == HSA_STATUS_SUCCESS && b == F.want_bdf && d == F.want_dom) {
+				F.gpu = a; F.have_gpu = true;
+			}
+		}
+		return HSA_STATUS_SUCCESS;
+	}, &F);
+	if (!F.have_gpu || !F.have_cpu) return;
+	// candidates per direction: the engines the runtime prefers for it, then the others among the four lowest it reports (the ones beside the PCIe root on this chip; an older
+	// runtime - the one a PyTorch wheel carries - names no preference at all)
+	auto candidates = [&](hsa_agent_t dst, hsa_agent_t src, LinkCopy::Dir &D) {
+		uint32_t pref = 0, avail = 0;
+		if (f_pref(dst, src, &pref) != HSA_STATUS_SUCCESS) pref = 0;
+		if (f_stat(dst, src, &avail) != HSA_STATUS_SUCCESS) avail = 0;
+		for (int pass = 0; pass < 2; ++pass)
+			for (uint32_t b = 0; b < 16; ++b) {
+				const uint32_t bit = 1u << b;
+				const bool take = pass == 0 ? (pref & bit) != 0 : (!(pref & bit) && (avail & bit) && b < 4);
+				if (take) { D.cand.push_back(bit); D.rate.push_back(0.0); }
+			}
+	};
+	L.gpu = F.gpu; L.cpu = F.cpu;
+	candidates(F.cpu, F.gpu, L.to_host);
+	candidates(F.gpu, F.cpu, L.to_device);
+	if (L.to_host.cand.empty() || L.to_device.cand.empty()) return;
+	if (L.to_host.cand.size() > 1 && L.to_host.cand[0] == L.to_device.cand[0]) L.to_host.cur = 1; // the two directions start on engines of their own (both run at once: tables out, chunks in)
+	L.eng_to_host = L.to_host.cand[L.to_host.cur]; L.eng_to_device = L.to_device.cand[L.to_device.cur];
+	{ // timestamps of the copies (the runtime's own profiling of async copies): without them the engines stay where they start
+		auto f_prof = reinterpret_cast<decltype(&hsa_amd_profiling_async_copy_enable)>(sym("hsa_amd_profiling_async_copy_enable"));
+		auto f_sys = reinterpret_cast<decltype(&hsa_system_get_info)>(sym("hsa_system_get_info"));
+		L.copy_time = reinterpret_cast<decltype(L.copy_time)>(sym("hsa_amd_profiling_get_async_copy_time"));
+		uint64_t hz = 0;
+		if (f_prof && f_sys && L.copy_time && f_prof(true) == HSA_STATUS_SUCCESS && f_sys(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &hz) == HSA_STATUS_SUCCESS && hz) L.ticks_per_s = (double)hz;
+		else L.copy_time = nullptr;
+	}
+	L.ok = true;
+	if (getenv("SSV_TIMING")) fprintf(stderr, "[timing] (host link: SDMA engines by name - to the host 0x%x of %zu candidates, to the device 0x%x of %zu%s)\n", L.eng_to_host, L.to_host.cand.size(), L.eng_to_device,
+	                                  L.to_device.cand.size(), L.copy_time ? ", copies timed" : "");
+}
+
+// one copy on the direction's engine; `sig` loses one when it has landed.  false: not done (the caller copies the runtime's way)
+static bool link_copy(ssv_ctx *c, void *dst, const void *src, size_t bytes, bool to_host, hsa_signal_t sig)
+{
+	const LinkCopy &L = c->link;
+	if (!L.ok || !bytes) return false;
+	return L.copy_on_engine(dst, to_host ? L.cpu : L.gpu, src, to_host ? L.gpu : L.cpu, bytes, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)(to_host ? L.eng_to_host : L.eng_to_device), true) == HSA_STATUS_SUCCESS;
+}
+
+// is [p, p + bytes) page-locked host memory the runtime knows (hipHostMalloc, hipHostRegister)?  Only such memory may be handed to an SDMA engine by address
+static bool link_host_ok(const void *p)
+{
+	hipPointerAttribute_t a;
+	memset(&a, 0, sizeof(a));
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+	return a.type == hipMemoryTypeHost;
+}
+
+static void link_wait(ssv_ctx *c, hsa_signal_t sig)
+{
+	while (c->link.signal_wait(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+}
+
+// a large copy has landed (its own signal: `sig`): what rate did its engine give, and should the direction move on?
+static void link_timed(ssv_ctx *c, hsa_signal_t sig, size_t bytes, bool to_host)
+{
+	LinkCopy &L = c->link;
+	if (!L.copy_time || bytes < ((size_t)8 << 20)) return;
+	hsa_amd_profiling_async_copy_time_t t{};
+	if (L.copy_time(sig, &t) != HSA_STATUS_SUCCESS || t.end <= t.start) return;
+	LinkCopy::Dir &D = to_host ? L.to_host : L.to_device;
+	const double rate = (double)bytes / ((double)(t.end - t.start) / L.ticks_per_s) / 1e9;
+	D.rate[D.cur] = rate;
+	double best = 0;
+	for (double r : D.rate) best = std::max(best, r);
+	if (rate >= 0.85 * best && rate >= 40.0) return; // (a PCIe Gen5 x16 link gives 55-57 GB/s)
+	// well below what this direction has seen (or what the link should give): an engine not tried yet, else the one whose last copy was the fastest
+	size_t next = D.cur;
+	for (size_t k = 0; k < D.cand.size(); ++k) if (D.rate[k] == 0.0) { next = k; break; }
+	if (next == D.cur) for (size_t k = 0; k < D.cand.size(); ++k) if (D.rate[k] > D.rate[next]) next = k;
+	if (next != D.cur) {
+		if (getenv("SSV_TIMING")) fprintf(stderr, "[timing] (host link: %s at %.1f GB/s on engine 0x%x: on to engine 0x%x)\n", to_host ? "to the host" : "to the device", rate, D.cand[D.cur], D.cand[next]);
+		D.cur = next;
+		(to_host ? L.eng_to_host : L.eng_to_device) = D.cand[next];
+	} else if (best > rate) D.rate[D.cur] = rate; // (everything is slow right now: stay, and let the stale best rates of the others age)
+	for (size_t k = 0; k < D.cand.size(); ++k) if (k != D.cur && D.rate[k] > 0.0) D.rate[k] = std::max(rate, D.rate[k] * 0.9); // (what an engine gave a while ago counts for less and less)
+}
+
+static void table_link_wait(ssv_ctx *c, ssv_ctx::TableSet &T)
+{
+	link_wait(c, T.copied_sig);
+	link_wait(c, T.big_sig);
+	if (T.big_bytes) { link_timed(c, T.big_sig, T.big_bytes, true); T.big_bytes = 0; }
 }
 
 int ensure_host(ssv_ctx *c, HBuf &b, size_t bytes)
@@ -603,6 +763,8 @@ int ssv_ctx_create(int device, ssv_ctx **out)
 	    hipEventCreateWithFlags(&c->tab[1].copied, hipEventDisableTiming) != hipSuccess) {
 		g_create_error = "cannot create the copy stream / events"; ssv_ctx_destroy(c); return SSV_E_NODEVICE;
 	}
+	link_init(c);
+	if (c->link.ok) for (auto &t : c->tab) if (c->link.signal_create(0, 0, nullptr, &t.copied_sig) != HSA_STATUS_SUCCESS || c->link.signal_create(0, 0, nullptr, &t.big_sig) != HSA_STATUS_SUCCESS) { c->link.ok = false; break; }
 	*out = c;
 	return SSV_OK;
 }
@@ -616,6 +778,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->st);
 
+	for (auto &t : c->tab) if (t.in_flight && t.via_link) { table_link_wait(c, t); t.in_flight = false; } // (a table still on its way out: its buffers go below)
 	bamdec_free(c);
 	realign_free(c);
 	if (c->h_batch.p) (void)pinned_delete(c->h_batch.p);
@@ -647,6 +810,8 @@ void ssv_ctx_destroy(ssv_ctx *c)
 		for (DBuf *b : td) if (b->p) (void)hipFree(b->p);
 		for (HBuf *b : th) if (b->p) (void)pinned_delete(b->p);
 		if (t.copied) (void)hipEventDestroy(t.copied);
+		if (c->link.signal_destroy && t.copied_sig.handle) (void)c->link.signal_destroy(t.copied_sig);
+		if (c->link.signal_destroy && t.big_sig.handle) (void)c->link.signal_destroy(t.big_sig);
 		if (t.packed_ev) (void)hipEventDestroy(t.packed_ev);
 	}
 	if (c->st_copy) { (void)hipStreamSynchronize(c->st_copy); (void)hipStreamDestroy(c->st_copy); }
@@ -981,7 +1146,7 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 	// take the table set that is not the most recent one; its previous copy (two calls ago) must have landed
 	const int s_ = c->tab_cur ^ 1;
 	ssv_ctx::TableSet &T = c->tab[s_];
-	if (T.in_flight) { HIPCHECK(c, hipEventSynchronize(T.copied)); T.in_flight = false; }
+	if (T.in_flight) { if (T.via_link) table_link_wait(c, T); else HIPCHECK(c, hipEventSynchronize(T.copied)); T.in_flight = false; }
 	c->tab_cur = s_;
 	const int64_t E = c->n_events, EL = c->n_l, ER = c->n_r;
 	T.n_events = E; T.n_clusters = 0;
@@ -1299,13 +1464,34 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 		      {&T.h_ll, &T.o_ll, (size_t)nc * 4}, {&T.h_lr, &T.o_lr, (size_t)nc * 4}, {&T.h_qmiss, &T.o_qmiss, (size_t)nc}, {&T.h_stroff, &T.o_stroff, (size_t)nc * 8},
 		      {&T.h_cigoff, &T.o_cigoff, (size_t)nc * 8}, {&T.h_ncig, &T.o_ncig, (size_t)nc * 4}, {&T.h_str, &T.o_str, (size_t)str_total}, {&T.h_cig, &T.o_cig, (size_t)cig_total * 4}};
 	// the table goes to pinned host memory on the copy stream, behind the pack kernels; ssv_clip_table_wait() waits for it
-	HIPCHECK(c, hipEventRecord(T.packed_ev, c->st));
-	HIPCHECK(c, hipStreamWaitEvent(c->st_copy, T.packed_ev, 0));
-	for (auto &x : cp) {
-		CHECK(ensure_host(c, *x.h, x.bytes + 16));
-		if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st_copy));
+	for (auto &x : cp) CHECK(ensure_host(c, *x.h, x.bytes + 16));
+	T.via_link = false;
+	if (c->link.ok) {
+		// (the pack kernels are done: the loop above left through a synchronisation of the stream.)  Every piece on the engine of the direction; the signal counts them down.
+		int64_t pieces = 0;
+		const CopyItem *big = nullptr;
+		for (auto &x : cp) if (x.bytes) { ++pieces; if (!big || x.bytes > big->bytes) big = &x; }
+		T.big_bytes = big ? big->bytes : 0;
+		c->link.signal_store(T.copied_sig, pieces - (big ? 1 : 0));
+		c->link.signal_store(T.big_sig, big ? 1 : 0);
+		int64_t started = 0;
+		for (auto &x : cp) if (x.bytes) { if (!link_copy(c, x.h->p, x.d->p, x.bytes, true, &x == big ? T.big_sig : T.copied_sig)) break; ++started; }
+		if (started == pieces) T.via_link = true;
+		else { // an engine that refuses: let what was started land, then copy everything the runtime's way
+			bool big_started = false;
+			{ int64_t k = 0; for (auto &x : cp) if (x.bytes) { if (k < started && &x == big) big_started = true; ++k; } }
+			c->link.signal_store(T.copied_sig, c->link.signal_load(T.copied_sig) - ((pieces - started) - (big && !big_started ? 1 : 0)));
+			if (big && !big_started) c->link.signal_store(T.big_sig, 0);
+			link_wait(c, T.copied_sig); link_wait(c, T.big_sig);
+			c->link.ok = false;
+		}
 	}
-	HIPCHECK(c, hipEventRecord(T.copied, c->st_copy));
+	if (!T.via_link) {
+		HIPCHECK(c, hipEventRecord(T.packed_ev, c->st));
+		HIPCHECK(c, hipStreamWaitEvent(c->st_copy, T.packed_ev, 0));
+		for (auto &x : cp) if (x.bytes) HIPCHECK(c, hipMemcpyAsync(x.h->p, x.d->p, x.bytes, hipMemcpyDeviceToHost, c->st_copy));
+		HIPCHECK(c, hipEventRecord(T.copied, c->st_copy));
+	}
 	T.in_flight = true;
 	// size the other table set like this one now (pinning ~2 GB of host memory takes ~100 ms: better here than in the caller's next pass)
 	ssv_ctx::TableSet &O = c->tab[s_ ^ 1];
@@ -1355,7 +1541,7 @@ static int table_wait(ssv_ctx *c, int which, ssv_cluster_table *out)
 	memset(out, 0, sizeof(*out));
 	if (T.in_flight) {
 		ProfScope pd(c, P_TABLE_D2H, T.n_clusters); // what is left of the copy when the caller asks for the table
-		HIPCHECK(c, hipEventSynchronize(T.copied));
+		if (T.via_link) table_link_wait(c, T); else HIPCHECK(c, hipEventSynchronize(T.copied));
 		T.in_flight = false;
 	}
 	out->n_events = T.n_events; out->n_clusters = T.n_clusters; out->seq_packed = T.packed; out->qual_bits = T.qual_bits; out->qual_group = T.qual_group; memcpy(out->qual_alphabet, T.qual_alphabet, sizeof(out->qual_alphabet));
