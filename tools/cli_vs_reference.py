@@ -28,9 +28,12 @@ def phases(stderr):
     """the `[timing] phase seconds s` lines the CLI prints under SSV_TIMING=1"""
     out = {}
     for line in stderr.splitlines():
-        if line.startswith("[timing] "):
-            name, sec, _ = line[9:].rsplit(" ", 2)
-            out[name] = round(float(sec), 3)
+        if line.startswith("[timing] ") and not line.startswith("[timing] ("):   # (the bracketed lines are detail, not phases)
+            try:
+                name, sec, _ = line[9:].rsplit(" ", 2)
+                out[name] = round(float(sec), 3)
+            except ValueError:
+                pass
     return out
 
 
