@@ -1344,14 +1344,17 @@ struct SlotCluster {
 	uint8_t qmiss_multi;
 };
 
+// (dense == false: everything but the three scanned words c, cig_off, str_off - the one-pass kernel works those out itself)
+template <bool dense = true>
 __device__ __forceinline__ SlotCluster slot_cluster_load(const PackArgs &p, int64_t j)
 {
 	SlotCluster s;
 	s.support = p.c.support[j];
 	s.cluster = s.support > 0;
 	s.single = !p.c.mflag[j] || s.support == 1;
-	const uint64_t sc = p.slot_cnt[j];
-	s.c = (uint32_t)sc; s.cig_off = sc >> 32; s.str_off = p.slot_bytes[j]; s.key = p.c.skey[j];
+	if (dense) { const uint64_t sc = p.slot_cnt[j]; s.c = (uint32_t)sc; s.cig_off = sc >> 32; s.str_off = p.slot_bytes[j]; }
+	else { s.c = 0; s.cig_off = 0; s.str_off = 0; }
+	s.key = p.c.skey[j];
 	const uint32_t e = s.single ? (uint32_t)j : p.c.c_cig_ev[j];
 	const uint4 *ep = reinterpret_cast<const uint4 *>(p.c.ev + (s.cluster ? e : 0u));
 	const uint4 ea = ep[0], eb = ep[1], ec = ep[2], ed = ep[3];

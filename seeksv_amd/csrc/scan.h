@@ -36,7 +36,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(const TIn *__restrict__ i
 // This kernel runs once per device-wide scan, ~25 times per pass of the path: walking the runs in global memory (a dependent load per
 // element) took 13-40 us per call, 0.2 ms per pass.
 template <typename TOut>
-__global__ __launch_bounds__(BLOCK) void k_scan_sums(TOut *__restrict__ sums, int64_t m, TOut carry_in, TOut *__restrict__ total)
+__device__ __forceinline__ void scan_sums_body(TOut *__restrict__ sums, int64_t m, TOut carry_in, TOut *__restrict__ total)
 {
 	constexpr int PER = 16, CH = BLOCK * PER;
 	__shared__ TOut buf[CH + BLOCK];
@@ -69,6 +69,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan_sums(TOut *__restrict__ sums, in
 	}
 	if (threadIdx.x == 0 && total) *total = carry;
 }
+
+template <typename TOut>
+__global__ __launch_bounds__(BLOCK) void k_scan_sums(TOut *__restrict__ sums, int64_t m, TOut carry_in, TOut *__restrict__ total) { scan_sums_body(sums, m, carry_in, total); }
+
+// several independent lists of sums, `stride` elements apart: one workgroup each
+template <typename TOut>
+__global__ __launch_bounds__(BLOCK) void k_scan_sums_lists(TOut *__restrict__ sums, int64_t m, int64_t stride) { scan_sums_body<TOut>(sums + (int64_t)blockIdx.x * stride, m, (TOut)0, nullptr); }
 
 // out[i] = block_sums[block] + exclusive prefix of in within the block (block_sums already include carry_in)
 template <typename TIn, typename TOut>

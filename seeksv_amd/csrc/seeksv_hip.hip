@@ -183,7 +183,7 @@ struct ssv_ctx {
 	uint64_t sum_ncig = 0;
 	int max_lq = 0, max_ncig = 0;
 	// clustering temporaries / outputs
-	DBuf keys2[2], vals2[2], evs, cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_bflag, c_boff, c_blist, c_dlist, bins4_tab, c_strings, slot_cnt, slot_bytes;
+	DBuf keys2[2], vals2[2], evs, cum_l, cum_r, ghist, c_support, c_ll, c_lr, c_cig_ev, c_qmiss, c_mflag, c_mslot, c_mlist, c_bflag, c_boff, c_blist, c_dlist, bins4_tab, c_strings, slot_cnt, slot_bytes, tile_sums;
 	DBuf o_slowlist, o_desc, totals;
 	HBuf h_totals;
 	// the dense cluster table: device columns + pinned host copy, double buffered so that the PCIe copy of one table can overlap
@@ -789,7 +789,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	DBuf *dbufs[] = {&c->tile_cnt, &c->tile_off, &c->tile_base, &c->scan_scratch, &c->scan_scratch64, &c->counters, &c->d_last_tid, &c->stage, &c->cand, &c->cand_cnt, &c->cand_off, &c->kv_stage, &c->ends_buf,
 	                 &c->ev, &c->ev_meta, &c->ev_idx, &c->key_l, &c->val_l, &c->key_r[0], &c->key_r[1], &c->val_r[0], &c->val_r[1], &c->g_seq_bytes, &c->g_cig_ops, &c->g_seq_off, &c->g_cig_off, &c->keys2[0],
 	                 &c->keys2[1], &c->vals2[0], &c->vals2[1], &c->evs, &c->cum_l, &c->cum_r, &c->ghist, &c->c_support, &c->c_ll, &c->c_lr, &c->c_cig_ev, &c->c_qmiss, &c->c_mflag, &c->c_mslot, &c->c_mlist, &c->c_bflag, &c->c_boff, &c->c_blist, &c->c_dlist, &c->bins4_tab, &c->c_strings,
-	                 &c->slot_cnt, &c->slot_bytes, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->pair_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
+	                 &c->slot_cnt, &c->slot_bytes, &c->tile_sums, &c->o_slowlist, &c->o_desc, &c->totals, &c->qual_lut, &c->pair_lut, &c->qual_seen, &c->isz_vals, &c->isz_acc, &c->isz_tmp,
 	                 &c->gs_djunc, &c->gs_counts, &c->gs_wtid, &c->gs_wbeg, &c->gs_wend, &c->gs_woff, &c->gs_diff, &c->gs_tilemap, &c->gs_tile_win, &c->gs_tile_junc, &c->dense_list, &c->cap_flags, &c->cap_deep, &c->cap_carry,
 	                 &c->cap_ring, &c->cap_ring_tmp, &c->cap_tail[0][0], &c->cap_tail[0][1], &c->cap_tail[0][2], &c->cap_tail[0][3], &c->cap_tail[1][0], &c->cap_tail[1][1], &c->cap_tail[1][2], &c->cap_tail[1][3],
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
@@ -1378,13 +1378,27 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 					HIPCHECK(c, hipMemcpyAsync(c->pair_lut.p, c->h_pair_lut.p, 8192, hipMemcpyHostToDevice, c->st));
 				}
 			}
-			k_cluster_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
-			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_cnt, pa.slot_cnt, E, 0ull, P<uint64_t>(c->scan_scratch64), tot);
-			exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_bytes, pa.slot_bytes, E, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
 			uint8_t *os = P<uint8_t>(T.o_str);
 			PackDesc *dsc = P<PackDesc>(c->o_desc);
-			if (fmt3) k_cluster_cols3<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, p3, dsc, P<uint32_t>(T.o_cig));
-			else k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, dsc, P<uint32_t>(T.o_cig));
+			// format 3: the scans behind the rows' columns over tiles of 256 slots (k_cluster_tile_sums, k_cluster_cols3_tiles); SSV_PACK_COLS=split: two words per slot,
+			// two device-wide scans, then the columns, as before round 6
+			static const bool split_cols = [] { const char *e = getenv("SSV_PACK_COLS"); return e && !strcmp(e, "split"); }();
+			if (fmt3 && !split_cols) {
+				const unsigned tiles = grid_for(E, BLOCK);
+				const int64_t stride = ((int64_t)tiles + 63) & ~63ll;
+				CHECK(ensure(c, c->tile_sums, (size_t)stride * 3 * 8));
+				TileSums ts;
+				ts.clusters = P<uint64_t>(c->tile_sums); ts.cig = ts.clusters + stride; ts.bytes = ts.cig + stride;
+				k_cluster_tile_sums<<<tiles, BLOCK, 0, c->st>>>(pa, ts);
+				k_scan_sums_lists<uint64_t><<<3, BLOCK, 0, c->st>>>(ts.clusters, (int64_t)tiles, stride);
+				k_cluster_cols3_tiles<<<tiles, BLOCK, 0, c->st>>>(pa, p3, dsc, P<uint32_t>(T.o_cig), ts, tot);
+			} else {
+				k_cluster_meta<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa);
+				exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_cnt, pa.slot_cnt, E, 0ull, P<uint64_t>(c->scan_scratch64), tot);
+				exclusive_scan<uint64_t, uint64_t>(c->st, pa.slot_bytes, pa.slot_bytes, E, 0ull, P<uint64_t>(c->scan_scratch64), tot + 1);
+				if (fmt3) k_cluster_cols3<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, p3, dsc, P<uint32_t>(T.o_cig));
+				else k_cluster_cols<<<grid_for(E, BLOCK), BLOCK, 0, c->st>>>(pa, dsc, P<uint32_t>(T.o_cig));
+			}
 			const unsigned int *nc_dev = reinterpret_cast<const unsigned int *>(tot);
 			if (fmt3) {
 				// one group of lanes per cluster (the grid is an upper bound, the kernel reads the cluster count itself), then the base-by-base path

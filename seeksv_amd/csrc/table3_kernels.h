@@ -123,6 +123,141 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_cols3(PackArgs p, Pack3Args q
 	dd[1] = make_uint4((uint32_t)s.lq, (uint32_t)s.ll, (uint32_t)s.lr, s.single ? (uint32_t)s.begin : (uint32_t)j);
 }
 
+// ---- the same with the scans over TILES instead of slots (round 6).  k_cluster_meta, the two device-wide scans behind it and k_cluster_cols3 carried two 8-byte
+// words per slot through memory four times (written, scanned twice, read: 0.5 GB a step); here
+//   k_cluster_tile_sums  adds up, per tile of 256 slots, what its clusters put into the table (clusters, CIGAR operations, string bytes) and lists the long reads,
+//   k_scan_sums_lists    scans the three lists of tile sums (a workgroup each: 25 K tiles a step, 35 us - letting every workgroup of the third kernel add up the
+//                        tiles before its own instead, through sums of groups of 64 tiles, cost the two other kernels what it saved),
+//   k_cluster_cols3_tiles works the slot's words out again from the line it reads anyway, scans them inside the tile and writes the rows.
+// (A single pass with a look-back from tile to tile was built first and measured: 331-397 us against 345 for what it replaced - 25 K tiles of 256 slots are
+// 20 generations of workgroups, each waiting out four dependent trips to memory plus its predecessors'; handing tiles out by a ticket costs as much again,
+// 25 K atomics on one address at ~90 a microsecond.)
+struct TileSums {
+	uint64_t *clusters, *cig, *bytes; // [tiles] each
+};
+
+// what a table row needs of slot j beyond SlotCluster: the words k_cluster_meta worked out
+struct SlotWords { uint64_t cnt, bytes; bool lng; };
+__device__ __forceinline__ SlotWords slot_words(const PackArgs &p, const SlotCluster &s)
+{
+	SlotWords w{0, 0, false};
+	if (s.cluster) {
+		w.cnt = 1ull | ((uint64_t)(uint32_t)s.ncg << 32);
+		w.bytes = 4ull * (((uint64_t)(s.ll + s.lr) * (uint64_t)p.base_bits + 31) / 32 + (qual_stream_bits((uint64_t)(s.ll + s.lr), (uint64_t)p.qual_bits, (uint64_t)p.qual_group) + 31) / 32);
+		w.lng = p.packed && s.single && s.lq > PACK_MAX_LQ;
+	}
+	return w;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cluster_tile_sums(PackArgs p, TileSums ts)
+{
+	__shared__ uint64_t s_cnt[WAVES_PER_BLOCK], s_bytes[WAVES_PER_BLOCK];
+	const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	uint64_t cnt = 0, bytes = 0;
+	bool lng = false;
+	if (j < p.c.E && p.c.support[j] > 0) { // (only what the sums need of the line: its second and third quarter)
+		const bool single = !p.c.mflag[j] || p.c.support[j] == 1;
+		const uint32_t e = single ? (uint32_t)j : p.c.c_cig_ev[j];
+		const uint4 *ep = reinterpret_cast<const uint4 *>(p.c.ev + e);
+		const uint4 eb = ep[1], ec = ep[2];
+		const uint64_t n = (uint64_t)(single ? (int)eb.w : p.c.c_ll[j]) + (uint64_t)(single ? (int)ec.x : p.c.c_lr[j]);
+		cnt = 1ull | ((uint64_t)ec.z << 32);
+		bytes = 4ull * ((n * (uint64_t)p.base_bits + 31) / 32 + (qual_stream_bits(n, (uint64_t)p.qual_bits, (uint64_t)p.qual_group) + 31) / 32);
+		lng = p.packed && single && (int)ec.y > PACK_MAX_LQ;
+	}
+	// one atomic per wavefront that holds long reads (same-address atomics run at ~90 per microsecond: with long-read data every slot is listed)
+	const uint64_t lm = __ballot(lng);
+	if (lm) {
+		uint32_t base = 0;
+		if (lane_id() == 0) base = atomicAdd(p.slow_count, (unsigned int)__popcll(lm));
+		base = __shfl(base, 0, WAVE);
+		if (lng) p.slow_list[base + (uint32_t)__popcll(lm & lanemask_lt())] = (uint32_t)j;
+	}
+	cnt = wave_sum(cnt); bytes = wave_sum(bytes);
+	if (lane_id() == 0) { s_cnt[wave_id()] = cnt; s_bytes[wave_id()] = bytes; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint64_t c = 0, b = 0;
+		for (int w = 0; w < WAVES_PER_BLOCK; ++w) { c += s_cnt[w]; b += s_bytes[w]; }
+		ts.clusters[blockIdx.x] = c & 0xffffffffull; ts.cig[blockIdx.x] = c >> 32; ts.bytes[blockIdx.x] = b;
+	}
+}
+
+// ts: the tile sums, scanned (exclusive); tot: [0] clusters | CIGAR operations << 32, [1] string bytes - the totals, written by the last tile
+__global__ __launch_bounds__(BLOCK) void k_cluster_cols3_tiles(PackArgs p, Pack3Args q, PackDesc *__restrict__ desc, uint32_t *__restrict__ out_cig, TileSums ts, uint64_t *__restrict__ tot)
+{
+	__shared__ uint64_t lds[WAVES_PER_BLOCK + 1];
+	const int64_t t = (int64_t)blockIdx.x;
+	const int64_t j = t * BLOCK + threadIdx.x;
+	const uint64_t s_pre[3] = {scalar_load(ts.clusters + t), scalar_load(ts.cig + t), scalar_load(ts.bytes + t)}; // (scanned: k_scan_sums_lists)
+	SlotCluster s = {};
+	uint64_t key = 0;
+	bool run_start = false;
+	if (j < p.c.E) {
+		s = slot_cluster_load<false>(p, j);
+		key = s.key;
+		run_start = j == 0 || (p.c.skey[j - 1] >> 32) != (key >> 32);
+	}
+	const SlotWords sw = slot_words(p, s);
+	const bool lng = sw.lng;
+	uint64_t tot_cnt, tot_bytes;
+	const uint64_t ex_cnt = block_exclusive_sum(sw.cnt, lds, &tot_cnt);
+	const uint64_t ex_bytes = block_exclusive_sum(sw.bytes, lds, &tot_bytes);
+	if (threadIdx.x == 0 && t == (int64_t)gridDim.x - 1) { tot[0] = (s_pre[0] + (tot_cnt & 0xffffffffull)) | ((s_pre[1] + (tot_cnt >> 32)) << 32); tot[1] = s_pre[2] + tot_bytes; }
+	if (j >= p.c.E) return;
+	const uint32_t c = (uint32_t)(s_pre[0] + (ex_cnt & 0xffffffffull));
+	if (run_start) { // first slot of a (contig, side): the next cluster at or after it starts the run
+		TableRun r;
+		r.tid = (int32_t)(key >> 33); r.side = ((key >> 32) & 1ull) ? '3' : '5'; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+		r.first = (int64_t)c;
+		q.runs[atomicAdd(q.run_count, 1u)] = r;
+	}
+	if (!s.cluster) return;
+	s.cig_off = s_pre[1] + (ex_cnt >> 32);
+	s.str_off = s_pre[2] + ex_bytes;
+	if (!s.single || lng) { p.slot_cnt[j] = (uint64_t)c | (s.cig_off << 32); p.slot_bytes[j] = s.str_off; } // (the base-by-base kernel finds its clusters by slot: k_pack3_slow)
+	q.pos[c] = (int32_t)(uint32_t)s.key;
+	if (q.len_bytes == 2) reinterpret_cast<uint32_t *>(q.len)[c] = (uint32_t)s.ll | ((uint32_t)s.lr << 16);
+	else reinterpret_cast<uint2 *>(q.len)[c] = make_uint2((uint32_t)s.ll, (uint32_t)s.lr);
+	if (q.support_bytes == 2) {
+		if (s.support > 0xffff) *q.support_miss = 1;
+		reinterpret_cast<uint16_t *>(q.support)[c] = (uint16_t)s.support;
+	} else reinterpret_cast<uint32_t *>(q.support)[c] = (uint32_t)s.support;
+	if (q.ncig_bytes == 1) reinterpret_cast<uint8_t *>(q.ncig)[c] = (uint8_t)s.ncg;
+	else reinterpret_cast<uint16_t *>(q.ncig)[c] = (uint16_t)s.ncg;
+	if (!s.single) q.flags[c] = s.qmiss_multi ? 1 : 0;
+	if (q.cig_bytes == 2) {
+		uint16_t *dc = reinterpret_cast<uint16_t *>(out_cig) + s.cig_off;
+		uint32_t wide = 0;
+		if (s.ncg <= 5) {
+			if (s.ncg > 0) { dc[0] = (uint16_t)s.cg0; wide |= s.cg0; }
+			if (s.ncg > 1) { dc[1] = (uint16_t)s.cg1; wide |= s.cg1; }
+			if (s.ncg > 2) { dc[2] = (uint16_t)s.cg2; wide |= s.cg2; }
+			if (s.ncg > 3) { dc[3] = (uint16_t)s.cg3; wide |= s.cg3; }
+			if (s.ncg > 4) { dc[4] = (uint16_t)s.cg4; wide |= s.cg4; }
+		} else {
+			const gptr<uint32_t> src = global_at<uint32_t>(s.cig_ptr);
+			for (int i = 0; i < s.ncg; ++i) { dc[i] = (uint16_t)src[i]; wide |= src[i]; }
+		}
+		if (wide >> 16) *q.cig_miss = 1;
+	} else {
+		uint32_t *dc = out_cig + s.cig_off;
+		if (s.ncg <= 5) {
+			if (s.ncg > 0) dc[0] = s.cg0;
+			if (s.ncg > 1) dc[1] = s.cg1;
+			if (s.ncg > 2) dc[2] = s.cg2;
+			if (s.ncg > 3) dc[3] = s.cg3;
+			if (s.ncg > 4) dc[4] = s.cg4;
+		} else {
+			const gptr<uint32_t> src = global_at<uint32_t>(s.cig_ptr);
+			for (int i = 0; i < s.ncg; ++i) dc[i] = src[i];
+		}
+	}
+	uint4 *dd = reinterpret_cast<uint4 *>(desc + c);
+	dd[0] = make_uint4((uint32_t)s.src, (uint32_t)(s.src >> 32), (uint32_t)s.str_off, (uint32_t)(s.str_off >> 32));
+	dd[1] = make_uint4((uint32_t)s.lq, (uint32_t)s.ll, (uint32_t)s.lr, s.single ? (uint32_t)s.begin : (uint32_t)j);
+}
+
 __device__ __forceinline__ void exc_append(const Pack3Args &q, uint64_t cluster, int base, uint32_t code)
 {
 	if (base >= (1 << 24) || cluster >= (1ull << 36)) { *q.exc_miss = 1; return; }

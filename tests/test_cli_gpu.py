@@ -36,15 +36,17 @@ GETCLIP = [("example", "cancer.sort.bam", "cancer", []), ("example", "normal.sor
            ("getclip", "lone_s2.bam", "lone_s2.q0", ["-q", "0"]), ("getclip", "unsorted.bam", "unsorted", [])]
 
 
-@pytest.mark.parametrize("passes", ["one-pass", "pass-per-contig", "pass-per-contig-small-batches"])
+@pytest.mark.parametrize("passes", ["one-pass", "pass-per-contig", "pass-per-contig-small-batches", "columns-by-scans"])
 @pytest.mark.parametrize("sub,bam,prefix,flags", GETCLIP, ids=[c[2] for c in GETCLIP])
 def test_cli_getclip(tmp_path, sub, bam, prefix, flags, passes):
-    """(pass-per-contig: SSV_PASS_RECORDS=1 ends the library's pass at every contig change - where the reference flushes - and the rows of a pass
+    """(columns-by-scans: SSV_PACK_COLS=split - the table's columns by two words per slot and two device-wide scans over them, the form before round 6's
+    scans over tiles of 256 slots, which every other test runs;
+    pass-per-contig: SSV_PASS_RECORDS=1 ends the library's pass at every contig change - where the reference flushes - and the rows of a pass
     are formatted and compressed beside the reading of the next one: what a whole-genome file does every 64 M records;
     small-batches: the host reader hands out batches of 7 records, each announced one ahead (ssv_batch_prefetch), so that passes end inside a
     batch while the next one is on its way to the GPU already - the announcements must survive the ssv_clip_begin in between)"""
     out = str(tmp_path / "o")
-    env = None if passes == "one-pass" else dict(os.environ, SSV_PASS_RECORDS="1")
+    env = None if passes == "one-pass" else dict(os.environ, SSV_PACK_COLS="split") if passes == "columns-by-scans" else dict(os.environ, SSV_PASS_RECORDS="1")
     if passes == "pass-per-contig-small-batches":
         env["SSV_HOST_BATCH_RECORDS"] = "7"
     r = subprocess.run([SEEKSV, "getclip"] + flags + ["-o", out, os.path.join(G.GOLDEN, sub, bam)], capture_output=True, text=True, env=env)

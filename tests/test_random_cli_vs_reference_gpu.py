@@ -183,3 +183,23 @@ def test_cli_getclip_unmapped_pairs_of_the_synthetic_sample(tmp_path, mode, env)
         assert gzip.open(str(tmp_path / f"our.{ext}")).read() == want, ext
         if ext.startswith("unmapped"):
             assert want.count(b"\n") == 4 * (n_un // 2)
+
+
+def test_cli_getclip_table_columns_both_ways(tmp_path):
+    """The cluster table's columns - dense cluster index, CIGAR offset, string offset of every sorted slot - come out of scans over TILES of 256 slots
+    (k_cluster_tile_sums / k_scan_sums_lists / k_cluster_cols3_tiles, table3_kernels.h), or the round-5 way out of two words per slot and two device-wide
+    scans (SSV_PACK_COLS=split).  A sample with some hundred tiles: both write what the real reference writes."""
+    from seeksv_amd import host, synth
+    w = synth.Workload(genome_frac=1 / 128, depth=30, n_sv=80)
+    b = w.generate_host(0, w.n_total, all_seq=True)
+    bam = str(tmp_path / "t.bam")
+    host.write_bam(bam, w.names, w.lens, [b])
+    r = subprocess.run([REF, "getclip", "-o", str(tmp_path / "ref"), bam], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    want = {ext: gzip.open(str(tmp_path / f"ref.{ext}")).read() for ext in ("clip.gz", "clip.fq.gz")}
+    assert want["clip.gz"].count(b"\n") > 64 * 256 * 2   # (rows = clusters: more than a hundred tiles)
+    for tag, env in (("tiles", {}), ("split", {"SSV_PACK_COLS": "split"})):
+        o = subprocess.run([SEEKSV, "getclip", "-Z", "-o", str(tmp_path / tag), bam], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert o.returncode == 0, o.stderr[-300:]
+        for ext, data in want.items():
+            assert gzip.open(str(tmp_path / f"{tag}.{ext}")).read() == data, (tag, ext)
