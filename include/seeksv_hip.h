@@ -173,7 +173,9 @@ int ssv_batch_prefetch_drop(ssv_ctx *ctx);
  * hot columns, one 64-byte line, the CIGARs, the bases of the soft-clipped reads - so a 30x genome (617 M records) stays resident in 50 GB
  * of HBM: ssv_batch_retain copies a device batch (the decoder's, valid only until the next decode) into device memory of its own -
  * SSV_MEM_DEVICE | SSV_MEM_PERSISTENT, record lines built once - and every later pass scans it in place: the file is inflated once.
- * ssv_batch_release frees it.  (`seeksv run` and bench.py's file leg work this way.)
+ * ssv_batch_release lets go of it: the memory is the context's again and the next ssv_batch_retain takes it from there (kept until the
+ * context goes or any of its allocations runs out of device memory - a fresh allocation of GBs behind the release of tens of GB waits
+ * for the driver to clear them, up to 1.7 s measured).  (`seeksv run` and bench.py's file leg work this way.)
  */
 int ssv_batch_retain(ssv_ctx *ctx, const ssv_batch_t *device_batch, ssv_batch_t *out);
 int ssv_batch_release(ssv_ctx *ctx, ssv_batch_t *retained);

@@ -42,30 +42,42 @@ __device__ __forceinline__ void scan_sums_body(TOut *__restrict__ sums, int64_t 
 	__shared__ TOut buf[CH + BLOCK];
 	__shared__ TOut lds[WAVES_PER_BLOCK + 1];
 	TOut carry = carry_in;
+	// (the next chunk's sums are asked for while this one is scanned: a chunk was one trip to memory plus three barriers, 5 us, and a step's 25 K tile sums are seven chunks)
+	TOut cur[PER];
+#pragma unroll
+	for (int k = 0; k < PER; ++k) { const int64_t i = (int64_t)k * BLOCK + threadIdx.x; cur[k] = i < m ? sums[i] : (TOut)0; }
 	for (int64_t base = 0; base < m; base += CH) {
 		const int64_t n = m - base < CH ? m - base : CH;
 #pragma unroll
 		for (int k = 0; k < PER; ++k) {
 			const int i = k * BLOCK + (int)threadIdx.x;
-			buf[i + i / PER] = i < n ? sums[base + i] : (TOut)0;
+			buf[i + i / PER] = cur[k];
 		}
-		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < PER; ++k) { const int64_t i = base + CH + (int64_t)k * BLOCK + threadIdx.x; cur[k] = i < m ? sums[i] : (TOut)0; }
+		lds_barrier(); // (not __syncthreads(): that one also waits for the loads just issued - common.h)
 		const int run = (int)threadIdx.x * (PER + 1);
 		TOut s = 0;
 #pragma unroll
 		for (int j = 0; j < PER; ++j) s += buf[run + j];
-		TOut tot;
-		TOut ex = carry + block_exclusive_sum(s, lds, &tot);
+		// block_exclusive_sum with LDS-only barriers
+		const TOut inc = wave_inclusive_sum(s);
+		if (lane_id() == 63) lds[wave_id()] = inc;
+		lds_barrier();
+		TOut before = 0, tot = 0;
+#pragma unroll
+		for (int w = 0; w < WAVES_PER_BLOCK; ++w) { const TOut x = lds[w]; if (w < wave_id()) before += x; tot += x; }
+		TOut ex = carry + before + inc - s;
 #pragma unroll
 		for (int j = 0; j < PER; ++j) { const TOut v = buf[run + j]; buf[run + j] = ex; ex += v; }
-		__syncthreads();
+		lds_barrier();
 #pragma unroll
 		for (int k = 0; k < PER; ++k) {
 			const int i = k * BLOCK + (int)threadIdx.x;
 			if (i < n) sums[base + i] = buf[i + i / PER];
 		}
 		carry += tot;
-		__syncthreads();
+		lds_barrier(); // (buf and lds[] are written again)
 	}
 	if (threadIdx.x == 0 && total) *total = carry;
 }

@@ -155,6 +155,11 @@ struct ssv_ctx {
 	// `seeksv run` spent 0.9 s in allocations that grew slower with every one; an arena is given back when its last batch is released)
 	struct RetainArena { uint8_t *base = nullptr; size_t cap = 0, used = 0; int64_t live = 0; std::vector<size_t> slabs; }; // slabs: where the arena's live batches begin
 	std::vector<RetainArena> arenas;
+	// arenas whose last batch was released: kept for the next ssv_batch_retain instead of handed back (round 6: a hipMalloc of 4 GB behind the release of tens of GB
+	// took 0.6-1.7 s - the driver clears freed memory before it hands it out again -, once in every third run of bench.py's file leg); handed back when any
+	// allocation of the context fails for lack of memory (dev_malloc), and with the context
+	struct SpareArena { uint8_t *base; size_t cap; };
+	std::vector<SpareArena> spare_arenas;
 
 	// staging of host batches, and the record lines built for batches that come without them
 	// host batches are copied into one of three staging sets: 0 and 1 take the batches announced with ssv_batch_prefetch (copied on st_h2d while
@@ -277,13 +282,27 @@ namespace {
 		if (rc_ != SSV_OK) return rc_; \
 	} while (0)
 
+// hipMalloc; out of memory: what the context keeps in reserve (ssv_batch_retain's spare arenas) goes back first
+hipError_t dev_malloc(ssv_ctx *c, void **p, size_t bytes)
+{
+	hipError_t e = hipMalloc(p, bytes);
+	if (e == hipErrorOutOfMemory && !c->spare_arenas.empty()) {
+		(void)hipGetLastError();
+		(void)hipStreamSynchronize(c->st);
+		for (auto &a : c->spare_arenas) (void)hipFree(a.base);
+		c->spare_arenas.clear();
+		e = hipMalloc(p, bytes);
+	}
+	return e;
+}
+
 int ensure(ssv_ctx *c, DBuf &b, size_t bytes, bool keep = false, size_t keep_bytes = 0)
 {
 	if (bytes <= b.cap) return SSV_OK;
 	size_t ncap = std::max(bytes, b.cap + b.cap / 2);
 	ncap = (ncap + 255) & ~(size_t)255;
 	void *np = nullptr;
-	HIPCHECK(c, hipMalloc(&np, ncap));
+	HIPCHECK(c, dev_malloc(c, &np, ncap));
 	if (keep && b.p && keep_bytes) {
 		HIPCHECK(c, hipMemcpyAsync(np, b.p, keep_bytes, hipMemcpyDeviceToDevice, c->st));
 		HIPCHECK(c, hipStreamSynchronize(c->st));
@@ -528,7 +547,7 @@ int arena_alloc(ssv_ctx *c, Arena &a, size_t bytes, void **out)
 	if (a.cur == a.chunks.size()) {
 		DBuf b;
 		const size_t cap = std::max<size_t>(bytes, (size_t)64 << 20);
-		HIPCHECK(c, hipMalloc(&b.p, cap));
+		HIPCHECK(c, dev_malloc(c, &b.p, cap));
 		b.cap = cap;
 		a.chunks.push_back(b);
 		a.used = 0;
@@ -795,6 +814,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	                 &c->gs_ctgoff, &c->gs_maxdepth, &c->gs_span, &c->q_tid, &c->q_beg, &c->q_end, &c->q_out64, &c->q_out32};
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (auto &a : c->arenas) if (a.base) (void)hipFree(a.base);
+	for (auto &a : c->spare_arenas) (void)hipFree(a.base);
 	for (auto &S : c->ss) {
 		for (DBuf &b : S.col) if (b.p) (void)hipFree(b.p);
 		if (S.rec.p) (void)hipFree(S.rec.p);
@@ -1066,7 +1086,12 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 			size_t cap = c->arenas.empty() ? std::min(arena_max, (size_t)256 << 20) : std::min(arena_max, c->arenas.back().cap * 2);
 			if (cap < off[7]) cap = off[7];
 			ssv_ctx::RetainArena a;
-			HIPCHECK(c, hipMalloc(reinterpret_cast<void **>(&a.base), cap));
+			// a spare one that is large enough (the smallest such), else a new one
+			size_t pick = c->spare_arenas.size();
+			for (size_t k = 0; k < c->spare_arenas.size(); ++k)
+				if (c->spare_arenas[k].cap >= off[7] && (pick == c->spare_arenas.size() || c->spare_arenas[k].cap < c->spare_arenas[pick].cap)) pick = k;
+			if (pick < c->spare_arenas.size()) { a.base = c->spare_arenas[pick].base; cap = c->spare_arenas[pick].cap; c->spare_arenas.erase(c->spare_arenas.begin() + (long)pick); }
+			else HIPCHECK(c, dev_malloc(c, reinterpret_cast<void **>(&a.base), cap));
 			a.cap = cap;
 			c->arenas.push_back(a);
 			arena = &c->arenas.back();
@@ -1115,7 +1140,7 @@ int ssv_batch_release(ssv_ctx *c, ssv_batch_t *b)
 		slabs.erase(it);
 		if (--c->arenas[k].live == 0) {
 			if (k + 1 == c->arenas.size()) c->arenas[k].used = 0;
-			else { HIPCHECK(c, hipFree(c->arenas[k].base)); c->arenas.erase(c->arenas.begin() + (long)k); }
+			else { c->spare_arenas.push_back({c->arenas[k].base, c->arenas[k].cap}); c->arenas.erase(c->arenas.begin() + (long)k); } // (kept for the next retain: ssv_ctx::spare_arenas)
 		}
 	}
 	free(const_cast<ssv_tid_run *>(b->tid_runs));
@@ -1522,11 +1547,11 @@ int ssv_clip_cluster_async(ssv_ctx *c, int64_t *n_clusters, int64_t *n_events)
 			{&O.h_exc, &O.o_exc, (size_t)T.n_exc * 8, (size_t)exc_cap_of(E) * 8}};
 		if (fmt3) for (auto &x : oc3) {
 			if (x.h->cap < x.bytes + 16) CHECK(ensure_host(c, *x.h, x.bytes + 16));
-			if (x.d->cap < x.dbytes + 16) { void *np = nullptr; HIPCHECK(c, hipMalloc(&np, x.dbytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.dbytes + 16; }
+			if (x.d->cap < x.dbytes + 16) { void *np = nullptr; HIPCHECK(c, dev_malloc(c, &np, x.dbytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.dbytes + 16; }
 		}
 		else for (auto &x : oc) {
 			if (x.h->cap < x.bytes + 16) CHECK(ensure_host(c, *x.h, x.bytes + 16));
-			if (x.d->cap < x.dbytes + 16) { void *np = nullptr; HIPCHECK(c, hipMalloc(&np, x.dbytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.dbytes + 16; }
+			if (x.d->cap < x.dbytes + 16) { void *np = nullptr; HIPCHECK(c, dev_malloc(c, &np, x.dbytes + 16)); if (x.d->p) HIPCHECK(c, hipFree(x.d->p)); x.d->p = np; x.d->cap = x.dbytes + 16; }
 		}
 	}
 	return SSV_OK;

@@ -27,7 +27,7 @@ GROUP_OF = {
     "k_merge_sides": "event_sort", "k_concat_sides": "event_sort", "k_gather_lines": "event_sort", "k_iota": "event_sort",
     "k_bin_mark": "cluster_bins", "k_multi_list": "cluster_bins", "k_bin_start_flags": "cluster_bins", "k_bin_start_list": "cluster_bins", "k_cluster_bins": "cluster_bins", "k_cluster_bins4": "cluster_bins", "k_bins4_tables": "cluster_bins",
     "k_cluster_meta": "cluster_pack", "k_cluster_cols": "cluster_pack", "k_cluster_pack_ascii": "cluster_pack",
-    "k_cluster_cols3": "cluster_pack", "k_pack3_direct": "cluster_pack", "k_pack3_stream": "cluster_pack", "k_pack3_slow": "cluster_pack",
+    "k_cluster_cols3": "cluster_pack", "k_cluster_tile_sums": "cluster_pack", "k_cluster_cols3_tiles": "cluster_pack", "k_pack3_direct": "cluster_pack", "k_pack3_stream": "cluster_pack", "k_pack3_slow": "cluster_pack",
     "k_isize_count": "isize_stats", "k_isize_collect": "isize_stats", "k_isize_reduce": "isize_stats",
     "k_tile_mark_windows": "getsv_scan", "k_tile_mark_junctions": "getsv_scan", "k_getsv_scan": "getsv_scan", "k_getsv_scan_runs": "getsv_scan", "k_max_span": "getsv_scan",
     "k_getsv_cand": "getsv_cand", "k_getsv_cand_dense": "getsv_cand", "k_dense_tiles": "getsv_cand", "k_cap_mark": "getsv_cand", "k_cap_sweep": "getsv_cand", "k_cap_tail": "getsv_cand", "k_cap_regrow": "getsv_cand",
