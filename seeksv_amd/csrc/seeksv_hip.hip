@@ -160,6 +160,10 @@ struct ssv_ctx {
 	// allocation of the context fails for lack of memory (dev_malloc), and with the context
 	struct SpareArena { uint8_t *base; size_t cap; };
 	std::vector<SpareArena> spare_arenas;
+	// ... and the arena behind the one in use is allocated AHEAD, on a thread of its own, when the newest one is first cut into: a fresh process has no spares, and
+	// its allocations may wait for memory that the process before it gave back (`seeksv run` behind `seeksv getsv`: 0.4-0.7 s of such waits inside getclip's
+	// scan phase in two runs of three) - behind the decode of the batches that fill the current arena nobody waits for them
+	struct ArenaAhead { std::thread th; bool pending = false; uint8_t *base = nullptr; size_t cap = 0; } ahead;
 
 	// staging of host batches, and the record lines built for batches that come without them
 	// host batches are copied into one of three staging sets: 0 and 1 take the batches announced with ssv_batch_prefetch (copied on st_h2d while
@@ -282,13 +286,41 @@ namespace {
 		if (rc_ != SSV_OK) return rc_; \
 	} while (0)
 
-// hipMalloc; out of memory: what the context keeps in reserve (ssv_batch_retain's spare arenas) goes back first
+// the arena that was asked for ahead, if any (null when there is none or its allocation failed); the caller owns it
+static uint8_t *arena_ahead_take(ssv_ctx *c, size_t *cap)
+{
+	if (!c->ahead.pending) return nullptr;
+	c->ahead.th.join();
+	c->ahead.pending = false;
+	uint8_t *b = c->ahead.base;
+	*cap = c->ahead.cap;
+	c->ahead.base = nullptr; c->ahead.cap = 0;
+	return b;
+}
+
+static void arena_ahead_start(ssv_ctx *c, size_t cap)
+{
+	if (c->ahead.pending) return;
+	c->ahead.pending = true;
+	c->ahead.base = nullptr; c->ahead.cap = cap;
+	const int device = c->device;
+	ssv_ctx::ArenaAhead *a = &c->ahead;
+	c->ahead.th = std::thread([a, device, cap] {
+		void *p = nullptr;
+		if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+		a->base = static_cast<uint8_t *>(p);
+	});
+}
+
+// hipMalloc; out of memory: what the context keeps in reserve (ssv_batch_retain's spare arenas, the one asked for ahead) goes back first
 hipError_t dev_malloc(ssv_ctx *c, void **p, size_t bytes)
 {
 	hipError_t e = hipMalloc(p, bytes);
-	if (e == hipErrorOutOfMemory && !c->spare_arenas.empty()) {
+	if (e == hipErrorOutOfMemory && (!c->spare_arenas.empty() || c->ahead.pending)) {
 		(void)hipGetLastError();
 		(void)hipStreamSynchronize(c->st);
+		size_t cap = 0;
+		if (uint8_t *b = arena_ahead_take(c, &cap)) (void)hipFree(b);
 		for (auto &a : c->spare_arenas) (void)hipFree(a.base);
 		c->spare_arenas.clear();
 		e = hipMalloc(p, bytes);
@@ -815,6 +847,7 @@ void ssv_ctx_destroy(ssv_ctx *c)
 	for (DBuf *b : dbufs) if (b->p) (void)hipFree(b->p);
 	for (auto &a : c->arenas) if (a.base) (void)hipFree(a.base);
 	for (auto &a : c->spare_arenas) (void)hipFree(a.base);
+	{ size_t cap = 0; if (uint8_t *b = arena_ahead_take(c, &cap)) (void)hipFree(b); }
 	for (auto &S : c->ss) {
 		for (DBuf &b : S.col) if (b.p) (void)hipFree(b.p);
 		if (S.rec.p) (void)hipFree(S.rec.p);
@@ -1091,10 +1124,19 @@ int ssv_batch_retain(ssv_ctx *c, const ssv_batch_t *b, ssv_batch_t *out)
 			for (size_t k = 0; k < c->spare_arenas.size(); ++k)
 				if (c->spare_arenas[k].cap >= off[7] && (pick == c->spare_arenas.size() || c->spare_arenas[k].cap < c->spare_arenas[pick].cap)) pick = k;
 			if (pick < c->spare_arenas.size()) { a.base = c->spare_arenas[pick].base; cap = c->spare_arenas[pick].cap; c->spare_arenas.erase(c->spare_arenas.begin() + (long)pick); }
-			else HIPCHECK(c, dev_malloc(c, reinterpret_cast<void **>(&a.base), cap));
+			else {
+				size_t acap = 0;
+				if (uint8_t *b = arena_ahead_take(c, &acap)) { // the one asked for ahead - if this batch fits (else it waits among the spares)
+					if (acap >= off[7]) { a.base = b; cap = acap; }
+					else c->spare_arenas.push_back({b, acap});
+				}
+				if (!a.base) HIPCHECK(c, dev_malloc(c, reinterpret_cast<void **>(&a.base), cap));
+			}
 			a.cap = cap;
 			c->arenas.push_back(a);
 			arena = &c->arenas.back();
+			// the next one, while this one fills (not when spares are waiting: a context that has been through a release has its memory)
+			if (c->spare_arenas.empty()) arena_ahead_start(c, std::min(arena_max, cap * 2));
 		}
 		slab = arena->base + arena->used;
 		arena->slabs.push_back(arena->used);
