@@ -675,11 +675,15 @@ def timing_phases(stderr):
 def run_command(cmd, env):
     """a command as a child process with SSV_TIMING=1: -> (CompletedProcess, dict(total_s, phases_s, exec_to_main_s, exit_to_reaped_s)) - the last two from the
     command's own wall-clock stamps: what the process costs before main() and after its last statement (the kernel tearing its device memory down)"""
+    import resource
     import subprocess
+    c0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0, w0 = time.perf_counter(), time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     dt, w1 = time.perf_counter() - t0, time.time()
-    out = dict(total_s=round(dt, 3), phases_s=timing_phases(r.stderr))
+    c1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    # cpu_s: the command's user + system time on all its threads - over total_s, the CPUs it kept busy (a box that gives 16 CPUs of host time bounds a command at 16)
+    out = dict(total_s=round(dt, 3), cpu_s=round(c1.ru_utime - c0.ru_utime + c1.ru_stime - c0.ru_stime, 2), phases_s=timing_phases(r.stderr))
     stamps = [float(l.split(":")[1]) for l in r.stderr.splitlines() if l.startswith("[stamp] wall clock at")]
     if len(stamps) == 2:
         out.update(exec_to_main_s=round(stamps[0] - w0, 3), exit_to_reaped_s=round(w1 - stamps[1], 3))
@@ -1113,7 +1117,8 @@ def cli_path_leg(args, w, bam, d, expect):
         if r1.returncode != 0 or r2.returncode != 0:
             raise RuntimeError((r1.stderr + r2.stderr)[-400:])
         cur = dict(getclip_s=round(t1 - t0, 3), getsv_s=round(t2 - t1, 3), total_s=round(t2 - t0, 3), getclip_phases_s=c1["phases_s"], getsv_phases_s=c2["phases_s"],
-                   process_s={"getclip": {k: c1.get(k) for k in ("exec_to_main_s", "exit_to_reaped_s")}, "getsv": {k: c2.get(k) for k in ("exec_to_main_s", "exit_to_reaped_s")}})
+                   process_s={"getclip": {k: c1.get(k) for k in ("exec_to_main_s", "exit_to_reaped_s", "cpu_s")}, "getsv": {k: c2.get(k) for k in ("exec_to_main_s", "exit_to_reaped_s", "cpu_s")},
+                              "host_cpus": effective_cpus()})
         if best is None or cur["total_s"] < best["total_s"]:
             best = cur
     res.update(best)

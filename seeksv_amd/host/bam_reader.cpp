@@ -10,6 +10,7 @@
 #include "../csrc/cpus.h"
 #include "seeksv_host.h"
 
+#include <pthread.h>
 #include <zlib.h>
 
 #include "huff_gz.h"
@@ -37,9 +38,9 @@ thread_local std::string g_err;
 // host threads at once.  (The reference is single threaded and spends 78 % of getclip in zlib inflate + BAM parsing)
 class Pool {
 public:
-	explicit Pool(int n)
+	explicit Pool(int n, const char *name = "ssv-pool")
 	{
-		for (int i = 0; i < n; ++i) th_.emplace_back([this] { work(); });
+		for (int i = 0; i < n; ++i) th_.emplace_back([this, name] { (void)pthread_setname_np(pthread_self(), name); work(); }); // (the names: SSV_TIMING=2's account of the CPU time, seeksv_cli.cpp)
 	}
 	~Pool()
 	{
@@ -107,14 +108,14 @@ static int host_threads()
 
 static Pool &pool() // the reading side (inflate + decode); may run on the read-ahead thread
 {
-	static Pool p(host_threads() - 1);
+	static Pool p(host_threads() - 1, "ssv-read");
 	return p;
 }
 
 static Pool &wpool() // the writing side (deflate), so that a read-ahead in flight and an output writer do not queue behind each other
 {
 	// SSV_WRITE_THREADS: beyond the readers' cap of 64 (writing a large BAM at deflate level 6 scales with every core of the box)
-	static Pool p([] { const char *e = getenv("SSV_WRITE_THREADS"); const int n = e ? atoi(e) : host_threads(); return (n < 1 ? 1 : n > 1024 ? 1024 : n) - 1; }());
+	static Pool p([] { const char *e = getenv("SSV_WRITE_THREADS"); const int n = e ? atoi(e) : host_threads(); return (n < 1 ? 1 : n > 1024 ? 1024 : n) - 1; }(), "ssv-write");
 	return p;
 }
 
@@ -683,6 +684,9 @@ static int read_blocks_impl(ssvh_bam *b, void *dst, const uint8_t *mapped, size_
 		const double tr0 = timing ? clk() : 0;
 		if (mapped) have += want; // (the bytes are there already)
 		else if (want) {
+			// (all threads of the pool copy: the copy out of the page cache is system time that grows with the threads on it - a quarter sample, 14.4 GB: 16 threads 4.0-7.6
+			// CPU-seconds, 8 threads 2.5 - but on a box that grants 16 CPUs of host time eight threads do not keep ahead of the host link: round 6, the whole sample:
+			// getsv 1.73-1.87 -> 2.12-2.30 s, the file leg with the read inside 1.23-1.37 -> 1.65-1.94 s)
 			const int ns = (int)((want + SLICE - 1) / SLICE);
 			std::vector<int> ok((size_t)ns, 1);
 			pool().run(ns, [&](int i) {

@@ -25,6 +25,9 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <dirent.h>
+#include <pthread.h>
+#include <sys/resource.h>
 #include <unistd.h>
 #include <atomic>
 #include "../csrc/cpus.h"
@@ -492,6 +495,7 @@ struct BatchSource {
 	// the reader thread: chunk k into slot k % NS as soon as the decoder has let go of chunk k - NS
 	void reader_main()
 	{
+		(void)pthread_setname_np(pthread_self(), "ssv-chunks");
 		for (int64_t k = 0;; ++k) {
 			{
 				std::unique_lock<std::mutex> lk(mu);
@@ -2186,6 +2190,38 @@ static int cmd_run(int argc, char **argv)
 
 static double wall_now() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }
 
+// SSV_TIMING=2: where the command's CPU time went - the process's user + system seconds (threads that have ended included) and, of the threads still alive, the ones
+// that used more than 50 ms, by name (/proc/self/task).  A box that gives a command 16 CPUs of host time bounds it by this sum.
+static void cpu_report()
+{
+	struct rusage ru;
+	if (getrusage(RUSAGE_SELF, &ru) != 0) return;
+	const double hz = (double)sysconf(_SC_CLK_TCK);
+	fprintf(stderr, "[timing] (cpu: user %.2f s, system %.2f s in all;", ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6);
+	std::map<string, std::pair<double, int>> by_name;
+	if (DIR *d = opendir("/proc/self/task")) {
+		while (struct dirent *e = readdir(d)) {
+			if (e->d_name[0] == '.') continue;
+			FILE *f = fopen((string("/proc/self/task/") + e->d_name + "/stat").c_str(), "r");
+			if (!f) continue;
+			char line[1024];
+			if (fgets(line, sizeof line, f)) {
+				const char *l = strchr(line, '('), *r = strrchr(line, ')');
+				unsigned long ut = 0, st = 0;
+				if (l && r && r > l && sscanf(r + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &st) == 2) {
+					auto &x = by_name[string(l + 1, r)];
+					x.first += (double)(ut + st) / hz; ++x.second;
+				}
+			}
+			fclose(f);
+		}
+		closedir(d);
+	}
+	fprintf(stderr, " threads alive at the end:");
+	for (auto &kv : by_name) if (kv.second.first >= 0.05) fprintf(stderr, " %s x%d %.2f s;", kv.first.c_str(), kv.second.second, kv.second.first);
+	fprintf(stderr, ")\n");
+}
+
 int main(int argc, char **argv)
 {
 	const bool stamp = getenv("SSV_TIMING") != nullptr; // with the caller's own clock around the process: exec -> main, main -> exit, exit -> reaped
@@ -2213,6 +2249,7 @@ int main(int argc, char **argv)
 	else rc = cmd == "getclip" ? cmd_getclip(argc - 1, argv + 1) : cmd_getsv(argc - 1, argv + 1);
 	if (kCleanExit) return rc;
 	cout.flush(); cerr.flush(); fflush(nullptr);
+	if (stamp && atoi(getenv("SSV_TIMING")) >= 2) cpu_report();
 	if (stamp) { fprintf(stderr, "[stamp] wall clock at exit: %.6f\n", wall_now()); fflush(stderr); }
 	_exit(rc); // (see release_ctx)
 }

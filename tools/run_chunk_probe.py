@@ -28,6 +28,9 @@ def main():
         print(json.dumps(out), flush=True)
         variants = [("default (1024 / 384)", {}), ("2048 / 768", {"SSV_CHUNK_INFLATED_MB": "2048", "SSV_STAGE_MB": "768"}), ("4096 / 1536", {"SSV_CHUNK_INFLATED_MB": "4096", "SSV_STAGE_MB": "1536"}),
                     ("512 / 192", {"SSV_CHUNK_INFLATED_MB": "512", "SSV_STAGE_MB": "192"}), ("default, again", {})]
+        if len(sys.argv) > 2:  # e.g. "SSV_HOST_THREADS=6,8,12": one variant per value (and the default before and after)
+            name, values = sys.argv[2].split("=")
+            variants = [("default", {})] + [(f"{name}={v}", {name: v}) for v in values.split(",")] + [("default, again", {})]
         for tag, extra in variants:
             env = dict(os.environ, SSV_TIMING="1", **extra)
             row = {}
@@ -35,7 +38,7 @@ def main():
                 r, cur = bench.run_command(argv, env)
                 if r.returncode != 0:
                     raise RuntimeError(r.stderr[-400:])
-                row[cmd] = {k: cur.get(k) for k in ("total_s", "exit_to_reaped_s")}
+                row[cmd] = {k: cur.get(k) for k in ("total_s", "cpu_s", "exit_to_reaped_s")}
                 row[cmd]["phases_s"] = {k: v for k, v in cur["phases_s"].items() if k.startswith("run:") or k.startswith("bam_read") or k.startswith("open")}
             print(json.dumps({tag: row}), flush=True)
     finally:
