@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""One line per bench.py output file (argv): the figures a comparison between two builds or two switches looks at - value, step, device time of a step, the
+cluster_pack group, hbm_frac_measured, config3_path, the file leg's rate and inflate / resolve / records kernels, cli_path and `seeksv run`."""
 import json,sys
 for f in sys.argv[1:]:
     try:
