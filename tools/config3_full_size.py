@@ -87,12 +87,12 @@ def run(w, hdr, ctx, n_chunks, probe=None):
                 seconds={k: round(v, 3) for k, v in t.items()})
 
 
-def main(genome_frac=1.0, depth=300.0, n_sv=10000, chunks_a=10, chunks_b=16, probe=None):
+def main(genome_frac=1.0, depth=300.0, n_sv=10000, chunks_a=10, chunks_b=16, unmap_permille=0, probe=None):
     from seeksv_amd import host, synth
     from seeksv_amd.device import Context
-    w = synth.Workload(genome_frac=genome_frac, depth=depth, n_sv=n_sv)
+    w = synth.Workload(genome_frac=genome_frac, depth=depth, n_sv=n_sv, unmap_permille=unmap_permille)  # (unmap_permille: that share of the records in pairs with one unmapped end)
     hdr = host.Header(w.names, w.lens)
-    out = {"records": w.n_total, "junctions": len(w.junctions), "depth": depth, "genome_frac": genome_frac}
+    out = {"records": w.n_total, "junctions": len(w.junctions), "depth": depth, "genome_frac": genome_frac, "unmap_permille": unmap_permille}
     with Context(0) as ctx:
         a = run(w, hdr, ctx, chunks_a, (lambda d: probe(w, d)) if probe else None)
         b = run(w, hdr, ctx, chunks_b)
@@ -117,6 +117,6 @@ def main(genome_frac=1.0, depth=300.0, n_sv=10000, chunks_a=10, chunks_b=16, pro
 if __name__ == "__main__":
     args = [float(x) for x in sys.argv[1:]]
     kw = {}
-    for name, v in zip(("genome_frac", "depth", "n_sv", "chunks_a", "chunks_b"), args):
+    for name, v in zip(("genome_frac", "depth", "n_sv", "chunks_a", "chunks_b", "unmap_permille"), args):
         kw[name] = v if name in ("genome_frac", "depth") else int(v)
     print(json.dumps(main(**kw)))
